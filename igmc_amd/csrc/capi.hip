@@ -1,0 +1,584 @@
+// capi.hip -- C-ABI host layer of libigmc_hip.so (see include/igmc_hip.h for the contract).
+#include "launch.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+int g_igmc_prof_on = 0;
+
+#define IGMC_FAIL(msg)                                                      \
+  do {                                                                      \
+    g_err = std::string(__func__) + ": " + (msg);                           \
+    return 1;                                                               \
+  } while (0)
+#define HIPCHECK(expr)                                                      \
+  do {                                                                      \
+    hipError_t e_ = (expr);                                                 \
+    if (e_ != hipSuccess) {                                                 \
+      g_err = std::string(__func__) + ": " #expr " -> " + hipGetErrorString(e_); \
+      return 1;                                                             \
+    }                                                                       \
+  } while (0)
+
+struct Allocs {
+  std::vector<void*> ptrs;
+  size_t bytes = 0;
+  template <typename T> int get(T** out, size_t n) {
+    void* p = nullptr;
+    const size_t b = std::max<size_t>(n, 1) * sizeof(T);
+    if (hipMalloc(&p, b) != hipSuccess) return 1;
+    ptrs.push_back(p);
+    bytes += b;
+    *out = (T*)p;
+    return 0;
+  }
+  void release() {
+    for (void* p : ptrs) hipFree(p);
+    ptrs.clear();
+  }
+};
+
+struct igmc_graph {
+  int device;
+  GraphDev d;
+  int64_t nnz;
+  int max_rel;
+  Allocs mem;
+};
+
+struct igmc_batch {
+  const igmc_graph* g;
+  BatchDev d;
+  int last_B;
+  const float* side;
+  int n_side;
+  Allocs mem;
+};
+
+struct igmc_model {
+  int device;
+  ModelDev d;
+  int last_B, last_training, last_flags;
+  Allocs mem;
+};
+
+extern "C" const char* igmc_last_error(void) { return g_err.c_str(); }
+extern "C" int igmc_version(void) { return 100; }
+
+// ------------------------------------------------------------------ profiling
+struct ProfRec {
+  std::string name;
+  hipEvent_t a, b;
+};
+static std::vector<ProfRec> g_prof;
+
+void igmc_prof_begin(const char* name, void* stream) {
+  ProfRec r;
+  r.name = name;
+  hipEventCreate(&r.a);
+  hipEventCreate(&r.b);
+  hipEventRecord(r.a, (hipStream_t)stream);
+  g_prof.push_back(r);
+}
+void igmc_prof_end(void* stream) { hipEventRecord(g_prof.back().b, (hipStream_t)stream); }
+
+extern "C" int igmc_profile_enable(int on) {
+  g_igmc_prof_on = on;
+  return 0;
+}
+
+extern "C" int igmc_profile_fetch(char names[][48], float* ms, int* calls, int cap) {
+  std::vector<std::string> order;
+  std::map<std::string, std::pair<double, int>> agg;
+  for (auto& r : g_prof) {
+    hipEventSynchronize(r.b);
+    float t = 0.f;
+    hipEventElapsedTime(&t, r.a, r.b);
+    if (!agg.count(r.name)) order.push_back(r.name);
+    agg[r.name].first += t;
+    agg[r.name].second += 1;
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  g_prof.clear();
+  int n = 0;
+  for (auto& nm : order) {
+    if (n >= cap) break;
+    snprintf(names[n], 48, "%s", nm.c_str());
+    ms[n] = (float)agg[nm].first;
+    if (calls) calls[n] = agg[nm].second;
+    ++n;
+  }
+  return n;
+}
+
+// ------------------------------------------------------------------ rating graph
+extern "C" int igmc_graph_create(int n_users, int n_items, int64_t nnz, const int32_t* h_indptr,
+                                 const int32_t* h_indices, const uint8_t* h_rating, int device,
+                                 igmc_graph** out) {
+  if (n_users <= 0 || n_items <= 0 || nnz < 0 || !h_indptr || !out) IGMC_FAIL("bad arguments");
+  if (nnz >= INT_MAX) IGMC_FAIL("nnz must fit int32");
+  HIPCHECK(hipSetDevice(device));
+  // drop explicit zeros, convert label+1 -> relation id, sort rows by (relation, item)
+  std::vector<int32_t> uptr(n_users + 1, 0), uidx, vptr(n_items + 1, 0), vidx;
+  std::vector<uint8_t> urel, vrel;
+  uidx.reserve(nnz);
+  urel.reserve(nnz);
+  int max_rel = 0;
+  std::vector<std::pair<int32_t, int32_t>> row;   // (rel, item)
+  for (int u = 0; u < n_users; ++u) {
+    row.clear();
+    for (int32_t p = h_indptr[u]; p < h_indptr[u + 1]; ++p) {
+      if (h_rating[p] == 0) continue;
+      const int it = h_indices[p];
+      if (it < 0 || it >= n_items) IGMC_FAIL("column index out of range");
+      row.emplace_back((int32_t)h_rating[p] - 1, it);
+    }
+    std::sort(row.begin(), row.end());
+    for (size_t k = 1; k < row.size(); ++k)
+      if (row[k].second == row[k - 1].second && row[k].first == row[k - 1].first) IGMC_FAIL("duplicate entries in CSR row");
+    for (auto& e : row) {
+      urel.push_back((uint8_t)e.first);
+      uidx.push_back(e.second);
+      max_rel = std::max(max_rel, (int)e.first);
+      vptr[e.second + 1]++;
+    }
+    uptr[u + 1] = (int32_t)uidx.size();
+  }
+  const int64_t nz = (int64_t)uidx.size();
+  for (int v = 0; v < n_items; ++v) vptr[v + 1] += vptr[v];
+  vidx.assign(nz, 0);
+  vrel.assign(nz, 0);
+  {
+    // counting sort by (item, relation, user): pass over relations keeps columns relation-sorted
+    std::vector<int32_t> cur(vptr.begin(), vptr.end() - 1);
+    for (int r = 0; r <= max_rel; ++r)
+      for (int u = 0; u < n_users; ++u)
+        for (int32_t p = uptr[u]; p < uptr[u + 1]; ++p)
+          if (urel[p] == r) {
+            const int32_t q = cur[uidx[p]]++;
+            vidx[q] = u;
+            vrel[q] = (uint8_t)r;
+          }
+  }
+  igmc_graph* g = new igmc_graph();
+  g->device = device;
+  g->nnz = nz;
+  g->max_rel = max_rel;
+  int32_t *d_uptr, *d_uidx, *d_vptr, *d_vidx;
+  uint8_t *d_urel, *d_vrel;
+  if (g->mem.get(&d_uptr, n_users + 1) || g->mem.get(&d_uidx, nz) || g->mem.get(&d_urel, nz) ||
+      g->mem.get(&d_vptr, n_items + 1) || g->mem.get(&d_vidx, nz) || g->mem.get(&d_vrel, nz)) {
+    g->mem.release();
+    delete g;
+    IGMC_FAIL("hipMalloc failed");
+  }
+  HIPCHECK(hipMemcpy(d_uptr, uptr.data(), (n_users + 1) * 4, hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy(d_vptr, vptr.data(), (n_items + 1) * 4, hipMemcpyHostToDevice));
+  if (nz) {
+    HIPCHECK(hipMemcpy(d_uidx, uidx.data(), nz * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(d_urel, urel.data(), nz, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(d_vidx, vidx.data(), nz * 4, hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(d_vrel, vrel.data(), nz, hipMemcpyHostToDevice));
+  }
+  g->d.n_users = n_users;
+  g->d.n_items = n_items;
+  g->d.u_ptr = d_uptr; g->d.u_idx = d_uidx; g->d.u_rel = d_urel;
+  g->d.v_ptr = d_vptr; g->d.v_idx = d_vidx; g->d.v_rel = d_vrel;
+  *out = g;
+  return 0;
+}
+
+extern "C" void igmc_graph_destroy(igmc_graph* g) {
+  if (!g) return;
+  g->mem.release();
+  delete g;
+}
+extern "C" int64_t igmc_graph_hbm_bytes(const igmc_graph* g) { return g ? (int64_t)g->mem.bytes : 0; }
+
+// ------------------------------------------------------------------ batch arena
+extern "C" int igmc_batch_create(const igmc_graph* g, int max_graphs, int hop, int max_nodes_per_hop,
+                                 igmc_batch** out) {
+  if (!g || !out || max_graphs <= 0 || hop < 1) IGMC_FAIL("bad arguments");
+  if (2 * hop + 2 > 250) IGMC_FAIL("hop too large");
+  HIPCHECK(hipSetDevice(g->device));
+  const size_t smem = igmc_extract_smem_bytes(g->d);
+  if (smem > 150 * 1024) IGMC_FAIL("graph too large for the LDS bitmaps (users+items must be < ~300k)");
+  if (igmc_extract_prepare(smem)) IGMC_FAIL("hipFuncSetAttribute failed");
+  auto side_cap = [&](int n) -> int64_t {
+    int64_t per = (max_nodes_per_hop < 0) ? (int64_t)n : std::min<int64_t>(max_nodes_per_hop, n);
+    return std::min<int64_t>(n, 1 + (int64_t)hop * per);
+  };
+  const int64_t cap_u = side_cap(g->d.n_users), cap_v = side_cap(g->d.n_items);
+  const int64_t slot = cap_u + cap_v;
+  const int64_t node_cap = (int64_t)max_graphs * slot;
+  const int64_t per_graph_e = std::min<int64_t>(2 * cap_u * cap_v, 2 * g->nnz);
+  int64_t edge_cap = (int64_t)max_graphs * per_graph_e;
+  if (node_cap > (int64_t)INT_MAX / 64) IGMC_FAIL("node capacity exceeds int32 indexing");
+  edge_cap = std::min<int64_t>(edge_cap, (int64_t)INT_MAX - 65536);
+  if (g->max_rel * (2 * hop + 2) + (2 * hop + 1) > 65535) IGMC_FAIL("relation*label code exceeds uint16");
+  igmc_batch* b = new igmc_batch();
+  b->g = g;
+  b->last_B = 0;
+  b->side = nullptr;
+  b->n_side = 0;
+  BatchDev& d = b->d;
+  Allocs& M = b->mem;
+  const int Bc = max_graphs;
+  int fail = 0;
+  fail |= M.get(&d.node_off, Bc + 1) | M.get(&d.n_users, Bc) | M.get(&d.n_items, Bc) | M.get(&d.edge_cnt, Bc) |
+          M.get(&d.edge_off, Bc + 1);
+  fail |= M.get(&d.node_label, node_cap) | M.get(&d.node_gid, node_cap) | M.get(&d.node_graph, node_cap) |
+          M.get(&d.row_ptr, node_cap + 1);
+  fail |= M.get(&d.col, edge_cap) | M.get(&d.erel, edge_cap) | M.get(&d.ecode, edge_cap) | M.get(&d.eflag, edge_cap);
+  fail |= M.get(&d.y, Bc) | M.get(&d.totals, 8);
+  fail |= M.get(&d.s_gid, Bc * slot) | M.get(&d.s_lab, Bc * slot) | M.get(&d.s_deg, Bc * slot) |
+          M.get(&d.t_list, Bc * slot) | M.get(&d.t_dist, Bc * slot);
+  if (fail) {
+    M.release();
+    delete b;
+    IGMC_FAIL("hipMalloc failed (batch arena)");
+  }
+  HIPCHECK(hipMemset(d.totals, 0, 8 * sizeof(int32_t)));
+  d.cap_u = (int)cap_u;
+  d.cap_v = (int)cap_v;
+  d.slot = (int)slot;
+  d.node_cap = (int)node_cap;
+  d.edge_cap = (int)edge_cap;
+  d.graph_cap = Bc;
+  d.hop = hop;
+  d.max_nodes_per_hop = max_nodes_per_hop;
+  d.num_labels = 2 * hop + 2;
+  *out = b;
+  return 0;
+}
+
+extern "C" void igmc_batch_destroy(igmc_batch* b) {
+  if (!b) return;
+  b->mem.release();
+  delete b;
+}
+
+extern "C" int igmc_extract_batch(const igmc_graph* g, igmc_batch* b, const int32_t* d_link_u,
+                                  const int32_t* d_link_v, const float* d_link_y, const int32_t* d_link_idx,
+                                  int first, int B, double sample_ratio, uint64_t seed, uint64_t epoch,
+                                  void* stream) {
+  if (!g || !b || b->g != g) IGMC_FAIL("batch does not belong to this graph");
+  if (B <= 0 || B > b->d.graph_cap) IGMC_FAIL("B exceeds the batch capacity");
+  if (!d_link_u || !d_link_v || !d_link_y) IGMC_FAIL("null link arrays");
+  igmc_launch_extract(g->d, b->d, d_link_u, d_link_v, d_link_y, d_link_idx, first, B, 0, sample_ratio, seed, epoch,
+                      stream);
+  HIPCHECK(hipGetLastError());
+  b->last_B = B;
+  return 0;
+}
+
+extern "C" int igmc_extract_batch_replay(const igmc_graph* g, igmc_batch* b, int B, const int32_t* h_unodes,
+                                         const uint8_t* h_udist, const int32_t* h_uoff, const int32_t* h_vnodes,
+                                         const uint8_t* h_vdist, const int32_t* h_voff, const float* h_y,
+                                         void* stream) {
+  if (!g || !b || b->g != g) IGMC_FAIL("batch does not belong to this graph");
+  if (B <= 0 || B > b->d.graph_cap) IGMC_FAIL("B exceeds the batch capacity");
+  const BatchDev& d = b->d;
+  std::vector<int32_t> tl((size_t)B * d.slot, 0), nu(B), nv(B);
+  std::vector<uint8_t> td((size_t)B * d.slot, 0);
+  for (int gi = 0; gi < B; ++gi) {
+    const int cu = h_uoff[gi + 1] - h_uoff[gi], cv = h_voff[gi + 1] - h_voff[gi];
+    if (cu < 1 || cv < 1 || cu > d.cap_u || cv > d.cap_v) IGMC_FAIL("replayed node list exceeds the slot capacity");
+    nu[gi] = cu;
+    nv[gi] = cv;
+    for (int i = 0; i < cu; ++i) {
+      const int id = h_unodes[h_uoff[gi] + i];
+      if (id < 0 || id >= g->d.n_users) IGMC_FAIL("user id out of range");
+      tl[(size_t)gi * d.slot + i] = id;
+      td[(size_t)gi * d.slot + i] = h_udist[h_uoff[gi] + i];
+    }
+    for (int i = 0; i < cv; ++i) {
+      const int id = h_vnodes[h_voff[gi] + i];
+      if (id < 0 || id >= g->d.n_items) IGMC_FAIL("item id out of range");
+      tl[(size_t)gi * d.slot + d.cap_u + i] = id;
+      td[(size_t)gi * d.slot + d.cap_u + i] = h_vdist[h_voff[gi] + i];
+    }
+  }
+  HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+  HIPCHECK(hipMemcpy(d.t_list, tl.data(), tl.size() * 4, hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy(d.t_dist, td.data(), td.size(), hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy(d.n_users, nu.data(), B * 4, hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy(d.n_items, nv.data(), B * 4, hipMemcpyHostToDevice));
+  HIPCHECK(hipMemcpy(d.y, h_y, B * sizeof(float), hipMemcpyHostToDevice));
+  igmc_launch_extract(g->d, b->d, nullptr, nullptr, nullptr, nullptr, 0, B, 1, 1.0, 0, 0, stream);
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+  b->last_B = B;
+  return 0;
+}
+
+extern "C" int igmc_batch_edge_dropout(igmc_batch* b, float p, int force_undirected, uint64_t seed, uint64_t step,
+                                       void* stream) {
+  if (!b) IGMC_FAIL("null batch");
+  igmc_launch_edge_flags(b->d, p, force_undirected, seed, step, stream);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int igmc_batch_get_info(const igmc_batch* b, igmc_batch_info* out, void* stream) {
+  if (!b || !out) IGMC_FAIL("null argument");
+  int32_t t[8];
+  HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+  HIPCHECK(hipMemcpy(t, b->d.totals, sizeof(t), hipMemcpyDeviceToHost));
+  out->num_graphs = t[3];
+  out->num_nodes = t[2] ? t[4] : t[0];
+  out->num_edges = t[2] ? t[5] : t[1];
+  out->overflow = t[2];
+  out->node_capacity = b->d.node_cap;
+  out->edge_capacity = b->d.edge_cap;
+  out->num_labels = b->d.num_labels;
+  out->hop = b->d.hop;
+  return 0;
+}
+
+extern "C" int igmc_batch_set_edge_flags(igmc_batch* b, const uint8_t* h_flags, int64_t n) {
+  if (!b || !h_flags) IGMC_FAIL("null argument");
+  if (n > b->d.edge_cap) IGMC_FAIL("too many flags");
+  HIPCHECK(hipDeviceSynchronize());
+  HIPCHECK(hipMemcpy(b->d.eflag, h_flags, (size_t)n, hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int igmc_batch_clear_edge_flags(igmc_batch* b) {
+  if (!b) IGMC_FAIL("null batch");
+  igmc_batch_info info;
+  if (igmc_batch_get_info(b, &info, nullptr)) return 1;
+  if (info.num_edges > 0) HIPCHECK(hipMemset(b->d.eflag, 3, (size_t)info.num_edges));
+  return 0;
+}
+
+extern "C" int igmc_batch_download(const igmc_batch* b, int32_t* node_off, int32_t* n_users, uint8_t* node_label,
+                                   int32_t* node_gid, int32_t* node_graph, int32_t* row_ptr, int32_t* col,
+                                   uint8_t* erel, uint8_t* elab, uint8_t* eflag, float* y, void* stream) {
+  igmc_batch_info info;
+  if (igmc_batch_get_info(b, &info, stream)) return 1;
+  if (info.overflow) IGMC_FAIL("batch arena overflow");
+  const int B = info.num_graphs, N = info.num_nodes, E = info.num_edges;
+  const BatchDev& d = b->d;
+  if (node_off) HIPCHECK(hipMemcpy(node_off, d.node_off, (B + 1) * 4, hipMemcpyDeviceToHost));
+  if (n_users) HIPCHECK(hipMemcpy(n_users, d.n_users, B * 4, hipMemcpyDeviceToHost));
+  if (node_label && N) HIPCHECK(hipMemcpy(node_label, d.node_label, N, hipMemcpyDeviceToHost));
+  if (node_gid && N) HIPCHECK(hipMemcpy(node_gid, d.node_gid, N * 4, hipMemcpyDeviceToHost));
+  if (node_graph && N) HIPCHECK(hipMemcpy(node_graph, d.node_graph, N * 4, hipMemcpyDeviceToHost));
+  if (row_ptr) HIPCHECK(hipMemcpy(row_ptr, d.row_ptr, (N + 1) * 4, hipMemcpyDeviceToHost));
+  if (col && E) HIPCHECK(hipMemcpy(col, d.col, (size_t)E * 4, hipMemcpyDeviceToHost));
+  if (erel && E) HIPCHECK(hipMemcpy(erel, d.erel, E, hipMemcpyDeviceToHost));
+  if (elab && E) {
+    std::vector<uint16_t> code(E);
+    HIPCHECK(hipMemcpy(code.data(), d.ecode, (size_t)E * 2, hipMemcpyDeviceToHost));
+    for (int e = 0; e < E; ++e) elab[e] = (uint8_t)(code[e] % d.num_labels);
+  }
+  if (eflag && E) HIPCHECK(hipMemcpy(eflag, d.eflag, E, hipMemcpyDeviceToHost));
+  if (y) HIPCHECK(hipMemcpy(y, d.y, B * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" void* igmc_batch_device_ptr(const igmc_batch* b, int which) {
+  if (!b) return nullptr;
+  const BatchDev& d = b->d;
+  switch (which) {
+    case IGMC_BUF_NODE_OFF: return d.node_off;
+    case IGMC_BUF_N_USERS: return d.n_users;
+    case IGMC_BUF_NODE_LABEL: return d.node_label;
+    case IGMC_BUF_NODE_GID: return d.node_gid;
+    case IGMC_BUF_NODE_GRAPH: return d.node_graph;
+    case IGMC_BUF_ROW_PTR: return d.row_ptr;
+    case IGMC_BUF_COL: return d.col;
+    case IGMC_BUF_EREL: return d.erel;
+    case IGMC_BUF_ECODE: return d.ecode;
+    case IGMC_BUF_EFLAG: return d.eflag;
+    case IGMC_BUF_Y: return d.y;
+    case IGMC_BUF_TOTALS: return d.totals;
+  }
+  return nullptr;
+}
+
+extern "C" int igmc_batch_set_side_features(igmc_batch* b, const float* d_feat, int n_side) {
+  if (!b) IGMC_FAIL("null batch");
+  b->side = d_feat;
+  b->n_side = n_side;
+  return 0;
+}
+
+// ------------------------------------------------------------------ model
+extern "C" int igmc_model_create(int device, int num_relations, int num_bases, int num_labels, int n_side,
+                                 int max_nodes, int max_edges, int max_graphs, igmc_model** out) {
+  if (!out) IGMC_FAIL("null out");
+  if (num_bases != 4) IGMC_FAIL("the gfx950 kernels are built for num_bases == 4 (reference Main.py:393)");
+  if (num_relations < 1 || num_relations > 255) IGMC_FAIL("num_relations out of range");
+  if (num_labels < 2 || n_side < 0 || max_nodes < 1 || max_graphs < 1) IGMC_FAIL("bad sizes");
+  HIPCHECK(hipSetDevice(device));
+  igmc_model* m = new igmc_model();
+  m->device = device;
+  m->last_B = 0;
+  m->last_training = 0;
+  m->last_flags = 0;
+  ModelDev& d = m->d;
+  d.R = num_relations;
+  d.Bs = 4;
+  d.L = num_labels;
+  d.S = n_side;
+  d.D = 256 + n_side;
+  int64_t off = 0;
+  for (int l = 0; l < 4; ++l) {
+    const int fin = l == 0 ? d.L : 32;
+    d.off_basis[l] = off; off += (int64_t)4 * fin * 32;
+    d.off_root[l] = off;  off += (int64_t)fin * 32;
+    d.off_bias[l] = off;  off += 32;
+    d.off_att[l] = off;   off += (int64_t)d.R * 4;
+  }
+  d.off_l1w = off; off += (int64_t)128 * d.D;
+  d.off_l1b = off; off += 128;
+  d.off_l2w = off; off += 128;
+  d.off_l2b = off; off += 1;
+  d.n_params = off;
+  d.node_cap = max_nodes;
+  d.edge_cap = max_edges;
+  d.graph_cap = max_graphs;
+  Allocs& M = m->mem;
+  int fail = 0;
+  const size_t N = (size_t)max_nodes, Bc = (size_t)max_graphs;
+  for (int l = 0; l < 4; ++l) fail |= M.get(&d.h[l], N * 32);
+  fail |= M.get(&d.agg, N * 128) | M.get(&d.Y, N * 128) | M.get(&d.dpre[0], N * 32) | M.get(&d.dpre[1], N * 32);
+  fail |= M.get(&d.feat, Bc * d.D) | M.get(&d.a1, Bc * 128) | M.get(&d.lmask, Bc * 128) | M.get(&d.dz, Bc * 128) |
+          M.get(&d.gfeat, Bc * d.D) | M.get(&d.err, Bc) | M.get(&d.gout, Bc);
+  fail |= M.get(&d.W0, (size_t)d.R * d.L * 32) | M.get(&d.w1T, (size_t)d.D * 128);
+  d.wT[0] = nullptr;
+  d.bcat[0] = nullptr;
+  for (int l = 1; l < 4; ++l) fail |= M.get(&d.wT[l], (size_t)IGMC_KCAT * 32) | M.get(&d.bcat[l], (size_t)32 * 128);
+  const size_t rows0 = (size_t)d.R * d.L + d.L + 1;
+  fail |= M.get(&d.wg_part, (size_t)3 * IGMC_WG_BLOCKS * igmc_wg_stride()) |
+          M.get(&d.gatt_part, (size_t)3 * IGMC_GATHER_BLOCKS * d.R * 4) |
+          M.get(&d.l0_part, (size_t)IGMC_L0_BLOCKS * rows0 * 32) |
+          M.get(&d.graw, (size_t)3 * igmc_wg_stride() + 3 * d.R * 4 + rows0 * 32) | M.get(&d.arr_part, 4);
+  d.side = nullptr;
+  if (fail) {
+    M.release();
+    delete m;
+    IGMC_FAIL("hipMalloc failed (model workspace)");
+  }
+  if (igmc_model_prepare(d)) {
+    M.release();
+    delete m;
+    IGMC_FAIL("hipFuncSetAttribute failed");
+  }
+  *out = m;
+  return 0;
+}
+
+extern "C" void igmc_model_destroy(igmc_model* m) {
+  if (!m) return;
+  m->mem.release();
+  delete m;
+}
+
+extern "C" int64_t igmc_param_count(const igmc_model* m) { return m ? m->d.n_params : 0; }
+
+extern "C" int64_t igmc_param_offset(const igmc_model* m, int layer, int which, int64_t* count) {
+  if (!m) return -1;
+  const ModelDev& d = m->d;
+  const int fin = (layer == 0) ? d.L : 32;
+  int64_t off = -1, n = 0;
+  switch (which) {
+    case IGMC_P_BASIS: off = d.off_basis[layer & 3]; n = (int64_t)4 * fin * 32; break;
+    case IGMC_P_ROOT: off = d.off_root[layer & 3]; n = (int64_t)fin * 32; break;
+    case IGMC_P_BIAS: off = d.off_bias[layer & 3]; n = 32; break;
+    case IGMC_P_ATT: off = d.off_att[layer & 3]; n = (int64_t)d.R * 4; break;
+    case IGMC_P_LIN1_W: off = d.off_l1w; n = (int64_t)128 * d.D; break;
+    case IGMC_P_LIN1_B: off = d.off_l1b; n = 128; break;
+    case IGMC_P_LIN2_W: off = d.off_l2w; n = 128; break;
+    case IGMC_P_LIN2_B: off = d.off_l2b; n = 1; break;
+  }
+  if (count) *count = n;
+  return off;
+}
+
+static int check_fit(igmc_model* m, const igmc_batch* b, std::string* why) {
+  if (!m || !b) { *why = "null model or batch"; return 1; }
+  if (b->last_B <= 0) { *why = "batch is empty (run igmc_extract_batch first)"; return 1; }
+  if (b->d.node_cap > m->d.node_cap || b->d.graph_cap > m->d.graph_cap) { *why = "batch capacity exceeds the model workspace"; return 1; }
+  if (b->d.num_labels != m->d.L) { *why = "num_labels mismatch (hop)"; return 1; }
+  if (b->g->max_rel >= m->d.R) { *why = "graph has more relations than the model"; return 1; }
+  if (m->d.S != b->n_side && m->d.S > 0) { *why = "side feature width mismatch"; return 1; }
+  return 0;
+}
+
+extern "C" int igmc_model_forward(igmc_model* m, const float* d_params, const igmc_batch* b, int training,
+                                  int use_edge_flags, const uint8_t* d_lin_mask, uint64_t seed, uint64_t step,
+                                  float multiply_by, float* d_out, void* stream) {
+  std::string why;
+  if (check_fit(m, b, &why)) IGMC_FAIL(why);
+  if (!d_params || !d_out) IGMC_FAIL("null buffer");
+  m->d.side = b->side;
+  igmc_launch_forward(m->d, b->d, d_params, b->last_B, training, use_edge_flags, d_lin_mask, seed, step, multiply_by,
+                      d_out, stream);
+  HIPCHECK(hipGetLastError());
+  m->last_B = b->last_B;
+  m->last_training = training;
+  m->last_flags = use_edge_flags;
+  return 0;
+}
+
+extern "C" int igmc_model_backward(igmc_model* m, const float* d_params, const igmc_batch* b, const float* d_gout,
+                                   float multiply_by, float* d_grad, void* stream) {
+  std::string why;
+  if (check_fit(m, b, &why)) IGMC_FAIL(why);
+  if (!m->last_training || m->last_B != b->last_B) IGMC_FAIL("backward needs a preceding training-mode forward on this batch");
+  if (!d_params || !d_gout || !d_grad) IGMC_FAIL("null buffer");
+  igmc_launch_backward(m->d, b->d, d_params, b->last_B, m->last_flags, d_gout, 0, 0.f, multiply_by, 2.f, 0.f, d_grad,
+                       stream);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int igmc_model_loss_grad(igmc_model* m, const float* d_params, const igmc_batch* b, int use_edge_flags,
+                                    const uint8_t* d_lin_mask, uint64_t seed, uint64_t step, float multiply_by,
+                                    float ARR, float grad_scale, float arr_scale, float* d_out, float* d_grad,
+                                    float* d_loss, void* stream) {
+  std::string why;
+  if (check_fit(m, b, &why)) IGMC_FAIL(why);
+  if (!d_params || !d_out || !d_grad || !d_loss) IGMC_FAIL("null buffer");
+  m->d.side = b->side;
+  igmc_launch_forward(m->d, b->d, d_params, b->last_B, 1, use_edge_flags, d_lin_mask, seed, step, multiply_by, d_out,
+                      stream);
+  igmc_launch_backward(m->d, b->d, d_params, b->last_B, use_edge_flags, nullptr, 1, grad_scale, multiply_by, 2.f,
+                       ARR * arr_scale, d_grad, stream);
+  igmc_launch_loss(m->d, b->d, ARR, d_loss, stream);
+  HIPCHECK(hipGetLastError());
+  m->last_B = b->last_B;
+  m->last_training = 1;
+  m->last_flags = use_edge_flags;
+  return 0;
+}
+
+extern "C" int igmc_adam_step(float* d_params, const float* d_grad, float* d_exp_avg, float* d_exp_avg_sq, int64_t n,
+                              int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                              void* stream) {
+  if (!d_params || !d_grad || !d_exp_avg || !d_exp_avg_sq || n <= 0 || step < 1) IGMC_FAIL("bad arguments");
+  const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+  igmc_launch_adam(d_params, d_grad, d_exp_avg, d_exp_avg_sq, n, (float)((double)lr / bc1),
+                   (float)(1.0 / std::sqrt(bc2)), beta1, beta2, eps, weight_decay, stream);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int igmc_sse_accumulate(const float* d_out, const igmc_batch* b, double* d_acc, void* stream) {
+  if (!d_out || !b || !d_acc) IGMC_FAIL("null argument");
+  igmc_launch_sse(b->d, d_out, d_acc, stream);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}

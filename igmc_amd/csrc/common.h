@@ -1,0 +1,117 @@
+// common.h -- internal definitions shared by the gfx950 kernels and the C-ABI host layer.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef IGMC_HIPEMU
+// tools/hipemu/hipemu.h is force-included (CPU emulation for kernel-logic tests only)
+#define IGMC_DYN_SMEM(name) unsigned char* name = hipemu::rt().dyn_smem
+#define IGMC_LAUNCH(kern, grid, block, shmem, stream, ...) \
+  hipemu::launch(dim3(grid), dim3(block), (size_t)(shmem), [=]() { kern(__VA_ARGS__); })
+#define IGMC_WAVE_SYNC() igmc_emu_wave_sync()
+typedef igmc_f32x4 f32x4;
+#else
+#include <hip/hip_runtime.h>
+#define IGMC_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#define IGMC_LAUNCH(kern, grid, block, shmem, stream, ...) \
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(block), (size_t)(shmem), (hipStream_t)(stream), __VA_ARGS__)
+// intra-wave ordering point for LDS traffic between lanes of one wave
+#define IGMC_WAVE_SYNC()                                     \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+  } while (0)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#endif
+
+#include "../../include/igmc_hip.h"
+#include "../../include/igmc_rng.h"
+
+#define IGMC_F 32          // hidden width
+#define IGMC_BS_MAX 4      // num_bases supported by the kernels (reference Main.py:393 uses 4)
+#define IGMC_BLOCK 256
+
+// ------------------------------------------------------------------ device views
+struct GraphDev {
+  int n_users, n_items;
+  const int32_t* u_ptr;   // [n_users+1]  CSR  user -> items, rows sorted by (relation, item)
+  const int32_t* u_idx;   // [nnz] item ids
+  const uint8_t* u_rel;   // [nnz] relation id = rating label (0..R-1)
+  const int32_t* v_ptr;   // [n_items+1]  CSC  item -> users, columns sorted by (relation, user)
+  const int32_t* v_idx;   // [nnz] user ids
+  const uint8_t* v_rel;   // [nnz]
+};
+
+// One collated batch.  Nodes of graph g occupy [node_off[g], node_off[g+1]): its n_users[g]
+// user nodes first (target user = first), then the item nodes (target item = first).
+struct BatchDev {
+  int32_t* node_off;     // [Bcap+1]
+  int32_t* n_users;      // [Bcap]
+  int32_t* n_items;      // [Bcap]
+  int32_t* edge_cnt;     // [Bcap]   directed edges of graph g
+  int32_t* edge_off;     // [Bcap+1]
+  uint8_t* node_label;   // [Ncap]   2*dist (user) / 2*dist+1 (item)   (reference util_functions.py:245)
+  int32_t* node_gid;     // [Ncap]   original user / item id
+  int32_t* node_graph;   // [Ncap]   PyG `batch` vector
+  int32_t* row_ptr;      // [Ncap+1] dst-sorted CSR over all nodes of the batch
+  int32_t* col;          // [Ecap]   source node (batch-global index)
+  uint8_t* erel;         // [Ecap]   relation id
+  uint16_t* ecode;       // [Ecap]   relation * num_labels + label(source)  (layer-0 table index)
+  uint8_t* eflag;        // [Ecap]   bit0: edge col->row kept, bit1: edge row->col kept
+  float* y;              // [Bcap]
+  int32_t* totals;       // [8]: 0 N, 1 E, 2 overflow flag, 3 B
+  // per-graph scratch slots (capacity cap_u + cap_v each)
+  int32_t* s_gid;        // [Bcap * slot]  ids by local index (users at 0.., items at cap_u..)
+  uint8_t* s_lab;        // [Bcap * slot]
+  int32_t* s_deg;        // [Bcap * slot]
+  int32_t* t_list;       // [Bcap * slot]  BFS discovery order (temporary)
+  uint8_t* t_dist;       // [Bcap * slot]
+  int cap_u, cap_v, slot;
+  int node_cap, edge_cap, graph_cap;
+  int hop, max_nodes_per_hop, num_labels;
+};
+
+// ------------------------------------------------------------------ small device helpers
+__device__ __forceinline__ int igmc_lane() { return threadIdx.x & 63; }
+
+// exclusive scan over the 256 threads of a block; *total = sum.  sm: >= 8 ints of LDS.
+__device__ __forceinline__ int igmc_block_scan_excl(int v, int* total, int* sm) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int t = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) sm[wave] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+  const int nw = (blockDim.x + 63) >> 6;
+  for (int w = 0; w < nw; ++w) {
+    int s = sm[w];
+    if (w < wave) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__device__ __forceinline__ int igmc_wave_sum_i(int v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+__device__ __forceinline__ int igmc_block_sum_i(int v, int* sm) {
+  v = igmc_wave_sum_i(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sm[wave] = v;
+  __syncthreads();
+  int tot = 0;
+  const int nw = (blockDim.x + 63) >> 6;
+  for (int w = 0; w < nw; ++w) tot += sm[w];
+  __syncthreads();
+  return tot;
+}

@@ -1,0 +1,499 @@
+// extract.hip -- enclosing-subgraph extraction, labelling and collation on gfx950.
+//
+// Replaces, for a whole batch and entirely in HBM/LDS:
+//   subgraph_extraction_labeling   reference util_functions.py:208-277
+//   neighbors                      reference util_functions.py:300-304
+//   construct_pyg_graph            reference util_functions.py:280-297
+//   PyG Batch.from_data_list       call site reference train_eval.py:44-51
+//
+// One 256-thread workgroup per (user,item) link.  The rating graph (CSR + CSC,
+// ~9 MB for ml_1m) is L2 / Infinity-Cache resident, so this stage is integer work
+// bounded by latency and LDS, not by HBM: all per-subgraph state lives in LDS
+// bitmaps over the user / item id spaces --
+//   vis  visited set          (reference :218-221, updated BEFORE sampling)
+//   new  this hop's fringe    (reference :217)
+//   sel  nodes kept so far    (u_nodes / v_nodes minus the targets)
+//   pre  per-word exclusive popcount of sel  -> local index = 1 + rank (target = 0)
+// Neighbour rows are read with 256 coalesced lanes; membership of an id in the
+// selected set is one LDS word + one popcount; there are no atomics on floats and
+// no order-dependent writes, so the output is bit-reproducible.
+//
+// Kernels:  k_extract_nodes (BFS + per-hop sampling + induced-degree count)
+//           k_scan_offsets  (node / edge offsets of the collated batch)
+//           k_fill          (dst-sorted CSR of the batch, labels, PyG `batch` vector)
+//           k_edge_flags    (edge dropout keep flags, reference models.py:193-198)
+#include "launch.h"
+
+struct ExtractArgs {
+  GraphDev g;
+  BatchDev b;
+  const int32_t* link_u;
+  const int32_t* link_v;
+  const float* link_y;
+  const int32_t* link_idx;
+  int first, B, replay;
+  double sample_ratio;
+  uint64_t seed, epoch;
+};
+
+// ---------------------------------------------------------------- bitmap helpers
+__device__ __forceinline__ void bm_clear(uint32_t* a, int W) {
+  for (int w = threadIdx.x; w < W; w += IGMC_BLOCK) a[w] = 0u;
+}
+__device__ __forceinline__ bool bm_test(const uint32_t* a, int j) { return (a[j >> 5] >> (j & 31)) & 1u; }
+__device__ __forceinline__ int bm_rank(const uint32_t* sel, const uint32_t* pre, int j) {
+  return (int)pre[j >> 5] + __popc(sel[j >> 5] & ((1u << (j & 31)) - 1u));
+}
+
+// mark the neighbours of list[lo,hi) in `out` (reference neighbors(), :300-304)
+__device__ void expand_fringe(const int32_t* list, int lo, int hi, const int32_t* ptr,
+                              const int32_t* idx, uint32_t* out) {
+  for (int f = lo; f < hi; ++f) {
+    const int n = list[f];
+    const int beg = ptr[n], end = ptr[n + 1];
+    for (int p = beg + (int)threadIdx.x; p < end; p += IGMC_BLOCK) {
+      const int j = idx[p];
+      atomicOr(&out[j >> 5], 1u << (j & 31));
+    }
+  }
+}
+
+// exclusive per-word popcount prefix of a bitmap; returns the total
+__device__ int bm_prefix(const uint32_t* bm, uint32_t* pre, int W, int* sm) {
+  int running = 0;
+  for (int base = 0; base < W; base += IGMC_BLOCK) {
+    const int w = base + threadIdx.x;
+    const int c = (w < W) ? __popc(bm[w]) : 0;
+    int tot;
+    const int ex = igmc_block_scan_excl(c, &tot, sm);
+    if (w < W) pre[w] = (uint32_t)(running + ex);
+    running += tot;
+  }
+  return running;
+}
+
+// k-th smallest (1-based) sampling key among the set bits of bm.  Keys are a bijection of
+// the id, so exactly k candidates have key <= the returned threshold.
+__device__ uint32_t radix_select(const uint32_t* bm, int W, int k, uint64_t salt, int* hist, int* sm) {
+  uint32_t prefix = 0u, mask = 0u;
+  int remaining = k;
+  for (int pass = 3; pass >= 0; --pass) {
+    const int shift = pass * 8;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int w = threadIdx.x; w < W; w += IGMC_BLOCK) {
+      uint32_t bits = bm[w];
+      while (bits) {
+        const int bp = __ffs((int)bits) - 1;
+        bits &= bits - 1u;
+        const uint32_t key = igmc_sample_key(salt, (uint32_t)(w * 32 + bp));
+        if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+      }
+    }
+    __syncthreads();
+    const int c = hist[threadIdx.x];
+    int tot;
+    const int ex = igmc_block_scan_excl(c, &tot, sm);
+    if (c > 0 && ex < remaining && remaining <= ex + c) {
+      sm[8] = (int)threadIdx.x;
+      sm[9] = remaining - ex;
+    }
+    __syncthreads();
+    prefix |= ((uint32_t)sm[8]) << shift;
+    mask |= 0xFFu << shift;
+    remaining = sm[9];
+    __syncthreads();
+  }
+  return prefix;
+}
+
+// keep only the k candidates with the smallest keys (uniform k-subset, reference :222-229)
+__device__ void sample_fringe(uint32_t* bm, int W, int cnt, int k, uint64_t salt, int* hist, int* sm) {
+  if (k >= cnt) return;
+  if (k <= 0) {
+    bm_clear(bm, W);
+    __syncthreads();
+    return;
+  }
+  const uint32_t T = radix_select(bm, W, k, salt, hist, sm);
+  for (int w = threadIdx.x; w < W; w += IGMC_BLOCK) {
+    uint32_t bits = bm[w], keep = 0u;
+    while (bits) {
+      const int bp = __ffs((int)bits) - 1;
+      bits &= bits - 1u;
+      if (igmc_sample_key(salt, (uint32_t)(w * 32 + bp)) <= T) keep |= 1u << bp;
+    }
+    bm[w] = keep;
+  }
+  __syncthreads();
+}
+
+// append the set bits of bm (ascending id) to list[cnt..], tag them with `dist`, OR into sel
+__device__ int append_fringe(const uint32_t* bm, uint32_t* sel, int W, int32_t* list, uint8_t* dists,
+                             int cnt, int dist, int* sm) {
+  int running = cnt;
+  for (int base = 0; base < W; base += IGMC_BLOCK) {
+    const int w = base + threadIdx.x;
+    uint32_t bits = (w < W) ? bm[w] : 0u;
+    int tot;
+    int o = running + igmc_block_scan_excl(__popc(bits), &tot, sm);
+    if (w < W) sel[w] |= bits;
+    while (bits) {
+      const int bp = __ffs((int)bits) - 1;
+      bits &= bits - 1u;
+      list[o] = w * 32 + bp;
+      dists[o] = (uint8_t)dist;
+      ++o;
+    }
+    running += tot;
+  }
+  return running;
+}
+
+// ---------------------------------------------------------------- kernel 1
+__global__ __launch_bounds__(IGMC_BLOCK) void k_extract_nodes(ExtractArgs a) {
+  IGMC_DYN_SMEM(smem);
+  __shared__ int hist[256];
+  __shared__ int sm[16];
+  const int g = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Wu = (a.g.n_users + 31) >> 5, Wv = (a.g.n_items + 31) >> 5;
+  uint32_t* vis_u = (uint32_t*)smem;
+  uint32_t* new_u = vis_u + Wu;
+  uint32_t* sel_u = new_u + Wu;
+  uint32_t* pre_u = sel_u + Wu;
+  uint32_t* vis_v = pre_u + Wu;
+  uint32_t* new_v = vis_v + Wv;
+  uint32_t* sel_v = new_v + Wv;
+  uint32_t* pre_v = sel_v + Wv;
+
+  const int cap_u = a.b.cap_u;
+  const size_t so = (size_t)g * a.b.slot;
+  int32_t* tl = a.b.t_list + so;
+  uint8_t* td = a.b.t_dist + so;
+  int32_t* sg = a.b.s_gid + so;
+  uint8_t* sl = a.b.s_lab + so;
+  int32_t* sd = a.b.s_deg + so;
+
+  int cu, cv, u0, v0;
+  bm_clear(sel_u, Wu);
+  bm_clear(sel_v, Wv);
+  if (!a.replay) {
+    const int pos = a.link_idx ? a.link_idx[a.first + g] : a.first + g;
+    u0 = a.link_u[pos];
+    v0 = a.link_v[pos];
+    bm_clear(vis_u, Wu);
+    bm_clear(vis_v, Wv);
+    __syncthreads();
+    if (tid == 0) {
+      vis_u[u0 >> 5] |= 1u << (u0 & 31);
+      vis_v[v0 >> 5] |= 1u << (v0 & 31);
+      tl[0] = u0;
+      td[0] = 0;
+      tl[cap_u] = v0;
+      td[cap_u] = 0;
+      a.b.y[g] = a.link_y[pos];
+    }
+    cu = 1;
+    cv = 1;
+    int fu_lo = 0, fu_hi = 1, fv_lo = 0, fv_hi = 1;
+    __syncthreads();
+    for (int dist = 1; dist <= a.b.hop; ++dist) {
+      bm_clear(new_u, Wu);
+      bm_clear(new_v, Wv);
+      __syncthreads();
+      // simultaneous swap (reference :217): users' rows give item candidates and vice versa
+      expand_fringe(tl, fu_lo, fu_hi, a.g.u_ptr, a.g.u_idx, new_v);
+      expand_fringe(tl + cap_u, fv_lo, fv_hi, a.g.v_ptr, a.g.v_idx, new_u);
+      __syncthreads();
+      int c = 0;
+      for (int w = tid; w < Wu; w += IGMC_BLOCK) {
+        const uint32_t x = new_u[w] & ~vis_u[w];
+        new_u[w] = x;
+        vis_u[w] |= x;   // visited updated before sampling (reference :220-221)
+        c += __popc(x);
+      }
+      const int cnt_u = igmc_block_sum_i(c, sm);
+      c = 0;
+      for (int w = tid; w < Wv; w += IGMC_BLOCK) {
+        const uint32_t x = new_v[w] & ~vis_v[w];
+        new_v[w] = x;
+        vis_v[w] |= x;
+        c += __popc(x);
+      }
+      const int cnt_v = igmc_block_sum_i(c, sm);
+      int ku = cnt_u, kv = cnt_v;
+      if (a.sample_ratio < 1.0) {   // int(sample_ratio*len), reference :222-224
+        ku = (int)(a.sample_ratio * (double)cnt_u);
+        kv = (int)(a.sample_ratio * (double)cnt_v);
+      }
+      if (a.b.max_nodes_per_hop >= 0) {   // reference :225-229
+        if (a.b.max_nodes_per_hop < ku) ku = a.b.max_nodes_per_hop;
+        if (a.b.max_nodes_per_hop < kv) kv = a.b.max_nodes_per_hop;
+      }
+      const uint64_t link_uid = (uint64_t)(uint32_t)pos;
+      sample_fringe(new_u, Wu, cnt_u, ku, igmc_sample_salt(a.seed, a.epoch, link_uid, dist, 0), hist, sm);
+      sample_fringe(new_v, Wv, cnt_v, kv, igmc_sample_salt(a.seed, a.epoch, link_uid, dist, 1), hist, sm);
+      if (ku == 0 && kv == 0) break;   // reference :230-231
+      const int ncu = append_fringe(new_u, sel_u, Wu, tl, td, cu, dist, sm);
+      const int ncv = append_fringe(new_v, sel_v, Wv, tl + cap_u, td + cap_u, cv, dist, sm);
+      fu_lo = cu; fu_hi = ncu; cu = ncu;
+      fv_lo = cv; fv_hi = ncv; cv = ncv;
+      __syncthreads();
+    }
+  } else {
+    cu = a.b.n_users[g];
+    cv = a.b.n_items[g];
+    u0 = tl[0];
+    v0 = tl[cap_u];
+    __syncthreads();
+    for (int i = 1 + tid; i < cu; i += IGMC_BLOCK) atomicOr(&sel_u[tl[i] >> 5], 1u << (tl[i] & 31));
+    for (int i = 1 + tid; i < cv; i += IGMC_BLOCK) atomicOr(&sel_v[tl[cap_u + i] >> 5], 1u << (tl[cap_u + i] & 31));
+  }
+  __syncthreads();
+
+  // local index = 1 + rank among the selected ids (ascending); targets are local 0
+  bm_prefix(sel_u, pre_u, Wu, sm);
+  bm_prefix(sel_v, pre_v, Wv, sm);
+  __syncthreads();
+  for (int i = tid; i < cu; i += IGMC_BLOCK) {
+    const int id = tl[i];
+    const int li = (i == 0) ? 0 : 1 + bm_rank(sel_u, pre_u, id);
+    sg[li] = id;
+    sl[li] = (uint8_t)(2 * td[i]);             // reference :245
+  }
+  for (int i = tid; i < cv; i += IGMC_BLOCK) {
+    const int id = tl[cap_u + i];
+    const int li = (i == 0) ? 0 : 1 + bm_rank(sel_v, pre_v, id);
+    sg[cap_u + li] = id;
+    sl[cap_u + li] = (uint8_t)(2 * td[cap_u + i] + 1);
+  }
+  if (tid == 0) {
+    a.b.n_users[g] = cu;
+    a.b.n_items[g] = cv;
+  }
+  __syncthreads();
+
+  // induced degrees: Arow[u_nodes][:, v_nodes] with the target entry removed (reference :236-238)
+  int etot = 0;
+  for (int li = wave; li < cu; li += IGMC_BLOCK / 64) {
+    const int id = sg[li];
+    const int beg = a.g.u_ptr[id], end = a.g.u_ptr[id + 1];
+    int c = 0;
+    for (int p = beg + lane; p < end; p += 64) {
+      const int j = a.g.u_idx[p];
+      c += (j == v0) ? (li != 0) : (int)bm_test(sel_v, j);
+    }
+    c = igmc_wave_sum_i(c);
+    if (lane == 0) { sd[li] = c; etot += c; }
+  }
+  for (int li = wave; li < cv; li += IGMC_BLOCK / 64) {
+    const int id = sg[cap_u + li];
+    const int beg = a.g.v_ptr[id], end = a.g.v_ptr[id + 1];
+    int c = 0;
+    for (int p = beg + lane; p < end; p += 64) {
+      const int j = a.g.v_idx[p];
+      c += (j == u0) ? (li != 0) : (int)bm_test(sel_u, j);
+    }
+    c = igmc_wave_sum_i(c);
+    if (lane == 0) { sd[cap_u + li] = c; etot += c; }
+  }
+  const int eg = igmc_block_sum_i(etot, sm);
+  if (tid == 0) a.b.edge_cnt[g] = eg;
+}
+
+// ---------------------------------------------------------------- kernel 2
+__global__ __launch_bounds__(IGMC_BLOCK) void k_scan_offsets(BatchDev b, int B) {
+  __shared__ int sm[16];
+  int run_n = 0, run_e = 0;
+  for (int base = 0; base < B; base += IGMC_BLOCK) {
+    const int i = base + threadIdx.x;
+    const int n = (i < B) ? b.n_users[i] + b.n_items[i] : 0;
+    const int e = (i < B) ? b.edge_cnt[i] : 0;
+    int tn, te;
+    const int xn = igmc_block_scan_excl(n, &tn, sm);
+    const int xe = igmc_block_scan_excl(e, &te, sm);
+    if (i < B) {
+      b.node_off[i] = run_n + xn;
+      b.edge_off[i] = run_e + xe;
+    }
+    run_n += tn;
+    run_e += te;
+  }
+  if (threadIdx.x == 0) {
+    b.node_off[B] = run_n;
+    b.edge_off[B] = run_e;
+    const int ovf = (run_n > b.node_cap) || (run_e > b.edge_cap);
+    b.totals[0] = ovf ? 0 : run_n;
+    b.totals[1] = ovf ? 0 : run_e;
+    b.totals[2] = ovf;
+    b.totals[3] = B;
+    b.totals[4] = run_n;
+    b.totals[5] = run_e;
+    if (!ovf) b.row_ptr[run_n] = run_e;
+  }
+}
+
+// ---------------------------------------------------------------- kernel 3
+__global__ __launch_bounds__(IGMC_BLOCK) void k_fill(GraphDev G, BatchDev b) {
+  IGMC_DYN_SMEM(smem);
+  __shared__ int sm[16];
+  if (b.totals[2]) return;
+  const int g = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Wu = (G.n_users + 31) >> 5, Wv = (G.n_items + 31) >> 5;
+  uint32_t* sel_u = (uint32_t*)smem;
+  uint32_t* pre_u = sel_u + Wu;
+  uint32_t* sel_v = pre_u + Wu;
+  uint32_t* pre_v = sel_v + Wv;
+  const int cap_u = b.cap_u;
+  const size_t so = (size_t)g * b.slot;
+  const int32_t* sg = b.s_gid + so;
+  const uint8_t* sl = b.s_lab + so;
+  const int32_t* sd = b.s_deg + so;
+  const int cu = b.n_users[g], cv = b.n_items[g];
+  const int nb = b.node_off[g], eb = b.edge_off[g];
+  const int u0 = sg[0], v0 = sg[cap_u];
+
+  bm_clear(sel_u, Wu);
+  bm_clear(sel_v, Wv);
+  __syncthreads();
+  for (int i = 1 + tid; i < cu; i += IGMC_BLOCK) atomicOr(&sel_u[sg[i] >> 5], 1u << (sg[i] & 31));
+  for (int i = 1 + tid; i < cv; i += IGMC_BLOCK) atomicOr(&sel_v[sg[cap_u + i] >> 5], 1u << (sg[cap_u + i] & 31));
+  __syncthreads();
+  bm_prefix(sel_u, pre_u, Wu, sm);
+  bm_prefix(sel_v, pre_v, Wv, sm);
+
+  // node arrays + CSR row pointers
+  const int nn = cu + cv;
+  int running = 0;
+  for (int base = 0; base < nn; base += IGMC_BLOCK) {
+    const int n = base + tid;
+    const int s = (n < cu) ? n : cap_u + (n - cu);
+    const int deg = (n < nn) ? sd[s] : 0;
+    int tot;
+    const int ex = igmc_block_scan_excl(deg, &tot, sm);
+    if (n < nn) {
+      b.row_ptr[nb + n] = eb + running + ex;
+      b.node_label[nb + n] = sl[s];
+      b.node_gid[nb + n] = sg[s];
+      b.node_graph[nb + n] = g;
+    }
+    running += tot;
+  }
+  __syncthreads();
+
+  // user rows: CSR row of the user intersected with the selected items
+  for (int li = wave; li < cu; li += IGMC_BLOCK / 64) {
+    const int id = sg[li];
+    const int beg = G.u_ptr[id], end = G.u_ptr[id + 1];
+    int o = b.row_ptr[nb + li];
+    for (int p0 = beg; p0 < end; p0 += 64) {
+      const int p = p0 + lane;
+      const bool valid = p < end;
+      const int j = valid ? G.u_idx[p] : 0;
+      const bool m = valid && ((j == v0) ? (li != 0) : bm_test(sel_v, j));
+      const unsigned long long bal = __ballot(m);
+      if (m) {
+        const int q = o + __popcll(bal & ((1ull << lane) - 1ull));
+        const int lv = (j == v0) ? 0 : 1 + bm_rank(sel_v, pre_v, j);
+        b.col[q] = nb + cu + lv;
+        b.erel[q] = G.u_rel[p];
+        b.ecode[q] = (uint16_t)((int)G.u_rel[p] * b.num_labels + (int)sl[cap_u + lv]);
+        b.eflag[q] = 3;
+      }
+      o += __popcll(bal);
+    }
+  }
+  // item rows: CSC column of the item intersected with the selected users
+  for (int li = wave; li < cv; li += IGMC_BLOCK / 64) {
+    const int id = sg[cap_u + li];
+    const int beg = G.v_ptr[id], end = G.v_ptr[id + 1];
+    int o = b.row_ptr[nb + cu + li];
+    for (int p0 = beg; p0 < end; p0 += 64) {
+      const int p = p0 + lane;
+      const bool valid = p < end;
+      const int j = valid ? G.v_idx[p] : 0;
+      const bool m = valid && ((j == u0) ? (li != 0) : bm_test(sel_u, j));
+      const unsigned long long bal = __ballot(m);
+      if (m) {
+        const int q = o + __popcll(bal & ((1ull << lane) - 1ull));
+        const int lu = (j == u0) ? 0 : 1 + bm_rank(sel_u, pre_u, j);
+        b.col[q] = nb + lu;
+        b.erel[q] = G.v_rel[p];
+        b.ecode[q] = (uint16_t)((int)G.v_rel[p] * b.num_labels + (int)sl[lu]);
+        b.eflag[q] = 3;
+      }
+      o += __popcll(bal);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- edge dropout flags
+// reference models.py:193-198 -> PyG dropout_adj: independent Bernoulli(1-p) per DIRECTED edge
+// (shared by the two directions when force_undirected).  16 lanes per CSR row.
+__global__ __launch_bounds__(IGMC_BLOCK) void k_edge_flags(BatchDev b, float p, int force_undirected,
+                                                            uint64_t seed, uint64_t step) {
+  const int N = b.totals[0];
+  const int grp = (blockIdx.x * IGMC_BLOCK + threadIdx.x) >> 4, t = threadIdx.x & 15;
+  const int ngrp = (gridDim.x * IGMC_BLOCK) >> 4;
+  for (int i = grp; i < N; i += ngrp) {
+    const int beg = b.row_ptr[i], end = b.row_ptr[i + 1];
+    const bool row_user = (b.node_label[i] & 1) == 0;
+    const uint32_t gi = (uint32_t)b.node_gid[i], gr = (uint32_t)b.node_graph[i];
+    for (int e = beg + t; e < end; e += 16) {
+      const uint32_t gc = (uint32_t)b.node_gid[b.col[e]];
+      const uint32_t u = row_user ? gi : gc, v = row_user ? gc : gi;
+      const uint32_t dirF = force_undirected ? 2u : (row_user ? 1u : 0u);   // col -> row
+      const uint32_t dirT = force_undirected ? 2u : (row_user ? 0u : 1u);   // row -> col
+      const int kf = igmc_u01(igmc_edge_hash(seed, step, gr, u, v, dirF)) >= p;
+      const int kt = igmc_u01(igmc_edge_hash(seed, step, gr, u, v, dirT)) >= p;
+      b.eflag[e] = (uint8_t)(kf | (kt << 1));
+    }
+  }
+}
+
+__global__ __launch_bounds__(IGMC_BLOCK) void k_fill_u8(uint8_t* p, int64_t n, uint8_t v) {
+  for (int64_t i = (int64_t)blockIdx.x * IGMC_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * IGMC_BLOCK) p[i] = v;
+}
+
+// ---------------------------------------------------------------- host launchers
+size_t igmc_extract_smem_bytes(const GraphDev& g) {
+  const size_t Wu = (g.n_users + 31) >> 5, Wv = (g.n_items + 31) >> 5;
+  return 4 * (Wu + Wv) * sizeof(uint32_t);
+}
+
+void igmc_launch_extract(const GraphDev& g, const BatchDev& b, const int32_t* link_u, const int32_t* link_v,
+                         const float* link_y, const int32_t* link_idx, int first, int B, int replay,
+                         double sample_ratio, uint64_t seed, uint64_t epoch, void* stream) {
+  ExtractArgs a;
+  a.g = g; a.b = b;
+  a.link_u = link_u; a.link_v = link_v; a.link_y = link_y; a.link_idx = link_idx;
+  a.first = first; a.B = B; a.replay = replay;
+  a.sample_ratio = sample_ratio; a.seed = seed; a.epoch = epoch;
+  const size_t smem = igmc_extract_smem_bytes(g);
+  IGMC_PLAUNCH("k_extract_nodes", k_extract_nodes, B, IGMC_BLOCK, smem, stream, a);
+  IGMC_PLAUNCH("k_scan_offsets", k_scan_offsets, 1, IGMC_BLOCK, 0, stream, b, B);
+  IGMC_PLAUNCH("k_fill", k_fill, B, IGMC_BLOCK, smem / 2, stream, g, b);
+}
+
+void igmc_launch_edge_flags(const BatchDev& b, float p, int force_undirected, uint64_t seed, uint64_t step,
+                            void* stream) {
+  IGMC_PLAUNCH("k_edge_flags", k_edge_flags, 512, IGMC_BLOCK, 0, stream, b, p, force_undirected, seed, step);
+}
+
+void igmc_launch_fill_u8(uint8_t* p, int64_t n, uint8_t v, void* stream) {
+  IGMC_PLAUNCH("k_fill_u8", k_fill_u8, 256, IGMC_BLOCK, 0, stream, p, n, v);
+}
+
+// dynamic LDS above 64 KB needs an explicit opt-in on HIP
+int igmc_extract_prepare(size_t smem) {
+#ifndef IGMC_HIPEMU
+  if (smem > 48 * 1024) {
+    if (hipFuncSetAttribute((const void*)k_extract_nodes, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem / 2)) != hipSuccess) return 1;
+  }
+#endif
+  (void)smem;
+  return 0;
+}

@@ -1,0 +1,38 @@
+// launch.h -- host-side launcher declarations + optional per-kernel HIP-event timing (internal).
+#pragma once
+#include "model.h"
+
+// extract.hip
+size_t igmc_extract_smem_bytes(const GraphDev& g);
+void igmc_launch_extract(const GraphDev& g, const BatchDev& b, const int32_t* link_u, const int32_t* link_v,
+                         const float* link_y, const int32_t* link_idx, int first, int B, int replay,
+                         double sample_ratio, uint64_t seed, uint64_t epoch, void* stream);
+void igmc_launch_edge_flags(const BatchDev& b, float p, int force_undirected, uint64_t seed, uint64_t step,
+                            void* stream);
+void igmc_launch_fill_u8(uint8_t* p, int64_t n, uint8_t v, void* stream);
+int igmc_extract_prepare(size_t smem);
+
+// model.hip
+void igmc_launch_forward(const ModelDev& m, const BatchDev& b, const float* P, int B, int training,
+                         int use_flags, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
+                         float* out, void* stream);
+void igmc_launch_backward(const ModelDev& m, const BatchDev& b, const float* P, int B, int use_flags,
+                          const float* gout, int from_err, float grad_scale, float mult, float drop_scale,
+                          float arr_coef, float* grad, void* stream);
+void igmc_launch_loss(const ModelDev& m, const BatchDev& b, float ARR, float* loss, void* stream);
+void igmc_launch_sse(const BatchDev& b, const float* out, double* acc, void* stream);
+int igmc_model_prepare(const ModelDev& m);
+void igmc_launch_adam(float* p, const float* g, float* m1, float* m2, int64_t n, float step_size,
+                      float inv_sqrt_bc2, float beta1, float beta2, float eps, float wd, void* stream);
+
+// ---- per-kernel timing (HIP events on the launch stream; bench.py's roofline leg) ----
+void igmc_prof_begin(const char* name, void* stream);
+void igmc_prof_end(void* stream);
+extern int g_igmc_prof_on;
+
+#define IGMC_PLAUNCH(name, kern, grid, block, shmem, stream, ...)          \
+  do {                                                                     \
+    if (g_igmc_prof_on) igmc_prof_begin(name, stream);                     \
+    IGMC_LAUNCH(kern, grid, block, shmem, stream, __VA_ARGS__);            \
+    if (g_igmc_prof_on) igmc_prof_end(stream);                             \
+  } while (0)

@@ -1,0 +1,824 @@
+// model.hip -- IGMC forward / backward / optimiser kernels for gfx950 (CDNA4).
+//
+// Math (reference models.py:190-217, PyG-1.4.2 RGCNConv):
+//   conv_l(x)[i] = sum_{(j->i, r)} x[j] W_l[r] + x[i] root_l + bias_l,  W_l[r] = sum_b att_l[r,b] basis_l[b]
+//   h_l = tanh(conv_l(h_{l-1}));  readout = [h_0..h_3](target user) | [h_0..h_3](target item)
+//   out = lin2(dropout(relu(lin1(readout)))) * multiply_by
+//
+// MI355X formulation (NOT the reference's per-edge [E,32,32] weight materialisation):
+//   * aggregate in BASIS space:  A[i][b] = sum_e att[rel_e, b] * x[src_e]   (4 accumulators per
+//     feature, independent of the number of relations R), then ONE dense transform
+//     [A | x] (N x 160) @ [basis ; root] (160 x 32) on f32 MFMA (16x16x4), + bias, tanh fused.
+//   * the gather walks a dst-sorted CSR (atomic-free, bit-reproducible); each 16-lane group owns
+//     one row and reads whole 128-byte feature rows (float2 per lane).
+//   * layer 0 has one-hot inputs: it degenerates to a table lookup W0[rel*L + label] per edge.
+//   * backward reuses the same gather on the symmetric CSR (keep-bit 1 = transposed edge):
+//       G[j][b]   = sum_{e: src=j} att[rel_e,b] dPre[dst_e]
+//       dX        = [G | dPre] @ [basis^T ; root^T]
+//       d basis_b = X^T G_b,  d root = X^T dPre,  d bias = sum dPre      (MFMA, per-block partials)
+//       d att[r,b]= sum_j < (x_j basis_b), sum_{e: src=j, rel=r} dPre[dst_e] >   (rows are sorted
+//                   by relation, so this is one dot product per relation RUN, not per edge)
+#include "model.h"
+
+__device__ __forceinline__ float igmc_wave_sum_f(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+__device__ __forceinline__ float igmc_group16_sum_f(float v) {
+#pragma unroll
+  for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d, 16);
+  return v;
+}
+
+// =================================================================== per-step derived weights
+__global__ __launch_bounds__(IGMC_BLOCK) void k_prep(ModelDev m, const float* __restrict__ P, int training) {
+  const int nW0 = m.R * m.L * 32, nW1 = m.D * 128;
+  const int nT = IGMC_KCAT * 32, nB = 32 * 128;
+  const int total = nW0 + nW1 + (training ? 3 * (nT + nB) : 0);
+  for (int idx = blockIdx.x * IGMC_BLOCK + threadIdx.x; idx < total; idx += gridDim.x * IGMC_BLOCK) {
+    if (idx < nW0) {
+      const int r = idx / (m.L * 32), cf = idx % (m.L * 32);
+      float s = 0.f;
+      for (int b = 0; b < 4; ++b) s += P[m.off_att[0] + r * 4 + b] * P[m.off_basis[0] + b * m.L * 32 + cf];
+      m.W0[idx] = s;
+    } else if (idx < nW0 + nW1) {
+      const int q = idx - nW0, k = q >> 7, j = q & 127;
+      m.w1T[q] = P[m.off_l1w + (int64_t)j * m.D + k];
+    } else {
+      int q = idx - nW0 - nW1;
+      const int l = 1 + q / (nT + nB);
+      q %= (nT + nB);
+      const float* basis = P + m.off_basis[l];
+      const float* root = P + m.off_root[l];
+      if (q < nT) {   // wT[k][f]
+        const int k = q >> 5, f = q & 31;
+        m.wT[l][q] = (k < 128) ? basis[((k >> 5) * 32 + f) * 32 + (k & 31)] : root[f * 32 + (k - 128)];
+      } else {        // bcat[f][n]
+        q -= nT;
+        const int f = q >> 7, n = q & 127;
+        m.bcat[l][q] = basis[((n >> 5) * 32 + f) * 32 + (n & 31)];
+      }
+    }
+  }
+}
+
+// =================================================================== layer 0 forward (one-hot input)
+template <bool FLAGS>
+__global__ __launch_bounds__(IGMC_BLOCK) void k_l0_fwd(BatchDev b, ModelDev m, const float* __restrict__ P,
+                                                         float* __restrict__ out) {
+  IGMC_DYN_SMEM(smem);
+  float* sW0 = (float*)smem;                 // [R*L][32]
+  float* sroot = sW0 + m.R * m.L * 32;       // [L][32]
+  float* sbias = sroot + m.L * 32;           // [32]
+  for (int i = threadIdx.x; i < m.R * m.L * 32; i += IGMC_BLOCK) sW0[i] = m.W0[i];
+  for (int i = threadIdx.x; i < m.L * 32; i += IGMC_BLOCK) sroot[i] = P[m.off_root[0] + i];
+  if (threadIdx.x < 32) sbias[threadIdx.x] = P[m.off_bias[0] + threadIdx.x];
+  __syncthreads();
+  const int N = b.totals[0];
+  const int grp = threadIdx.x >> 4, t = threadIdx.x & 15;
+  for (int tile = blockIdx.x; tile * 16 < N; tile += gridDim.x) {
+    const int i = tile * 16 + grp;
+    if (i >= N) continue;
+    const int lab = b.node_label[i];
+    float ax = sbias[2 * t] + sroot[lab * 32 + 2 * t];
+    float ay = sbias[2 * t + 1] + sroot[lab * 32 + 2 * t + 1];
+    const int beg = b.row_ptr[i], end = b.row_ptr[i + 1];
+    for (int e = beg; e < end; ++e) {
+      const int code = b.ecode[e];
+      const bool keep = !FLAGS || (b.eflag[e] & 1);
+      if (keep) {
+        ax += sW0[code * 32 + 2 * t];
+        ay += sW0[code * 32 + 2 * t + 1];
+      }
+    }
+    float2 o;
+    o.x = tanhf(ax);
+    o.y = tanhf(ay);
+    *(float2*)(out + (size_t)i * 32 + 2 * t) = o;
+  }
+}
+
+// =================================================================== basis-space gather (layers 1..3)
+// FLAGS: honour edge keep flags; TRANS: use the transposed-edge keep bit (backward);
+// ATTG: additionally accumulate d att via relation runs (needs Y = x @ [basis_0..3]).
+template <bool FLAGS, bool TRANS, bool ATTG>
+__global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_gather(BatchDev b, int R, const float* __restrict__ in,
+                                                              const float* __restrict__ att,
+                                                              float* __restrict__ out,
+                                                              const float* __restrict__ Y,
+                                                              float* __restrict__ gatt_part) {
+  IGMC_DYN_SMEM(smem);
+  float* s_att = (float*)smem;              // [R][4]
+  float* s_gatt = s_att + R * 4;            // [16 groups][R*4]   (ATTG only)
+  for (int i = threadIdx.x; i < R * 4; i += IGMC_BLOCK) s_att[i] = att[i];
+  if (ATTG)
+    for (int i = threadIdx.x; i < 16 * R * 4; i += IGMC_BLOCK) s_gatt[i] = 0.f;
+  __syncthreads();
+  const int N = b.totals[0];
+  const int grp = threadIdx.x >> 4, t = threadIdx.x & 15;
+  const int kbit = TRANS ? 1 : 0;
+  for (int tile = blockIdx.x; tile * 16 < N; tile += gridDim.x) {
+    const int i = tile * 16 + grp;
+    if (i >= N) continue;
+    float ax[4] = {0.f, 0.f, 0.f, 0.f}, ay[4] = {0.f, 0.f, 0.f, 0.f};
+    float yx[4], yy[4];
+    float tx = 0.f, ty = 0.f;
+    int cur = -1;
+    if (ATTG) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float2 v = *(const float2*)(Y + (size_t)i * 128 + q * 32 + 2 * t);
+        yx[q] = v.x;
+        yy[q] = v.y;
+      }
+    }
+    const int beg = b.row_ptr[i], end = b.row_ptr[i + 1];
+    for (int e0 = beg; e0 < end; e0 += 4) {
+      int c[4], r[4];
+      bool k[4];
+      float2 x[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = e0 + q;
+        const bool ok = e < end;
+        c[q] = ok ? b.col[e] : 0;
+        r[q] = ok ? (int)b.erel[e] : 0;
+        k[q] = ok && (!FLAGS || ((b.eflag[e] >> kbit) & 1));
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (k[q]) x[q] = *(const float2*)(in + (size_t)c[q] * 32 + 2 * t);
+        else { x[q].x = 0.f; x[q].y = 0.f; }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (!ATTG) {
+          const float* a = s_att + r[q] * 4;
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) {
+            ax[bb] += a[bb] * x[q].x;
+            ay[bb] += a[bb] * x[q].y;
+          }
+        } else if (k[q]) {
+          if (r[q] != cur) {
+            if (cur >= 0) {   // flush the finished relation run
+              const float* a = s_att + cur * 4;
+#pragma unroll
+              for (int bb = 0; bb < 4; ++bb) {
+                ax[bb] += a[bb] * tx;
+                ay[bb] += a[bb] * ty;
+                const float p = igmc_group16_sum_f(yx[bb] * tx + yy[bb] * ty);
+                if (t == 0) s_gatt[grp * R * 4 + cur * 4 + bb] += p;
+              }
+            }
+            cur = r[q];
+            tx = 0.f;
+            ty = 0.f;
+          }
+          tx += x[q].x;
+          ty += x[q].y;
+        }
+      }
+    }
+    if (ATTG && cur >= 0) {
+      const float* a = s_att + cur * 4;
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        ax[bb] += a[bb] * tx;
+        ay[bb] += a[bb] * ty;
+        const float p = igmc_group16_sum_f(yx[bb] * tx + yy[bb] * ty);
+        if (t == 0) s_gatt[grp * R * 4 + cur * 4 + bb] += p;
+      }
+    }
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+      float2 o;
+      o.x = ax[bb];
+      o.y = ay[bb];
+      *(float2*)(out + (size_t)i * 128 + bb * 32 + 2 * t) = o;
+    }
+  }
+  if (ATTG) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < R * 4; i += IGMC_BLOCK) {
+      float s = 0.f;
+      for (int g = 0; g < 16; ++g) s += s_gatt[g * R * 4 + i];
+      gatt_part[(size_t)blockIdx.x * R * 4 + i] = s;
+    }
+  }
+}
+
+// =================================================================== dense row transform on f32 MFMA
+// OUT[N,NO] = epilogue([A1[N,K1] | A2[N,K2]] @ W[K1+K2, NO]).  One wave = 16 rows x NO columns,
+// v_mfma_f32_16x16x4_f32; W is staged once per block in LDS (pitch NO+4: conflict-free b32 reads).
+enum { EPI_NONE = 0, EPI_BIAS_TANH = 1, EPI_BWD = 2 };
+
+template <int K1, int K2, int NO, int EPI>
+__global__ __launch_bounds__(IGMC_BLOCK) void k_dense(BatchDev b, const float* __restrict__ A1,
+                                                        const float* __restrict__ A2,
+                                                        const float* __restrict__ W,
+                                                        const float* __restrict__ bias,
+                                                        float* __restrict__ out,
+                                                        const float* __restrict__ xin,     // EPI_BWD: input activations
+                                                        const float* __restrict__ gfeat,   // EPI_BWD: readout gradient [B,D]
+                                                        int D, int rlayer) {
+  constexpr int K = K1 + K2, PITCH = NO + 4, NT = NO / 16;
+  IGMC_DYN_SMEM(smem);
+  float* sW = (float*)smem;
+  for (int idx = threadIdx.x; idx < K * NO; idx += IGMC_BLOCK) sW[(idx / NO) * PITCH + (idx % NO)] = W[idx];
+  __syncthreads();
+  const int N = b.totals[0];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  for (int tile = blockIdx.x; tile * 64 < N; tile += gridDim.x) {
+    const int row0 = tile * 64 + wave * 16;
+    if (row0 >= N) continue;
+    const int row = (row0 + li < N) ? row0 + li : N - 1;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < K / 16; ++s) {
+      const float* src = (s * 16 < K1) ? (A1 + (size_t)row * K1 + s * 16) : (A2 + (size_t)row * K2 + (s * 16 - K1));
+      const float4 a4 = *(const float4*)(src + 4 * kq);
+      const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+      for (int mm = 0; mm < 4; ++mm) {
+        const int k = s * 16 + 4 * kq + mm;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float bv = sW[k * PITCH + nt * 16 + li];
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mm], bv, acc[nt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int orow = row0 + kq * 4 + rr;
+        if (orow >= N) continue;
+        const int n = nt * 16 + li;
+        float v = acc[nt][rr];
+        if (EPI == EPI_BIAS_TANH) v = tanhf(v + bias[n]);
+        if (EPI == EPI_BWD) {
+          const int lab = b.node_label[orow];
+          if (lab < 2) v += gfeat[(size_t)b.node_graph[orow] * D + lab * 128 + rlayer * 32 + n];
+          const float xv = xin[(size_t)orow * 32 + n];
+          v *= (1.f - xv * xv);
+        }
+        out[(size_t)orow * NO + n] = v;
+      }
+    }
+  }
+}
+
+// =================================================================== weight gradients  G = X^T [D1 | D2]
+// X [N,32], D1 [N,128], D2 [N,32]  ->  per-block partial [32][160] (+ column sums of D2 = d bias).
+__global__ __launch_bounds__(IGMC_BLOCK) void k_wgrad(BatchDev b, const float* __restrict__ X,
+                                                        const float* __restrict__ D1, const float* __restrict__ D2,
+                                                        float* __restrict__ part) {
+  __shared__ float sacc[32 * IGMC_KCAT + 32];
+  const int N = b.totals[0];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  f32x4 acc[2][10];
+#pragma unroll
+  for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+    for (int nt = 0; nt < 10; ++nt) acc[m2][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[2] = {0.f, 0.f};
+  const int ntile = (N + 15) >> 4;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntile; tile += gridDim.x * 4) {
+    const int row0 = tile * 16;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int row = row0 + 4 * r4 + kq;
+      const bool ok = row < N;
+      const int rs = ok ? row : 0;
+      float2 a2 = *(const float2*)(X + (size_t)rs * 32 + 2 * li);
+      if (!ok) { a2.x = 0.f; a2.y = 0.f; }
+#pragma unroll
+      for (int nt = 0; nt < 10; ++nt) {
+        float bv = (nt < 8) ? D1[(size_t)rs * 128 + nt * 16 + li] : D2[(size_t)rs * 32 + (nt - 8) * 16 + li];
+        if (!ok) bv = 0.f;
+        if (nt >= 8) bsum[nt - 8] += bv;
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, bv, acc[0][nt], 0, 0, 0);
+        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, bv, acc[1][nt], 0, 0, 0);
+      }
+    }
+  }
+  // d bias: reduce the 4 row-slots (kq) of each column
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    bsum[q] += __shfl_xor(bsum[q], 16, 64);
+    bsum[q] += __shfl_xor(bsum[q], 32, 64);
+  }
+  // deterministic cross-wave reduction through LDS, wave 0 first
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+        for (int nt = 0; nt < 10; ++nt)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int f = 2 * (kq * 4 + rr) + m2, n = nt * 16 + li;
+            const float v = acc[m2][nt][rr];
+            if (w == 0) sacc[f * IGMC_KCAT + n] = v;
+            else sacc[f * IGMC_KCAT + n] += v;
+          }
+      if (kq == 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          if (w == 0) sacc[32 * IGMC_KCAT + q * 16 + li] = bsum[q];
+          else sacc[32 * IGMC_KCAT + q * 16 + li] += bsum[q];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* dst = part + (size_t)blockIdx.x * (32 * IGMC_KCAT + 32);
+  for (int i = threadIdx.x; i < 32 * IGMC_KCAT + 32; i += IGMC_BLOCK) dst[i] = sacc[i];
+}
+
+// =================================================================== layer 0 backward
+// table[code] += dPre0[dst]  for every kept edge (code = rel*L + label(src)); extra rows:
+// R*L + label(i) (d root0) and R*L + L (d bias0).  PRIVATE: one table per 16-lane group.
+template <bool FLAGS, bool PRIVATE>
+__global__ __launch_bounds__(IGMC_BLOCK) void k_l0_bwd(BatchDev b, ModelDev m, const float* __restrict__ dpre,
+                                                         float* __restrict__ part) {
+  IGMC_DYN_SMEM(smem);
+  float* tab = (float*)smem;
+  const int rows = m.R * m.L + m.L + 1;
+  const int ntab = PRIVATE ? 16 : 1;
+  for (int i = threadIdx.x; i < ntab * rows * 32; i += IGMC_BLOCK) tab[i] = 0.f;
+  __syncthreads();
+  const int N = b.totals[0];
+  const int grp = threadIdx.x >> 4, t = threadIdx.x & 15;
+  float* my = tab + (PRIVATE ? grp * rows * 32 : 0);
+  for (int tile = blockIdx.x; tile * 16 < N; tile += gridDim.x) {
+    const int i = tile * 16 + grp;
+    if (i >= N) continue;
+    const float2 d = *(const float2*)(dpre + (size_t)i * 32 + 2 * t);
+    const int beg = b.row_ptr[i], end = b.row_ptr[i + 1];
+    const int lab = b.node_label[i];
+    if (PRIVATE) {
+      // consecutive edges often share the code (rows are relation-sorted): count, then one update
+      int cur = -1, cnt = 0;
+      for (int e = beg; e < end; ++e) {
+        const bool keep = !FLAGS || (b.eflag[e] & 1);
+        if (!keep) continue;
+        const int code = b.ecode[e];
+        if (code != cur) {
+          if (cur >= 0) {
+            my[cur * 32 + 2 * t] += cnt * d.x;
+            my[cur * 32 + 2 * t + 1] += cnt * d.y;
+          }
+          cur = code;
+          cnt = 0;
+        }
+        ++cnt;
+      }
+      if (cur >= 0) {
+        my[cur * 32 + 2 * t] += cnt * d.x;
+        my[cur * 32 + 2 * t + 1] += cnt * d.y;
+      }
+      my[(m.R * m.L + lab) * 32 + 2 * t] += d.x;
+      my[(m.R * m.L + lab) * 32 + 2 * t + 1] += d.y;
+      my[(m.R * m.L + m.L) * 32 + 2 * t] += d.x;
+      my[(m.R * m.L + m.L) * 32 + 2 * t + 1] += d.y;
+    } else {
+      for (int e = beg; e < end; ++e) {
+        const bool keep = !FLAGS || (b.eflag[e] & 1);
+        if (!keep) continue;
+        const int code = b.ecode[e];
+        atomicAdd(&my[code * 32 + 2 * t], d.x);
+        atomicAdd(&my[code * 32 + 2 * t + 1], d.y);
+      }
+      atomicAdd(&my[(m.R * m.L + lab) * 32 + 2 * t], d.x);
+      atomicAdd(&my[(m.R * m.L + lab) * 32 + 2 * t + 1], d.y);
+      atomicAdd(&my[(m.R * m.L + m.L) * 32 + 2 * t], d.x);
+      atomicAdd(&my[(m.R * m.L + m.L) * 32 + 2 * t + 1], d.y);
+    }
+  }
+  __syncthreads();
+  float* dst = part + (size_t)blockIdx.x * rows * 32;
+  for (int i = threadIdx.x; i < rows * 32; i += IGMC_BLOCK) {
+    float s = 0.f;
+    for (int g = 0; g < ntab; ++g) s += tab[g * rows * 32 + i];
+    dst[i] = s;
+  }
+}
+
+// =================================================================== head: readout + MLP (+loss residual)
+// One 128-thread block per graph.  reference models.py:203-215.
+__global__ __launch_bounds__(128) void k_head_fwd(BatchDev b, ModelDev m, const float* __restrict__ P,
+                                                    int training, const uint8_t* __restrict__ inj_mask,
+                                                    uint64_t seed, uint64_t step, float mult,
+                                                    float* __restrict__ out) {
+  IGMC_DYN_SMEM(smem);
+  float* sfeat = (float*)smem;      // [D]
+  __shared__ float red[2];
+  const int g = blockIdx.x, j = threadIdx.x;
+  const int nu = b.node_off[g], nv = nu + b.n_users[g];
+  for (int k = j; k < m.D; k += 128) {
+    float v;
+    if (k < 256) {
+      const int side = k >> 7, l = (k >> 5) & 3, f = k & 31;
+      v = m.h[l][(size_t)(side ? nv : nu) * 32 + f];
+    } else {
+      v = m.side[(size_t)g * m.S + (k - 256)];
+    }
+    sfeat[k] = v;
+    if (training) m.feat[(size_t)g * m.D + k] = v;
+  }
+  __syncthreads();
+  float acc = P[m.off_l1b + j];
+  for (int k = 0; k < m.D; ++k) acc += m.w1T[k * 128 + j] * sfeat[k];
+  float a = acc > 0.f ? acc : 0.f;
+  if (training) {
+    m.a1[g * 128 + j] = a;
+    const int keep = inj_mask ? (int)inj_mask[g * 128 + j]
+                              : (int)(igmc_u01(igmc_unit_hash(seed, step, (uint32_t)g, (uint32_t)j)) >= 0.5f);
+    m.lmask[g * 128 + j] = (uint8_t)keep;
+    a = keep ? a * 2.f : 0.f;    // F.dropout(p=0.5): kept units scaled by 1/(1-p)
+  }
+  float p = igmc_wave_sum_f(a * P[m.off_l2w + j]);
+  if ((j & 63) == 0) red[j >> 6] = p;
+  __syncthreads();
+  if (j == 0) {
+    const float o = (red[0] + red[1] + P[m.off_l2b]) * mult;
+    out[g] = o;
+    m.err[g] = o - b.y[g];
+  }
+}
+
+// backward A: per graph -- dz, d feat, and dPre of the top layer on the two target rows
+__global__ __launch_bounds__(128) void k_head_bwd_a(BatchDev b, ModelDev m, const float* __restrict__ P,
+                                                      const float* __restrict__ gout, int from_err,
+                                                      float grad_scale, float mult, float drop_scale,
+                                                      float* __restrict__ dpre_top) {
+  __shared__ float sdz[128];
+  const int g = blockIdx.x, j = threadIdx.x;
+  const float dp = (from_err ? 2.f * m.err[g] * grad_scale : gout[g]) * mult;
+  const float a = m.a1[g * 128 + j];
+  const float dzv = (a > 0.f && m.lmask[g * 128 + j]) ? dp * P[m.off_l2w + j] * drop_scale : 0.f;
+  m.dz[g * 128 + j] = dzv;
+  sdz[j] = dzv;
+  __syncthreads();
+  const int nu = b.node_off[g], nv = nu + b.n_users[g];
+  for (int k = j; k < m.D; k += 128) {
+    float s = 0.f;
+    for (int jj = 0; jj < 128; ++jj) s += sdz[jj] * P[m.off_l1w + (int64_t)jj * m.D + k];
+    m.gfeat[(size_t)g * m.D + k] = s;
+    if (k < 256 && ((k >> 5) & 3) == 3) {
+      const int side = k >> 7, f = k & 31;
+      const size_t node = (size_t)(side ? nv : nu);
+      const float hv = m.h[3][node * 32 + f];
+      dpre_top[node * 32 + f] = s * (1.f - hv * hv);
+    }
+  }
+}
+
+// backward B: d lin1.weight / d lin1.bias / d lin2.weight / d lin2.bias (sum over the B graphs)
+__global__ __launch_bounds__(IGMC_BLOCK) void k_head_bwd_w(BatchDev b, ModelDev m, const float* __restrict__ P,
+                                                             const float* __restrict__ gout, int from_err,
+                                                             float grad_scale, float mult, float drop_scale,
+                                                             float* __restrict__ grad) {
+  const int B = b.totals[3];
+  const int nW = 128 * m.D;
+  const int idx = blockIdx.x * IGMC_BLOCK + threadIdx.x;
+  if (idx < nW) {
+    const int j = idx / m.D, k = idx % m.D;
+    float s = 0.f;
+    for (int g = 0; g < B; ++g) s += m.dz[g * 128 + j] * m.feat[(size_t)g * m.D + k];
+    grad[m.off_l1w + idx] = s;
+  } else if (idx < nW + 128) {
+    const int j = idx - nW;
+    float s = 0.f;
+    for (int g = 0; g < B; ++g) s += m.dz[g * 128 + j];
+    grad[m.off_l1b + j] = s;
+  } else if (idx < nW + 256) {
+    const int j = idx - nW - 128;
+    float s = 0.f;
+    for (int g = 0; g < B; ++g) {
+      const float dp = (from_err ? 2.f * m.err[g] * grad_scale : gout[g]) * mult;
+      const float a = m.lmask[g * 128 + j] ? m.a1[g * 128 + j] * drop_scale : 0.f;
+      s += dp * a;
+    }
+    grad[m.off_l2w + j] = s;
+  } else if (idx == nW + 256) {
+    float s = 0.f;
+    for (int g = 0; g < B; ++g) s += (from_err ? 2.f * m.err[g] * grad_scale : gout[g]) * mult;
+    grad[m.off_l2b] = s;
+  }
+}
+
+// =================================================================== partial reduction + finalize
+// graw layout: [3][5152] conv1..3 (32x160 + 32) | [3][R*4] d att | [(R*L+L+1)*32] layer-0 table
+__global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_partials(ModelDev m) {
+  const int wgs = 32 * IGMC_KCAT + 32, na = m.R * 4, n0 = (m.R * m.L + m.L + 1) * 32;
+  const int total = 3 * wgs + 3 * na + n0;
+  for (int idx = blockIdx.x * IGMC_BLOCK + threadIdx.x; idx < total; idx += gridDim.x * IGMC_BLOCK) {
+    float s = 0.f;
+    if (idx < 3 * wgs) {
+      const int l = idx / wgs, i = idx % wgs;
+      const float* p = m.wg_part + (size_t)l * IGMC_WG_BLOCKS * wgs + i;
+      for (int k = 0; k < IGMC_WG_BLOCKS; ++k) s += p[(size_t)k * wgs];
+    } else if (idx < 3 * wgs + 3 * na) {
+      const int q = idx - 3 * wgs, l = q / na, i = q % na;
+      const float* p = m.gatt_part + (size_t)l * IGMC_GATHER_BLOCKS * na + i;
+      for (int k = 0; k < IGMC_GATHER_BLOCKS; ++k) s += p[(size_t)k * na];
+    } else {
+      const int i = idx - 3 * wgs - 3 * na;
+      const float* p = m.l0_part + i;
+      for (int k = 0; k < IGMC_L0_BLOCKS; ++k) s += p[(size_t)k * n0];
+    }
+    m.graw[idx] = s;
+  }
+}
+
+__device__ __forceinline__ float igmc_block_sum_f(float v, float* sm) {
+  v = igmc_wave_sum_f(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sm[wave] = v;
+  __syncthreads();
+  float tot = 0.f;
+  const int nw = (blockDim.x + 63) >> 6;
+  for (int w = 0; w < nw; ++w) tot += sm[w];
+  __syncthreads();
+  return tot;
+}
+
+// one block per conv layer: scatter the reduced partials into the flat gradient, add the
+// adjacent-rating-regulariser gradient (reference train_eval.py:167-174), emit the ARR value.
+__global__ __launch_bounds__(IGMC_BLOCK) void k_finalize(ModelDev m, const float* __restrict__ P,
+                                                           float* __restrict__ grad, float arr_coef) {
+  __shared__ float smf[8];
+  const int l = blockIdx.x, tid = threadIdx.x;
+  const int fin = (l == 0) ? m.L : 32;
+  const int nE = fin * 32;                 // elements of one W[r] / basis[b]
+  const int wgs = 32 * IGMC_KCAT + 32, na = m.R * 4;
+  const float* basis = P + m.off_basis[l];
+  const float* att = P + m.off_att[l];
+  float* gb = grad + m.off_basis[l];
+  float* ga = grad + m.off_att[l];
+  if (l >= 1) {
+    const float* raw = m.graw + (size_t)(l - 1) * wgs;
+    for (int e = tid; e < 4 * 1024; e += IGMC_BLOCK) {
+      const int bb = e >> 10, f = (e >> 5) & 31, fo = e & 31;
+      gb[e] = raw[f * IGMC_KCAT + bb * 32 + fo];
+    }
+    for (int e = tid; e < 1024; e += IGMC_BLOCK) grad[m.off_root[l] + e] = raw[(e >> 5) * IGMC_KCAT + 128 + (e & 31)];
+    if (tid < 32) grad[m.off_bias[l] + tid] = raw[32 * IGMC_KCAT + tid];
+    const float* rawa = m.graw + 3 * wgs + (size_t)(l - 1) * na;
+    for (int i = tid; i < na; i += IGMC_BLOCK) ga[i] = rawa[i];
+  } else {
+    const float* t0 = m.graw + 3 * wgs + 3 * na;     // [R*L + L + 1][32]
+    for (int e = tid; e < 4 * nE; e += IGMC_BLOCK) {   // d basis0[b][c][f] = sum_r att[r,b] GW0[r*L+c][f]
+      const int bb = e / nE, cf = e % nE;
+      float s = 0.f;
+      for (int r = 0; r < m.R; ++r) s += att[r * 4 + bb] * t0[(size_t)r * nE + cf];
+      gb[e] = s;
+    }
+    for (int e = tid; e < nE; e += IGMC_BLOCK) grad[m.off_root[0] + e] = t0[(size_t)m.R * nE + e];
+    if (tid < 32) grad[m.off_bias[0] + tid] = t0[(size_t)(m.R * m.L + m.L) * 32 + tid];
+    for (int rb = 0; rb < na; ++rb) {                 // d att0[r,b] = <GW0[r], basis0[b]>
+      const int r = rb >> 2, bb = rb & 3;
+      float s = 0.f;
+      for (int e = tid; e < nE; e += IGMC_BLOCK) s += t0[(size_t)r * nE + e] * basis[bb * nE + e];
+      s = igmc_block_sum_f(s, smf);
+      if (tid == 0) ga[rb] = s;
+    }
+  }
+  __syncthreads();
+  // ---- ARR: reg = sum_r ||W[r+1]-W[r]||^2 ; dreg/dW[r] = 2 (D[r-1] - D[r]),  D[r] = W[r+1]-W[r]
+  float reg = 0.f;
+  {
+    float bs[4][4];   // basis[b][e] for this thread's (up to 4) elements
+    int ne = 0;
+    for (int e = tid; e < nE && ne < 4; e += IGMC_BLOCK, ++ne)
+      for (int bb = 0; bb < 4; ++bb) bs[bb][ne] = basis[bb * nE + e];
+    float gbas[4][4];
+    for (int bb = 0; bb < 4; ++bb)
+      for (int q = 0; q < 4; ++q) gbas[bb][q] = 0.f;
+    float wprev[4] = {0.f, 0.f, 0.f, 0.f}, wcur[4] = {0.f, 0.f, 0.f, 0.f}, wnext[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < ne; ++q) {
+      float s = 0.f;
+      for (int bb = 0; bb < 4; ++bb) s += att[bb] * bs[bb][q];
+      wcur[q] = s;
+    }
+    for (int r = 0; r < m.R; ++r) {
+      float pa[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < ne; ++q) {
+        float dw = 0.f;
+        if (r + 1 < m.R) {
+          float s = 0.f;
+          for (int bb = 0; bb < 4; ++bb) s += att[(r + 1) * 4 + bb] * bs[bb][q];
+          wnext[q] = s;
+          const float dn = wnext[q] - wcur[q];
+          reg += dn * dn;
+          dw -= 2.f * dn;
+        }
+        if (r > 0) dw += 2.f * (wcur[q] - wprev[q]);
+        for (int bb = 0; bb < 4; ++bb) {
+          gbas[bb][q] += att[r * 4 + bb] * dw;
+          pa[bb] += dw * bs[bb][q];
+        }
+      }
+      for (int bb = 0; bb < 4; ++bb) {
+        const float s = igmc_block_sum_f(pa[bb], smf);
+        if (tid == 0 && arr_coef != 0.f) ga[r * 4 + bb] += arr_coef * s;
+      }
+      for (int q = 0; q < ne; ++q) {
+        wprev[q] = wcur[q];
+        wcur[q] = wnext[q];
+      }
+    }
+    if (arr_coef != 0.f) {
+      int q = 0;
+      for (int e = tid; e < nE && q < 4; e += IGMC_BLOCK, ++q)
+        for (int bb = 0; bb < 4; ++bb) gb[bb * nE + e] += arr_coef * gbas[bb][q];
+    }
+  }
+  reg = igmc_block_sum_f(reg, smf);
+  if (tid == 0) m.arr_part[l] = reg;
+}
+
+// loss[0] = mean_g err^2 + ARR * sum_l reg_l   (reference train_eval.py:162-174); loss[1] = sum err^2
+__global__ __launch_bounds__(IGMC_BLOCK) void k_loss(BatchDev b, ModelDev m, float ARR, float* __restrict__ loss) {
+  __shared__ float smf[8];
+  const int B = b.totals[3];
+  float s = 0.f;
+  for (int g = threadIdx.x; g < B; g += IGMC_BLOCK) s += m.err[g] * m.err[g];
+  s = igmc_block_sum_f(s, smf);
+  if (threadIdx.x == 0) {
+    const float reg = m.arr_part[0] + m.arr_part[1] + m.arr_part[2] + m.arr_part[3];
+    loss[0] = s / (float)B + ARR * reg;
+    loss[1] = s;
+  }
+}
+
+__global__ __launch_bounds__(IGMC_BLOCK) void k_sse_acc(BatchDev b, const float* __restrict__ out, double* acc) {
+  __shared__ float smf[8];
+  const int B = b.totals[3];
+  float s = 0.f;
+  for (int g = threadIdx.x; g < B; g += IGMC_BLOCK) {
+    const float d = out[g] - b.y[g];
+    s += d * d;
+  }
+  s = igmc_block_sum_f(s, smf);
+  if (threadIdx.x == 0) {
+    acc[0] += (double)s;
+    acc[1] += (double)B;
+  }
+}
+
+// =================================================================== fused Adam (flat buffer)
+__global__ __launch_bounds__(IGMC_BLOCK) void k_adam(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m1, float* __restrict__ m2, int64_t n,
+                                                       float step_size, float inv_sqrt_bc2, float beta1, float beta2,
+                                                       float eps, float wd) {
+  for (int64_t i = (int64_t)blockIdx.x * IGMC_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * IGMC_BLOCK) {
+    float gi = g[i];
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float a = beta1 * m1[i] + (1.f - beta1) * gi;
+    const float v = beta2 * m2[i] + (1.f - beta2) * gi * gi;
+    m1[i] = a;
+    m2[i] = v;
+    p[i] = pi - step_size * a / (sqrtf(v) * inv_sqrt_bc2 + eps);
+  }
+}
+
+__global__ __launch_bounds__(IGMC_BLOCK) void k_zero_rows(BatchDev b, float* __restrict__ p, int per_row) {
+  const int64_t n = (int64_t)b.totals[0] * per_row;
+  for (int64_t i = (int64_t)blockIdx.x * IGMC_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * IGMC_BLOCK) p[i] = 0.f;
+}
+
+// =================================================================== host launch sequences
+#include "launch.h"
+
+static inline int igmc_rows_grid(int cap_rows, int rows_per_block, int max_blocks) {
+  int g = (cap_rows + rows_per_block - 1) / rows_per_block;
+  if (g < 1) g = 1;
+  return g < max_blocks ? g : max_blocks;
+}
+
+void igmc_launch_forward(const ModelDev& m, const BatchDev& b, const float* P, int B, int training,
+                         int use_flags, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
+                         float* out, void* stream) {
+  IGMC_PLAUNCH("k_prep", k_prep, 64, IGMC_BLOCK, 0, stream, m, P, training);
+  const size_t l0s = (size_t)(m.R * m.L * 32 + m.L * 32 + 32) * sizeof(float);
+  const int g16 = igmc_rows_grid(m.node_cap, 16, IGMC_GATHER_BLOCKS);
+  const int g64 = igmc_rows_grid(m.node_cap, 64, 512);
+  if (use_flags) IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<true>), g16, IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
+  else IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<false>), g16, IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
+  const size_t gs = (size_t)(m.R * 4) * sizeof(float);
+  const size_t ds = (size_t)IGMC_KCAT * (32 + 4) * sizeof(float);
+  for (int l = 1; l < 4; ++l) {
+    if (use_flags)
+      IGMC_PLAUNCH("k_rgcn_gather_fwd", (k_rgcn_gather<true, false, false>), g16, IGMC_BLOCK, gs, stream, b, m.R,
+                   (const float*)m.h[l - 1], P + m.off_att[l], m.agg, (const float*)nullptr, (float*)nullptr);
+    else
+      IGMC_PLAUNCH("k_rgcn_gather_fwd", (k_rgcn_gather<false, false, false>), g16, IGMC_BLOCK, gs, stream, b, m.R,
+                   (const float*)m.h[l - 1], P + m.off_att[l], m.agg, (const float*)nullptr, (float*)nullptr);
+    // [agg | h_{l-1}] @ [basis ; root]  (contiguous in the flat parameter buffer) + bias, tanh
+    IGMC_PLAUNCH("k_dense_fwd", (k_dense<128, 32, 32, EPI_BIAS_TANH>), g64, IGMC_BLOCK, ds, stream, b,
+                 (const float*)m.agg, (const float*)m.h[l - 1], P + m.off_basis[l], P + m.off_bias[l], m.h[l],
+                 (const float*)nullptr, (const float*)nullptr, 0, 0);
+  }
+  IGMC_PLAUNCH("k_head_fwd", k_head_fwd, B, 128, (size_t)m.D * sizeof(float), stream, b, m, P, training, inj_mask,
+               seed, step, mult, out);
+}
+
+void igmc_launch_backward(const ModelDev& m, const BatchDev& b, const float* P, int B, int use_flags,
+                          const float* gout, int from_err, float grad_scale, float mult, float drop_scale,
+                          float arr_coef, float* grad, void* stream) {
+  const int g16 = igmc_rows_grid(m.node_cap, 16, IGMC_GATHER_BLOCKS);
+  const int g64 = igmc_rows_grid(m.node_cap, 64, 512);
+  IGMC_PLAUNCH("k_zero_rows", k_zero_rows, 256, IGMC_BLOCK, 0, stream, b, m.dpre[1], 32);
+  IGMC_PLAUNCH("k_head_bwd_a", k_head_bwd_a, B, 128, 0, stream, b, m, P, gout, from_err, grad_scale, mult,
+               drop_scale, m.dpre[1]);
+  const int nhw = (128 * m.D + 257 + IGMC_BLOCK - 1) / IGMC_BLOCK;
+  IGMC_PLAUNCH("k_head_bwd_w", k_head_bwd_w, nhw, IGMC_BLOCK, 0, stream, b, m, P, gout, from_err, grad_scale, mult,
+               drop_scale, grad);
+  const int wgs = igmc_wg_stride(), na = m.R * 4;
+  const size_t gsa = (size_t)(m.R * 4 + 16 * m.R * 4) * sizeof(float);
+  const size_t ysz = (size_t)32 * (128 + 4) * sizeof(float);
+  const size_t ds = (size_t)IGMC_KCAT * (32 + 4) * sizeof(float);
+  for (int l = 3; l >= 1; --l) {
+    float* dcur = m.dpre[l & 1];
+    float* dnext = m.dpre[(l - 1) & 1];
+    IGMC_PLAUNCH("k_dense_y", (k_dense<0, 32, 128, EPI_NONE>), g64, IGMC_BLOCK, ysz, stream, b,
+                 (const float*)nullptr, (const float*)m.h[l - 1], (const float*)m.bcat[l], (const float*)nullptr, m.Y,
+                 (const float*)nullptr, (const float*)nullptr, 0, 0);
+    float* gp = m.gatt_part + (size_t)(l - 1) * IGMC_GATHER_BLOCKS * na;
+    // every block of the partial grid must write its slot -> launch the full partial grid
+    if (use_flags)
+      IGMC_PLAUNCH("k_rgcn_gather_bwd", (k_rgcn_gather<true, true, true>), IGMC_GATHER_BLOCKS, IGMC_BLOCK, gsa, stream,
+                   b, m.R, (const float*)dcur, P + m.off_att[l], m.agg, (const float*)m.Y, gp);
+    else
+      IGMC_PLAUNCH("k_rgcn_gather_bwd", (k_rgcn_gather<false, true, true>), IGMC_GATHER_BLOCKS, IGMC_BLOCK, gsa, stream,
+                   b, m.R, (const float*)dcur, P + m.off_att[l], m.agg, (const float*)m.Y, gp);
+    IGMC_PLAUNCH("k_dense_bwd", (k_dense<128, 32, 32, EPI_BWD>), g64, IGMC_BLOCK, ds, stream, b, (const float*)m.agg,
+                 (const float*)dcur, (const float*)m.wT[l], (const float*)nullptr, dnext, (const float*)m.h[l - 1],
+                 (const float*)m.gfeat, m.D, l - 1);
+    IGMC_PLAUNCH("k_wgrad", k_wgrad, IGMC_WG_BLOCKS, IGMC_BLOCK, 0, stream, b, (const float*)m.h[l - 1],
+                 (const float*)m.agg, (const float*)dcur, m.wg_part + (size_t)(l - 1) * IGMC_WG_BLOCKS * wgs);
+  }
+  const int rows0 = m.R * m.L + m.L + 1;
+  const bool priv = (size_t)16 * rows0 * 32 * sizeof(float) <= 96 * 1024;   // opt-in done by igmc_model_prepare
+  const size_t l0s = (size_t)(priv ? 16 : 1) * rows0 * 32 * sizeof(float);
+  const float* d0 = m.dpre[0];
+  if (use_flags) {
+    if (priv) IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<true, true>), IGMC_L0_BLOCKS, IGMC_BLOCK, l0s, stream, b, m, d0, m.l0_part);
+    else IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<true, false>), IGMC_L0_BLOCKS, IGMC_BLOCK, l0s, stream, b, m, d0, m.l0_part);
+  } else {
+    if (priv) IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<false, true>), IGMC_L0_BLOCKS, IGMC_BLOCK, l0s, stream, b, m, d0, m.l0_part);
+    else IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<false, false>), IGMC_L0_BLOCKS, IGMC_BLOCK, l0s, stream, b, m, d0, m.l0_part);
+  }
+  IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, 64, IGMC_BLOCK, 0, stream, m);
+  IGMC_PLAUNCH("k_finalize", k_finalize, 4, IGMC_BLOCK, 0, stream, m, P, grad, arr_coef);
+}
+
+void igmc_launch_loss(const ModelDev& m, const BatchDev& b, float ARR, float* loss, void* stream) {
+  IGMC_PLAUNCH("k_loss", k_loss, 1, IGMC_BLOCK, 0, stream, b, m, ARR, loss);
+}
+
+void igmc_launch_sse(const BatchDev& b, const float* out, double* acc, void* stream) {
+  IGMC_PLAUNCH("k_sse_acc", k_sse_acc, 1, IGMC_BLOCK, 0, stream, b, out, acc);
+}
+
+void igmc_launch_adam(float* p, const float* g, float* m1, float* m2, int64_t n, float step_size,
+                      float inv_sqrt_bc2, float beta1, float beta2, float eps, float wd, void* stream) {
+  int grid = (int)((n + IGMC_BLOCK - 1) / IGMC_BLOCK);
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  IGMC_PLAUNCH("k_adam", k_adam, grid, IGMC_BLOCK, 0, stream, p, g, m1, m2, n, step_size, inv_sqrt_bc2, beta1, beta2,
+               eps, wd);
+}
+
+// dynamic LDS above 64 KB needs an explicit opt-in on HIP (layer-0 backward tables)
+int igmc_model_prepare(const ModelDev& m) {
+#ifndef IGMC_HIPEMU
+  const int rows0 = m.R * m.L + m.L + 1;
+  const bool priv = (size_t)16 * rows0 * 32 * sizeof(float) <= 96 * 1024;
+  const int l0s = (int)((size_t)(priv ? 16 : 1) * rows0 * 32 * sizeof(float));
+  if (l0s > 48 * 1024) {
+    hipError_t e = hipSuccess;
+    if (priv) {
+      e = hipFuncSetAttribute((const void*)k_l0_bwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l0s);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_l0_bwd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l0s);
+    } else {
+      e = hipFuncSetAttribute((const void*)k_l0_bwd<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l0s);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_l0_bwd<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l0s);
+    }
+    if (e != hipSuccess) return 1;
+  }
+#endif
+  (void)m;
+  return 0;
+}

@@ -1,0 +1,267 @@
+"""Host-side dataset loading: produces the reference's 13-tuple
+``(u_features, v_features, adj_train, train_labels, train_u, train_v, val_labels, val_u, val_v,
+test_labels, test_u, test_v, class_values)`` whose ``adj_train`` stores rating-label + 1
+(reference ``preprocessing.py:190-197, 316-321``) -- the input contract of the hot path.
+
+* :func:`load_data_monti`      -- flixster / douban / yahoo_music, restating the split logic of
+  reference ``preprocessing.py:203-333`` on the bundled matrices (read from the ``.npz`` produced by
+  ``tests/golden/convert_mat.py``, or from the original HDF5 ``.mat`` when h5py is importable).
+* :func:`synth_ml`             -- MovieLens-shaped synthetic generator of SURVEY.md section 8(d)
+  (MovieLens itself is not available offline).
+* :func:`create_trainvaltest_split` -- random split with the reference's proportions
+  (``preprocessing.py:159-197``) over real MovieLens files when present under ``raw_data/``, else over
+  :func:`synth_ml`.
+
+One-off host preprocessing (seconds); not part of the accelerated path.
+"""
+import os
+
+import numpy as np
+import scipy.sparse as sp
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+ML_HIST = {
+    'ml_100k': (943, 1682, 100000, [6110, 11370, 27145, 34174, 21201]),
+    'ml_1m': (6040, 3706, 1000209, [56174, 107557, 261197, 348971, 226310]),
+}
+
+
+def _find_raw(dataset, fname):
+    for base in ('raw_data', os.path.join(_PKG_ROOT, 'raw_data')):
+        p = os.path.join(base, dataset, fname)
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def _load_monti_arrays(dataset):
+    """-> dict(shape, M (coo triplets), Otraining, Otest, W_* optional)."""
+    p = _find_raw(dataset, 'training_test_dataset.npz')
+    if p is not None:
+        z = np.load(p)
+        return {k: z[k] for k in z.files}
+    p = _find_raw(dataset, 'training_test_dataset.mat')
+    if p is None:
+        raise FileNotFoundError('raw_data/%s/training_test_dataset.{npz,mat} not found' % dataset)
+    import h5py  # optional: only for the original MATLAB v7.3 files
+    out = {}
+    with h5py.File(p, 'r') as db:
+        def dense(name):
+            ds = db[name]
+            if isinstance(ds, h5py.Group) and 'ir' in ds.keys():
+                return sp.csc_matrix((np.asarray(ds['data']), np.asarray(ds['ir']), np.asarray(ds['jc']))
+                                     ).astype(np.float32).toarray()
+            return np.asarray(ds).astype(np.float32).T   # MATLAB column-major (ref preprocessing.py:49-51)
+        M = dense('M')
+        out['shape'] = np.array(M.shape, np.int64)
+        r, c = np.nonzero(M)
+        out['M_row'], out['M_col'], out['M_val'] = r.astype(np.int32), c.astype(np.int32), M[r, c]
+        for k in ('Otraining', 'Otest'):
+            r, c = np.nonzero(dense(k))
+            out[k + '_row'], out[k + '_col'] = r.astype(np.int32), c.astype(np.int32)
+        for k in ('W_users', 'W_movies', 'W_tracks'):
+            if k in db.keys():
+                W = dense(k)
+                r, c = np.nonzero(W)
+                out[k + '_shape'] = np.array(W.shape, np.int64)
+                out[k + '_row'], out[k + '_col'], out[k + '_val'] = r.astype(np.int32), c.astype(np.int32), W[r, c]
+    return out
+
+
+def _side(z, key, n):
+    if key + '_row' in z:
+        return sp.csr_matrix((z[key + '_val'], (z[key + '_row'], z[key + '_col'])),
+                             shape=tuple(int(x) for x in z[key + '_shape']))
+    return sp.identity(n, format='csr')
+
+
+def load_data_monti(dataset, testing=False, rating_map=None, post_rating_map=None):
+    """Monti et al. splits (reference ``preprocessing.py:203-333``)."""
+    z = _load_monti_arrays(dataset)
+    num_users, num_items = int(z['shape'][0]), int(z['shape'][1])
+    u_nodes = z['M_row'].astype(np.int64)          # np.where(M) order = row-major
+    v_nodes = z['M_col'].astype(np.int64)
+    ratings = z['M_val'].astype(np.float64)
+    if rating_map is not None:
+        ratings = np.array([rating_map[x] for x in ratings], dtype=np.float64)
+
+    if dataset == 'flixster':
+        u_features, v_features = _side(z, 'W_users', num_users), _side(z, 'W_movies', num_items)
+    elif dataset == 'douban':
+        u_features, v_features = _side(z, 'W_users', num_users), sp.identity(num_items, format='csr')
+    elif dataset == 'yahoo_music':
+        u_features, v_features = sp.identity(num_users, format='csr'), _side(z, 'W_tracks', num_items)
+    else:
+        raise ValueError(dataset)
+
+    class_values = np.sort(np.unique(ratings))
+    rating_dict = {r: i for i, r in enumerate(class_values.tolist())}
+    labels = np.full(num_users * num_items, -1, dtype=np.int32)     # neutral_rating = -1
+    labels[u_nodes * num_items + v_nodes] = np.array([rating_dict[r] for r in ratings], dtype=np.int32)
+
+    tr_u, tr_v = z['Otraining_row'].astype(np.int64), z['Otraining_col'].astype(np.int64)
+    te_u, te_v = z['Otest_row'].astype(np.int64), z['Otest_col'].astype(np.int64)
+    num_train_all = len(tr_u)
+    num_test = len(te_u)
+    num_val = int(np.ceil(num_train_all * 0.2))
+    num_train = num_train_all - num_val
+
+    pairs_train = np.stack([tr_u, tr_v], 1)
+    # internal shuffle of the training set before the validation split-off (ref :275-280)
+    rand_idx = list(range(num_train_all))
+    np.random.seed(42)
+    np.random.shuffle(rand_idx)
+    pairs_train = pairs_train[rand_idx]
+    pairs = np.concatenate([pairs_train, np.stack([te_u, te_v], 1)], 0)
+    idx = pairs[:, 0] * num_items + pairs[:, 1]
+
+    val_idx, train_idx, test_idx = idx[:num_val], idx[num_val:num_val + num_train], idx[num_val + num_train:]
+    assert len(test_idx) == num_test                                 # ref :289
+    val_pairs, train_pairs, test_pairs = pairs[:num_val], pairs[num_val:num_val + num_train], pairs[num_val + num_train:]
+    u_test_idx, v_test_idx = test_pairs.T
+    u_val_idx, v_val_idx = val_pairs.T
+    u_train_idx, v_train_idx = train_pairs.T
+    train_labels, val_labels, test_labels = labels[train_idx], labels[val_idx], labels[test_idx]
+
+    if testing:
+        u_train_idx = np.hstack([u_train_idx, u_val_idx])
+        v_train_idx = np.hstack([v_train_idx, v_val_idx])
+        train_labels = np.hstack([train_labels, val_labels])
+        train_idx = np.hstack([train_idx, val_idx])
+
+    # training adjacency: values = label + 1  (ref :312-321)
+    rating_mx_train = np.zeros(num_users * num_items, dtype=np.float32)
+    if post_rating_map is None:
+        rating_mx_train[train_idx] = labels[train_idx].astype(np.float32) + 1.
+    else:
+        rating_mx_train[train_idx] = np.array([post_rating_map[r] for r in class_values[labels[train_idx]]]) + 1.
+    rating_mx_train = sp.csr_matrix(rating_mx_train.reshape(num_users, num_items))
+
+    return (sp.csr_matrix(u_features), sp.csr_matrix(v_features), rating_mx_train, train_labels, u_train_idx,
+            v_train_idx, val_labels, u_val_idx, v_val_idx, test_labels, u_test_idx, v_test_idx, class_values)
+
+
+# ------------------------------------------------------------------------------------------ synthetic ML
+def synth_ml(n_users, n_items, nnz, hist, seed=0):
+    """MovieLens-shaped bipartite rating list.
+
+    user activity ~ LogNormal(0,1), item popularity ~ LogNormal(0,1.6); user degree
+    ``clip(round(s*a_u), 20, 0.65*n_items)`` with ``s`` bisected so the degrees sum to ``nnz``; every user
+    draws that many distinct items with probability proportional to popularity (Gumbel top-k); ratings iid
+    from the real MovieLens histogram.  Returns (u, v, rating_value) in user-major order.
+    """
+    rng = np.random.default_rng(seed)
+    a = rng.lognormal(0.0, 1.0, n_users)
+    b = rng.lognormal(0.0, 1.6, n_items)
+    lo_d, hi_d = 20, int(0.65 * n_items)
+
+    def degs(s):
+        return np.clip(np.round(s * a), lo_d, hi_d).astype(np.int64)
+    lo, hi = 0.0, float(nnz)
+    for _ in range(100):
+        mid = 0.5 * (lo + hi)
+        if degs(mid).sum() < nnz:
+            lo = mid
+        else:
+            hi = mid
+    d = degs(hi)
+    diff = int(d.sum() - nnz)            # fix up to exactly nnz
+    order = rng.permutation(n_users)
+    k = 0
+    while diff != 0:
+        u = order[k % n_users]
+        k += 1
+        if diff > 0 and d[u] > lo_d:
+            d[u] -= 1
+            diff -= 1
+        elif diff < 0 and d[u] < hi_d:
+            d[u] += 1
+            diff += 1
+    logb = np.log(b)
+    us, vs = [], []
+    chunk = 512
+    for s in range(0, n_users, chunk):
+        e = min(n_users, s + chunk)
+        keys = logb[None, :] + rng.gumbel(size=(e - s, n_items))
+        rank = np.argsort(-keys, axis=1)
+        for i in range(s, e):
+            items = np.sort(rank[i - s, :d[i]])
+            us.append(np.full(d[i], i, np.int64))
+            vs.append(items.astype(np.int64))
+    u = np.concatenate(us)
+    v = np.concatenate(vs)
+    p = np.asarray(hist, np.float64)
+    p = p / p.sum()
+    r = rng.choice(np.arange(1, len(hist) + 1), size=len(u), p=p).astype(np.float64)
+    return u, v, r
+
+
+def _load_real_movielens(dataset):
+    """Real files when an operator provides them (plain parsers; ids remapped to 0..n-1)."""
+    if dataset == 'ml_1m':
+        p = _find_raw('ml_1m', 'ratings.dat')
+        if p is None:
+            return None
+        raw = np.loadtxt(p, delimiter=':', usecols=(0, 2, 4), dtype=np.int64)
+    elif dataset == 'ml_100k':
+        p = _find_raw('ml_100k', 'u.data')
+        if p is None:
+            return None
+        raw = np.loadtxt(p, usecols=(0, 1, 2), dtype=np.int64)
+    else:
+        return None
+    _, u = np.unique(raw[:, 0], return_inverse=True)
+    _, v = np.unique(raw[:, 1], return_inverse=True)
+    return u.astype(np.int64), v.astype(np.int64), raw[:, 2].astype(np.float64)
+
+
+def create_trainvaltest_split(dataset, seed=1234, testing=False, datasplit_path=None, datasplit_from_file=False,
+                              verbose=True, rating_map=None, post_rating_map=None, ratio=1.0, synth_seed=0):
+    """Random split with the reference's proportions (``preprocessing.py:159-197``): test = ceil(0.1 n),
+    val = ceil(0.9*0.05 n), the rest train; ``testing`` merges val into train.  Data = real MovieLens files if
+    present, else the synthetic generator (``data`` field of every report says which)."""
+    real = _load_real_movielens(dataset)
+    if real is not None:
+        u_nodes, v_nodes, ratings = real
+        num_users, num_items = int(u_nodes.max()) + 1, int(v_nodes.max()) + 1
+        source = 'real'
+    else:
+        if dataset not in ML_HIST:
+            raise FileNotFoundError('no raw data for %s and no synthetic spec' % dataset)
+        num_users, num_items, nnz, hist = ML_HIST[dataset]
+        u_nodes, v_nodes, ratings = synth_ml(num_users, num_items, nnz, hist, seed=synth_seed)
+        source = 'synthetic'
+    # the reference shuffles inside load_data (data_utils.py) with `seed`; same role here
+    perm = np.random.default_rng(seed).permutation(len(ratings))
+    u_nodes, v_nodes, ratings = u_nodes[perm], v_nodes[perm], ratings[perm]
+    if rating_map is not None:
+        ratings = np.array([rating_map[x] for x in ratings], dtype=np.float64)
+    class_values = np.sort(np.unique(ratings))
+    rating_dict = {r: i for i, r in enumerate(class_values.tolist())}
+    n = len(ratings)
+    num_test = int(np.ceil(n * 0.1))
+    num_val = int(np.ceil(n * 0.9 * 0.05))
+    num_train = n - num_val - num_test
+    all_labels = np.array([rating_dict[r] for r in ratings], dtype=np.int32)
+    ntr = int(num_train * ratio)
+    u_train_idx, v_train_idx, train_labels = u_nodes[:ntr], v_nodes[:ntr], all_labels[:ntr]
+    u_val_idx, v_val_idx, val_labels = (u_nodes[num_train:num_train + num_val], v_nodes[num_train:num_train + num_val],
+                                        all_labels[num_train:num_train + num_val])
+    u_test_idx, v_test_idx, test_labels = (u_nodes[num_train + num_val:], v_nodes[num_train + num_val:],
+                                           all_labels[num_train + num_val:])
+    if testing:
+        u_train_idx = np.hstack([u_train_idx, u_val_idx])
+        v_train_idx = np.hstack([v_train_idx, v_val_idx])
+        train_labels = np.hstack([train_labels, val_labels])
+    if post_rating_map is None:
+        data = train_labels + 1.
+    else:
+        data = np.array([post_rating_map[r] for r in class_values[train_labels]]) + 1.
+    rating_mx_train = sp.csr_matrix((data.astype(np.float32), (u_train_idx, v_train_idx)),
+                                    shape=[num_users, num_items], dtype=np.float32)
+    if verbose:
+        print('%s (%s): %d users, %d items, %d ratings, train %d / val %d / test %d' % (
+            dataset, source, num_users, num_items, n, len(train_labels), len(val_labels), len(test_labels)))
+    return (None, None, rating_mx_train, train_labels, u_train_idx, v_train_idx, val_labels, u_val_idx, v_val_idx,
+            test_labels, u_test_idx, v_test_idx, class_values)

@@ -1,0 +1,174 @@
+/* igmc_hip.h -- C ABI of libigmc_hip.so, the MI355X (gfx950) engine behind the IGMC hot path.
+ *
+ * The reference (muhanzhang/IGMC) has no FFI layer: its boundary is a Python call
+ * surface.  Every entry point below therefore cites the reference Python
+ * function(s) it replaces; the Python mirror in igmc_amd/{util_functions,models,
+ * train_eval}.py binds them with ctypes (see INTEGRATION.md for the stub).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; the message is
+ *     available from igmc_last_error() (thread-local).
+ *   - "d_" arguments are DEVICE pointers (HBM), "h_" arguments are HOST pointers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls
+ *     are asynchronous on that stream unless documented otherwise.
+ *   - handles own their HBM; borrowed buffers (parameters, gradients, outputs)
+ *     stay owned by the caller.
+ *   - no torch types anywhere in this interface.
+ */
+#ifndef IGMC_HIP_H
+#define IGMC_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct igmc_graph igmc_graph;   /* bipartite rating graph (CSR + CSC) resident in HBM */
+typedef struct igmc_batch igmc_batch;   /* one extracted + collated batch of enclosing subgraphs */
+typedef struct igmc_model igmc_model;   /* model geometry + activation / gradient workspace */
+
+#define IGMC_HIDDEN 32        /* latent_dim = [32,32,32,32]  (reference Main.py:391) */
+#define IGMC_NUM_LAYERS 4
+#define IGMC_LIN1_OUT 128     /* reference models.py:25 */
+
+const char* igmc_last_error(void);
+int igmc_version(void);
+
+/* ------------------------------------------------------------------ rating graph
+ * Replaces SparseRowIndexer / SparseColIndexer construction
+ * (reference util_functions.py:20-66, built in MyDataset/MyDynamicDataset.__init__
+ * :72-73, :116-117).  Input = scipy CSR of the training rating matrix whose stored
+ * values are rating-label + 1 (reference preprocessing.py:190-197); `h_rating`
+ * holds label+1 as uint8 (1..R).  Rows are re-sorted by (relation, id) on the host
+ * and both orientations are uploaded once. Synchronous. */
+int igmc_graph_create(int n_users, int n_items, int64_t nnz,
+                      const int32_t* h_indptr, const int32_t* h_indices, const uint8_t* h_rating,
+                      int device, igmc_graph** out);
+void igmc_graph_destroy(igmc_graph* g);
+int64_t igmc_graph_hbm_bytes(const igmc_graph* g);
+
+/* ------------------------------------------------------------------ batch arena
+ * Capacity is fixed at creation from (max_graphs, hop, max_nodes_per_hop) and the
+ * graph's sizes; nothing is allocated per step. */
+int igmc_batch_create(const igmc_graph* g, int max_graphs, int hop, int max_nodes_per_hop,
+                      igmc_batch** out);
+void igmc_batch_destroy(igmc_batch* b);
+
+/* Enclosing-subgraph extraction + labelling + collation for B links.
+ * Replaces MyDynamicDataset.get -> subgraph_extraction_labeling + construct_pyg_graph
+ * (reference util_functions.py:138-145, :208-297) and the PyG DataLoader collate
+ * (reference train_eval.py:44-51) for a whole batch, in HBM.
+ *   d_link_u/d_link_v/d_link_y : dataset-wide link arrays (user id, item id, rating VALUE
+ *                                class_values[label], reference :247)
+ *   d_link_idx                 : permutation of dataset positions; the batch is
+ *                                d_link_idx[first .. first+B-1]  (NULL = identity)
+ *   sample_ratio, max_nodes_per_hop(from create), hop : reference :222-229
+ *   seed, epoch                : counter-based sampler key (seed, epoch, link position, hop, side);
+ *                                a static dataset (MyDataset) passes a constant epoch.
+ */
+int igmc_extract_batch(const igmc_graph* g, igmc_batch* b,
+                       const int32_t* d_link_u, const int32_t* d_link_v, const float* d_link_y,
+                       const int32_t* d_link_idx, int first, int B,
+                       double sample_ratio, uint64_t seed, uint64_t epoch, void* stream);
+
+/* Parity mode: node sets are supplied (e.g. by the reference / oracle), only the
+ * induced-edge, labelling and collation stages run on the GPU.
+ *   h_unodes/h_vnodes : concatenated global ids, target first within each graph
+ *   h_udist/h_vdist   : hop distance per node;  h_uoff/h_voff : B+1 offsets.  Synchronous. */
+int igmc_extract_batch_replay(const igmc_graph* g, igmc_batch* b, int B,
+                              const int32_t* h_unodes, const uint8_t* h_udist, const int32_t* h_uoff,
+                              const int32_t* h_vnodes, const uint8_t* h_vdist, const int32_t* h_voff,
+                              const float* h_y, void* stream);
+
+/* Edge dropout (reference models.py:193-198 -> PyG dropout_adj): fills the per-entry keep
+ * flags (bit0: edge col->row kept, bit1: edge row->col kept) from a counter-based hash of
+ * (seed, step, graph, user id, item id, direction).  p = drop probability. */
+int igmc_batch_edge_dropout(igmc_batch* b, float p, int force_undirected,
+                            uint64_t seed, uint64_t step, void* stream);
+/* Parity mode: inject the flags (host array, one byte per CSR entry). Synchronous. */
+int igmc_batch_set_edge_flags(igmc_batch* b, const uint8_t* h_flags, int64_t n);
+int igmc_batch_clear_edge_flags(igmc_batch* b);   /* no dropout: every edge kept */
+
+/* Batch introspection (synchronises the stream; used by the Python Data view and tests). */
+typedef struct igmc_batch_info {
+  int32_t num_graphs, num_nodes, num_edges, overflow;
+  int32_t node_capacity, edge_capacity, num_labels, hop;
+} igmc_batch_info;
+int igmc_batch_get_info(const igmc_batch* b, igmc_batch_info* out, void* stream);
+/* Copies to host (any pointer may be NULL):
+ *  node_off[B+1], n_users[B], node_label[N](u8), node_gid[N], node_graph[N], row_ptr[N+1],
+ *  col[E], erel[E](u8), elab[E](u8), eflag[E](u8), y[B] */
+int igmc_batch_download(const igmc_batch* b, int32_t* node_off, int32_t* n_users, uint8_t* node_label,
+                        int32_t* node_gid, int32_t* node_graph, int32_t* row_ptr, int32_t* col,
+                        uint8_t* erel, uint8_t* elab, uint8_t* eflag, float* y, void* stream);
+/* Device pointers of the collated batch (for zero-copy views): index by IGMC_BUF_*. */
+enum { IGMC_BUF_NODE_OFF = 0, IGMC_BUF_N_USERS, IGMC_BUF_NODE_LABEL, IGMC_BUF_NODE_GID,
+       IGMC_BUF_NODE_GRAPH, IGMC_BUF_ROW_PTR, IGMC_BUF_COL, IGMC_BUF_EREL, IGMC_BUF_ECODE,
+       IGMC_BUF_EFLAG, IGMC_BUF_Y, IGMC_BUF_TOTALS, IGMC_BUF_COUNT };
+void* igmc_batch_device_ptr(const igmc_batch* b, int which);
+/* Optional side features of the two target nodes (reference util_functions.py:250-253,
+ * models.py:208-209): d_feat[B, n_side] fp32, borrowed for the next forward. */
+int igmc_batch_set_side_features(igmc_batch* b, const float* d_feat, int n_side);
+
+/* ------------------------------------------------------------------ model
+ * Flat fp32 parameter buffer layout (offsets in floats; query with igmc_param_offset):
+ *   for l in 0..3:  conv{l}.basis [Bs, Fin_l, 32]   conv{l}.root [Fin_l, 32]
+ *                   conv{l}.bias [32]               conv{l}.att [R, Bs]
+ *   lin1.weight [128, 256+n_side]  lin1.bias [128]  lin2.weight [1,128]  lin2.bias [1]
+ * with Fin_0 = 2*hop+2, Fin_l = 32.  Shapes = PyG-1.4.2 RGCNConv / torch.nn.Linear, i.e. the
+ * reference state_dict keys convs.{l}.{basis,att,root,bias}, lin1.*, lin2.* (Main.py:36-45). */
+enum { IGMC_P_BASIS = 0, IGMC_P_ROOT, IGMC_P_BIAS, IGMC_P_ATT,
+       IGMC_P_LIN1_W, IGMC_P_LIN1_B, IGMC_P_LIN2_W, IGMC_P_LIN2_B };
+int igmc_model_create(int device, int num_relations, int num_bases, int num_labels /*2*hop+2*/,
+                      int n_side_features, int max_nodes, int max_edges, int max_graphs,
+                      igmc_model** out);
+void igmc_model_destroy(igmc_model* m);
+int64_t igmc_param_count(const igmc_model* m);
+/* offset (floats) and element count of a tensor; layer is ignored for lin1/lin2. */
+int64_t igmc_param_offset(const igmc_model* m, int layer, int which, int64_t* count);
+
+/* IGMC.forward (reference models.py:190-217): 4x (RGCNConv + tanh), centre-node readout,
+ * lin1+ReLU+dropout(0.5)+lin2, * multiply_by.  Writes d_out[B].
+ *   training      : 0 = eval (no dropout), 1 = train
+ *   d_lin_mask    : optional injected keep-mask for the 0.5 dropout, uint8 [B,128] (parity);
+ *                   NULL = draw from the counter-based hash (seed, step)
+ *   use_edge_flags: 1 = honour the batch's edge keep flags (training with adj_dropout>0) */
+int igmc_model_forward(igmc_model* m, const float* d_params, const igmc_batch* b,
+                       int training, int use_edge_flags, const uint8_t* d_lin_mask,
+                       uint64_t seed, uint64_t step, float multiply_by,
+                       float* d_out, void* stream);
+/* Backward of the last igmc_model_forward(training=1) given d_gout[B] = dLoss/d_out.
+ * Accumulates nothing: d_grad (flat, same layout as params) is overwritten. */
+int igmc_model_backward(igmc_model* m, const float* d_params, const igmc_batch* b,
+                        const float* d_gout, float multiply_by, float* d_grad, void* stream);
+
+/* One optimisation step's loss + gradient (reference train_eval.py:158-175):
+ * forward, loss = mse_loss(out, y) (mean over the B graphs * loss_scale) + ARR * sum_l sum_r
+ * ||W_l[r+1]-W_l[r]||^2, backward.  d_loss[0] = loss, d_loss[1] = sum of squared errors.
+ * `grad_scale` multiplies the data-term gradient (1/B for the reference; 1/(global B) under
+ * data parallelism, where `arr_scale` = 1/world_size keeps the all-reduced ARR term exact). */
+int igmc_model_loss_grad(igmc_model* m, const float* d_params, const igmc_batch* b,
+                         int use_edge_flags, const uint8_t* d_lin_mask, uint64_t seed, uint64_t step,
+                         float multiply_by, float ARR, float grad_scale, float arr_scale,
+                         float* d_out, float* d_grad, float* d_loss, void* stream);
+
+/* Fused Adam over the flat buffer (reference train_eval.py:54,177: torch.optim.Adam,
+ * betas (0.9,0.999), eps 1e-8, weight_decay added to the gradient).  `step` is 1-based. */
+int igmc_adam_step(float* d_params, const float* d_grad, float* d_exp_avg, float* d_exp_avg_sq,
+                   int64_t n, int64_t step, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, void* stream);
+
+/* Eval reduction helper (reference train_eval.py:195): d_acc[0] += sum_g (out-y)^2, d_acc[1] += B. */
+int igmc_sse_accumulate(const float* d_out, const igmc_batch* b, double* d_acc, void* stream);
+
+/* Per-kernel timing of the last call (HIP events on the launch stream); names/ms arrays are
+ * filled up to `cap` (ms = total over `calls` launches of that kernel since the last fetch);
+ * returns the number of distinct kernels recorded, or <0 on error. */
+int igmc_profile_enable(int on);
+int igmc_profile_fetch(char names[][48], float* ms, int* calls, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IGMC_HIP_H */

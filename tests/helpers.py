@@ -1,0 +1,120 @@
+"""Shared helpers for the test-suite (host side only)."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import scipy.sparse as ssp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def emu_lib():
+    """Host emulation build of the HIP sources (kernel-logic tests only; never the product path)."""
+    from igmc_amd import _lib, build
+    path = build.build_emu()
+    return _lib.bind(ctypes.CDLL(path), path)
+
+
+def hand_graph():
+    """Known-answer graph #1 of SURVEY.md section 8(c)."""
+    return ssp.csr_matrix(np.array([[1, 2, 0, 5], [0, 3, 4, 0], [2, 0, 0, 1]], dtype=np.float32))
+
+
+def random_rating_graph(n_users, n_items, density, n_rel, seed):
+    rng = np.random.default_rng(seed)
+    mask = rng.random((n_users, n_items)) < density
+    vals = rng.integers(1, n_rel + 1, size=(n_users, n_items))
+    return ssp.csr_matrix((mask * vals).astype(np.float32))
+
+
+def batch_to_pyg(d, num_labels):
+    """Downloaded engine batch -> PyG-style arrays (x one-hot, edge_index [src;dst], edge_type, batch, y)."""
+    import torch
+    N = d['N']
+    dst = np.repeat(np.arange(N, dtype=np.int64), np.diff(d['row_ptr']).astype(np.int64))
+    src = d['col'].astype(np.int64)
+    x = np.zeros((N, num_labels), np.float32)
+    x[np.arange(N), d['node_label']] = 1.0
+
+    class B(object):
+        pass
+    b = B()
+    b.x = torch.from_numpy(x)
+    b.edge_index = torch.from_numpy(np.stack([src, dst], 0))
+    b.edge_type = torch.from_numpy(d['erel'].astype(np.int64))
+    b.batch = torch.from_numpy(d['node_graph'].astype(np.int64))
+    b.y = torch.from_numpy(d['y'].copy())
+    b.num_graphs = d['B']
+    return b
+
+
+def graph_canonical(d, g):
+    """Order-independent description of graph g of a downloaded batch:
+    (sorted user ids, sorted item ids, {gid: label}, sorted (u_gid, v_gid, rel) triples of the
+    user->item... both directions checked for symmetry)."""
+    lo, hi = d['node_off'][g], d['node_off'][g + 1]
+    nu = d['n_users'][g]
+    gid = d['node_gid']
+    lab = d['node_label']
+    users = gid[lo:lo + nu]
+    items = gid[lo + nu:hi]
+    fwd, bwd = [], []
+    for i in range(lo, hi):
+        for p in range(d['row_ptr'][i], d['row_ptr'][i + 1]):
+            c = d['col'][p]
+            assert lo <= c < hi, 'edge leaves its graph'
+            if i < lo + nu:      # dst is a user, src must be an item
+                assert c >= lo + nu
+                bwd.append((gid[i], gid[c], int(d['erel'][p])))
+            else:
+                assert c < lo + nu
+                fwd.append((gid[c], gid[i], int(d['erel'][p])))
+            assert d['elab'][p] == lab[c]
+    fwd.sort()
+    bwd.sort()
+    assert fwd == bwd, 'CSR is not symmetric'
+    ulab = {int(gid[i]): int(lab[i]) for i in range(lo, lo + nu)}
+    vlab = {int(gid[i]): int(lab[i]) for i in range(lo + nu, hi)}
+    return users, items, ulab, vlab, np.array(fwd, dtype=np.int64).reshape(-1, 3)
+
+
+# ------------------------------------------------------------------ golden fixtures
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def load_extract_golden():
+    """-> {case: dict(A csr, links, link_labels, class_values, h, sample_ratio, mnph, recs=[...])}"""
+    z = np.load(os.path.join(GOLDEN, 'extract_golden.npz'))
+    names = sorted(set(k.split('/')[0] for k in z.files))
+    out = {}
+    for n in names:
+        g = lambda k: z[n + '/' + k]
+        shape = tuple(int(x) for x in g('A_shape'))
+        A = ssp.csr_matrix((g('A_val').astype(np.float32), (g('A_row'), g('A_col'))), shape=shape)
+        h, ratio, mnph = g('params')
+        recs = []
+        for i in range(len(g('y'))):
+            rec = {}
+            for key in ('u_nodes', 'v_nodes', 'u', 'v', 'r', 'labels'):
+                off = g(key + '_off')
+                rec[key] = g(key)[off[i]:off[i + 1]]
+            rec['y'] = float(g('y')[i])
+            recs.append(rec)
+        out[n] = dict(A=A, links=g('links'), link_labels=g('link_labels'), class_values=g('class_values'),
+                      h=int(h), sample_ratio=float(ratio), mnph=None if mnph < 0 else int(mnph), recs=recs)
+    return out
+
+
+def golden_canonical(rec):
+    """Reference record -> (user ids, item ids, {uid: label}, {vid: label}, sorted (u,v,rel) triples)."""
+    un, vn = rec['u_nodes'], rec['v_nodes']
+    nu = len(un)
+    ulab = {int(g): int(l) for g, l in zip(un, rec['labels'][:nu])}
+    vlab = {int(g): int(l) for g, l in zip(vn, rec['labels'][nu:])}
+    t = np.stack([un[rec['u']], vn[rec['v'] - nu], rec['r']], 1).astype(np.int64) if len(rec['u']) else np.zeros((0, 3), np.int64)
+    if len(t):
+        t = t[np.lexsort((t[:, 2], t[:, 1], t[:, 0]))]
+    return un, vn, ulab, vlab, t
