@@ -52,8 +52,8 @@ SIGNATURES = {
     'igmc_profile_fetch': (i32, [vp, vp, vp, i32]),
 }
 
-BUF = dict(NODE_OFF=0, N_USERS=1, NODE_LABEL=2, NODE_GID=3, NODE_GRAPH=4, ROW_PTR=5, COL=6, EREL=7,
-           ECODE=8, EFLAG=9, Y=10, TOTALS=11)
+BUF = dict(NODE_OFF=0, N_USERS=1, NODE_LABEL=2, NODE_GID=3, NODE_GRAPH=4, ROW_PTR=5, ECR=6, ECODE=7,
+           EFLAG=8, Y=9, TOTALS=10)
 P = dict(BASIS=0, ROOT=1, BIAS=2, ATT=3, LIN1_W=4, LIN1_B=5, LIN2_W=6, LIN2_B=7)
 
 

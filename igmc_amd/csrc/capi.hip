@@ -221,7 +221,7 @@ extern "C" int igmc_batch_create(const igmc_graph* g, int max_graphs, int hop, i
   const int64_t node_cap = (int64_t)max_graphs * slot;
   const int64_t per_graph_e = std::min<int64_t>(2 * cap_u * cap_v, 2 * g->nnz);
   int64_t edge_cap = (int64_t)max_graphs * per_graph_e;
-  if (node_cap > (int64_t)INT_MAX / 64) IGMC_FAIL("node capacity exceeds int32 indexing");
+  if (node_cap >= (1 << 24)) IGMC_FAIL("node capacity exceeds the 24-bit source index of a CSR entry; lower the batch size");
   edge_cap = std::min<int64_t>(edge_cap, (int64_t)INT_MAX - 65536);
   if (g->max_rel * (2 * hop + 2) + (2 * hop + 1) > 65535) IGMC_FAIL("relation*label code exceeds uint16");
   igmc_batch* b = new igmc_batch();
@@ -237,7 +237,7 @@ extern "C" int igmc_batch_create(const igmc_graph* g, int max_graphs, int hop, i
           M.get(&d.edge_off, Bc + 1);
   fail |= M.get(&d.node_label, node_cap) | M.get(&d.node_gid, node_cap) | M.get(&d.node_graph, node_cap) |
           M.get(&d.row_ptr, node_cap + 1);
-  fail |= M.get(&d.col, edge_cap) | M.get(&d.erel, edge_cap) | M.get(&d.ecode, edge_cap) | M.get(&d.eflag, edge_cap);
+  fail |= M.get(&d.ecr, edge_cap) | M.get(&d.ecode, edge_cap) | M.get(&d.eflag, edge_cap);
   fail |= M.get(&d.y, Bc) | M.get(&d.totals, 8);
   fail |= M.get(&d.s_gid, Bc * slot) | M.get(&d.s_lab, Bc * slot) | M.get(&d.s_deg, Bc * slot) |
           M.get(&d.t_list, Bc * slot) | M.get(&d.t_dist, Bc * slot);
@@ -374,8 +374,14 @@ extern "C" int igmc_batch_download(const igmc_batch* b, int32_t* node_off, int32
   if (node_gid && N) HIPCHECK(hipMemcpy(node_gid, d.node_gid, N * 4, hipMemcpyDeviceToHost));
   if (node_graph && N) HIPCHECK(hipMemcpy(node_graph, d.node_graph, N * 4, hipMemcpyDeviceToHost));
   if (row_ptr) HIPCHECK(hipMemcpy(row_ptr, d.row_ptr, (N + 1) * 4, hipMemcpyDeviceToHost));
-  if (col && E) HIPCHECK(hipMemcpy(col, d.col, (size_t)E * 4, hipMemcpyDeviceToHost));
-  if (erel && E) HIPCHECK(hipMemcpy(erel, d.erel, E, hipMemcpyDeviceToHost));
+  if ((col || erel) && E) {
+    std::vector<uint32_t> ecr(E);
+    HIPCHECK(hipMemcpy(ecr.data(), d.ecr, (size_t)E * 4, hipMemcpyDeviceToHost));
+    for (int e = 0; e < E; ++e) {
+      if (col) col[e] = (int32_t)(ecr[e] & 0xFFFFFFu);
+      if (erel) erel[e] = (uint8_t)(ecr[e] >> 24);
+    }
+  }
   if (elab && E) {
     std::vector<uint16_t> code(E);
     HIPCHECK(hipMemcpy(code.data(), d.ecode, (size_t)E * 2, hipMemcpyDeviceToHost));
@@ -396,8 +402,7 @@ extern "C" void* igmc_batch_device_ptr(const igmc_batch* b, int which) {
     case IGMC_BUF_NODE_GID: return d.node_gid;
     case IGMC_BUF_NODE_GRAPH: return d.node_graph;
     case IGMC_BUF_ROW_PTR: return d.row_ptr;
-    case IGMC_BUF_COL: return d.col;
-    case IGMC_BUF_EREL: return d.erel;
+    case IGMC_BUF_ECR: return d.ecr;
     case IGMC_BUF_ECODE: return d.ecode;
     case IGMC_BUF_EFLAG: return d.eflag;
     case IGMC_BUF_Y: return d.y;

@@ -55,8 +55,7 @@ struct BatchDev {
   int32_t* node_gid;     // [Ncap]   original user / item id
   int32_t* node_graph;   // [Ncap]   PyG `batch` vector
   int32_t* row_ptr;      // [Ncap+1] dst-sorted CSR over all nodes of the batch
-  int32_t* col;          // [Ecap]   source node (batch-global index)
-  uint8_t* erel;         // [Ecap]   relation id
+  uint32_t* ecr;         // [Ecap]   source node (batch-global index, 24 bits) | relation id << 24
   uint16_t* ecode;       // [Ecap]   relation * num_labels + label(source)  (layer-0 table index)
   uint8_t* eflag;        // [Ecap]   bit0: edge col->row kept, bit1: edge row->col kept
   float* y;              // [Bcap]

@@ -18,9 +18,10 @@
 // selected set is one LDS word + one popcount; there are no atomics on floats and
 // no order-dependent writes, so the output is bit-reproducible.
 //
-// Kernels:  k_extract_nodes (BFS + per-hop sampling + induced-degree count)
+// Kernels:  k_extract_nodes (BFS + per-hop sampling -> node lists; one workgroup per link)
+//           k_count         (induced degree of every selected node; S workgroups per link)
 //           k_scan_offsets  (node / edge offsets of the collated batch)
-//           k_fill          (dst-sorted CSR of the batch, labels, PyG `batch` vector)
+//           k_fill          (dst-sorted CSR of the batch, labels, PyG `batch` vector; S per link)
 //           k_edge_flags    (edge dropout keep flags, reference models.py:193-198)
 #include "launch.h"
 
@@ -271,38 +272,73 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_extract_nodes(ExtractArgs a) {
   if (tid == 0) {
     a.b.n_users[g] = cu;
     a.b.n_items[g] = cv;
+    a.b.edge_cnt[g] = 0;
   }
-  __syncthreads();
-
-  // induced degrees: Arow[u_nodes][:, v_nodes] with the target entry removed (reference :236-238)
-  int etot = 0;
-  for (int li = wave; li < cu; li += IGMC_BLOCK / 64) {
-    const int id = sg[li];
-    const int beg = a.g.u_ptr[id], end = a.g.u_ptr[id + 1];
-    int c = 0;
-    for (int p = beg + lane; p < end; p += 64) {
-      const int j = a.g.u_idx[p];
-      c += (j == v0) ? (li != 0) : (int)bm_test(sel_v, j);
-    }
-    c = igmc_wave_sum_i(c);
-    if (lane == 0) { sd[li] = c; etot += c; }
-  }
-  for (int li = wave; li < cv; li += IGMC_BLOCK / 64) {
-    const int id = sg[cap_u + li];
-    const int beg = a.g.v_ptr[id], end = a.g.v_ptr[id + 1];
-    int c = 0;
-    for (int p = beg + lane; p < end; p += 64) {
-      const int j = a.g.v_idx[p];
-      c += (j == u0) ? (li != 0) : (int)bm_test(sel_u, j);
-    }
-    c = igmc_wave_sum_i(c);
-    if (lane == 0) { sd[cap_u + li] = c; etot += c; }
-  }
-  const int eg = igmc_block_sum_i(etot, sm);
-  if (tid == 0) a.b.edge_cnt[g] = eg;
 }
 
-// ---------------------------------------------------------------- kernel 2
+
+// ---------------------------------------------------------------- shared by k_count / k_fill
+// Rebuild the membership bitmaps of graph g from its node slot (ids by local index).
+__device__ void rebuild_sel(const int32_t* sg, int cap_u, int cu, int cv, uint32_t* sel_u, int Wu,
+                            uint32_t* sel_v, int Wv) {
+  bm_clear(sel_u, Wu);
+  bm_clear(sel_v, Wv);
+  __syncthreads();
+  for (int i = 1 + threadIdx.x; i < cu; i += IGMC_BLOCK) atomicOr(&sel_u[sg[i] >> 5], 1u << (sg[i] & 31));
+  for (int i = 1 + threadIdx.x; i < cv; i += IGMC_BLOCK) atomicOr(&sel_v[sg[cap_u + i] >> 5], 1u << (sg[cap_u + i] & 31));
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------- kernel 2: induced degrees
+// Arow[u_nodes][:, v_nodes] with the target entry removed (reference :236-238).  Row r of graph g
+// (users first, then items) is owned by exactly one wave: r = (blockIdx.y*4 + wave) mod (4*S).
+__global__ __launch_bounds__(IGMC_BLOCK) void k_count(GraphDev G, BatchDev b) {
+  IGMC_DYN_SMEM(smem);
+  const int g = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Wu = (G.n_users + 31) >> 5, Wv = (G.n_items + 31) >> 5;
+  uint32_t* sel_u = (uint32_t*)smem;
+  uint32_t* sel_v = sel_u + Wu;
+  const int cap_u = b.cap_u;
+  const size_t so = (size_t)g * b.slot;
+  const int32_t* sg = b.s_gid + so;
+  int32_t* sd = b.s_deg + so;
+  const int cu = b.n_users[g], cv = b.n_items[g];
+  const int u0 = sg[0], v0 = sg[cap_u];
+  rebuild_sel(sg, cap_u, cu, cv, sel_u, Wu, sel_v, Wv);
+  const int stride = gridDim.y * (IGMC_BLOCK / 64);
+  int etot = 0;
+  for (int r = blockIdx.y * (IGMC_BLOCK / 64) + wave; r < cu + cv; r += stride) {
+    const bool is_u = r < cu;
+    const int li = is_u ? r : r - cu;
+    const int id = sg[is_u ? li : cap_u + li];
+    const int32_t* ptr = is_u ? G.u_ptr : G.v_ptr;
+    const int32_t* idx = is_u ? G.u_idx : G.v_idx;
+    const uint32_t* sel = is_u ? sel_v : sel_u;
+    const int t0 = is_u ? v0 : u0;
+    const int beg = ptr[id], end = ptr[id + 1];
+    int c = 0;
+    for (int p0 = beg; p0 < end; p0 += 256) {
+      int j[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int p = p0 + q * 64 + lane;
+        j[q] = (p < end) ? idx[p] : -1;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (j[q] >= 0) c += (j[q] == t0) ? (li != 0) : (int)bm_test(sel, j[q]);
+    }
+    c = igmc_wave_sum_i(c);
+    if (lane == 0) {
+      sd[is_u ? li : cap_u + li] = c;
+      etot += c;
+    }
+  }
+  if (lane == 0 && etot) atomicAdd(&b.edge_cnt[g], etot);   // integer: order-independent
+}
+
+// ---------------------------------------------------------------- kernel 3
 __global__ __launch_bounds__(IGMC_BLOCK) void k_scan_offsets(BatchDev b, int B) {
   __shared__ int sm[16];
   int run_n = 0, run_e = 0;
@@ -334,7 +370,8 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_scan_offsets(BatchDev b, int B) 
   }
 }
 
-// ---------------------------------------------------------------- kernel 3
+// ---------------------------------------------------------------- kernel 4: CSR fill
+// Entry layout: ecr = source node (24 bits) | relation << 24 ;  ecode = relation*L + label(source).
 __global__ __launch_bounds__(IGMC_BLOCK) void k_fill(GraphDev G, BatchDev b) {
   IGMC_DYN_SMEM(smem);
   __shared__ int sm[16];
@@ -354,18 +391,17 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_fill(GraphDev G, BatchDev b) {
   const int cu = b.n_users[g], cv = b.n_items[g];
   const int nb = b.node_off[g], eb = b.edge_off[g];
   const int u0 = sg[0], v0 = sg[cap_u];
+  const int L = b.num_labels;
 
-  bm_clear(sel_u, Wu);
-  bm_clear(sel_v, Wv);
-  __syncthreads();
-  for (int i = 1 + tid; i < cu; i += IGMC_BLOCK) atomicOr(&sel_u[sg[i] >> 5], 1u << (sg[i] & 31));
-  for (int i = 1 + tid; i < cv; i += IGMC_BLOCK) atomicOr(&sel_v[sg[cap_u + i] >> 5], 1u << (sg[cap_u + i] & 31));
-  __syncthreads();
+  rebuild_sel(sg, cap_u, cu, cv, sel_u, Wu, sel_v, Wv);
   bm_prefix(sel_u, pre_u, Wu, sm);
   bm_prefix(sel_v, pre_v, Wv, sm);
 
-  // node arrays + CSR row pointers
+  // CSR row pointers (every block of the graph recomputes the scan; block y == 0 publishes it together
+  // with the node arrays).  Row starts of THIS block's rows are kept in registers via the same scan.
   const int nn = cu + cv;
+  const int stride = gridDim.y * (IGMC_BLOCK / 64);
+  const int my_first = blockIdx.y * (IGMC_BLOCK / 64) + wave;
   int running = 0;
   for (int base = 0; base < nn; base += IGMC_BLOCK) {
     const int n = base + tid;
@@ -374,57 +410,55 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_fill(GraphDev G, BatchDev b) {
     int tot;
     const int ex = igmc_block_scan_excl(deg, &tot, sm);
     if (n < nn) {
+      // rows handled by this block need their start: publish through global row_ptr (all blocks write the
+      // same value -> benign), node arrays only once
       b.row_ptr[nb + n] = eb + running + ex;
-      b.node_label[nb + n] = sl[s];
-      b.node_gid[nb + n] = sg[s];
-      b.node_graph[nb + n] = g;
+      if (blockIdx.y == 0) {
+        b.node_label[nb + n] = sl[s];
+        b.node_gid[nb + n] = sg[s];
+        b.node_graph[nb + n] = g;
+      }
     }
     running += tot;
   }
   __syncthreads();
 
-  // user rows: CSR row of the user intersected with the selected items
-  for (int li = wave; li < cu; li += IGMC_BLOCK / 64) {
-    const int id = sg[li];
-    const int beg = G.u_ptr[id], end = G.u_ptr[id + 1];
-    int o = b.row_ptr[nb + li];
-    for (int p0 = beg; p0 < end; p0 += 64) {
-      const int p = p0 + lane;
-      const bool valid = p < end;
-      const int j = valid ? G.u_idx[p] : 0;
-      const bool m = valid && ((j == v0) ? (li != 0) : bm_test(sel_v, j));
-      const unsigned long long bal = __ballot(m);
-      if (m) {
-        const int q = o + __popcll(bal & ((1ull << lane) - 1ull));
-        const int lv = (j == v0) ? 0 : 1 + bm_rank(sel_v, pre_v, j);
-        b.col[q] = nb + cu + lv;
-        b.erel[q] = G.u_rel[p];
-        b.ecode[q] = (uint16_t)((int)G.u_rel[p] * b.num_labels + (int)sl[cap_u + lv]);
-        b.eflag[q] = 3;
+  for (int r = my_first; r < nn; r += stride) {
+    const bool is_u = r < cu;            // user row: CSR row of the user  intersected with selected items
+    const int li = is_u ? r : r - cu;    // item row: CSC column of the item intersected with selected users
+    const int id = sg[is_u ? li : cap_u + li];
+    const int32_t* ptr = is_u ? G.u_ptr : G.v_ptr;
+    const int32_t* idx = is_u ? G.u_idx : G.v_idx;
+    const uint8_t* rel = is_u ? G.u_rel : G.v_rel;
+    const uint32_t* sel = is_u ? sel_v : sel_u;
+    const uint32_t* pre = is_u ? pre_v : pre_u;
+    const int t0 = is_u ? v0 : u0;
+    const int nbase = is_u ? nb + cu : nb;         // node index base of the neighbour side
+    const int sbase = is_u ? cap_u : 0;            // slot base of the neighbour side (labels)
+    const int beg = ptr[id], end = ptr[id + 1];
+    int o = b.row_ptr[nb + r];
+    for (int p0 = beg; p0 < end; p0 += 256) {
+      int j[4], rl[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int p = p0 + q * 64 + lane;
+        const bool valid = p < end;
+        j[q] = valid ? idx[p] : -1;
+        rl[q] = valid ? (int)rel[p] : 0;
       }
-      o += __popcll(bal);
-    }
-  }
-  // item rows: CSC column of the item intersected with the selected users
-  for (int li = wave; li < cv; li += IGMC_BLOCK / 64) {
-    const int id = sg[cap_u + li];
-    const int beg = G.v_ptr[id], end = G.v_ptr[id + 1];
-    int o = b.row_ptr[nb + cu + li];
-    for (int p0 = beg; p0 < end; p0 += 64) {
-      const int p = p0 + lane;
-      const bool valid = p < end;
-      const int j = valid ? G.v_idx[p] : 0;
-      const bool m = valid && ((j == u0) ? (li != 0) : bm_test(sel_u, j));
-      const unsigned long long bal = __ballot(m);
-      if (m) {
-        const int q = o + __popcll(bal & ((1ull << lane) - 1ull));
-        const int lu = (j == u0) ? 0 : 1 + bm_rank(sel_u, pre_u, j);
-        b.col[q] = nb + lu;
-        b.erel[q] = G.v_rel[p];
-        b.ecode[q] = (uint16_t)((int)G.v_rel[p] * b.num_labels + (int)sl[lu]);
-        b.eflag[q] = 3;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool m = (j[q] >= 0) && ((j[q] == t0) ? (li != 0) : bm_test(sel, j[q]));
+        const unsigned long long bal = __ballot(m);
+        if (m) {
+          const int pos = o + __popcll(bal & ((1ull << lane) - 1ull));
+          const int ln = (j[q] == t0) ? 0 : 1 + bm_rank(sel, pre, j[q]);
+          b.ecr[pos] = (uint32_t)(nbase + ln) | ((uint32_t)rl[q] << 24);
+          b.ecode[pos] = (uint16_t)(rl[q] * L + (int)sl[sbase + ln]);
+          b.eflag[pos] = 3;
+        }
+        o += __popcll(bal);
       }
-      o += __popcll(bal);
     }
   }
 }
@@ -442,7 +476,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_edge_flags(BatchDev b, float p, 
     const bool row_user = (b.node_label[i] & 1) == 0;
     const uint32_t gi = (uint32_t)b.node_gid[i], gr = (uint32_t)b.node_graph[i];
     for (int e = beg + t; e < end; e += 16) {
-      const uint32_t gc = (uint32_t)b.node_gid[b.col[e]];
+      const uint32_t gc = (uint32_t)b.node_gid[b.ecr[e] & 0xFFFFFFu];
       const uint32_t u = row_user ? gi : gc, v = row_user ? gc : gi;
       const uint32_t dirF = force_undirected ? 2u : (row_user ? 1u : 0u);   // col -> row
       const uint32_t dirT = force_undirected ? 2u : (row_user ? 0u : 1u);   // row -> col
@@ -472,9 +506,13 @@ void igmc_launch_extract(const GraphDev& g, const BatchDev& b, const int32_t* li
   a.first = first; a.B = B; a.replay = replay;
   a.sample_ratio = sample_ratio; a.seed = seed; a.epoch = epoch;
   const size_t smem = igmc_extract_smem_bytes(g);
+  // S workgroups per link for the row passes: fill the chip even at batch 50
+  int S = 2048 / (B > 0 ? B : 1);
+  S = S < 1 ? 1 : (S > 16 ? 16 : S);
   IGMC_PLAUNCH("k_extract_nodes", k_extract_nodes, B, IGMC_BLOCK, smem, stream, a);
+  IGMC_PLAUNCH("k_count", k_count, dim3(B, S), IGMC_BLOCK, smem / 4, stream, g, b);
   IGMC_PLAUNCH("k_scan_offsets", k_scan_offsets, 1, IGMC_BLOCK, 0, stream, b, B);
-  IGMC_PLAUNCH("k_fill", k_fill, B, IGMC_BLOCK, smem / 2, stream, g, b);
+  IGMC_PLAUNCH("k_fill", k_fill, dim3(B, S), IGMC_BLOCK, smem / 2, stream, g, b);
 }
 
 void igmc_launch_edge_flags(const BatchDev& b, float p, int force_undirected, uint64_t seed, uint64_t step,

@@ -4,7 +4,7 @@
 
 #define IGMC_KCAT 160     // (num_bases + 1) * 32 : [basis-space aggregate | self] width
 #define IGMC_WG_BLOCKS 128   // grid of the weight-gradient kernel (per-block partials)
-#define IGMC_GATHER_BLOCKS 1024
+#define IGMC_GATHER_BLOCKS 4096   // max grid of the row-walker kernels (4 rows = 4 waves per block)
 #define IGMC_L0_BLOCKS 256
 
 struct ModelDev {

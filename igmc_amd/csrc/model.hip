@@ -63,7 +63,15 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_prep(ModelDev m, const float* __
   }
 }
 
+// =================================================================== row walkers
+// One WAVE per destination row.  The row's CSR entries are consumed in chunks of 16: 16-lane group
+// `grp` of the wave owns chunks grp, grp+4, ...; lane t of the group loads entry c0+t (one coalesced
+// 64-byte index load per chunk) and the group then broadcasts entry k with a width-16 shuffle, so
+// 4 x 4 feature-row loads (128 B each, float2 per lane) are in flight per wave instruction.  The four
+// partial sums are combined with two xor-shuffles at the end of the row.
+
 // =================================================================== layer 0 forward (one-hot input)
+// h0[i] = tanh( sum_e W0[rel_e*L + label(src_e)] + root0[label_i] + bias0 )
 template <bool FLAGS>
 __global__ __launch_bounds__(IGMC_BLOCK) void k_l0_fwd(BatchDev b, ModelDev m, const float* __restrict__ P,
                                                          float* __restrict__ out) {
@@ -76,26 +84,35 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_l0_fwd(BatchDev b, ModelDev m, c
   if (threadIdx.x < 32) sbias[threadIdx.x] = P[m.off_bias[0] + threadIdx.x];
   __syncthreads();
   const int N = b.totals[0];
-  const int grp = threadIdx.x >> 4, t = threadIdx.x & 15;
-  for (int tile = blockIdx.x; tile * 16 < N; tile += gridDim.x) {
-    const int i = tile * 16 + grp;
-    if (i >= N) continue;
-    const int lab = b.node_label[i];
-    float ax = sbias[2 * t] + sroot[lab * 32 + 2 * t];
-    float ay = sbias[2 * t + 1] + sroot[lab * 32 + 2 * t + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = lane >> 4, t = lane & 15;
+  for (int i = blockIdx.x * 4 + wave; i < N; i += gridDim.x * 4) {
+    float ax = 0.f, ay = 0.f;
     const int beg = b.row_ptr[i], end = b.row_ptr[i + 1];
-    for (int e = beg; e < end; ++e) {
-      const int code = b.ecode[e];
-      const bool keep = !FLAGS || (b.eflag[e] & 1);
-      if (keep) {
-        ax += sW0[code * 32 + 2 * t];
-        ay += sW0[code * 32 + 2 * t + 1];
+    for (int c0 = beg + grp * 16; c0 < end; c0 += 64) {
+      const int e = c0 + t;
+      int w = -1;                              // code, or -1 = skip
+      if (e < end && (!FLAGS || (b.eflag[e] & 1))) w = b.ecode[e];
+      const int n = (end - c0 < 16) ? end - c0 : 16;
+      for (int k = 0; k < n; ++k) {
+        const int code = __shfl(w, k, 16);
+        if (code >= 0) {
+          ax += sW0[code * 32 + 2 * t];
+          ay += sW0[code * 32 + 2 * t + 1];
+        }
       }
     }
-    float2 o;
-    o.x = tanhf(ax);
-    o.y = tanhf(ay);
-    *(float2*)(out + (size_t)i * 32 + 2 * t) = o;
+    ax += __shfl_xor(ax, 16, 64);
+    ay += __shfl_xor(ay, 16, 64);
+    ax += __shfl_xor(ax, 32, 64);
+    ay += __shfl_xor(ay, 32, 64);
+    if (grp == 0) {
+      const int lab = b.node_label[i];
+      float2 o;
+      o.x = tanhf(ax + sbias[2 * t] + sroot[lab * 32 + 2 * t]);
+      o.y = tanhf(ay + sbias[2 * t + 1] + sroot[lab * 32 + 2 * t + 1]);
+      *(float2*)(out + (size_t)i * 32 + 2 * t) = o;
+    }
   }
 }
 
@@ -116,11 +133,11 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_gather(BatchDev b, int R, c
     for (int i = threadIdx.x; i < 16 * R * 4; i += IGMC_BLOCK) s_gatt[i] = 0.f;
   __syncthreads();
   const int N = b.totals[0];
-  const int grp = threadIdx.x >> 4, t = threadIdx.x & 15;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = lane >> 4, t = lane & 15;
   const int kbit = TRANS ? 1 : 0;
-  for (int tile = blockIdx.x; tile * 16 < N; tile += gridDim.x) {
-    const int i = tile * 16 + grp;
-    if (i >= N) continue;
+  float* my_gatt = s_gatt + (wave * 4 + grp) * R * 4;
+  for (int i = blockIdx.x * 4 + wave; i < N; i += gridDim.x * 4) {
     float ax[4] = {0.f, 0.f, 0.f, 0.f}, ay[4] = {0.f, 0.f, 0.f, 0.f};
     float yx[4], yy[4];
     float tx = 0.f, ty = 0.f;
@@ -134,50 +151,56 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_gather(BatchDev b, int R, c
       }
     }
     const int beg = b.row_ptr[i], end = b.row_ptr[i + 1];
-    for (int e0 = beg; e0 < end; e0 += 4) {
-      int c[4], r[4];
-      bool k[4];
-      float2 x[4];
+    for (int c0 = beg + grp * 16; c0 < end; c0 += 64) {
+      const int e = c0 + t;
+      const bool ok = e < end;
+      const uint32_t w = ok ? b.ecr[e] : 0u;
+      int kp = ok ? 1 : 0;
+      if (FLAGS && ok) kp = (b.eflag[e] >> kbit) & 1;
+      const int n = (end - c0 < 16) ? end - c0 : 16;
+      for (int k0 = 0; k0 < n; k0 += 4) {
+        uint32_t wk[4];
+        int kk[4];
+        float2 x[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int e = e0 + q;
-        const bool ok = e < end;
-        c[q] = ok ? b.col[e] : 0;
-        r[q] = ok ? (int)b.erel[e] : 0;
-        k[q] = ok && (!FLAGS || ((b.eflag[e] >> kbit) & 1));
-      }
+        for (int q = 0; q < 4; ++q) {
+          wk[q] = __shfl(w, k0 + q, 16);
+          kk[q] = __shfl(kp, k0 + q, 16);
+        }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (k[q]) x[q] = *(const float2*)(in + (size_t)c[q] * 32 + 2 * t);
-        else { x[q].x = 0.f; x[q].y = 0.f; }
-      }
+        for (int q = 0; q < 4; ++q) {
+          if (kk[q]) x[q] = *(const float2*)(in + (size_t)(wk[q] & 0xFFFFFFu) * 32 + 2 * t);
+          else { x[q].x = 0.f; x[q].y = 0.f; }
+        }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (!ATTG) {
-          const float* a = s_att + r[q] * 4;
+        for (int q = 0; q < 4; ++q) {
+          const int r = (int)(wk[q] >> 24);
+          if (!ATTG) {
+            const float* a = s_att + r * 4;
 #pragma unroll
-          for (int bb = 0; bb < 4; ++bb) {
-            ax[bb] += a[bb] * x[q].x;
-            ay[bb] += a[bb] * x[q].y;
-          }
-        } else if (k[q]) {
-          if (r[q] != cur) {
-            if (cur >= 0) {   // flush the finished relation run
-              const float* a = s_att + cur * 4;
-#pragma unroll
-              for (int bb = 0; bb < 4; ++bb) {
-                ax[bb] += a[bb] * tx;
-                ay[bb] += a[bb] * ty;
-                const float p = igmc_group16_sum_f(yx[bb] * tx + yy[bb] * ty);
-                if (t == 0) s_gatt[grp * R * 4 + cur * 4 + bb] += p;
-              }
+            for (int bb = 0; bb < 4; ++bb) {
+              ax[bb] += a[bb] * x[q].x;
+              ay[bb] += a[bb] * x[q].y;
             }
-            cur = r[q];
-            tx = 0.f;
-            ty = 0.f;
+          } else if (kk[q]) {
+            if (r != cur) {
+              if (cur >= 0) {   // flush the finished relation run
+                const float* a = s_att + cur * 4;
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                  ax[bb] += a[bb] * tx;
+                  ay[bb] += a[bb] * ty;
+                  const float p = igmc_group16_sum_f(yx[bb] * tx + yy[bb] * ty);
+                  if (t == 0) my_gatt[cur * 4 + bb] += p;
+                }
+              }
+              cur = r;
+              tx = 0.f;
+              ty = 0.f;
+            }
+            tx += x[q].x;
+            ty += x[q].y;
           }
-          tx += x[q].x;
-          ty += x[q].y;
         }
       }
     }
@@ -188,15 +211,24 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_gather(BatchDev b, int R, c
         ax[bb] += a[bb] * tx;
         ay[bb] += a[bb] * ty;
         const float p = igmc_group16_sum_f(yx[bb] * tx + yy[bb] * ty);
-        if (t == 0) s_gatt[grp * R * 4 + cur * 4 + bb] += p;
+        if (t == 0) my_gatt[cur * 4 + bb] += p;
       }
     }
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) {
-      float2 o;
-      o.x = ax[bb];
-      o.y = ay[bb];
-      *(float2*)(out + (size_t)i * 128 + bb * 32 + 2 * t) = o;
+      ax[bb] += __shfl_xor(ax[bb], 16, 64);
+      ay[bb] += __shfl_xor(ay[bb], 16, 64);
+      ax[bb] += __shfl_xor(ax[bb], 32, 64);
+      ay[bb] += __shfl_xor(ay[bb], 32, 64);
+    }
+    if (grp == 0) {
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        float2 o;
+        o.x = ax[bb];
+        o.y = ay[bb];
+        *(float2*)(out + (size_t)i * 128 + bb * 32 + 2 * t) = o;
+      }
     }
   }
   if (ATTG) {
@@ -345,7 +377,8 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_wgrad(BatchDev b, const float* _
 
 // =================================================================== layer 0 backward
 // table[code] += dPre0[dst]  for every kept edge (code = rel*L + label(src)); extra rows:
-// R*L + label(i) (d root0) and R*L + L (d bias0).  PRIVATE: one table per 16-lane group.
+// R*L + label(i) (d root0) and R*L + L (d bias0).  PRIVATE: one table per 16-lane group
+// (plain read-modify-write, bit-reproducible); otherwise one table per block with LDS float atomics.
 template <bool FLAGS, bool PRIVATE>
 __global__ __launch_bounds__(IGMC_BLOCK) void k_l0_bwd(BatchDev b, ModelDev m, const float* __restrict__ dpre,
                                                          float* __restrict__ part) {
@@ -356,51 +389,55 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_l0_bwd(BatchDev b, ModelDev m, c
   for (int i = threadIdx.x; i < ntab * rows * 32; i += IGMC_BLOCK) tab[i] = 0.f;
   __syncthreads();
   const int N = b.totals[0];
-  const int grp = threadIdx.x >> 4, t = threadIdx.x & 15;
-  float* my = tab + (PRIVATE ? grp * rows * 32 : 0);
-  for (int tile = blockIdx.x; tile * 16 < N; tile += gridDim.x) {
-    const int i = tile * 16 + grp;
-    if (i >= N) continue;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = lane >> 4, t = lane & 15;
+  float* my = tab + (PRIVATE ? (wave * 4 + grp) * rows * 32 : 0);
+  for (int i = blockIdx.x * 4 + wave; i < N; i += gridDim.x * 4) {
     const float2 d = *(const float2*)(dpre + (size_t)i * 32 + 2 * t);
     const int beg = b.row_ptr[i], end = b.row_ptr[i + 1];
-    const int lab = b.node_label[i];
-    if (PRIVATE) {
-      // consecutive edges often share the code (rows are relation-sorted): count, then one update
-      int cur = -1, cnt = 0;
-      for (int e = beg; e < end; ++e) {
-        const bool keep = !FLAGS || (b.eflag[e] & 1);
-        if (!keep) continue;
-        const int code = b.ecode[e];
-        if (code != cur) {
-          if (cur >= 0) {
-            my[cur * 32 + 2 * t] += cnt * d.x;
-            my[cur * 32 + 2 * t + 1] += cnt * d.y;
+    int cur = -1, cnt = 0;
+    for (int c0 = beg + grp * 16; c0 < end; c0 += 64) {
+      const int e = c0 + t;
+      int w = -1;
+      if (e < end && (!FLAGS || (b.eflag[e] & 1))) w = b.ecode[e];
+      const int n = (end - c0 < 16) ? end - c0 : 16;
+      for (int k = 0; k < n; ++k) {
+        const int code = __shfl(w, k, 16);
+        if (code < 0) continue;
+        if (PRIVATE) {
+          // consecutive edges often share the code (rows are relation-sorted): count, then one update
+          if (code != cur) {
+            if (cur >= 0) {
+              my[cur * 32 + 2 * t] += cnt * d.x;
+              my[cur * 32 + 2 * t + 1] += cnt * d.y;
+            }
+            cur = code;
+            cnt = 0;
           }
-          cur = code;
-          cnt = 0;
+          ++cnt;
+        } else {
+          atomicAdd(&my[code * 32 + 2 * t], d.x);
+          atomicAdd(&my[code * 32 + 2 * t + 1], d.y);
         }
-        ++cnt;
       }
-      if (cur >= 0) {
-        my[cur * 32 + 2 * t] += cnt * d.x;
-        my[cur * 32 + 2 * t + 1] += cnt * d.y;
+    }
+    if (PRIVATE && cur >= 0) {
+      my[cur * 32 + 2 * t] += cnt * d.x;
+      my[cur * 32 + 2 * t + 1] += cnt * d.y;
+    }
+    if (grp == 0) {     // d root0[label_i] and d bias0: once per row
+      const int lab = b.node_label[i];
+      if (PRIVATE) {
+        my[(m.R * m.L + lab) * 32 + 2 * t] += d.x;
+        my[(m.R * m.L + lab) * 32 + 2 * t + 1] += d.y;
+        my[(m.R * m.L + m.L) * 32 + 2 * t] += d.x;
+        my[(m.R * m.L + m.L) * 32 + 2 * t + 1] += d.y;
+      } else {
+        atomicAdd(&my[(m.R * m.L + lab) * 32 + 2 * t], d.x);
+        atomicAdd(&my[(m.R * m.L + lab) * 32 + 2 * t + 1], d.y);
+        atomicAdd(&my[(m.R * m.L + m.L) * 32 + 2 * t], d.x);
+        atomicAdd(&my[(m.R * m.L + m.L) * 32 + 2 * t + 1], d.y);
       }
-      my[(m.R * m.L + lab) * 32 + 2 * t] += d.x;
-      my[(m.R * m.L + lab) * 32 + 2 * t + 1] += d.y;
-      my[(m.R * m.L + m.L) * 32 + 2 * t] += d.x;
-      my[(m.R * m.L + m.L) * 32 + 2 * t + 1] += d.y;
-    } else {
-      for (int e = beg; e < end; ++e) {
-        const bool keep = !FLAGS || (b.eflag[e] & 1);
-        if (!keep) continue;
-        const int code = b.ecode[e];
-        atomicAdd(&my[code * 32 + 2 * t], d.x);
-        atomicAdd(&my[code * 32 + 2 * t + 1], d.y);
-      }
-      atomicAdd(&my[(m.R * m.L + lab) * 32 + 2 * t], d.x);
-      atomicAdd(&my[(m.R * m.L + lab) * 32 + 2 * t + 1], d.y);
-      atomicAdd(&my[(m.R * m.L + m.L) * 32 + 2 * t], d.x);
-      atomicAdd(&my[(m.R * m.L + m.L) * 32 + 2 * t + 1], d.y);
     }
   }
   __syncthreads();
@@ -518,25 +555,46 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_head_bwd_w(BatchDev b, ModelDev 
 
 // =================================================================== partial reduction + finalize
 // graw layout: [3][5152] conv1..3 (32x160 + 32) | [3][R*4] d att | [(R*L+L+1)*32] layer-0 table
-__global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_partials(ModelDev m) {
+// Sections A (weight-gradient partials) and C (layer-0 tables): 64 outputs x 4 partial-slices per block;
+// section B (d att, few outputs x many partials): one wave per output.  Fixed summation order.
+__global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_partials(ModelDev m, int n_gatt_parts) {
+  __shared__ float sred[4][64];
   const int wgs = 32 * IGMC_KCAT + 32, na = m.R * 4, n0 = (m.R * m.L + m.L + 1) * 32;
-  const int total = 3 * wgs + 3 * na + n0;
-  for (int idx = blockIdx.x * IGMC_BLOCK + threadIdx.x; idx < total; idx += gridDim.x * IGMC_BLOCK) {
+  const int nblkA = (3 * wgs + 63) / 64, nblkB = (3 * na + 3) / 4, nblkC = (n0 + 63) / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int blk = blockIdx.x;
+  if (blk < nblkA + nblkC) {
+    const bool secA = blk < nblkA;
+    const int o = (secA ? blk : blk - nblkA) * 64 + lane;
+    const int nout = secA ? 3 * wgs : n0;
     float s = 0.f;
-    if (idx < 3 * wgs) {
-      const int l = idx / wgs, i = idx % wgs;
-      const float* p = m.wg_part + (size_t)l * IGMC_WG_BLOCKS * wgs + i;
-      for (int k = 0; k < IGMC_WG_BLOCKS; ++k) s += p[(size_t)k * wgs];
-    } else if (idx < 3 * wgs + 3 * na) {
-      const int q = idx - 3 * wgs, l = q / na, i = q % na;
-      const float* p = m.gatt_part + (size_t)l * IGMC_GATHER_BLOCKS * na + i;
-      for (int k = 0; k < IGMC_GATHER_BLOCKS; ++k) s += p[(size_t)k * na];
-    } else {
-      const int i = idx - 3 * wgs - 3 * na;
-      const float* p = m.l0_part + i;
-      for (int k = 0; k < IGMC_L0_BLOCKS; ++k) s += p[(size_t)k * n0];
+    if (o < nout) {
+      if (secA) {
+        const int l = o / wgs, i = o % wgs;
+        const float* p = m.wg_part + (size_t)l * IGMC_WG_BLOCKS * wgs + i;
+        for (int k = wave; k < IGMC_WG_BLOCKS; k += 4) s += p[(size_t)k * wgs];
+      } else {
+        const float* p = m.l0_part + o;
+        for (int k = wave; k < IGMC_L0_BLOCKS; k += 4) s += p[(size_t)k * n0];
+      }
     }
-    m.graw[idx] = s;
+    sred[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && o < nout) {
+      const float tot = (sred[0][lane] + sred[1][lane]) + (sred[2][lane] + sred[3][lane]);
+      m.graw[secA ? o : 3 * wgs + 3 * na + o] = tot;
+    }
+  } else {
+    blk -= nblkA + nblkC;
+    const int o = blk * 4 + wave;
+    if (o < 3 * na && blk < nblkB) {
+      const int l = o / na, i = o % na;
+      const float* p = m.gatt_part + (size_t)l * IGMC_GATHER_BLOCKS * na + i;
+      float s = 0.f;
+      for (int k = lane; k < n_gatt_parts; k += 64) s += p[(size_t)k * na];
+      s = igmc_wave_sum_f(s);
+      if (lane == 0) m.graw[3 * wgs + o] = s;
+    }
   }
 }
 
@@ -712,7 +770,7 @@ void igmc_launch_forward(const ModelDev& m, const BatchDev& b, const float* P, i
                          float* out, void* stream) {
   IGMC_PLAUNCH("k_prep", k_prep, 64, IGMC_BLOCK, 0, stream, m, P, training);
   const size_t l0s = (size_t)(m.R * m.L * 32 + m.L * 32 + 32) * sizeof(float);
-  const int g16 = igmc_rows_grid(m.node_cap, 16, IGMC_GATHER_BLOCKS);
+  const int g16 = igmc_rows_grid(m.node_cap, 4, IGMC_GATHER_BLOCKS);   // one wave per row, 4 rows per block
   const int g64 = igmc_rows_grid(m.node_cap, 64, 512);
   if (use_flags) IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<true>), g16, IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
   else IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<false>), g16, IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
@@ -737,7 +795,7 @@ void igmc_launch_forward(const ModelDev& m, const BatchDev& b, const float* P, i
 void igmc_launch_backward(const ModelDev& m, const BatchDev& b, const float* P, int B, int use_flags,
                           const float* gout, int from_err, float grad_scale, float mult, float drop_scale,
                           float arr_coef, float* grad, void* stream) {
-  const int g16 = igmc_rows_grid(m.node_cap, 16, IGMC_GATHER_BLOCKS);
+  const int g16 = igmc_rows_grid(m.node_cap, 4, IGMC_GATHER_BLOCKS);
   const int g64 = igmc_rows_grid(m.node_cap, 64, 512);
   IGMC_PLAUNCH("k_zero_rows", k_zero_rows, 256, IGMC_BLOCK, 0, stream, b, m.dpre[1], 32);
   IGMC_PLAUNCH("k_head_bwd_a", k_head_bwd_a, B, 128, 0, stream, b, m, P, gout, from_err, grad_scale, mult,
@@ -756,12 +814,11 @@ void igmc_launch_backward(const ModelDev& m, const BatchDev& b, const float* P, 
                  (const float*)nullptr, (const float*)m.h[l - 1], (const float*)m.bcat[l], (const float*)nullptr, m.Y,
                  (const float*)nullptr, (const float*)nullptr, 0, 0);
     float* gp = m.gatt_part + (size_t)(l - 1) * IGMC_GATHER_BLOCKS * na;
-    // every block of the partial grid must write its slot -> launch the full partial grid
     if (use_flags)
-      IGMC_PLAUNCH("k_rgcn_gather_bwd", (k_rgcn_gather<true, true, true>), IGMC_GATHER_BLOCKS, IGMC_BLOCK, gsa, stream,
+      IGMC_PLAUNCH("k_rgcn_gather_bwd", (k_rgcn_gather<true, true, true>), g16, IGMC_BLOCK, gsa, stream,
                    b, m.R, (const float*)dcur, P + m.off_att[l], m.agg, (const float*)m.Y, gp);
     else
-      IGMC_PLAUNCH("k_rgcn_gather_bwd", (k_rgcn_gather<false, true, true>), IGMC_GATHER_BLOCKS, IGMC_BLOCK, gsa, stream,
+      IGMC_PLAUNCH("k_rgcn_gather_bwd", (k_rgcn_gather<false, true, true>), g16, IGMC_BLOCK, gsa, stream,
                    b, m.R, (const float*)dcur, P + m.off_att[l], m.agg, (const float*)m.Y, gp);
     IGMC_PLAUNCH("k_dense_bwd", (k_dense<128, 32, 32, EPI_BWD>), g64, IGMC_BLOCK, ds, stream, b, (const float*)m.agg,
                  (const float*)dcur, (const float*)m.wT[l], (const float*)nullptr, dnext, (const float*)m.h[l - 1],
@@ -780,7 +837,11 @@ void igmc_launch_backward(const ModelDev& m, const BatchDev& b, const float* P, 
     if (priv) IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<false, true>), IGMC_L0_BLOCKS, IGMC_BLOCK, l0s, stream, b, m, d0, m.l0_part);
     else IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<false, false>), IGMC_L0_BLOCKS, IGMC_BLOCK, l0s, stream, b, m, d0, m.l0_part);
   }
-  IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, 64, IGMC_BLOCK, 0, stream, m);
+  {
+    const int wgs2 = igmc_wg_stride(), n0 = rows0 * 32;
+    const int nblk = (3 * wgs2 + 63) / 64 + (n0 + 63) / 64 + (3 * na + 3) / 4;
+    IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk, IGMC_BLOCK, 0, stream, m, g16);
+  }
   IGMC_PLAUNCH("k_finalize", k_finalize, 4, IGMC_BLOCK, 0, stream, m, P, grad, arr_coef);
 }
 

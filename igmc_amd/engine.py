@@ -224,6 +224,13 @@ class ModelWorkspace(object):
             pass
 
 
+def adam_step(lib, params, grad, exp_avg, exp_avg_sq, n, step, lr, beta1=0.9, beta2=0.999, eps=1e-8,
+              weight_decay=0.0, stream=None):
+    """Fused Adam over a flat buffer (no model workspace needed)."""
+    lib.call('igmc_adam_step', _p(params), _p(grad), _p(exp_avg), _p(exp_avg_sq), int(n), int(step), float(lr),
+             float(beta1), float(beta2), float(eps), float(weight_decay), _p(stream))
+
+
 def profile_enable(lib, on):
     lib.igmc_profile_enable(int(bool(on)))
 

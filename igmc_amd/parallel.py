@@ -1,0 +1,76 @@
+"""Data parallelism over the GPUs of one node: one process per GPU, ``torch.distributed`` with the
+``nccl`` backend (= RCCL over xGMI on ROCm); ``gloo`` for the CPU-side tests of the host logic.
+
+The reference has no distributed code (single process, single device: ``train_eval.py:20``).  The hot path
+shards by LINKS: the rating graph (~9 MB) and the 197 KB parameter / optimiser state are replicated, rank k
+takes ``perm[k::G]`` of the (identical) epoch permutation, extracts and trains its own batches, and the only
+exchange is ONE all-reduce of the single flat gradient buffer per step (latency-bound at 197 KB, so never one
+call per tensor) followed by the identical fused Adam on every rank.  Evaluation all-reduces (sum of squared
+errors, count) once.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized()
+
+
+def rank():
+    return dist.get_rank() if is_dist() else 0
+
+
+def world_size():
+    return dist.get_world_size() if is_dist() else 1
+
+
+def init_from_env(backend=None):
+    """Initialise from torchrun's environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*); no-op for 1 process."""
+    ws = int(os.environ.get('WORLD_SIZE', '1'))
+    if ws <= 1 or is_dist():
+        return rank(), world_size()
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    local = int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0')))
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend == 'nccl':
+        torch.cuda.set_device(local)
+    dist.init_process_group(backend=backend, rank=int(os.environ['RANK']), world_size=ws)
+    return rank(), world_size()
+
+
+def shard_positions(perm, rank_, world, pad=True):
+    """Rank ``rank_``'s share ``perm[rank_::world]`` of a permutation (any indexable 1-D tensor/array).
+    ``pad``: wrap around so that every rank gets ceil(n/world) items (equal step counts -> no collective
+    mismatch during training); evaluation uses ``pad=False`` so nothing is counted twice."""
+    n = len(perm)
+    if world <= 1:
+        return perm
+    mine = perm[rank_::world]
+    if pad:
+        per = (n + world - 1) // world
+        if len(mine) < per:
+            mine = torch.cat([mine, perm[:per - len(mine)]]) if torch.is_tensor(mine) else \
+                type(perm)(list(mine) + list(perm[:per - len(mine)]))
+    return mine
+
+
+def all_reduce_sum_(t):
+    """In-place sum over ranks of ONE flat tensor (the gradient buffer / the eval accumulators)."""
+    if is_dist() and world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def barrier():
+    if is_dist() and world_size() > 1:
+        dist.barrier()
+
+
+def broadcast_(t, src=0):
+    if is_dist() and world_size() > 1:
+        dist.broadcast(t, src=src)
+    return t

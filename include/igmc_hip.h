@@ -104,7 +104,7 @@ int igmc_batch_download(const igmc_batch* b, int32_t* node_off, int32_t* n_users
                         uint8_t* erel, uint8_t* elab, uint8_t* eflag, float* y, void* stream);
 /* Device pointers of the collated batch (for zero-copy views): index by IGMC_BUF_*. */
 enum { IGMC_BUF_NODE_OFF = 0, IGMC_BUF_N_USERS, IGMC_BUF_NODE_LABEL, IGMC_BUF_NODE_GID,
-       IGMC_BUF_NODE_GRAPH, IGMC_BUF_ROW_PTR, IGMC_BUF_COL, IGMC_BUF_EREL, IGMC_BUF_ECODE,
+       IGMC_BUF_NODE_GRAPH, IGMC_BUF_ROW_PTR, IGMC_BUF_ECR, IGMC_BUF_ECODE,
        IGMC_BUF_EFLAG, IGMC_BUF_Y, IGMC_BUF_TOTALS, IGMC_BUF_COUNT };
 void* igmc_batch_device_ptr(const igmc_batch* b, int which);
 /* Optional side features of the two target nodes (reference util_functions.py:250-253,

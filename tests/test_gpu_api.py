@@ -1,0 +1,203 @@
+"""The reference-shaped Python surface on a real MI355X: datasets, IGMC module, train/eval loops, checkpoints,
+the differentiable forward, and RMSE parity of a fixed checkpoint against the oracle (tolerance 1e-4, the
+north_star's bar, on identical inputs)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from helpers import batch_to_pyg, load_extract_golden
+
+pytestmark = pytest.mark.gpu
+CASES = load_extract_golden()
+
+
+@pytest.fixture(scope='module')
+def flix():
+    import torch
+    assert torch.cuda.is_available()
+    from igmc_amd import preprocessing
+    return preprocessing.load_data_monti('flixster', testing=True)
+
+
+def make_sets(split, ntr=600, nte=300, dynamic=True, mnph=10000):
+    from igmc_amd.util_functions import MyDataset, MyDynamicDataset
+    (uf, vf, adj, trl, tru, trv, _, _, _, tel, teu, tev, cv) = split
+    cls = MyDynamicDataset if dynamic else MyDataset
+    tr = cls('data/t/train', adj, (tru[:ntr], trv[:ntr]), trl[:ntr], 1, 1.0, mnph, None, None, cv)
+    te = MyDataset('data/t/test', adj, (teu[:nte], tev[:nte]), tel[:nte], 1, 1.0, mnph, None, None, cv)
+    return tr, te, cv
+
+
+def test_extraction_api_known_answer():
+    from igmc_amd.util_functions import SparseColIndexer, SparseRowIndexer, construct_pyg_graph, \
+        subgraph_extraction_labeling
+    c = CASES['hand']
+    Arow, Acol = SparseRowIndexer(c['A']), SparseColIndexer(c['A'].tocsc())
+    out = subgraph_extraction_labeling((0, 1), Arow, Acol, 1, 1.0, None, None, None, c['class_values'], 1)
+    u, v, r, labels, ml, y, nf = out
+    # same graph as the reference's known answer up to the order of non-target nodes
+    assert labels == [0, 2, 1, 3, 3] and ml == 3 and y == 2.0 and nf is None
+    d = construct_pyg_graph(*out)
+    assert sorted(zip(d.edge_index[0].tolist(), d.edge_index[1].tolist(), d.edge_type.tolist())) == \
+        sorted(zip([0, 0, 1, 3, 4, 2], [3, 4, 2, 0, 0, 1], [0, 4, 2, 0, 4, 2]))
+
+
+def test_dataset_surface(flix):
+    tr, te, cv = make_sets(flix)
+    assert len(tr) == 600 and tr.num_features == 4 and tr.__class__.__name__ == 'MyDynamicDataset'
+    d = tr[3]
+    assert d.x.shape[1] == 4 and d.edge_index.shape[0] == 2 and d.edge_type.shape[0] == d.edge_index.shape[1]
+    assert float(d.y) == float(cv[flix[3][3]])
+    assert d.x[0].tolist() == [1, 0, 0, 0]
+
+
+def test_train_eval_checkpoint_roundtrip(flix, tmp_path):
+    import torch
+    from igmc_amd.models import IGMC
+    from igmc_amd.train_eval import DataLoader, eval_rmse, test_once, train_multiple_epochs
+    tr, te, cv = make_sets(flix)
+    torch.manual_seed(1)
+    model = IGMC(tr, latent_dim=[32, 32, 32, 32], num_relations=len(cv), num_bases=4, regression=True,
+                 adj_dropout=0.2, multiply_by=1)
+    logs = []
+
+    def logger(info, m, opt):
+        logs.append(dict(info))
+        if m is not None:
+            torch.save(m.state_dict(), str(tmp_path / ('model_checkpoint%d.pth' % info['epoch'])))
+            torch.save(opt.state_dict(), str(tmp_path / ('optimizer_checkpoint%d.pth' % info['epoch'])))
+    rmse = train_multiple_epochs(tr, te, model, 3, 50, 1e-3, 0.1, 2, 0, ARR=0.001, test_freq=1, logger=logger,
+                                 res_dir=str(tmp_path))
+    assert len(logs) == 3 and math.isfinite(rmse) and rmse == logs[-1]['test_rmse']
+    assert logs[0]['train_loss'] > logs[-1]['train_loss'] > 0          # it learns
+    sd = torch.load(str(tmp_path / 'model_checkpoint3.pth'))
+    want = {}
+    for l in range(4):
+        fin = 4 if l == 0 else 32
+        want.update({'convs.%d.basis' % l: (4, fin, 32), 'convs.%d.att' % l: (len(cv), 4),
+                     'convs.%d.root' % l: (fin, 32), 'convs.%d.bias' % l: (32,)})
+    want.update({'lin1.weight': (128, 256), 'lin1.bias': (128,), 'lin2.weight': (1, 128), 'lin2.bias': (1,)})
+    assert {k: tuple(v.shape) for k, v in sd.items()} == want           # reference state_dict contract
+    assert list(sd.keys())[:4] == ['convs.0.basis', 'convs.0.att', 'convs.0.root', 'convs.0.bias']
+    osd = torch.load(str(tmp_path / 'optimizer_checkpoint3.pth'), weights_only=False)
+    assert osd['param_groups'][0]['lr'] == pytest.approx(1e-4) and len(osd['state']) == 20
+    # reload into a fresh model: identical eval RMSE
+    m2 = IGMC(tr, latent_dim=[32, 32, 32, 32], num_relations=len(cv), num_bases=4, regression=True).to('cuda')
+    m2.load_state_dict(sd)
+    r2 = test_once(te, m2, 50)
+    assert r2 == pytest.approx(rmse, abs=1e-6)
+    # resume (reference --continue-from): runs and keeps improving or at least stays finite
+    r3 = train_multiple_epochs(tr, te, m2, 4, 50, 1e-3, 0.1, 50, 0, ARR=0.001, logger=None, continue_from=3,
+                               res_dir=str(tmp_path))
+    assert math.isfinite(r3)
+
+
+def test_eval_rmse_matches_oracle_within_1e4(flix):
+    """Fixed checkpoint, fixed (static) test set: RMSE equals the PyG-restatement's within 1e-4."""
+    import torch
+    from igmc_amd.models import IGMC
+    from igmc_amd.train_eval import DataLoader, eval_rmse
+    from oracle import pyg_ref
+    tr, te, cv = make_sets(flix, nte=200)
+    torch.manual_seed(3)
+    model = IGMC(tr, latent_dim=[32, 32, 32, 32], num_relations=len(cv), num_bases=4, regression=True).to('cuda')
+    model.reset_parameters()
+    loader = DataLoader(te, 50, shuffle=False)
+    rmse = eval_rmse(model, loader, 'cuda')
+    ref = pyg_ref.IGMCRef(4, (32, 32, 32, 32), len(cv), 4, adj_dropout=0.2, fast=True)
+    ref.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    sse, n = 0.0, 0
+    for data in DataLoader(te, 50, shuffle=False):
+        raw = data._materialise()['raw']
+        s, _ = pyg_ref.eval_sse(ref, batch_to_pyg(raw, 4))
+        sse += s
+        n += raw['B']
+    assert n == 200
+    assert rmse == pytest.approx(math.sqrt(sse / n), abs=1e-4)
+
+
+def test_differentiable_forward_matches_fused_path(flix):
+    """Foreign training loops: model(data) -> loss.backward() gives the same gradients as the fused kernel path."""
+    import torch
+    import torch.nn.functional as F
+    from igmc_amd.models import IGMC
+    from igmc_amd.train_eval import DataLoader
+    tr, te, cv = make_sets(flix, dynamic=False)
+    torch.manual_seed(5)
+    model = IGMC(tr, latent_dim=[32, 32, 32, 32], num_relations=len(cv), num_bases=4, regression=True,
+                 adj_dropout=0.0).to('cuda')
+    model.reset_parameters()
+    data = next(iter(DataLoader(tr, 50, shuffle=False)))
+    model.train()
+    model._step = 10
+    out = model(data)
+    loss = F.mse_loss(out, data.y.view(-1))
+    loss.backward()
+    g_auto = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    step_used = model._step
+    # fused path with the same MLP-dropout key (seed, step)
+    ws = model._workspace(data)
+    flat = model.flat_parameters()
+    grad = torch.zeros_like(flat)
+    outb, lossb = torch.empty(50, device='cuda'), torch.zeros(2, device='cuda')
+    ws.loss_grad(flat.data_ptr(), data.arena, outb.data_ptr(), grad.data_ptr(), lossb.data_ptr(), seed=model.seed,
+                 step=step_used, ARR=0.0, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert lossb[0].item() == pytest.approx(loss.item(), rel=1e-5)
+    where = {k: (o, n, s) for (k, o, n, s) in model._views}
+    for k, g in g_auto.items():
+        o, n, s = where[k]
+        assert torch.allclose(g.reshape(-1), grad[o:o + n], rtol=1e-4, atol=1e-6), k
+    # a torch optimiser can drive it
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    before = model.flat_parameters().clone()
+    opt.step()
+    assert not torch.equal(before, model.flat_parameters())
+
+
+def test_ensemble_eval(flix, tmp_path):
+    import torch
+    from igmc_amd.models import IGMC
+    from igmc_amd.train_eval import test_once
+    tr, te, cv = make_sets(flix, nte=100)
+    paths = []
+    for i in range(3):
+        torch.manual_seed(10 + i)
+        m = IGMC(tr, latent_dim=[32, 32, 32, 32], num_relations=len(cv), num_bases=4, regression=True).to('cuda')
+        m.reset_parameters()
+        p = str(tmp_path / ('model_checkpoint%d.pth' % i))
+        torch.save(m.state_dict(), p)
+        paths.append(p)
+    m = IGMC(tr, latent_dim=[32, 32, 32, 32], num_relations=len(cv), num_bases=4, regression=True).to('cuda')
+    singles = []
+    for p in paths:
+        m.load_state_dict(torch.load(p))
+        singles.append(test_once(te, m, 50))
+    ens = test_once(te, m, 50, ensemble=True, checkpoints=paths)
+    assert math.isfinite(ens) and ens <= max(singles) + 1e-6
+
+
+def test_main_script_end_to_end(tmp_path):
+    """Main.py flags / result files (reference Main.py:31-45,188-210) on yahoo_music, --debug sized."""
+    import subprocess
+    import sys
+    from helpers import ROOT
+    cmd = [sys.executable, os.path.join(ROOT, 'Main.py'), '--data-name', 'yahoo_music', '--epochs', '2', '--testing',
+           '--save-interval', '1', '--debug', '--dynamic-train', '--ensemble', '--save-appendix', '_t',
+           '--max-nodes-per-hop', '200']
+    # ensemble of range(epochs-30..): with 2 epochs the reference schedule needs checkpoints we do not have;
+    # run without --ensemble for the end-to-end check of files and log format
+    cmd.remove('--ensemble')
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    # raw_data is looked up relative to cwd first, then next to the package
+    r = subprocess.run(cmd, cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-3000:]
+    res = tmp_path / 'results' / 'yahoo_music_t_testmode'
+    lines = (res / 'log.txt').read_text().strip().split('\n')
+    assert len(lines) == 3 and lines[0].startswith('Epoch 1, train loss ')
+    float(lines[-1].split(' ')[-1])                      # summarize_fdy.py:25-26 parses the last token
+    assert (res / 'model_checkpoint2.pth').exists() and (res / 'optimizer_checkpoint2.pth').exists()
+    assert (res / 'cmd_input.txt').exists()
