@@ -59,6 +59,7 @@ struct igmc_batch {
   int last_B;
   const float* side;
   int n_side;
+  const int64_t* ctrl;
   Allocs mem;
 };
 
@@ -229,6 +230,7 @@ extern "C" int igmc_batch_create(const igmc_graph* g, int max_graphs, int hop, i
   b->last_B = 0;
   b->side = nullptr;
   b->n_side = 0;
+  b->ctrl = nullptr;
   BatchDev& d = b->d;
   Allocs& M = b->mem;
   const int Bc = max_graphs;
@@ -274,7 +276,7 @@ extern "C" int igmc_extract_batch(const igmc_graph* g, igmc_batch* b, const int3
   if (B <= 0 || B > b->d.graph_cap) IGMC_FAIL("B exceeds the batch capacity");
   if (!d_link_u || !d_link_v || !d_link_y) IGMC_FAIL("null link arrays");
   igmc_launch_extract(g->d, b->d, d_link_u, d_link_v, d_link_y, d_link_idx, first, B, 0, sample_ratio, seed, epoch,
-                      stream);
+                      b->ctrl, stream);
   HIPCHECK(hipGetLastError());
   b->last_B = B;
   return 0;
@@ -313,7 +315,7 @@ extern "C" int igmc_extract_batch_replay(const igmc_graph* g, igmc_batch* b, int
   HIPCHECK(hipMemcpy(d.n_users, nu.data(), B * 4, hipMemcpyHostToDevice));
   HIPCHECK(hipMemcpy(d.n_items, nv.data(), B * 4, hipMemcpyHostToDevice));
   HIPCHECK(hipMemcpy(d.y, h_y, B * sizeof(float), hipMemcpyHostToDevice));
-  igmc_launch_extract(g->d, b->d, nullptr, nullptr, nullptr, nullptr, 0, B, 1, 1.0, 0, 0, stream);
+  igmc_launch_extract(g->d, b->d, nullptr, nullptr, nullptr, nullptr, 0, B, 1, 1.0, 0, 0, nullptr, stream);
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
   b->last_B = B;
@@ -323,7 +325,7 @@ extern "C" int igmc_extract_batch_replay(const igmc_graph* g, igmc_batch* b, int
 extern "C" int igmc_batch_edge_dropout(igmc_batch* b, float p, int force_undirected, uint64_t seed, uint64_t step,
                                        void* stream) {
   if (!b) IGMC_FAIL("null batch");
-  igmc_launch_edge_flags(b->d, p, force_undirected, seed, step, stream);
+  igmc_launch_edge_flags(b->d, p, force_undirected, seed, step, b->ctrl, stream);
   HIPCHECK(hipGetLastError());
   return 0;
 }
@@ -424,6 +426,7 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   if (!out) IGMC_FAIL("null out");
   if (num_bases != 4) IGMC_FAIL("the gfx950 kernels are built for num_bases == 4 (reference Main.py:393)");
   if (num_relations < 1 || num_relations > 255) IGMC_FAIL("num_relations out of range");
+  if (num_relations * num_labels + num_labels + 1 > 320) IGMC_FAIL("num_relations * num_labels too large for the layer-0 gradient kernel");
   if (num_labels < 2 || n_side < 0 || max_nodes < 1 || max_graphs < 1) IGMC_FAIL("bad sizes");
   HIPCHECK(hipSetDevice(device));
   igmc_model* m = new igmc_model();
@@ -460,7 +463,7 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   fail |= M.get(&d.agg, N * 128) | M.get(&d.Y, N * 128) | M.get(&d.dpre[0], N * 32) | M.get(&d.dpre[1], N * 32);
   fail |= M.get(&d.feat, Bc * d.D) | M.get(&d.a1, Bc * 128) | M.get(&d.lmask, Bc * 128) | M.get(&d.dz, Bc * 128) |
           M.get(&d.gfeat, Bc * d.D) | M.get(&d.err, Bc) | M.get(&d.gout, Bc);
-  fail |= M.get(&d.W0, (size_t)d.R * d.L * 32) | M.get(&d.w1T, (size_t)d.D * 128);
+  fail |= M.get(&d.W0, (size_t)d.R * d.L * 32) | M.get(&d.w1T, (size_t)d.D * 128) | M.get(&d.cnt0, N * d.R * d.L);
   d.wT[0] = nullptr;
   d.bcat[0] = nullptr;
   for (int l = 1; l < 4; ++l) fail |= M.get(&d.wT[l], (size_t)IGMC_KCAT * 32) | M.get(&d.bcat[l], (size_t)32 * 128);
@@ -470,6 +473,7 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
           M.get(&d.l0_part, (size_t)IGMC_L0_BLOCKS * rows0 * 32) |
           M.get(&d.graw, (size_t)3 * igmc_wg_stride() + 3 * d.R * 4 + rows0 * 32) | M.get(&d.arr_part, 4);
   d.side = nullptr;
+  d.ctrl = nullptr;
   if (fail) {
     M.release();
     delete m;
@@ -576,7 +580,7 @@ extern "C" int igmc_adam_step(float* d_params, const float* d_grad, float* d_exp
   const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
   const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
   igmc_launch_adam(d_params, d_grad, d_exp_avg, d_exp_avg_sq, n, (float)((double)lr / bc1),
-                   (float)(1.0 / std::sqrt(bc2)), beta1, beta2, eps, weight_decay, stream);
+                   (float)(1.0 / std::sqrt(bc2)), beta1, beta2, eps, weight_decay, nullptr, stream);
   HIPCHECK(hipGetLastError());
   return 0;
 }
@@ -584,6 +588,31 @@ extern "C" int igmc_adam_step(float* d_params, const float* d_grad, float* d_exp
 extern "C" int igmc_sse_accumulate(const float* d_out, const igmc_batch* b, double* d_acc, void* stream) {
   if (!d_out || !b || !d_acc) IGMC_FAIL("null argument");
   igmc_launch_sse(b->d, d_out, d_acc, stream);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------ device-side step control
+extern "C" int igmc_ctrl_tick(int64_t* d_ctrl, void* stream) {
+  if (!d_ctrl) IGMC_FAIL("null ctrl");
+  igmc_launch_tick(d_ctrl, stream);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+extern "C" int igmc_batch_set_ctrl(igmc_batch* b, const int64_t* d_ctrl) {
+  if (!b) IGMC_FAIL("null batch");
+  b->ctrl = d_ctrl;
+  return 0;
+}
+extern "C" int igmc_model_set_ctrl(igmc_model* m, const int64_t* d_ctrl) {
+  if (!m) IGMC_FAIL("null model");
+  m->d.ctrl = d_ctrl;
+  return 0;
+}
+extern "C" int igmc_adam_step_ctrl(float* d_params, const float* d_grad, float* d_exp_avg, float* d_exp_avg_sq,
+                                   int64_t n, const int64_t* d_ctrl, void* stream) {
+  if (!d_params || !d_grad || !d_exp_avg || !d_exp_avg_sq || n <= 0 || !d_ctrl) IGMC_FAIL("bad arguments");
+  igmc_launch_adam(d_params, d_grad, d_exp_avg, d_exp_avg_sq, n, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, d_ctrl, stream);
   HIPCHECK(hipGetLastError());
   return 0;
 }

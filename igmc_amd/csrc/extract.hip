@@ -35,6 +35,7 @@ struct ExtractArgs {
   int first, B, replay;
   double sample_ratio;
   uint64_t seed, epoch;
+  const int64_t* ctrl;   // optional device-side step control (first / epoch), see igmc_hip.h
 };
 
 // ---------------------------------------------------------------- bitmap helpers
@@ -180,7 +181,9 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_extract_nodes(ExtractArgs a) {
   bm_clear(sel_u, Wu);
   bm_clear(sel_v, Wv);
   if (!a.replay) {
-    const int pos = a.link_idx ? a.link_idx[a.first + g] : a.first + g;
+    const int first = a.ctrl ? (int)a.ctrl[IGMC_CTRL_FIRST] : a.first;
+    const uint64_t epoch = a.ctrl ? (uint64_t)a.ctrl[IGMC_CTRL_EPOCH] : a.epoch;
+    const int pos = a.link_idx ? a.link_idx[first + g] : first + g;
     u0 = a.link_u[pos];
     v0 = a.link_v[pos];
     bm_clear(vis_u, Wu);
@@ -233,8 +236,8 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_extract_nodes(ExtractArgs a) {
         if (a.b.max_nodes_per_hop < kv) kv = a.b.max_nodes_per_hop;
       }
       const uint64_t link_uid = (uint64_t)(uint32_t)pos;
-      sample_fringe(new_u, Wu, cnt_u, ku, igmc_sample_salt(a.seed, a.epoch, link_uid, dist, 0), hist, sm);
-      sample_fringe(new_v, Wv, cnt_v, kv, igmc_sample_salt(a.seed, a.epoch, link_uid, dist, 1), hist, sm);
+      sample_fringe(new_u, Wu, cnt_u, ku, igmc_sample_salt(a.seed, epoch, link_uid, dist, 0), hist, sm);
+      sample_fringe(new_v, Wv, cnt_v, kv, igmc_sample_salt(a.seed, epoch, link_uid, dist, 1), hist, sm);
       if (ku == 0 && kv == 0) break;   // reference :230-231
       const int ncu = append_fringe(new_u, sel_u, Wu, tl, td, cu, dist, sm);
       const int ncv = append_fringe(new_v, sel_v, Wv, tl + cap_u, td + cap_u, cv, dist, sm);
@@ -467,7 +470,8 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_fill(GraphDev G, BatchDev b) {
 // reference models.py:193-198 -> PyG dropout_adj: independent Bernoulli(1-p) per DIRECTED edge
 // (shared by the two directions when force_undirected).  16 lanes per CSR row.
 __global__ __launch_bounds__(IGMC_BLOCK) void k_edge_flags(BatchDev b, float p, int force_undirected,
-                                                            uint64_t seed, uint64_t step) {
+                                                            uint64_t seed, uint64_t step_arg, const int64_t* ctrl) {
+  const uint64_t step = ctrl ? (uint64_t)ctrl[IGMC_CTRL_STEP] : step_arg;
   const int N = b.totals[0];
   const int grp = (blockIdx.x * IGMC_BLOCK + threadIdx.x) >> 4, t = threadIdx.x & 15;
   const int ngrp = (gridDim.x * IGMC_BLOCK) >> 4;
@@ -499,8 +503,9 @@ size_t igmc_extract_smem_bytes(const GraphDev& g) {
 
 void igmc_launch_extract(const GraphDev& g, const BatchDev& b, const int32_t* link_u, const int32_t* link_v,
                          const float* link_y, const int32_t* link_idx, int first, int B, int replay,
-                         double sample_ratio, uint64_t seed, uint64_t epoch, void* stream) {
+                         double sample_ratio, uint64_t seed, uint64_t epoch, const int64_t* ctrl, void* stream) {
   ExtractArgs a;
+  a.ctrl = ctrl;
   a.g = g; a.b = b;
   a.link_u = link_u; a.link_v = link_v; a.link_y = link_y; a.link_idx = link_idx;
   a.first = first; a.B = B; a.replay = replay;
@@ -516,8 +521,8 @@ void igmc_launch_extract(const GraphDev& g, const BatchDev& b, const int32_t* li
 }
 
 void igmc_launch_edge_flags(const BatchDev& b, float p, int force_undirected, uint64_t seed, uint64_t step,
-                            void* stream) {
-  IGMC_PLAUNCH("k_edge_flags", k_edge_flags, 512, IGMC_BLOCK, 0, stream, b, p, force_undirected, seed, step);
+                            const int64_t* ctrl, void* stream) {
+  IGMC_PLAUNCH("k_edge_flags", k_edge_flags, 512, IGMC_BLOCK, 0, stream, b, p, force_undirected, seed, step, ctrl);
 }
 
 void igmc_launch_fill_u8(uint8_t* p, int64_t n, uint8_t v, void* stream) {
@@ -535,3 +540,16 @@ int igmc_extract_prepare(size_t smem) {
   (void)smem;
   return 0;
 }
+
+// advance the device-side step control (see igmc_hip.h)
+__global__ void k_tick(int64_t* ctrl) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double* d = (double*)ctrl;
+  ctrl[IGMC_CTRL_STEP] += 1;
+  ctrl[IGMC_CTRL_FIRST] += ctrl[IGMC_CTRL_BATCH];
+  ctrl[IGMC_CTRL_ADAM_T] += 1;
+  const double t = (double)ctrl[IGMC_CTRL_ADAM_T];
+  d[IGMC_CTRL_STEP_SIZE] = d[IGMC_CTRL_LR] / (1.0 - pow(d[IGMC_CTRL_BETA1], t));
+  d[IGMC_CTRL_INV_SQRT_BC2] = 1.0 / sqrt(1.0 - pow(d[IGMC_CTRL_BETA2], t));
+}
+void igmc_launch_tick(int64_t* ctrl, void* stream) { IGMC_PLAUNCH("k_tick", k_tick, 1, 64, 0, stream, ctrl); }

@@ -6,9 +6,10 @@
 size_t igmc_extract_smem_bytes(const GraphDev& g);
 void igmc_launch_extract(const GraphDev& g, const BatchDev& b, const int32_t* link_u, const int32_t* link_v,
                          const float* link_y, const int32_t* link_idx, int first, int B, int replay,
-                         double sample_ratio, uint64_t seed, uint64_t epoch, void* stream);
+                         double sample_ratio, uint64_t seed, uint64_t epoch, const int64_t* ctrl, void* stream);
 void igmc_launch_edge_flags(const BatchDev& b, float p, int force_undirected, uint64_t seed, uint64_t step,
-                            void* stream);
+                            const int64_t* ctrl, void* stream);
+void igmc_launch_tick(int64_t* ctrl, void* stream);
 void igmc_launch_fill_u8(uint8_t* p, int64_t n, uint8_t v, void* stream);
 int igmc_extract_prepare(size_t smem);
 
@@ -23,7 +24,8 @@ void igmc_launch_loss(const ModelDev& m, const BatchDev& b, float ARR, float* lo
 void igmc_launch_sse(const BatchDev& b, const float* out, double* acc, void* stream);
 int igmc_model_prepare(const ModelDev& m);
 void igmc_launch_adam(float* p, const float* g, float* m1, float* m2, int64_t n, float step_size,
-                      float inv_sqrt_bc2, float beta1, float beta2, float eps, float wd, void* stream);
+                      float inv_sqrt_bc2, float beta1, float beta2, float eps, float wd, const int64_t* ctrl,
+                      void* stream);
 
 // ---- per-kernel timing (HIP events on the launch stream; bench.py's roofline leg) ----
 void igmc_prof_begin(const char* name, void* stream);

@@ -25,6 +25,7 @@ struct ModelDev {
   float* err;         // [Bcap]      out - y
   float* gout;        // [Bcap]      dLoss/d out (loss_grad path)
   // per-step derived weights
+  uint16_t* cnt0;     // [Ncap, R*L]  per-node histogram of kept in-edge codes (layer-0 weight gradient)
   float* W0;          // [R*L,32]    composed layer-0 weight  W0[r][c] = sum_b att0[r,b] basis0[b][c]
   float* wT[4];       // [160,32]    [basis_b^T ; root^T] of layer l (l>=1), for dLoss/dx
   float* bcat[4];     // [32,128]    [basis_0|..|basis_3]   of layer l (l>=1), for Y
@@ -36,6 +37,7 @@ struct ModelDev {
   float* graw;        // [3][32*160+32] + [R*4]*3 + l0 rows: reduced partials
   float* arr_part;    // [4] ARR regulariser per layer
   const float* side;  // [B,S] borrowed side features or NULL
+  const int64_t* ctrl;  // optional device-side step control (igmc_hip.h) or NULL
 };
 
 static inline int igmc_wg_stride() { return 32 * IGMC_KCAT + 32; }

@@ -71,28 +71,38 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_prep(ModelDev m, const float* __
 // partial sums are combined with two xor-shuffles at the end of the row.
 
 // =================================================================== layer 0 forward (one-hot input)
-// h0[i] = tanh( sum_e W0[rel_e*L + label(src_e)] + root0[label_i] + bias0 )
-template <bool FLAGS>
+// h0[i] = tanh( sum_e W0[rel_e*L + label(src_e)] + root0[label_i] + bias0 ).
+// STORE (training): also emits cnt0[i][code] = number of kept incoming edges with that code, so that the
+// layer-0 weight gradient is a dense [codes x N] @ [N x 32] product that never touches the edges again.
+template <bool FLAGS, bool STORE>
 __global__ __launch_bounds__(IGMC_BLOCK) void k_l0_fwd(BatchDev b, ModelDev m, const float* __restrict__ P,
                                                          float* __restrict__ out) {
   IGMC_DYN_SMEM(smem);
+  const int RL = m.R * m.L;
   float* sW0 = (float*)smem;                 // [R*L][32]
-  float* sroot = sW0 + m.R * m.L * 32;       // [L][32]
+  float* sroot = sW0 + RL * 32;              // [L][32]
   float* sbias = sroot + m.L * 32;           // [32]
-  for (int i = threadIdx.x; i < m.R * m.L * 32; i += IGMC_BLOCK) sW0[i] = m.W0[i];
+  int* shist = (int*)(sbias + 32);           // [4 waves][R*L]   (STORE only)
+  for (int i = threadIdx.x; i < RL * 32; i += IGMC_BLOCK) sW0[i] = m.W0[i];
   for (int i = threadIdx.x; i < m.L * 32; i += IGMC_BLOCK) sroot[i] = P[m.off_root[0] + i];
   if (threadIdx.x < 32) sbias[threadIdx.x] = P[m.off_bias[0] + threadIdx.x];
   __syncthreads();
   const int N = b.totals[0];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp = lane >> 4, t = lane & 15;
+  int* hist = shist + wave * RL;
   for (int i = blockIdx.x * 4 + wave; i < N; i += gridDim.x * 4) {
     float ax = 0.f, ay = 0.f;
+    if (STORE) {
+      for (int c = lane; c < RL; c += 64) hist[c] = 0;
+      IGMC_WAVE_SYNC();
+    }
     const int beg = b.row_ptr[i], end = b.row_ptr[i + 1];
     for (int c0 = beg + grp * 16; c0 < end; c0 += 64) {
       const int e = c0 + t;
       int w = -1;                              // code, or -1 = skip
       if (e < end && (!FLAGS || (b.eflag[e] & 1))) w = b.ecode[e];
+      if (STORE && w >= 0) atomicAdd(&hist[w], 1);
       const int n = (end - c0 < 16) ? end - c0 : 16;
       for (int k = 0; k < n; ++k) {
         const int code = __shfl(w, k, 16);
@@ -112,6 +122,11 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_l0_fwd(BatchDev b, ModelDev m, c
       o.x = tanhf(ax + sbias[2 * t] + sroot[lab * 32 + 2 * t]);
       o.y = tanhf(ay + sbias[2 * t + 1] + sroot[lab * 32 + 2 * t + 1]);
       *(float2*)(out + (size_t)i * 32 + 2 * t) = o;
+    }
+    if (STORE) {
+      IGMC_WAVE_SYNC();
+      for (int c = lane; c < RL; c += 64) m.cnt0[(size_t)i * RL + c] = (uint16_t)hist[c];
+      IGMC_WAVE_SYNC();
     }
   }
 }
@@ -254,7 +269,8 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_dense(BatchDev b, const float* _
                                                         float* __restrict__ out,
                                                         const float* __restrict__ xin,     // EPI_BWD: input activations
                                                         const float* __restrict__ gfeat,   // EPI_BWD: readout gradient [B,D]
-                                                        int D, int rlayer) {
+                                                        int D, int rlayer,
+                                                        float* __restrict__ zero_out) {    // optional [N,32] buffer to clear
   constexpr int K = K1 + K2, PITCH = NO + 4, NT = NO / 16;
   IGMC_DYN_SMEM(smem);
   float* sW = (float*)smem;
@@ -293,7 +309,10 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_dense(BatchDev b, const float* _
         if (orow >= N) continue;
         const int n = nt * 16 + li;
         float v = acc[nt][rr];
-        if (EPI == EPI_BIAS_TANH) v = tanhf(v + bias[n]);
+        if (EPI == EPI_BIAS_TANH) {
+          v = tanhf(v + bias[n]);
+          if (zero_out) zero_out[(size_t)orow * 32 + n] = 0.f;
+        }
         if (EPI == EPI_BWD) {
           const int lab = b.node_label[orow];
           if (lab < 2) v += gfeat[(size_t)b.node_graph[orow] * D + lab * 128 + rlayer * 32 + n];
@@ -375,146 +394,150 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_wgrad(BatchDev b, const float* _
   for (int i = threadIdx.x; i < 32 * IGMC_KCAT + 32; i += IGMC_BLOCK) dst[i] = sacc[i];
 }
 
-// =================================================================== layer 0 backward
-// table[code] += dPre0[dst]  for every kept edge (code = rel*L + label(src)); extra rows:
-// R*L + label(i) (d root0) and R*L + L (d bias0).  PRIVATE: one table per 16-lane group
-// (plain read-modify-write, bit-reproducible); otherwise one table per block with LDS float atomics.
-template <bool FLAGS, bool PRIVATE>
+// =================================================================== layer 0 backward (dense, no edges)
+// T[c][f] = sum_i weight(i,c) * dPre0[i][f],  c < R*L: cnt0[i][c] (kept in-edges with that code);
+// c = R*L + label_i: d root0;  c = R*L + L: d bias0.   Thread (cg = tid>>5, f = tid&31) owns codes cg + 8k.
+// Each block reduces a contiguous node range into its own partial (fixed order -> reproducible).
+template <int KMAX>
 __global__ __launch_bounds__(IGMC_BLOCK) void k_l0_bwd(BatchDev b, ModelDev m, const float* __restrict__ dpre,
                                                          float* __restrict__ part) {
-  IGMC_DYN_SMEM(smem);
-  float* tab = (float*)smem;
-  const int rows = m.R * m.L + m.L + 1;
-  const int ntab = PRIVATE ? 16 : 1;
-  for (int i = threadIdx.x; i < ntab * rows * 32; i += IGMC_BLOCK) tab[i] = 0.f;
-  __syncthreads();
   const int N = b.totals[0];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int grp = lane >> 4, t = lane & 15;
-  float* my = tab + (PRIVATE ? (wave * 4 + grp) * rows * 32 : 0);
-  for (int i = blockIdx.x * 4 + wave; i < N; i += gridDim.x * 4) {
-    const float2 d = *(const float2*)(dpre + (size_t)i * 32 + 2 * t);
-    const int beg = b.row_ptr[i], end = b.row_ptr[i + 1];
-    int cur = -1, cnt = 0;
-    for (int c0 = beg + grp * 16; c0 < end; c0 += 64) {
-      const int e = c0 + t;
-      int w = -1;
-      if (e < end && (!FLAGS || (b.eflag[e] & 1))) w = b.ecode[e];
-      const int n = (end - c0 < 16) ? end - c0 : 16;
-      for (int k = 0; k < n; ++k) {
-        const int code = __shfl(w, k, 16);
-        if (code < 0) continue;
-        if (PRIVATE) {
-          // consecutive edges often share the code (rows are relation-sorted): count, then one update
-          if (code != cur) {
-            if (cur >= 0) {
-              my[cur * 32 + 2 * t] += cnt * d.x;
-              my[cur * 32 + 2 * t + 1] += cnt * d.y;
-            }
-            cur = code;
-            cnt = 0;
-          }
-          ++cnt;
-        } else {
-          atomicAdd(&my[code * 32 + 2 * t], d.x);
-          atomicAdd(&my[code * 32 + 2 * t + 1], d.y);
-        }
-      }
-    }
-    if (PRIVATE && cur >= 0) {
-      my[cur * 32 + 2 * t] += cnt * d.x;
-      my[cur * 32 + 2 * t + 1] += cnt * d.y;
-    }
-    if (grp == 0) {     // d root0[label_i] and d bias0: once per row
-      const int lab = b.node_label[i];
-      if (PRIVATE) {
-        my[(m.R * m.L + lab) * 32 + 2 * t] += d.x;
-        my[(m.R * m.L + lab) * 32 + 2 * t + 1] += d.y;
-        my[(m.R * m.L + m.L) * 32 + 2 * t] += d.x;
-        my[(m.R * m.L + m.L) * 32 + 2 * t + 1] += d.y;
-      } else {
-        atomicAdd(&my[(m.R * m.L + lab) * 32 + 2 * t], d.x);
-        atomicAdd(&my[(m.R * m.L + lab) * 32 + 2 * t + 1], d.y);
-        atomicAdd(&my[(m.R * m.L + m.L) * 32 + 2 * t], d.x);
-        atomicAdd(&my[(m.R * m.L + m.L) * 32 + 2 * t + 1], d.y);
-      }
+  const int RL = m.R * m.L, rows = RL + m.L + 1;
+  const int f = threadIdx.x & 31, cg = threadIdx.x >> 5;
+  float acc[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
+  const int chunk = (N + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int lo = blockIdx.x * chunk, hi = (lo + chunk < N) ? lo + chunk : N;
+  for (int i = lo; i < hi; ++i) {
+    const float d = dpre[(size_t)i * 32 + f];
+    const int lab = b.node_label[i];
+    const uint16_t* cn = m.cnt0 + (size_t)i * RL;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      const int c = cg + 8 * k;
+      float w = 0.f;
+      if (c < RL) w = (float)cn[c];
+      else if (c == RL + lab || c == RL + m.L) w = 1.f;
+      acc[k] += w * d;
     }
   }
-  __syncthreads();
   float* dst = part + (size_t)blockIdx.x * rows * 32;
-  for (int i = threadIdx.x; i < rows * 32; i += IGMC_BLOCK) {
-    float s = 0.f;
-    for (int g = 0; g < ntab; ++g) s += tab[g * rows * 32 + i];
-    dst[i] = s;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const int c = cg + 8 * k;
+    if (c < rows) dst[c * 32 + f] = acc[k];
   }
 }
 
 // =================================================================== head: readout + MLP (+loss residual)
-// One 128-thread block per graph.  reference models.py:203-215.
+// reference models.py:203-215.  HG graphs per block so every lin1 weight is loaded once per HG graphs and
+// the k-loops carry HG independent FMA chains.
+#define IGMC_HG 8
+
 __global__ __launch_bounds__(128) void k_head_fwd(BatchDev b, ModelDev m, const float* __restrict__ P,
                                                     int training, const uint8_t* __restrict__ inj_mask,
-                                                    uint64_t seed, uint64_t step, float mult,
+                                                    uint64_t seed, uint64_t step_arg, float mult,
                                                     float* __restrict__ out) {
   IGMC_DYN_SMEM(smem);
-  float* sfeat = (float*)smem;      // [D]
-  __shared__ float red[2];
-  const int g = blockIdx.x, j = threadIdx.x;
-  const int nu = b.node_off[g], nv = nu + b.n_users[g];
-  for (int k = j; k < m.D; k += 128) {
-    float v;
-    if (k < 256) {
-      const int side = k >> 7, l = (k >> 5) & 3, f = k & 31;
-      v = m.h[l][(size_t)(side ? nv : nu) * 32 + f];
-    } else {
-      v = m.side[(size_t)g * m.S + (k - 256)];
+  const uint64_t step = m.ctrl ? (uint64_t)m.ctrl[IGMC_CTRL_STEP] : step_arg;
+  float* sfeat = (float*)smem;      // [HG][D]
+  __shared__ float red[2][IGMC_HG];
+  const int B = b.totals[3];
+  const int g0 = blockIdx.x * IGMC_HG, j = threadIdx.x;
+  const int D = m.D;
+  for (int idx = j; idx < IGMC_HG * D; idx += 128) {
+    const int gg = idx / D, k = idx % D, g = g0 + gg;
+    float v = 0.f;
+    if (g < B) {
+      if (k < 256) {
+        const int side = k >> 7, l = (k >> 5) & 3, f = k & 31;
+        const int nu = b.node_off[g], nv = nu + b.n_users[g];
+        v = m.h[l][(size_t)(side ? nv : nu) * 32 + f];
+      } else {
+        v = m.side[(size_t)g * m.S + (k - 256)];
+      }
+      if (training) m.feat[(size_t)g * D + k] = v;
     }
-    sfeat[k] = v;
-    if (training) m.feat[(size_t)g * m.D + k] = v;
+    sfeat[idx] = v;
   }
   __syncthreads();
-  float acc = P[m.off_l1b + j];
-  for (int k = 0; k < m.D; ++k) acc += m.w1T[k * 128 + j] * sfeat[k];
-  float a = acc > 0.f ? acc : 0.f;
-  if (training) {
-    m.a1[g * 128 + j] = a;
-    const int keep = inj_mask ? (int)inj_mask[g * 128 + j]
-                              : (int)(igmc_u01(igmc_unit_hash(seed, step, (uint32_t)g, (uint32_t)j)) >= 0.5f);
-    m.lmask[g * 128 + j] = (uint8_t)keep;
-    a = keep ? a * 2.f : 0.f;    // F.dropout(p=0.5): kept units scaled by 1/(1-p)
+  float acc[IGMC_HG];
+  const float b1 = P[m.off_l1b + j];
+#pragma unroll
+  for (int gg = 0; gg < IGMC_HG; ++gg) acc[gg] = b1;
+#pragma unroll 4
+  for (int k = 0; k < D; ++k) {
+    const float w = m.w1T[k * 128 + j];
+#pragma unroll
+    for (int gg = 0; gg < IGMC_HG; ++gg) acc[gg] += w * sfeat[gg * D + k];
   }
-  float p = igmc_wave_sum_f(a * P[m.off_l2w + j]);
-  if ((j & 63) == 0) red[j >> 6] = p;
+  const float w2 = P[m.off_l2w + j];
+#pragma unroll
+  for (int gg = 0; gg < IGMC_HG; ++gg) {
+    const int g = g0 + gg;
+    float a = acc[gg] > 0.f ? acc[gg] : 0.f;
+    if (training && g < B) {
+      m.a1[g * 128 + j] = a;
+      const int keep = inj_mask ? (int)inj_mask[g * 128 + j]
+                                : (int)(igmc_u01(igmc_unit_hash(seed, step, (uint32_t)g, (uint32_t)j)) >= 0.5f);
+      m.lmask[g * 128 + j] = (uint8_t)keep;
+      a = keep ? a * 2.f : 0.f;    // F.dropout(p=0.5): kept units scaled by 1/(1-p)
+    }
+    const float p = igmc_wave_sum_f(a * w2);
+    if ((j & 63) == 0) red[j >> 6][gg] = p;
+  }
   __syncthreads();
-  if (j == 0) {
-    const float o = (red[0] + red[1] + P[m.off_l2b]) * mult;
-    out[g] = o;
-    m.err[g] = o - b.y[g];
+  if (j < IGMC_HG && g0 + j < B) {
+    const float o = (red[0][j] + red[1][j] + P[m.off_l2b]) * mult;
+    out[g0 + j] = o;
+    m.err[g0 + j] = o - b.y[g0 + j];
   }
 }
 
-// backward A: per graph -- dz, d feat, and dPre of the top layer on the two target rows
-__global__ __launch_bounds__(128) void k_head_bwd_a(BatchDev b, ModelDev m, const float* __restrict__ P,
-                                                      const float* __restrict__ gout, int from_err,
-                                                      float grad_scale, float mult, float drop_scale,
-                                                      float* __restrict__ dpre_top) {
-  __shared__ float sdz[128];
-  const int g = blockIdx.x, j = threadIdx.x;
-  const float dp = (from_err ? 2.f * m.err[g] * grad_scale : gout[g]) * mult;
-  const float a = m.a1[g * 128 + j];
-  const float dzv = (a > 0.f && m.lmask[g * 128 + j]) ? dp * P[m.off_l2w + j] * drop_scale : 0.f;
-  m.dz[g * 128 + j] = dzv;
-  sdz[j] = dzv;
+// backward A: dz, d feat, and dPre of the top layer on the two target rows of each graph
+__global__ __launch_bounds__(IGMC_BLOCK) void k_head_bwd_a(BatchDev b, ModelDev m, const float* __restrict__ P,
+                                                             const float* __restrict__ gout, int from_err,
+                                                             float grad_scale, float mult, float drop_scale,
+                                                             float* __restrict__ dpre_top) {
+  __shared__ float sdz[IGMC_HG][128];
+  const int B = b.totals[3];
+  const int g0 = blockIdx.x * IGMC_HG, tid = threadIdx.x;
+  const int D = m.D;
+  for (int idx = tid; idx < IGMC_HG * 128; idx += IGMC_BLOCK) {
+    const int gg = idx >> 7, j = idx & 127, g = g0 + gg;
+    float dzv = 0.f;
+    if (g < B) {
+      const float dp = (from_err ? 2.f * m.err[g] * grad_scale : gout[g]) * mult;
+      const float a = m.a1[g * 128 + j];
+      dzv = (a > 0.f && m.lmask[g * 128 + j]) ? dp * P[m.off_l2w + j] * drop_scale : 0.f;
+      m.dz[g * 128 + j] = dzv;
+    }
+    sdz[gg][j] = dzv;
+  }
   __syncthreads();
-  const int nu = b.node_off[g], nv = nu + b.n_users[g];
-  for (int k = j; k < m.D; k += 128) {
-    float s = 0.f;
-    for (int jj = 0; jj < 128; ++jj) s += sdz[jj] * P[m.off_l1w + (int64_t)jj * m.D + k];
-    m.gfeat[(size_t)g * m.D + k] = s;
-    if (k < 256 && ((k >> 5) & 3) == 3) {
-      const int side = k >> 7, f = k & 31;
-      const size_t node = (size_t)(side ? nv : nu);
-      const float hv = m.h[3][node * 32 + f];
-      dpre_top[node * 32 + f] = s * (1.f - hv * hv);
+  for (int k = tid; k < D; k += IGMC_BLOCK) {
+    float acc[IGMC_HG];
+#pragma unroll
+    for (int gg = 0; gg < IGMC_HG; ++gg) acc[gg] = 0.f;
+#pragma unroll 4
+    for (int jj = 0; jj < 128; ++jj) {
+      const float w = P[m.off_l1w + (int64_t)jj * D + k];
+#pragma unroll
+      for (int gg = 0; gg < IGMC_HG; ++gg) acc[gg] += sdz[gg][jj] * w;
+    }
+#pragma unroll
+    for (int gg = 0; gg < IGMC_HG; ++gg) {
+      const int g = g0 + gg;
+      if (g >= B) continue;
+      m.gfeat[(size_t)g * D + k] = acc[gg];
+      if (k < 256 && ((k >> 5) & 3) == 3) {
+        const int side = k >> 7, f = k & 31;
+        const int nu = b.node_off[g], nv = nu + b.n_users[g];
+        const size_t node = (size_t)(side ? nv : nu);
+        const float hv = m.h[3][node * 32 + f];
+        dpre_top[node * 32 + f] = acc[gg] * (1.f - hv * hv);
+      }
     }
   }
 }
@@ -529,9 +552,16 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_head_bwd_w(BatchDev b, ModelDev 
   const int idx = blockIdx.x * IGMC_BLOCK + threadIdx.x;
   if (idx < nW) {
     const int j = idx / m.D, k = idx % m.D;
-    float s = 0.f;
-    for (int g = 0; g < B; ++g) s += m.dz[g * 128 + j] * m.feat[(size_t)g * m.D + k];
-    grad[m.off_l1w + idx] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int g = 0;
+    for (; g + 4 <= B; g += 4) {      // 4 independent chains: the loads of a group are issued together
+      s0 += m.dz[(g + 0) * 128 + j] * m.feat[(size_t)(g + 0) * m.D + k];
+      s1 += m.dz[(g + 1) * 128 + j] * m.feat[(size_t)(g + 1) * m.D + k];
+      s2 += m.dz[(g + 2) * 128 + j] * m.feat[(size_t)(g + 2) * m.D + k];
+      s3 += m.dz[(g + 3) * 128 + j] * m.feat[(size_t)(g + 3) * m.D + k];
+    }
+    for (; g < B; ++g) s0 += m.dz[g * 128 + j] * m.feat[(size_t)g * m.D + k];
+    grad[m.off_l1w + idx] = (s0 + s1) + (s2 + s3);
   } else if (idx < nW + 128) {
     const int j = idx - nW;
     float s = 0.f;
@@ -612,10 +642,16 @@ __device__ __forceinline__ float igmc_block_sum_f(float v, float* sm) {
 
 // one block per conv layer: scatter the reduced partials into the flat gradient, add the
 // adjacent-rating-regulariser gradient (reference train_eval.py:167-174), emit the ARR value.
+// ARR through the 4x4 Gram matrix of the bases:  W[r] = sum_b att[r,b] basis[b]  =>
+//   D[r] = W[r+1]-W[r] = sum_b d[r,b] basis[b],  d[r] = att[r+1]-att[r]
+//   reg = sum_r d[r]^T Gm d[r],  dreg/dW[r] = 2(D[r-1]-D[r]) = sum_b c[r,b] basis[b],  c[r] = 2(d[r-1]-d[r])
+//   d att[r,b] += ARR * sum_b' c[r,b'] Gm[b',b];   d basis[b] += ARR * sum_b' (sum_r att[r,b] c[r,b']) basis[b']
 __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize(ModelDev m, const float* __restrict__ P,
                                                            float* __restrict__ grad, float arr_coef) {
   __shared__ float smf[8];
+  __shared__ float sG[16], sM[16];
   const int l = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int fin = (l == 0) ? m.L : 32;
   const int nE = fin * 32;                 // elements of one W[r] / basis[b]
   const int wgs = 32 * IGMC_KCAT + 32, na = m.R * 4;
@@ -643,66 +679,74 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize(ModelDev m, const float
     }
     for (int e = tid; e < nE; e += IGMC_BLOCK) grad[m.off_root[0] + e] = t0[(size_t)m.R * nE + e];
     if (tid < 32) grad[m.off_bias[0] + tid] = t0[(size_t)(m.R * m.L + m.L) * 32 + tid];
-    for (int rb = 0; rb < na; ++rb) {                 // d att0[r,b] = <GW0[r], basis0[b]>
+    for (int rb = wave; rb < na; rb += IGMC_BLOCK / 64) {   // d att0[r,b] = <GW0[r], basis0[b]>, one wave each
       const int r = rb >> 2, bb = rb & 3;
       float s = 0.f;
-      for (int e = tid; e < nE; e += IGMC_BLOCK) s += t0[(size_t)r * nE + e] * basis[bb * nE + e];
-      s = igmc_block_sum_f(s, smf);
-      if (tid == 0) ga[rb] = s;
+      for (int e = lane; e < nE; e += 64) s += t0[(size_t)r * nE + e] * basis[bb * nE + e];
+      s = igmc_wave_sum_f(s);
+      if (lane == 0) ga[rb] = s;
+    }
+  }
+  // ---- Gram matrix of the bases (10 unique entries)
+  float gp[10];
+#pragma unroll
+  for (int q = 0; q < 10; ++q) gp[q] = 0.f;
+  for (int e = tid; e < nE; e += IGMC_BLOCK) {
+    const float b0 = basis[e], b1 = basis[nE + e], b2 = basis[2 * nE + e], b3 = basis[3 * nE + e];
+    gp[0] += b0 * b0; gp[1] += b0 * b1; gp[2] += b0 * b2; gp[3] += b0 * b3;
+    gp[4] += b1 * b1; gp[5] += b1 * b2; gp[6] += b1 * b3;
+    gp[7] += b2 * b2; gp[8] += b2 * b3; gp[9] += b3 * b3;
+  }
+#pragma unroll
+  for (int q = 0; q < 10; ++q) gp[q] = igmc_block_sum_f(gp[q], smf);
+  if (tid == 0) {
+    const int ij[10][2] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {1, 1}, {1, 2}, {1, 3}, {2, 2}, {2, 3}, {3, 3}};
+    for (int q = 0; q < 10; ++q) {
+      sG[ij[q][0] * 4 + ij[q][1]] = gp[q];
+      sG[ij[q][1] * 4 + ij[q][0]] = gp[q];
     }
   }
   __syncthreads();
-  // ---- ARR: reg = sum_r ||W[r+1]-W[r]||^2 ; dreg/dW[r] = 2 (D[r-1] - D[r]),  D[r] = W[r+1]-W[r]
-  float reg = 0.f;
-  {
-    float bs[4][4];   // basis[b][e] for this thread's (up to 4) elements
-    int ne = 0;
-    for (int e = tid; e < nE && ne < 4; e += IGMC_BLOCK, ++ne)
-      for (int bb = 0; bb < 4; ++bb) bs[bb][ne] = basis[bb * nE + e];
-    float gbas[4][4];
-    for (int bb = 0; bb < 4; ++bb)
-      for (int q = 0; q < 4; ++q) gbas[bb][q] = 0.f;
-    float wprev[4] = {0.f, 0.f, 0.f, 0.f}, wcur[4] = {0.f, 0.f, 0.f, 0.f}, wnext[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int q = 0; q < ne; ++q) {
-      float s = 0.f;
-      for (int bb = 0; bb < 4; ++bb) s += att[bb] * bs[bb][q];
-      wcur[q] = s;
-    }
+  // c[r][b] = 2 (d[r-1][b] - d[r][b]),  d[r] = att[r+1]-att[r]  (d[-1] = d[R-1] = 0)
+  if (tid < 16) {           // M[b][b'] = sum_r att[r,b] c[r,b']
+    const int bb = tid >> 2, bp = tid & 3;
+    float s = 0.f;
     for (int r = 0; r < m.R; ++r) {
-      float pa[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int q = 0; q < ne; ++q) {
-        float dw = 0.f;
-        if (r + 1 < m.R) {
-          float s = 0.f;
-          for (int bb = 0; bb < 4; ++bb) s += att[(r + 1) * 4 + bb] * bs[bb][q];
-          wnext[q] = s;
-          const float dn = wnext[q] - wcur[q];
-          reg += dn * dn;
-          dw -= 2.f * dn;
-        }
-        if (r > 0) dw += 2.f * (wcur[q] - wprev[q]);
-        for (int bb = 0; bb < 4; ++bb) {
-          gbas[bb][q] += att[r * 4 + bb] * dw;
-          pa[bb] += dw * bs[bb][q];
-        }
-      }
-      for (int bb = 0; bb < 4; ++bb) {
-        const float s = igmc_block_sum_f(pa[bb], smf);
-        if (tid == 0 && arr_coef != 0.f) ga[r * 4 + bb] += arr_coef * s;
-      }
-      for (int q = 0; q < ne; ++q) {
-        wprev[q] = wcur[q];
-        wcur[q] = wnext[q];
-      }
+      const float dm = (r > 0) ? att[r * 4 + bp] - att[(r - 1) * 4 + bp] : 0.f;
+      const float dn = (r + 1 < m.R) ? att[(r + 1) * 4 + bp] - att[r * 4 + bp] : 0.f;
+      s += att[r * 4 + bb] * 2.f * (dm - dn);
     }
-    if (arr_coef != 0.f) {
-      int q = 0;
-      for (int e = tid; e < nE && q < 4; e += IGMC_BLOCK, ++q)
-        for (int bb = 0; bb < 4; ++bb) gb[bb * nE + e] += arr_coef * gbas[bb][q];
+    sM[tid] = s;
+  }
+  if (tid == 64) {          // reg = sum_r d[r]^T Gm d[r]
+    float reg = 0.f;
+    for (int r = 0; r + 1 < m.R; ++r) {
+      float d[4];
+      for (int q = 0; q < 4; ++q) d[q] = att[(r + 1) * 4 + q] - att[r * 4 + q];
+      for (int p1 = 0; p1 < 4; ++p1)
+        for (int p2 = 0; p2 < 4; ++p2) reg += d[p1] * sG[p1 * 4 + p2] * d[p2];
+    }
+    m.arr_part[l] = reg;
+  }
+  __syncthreads();
+  if (arr_coef != 0.f) {
+    for (int rb = tid; rb < na; rb += IGMC_BLOCK) {
+      const int r = rb >> 2, bb = rb & 3;
+      float s = 0.f;
+      for (int bp = 0; bp < 4; ++bp) {
+        const float dm = (r > 0) ? att[r * 4 + bp] - att[(r - 1) * 4 + bp] : 0.f;
+        const float dn = (r + 1 < m.R) ? att[(r + 1) * 4 + bp] - att[r * 4 + bp] : 0.f;
+        s += 2.f * (dm - dn) * sG[bp * 4 + bb];
+      }
+      ga[rb] += arr_coef * s;
+    }
+    for (int e = tid; e < nE; e += IGMC_BLOCK) {
+      const float b0 = basis[e], b1 = basis[nE + e], b2 = basis[2 * nE + e], b3 = basis[3 * nE + e];
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb)
+        gb[bb * nE + e] += arr_coef * (sM[bb * 4 + 0] * b0 + sM[bb * 4 + 1] * b1 + sM[bb * 4 + 2] * b2 + sM[bb * 4 + 3] * b3);
     }
   }
-  reg = igmc_block_sum_f(reg, smf);
-  if (tid == 0) m.arr_part[l] = reg;
 }
 
 // loss[0] = mean_g err^2 + ARR * sum_l reg_l   (reference train_eval.py:162-174); loss[1] = sum err^2
@@ -738,7 +782,16 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_sse_acc(BatchDev b, const float*
 __global__ __launch_bounds__(IGMC_BLOCK) void k_adam(float* __restrict__ p, const float* __restrict__ g,
                                                        float* __restrict__ m1, float* __restrict__ m2, int64_t n,
                                                        float step_size, float inv_sqrt_bc2, float beta1, float beta2,
-                                                       float eps, float wd) {
+                                                       float eps, float wd, const int64_t* ctrl) {
+  if (ctrl) {      // hipGraph replay: the scalars live in HBM (igmc_ctrl_tick keeps them current)
+    const double* d = (const double*)ctrl;
+    step_size = (float)d[IGMC_CTRL_STEP_SIZE];
+    inv_sqrt_bc2 = (float)d[IGMC_CTRL_INV_SQRT_BC2];
+    beta1 = (float)d[IGMC_CTRL_BETA1];
+    beta2 = (float)d[IGMC_CTRL_BETA2];
+    eps = (float)d[IGMC_CTRL_EPS];
+    wd = (float)d[IGMC_CTRL_WD];
+  }
   for (int64_t i = (int64_t)blockIdx.x * IGMC_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * IGMC_BLOCK) {
     float gi = g[i];
     const float pi = p[i];
@@ -769,11 +822,16 @@ void igmc_launch_forward(const ModelDev& m, const BatchDev& b, const float* P, i
                          int use_flags, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
                          float* out, void* stream) {
   IGMC_PLAUNCH("k_prep", k_prep, 64, IGMC_BLOCK, 0, stream, m, P, training);
-  const size_t l0s = (size_t)(m.R * m.L * 32 + m.L * 32 + 32) * sizeof(float);
+  const size_t l0s = (size_t)(m.R * m.L * 32 + m.L * 32 + 32) * sizeof(float) + (size_t)4 * m.R * m.L * sizeof(int);
   const int g16 = igmc_rows_grid(m.node_cap, 4, IGMC_GATHER_BLOCKS);   // one wave per row, 4 rows per block
   const int g64 = igmc_rows_grid(m.node_cap, 64, 512);
-  if (use_flags) IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<true>), g16, IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
-  else IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<false>), g16, IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
+  if (training) {
+    if (use_flags) IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<true, true>), g16, IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
+    else IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<false, true>), g16, IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
+  } else {
+    if (use_flags) IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<true, false>), g16, IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
+    else IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<false, false>), g16, IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
+  }
   const size_t gs = (size_t)(m.R * 4) * sizeof(float);
   const size_t ds = (size_t)IGMC_KCAT * (32 + 4) * sizeof(float);
   for (int l = 1; l < 4; ++l) {
@@ -786,10 +844,11 @@ void igmc_launch_forward(const ModelDev& m, const BatchDev& b, const float* P, i
     // [agg | h_{l-1}] @ [basis ; root]  (contiguous in the flat parameter buffer) + bias, tanh
     IGMC_PLAUNCH("k_dense_fwd", (k_dense<128, 32, 32, EPI_BIAS_TANH>), g64, IGMC_BLOCK, ds, stream, b,
                  (const float*)m.agg, (const float*)m.h[l - 1], P + m.off_basis[l], P + m.off_bias[l], m.h[l],
-                 (const float*)nullptr, (const float*)nullptr, 0, 0);
+                 (const float*)nullptr, (const float*)nullptr, 0, 0,
+                 (float*)((training && l == 3) ? m.dpre[1] : nullptr));   // clear dPre of the top layer
   }
-  IGMC_PLAUNCH("k_head_fwd", k_head_fwd, B, 128, (size_t)m.D * sizeof(float), stream, b, m, P, training, inj_mask,
-               seed, step, mult, out);
+  IGMC_PLAUNCH("k_head_fwd", k_head_fwd, (B + IGMC_HG - 1) / IGMC_HG, 128, (size_t)IGMC_HG * m.D * sizeof(float),
+               stream, b, m, P, training, inj_mask, seed, step, mult, out);
 }
 
 void igmc_launch_backward(const ModelDev& m, const BatchDev& b, const float* P, int B, int use_flags,
@@ -797,9 +856,8 @@ void igmc_launch_backward(const ModelDev& m, const BatchDev& b, const float* P, 
                           float arr_coef, float* grad, void* stream) {
   const int g16 = igmc_rows_grid(m.node_cap, 4, IGMC_GATHER_BLOCKS);
   const int g64 = igmc_rows_grid(m.node_cap, 64, 512);
-  IGMC_PLAUNCH("k_zero_rows", k_zero_rows, 256, IGMC_BLOCK, 0, stream, b, m.dpre[1], 32);
-  IGMC_PLAUNCH("k_head_bwd_a", k_head_bwd_a, B, 128, 0, stream, b, m, P, gout, from_err, grad_scale, mult,
-               drop_scale, m.dpre[1]);
+  IGMC_PLAUNCH("k_head_bwd_a", k_head_bwd_a, (B + IGMC_HG - 1) / IGMC_HG, IGMC_BLOCK, 0, stream, b, m, P, gout,
+               from_err, grad_scale, mult, drop_scale, m.dpre[1]);
   const int nhw = (128 * m.D + 257 + IGMC_BLOCK - 1) / IGMC_BLOCK;
   IGMC_PLAUNCH("k_head_bwd_w", k_head_bwd_w, nhw, IGMC_BLOCK, 0, stream, b, m, P, gout, from_err, grad_scale, mult,
                drop_scale, grad);
@@ -812,7 +870,7 @@ void igmc_launch_backward(const ModelDev& m, const BatchDev& b, const float* P, 
     float* dnext = m.dpre[(l - 1) & 1];
     IGMC_PLAUNCH("k_dense_y", (k_dense<0, 32, 128, EPI_NONE>), g64, IGMC_BLOCK, ysz, stream, b,
                  (const float*)nullptr, (const float*)m.h[l - 1], (const float*)m.bcat[l], (const float*)nullptr, m.Y,
-                 (const float*)nullptr, (const float*)nullptr, 0, 0);
+                 (const float*)nullptr, (const float*)nullptr, 0, 0, (float*)nullptr);
     float* gp = m.gatt_part + (size_t)(l - 1) * IGMC_GATHER_BLOCKS * na;
     if (use_flags)
       IGMC_PLAUNCH("k_rgcn_gather_bwd", (k_rgcn_gather<true, true, true>), g16, IGMC_BLOCK, gsa, stream,
@@ -822,21 +880,15 @@ void igmc_launch_backward(const ModelDev& m, const BatchDev& b, const float* P, 
                    b, m.R, (const float*)dcur, P + m.off_att[l], m.agg, (const float*)m.Y, gp);
     IGMC_PLAUNCH("k_dense_bwd", (k_dense<128, 32, 32, EPI_BWD>), g64, IGMC_BLOCK, ds, stream, b, (const float*)m.agg,
                  (const float*)dcur, (const float*)m.wT[l], (const float*)nullptr, dnext, (const float*)m.h[l - 1],
-                 (const float*)m.gfeat, m.D, l - 1);
+                 (const float*)m.gfeat, m.D, l - 1, (float*)nullptr);
     IGMC_PLAUNCH("k_wgrad", k_wgrad, IGMC_WG_BLOCKS, IGMC_BLOCK, 0, stream, b, (const float*)m.h[l - 1],
                  (const float*)m.agg, (const float*)dcur, m.wg_part + (size_t)(l - 1) * IGMC_WG_BLOCKS * wgs);
   }
   const int rows0 = m.R * m.L + m.L + 1;
-  const bool priv = (size_t)16 * rows0 * 32 * sizeof(float) <= 96 * 1024;   // opt-in done by igmc_model_prepare
-  const size_t l0s = (size_t)(priv ? 16 : 1) * rows0 * 32 * sizeof(float);
   const float* d0 = m.dpre[0];
-  if (use_flags) {
-    if (priv) IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<true, true>), IGMC_L0_BLOCKS, IGMC_BLOCK, l0s, stream, b, m, d0, m.l0_part);
-    else IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<true, false>), IGMC_L0_BLOCKS, IGMC_BLOCK, l0s, stream, b, m, d0, m.l0_part);
-  } else {
-    if (priv) IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<false, true>), IGMC_L0_BLOCKS, IGMC_BLOCK, l0s, stream, b, m, d0, m.l0_part);
-    else IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<false, false>), IGMC_L0_BLOCKS, IGMC_BLOCK, l0s, stream, b, m, d0, m.l0_part);
-  }
+  if (rows0 <= 32) IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<4>), IGMC_L0_BLOCKS, IGMC_BLOCK, 0, stream, b, m, d0, m.l0_part);
+  else if (rows0 <= 64) IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<8>), IGMC_L0_BLOCKS, IGMC_BLOCK, 0, stream, b, m, d0, m.l0_part);
+  else IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<40>), IGMC_L0_BLOCKS, IGMC_BLOCK, 0, stream, b, m, d0, m.l0_part);
   {
     const int wgs2 = igmc_wg_stride(), n0 = rows0 * 32;
     const int nblk = (3 * wgs2 + 63) / 64 + (n0 + 63) / 64 + (3 * na + 3) / 4;
@@ -854,32 +906,16 @@ void igmc_launch_sse(const BatchDev& b, const float* out, double* acc, void* str
 }
 
 void igmc_launch_adam(float* p, const float* g, float* m1, float* m2, int64_t n, float step_size,
-                      float inv_sqrt_bc2, float beta1, float beta2, float eps, float wd, void* stream) {
+                      float inv_sqrt_bc2, float beta1, float beta2, float eps, float wd, const int64_t* ctrl,
+                      void* stream) {
   int grid = (int)((n + IGMC_BLOCK - 1) / IGMC_BLOCK);
   if (grid > 1024) grid = 1024;
   if (grid < 1) grid = 1;
   IGMC_PLAUNCH("k_adam", k_adam, grid, IGMC_BLOCK, 0, stream, p, g, m1, m2, n, step_size, inv_sqrt_bc2, beta1, beta2,
-               eps, wd);
+               eps, wd, ctrl);
 }
 
-// dynamic LDS above 64 KB needs an explicit opt-in on HIP (layer-0 backward tables)
 int igmc_model_prepare(const ModelDev& m) {
-#ifndef IGMC_HIPEMU
-  const int rows0 = m.R * m.L + m.L + 1;
-  const bool priv = (size_t)16 * rows0 * 32 * sizeof(float) <= 96 * 1024;
-  const int l0s = (int)((size_t)(priv ? 16 : 1) * rows0 * 32 * sizeof(float));
-  if (l0s > 48 * 1024) {
-    hipError_t e = hipSuccess;
-    if (priv) {
-      e = hipFuncSetAttribute((const void*)k_l0_bwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l0s);
-      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_l0_bwd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l0s);
-    } else {
-      e = hipFuncSetAttribute((const void*)k_l0_bwd<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l0s);
-      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_l0_bwd<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, l0s);
-    }
-    if (e != hipSuccess) return 1;
-  }
-#endif
   (void)m;
   return 0;
 }

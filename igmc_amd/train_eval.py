@@ -22,6 +22,7 @@ import torch.nn.functional as F
 
 from . import _lib, engine, parallel
 from .models import IGMC
+from .stepgraph import StepGraph
 from .util_functions import DeviceBatch
 
 device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
@@ -50,18 +51,20 @@ class DataLoader(object):
     def __len__(self):
         return (self._n_local() + self.batch_size - 1) // self.batch_size
 
-    def __iter__(self):
+    def epoch_positions(self):
+        """Start a new epoch: this rank's link positions (1-D CPU int64 tensor), shuffled when requested."""
         self.epoch += 1
         n = len(self.dataset)
-        dev = self.dataset.link_y.device
         if self.shuffle:
             gen = torch.Generator()
             gen.manual_seed(self._base_seed + 7919 * self.epoch)
             perm = torch.randperm(n, generator=gen)
         else:
             perm = torch.arange(n)
-        perm = parallel.shard_positions(perm, parallel.rank(), parallel.world_size(), pad=self.pad_shards)
-        perm = perm.to(device=dev, dtype=torch.int32)
+        return parallel.shard_positions(perm, parallel.rank(), parallel.world_size(), pad=self.pad_shards)
+
+    def __iter__(self):
+        perm = self.epoch_positions().to(device=self.dataset.link_y.device, dtype=torch.int32)
         nl = len(perm)
         for first in range(0, nl, self.batch_size):
             B = min(self.batch_size, nl - first)
@@ -209,37 +212,20 @@ def train(model, optimizer, loader, device, regression=False, ARR=0, show_progre
     G = parallel.world_size()
     n_total = 0
     if isinstance(optimizer, FlatAdam):
-        # ---- fused path: no autograd, no host sync inside the epoch
-        flat, grad = model.flat_parameters(), model.flat_grad()
-        dev = flat.device
-        loss_buf = torch.zeros(2, dtype=torch.float32, device=dev)
-        total = torch.zeros(1, dtype=torch.float64, device=dev)
-        out = None
-        for data in loader:
-            ws = model._workspace(data)
-            st = torch.cuda.current_stream().cuda_stream
-            B = data.num_graphs
-            if out is None or out.numel() < B:
-                out = torch.empty(max(B, loader.batch_size), dtype=torch.float32, device=dev)
-            model._step += 1
-            use_flags = model.adj_dropout > 0
-            if use_flags:
-                data.arena.edge_dropout(model.adj_dropout, model.force_undirected, model.seed, model._step, st)
-            # global-batch mean under DP (every rank has the same B thanks to padded shards)
-            ws.loss_grad(flat.data_ptr(), data.arena, out.data_ptr(), grad.data_ptr(), loss_buf.data_ptr(),
-                         use_edge_flags=use_flags, seed=model.seed, step=model._step,
-                         multiply_by=float(model.multiply_by), ARR=float(ARR), grad_scale=1.0 / (B * G),
-                         arr_scale=1.0 / G, stream=st)
-            if G > 1:
-                parallel.all_reduce_sum_(grad)      # ONE flat all-reduce per step (RCCL over xGMI)
-            optimizer.step()
-            total += loss_buf[0].double() * B
-            n_total += B
+        # ---- fused path: no autograd, no host sync inside the epoch; the step is replayed as a hipGraph
+        sg = getattr(loader, '_stepgraph', None)
+        if sg is None or sg.model is not model or sg.opt is not optimizer or sg.ARR != float(ARR):
+            if sg is not None:
+                sg.detach()
+            sg = StepGraph(model, optimizer, loader.dataset, loader.batch_size, ARR)
+            loader._stepgraph = sg
+        total, n_total = sg.run_epoch(loader.epoch_positions(), loader.epoch)
         if G > 1:
-            cnt = torch.tensor([float(n_total)], dtype=torch.float64, device=dev)
-            parallel.all_reduce_sum_(total)
+            cnt = torch.tensor([float(n_total)], dtype=torch.float64, device=total.device)
+            tot = total.clone()
+            parallel.all_reduce_sum_(tot)
             parallel.all_reduce_sum_(cnt)
-            return float(total.item() / cnt.item())
+            return float(tot.item() / cnt.item())
         return float(total.item()) / max(len(loader.dataset), 1)
     # ---- generic path: any torch optimiser through the differentiable forward (reference-style loop)
     total_loss = 0.0

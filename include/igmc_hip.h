@@ -159,6 +159,23 @@ int igmc_adam_step(float* d_params, const float* d_grad, float* d_exp_avg, float
                    int64_t n, int64_t step, float lr, float beta1, float beta2, float eps,
                    float weight_decay, void* stream);
 
+/* ------------------------------------------------------------------ device-side step control
+ * A hipGraph replay cannot change kernel arguments, so the per-step scalars can live in HBM instead:
+ * d_ctrl is an int64[IGMC_CTRL_WORDS] device buffer (slots 8.. hold doubles, bit-cast):
+ *   [0] step   [1] first (offset into the link permutation)   [2] epoch   [3] adam_t   [4] batch size
+ *   [8] lr  [9] beta1  [10] beta2  [11] eps  [12] weight_decay   [13] lr/(1-beta1^t)  [14] 1/sqrt(1-beta2^t)
+ * igmc_ctrl_tick advances it on the device: step+=1, first+=batch, adam_t+=1, slots 13/14 recomputed.
+ * Once attached, igmc_extract_batch takes first/epoch, igmc_batch_edge_dropout and the forward's MLP dropout
+ * take `step` from it (the host arguments are ignored); NULL detaches. */
+enum { IGMC_CTRL_STEP = 0, IGMC_CTRL_FIRST = 1, IGMC_CTRL_EPOCH = 2, IGMC_CTRL_ADAM_T = 3, IGMC_CTRL_BATCH = 4,
+       IGMC_CTRL_LR = 8, IGMC_CTRL_BETA1 = 9, IGMC_CTRL_BETA2 = 10, IGMC_CTRL_EPS = 11, IGMC_CTRL_WD = 12,
+       IGMC_CTRL_STEP_SIZE = 13, IGMC_CTRL_INV_SQRT_BC2 = 14, IGMC_CTRL_WORDS = 16 };
+int igmc_ctrl_tick(int64_t* d_ctrl, void* stream);
+int igmc_batch_set_ctrl(igmc_batch* b, const int64_t* d_ctrl);
+int igmc_model_set_ctrl(igmc_model* m, const int64_t* d_ctrl);
+int igmc_adam_step_ctrl(float* d_params, const float* d_grad, float* d_exp_avg, float* d_exp_avg_sq,
+                        int64_t n, const int64_t* d_ctrl, void* stream);
+
 /* Eval reduction helper (reference train_eval.py:195): d_acc[0] += sum_g (out-y)^2, d_acc[1] += B. */
 int igmc_sse_accumulate(const float* d_out, const igmc_batch* b, double* d_acc, void* stream);
 

@@ -1,0 +1,79 @@
+"""Device-side step control (the hipGraph-replay mode): with the control block attached, the kernels must take
+first / epoch / step / Adam scalars from HBM and produce exactly what the host-argument path produces
+(kernel logic on the CPU emulation of the HIP sources)."""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+import parity_checks as PC
+from helpers import load_extract_golden
+from igmc_amd import _lib, engine
+
+CASES = load_extract_golden()
+
+
+def ctrl_words(step, first, epoch, adam_t, batch, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, wd=0.0):
+    w = np.zeros(_lib.CTRL['WORDS'], np.int64)
+    w[0], w[1], w[2], w[3], w[4] = step, first, epoch, adam_t, batch
+    for k, v in ((8, lr), (9, b1), (10, b2), (11, eps), (12, wd)):
+        w[k] = struct.unpack('<q', struct.pack('<d', float(v)))[0]
+    return w
+
+
+def test_ctrl_path_equals_host_argument_path():
+    be = PC.EmuBackend()
+    lib = be.lib
+    case = CASES['synth_cap']
+    A = case['A']
+    g = engine.Graph(A, lib=lib)
+    n = len(case['links'])
+    lu = case['links'][:, 0].astype(np.int32).copy()
+    lv = case['links'][:, 1].astype(np.int32).copy()
+    ly = case['class_values'][case['link_labels']].astype(np.float32)
+    perm = np.random.default_rng(0).permutation(n).astype(np.int32)
+    B = 4
+    b1 = engine.Batch(g, B, 1, case['mnph'])
+    b2 = engine.Batch(g, B, 1, case['mnph'])
+    ws = engine.ModelWorkspace(lib, 0, 5, 4, 4, 0, b1.node_capacity, b1.edge_capacity, B)
+    ref = PC.make_ref_model(4, 5, seed=4)
+    P0 = PC.flatten_params(ws, ref)
+    outs = {}
+    for mode in ('host', 'ctrl'):
+        P, M1, M2 = P0.copy(), np.zeros_like(P0), np.zeros_like(P0)
+        G, out, loss = np.zeros_like(P0), np.zeros(B, np.float32), np.zeros(2, np.float32)
+        batch = b1 if mode == 'host' else b2
+        ctrl = ctrl_words(step=10, first=-B, epoch=3, adam_t=0, batch=B)
+        if mode == 'ctrl':
+            lib.call('igmc_batch_set_ctrl', batch.handle, C.c_void_p(ctrl.ctypes.data))
+            lib.call('igmc_model_set_ctrl', ws.handle, C.c_void_p(ctrl.ctypes.data))
+        else:
+            lib.call('igmc_model_set_ctrl', ws.handle, None)
+        rec = []
+        for i in range(3):
+            if mode == 'ctrl':
+                lib.call('igmc_ctrl_tick', C.c_void_p(ctrl.ctypes.data), None)
+                batch.extract(lu, lv, ly, perm, 12345, B, 1.0, 7, 999)          # first/epoch args ignored
+                batch.edge_dropout(0.2, False, 7, 424242)                        # step arg ignored
+                ws.loss_grad(P.ctypes.data, batch, out.ctypes.data, G.ctypes.data, loss.ctypes.data,
+                             use_edge_flags=True, seed=7, step=424242, ARR=0.001)
+                lib.call('igmc_adam_step_ctrl', C.c_void_p(P.ctypes.data), C.c_void_p(G.ctypes.data),
+                         C.c_void_p(M1.ctypes.data), C.c_void_p(M2.ctypes.data), len(P), C.c_void_p(ctrl.ctypes.data), None)
+            else:
+                batch.extract(lu, lv, ly, perm, i * B, B, 1.0, 7, 3)
+                batch.edge_dropout(0.2, False, 7, 11 + i)
+                ws.loss_grad(P.ctypes.data, batch, out.ctypes.data, G.ctypes.data, loss.ctypes.data,
+                             use_edge_flags=True, seed=7, step=11 + i, ARR=0.001)
+                ws.adam_step(P.ctypes.data, G.ctypes.data, M1.ctypes.data, M2.ctypes.data, i + 1, 1e-3)
+            d = batch.download()
+            rec.append((d['node_gid'].copy(), d['eflag'].copy(), out.copy(), loss.copy(), P.copy()))
+        outs[mode] = rec
+        if mode == 'ctrl':
+            assert ctrl[0] == 13 and ctrl[1] == 2 * B and ctrl[3] == 3
+    for a, b in zip(outs['host'], outs['ctrl']):
+        for x, y in zip(a[:2], b[:2]):
+            assert np.array_equal(x, y)          # same links, same sampling, same dropout flags
+        # lr is a float argument on the host path and a double in the control block: last-ulp differences only
+        for x, y in zip(a[2:], b[2:]):
+            np.testing.assert_allclose(x, y, rtol=2e-5, atol=1e-7)
