@@ -459,14 +459,11 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   Allocs& M = m->mem;
   int fail = 0;
   const size_t N = (size_t)max_nodes, Bc = (size_t)max_graphs;
-  for (int l = 0; l < 4; ++l) fail |= M.get(&d.h[l], N * 32);
-  fail |= M.get(&d.agg, N * 128) | M.get(&d.Y, N * 128) | M.get(&d.dpre[0], N * 32) | M.get(&d.dpre[1], N * 32);
+  for (int l = 0; l < 4; ++l) fail |= M.get(&d.h[l], N * 32) | M.get(&d.dpre[l], N * 32);
+  fail |= M.get(&d.agg, N * 128);
+  for (int l = 0; l < 3; ++l) fail |= M.get(&d.gagg[l], N * 128) | M.get(&d.Y[l], N * 128);
   fail |= M.get(&d.feat, Bc * d.D) | M.get(&d.a1, Bc * 128) | M.get(&d.lmask, Bc * 128) | M.get(&d.dz, Bc * 128) |
-          M.get(&d.gfeat, Bc * d.D) | M.get(&d.err, Bc) | M.get(&d.gout, Bc);
-  fail |= M.get(&d.W0, (size_t)d.R * d.L * 32) | M.get(&d.w1T, (size_t)d.D * 128) | M.get(&d.cnt0, N * d.R * d.L);
-  d.wT[0] = nullptr;
-  d.bcat[0] = nullptr;
-  for (int l = 1; l < 4; ++l) fail |= M.get(&d.wT[l], (size_t)IGMC_KCAT * 32) | M.get(&d.bcat[l], (size_t)32 * 128);
+          M.get(&d.gfeat, Bc * d.D) | M.get(&d.err, Bc) | M.get(&d.cnt0, N * d.R * d.L);
   const size_t rows0 = (size_t)d.R * d.L + d.L + 1;
   fail |= M.get(&d.wg_part, (size_t)3 * IGMC_WG_BLOCKS * igmc_wg_stride()) |
           M.get(&d.gatt_part, (size_t)3 * IGMC_GATHER_BLOCKS * d.R * 4) |
@@ -559,13 +556,13 @@ extern "C" int igmc_model_loss_grad(igmc_model* m, const float* d_params, const 
                                     float* d_loss, void* stream) {
   std::string why;
   if (check_fit(m, b, &why)) IGMC_FAIL(why);
-  if (!d_params || !d_out || !d_grad || !d_loss) IGMC_FAIL("null buffer");
+  if (!d_params || !d_out || !d_grad) IGMC_FAIL("null buffer");
   m->d.side = b->side;
   igmc_launch_forward(m->d, b->d, d_params, b->last_B, 1, use_edge_flags, d_lin_mask, seed, step, multiply_by, d_out,
                       stream);
   igmc_launch_backward(m->d, b->d, d_params, b->last_B, use_edge_flags, nullptr, 1, grad_scale, multiply_by, 2.f,
                        ARR * arr_scale, d_grad, stream);
-  igmc_launch_loss(m->d, b->d, ARR, d_loss, stream);
+  if (d_loss) igmc_launch_loss(m->d, b->d, ARR, d_loss, stream);
   HIPCHECK(hipGetLastError());
   m->last_B = b->last_B;
   m->last_training = 1;
@@ -580,7 +577,7 @@ extern "C" int igmc_adam_step(float* d_params, const float* d_grad, float* d_exp
   const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
   const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
   igmc_launch_adam(d_params, d_grad, d_exp_avg, d_exp_avg_sq, n, (float)((double)lr / bc1),
-                   (float)(1.0 / std::sqrt(bc2)), beta1, beta2, eps, weight_decay, nullptr, stream);
+                   (float)(1.0 / std::sqrt(bc2)), beta1, beta2, eps, weight_decay, nullptr, 0, stream);
   HIPCHECK(hipGetLastError());
   return 0;
 }
@@ -612,7 +609,26 @@ extern "C" int igmc_model_set_ctrl(igmc_model* m, const int64_t* d_ctrl) {
 extern "C" int igmc_adam_step_ctrl(float* d_params, const float* d_grad, float* d_exp_avg, float* d_exp_avg_sq,
                                    int64_t n, const int64_t* d_ctrl, void* stream) {
   if (!d_params || !d_grad || !d_exp_avg || !d_exp_avg_sq || n <= 0 || !d_ctrl) IGMC_FAIL("bad arguments");
-  igmc_launch_adam(d_params, d_grad, d_exp_avg, d_exp_avg_sq, n, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, d_ctrl, stream);
+  igmc_launch_adam(d_params, d_grad, d_exp_avg, d_exp_avg_sq, n, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, (int64_t*)d_ctrl, 0, stream);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int igmc_step_finish(igmc_model* m, const igmc_batch* b, float* d_params, const float* d_grad,
+                                float* d_exp_avg, float* d_exp_avg_sq, float ARR, float* d_loss, double* d_total,
+                                int64_t* d_ctrl, int64_t step, float lr, float beta1, float beta2, float eps,
+                                float weight_decay, void* stream) {
+  if (!m || !b || !d_params || !d_grad || !d_exp_avg || !d_exp_avg_sq || !d_loss) IGMC_FAIL("bad arguments");
+  if (!d_ctrl && step < 1) IGMC_FAIL("step must be >= 1");
+  float step_size = 0.f, inv = 0.f;
+  if (!d_ctrl) {
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    step_size = (float)((double)lr / bc1);
+    inv = (float)(1.0 / std::sqrt(bc2));
+  }
+  igmc_launch_finish(m->d, b->d, d_params, d_grad, d_exp_avg, d_exp_avg_sq, step_size, inv, beta1, beta2, eps,
+                     weight_decay, d_ctrl, ARR, d_loss, d_total, stream);
   HIPCHECK(hipGetLastError());
   return 0;
 }

@@ -20,8 +20,7 @@
 //
 // Kernels:  k_extract_nodes (BFS + per-hop sampling -> node lists; one workgroup per link)
 //           k_count         (induced degree of every selected node; S workgroups per link)
-//           k_scan_offsets  (node / edge offsets of the collated batch)
-//           k_fill          (dst-sorted CSR of the batch, labels, PyG `batch` vector; S per link)
+//           k_fill          (batch offsets + dst-sorted CSR of the batch, labels, PyG `batch` vector; S per link)
 //           k_edge_flags    (edge dropout keep flags, reference models.py:193-198)
 #include "launch.h"
 
@@ -341,46 +340,42 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_count(GraphDev G, BatchDev b) {
   if (lane == 0 && etot) atomicAdd(&b.edge_cnt[g], etot);   // integer: order-independent
 }
 
-// ---------------------------------------------------------------- kernel 3
-__global__ __launch_bounds__(IGMC_BLOCK) void k_scan_offsets(BatchDev b, int B) {
-  __shared__ int sm[16];
-  int run_n = 0, run_e = 0;
-  for (int base = 0; base < B; base += IGMC_BLOCK) {
-    const int i = base + threadIdx.x;
-    const int n = (i < B) ? b.n_users[i] + b.n_items[i] : 0;
-    const int e = (i < B) ? b.edge_cnt[i] : 0;
-    int tn, te;
-    const int xn = igmc_block_scan_excl(n, &tn, sm);
-    const int xe = igmc_block_scan_excl(e, &te, sm);
-    if (i < B) {
-      b.node_off[i] = run_n + xn;
-      b.edge_off[i] = run_e + xe;
-    }
-    run_n += tn;
-    run_e += te;
-  }
-  if (threadIdx.x == 0) {
-    b.node_off[B] = run_n;
-    b.edge_off[B] = run_e;
-    const int ovf = (run_n > b.node_cap) || (run_e > b.edge_cap);
-    b.totals[0] = ovf ? 0 : run_n;
-    b.totals[1] = ovf ? 0 : run_e;
-    b.totals[2] = ovf;
-    b.totals[3] = B;
-    b.totals[4] = run_n;
-    b.totals[5] = run_e;
-    if (!ovf) b.row_ptr[run_n] = run_e;
-  }
-}
-
 // ---------------------------------------------------------------- kernel 4: CSR fill
 // Entry layout: ecr = source node (24 bits) | relation << 24 ;  ecode = relation*L + label(source).
 __global__ __launch_bounds__(IGMC_BLOCK) void k_fill(GraphDev G, BatchDev b) {
   IGMC_DYN_SMEM(smem);
   __shared__ int sm[16];
-  if (b.totals[2]) return;
-  const int g = blockIdx.x;
+  const int g = blockIdx.x, B = gridDim.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // batch-wide node / edge offsets: every workgroup derives them from the per-graph counts (B is small), the
+  // y == 0 workgroup of each graph publishes them -- no separate scan launch.
+  int nb = 0, eb = 0, totn = 0, tote = 0;
+  for (int base = 0; base < B; base += IGMC_BLOCK) {
+    const int i = base + tid;
+    const int n = (i < B) ? b.n_users[i] + b.n_items[i] : 0;
+    const int e = (i < B) ? b.edge_cnt[i] : 0;
+    nb += igmc_block_sum_i(i < g ? n : 0, sm);
+    eb += igmc_block_sum_i(i < g ? e : 0, sm);
+    totn += igmc_block_sum_i(n, sm);
+    tote += igmc_block_sum_i(e, sm);
+  }
+  const int ovf = (totn > b.node_cap) || (tote > b.edge_cap);
+  if (blockIdx.y == 0 && tid == 0) {
+    b.node_off[g] = nb;
+    b.edge_off[g] = eb;
+    if (g == 0) {
+      b.node_off[B] = totn;
+      b.edge_off[B] = tote;
+      b.totals[0] = ovf ? 0 : totn;
+      b.totals[1] = ovf ? 0 : tote;
+      b.totals[2] = ovf;
+      b.totals[3] = B;
+      b.totals[4] = totn;
+      b.totals[5] = tote;
+      if (!ovf) b.row_ptr[totn] = tote;
+    }
+  }
+  if (ovf) return;
   const int Wu = (G.n_users + 31) >> 5, Wv = (G.n_items + 31) >> 5;
   uint32_t* sel_u = (uint32_t*)smem;
   uint32_t* pre_u = sel_u + Wu;
@@ -392,7 +387,6 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_fill(GraphDev G, BatchDev b) {
   const uint8_t* sl = b.s_lab + so;
   const int32_t* sd = b.s_deg + so;
   const int cu = b.n_users[g], cv = b.n_items[g];
-  const int nb = b.node_off[g], eb = b.edge_off[g];
   const int u0 = sg[0], v0 = sg[cap_u];
   const int L = b.num_labels;
 
@@ -516,7 +510,6 @@ void igmc_launch_extract(const GraphDev& g, const BatchDev& b, const int32_t* li
   S = S < 1 ? 1 : (S > 16 ? 16 : S);
   IGMC_PLAUNCH("k_extract_nodes", k_extract_nodes, B, IGMC_BLOCK, smem, stream, a);
   IGMC_PLAUNCH("k_count", k_count, dim3(B, S), IGMC_BLOCK, smem / 4, stream, g, b);
-  IGMC_PLAUNCH("k_scan_offsets", k_scan_offsets, 1, IGMC_BLOCK, 0, stream, b, B);
   IGMC_PLAUNCH("k_fill", k_fill, dim3(B, S), IGMC_BLOCK, smem / 2, stream, g, b);
 }
 
@@ -541,15 +534,3 @@ int igmc_extract_prepare(size_t smem) {
   return 0;
 }
 
-// advance the device-side step control (see igmc_hip.h)
-__global__ void k_tick(int64_t* ctrl) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double* d = (double*)ctrl;
-  ctrl[IGMC_CTRL_STEP] += 1;
-  ctrl[IGMC_CTRL_FIRST] += ctrl[IGMC_CTRL_BATCH];
-  ctrl[IGMC_CTRL_ADAM_T] += 1;
-  const double t = (double)ctrl[IGMC_CTRL_ADAM_T];
-  d[IGMC_CTRL_STEP_SIZE] = d[IGMC_CTRL_LR] / (1.0 - pow(d[IGMC_CTRL_BETA1], t));
-  d[IGMC_CTRL_INV_SQRT_BC2] = 1.0 / sqrt(1.0 - pow(d[IGMC_CTRL_BETA2], t));
-}
-void igmc_launch_tick(int64_t* ctrl, void* stream) { IGMC_PLAUNCH("k_tick", k_tick, 1, 64, 0, stream, ctrl); }

@@ -1,6 +1,7 @@
 // launch.h -- host-side launcher declarations + optional per-kernel HIP-event timing (internal).
 #pragma once
 #include "model.h"
+#include <string.h>
 
 // extract.hip
 size_t igmc_extract_smem_bytes(const GraphDev& g);
@@ -24,8 +25,11 @@ void igmc_launch_loss(const ModelDev& m, const BatchDev& b, float ARR, float* lo
 void igmc_launch_sse(const BatchDev& b, const float* out, double* acc, void* stream);
 int igmc_model_prepare(const ModelDev& m);
 void igmc_launch_adam(float* p, const float* g, float* m1, float* m2, int64_t n, float step_size,
-                      float inv_sqrt_bc2, float beta1, float beta2, float eps, float wd, const int64_t* ctrl,
+                      float inv_sqrt_bc2, float beta1, float beta2, float eps, float wd, int64_t* ctrl, int tick,
                       void* stream);
+void igmc_launch_finish(const ModelDev& m, const BatchDev& b, float* p, const float* g, float* m1, float* m2,
+                        float step_size, float inv_sqrt_bc2, float beta1, float beta2, float eps, float wd,
+                        int64_t* ctrl, float ARR, float* loss, double* total, void* stream);
 
 // ---- per-kernel timing (HIP events on the launch stream; bench.py's roofline leg) ----
 void igmc_prof_begin(const char* name, void* stream);

@@ -9,8 +9,7 @@
 //   * aggregate in BASIS space:  A[i][b] = sum_e att[rel_e, b] * x[src_e]   (4 accumulators per
 //     feature, independent of the number of relations R), then ONE dense transform
 //     [A | x] (N x 160) @ [basis ; root] (160 x 32) on f32 MFMA (16x16x4), + bias, tanh fused.
-//   * the gather walks a dst-sorted CSR (atomic-free, bit-reproducible); each 16-lane group owns
-//     one row and reads whole 128-byte feature rows (float2 per lane).
+//   * the gather walks a dst-sorted CSR (atomic-free, bit-reproducible): one wave per row.
 //   * layer 0 has one-hot inputs: it degenerates to a table lookup W0[rel*L + label] per edge.
 //   * backward reuses the same gather on the symmetric CSR (keep-bit 1 = transposed edge):
 //       G[j][b]   = sum_{e: src=j} att[rel_e,b] dPre[dst_e]
@@ -18,6 +17,10 @@
 //       d basis_b = X^T G_b,  d root = X^T dPre,  d bias = sum dPre      (MFMA, per-block partials)
 //       d att[r,b]= sum_j < (x_j basis_b), sum_{e: src=j, rel=r} dPre[dst_e] >   (rows are sorted
 //                   by relation, so this is one dot product per relation RUN, not per edge)
+//   * every serialized kernel costs >= 4.7 us on this part even when trivial (rocprofv3), so the step is
+//     organised for FEW launches: derived weight layouts are produced while staging into LDS (no prep
+//     kernel), the three Y products and the three weight-gradient products are batched into one launch
+//     each (blockIdx.y = layer), and loss / epoch-total / control-block tick ride in the Adam kernel.
 #include "model.h"
 
 __device__ __forceinline__ float igmc_wave_sum_f(float v) {
@@ -30,37 +33,16 @@ __device__ __forceinline__ float igmc_group16_sum_f(float v) {
   for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d, 16);
   return v;
 }
-
-// =================================================================== per-step derived weights
-__global__ __launch_bounds__(IGMC_BLOCK) void k_prep(ModelDev m, const float* __restrict__ P, int training) {
-  const int nW0 = m.R * m.L * 32, nW1 = m.D * 128;
-  const int nT = IGMC_KCAT * 32, nB = 32 * 128;
-  const int total = nW0 + nW1 + (training ? 3 * (nT + nB) : 0);
-  for (int idx = blockIdx.x * IGMC_BLOCK + threadIdx.x; idx < total; idx += gridDim.x * IGMC_BLOCK) {
-    if (idx < nW0) {
-      const int r = idx / (m.L * 32), cf = idx % (m.L * 32);
-      float s = 0.f;
-      for (int b = 0; b < 4; ++b) s += P[m.off_att[0] + r * 4 + b] * P[m.off_basis[0] + b * m.L * 32 + cf];
-      m.W0[idx] = s;
-    } else if (idx < nW0 + nW1) {
-      const int q = idx - nW0, k = q >> 7, j = q & 127;
-      m.w1T[q] = P[m.off_l1w + (int64_t)j * m.D + k];
-    } else {
-      int q = idx - nW0 - nW1;
-      const int l = 1 + q / (nT + nB);
-      q %= (nT + nB);
-      const float* basis = P + m.off_basis[l];
-      const float* root = P + m.off_root[l];
-      if (q < nT) {   // wT[k][f]
-        const int k = q >> 5, f = q & 31;
-        m.wT[l][q] = (k < 128) ? basis[((k >> 5) * 32 + f) * 32 + (k & 31)] : root[f * 32 + (k - 128)];
-      } else {        // bcat[f][n]
-        q -= nT;
-        const int f = q >> 7, n = q & 127;
-        m.bcat[l][q] = basis[((n >> 5) * 32 + f) * 32 + (n & 31)];
-      }
-    }
-  }
+__device__ __forceinline__ float igmc_block_sum_f(float v, float* sm) {
+  v = igmc_wave_sum_f(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sm[wave] = v;
+  __syncthreads();
+  float tot = 0.f;
+  const int nw = (blockDim.x + 63) >> 6;
+  for (int w = 0; w < nw; ++w) tot += sm[w];
+  __syncthreads();
+  return tot;
 }
 
 // =================================================================== row walkers
@@ -71,20 +53,26 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_prep(ModelDev m, const float* __
 // partial sums are combined with two xor-shuffles at the end of the row.
 
 // =================================================================== layer 0 forward (one-hot input)
-// h0[i] = tanh( sum_e W0[rel_e*L + label(src_e)] + root0[label_i] + bias0 ).
+// h0[i] = tanh( sum_e W0[rel_e*L + label(src_e)] + root0[label_i] + bias0 ),  W0[r][c] = sum_b att0[r,b] basis0[b][c]
 // STORE (training): also emits cnt0[i][code] = number of kept incoming edges with that code, so that the
 // layer-0 weight gradient is a dense [codes x N] @ [N x 32] product that never touches the edges again.
 template <bool FLAGS, bool STORE>
 __global__ __launch_bounds__(IGMC_BLOCK) void k_l0_fwd(BatchDev b, ModelDev m, const float* __restrict__ P,
                                                          float* __restrict__ out) {
   IGMC_DYN_SMEM(smem);
-  const int RL = m.R * m.L;
+  const int RL = m.R * m.L, LF = m.L * 32;
   float* sW0 = (float*)smem;                 // [R*L][32]
   float* sroot = sW0 + RL * 32;              // [L][32]
-  float* sbias = sroot + m.L * 32;           // [32]
+  float* sbias = sroot + LF;                 // [32]
   int* shist = (int*)(sbias + 32);           // [4 waves][R*L]   (STORE only)
-  for (int i = threadIdx.x; i < RL * 32; i += IGMC_BLOCK) sW0[i] = m.W0[i];
-  for (int i = threadIdx.x; i < m.L * 32; i += IGMC_BLOCK) sroot[i] = P[m.off_root[0] + i];
+  for (int i = threadIdx.x; i < RL * 32; i += IGMC_BLOCK) {
+    const int r = i / LF, cf = i % LF;
+    float s = 0.f;
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) s += P[m.off_att[0] + r * 4 + bb] * P[m.off_basis[0] + bb * LF + cf];
+    sW0[i] = s;
+  }
+  for (int i = threadIdx.x; i < LF; i += IGMC_BLOCK) sroot[i] = P[m.off_root[0] + i];
   if (threadIdx.x < 32) sbias[threadIdx.x] = P[m.off_bias[0] + threadIdx.x];
   __syncthreads();
   const int N = b.totals[0];
@@ -259,22 +247,32 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_gather(BatchDev b, int R, c
 // =================================================================== dense row transform on f32 MFMA
 // OUT[N,NO] = epilogue([A1[N,K1] | A2[N,K2]] @ W[K1+K2, NO]).  One wave = 16 rows x NO columns,
 // v_mfma_f32_16x16x4_f32; W is staged once per block in LDS (pitch NO+4: conflict-free b32 reads).
+// WMODE selects how W is derived from the layer's parameters WHILE staging (no prep kernel):
+//   W_PLAIN : [basis ; root] as stored (contiguous in the flat buffer)           -> forward
+//   W_BWD_T : [basis_b^T ; root^T]   sW[b*32+fo][f] = basis[b][f][fo]            -> dLoss/dx
+//   W_YCAT  : [basis_0|..|basis_3]   sW[f][b*32+fo] = basis[b][f][fo]            -> Y (att gradient)
 enum { EPI_NONE = 0, EPI_BIAS_TANH = 1, EPI_BWD = 2 };
+enum { W_PLAIN = 0, W_BWD_T = 1, W_YCAT = 2 };
 
-template <int K1, int K2, int NO, int EPI>
-__global__ __launch_bounds__(IGMC_BLOCK) void k_dense(BatchDev b, const float* __restrict__ A1,
-                                                        const float* __restrict__ A2,
-                                                        const float* __restrict__ W,
-                                                        const float* __restrict__ bias,
-                                                        float* __restrict__ out,
-                                                        const float* __restrict__ xin,     // EPI_BWD: input activations
-                                                        const float* __restrict__ gfeat,   // EPI_BWD: readout gradient [B,D]
-                                                        int D, int rlayer,
-                                                        float* __restrict__ zero_out) {    // optional [N,32] buffer to clear
+template <int K1, int K2, int NO, int EPI, int WMODE>
+__device__ __forceinline__ void dense_body(const BatchDev& b, const float* __restrict__ A1,
+                                           const float* __restrict__ A2, const float* __restrict__ basis,
+                                           const float* __restrict__ root, const float* __restrict__ bias,
+                                           float* __restrict__ out, const float* __restrict__ xin,
+                                           const float* __restrict__ gfeat, int D, int rlayer,
+                                           float* __restrict__ zero_out, float* sW) {
   constexpr int K = K1 + K2, PITCH = NO + 4, NT = NO / 16;
-  IGMC_DYN_SMEM(smem);
-  float* sW = (float*)smem;
-  for (int idx = threadIdx.x; idx < K * NO; idx += IGMC_BLOCK) sW[(idx / NO) * PITCH + (idx % NO)] = W[idx];
+  if (WMODE == W_PLAIN) {
+    for (int idx = threadIdx.x; idx < K * NO; idx += IGMC_BLOCK) sW[(idx / NO) * PITCH + (idx % NO)] = basis[idx];
+  } else {
+    for (int idx = threadIdx.x; idx < 4096; idx += IGMC_BLOCK) {     // coalesced read of basis[b][f][fo]
+      const int bb = idx >> 10, f = (idx >> 5) & 31, fo = idx & 31;
+      if (WMODE == W_BWD_T) sW[(bb * 32 + fo) * PITCH + f] = basis[idx];
+      else sW[f * PITCH + bb * 32 + fo] = basis[idx];
+    }
+    if (WMODE == W_BWD_T)
+      for (int idx = threadIdx.x; idx < 1024; idx += IGMC_BLOCK) sW[(128 + (idx & 31)) * PITCH + (idx >> 5)] = root[idx];
+  }
   __syncthreads();
   const int N = b.totals[0];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -325,12 +323,47 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_dense(BatchDev b, const float* _
   }
 }
 
+// h_l = tanh([agg | h_{l-1}] @ [basis_l ; root_l] + bias_l); optionally clears another [N,32] buffer
+__global__ __launch_bounds__(IGMC_BLOCK) void k_dense_fwd(BatchDev b, const float* __restrict__ agg,
+                                                            const float* __restrict__ x,
+                                                            const float* __restrict__ basis,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            float* __restrict__ zero_out) {
+  IGMC_DYN_SMEM(smem);
+  dense_body<128, 32, 32, EPI_BIAS_TANH, W_PLAIN>(b, agg, x, basis, nullptr, bias, out, nullptr, nullptr, 0, 0,
+                                                  zero_out, (float*)smem);
+}
+
+// dPre_{l-1} = ([G | dPre_l] @ [basis_l^T ; root_l^T] + readout gradient on target rows) * (1 - h_{l-1}^2)
+__global__ __launch_bounds__(IGMC_BLOCK) void k_dense_bwd(BatchDev b, const float* __restrict__ gagg,
+                                                            const float* __restrict__ dcur,
+                                                            const float* __restrict__ basis,
+                                                            const float* __restrict__ root, float* __restrict__ dnext,
+                                                            const float* __restrict__ xin,
+                                                            const float* __restrict__ gfeat, int D, int rlayer) {
+  IGMC_DYN_SMEM(smem);
+  dense_body<128, 32, 32, EPI_BWD, W_BWD_T>(b, gagg, dcur, basis, root, nullptr, dnext, xin, gfeat, D, rlayer,
+                                            nullptr, (float*)smem);
+}
+
+// Y_l = h_{l-1} @ [basis_0|..|basis_3] for l = 1..3 in ONE launch (blockIdx.y = l-1)
+__global__ __launch_bounds__(IGMC_BLOCK) void k_dense_y_all(BatchDev b, ModelDev m, const float* __restrict__ P) {
+  IGMC_DYN_SMEM(smem);
+  const int li = blockIdx.y;
+  dense_body<0, 32, 128, EPI_NONE, W_YCAT>(b, nullptr, m.h[li], P + m.off_basis[li + 1], nullptr, nullptr, m.Y[li],
+                                           nullptr, nullptr, 0, 0, nullptr, (float*)smem);
+}
+
 // =================================================================== weight gradients  G = X^T [D1 | D2]
-// X [N,32], D1 [N,128], D2 [N,32]  ->  per-block partial [32][160] (+ column sums of D2 = d bias).
-__global__ __launch_bounds__(IGMC_BLOCK) void k_wgrad(BatchDev b, const float* __restrict__ X,
-                                                        const float* __restrict__ D1, const float* __restrict__ D2,
-                                                        float* __restrict__ part) {
+// X = h_{l-1} [N,32], D1 = G_l [N,128], D2 = dPre_l [N,32]  ->  per-block partial [32][160] (+ column sums of
+// D2 = d bias).  All three layers in ONE launch (blockIdx.y = l-1).
+__global__ __launch_bounds__(IGMC_BLOCK) void k_wgrad_all(BatchDev b, ModelDev m) {
   __shared__ float sacc[32 * IGMC_KCAT + 32];
+  const int ly = blockIdx.y;
+  const float* __restrict__ X = m.h[ly];
+  const float* __restrict__ D1 = m.gagg[ly];
+  const float* __restrict__ D2 = m.dpre[ly + 1];
+  float* part = m.wg_part + ((size_t)ly * IGMC_WG_BLOCKS + blockIdx.x) * (32 * IGMC_KCAT + 32);
   const int N = b.totals[0];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, kq = lane >> 4;
@@ -390,8 +423,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_wgrad(BatchDev b, const float* _
     }
     __syncthreads();
   }
-  float* dst = part + (size_t)blockIdx.x * (32 * IGMC_KCAT + 32);
-  for (int i = threadIdx.x; i < 32 * IGMC_KCAT + 32; i += IGMC_BLOCK) dst[i] = sacc[i];
+  for (int i = threadIdx.x; i < 32 * IGMC_KCAT + 32; i += IGMC_BLOCK) part[i] = sacc[i];
 }
 
 // =================================================================== layer 0 backward (dense, no edges)
@@ -431,80 +463,95 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_l0_bwd(BatchDev b, ModelDev m, c
 }
 
 // =================================================================== head: readout + MLP (+loss residual)
-// reference models.py:203-215.  HG graphs per block so every lin1 weight is loaded once per HG graphs and
-// the k-loops carry HG independent FMA chains.
-#define IGMC_HG 8
+// reference models.py:203-215.  IGMC_HG graphs per workgroup; lin1.weight [128, D] is read in its native
+// layout: one wave per output unit j, lanes across the fan-in (coalesced), wave reduction per (graph, j).
+__device__ __forceinline__ float head_feat(const BatchDev& b, const ModelDev& m, int g, int k) {
+  if (k < 256) {
+    const int side = k >> 7, l = (k >> 5) & 3, f = k & 31;
+    const int nu = b.node_off[g], nv = nu + b.n_users[g];
+    return m.h[l][(size_t)(side ? nv : nu) * 32 + f];
+  }
+  return m.side[(size_t)g * m.S + (k - 256)];
+}
 
-__global__ __launch_bounds__(128) void k_head_fwd(BatchDev b, ModelDev m, const float* __restrict__ P,
-                                                    int training, const uint8_t* __restrict__ inj_mask,
-                                                    uint64_t seed, uint64_t step_arg, float mult,
-                                                    float* __restrict__ out) {
+template <bool FEAT_LDS>
+__global__ __launch_bounds__(512) void k_head_fwd(BatchDev b, ModelDev m, const float* __restrict__ P, int training,
+                                                    const uint8_t* __restrict__ inj_mask, uint64_t seed,
+                                                    uint64_t step_arg, float mult, float* __restrict__ out) {
   IGMC_DYN_SMEM(smem);
   const uint64_t step = m.ctrl ? (uint64_t)m.ctrl[IGMC_CTRL_STEP] : step_arg;
-  float* sfeat = (float*)smem;      // [HG][D]
+  __shared__ float sa[IGMC_HG][128];
   __shared__ float red[2][IGMC_HG];
+  float* sfeat = (float*)smem;      // [HG][D]  (FEAT_LDS)
   const int B = b.totals[3];
-  const int g0 = blockIdx.x * IGMC_HG, j = threadIdx.x;
+  const int g0 = blockIdx.x * IGMC_HG, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int D = m.D;
-  for (int idx = j; idx < IGMC_HG * D; idx += 128) {
+  for (int idx = tid; idx < IGMC_HG * D; idx += 512) {
     const int gg = idx / D, k = idx % D, g = g0 + gg;
-    float v = 0.f;
-    if (g < B) {
-      if (k < 256) {
-        const int side = k >> 7, l = (k >> 5) & 3, f = k & 31;
-        const int nu = b.node_off[g], nv = nu + b.n_users[g];
-        v = m.h[l][(size_t)(side ? nv : nu) * 32 + f];
-      } else {
-        v = m.side[(size_t)g * m.S + (k - 256)];
+    const float v = (g < B) ? head_feat(b, m, g, k) : 0.f;
+    if (g < B) m.feat[(size_t)g * D + k] = v;
+    if (FEAT_LDS) sfeat[idx] = v;
+  }
+  __syncthreads();
+  for (int j = wave; j < 128; j += 8) {
+    float acc[IGMC_HG];
+#pragma unroll
+    for (int gg = 0; gg < IGMC_HG; ++gg) acc[gg] = 0.f;
+    const float* wrow = P + m.off_l1w + (int64_t)j * D;
+    for (int k = lane; k < D; k += 64) {
+      const float w = wrow[k];
+#pragma unroll
+      for (int gg = 0; gg < IGMC_HG; ++gg) {
+        const float fv = FEAT_LDS ? sfeat[gg * D + k] : ((g0 + gg < B) ? m.feat[(size_t)(g0 + gg) * D + k] : 0.f);
+        acc[gg] += w * fv;
       }
-      if (training) m.feat[(size_t)g * D + k] = v;
     }
-    sfeat[idx] = v;
+#pragma unroll
+    for (int gg = 0; gg < IGMC_HG; ++gg) {
+      const float s = igmc_wave_sum_f(acc[gg]);
+      if (lane == 0) sa[gg][j] = s + P[m.off_l1b + j];
+    }
   }
   __syncthreads();
-  float acc[IGMC_HG];
-  const float b1 = P[m.off_l1b + j];
+  if (tid < 128) {
+    const int j = tid;
+    const float w2 = P[m.off_l2w + j];
 #pragma unroll
-  for (int gg = 0; gg < IGMC_HG; ++gg) acc[gg] = b1;
-#pragma unroll 4
-  for (int k = 0; k < D; ++k) {
-    const float w = m.w1T[k * 128 + j];
-#pragma unroll
-    for (int gg = 0; gg < IGMC_HG; ++gg) acc[gg] += w * sfeat[gg * D + k];
-  }
-  const float w2 = P[m.off_l2w + j];
-#pragma unroll
-  for (int gg = 0; gg < IGMC_HG; ++gg) {
-    const int g = g0 + gg;
-    float a = acc[gg] > 0.f ? acc[gg] : 0.f;
-    if (training && g < B) {
-      m.a1[g * 128 + j] = a;
-      const int keep = inj_mask ? (int)inj_mask[g * 128 + j]
-                                : (int)(igmc_u01(igmc_unit_hash(seed, step, (uint32_t)g, (uint32_t)j)) >= 0.5f);
-      m.lmask[g * 128 + j] = (uint8_t)keep;
-      a = keep ? a * 2.f : 0.f;    // F.dropout(p=0.5): kept units scaled by 1/(1-p)
+    for (int gg = 0; gg < IGMC_HG; ++gg) {
+      const int g = g0 + gg;
+      float a = sa[gg][j] > 0.f ? sa[gg][j] : 0.f;
+      if (training && g < B) {
+        m.a1[g * 128 + j] = a;
+        const int keep = inj_mask ? (int)inj_mask[g * 128 + j]
+                                  : (int)(igmc_u01(igmc_unit_hash(seed, step, (uint32_t)g, (uint32_t)j)) >= 0.5f);
+        m.lmask[g * 128 + j] = (uint8_t)keep;
+        a = keep ? a * 2.f : 0.f;    // F.dropout(p=0.5): kept units scaled by 1/(1-p)
+      }
+      const float p = igmc_wave_sum_f(a * w2);
+      if ((j & 63) == 0) red[j >> 6][gg] = p;
     }
-    const float p = igmc_wave_sum_f(a * w2);
-    if ((j & 63) == 0) red[j >> 6][gg] = p;
   }
   __syncthreads();
-  if (j < IGMC_HG && g0 + j < B) {
-    const float o = (red[0][j] + red[1][j] + P[m.off_l2b]) * mult;
-    out[g0 + j] = o;
-    m.err[g0 + j] = o - b.y[g0 + j];
+  if (tid < IGMC_HG && g0 + tid < B) {
+    const float o = (red[0][tid] + red[1][tid] + P[m.off_l2b]) * mult;
+    out[g0 + tid] = o;
+    m.err[g0 + tid] = o - b.y[g0 + tid];
   }
 }
 
-// backward A: dz, d feat, and dPre of the top layer on the two target rows of each graph
-__global__ __launch_bounds__(IGMC_BLOCK) void k_head_bwd_a(BatchDev b, ModelDev m, const float* __restrict__ P,
-                                                             const float* __restrict__ gout, int from_err,
-                                                             float grad_scale, float mult, float drop_scale,
-                                                             float* __restrict__ dpre_top) {
+// backward A: dz, d feat, and dPre of the top layer on the two target rows of each graph.
+// 1024 threads = 4 slices of the 128 hidden units x 256 fan-in columns.
+__global__ __launch_bounds__(1024) void k_head_bwd_a(BatchDev b, ModelDev m, const float* __restrict__ P,
+                                                       const float* __restrict__ gout, int from_err,
+                                                       float grad_scale, float mult, float drop_scale,
+                                                       float* __restrict__ dpre_top) {
   __shared__ float sdz[IGMC_HG][128];
+  __shared__ float sred[3][IGMC_HG][256];
   const int B = b.totals[3];
   const int g0 = blockIdx.x * IGMC_HG, tid = threadIdx.x;
   const int D = m.D;
-  for (int idx = tid; idx < IGMC_HG * 128; idx += IGMC_BLOCK) {
+  for (int idx = tid; idx < IGMC_HG * 128; idx += 1024) {
     const int gg = idx >> 7, j = idx & 127, g = g0 + gg;
     float dzv = 0.f;
     if (g < B) {
@@ -516,70 +563,95 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_head_bwd_a(BatchDev b, ModelDev 
     sdz[gg][j] = dzv;
   }
   __syncthreads();
-  for (int k = tid; k < D; k += IGMC_BLOCK) {
+  const int kk = tid & 255, js = tid >> 8;
+  for (int kc = 0; kc < D; kc += 256) {
+    const int k = kc + kk;
     float acc[IGMC_HG];
 #pragma unroll
     for (int gg = 0; gg < IGMC_HG; ++gg) acc[gg] = 0.f;
-#pragma unroll 4
-    for (int jj = 0; jj < 128; ++jj) {
-      const float w = P[m.off_l1w + (int64_t)jj * D + k];
+    if (k < D) {
+#pragma unroll 8
+      for (int jj = js * 32; jj < js * 32 + 32; ++jj) {
+        const float w = P[m.off_l1w + (int64_t)jj * D + k];
 #pragma unroll
-      for (int gg = 0; gg < IGMC_HG; ++gg) acc[gg] += sdz[gg][jj] * w;
-    }
-#pragma unroll
-    for (int gg = 0; gg < IGMC_HG; ++gg) {
-      const int g = g0 + gg;
-      if (g >= B) continue;
-      m.gfeat[(size_t)g * D + k] = acc[gg];
-      if (k < 256 && ((k >> 5) & 3) == 3) {
-        const int side = k >> 7, f = k & 31;
-        const int nu = b.node_off[g], nv = nu + b.n_users[g];
-        const size_t node = (size_t)(side ? nv : nu);
-        const float hv = m.h[3][node * 32 + f];
-        dpre_top[node * 32 + f] = acc[gg] * (1.f - hv * hv);
+        for (int gg = 0; gg < IGMC_HG; ++gg) acc[gg] += sdz[gg][jj] * w;
       }
     }
+    if (js > 0) {
+#pragma unroll
+      for (int gg = 0; gg < IGMC_HG; ++gg) sred[js - 1][gg][kk] = acc[gg];
+    }
+    __syncthreads();
+    if (js == 0 && k < D) {
+#pragma unroll
+      for (int gg = 0; gg < IGMC_HG; ++gg) {
+        const int g = g0 + gg;
+        if (g >= B) continue;
+        const float v = ((acc[gg] + sred[0][gg][kk]) + sred[1][gg][kk]) + sred[2][gg][kk];
+        m.gfeat[(size_t)g * D + k] = v;
+        if (k < 256 && ((k >> 5) & 3) == 3) {
+          const int side = k >> 7, f = k & 31;
+          const int nu = b.node_off[g], nv = nu + b.n_users[g];
+          const size_t node = (size_t)(side ? nv : nu);
+          const float hv = m.h[3][node * 32 + f];
+          dpre_top[node * 32 + f] = v * (1.f - hv * hv);
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 
-// backward B: d lin1.weight / d lin1.bias / d lin2.weight / d lin2.bias (sum over the B graphs)
+// backward B: d lin1.weight [128, D] = dz^T @ feat.  Block (jt, kc): 8 hidden units x 256 fan-in columns;
+// feat / dz are staged through LDS in chunks of 32 graphs.  One extra block row does the bias/lin2 grads.
+#define IGMC_HW_G 32
 __global__ __launch_bounds__(IGMC_BLOCK) void k_head_bwd_w(BatchDev b, ModelDev m, const float* __restrict__ P,
                                                              const float* __restrict__ gout, int from_err,
                                                              float grad_scale, float mult, float drop_scale,
                                                              float* __restrict__ grad) {
+  __shared__ float sfe[IGMC_HW_G][256];
+  __shared__ float sdz[IGMC_HW_G][8];
   const int B = b.totals[3];
-  const int nW = 128 * m.D;
-  const int idx = blockIdx.x * IGMC_BLOCK + threadIdx.x;
-  if (idx < nW) {
-    const int j = idx / m.D, k = idx % m.D;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int g = 0;
-    for (; g + 4 <= B; g += 4) {      // 4 independent chains: the loads of a group are issued together
-      s0 += m.dz[(g + 0) * 128 + j] * m.feat[(size_t)(g + 0) * m.D + k];
-      s1 += m.dz[(g + 1) * 128 + j] * m.feat[(size_t)(g + 1) * m.D + k];
-      s2 += m.dz[(g + 2) * 128 + j] * m.feat[(size_t)(g + 2) * m.D + k];
-      s3 += m.dz[(g + 3) * 128 + j] * m.feat[(size_t)(g + 3) * m.D + k];
+  const int D = m.D, tid = threadIdx.x;
+  if (blockIdx.x == 16) {                 // d lin1.bias, d lin2.weight, d lin2.bias (blockIdx.y == 0 only)
+    if (blockIdx.y != 0) return;
+    if (tid < 128) {
+      float s = 0.f;
+      for (int g = 0; g < B; ++g) s += m.dz[g * 128 + tid];
+      grad[m.off_l1b + tid] = s;
+    } else {
+      const int j = tid - 128;
+      float s = 0.f, s2 = 0.f;
+      for (int g = 0; g < B; ++g) {
+        const float dp = (from_err ? 2.f * m.err[g] * grad_scale : gout[g]) * mult;
+        const float a = m.lmask[g * 128 + j] ? m.a1[g * 128 + j] * drop_scale : 0.f;
+        s += dp * a;
+        s2 += dp;
+      }
+      grad[m.off_l2w + j] = s;
+      if (j == 0) grad[m.off_l2b] = s2;
     }
-    for (; g < B; ++g) s0 += m.dz[g * 128 + j] * m.feat[(size_t)g * m.D + k];
-    grad[m.off_l1w + idx] = (s0 + s1) + (s2 + s3);
-  } else if (idx < nW + 128) {
-    const int j = idx - nW;
-    float s = 0.f;
-    for (int g = 0; g < B; ++g) s += m.dz[g * 128 + j];
-    grad[m.off_l1b + j] = s;
-  } else if (idx < nW + 256) {
-    const int j = idx - nW - 128;
-    float s = 0.f;
-    for (int g = 0; g < B; ++g) {
-      const float dp = (from_err ? 2.f * m.err[g] * grad_scale : gout[g]) * mult;
-      const float a = m.lmask[g * 128 + j] ? m.a1[g * 128 + j] * drop_scale : 0.f;
-      s += dp * a;
+    return;
+  }
+  const int j0 = blockIdx.x * 8, k = blockIdx.y * 256 + tid;
+  float acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+  for (int gc = 0; gc < B; gc += IGMC_HW_G) {
+    const int ng = (B - gc < IGMC_HW_G) ? B - gc : IGMC_HW_G;
+    for (int gg = 0; gg < ng; ++gg) sfe[gg][tid] = (k < D) ? m.feat[(size_t)(gc + gg) * D + k] : 0.f;
+    if (tid < ng * 8) sdz[tid >> 3][tid & 7] = m.dz[(gc + (tid >> 3)) * 128 + j0 + (tid & 7)];
+    __syncthreads();
+    for (int gg = 0; gg < ng; ++gg) {
+      const float fv = sfe[gg][tid];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] += sdz[gg][q] * fv;
     }
-    grad[m.off_l2w + j] = s;
-  } else if (idx == nW + 256) {
-    float s = 0.f;
-    for (int g = 0; g < B; ++g) s += (from_err ? 2.f * m.err[g] * grad_scale : gout[g]) * mult;
-    grad[m.off_l2b] = s;
+    __syncthreads();
+  }
+  if (k < D) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) grad[m.off_l1w + (int64_t)(j0 + q) * D + k] = acc[q];
   }
 }
 
@@ -626,18 +698,6 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_partials(ModelDev m, int 
       if (lane == 0) m.graw[3 * wgs + o] = s;
     }
   }
-}
-
-__device__ __forceinline__ float igmc_block_sum_f(float v, float* sm) {
-  v = igmc_wave_sum_f(v);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) sm[wave] = v;
-  __syncthreads();
-  float tot = 0.f;
-  const int nw = (blockDim.x + 63) >> 6;
-  for (int w = 0; w < nw; ++w) tot += sm[w];
-  __syncthreads();
-  return tot;
 }
 
 // one block per conv layer: scatter the reduced partials into the flat gradient, add the
@@ -750,17 +810,24 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize(ModelDev m, const float
 }
 
 // loss[0] = mean_g err^2 + ARR * sum_l reg_l   (reference train_eval.py:162-174); loss[1] = sum err^2
-__global__ __launch_bounds__(IGMC_BLOCK) void k_loss(BatchDev b, ModelDev m, float ARR, float* __restrict__ loss) {
-  __shared__ float smf[8];
+__device__ __forceinline__ void loss_body(const BatchDev& b, const ModelDev& m, float ARR, float* loss,
+                                          double* total, float* smf) {
   const int B = b.totals[3];
   float s = 0.f;
   for (int g = threadIdx.x; g < B; g += IGMC_BLOCK) s += m.err[g] * m.err[g];
   s = igmc_block_sum_f(s, smf);
   if (threadIdx.x == 0) {
     const float reg = m.arr_part[0] + m.arr_part[1] + m.arr_part[2] + m.arr_part[3];
-    loss[0] = s / (float)B + ARR * reg;
+    const float l0 = s / (float)B + ARR * reg;
+    loss[0] = l0;
     loss[1] = s;
+    if (total) total[0] += (double)l0 * (double)B;     // epoch total of loss * num_graphs (ref :176)
   }
+}
+
+__global__ __launch_bounds__(IGMC_BLOCK) void k_loss(BatchDev b, ModelDev m, float ARR, float* __restrict__ loss) {
+  __shared__ float smf[8];
+  loss_body(b, m, ARR, loss, nullptr, smf);
 }
 
 __global__ __launch_bounds__(IGMC_BLOCK) void k_sse_acc(BatchDev b, const float* __restrict__ out, double* acc) {
@@ -778,12 +845,38 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_sse_acc(BatchDev b, const float*
   }
 }
 
-// =================================================================== fused Adam (flat buffer)
+// =================================================================== fused Adam (flat buffer) + step epilogue
+// With `fin` set, block 0 also produces the step's loss / epoch total, and the LAST block to finish advances
+// the device-side step control (igmc_hip.h) for the next replay of the step graph.
+struct FinishArgs {
+  int enabled;
+  BatchDev b;
+  ModelDev m;
+  float ARR;
+  float* loss;
+  double* total;
+};
+
+__device__ __forceinline__ void ctrl_advance(int64_t* ctrl) {
+  double* d = (double*)ctrl;
+  ctrl[IGMC_CTRL_STEP] += 1;
+  ctrl[IGMC_CTRL_FIRST] += ctrl[IGMC_CTRL_BATCH];
+  ctrl[IGMC_CTRL_ADAM_T] += 1;
+  const double t = (double)ctrl[IGMC_CTRL_ADAM_T];
+  d[IGMC_CTRL_STEP_SIZE] = d[IGMC_CTRL_LR] / (1.0 - pow(d[IGMC_CTRL_BETA1], t));
+  d[IGMC_CTRL_INV_SQRT_BC2] = 1.0 / sqrt(1.0 - pow(d[IGMC_CTRL_BETA2], t));
+}
+
+__global__ void k_tick(int64_t* ctrl) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) ctrl_advance(ctrl);
+}
+
 __global__ __launch_bounds__(IGMC_BLOCK) void k_adam(float* __restrict__ p, const float* __restrict__ g,
                                                        float* __restrict__ m1, float* __restrict__ m2, int64_t n,
                                                        float step_size, float inv_sqrt_bc2, float beta1, float beta2,
-                                                       float eps, float wd, const int64_t* ctrl) {
-  if (ctrl) {      // hipGraph replay: the scalars live in HBM (igmc_ctrl_tick keeps them current)
+                                                       float eps, float wd, int64_t* ctrl, int tick, FinishArgs fin) {
+  __shared__ float smf[8];
+  if (ctrl) {      // hipGraph replay: the scalars live in HBM
     const double* d = (const double*)ctrl;
     step_size = (float)d[IGMC_CTRL_STEP_SIZE];
     inv_sqrt_bc2 = (float)d[IGMC_CTRL_INV_SQRT_BC2];
@@ -802,11 +895,19 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_adam(float* __restrict__ p, cons
     m2[i] = v;
     p[i] = pi - step_size * a / (sqrtf(v) * inv_sqrt_bc2 + eps);
   }
-}
-
-__global__ __launch_bounds__(IGMC_BLOCK) void k_zero_rows(BatchDev b, float* __restrict__ p, int per_row) {
-  const int64_t n = (int64_t)b.totals[0] * per_row;
-  for (int64_t i = (int64_t)blockIdx.x * IGMC_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * IGMC_BLOCK) p[i] = 0.f;
+  if (fin.enabled && blockIdx.x == 0) loss_body(fin.b, fin.m, fin.ARR, fin.loss, fin.total, smf);
+  if (ctrl && tick) {
+    // every block has read its scalars above; the last one to get here advances the control block
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      int* done = (int*)&ctrl[IGMC_CTRL_DONE];
+      if (atomicAdd(done, 1) == (int)gridDim.x - 1) {
+        *done = 0;
+        ctrl_advance(ctrl);
+      }
+    }
+  }
 }
 
 // =================================================================== host launch sequences
@@ -821,7 +922,6 @@ static inline int igmc_rows_grid(int cap_rows, int rows_per_block, int max_block
 void igmc_launch_forward(const ModelDev& m, const BatchDev& b, const float* P, int B, int training,
                          int use_flags, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
                          float* out, void* stream) {
-  IGMC_PLAUNCH("k_prep", k_prep, 64, IGMC_BLOCK, 0, stream, m, P, training);
   const size_t l0s = (size_t)(m.R * m.L * 32 + m.L * 32 + 32) * sizeof(float) + (size_t)4 * m.R * m.L * sizeof(int);
   const int g16 = igmc_rows_grid(m.node_cap, 4, IGMC_GATHER_BLOCKS);   // one wave per row, 4 rows per block
   const int g64 = igmc_rows_grid(m.node_cap, 64, 512);
@@ -841,14 +941,20 @@ void igmc_launch_forward(const ModelDev& m, const BatchDev& b, const float* P, i
     else
       IGMC_PLAUNCH("k_rgcn_gather_fwd", (k_rgcn_gather<false, false, false>), g16, IGMC_BLOCK, gs, stream, b, m.R,
                    (const float*)m.h[l - 1], P + m.off_att[l], m.agg, (const float*)nullptr, (float*)nullptr);
-    // [agg | h_{l-1}] @ [basis ; root]  (contiguous in the flat parameter buffer) + bias, tanh
-    IGMC_PLAUNCH("k_dense_fwd", (k_dense<128, 32, 32, EPI_BIAS_TANH>), g64, IGMC_BLOCK, ds, stream, b,
-                 (const float*)m.agg, (const float*)m.h[l - 1], P + m.off_basis[l], P + m.off_bias[l], m.h[l],
-                 (const float*)nullptr, (const float*)nullptr, 0, 0,
-                 (float*)((training && l == 3) ? m.dpre[1] : nullptr));   // clear dPre of the top layer
+    // [agg | h_{l-1}] @ [basis ; root]  (contiguous in the flat parameter buffer) + bias, tanh;
+    // the top layer's launch also clears dPre_3 (only its target rows are written by the head backward)
+    IGMC_PLAUNCH("k_dense_fwd", k_dense_fwd, g64, IGMC_BLOCK, ds, stream, b, (const float*)m.agg,
+                 (const float*)m.h[l - 1], P + m.off_basis[l], P + m.off_bias[l], m.h[l],
+                 (float*)((training && l == 3) ? m.dpre[3] : nullptr));
   }
-  IGMC_PLAUNCH("k_head_fwd", k_head_fwd, (B + IGMC_HG - 1) / IGMC_HG, 128, (size_t)IGMC_HG * m.D * sizeof(float),
-               stream, b, m, P, training, inj_mask, seed, step, mult, out);
+  const int hgrid = (B + IGMC_HG - 1) / IGMC_HG;
+  const size_t fs = (size_t)IGMC_HG * m.D * sizeof(float);
+  if (fs <= 48 * 1024)
+    IGMC_PLAUNCH("k_head_fwd", (k_head_fwd<true>), hgrid, 512, fs, stream, b, m, P, training, inj_mask, seed, step,
+                 mult, out);
+  else
+    IGMC_PLAUNCH("k_head_fwd", (k_head_fwd<false>), hgrid, 512, 0, stream, b, m, P, training, inj_mask, seed, step,
+                 mult, out);
 }
 
 void igmc_launch_backward(const ModelDev& m, const BatchDev& b, const float* P, int B, int use_flags,
@@ -856,34 +962,29 @@ void igmc_launch_backward(const ModelDev& m, const BatchDev& b, const float* P, 
                           float arr_coef, float* grad, void* stream) {
   const int g16 = igmc_rows_grid(m.node_cap, 4, IGMC_GATHER_BLOCKS);
   const int g64 = igmc_rows_grid(m.node_cap, 64, 512);
-  IGMC_PLAUNCH("k_head_bwd_a", k_head_bwd_a, (B + IGMC_HG - 1) / IGMC_HG, IGMC_BLOCK, 0, stream, b, m, P, gout,
-               from_err, grad_scale, mult, drop_scale, m.dpre[1]);
-  const int nhw = (128 * m.D + 257 + IGMC_BLOCK - 1) / IGMC_BLOCK;
-  IGMC_PLAUNCH("k_head_bwd_w", k_head_bwd_w, nhw, IGMC_BLOCK, 0, stream, b, m, P, gout, from_err, grad_scale, mult,
-               drop_scale, grad);
-  const int wgs = igmc_wg_stride(), na = m.R * 4;
+  const int hgrid = (B + IGMC_HG - 1) / IGMC_HG;
+  IGMC_PLAUNCH("k_head_bwd_a", k_head_bwd_a, hgrid, 1024, 0, stream, b, m, P, gout, from_err, grad_scale, mult,
+               drop_scale, m.dpre[3]);
+  IGMC_PLAUNCH("k_head_bwd_w", k_head_bwd_w, dim3(17, (m.D + 255) / 256), IGMC_BLOCK, 0, stream, b, m, P, gout,
+               from_err, grad_scale, mult, drop_scale, grad);
+  const int na = m.R * 4;
   const size_t gsa = (size_t)(m.R * 4 + 16 * m.R * 4) * sizeof(float);
   const size_t ysz = (size_t)32 * (128 + 4) * sizeof(float);
   const size_t ds = (size_t)IGMC_KCAT * (32 + 4) * sizeof(float);
+  IGMC_PLAUNCH("k_dense_y_all", k_dense_y_all, dim3(g64, 3), IGMC_BLOCK, ysz, stream, b, m, P);
   for (int l = 3; l >= 1; --l) {
-    float* dcur = m.dpre[l & 1];
-    float* dnext = m.dpre[(l - 1) & 1];
-    IGMC_PLAUNCH("k_dense_y", (k_dense<0, 32, 128, EPI_NONE>), g64, IGMC_BLOCK, ysz, stream, b,
-                 (const float*)nullptr, (const float*)m.h[l - 1], (const float*)m.bcat[l], (const float*)nullptr, m.Y,
-                 (const float*)nullptr, (const float*)nullptr, 0, 0, (float*)nullptr);
     float* gp = m.gatt_part + (size_t)(l - 1) * IGMC_GATHER_BLOCKS * na;
     if (use_flags)
-      IGMC_PLAUNCH("k_rgcn_gather_bwd", (k_rgcn_gather<true, true, true>), g16, IGMC_BLOCK, gsa, stream,
-                   b, m.R, (const float*)dcur, P + m.off_att[l], m.agg, (const float*)m.Y, gp);
+      IGMC_PLAUNCH("k_rgcn_gather_bwd", (k_rgcn_gather<true, true, true>), g16, IGMC_BLOCK, gsa, stream, b, m.R,
+                   (const float*)m.dpre[l], P + m.off_att[l], m.gagg[l - 1], (const float*)m.Y[l - 1], gp);
     else
-      IGMC_PLAUNCH("k_rgcn_gather_bwd", (k_rgcn_gather<false, true, true>), g16, IGMC_BLOCK, gsa, stream,
-                   b, m.R, (const float*)dcur, P + m.off_att[l], m.agg, (const float*)m.Y, gp);
-    IGMC_PLAUNCH("k_dense_bwd", (k_dense<128, 32, 32, EPI_BWD>), g64, IGMC_BLOCK, ds, stream, b, (const float*)m.agg,
-                 (const float*)dcur, (const float*)m.wT[l], (const float*)nullptr, dnext, (const float*)m.h[l - 1],
-                 (const float*)m.gfeat, m.D, l - 1, (float*)nullptr);
-    IGMC_PLAUNCH("k_wgrad", k_wgrad, IGMC_WG_BLOCKS, IGMC_BLOCK, 0, stream, b, (const float*)m.h[l - 1],
-                 (const float*)m.agg, (const float*)dcur, m.wg_part + (size_t)(l - 1) * IGMC_WG_BLOCKS * wgs);
+      IGMC_PLAUNCH("k_rgcn_gather_bwd", (k_rgcn_gather<false, true, true>), g16, IGMC_BLOCK, gsa, stream, b, m.R,
+                   (const float*)m.dpre[l], P + m.off_att[l], m.gagg[l - 1], (const float*)m.Y[l - 1], gp);
+    IGMC_PLAUNCH("k_dense_bwd", k_dense_bwd, g64, IGMC_BLOCK, ds, stream, b, (const float*)m.gagg[l - 1],
+                 (const float*)m.dpre[l], P + m.off_basis[l], P + m.off_root[l], m.dpre[l - 1],
+                 (const float*)m.h[l - 1], (const float*)m.gfeat, m.D, l - 1);
   }
+  IGMC_PLAUNCH("k_wgrad_all", k_wgrad_all, dim3(IGMC_WG_BLOCKS, 3), IGMC_BLOCK, 0, stream, b, m);
   const int rows0 = m.R * m.L + m.L + 1;
   const float* d0 = m.dpre[0];
   if (rows0 <= 32) IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<4>), IGMC_L0_BLOCKS, IGMC_BLOCK, 0, stream, b, m, d0, m.l0_part);
@@ -905,14 +1006,36 @@ void igmc_launch_sse(const BatchDev& b, const float* out, double* acc, void* str
   IGMC_PLAUNCH("k_sse_acc", k_sse_acc, 1, IGMC_BLOCK, 0, stream, b, out, acc);
 }
 
-void igmc_launch_adam(float* p, const float* g, float* m1, float* m2, int64_t n, float step_size,
-                      float inv_sqrt_bc2, float beta1, float beta2, float eps, float wd, const int64_t* ctrl,
-                      void* stream) {
+void igmc_launch_tick(int64_t* ctrl, void* stream) { IGMC_PLAUNCH("k_tick", k_tick, 1, 64, 0, stream, ctrl); }
+
+static int adam_grid(int64_t n) {
   int grid = (int)((n + IGMC_BLOCK - 1) / IGMC_BLOCK);
   if (grid > 1024) grid = 1024;
-  if (grid < 1) grid = 1;
-  IGMC_PLAUNCH("k_adam", k_adam, grid, IGMC_BLOCK, 0, stream, p, g, m1, m2, n, step_size, inv_sqrt_bc2, beta1, beta2,
-               eps, wd, ctrl);
+  return grid < 1 ? 1 : grid;
+}
+
+void igmc_launch_adam(float* p, const float* g, float* m1, float* m2, int64_t n, float step_size,
+                      float inv_sqrt_bc2, float beta1, float beta2, float eps, float wd, int64_t* ctrl, int tick,
+                      void* stream) {
+  FinishArgs fin;
+  memset(&fin, 0, sizeof(fin));
+  IGMC_PLAUNCH("k_adam", k_adam, adam_grid(n), IGMC_BLOCK, 0, stream, p, g, m1, m2, n, step_size, inv_sqrt_bc2, beta1,
+               beta2, eps, wd, ctrl, tick, fin);
+}
+
+// Adam + loss + epoch total (+ control-block tick) in ONE launch
+void igmc_launch_finish(const ModelDev& m, const BatchDev& b, float* p, const float* g, float* m1, float* m2,
+                        float step_size, float inv_sqrt_bc2, float beta1, float beta2, float eps, float wd,
+                        int64_t* ctrl, float ARR, float* loss, double* total, void* stream) {
+  FinishArgs fin;
+  fin.enabled = 1;
+  fin.b = b;
+  fin.m = m;
+  fin.ARR = ARR;
+  fin.loss = loss;
+  fin.total = total;
+  IGMC_PLAUNCH("k_step_finish", k_adam, adam_grid(m.n_params), IGMC_BLOCK, 0, stream, p, g, m1, m2,
+               (int64_t)m.n_params, step_size, inv_sqrt_bc2, beta1, beta2, eps, wd, ctrl, ctrl ? 1 : 0, fin);
 }
 
 int igmc_model_prepare(const ModelDev& m) {

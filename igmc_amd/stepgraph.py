@@ -2,10 +2,11 @@
 
 At batch 50 the step is ~35 short kernels: launch-bound.  The per-step scalars (offset into the
 link permutation, epoch, step counter for the dropout hashes, Adam bias corrections) live in a small HBM control
-block advanced by a one-thread kernel (``igmc_ctrl_tick``), so the launch sequence is identical every step and
+block advanced by the step's own last kernel (``igmc_step_finish``), so the launch sequence is identical every step and
 is captured ONCE into a hipGraph (``torch.cuda.CUDAGraph`` capturing the stream the C ABI launches on):
 
-    tick -> extract (4 kernels) -> [edge dropout] -> forward/backward/finalize -> [all-reduce] -> Adam
+    extract (3 kernels) -> [edge dropout] -> forward / backward / finalize -> [all-reduce] -> step_finish
+    (step_finish = Adam + loss + epoch total + control-block advance in one kernel)
 
 Under data parallelism the graph ends before the gradient all-reduce (RCCL runs eagerly on the same stream),
 followed by the control-block Adam launch.
@@ -21,10 +22,14 @@ from . import _lib, engine, parallel
 
 
 def _ctrl_words(step, first, epoch, adam_t, batch, lr, beta1, beta2, eps, wd):
+    """Control block describing the NEXT step to run (the step's last kernel advances it)."""
     w = np.zeros(_lib.CTRL['WORDS'], dtype=np.int64)
     w[_lib.CTRL['STEP']], w[_lib.CTRL['FIRST']], w[_lib.CTRL['EPOCH']] = step, first, epoch
     w[_lib.CTRL['ADAM_T']], w[_lib.CTRL['BATCH']] = adam_t, batch
-    for key, val in (('LR', lr), ('BETA1', beta1), ('BETA2', beta2), ('EPS', eps), ('WD', wd)):
+    step_size = float(lr) / (1.0 - float(beta1) ** adam_t)
+    inv_sqrt_bc2 = 1.0 / (1.0 - float(beta2) ** adam_t) ** 0.5
+    for key, val in (('LR', lr), ('BETA1', beta1), ('BETA2', beta2), ('EPS', eps), ('WD', wd),
+                     ('STEP_SIZE', step_size), ('INV_SQRT_BC2', inv_sqrt_bc2)):
         w[_lib.CTRL[key]] = struct.unpack('<q', struct.pack('<d', float(val)))[0]
     return w
 
@@ -73,7 +78,7 @@ class StepGraph(object):
         n = len(perm)
         self.perm[:n].copy_(perm.to(dtype=torch.int32), non_blocking=False)
         g = self.opt.param_groups[0]
-        w = _ctrl_words(self.model._step, -self.B, epoch if self.ds.dynamic else 0, self.opt.t, self.B, g['lr'],
+        w = _ctrl_words(self.model._step + 1, 0, epoch if self.ds.dynamic else 0, self.opt.t + 1, self.B, g['lr'],
                         g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'])
         self.ctrl.copy_(torch.from_numpy(w))
         self.total.zero_()
@@ -88,13 +93,12 @@ class StepGraph(object):
     def _enqueue(self, B, upto_grad_only=False):
         m, st = self.model, torch.cuda.current_stream().cuda_stream
         flat, grad = m.flat_parameters(), m.flat_grad()
-        self.lib.call('igmc_ctrl_tick', C.c_void_p(self.ctrl.data_ptr()), C.c_void_p(st))
         self.arena.extract(self.ds.link_u.data_ptr(), self.ds.link_v.data_ptr(), self.ds.link_y.data_ptr(),
                            self.perm.data_ptr(), 0, B, self.ds.sample_ratio, self.ds.seed, 0, st)
         use_flags = m.adj_dropout > 0
         if use_flags:
             self.arena.edge_dropout(m.adj_dropout, m.force_undirected, m.seed, 0, st)
-        self.ws.loss_grad(flat.data_ptr(), self.arena, self.out.data_ptr(), grad.data_ptr(), self.loss.data_ptr(),
+        self.ws.loss_grad(flat.data_ptr(), self.arena, self.out.data_ptr(), grad.data_ptr(), None,
                           use_edge_flags=use_flags, seed=m.seed, step=0, multiply_by=float(m.multiply_by),
                           ARR=self.ARR, grad_scale=1.0 / (B * self.world), arr_scale=1.0 / self.world, stream=st)
         if upto_grad_only:
@@ -106,10 +110,13 @@ class StepGraph(object):
         flat, grad = m.flat_parameters(), m.flat_grad()
         if self.world > 1:
             parallel.all_reduce_sum_(grad)
-        self.lib.call('igmc_adam_step_ctrl', C.c_void_p(flat.data_ptr()), C.c_void_p(grad.data_ptr()),
-                      C.c_void_p(self.opt.exp_avg.data_ptr()), C.c_void_p(self.opt.exp_avg_sq.data_ptr()),
-                      flat.numel(), C.c_void_p(self.ctrl.data_ptr()), C.c_void_p(st))
-        self.total += self.loss[0].double() * B
+        # Adam + loss + epoch total + control-block advance in ONE launch (the step's last kernel)
+        g = self.opt.param_groups[0]
+        self.lib.call('igmc_step_finish', self.ws.handle, self.arena.handle, C.c_void_p(flat.data_ptr()),
+                      C.c_void_p(grad.data_ptr()), C.c_void_p(self.opt.exp_avg.data_ptr()),
+                      C.c_void_p(self.opt.exp_avg_sq.data_ptr()), self.ARR, C.c_void_p(self.loss.data_ptr()),
+                      C.c_void_p(self.total.data_ptr()), C.c_void_p(self.ctrl.data_ptr()), 1, g['lr'],
+                      g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], C.c_void_p(st))
 
     def _capture(self):
         torch.cuda.synchronize()

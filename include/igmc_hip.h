@@ -144,6 +144,7 @@ int igmc_model_backward(igmc_model* m, const float* d_params, const igmc_batch* 
                         const float* d_gout, float multiply_by, float* d_grad, void* stream);
 
 /* One optimisation step's loss + gradient (reference train_eval.py:158-175):
+ * (d_loss may be NULL when igmc_step_finish will produce it.)
  * forward, loss = mse_loss(out, y) (mean over the B graphs * loss_scale) + ARR * sum_l sum_r
  * ||W_l[r+1]-W_l[r]||^2, backward.  d_loss[0] = loss, d_loss[1] = sum of squared errors.
  * `grad_scale` multiplies the data-term gradient (1/B for the reference; 1/(global B) under
@@ -163,16 +164,26 @@ int igmc_adam_step(float* d_params, const float* d_grad, float* d_exp_avg, float
  * A hipGraph replay cannot change kernel arguments, so the per-step scalars can live in HBM instead:
  * d_ctrl is an int64[IGMC_CTRL_WORDS] device buffer (slots 8.. hold doubles, bit-cast):
  *   [0] step   [1] first (offset into the link permutation)   [2] epoch   [3] adam_t   [4] batch size
+ *   [5] internal arrival counter (keep 0)
  *   [8] lr  [9] beta1  [10] beta2  [11] eps  [12] weight_decay   [13] lr/(1-beta1^t)  [14] 1/sqrt(1-beta2^t)
  * igmc_ctrl_tick advances it on the device: step+=1, first+=batch, adam_t+=1, slots 13/14 recomputed.
  * Once attached, igmc_extract_batch takes first/epoch, igmc_batch_edge_dropout and the forward's MLP dropout
  * take `step` from it (the host arguments are ignored); NULL detaches. */
 enum { IGMC_CTRL_STEP = 0, IGMC_CTRL_FIRST = 1, IGMC_CTRL_EPOCH = 2, IGMC_CTRL_ADAM_T = 3, IGMC_CTRL_BATCH = 4,
+       IGMC_CTRL_DONE = 5,
        IGMC_CTRL_LR = 8, IGMC_CTRL_BETA1 = 9, IGMC_CTRL_BETA2 = 10, IGMC_CTRL_EPS = 11, IGMC_CTRL_WD = 12,
        IGMC_CTRL_STEP_SIZE = 13, IGMC_CTRL_INV_SQRT_BC2 = 14, IGMC_CTRL_WORDS = 16 };
 int igmc_ctrl_tick(int64_t* d_ctrl, void* stream);
 int igmc_batch_set_ctrl(igmc_batch* b, const int64_t* d_ctrl);
 int igmc_model_set_ctrl(igmc_model* m, const int64_t* d_ctrl);
+/* Adam + loss/epoch-total epilogue in ONE launch (the step's last kernel): updates d_params like
+ * igmc_adam_step, writes d_loss[0..1] like igmc_model_loss_grad (call that one with d_loss = NULL), adds
+ * loss*num_graphs to d_total[0] (reference train_eval.py:176), and -- when d_ctrl is given -- takes the Adam
+ * scalars from the control block and ADVANCES it for the next step (the tick rides in this kernel). */
+int igmc_step_finish(igmc_model* m, const igmc_batch* b, float* d_params, const float* d_grad,
+                     float* d_exp_avg, float* d_exp_avg_sq, float ARR, float* d_loss, double* d_total,
+                     int64_t* d_ctrl, int64_t step, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, void* stream);
 int igmc_adam_step_ctrl(float* d_params, const float* d_grad, float* d_exp_avg, float* d_exp_avg_sq,
                         int64_t n, const int64_t* d_ctrl, void* stream);
 

@@ -40,12 +40,17 @@ def test_ctrl_path_equals_host_argument_path():
     ref = PC.make_ref_model(4, 5, seed=4)
     P0 = PC.flatten_params(ws, ref)
     outs = {}
-    for mode in ('host', 'ctrl'):
+    for mode in ('host', 'ctrl', 'finish'):
         P, M1, M2 = P0.copy(), np.zeros_like(P0), np.zeros_like(P0)
         G, out, loss = np.zeros_like(P0), np.zeros(B, np.float32), np.zeros(2, np.float32)
         batch = b1 if mode == 'host' else b2
         ctrl = ctrl_words(step=10, first=-B, epoch=3, adam_t=0, batch=B)
-        if mode == 'ctrl':
+        if mode == 'finish':      # control block describes the NEXT step; the step's last kernel advances it
+            ctrl = ctrl_words(step=11, first=0, epoch=3, adam_t=1, batch=B)
+            for k, v in ((13, 1e-3 / (1 - 0.9)), (14, 1.0 / (1 - 0.999) ** 0.5)):
+                ctrl[k] = struct.unpack('<q', struct.pack('<d', v))[0]
+        total = np.zeros(1, np.float64)
+        if mode != 'host':
             lib.call('igmc_batch_set_ctrl', batch.handle, C.c_void_p(ctrl.ctypes.data))
             lib.call('igmc_model_set_ctrl', ws.handle, C.c_void_p(ctrl.ctypes.data))
         else:
@@ -60,6 +65,14 @@ def test_ctrl_path_equals_host_argument_path():
                              use_edge_flags=True, seed=7, step=424242, ARR=0.001)
                 lib.call('igmc_adam_step_ctrl', C.c_void_p(P.ctypes.data), C.c_void_p(G.ctypes.data),
                          C.c_void_p(M1.ctypes.data), C.c_void_p(M2.ctypes.data), len(P), C.c_void_p(ctrl.ctypes.data), None)
+            elif mode == 'finish':
+                batch.extract(lu, lv, ly, perm, 12345, B, 1.0, 7, 999)
+                batch.edge_dropout(0.2, False, 7, 424242)
+                ws.loss_grad(P.ctypes.data, batch, out.ctypes.data, G.ctypes.data, None,
+                             use_edge_flags=True, seed=7, step=424242, ARR=0.001)
+                lib.call('igmc_step_finish', ws.handle, batch.handle, C.c_void_p(P.ctypes.data), C.c_void_p(G.ctypes.data),
+                         C.c_void_p(M1.ctypes.data), C.c_void_p(M2.ctypes.data), 0.001, C.c_void_p(loss.ctypes.data),
+                         C.c_void_p(total.ctypes.data), C.c_void_p(ctrl.ctypes.data), 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, None)
             else:
                 batch.extract(lu, lv, ly, perm, i * B, B, 1.0, 7, 3)
                 batch.edge_dropout(0.2, False, 7, 11 + i)
@@ -71,7 +84,10 @@ def test_ctrl_path_equals_host_argument_path():
         outs[mode] = rec
         if mode == 'ctrl':
             assert ctrl[0] == 13 and ctrl[1] == 2 * B and ctrl[3] == 3
-    for a, b in zip(outs['host'], outs['ctrl']):
+        if mode == 'finish':
+            assert ctrl[0] == 14 and ctrl[1] == 3 * B and ctrl[3] == 4 and ctrl[5] == 0
+            assert total[0] == pytest.approx(sum(float(r[3][0]) * B for r in rec), rel=1e-6)
+    for a, b in list(zip(outs['host'], outs['ctrl'])) + list(zip(outs['host'], outs['finish'])):
         for x, y in zip(a[:2], b[:2]):
             assert np.array_equal(x, y)          # same links, same sampling, same dropout flags
         # lr is a float argument on the host path and a double in the control block: last-ulp differences only
