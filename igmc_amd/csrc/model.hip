@@ -441,17 +441,26 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_l0_bwd(BatchDev b, ModelDev m, c
   for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
   const int chunk = (N + (int)gridDim.x - 1) / (int)gridDim.x;
   const int lo = blockIdx.x * chunk, hi = (lo + chunk < N) ? lo + chunk : N;
-  for (int i = lo; i < hi; ++i) {
-    const float d = dpre[(size_t)i * 32 + f];
-    const int lab = b.node_label[i];
-    const uint16_t* cn = m.cnt0 + (size_t)i * RL;
+  for (int i0 = lo; i0 < hi; i0 += 4) {          // 4 nodes in flight: the loads of a group are independent
+    float d[4];
+    int lab[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = (i0 + u < hi) ? i0 + u : hi - 1;
+      d[u] = (i0 + u < hi) ? dpre[(size_t)i * 32 + f] : 0.f;
+      lab[u] = b.node_label[i];
+    }
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
       const int c = cg + 8 * k;
-      float w = 0.f;
-      if (c < RL) w = (float)cn[c];
-      else if (c == RL + lab || c == RL + m.L) w = 1.f;
-      acc[k] += w * d;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = (i0 + u < hi) ? i0 + u : hi - 1;
+        float w = 0.f;
+        if (c < RL) w = (float)m.cnt0[(size_t)i * RL + c];
+        else if (c == RL + lab[u] || c == RL + m.L) w = 1.f;
+        acc[k] += w * d[u];
+      }
     }
   }
   float* dst = part + (size_t)blockIdx.x * rows * 32;
@@ -655,6 +664,173 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_head_bwd_w(BatchDev b, ModelDev 
   }
 }
 
+// =================================================================== head on f32 MFMA (D % 16 == 0)
+// The three head products are tiny GEMMs ([B,D]x[D,128], [B,128]x[128,D], [128,B]x[B,D]); both MFMA operands
+// are loaded straight from global memory as float4 / 64-byte row segments (no LDS staging), so each kernel is
+// a handful of MFMAs per wave and finishes in the launch floor.
+__device__ __forceinline__ const float* head_feat_ptr(const BatchDev& b, const ModelDev& m, int g, int k) {
+  if (k < 256) {
+    const int side = k >> 7, l = (k >> 5) & 3, f = k & 31;
+    const int nu = b.node_off[g], nv = nu + b.n_users[g];
+    return m.h[l] + (size_t)(side ? nv : nu) * 32 + f;
+  }
+  return m.side + (size_t)g * m.S + (k - 256);
+}
+
+// lin1 (+ReLU, dropout) + lin2 for 16 graphs per workgroup; wave w owns hidden units [16w, 16w+16)
+__global__ __launch_bounds__(512) void k_head_fwd_mfma(BatchDev b, ModelDev m, const float* __restrict__ P,
+                                                         int training, const uint8_t* __restrict__ inj_mask,
+                                                         uint64_t seed, uint64_t step_arg, float mult,
+                                                         float* __restrict__ out) {
+  __shared__ float spart[8][16];
+  const uint64_t step = m.ctrl ? (uint64_t)m.ctrl[IGMC_CTRL_STEP] : step_arg;
+  const int B = b.totals[3], D = m.D;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int row0 = blockIdx.x * 16, n0 = wave * 16;
+  const int ga = (row0 + li < B) ? row0 + li : B - 1;        // graph feeding the A fragment of this lane
+  const float* wrow = P + m.off_l1w + (int64_t)(n0 + li) * D;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < D / 16; ++s) {
+    const int k0 = s * 16 + 4 * kq;
+    const float4 a4 = *(const float4*)head_feat_ptr(b, m, ga, k0);
+    const float4 b4 = *(const float4*)(wrow + k0);
+    if (training && wave == 0 && row0 + li < B) *(float4*)(m.feat + (size_t)ga * D + k0) = a4;
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc, 0, 0, 0);
+  }
+  const int n = n0 + li;
+  const float b1 = P[m.off_l1b + n], w2 = P[m.off_l2w + n];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = kq * 4 + rr, g = row0 + r;
+    float a = acc[rr] + b1;
+    a = a > 0.f ? a : 0.f;
+    if (training && g < B) {
+      m.a1[g * 128 + n] = a;
+      const int keep = inj_mask ? (int)inj_mask[g * 128 + n]
+                                : (int)(igmc_u01(igmc_unit_hash(seed, step, (uint32_t)g, (uint32_t)n)) >= 0.5f);
+      m.lmask[g * 128 + n] = (uint8_t)keep;
+      a = keep ? a * 2.f : 0.f;    // F.dropout(p=0.5): kept units scaled by 1/(1-p)
+    }
+    const float p = igmc_group16_sum_f(a * w2);
+    if (li == 0) spart[wave][r] = p;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16 && row0 + (int)threadIdx.x < B) {
+    const int g = row0 + threadIdx.x;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) s += spart[w][threadIdx.x];
+    const float o = (s + P[m.off_l2b]) * mult;
+    out[g] = o;
+    m.err[g] = o - b.y[g];
+  }
+}
+
+// d feat = dz @ lin1.weight, dz formed on the fly; wave -> 16 fan-in columns; also dPre of the top layer
+__global__ __launch_bounds__(512) void k_head_bwd_a_mfma(BatchDev b, ModelDev m, const float* __restrict__ P,
+                                                           const float* __restrict__ gout, int from_err,
+                                                           float grad_scale, float mult, float drop_scale,
+                                                           float* __restrict__ dpre_top) {
+  const int B = b.totals[3], D = m.D;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int row0 = blockIdx.x * 16;
+  const int nt = blockIdx.y * 8 + wave;
+  if (nt * 16 >= D) return;
+  const int n0 = nt * 16;
+  const int ga = (row0 + li < B) ? row0 + li : B - 1;
+  const bool arow_ok = row0 + li < B;
+  const float dp = (from_err ? 2.f * m.err[ga] * grad_scale : gout[ga]) * mult;
+  const float* w1 = P + m.off_l1w;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int j0 = s * 16 + 4 * kq;
+    const float4 a4 = *(const float4*)(m.a1 + ga * 128 + j0);
+    const uint32_t mk = *(const uint32_t*)(m.lmask + ga * 128 + j0);
+    const float4 w4 = *(const float4*)(P + m.off_l2w + j0);
+    float dzv[4];
+    dzv[0] = (arow_ok && a4.x > 0.f && (mk & 0xFFu)) ? dp * w4.x * drop_scale : 0.f;
+    dzv[1] = (arow_ok && a4.y > 0.f && ((mk >> 8) & 0xFFu)) ? dp * w4.y * drop_scale : 0.f;
+    dzv[2] = (arow_ok && a4.z > 0.f && ((mk >> 16) & 0xFFu)) ? dp * w4.z * drop_scale : 0.f;
+    dzv[3] = (arow_ok && a4.w > 0.f && ((mk >> 24) & 0xFFu)) ? dp * w4.w * drop_scale : 0.f;
+    if (nt == 0 && arow_ok) {
+      float4 o;
+      o.x = dzv[0]; o.y = dzv[1]; o.z = dzv[2]; o.w = dzv[3];
+      *(float4*)(m.dz + ga * 128 + j0) = o;
+    }
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm) {
+      const float bv = w1[(int64_t)(j0 + mm) * D + n0 + li];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv[mm], bv, acc, 0, 0, 0);
+    }
+  }
+  const int k = n0 + li;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int g = row0 + kq * 4 + rr;
+    if (g >= B) continue;
+    const float v = acc[rr];
+    m.gfeat[(size_t)g * D + k] = v;
+    if (k < 256 && ((k >> 5) & 3) == 3) {
+      const int side = k >> 7, f = k & 31;
+      const int nu = b.node_off[g], nv = nu + b.n_users[g];
+      const size_t node = (size_t)(side ? nv : nu);
+      const float hv = m.h[3][node * 32 + f];
+      dpre_top[node * 32 + f] = v * (1.f - hv * hv);
+    }
+  }
+}
+
+// d lin1.weight = dz^T @ feat (reduction over the B graphs, 4 per MFMA); block x = 16 hidden units, wave -> 16
+// fan-in columns; block x == 8 does d lin1.bias / d lin2.weight / d lin2.bias
+__global__ __launch_bounds__(IGMC_BLOCK) void k_head_bwd_w_mfma(BatchDev b, ModelDev m, const float* __restrict__ P,
+                                                                  const float* __restrict__ gout, int from_err,
+                                                                  float grad_scale, float mult, float drop_scale,
+                                                                  float* __restrict__ grad) {
+  const int B = b.totals[3], D = m.D, tid = threadIdx.x;
+  if (blockIdx.x == 8) {
+    if (blockIdx.y != 0) return;
+    if (tid < 128) {
+      float s = 0.f;
+      for (int g = 0; g < B; ++g) s += m.dz[g * 128 + tid];
+      grad[m.off_l1b + tid] = s;
+    } else {
+      const int j = tid - 128;
+      float s = 0.f, s2 = 0.f;
+      for (int g = 0; g < B; ++g) {
+        const float dp = (from_err ? 2.f * m.err[g] * grad_scale : gout[g]) * mult;
+        const float a = m.lmask[g * 128 + j] ? m.a1[g * 128 + j] * drop_scale : 0.f;
+        s += dp * a;
+        s2 += dp;
+      }
+      grad[m.off_l2w + j] = s;
+      if (j == 0) grad[m.off_l2b] = s2;
+    }
+    return;
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int j0 = blockIdx.x * 16;
+  const int nt = blockIdx.y * 4 + wave;
+  if (nt * 16 >= D) return;
+  const int n0 = nt * 16;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int g0 = 0; g0 < B; g0 += 4) {
+    const int g = g0 + kq;
+    const bool ok = g < B;
+    const float av = ok ? m.dz[g * 128 + j0 + li] : 0.f;
+    const float bv = ok ? m.feat[(size_t)g * D + n0 + li] : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) grad[m.off_l1w + (int64_t)(j0 + kq * 4 + rr) * D + n0 + li] = acc[rr];
+}
+
 // =================================================================== partial reduction + finalize
 // graw layout: [3][5152] conv1..3 (32x160 + 32) | [3][R*4] d att | [(R*L+L+1)*32] layer-0 table
 // Sections A (weight-gradient partials) and C (layer-0 tables): 64 outputs x 4 partial-slices per block;
@@ -757,8 +933,18 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize(ModelDev m, const float
     gp[4] += b1 * b1; gp[5] += b1 * b2; gp[6] += b1 * b3;
     gp[7] += b2 * b2; gp[8] += b2 * b3; gp[9] += b3 * b3;
   }
+  {
+    __shared__ float sg10[4][10];
 #pragma unroll
-  for (int q = 0; q < 10; ++q) gp[q] = igmc_block_sum_f(gp[q], smf);
+    for (int q = 0; q < 10; ++q) gp[q] = igmc_wave_sum_f(gp[q]);
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 10; ++q) sg10[wave][q] = gp[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 10; ++q) gp[q] = (sg10[0][q] + sg10[1][q]) + (sg10[2][q] + sg10[3][q]);
+  }
   if (tid == 0) {
     const int ij[10][2] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {1, 1}, {1, 2}, {1, 3}, {2, 2}, {2, 3}, {3, 3}};
     for (int q = 0; q < 10; ++q) {
@@ -949,7 +1135,10 @@ void igmc_launch_forward(const ModelDev& m, const BatchDev& b, const float* P, i
   }
   const int hgrid = (B + IGMC_HG - 1) / IGMC_HG;
   const size_t fs = (size_t)IGMC_HG * m.D * sizeof(float);
-  if (fs <= 48 * 1024)
+  if (m.D % 16 == 0)
+    IGMC_PLAUNCH("k_head_fwd", k_head_fwd_mfma, (B + 15) / 16, 512, 0, stream, b, m, P, training, inj_mask, seed, step,
+                 mult, out);
+  else if (fs <= 48 * 1024)
     IGMC_PLAUNCH("k_head_fwd", (k_head_fwd<true>), hgrid, 512, fs, stream, b, m, P, training, inj_mask, seed, step,
                  mult, out);
   else
@@ -963,10 +1152,17 @@ void igmc_launch_backward(const ModelDev& m, const BatchDev& b, const float* P, 
   const int g16 = igmc_rows_grid(m.node_cap, 4, IGMC_GATHER_BLOCKS);
   const int g64 = igmc_rows_grid(m.node_cap, 64, 512);
   const int hgrid = (B + IGMC_HG - 1) / IGMC_HG;
-  IGMC_PLAUNCH("k_head_bwd_a", k_head_bwd_a, hgrid, 1024, 0, stream, b, m, P, gout, from_err, grad_scale, mult,
-               drop_scale, m.dpre[3]);
-  IGMC_PLAUNCH("k_head_bwd_w", k_head_bwd_w, dim3(17, (m.D + 255) / 256), IGMC_BLOCK, 0, stream, b, m, P, gout,
-               from_err, grad_scale, mult, drop_scale, grad);
+  if (m.D % 16 == 0) {
+    IGMC_PLAUNCH("k_head_bwd_a", k_head_bwd_a_mfma, dim3((B + 15) / 16, (m.D / 16 + 7) / 8), 512, 0, stream, b, m, P,
+                 gout, from_err, grad_scale, mult, drop_scale, m.dpre[3]);
+    IGMC_PLAUNCH("k_head_bwd_w", k_head_bwd_w_mfma, dim3(9, (m.D / 16 + 3) / 4), IGMC_BLOCK, 0, stream, b, m, P, gout,
+                 from_err, grad_scale, mult, drop_scale, grad);
+  } else {
+    IGMC_PLAUNCH("k_head_bwd_a", k_head_bwd_a, hgrid, 1024, 0, stream, b, m, P, gout, from_err, grad_scale, mult,
+                 drop_scale, m.dpre[3]);
+    IGMC_PLAUNCH("k_head_bwd_w", k_head_bwd_w, dim3(17, (m.D + 255) / 256), IGMC_BLOCK, 0, stream, b, m, P, gout,
+                 from_err, grad_scale, mult, drop_scale, grad);
+  }
   const int na = m.R * 4;
   const size_t gsa = (size_t)(m.R * 4 + 16 * m.R * 4) * sizeof(float);
   const size_t ysz = (size_t)32 * (128 + 4) * sizeof(float);

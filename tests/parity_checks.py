@@ -180,20 +180,28 @@ def reverse_positions(d):
 
 
 def run_model_parity(be, case, R, ARR=0.001, use_dropout=True, multiply_by=1.0, seed=3, check_eval=True,
-                     rtol=2e-4, atol=2e-5):
+                     rtol=2e-4, atol=2e-5, n_side=0):
     """Engine forward / loss+grad on one extracted batch vs the PyG-1.4.2 restatement (oracle/pyg_ref.py)
     on IDENTICAL inputs: same subgraphs, same weights, same dropout masks."""
     import torch
     from oracle import pyg_ref
     g, b, d = extract_case(be, case, replay=False)
     L = 2 * case['h'] + 2
-    ws = engine.ModelWorkspace(be.lib, be.device, R, 4, L, 0, b.node_capacity, b.edge_capacity, b.max_graphs)
-    ref = make_ref_model(L, R, seed=seed, adj_dropout=0.2 if use_dropout else 0.0, multiply_by=multiply_by)
+    ws = engine.ModelWorkspace(be.lib, be.device, R, 4, L, n_side, b.node_capacity, b.edge_capacity, b.max_graphs)
+    ref = make_ref_model(L, R, n_side=n_side, seed=seed, adj_dropout=0.2 if use_dropout else 0.0,
+                         multiply_by=multiply_by)
     flat = flatten_params(ws, ref)
     P = be.dev(flat)
     B = d['B']
     out = be.dev(np.zeros(B, np.float32))
     pyg = batch_to_pyg(d, L)
+    side_buf = None
+    if n_side:        # side features of the two target nodes (reference models.py:208-209)
+        side = np.random.default_rng(seed + 1).standard_normal((B, n_side)).astype(np.float32)
+        side_buf = be.dev(side)
+        b.set_side_features(be.ptr(side_buf), n_side)
+        pyg.u_feature = torch.from_numpy(side[:, :n_side // 2].copy())
+        pyg.v_feature = torch.from_numpy(side[:, n_side // 2:].copy())
     res = {}
     if check_eval:
         ws.forward(be.ptr(P), b, be.ptr(out), training=False, multiply_by=multiply_by)
@@ -233,7 +241,7 @@ def run_model_parity(be, case, R, ARR=0.001, use_dropout=True, multiply_by=1.0, 
         worst = max(worst, err)
         assert err < 2e-3, '%s: max rel-to-peak grad error %.3e' % (key, err)
     res.update(train_out=got_out, loss=got_loss, worst_grad_err=worst, ws=ws, batch=b, graph=g, P=P, flat=flat,
-               ref=ref, d=d)
+               ref=ref, d=d, side=side_buf)
     return res
 
 

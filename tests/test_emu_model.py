@@ -32,6 +32,14 @@ def test_forward_backward_parity(be, name, n, R, drop, mult):
     assert res['worst_grad_err'] < 1e-4
 
 
+@pytest.mark.parametrize('n_side', [32, 10])
+def test_side_features(be, n_side):
+    """--use-features path (reference models.py:186-188,208-209): lin1 widens by n_side; 32 -> MFMA head
+    kernels (D %% 16 == 0), 10 -> the generic head kernels."""
+    res = PC.run_model_parity(be, sub('synth_nocap', 3), R=5, use_dropout=False, n_side=n_side)
+    assert res['worst_grad_err'] < 1e-4
+
+
 def test_adam_matches_torch(be):
     import torch
     rng = np.random.default_rng(0)

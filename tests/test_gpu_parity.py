@@ -71,6 +71,12 @@ def test_model_forward_backward_parity(be, name, n, R, drop, mult):
     assert res['worst_grad_err'] < 2e-3
 
 
+@pytest.mark.parametrize('n_side', [48, 10])
+def test_side_features(be, n_side):
+    res = PC.run_model_parity(be, sub('flixster', 40), R=10, use_dropout=True, n_side=n_side)
+    assert res['worst_grad_err'] < 2e-3
+
+
 def test_bitwise_reproducible(be):
     """atomic-free aggregation: two runs of the same step give identical bits (doubles as a race detector)."""
     r1 = PC.run_model_parity(be, sub('synth_nocap', 16), R=5, use_dropout=True)
