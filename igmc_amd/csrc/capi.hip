@@ -465,7 +465,7 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   fail |= M.get(&d.feat, Bc * d.D) | M.get(&d.a1, Bc * 128) | M.get(&d.lmask, Bc * 128) | M.get(&d.dz, Bc * 128) |
           M.get(&d.gfeat, Bc * d.D) | M.get(&d.err, Bc) | M.get(&d.cnt0, N * d.R * d.L);
   const size_t rows0 = (size_t)d.R * d.L + d.L + 1;
-  fail |= M.get(&d.wg_part, (size_t)3 * IGMC_WG_BLOCKS * igmc_wg_stride()) |
+  fail |= M.get(&d.wg_part, (size_t)4 * IGMC_WG_BLOCKS * igmc_wg_stride()) |
           M.get(&d.gatt_part, (size_t)3 * IGMC_GATHER_BLOCKS * d.R * 4) |
           M.get(&d.l0_part, (size_t)IGMC_L0_BLOCKS * rows0 * 32) |
           M.get(&d.graw, (size_t)3 * igmc_wg_stride() + 3 * d.R * 4 + rows0 * 32) | M.get(&d.arr_part, 4);

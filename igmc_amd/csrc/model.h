@@ -27,7 +27,7 @@ struct ModelDev {
   float* err;         // [Bcap]      out - y
   uint16_t* cnt0;     // [Ncap,R*L]  per-node histogram of kept in-edge codes (layer-0 weight gradient)
   // gradient partials
-  float* wg_part;     // [3][IGMC_WG_BLOCKS][32*160+32]
+  float* wg_part;     // [4][IGMC_WG_BLOCKS][32*160+32]  (slice 3 = layer-0 table when it has <= 32 rows)
   float* gatt_part;   // [3][IGMC_GATHER_BLOCKS][R*4]
   float* l0_part;     // [IGMC_L0_BLOCKS][(R*L+L+1)*32]
   float* graw;        // [3][32*160+32] + [3][R*4] + l0 rows: reduced partials

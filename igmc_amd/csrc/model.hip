@@ -160,50 +160,50 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_gather(BatchDev b, int R, c
       const uint32_t w = ok ? b.ecr[e] : 0u;
       int kp = ok ? 1 : 0;
       if (FLAGS && ok) kp = (b.eflag[e] >> kbit) & 1;
-      const int n = (end - c0 < 16) ? end - c0 : 16;
-      for (int k0 = 0; k0 < n; k0 += 4) {
-        uint32_t wk[4];
-        int kk[4];
-        float2 x[4];
+      // broadcast the 16 entries of the chunk and issue ALL their feature-row loads before any use:
+      // one memory round trip per chunk instead of four
+      uint32_t wk[16];
+      float2 x[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          wk[q] = __shfl(w, k0 + q, 16);
-          kk[q] = __shfl(kp, k0 + q, 16);
-        }
+      for (int q = 0; q < 16; ++q) {
+        wk[q] = __shfl(w, q, 16);
+        const int kk = __shfl(kp, q, 16);          // 0 for dropped edges and for lanes past the row end
+        wk[q] = kk ? wk[q] : 0xFFFFFFFFu;
+      }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (kk[q]) x[q] = *(const float2*)(in + (size_t)(wk[q] & 0xFFFFFFu) * 32 + 2 * t);
-          else { x[q].x = 0.f; x[q].y = 0.f; }
-        }
+      for (int q = 0; q < 16; ++q) {
+        if (wk[q] != 0xFFFFFFFFu) x[q] = *(const float2*)(in + (size_t)(wk[q] & 0xFFFFFFu) * 32 + 2 * t);
+        else { x[q].x = 0.f; x[q].y = 0.f; }
+      }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int r = (int)(wk[q] >> 24);
-          if (!ATTG) {
-            const float* a = s_att + r * 4;
+      for (int q = 0; q < 16; ++q) {
+        if (wk[q] == 0xFFFFFFFFu) continue;
+        const int r = (int)(wk[q] >> 24);
+        if (!ATTG) {
+          const float* a = s_att + r * 4;
 #pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-              ax[bb] += a[bb] * x[q].x;
-              ay[bb] += a[bb] * x[q].y;
-            }
-          } else if (kk[q]) {
-            if (r != cur) {
-              if (cur >= 0) {   // flush the finished relation run
-                const float* a = s_att + cur * 4;
-#pragma unroll
-                for (int bb = 0; bb < 4; ++bb) {
-                  ax[bb] += a[bb] * tx;
-                  ay[bb] += a[bb] * ty;
-                  const float p = igmc_group16_sum_f(yx[bb] * tx + yy[bb] * ty);
-                  if (t == 0) my_gatt[cur * 4 + bb] += p;
-                }
-              }
-              cur = r;
-              tx = 0.f;
-              ty = 0.f;
-            }
-            tx += x[q].x;
-            ty += x[q].y;
+          for (int bb = 0; bb < 4; ++bb) {
+            ax[bb] += a[bb] * x[q].x;
+            ay[bb] += a[bb] * x[q].y;
           }
+        } else {
+          if (r != cur) {
+            if (cur >= 0) {   // flush the finished relation run
+              const float* a = s_att + cur * 4;
+#pragma unroll
+              for (int bb = 0; bb < 4; ++bb) {
+                ax[bb] += a[bb] * tx;
+                ay[bb] += a[bb] * ty;
+                const float p = igmc_group16_sum_f(yx[bb] * tx + yy[bb] * ty);
+                if (t == 0) my_gatt[cur * 4 + bb] += p;
+              }
+            }
+            cur = r;
+            tx = 0.f;
+            ty = 0.f;
+          }
+          tx += x[q].x;
+          ty += x[q].y;
         }
       }
     }
@@ -360,9 +360,13 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_dense_y_all(BatchDev b, ModelDev
 __global__ __launch_bounds__(IGMC_BLOCK) void k_wgrad_all(BatchDev b, ModelDev m) {
   __shared__ float sacc[32 * IGMC_KCAT + 32];
   const int ly = blockIdx.y;
-  const float* __restrict__ X = m.h[ly];
-  const float* __restrict__ D1 = m.gagg[ly];
-  const float* __restrict__ D2 = m.dpre[ly + 1];
+  // ly == 3: layer 0, whose "X" is synthesised from the per-node code histogram cnt0 plus the one-hot
+  // columns for d root0[label] / d bias0 (codes < 32 only; larger tables use k_l0_bwd)
+  const bool is_l0 = ly == 3;
+  const int RL = m.R * m.L;
+  const float* __restrict__ X = m.h[is_l0 ? 0 : ly];
+  const float* __restrict__ D1 = m.gagg[is_l0 ? 0 : ly];
+  const float* __restrict__ D2 = m.dpre[is_l0 ? 0 : ly + 1];
   float* part = m.wg_part + ((size_t)ly * IGMC_WG_BLOCKS + blockIdx.x) * (32 * IGMC_KCAT + 32);
   const int N = b.totals[0];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -381,10 +385,19 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_wgrad_all(BatchDev b, ModelDev m
       const int row = row0 + 4 * r4 + kq;
       const bool ok = row < N;
       const int rs = ok ? row : 0;
-      float2 a2 = *(const float2*)(X + (size_t)rs * 32 + 2 * li);
+      float2 a2;
+      if (!is_l0) {
+        a2 = *(const float2*)(X + (size_t)rs * 32 + 2 * li);
+      } else {
+        const int lab = b.node_label[rs];
+        const int c0 = 2 * li, c1 = 2 * li + 1;
+        a2.x = (c0 < RL) ? (float)m.cnt0[(size_t)rs * RL + c0] : ((c0 == RL + lab || c0 == RL + m.L) ? 1.f : 0.f);
+        a2.y = (c1 < RL) ? (float)m.cnt0[(size_t)rs * RL + c1] : ((c1 == RL + lab || c1 == RL + m.L) ? 1.f : 0.f);
+      }
       if (!ok) { a2.x = 0.f; a2.y = 0.f; }
 #pragma unroll
       for (int nt = 0; nt < 10; ++nt) {
+        if (is_l0 && nt < 8) continue;
         float bv = (nt < 8) ? D1[(size_t)rs * 128 + nt * 16 + li] : D2[(size_t)rs * 32 + (nt - 8) * 16 + li];
         if (!ok) bv = 0.f;
         if (nt >= 8) bsum[nt - 8] += bv;
@@ -691,15 +704,25 @@ __global__ __launch_bounds__(512) void k_head_fwd_mfma(BatchDev b, ModelDev m, c
   const int ga = (row0 + li < B) ? row0 + li : B - 1;        // graph feeding the A fragment of this lane
   const float* wrow = P + m.off_l1w + (int64_t)(n0 + li) * D;
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s < D / 16; ++s) {
-    const int k0 = s * 16 + 4 * kq;
-    const float4 a4 = *(const float4*)head_feat_ptr(b, m, ga, k0);
-    const float4 b4 = *(const float4*)(wrow + k0);
-    if (training && wave == 0 && row0 + li < B) *(float4*)(m.feat + (size_t)ga * D + k0) = a4;
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc, 0, 0, 0);
+  const int nch = D / 16;
+  for (int s0 = 0; s0 < nch; s0 += 8) {          // 8 chunks (16 float4 loads) in flight before the MFMAs
+    float4 a4[8], b4[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k0 = ((s0 + u < nch) ? s0 + u : nch - 1) * 16 + 4 * kq;
+      a4[u] = *(const float4*)head_feat_ptr(b, m, ga, k0);
+      b4[u] = *(const float4*)(wrow + k0);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (s0 + u >= nch) continue;
+      const int k0 = (s0 + u) * 16 + 4 * kq;
+      if (training && wave == 0 && row0 + li < B) *(float4*)(m.feat + (size_t)ga * D + k0) = a4[u];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u].x, b4[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u].y, b4[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u].z, b4[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u].w, b4[u].w, acc, 0, 0, 0);
+    }
   }
   const int n = n0 + li;
   const float b1 = P[m.off_l1b + n], w2 = P[m.off_l2w + n];
@@ -797,11 +820,13 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_head_bwd_w_mfma(BatchDev b, Mode
     if (blockIdx.y != 0) return;
     if (tid < 128) {
       float s = 0.f;
+#pragma unroll 8
       for (int g = 0; g < B; ++g) s += m.dz[g * 128 + tid];
       grad[m.off_l1b + tid] = s;
     } else {
       const int j = tid - 128;
       float s = 0.f, s2 = 0.f;
+#pragma unroll 8
       for (int g = 0; g < B; ++g) {
         const float dp = (from_err ? 2.f * m.err[g] * grad_scale : gout[g]) * mult;
         const float a = m.lmask[g * 128 + j] ? m.a1[g * 128 + j] * drop_scale : 0.f;
@@ -835,16 +860,17 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_head_bwd_w_mfma(BatchDev b, Mode
 // graw layout: [3][5152] conv1..3 (32x160 + 32) | [3][R*4] d att | [(R*L+L+1)*32] layer-0 table
 // Sections A (weight-gradient partials) and C (layer-0 tables): 64 outputs x 4 partial-slices per block;
 // section B (d att, few outputs x many partials): one wave per output.  Fixed summation order.
-__global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_partials(ModelDev m, int n_gatt_parts) {
+__global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_partials(ModelDev m, int n_gatt_parts, int l0_mfma) {
   __shared__ float sred[4][64];
-  const int wgs = 32 * IGMC_KCAT + 32, na = m.R * 4, n0 = (m.R * m.L + m.L + 1) * 32;
-  const int nblkA = (3 * wgs + 63) / 64, nblkB = (3 * na + 3) / 4, nblkC = (n0 + 63) / 64;
+  const int wgs = 32 * IGMC_KCAT + 32, na = m.R * 4, rows0 = m.R * m.L + m.L + 1, n0 = rows0 * 32;
+  const int nlay = l0_mfma ? 4 : 3;
+  const int nblkA = (nlay * wgs + 63) / 64, nblkB = (3 * na + 3) / 4, nblkC = l0_mfma ? 0 : (n0 + 63) / 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int blk = blockIdx.x;
   if (blk < nblkA + nblkC) {
     const bool secA = blk < nblkA;
     const int o = (secA ? blk : blk - nblkA) * 64 + lane;
-    const int nout = secA ? 3 * wgs : n0;
+    const int nout = secA ? nlay * wgs : n0;
     float s = 0.f;
     if (o < nout) {
       if (secA) {
@@ -860,7 +886,13 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_partials(ModelDev m, int 
     __syncthreads();
     if (wave == 0 && o < nout) {
       const float tot = (sred[0][lane] + sred[1][lane]) + (sred[2][lane] + sred[3][lane]);
-      m.graw[secA ? o : 3 * wgs + 3 * na + o] = tot;
+      if (secA && o >= 3 * wgs) {
+        // layer-0 slice of k_wgrad_all: partial[c][128 + f]  ->  table T0[c][f]
+        const int i = o - 3 * wgs, c = i / IGMC_KCAT, col = i % IGMC_KCAT;
+        if (i < 32 * IGMC_KCAT && c < rows0 && col >= 128) m.graw[3 * wgs + 3 * na + c * 32 + (col - 128)] = tot;
+      } else {
+        m.graw[secA ? o : 3 * wgs + 3 * na + o] = tot;
+      }
     }
   } else {
     blk -= nblkA + nblkC;
@@ -1180,16 +1212,18 @@ void igmc_launch_backward(const ModelDev& m, const BatchDev& b, const float* P, 
                  (const float*)m.dpre[l], P + m.off_basis[l], P + m.off_root[l], m.dpre[l - 1],
                  (const float*)m.h[l - 1], (const float*)m.gfeat, m.D, l - 1);
   }
-  IGMC_PLAUNCH("k_wgrad_all", k_wgrad_all, dim3(IGMC_WG_BLOCKS, 3), IGMC_BLOCK, 0, stream, b, m);
   const int rows0 = m.R * m.L + m.L + 1;
-  const float* d0 = m.dpre[0];
-  if (rows0 <= 32) IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<4>), IGMC_L0_BLOCKS, IGMC_BLOCK, 0, stream, b, m, d0, m.l0_part);
-  else if (rows0 <= 64) IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<8>), IGMC_L0_BLOCKS, IGMC_BLOCK, 0, stream, b, m, d0, m.l0_part);
-  else IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<40>), IGMC_L0_BLOCKS, IGMC_BLOCK, 0, stream, b, m, d0, m.l0_part);
+  const int l0_mfma = rows0 <= 32;       // layer-0 table gradient rides in the batched MFMA launch
+  IGMC_PLAUNCH("k_wgrad_all", k_wgrad_all, dim3(IGMC_WG_BLOCKS, l0_mfma ? 4 : 3), IGMC_BLOCK, 0, stream, b, m);
+  if (!l0_mfma) {
+    const float* d0 = m.dpre[0];
+    if (rows0 <= 64) IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<8>), IGMC_L0_BLOCKS, IGMC_BLOCK, 0, stream, b, m, d0, m.l0_part);
+    else IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<40>), IGMC_L0_BLOCKS, IGMC_BLOCK, 0, stream, b, m, d0, m.l0_part);
+  }
   {
     const int wgs2 = igmc_wg_stride(), n0 = rows0 * 32;
-    const int nblk = (3 * wgs2 + 63) / 64 + (n0 + 63) / 64 + (3 * na + 3) / 4;
-    IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk, IGMC_BLOCK, 0, stream, m, g16);
+    const int nblk = ((l0_mfma ? 4 : 3) * wgs2 + 63) / 64 + (l0_mfma ? 0 : (n0 + 63) / 64) + (3 * na + 3) / 4;
+    IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk, IGMC_BLOCK, 0, stream, m, g16, l0_mfma);
   }
   IGMC_PLAUNCH("k_finalize", k_finalize, 4, IGMC_BLOCK, 0, stream, m, P, grad, arr_coef);
 }
