@@ -101,6 +101,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-steps', type=int, default=20)
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly (no hipGraph replay)')
+    ap.add_argument('--no-overlap', action='store_true', help='extract batch t+1 on the same stream (no overlap)')
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -135,8 +136,8 @@ def main():
     steps_avail = len(perm) // BATCH
     st = torch.cuda.current_stream().cuda_stream
     # the product's training path: one optimisation step = hipGraph replay of
-    # tick -> extract -> [edge dropout] -> forward/backward/finalize -> [flat all-reduce] -> Adam
-    sg = StepGraph(model, opt, ds, BATCH, 0.001, use_graph=not args.no_graph)
+    # { forward/backward/finalize (batch t)  ||  extract batch t+1 } -> [flat all-reduce] -> Adam+loss+tick
+    sg = StepGraph(model, opt, ds, BATCH, 0.001, use_graph=not args.no_graph, overlap=not args.no_overlap)
     state = dict(i=0, epoch=0)
 
     def step():
@@ -170,7 +171,7 @@ def main():
     if rank == 0 and args.profile_steps > 0:
         engine.profile_enable(lib, True)
         Ns, Es = [], []
-        sg.use_graph, sg.graph = False, None          # instrumented pass launches eagerly
+        sg.use_graph, sg.graphs = False, [None, None]   # instrumented pass launches eagerly
         for _ in range(args.profile_steps):
             step()
             info = sg.arena.info(st)

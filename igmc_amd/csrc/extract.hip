@@ -180,7 +180,9 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_extract_nodes(ExtractArgs a) {
   bm_clear(sel_u, Wu);
   bm_clear(sel_v, Wv);
   if (!a.replay) {
-    const int first = a.ctrl ? (int)a.ctrl[IGMC_CTRL_FIRST] : a.first;
+    // with a control block attached the host `first` is an OFFSET relative to the block's (prefetching the
+    // next batch on a second stream uses +B)
+    const int first = a.ctrl ? (int)a.ctrl[IGMC_CTRL_FIRST] + a.first : a.first;
     const uint64_t epoch = a.ctrl ? (uint64_t)a.ctrl[IGMC_CTRL_EPOCH] : a.epoch;
     const int pos = a.link_idx ? a.link_idx[first + g] : first + g;
     u0 = a.link_u[pos];
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_fill(GraphDev G, BatchDev b) {
 // (shared by the two directions when force_undirected).  16 lanes per CSR row.
 __global__ __launch_bounds__(IGMC_BLOCK) void k_edge_flags(BatchDev b, float p, int force_undirected,
                                                             uint64_t seed, uint64_t step_arg, const int64_t* ctrl) {
-  const uint64_t step = ctrl ? (uint64_t)ctrl[IGMC_CTRL_STEP] : step_arg;
+  const uint64_t step = ctrl ? (uint64_t)ctrl[IGMC_CTRL_STEP] + step_arg : step_arg;
   const int N = b.totals[0];
   const int grp = (blockIdx.x * IGMC_BLOCK + threadIdx.x) >> 4, t = threadIdx.x & 15;
   const int ngrp = (gridDim.x * IGMC_BLOCK) >> 4;

@@ -28,10 +28,20 @@ __device__ __forceinline__ float igmc_wave_sum_f(float v) {
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
   return v;
 }
+// sum over the 16 lanes of a DPP row (= one 16-lane group), result in every lane of the row.
+// On gfx950 this is four VALU adds with the row_ror DPP modifier (no LDS-crossbar round trips).
 __device__ __forceinline__ float igmc_group16_sum_f(float v) {
+#ifdef IGMC_HIPEMU
 #pragma unroll
   for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d, 16);
   return v;
+#else
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
+  return v;
+#endif
 }
 __device__ __forceinline__ float igmc_block_sum_f(float v, float* sm) {
   v = igmc_wave_sum_f(v);
@@ -819,22 +829,27 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_head_bwd_w_mfma(BatchDev b, Mode
   if (blockIdx.x == 8) {
     if (blockIdx.y != 0) return;
     if (tid < 128) {
-      float s = 0.f;
-#pragma unroll 8
-      for (int g = 0; g < B; ++g) s += m.dz[g * 128 + tid];
-      grad[m.off_l1b + tid] = s;
+      float s4[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < B; g += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s4[u] += (g + u < B) ? m.dz[(g + u) * 128 + tid] : 0.f;
+      }
+      grad[m.off_l1b + tid] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     } else {
       const int j = tid - 128;
-      float s = 0.f, s2 = 0.f;
-#pragma unroll 8
-      for (int g = 0; g < B; ++g) {
-        const float dp = (from_err ? 2.f * m.err[g] * grad_scale : gout[g]) * mult;
-        const float a = m.lmask[g * 128 + j] ? m.a1[g * 128 + j] * drop_scale : 0.f;
-        s += dp * a;
-        s2 += dp;
+      float s4[4] = {0.f, 0.f, 0.f, 0.f}, t4[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < B; g += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int gg = (g + u < B) ? g + u : B - 1;
+          const float dp = (g + u < B) ? (from_err ? 2.f * m.err[gg] * grad_scale : gout[gg]) * mult : 0.f;
+          const float a = m.lmask[gg * 128 + j] ? m.a1[gg * 128 + j] * drop_scale : 0.f;
+          s4[u] += dp * a;
+          t4[u] += dp;
+        }
       }
-      grad[m.off_l2w + j] = s;
-      if (j == 0) grad[m.off_l2b] = s2;
+      grad[m.off_l2w + j] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+      if (j == 0) grad[m.off_l2b] = (t4[0] + t4[1]) + (t4[2] + t4[3]);
     }
     return;
   }
@@ -845,12 +860,17 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_head_bwd_w_mfma(BatchDev b, Mode
   if (nt * 16 >= D) return;
   const int n0 = nt * 16;
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int g0 = 0; g0 < B; g0 += 4) {
-    const int g = g0 + kq;
-    const bool ok = g < B;
-    const float av = ok ? m.dz[g * 128 + j0 + li] : 0.f;
-    const float bv = ok ? m.feat[(size_t)g * D + n0 + li] : 0.f;
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+  for (int g0 = 0; g0 < B; g0 += 16) {            // 4 MFMA steps (16 graphs) of loads in flight
+    float av[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int g = g0 + 4 * u + kq;
+      const bool ok = g < B;
+      av[u] = ok ? m.dz[g * 128 + j0 + li] : 0.f;
+      bv[u] = ok ? m.feat[(size_t)g * D + n0 + li] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
   }
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) grad[m.off_l1w + (int64_t)(j0 + kq * 4 + rr) * D + n0 + li] = acc[rr];

@@ -1,15 +1,19 @@
-"""hipGraph replay of one optimisation step.
+"""hipGraph replay of the optimisation step, with the NEXT batch's extraction overlapped.
 
-At batch 50 the step is ~35 short kernels: launch-bound.  The per-step scalars (offset into the
-link permutation, epoch, step counter for the dropout hashes, Adam bias corrections) live in a small HBM control
-block advanced by the step's own last kernel (``igmc_step_finish``), so the launch sequence is identical every step and
-is captured ONCE into a hipGraph (``torch.cuda.CUDAGraph`` capturing the stream the C ABI launches on):
+At batch 50 the step is ~25 short kernels and every serialized kernel costs >= 4.7 us on MI355X even when
+trivial (rocprofv3, profiles/): the step is latency-bound, the chip is mostly idle.  Two measures:
 
-    extract (3 kernels) -> [edge dropout] -> forward / backward / finalize -> [all-reduce] -> step_finish
-    (step_finish = Adam + loss + epoch total + control-block advance in one kernel)
+* the per-step scalars (offset into the link permutation, epoch, step counter for the dropout hashes, Adam bias
+  corrections) live in a small HBM control block advanced by the step's own last kernel (``igmc_step_finish``),
+  so the launch sequence is identical every step and is captured ONCE into a hipGraph
+  (``torch.cuda.CUDAGraph`` capturing the streams the C ABI launches on);
+* enclosing-subgraph extraction depends only on the link indices, so the extraction of batch t+1 runs on a
+  second stream (into the other of two arenas) while forward/backward of batch t run on the first:
 
-Under data parallelism the graph ends before the gradient all-reduce (RCCL runs eagerly on the same stream),
-followed by the control-block Adam launch.
+      main :  forward / backward / finalize (arena t%2) ------------------+-> [all-reduce] -> step_finish
+      side :  extract batch t+1 (arena (t+1)%2) [+ its edge dropout] -----+      (Adam + loss + tick)
+
+Under data parallelism the graphs end before the gradient all-reduce (RCCL runs eagerly on the same stream).
 """
 import ctypes as C
 import os
@@ -18,7 +22,7 @@ import struct
 import numpy as np
 import torch
 
-from . import _lib, engine, parallel
+from . import _lib, parallel
 
 
 def _ctrl_words(step, first, epoch, adam_t, batch, lr, beta1, beta2, eps, wd):
@@ -35,9 +39,9 @@ def _ctrl_words(step, first, epoch, adam_t, batch, lr, beta1, beta2, eps, wd):
 
 
 class StepGraph(object):
-    """Runs training steps of ``batch_size`` links of ``dataset`` through the fused path, replaying a hipGraph."""
+    """Runs training steps of ``batch_size`` links of ``dataset`` through the fused path."""
 
-    def __init__(self, model, optimizer, dataset, batch_size, ARR, use_graph=None):
+    def __init__(self, model, optimizer, dataset, batch_size, ARR, use_graph=None, overlap=None):
         self.model, self.opt, self.ds = model, optimizer, dataset
         self.B = int(batch_size)
         self.ARR = float(ARR)
@@ -46,98 +50,131 @@ class StepGraph(object):
         flat = model.flat_parameters()
         self.dev = flat.device
         self.ctrl = torch.zeros(_lib.CTRL['WORDS'], dtype=torch.int64, device=self.dev)
-        self.perm = torch.zeros(max(len(dataset), 1) + self.B, dtype=torch.int32, device=self.dev)
-        self.arena = dataset.arena(self.B, slot='stepgraph')
+        # permutation buffer, padded so that the (discarded) prefetch after the last batch stays in range
+        self.perm = torch.zeros(max(len(dataset), 1) + 2 * self.B, dtype=torch.int32, device=self.dev)
+        self.arenas = [dataset.arena(self.B, slot='stepgraph0'), dataset.arena(self.B, slot='stepgraph1')]
         from .util_functions import DeviceBatch
-        self._db = DeviceBatch(dataset, self.arena, self.B, self.perm, 0)
-        self.ws = model._workspace(self._db)
+        self.ws = model._workspace(DeviceBatch(dataset, self.arenas[0], self.B, self.perm, 0))
         self.out = torch.empty(self.B, dtype=torch.float32, device=self.dev)
         self.loss = torch.zeros(2, dtype=torch.float32, device=self.dev)
         self.total = torch.zeros(1, dtype=torch.float64, device=self.dev)
         if use_graph is None:
             use_graph = os.environ.get('IGMC_NO_GRAPH', '0') != '1'
-        self.use_graph = use_graph
-        self.graph = None
+        if overlap is None:
+            overlap = os.environ.get('IGMC_NO_OVERLAP', '0') != '1'
+        self.use_graph, self.overlap = use_graph, overlap
+        self.side = torch.cuda.Stream(device=self.dev) if overlap else None
+        self.graphs = [None, None]
         self._attached = False
+        self.k = 0                      # steps done in the current epoch (parity selects the arena)
         self.steps_done = 0
+
+    @property
+    def arena(self):                    # the arena holding the batch of the most recent step
+        return self.arenas[(self.k - 1) % 2 if self.k else 0]
 
     # ------------------------------------------------------------------ control block
     def _attach(self):
-        self.lib.call('igmc_batch_set_ctrl', self.arena.handle, C.c_void_p(self.ctrl.data_ptr()))
+        for a in self.arenas:
+            self.lib.call('igmc_batch_set_ctrl', a.handle, C.c_void_p(self.ctrl.data_ptr()))
         self.lib.call('igmc_model_set_ctrl', self.ws.handle, C.c_void_p(self.ctrl.data_ptr()))
         self._attached = True
 
     def detach(self):
         if self._attached:
-            self.lib.call('igmc_batch_set_ctrl', self.arena.handle, None)
+            for a in self.arenas:
+                self.lib.call('igmc_batch_set_ctrl', a.handle, None)
             self.lib.call('igmc_model_set_ctrl', self.ws.handle, None)
             self._attached = False
+
+    def _extract(self, arena, offset, B, step_offset):
+        """Extraction (+ edge dropout) of the batch at ctrl.first + offset into ``arena`` on the current stream."""
+        m, st = self.model, torch.cuda.current_stream().cuda_stream
+        arena.extract(self.ds.link_u.data_ptr(), self.ds.link_v.data_ptr(), self.ds.link_y.data_ptr(),
+                      self.perm.data_ptr(), offset, B, self.ds.sample_ratio, self.ds.seed, 0, st)
+        if m.adj_dropout > 0:
+            arena.edge_dropout(m.adj_dropout, m.force_undirected, m.seed, step_offset, st)
 
     def begin_epoch(self, perm, epoch):
         """``perm``: this rank's link positions for the epoch (1-D int tensor, any device)."""
         n = len(perm)
         self.perm[:n].copy_(perm.to(dtype=torch.int32), non_blocking=False)
+        self.perm[n:n + 2 * self.B].copy_(self.perm[:2 * self.B] if n >= 2 * self.B else self.perm[n - 1].expand(2 * self.B))
         g = self.opt.param_groups[0]
         w = _ctrl_words(self.model._step + 1, 0, epoch if self.ds.dynamic else 0, self.opt.t + 1, self.B, g['lr'],
                         g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'])
         self.ctrl.copy_(torch.from_numpy(w))
         self.total.zero_()
         self.n_links = n
+        self.k = 0
         if not self._attached:
             self._attach()
-        if self.graph is not None and abs(self._graph_lr - g['lr']) > 0:
-            pass          # lr lives in the control block: no re-capture needed
-        self._graph_lr = g['lr']
+        # the first batch of the epoch has nobody to prefetch it
+        self._extract(self.arenas[0], 0, min(self.B, n), 0)
 
     # ------------------------------------------------------------------ one step
-    def _enqueue(self, B, upto_grad_only=False):
+    def _model(self, arena, B):
         m, st = self.model, torch.cuda.current_stream().cuda_stream
         flat, grad = m.flat_parameters(), m.flat_grad()
-        self.arena.extract(self.ds.link_u.data_ptr(), self.ds.link_v.data_ptr(), self.ds.link_y.data_ptr(),
-                           self.perm.data_ptr(), 0, B, self.ds.sample_ratio, self.ds.seed, 0, st)
-        use_flags = m.adj_dropout > 0
-        if use_flags:
-            self.arena.edge_dropout(m.adj_dropout, m.force_undirected, m.seed, 0, st)
-        self.ws.loss_grad(flat.data_ptr(), self.arena, self.out.data_ptr(), grad.data_ptr(), None,
-                          use_edge_flags=use_flags, seed=m.seed, step=0, multiply_by=float(m.multiply_by),
+        self.ws.loss_grad(flat.data_ptr(), arena, self.out.data_ptr(), grad.data_ptr(), None,
+                          use_edge_flags=m.adj_dropout > 0, seed=m.seed, step=0, multiply_by=float(m.multiply_by),
                           ARR=self.ARR, grad_scale=1.0 / (B * self.world), arr_scale=1.0 / self.world, stream=st)
-        if upto_grad_only:
-            return
-        self._finish(B)
 
-    def _finish(self, B):
+    def _finish(self, arena):
         m, st = self.model, torch.cuda.current_stream().cuda_stream
         flat, grad = m.flat_parameters(), m.flat_grad()
         if self.world > 1:
             parallel.all_reduce_sum_(grad)
         # Adam + loss + epoch total + control-block advance in ONE launch (the step's last kernel)
         g = self.opt.param_groups[0]
-        self.lib.call('igmc_step_finish', self.ws.handle, self.arena.handle, C.c_void_p(flat.data_ptr()),
+        self.lib.call('igmc_step_finish', self.ws.handle, arena.handle, C.c_void_p(flat.data_ptr()),
                       C.c_void_p(grad.data_ptr()), C.c_void_p(self.opt.exp_avg.data_ptr()),
                       C.c_void_p(self.opt.exp_avg_sq.data_ptr()), self.ARR, C.c_void_p(self.loss.data_ptr()),
                       C.c_void_p(self.total.data_ptr()), C.c_void_p(self.ctrl.data_ptr()), 1, g['lr'],
                       g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], C.c_void_p(st))
 
-    def _capture(self):
+    def _enqueue(self, parity, B, with_finish=True):
+        """model(batch in arenas[parity]) || extract(next batch -> arenas[1-parity]); then finish."""
+        cur, nxt = self.arenas[parity], self.arenas[1 - parity]
+        main = torch.cuda.current_stream()
+        if self.side is not None:
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                self._extract(nxt, self.B, self.B, 1)
+            self._model(cur, B)
+            main.wait_stream(self.side)          # join BEFORE the control block is advanced
+        else:
+            self._model(cur, B)
+            self._extract(nxt, self.B, self.B, 1)
+        if with_finish:
+            self._finish(cur)
+
+    def _capture(self, parity):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self._enqueue(self.B, upto_grad_only=self.world > 1)
-        self.graph = g
+            self._enqueue(parity, self.B, with_finish=self.world == 1)
+        self.graphs[parity] = g
 
     def step(self, B=None):
         """One optimisation step on the next ``B`` links of the epoch permutation."""
         B = self.B if B is None else int(B)
-        full = B == self.B
-        if full and self.use_graph and self.graph is None and self.steps_done >= 3:
-            # the captured step is NOT executed by the capture, so nothing is skipped or repeated
-            self._capture()
-        if full and self.graph is not None:
-            self.graph.replay()
-            if self.world > 1:
-                self._finish(B)
+        parity = self.k % 2
+        if B != self.B:
+            # ragged last batch of the epoch: its prefetch assumed a full batch -> extract again, run eagerly
+            self._extract(self.arenas[parity], 0, B, 0)
+            self._model(self.arenas[parity], B)
+            self._finish(self.arenas[parity])
         else:
-            self._enqueue(B)
+            if self.use_graph and self.graphs[parity] is None and self.steps_done >= 4:
+                self._capture(parity)     # capturing does not execute: nothing is skipped or repeated
+            if self.graphs[parity] is not None:
+                self.graphs[parity].replay()
+                if self.world > 1:
+                    self._finish(self.arenas[parity])
+            else:
+                self._enqueue(parity, B)
+        self.k += 1
         self.steps_done += 1
         self.model._step += 1
         self.opt.t += 1

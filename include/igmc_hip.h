@@ -167,8 +167,9 @@ int igmc_adam_step(float* d_params, const float* d_grad, float* d_exp_avg, float
  *   [5] internal arrival counter (keep 0)
  *   [8] lr  [9] beta1  [10] beta2  [11] eps  [12] weight_decay   [13] lr/(1-beta1^t)  [14] 1/sqrt(1-beta2^t)
  * igmc_ctrl_tick advances it on the device: step+=1, first+=batch, adam_t+=1, slots 13/14 recomputed.
- * Once attached, igmc_extract_batch takes first/epoch, igmc_batch_edge_dropout and the forward's MLP dropout
- * take `step` from it (the host arguments are ignored); NULL detaches. */
+ * Once attached, igmc_extract_batch uses first = ctrl.first + <host first> (the host value becomes an OFFSET:
+ * +B prefetches the next batch on another stream) and ctrl.epoch; igmc_batch_edge_dropout uses
+ * ctrl.step + <host step>; the forward's MLP dropout uses ctrl.step.  NULL detaches. */
 enum { IGMC_CTRL_STEP = 0, IGMC_CTRL_FIRST = 1, IGMC_CTRL_EPOCH = 2, IGMC_CTRL_ADAM_T = 3, IGMC_CTRL_BATCH = 4,
        IGMC_CTRL_DONE = 5,
        IGMC_CTRL_LR = 8, IGMC_CTRL_BETA1 = 9, IGMC_CTRL_BETA2 = 10, IGMC_CTRL_EPS = 11, IGMC_CTRL_WD = 12,

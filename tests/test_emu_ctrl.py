@@ -59,15 +59,15 @@ def test_ctrl_path_equals_host_argument_path():
         for i in range(3):
             if mode == 'ctrl':
                 lib.call('igmc_ctrl_tick', C.c_void_p(ctrl.ctypes.data), None)
-                batch.extract(lu, lv, ly, perm, 12345, B, 1.0, 7, 999)          # first/epoch args ignored
-                batch.edge_dropout(0.2, False, 7, 424242)                        # step arg ignored
+                batch.extract(lu, lv, ly, perm, 0, B, 1.0, 7, 999)              # first = offset to ctrl.first; epoch ignored
+                batch.edge_dropout(0.2, False, 7, 0)                             # step = offset to ctrl.step
                 ws.loss_grad(P.ctypes.data, batch, out.ctypes.data, G.ctypes.data, loss.ctypes.data,
                              use_edge_flags=True, seed=7, step=424242, ARR=0.001)
                 lib.call('igmc_adam_step_ctrl', C.c_void_p(P.ctypes.data), C.c_void_p(G.ctypes.data),
                          C.c_void_p(M1.ctypes.data), C.c_void_p(M2.ctypes.data), len(P), C.c_void_p(ctrl.ctypes.data), None)
             elif mode == 'finish':
-                batch.extract(lu, lv, ly, perm, 12345, B, 1.0, 7, 999)
-                batch.edge_dropout(0.2, False, 7, 424242)
+                batch.extract(lu, lv, ly, perm, 0, B, 1.0, 7, 999)
+                batch.edge_dropout(0.2, False, 7, 0)
                 ws.loss_grad(P.ctypes.data, batch, out.ctypes.data, G.ctypes.data, None,
                              use_edge_flags=True, seed=7, step=424242, ARR=0.001)
                 lib.call('igmc_step_finish', ws.handle, batch.handle, C.c_void_p(P.ctypes.data), C.c_void_p(G.ctypes.data),
