@@ -66,6 +66,7 @@ struct igmc_batch {
 struct igmc_model {
   int device;
   ModelDev d;
+  ModelAux ax;
   int last_B, last_training, last_flags;
   Allocs mem;
 };
@@ -476,6 +477,22 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
     delete m;
     IGMC_FAIL("hipMalloc failed (model workspace)");
   }
+  {
+    hipStream_t st1, st2;
+    if (hipStreamCreateWithFlags(&st1, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&st2, hipStreamNonBlocking) != hipSuccess) {
+      M.release();
+      delete m;
+      IGMC_FAIL("hipStreamCreate failed");
+    }
+    m->ax.s1 = st1;
+    m->ax.s2 = st2;
+    for (int i = 0; i < 8; ++i) {
+      hipEvent_t e;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) IGMC_FAIL("hipEventCreate failed");
+      m->ax.ev[i] = e;
+    }
+  }
   if (igmc_model_prepare(d)) {
     M.release();
     delete m;
@@ -487,6 +504,9 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
 
 extern "C" void igmc_model_destroy(igmc_model* m) {
   if (!m) return;
+  for (int i = 0; i < 8; ++i) hipEventDestroy((hipEvent_t)m->ax.ev[i]);
+  hipStreamDestroy((hipStream_t)m->ax.s1);
+  hipStreamDestroy((hipStream_t)m->ax.s2);
   m->mem.release();
   delete m;
 }
@@ -529,7 +549,7 @@ extern "C" int igmc_model_forward(igmc_model* m, const float* d_params, const ig
   if (check_fit(m, b, &why)) IGMC_FAIL(why);
   if (!d_params || !d_out) IGMC_FAIL("null buffer");
   m->d.side = b->side;
-  igmc_launch_forward(m->d, b->d, d_params, b->last_B, training, use_edge_flags, d_lin_mask, seed, step, multiply_by,
+  igmc_launch_forward(m->d, m->ax, b->d, d_params, b->last_B, training, use_edge_flags, d_lin_mask, seed, step, multiply_by,
                       d_out, stream);
   HIPCHECK(hipGetLastError());
   m->last_B = b->last_B;
@@ -544,7 +564,7 @@ extern "C" int igmc_model_backward(igmc_model* m, const float* d_params, const i
   if (check_fit(m, b, &why)) IGMC_FAIL(why);
   if (!m->last_training || m->last_B != b->last_B) IGMC_FAIL("backward needs a preceding training-mode forward on this batch");
   if (!d_params || !d_gout || !d_grad) IGMC_FAIL("null buffer");
-  igmc_launch_backward(m->d, b->d, d_params, b->last_B, m->last_flags, d_gout, 0, 0.f, multiply_by, 2.f, 0.f, d_grad,
+  igmc_launch_backward(m->d, m->ax, b->d, d_params, b->last_B, m->last_flags, d_gout, 0, 0.f, multiply_by, 2.f, 0.f, d_grad,
                        stream);
   HIPCHECK(hipGetLastError());
   return 0;
@@ -558,9 +578,9 @@ extern "C" int igmc_model_loss_grad(igmc_model* m, const float* d_params, const 
   if (check_fit(m, b, &why)) IGMC_FAIL(why);
   if (!d_params || !d_out || !d_grad) IGMC_FAIL("null buffer");
   m->d.side = b->side;
-  igmc_launch_forward(m->d, b->d, d_params, b->last_B, 1, use_edge_flags, d_lin_mask, seed, step, multiply_by, d_out,
+  igmc_launch_forward(m->d, m->ax, b->d, d_params, b->last_B, 1, use_edge_flags, d_lin_mask, seed, step, multiply_by, d_out,
                       stream);
-  igmc_launch_backward(m->d, b->d, d_params, b->last_B, use_edge_flags, nullptr, 1, grad_scale, multiply_by, 2.f,
+  igmc_launch_backward(m->d, m->ax, b->d, d_params, b->last_B, use_edge_flags, nullptr, 1, grad_scale, multiply_by, 2.f,
                        ARR * arr_scale, d_grad, stream);
   if (d_loss) igmc_launch_loss(m->d, b->d, ARR, d_loss, stream);
   HIPCHECK(hipGetLastError());

@@ -15,10 +15,17 @@ void igmc_launch_fill_u8(uint8_t* p, int64_t n, uint8_t v, void* stream);
 int igmc_extract_prepare(size_t smem);
 
 // model.hip
-void igmc_launch_forward(const ModelDev& m, const BatchDev& b, const float* P, int B, int training,
+// auxiliary streams / events of a model: independent kernels of the step run as parallel branches (also when
+// the step is being captured into a hipGraph: event waits become graph edges)
+struct ModelAux {
+  void* s1;      // Y products (needed only by the backward gathers)
+  void* s2;      // weight-gradient products + lin1 weight gradient
+  void* ev[8];
+};
+void igmc_launch_forward(const ModelDev& m, const ModelAux& ax, const BatchDev& b, const float* P, int B, int training,
                          int use_flags, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
                          float* out, void* stream);
-void igmc_launch_backward(const ModelDev& m, const BatchDev& b, const float* P, int B, int use_flags,
+void igmc_launch_backward(const ModelDev& m, const ModelAux& ax, const BatchDev& b, const float* P, int B, int use_flags,
                           const float* gout, int from_err, float grad_scale, float mult, float drop_scale,
                           float arr_coef, float* grad, void* stream);
 void igmc_launch_loss(const ModelDev& m, const BatchDev& b, float ARR, float* loss, void* stream);

@@ -366,10 +366,10 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_dense_y_all(BatchDev b, ModelDev
 
 // =================================================================== weight gradients  G = X^T [D1 | D2]
 // X = h_{l-1} [N,32], D1 = G_l [N,128], D2 = dPre_l [N,32]  ->  per-block partial [32][160] (+ column sums of
-// D2 = d bias).  All three layers in ONE launch (blockIdx.y = l-1).
-__global__ __launch_bounds__(IGMC_BLOCK) void k_wgrad_all(BatchDev b, ModelDev m) {
+// D2 = d bias).  One launch per layer slice `ly` (0..2 = conv layers 1..3, 3 = layer 0) on the auxiliary
+// stream, i.e. concurrently with the next layer's backward gather on the main stream.
+__global__ __launch_bounds__(IGMC_BLOCK) void k_wgrad(BatchDev b, ModelDev m, int ly) {
   __shared__ float sacc[32 * IGMC_KCAT + 32];
-  const int ly = blockIdx.y;
   // ly == 3: layer 0, whose "X" is synthesised from the per-node code histogram cnt0 plus the one-hot
   // columns for d root0[label] / d bias0 (codes < 32 only; larger tables use k_l0_bwd)
   const bool is_l0 = ly == 3;
@@ -391,28 +391,39 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_wgrad_all(BatchDev b, ModelDev m
   for (int tile = blockIdx.x * 4 + wave; tile < ntile; tile += gridDim.x * 4) {
     const int row0 = tile * 16;
 #pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      const int row = row0 + 4 * r4 + kq;
-      const bool ok = row < N;
-      const int rs = ok ? row : 0;
-      float2 a2;
-      if (!is_l0) {
-        a2 = *(const float2*)(X + (size_t)rs * 32 + 2 * li);
-      } else {
-        const int lab = b.node_label[rs];
-        const int c0 = 2 * li, c1 = 2 * li + 1;
-        a2.x = (c0 < RL) ? (float)m.cnt0[(size_t)rs * RL + c0] : ((c0 == RL + lab || c0 == RL + m.L) ? 1.f : 0.f);
-        a2.y = (c1 < RL) ? (float)m.cnt0[(size_t)rs * RL + c1] : ((c1 == RL + lab || c1 == RL + m.L) ? 1.f : 0.f);
-      }
-      if (!ok) { a2.x = 0.f; a2.y = 0.f; }
+    for (int r2 = 0; r2 < 4; r2 += 2) {          // two row-groups (22 loads) in flight before their 40 MFMAs
+      float2 a2[2];
+      float bv[2][10];
 #pragma unroll
-      for (int nt = 0; nt < 10; ++nt) {
-        if (is_l0 && nt < 8) continue;
-        float bv = (nt < 8) ? D1[(size_t)rs * 128 + nt * 16 + li] : D2[(size_t)rs * 32 + (nt - 8) * 16 + li];
-        if (!ok) bv = 0.f;
-        if (nt >= 8) bsum[nt - 8] += bv;
-        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, bv, acc[0][nt], 0, 0, 0);
-        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, bv, acc[1][nt], 0, 0, 0);
+      for (int u = 0; u < 2; ++u) {
+        const int row = row0 + 4 * (r2 + u) + kq;
+        const bool ok = row < N;
+        const int rs = ok ? row : 0;
+        if (!is_l0) {
+          a2[u] = *(const float2*)(X + (size_t)rs * 32 + 2 * li);
+        } else {
+          const int lab = b.node_label[rs];
+          const int c0 = 2 * li, c1 = 2 * li + 1;
+          a2[u].x = (c0 < RL) ? (float)m.cnt0[(size_t)rs * RL + c0] : ((c0 == RL + lab || c0 == RL + m.L) ? 1.f : 0.f);
+          a2[u].y = (c1 < RL) ? (float)m.cnt0[(size_t)rs * RL + c1] : ((c1 == RL + lab || c1 == RL + m.L) ? 1.f : 0.f);
+        }
+        if (!ok) { a2[u].x = 0.f; a2[u].y = 0.f; }
+#pragma unroll
+        for (int nt = 0; nt < 10; ++nt) {
+          bv[u][nt] = 0.f;
+          if (is_l0 && nt < 8) continue;
+          if (ok) bv[u][nt] = (nt < 8) ? D1[(size_t)rs * 128 + nt * 16 + li] : D2[(size_t)rs * 32 + (nt - 8) * 16 + li];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int nt = 0; nt < 10; ++nt) {
+          if (is_l0 && nt < 8) continue;
+          if (nt >= 8) bsum[nt - 8] += bv[u][nt];
+          acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[u].x, bv[u][nt], acc[0][nt], 0, 0, 0);
+          acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[u].y, bv[u][nt], acc[1][nt], 0, 0, 0);
+        }
       }
     }
   }
@@ -820,60 +831,56 @@ __global__ __launch_bounds__(512) void k_head_bwd_a_mfma(BatchDev b, ModelDev m,
 }
 
 // d lin1.weight = dz^T @ feat (reduction over the B graphs, 4 per MFMA); block x = 16 hidden units, wave -> 16
-// fan-in columns; block x == 8 does d lin1.bias / d lin2.weight / d lin2.bias
+// fan-in columns.  Wave 0 of the y == 0 blocks also forms d lin1.bias = dz^T 1, d lin2.weight = adrop^T dp and
+// d lin2.bias = 1^T dp with three more MFMAs per step (B operand = 1 / dp_g), so there is no serial tail.
 __global__ __launch_bounds__(IGMC_BLOCK) void k_head_bwd_w_mfma(BatchDev b, ModelDev m, const float* __restrict__ P,
                                                                   const float* __restrict__ gout, int from_err,
                                                                   float grad_scale, float mult, float drop_scale,
                                                                   float* __restrict__ grad) {
   const int B = b.totals[3], D = m.D, tid = threadIdx.x;
-  if (blockIdx.x == 8) {
-    if (blockIdx.y != 0) return;
-    if (tid < 128) {
-      float s4[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int g = 0; g < B; g += 4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) s4[u] += (g + u < B) ? m.dz[(g + u) * 128 + tid] : 0.f;
-      }
-      grad[m.off_l1b + tid] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-    } else {
-      const int j = tid - 128;
-      float s4[4] = {0.f, 0.f, 0.f, 0.f}, t4[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int g = 0; g < B; g += 4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int gg = (g + u < B) ? g + u : B - 1;
-          const float dp = (g + u < B) ? (from_err ? 2.f * m.err[gg] * grad_scale : gout[gg]) * mult : 0.f;
-          const float a = m.lmask[gg * 128 + j] ? m.a1[gg * 128 + j] * drop_scale : 0.f;
-          s4[u] += dp * a;
-          t4[u] += dp;
-        }
-      }
-      grad[m.off_l2w + j] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-      if (j == 0) grad[m.off_l2b] = (t4[0] + t4[1]) + (t4[2] + t4[3]);
-    }
-    return;
-  }
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int j0 = blockIdx.x * 16;
   const int nt = blockIdx.y * 4 + wave;
   if (nt * 16 >= D) return;
   const int n0 = nt * 16;
+  const bool extra = nt == 0;
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 accb1 = acc, accw2 = acc, accb2 = acc;
   for (int g0 = 0; g0 < B; g0 += 16) {            // 4 MFMA steps (16 graphs) of loads in flight
-    float av[4], bv[4];
+    float av[4], bv[4], ad[4], dpv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int g = g0 + 4 * u + kq;
       const bool ok = g < B;
-      av[u] = ok ? m.dz[g * 128 + j0 + li] : 0.f;
-      bv[u] = ok ? m.feat[(size_t)g * D + n0 + li] : 0.f;
+      const int gs = ok ? g : 0;
+      av[u] = ok ? m.dz[gs * 128 + j0 + li] : 0.f;
+      bv[u] = ok ? m.feat[(size_t)gs * D + n0 + li] : 0.f;
+      if (extra) {
+        dpv[u] = ok ? (from_err ? 2.f * m.err[gs] * grad_scale : gout[gs]) * mult : 0.f;
+        ad[u] = (ok && m.lmask[gs * 128 + j0 + li]) ? m.a1[gs * 128 + j0 + li] * drop_scale : 0.f;
+      }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+    for (int u = 0; u < 4; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+      if (extra) {
+        accb1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], (g0 + 4 * u + kq < B) ? 1.f : 0.f, accb1, 0, 0, 0);
+        accw2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ad[u], dpv[u], accw2, 0, 0, 0);
+        accb2 = __builtin_amdgcn_mfma_f32_16x16x4f32(1.f, dpv[u], accb2, 0, 0, 0);
+      }
+    }
   }
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) grad[m.off_l1w + (int64_t)(j0 + kq * 4 + rr) * D + n0 + li] = acc[rr];
+  if (extra && li == 0) {       // every column of the extra accumulators holds the same sums
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      grad[m.off_l1b + j0 + kq * 4 + rr] = accb1[rr];
+      grad[m.off_l2w + j0 + kq * 4 + rr] = accw2[rr];
+    }
+    if (blockIdx.x == 0 && kq == 0) grad[m.off_l2b] = accb2[0];
+  }
 }
 
 // =================================================================== partial reduction + finalize
@@ -1157,7 +1164,13 @@ static inline int igmc_rows_grid(int cap_rows, int rows_per_block, int max_block
   return g < max_blocks ? g : max_blocks;
 }
 
-void igmc_launch_forward(const ModelDev& m, const BatchDev& b, const float* P, int B, int training,
+// fork: `to` waits for everything enqueued on `from` so far (an event edge; a graph edge under capture)
+static inline void igmc_edge(void* ev, void* from, void* to) {
+  hipEventRecord((hipEvent_t)ev, (hipStream_t)from);
+  hipStreamWaitEvent((hipStream_t)to, (hipEvent_t)ev, 0);
+}
+
+void igmc_launch_forward(const ModelDev& m, const ModelAux& ax, const BatchDev& b, const float* P, int B, int training,
                          int use_flags, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
                          float* out, void* stream) {
   const size_t l0s = (size_t)(m.R * m.L * 32 + m.L * 32 + 32) * sizeof(float) + (size_t)4 * m.R * m.L * sizeof(int);
@@ -1172,6 +1185,7 @@ void igmc_launch_forward(const ModelDev& m, const BatchDev& b, const float* P, i
   }
   const size_t gs = (size_t)(m.R * 4) * sizeof(float);
   const size_t ds = (size_t)IGMC_KCAT * (32 + 4) * sizeof(float);
+  const size_t ysz = (size_t)32 * (128 + 4) * sizeof(float);
   for (int l = 1; l < 4; ++l) {
     if (use_flags)
       IGMC_PLAUNCH("k_rgcn_gather_fwd", (k_rgcn_gather<true, false, false>), g16, IGMC_BLOCK, gs, stream, b, m.R,
@@ -1184,6 +1198,11 @@ void igmc_launch_forward(const ModelDev& m, const BatchDev& b, const float* P, i
     IGMC_PLAUNCH("k_dense_fwd", k_dense_fwd, g64, IGMC_BLOCK, ds, stream, b, (const float*)m.agg,
                  (const float*)m.h[l - 1], P + m.off_basis[l], P + m.off_bias[l], m.h[l],
                  (float*)((training && l == 3) ? m.dpre[3] : nullptr));
+    if (training && l == 2) {
+      // branch s1: the Y products (inputs h_0..h_2 are final now) run beside the rest of the forward + head
+      igmc_edge(ax.ev[0], stream, ax.s1);
+      IGMC_PLAUNCH("k_dense_y_all", k_dense_y_all, dim3(g64, 3), IGMC_BLOCK, ysz, ax.s1, b, m, P);
+    }
   }
   const int hgrid = (B + IGMC_HG - 1) / IGMC_HG;
   const size_t fs = (size_t)IGMC_HG * m.D * sizeof(float);
@@ -1196,30 +1215,35 @@ void igmc_launch_forward(const ModelDev& m, const BatchDev& b, const float* P, i
   else
     IGMC_PLAUNCH("k_head_fwd", (k_head_fwd<false>), hgrid, 512, 0, stream, b, m, P, training, inj_mask, seed, step,
                  mult, out);
+  if (training) igmc_edge(ax.ev[1], ax.s1, stream);     // join s1 (cheap: Y finished long ago)
 }
 
-void igmc_launch_backward(const ModelDev& m, const BatchDev& b, const float* P, int B, int use_flags,
+void igmc_launch_backward(const ModelDev& m, const ModelAux& ax, const BatchDev& b, const float* P, int B, int use_flags,
                           const float* gout, int from_err, float grad_scale, float mult, float drop_scale,
                           float arr_coef, float* grad, void* stream) {
   const int g16 = igmc_rows_grid(m.node_cap, 4, IGMC_GATHER_BLOCKS);
   const int g64 = igmc_rows_grid(m.node_cap, 64, 512);
   const int hgrid = (B + IGMC_HG - 1) / IGMC_HG;
-  if (m.D % 16 == 0) {
+  const int na = m.R * 4;
+  const int rows0 = m.R * m.L + m.L + 1;
+  const int l0_mfma = rows0 <= 32;       // layer-0 table gradient rides in the MFMA weight-gradient kernel
+  void* s2 = ax.s2;
+  if (m.D % 16 == 0)
     IGMC_PLAUNCH("k_head_bwd_a", k_head_bwd_a_mfma, dim3((B + 15) / 16, (m.D / 16 + 7) / 8), 512, 0, stream, b, m, P,
                  gout, from_err, grad_scale, mult, drop_scale, m.dpre[3]);
-    IGMC_PLAUNCH("k_head_bwd_w", k_head_bwd_w_mfma, dim3(9, (m.D / 16 + 3) / 4), IGMC_BLOCK, 0, stream, b, m, P, gout,
-                 from_err, grad_scale, mult, drop_scale, grad);
-  } else {
+  else
     IGMC_PLAUNCH("k_head_bwd_a", k_head_bwd_a, hgrid, 1024, 0, stream, b, m, P, gout, from_err, grad_scale, mult,
                  drop_scale, m.dpre[3]);
-    IGMC_PLAUNCH("k_head_bwd_w", k_head_bwd_w, dim3(17, (m.D + 255) / 256), IGMC_BLOCK, 0, stream, b, m, P, gout,
+  // branch s2: weight-gradient products, concurrent with the backward gathers of the main stream
+  igmc_edge(ax.ev[2], stream, s2);
+  if (m.D % 16 == 0)
+    IGMC_PLAUNCH("k_head_bwd_w", k_head_bwd_w_mfma, dim3(8, (m.D / 16 + 3) / 4), IGMC_BLOCK, 0, s2, b, m, P, gout,
                  from_err, grad_scale, mult, drop_scale, grad);
-  }
-  const int na = m.R * 4;
+  else
+    IGMC_PLAUNCH("k_head_bwd_w", k_head_bwd_w, dim3(17, (m.D + 255) / 256), IGMC_BLOCK, 0, s2, b, m, P, gout, from_err,
+                 grad_scale, mult, drop_scale, grad);
   const size_t gsa = (size_t)(m.R * 4 + 16 * m.R * 4) * sizeof(float);
-  const size_t ysz = (size_t)32 * (128 + 4) * sizeof(float);
   const size_t ds = (size_t)IGMC_KCAT * (32 + 4) * sizeof(float);
-  IGMC_PLAUNCH("k_dense_y_all", k_dense_y_all, dim3(g64, 3), IGMC_BLOCK, ysz, stream, b, m, P);
   for (int l = 3; l >= 1; --l) {
     float* gp = m.gatt_part + (size_t)(l - 1) * IGMC_GATHER_BLOCKS * na;
     if (use_flags)
@@ -1228,18 +1252,18 @@ void igmc_launch_backward(const ModelDev& m, const BatchDev& b, const float* P, 
     else
       IGMC_PLAUNCH("k_rgcn_gather_bwd", (k_rgcn_gather<false, true, true>), g16, IGMC_BLOCK, gsa, stream, b, m.R,
                    (const float*)m.dpre[l], P + m.off_att[l], m.gagg[l - 1], (const float*)m.Y[l - 1], gp);
+    // d basis_l / d root_l / d bias_l need G_l, dPre_l, h_{l-1}: all final -> off the critical path
+    igmc_edge(ax.ev[2 + l], stream, s2);
+    IGMC_PLAUNCH("k_wgrad", k_wgrad, IGMC_WG_BLOCKS, IGMC_BLOCK, 0, s2, b, m, l - 1);
     IGMC_PLAUNCH("k_dense_bwd", k_dense_bwd, g64, IGMC_BLOCK, ds, stream, b, (const float*)m.gagg[l - 1],
                  (const float*)m.dpre[l], P + m.off_basis[l], P + m.off_root[l], m.dpre[l - 1],
                  (const float*)m.h[l - 1], (const float*)m.gfeat, m.D, l - 1);
   }
-  const int rows0 = m.R * m.L + m.L + 1;
-  const int l0_mfma = rows0 <= 32;       // layer-0 table gradient rides in the batched MFMA launch
-  IGMC_PLAUNCH("k_wgrad_all", k_wgrad_all, dim3(IGMC_WG_BLOCKS, l0_mfma ? 4 : 3), IGMC_BLOCK, 0, stream, b, m);
-  if (!l0_mfma) {
-    const float* d0 = m.dpre[0];
-    if (rows0 <= 64) IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<8>), IGMC_L0_BLOCKS, IGMC_BLOCK, 0, stream, b, m, d0, m.l0_part);
-    else IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<40>), IGMC_L0_BLOCKS, IGMC_BLOCK, 0, stream, b, m, d0, m.l0_part);
-  }
+  const float* d0 = m.dpre[0];
+  if (l0_mfma) IGMC_PLAUNCH("k_wgrad", k_wgrad, IGMC_WG_BLOCKS, IGMC_BLOCK, 0, stream, b, m, 3);
+  else if (rows0 <= 64) IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<8>), IGMC_L0_BLOCKS, IGMC_BLOCK, 0, stream, b, m, d0, m.l0_part);
+  else IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<40>), IGMC_L0_BLOCKS, IGMC_BLOCK, 0, stream, b, m, d0, m.l0_part);
+  igmc_edge(ax.ev[6], s2, stream);      // join s2
   {
     const int wgs2 = igmc_wg_stride(), n0 = rows0 * 32;
     const int nblk = ((l0_mfma ? 4 : 3) * wgs2 + 63) / 64 + (l0_mfma ? 0 : (n0 + 63) / 64) + (3 * na + 3) / 4;

@@ -387,6 +387,12 @@ static inline hipError_t hipSetDevice(int) { return 0; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 static inline hipError_t hipDeviceSynchronize() { return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return 0; }
+#define hipStreamNonBlocking 1
+#define hipEventDisableTiming 2
 static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipPeekAtLastError() { return 0; }
 static inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
