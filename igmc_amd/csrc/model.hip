@@ -366,10 +366,12 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_dense_y_all(BatchDev b, ModelDev
 
 // =================================================================== weight gradients  G = X^T [D1 | D2]
 // X = h_{l-1} [N,32], D1 = G_l [N,128], D2 = dPre_l [N,32]  ->  per-block partial [32][160] (+ column sums of
-// D2 = d bias).  One launch per layer slice `ly` (0..2 = conv layers 1..3, 3 = layer 0) on the auxiliary
-// stream, i.e. concurrently with the next layer's backward gather on the main stream.
-__global__ __launch_bounds__(IGMC_BLOCK) void k_wgrad(BatchDev b, ModelDev m, int ly) {
+// D2 = d bias).  Layer slices ly = ly_base + blockIdx.y (0..2 = conv layers 1..3, 3 = layer 0) in ONE launch.
+// (Running the slices as parallel graph branches on auxiliary streams was measured SLOWER: every cross-stream
+// edge of the hipGraph costs several microseconds on this part -- more than the kernels it would hide.)
+__global__ __launch_bounds__(IGMC_BLOCK) void k_wgrad(BatchDev b, ModelDev m, int ly_base) {
   __shared__ float sacc[32 * IGMC_KCAT + 32];
+  const int ly = ly_base + blockIdx.y;
   // ly == 3: layer 0, whose "X" is synthesised from the per-node code histogram cnt0 plus the one-hot
   // columns for d root0[label] / d bias0 (codes < 32 only; larger tables use k_l0_bwd)
   const bool is_l0 = ly == 3;
@@ -1198,11 +1200,6 @@ void igmc_launch_forward(const ModelDev& m, const ModelAux& ax, const BatchDev& 
     IGMC_PLAUNCH("k_dense_fwd", k_dense_fwd, g64, IGMC_BLOCK, ds, stream, b, (const float*)m.agg,
                  (const float*)m.h[l - 1], P + m.off_basis[l], P + m.off_bias[l], m.h[l],
                  (float*)((training && l == 3) ? m.dpre[3] : nullptr));
-    if (training && l == 2) {
-      // branch s1: the Y products (inputs h_0..h_2 are final now) run beside the rest of the forward + head
-      igmc_edge(ax.ev[0], stream, ax.s1);
-      IGMC_PLAUNCH("k_dense_y_all", k_dense_y_all, dim3(g64, 3), IGMC_BLOCK, ysz, ax.s1, b, m, P);
-    }
   }
   const int hgrid = (B + IGMC_HG - 1) / IGMC_HG;
   const size_t fs = (size_t)IGMC_HG * m.D * sizeof(float);
@@ -1215,7 +1212,8 @@ void igmc_launch_forward(const ModelDev& m, const ModelAux& ax, const BatchDev& 
   else
     IGMC_PLAUNCH("k_head_fwd", (k_head_fwd<false>), hgrid, 512, 0, stream, b, m, P, training, inj_mask, seed, step,
                  mult, out);
-  if (training) igmc_edge(ax.ev[1], ax.s1, stream);     // join s1 (cheap: Y finished long ago)
+  if (training) IGMC_PLAUNCH("k_dense_y_all", k_dense_y_all, dim3(g64, 3), IGMC_BLOCK, ysz, stream, b, m, P);
+  (void)ax;
 }
 
 void igmc_launch_backward(const ModelDev& m, const ModelAux& ax, const BatchDev& b, const float* P, int B, int use_flags,
@@ -1227,15 +1225,14 @@ void igmc_launch_backward(const ModelDev& m, const ModelAux& ax, const BatchDev&
   const int na = m.R * 4;
   const int rows0 = m.R * m.L + m.L + 1;
   const int l0_mfma = rows0 <= 32;       // layer-0 table gradient rides in the MFMA weight-gradient kernel
-  void* s2 = ax.s2;
+  void* s2 = stream;      // single stream: see the note at k_wgrad
+  (void)ax;
   if (m.D % 16 == 0)
     IGMC_PLAUNCH("k_head_bwd_a", k_head_bwd_a_mfma, dim3((B + 15) / 16, (m.D / 16 + 7) / 8), 512, 0, stream, b, m, P,
                  gout, from_err, grad_scale, mult, drop_scale, m.dpre[3]);
   else
     IGMC_PLAUNCH("k_head_bwd_a", k_head_bwd_a, hgrid, 1024, 0, stream, b, m, P, gout, from_err, grad_scale, mult,
                  drop_scale, m.dpre[3]);
-  // branch s2: weight-gradient products, concurrent with the backward gathers of the main stream
-  igmc_edge(ax.ev[2], stream, s2);
   if (m.D % 16 == 0)
     IGMC_PLAUNCH("k_head_bwd_w", k_head_bwd_w_mfma, dim3(8, (m.D / 16 + 3) / 4), IGMC_BLOCK, 0, s2, b, m, P, gout,
                  from_err, grad_scale, mult, drop_scale, grad);
@@ -1252,18 +1249,15 @@ void igmc_launch_backward(const ModelDev& m, const ModelAux& ax, const BatchDev&
     else
       IGMC_PLAUNCH("k_rgcn_gather_bwd", (k_rgcn_gather<false, true, true>), g16, IGMC_BLOCK, gsa, stream, b, m.R,
                    (const float*)m.dpre[l], P + m.off_att[l], m.gagg[l - 1], (const float*)m.Y[l - 1], gp);
-    // d basis_l / d root_l / d bias_l need G_l, dPre_l, h_{l-1}: all final -> off the critical path
-    igmc_edge(ax.ev[2 + l], stream, s2);
-    IGMC_PLAUNCH("k_wgrad", k_wgrad, IGMC_WG_BLOCKS, IGMC_BLOCK, 0, s2, b, m, l - 1);
     IGMC_PLAUNCH("k_dense_bwd", k_dense_bwd, g64, IGMC_BLOCK, ds, stream, b, (const float*)m.gagg[l - 1],
                  (const float*)m.dpre[l], P + m.off_basis[l], P + m.off_root[l], m.dpre[l - 1],
                  (const float*)m.h[l - 1], (const float*)m.gfeat, m.D, l - 1);
   }
   const float* d0 = m.dpre[0];
-  if (l0_mfma) IGMC_PLAUNCH("k_wgrad", k_wgrad, IGMC_WG_BLOCKS, IGMC_BLOCK, 0, stream, b, m, 3);
-  else if (rows0 <= 64) IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<8>), IGMC_L0_BLOCKS, IGMC_BLOCK, 0, stream, b, m, d0, m.l0_part);
+  IGMC_PLAUNCH("k_wgrad", k_wgrad, dim3(IGMC_WG_BLOCKS, l0_mfma ? 4 : 3), IGMC_BLOCK, 0, stream, b, m, 0);
+  if (l0_mfma) {
+  } else if (rows0 <= 64) IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<8>), IGMC_L0_BLOCKS, IGMC_BLOCK, 0, stream, b, m, d0, m.l0_part);
   else IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<40>), IGMC_L0_BLOCKS, IGMC_BLOCK, 0, stream, b, m, d0, m.l0_part);
-  igmc_edge(ax.ev[6], s2, stream);      // join s2
   {
     const int wgs2 = igmc_wg_stride(), n0 = rows0 * 32;
     const int nblk = ((l0_mfma ? 4 : 3) * wgs2 + 63) / 64 + (l0_mfma ? 0 : (n0 + 63) / 64) + (3 * na + 3) / 4;
