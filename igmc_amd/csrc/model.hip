@@ -129,29 +129,18 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_l0_fwd(BatchDev b, ModelDev m, c
   }
 }
 
-// =================================================================== basis-space gather (layers 1..3)
-// FLAGS: honour edge keep flags; TRANS: use the transposed-edge keep bit (backward);
-// ATTG: additionally accumulate d att via relation runs (needs Y = x @ [basis_0..3]).
+// Basis-space aggregate of ONE row by one wave (see "row walkers" above).  On return lanes of group 0
+// (t = lane & 15) hold ax[bb], ay[bb] = features 2t, 2t+1 of A[i][bb].
 template <bool FLAGS, bool TRANS, bool ATTG>
-__global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_gather(BatchDev b, int R, const float* __restrict__ in,
-                                                              const float* __restrict__ att,
-                                                              float* __restrict__ out,
-                                                              const float* __restrict__ Y,
-                                                              float* __restrict__ gatt_part) {
-  IGMC_DYN_SMEM(smem);
-  float* s_att = (float*)smem;              // [R][4]
-  float* s_gatt = s_att + R * 4;            // [16 groups][R*4]   (ATTG only)
-  for (int i = threadIdx.x; i < R * 4; i += IGMC_BLOCK) s_att[i] = att[i];
-  if (ATTG)
-    for (int i = threadIdx.x; i < 16 * R * 4; i += IGMC_BLOCK) s_gatt[i] = 0.f;
-  __syncthreads();
-  const int N = b.totals[0];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void gather_row(const BatchDev& b, const float* __restrict__ in, const float* s_att,
+                                           float* my_gatt, const float* __restrict__ Y, int i, int lane,
+                                           float (&ax)[4], float (&ay)[4]) {
   const int grp = lane >> 4, t = lane & 15;
   const int kbit = TRANS ? 1 : 0;
-  float* my_gatt = s_gatt + (wave * 4 + grp) * R * 4;
-  for (int i = blockIdx.x * 4 + wave; i < N; i += gridDim.x * 4) {
-    float ax[4] = {0.f, 0.f, 0.f, 0.f}, ay[4] = {0.f, 0.f, 0.f, 0.f};
+  (void)grp;
+#pragma unroll
+  for (int bb = 0; bb < 4; ++bb) { ax[bb] = 0.f; ay[bb] = 0.f; }
+  {
     float yx[4], yy[4];
     float tx = 0.f, ty = 0.f;
     int cur = -1;
@@ -234,6 +223,32 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_gather(BatchDev b, int R, c
       ax[bb] += __shfl_xor(ax[bb], 32, 64);
       ay[bb] += __shfl_xor(ay[bb], 32, 64);
     }
+  }
+}
+
+// =================================================================== basis-space gather (layers 1..3)
+// FLAGS: honour edge keep flags; TRANS: use the transposed-edge keep bit (backward);
+// ATTG: additionally accumulate d att via relation runs (needs Y = x @ [basis_0..3]).
+template <bool FLAGS, bool TRANS, bool ATTG>
+__global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_gather(BatchDev b, int R, const float* __restrict__ in,
+                                                              const float* __restrict__ att,
+                                                              float* __restrict__ out,
+                                                              const float* __restrict__ Y,
+                                                              float* __restrict__ gatt_part) {
+  IGMC_DYN_SMEM(smem);
+  float* s_att = (float*)smem;              // [R][4]
+  float* s_gatt = s_att + R * 4;            // [16 groups][R*4]   (ATTG only)
+  for (int i = threadIdx.x; i < R * 4; i += IGMC_BLOCK) s_att[i] = att[i];
+  if (ATTG)
+    for (int i = threadIdx.x; i < 16 * R * 4; i += IGMC_BLOCK) s_gatt[i] = 0.f;
+  __syncthreads();
+  const int N = b.totals[0];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = lane >> 4, t = lane & 15;
+  float* my_gatt = s_gatt + (wave * 4 + grp) * R * 4;
+  for (int i = blockIdx.x * 4 + wave; i < N; i += gridDim.x * 4) {
+    float ax[4], ay[4];
+    gather_row<FLAGS, TRANS, ATTG>(b, in, s_att, my_gatt, Y, i, lane, ax, ay);
     if (grp == 0) {
 #pragma unroll
       for (int bb = 0; bb < 4; ++bb) {
@@ -362,6 +377,122 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_dense_y_all(BatchDev b, ModelDev
   const int li = blockIdx.y;
   dense_body<0, 32, 128, EPI_NONE, W_YCAT>(b, nullptr, m.h[li], P + m.off_basis[li + 1], nullptr, nullptr, m.Y[li],
                                            nullptr, nullptr, 0, 0, nullptr, (float*)smem);
+}
+
+// =================================================================== fused R-GCN layer (gather + dense)
+// One 1024-thread workgroup per tile of 16 rows: wave w gathers row w of the tile in basis space straight into
+// an LDS tile [16][A(128) | self(32)], then 8 waves multiply the tile with the layer's [basis ; root] operand
+// on f32 MFMA (2 column tiles x 4 K-slices; B fragments are loaded ONCE per workgroup into registers) and the
+// epilogue (bias + tanh, or the tanh' / readout-gradient backward epilogue) writes the 128-byte output rows.
+// Forward never materialises the 512-byte basis-space rows in HBM; backward writes them once (the weight
+// gradient needs them).  Removes one launch per layer and direction (each >= 4.7 us on this part).
+#define IGMC_TP 164
+template <bool FLAGS, bool BWD>
+__global__ __launch_bounds__(1024) void k_rgcn_layer(BatchDev b, ModelDev m, const float* __restrict__ P, int l,
+                                                      float* __restrict__ zero_out) {
+  IGMC_DYN_SMEM(smem);
+  const int R = m.R;
+  float* tile = (float*)smem;               // [16][IGMC_TP]
+  float* red = tile + 16 * IGMC_TP;         // [4 k-slices][2 col tiles][64 lanes * 4]
+  float* s_att = red + 2048;                // [R][4]
+  float* s_gatt = s_att + R * 4;            // BWD: [64 groups][R*4]
+  const float* __restrict__ in = BWD ? m.dpre[l] : m.h[l - 1];
+  const float* __restrict__ Yl = BWD ? m.Y[l - 1] : nullptr;
+  const float* att = P + m.off_att[l];
+  const float* basis = P + m.off_basis[l];
+  const float* root = P + m.off_root[l];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = lane >> 4, t = lane & 15;
+  const int li = lane & 15, kq = lane >> 4;
+  for (int i = tid; i < R * 4; i += 1024) s_att[i] = att[i];
+  if (BWD)
+    for (int i = tid; i < 64 * R * 4; i += 1024) s_gatt[i] = 0.f;
+  // B fragments of this wave's (column tile, K-slice), loaded once: k = ks*40 + 4j + kq, n = nt*16 + li
+  const int nt = wave & 1, ks = (wave >> 1) & 3;
+  float bw[10];
+  if (wave < 8) {
+#pragma unroll
+    for (int j = 0; j < 10; ++j) {
+      const int k = ks * 40 + 4 * j + kq, n = nt * 16 + li;
+      if (!BWD) bw[j] = basis[k * 32 + n];                 // [basis ; root] contiguous: rows 0..159
+      else bw[j] = (k < 128) ? basis[((k >> 5) * 32 + n) * 32 + (k & 31)] : root[n * 32 + (k - 128)];
+    }
+  }
+  __syncthreads();
+  const int N = b.totals[0];
+  float* my_gatt = s_gatt + (wave * 4 + grp) * R * 4;
+  for (int tl = blockIdx.x; tl * 16 < N; tl += gridDim.x) {
+    const int i = tl * 16 + wave;
+    // ---- phase 1: one row per wave -> LDS tile
+    if (i < N) {
+      float ax[4], ay[4];
+      gather_row<FLAGS, BWD, BWD>(b, in, s_att, my_gatt, Yl, i, lane, ax, ay);
+      if (grp == 0) {
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+          tile[wave * IGMC_TP + bb * 32 + 2 * t] = ax[bb];
+          tile[wave * IGMC_TP + bb * 32 + 2 * t + 1] = ay[bb];
+          if (BWD) {
+            float2 o;
+            o.x = ax[bb];
+            o.y = ay[bb];
+            *(float2*)(m.gagg[l - 1] + (size_t)i * 128 + bb * 32 + 2 * t) = o;
+          }
+        }
+        const float2 xs = *(const float2*)(in + (size_t)i * 32 + 2 * t);
+        tile[wave * IGMC_TP + 128 + 2 * t] = xs.x;
+        tile[wave * IGMC_TP + 128 + 2 * t + 1] = xs.y;
+      }
+    } else if (grp == 0) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        tile[wave * IGMC_TP + q * 32 + 2 * t] = 0.f;
+        tile[wave * IGMC_TP + q * 32 + 2 * t + 1] = 0.f;
+      }
+    }
+    __syncthreads();
+    // ---- phase 2: [16 x 160] @ [160 x 32] on MFMA, 10 k-steps per wave
+    if (wave < 8) {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        const float a = tile[li * IGMC_TP + ks * 40 + 4 * j + kq];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[j], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) red[(ks * 2 + nt) * 256 + lane * 4 + rr] = acc[rr];
+    }
+    __syncthreads();
+    // ---- phase 3: combine the 4 K-slices + epilogue (512 outputs)
+    if (tid < 512) {
+      const int ont = tid >> 8, idx = tid & 255, ol = idx >> 2, rr = idx & 3;
+      const float v0 = (red[(0 * 2 + ont) * 256 + idx] + red[(1 * 2 + ont) * 256 + idx]) +
+                       (red[(2 * 2 + ont) * 256 + idx] + red[(3 * 2 + ont) * 256 + idx]);
+      const int orow = tl * 16 + (ol >> 4) * 4 + rr, n = ont * 16 + (ol & 15);
+      if (orow < N) {
+        float v = v0;
+        if (!BWD) {
+          v = tanhf(v + P[m.off_bias[l] + n]);
+          m.h[l][(size_t)orow * 32 + n] = v;
+          if (zero_out) zero_out[(size_t)orow * 32 + n] = 0.f;
+        } else {
+          const int lab = b.node_label[orow];
+          if (lab < 2) v += m.gfeat[(size_t)b.node_graph[orow] * m.D + lab * 128 + (l - 1) * 32 + n];
+          const float xv = m.h[l - 1][(size_t)orow * 32 + n];
+          m.dpre[l - 1][(size_t)orow * 32 + n] = v * (1.f - xv * xv);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (BWD) {
+    float* gp = m.gatt_part + ((size_t)(l - 1) * IGMC_GATHER_BLOCKS + blockIdx.x) * R * 4;
+    for (int i = tid; i < R * 4; i += 1024) {
+      float sacc = 0.f;
+      for (int g = 0; g < 64; ++g) sacc += s_gatt[g * R * 4 + i];
+      gp[i] = sacc;
+    }
+  }
 }
 
 // =================================================================== weight gradients  G = X^T [D1 | D2]
@@ -1185,21 +1316,15 @@ void igmc_launch_forward(const ModelDev& m, const ModelAux& ax, const BatchDev& 
     if (use_flags) IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<true, false>), g16, IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
     else IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<false, false>), g16, IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
   }
-  const size_t gs = (size_t)(m.R * 4) * sizeof(float);
-  const size_t ds = (size_t)IGMC_KCAT * (32 + 4) * sizeof(float);
   const size_t ysz = (size_t)32 * (128 + 4) * sizeof(float);
+  const int gt = igmc_rows_grid(m.node_cap, 16, 2048);                 // fused layer: 16 rows per workgroup
+  const size_t fsm = (size_t)(16 * IGMC_TP + 2048 + m.R * 4) * sizeof(float);
   for (int l = 1; l < 4; ++l) {
-    if (use_flags)
-      IGMC_PLAUNCH("k_rgcn_gather_fwd", (k_rgcn_gather<true, false, false>), g16, IGMC_BLOCK, gs, stream, b, m.R,
-                   (const float*)m.h[l - 1], P + m.off_att[l], m.agg, (const float*)nullptr, (float*)nullptr);
-    else
-      IGMC_PLAUNCH("k_rgcn_gather_fwd", (k_rgcn_gather<false, false, false>), g16, IGMC_BLOCK, gs, stream, b, m.R,
-                   (const float*)m.h[l - 1], P + m.off_att[l], m.agg, (const float*)nullptr, (float*)nullptr);
-    // [agg | h_{l-1}] @ [basis ; root]  (contiguous in the flat parameter buffer) + bias, tanh;
-    // the top layer's launch also clears dPre_3 (only its target rows are written by the head backward)
-    IGMC_PLAUNCH("k_dense_fwd", k_dense_fwd, g64, IGMC_BLOCK, ds, stream, b, (const float*)m.agg,
-                 (const float*)m.h[l - 1], P + m.off_basis[l], P + m.off_bias[l], m.h[l],
-                 (float*)((training && l == 3) ? m.dpre[3] : nullptr));
+    // gather (basis space) + [A | h_{l-1}] @ [basis ; root] + bias + tanh in ONE kernel; the top layer's
+    // launch also clears dPre_3 (only its target rows are written by the head backward)
+    float* zo = (training && l == 3) ? m.dpre[3] : nullptr;
+    if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer<true, false>), gt, 1024, fsm, stream, b, m, P, l, zo);
+    else IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer<false, false>), gt, 1024, fsm, stream, b, m, P, l, zo);
   }
   const int hgrid = (B + IGMC_HG - 1) / IGMC_HG;
   const size_t fs = (size_t)IGMC_HG * m.D * sizeof(float);
@@ -1239,19 +1364,12 @@ void igmc_launch_backward(const ModelDev& m, const ModelAux& ax, const BatchDev&
   else
     IGMC_PLAUNCH("k_head_bwd_w", k_head_bwd_w, dim3(17, (m.D + 255) / 256), IGMC_BLOCK, 0, s2, b, m, P, gout, from_err,
                  grad_scale, mult, drop_scale, grad);
-  const size_t gsa = (size_t)(m.R * 4 + 16 * m.R * 4) * sizeof(float);
-  const size_t ds = (size_t)IGMC_KCAT * (32 + 4) * sizeof(float);
+  const int gt = igmc_rows_grid(m.node_cap, 16, 2048);
+  const size_t bsm = (size_t)(16 * IGMC_TP + 2048 + m.R * 4 + 64 * m.R * 4) * sizeof(float);
   for (int l = 3; l >= 1; --l) {
-    float* gp = m.gatt_part + (size_t)(l - 1) * IGMC_GATHER_BLOCKS * na;
-    if (use_flags)
-      IGMC_PLAUNCH("k_rgcn_gather_bwd", (k_rgcn_gather<true, true, true>), g16, IGMC_BLOCK, gsa, stream, b, m.R,
-                   (const float*)m.dpre[l], P + m.off_att[l], m.gagg[l - 1], (const float*)m.Y[l - 1], gp);
-    else
-      IGMC_PLAUNCH("k_rgcn_gather_bwd", (k_rgcn_gather<false, true, true>), g16, IGMC_BLOCK, gsa, stream, b, m.R,
-                   (const float*)m.dpre[l], P + m.off_att[l], m.gagg[l - 1], (const float*)m.Y[l - 1], gp);
-    IGMC_PLAUNCH("k_dense_bwd", k_dense_bwd, g64, IGMC_BLOCK, ds, stream, b, (const float*)m.gagg[l - 1],
-                 (const float*)m.dpre[l], P + m.off_basis[l], P + m.off_root[l], m.dpre[l - 1],
-                 (const float*)m.h[l - 1], (const float*)m.gfeat, m.D, l - 1);
+    // transposed gather of dPre_l (+ d att partials) + [G | dPre_l] @ [basis^T ; root^T] + backward epilogue
+    if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer<true, true>), gt, 1024, bsm, stream, b, m, P, l, (float*)nullptr);
+    else IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer<false, true>), gt, 1024, bsm, stream, b, m, P, l, (float*)nullptr);
   }
   const float* d0 = m.dpre[0];
   IGMC_PLAUNCH("k_wgrad", k_wgrad, dim3(IGMC_WG_BLOCKS, l0_mfma ? 4 : 3), IGMC_BLOCK, 0, stream, b, m, 0);
@@ -1261,7 +1379,7 @@ void igmc_launch_backward(const ModelDev& m, const ModelAux& ax, const BatchDev&
   {
     const int wgs2 = igmc_wg_stride(), n0 = rows0 * 32;
     const int nblk = ((l0_mfma ? 4 : 3) * wgs2 + 63) / 64 + (l0_mfma ? 0 : (n0 + 63) / 64) + (3 * na + 3) / 4;
-    IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk, IGMC_BLOCK, 0, stream, m, g16, l0_mfma);
+    IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk, IGMC_BLOCK, 0, stream, m, gt, l0_mfma);
   }
   IGMC_PLAUNCH("k_finalize", k_finalize, 4, IGMC_BLOCK, 0, stream, m, P, grad, arr_coef);
 }
@@ -1306,7 +1424,16 @@ void igmc_launch_finish(const ModelDev& m, const BatchDev& b, float* p, const fl
                (int64_t)m.n_params, step_size, inv_sqrt_bc2, beta1, beta2, eps, wd, ctrl, ctrl ? 1 : 0, fin);
 }
 
+// dynamic LDS above 64 KB needs an explicit opt-in on HIP (many relations -> large d-att tables)
 int igmc_model_prepare(const ModelDev& m) {
+#ifndef IGMC_HIPEMU
+  const int bsm = (int)((size_t)(16 * IGMC_TP + 2048 + m.R * 4 + 64 * m.R * 4) * sizeof(float));
+  if (bsm > 48 * 1024) {
+    if (bsm > 150 * 1024) return 1;
+    if (hipFuncSetAttribute((const void*)k_rgcn_layer<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bsm) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_rgcn_layer<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bsm) != hipSuccess) return 1;
+  }
+#endif
   (void)m;
   return 0;
 }
