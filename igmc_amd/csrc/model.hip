@@ -22,6 +22,8 @@
 //     kernel), the three Y products and the three weight-gradient products are batched into one launch
 //     each (blockIdx.y = layer), and loss / epoch-total / control-block tick ride in the Adam kernel.
 #include "model.h"
+#include <stdlib.h>
+#define IGMC_LAYER_MODE_DEFAULT 0
 
 __device__ __forceinline__ float igmc_wave_sum_f(float v) {
 #pragma unroll
@@ -129,9 +131,10 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_l0_fwd(BatchDev b, ModelDev m, c
   }
 }
 
-// Basis-space aggregate of ONE row by one wave (see "row walkers" above).  On return lanes of group 0
-// (t = lane & 15) hold ax[bb], ay[bb] = features 2t, 2t+1 of A[i][bb].
-template <bool FLAGS, bool TRANS, bool ATTG>
+// Basis-space aggregate of ONE row (see "row walkers" above) by NG 16-lane groups: NG = 4 -> the whole wave
+// works on row i and lanes of group 0 hold the result; NG = 1 -> every group walks its OWN row i (i differs
+// between the groups of a wave) and holds its own result.  ax[bb], ay[bb] = features 2t, 2t+1 of A[i][bb].
+template <bool FLAGS, bool TRANS, bool ATTG, int NG = 4>
 __device__ __forceinline__ void gather_row(const BatchDev& b, const float* __restrict__ in, const float* s_att,
                                            float* my_gatt, const float* __restrict__ Y, int i, int lane,
                                            float (&ax)[4], float (&ay)[4]) {
@@ -153,7 +156,7 @@ __device__ __forceinline__ void gather_row(const BatchDev& b, const float* __res
       }
     }
     const int beg = b.row_ptr[i], end = b.row_ptr[i + 1];
-    for (int c0 = beg + grp * 16; c0 < end; c0 += 64) {
+    for (int c0 = beg + (NG == 4 ? grp * 16 : 0); c0 < end; c0 += 16 * NG) {
       const int e = c0 + t;
       const bool ok = e < end;
       const uint32_t w = ok ? b.ecr[e] : 0u;
@@ -216,12 +219,14 @@ __device__ __forceinline__ void gather_row(const BatchDev& b, const float* __res
         if (t == 0) my_gatt[cur * 4 + bb] += p;
       }
     }
+    if (NG == 4) {
 #pragma unroll
-    for (int bb = 0; bb < 4; ++bb) {
-      ax[bb] += __shfl_xor(ax[bb], 16, 64);
-      ay[bb] += __shfl_xor(ay[bb], 16, 64);
-      ax[bb] += __shfl_xor(ax[bb], 32, 64);
-      ay[bb] += __shfl_xor(ay[bb], 32, 64);
+      for (int bb = 0; bb < 4; ++bb) {
+        ax[bb] += __shfl_xor(ax[bb], 16, 64);
+        ay[bb] += __shfl_xor(ay[bb], 16, 64);
+        ax[bb] += __shfl_xor(ax[bb], 32, 64);
+        ay[bb] += __shfl_xor(ay[bb], 32, 64);
+      }
     }
   }
 }
@@ -490,6 +495,111 @@ __global__ __launch_bounds__(1024) void k_rgcn_layer(BatchDev b, ModelDev m, con
     for (int i = tid; i < R * 4; i += 1024) {
       float sacc = 0.f;
       for (int g = 0; g < 64; ++g) sacc += s_gatt[g * R * 4 + i];
+      gp[i] = sacc;
+    }
+  }
+}
+
+// Variant with 256-thread workgroups: wave w walks rows 4w..4w+3 of the tile, ONE 16-lane group per row (all
+// 2400 waves of an ml_1m batch are resident at once), then the 4 waves share the MFMA phase
+// (2 column tiles x 2 K-slices of 80, 20 MFMAs each).
+template <bool FLAGS, bool BWD>
+__global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_layer4(BatchDev b, ModelDev m, const float* __restrict__ P, int l,
+                                                             float* __restrict__ zero_out) {
+  IGMC_DYN_SMEM(smem);
+  const int R = m.R;
+  float* tile = (float*)smem;               // [16][IGMC_TP]
+  float* red = tile + 16 * IGMC_TP;         // [2 k-slices][2 col tiles][64 lanes * 4]
+  float* s_att = red + 1024;                // [R][4]
+  float* s_gatt = s_att + R * 4;            // BWD: [16 groups][R*4]
+  const float* __restrict__ in = BWD ? m.dpre[l] : m.h[l - 1];
+  const float* __restrict__ Yl = BWD ? m.Y[l - 1] : nullptr;
+  const float* att = P + m.off_att[l];
+  const float* basis = P + m.off_basis[l];
+  const float* root = P + m.off_root[l];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = lane >> 4, t = lane & 15;
+  const int li = lane & 15, kq = lane >> 4;
+  for (int i = tid; i < R * 4; i += IGMC_BLOCK) s_att[i] = att[i];
+  if (BWD)
+    for (int i = tid; i < 16 * R * 4; i += IGMC_BLOCK) s_gatt[i] = 0.f;
+  const int nt = wave & 1, ks = wave >> 1;
+  float bw[20];
+#pragma unroll
+  for (int j = 0; j < 20; ++j) {
+    const int k = ks * 80 + 4 * j + kq, n = nt * 16 + li;
+    if (!BWD) bw[j] = basis[k * 32 + n];
+    else bw[j] = (k < 128) ? basis[((k >> 5) * 32 + n) * 32 + (k & 31)] : root[n * 32 + (k - 128)];
+  }
+  __syncthreads();
+  const int N = b.totals[0];
+  const int trow = wave * 4 + grp;            // row of the tile owned by this 16-lane group
+  float* my_gatt = s_gatt + trow * R * 4;
+  for (int tl = blockIdx.x; tl * 16 < N; tl += gridDim.x) {
+    const int i = tl * 16 + trow;
+    if (i < N) {
+      float ax[4], ay[4];
+      gather_row<FLAGS, BWD, BWD, 1>(b, in, s_att, my_gatt, Yl, i, lane, ax, ay);
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        tile[trow * IGMC_TP + bb * 32 + 2 * t] = ax[bb];
+        tile[trow * IGMC_TP + bb * 32 + 2 * t + 1] = ay[bb];
+        if (BWD) {
+          float2 o;
+          o.x = ax[bb];
+          o.y = ay[bb];
+          *(float2*)(m.gagg[l - 1] + (size_t)i * 128 + bb * 32 + 2 * t) = o;
+        }
+      }
+      const float2 xs = *(const float2*)(in + (size_t)i * 32 + 2 * t);
+      tile[trow * IGMC_TP + 128 + 2 * t] = xs.x;
+      tile[trow * IGMC_TP + 128 + 2 * t + 1] = xs.y;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        tile[trow * IGMC_TP + q * 32 + 2 * t] = 0.f;
+        tile[trow * IGMC_TP + q * 32 + 2 * t + 1] = 0.f;
+      }
+    }
+    __syncthreads();
+    {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 20; ++j) {
+        const float a = tile[li * IGMC_TP + ks * 80 + 4 * j + kq];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[j], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) red[(ks * 2 + nt) * 256 + lane * 4 + rr] = acc[rr];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int o = tid + h2 * IGMC_BLOCK;
+      const int ont = o >> 8, idx = o & 255, ol = idx >> 2, rr = idx & 3;
+      const float v0 = red[(0 * 2 + ont) * 256 + idx] + red[(1 * 2 + ont) * 256 + idx];
+      const int orow = tl * 16 + (ol >> 4) * 4 + rr, n = ont * 16 + (ol & 15);
+      if (orow < N) {
+        float v = v0;
+        if (!BWD) {
+          v = tanhf(v + P[m.off_bias[l] + n]);
+          m.h[l][(size_t)orow * 32 + n] = v;
+          if (zero_out) zero_out[(size_t)orow * 32 + n] = 0.f;
+        } else {
+          const int lab = b.node_label[orow];
+          if (lab < 2) v += m.gfeat[(size_t)b.node_graph[orow] * m.D + lab * 128 + (l - 1) * 32 + n];
+          const float xv = m.h[l - 1][(size_t)orow * 32 + n];
+          m.dpre[l - 1][(size_t)orow * 32 + n] = v * (1.f - xv * xv);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (BWD) {
+    float* gp = m.gatt_part + ((size_t)(l - 1) * IGMC_GATHER_BLOCKS + blockIdx.x) * R * 4;
+    for (int i = tid; i < R * 4; i += IGMC_BLOCK) {
+      float sacc = 0.f;
+      for (int g = 0; g < 16; ++g) sacc += s_gatt[g * R * 4 + i];
       gp[i] = sacc;
     }
   }
@@ -1291,6 +1401,16 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_adam(float* __restrict__ p, cons
 // =================================================================== host launch sequences
 #include "launch.h"
 
+// R-GCN layer formulation: 0 = gather kernel + dense kernel, 1 = fused (16 waves / tile), 2 = fused (4 waves / tile)
+static int igmc_layer_mode() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("IGMC_LAYER_MODE");
+    mode = e ? atoi(e) : IGMC_LAYER_MODE_DEFAULT;
+  }
+  return mode;
+}
+
 static inline int igmc_rows_grid(int cap_rows, int rows_per_block, int max_blocks) {
   int g = (cap_rows + rows_per_block - 1) / rows_per_block;
   if (g < 1) g = 1;
@@ -1319,12 +1439,29 @@ void igmc_launch_forward(const ModelDev& m, const ModelAux& ax, const BatchDev& 
   const size_t ysz = (size_t)32 * (128 + 4) * sizeof(float);
   const int gt = igmc_rows_grid(m.node_cap, 16, 2048);                 // fused layer: 16 rows per workgroup
   const size_t fsm = (size_t)(16 * IGMC_TP + 2048 + m.R * 4) * sizeof(float);
+  const int mode = igmc_layer_mode();
+  const size_t gs = (size_t)(m.R * 4) * sizeof(float);
+  const size_t ds = (size_t)IGMC_KCAT * (32 + 4) * sizeof(float);
+  const size_t fsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4) * sizeof(float);
   for (int l = 1; l < 4; ++l) {
-    // gather (basis space) + [A | h_{l-1}] @ [basis ; root] + bias + tanh in ONE kernel; the top layer's
-    // launch also clears dPre_3 (only its target rows are written by the head backward)
+    // the top layer's launch also clears dPre_3 (only its target rows are written by the head backward)
     float* zo = (training && l == 3) ? m.dpre[3] : nullptr;
-    if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer<true, false>), gt, 1024, fsm, stream, b, m, P, l, zo);
-    else IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer<false, false>), gt, 1024, fsm, stream, b, m, P, l, zo);
+    if (mode == 1) {
+      if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer<true, false>), gt, 1024, fsm, stream, b, m, P, l, zo);
+      else IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer<false, false>), gt, 1024, fsm, stream, b, m, P, l, zo);
+    } else if (mode == 2) {
+      if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer4<true, false>), gt, IGMC_BLOCK, fsm4, stream, b, m, P, l, zo);
+      else IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer4<false, false>), gt, IGMC_BLOCK, fsm4, stream, b, m, P, l, zo);
+    } else {
+      if (use_flags)
+        IGMC_PLAUNCH("k_rgcn_gather_fwd", (k_rgcn_gather<true, false, false>), g16, IGMC_BLOCK, gs, stream, b, m.R,
+                     (const float*)m.h[l - 1], P + m.off_att[l], m.agg, (const float*)nullptr, (float*)nullptr);
+      else
+        IGMC_PLAUNCH("k_rgcn_gather_fwd", (k_rgcn_gather<false, false, false>), g16, IGMC_BLOCK, gs, stream, b, m.R,
+                     (const float*)m.h[l - 1], P + m.off_att[l], m.agg, (const float*)nullptr, (float*)nullptr);
+      IGMC_PLAUNCH("k_dense_fwd", k_dense_fwd, g64, IGMC_BLOCK, ds, stream, b, (const float*)m.agg,
+                   (const float*)m.h[l - 1], P + m.off_basis[l], P + m.off_bias[l], m.h[l], zo);
+    }
   }
   const int hgrid = (B + IGMC_HG - 1) / IGMC_HG;
   const size_t fs = (size_t)IGMC_HG * m.D * sizeof(float);
@@ -1366,10 +1503,30 @@ void igmc_launch_backward(const ModelDev& m, const ModelAux& ax, const BatchDev&
                  grad_scale, mult, drop_scale, grad);
   const int gt = igmc_rows_grid(m.node_cap, 16, 2048);
   const size_t bsm = (size_t)(16 * IGMC_TP + 2048 + m.R * 4 + 64 * m.R * 4) * sizeof(float);
+  const int mode = igmc_layer_mode();
+  const size_t gsa = (size_t)(m.R * 4 + 16 * m.R * 4) * sizeof(float);
+  const size_t ds = (size_t)IGMC_KCAT * (32 + 4) * sizeof(float);
+  const size_t bsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4 + 16 * m.R * 4) * sizeof(float);
   for (int l = 3; l >= 1; --l) {
-    // transposed gather of dPre_l (+ d att partials) + [G | dPre_l] @ [basis^T ; root^T] + backward epilogue
-    if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer<true, true>), gt, 1024, bsm, stream, b, m, P, l, (float*)nullptr);
-    else IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer<false, true>), gt, 1024, bsm, stream, b, m, P, l, (float*)nullptr);
+    // transposed gather of dPre_l (+ d att partials), then [G | dPre_l] @ [basis^T ; root^T] + backward epilogue
+    if (mode == 1) {
+      if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer<true, true>), gt, 1024, bsm, stream, b, m, P, l, (float*)nullptr);
+      else IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer<false, true>), gt, 1024, bsm, stream, b, m, P, l, (float*)nullptr);
+    } else if (mode == 2) {
+      if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer4<true, true>), gt, IGMC_BLOCK, bsm4, stream, b, m, P, l, (float*)nullptr);
+      else IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer4<false, true>), gt, IGMC_BLOCK, bsm4, stream, b, m, P, l, (float*)nullptr);
+    } else {
+      float* gp = m.gatt_part + (size_t)(l - 1) * IGMC_GATHER_BLOCKS * na;
+      if (use_flags)
+        IGMC_PLAUNCH("k_rgcn_gather_bwd", (k_rgcn_gather<true, true, true>), g16, IGMC_BLOCK, gsa, stream, b, m.R,
+                     (const float*)m.dpre[l], P + m.off_att[l], m.gagg[l - 1], (const float*)m.Y[l - 1], gp);
+      else
+        IGMC_PLAUNCH("k_rgcn_gather_bwd", (k_rgcn_gather<false, true, true>), g16, IGMC_BLOCK, gsa, stream, b, m.R,
+                     (const float*)m.dpre[l], P + m.off_att[l], m.gagg[l - 1], (const float*)m.Y[l - 1], gp);
+      IGMC_PLAUNCH("k_dense_bwd", k_dense_bwd, g64, IGMC_BLOCK, ds, stream, b, (const float*)m.gagg[l - 1],
+                   (const float*)m.dpre[l], P + m.off_basis[l], P + m.off_root[l], m.dpre[l - 1],
+                   (const float*)m.h[l - 1], (const float*)m.gfeat, m.D, l - 1);
+    }
   }
   const float* d0 = m.dpre[0];
   IGMC_PLAUNCH("k_wgrad", k_wgrad, dim3(IGMC_WG_BLOCKS, l0_mfma ? 4 : 3), IGMC_BLOCK, 0, stream, b, m, 0);
@@ -1379,7 +1536,7 @@ void igmc_launch_backward(const ModelDev& m, const ModelAux& ax, const BatchDev&
   {
     const int wgs2 = igmc_wg_stride(), n0 = rows0 * 32;
     const int nblk = ((l0_mfma ? 4 : 3) * wgs2 + 63) / 64 + (l0_mfma ? 0 : (n0 + 63) / 64) + (3 * na + 3) / 4;
-    IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk, IGMC_BLOCK, 0, stream, m, gt, l0_mfma);
+    IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk, IGMC_BLOCK, 0, stream, m, mode == 0 ? g16 : gt, l0_mfma);
   }
   IGMC_PLAUNCH("k_finalize", k_finalize, 4, IGMC_BLOCK, 0, stream, m, P, grad, arr_coef);
 }
