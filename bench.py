@@ -11,9 +11,10 @@ SURVEY.md 8(d) (6040 x 3706, 1 000 209 ratings, 90/10 split) unless raw_data/ml_
 Weights are random-init (reference init).  Inputs (graph, link arrays) are resident in HBM before timing.
 
 The ONE JSON line printed by rank 0 also carries
-  roofline      : the R-GCN edge-gather kernel (k_rgcn_gather_fwd): algorithmic bytes per launch
-                  (133*E + 132*N) / its average duration measured with HIP events on the
-                  launch stream in a separate instrumented pass of the same steps;
+  roofline      : the dominant kernel = the fused R-GCN layer forward (k_rgcn_layer_fwd: edge gather in basis
+                  space + MFMA transform + tanh): algorithmic bytes per launch (133*E + 132*N)
+                  / its average duration measured with HIP events on the launch stream in a separate
+                  instrumented pass of the same steps;
   cpu_baseline  : the oracle's restatement of the reference CPU path (scipy/python extraction + PyG-1.4.2
                   per-edge-weight formulation in torch, all host cores) on a bounded sample of the same workload.
 """
@@ -183,7 +184,7 @@ def main():
         N, E = float(np.mean(Ns)), float(np.mean(Es))
         kernels = {name: dict(us=ms / calls * 1e3, calls_per_step=calls / args.profile_steps) for name, ms, calls in rows}
         tot = sum(ms for _, ms, _ in rows)
-        dom = 'k_rgcn_gather_fwd'
+        dom = 'k_rgcn_layer_fwd' if 'k_rgcn_layer_fwd' in kernels else 'k_rgcn_gather_fwd'
         if dom in kernels and args.profile_steps > 0:
             algo_bytes = 133.0 * E + 132.0 * N                  # one layer, one direction
             dur_s = kernels[dom]['us'] * 1e-6

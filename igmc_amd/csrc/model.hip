@@ -23,7 +23,7 @@
 //     each (blockIdx.y = layer), and loss / epoch-total / control-block tick ride in the Adam kernel.
 #include "model.h"
 #include <stdlib.h>
-#define IGMC_LAYER_MODE_DEFAULT 0
+#define IGMC_LAYER_MODE_DEFAULT 2
 
 __device__ __forceinline__ float igmc_wave_sum_f(float v) {
 #pragma unroll
