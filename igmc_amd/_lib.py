@@ -52,6 +52,8 @@ SIGNATURES = {
     'igmc_batch_set_ctrl': (i32, [vp, vp]),
     'igmc_model_set_ctrl': (i32, [vp, vp]),
     'igmc_adam_step_ctrl': (i32, [vp, vp, vp, vp, i64, vp, vp]),
+    'igmc_train_step': (i32, [vp, vp, vp, i32, vp, u64, u64, f32, f32, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32,
+                              f32, f32, vp]),
     'igmc_step_finish': (i32, [vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp]),
     'igmc_profile_enable': (i32, [i32]),
     'igmc_profile_fetch': (i32, [vp, vp, vp, i32]),
@@ -59,7 +61,7 @@ SIGNATURES = {
 
 BUF = dict(NODE_OFF=0, N_USERS=1, NODE_LABEL=2, NODE_GID=3, NODE_GRAPH=4, ROW_PTR=5, ECR=6, ECODE=7,
            EFLAG=8, Y=9, TOTALS=10)
-CTRL = dict(STEP=0, FIRST=1, EPOCH=2, ADAM_T=3, BATCH=4, DONE=5, LR=8, BETA1=9, BETA2=10, EPS=11, WD=12, STEP_SIZE=13,
+CTRL = dict(STEP=0, FIRST=1, EPOCH=2, ADAM_T=3, BATCH=4, DONE=5, FIRST_ODD=6, K=7, LR=8, BETA1=9, BETA2=10, EPS=11, WD=12, STEP_SIZE=13,
             INV_SQRT_BC2=14, WORDS=16)
 P = dict(BASIS=0, ROOT=1, BIAS=2, ATT=3, LIN1_W=4, LIN1_B=5, LIN2_W=6, LIN2_B=7)
 

@@ -67,6 +67,7 @@ struct igmc_model {
   int device;
   ModelDev d;
   ModelAux ax;
+  int* done_ctr;
   int last_B, last_training, last_flags;
   Allocs mem;
 };
@@ -472,6 +473,7 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
           M.get(&d.graw, (size_t)3 * igmc_wg_stride() + 3 * d.R * 4 + rows0 * 32) | M.get(&d.arr_part, 4);
   d.side = nullptr;
   d.ctrl = nullptr;
+  fail |= M.get(&m->done_ctr, 4);
   if (fail) {
     M.release();
     delete m;
@@ -493,6 +495,7 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
       m->ax.ev[i] = e;
     }
   }
+  HIPCHECK(hipMemset(m->done_ctr, 0, 4 * sizeof(int)));
   if (igmc_model_prepare(d)) {
     M.release();
     delete m;
@@ -578,11 +581,8 @@ extern "C" int igmc_model_loss_grad(igmc_model* m, const float* d_params, const 
   if (check_fit(m, b, &why)) IGMC_FAIL(why);
   if (!d_params || !d_out || !d_grad) IGMC_FAIL("null buffer");
   m->d.side = b->side;
-  igmc_launch_forward(m->d, m->ax, b->d, d_params, b->last_B, 1, use_edge_flags, d_lin_mask, seed, step, multiply_by, d_out,
-                      stream);
-  igmc_launch_backward(m->d, m->ax, b->d, d_params, b->last_B, use_edge_flags, nullptr, 1, grad_scale, multiply_by, 2.f,
-                       ARR * arr_scale, d_grad, stream);
-  if (d_loss) igmc_launch_loss(m->d, b->d, ARR, d_loss, stream);
+  igmc_launch_loss_grad(m->d, m->ax, b->d, (float*)d_params, b->last_B, use_edge_flags, d_lin_mask, seed, step,
+                        multiply_by, ARR, grad_scale, arr_scale, d_out, d_grad, d_loss, nullptr, stream);
   HIPCHECK(hipGetLastError());
   m->last_B = b->last_B;
   m->last_training = 1;
@@ -650,5 +650,32 @@ extern "C" int igmc_step_finish(igmc_model* m, const igmc_batch* b, float* d_par
   igmc_launch_finish(m->d, b->d, d_params, d_grad, d_exp_avg, d_exp_avg_sq, step_size, inv, beta1, beta2, eps,
                      weight_decay, d_ctrl, ARR, d_loss, d_total, stream);
   HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int igmc_train_step(igmc_model* m, float* d_params, const igmc_batch* b, int use_edge_flags,
+                               const uint8_t* d_lin_mask, uint64_t seed, uint64_t step, float multiply_by, float ARR,
+                               float* d_out, float* d_grad, float* d_exp_avg, float* d_exp_avg_sq, float* d_loss,
+                               double* d_total, int64_t* d_ctrl, int64_t adam_t, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, void* stream) {
+  std::string why;
+  if (check_fit(m, b, &why)) IGMC_FAIL(why);
+  if (!d_params || !d_out || !d_grad || !d_exp_avg || !d_exp_avg_sq || !d_loss) IGMC_FAIL("null buffer");
+  if (!d_ctrl && adam_t < 1) IGMC_FAIL("adam_t must be >= 1");
+  float step_size = 0.f, inv = 0.f;
+  if (!d_ctrl) {
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)adam_t);
+    const double bc2 = 1.0 - std::pow((double)beta2, (double)adam_t);
+    step_size = (float)((double)lr / bc1);
+    inv = (float)(1.0 / std::sqrt(bc2));
+  }
+  m->d.side = b->side;
+  igmc_launch_train_step(m->d, m->ax, b->d, d_params, b->last_B, use_edge_flags, d_lin_mask, seed, step, multiply_by, ARR,
+                         d_out, d_grad, d_exp_avg, d_exp_avg_sq, step_size, inv, beta1, beta2, eps, weight_decay, d_ctrl,
+                         m->done_ctr, d_loss, d_total, stream);
+  HIPCHECK(hipGetLastError());
+  m->last_B = b->last_B;
+  m->last_training = 1;
+  m->last_flags = use_edge_flags;
   return 0;
 }

@@ -180,9 +180,9 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_extract_nodes(ExtractArgs a) {
   bm_clear(sel_u, Wu);
   bm_clear(sel_v, Wv);
   if (!a.replay) {
-    // with a control block attached the host `first` is an OFFSET relative to the block's (prefetching the
-    // next batch on a second stream uses +B)
-    const int first = a.ctrl ? (int)a.ctrl[IGMC_CTRL_FIRST] + a.first : a.first;
+    // with a control block attached the host `first` selects the even / odd slot (see igmc_hip.h): a prefetch of
+    // the next batch on another stream reads the slot the concurrent step never writes
+    const int first = a.ctrl ? (int)a.ctrl[(a.first & 1) ? IGMC_CTRL_FIRST_ODD : IGMC_CTRL_FIRST] : a.first;
     const uint64_t epoch = a.ctrl ? (uint64_t)a.ctrl[IGMC_CTRL_EPOCH] : a.epoch;
     const int pos = a.link_idx ? a.link_idx[first + g] : first + g;
     u0 = a.link_u[pos];
@@ -467,7 +467,11 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_fill(GraphDev G, BatchDev b) {
 // (shared by the two directions when force_undirected).  16 lanes per CSR row.
 __global__ __launch_bounds__(IGMC_BLOCK) void k_edge_flags(BatchDev b, float p, int force_undirected,
                                                             uint64_t seed, uint64_t step_arg, const int64_t* ctrl) {
-  const uint64_t step = ctrl ? (uint64_t)ctrl[IGMC_CTRL_STEP] + step_arg : step_arg;
+  // control block: key by (epoch, batch index) of the selected slot -- race-free under prefetching
+  const uint64_t step = ctrl ? (((uint64_t)ctrl[IGMC_CTRL_EPOCH] << 32) ^
+                                (uint64_t)(ctrl[(step_arg & 1) ? IGMC_CTRL_FIRST_ODD : IGMC_CTRL_FIRST] /
+                                           (ctrl[IGMC_CTRL_BATCH] > 0 ? ctrl[IGMC_CTRL_BATCH] : 1)))
+                             : step_arg;
   const int N = b.totals[0];
   const int grp = (blockIdx.x * IGMC_BLOCK + threadIdx.x) >> 4, t = threadIdx.x & 15;
   const int ngrp = (gridDim.x * IGMC_BLOCK) >> 4;

@@ -28,6 +28,16 @@ void igmc_launch_forward(const ModelDev& m, const ModelAux& ax, const BatchDev& 
 void igmc_launch_backward(const ModelDev& m, const ModelAux& ax, const BatchDev& b, const float* P, int B, int use_flags,
                           const float* gout, int from_err, float grad_scale, float mult, float drop_scale,
                           float arr_coef, float* grad, void* stream);
+struct AdamTail;
+void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev& b, float* P, int B, int use_flags,
+                           const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult, float ARR,
+                           float grad_scale, float arr_scale, float* out, float* grad, float* loss, const AdamTail* adam,
+                           void* stream);
+void igmc_launch_train_step(const ModelDev& m, const ModelAux& ax, const BatchDev& b, float* P, int B, int use_flags,
+                            const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult, float ARR, float* out,
+                            float* grad, float* m1, float* m2, float step_size, float inv_sqrt_bc2, float beta1,
+                            float beta2, float eps, float wd, int64_t* ctrl, int* done, float* loss, double* total,
+                            void* stream);
 void igmc_launch_loss(const ModelDev& m, const BatchDev& b, float ARR, float* loss, void* stream);
 void igmc_launch_sse(const BatchDev& b, const float* out, double* acc, void* stream);
 int igmc_model_prepare(const ModelDev& m);

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_gather(BatchDev b, int R, c
 enum { EPI_NONE = 0, EPI_BIAS_TANH = 1, EPI_BWD = 2 };
 enum { W_PLAIN = 0, W_BWD_T = 1, W_YCAT = 2 };
 
-template <int K1, int K2, int NO, int EPI, int WMODE>
+template <int K1, int K2, int NO, int EPI, int WMODE, int NTH = IGMC_BLOCK>
 __device__ __forceinline__ void dense_body(const BatchDev& b, const float* __restrict__ A1,
                                            const float* __restrict__ A2, const float* __restrict__ basis,
                                            const float* __restrict__ root, const float* __restrict__ bias,
@@ -293,22 +293,23 @@ __device__ __forceinline__ void dense_body(const BatchDev& b, const float* __res
                                            float* __restrict__ zero_out, float* sW) {
   constexpr int K = K1 + K2, PITCH = NO + 4, NT = NO / 16;
   if (WMODE == W_PLAIN) {
-    for (int idx = threadIdx.x; idx < K * NO; idx += IGMC_BLOCK) sW[(idx / NO) * PITCH + (idx % NO)] = basis[idx];
+    for (int idx = threadIdx.x; idx < K * NO; idx += NTH) sW[(idx / NO) * PITCH + (idx % NO)] = basis[idx];
   } else {
-    for (int idx = threadIdx.x; idx < 4096; idx += IGMC_BLOCK) {     // coalesced read of basis[b][f][fo]
+    for (int idx = threadIdx.x; idx < 4096; idx += NTH) {     // coalesced read of basis[b][f][fo]
       const int bb = idx >> 10, f = (idx >> 5) & 31, fo = idx & 31;
       if (WMODE == W_BWD_T) sW[(bb * 32 + fo) * PITCH + f] = basis[idx];
       else sW[f * PITCH + bb * 32 + fo] = basis[idx];
     }
     if (WMODE == W_BWD_T)
-      for (int idx = threadIdx.x; idx < 1024; idx += IGMC_BLOCK) sW[(128 + (idx & 31)) * PITCH + (idx >> 5)] = root[idx];
+      for (int idx = threadIdx.x; idx < 1024; idx += NTH) sW[(128 + (idx & 31)) * PITCH + (idx >> 5)] = root[idx];
   }
   __syncthreads();
   const int N = b.totals[0];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, kq = lane >> 4;
-  for (int tile = blockIdx.x; tile * 64 < N; tile += gridDim.x) {
-    const int row0 = tile * 64 + wave * 16;
+  constexpr int ROWS = NTH / 4;      // 16 rows per wave
+  for (int tile = blockIdx.x; tile * ROWS < N; tile += gridDim.x) {
+    const int row0 = tile * ROWS + wave * 16;
     if (row0 >= N) continue;
     const int row = (row0 + li < N) ? row0 + li : N - 1;
     f32x4 acc[NT];
@@ -610,9 +611,8 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_layer4(BatchDev b, ModelDev
 // D2 = d bias).  Layer slices ly = ly_base + blockIdx.y (0..2 = conv layers 1..3, 3 = layer 0) in ONE launch.
 // (Running the slices as parallel graph branches on auxiliary streams was measured SLOWER: every cross-stream
 // edge of the hipGraph costs several microseconds on this part -- more than the kernels it would hide.)
-__global__ __launch_bounds__(IGMC_BLOCK) void k_wgrad(BatchDev b, ModelDev m, int ly_base) {
+__device__ __forceinline__ void wgrad_body(const BatchDev& b, const ModelDev& m, int ly) {
   __shared__ float sacc[32 * IGMC_KCAT + 32];
-  const int ly = ly_base + blockIdx.y;
   // ly == 3: layer 0, whose "X" is synthesised from the per-node code histogram cnt0 plus the one-hot
   // columns for d root0[label] / d bias0 (codes < 32 only; larger tables use k_l0_bwd)
   const bool is_l0 = ly == 3;
@@ -701,6 +701,10 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_wgrad(BatchDev b, ModelDev m, in
     __syncthreads();
   }
   for (int i = threadIdx.x; i < 32 * IGMC_KCAT + 32; i += IGMC_BLOCK) part[i] = sacc[i];
+}
+
+__global__ __launch_bounds__(IGMC_BLOCK) void k_wgrad(BatchDev b, ModelDev m, int ly_base) {
+  wgrad_body(b, m, ly_base + blockIdx.y);
 }
 
 // =================================================================== layer 0 backward (dense, no edges)
@@ -1017,6 +1021,135 @@ __global__ __launch_bounds__(512) void k_head_fwd_mfma(BatchDev b, ModelDev m, c
   }
 }
 
+// Training head in ONE launch (fused-step path): blockIdx.y == 0 -> forward of 16 graphs, their residual, and
+// immediately the backward down to d feat / dPre of the top layer (dz never leaves the workgroup except for
+// the copy the lin1 weight gradient needs); blockIdx.y = 1..3 -> the Y products of the conv layers.
+__global__ __launch_bounds__(512) void k_head_train(BatchDev b, ModelDev m, const float* __restrict__ P,
+                                                      const uint8_t* __restrict__ inj_mask, uint64_t seed,
+                                                      uint64_t step_arg, float mult, float grad_scale,
+                                                      float* __restrict__ out) {
+  IGMC_DYN_SMEM(smem);
+  if (blockIdx.y > 0) {
+    const int ly = blockIdx.y - 1;
+    dense_body<0, 32, 128, EPI_NONE, W_YCAT, 512>(b, nullptr, m.h[ly], P + m.off_basis[ly + 1], nullptr, nullptr,
+                                                  m.Y[ly], nullptr, nullptr, 0, 0, nullptr, (float*)smem);
+    return;
+  }
+  const int B = b.totals[3], D = m.D;
+  const int row0 = blockIdx.x * 16;
+  if (row0 >= B) return;
+  __shared__ float spart[8][16];
+  __shared__ float serr[16];
+  __shared__ float sdz[16][132];
+  const uint64_t step = m.ctrl ? (uint64_t)m.ctrl[IGMC_CTRL_STEP] : step_arg;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int n0 = wave * 16;
+  const int ga = (row0 + li < B) ? row0 + li : B - 1;
+  const float* wrow = P + m.off_l1w + (int64_t)(n0 + li) * D;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nch = D / 16;
+  for (int s0 = 0; s0 < nch; s0 += 8) {
+    float4 a4[8], b4[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k0 = ((s0 + u < nch) ? s0 + u : nch - 1) * 16 + 4 * kq;
+      a4[u] = *(const float4*)head_feat_ptr(b, m, ga, k0);
+      b4[u] = *(const float4*)(wrow + k0);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (s0 + u >= nch) continue;
+      const int k0 = (s0 + u) * 16 + 4 * kq;
+      if (wave == 0 && row0 + li < B) *(float4*)(m.feat + (size_t)ga * D + k0) = a4[u];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u].x, b4[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u].y, b4[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u].z, b4[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u].w, b4[u].w, acc, 0, 0, 0);
+    }
+  }
+  const int n = n0 + li;
+  const float b1 = P[m.off_l1b + n], w2 = P[m.off_l2w + n];
+  float av[4];
+  int kp[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = kq * 4 + rr, g = row0 + r;
+    float a = acc[rr] + b1;
+    a = a > 0.f ? a : 0.f;
+    av[rr] = a;
+    kp[rr] = 0;
+    if (g < B) {
+      m.a1[g * 128 + n] = a;
+      kp[rr] = inj_mask ? (int)inj_mask[g * 128 + n]
+                        : (int)(igmc_u01(igmc_unit_hash(seed, step, (uint32_t)g, (uint32_t)n)) >= 0.5f);
+      m.lmask[g * 128 + n] = (uint8_t)kp[rr];
+    }
+    const float p = igmc_group16_sum_f((kp[rr] ? a * 2.f : 0.f) * w2);
+    if (li == 0) spart[wave][r] = p;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const int g = row0 + threadIdx.x;
+    float e = 0.f;
+    if (g < B) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) s += spart[w][threadIdx.x];
+      const float o = (s + P[m.off_l2b]) * mult;
+      out[g] = o;
+      e = o - b.y[g];
+      m.err[g] = e;
+    }
+    serr[threadIdx.x] = e;
+  }
+  __syncthreads();
+  // ---- backward through lin2 / dropout / relu: dz (kept in LDS for the next product, copied out for d lin1.weight)
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = kq * 4 + rr, g = row0 + r;
+    const float dp = 2.f * serr[r] * grad_scale * mult;
+    const float dzv = (g < B && av[rr] > 0.f && kp[rr]) ? dp * w2 * 2.f : 0.f;
+    sdz[r][n] = dzv;
+    if (g < B) m.dz[g * 128 + n] = dzv;
+  }
+  __syncthreads();
+  // ---- d feat = dz @ lin1.weight  (16 x 128 @ 128 x D), column tiles strided over the 8 waves
+  for (int nt = wave; nt * 16 < D; nt += 8) {
+    const int c0 = nt * 16;
+    f32x4 g4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < 8; s2 += 4) {
+      float bv[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm)
+          bv[u][mm] = P[m.off_l1w + (int64_t)((s2 + u) * 16 + 4 * kq + mm) * D + c0 + li];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm)
+          g4 = __builtin_amdgcn_mfma_f32_16x16x4f32(sdz[li][(s2 + u) * 16 + 4 * kq + mm], bv[u][mm], g4, 0, 0, 0);
+    }
+    const int k = c0 + li;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int g = row0 + kq * 4 + rr;
+      if (g >= B) continue;
+      const float v = g4[rr];
+      m.gfeat[(size_t)g * D + k] = v;
+      if (k < 256 && ((k >> 5) & 3) == 3) {
+        const int side = k >> 7, f = k & 31;
+        const int nu = b.node_off[g], nv = nu + b.n_users[g];
+        const size_t node = (size_t)(side ? nv : nu);
+        const float hv = m.h[3][node * 32 + f];
+        m.dpre[3][node * 32 + f] = v * (1.f - hv * hv);
+      }
+    }
+  }
+}
+
 // d feat = dz @ lin1.weight, dz formed on the fly; wave -> 16 fan-in columns; also dPre of the top layer
 __global__ __launch_bounds__(512) void k_head_bwd_a_mfma(BatchDev b, ModelDev m, const float* __restrict__ P,
                                                            const float* __restrict__ gout, int from_err,
@@ -1076,15 +1209,14 @@ __global__ __launch_bounds__(512) void k_head_bwd_a_mfma(BatchDev b, ModelDev m,
 // d lin1.weight = dz^T @ feat (reduction over the B graphs, 4 per MFMA); block x = 16 hidden units, wave -> 16
 // fan-in columns.  Wave 0 of the y == 0 blocks also forms d lin1.bias = dz^T 1, d lin2.weight = adrop^T dp and
 // d lin2.bias = 1^T dp with three more MFMAs per step (B operand = 1 / dp_g), so there is no serial tail.
-__global__ __launch_bounds__(IGMC_BLOCK) void k_head_bwd_w_mfma(BatchDev b, ModelDev m, const float* __restrict__ P,
-                                                                  const float* __restrict__ gout, int from_err,
-                                                                  float grad_scale, float mult, float drop_scale,
-                                                                  float* __restrict__ grad) {
+__device__ __forceinline__ void head_bwd_w_body(const BatchDev& b, const ModelDev& m, const float* __restrict__ P,
+                                                const float* __restrict__ gout, int from_err, float grad_scale,
+                                                float mult, float drop_scale, float* __restrict__ grad, int bx, int by) {
   const int B = b.totals[3], D = m.D, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
-  const int j0 = blockIdx.x * 16;
-  const int nt = blockIdx.y * 4 + wave;
+  const int j0 = bx * 16;
+  const int nt = by * 4 + wave;
   if (nt * 16 >= D) return;
   const int n0 = nt * 16;
   const bool extra = nt == 0;
@@ -1122,7 +1254,29 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_head_bwd_w_mfma(BatchDev b, Mode
       grad[m.off_l1b + j0 + kq * 4 + rr] = accb1[rr];
       grad[m.off_l2w + j0 + kq * 4 + rr] = accw2[rr];
     }
-    if (blockIdx.x == 0 && kq == 0) grad[m.off_l2b] = accb2[0];
+    if (bx == 0 && kq == 0) grad[m.off_l2b] = accb2[0];
+  }
+}
+
+__global__ __launch_bounds__(IGMC_BLOCK) void k_head_bwd_w_mfma(BatchDev b, ModelDev m, const float* __restrict__ P,
+                                                                  const float* __restrict__ gout, int from_err,
+                                                                  float grad_scale, float mult, float drop_scale,
+                                                                  float* __restrict__ grad) {
+  head_bwd_w_body(b, m, P, gout, from_err, grad_scale, mult, drop_scale, grad, blockIdx.x, blockIdx.y);
+}
+
+// ONE launch for every weight-gradient product of the step: blockIdx.y < nsl -> conv weight-gradient slice,
+// blockIdx.y == nsl -> d lin1 / d lin2 (linear block id = (j tile, column tile)).
+__global__ __launch_bounds__(IGMC_BLOCK) void k_wgrad_head(BatchDev b, ModelDev m, const float* __restrict__ P,
+                                                             const float* __restrict__ gout, int from_err,
+                                                             float grad_scale, float mult, float drop_scale,
+                                                             float* __restrict__ grad, int nsl) {
+  if ((int)blockIdx.y < nsl) {
+    wgrad_body(b, m, blockIdx.y);
+  } else {
+    const int ny = (m.D / 16 + 3) / 4;
+    if ((int)blockIdx.x < 8 * ny)
+      head_bwd_w_body(b, m, P, gout, from_err, grad_scale, mult, drop_scale, grad, blockIdx.x & 7, blockIdx.x >> 3);
   }
 }
 
@@ -1178,16 +1332,103 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_partials(ModelDev m, int 
   }
 }
 
+struct FinishArgs {
+  int enabled;
+  BatchDev b;
+  ModelDev m;
+  float ARR;
+  float* loss;
+  double* total;
+};
+
+__device__ __forceinline__ void ctrl_advance(int64_t* ctrl) {
+  double* d = (double*)ctrl;
+  const int64_t k = ctrl[IGMC_CTRL_K];
+  ctrl[IGMC_CTRL_STEP] += 1;
+  ctrl[(k & 1) ? IGMC_CTRL_FIRST_ODD : IGMC_CTRL_FIRST] += 2 * ctrl[IGMC_CTRL_BATCH];   // the slot step k used
+  ctrl[IGMC_CTRL_K] = k + 1;
+  ctrl[IGMC_CTRL_ADAM_T] += 1;
+  const double t = (double)ctrl[IGMC_CTRL_ADAM_T];
+  d[IGMC_CTRL_STEP_SIZE] = d[IGMC_CTRL_LR] / (1.0 - pow(d[IGMC_CTRL_BETA1], t));
+  d[IGMC_CTRL_INV_SQRT_BC2] = 1.0 / sqrt(1.0 - pow(d[IGMC_CTRL_BETA2], t));
+}
+
+// loss[0] = mean_g err^2 + ARR * sum_l reg_l   (reference train_eval.py:162-174); loss[1] = sum err^2
+__device__ __forceinline__ void loss_body(const BatchDev& b, const ModelDev& m, float ARR, float* loss,
+                                          double* total, float* smf) {
+  const int B = b.totals[3];
+  float s = 0.f;
+  for (int g = threadIdx.x; g < B; g += IGMC_BLOCK) s += m.err[g] * m.err[g];
+  s = igmc_block_sum_f(s, smf);
+  if (threadIdx.x == 0) {
+    const float reg = m.arr_part[0] + m.arr_part[1] + m.arr_part[2] + m.arr_part[3];
+    const float l0 = s / (float)B + ARR * reg;
+    loss[0] = l0;
+    loss[1] = s;
+    if (total) total[0] += (double)l0 * (double)B;     // epoch total of loss * num_graphs (ref :176)
+  }
+}
+
+// one Adam update (torch.optim.Adam semantics)
+__device__ __forceinline__ void adam_elem(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1,
+                                          float* __restrict__ m2, int64_t i, float step_size, float inv_sqrt_bc2,
+                                          float beta1, float beta2, float eps, float wd) {
+  float gi = g[i];
+  const float pi = p[i];
+  if (wd != 0.f) gi += wd * pi;
+  const float a = beta1 * m1[i] + (1.f - beta1) * gi;
+  const float v = beta2 * m2[i] + (1.f - beta2) * gi * gi;
+  m1[i] = a;
+  m2[i] = v;
+  p[i] = pi - step_size * a / (sqrtf(v) * inv_sqrt_bc2 + eps);
+}
+
+// optional optimiser tail of k_finalize (single-GPU fused step): Adam on the parameters whose gradient the
+// workgroup just produced (conv layers) / on a slice of the lin parameters (extra workgroups), then the LAST
+// workgroup to finish emits loss / epoch total and advances the control block.
+struct AdamTail {
+  int enabled;
+  float* p;
+  float* m1;
+  float* m2;
+  float step_size, inv_sqrt_bc2, beta1, beta2, eps, wd;
+  int64_t* ctrl;
+  int* done;
+  BatchDev b;
+  float ARR;
+  float* loss;
+  double* total;
+};
+
 // one block per conv layer: scatter the reduced partials into the flat gradient, add the
 // adjacent-rating-regulariser gradient (reference train_eval.py:167-174), emit the ARR value.
 // ARR through the 4x4 Gram matrix of the bases:  W[r] = sum_b att[r,b] basis[b]  =>
 //   D[r] = W[r+1]-W[r] = sum_b d[r,b] basis[b],  d[r] = att[r+1]-att[r]
 //   reg = sum_r d[r]^T Gm d[r],  dreg/dW[r] = 2(D[r-1]-D[r]) = sum_b c[r,b] basis[b],  c[r] = 2(d[r-1]-d[r])
 //   d att[r,b] += ARR * sum_b' c[r,b'] Gm[b',b];   d basis[b] += ARR * sum_b' (sum_r att[r,b] c[r,b']) basis[b']
-__global__ __launch_bounds__(IGMC_BLOCK) void k_finalize(ModelDev m, const float* __restrict__ P,
-                                                           float* __restrict__ grad, float arr_coef) {
+__global__ __launch_bounds__(IGMC_BLOCK) void k_finalize(ModelDev m, const float* P, float* __restrict__ grad,
+                                                           float arr_coef, AdamTail at) {
   __shared__ float smf[8];
   __shared__ float sG[16], sM[16];
+  __shared__ int s_last;
+  if (at.enabled && at.ctrl) {      // hipGraph replay: the Adam scalars live in HBM
+    const double* d = (const double*)at.ctrl;
+    at.step_size = (float)d[IGMC_CTRL_STEP_SIZE];
+    at.inv_sqrt_bc2 = (float)d[IGMC_CTRL_INV_SQRT_BC2];
+    at.beta1 = (float)d[IGMC_CTRL_BETA1];
+    at.beta2 = (float)d[IGMC_CTRL_BETA2];
+    at.eps = (float)d[IGMC_CTRL_EPS];
+    at.wd = (float)d[IGMC_CTRL_WD];
+  }
+  if (blockIdx.x >= 4) {            // extra workgroups: Adam on lin1 / lin2 (their gradients are final already)
+    const int64_t n_lin = m.n_params - m.off_l1w;
+    const int nb = gridDim.x - 4;
+    const int64_t chunk = (n_lin + nb - 1) / nb;
+    const int64_t lo = m.off_l1w + (int64_t)(blockIdx.x - 4) * chunk;
+    const int64_t hi = (lo + chunk < m.n_params) ? lo + chunk : m.n_params;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += IGMC_BLOCK)
+      adam_elem(at.p, grad, at.m1, at.m2, i, at.step_size, at.inv_sqrt_bc2, at.beta1, at.beta2, at.eps, at.wd);
+  } else {
   const int l = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int fin = (l == 0) ? m.L : 32;
@@ -1295,21 +1536,29 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize(ModelDev m, const float
         gb[bb * nE + e] += arr_coef * (sM[bb * 4 + 0] * b0 + sM[bb * 4 + 1] * b1 + sM[bb * 4 + 2] * b2 + sM[bb * 4 + 3] * b3);
     }
   }
-}
-
-// loss[0] = mean_g err^2 + ARR * sum_l reg_l   (reference train_eval.py:162-174); loss[1] = sum err^2
-__device__ __forceinline__ void loss_body(const BatchDev& b, const ModelDev& m, float ARR, float* loss,
-                                          double* total, float* smf) {
-  const int B = b.totals[3];
-  float s = 0.f;
-  for (int g = threadIdx.x; g < B; g += IGMC_BLOCK) s += m.err[g] * m.err[g];
-  s = igmc_block_sum_f(s, smf);
-  if (threadIdx.x == 0) {
-    const float reg = m.arr_part[0] + m.arr_part[1] + m.arr_part[2] + m.arr_part[3];
-    const float l0 = s / (float)B + ARR * reg;
-    loss[0] = l0;
-    loss[1] = s;
-    if (total) total[0] += (double)l0 * (double)B;     // epoch total of loss * num_graphs (ref :176)
+  if (at.enabled) {               // Adam on this conv layer's parameters (basis, root, bias, att are contiguous)
+    __syncthreads();
+    const int64_t lo = m.off_basis[l], hi = m.off_att[l] + na;
+    for (int64_t i = lo + tid; i < hi; i += IGMC_BLOCK)
+      adam_elem(at.p, grad, at.m1, at.m2, i, at.step_size, at.inv_sqrt_bc2, at.beta1, at.beta2, at.eps, at.wd);
+  }
+  }   // conv-layer workgroups
+  if (at.enabled) {
+    // the last workgroup to arrive has every arr_part / err in sight: loss, epoch total, control-block tick
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      s_last = (atomicAdd(at.done, 1) == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (s_last) {
+      __threadfence();
+      loss_body(at.b, m, at.ARR, at.loss, at.total, smf);
+      if (threadIdx.x == 0) {
+        *at.done = 0;
+        if (at.ctrl) ctrl_advance(at.ctrl);
+      }
+    }
   }
 }
 
@@ -1336,25 +1585,6 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_sse_acc(BatchDev b, const float*
 // =================================================================== fused Adam (flat buffer) + step epilogue
 // With `fin` set, block 0 also produces the step's loss / epoch total, and the LAST block to finish advances
 // the device-side step control (igmc_hip.h) for the next replay of the step graph.
-struct FinishArgs {
-  int enabled;
-  BatchDev b;
-  ModelDev m;
-  float ARR;
-  float* loss;
-  double* total;
-};
-
-__device__ __forceinline__ void ctrl_advance(int64_t* ctrl) {
-  double* d = (double*)ctrl;
-  ctrl[IGMC_CTRL_STEP] += 1;
-  ctrl[IGMC_CTRL_FIRST] += ctrl[IGMC_CTRL_BATCH];
-  ctrl[IGMC_CTRL_ADAM_T] += 1;
-  const double t = (double)ctrl[IGMC_CTRL_ADAM_T];
-  d[IGMC_CTRL_STEP_SIZE] = d[IGMC_CTRL_LR] / (1.0 - pow(d[IGMC_CTRL_BETA1], t));
-  d[IGMC_CTRL_INV_SQRT_BC2] = 1.0 / sqrt(1.0 - pow(d[IGMC_CTRL_BETA2], t));
-}
-
 __global__ void k_tick(int64_t* ctrl) {
   if (threadIdx.x == 0 && blockIdx.x == 0) ctrl_advance(ctrl);
 }
@@ -1538,7 +1768,94 @@ void igmc_launch_backward(const ModelDev& m, const ModelAux& ax, const BatchDev&
     const int nblk = ((l0_mfma ? 4 : 3) * wgs2 + 63) / 64 + (l0_mfma ? 0 : (n0 + 63) / 64) + (3 * na + 3) / 4;
     IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk, IGMC_BLOCK, 0, stream, m, mode == 0 ? g16 : gt, l0_mfma);
   }
-  IGMC_PLAUNCH("k_finalize", k_finalize, 4, IGMC_BLOCK, 0, stream, m, P, grad, arr_coef);
+  {
+    AdamTail none;
+    memset(&none, 0, sizeof(none));
+    IGMC_PLAUNCH("k_finalize", k_finalize, 4, IGMC_BLOCK, 0, stream, m, P, grad, arr_coef, none);
+  }
+}
+
+// Fused-step sequence (loss + gradients [+ Adam]) with the multi-role launches:
+//   l0_fwd, 3 x layer_fwd, {head fwd+bwd | Y}, 3 x layer_bwd, {weight grads | lin grads}, reduce, finalize[+Adam]
+void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev& b, float* P, int B, int use_flags,
+                           const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult, float ARR,
+                           float grad_scale, float arr_scale, float* out, float* grad, float* loss, const AdamTail* adam,
+                           void* stream) {
+  const int rows0 = m.R * m.L + m.L + 1;
+  const int l0_mfma = rows0 <= 32;
+  const int gy = igmc_rows_grid(m.node_cap, 128, 512);
+  const int hb = (B + 15) / 16;
+  const int ny = (m.D / 16 + 3) / 4;
+  const bool fast_head = (m.D % 16 == 0) && igmc_layer_mode() == 2 && 8 * ny <= IGMC_WG_BLOCKS;
+  AdamTail at;
+  memset(&at, 0, sizeof(at));
+  if (adam) at = *adam;
+  if (!fast_head) {      // generic sequence
+    igmc_launch_forward(m, ax, b, P, B, 1, use_flags, inj_mask, seed, step, mult, out, stream);
+    igmc_launch_backward(m, ax, b, P, B, use_flags, nullptr, 1, grad_scale, mult, 2.f, ARR * arr_scale, grad, stream);
+    if (adam) {
+      igmc_launch_finish(m, b, at.p, grad, at.m1, at.m2, at.step_size, at.inv_sqrt_bc2, at.beta1, at.beta2, at.eps, at.wd,
+                         at.ctrl, ARR, at.loss, at.total, stream);
+    } else if (loss) {
+      igmc_launch_loss(m, b, ARR, loss, stream);
+    }
+    return;
+  }
+  const size_t l0s = (size_t)(m.R * m.L * 32 + m.L * 32 + 32) * sizeof(float) + (size_t)4 * m.R * m.L * sizeof(int);
+  const int g16 = igmc_rows_grid(m.node_cap, 4, IGMC_GATHER_BLOCKS);
+  const int gt = igmc_rows_grid(m.node_cap, 16, 2048);
+  if (use_flags) IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<true, true>), g16, IGMC_BLOCK, l0s, stream, b, m, (const float*)P, m.h[0]);
+  else IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<false, true>), g16, IGMC_BLOCK, l0s, stream, b, m, (const float*)P, m.h[0]);
+  const size_t fsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4) * sizeof(float);
+  const size_t bsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4 + 16 * m.R * 4) * sizeof(float);
+  for (int l = 1; l < 4; ++l) {
+    float* zo = (l == 3) ? m.dpre[3] : nullptr;
+    if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer4<true, false>), gt, IGMC_BLOCK, fsm4, stream, b, m, (const float*)P, l, zo);
+    else IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer4<false, false>), gt, IGMC_BLOCK, fsm4, stream, b, m, (const float*)P, l, zo);
+  }
+  const size_t ysz = (size_t)32 * (128 + 4) * sizeof(float);
+  IGMC_PLAUNCH("k_head_train", k_head_train, dim3(hb > gy ? hb : gy, 4), 512, ysz, stream, b, m, (const float*)P, inj_mask,
+               seed, step, mult, grad_scale, out);
+  for (int l = 3; l >= 1; --l) {
+    if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer4<true, true>), gt, IGMC_BLOCK, bsm4, stream, b, m, (const float*)P, l, (float*)nullptr);
+    else IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer4<false, true>), gt, IGMC_BLOCK, bsm4, stream, b, m, (const float*)P, l, (float*)nullptr);
+  }
+  const int nsl = l0_mfma ? 4 : 3;
+  IGMC_PLAUNCH("k_wgrad_head", k_wgrad_head, dim3(IGMC_WG_BLOCKS, nsl + 1), IGMC_BLOCK, 0, stream, b, m, (const float*)P,
+               (const float*)nullptr, 1, grad_scale, mult, 2.f, grad, nsl);
+  if (!l0_mfma) {
+    const float* d0 = m.dpre[0];
+    if (rows0 <= 64) IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<8>), IGMC_L0_BLOCKS, IGMC_BLOCK, 0, stream, b, m, d0, m.l0_part);
+    else IGMC_PLAUNCH("k_l0_bwd", (k_l0_bwd<40>), IGMC_L0_BLOCKS, IGMC_BLOCK, 0, stream, b, m, d0, m.l0_part);
+  }
+  {
+    const int wgs2 = igmc_wg_stride(), n0 = rows0 * 32, na = m.R * 4;
+    const int nblk = (nsl * wgs2 + 63) / 64 + (l0_mfma ? 0 : (n0 + 63) / 64) + (3 * na + 3) / 4;
+    IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk, IGMC_BLOCK, 0, stream, m, gt, l0_mfma);
+  }
+  if (adam) {
+    at.enabled = 1;
+    at.b = b;
+    at.ARR = ARR;
+    IGMC_PLAUNCH("k_finalize_adam", k_finalize, 4 + 32, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at);
+  } else {
+    IGMC_PLAUNCH("k_finalize", k_finalize, 4, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at);
+    if (loss) igmc_launch_loss(m, b, ARR, loss, stream);
+  }
+}
+
+void igmc_launch_train_step(const ModelDev& m, const ModelAux& ax, const BatchDev& b, float* P, int B, int use_flags,
+                            const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult, float ARR, float* out,
+                            float* grad, float* m1, float* m2, float step_size, float inv_sqrt_bc2, float beta1,
+                            float beta2, float eps, float wd, int64_t* ctrl, int* done, float* loss, double* total,
+                            void* stream) {
+  AdamTail at;
+  memset(&at, 0, sizeof(at));
+  at.p = P; at.m1 = m1; at.m2 = m2;
+  at.step_size = step_size; at.inv_sqrt_bc2 = inv_sqrt_bc2; at.beta1 = beta1; at.beta2 = beta2; at.eps = eps; at.wd = wd;
+  at.ctrl = ctrl; at.done = done; at.loss = loss; at.total = total;
+  igmc_launch_loss_grad(m, ax, b, P, B, use_flags, inj_mask, seed, step, mult, ARR, 1.0f / (float)B, 1.0f, out, grad,
+                        nullptr, &at, stream);
 }
 
 void igmc_launch_loss(const ModelDev& m, const BatchDev& b, float ARR, float* loss, void* stream) {

@@ -29,6 +29,7 @@ def _ctrl_words(step, first, epoch, adam_t, batch, lr, beta1, beta2, eps, wd):
     """Control block describing the NEXT step to run (the step's last kernel advances it)."""
     w = np.zeros(_lib.CTRL['WORDS'], dtype=np.int64)
     w[_lib.CTRL['STEP']], w[_lib.CTRL['FIRST']], w[_lib.CTRL['EPOCH']] = step, first, epoch
+    w[_lib.CTRL['FIRST_ODD']], w[_lib.CTRL['K']] = first + batch, 0     # batch k starts at slot[k & 1]
     w[_lib.CTRL['ADAM_T']], w[_lib.CTRL['BATCH']] = adam_t, batch
     step_size = float(lr) / (1.0 - float(beta1) ** adam_t)
     inv_sqrt_bc2 = 1.0 / (1.0 - float(beta2) ** adam_t) ** 0.5
@@ -87,13 +88,14 @@ class StepGraph(object):
             self.lib.call('igmc_model_set_ctrl', self.ws.handle, None)
             self._attached = False
 
-    def _extract(self, arena, offset, B, step_offset):
-        """Extraction (+ edge dropout) of the batch at ctrl.first + offset into ``arena`` on the current stream."""
+    def _extract(self, arena, slot, B):
+        """Extraction (+ edge dropout) of the batch whose offset is in control slot ``slot`` (even/odd) into
+        ``arena`` on the current stream."""
         m, st = self.model, torch.cuda.current_stream().cuda_stream
         arena.extract(self.ds.link_u.data_ptr(), self.ds.link_v.data_ptr(), self.ds.link_y.data_ptr(),
-                      self.perm.data_ptr(), offset, B, self.ds.sample_ratio, self.ds.seed, 0, st)
+                      self.perm.data_ptr(), slot, B, self.ds.sample_ratio, self.ds.seed, 0, st)
         if m.adj_dropout > 0:
-            arena.edge_dropout(m.adj_dropout, m.force_undirected, m.seed, step_offset, st)
+            arena.edge_dropout(m.adj_dropout, m.force_undirected, m.seed, slot, st)
 
     def begin_epoch(self, perm, epoch):
         """``perm``: this rank's link positions for the epoch (1-D int tensor, any device)."""
@@ -110,7 +112,7 @@ class StepGraph(object):
         if not self._attached:
             self._attach()
         # the first batch of the epoch has nobody to prefetch it
-        self._extract(self.arenas[0], 0, min(self.B, n), 0)
+        self._extract(self.arenas[0], 0, min(self.B, n))
 
     # ------------------------------------------------------------------ one step
     def _model(self, arena, B):
@@ -133,20 +135,44 @@ class StepGraph(object):
                       C.c_void_p(self.total.data_ptr()), C.c_void_p(self.ctrl.data_ptr()), 1, g['lr'],
                       g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], C.c_void_p(st))
 
+    def _train_step(self, arena):
+        """Single GPU: forward + loss + backward + Adam (+ loss / total / control-block advance) with the minimum
+        number of launches (``igmc_train_step``)."""
+        m, st = self.model, torch.cuda.current_stream().cuda_stream
+        flat, grad = m.flat_parameters(), m.flat_grad()
+        g = self.opt.param_groups[0]
+        self.lib.call('igmc_train_step', self.ws.handle, C.c_void_p(flat.data_ptr()), arena.handle,
+                      int(m.adj_dropout > 0), None, m.seed & (2 ** 64 - 1), 0, float(m.multiply_by), self.ARR,
+                      C.c_void_p(self.out.data_ptr()), C.c_void_p(grad.data_ptr()),
+                      C.c_void_p(self.opt.exp_avg.data_ptr()), C.c_void_p(self.opt.exp_avg_sq.data_ptr()),
+                      C.c_void_p(self.loss.data_ptr()), C.c_void_p(self.total.data_ptr()),
+                      C.c_void_p(self.ctrl.data_ptr()), 1, g['lr'], g['betas'][0], g['betas'][1], g['eps'],
+                      g['weight_decay'], C.c_void_p(st))
+
     def _enqueue(self, parity, B, with_finish=True):
         """model(batch in arenas[parity]) || extract(next batch -> arenas[1-parity]); then finish."""
         cur, nxt = self.arenas[parity], self.arenas[1 - parity]
         main = torch.cuda.current_stream()
+        fused = self.world == 1 and with_finish and B == self.B
         if self.side is not None:
             self.side.wait_stream(main)
             with torch.cuda.stream(self.side):
-                self._extract(nxt, self.B, self.B, 1)
-            self._model(cur, B)
-            main.wait_stream(self.side)          # join BEFORE the control block is advanced
+                self._extract(nxt, 1 - parity, self.B)
+            if fused:
+                # the step's last kernel advances ONLY the control slot of its own parity; the prefetch reads the
+                # other one, so the two branches never touch the same word
+                self._train_step(cur)
+            else:
+                self._model(cur, B)
+            main.wait_stream(self.side)
         else:
-            self._model(cur, B)
-            self._extract(nxt, self.B, self.B, 1)
-        if with_finish:
+            if fused:
+                self._extract(nxt, 1 - parity, self.B)
+                self._train_step(cur)
+            else:
+                self._model(cur, B)
+                self._extract(nxt, 1 - parity, self.B)
+        if with_finish and not fused:
             self._finish(cur)
 
     def _capture(self, parity):
@@ -162,7 +188,7 @@ class StepGraph(object):
         parity = self.k % 2
         if B != self.B:
             # ragged last batch of the epoch: its prefetch assumed a full batch -> extract again, run eagerly
-            self._extract(self.arenas[parity], 0, B, 0)
+            self._extract(self.arenas[parity], parity, B)
             self._model(self.arenas[parity], B)
             self._finish(self.arenas[parity])
         else:

@@ -163,15 +163,18 @@ int igmc_adam_step(float* d_params, const float* d_grad, float* d_exp_avg, float
 /* ------------------------------------------------------------------ device-side step control
  * A hipGraph replay cannot change kernel arguments, so the per-step scalars can live in HBM instead:
  * d_ctrl is an int64[IGMC_CTRL_WORDS] device buffer (slots 8.. hold doubles, bit-cast):
- *   [0] step   [1] first (offset into the link permutation)   [2] epoch   [3] adam_t   [4] batch size
- *   [5] internal arrival counter (keep 0)
+ *   [0] step   [1] first_even   [2] epoch   [3] adam_t   [4] batch size   [5] internal arrival counter (keep 0)
+ *   [6] first_odd   [7] k = steps done in this epoch
+ * first_even / first_odd = offset into the link permutation of the batch of the even / odd steps: the batch of
+ * step k starts at slot[k & 1]; a tick (end of step k) does slot[k & 1] += 2*batch, so the OTHER slot -- the one
+ * a concurrent prefetch of batch k+1 reads -- is never written while it may be read.
  *   [8] lr  [9] beta1  [10] beta2  [11] eps  [12] weight_decay   [13] lr/(1-beta1^t)  [14] 1/sqrt(1-beta2^t)
- * igmc_ctrl_tick advances it on the device: step+=1, first+=batch, adam_t+=1, slots 13/14 recomputed.
- * Once attached, igmc_extract_batch uses first = ctrl.first + <host first> (the host value becomes an OFFSET:
- * +B prefetches the next batch on another stream) and ctrl.epoch; igmc_batch_edge_dropout uses
- * ctrl.step + <host step>; the forward's MLP dropout uses ctrl.step.  NULL detaches. */
+ * igmc_ctrl_tick advances it on the device: step+=1, slot[k&1]+=2*batch, k+=1, adam_t+=1, slots 13/14 recomputed.
+ * Once attached, igmc_extract_batch reads first from slot[<host first> & 1] (the host value becomes the slot
+ * SELECTOR) and ctrl.epoch; igmc_batch_edge_dropout keys its hash by (epoch, first/batch) of slot[<host step> & 1];
+ * the forward's MLP dropout uses ctrl.step.  NULL detaches. */
 enum { IGMC_CTRL_STEP = 0, IGMC_CTRL_FIRST = 1, IGMC_CTRL_EPOCH = 2, IGMC_CTRL_ADAM_T = 3, IGMC_CTRL_BATCH = 4,
-       IGMC_CTRL_DONE = 5,
+       IGMC_CTRL_DONE = 5, IGMC_CTRL_FIRST_ODD = 6, IGMC_CTRL_K = 7,
        IGMC_CTRL_LR = 8, IGMC_CTRL_BETA1 = 9, IGMC_CTRL_BETA2 = 10, IGMC_CTRL_EPS = 11, IGMC_CTRL_WD = 12,
        IGMC_CTRL_STEP_SIZE = 13, IGMC_CTRL_INV_SQRT_BC2 = 14, IGMC_CTRL_WORDS = 16 };
 int igmc_ctrl_tick(int64_t* d_ctrl, void* stream);
@@ -185,6 +188,16 @@ int igmc_step_finish(igmc_model* m, const igmc_batch* b, float* d_params, const 
                      float* d_exp_avg, float* d_exp_avg_sq, float ARR, float* d_loss, double* d_total,
                      int64_t* d_ctrl, int64_t step, float lr, float beta1, float beta2, float eps,
                      float weight_decay, void* stream);
+/* The whole single-GPU optimisation step on an extracted batch (reference train_eval.py:158-177: forward, loss,
+ * backward, optimizer.step) in the minimum number of launches: the last kernel applies Adam to the parameters
+ * whose gradients it finalises, emits d_loss[0..1], adds loss*num_graphs to d_total[0] and (with d_ctrl) advances
+ * the control block.  grad_scale = 1/B.  Data-parallel runs use igmc_model_loss_grad + all-reduce +
+ * igmc_step_finish instead. */
+int igmc_train_step(igmc_model* m, float* d_params, const igmc_batch* b, int use_edge_flags,
+                    const uint8_t* d_lin_mask, uint64_t seed, uint64_t step, float multiply_by, float ARR,
+                    float* d_out, float* d_grad, float* d_exp_avg, float* d_exp_avg_sq, float* d_loss,
+                    double* d_total, int64_t* d_ctrl, int64_t adam_t, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, void* stream);
 int igmc_adam_step_ctrl(float* d_params, const float* d_grad, float* d_exp_avg, float* d_exp_avg_sq,
                         int64_t n, const int64_t* d_ctrl, void* stream);
 

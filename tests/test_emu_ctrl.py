@@ -17,6 +17,7 @@ CASES = load_extract_golden()
 def ctrl_words(step, first, epoch, adam_t, batch, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, wd=0.0):
     w = np.zeros(_lib.CTRL['WORDS'], np.int64)
     w[0], w[1], w[2], w[3], w[4] = step, first, epoch, adam_t, batch
+    w[6], w[7] = first + batch, 0          # odd slot, k
     for k, v in ((8, lr), (9, b1), (10, b2), (11, eps), (12, wd)):
         w[k] = struct.unpack('<q', struct.pack('<d', float(v)))[0]
     return w
@@ -40,12 +41,12 @@ def test_ctrl_path_equals_host_argument_path():
     ref = PC.make_ref_model(4, 5, seed=4)
     P0 = PC.flatten_params(ws, ref)
     outs = {}
-    for mode in ('host', 'ctrl', 'finish'):
+    for mode in ('host', 'ctrl', 'finish', 'train_step'):
         P, M1, M2 = P0.copy(), np.zeros_like(P0), np.zeros_like(P0)
         G, out, loss = np.zeros_like(P0), np.zeros(B, np.float32), np.zeros(2, np.float32)
         batch = b1 if mode == 'host' else b2
-        ctrl = ctrl_words(step=10, first=-B, epoch=3, adam_t=0, batch=B)
-        if mode == 'finish':      # control block describes the NEXT step; the step's last kernel advances it
+        ctrl = ctrl_words(step=10, first=-2 * B, epoch=3, adam_t=0, batch=B)     # tick-before-use: slot[k&1] += 2B
+        if mode in ('finish', 'train_step'):      # control block describes the NEXT step; the step's last kernel advances it
             ctrl = ctrl_words(step=11, first=0, epoch=3, adam_t=1, batch=B)
             for k, v in ((13, 1e-3 / (1 - 0.9)), (14, 1.0 / (1 - 0.999) ** 0.5)):
                 ctrl[k] = struct.unpack('<q', struct.pack('<d', v))[0]
@@ -59,15 +60,22 @@ def test_ctrl_path_equals_host_argument_path():
         for i in range(3):
             if mode == 'ctrl':
                 lib.call('igmc_ctrl_tick', C.c_void_p(ctrl.ctypes.data), None)
-                batch.extract(lu, lv, ly, perm, 0, B, 1.0, 7, 999)              # first = offset to ctrl.first; epoch ignored
-                batch.edge_dropout(0.2, False, 7, 0)                             # step = offset to ctrl.step
+                batch.extract(lu, lv, ly, perm, i & 1, B, 1.0, 7, 999)          # first = slot selector; epoch ignored
+                batch.edge_dropout(0.2, False, 7, i & 1)                         # keyed by (epoch, batch index) of the slot
                 ws.loss_grad(P.ctypes.data, batch, out.ctypes.data, G.ctypes.data, loss.ctypes.data,
                              use_edge_flags=True, seed=7, step=424242, ARR=0.001)
                 lib.call('igmc_adam_step_ctrl', C.c_void_p(P.ctypes.data), C.c_void_p(G.ctypes.data),
                          C.c_void_p(M1.ctypes.data), C.c_void_p(M2.ctypes.data), len(P), C.c_void_p(ctrl.ctypes.data), None)
+            elif mode == 'train_step':    # the whole step through igmc_train_step (multi-role launches + Adam tail)
+                batch.extract(lu, lv, ly, perm, i & 1, B, 1.0, 7, 999)
+                batch.edge_dropout(0.2, False, 7, i & 1)
+                lib.call('igmc_train_step', ws.handle, C.c_void_p(P.ctypes.data), batch.handle, 1, None, 7, 0, 1.0, 0.001,
+                         C.c_void_p(out.ctypes.data), C.c_void_p(G.ctypes.data), C.c_void_p(M1.ctypes.data),
+                         C.c_void_p(M2.ctypes.data), C.c_void_p(loss.ctypes.data), C.c_void_p(total.ctypes.data),
+                         C.c_void_p(ctrl.ctypes.data), 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, None)
             elif mode == 'finish':
-                batch.extract(lu, lv, ly, perm, 0, B, 1.0, 7, 999)
-                batch.edge_dropout(0.2, False, 7, 0)
+                batch.extract(lu, lv, ly, perm, i & 1, B, 1.0, 7, 999)
+                batch.edge_dropout(0.2, False, 7, i & 1)
                 ws.loss_grad(P.ctypes.data, batch, out.ctypes.data, G.ctypes.data, None,
                              use_edge_flags=True, seed=7, step=424242, ARR=0.001)
                 lib.call('igmc_step_finish', ws.handle, batch.handle, C.c_void_p(P.ctypes.data), C.c_void_p(G.ctypes.data),
@@ -75,7 +83,7 @@ def test_ctrl_path_equals_host_argument_path():
                          C.c_void_p(total.ctypes.data), C.c_void_p(ctrl.ctypes.data), 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, None)
             else:
                 batch.extract(lu, lv, ly, perm, i * B, B, 1.0, 7, 3)
-                batch.edge_dropout(0.2, False, 7, 11 + i)
+                batch.edge_dropout(0.2, False, 7, (3 << 32) ^ i)
                 ws.loss_grad(P.ctypes.data, batch, out.ctypes.data, G.ctypes.data, loss.ctypes.data,
                              use_edge_flags=True, seed=7, step=11 + i, ARR=0.001)
                 ws.adam_step(P.ctypes.data, G.ctypes.data, M1.ctypes.data, M2.ctypes.data, i + 1, 1e-3)
@@ -83,11 +91,12 @@ def test_ctrl_path_equals_host_argument_path():
             rec.append((d['node_gid'].copy(), d['eflag'].copy(), out.copy(), loss.copy(), P.copy()))
         outs[mode] = rec
         if mode == 'ctrl':
-            assert ctrl[0] == 13 and ctrl[1] == 2 * B and ctrl[3] == 3
-        if mode == 'finish':
-            assert ctrl[0] == 14 and ctrl[1] == 3 * B and ctrl[3] == 4 and ctrl[5] == 0
+            assert ctrl[0] == 13 and ctrl[7] == 3 and ctrl[3] == 3
+        if mode in ('finish', 'train_step'):
+            assert ctrl[0] == 14 and ctrl[7] == 3 and ctrl[1] == 4 * B and ctrl[6] == 3 * B and ctrl[3] == 4 and ctrl[5] == 0
             assert total[0] == pytest.approx(sum(float(r[3][0]) * B for r in rec), rel=1e-6)
-    for a, b in list(zip(outs['host'], outs['ctrl'])) + list(zip(outs['host'], outs['finish'])):
+    for a, b in (list(zip(outs['host'], outs['ctrl'])) + list(zip(outs['host'], outs['finish'])) +
+                 list(zip(outs['host'], outs['train_step']))):
         for x, y in zip(a[:2], b[:2]):
             assert np.array_equal(x, y)          # same links, same sampling, same dropout flags
         # lr is a float argument on the host path and a double in the control block: last-ulp differences only
