@@ -538,38 +538,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_layer4(BatchDev b, ModelDev
   float* my_gatt = s_gatt + trow * R * 4;
   for (int tl = blockIdx.x; tl * 16 < N; tl += gridDim.x) {
     const int i = tl * 16 + trow;
-    // Row lengths are bimodal (the two target rows of a subgraph see every sampled neighbour, ~max_nodes_per_hop
-    // entries; the rest ~a quarter of that).  Long rows are walked by the WHOLE wave (4 groups x 16 entries per
-    // round), the others by their own 16-lane group, so a tile is not held up by one 7-round row.
-    const int len = (i < N) ? b.row_ptr[i + 1] - b.row_ptr[i] : 0;
-    const bool is_long = len > 40;
-    const unsigned long long bl = __ballot(is_long);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (!((bl >> (g * 16)) & 1ull)) continue;          // wave-uniform
-      const int ig = tl * 16 + wave * 4 + g, tr = wave * 4 + g;
-      float ax[4], ay[4];
-      gather_row<FLAGS, BWD, BWD, 4>(b, in, s_att, my_gatt, Yl, ig, lane, ax, ay);
-      if (grp == 0) {
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-          tile[tr * IGMC_TP + bb * 32 + 2 * t] = ax[bb];
-          tile[tr * IGMC_TP + bb * 32 + 2 * t + 1] = ay[bb];
-          if (BWD) {
-            float2 o;
-            o.x = ax[bb];
-            o.y = ay[bb];
-            *(float2*)(m.gagg[l - 1] + (size_t)ig * 128 + bb * 32 + 2 * t) = o;
-          }
-        }
-        const float2 xs = *(const float2*)(in + (size_t)ig * 32 + 2 * t);
-        tile[tr * IGMC_TP + 128 + 2 * t] = xs.x;
-        tile[tr * IGMC_TP + 128 + 2 * t + 1] = xs.y;
-      }
-    }
-    if (is_long) {
-      // done cooperatively above
-    } else if (i < N) {
+    if (i < N) {
       float ax[4], ay[4];
       gather_row<FLAGS, BWD, BWD, 1>(b, in, s_att, my_gatt, Yl, i, lane, ax, ay);
 #pragma unroll
