@@ -57,6 +57,28 @@ __device__ __forceinline__ float igmc_block_sum_f(float v, float* sm) {
   return tot;
 }
 
+// ---- XCD affinity -------------------------------------------------------------------------------------
+// MI355X has 8 XCDs with private, mutually non-coherent 4 MiB L2s, and workgroup b of a launch runs on XCD
+// b % 8 (observed placement; used for SPEED only, never for correctness).  Subgraphs are independent: a row of
+// graph g only ever reads rows of graph g.  So the graphs of a batch are split into 8 contiguous segments and
+// every row-walking kernel lets XCD x work on segment x: what layer l wrote stays in the L2 that layer l+1
+// reads it from, instead of being re-fetched from the other XCDs / Infinity Cache by all eight L2s
+// (rocprofv3: TCC hit rate 50 % and FETCH_SIZE = 8 x the feature matrix without this).
+struct XcdSeg {
+  int lo, hi;      // row range [lo, hi) of this workgroup's XCD segment
+  int j, nj;       // index of the workgroup within its XCD, workgroups per XCD
+};
+__device__ __forceinline__ XcdSeg igmc_xcd_segment(const BatchDev& b) {
+  XcdSeg s;
+  const int B = b.totals[3];
+  const int x = blockIdx.x & 7;
+  s.j = blockIdx.x >> 3;
+  s.nj = (gridDim.x + 7 - x) >> 3;          // workgroups with this residue
+  s.lo = b.node_off[(x * B) >> 3];
+  s.hi = b.node_off[((x + 1) * B) >> 3];
+  return s;
+}
+
 // =================================================================== row walkers
 // One WAVE per destination row.  The row's CSR entries are consumed in chunks of 16: 16-lane group
 // `grp` of the wave owns chunks grp, grp+4, ...; lane t of the group loads entry c0+t (one coalesced
@@ -91,7 +113,9 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_l0_fwd(BatchDev b, ModelDev m, c
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp = lane >> 4, t = lane & 15;
   int* hist = shist + wave * RL;
-  for (int i = blockIdx.x * 4 + wave; i < N; i += gridDim.x * 4) {
+  const XcdSeg seg = igmc_xcd_segment(b);
+  (void)N;
+  for (int i = seg.lo + seg.j * 4 + wave; i < seg.hi; i += seg.nj * 4) {
     float ax = 0.f, ay = 0.f;
     if (STORE) {
       for (int c = lane; c < RL; c += 64) hist[c] = 0;
@@ -536,9 +560,12 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_layer4(BatchDev b, ModelDev
   const int N = b.totals[0];
   const int trow = wave * 4 + grp;            // row of the tile owned by this 16-lane group
   float* my_gatt = s_gatt + trow * R * 4;
-  for (int tl = blockIdx.x; tl * 16 < N; tl += gridDim.x) {
-    const int i = tl * 16 + trow;
-    if (i < N) {
+  const XcdSeg seg = igmc_xcd_segment(b);
+  (void)N;
+  for (int tl = seg.j; seg.lo + tl * 16 < seg.hi; tl += seg.nj) {
+    const int trow0 = seg.lo + tl * 16;       // first row of the tile (tiles are cut per XCD segment)
+    const int i = trow0 + trow;
+    if (i < seg.hi) {
       float ax[4], ay[4];
       gather_row<FLAGS, BWD, BWD, 1>(b, in, s_att, my_gatt, Yl, i, lane, ax, ay);
 #pragma unroll
@@ -579,8 +606,8 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_layer4(BatchDev b, ModelDev
       const int o = tid + h2 * IGMC_BLOCK;
       const int ont = o >> 8, idx = o & 255, ol = idx >> 2, rr = idx & 3;
       const float v0 = red[(0 * 2 + ont) * 256 + idx] + red[(1 * 2 + ont) * 256 + idx];
-      const int orow = tl * 16 + (ol >> 4) * 4 + rr, n = ont * 16 + (ol & 15);
-      if (orow < N) {
+      const int orow = trow0 + (ol >> 4) * 4 + rr, n = ont * 16 + (ol & 15);
+      if (orow < seg.hi) {
         float v = v0;
         if (!BWD) {
           v = tanhf(v + P[m.off_bias[l] + n]);
@@ -1641,10 +1668,13 @@ static int igmc_layer_mode() {
   return mode;
 }
 
+// grid for row-parallel kernels: enough workgroups for the capacity, capped, and a multiple of 8 (>= 8) so
+// that every XCD residue owns workgroups (XCD-affine segments, see igmc_xcd_segment)
 static inline int igmc_rows_grid(int cap_rows, int rows_per_block, int max_blocks) {
   int g = (cap_rows + rows_per_block - 1) / rows_per_block;
-  if (g < 1) g = 1;
-  return g < max_blocks ? g : max_blocks;
+  if (g > max_blocks) g = max_blocks;
+  g = (g + 7) & ~7;
+  return g < 8 ? 8 : g;
 }
 
 // fork: `to` waits for everything enqueued on `from` so far (an event edge; a graph edge under capture)
