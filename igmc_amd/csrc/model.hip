@@ -1676,6 +1676,17 @@ static inline int igmc_rows_grid(int cap_rows, int rows_per_block, int max_block
   g = (g + 7) & ~7;
   return g < 8 ? 8 : g;
 }
+// grid for the XCD-segmented kernels: 8 x (workgroups needed by the LARGEST segment = ceil(B/8) graphs of at
+// most `slot` rows each), so that no XCD has to take a second round
+static inline int igmc_xcd_grid(const ModelDev& m, int B, int rows_per_block, int max_blocks) {
+  const int slot = (m.node_cap + m.graph_cap - 1) / m.graph_cap;
+  const long rows = (long)((B + 7) / 8) * slot;
+  long per = (rows + rows_per_block - 1) / rows_per_block;
+  if (per < 1) per = 1;
+  long g = 8 * per;
+  if (g > max_blocks) g = max_blocks & ~7;
+  return (int)(g < 8 ? 8 : g);
+}
 
 // fork: `to` waits for everything enqueued on `from` so far (an event edge; a graph edge under capture)
 static inline void igmc_edge(void* ev, void* from, void* to) {
@@ -1687,7 +1698,7 @@ void igmc_launch_forward(const ModelDev& m, const ModelAux& ax, const BatchDev& 
                          int use_flags, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
                          float* out, void* stream) {
   const size_t l0s = (size_t)(m.R * m.L * 32 + m.L * 32 + 32) * sizeof(float) + (size_t)4 * m.R * m.L * sizeof(int);
-  const int g16 = igmc_rows_grid(m.node_cap, 4, IGMC_GATHER_BLOCKS);   // one wave per row, 4 rows per block
+  const int g16 = igmc_xcd_grid(m, B, 4, IGMC_GATHER_BLOCKS);   // one wave per row, 4 rows per block
   const int g64 = igmc_rows_grid(m.node_cap, 64, 512);
   if (training) {
     if (use_flags) IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<true, true>), g16, IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
@@ -1697,7 +1708,7 @@ void igmc_launch_forward(const ModelDev& m, const ModelAux& ax, const BatchDev& 
     else IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<false, false>), g16, IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
   }
   const size_t ysz = (size_t)32 * (128 + 4) * sizeof(float);
-  const int gt = igmc_rows_grid(m.node_cap, 16, 2048);                 // fused layer: 16 rows per workgroup
+  const int gt = igmc_xcd_grid(m, B, 16, 2048);                        // fused layer: 16 rows per workgroup
   const size_t fsm = (size_t)(16 * IGMC_TP + 2048 + m.R * 4) * sizeof(float);
   const int mode = igmc_layer_mode();
   const size_t gs = (size_t)(m.R * 4) * sizeof(float);
@@ -1741,7 +1752,7 @@ void igmc_launch_forward(const ModelDev& m, const ModelAux& ax, const BatchDev& 
 void igmc_launch_backward(const ModelDev& m, const ModelAux& ax, const BatchDev& b, const float* P, int B, int use_flags,
                           const float* gout, int from_err, float grad_scale, float mult, float drop_scale,
                           float arr_coef, float* grad, void* stream) {
-  const int g16 = igmc_rows_grid(m.node_cap, 4, IGMC_GATHER_BLOCKS);
+  const int g16 = igmc_xcd_grid(m, B, 4, IGMC_GATHER_BLOCKS);
   const int g64 = igmc_rows_grid(m.node_cap, 64, 512);
   const int hgrid = (B + IGMC_HG - 1) / IGMC_HG;
   const int na = m.R * 4;
@@ -1761,7 +1772,7 @@ void igmc_launch_backward(const ModelDev& m, const ModelAux& ax, const BatchDev&
   else
     IGMC_PLAUNCH("k_head_bwd_w", k_head_bwd_w, dim3(17, (m.D + 255) / 256), IGMC_BLOCK, 0, s2, b, m, P, gout, from_err,
                  grad_scale, mult, drop_scale, grad);
-  const int gt = igmc_rows_grid(m.node_cap, 16, 2048);
+  const int gt = igmc_xcd_grid(m, B, 16, 2048);
   const size_t bsm = (size_t)(16 * IGMC_TP + 2048 + m.R * 4 + 64 * m.R * 4) * sizeof(float);
   const int mode = igmc_layer_mode();
   const size_t gsa = (size_t)(m.R * 4 + 16 * m.R * 4) * sizeof(float);
@@ -1832,8 +1843,8 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
     return;
   }
   const size_t l0s = (size_t)(m.R * m.L * 32 + m.L * 32 + 32) * sizeof(float) + (size_t)4 * m.R * m.L * sizeof(int);
-  const int g16 = igmc_rows_grid(m.node_cap, 4, IGMC_GATHER_BLOCKS);
-  const int gt = igmc_rows_grid(m.node_cap, 16, 2048);
+  const int g16 = igmc_xcd_grid(m, B, 4, IGMC_GATHER_BLOCKS);
+  const int gt = igmc_xcd_grid(m, B, 16, 2048);
   if (use_flags) IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<true, true>), g16, IGMC_BLOCK, l0s, stream, b, m, (const float*)P, m.h[0]);
   else IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<false, true>), g16, IGMC_BLOCK, l0s, stream, b, m, (const float*)P, m.h[0]);
   const size_t fsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4) * sizeof(float);
