@@ -64,6 +64,9 @@ class StepGraph(object):
         if overlap is None:
             overlap = os.environ.get('IGMC_NO_OVERLAP', '0') != '1'
         self.use_graph, self.overlap = use_graph, overlap
+        # the multi-GPU launch structure (graph up to the gradients, eager all-reduce + step_finish) can be forced on
+        # one GPU to test it: IGMC_FORCE_DP_PATH=1
+        self.dp_path = self.world > 1 or os.environ.get('IGMC_FORCE_DP_PATH', '0') == '1'
         self.side = torch.cuda.Stream(device=self.dev) if overlap else None
         self.graphs = [None, None]
         self._attached = False
@@ -153,7 +156,7 @@ class StepGraph(object):
         """model(batch in arenas[parity]) || extract(next batch -> arenas[1-parity]); then finish."""
         cur, nxt = self.arenas[parity], self.arenas[1 - parity]
         main = torch.cuda.current_stream()
-        fused = self.world == 1 and with_finish and B == self.B
+        fused = (not self.dp_path) and with_finish and B == self.B
         if self.side is not None:
             self.side.wait_stream(main)
             with torch.cuda.stream(self.side):
@@ -179,7 +182,7 @@ class StepGraph(object):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self._enqueue(parity, self.B, with_finish=self.world == 1)
+            self._enqueue(parity, self.B, with_finish=not self.dp_path)
         self.graphs[parity] = g
 
     def step(self, B=None):
@@ -196,7 +199,7 @@ class StepGraph(object):
                 self._capture(parity)     # capturing does not execute: nothing is skipped or repeated
             if self.graphs[parity] is not None:
                 self.graphs[parity].replay()
-                if self.world > 1:
+                if self.dp_path:
                     self._finish(self.arenas[parity])
             else:
                 self._enqueue(parity, B)

@@ -201,3 +201,36 @@ def test_main_script_end_to_end(tmp_path):
     float(lines[-1].split(' ')[-1])                      # summarize_fdy.py:25-26 parses the last token
     assert (res / 'model_checkpoint2.pth').exists() and (res / 'optimizer_checkpoint2.pth').exists()
     assert (res / 'cmd_input.txt').exists()
+
+
+def test_step_graph_paths_agree(flix, monkeypatch):
+    """The captured single-GPU step (igmc_train_step inside a hipGraph, prefetch on a second stream), the eager
+    step, and the multi-GPU launch structure (graph up to the gradients + eager all-reduce slot + step_finish)
+    must walk the same trajectory."""
+    import torch
+    from igmc_amd.models import IGMC
+    from igmc_amd.stepgraph import StepGraph
+    from igmc_amd.train_eval import FlatAdam
+    tr, te, cv = make_sets(flix, ntr=600)
+    results = {}
+    for name, env, kw in (('graph', {}, {}), ('eager', {}, dict(use_graph=False, overlap=False)),
+                          ('dp_path', {'IGMC_FORCE_DP_PATH': '1'}, {})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        torch.manual_seed(7)
+        model = IGMC(tr, latent_dim=[32, 32, 32, 32], num_relations=len(cv), num_bases=4, regression=True,
+                     adj_dropout=0.2, seed=3).to('cuda')
+        model.reset_parameters()
+        opt = FlatAdam(model, lr=1e-3)
+        sg = StepGraph(model, opt, tr, 50, 0.001, **kw)
+        perm = torch.randperm(len(tr), generator=torch.Generator().manual_seed(5))
+        total, n = sg.run_epoch(perm, 1)
+        total2, _ = sg.run_epoch(perm, 2)
+        torch.cuda.synchronize()
+        results[name] = (model.flat_parameters().detach().cpu().clone(), float(total2.item()), opt.t, model._step)
+        for k in env:
+            monkeypatch.delenv(k)
+    assert results['graph'][2] == 24 and results['graph'][3] == 24
+    for other in ('eager', 'dp_path'):
+        assert torch.allclose(results['graph'][0], results[other][0], rtol=2e-4, atol=2e-6), other
+        assert results['graph'][1] == pytest.approx(results[other][1], rel=1e-4)
