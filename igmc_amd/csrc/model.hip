@@ -160,8 +160,8 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_l0_fwd(BatchDev b, ModelDev m, c
 // between the groups of a wave) and holds its own result.  ax[bb], ay[bb] = features 2t, 2t+1 of A[i][bb].
 template <bool FLAGS, bool TRANS, bool ATTG, int NG = 4>
 __device__ __forceinline__ void gather_row(const BatchDev& b, const float* __restrict__ in, const float* s_att,
-                                           float* my_gatt, const float* __restrict__ Y, int i, int lane,
-                                           float (&ax)[4], float (&ay)[4]) {
+                                           float* my_gatt, const float* __restrict__ Y, int i, int beg, int end,
+                                           int lane, float (&ax)[4], float (&ay)[4]) {
   const int grp = lane >> 4, t = lane & 15;
   const int kbit = TRANS ? 1 : 0;
   (void)grp;
@@ -179,13 +179,28 @@ __device__ __forceinline__ void gather_row(const BatchDev& b, const float* __res
         yy[q] = v.y;
       }
     }
-    const int beg = b.row_ptr[i], end = b.row_ptr[i + 1];
-    for (int c0 = beg + (NG == 4 ? grp * 16 : 0); c0 < end; c0 += 16 * NG) {
+    int c0 = beg + (NG == 4 ? grp * 16 : 0);
+    uint32_t w_next = 0u;
+    int kp_next = 0;
+    {
       const int e = c0 + t;
-      const bool ok = e < end;
-      const uint32_t w = ok ? b.ecr[e] : 0u;
-      int kp = ok ? 1 : 0;
-      if (FLAGS && ok) kp = (b.eflag[e] >> kbit) & 1;
+      if (e < end) {
+        w_next = b.ecr[e];
+        kp_next = FLAGS ? (b.eflag[e] >> kbit) & 1 : 1;
+      }
+    }
+    for (; c0 < end; c0 += 16 * NG) {
+      const uint32_t w = w_next;
+      const int kp = kp_next;
+      {   // prefetch the NEXT chunk's entries: the load overlaps with this chunk's feature-row loads
+        const int e1 = c0 + 16 * NG + t;
+        w_next = 0u;
+        kp_next = 0;
+        if (e1 < end) {
+          w_next = b.ecr[e1];
+          kp_next = FLAGS ? (b.eflag[e1] >> kbit) & 1 : 1;
+        }
+      }
       // broadcast the 16 entries of the chunk and issue ALL their feature-row loads before any use:
       // one memory round trip per chunk instead of four
       uint32_t wk[16];
@@ -277,7 +292,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_gather(BatchDev b, int R, c
   float* my_gatt = s_gatt + (wave * 4 + grp) * R * 4;
   for (int i = blockIdx.x * 4 + wave; i < N; i += gridDim.x * 4) {
     float ax[4], ay[4];
-    gather_row<FLAGS, TRANS, ATTG>(b, in, s_att, my_gatt, Y, i, lane, ax, ay);
+    gather_row<FLAGS, TRANS, ATTG>(b, in, s_att, my_gatt, Y, i, b.row_ptr[i], b.row_ptr[i + 1], lane, ax, ay);
     if (grp == 0) {
 #pragma unroll
       for (int bb = 0; bb < 4; ++bb) {
@@ -456,7 +471,7 @@ __global__ __launch_bounds__(1024) void k_rgcn_layer(BatchDev b, ModelDev m, con
     // ---- phase 1: one row per wave -> LDS tile
     if (i < N) {
       float ax[4], ay[4];
-      gather_row<FLAGS, BWD, BWD>(b, in, s_att, my_gatt, Yl, i, lane, ax, ay);
+      gather_row<FLAGS, BWD, BWD>(b, in, s_att, my_gatt, Yl, i, b.row_ptr[i], b.row_ptr[i + 1], lane, ax, ay);
       if (grp == 0) {
 #pragma unroll
         for (int bb = 0; bb < 4; ++bb) {
@@ -565,9 +580,35 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_layer4(BatchDev b, ModelDev
   for (int tl = seg.j; seg.lo + tl * 16 < seg.hi; tl += seg.nj) {
     const int trow0 = seg.lo + tl * 16;       // first row of the tile (tiles are cut per XCD segment)
     const int i = trow0 + trow;
+    // everything that does not depend on the gather is requested FIRST, so that it is in flight during the
+    // index / feature-row round trips: row bounds, the self row, and the epilogue operands of this thread
+    int beg = 0, end = 0;
+    float2 xs;
+    xs.x = 0.f;
+    xs.y = 0.f;
+    if (i < seg.hi) {
+      beg = b.row_ptr[i];
+      end = b.row_ptr[i + 1];
+      xs = *(const float2*)(in + (size_t)i * 32 + 2 * t);
+    }
+    float epi_x[2] = {0.f, 0.f}, epi_b[2] = {0.f, 0.f};
+    int epi_lab[2] = {9, 9}, epi_g[2] = {0, 0};
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int o = tid + h2 * IGMC_BLOCK;
+      const int ol = (o & 255) >> 2, rr = o & 3;
+      const int orow = trow0 + (ol >> 4) * 4 + rr, n = (o >> 8) * 16 + (ol & 15);
+      if (!BWD) {
+        epi_b[h2] = P[m.off_bias[l] + n];
+      } else if (orow < seg.hi) {
+        epi_lab[h2] = b.node_label[orow];
+        epi_g[h2] = b.node_graph[orow];
+        epi_x[h2] = m.h[l - 1][(size_t)orow * 32 + n];
+      }
+    }
     if (i < seg.hi) {
       float ax[4], ay[4];
-      gather_row<FLAGS, BWD, BWD, 1>(b, in, s_att, my_gatt, Yl, i, lane, ax, ay);
+      gather_row<FLAGS, BWD, BWD, 1>(b, in, s_att, my_gatt, Yl, i, beg, end, lane, ax, ay);
 #pragma unroll
       for (int bb = 0; bb < 4; ++bb) {
         tile[trow * IGMC_TP + bb * 32 + 2 * t] = ax[bb];
@@ -579,7 +620,6 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_layer4(BatchDev b, ModelDev
           *(float2*)(m.gagg[l - 1] + (size_t)i * 128 + bb * 32 + 2 * t) = o;
         }
       }
-      const float2 xs = *(const float2*)(in + (size_t)i * 32 + 2 * t);
       tile[trow * IGMC_TP + 128 + 2 * t] = xs.x;
       tile[trow * IGMC_TP + 128 + 2 * t + 1] = xs.y;
     } else {
@@ -610,13 +650,13 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_layer4(BatchDev b, ModelDev
       if (orow < seg.hi) {
         float v = v0;
         if (!BWD) {
-          v = tanhf(v + P[m.off_bias[l] + n]);
+          v = tanhf(v + epi_b[h2]);
           m.h[l][(size_t)orow * 32 + n] = v;
           if (zero_out) zero_out[(size_t)orow * 32 + n] = 0.f;
         } else {
-          const int lab = b.node_label[orow];
-          if (lab < 2) v += m.gfeat[(size_t)b.node_graph[orow] * m.D + lab * 128 + (l - 1) * 32 + n];
-          const float xv = m.h[l - 1][(size_t)orow * 32 + n];
+          const int lab = epi_lab[h2];
+          if (lab < 2) v += m.gfeat[(size_t)epi_g[h2] * m.D + lab * 128 + (l - 1) * 32 + n];
+          const float xv = epi_x[h2];
           m.dpre[l - 1][(size_t)orow * 32 + n] = v * (1.f - xv * xv);
         }
       }
