@@ -222,6 +222,13 @@ def main(argv=None):
         ckpt_dir = args.transfer if args.transfer else args.res_dir
         checkpoints = [os.path.join(ckpt_dir, 'model_checkpoint%d.pth' % x)
                        for x in range(start_epoch, end_epoch + 1, interval)]
+        missing = [c for c in checkpoints if not os.path.exists(c)]
+        if missing:      # the reference's fixed schedule assumes its default epoch counts (Main.py:437-441)
+            if rank == 0:
+                print('ensemble: skipping %d missing checkpoint(s): %s' % (len(missing), ', '.join(map(os.path.basename, missing))))
+            checkpoints = [c for c in checkpoints if os.path.exists(c)]
+            if not checkpoints:
+                raise FileNotFoundError('--ensemble: none of the scheduled checkpoints exist in %s' % ckpt_dir)
         epoch_info = ('transfer {}, '.format(args.transfer) if args.transfer else '') + \
             'ensemble of range({}, {}, {})'.format(start_epoch, end_epoch, interval)
         rmse = test_once(test_graphs, model, args.batch_size, logger=None, ensemble=True, checkpoints=checkpoints)
