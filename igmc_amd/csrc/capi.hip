@@ -243,6 +243,11 @@ extern "C" int igmc_batch_create(const igmc_graph* g, int max_graphs, int hop, i
           M.get(&d.row_ptr, node_cap + 1);
   fail |= M.get(&d.ecr, edge_cap) | M.get(&d.ecode, edge_cap) | M.get(&d.eflag, edge_cap);
   fail |= M.get(&d.y, Bc) | M.get(&d.totals, 8);
+  d.relm = nullptr;
+  d.max_rel = g->max_rel;
+  d.relm_ld = (int)((cap_v + 3) & ~(size_t)3);
+  // dense path: rows of the block fit one 256-entry super-chunk and block + row starts fit the default LDS window
+  if (cap_u <= 256 && cap_v <= 256 && cap_u * (size_t)d.relm_ld + slot * 4 <= 60 * 1024) fail |= M.get(&d.relm, (size_t)Bc * cap_u * d.relm_ld);   // dense induced block per link
   fail |= M.get(&d.s_gid, Bc * slot) | M.get(&d.s_lab, Bc * slot) | M.get(&d.s_deg, Bc * slot) |
           M.get(&d.t_list, Bc * slot) | M.get(&d.t_dist, Bc * slot);
   if (fail) {

@@ -66,6 +66,10 @@ struct BatchDev {
   int32_t* s_deg;        // [Bcap * slot]
   int32_t* t_list;       // [Bcap * slot]  BFS discovery order (temporary)
   uint8_t* t_dist;       // [Bcap * slot]
+  uint8_t* relm;         // [Bcap * cap_u * cap_v] dense (user local, item local) -> relation+1 (0 = no edge); NULL when
+                         // the slots are too large (uncapped extraction): then the CSC-scanning kernels are used
+  int relm_ld;           // row stride of relm (cap_v rounded up to 4 so that every block is dword-aligned)
+  int max_rel;           // largest relation id of the rating graph
   int cap_u, cap_v, slot;
   int node_cap, edge_cap, graph_cap;
   int hop, max_nodes_per_hop, num_labels;

@@ -19,7 +19,8 @@
 // no order-dependent writes, so the output is bit-reproducible.
 //
 // Kernels:  k_extract_nodes (BFS + per-hop sampling -> node lists; one workgroup per link)
-//           k_count         (induced degree of every selected node; S workgroups per link)
+//           k_relm + k_emit (capped extraction: dense induced block from the user rows, then CSR emission)
+//           k_count         (uncapped fallback: induced degree of every selected node; S workgroups per link)
 //           k_fill          (batch offsets + dst-sorted CSR of the batch, labels, PyG `batch` vector; S per link)
 //           k_edge_flags    (edge dropout keep flags, reference models.py:193-198)
 #include "launch.h"
@@ -278,6 +279,11 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_extract_nodes(ExtractArgs a) {
     a.b.n_items[g] = cv;
     a.b.edge_cnt[g] = 0;
   }
+  if (a.b.relm) {      // clear this link's dense (user, item) -> relation block (only the cu x cap_v part is used)
+    uint32_t* rm = (uint32_t*)(a.b.relm + (size_t)g * a.b.cap_u * a.b.relm_ld);
+    const int nw = (cu * a.b.relm_ld) >> 2;
+    for (int i = tid; i < nw; i += IGMC_BLOCK) rm[i] = 0u;
+  }
 }
 
 
@@ -462,6 +468,182 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_fill(GraphDev G, BatchDev b) {
   }
 }
 
+// ================================================================ dense-block path (capped extraction)
+// With a per-hop cap the induced block Arow[u_nodes][:, v_nodes] is at most ~(1+h*cap)^2 entries (101 x 101 for
+// ml_1m): it is materialised ONCE as a dense byte matrix relm[u_local][v_local] = relation+1 from the selected
+// USERS' CSR rows only.  Degrees, item rows and the relation-sorted order all come from that matrix, so the
+// long CSC columns of popular items (thousands of entries, ~4/5 of the traversal work of the generic kernels)
+// are never scanned.  Everything stays atomic-free on data => bit-reproducible.
+
+// kernel 2d: fill relm from the selected users' rows; counts the (undirected) edges of the link
+__global__ __launch_bounds__(IGMC_BLOCK) void k_relm(GraphDev G, BatchDev b) {
+  IGMC_DYN_SMEM(smem);
+  __shared__ int sm[16];
+  const int g = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Wu = (G.n_users + 31) >> 5, Wv = (G.n_items + 31) >> 5;
+  uint32_t* sel_u = (uint32_t*)smem;
+  uint32_t* sel_v = sel_u + Wu;
+  uint32_t* pre_v = sel_v + Wv;
+  const int cap_u = b.cap_u, cap_v = b.cap_v;
+  const size_t so = (size_t)g * b.slot;
+  const int32_t* sg = b.s_gid + so;
+  const int cu = b.n_users[g], cv = b.n_items[g];
+  const int v0 = sg[cap_u];
+  const int ld = b.relm_ld;
+  uint8_t* rm = b.relm + (size_t)g * cap_u * ld;
+  rebuild_sel(sg, cap_u, cu, cv, sel_u, Wu, sel_v, Wv);
+  bm_prefix(sel_v, pre_v, Wv, sm);
+  __syncthreads();                        // pre_v is read across waves below
+  const int stride = gridDim.y * (IGMC_BLOCK / 64);
+  int etot = 0;
+  for (int li = blockIdx.y * (IGMC_BLOCK / 64) + wave; li < cu; li += stride) {
+    const int id = sg[li];
+    const int beg = G.u_ptr[id], end = G.u_ptr[id + 1];
+    int c = 0;
+    for (int p0 = beg; p0 < end; p0 += 256) {
+      int j[4], rl[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int p = p0 + q * 64 + lane;
+        const bool valid = p < end;
+        j[q] = valid ? G.u_idx[p] : -1;
+        rl[q] = valid ? (int)G.u_rel[p] : 0;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (j[q] < 0) continue;
+        const bool m = (j[q] == v0) ? (li != 0) : bm_test(sel_v, j[q]);
+        if (m) {
+          const int lv = (j[q] == v0) ? 0 : 1 + bm_rank(sel_v, pre_v, j[q]);
+          rm[(size_t)li * ld + lv] = (uint8_t)(rl[q] + 1);
+          ++c;
+        }
+      }
+    }
+    c = igmc_wave_sum_i(c);
+    if (lane == 0) etot += c;
+  }
+  if (lane == 0 && etot) atomicAdd(&b.edge_cnt[g], 2 * etot);   // directed edges; integer => order-independent
+}
+
+// kernel 3d: batch offsets, degrees, row pointers and the relation-sorted CSR, all from relm
+__global__ __launch_bounds__(IGMC_BLOCK) void k_emit(BatchDev b) {
+  IGMC_DYN_SMEM(smem);
+  __shared__ int sm[16];
+  const int g = blockIdx.x, B = gridDim.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int nb = 0, eb = 0, totn = 0, tote = 0;
+  for (int base = 0; base < B; base += IGMC_BLOCK) {
+    const int i = base + tid;
+    const int n = (i < B) ? b.n_users[i] + b.n_items[i] : 0;
+    const int e = (i < B) ? b.edge_cnt[i] : 0;
+    nb += igmc_block_sum_i(i < g ? n : 0, sm);
+    eb += igmc_block_sum_i(i < g ? e : 0, sm);
+    totn += igmc_block_sum_i(n, sm);
+    tote += igmc_block_sum_i(e, sm);
+  }
+  const int ovf = (totn > b.node_cap) || (tote > b.edge_cap);
+  if (blockIdx.y == 0 && tid == 0) {
+    b.node_off[g] = nb;
+    b.edge_off[g] = eb;
+    if (g == 0) {
+      b.node_off[B] = totn;
+      b.edge_off[B] = tote;
+      b.totals[0] = ovf ? 0 : totn;
+      b.totals[1] = ovf ? 0 : tote;
+      b.totals[2] = ovf;
+      b.totals[3] = B;
+      b.totals[4] = totn;
+      b.totals[5] = tote;
+      if (!ovf) b.row_ptr[totn] = tote;
+    }
+  }
+  if (ovf) return;
+  const int cap_u = b.cap_u;
+  const size_t so = (size_t)g * b.slot;
+  const int32_t* sg = b.s_gid + so;
+  const uint8_t* sl = b.s_lab + so;
+  const int cu = b.n_users[g], cv = b.n_items[g];
+  const int ld = b.relm_ld, ldw = ld >> 2;
+  const int L = b.num_labels, nn = cu + cv;
+  int* rstart = (int*)smem;                              // [slot] CSR row starts of this graph
+  uint32_t* rmw = (uint32_t*)(rstart + b.slot);          // [cu * ld / 4] the dense block, staged in LDS
+  const uint8_t* rm = (const uint8_t*)rmw;
+  {
+    const uint32_t* src = (const uint32_t*)(b.relm + (size_t)g * cap_u * ld);
+    const int nw = cu * ldw;
+    for (int i = tid; i < nw; i += IGMC_BLOCK) rmw[i] = src[i];
+  }
+  __syncthreads();
+  // ---- degrees (one thread per row / column), row pointers
+  int running = 0;
+  for (int base = 0; base < nn; base += IGMC_BLOCK) {
+    const int n = base + tid;
+    int deg = 0;
+    if (n < cu) {
+      for (int k = 0; k < ldw; ++k) {                    // bytes beyond cv are zero
+        const uint32_t w = rmw[n * ldw + k];
+        deg += ((w & 0xffu) != 0) + ((w & 0xff00u) != 0) + ((w & 0xff0000u) != 0) + ((w >> 24) != 0);
+      }
+    } else if (n < nn) {
+      const int vl = n - cu;
+      for (int u = 0; u < cu; ++u) deg += rm[u * ld + vl] != 0;
+    }
+    int tot;
+    const int ex = igmc_block_scan_excl(deg, &tot, sm);
+    if (n < nn) {
+      const int rs = eb + running + ex;
+      rstart[n] = rs;
+      if (blockIdx.y == 0) {
+        const int s = (n < cu) ? n : cap_u + (n - cu);
+        b.row_ptr[nb + n] = rs;
+        b.node_label[nb + n] = sl[s];
+        b.node_gid[nb + n] = sg[s];
+        b.node_graph[nb + n] = g;
+      }
+    }
+    running += tot;
+  }
+  __syncthreads();
+  // ---- emission: a row's bytes are read once (<= 4 per lane), then one ballot-compaction pass per relation
+  const int stride = gridDim.y * (IGMC_BLOCK / 64);
+  const int R = b.max_rel + 1;
+  for (int r = blockIdx.y * (IGMC_BLOCK / 64) + wave; r < nn; r += stride) {
+    const bool is_u = r < cu;
+    const int len = is_u ? cv : cu;                 // neighbours live on the other side (len <= 256, see launcher)
+    const int nbase = is_u ? nb + cu : nb;
+    const int sbase = is_u ? cap_u : 0;
+    int o = rstart[r];
+    int val[4], lab[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = q * 64 + lane;
+      val[q] = 0;
+      lab[q] = 0;
+      if (k < len) {
+        val[q] = is_u ? rm[r * ld + k] : rm[k * ld + (r - cu)];
+        if (val[q]) lab[q] = sl[sbase + k];
+      }
+    }
+    for (int rel = 0; rel < R; ++rel) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q * 64 >= len) break;
+        const bool mt = val[q] == rel + 1;
+        const unsigned long long bal = __ballot(mt);
+        if (mt) {
+          const int pos = o + __popcll(bal & ((1ull << lane) - 1ull));
+          b.ecr[pos] = (uint32_t)(nbase + q * 64 + lane) | ((uint32_t)rel << 24);
+          b.ecode[pos] = (uint16_t)(rel * L + lab[q]);
+          b.eflag[pos] = 3;
+        }
+        o += __popcll(bal);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- edge dropout flags
 // reference models.py:193-198 -> PyG dropout_adj: independent Bernoulli(1-p) per DIRECTED edge
 // (shared by the two directions when force_undirected).  16 lanes per CSR row.
@@ -515,8 +697,14 @@ void igmc_launch_extract(const GraphDev& g, const BatchDev& b, const int32_t* li
   int S = 2048 / (B > 0 ? B : 1);
   S = S < 1 ? 1 : (S > 16 ? 16 : S);
   IGMC_PLAUNCH("k_extract_nodes", k_extract_nodes, B, IGMC_BLOCK, smem, stream, a);
-  IGMC_PLAUNCH("k_count", k_count, dim3(B, S), IGMC_BLOCK, smem / 4, stream, g, b);
-  IGMC_PLAUNCH("k_fill", k_fill, dim3(B, S), IGMC_BLOCK, smem / 2, stream, g, b);
+  if (b.relm) {      // capped extraction (igmc_batch_create decides)
+    const size_t Wu = (g.n_users + 31) >> 5, Wv = (g.n_items + 31) >> 5;
+    IGMC_PLAUNCH("k_relm", k_relm, dim3(B, S), IGMC_BLOCK, (Wu + 2 * Wv) * sizeof(uint32_t), stream, g, b);
+    IGMC_PLAUNCH("k_emit", k_emit, dim3(B, S), IGMC_BLOCK, (size_t)b.slot * sizeof(int) + (size_t)b.cap_u * b.relm_ld, stream, b);
+  } else {
+    IGMC_PLAUNCH("k_count", k_count, dim3(B, S), IGMC_BLOCK, smem / 4, stream, g, b);
+    IGMC_PLAUNCH("k_fill", k_fill, dim3(B, S), IGMC_BLOCK, smem / 2, stream, g, b);
+  }
 }
 
 void igmc_launch_edge_flags(const BatchDev& b, float p, int force_undirected, uint64_t seed, uint64_t step,
