@@ -241,7 +241,8 @@ extern "C" int igmc_batch_create(const igmc_graph* g, int max_graphs, int hop, i
           M.get(&d.edge_off, Bc + 1);
   fail |= M.get(&d.node_label, node_cap) | M.get(&d.node_gid, node_cap) | M.get(&d.node_graph, node_cap) |
           M.get(&d.row_ptr, node_cap + 1);
-  fail |= M.get(&d.ecr, edge_cap) | M.get(&d.ecode, edge_cap) | M.get(&d.eflag, edge_cap);
+  fail |= M.get(&d.ecr, edge_cap) | M.get(&d.ecode, edge_cap) | M.get(&d.eflag, edge_cap) |
+          M.get(&d.edst, edge_cap);
   fail |= M.get(&d.y, Bc) | M.get(&d.totals, 8);
   d.relm = nullptr;
   d.max_rel = g->max_rel;
@@ -472,6 +473,12 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   fail |= M.get(&d.feat, Bc * d.D) | M.get(&d.a1, Bc * 128) | M.get(&d.lmask, Bc * 128) | M.get(&d.dz, Bc * 128) |
           M.get(&d.gfeat, Bc * d.D) | M.get(&d.err, Bc) | M.get(&d.cnt0, N * d.R * d.L);
   const size_t rows0 = (size_t)d.R * d.L + d.L + 1;
+  // relation-space gradient tables of the one-workgroup-per-subgraph path (graphstep.hip), R <= 5 only
+  d.ts_part = nullptr;
+  d.ts_raw = nullptr;
+  d.ts_stride = (d.R * 32 + 33) * 32;
+  if (d.R <= 5)
+    fail |= M.get(&d.ts_part, (size_t)4 * IGMC_WG_BLOCKS * d.ts_stride) | M.get(&d.ts_raw, (size_t)4 * d.ts_stride);
   fail |= M.get(&d.wg_part, (size_t)4 * IGMC_WG_BLOCKS * igmc_wg_stride()) |
           M.get(&d.gatt_part, (size_t)3 * IGMC_GATHER_BLOCKS * d.R * 4) |
           M.get(&d.l0_part, (size_t)IGMC_L0_BLOCKS * rows0 * 32) |

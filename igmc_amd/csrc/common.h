@@ -9,6 +9,7 @@
 #define IGMC_LAUNCH(kern, grid, block, shmem, stream, ...) \
   hipemu::launch(dim3(grid), dim3(block), (size_t)(shmem), [=]() { kern(__VA_ARGS__); })
 #define IGMC_WAVE_SYNC() igmc_emu_wave_sync()
+#define IGMC_GROUP16_SYNC() ((void)__shfl(0, 0, 16))
 typedef igmc_f32x4 f32x4;
 #else
 #include <hip/hip_runtime.h>
@@ -23,6 +24,8 @@ typedef igmc_f32x4 f32x4;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
   } while (0)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// ordering point for LDS traffic between lanes of one 16-lane group (same wave: a fence is enough)
+#define IGMC_GROUP16_SYNC() IGMC_WAVE_SYNC()
 #endif
 
 #include "../../include/igmc_hip.h"
@@ -57,6 +60,7 @@ struct BatchDev {
   int32_t* row_ptr;      // [Ncap+1] dst-sorted CSR over all nodes of the batch
   uint32_t* ecr;         // [Ecap]   source node (batch-global index, 24 bits) | relation id << 24
   uint16_t* ecode;       // [Ecap]   relation * num_labels + label(source)  (layer-0 table index)
+  uint16_t* edst;        // [Ecap]   destination row of the entry, local to its subgraph (flat per-edge passes)
   uint8_t* eflag;        // [Ecap]   bit0: edge col->row kept, bit1: edge row->col kept
   float* y;              // [Bcap]
   int32_t* totals;       // [8]: 0 N, 1 E, 2 overflow flag, 3 B

@@ -460,6 +460,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_fill(GraphDev G, BatchDev b) {
           const int ln = (j[q] == t0) ? 0 : 1 + bm_rank(sel, pre, j[q]);
           b.ecr[pos] = (uint32_t)(nbase + ln) | ((uint32_t)rl[q] << 24);
           b.ecode[pos] = (uint16_t)(rl[q] * L + (int)sl[sbase + ln]);
+          b.edst[pos] = (uint16_t)r;
           b.eflag[pos] = 3;
         }
         o += __popcll(bal);
@@ -636,6 +637,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_emit(BatchDev b) {
           const int pos = o + __popcll(bal & ((1ull << lane) - 1ull));
           b.ecr[pos] = (uint32_t)(nbase + q * 64 + lane) | ((uint32_t)rel << 24);
           b.ecode[pos] = (uint16_t)(rel * L + lab[q]);
+          b.edst[pos] = (uint16_t)r;
           b.eflag[pos] = 3;
         }
         o += __popcll(bal);

@@ -48,6 +48,26 @@ void igmc_launch_finish(const ModelDev& m, const BatchDev& b, float* p, const fl
                         float step_size, float inv_sqrt_bc2, float beta1, float beta2, float eps, float wd,
                         int64_t* ctrl, float ARR, float* loss, double* total, void* stream);
 
+// graphstep.hip: one workgroup per enclosing subgraph (LDS-resident layers)
+struct GsLayout {      // LDS plan, offsets in 4-byte words
+  int nmax, rlp;
+  int xa, xb, zrow, tile, hs, att, t0, cnt, rp, lab, deg, order, sched, relp, wreg, head, words;
+};
+struct GsArgs {
+  const uint8_t* inj_mask;
+  uint64_t seed, step;
+  float mult, grad_scale;
+  float* out;
+  int timing;
+  GsLayout lay;
+};
+int igmc_gs_eligible(const ModelDev& m, const BatchDev& b, GsLayout* lay);
+int igmc_gs_grid(int B);
+void igmc_launch_graph_step(const ModelDev& m, const BatchDev& b, const float* P, int B, int training, int use_flags,
+                            const GsLayout& lay, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
+                            float grad_scale, float* out, void* stream);
+int igmc_gs_prepare();
+
 // ---- per-kernel timing (HIP events on the launch stream; bench.py's roofline leg) ----
 void igmc_prof_begin(const char* name, void* stream);
 void igmc_prof_end(void* stream);

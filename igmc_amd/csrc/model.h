@@ -31,9 +31,46 @@ struct ModelDev {
   float* gatt_part;   // [3][IGMC_GATHER_BLOCKS][R*4]
   float* l0_part;     // [IGMC_L0_BLOCKS][(R*L+L+1)*32]
   float* graw;        // [3][32*160+32] + [3][R*4] + l0 rows: reduced partials
+  float* ts_part;     // [4][IGMC_WG_BLOCKS][ts_stride] relation-space tables [W_r rows | root rows | bias] per layer (or NULL)
+  float* ts_raw;      // [4][ts_stride] their sum over the workgroups
+  int ts_stride;      // (R*32 + 33) * 32
   float* arr_part;    // [4] ARR regulariser per layer
   const float* side;  // [B,S] borrowed side features or NULL
   const int64_t* ctrl;  // optional device-side step control (igmc_hip.h) or NULL
 };
 
 static inline int igmc_wg_stride() { return 32 * IGMC_KCAT + 32; }
+
+// ---- small device-side reductions shared by model.hip / graphstep.hip
+__device__ __forceinline__ float igmc_wave_sum_f(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+// sum over the 16 lanes of a DPP row (= one 16-lane group), result in every lane of the row.
+// On gfx950 this is four VALU adds with the row_ror DPP modifier (no LDS-crossbar round trips).
+__device__ __forceinline__ float igmc_group16_sum_f(float v) {
+#ifdef IGMC_HIPEMU
+#pragma unroll
+  for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d, 16);
+  return v;
+#else
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
+  return v;
+#endif
+}
+__device__ __forceinline__ float igmc_block_sum_f(float v, float* sm) {
+  v = igmc_wave_sum_f(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sm[wave] = v;
+  __syncthreads();
+  float tot = 0.f;
+  const int nw = (blockDim.x + 63) >> 6;
+  for (int w = 0; w < nw; ++w) tot += sm[w];
+  __syncthreads();
+  return tot;
+}
+

@@ -25,38 +25,6 @@
 #include <stdlib.h>
 #define IGMC_LAYER_MODE_DEFAULT 2
 
-__device__ __forceinline__ float igmc_wave_sum_f(float v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
-}
-// sum over the 16 lanes of a DPP row (= one 16-lane group), result in every lane of the row.
-// On gfx950 this is four VALU adds with the row_ror DPP modifier (no LDS-crossbar round trips).
-__device__ __forceinline__ float igmc_group16_sum_f(float v) {
-#ifdef IGMC_HIPEMU
-#pragma unroll
-  for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d, 16);
-  return v;
-#else
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
-  return v;
-#endif
-}
-__device__ __forceinline__ float igmc_block_sum_f(float v, float* sm) {
-  v = igmc_wave_sum_f(v);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) sm[wave] = v;
-  __syncthreads();
-  float tot = 0.f;
-  const int nw = (blockDim.x + 63) >> 6;
-  for (int w = 0; w < nw; ++w) tot += sm[w];
-  __syncthreads();
-  return tot;
-}
-
 // ---- XCD affinity -------------------------------------------------------------------------------------
 // MI355X has 8 XCDs with private, mutually non-coherent 4 MiB L2s, and workgroup b of a launch runs on XCD
 // b % 8 (observed placement; used for SPEED only, never for correctness).  Subgraphs are independent: a row of
@@ -1351,7 +1319,8 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_wgrad_head(BatchDev b, ModelDev 
 // graw layout: [3][5152] conv1..3 (32x160 + 32) | [3][R*4] d att | [(R*L+L+1)*32] layer-0 table
 // Sections A (weight-gradient partials) and C (layer-0 tables): 64 outputs x 4 partial-slices per block;
 // section B (d att, few outputs x many partials): one wave per output.  Fixed summation order.
-__global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_partials(ModelDev m, int n_gatt_parts, int l0_mfma) {
+__global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_partials(ModelDev m, int n_gatt_parts, int l0_mfma,
+                                                                  int n_wg_parts) {
   __shared__ float sred[4][64];
   const int wgs = 32 * IGMC_KCAT + 32, na = m.R * 4, rows0 = m.R * m.L + m.L + 1, n0 = rows0 * 32;
   const int nlay = l0_mfma ? 4 : 3;
@@ -1367,7 +1336,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_partials(ModelDev m, int 
       if (secA) {
         const int l = o / wgs, i = o % wgs;
         const float* p = m.wg_part + (size_t)l * IGMC_WG_BLOCKS * wgs + i;
-        for (int k = wave; k < IGMC_WG_BLOCKS; k += 4) s += p[(size_t)k * wgs];
+        for (int k = wave; k < n_wg_parts; k += 4) s += p[(size_t)k * wgs];
       } else {
         const float* p = m.l0_part + o;
         for (int k = wave; k < IGMC_L0_BLOCKS; k += 4) s += p[(size_t)k * n0];
@@ -1397,6 +1366,25 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_partials(ModelDev m, int 
       if (lane == 0) m.graw[3 * wgs + o] = s;
     }
   }
+}
+
+// relation-space tables of graphstep.hip: ts_raw[l][i] = sum over the workgroups' partials (fixed order);
+// 64 outputs per block, the 4 waves split the partial slices
+__global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_ts(ModelDev m, int nparts) {
+  __shared__ float sred[4][64];
+  const int ts = m.ts_stride, rows0 = m.R * m.L + m.L + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int o = blockIdx.x * 64 + lane;
+  const int l = o / ts, i = o % ts;
+  float s = 0.f;
+  const bool ok = l < 4 && (l > 0 || i < rows0 * 32);
+  if (ok) {
+    const float* p = m.ts_part + (size_t)l * IGMC_WG_BLOCKS * ts + i;
+    for (int k = wave; k < nparts; k += 4) s += p[(size_t)k * ts];
+  }
+  sred[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && ok) m.ts_raw[o] = (sred[0][lane] + sred[1][lane]) + (sred[2][lane] + sred[3][lane]);
 }
 
 struct FinishArgs {
@@ -1473,8 +1461,10 @@ struct AdamTail {
 //   D[r] = W[r+1]-W[r] = sum_b d[r,b] basis[b],  d[r] = att[r+1]-att[r]
 //   reg = sum_r d[r]^T Gm d[r],  dreg/dW[r] = 2(D[r-1]-D[r]) = sum_b c[r,b] basis[b],  c[r] = 2(d[r-1]-d[r])
 //   d att[r,b] += ARR * sum_b' c[r,b'] Gm[b',b];   d basis[b] += ARR * sum_b' (sum_r att[r,b] c[r,b']) basis[b']
+// ts_mode: every layer's gradient arrives as a relation-space table [R*fin + fin + 1][32] (graphstep.hip) and takes
+// the table branch below (fin = L for layer 0, 32 for the conv layers 1..3).
 __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize(ModelDev m, const float* P, float* __restrict__ grad,
-                                                           float arr_coef, AdamTail at) {
+                                                           float arr_coef, AdamTail at, int ts_mode) {
   __shared__ float smf[8];
   __shared__ float sG[16], sM[16];
   __shared__ int s_last;
@@ -1505,7 +1495,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize(ModelDev m, const float
   const float* att = P + m.off_att[l];
   float* gb = grad + m.off_basis[l];
   float* ga = grad + m.off_att[l];
-  if (l >= 1) {
+  if (l >= 1 && !ts_mode) {
     const float* raw = m.graw + (size_t)(l - 1) * wgs;
     for (int e = tid; e < 4 * 1024; e += IGMC_BLOCK) {
       const int bb = e >> 10, f = (e >> 5) & 31, fo = e & 31;
@@ -1516,15 +1506,16 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize(ModelDev m, const float
     const float* rawa = m.graw + 3 * wgs + (size_t)(l - 1) * na;
     for (int i = tid; i < na; i += IGMC_BLOCK) ga[i] = rawa[i];
   } else {
-    const float* t0 = m.graw + 3 * wgs + 3 * na;     // [R*L + L + 1][32]
+    // [R*fin + fin + 1][32]: rows r*fin + c = d W[r][c], then d root[c], then d bias
+    const float* t0 = ts_mode ? m.ts_raw + (size_t)l * m.ts_stride : m.graw + 3 * wgs + 3 * na;
     for (int e = tid; e < 4 * nE; e += IGMC_BLOCK) {   // d basis0[b][c][f] = sum_r att[r,b] GW0[r*L+c][f]
       const int bb = e / nE, cf = e % nE;
       float s = 0.f;
       for (int r = 0; r < m.R; ++r) s += att[r * 4 + bb] * t0[(size_t)r * nE + cf];
       gb[e] = s;
     }
-    for (int e = tid; e < nE; e += IGMC_BLOCK) grad[m.off_root[0] + e] = t0[(size_t)m.R * nE + e];
-    if (tid < 32) grad[m.off_bias[0] + tid] = t0[(size_t)(m.R * m.L + m.L) * 32 + tid];
+    for (int e = tid; e < nE; e += IGMC_BLOCK) grad[m.off_root[l] + e] = t0[(size_t)m.R * nE + e];
+    if (tid < 32) grad[m.off_bias[l] + tid] = t0[(size_t)(m.R * fin + fin) * 32 + tid];
     for (int rb = wave; rb < na; rb += IGMC_BLOCK / 64) {   // d att0[r,b] = <GW0[r], basis0[b]>, one wave each
       const int r = rb >> 2, bb = rb & 3;
       float s = 0.f;
@@ -1737,6 +1728,13 @@ static inline void igmc_edge(void* ev, void* from, void* to) {
 void igmc_launch_forward(const ModelDev& m, const ModelAux& ax, const BatchDev& b, const float* P, int B, int training,
                          int use_flags, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
                          float* out, void* stream) {
+  {
+    GsLayout lay;
+    if (!training && igmc_layer_mode() == 2 && igmc_gs_eligible(m, b, &lay)) {   // one workgroup per subgraph
+      igmc_launch_graph_step(m, b, P, B, 0, use_flags, lay, nullptr, seed, step, mult, 0.f, out, stream);
+      return;
+    }
+  }
   const size_t l0s = (size_t)(m.R * m.L * 32 + m.L * 32 + 32) * sizeof(float) + (size_t)4 * m.R * m.L * sizeof(int);
   const int g16 = igmc_xcd_grid(m, B, 4, IGMC_GATHER_BLOCKS);   // one wave per row, 4 rows per block
   const int g64 = igmc_rows_grid(m.node_cap, 64, 512);
@@ -1847,12 +1845,13 @@ void igmc_launch_backward(const ModelDev& m, const ModelAux& ax, const BatchDev&
   {
     const int wgs2 = igmc_wg_stride(), n0 = rows0 * 32;
     const int nblk = ((l0_mfma ? 4 : 3) * wgs2 + 63) / 64 + (l0_mfma ? 0 : (n0 + 63) / 64) + (3 * na + 3) / 4;
-    IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk, IGMC_BLOCK, 0, stream, m, mode == 0 ? g16 : gt, l0_mfma);
+    IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk, IGMC_BLOCK, 0, stream, m, mode == 0 ? g16 : gt, l0_mfma,
+                 IGMC_WG_BLOCKS);
   }
   {
     AdamTail none;
     memset(&none, 0, sizeof(none));
-    IGMC_PLAUNCH("k_finalize", k_finalize, 4, IGMC_BLOCK, 0, stream, m, P, grad, arr_coef, none);
+    IGMC_PLAUNCH("k_finalize", k_finalize, 4, IGMC_BLOCK, 0, stream, m, P, grad, arr_coef, none, 0);
   }
 }
 
@@ -1879,6 +1878,25 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
                          at.ctrl, ARR, at.loss, at.total, stream);
     } else if (loss) {
       igmc_launch_loss(m, b, ARR, loss, stream);
+    }
+    return;
+  }
+  GsLayout lay;
+  if (l0_mfma && igmc_gs_eligible(m, b, &lay)) {
+    // one workgroup per subgraph: forward, residual and backward down to the per-workgroup gradient partials
+    const int gg = igmc_gs_grid(B);
+    igmc_launch_graph_step(m, b, P, B, 1, use_flags, lay, inj_mask, seed, step, mult, grad_scale, out, stream);
+    IGMC_PLAUNCH("k_wgrad_head", k_wgrad_head, dim3(8 * ny, 1), IGMC_BLOCK, 0, stream, b, m, (const float*)P,
+                 (const float*)nullptr, 1, grad_scale, mult, 2.f, grad, 0);
+    IGMC_PLAUNCH("k_reduce_ts", k_reduce_ts, (4 * m.ts_stride + 63) / 64, IGMC_BLOCK, 0, stream, m, gg);
+    if (adam) {
+      at.enabled = 1;
+      at.b = b;
+      at.ARR = ARR;
+      IGMC_PLAUNCH("k_finalize_adam", k_finalize, 4 + 32, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 1);
+    } else {
+      IGMC_PLAUNCH("k_finalize", k_finalize, 4, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 1);
+      if (loss) igmc_launch_loss(m, b, ARR, loss, stream);
     }
     return;
   }
@@ -1912,15 +1930,15 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
   {
     const int wgs2 = igmc_wg_stride(), n0 = rows0 * 32, na = m.R * 4;
     const int nblk = (nsl * wgs2 + 63) / 64 + (l0_mfma ? 0 : (n0 + 63) / 64) + (3 * na + 3) / 4;
-    IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk, IGMC_BLOCK, 0, stream, m, gt, l0_mfma);
+    IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk, IGMC_BLOCK, 0, stream, m, gt, l0_mfma, IGMC_WG_BLOCKS);
   }
   if (adam) {
     at.enabled = 1;
     at.b = b;
     at.ARR = ARR;
-    IGMC_PLAUNCH("k_finalize_adam", k_finalize, 4 + 32, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at);
+    IGMC_PLAUNCH("k_finalize_adam", k_finalize, 4 + 32, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 0);
   } else {
-    IGMC_PLAUNCH("k_finalize", k_finalize, 4, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at);
+    IGMC_PLAUNCH("k_finalize", k_finalize, 4, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 0);
     if (loss) igmc_launch_loss(m, b, ARR, loss, stream);
   }
 }
@@ -1990,5 +2008,5 @@ int igmc_model_prepare(const ModelDev& m) {
   }
 #endif
   (void)m;
-  return 0;
+  return igmc_gs_prepare();
 }

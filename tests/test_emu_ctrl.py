@@ -23,7 +23,9 @@ def ctrl_words(step, first, epoch, adam_t, batch, lr=1e-3, b1=0.9, b2=0.999, eps
     return w
 
 
-def test_ctrl_path_equals_host_argument_path():
+@pytest.mark.parametrize('graph_step', ['0', '1'])
+def test_ctrl_path_equals_host_argument_path(monkeypatch, graph_step):
+    monkeypatch.setenv('IGMC_GRAPH_STEP', graph_step)     # per-layer kernels / one workgroup per subgraph
     be = PC.EmuBackend()
     lib = be.lib
     case = CASES['synth_cap']

@@ -15,8 +15,18 @@ def be():
     return PC.EmuBackend()
 
 
+@pytest.fixture(autouse=True)
+def _graph_step_path(monkeypatch):
+    # capped cases go through the opt-in one-workgroup-per-subgraph kernel (graphstep.hip); uncapped ones are not
+    # eligible for it and keep exercising the per-layer kernels
+    monkeypatch.setenv('IGMC_GRAPH_STEP', '1')
+
+
 def sub(name, n):
+    name, _, cap = name.partition(':')       # 'case:cap' = the case's graph and links with another per-hop cap
     case = dict(CASES[name])
+    if cap:
+        case['mnph'] = int(cap)
     case['recs'], case['links'], case['link_labels'] = case['recs'][:n], case['links'][:n], case['link_labels'][:n]
     return case
 
@@ -26,6 +36,11 @@ def sub(name, n):
     ('flixster', 5, 10, False, 1.0),       # 10 relations
     ('yahoo_music', 4, 71, True, 20.0),    # 71 relations (shared layer-0 table path), multiply_by
     ('hand_h2', 5, 5, True, 1.0),          # 2 hops -> 6 node labels
+    # capped subgraphs: the one-workgroup-per-subgraph kernel (graphstep.hip)
+    ('synth_cap', 6, 5, True, 1.0),
+    ('douban_cap20', 5, 5, False, 2.0),
+    ('hand', 5, 5, True, 1.0),
+    ('synth_nocap:45', 3, 5, True, 1.0),   # up to 92 nodes: two 64-row passes per layer
 ])
 def test_forward_backward_parity(be, name, n, R, drop, mult):
     res = PC.run_model_parity(be, sub(name, n), R=R, use_dropout=drop, multiply_by=mult)

@@ -23,8 +23,18 @@ def be():
     return PC.GpuBackend()
 
 
+@pytest.fixture(autouse=True)
+def _graph_step_path(monkeypatch):
+    # capped cases go through the opt-in one-workgroup-per-subgraph kernel (graphstep.hip); uncapped ones are not
+    # eligible for it and keep exercising the per-layer kernels
+    monkeypatch.setenv('IGMC_GRAPH_STEP', '1')
+
+
 def sub(name, n):
+    name, _, cap = name.partition(':')       # 'case:cap' = the case's graph and links with another per-hop cap
     case = dict(CASES[name])
+    if cap:
+        case['mnph'] = int(cap)
     case['recs'], case['links'], case['link_labels'] = case['recs'][:n], case['links'][:n], case['link_labels'][:n]
     return case
 
@@ -65,9 +75,23 @@ def test_sampler_free_run(be, name):
     ('yahoo_music', 48, 71, True, 20.0),
     ('hand_h2', 5, 5, True, 1.0),
     ('flixster_h2', 6, 10, False, 1.0),
+    # capped subgraphs: the one-workgroup-per-subgraph kernel (graphstep.hip)
+    ('synth_cap', 16, 5, True, 1.0),
+    ('douban_cap20', 24, 5, False, 2.0),
+    ('hand', 5, 5, True, 1.0),
+    ('synth_nocap:45', 16, 5, True, 1.0),      # two 64-row passes per layer
+    ('synth_nocap:100', 16, 5, True, 1.0),     # up to 202 nodes (the ml_1m shape): four passes
+    ('douban:100', 24, 5, False, 1.0),
 ])
 def test_model_forward_backward_parity(be, name, n, R, drop, mult):
     res = PC.run_model_parity(be, sub(name, n), R=R, use_dropout=drop, multiply_by=mult)
+    assert res['worst_grad_err'] < 2e-3
+
+
+@pytest.mark.parametrize('name,n,R,drop', [('synth_cap', 16, 5, True), ('synth_nocap:100', 16, 5, False)])
+def test_capped_cases_per_layer_kernels(be, monkeypatch, name, n, R, drop):
+    monkeypatch.setenv('IGMC_GRAPH_STEP', '0')        # the default path also on batches the graph kernel could take
+    res = PC.run_model_parity(be, sub(name, n), R=R, use_dropout=drop)
     assert res['worst_grad_err'] < 2e-3
 
 

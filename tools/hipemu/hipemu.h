@@ -69,12 +69,12 @@ constexpr size_t STACK = 256 * 1024;
 struct WaveState {
   int active = 0, arrived = 0;
   unsigned gen = 0;
-  // sub-wave groups (width 16 / 32 collectives rendezvous only inside their group, as on
+  // sub-wave groups (width 4 / 8 / 16 / 32 collectives rendezvous only inside their group, as on
   // hardware where a group-uniform branch keeps the whole group active together)
-  int g_arrived[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-  unsigned g_gen[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-  // exchange slots for collectives: [class 0: w16, 1: w32, 2: w64][double buffer][lane]
-  uint64_t slot[3][2][WAVE];
+  int g_arrived[4][16] = {};
+  unsigned g_gen[4][16] = {};
+  // exchange slots for collectives: [class 0: w4, 1: w8, 2: w16, 3: w32, 4: w64][double buffer][lane]
+  uint64_t slot[5][2][WAVE];
   uint64_t part[2] = {0, 0};   // lanes that took part in the current / previous full-wave exchange
   float fa[WAVE], fb[WAVE], fc[WAVE][4];
 };
@@ -241,12 +241,12 @@ inline const uint64_t* wave_exchange(uint64_t v, int width = WAVE) {
     int buf = w.gen & 1;
     if (w.arrived == 0) w.part[buf] = 0;
     w.part[buf] |= (1ull << lane);
-    w.slot[2][buf][lane] = v;
+    w.slot[4][buf][lane] = v;
     wave_rendezvous();
-    return w.slot[2][buf];
+    return w.slot[4][buf];
   }
-  if (width != 16 && width != 32) { fprintf(stderr, "hipemu: unsupported shuffle width %d\n", width); abort(); }
-  const int cls = (width == 16) ? 0 : 1;
+  if (width != 4 && width != 8 && width != 16 && width != 32) { fprintf(stderr, "hipemu: unsupported shuffle width %d\n", width); abort(); }
+  const int cls = (width == 4) ? 0 : (width == 8) ? 1 : (width == 16) ? 2 : 3;
   const int grp = lane / width;
   unsigned gen = w.g_gen[cls][grp];
   int buf = gen & 1;
