@@ -113,6 +113,8 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    if os.environ.get('IGMC_LIB_PATH'):                # debug hook: time an experimental build of the library
+        _lib.LIB_PATH = os.environ['IGMC_LIB_PATH']
     lib = _lib.load()                                  # fails loudly without the gfx950 library
 
     # ---- workload (identical on every rank)

@@ -243,6 +243,8 @@ extern "C" int igmc_batch_create(const igmc_graph* g, int max_graphs, int hop, i
           M.get(&d.row_ptr, node_cap + 1);
   fail |= M.get(&d.ecr, edge_cap) | M.get(&d.ecode, edge_cap) | M.get(&d.eflag, edge_cap) |
           M.get(&d.edst, edge_cap);
+  d.slot_cap = node_cap + edge_cap / 8 + 16 * (int64_t)Bc;      // >= sum of igmc_row_slots + per-graph padding
+  fail |= M.get(&d.slot_tab, d.slot_cap) | M.get(&d.slot_off, Bc + 1) | M.get(&d.slot_cnt, Bc);
   fail |= M.get(&d.y, Bc) | M.get(&d.totals, 8);
   d.relm = nullptr;
   d.max_rel = g->max_rel;

@@ -576,6 +576,9 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_layer4(BatchDev b, ModelDev
     }
     if (i < seg.hi) {
       float ax[4], ay[4];
+#ifdef IGMC_EXP_CAPROW
+      if (end > beg + IGMC_EXP_CAPROW) end = beg + IGMC_EXP_CAPROW;      // timing experiment only (wrong results)
+#endif
       gather_row<FLAGS, BWD, BWD, 1>(b, in, s_att, my_gatt, Yl, i, beg, end, lane, ax, ay);
 #pragma unroll
       for (int bb = 0; bb < 4; ++bb) {
@@ -616,6 +619,166 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_layer4(BatchDev b, ModelDev
       const float v0 = red[(0 * 2 + ont) * 256 + idx] + red[(1 * 2 + ont) * 256 + idx];
       const int orow = trow0 + (ol >> 4) * 4 + rr, n = ont * 16 + (ol & 15);
       if (orow < seg.hi) {
+        float v = v0;
+        if (!BWD) {
+          v = tanhf(v + epi_b[h2]);
+          m.h[l][(size_t)orow * 32 + n] = v;
+          if (zero_out) zero_out[(size_t)orow * 32 + n] = 0.f;
+        } else {
+          const int lab = epi_lab[h2];
+          if (lab < 2) v += m.gfeat[(size_t)epi_g[h2] * m.D + lab * 128 + (l - 1) * 32 + n];
+          const float xv = epi_x[h2];
+          m.dpre[l - 1][(size_t)orow * 32 + n] = v * (1.f - xv * xv);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (BWD) {
+    float* gp = m.gatt_part + ((size_t)(l - 1) * IGMC_GATHER_BLOCKS + blockIdx.x) * R * 4;
+    for (int i = tid; i < R * 4; i += IGMC_BLOCK) {
+      float sacc = 0.f;
+      for (int g = 0; g < 16; ++g) sacc += s_gatt[g * R * 4 + i];
+      gp[i] = sacc;
+    }
+  }
+}
+
+// Edge-balanced variant (IGMC_LAYER_MODE=3, opt-in): the 16 tile slots are row SEGMENTS of at most 16 entries (slot table of the
+// batch, built by k_slots), so every 16-lane group does exactly one chunk of gather work per tile -- the 2 us per
+// extra sequential chunk of the ~100-entry rows (profiles/: 23.7 us -> 11.5 us with rows cut at 16 entries) is
+// gone.  The segments of a row sit in consecutive slots of the SAME tile; they are summed in LDS before the MFMA
+// phase, and only the row's first slot takes part in the epilogue.
+__device__ __forceinline__ XcdSeg igmc_xcd_slot_segment(const BatchDev& b) {
+  XcdSeg s;
+  const int B = b.totals[3];
+  const int x = blockIdx.x & 7;
+  s.j = blockIdx.x >> 3;
+  s.nj = (gridDim.x + 7 - x) >> 3;
+  s.lo = b.slot_off[(x * B) >> 3];
+  s.hi = b.slot_off[((x + 1) * B) >> 3];
+  return s;
+}
+
+template <bool FLAGS, bool BWD>
+__global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_layer_s(BatchDev b, ModelDev m, const float* __restrict__ P, int l,
+                                                              float* __restrict__ zero_out) {
+  IGMC_DYN_SMEM(smem);
+  const int R = m.R;
+  float* tile = (float*)smem;               // [16][IGMC_TP]
+  float* red = tile + 16 * IGMC_TP;         // [2 k-slices][2 col tiles][64 lanes * 4]
+  float* s_att = red + 1024;                // [R][4]
+  float* s_gatt = s_att + R * 4;            // BWD: [16 groups][R*4]
+  const float* __restrict__ in = BWD ? m.dpre[l] : m.h[l - 1];
+  const float* __restrict__ Yl = BWD ? m.Y[l - 1] : nullptr;
+  const float* att = P + m.off_att[l];
+  const float* basis = P + m.off_basis[l];
+  const float* root = P + m.off_root[l];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = lane >> 4, t = lane & 15;
+  const int li = lane & 15, kq = lane >> 4;
+  for (int i = tid; i < R * 4; i += IGMC_BLOCK) s_att[i] = att[i];
+  if (BWD)
+    for (int i = tid; i < 16 * R * 4; i += IGMC_BLOCK) s_gatt[i] = 0.f;
+  const int nt = wave & 1, ks = wave >> 1;
+  float bw[20];
+#pragma unroll
+  for (int j = 0; j < 20; ++j) {
+    const int k = ks * 80 + 4 * j + kq, n = nt * 16 + li;
+    if (!BWD) bw[j] = basis[k * 32 + n];
+    else bw[j] = (k < 128) ? basis[((k >> 5) * 32 + n) * 32 + (k & 31)] : root[n * 32 + (k - 128)];
+  }
+  __syncthreads();
+  const int trow = wave * 4 + grp;            // slot of the tile owned by this 16-lane group
+  float* my_gatt = s_gatt + trow * R * 4;
+  const XcdSeg seg = igmc_xcd_slot_segment(b);
+  for (int tl = seg.j; seg.lo + tl * 16 < seg.hi; tl += seg.nj) {
+    const int base = seg.lo + tl * 16;        // first slot of the tile
+    const uint32_t ent = b.slot_tab[base + trow];
+    const bool live = ent != IGMC_SLOT_EMPTY;
+    const int i = (int)(ent & 0xFFFFFFu), sg = (int)((ent >> 24) & 15u), nseg = (int)(ent >> 28) + 1;
+    // everything that does not depend on the gather is requested FIRST: row bounds, the self row and the epilogue
+    // operands of this thread's two outputs
+    int beg = 0, end = 0;
+    float2 xs;
+    xs.x = 0.f;
+    xs.y = 0.f;
+    if (live) {
+      const int rb = b.row_ptr[i], re = b.row_ptr[i + 1];
+      beg = rb + sg * IGMC_SEG;
+      end = (sg == 15 || beg + IGMC_SEG > re) ? re : beg + IGMC_SEG;
+      if (sg == 0) xs = *(const float2*)(in + (size_t)i * 32 + 2 * t);
+    }
+    float epi_x[2] = {0.f, 0.f}, epi_b[2] = {0.f, 0.f};
+    int epi_lab[2] = {9, 9}, epi_g[2] = {0, 0}, epi_row[2] = {-1, -1};
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int o = tid + h2 * IGMC_BLOCK;
+      const int ol = (o & 255) >> 2, rr = o & 3;
+      const int srow = (ol >> 4) * 4 + rr, n = (o >> 8) * 16 + (ol & 15);
+      const uint32_t e2 = b.slot_tab[base + srow];
+      if (e2 != IGMC_SLOT_EMPTY && ((e2 >> 24) & 15u) == 0u) {
+        const int orow = (int)(e2 & 0xFFFFFFu);
+        epi_row[h2] = orow;
+        if (BWD) {
+          epi_lab[h2] = b.node_label[orow];
+          epi_g[h2] = b.node_graph[orow];
+          epi_x[h2] = m.h[l - 1][(size_t)orow * 32 + n];
+        }
+      }
+      if (!BWD) epi_b[h2] = P[m.off_bias[l] + n];
+    }
+    {
+      float ax[4] = {0.f, 0.f, 0.f, 0.f}, ay[4] = {0.f, 0.f, 0.f, 0.f};
+      if (live) gather_row<FLAGS, BWD, BWD, 1>(b, in, s_att, my_gatt, Yl, i, beg, end, lane, ax, ay);
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        tile[trow * IGMC_TP + bb * 32 + 2 * t] = ax[bb];
+        tile[trow * IGMC_TP + bb * 32 + 2 * t + 1] = ay[bb];
+      }
+      tile[trow * IGMC_TP + 128 + 2 * t] = xs.x;
+      tile[trow * IGMC_TP + 128 + 2 * t + 1] = xs.y;
+    }
+    __syncthreads();
+    // the first slot of a row adds the row's other segments (same tile), and in the backward pass writes the
+    // basis-space row the weight gradient needs
+    if (live && sg == 0) {
+      float2 a2[4];
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) a2[bb] = *(const float2*)(tile + trow * IGMC_TP + bb * 32 + 2 * t);
+      for (int k = 1; k < nseg; ++k) {
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+          const float2 v = *(const float2*)(tile + (trow + k) * IGMC_TP + bb * 32 + 2 * t);
+          a2[bb].x += v.x;
+          a2[bb].y += v.y;
+        }
+      }
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        if (nseg > 1) *(float2*)(tile + trow * IGMC_TP + bb * 32 + 2 * t) = a2[bb];
+        if (BWD) *(float2*)(m.gagg[l - 1] + (size_t)i * 128 + bb * 32 + 2 * t) = a2[bb];
+      }
+    }
+    __syncthreads();
+    {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 20; ++j) {
+        const float a = tile[li * IGMC_TP + ks * 80 + 4 * j + kq];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[j], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) red[(ks * 2 + nt) * 256 + lane * 4 + rr] = acc[rr];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int o = tid + h2 * IGMC_BLOCK;
+      const int ont = o >> 8, idx = o & 255, ol = idx >> 2;
+      const float v0 = red[(0 * 2 + ont) * 256 + idx] + red[(1 * 2 + ont) * 256 + idx];
+      const int orow = epi_row[h2], n = ont * 16 + (ol & 15);
+      if (orow >= 0) {
         float v = v0;
         if (!BWD) {
           v = tanhf(v + epi_b[h2]);
@@ -1689,14 +1852,11 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_adam(float* __restrict__ p, cons
 // =================================================================== host launch sequences
 #include "launch.h"
 
-// R-GCN layer formulation: 0 = gather kernel + dense kernel, 1 = fused (16 waves / tile), 2 = fused (4 waves / tile)
-static int igmc_layer_mode() {
-  static int mode = -1;
-  if (mode < 0) {
-    const char* e = getenv("IGMC_LAYER_MODE");
-    mode = e ? atoi(e) : IGMC_LAYER_MODE_DEFAULT;
-  }
-  return mode;
+// R-GCN layer formulation: 0 = gather kernel + dense kernel, 1 = fused (16 waves / tile), 2 = fused (4 waves / tile),
+// 3 = fused, tiles of row segments (edge-balanced; measured slower: one more dependent hop and 2x the tiles)
+int igmc_layer_mode() {
+  const char* e = getenv("IGMC_LAYER_MODE");        // read on every call: tests switch it per case
+  return e ? atoi(e) : IGMC_LAYER_MODE_DEFAULT;
 }
 
 // grid for row-parallel kernels: enough workgroups for the capacity, capped, and a multiple of 8 (>= 8) so
@@ -1719,6 +1879,20 @@ static inline int igmc_xcd_grid(const ModelDev& m, int B, int rows_per_block, in
   return (int)(g < 8 ? 8 : g);
 }
 
+// grid for the slot-tile kernels: 8 x (tiles of the largest XCD segment, estimated at 2.25 slots per node; a
+// larger batch just makes the workgroups loop)
+static inline int igmc_slot_grid(const ModelDev& m, int B, int max_blocks) {
+  const int slot = (m.node_cap + m.graph_cap - 1) / m.graph_cap;
+  const long tiles_per_graph = ((long)slot * 9 / 4 + 15) / 16;
+  long g = 8 * (long)((B + 7) / 8) * tiles_per_graph;
+  {
+    const char* e = getenv("IGMC_SLOT_GRID");       // tuning hook
+    if (e && atoi(e) >= 8) g = atoi(e) & ~7;
+  }
+  if (g > max_blocks) g = max_blocks & ~7;
+  return (int)(g < 8 ? 8 : g);
+}
+
 // fork: `to` waits for everything enqueued on `from` so far (an event edge; a graph edge under capture)
 static inline void igmc_edge(void* ev, void* from, void* to) {
   hipEventRecord((hipEvent_t)ev, (hipStream_t)from);
@@ -1730,7 +1904,7 @@ void igmc_launch_forward(const ModelDev& m, const ModelAux& ax, const BatchDev& 
                          float* out, void* stream) {
   {
     GsLayout lay;
-    if (!training && igmc_layer_mode() == 2 && igmc_gs_eligible(m, b, &lay)) {   // one workgroup per subgraph
+    if (!training && igmc_layer_mode() >= 2 && igmc_gs_eligible(m, b, &lay)) {   // one workgroup per subgraph
       igmc_launch_graph_step(m, b, P, B, 0, use_flags, lay, nullptr, seed, step, mult, 0.f, out, stream);
       return;
     }
@@ -1761,6 +1935,10 @@ void igmc_launch_forward(const ModelDev& m, const ModelAux& ax, const BatchDev& 
     } else if (mode == 2) {
       if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer4<true, false>), gt, IGMC_BLOCK, fsm4, stream, b, m, P, l, zo);
       else IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer4<false, false>), gt, IGMC_BLOCK, fsm4, stream, b, m, P, l, zo);
+    } else if (mode == 3) {
+      const int gs3 = igmc_slot_grid(m, B, 2048);
+      if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer_s<true, false>), gs3, IGMC_BLOCK, fsm4, stream, b, m, P, l, zo);
+      else IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer_s<false, false>), gs3, IGMC_BLOCK, fsm4, stream, b, m, P, l, zo);
     } else {
       if (use_flags)
         IGMC_PLAUNCH("k_rgcn_gather_fwd", (k_rgcn_gather<true, false, false>), g16, IGMC_BLOCK, gs, stream, b, m.R,
@@ -1824,6 +2002,10 @@ void igmc_launch_backward(const ModelDev& m, const ModelAux& ax, const BatchDev&
     } else if (mode == 2) {
       if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer4<true, true>), gt, IGMC_BLOCK, bsm4, stream, b, m, P, l, (float*)nullptr);
       else IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer4<false, true>), gt, IGMC_BLOCK, bsm4, stream, b, m, P, l, (float*)nullptr);
+    } else if (mode == 3) {
+      const int gs3 = igmc_slot_grid(m, B, 2048);
+      if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer_s<true, true>), gs3, IGMC_BLOCK, bsm4, stream, b, m, P, l, (float*)nullptr);
+      else IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer_s<false, true>), gs3, IGMC_BLOCK, bsm4, stream, b, m, P, l, (float*)nullptr);
     } else {
       float* gp = m.gatt_part + (size_t)(l - 1) * IGMC_GATHER_BLOCKS * na;
       if (use_flags)
@@ -1845,8 +2027,8 @@ void igmc_launch_backward(const ModelDev& m, const ModelAux& ax, const BatchDev&
   {
     const int wgs2 = igmc_wg_stride(), n0 = rows0 * 32;
     const int nblk = ((l0_mfma ? 4 : 3) * wgs2 + 63) / 64 + (l0_mfma ? 0 : (n0 + 63) / 64) + (3 * na + 3) / 4;
-    IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk, IGMC_BLOCK, 0, stream, m, mode == 0 ? g16 : gt, l0_mfma,
-                 IGMC_WG_BLOCKS);
+    IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk, IGMC_BLOCK, 0, stream, m,
+                 mode == 0 ? g16 : (mode == 3 ? igmc_slot_grid(m, B, 2048) : gt), l0_mfma, IGMC_WG_BLOCKS);
   }
   {
     AdamTail none;
@@ -1866,7 +2048,8 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
   const int gy = igmc_rows_grid(m.node_cap, 128, 512);
   const int hb = (B + 15) / 16;
   const int ny = (m.D / 16 + 3) / 4;
-  const bool fast_head = (m.D % 16 == 0) && igmc_layer_mode() == 2 && 8 * ny <= IGMC_WG_BLOCKS;
+  const int lmode = igmc_layer_mode();
+  const bool fast_head = (m.D % 16 == 0) && (lmode == 2 || lmode == 3) && 8 * ny <= IGMC_WG_BLOCKS;
   AdamTail at;
   memset(&at, 0, sizeof(at));
   if (adam) at = *adam;
@@ -1907,17 +2090,28 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
   else IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<false, true>), g16, IGMC_BLOCK, l0s, stream, b, m, (const float*)P, m.h[0]);
   const size_t fsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4) * sizeof(float);
   const size_t bsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4 + 16 * m.R * 4) * sizeof(float);
+  const int gl = (lmode == 3) ? igmc_slot_grid(m, B, 2048) : gt;      // grid of the layer kernels
   for (int l = 1; l < 4; ++l) {
     float* zo = (l == 3) ? m.dpre[3] : nullptr;
-    if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer4<true, false>), gt, IGMC_BLOCK, fsm4, stream, b, m, (const float*)P, l, zo);
-    else IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer4<false, false>), gt, IGMC_BLOCK, fsm4, stream, b, m, (const float*)P, l, zo);
+    if (lmode == 3) {
+      if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer_s<true, false>), gl, IGMC_BLOCK, fsm4, stream, b, m, (const float*)P, l, zo);
+      else IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer_s<false, false>), gl, IGMC_BLOCK, fsm4, stream, b, m, (const float*)P, l, zo);
+    } else {
+      if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer4<true, false>), gt, IGMC_BLOCK, fsm4, stream, b, m, (const float*)P, l, zo);
+      else IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer4<false, false>), gt, IGMC_BLOCK, fsm4, stream, b, m, (const float*)P, l, zo);
+    }
   }
   const size_t ysz = (size_t)32 * (128 + 4) * sizeof(float);
   IGMC_PLAUNCH("k_head_train", k_head_train, dim3(hb > gy ? hb : gy, 4), 512, ysz, stream, b, m, (const float*)P, inj_mask,
                seed, step, mult, grad_scale, out);
   for (int l = 3; l >= 1; --l) {
-    if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer4<true, true>), gt, IGMC_BLOCK, bsm4, stream, b, m, (const float*)P, l, (float*)nullptr);
-    else IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer4<false, true>), gt, IGMC_BLOCK, bsm4, stream, b, m, (const float*)P, l, (float*)nullptr);
+    if (lmode == 3) {
+      if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer_s<true, true>), gl, IGMC_BLOCK, bsm4, stream, b, m, (const float*)P, l, (float*)nullptr);
+      else IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer_s<false, true>), gl, IGMC_BLOCK, bsm4, stream, b, m, (const float*)P, l, (float*)nullptr);
+    } else {
+      if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer4<true, true>), gt, IGMC_BLOCK, bsm4, stream, b, m, (const float*)P, l, (float*)nullptr);
+      else IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer4<false, true>), gt, IGMC_BLOCK, bsm4, stream, b, m, (const float*)P, l, (float*)nullptr);
+    }
   }
   const int nsl = l0_mfma ? 4 : 3;
   IGMC_PLAUNCH("k_wgrad_head", k_wgrad_head, dim3(IGMC_WG_BLOCKS, nsl + 1), IGMC_BLOCK, 0, stream, b, m, (const float*)P,
@@ -1930,7 +2124,7 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
   {
     const int wgs2 = igmc_wg_stride(), n0 = rows0 * 32, na = m.R * 4;
     const int nblk = (nsl * wgs2 + 63) / 64 + (l0_mfma ? 0 : (n0 + 63) / 64) + (3 * na + 3) / 4;
-    IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk, IGMC_BLOCK, 0, stream, m, gt, l0_mfma, IGMC_WG_BLOCKS);
+    IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk, IGMC_BLOCK, 0, stream, m, gl, l0_mfma, IGMC_WG_BLOCKS);
   }
   if (adam) {
     at.enabled = 1;

@@ -95,6 +95,14 @@ def test_capped_cases_per_layer_kernels(be, monkeypatch, name, n, R, drop):
     assert res['worst_grad_err'] < 2e-3
 
 
+@pytest.mark.parametrize('mode', ['0', '1', '3'])
+def test_layer_kernel_variants(be, monkeypatch, mode):
+    monkeypatch.setenv('IGMC_LAYER_MODE', mode)
+    monkeypatch.setenv('IGMC_GRAPH_STEP', '0')
+    res = PC.run_model_parity(be, sub('synth_nocap:100', 16), R=5, use_dropout=True)
+    assert res['worst_grad_err'] < 2e-3
+
+
 @pytest.mark.parametrize('n_side', [48, 10])
 def test_side_features(be, n_side):
     res = PC.run_model_parity(be, sub('flixster', 40), R=10, use_dropout=True, n_side=n_side)
