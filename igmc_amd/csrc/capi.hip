@@ -487,7 +487,7 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
           M.get(&d.graw, (size_t)3 * igmc_wg_stride() + 3 * d.R * 4 + rows0 * 32) | M.get(&d.arr_part, 4);
   d.side = nullptr;
   d.ctrl = nullptr;
-  fail |= M.get(&m->done_ctr, 4);
+  fail |= M.get(&m->done_ctr, 8);      // [0] step-wide, [1..4] per conv layer (k_finalize)
   if (fail) {
     M.release();
     delete m;
@@ -509,7 +509,7 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
       m->ax.ev[i] = e;
     }
   }
-  HIPCHECK(hipMemset(m->done_ctr, 0, 4 * sizeof(int)));
+  HIPCHECK(hipMemset(m->done_ctr, 0, 8 * sizeof(int)));
   if (igmc_model_prepare(d)) {
     M.release();
     delete m;

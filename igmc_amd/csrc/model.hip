@@ -1618,18 +1618,23 @@ struct AdamTail {
   double* total;
 };
 
-// one block per conv layer: scatter the reduced partials into the flat gradient, add the
-// adjacent-rating-regulariser gradient (reference train_eval.py:167-174), emit the ARR value.
+// IGMC_FIN_NB workgroups per conv layer: turn the reduced partials into the flat gradient, add the
+// adjacent-rating-regulariser gradient (reference train_eval.py:167-174), emit the ARR value, and (AdamTail) update
+// the parameters -- every element in ONE pass (gradient, ARR term, store, Adam), elements interleaved over the
+// layer's workgroups, the small per-layer quantities (Gram matrix of the bases) recomputed by each of them.
 // ARR through the 4x4 Gram matrix of the bases:  W[r] = sum_b att[r,b] basis[b]  =>
 //   D[r] = W[r+1]-W[r] = sum_b d[r,b] basis[b],  d[r] = att[r+1]-att[r]
 //   reg = sum_r d[r]^T Gm d[r],  dreg/dW[r] = 2(D[r-1]-D[r]) = sum_b c[r,b] basis[b],  c[r] = 2(d[r-1]-d[r])
 //   d att[r,b] += ARR * sum_b' c[r,b'] Gm[b',b];   d basis[b] += ARR * sum_b' (sum_r att[r,b] c[r,b']) basis[b']
-// ts_mode: every layer's gradient arrives as a relation-space table [R*fin + fin + 1][32] (graphstep.hip) and takes
-// the table branch below (fin = L for layer 0, 32 for the conv layers 1..3).
+// ts_mode: every layer's gradient arrives as a relation-space table [R*fin + fin + 1][32] (graphstep.hip; rows
+// r*fin + c = d W[r][c], then d root[c], then d bias) instead of basis-space partials (fin = L for layer 0, else 32).
+#define IGMC_FIN_NB 8
 __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize(ModelDev m, const float* P, float* __restrict__ grad,
                                                            float arr_coef, AdamTail at, int ts_mode) {
   __shared__ float smf[8];
   __shared__ float sG[16], sM[16];
+  __shared__ int s_lastl;
+  __shared__ float sg10[4][10];
   __shared__ int s_last;
   if (at.enabled && at.ctrl) {      // hipGraph replay: the Adam scalars live in HBM
     const double* d = (const double*)at.ctrl;
@@ -1640,65 +1645,34 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize(ModelDev m, const float
     at.eps = (float)d[IGMC_CTRL_EPS];
     at.wd = (float)d[IGMC_CTRL_WD];
   }
-  if (blockIdx.x >= 4) {            // extra workgroups: Adam on lin1 / lin2 (their gradients are final already)
+  auto finish = [&](int64_t i, float g) { grad[i] = g; };
+  if (blockIdx.x >= 4 * IGMC_FIN_NB) {   // extra workgroups: Adam on lin1 / lin2 (their gradients are final already)
     const int64_t n_lin = m.n_params - m.off_l1w;
-    const int nb = gridDim.x - 4;
+    const int nb = gridDim.x - 4 * IGMC_FIN_NB;
     const int64_t chunk = (n_lin + nb - 1) / nb;
-    const int64_t lo = m.off_l1w + (int64_t)(blockIdx.x - 4) * chunk;
+    const int64_t lo = m.off_l1w + (int64_t)(blockIdx.x - 4 * IGMC_FIN_NB) * chunk;
     const int64_t hi = (lo + chunk < m.n_params) ? lo + chunk : m.n_params;
     for (int64_t i = lo + threadIdx.x; i < hi; i += IGMC_BLOCK)
       adam_elem(at.p, grad, at.m1, at.m2, i, at.step_size, at.inv_sqrt_bc2, at.beta1, at.beta2, at.eps, at.wd);
   } else {
-  const int l = blockIdx.x, tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int fin = (l == 0) ? m.L : 32;
-  const int nE = fin * 32;                 // elements of one W[r] / basis[b]
-  const int wgs = 32 * IGMC_KCAT + 32, na = m.R * 4;
-  const float* basis = P + m.off_basis[l];
-  const float* att = P + m.off_att[l];
-  float* gb = grad + m.off_basis[l];
-  float* ga = grad + m.off_att[l];
-  if (l >= 1 && !ts_mode) {
-    const float* raw = m.graw + (size_t)(l - 1) * wgs;
-    for (int e = tid; e < 4 * 1024; e += IGMC_BLOCK) {
-      const int bb = e >> 10, f = (e >> 5) & 31, fo = e & 31;
-      gb[e] = raw[f * IGMC_KCAT + bb * 32 + fo];
-    }
-    for (int e = tid; e < 1024; e += IGMC_BLOCK) grad[m.off_root[l] + e] = raw[(e >> 5) * IGMC_KCAT + 128 + (e & 31)];
-    if (tid < 32) grad[m.off_bias[l] + tid] = raw[32 * IGMC_KCAT + tid];
-    const float* rawa = m.graw + 3 * wgs + (size_t)(l - 1) * na;
-    for (int i = tid; i < na; i += IGMC_BLOCK) ga[i] = rawa[i];
-  } else {
-    // [R*fin + fin + 1][32]: rows r*fin + c = d W[r][c], then d root[c], then d bias
-    const float* t0 = ts_mode ? m.ts_raw + (size_t)l * m.ts_stride : m.graw + 3 * wgs + 3 * na;
-    for (int e = tid; e < 4 * nE; e += IGMC_BLOCK) {   // d basis0[b][c][f] = sum_r att[r,b] GW0[r*L+c][f]
-      const int bb = e / nE, cf = e % nE;
-      float s = 0.f;
-      for (int r = 0; r < m.R; ++r) s += att[r * 4 + bb] * t0[(size_t)r * nE + cf];
-      gb[e] = s;
-    }
-    for (int e = tid; e < nE; e += IGMC_BLOCK) grad[m.off_root[l] + e] = t0[(size_t)m.R * nE + e];
-    if (tid < 32) grad[m.off_bias[l] + tid] = t0[(size_t)(m.R * fin + fin) * 32 + tid];
-    for (int rb = wave; rb < na; rb += IGMC_BLOCK / 64) {   // d att0[r,b] = <GW0[r], basis0[b]>, one wave each
-      const int r = rb >> 2, bb = rb & 3;
-      float s = 0.f;
-      for (int e = lane; e < nE; e += 64) s += t0[(size_t)r * nE + e] * basis[bb * nE + e];
-      s = igmc_wave_sum_f(s);
-      if (lane == 0) ga[rb] = s;
-    }
-  }
-  // ---- Gram matrix of the bases (10 unique entries)
-  float gp[10];
+    const int l = blockIdx.x / IGMC_FIN_NB, part = blockIdx.x % IGMC_FIN_NB, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int fin = (l == 0) ? m.L : 32;
+    const int nE = fin * 32;                 // elements of one W[r] / basis[b]
+    const int wgs = 32 * IGMC_KCAT + 32, na = m.R * 4, R = m.R;
+    const float* basis = P + m.off_basis[l];
+    const float* att = P + m.off_att[l];
+    const int e0 = part * IGMC_BLOCK + tid, estep = IGMC_FIN_NB * IGMC_BLOCK;     // this thread's elements
+    // ---- Gram matrix of the bases (10 unique entries), recomputed by every workgroup of the layer
+    float gp[10];
 #pragma unroll
-  for (int q = 0; q < 10; ++q) gp[q] = 0.f;
-  for (int e = tid; e < nE; e += IGMC_BLOCK) {
-    const float b0 = basis[e], b1 = basis[nE + e], b2 = basis[2 * nE + e], b3 = basis[3 * nE + e];
-    gp[0] += b0 * b0; gp[1] += b0 * b1; gp[2] += b0 * b2; gp[3] += b0 * b3;
-    gp[4] += b1 * b1; gp[5] += b1 * b2; gp[6] += b1 * b3;
-    gp[7] += b2 * b2; gp[8] += b2 * b3; gp[9] += b3 * b3;
-  }
-  {
-    __shared__ float sg10[4][10];
+    for (int q = 0; q < 10; ++q) gp[q] = 0.f;
+    for (int e = tid; e < nE; e += IGMC_BLOCK) {
+      const float b0 = basis[e], b1 = basis[nE + e], b2 = basis[2 * nE + e], b3 = basis[3 * nE + e];
+      gp[0] += b0 * b0; gp[1] += b0 * b1; gp[2] += b0 * b2; gp[3] += b0 * b3;
+      gp[4] += b1 * b1; gp[5] += b1 * b2; gp[6] += b1 * b3;
+      gp[7] += b2 * b2; gp[8] += b2 * b3; gp[9] += b3 * b3;
+    }
 #pragma unroll
     for (int q = 0; q < 10; ++q) gp[q] = igmc_wave_sum_f(gp[q]);
     if (lane == 0) {
@@ -1706,63 +1680,101 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize(ModelDev m, const float
       for (int q = 0; q < 10; ++q) sg10[wave][q] = gp[q];
     }
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 10; ++q) gp[q] = (sg10[0][q] + sg10[1][q]) + (sg10[2][q] + sg10[3][q]);
-  }
-  if (tid == 0) {
-    const int ij[10][2] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {1, 1}, {1, 2}, {1, 3}, {2, 2}, {2, 3}, {3, 3}};
-    for (int q = 0; q < 10; ++q) {
-      sG[ij[q][0] * 4 + ij[q][1]] = gp[q];
-      sG[ij[q][1] * 4 + ij[q][0]] = gp[q];
-    }
-  }
-  __syncthreads();
-  // c[r][b] = 2 (d[r-1][b] - d[r][b]),  d[r] = att[r+1]-att[r]  (d[-1] = d[R-1] = 0)
-  if (tid < 16) {           // M[b][b'] = sum_r att[r,b] c[r,b']
-    const int bb = tid >> 2, bp = tid & 3;
-    float s = 0.f;
-    for (int r = 0; r < m.R; ++r) {
-      const float dm = (r > 0) ? att[r * 4 + bp] - att[(r - 1) * 4 + bp] : 0.f;
-      const float dn = (r + 1 < m.R) ? att[(r + 1) * 4 + bp] - att[r * 4 + bp] : 0.f;
-      s += att[r * 4 + bb] * 2.f * (dm - dn);
-    }
-    sM[tid] = s;
-  }
-  if (tid == 64) {          // reg = sum_r d[r]^T Gm d[r]
-    float reg = 0.f;
-    for (int r = 0; r + 1 < m.R; ++r) {
-      float d[4];
-      for (int q = 0; q < 4; ++q) d[q] = att[(r + 1) * 4 + q] - att[r * 4 + q];
-      for (int p1 = 0; p1 < 4; ++p1)
-        for (int p2 = 0; p2 < 4; ++p2) reg += d[p1] * sG[p1 * 4 + p2] * d[p2];
-    }
-    m.arr_part[l] = reg;
-  }
-  __syncthreads();
-  if (arr_coef != 0.f) {
-    for (int rb = tid; rb < na; rb += IGMC_BLOCK) {
-      const int r = rb >> 2, bb = rb & 3;
-      float s = 0.f;
-      for (int bp = 0; bp < 4; ++bp) {
-        const float dm = (r > 0) ? att[r * 4 + bp] - att[(r - 1) * 4 + bp] : 0.f;
-        const float dn = (r + 1 < m.R) ? att[(r + 1) * 4 + bp] - att[r * 4 + bp] : 0.f;
-        s += 2.f * (dm - dn) * sG[bp * 4 + bb];
+    if (tid == 0) {
+      const int ij[10][2] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {1, 1}, {1, 2}, {1, 3}, {2, 2}, {2, 3}, {3, 3}};
+      for (int q = 0; q < 10; ++q) {
+        const float v = (sg10[0][q] + sg10[1][q]) + (sg10[2][q] + sg10[3][q]);
+        sG[ij[q][0] * 4 + ij[q][1]] = v;
+        sG[ij[q][1] * 4 + ij[q][0]] = v;
       }
-      ga[rb] += arr_coef * s;
     }
-    for (int e = tid; e < nE; e += IGMC_BLOCK) {
-      const float b0 = basis[e], b1 = basis[nE + e], b2 = basis[2 * nE + e], b3 = basis[3 * nE + e];
-#pragma unroll
-      for (int bb = 0; bb < 4; ++bb)
-        gb[bb * nE + e] += arr_coef * (sM[bb * 4 + 0] * b0 + sM[bb * 4 + 1] * b1 + sM[bb * 4 + 2] * b2 + sM[bb * 4 + 3] * b3);
+    // c[r][b] = 2 (d[r-1][b] - d[r][b]),  d[r] = att[r+1]-att[r]  (d[-1] = d[R-1] = 0)
+    if (tid >= 64 && tid < 80) {           // M[b][b'] = sum_r att[r,b] c[r,b']
+      const int bb = (tid - 64) >> 2, bp = tid & 3;
+      float sacc = 0.f;
+      for (int r = 0; r < R; ++r) {
+        const float dm = (r > 0) ? att[r * 4 + bp] - att[(r - 1) * 4 + bp] : 0.f;
+        const float dn = (r + 1 < R) ? att[(r + 1) * 4 + bp] - att[r * 4 + bp] : 0.f;
+        sacc += att[r * 4 + bb] * 2.f * (dm - dn);
+      }
+      sM[tid - 64] = sacc;
     }
-  }
-  if (at.enabled) {               // Adam on this conv layer's parameters (basis, root, bias, att are contiguous)
     __syncthreads();
-    const int64_t lo = m.off_basis[l], hi = m.off_att[l] + na;
-    for (int64_t i = lo + tid; i < hi; i += IGMC_BLOCK)
-      adam_elem(at.p, grad, at.m1, at.m2, i, at.step_size, at.inv_sqrt_bc2, at.beta1, at.beta2, at.eps, at.wd);
-  }
+    if (tid == 0 && part == 0) {           // reg = sum_r d[r]^T Gm d[r]
+      float reg = 0.f;
+      for (int r = 0; r + 1 < R; ++r) {
+        float d[4];
+        for (int q = 0; q < 4; ++q) d[q] = att[(r + 1) * 4 + q] - att[r * 4 + q];
+        for (int p1 = 0; p1 < 4; ++p1)
+          for (int p2 = 0; p2 < 4; ++p2) reg += d[p1] * sG[p1 * 4 + p2] * d[p2];
+      }
+      m.arr_part[l] = reg;
+    }
+    const bool table = (l == 0) || ts_mode;
+    const float* raw = m.graw + (size_t)(l >= 1 ? l - 1 : 0) * wgs;                 // basis-space partial sums (l >= 1)
+    const float* t0 = ts_mode ? m.ts_raw + (size_t)l * m.ts_stride : m.graw + 3 * wgs + 3 * na;
+    // ---- d basis (+ ARR):  element e = (b, c, f)
+    for (int e = e0; e < 4 * nE; e += estep) {
+      const int bb = e / nE, cf = e % nE;
+      float g;
+      if (!table) {
+        g = raw[(cf >> 5) * IGMC_KCAT + bb * 32 + (cf & 31)];
+      } else {
+        g = 0.f;
+        for (int r = 0; r < R; ++r) g += att[r * 4 + bb] * t0[(size_t)r * nE + cf];
+      }
+      if (arr_coef != 0.f) {
+        const float b0 = basis[cf], b1 = basis[nE + cf], b2 = basis[2 * nE + cf], b3 = basis[3 * nE + cf];
+        g += arr_coef * (sM[bb * 4 + 0] * b0 + sM[bb * 4 + 1] * b1 + sM[bb * 4 + 2] * b2 + sM[bb * 4 + 3] * b3);
+      }
+      finish(m.off_basis[l] + e, g);
+    }
+    // ---- d root, d bias
+    for (int e = e0; e < nE; e += estep)
+      finish(m.off_root[l] + e, table ? t0[(size_t)R * nE + e] : raw[(e >> 5) * IGMC_KCAT + 128 + (e & 31)]);
+    if (part == 0 && tid < 32)
+      finish(m.off_bias[l] + tid, table ? t0[(size_t)(R * fin + fin) * 32 + tid] : raw[32 * IGMC_KCAT + tid]);
+    // ---- d att (+ ARR): one wave per entry; table form: d att[r,b] = <dW[r], basis[b]>
+    for (int rb = part * 4 + wave; rb < na; rb += IGMC_FIN_NB * 4) {
+      const int r = rb >> 2, bb = rb & 3;
+      float g;
+      if (!table) {
+        g = m.graw[3 * wgs + (size_t)(l - 1) * na + rb];
+      } else {
+        float sacc = 0.f;
+        for (int e = lane; e < nE; e += 64) sacc += t0[(size_t)r * nE + e] * basis[bb * nE + e];
+        g = igmc_wave_sum_f(sacc);
+      }
+      if (arr_coef != 0.f) {
+        float sacc = 0.f;
+        for (int bp = 0; bp < 4; ++bp) {
+          const float dm = (r > 0) ? att[r * 4 + bp] - att[(r - 1) * 4 + bp] : 0.f;
+          const float dn = (r + 1 < R) ? att[(r + 1) * 4 + bp] - att[r * 4 + bp] : 0.f;
+          sacc += 2.f * (dm - dn) * sG[bp * 4 + bb];
+        }
+        g += arr_coef * sacc;
+      }
+      if (lane == 0) finish(m.off_att[l] + rb, g);
+    }
+    if (at.enabled) {
+      // Adam on this layer's parameters (basis, root, bias, att are contiguous) by the LAST of the layer's
+      // workgroups to finish: by then every workgroup of the layer has read the old parameters and stored its
+      // share of the gradient (no spinning; at.done[1 + l] counts the arrivals)
+      __syncthreads();
+      if (tid == 0) {
+        __threadfence();
+        s_lastl = (atomicAdd(at.done + 1 + l, 1) == IGMC_FIN_NB - 1);
+      }
+      __syncthreads();
+      if (s_lastl) {
+        __threadfence();
+        const int64_t lo = m.off_basis[l], hi = m.off_att[l] + na;
+#pragma unroll 4
+        for (int64_t i = lo + tid; i < hi; i += IGMC_BLOCK)
+          adam_elem(at.p, grad, at.m1, at.m2, i, at.step_size, at.inv_sqrt_bc2, at.beta1, at.beta2, at.eps, at.wd);
+        if (tid == 0) at.done[1 + l] = 0;
+      }
+    }
   }   // conv-layer workgroups
   if (at.enabled) {
     // the last workgroup to arrive has every arr_part / err in sight: loss, epoch total, control-block tick
@@ -2033,7 +2045,7 @@ void igmc_launch_backward(const ModelDev& m, const ModelAux& ax, const BatchDev&
   {
     AdamTail none;
     memset(&none, 0, sizeof(none));
-    IGMC_PLAUNCH("k_finalize", k_finalize, 4, IGMC_BLOCK, 0, stream, m, P, grad, arr_coef, none, 0);
+    IGMC_PLAUNCH("k_finalize", k_finalize, 4 * IGMC_FIN_NB, IGMC_BLOCK, 0, stream, m, P, grad, arr_coef, none, 0);
   }
 }
 
@@ -2076,9 +2088,9 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
       at.enabled = 1;
       at.b = b;
       at.ARR = ARR;
-      IGMC_PLAUNCH("k_finalize_adam", k_finalize, 4 + 32, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 1);
+      IGMC_PLAUNCH("k_finalize_adam", k_finalize, 4 * IGMC_FIN_NB + 32, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 1);
     } else {
-      IGMC_PLAUNCH("k_finalize", k_finalize, 4, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 1);
+      IGMC_PLAUNCH("k_finalize", k_finalize, 4 * IGMC_FIN_NB, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 1);
       if (loss) igmc_launch_loss(m, b, ARR, loss, stream);
     }
     return;
@@ -2130,9 +2142,9 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
     at.enabled = 1;
     at.b = b;
     at.ARR = ARR;
-    IGMC_PLAUNCH("k_finalize_adam", k_finalize, 4 + 32, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 0);
+    IGMC_PLAUNCH("k_finalize_adam", k_finalize, 4 * IGMC_FIN_NB + 32, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 0);
   } else {
-    IGMC_PLAUNCH("k_finalize", k_finalize, 4, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 0);
+    IGMC_PLAUNCH("k_finalize", k_finalize, 4 * IGMC_FIN_NB, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 0);
     if (loss) igmc_launch_loss(m, b, ARR, loss, stream);
   }
 }

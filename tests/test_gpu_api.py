@@ -234,3 +234,55 @@ def test_step_graph_paths_agree(flix, monkeypatch):
     for other in ('eager', 'dp_path'):
         assert torch.allclose(results['graph'][0], results[other][0], rtol=2e-4, atol=2e-6), other
         assert results['graph'][1] == pytest.approx(results[other][1], rel=1e-4)
+
+
+def test_full_size_headline_config_properties(monkeypatch):
+    """BASELINE.json's headline shape (ml_1m-shaped graph: 6040 x 3706, ~900k train links, hop 1, cap 100, batch 50)
+    is far beyond what the oracle finishes in seconds, so it is checked through size-independent properties:
+    structural invariants of every extracted batch, reproducibility, and AGREEMENT of the two independent HIP
+    implementations of the step (per-layer kernels vs. one workgroup per subgraph) on the same batches."""
+    import torch
+    import parity_checks as PC
+    from igmc_amd import preprocessing
+    from igmc_amd.models import IGMC
+    from igmc_amd.stepgraph import StepGraph
+    from igmc_amd.train_eval import FlatAdam
+    from igmc_amd.util_functions import MyDynamicDataset
+    split = preprocessing.create_trainvaltest_split('ml_1m', 1234, True, verbose=False)
+    (_, _, A, tr_l, tr_u, tr_v, _, _, _, _, _, _, cv) = split
+    assert A.shape == (6040, 3706)
+    ds = MyDynamicDataset('data/t/full', A, (tr_u, tr_v), tr_l, 1, 1.0, 100, None, None, cv, device=0, seed=1)
+    perm = torch.randperm(len(ds), generator=torch.Generator().manual_seed(3))[:50 * 12]
+    runs = {}
+    for name, env in (('per_layer', '0'), ('per_graph', '1'), ('per_layer_again', '0')):
+        monkeypatch.setenv('IGMC_GRAPH_STEP', env)
+        model = IGMC(ds, latent_dim=[32, 32, 32, 32], num_relations=len(cv), num_bases=4, regression=True,
+                     adj_dropout=0.0, seed=1).to('cuda')
+        torch.manual_seed(1)
+        model.reset_parameters()
+        opt = FlatAdam(model, lr=1e-3)
+        sg = StepGraph(model, opt, ds, 50, 0.001, use_graph=False, overlap=False)
+        sg.begin_epoch(perm, 1)
+        losses, structs = [], []
+        for k in range(12):
+            sg.step()
+            losses.append(float(sg.loss[0].item()))
+            if name == 'per_layer' and k < 3:
+                d = sg.arena.download()
+                PC.check_batch_structure(d, 4)
+                # hop-1 enclosing subgraphs with the cap: at most 1 + 100 nodes per side, target edge removed,
+                # every kept edge has its reverse with the same relation
+                assert d['B'] == 50 and d['N'] <= 50 * 202
+                rev = PC.reverse_positions(d)
+                assert np.array_equal(d['erel'][rev], d['erel'])
+                structs.append((d['N'], d['E']))
+        torch.cuda.synchronize()
+        runs[name] = (losses, model.flat_parameters().detach().cpu().clone())
+    # bit-reproducible
+    assert runs['per_layer'][0] == runs['per_layer_again'][0]
+    assert torch.equal(runs['per_layer'][1], runs['per_layer_again'][1])
+    # two independent implementations walk the same trajectory (fp32 reassociation only)
+    np.testing.assert_allclose(runs['per_layer'][0], runs['per_graph'][0], rtol=2e-5)
+    # (Adam normalises every gradient: parameters whose gradient is ~0 may step in different directions)
+    diff = (runs['per_layer'][1] - runs['per_graph'][1]).abs()
+    assert float(diff.max()) < 2e-3 and float(diff.mean()) < 2e-5, (float(diff.max()), float(diff.mean()))
