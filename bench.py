@@ -191,8 +191,14 @@ def main():
             algo_bytes = 133.0 * E + 132.0 * N                  # one layer, one direction
             dur_s = kernels[dom]['us'] * 1e-6
             achieved = algo_bytes / dur_s / 1e9
+            # HBM-side bytes per launch of this kernel: PMC counters cannot be read from inside this process, they come
+            # from the committed rocprofv3 --pmc passes of the same command (tools/profile_round.sh -> pmc_traffic.py)
+            traffic = None
+            tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+            if dom == 'k_rgcn_layer_fwd' and args.config == 'ml_1m' and os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get('traffic_bytes')
             roofline = dict(bound='hbm', kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
-                            frac=achieved / HBM_PEAK_GBS, traffic=None, avg_us=kernels[dom]['us'],
+                            frac=achieved / HBM_PEAK_GBS, traffic=traffic, avg_us=kernels[dom]['us'],
                             algorithmic_bytes=algo_bytes, nodes=N, edges=E,
                             share_of_kernel_time=kernels[dom]['us'] * kernels[dom]['calls_per_step'] * args.profile_steps
                             / (tot * 1e3) if tot > 0 else None)

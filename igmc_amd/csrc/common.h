@@ -36,7 +36,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define IGMC_BLOCK 256
 
 // ------------------------------------------------------------------ device views
-#define IGMC_SEG 16             // entries per row segment
+#define IGMC_SEG 32             // entries per row segment (two gather chunks)
 #define IGMC_SLOT_EMPTY 0xFFFFFFFFu
 // slots owned by a row of `deg` entries: pow2ceil(min(16, max(1, ceil(deg / 16))))
 __host__ __device__ inline int igmc_row_slots(int deg) {
