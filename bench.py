@@ -11,10 +11,11 @@ SURVEY.md 8(d) (6040 x 3706, 1 000 209 ratings, 90/10 split) unless raw_data/ml_
 Weights are random-init (reference init).  Inputs (graph, link arrays) are resident in HBM before timing.
 
 The ONE JSON line printed by rank 0 also carries
-  roofline      : the dominant kernel = the fused R-GCN layer forward (k_rgcn_layer_fwd: edge gather in basis
-                  space + MFMA transform + tanh): algorithmic bytes per launch (133*E + 132*N)
-                  / its average duration measured with HIP events on the launch stream in a separate
-                  instrumented pass of the same steps;
+  roofline      : the dominant kernel = k_graph_step (forward + backward of every subgraph, one workgroup cluster
+                  each; the three conv layers in both directions = 6 x the per-layer gather bytes 133*E + 132*N of
+                  SURVEY.md 8(d)) -- or, for configurations it does not take, the fused forward layer kernel
+                  k_rgcn_layer_fwd (1 x those bytes): algorithmic bytes per launch / its average duration measured
+                  with HIP events on the launch stream in a separate instrumented pass of the same steps;
   cpu_baseline  : the oracle's restatement of the reference CPU path (scipy/python extraction + PyG-1.4.2
                   per-edge-weight formulation in torch, all host cores) on a bounded sample of the same workload.
 """
@@ -166,6 +167,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     value = args.steps * BATCH * world / dt
+    sg.check()                                          # no device-side wait timed out during the timed steps
     final_loss = float(sg.loss[0].item())
 
     # ---- roofline leg: instrumented pass (HIP events around every kernel on the launch stream)
@@ -186,17 +188,22 @@ def main():
         N, E = float(np.mean(Ns)), float(np.mean(Es))
         kernels = {name: dict(us=ms / calls * 1e3, calls_per_step=calls / args.profile_steps) for name, ms, calls in rows}
         tot = sum(ms for _, ms, _ in rows)
-        dom = 'k_rgcn_layer_fwd' if 'k_rgcn_layer_fwd' in kernels else 'k_rgcn_gather_fwd'
+        dom = 'k_graph_step' if 'k_graph_step' in kernels else (
+            'k_rgcn_layer_fwd' if 'k_rgcn_layer_fwd' in kernels else 'k_rgcn_gather_fwd')
         if dom in kernels and args.profile_steps > 0:
             algo_bytes = 133.0 * E + 132.0 * N                  # one layer, one direction
+            if dom == 'k_graph_step':                           # forward + backward of the 3 conv layers in one launch
+                algo_bytes *= 6.0
             dur_s = kernels[dom]['us'] * 1e-6
             achieved = algo_bytes / dur_s / 1e9
             # HBM-side bytes per launch of this kernel: PMC counters cannot be read from inside this process, they come
             # from the committed rocprofv3 --pmc passes of the same command (tools/profile_round.sh -> pmc_traffic.py)
             traffic = None
             tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-            if dom == 'k_rgcn_layer_fwd' and args.config == 'ml_1m' and os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get('traffic_bytes')
+            if args.config == 'ml_1m' and os.path.exists(tpath):
+                trec = json.load(open(tpath))
+                if trec.get('kernel') == dom:
+                    traffic = trec.get('traffic_bytes')
             roofline = dict(bound='hbm', kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
                             frac=achieved / HBM_PEAK_GBS, traffic=traffic, avg_us=kernels[dom]['us'],
                             algorithmic_bytes=algo_bytes, nodes=N, edges=E,

@@ -57,6 +57,7 @@ SIGNATURES = {
     'igmc_step_finish': (i32, [vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp]),
     'igmc_profile_enable': (i32, [i32]),
     'igmc_profile_fetch': (i32, [vp, vp, vp, i32]),
+    'igmc_model_check': (i32, [vp, vp]),
 }
 
 BUF = dict(NODE_OFF=0, N_USERS=1, NODE_LABEL=2, NODE_GID=3, NODE_GRAPH=4, ROW_PTR=5, ECR=6, ECODE=7,

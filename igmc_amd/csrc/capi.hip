@@ -501,7 +501,9 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   d.ts_raw = nullptr;
   d.ts_stride = (d.R * 32 + 33) * 32;
   if (d.R <= 5)
-    fail |= M.get(&d.ts_part, (size_t)4 * IGMC_WG_BLOCKS * d.ts_stride) | M.get(&d.ts_raw, (size_t)4 * d.ts_stride);
+    fail |= M.get(&d.ts_part, (size_t)4 * IGMC_TS_BLOCKS * d.ts_stride) | M.get(&d.ts_raw, (size_t)4 * d.ts_stride);
+  fail |= M.get(&d.gs_bar, 2 * Bc + 1);
+  d.gs_err = d.gs_bar ? d.gs_bar + 2 * Bc : nullptr;
   fail |= M.get(&d.wg_part, (size_t)4 * IGMC_WG_BLOCKS * igmc_wg_stride()) |
           M.get(&d.gatt_part, (size_t)3 * IGMC_GATHER_BLOCKS * d.R * 4) |
           M.get(&d.l0_part, (size_t)IGMC_L0_BLOCKS * rows0 * 32) |
@@ -531,6 +533,7 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
     }
   }
   HIPCHECK(hipMemset(m->done_ctr, 0, 8 * sizeof(int)));
+  HIPCHECK(hipMemset(m->d.gs_bar, 0, (2 * (size_t)max_graphs + 1) * sizeof(int)));
   if (igmc_model_prepare(d)) {
     M.release();
     delete m;
@@ -659,6 +662,20 @@ extern "C" int igmc_batch_set_ctrl(igmc_batch* b, const int64_t* d_ctrl) {
 extern "C" int igmc_model_set_ctrl(igmc_model* m, const int64_t* d_ctrl) {
   if (!m) IGMC_FAIL("null model");
   m->d.ctrl = d_ctrl;
+  return 0;
+}
+extern "C" int igmc_model_check(igmc_model* m, void* stream) {
+  if (!m) IGMC_FAIL("null model");
+  int v = 0;
+  if (m->d.gs_err) {
+    HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+    HIPCHECK(hipMemcpy(&v, m->d.gs_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (v) {
+      HIPCHECK(hipMemset(m->d.gs_bar, 0, (2 * (size_t)m->d.graph_cap + 1) * sizeof(int)));
+      IGMC_FAIL("a workgroup-cluster barrier of k_graph_step timed out (GPU shared with another job?): results of the "
+                "affected steps are invalid; set IGMC_GS_CLUSTER=1 or IGMC_GRAPH_STEP=0");
+    }
+  }
   return 0;
 }
 extern "C" int igmc_adam_step_ctrl(float* d_params, const float* d_grad, float* d_exp_avg, float* d_exp_avg_sq,

@@ -38,7 +38,9 @@
 #define GS_KS (GS_NR * 8 + 8)   // MFMA k-steps of [T | x] @ [W_r ; root]
 #define GS_WN (GS_NR * 2 + 2)   // 16-column tiles of the weight-gradient table
 #define GS_HP 36            // pitch of a wave's 16-row h_{l-1} chunk
-#define GS_SMAX 32          // max bundles (16 rows) per subgraph: nmax <= 512
+#define GS_SMAX 20          // max bundles (16 rows) per subgraph: nmax <= 320
+#define GS_CMAX 4           // max workgroups per subgraph (cluster)
+#define GS_WMAX (GS_NW * GS_CMAX)   // waves of a cluster
 #define GS_INVALID 0xFFFFFFFFu
 // keeps per-lane index arithmetic INSIDE the loop it is used in (LLVM otherwise hoists hundreds of loop-invariant
 // addresses out of the layer / bundle loops and spills them)
@@ -53,9 +55,12 @@ __device__ unsigned long long g_gs_clk[64];
 #ifdef IGMC_HIPEMU
 #define GS_STAMP(k) do { } while (0)
 #define GS_WSTAMP(k) do { } while (0)
+#define GS_CSTAMP(k) do { } while (0)
 #else
 #define GS_STAMP(k) do { if (a.timing && blockIdx.x == 0 && threadIdx.x == 0) g_gs_clk[k] = __builtin_readcyclecounter(); } while (0)
 #define GS_WSTAMP(k) do { if (a.timing && blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_gs_clk[(k) + (threadIdx.x >> 6)] = __builtin_readcyclecounter(); } while (0)
+// member m of the cluster of subgraph 0, event k (0 start, 1 setup done, 2 before / 3 after the first barrier)
+#define GS_CSTAMP(k) do { if (a.timing && a.cs > 1 && blockIdx.x % a.stride == 0 && threadIdx.x == 0) g_gs_clk[40 + (blockIdx.x / a.stride) * 4 + (k)] = __builtin_readcyclecounter(); } while (0)
 #endif
 
 // tanh(x) = 1 - 2 / (1 + e^{2x}) on the transcendental unit (v_exp_f32 + v_rcp_f32): |error| ~1e-7 absolute
@@ -100,13 +105,22 @@ __device__ __forceinline__ const float* gs_rowptr(uint32_t wk, const float* src,
 // (Measured alternatives, all slower on this part with one wave per SIMD: run-change branches in a row-order
 // stream, 16-entry super-chunks with position masks, one OCTET per row with a single ds_read_b128 per edge --
 // the loop is bound by per-slot address arithmetic and dependent-issue latency, not by LDS bandwidth.)
+// One bundle = 16 rows x R relation runs = 16 R work units (any quad may fill any (row, relation) block of the
+// tile).  The units are ranked by run length once per subgraph; round `it` gives quad q the unit of rank
+// 16 it + q, so the 16 quads of a wave -- which advance in lockstep -- always work on runs of similar length and
+// the ~100-entry target rows are spread over R quads instead of serialising one.
 template <bool FLAGS, bool TRANS>
-__device__ __forceinline__ void gs_gather(const BatchDev& b, const float* src, const float* zrow, int nb, float* trow,
-                                          const int* rptr, bool live, int R, int j) {
+__device__ __forceinline__ void gs_gather(const BatchDev& b, const float* src, const float* zrow, int nb, float* tile,
+                                          const int* relp, const int* order, const unsigned char* ulist, int b0, int N,
+                                          int R, int qd, int j) {
 #pragma unroll 1
-  for (int r = 0; r < R; ++r) {
+  for (int it = 0; it < R; ++it) {
+    const int u = ulist[qd + 16 * it];             // units of the bundle by decreasing run length: a round of 16
+    const int slot = u >> 3, r = u & 7;            // quads works on runs of similar length
+    const bool live = b0 + slot < N;
     int beg = 0, end = 0;
     if (live) {
+      const int* rptr = relp + order[b0 + slot] * 8;
       beg = rptr[r];
       end = rptr[r + 1];
     }
@@ -114,48 +128,119 @@ __device__ __forceinline__ void gs_gather(const BatchDev& b, const float* src, c
 #pragma unroll
     for (int f = 0; f < 8; ++f) tx[f] = 0.f;
     if (beg < end) {
-      uint32_t w_cur = gs_entry<FLAGS, TRANS>(b, beg + j, end);
-      uint32_t w_nxt = gs_entry<FLAGS, TRANS>(b, beg + 4 + j, end);
-      float4 xa[4], xb[4];
-      {
-        const float* p0 = gs_rowptr(gs_qbcast<0>(w_cur), src, zrow, nb, j);
-        const float* p1 = gs_rowptr(gs_qbcast<1>(w_cur), src, zrow, nb, j);
-        const float* p2 = gs_rowptr(gs_qbcast<2>(w_cur), src, zrow, nb, j);
-        const float* p3 = gs_rowptr(gs_qbcast<3>(w_cur), src, zrow, nb, j);
-        xa[0] = *(const float4*)p0; xb[0] = *(const float4*)(p0 + 4);
-        xa[1] = *(const float4*)p1; xb[1] = *(const float4*)(p1 + 4);
-        xa[2] = *(const float4*)p2; xb[2] = *(const float4*)(p2 + 4);
-        xa[3] = *(const float4*)p3; xb[3] = *(const float4*)(p3 + 4);
-      }
-#pragma unroll 1
-      for (int c0 = beg; c0 < end; c0 += 4) {
-        const uint32_t w_use = w_nxt;                      // entries of the NEXT group (invalid past the run end)
-        w_nxt = gs_entry<FLAGS, TRANS>(b, c0 + 8 + j, end);
-        float4 ya[4], yb[4];
-        {
-          const float* p0 = gs_rowptr(gs_qbcast<0>(w_use), src, zrow, nb, j);
-          const float* p1 = gs_rowptr(gs_qbcast<1>(w_use), src, zrow, nb, j);
-          const float* p2 = gs_rowptr(gs_qbcast<2>(w_use), src, zrow, nb, j);
-          const float* p3 = gs_rowptr(gs_qbcast<3>(w_use), src, zrow, nb, j);
-          ya[0] = *(const float4*)p0; yb[0] = *(const float4*)(p0 + 4);
-          ya[1] = *(const float4*)p1; yb[1] = *(const float4*)(p1 + 4);
-          ya[2] = *(const float4*)p2; yb[2] = *(const float4*)(p2 + 4);
-          ya[3] = *(const float4*)p3; yb[3] = *(const float4*)(p3 + 4);
-        }
+      // 4 groups of 4 entries per iteration; the entries of group q of the NEXT iteration are requested right after
+      // group q is consumed, i.e. a whole iteration before they are needed (the index loads come from L2 / HBM)
+      uint32_t w[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          tx[0] += xa[k].x; tx[1] += xa[k].y; tx[2] += xa[k].z; tx[3] += xa[k].w;
-          tx[4] += xb[k].x; tx[5] += xb[k].y; tx[6] += xb[k].z; tx[7] += xb[k].w;
-          xa[k] = ya[k];
-          xb[k] = yb[k];
+      for (int q = 0; q < 4; ++q) w[q] = gs_entry<FLAGS, TRANS>(b, beg + 4 * q + j, end);
+#pragma unroll 1
+      for (int c0 = beg; c0 < end; c0 += 16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (c0 + 4 * q < end) {
+            const float* p0 = gs_rowptr(gs_qbcast<0>(w[q]), src, zrow, nb, j);
+            const float* p1 = gs_rowptr(gs_qbcast<1>(w[q]), src, zrow, nb, j);
+            const float* p2 = gs_rowptr(gs_qbcast<2>(w[q]), src, zrow, nb, j);
+            const float* p3 = gs_rowptr(gs_qbcast<3>(w[q]), src, zrow, nb, j);
+            const float4 a0 = *(const float4*)p0, b0v = *(const float4*)(p0 + 4);
+            const float4 a1 = *(const float4*)p1, b1v = *(const float4*)(p1 + 4);
+            const float4 a2 = *(const float4*)p2, b2v = *(const float4*)(p2 + 4);
+            const float4 a3 = *(const float4*)p3, b3v = *(const float4*)(p3 + 4);
+            tx[0] += (a0.x + a1.x) + (a2.x + a3.x); tx[1] += (a0.y + a1.y) + (a2.y + a3.y);
+            tx[2] += (a0.z + a1.z) + (a2.z + a3.z); tx[3] += (a0.w + a1.w) + (a2.w + a3.w);
+            tx[4] += (b0v.x + b1v.x) + (b2v.x + b3v.x); tx[5] += (b0v.y + b1v.y) + (b2v.y + b3v.y);
+            tx[6] += (b0v.z + b1v.z) + (b2v.z + b3v.z); tx[7] += (b0v.w + b1v.w) + (b2v.w + b3v.w);
+          }
+          w[q] = gs_entry<FLAGS, TRANS>(b, c0 + 16 + 4 * q + j, end);
         }
       }
     }
-    if (live) {
-      *(float4*)(trow + r * 32 + 8 * j) = make_float4(tx[0], tx[1], tx[2], tx[3]);
-      *(float4*)(trow + r * 32 + 8 * j + 4) = make_float4(tx[4], tx[5], tx[6], tx[7]);
+    // rows past the end of the subgraph get zeros (they are K entries of the weight-gradient product)
+    *(float4*)(tile + slot * GS_TP + r * 32 + 8 * j) = make_float4(tx[0], tx[1], tx[2], tx[3]);
+    *(float4*)(tile + slot * GS_TP + r * 32 + 8 * j + 4) = make_float4(tx[4], tx[5], tx[6], tx[7]);
+  }
+}
+
+// ---- cluster of workgroups working on ONE subgraph --------------------------------------------------------
+// With B = 50 subgraphs and one workgroup each, 206 of the 256 CUs idle.  `cs` workgroups (same XCD: block index
+// = subgraph + stride * member, stride a multiple of 8) therefore share a subgraph: the bundles of every layer are
+// scheduled over all their waves, each member publishes the rows it produced (h_l / dPre_l in HBM), the members
+// meet at a flag barrier and every member reloads the whole 26 KB matrix into its LDS.  Barrier = an arrival
+// counter per subgraph (agent-scope release / acquire), spins are BOUNDED (a missing member -- which a grid of
+// <= 224 workgroups of one-per-CU size excludes on this part -- raises gs_err instead of hanging the GPU); the
+// last member to leave the kernel resets the counters.
+// Exchanged rows are written and read with AGENT-scope relaxed atomics (sc1 accesses: they meet in the coherent
+// level without any cache-wide maintenance); an agent-scope release / acquire fence pair instead writes back and
+// invalidates the whole L2 of the XCD at every barrier of every workgroup and slowed the whole kernel 2-3x.
+__device__ __forceinline__ void gs_pub(float* p, float v) {
+#ifndef IGMC_HIPEMU
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ float gs_sub(const float* p) {
+#ifndef IGMC_HIPEMU
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  return *p;
+#endif
+}
+// Reload of the whole [N][32] matrix after a cluster barrier: agent-scope (sc1) 16-byte loads, all of a thread's
+// requests in flight before the single wait (the relaxed-atomic dword form is serialised by the compiler: ~9 us
+// per exchange); N <= 320 rows = 2560 float4 = at most 10 per thread.
+__device__ __forceinline__ void gs_reload(float* dst, const float* gsrc, int N) {
+#ifndef IGMC_HIPEMU
+  f32x4 v0, v1, v2, v3, v4, v5, v6, v7, v8, v9;
+  const f32x4* gp = (const f32x4*)gsrc;
+  const int n4 = N * 8, t0 = (int)threadIdx.x;
+#define GS_LD(V, U)                                                                            \
+  {                                                                                            \
+    const f32x4* p = gp + ((t0 + (U) * GS_THREADS < n4) ? t0 + (U) * GS_THREADS : 0);          \
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(V) : "v"(p) : "memory");         \
+  }
+  GS_LD(v0, 0) GS_LD(v1, 1) GS_LD(v2, 2) GS_LD(v3, 3) GS_LD(v4, 4)
+  GS_LD(v5, 5) GS_LD(v6, 6) GS_LD(v7, 7) GS_LD(v8, 8) GS_LD(v9, 9)
+#undef GS_LD
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "+v"(v9)
+               :
+               : "memory");
+  f32x4* d4 = (f32x4*)dst;
+  if (t0 < n4) d4[t0] = v0;
+  if (t0 + GS_THREADS < n4) d4[t0 + GS_THREADS] = v1;
+  if (t0 + 2 * GS_THREADS < n4) d4[t0 + 2 * GS_THREADS] = v2;
+  if (t0 + 3 * GS_THREADS < n4) d4[t0 + 3 * GS_THREADS] = v3;
+  if (t0 + 4 * GS_THREADS < n4) d4[t0 + 4 * GS_THREADS] = v4;
+  if (t0 + 5 * GS_THREADS < n4) d4[t0 + 5 * GS_THREADS] = v5;
+  if (t0 + 6 * GS_THREADS < n4) d4[t0 + 6 * GS_THREADS] = v6;
+  if (t0 + 7 * GS_THREADS < n4) d4[t0 + 7 * GS_THREADS] = v7;
+  if (t0 + 8 * GS_THREADS < n4) d4[t0 + 8 * GS_THREADS] = v8;
+  if (t0 + 9 * GS_THREADS < n4) d4[t0 + 9 * GS_THREADS] = v9;
+#else
+  for (int i = threadIdx.x; i < N * 32; i += GS_THREADS) dst[i] = gsrc[i];
+#endif
+}
+
+__device__ __forceinline__ void gs_cluster_barrier(int* bar, int g, int target, int* err) {
+#ifndef IGMC_HIPEMU
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // this wave's published rows have left the CU
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(bar + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int it = 0;
+    while (__hip_atomic_load(bar + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++it > (1 << 22)) {
+        *err = 1;
+        break;
+      }
     }
   }
+  __syncthreads();
+#else
+  (void)bar; (void)g; (void)target; (void)err;
+#endif
 }
 
 template <bool FLAGS, bool TRAIN>
@@ -179,7 +264,8 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
   int* relp = (int*)(S + lay.relp);       // [nmax][8]  start of every relation run of a row (global edge positions), [R] = row end
   float2* sW2 = (float2*)(S + lay.wreg);  // [GS_KT + 32][16] B operand of the layer: element (k, n) of [W_r ; root] (backward:
                                           // its transpose) at [k][n & 15].{x: n < 16, y: n >= 16}
-  int* sched = (int*)(S + lay.sched);     // [2 dirs][4 waves][GS_SMAX] bundle lists, then [2][4] list lengths
+  int* sched = (int*)(S + lay.sched);     // [2 dirs][GS_WMAX waves][GS_SMAX] bundle lists, then [2][GS_WMAX] list lengths
+  unsigned char* ulist = (unsigned char*)(S + lay.ulist);   // [GS_SMAX bundles][16 * GS_NR] units (slot << 3 | rel) by length
   float* sfeat = S + lay.head;            // [256] centre-node readout
   float* sgf = sfeat + 256;               // [256] d feat
   float* sa1 = sgf + 256;                 // [128]
@@ -195,8 +281,13 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
   float* HS = HSS + wave * 16 * GS_HP;
   const int B = b.totals[3];
   const int ts = m.ts_stride;
+  const int cs = a.cs;                               // workgroups per subgraph
+  const int cm = (cs > 1) ? blockIdx.x / a.stride : 0;   // this workgroup's member index
+  const int gw = cm * GS_NW + wave, nwt = cs * GS_NW; // wave of the cluster, waves of the cluster
+  int nbar = 0;                                      // cluster barriers passed so far
   const uint64_t step = m.ctrl ? (uint64_t)m.ctrl[IGMC_CTRL_STEP] : a.step;
   GS_STAMP(0);
+  GS_CSTAMP(0);
 
   // ---- layer-0 table, staged once per workgroup
   for (int i = tid; i < 1024; i += GS_THREADS) {
@@ -217,9 +308,10 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
   f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};        // layer-0 table gradient tile (code half, feature half) of this wave
   bool first_graph = true;
   __syncthreads();
+  GS_STAMP(56);
 
 #pragma unroll 1
-  for (int g = blockIdx.x; g < B; g += gridDim.x) {
+  for (int g = (cs > 1) ? blockIdx.x % a.stride : blockIdx.x; g < B; g += (cs > 1) ? B : gridDim.x) {
     const int nb = b.node_off[g];
     const int N = b.node_off[g + 1] - nb;
     const int cu = b.n_users[g];
@@ -229,20 +321,36 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
     for (int i = tid; i < N * rlp; i += GS_THREADS) cnt[i] = 0;
     for (int i = tid; i < N * 8; i += GS_THREADS) relp[i] = 0;
     __syncthreads();
+    GS_STAMP(57);
     for (int i = tid; i < ((N + 3) & ~3); i += GS_THREADS) sdeg[i] = (i < N) ? rp[i + 1] - rp[i] : -1;
     // layer-0 histogram: a flat pass over the subgraph's contiguous CSR range (edst = destination row)
     {
       const int e0 = rp[0], e1 = rp[N];
-#pragma unroll 4
-      for (int e = e0 + tid; e < e1; e += GS_THREADS) {
-        const int code = b.ecode[e], row = b.edst[e];
-        const int rel = (int)(b.ecr[e] >> 24);
-        atomicAdd(&relp[row * 8 + rel + 1], 1);        // run lengths count every entry, dropped or not
-        if (!FLAGS || (b.eflag[e] & 1)) atomicAdd(&cnt[row * rlp + (code >> 1)], 1 << ((code & 1) * 16));
+      for (int eb = e0 + tid; eb < e1; eb += 8 * GS_THREADS) {     // 8 entries (24 loads) in flight per thread
+        int code[8], row[8], rel[8], keep[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = eb + u * GS_THREADS;
+          const bool in = e < e1;
+          const int es = in ? e : e0;
+          code[u] = b.ecode[es];
+          row[u] = in ? (int)b.edst[es] : -1;
+          rel[u] = (int)(b.ecr[es] >> 24);
+          keep[u] = FLAGS ? (b.eflag[es] & 1) : 1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (row[u] < 0) continue;
+          atomicAdd(&relp[row[u] * 8 + rel[u] + 1], 1);        // run lengths count every entry, dropped or not
+          if (keep[u]) atomicAdd(&cnt[row[u] * rlp + (code[u] >> 1)], 1 << ((code[u] & 1) * 16));
+        }
       }
     }
     __syncthreads();
-    // rows by decreasing degree (rank counting, ties by index); run lengths -> run starts
+    GS_STAMP(58);
+    // run lengths -> run starts; rows by decreasing degree (rank counting, ties by index) unless every bundle gets a
+    // wave of its own anyway (clustered launch: the bundle order then does not matter, natural order is kept)
+    const bool ranked = nbun > nwt;
     for (int i = tid; i < N; i += GS_THREADS) {
       int acc = rp[i];
       for (int r = 0; r <= GS_NR; ++r) {
@@ -250,8 +358,9 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
         relp[i * 8 + r] = acc;
       }
       const int di = sdeg[i];
-      int rank = 0;
-      for (int q = 0; q < N; q += 4) {
+      int rank = ranked ? 0 : i;
+#pragma unroll 4
+      for (int q = 0; ranked && q < N; q += 4) {
         const int4 d4 = *(const int4*)(sdeg + q);
         rank += (d4.x > di) || (d4.x == di && q < i);
         rank += (d4.y > di) || (d4.y == di && q + 1 < i);
@@ -261,25 +370,80 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
       order[rank] = i;
     }
     __syncthreads();
+    GS_STAMP(59);
     // static longest-first schedule of the bundles over the 4 waves (depends only on the data => reproducible);
     // cost of a bundle = its longest row (edge steps) + the dense work that follows it
-    if (tid < 2) {
+    if (!ranked) {
+      if (tid < 2 * GS_WMAX) {          // bundle w -> wave w
+        sched[tid * GS_SMAX] = tid & (GS_WMAX - 1);
+        sched[2 * GS_WMAX * GS_SMAX + tid] = ((tid & (GS_WMAX - 1)) < nbun) ? 1 : 0;
+      }
+    } else if (tid < 2) {
+      // (everything in registers with static indices: a dynamically indexed private array lives in scratch memory
+      //  and made this loop the longest phase of the set-up)
       const int cdense = tid ? 100 : 50;
-      int load[GS_NW], cntw[GS_NW];
-      for (int w = 0; w < GS_NW; ++w) { load[w] = 0; cntw[w] = 0; }
-      int* sl = sched + tid * GS_NW * GS_SMAX;
+      int load[GS_WMAX], cntw[GS_WMAX];
+#pragma unroll
+      for (int w = 0; w < GS_WMAX; ++w) { load[w] = (w < nwt) ? 0 : 0x3fffffff; cntw[w] = 0; }
+      int* sl = sched + tid * GS_WMAX * GS_SMAX;
       for (int k = 0; k < nbun; ++k) {
         const int cost = sdeg[order[k * 16]] + cdense;
-        int best = 0;
-        for (int w = 1; w < GS_NW; ++w)
-          if (load[w] < load[best]) best = w;
-        sl[best * GS_SMAX + cntw[best]++] = k;
-        load[best] += cost;
+        int best = 0, bl = load[0];
+#pragma unroll
+        for (int w = 1; w < GS_WMAX; ++w)
+          if (load[w] < bl) { bl = load[w]; best = w; }
+        int pos = 0;
+#pragma unroll
+        for (int w = 0; w < GS_WMAX; ++w)
+          if (w == best) { pos = cntw[w]; cntw[w] += 1; load[w] += cost; }
+        sl[best * GS_SMAX + pos] = k;
       }
-      for (int w = 0; w < GS_NW; ++w) sched[2 * GS_NW * GS_SMAX + tid * GS_NW + w] = cntw[w];
+#pragma unroll
+      for (int w = 0; w < GS_WMAX; ++w) sched[2 * GS_WMAX * GS_SMAX + tid * GS_WMAX + w] = cntw[w];
+    }
+    __syncthreads();
+    // unit lists of the bundles this workgroup will process (either direction), one wave per bundle
+    {
+      int* ulen = (int*)TILES + wave * 128;              // scratch: the tiles are idle during the set-up
+      const int nun = 16 * R;
+      for (int d = 0; d < 2; ++d) {
+        const int ns = sched[2 * GS_WMAX * GS_SMAX + d * GS_WMAX + gw];
+        for (int si = 0; si < ns; ++si) {
+          const int bun = sched[(d * GS_WMAX + gw) * GS_SMAX + si];
+          if (d == 1) {                                   // already done for the forward list of this very wave?
+            bool dup = false;
+            const int nf = sched[2 * GS_WMAX * GS_SMAX + gw];
+            for (int q = 0; q < nf; ++q) dup |= sched[gw * GS_SMAX + q] == bun;
+            if (dup) continue;
+          }
+          const int b0 = bun * 16;
+          for (int u = lane; u < nun; u += 64) {
+            const int slot = u / R, r = u - slot * R;
+            int len = 0;
+            if (b0 + slot < N) {
+              const int* rptr = relp + order[b0 + slot] * 8;
+              len = rptr[r + 1] - rptr[r];
+            }
+            ulen[u] = len;
+          }
+          IGMC_WAVE_SYNC();
+          for (int u = lane; u < nun; u += 64) {
+            const int lu = ulen[u];
+            int rank = 0;
+            for (int v = 0; v < nun; ++v) {
+              const int lv = ulen[v];
+              rank += (lv > lu) || (lv == lu && v < u);
+            }
+            const int slot = u / R, r = u - slot * R;
+            ulist[bun * 16 * GS_NR + rank] = (unsigned char)((slot << 3) | r);
+          }
+          IGMC_WAVE_SYNC();
+        }
+      }
     }
     __syncthreads();
     GS_STAMP(1);
+    GS_CSTAMP(1);
 
     // ================================================================ layer 0: h0 = tanh([cnt | onehot(label) | 1] @ T0)
     {
@@ -288,7 +452,7 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int s = 0; s < 8; ++s) t0f[nt][s] = sT0[(4 * s + kq) * 32 + nt * 16 + li];
-      for (int bun = wave; bun < nbun; bun += GS_NW) {
+      for (int bun = gw; bun < nbun; bun += nwt) {
         const int b0 = bun * 16;
         const int prow = (b0 + li < N) ? b0 + li : N - 1;
         const int row = order[prow];
@@ -310,13 +474,19 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
             const float v0 = gs_tanh(c0[rr]), v1 = gs_tanh(c1[rr]);
             XA[orow * 32 + li] = v0;
             XA[orow * 32 + 16 + li] = v1;
-            if (TRAIN) {
-              m.h[0][(size_t)(nb + orow) * 32 + li] = v0;
-              m.h[0][(size_t)(nb + orow) * 32 + 16 + li] = v1;
+            if (TRAIN || cs > 1) {
+              gs_pub(m.h[0] + (size_t)(nb + orow) * 32 + li, v0);
+              gs_pub(m.h[0] + (size_t)(nb + orow) * 32 + 16 + li, v1);
             }
           }
         }
       }
+    }
+    if (cs > 1) {        // every member needs all of h_0
+      GS_CSTAMP(2);
+      gs_cluster_barrier(m.gs_bar, g, cs * (++nbar), m.gs_err);
+      GS_CSTAMP(3);
+      gs_reload(XA, m.h[0] + (size_t)nb * 32, N);
     }
     __syncthreads();
     if (tid < 64) sfeat[(tid >> 5) * 128 + (tid & 31)] = XA[((tid >> 5) ? cu : 0) * 32 + (tid & 31)];
@@ -356,26 +526,23 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
       }
       const float bias0 = P[m.off_bias[l] + li], bias1 = P[m.off_bias[l] + 16 + li];
       __syncthreads();
-      const int ns = sched[2 * GS_NW * GS_SMAX + wave];
+      const int ns = sched[2 * GS_WMAX * GS_SMAX + gw];
 #pragma unroll 1
       for (int si = 0; si < ns; ++si) {
-        const int b0 = sched[wave * GS_SMAX + si] * 16;
+        const int b0 = sched[gw * GS_SMAX + si] * 16;
         int lane_ = lane;
         GS_OPAQUE(lane_);
         const int qd_ = lane_ >> 2, j_ = lane_ & 3, li_ = lane_ & 15, kq_ = lane_ >> 4;
         if (l == 1 && si == 0) GS_STAMP(16);
-        {
-          const bool live = b0 + qd_ < N;
-          const int i = order[live ? b0 + qd_ : 0];
-          if (R < GS_NR || !live) {
+        if (R < GS_NR) {
 #pragma unroll
-            for (int r = 0; r < GS_NR; ++r) {
-              *(float4*)(T + qd_ * GS_TP + r * 32 + 8 * j_) = make_float4(0.f, 0.f, 0.f, 0.f);
-              *(float4*)(T + qd_ * GS_TP + r * 32 + 8 * j_ + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+          for (int r = 0; r < GS_NR; ++r) {
+            *(float4*)(T + qd_ * GS_TP + r * 32 + 8 * j_) = make_float4(0.f, 0.f, 0.f, 0.f);
+            *(float4*)(T + qd_ * GS_TP + r * 32 + 8 * j_ + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
           }
-          gs_gather<FLAGS, false>(b, src, zrow, nb, T + qd_ * GS_TP, relp + i * 8, live, R, j_);
+          IGMC_WAVE_SYNC();
         }
+        gs_gather<FLAGS, false>(b, src, zrow, nb, T, relp, order, ulist + (b0 >> 4) * 16 * GS_NR, b0, N, R, qd_, j_);
         IGMC_WAVE_SYNC();
         if (l == 1 && si == 0) GS_STAMP(17);
         const int rowA = order[(b0 + li_ < N) ? b0 + li_ : N - 1];
@@ -401,9 +568,9 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
             const float v1 = gs_tanh((acc[1][0][rr] + acc[1][1][rr]) + (acc[1][2][rr] + acc[1][3][rr]) + bias1);
             dst[orow * 32 + li_] = v0;
             dst[orow * 32 + 16 + li_] = v1;
-            if (TRAIN) {
-              m.h[l][(size_t)(nb + orow) * 32 + li_] = v0;
-              m.h[l][(size_t)(nb + orow) * 32 + 16 + li_] = v1;
+            if (TRAIN || cs > 1) {
+              gs_pub(m.h[l] + (size_t)(nb + orow) * 32 + li_, v0);
+              gs_pub(m.h[l] + (size_t)(nb + orow) * 32 + 16 + li_, v1);
             }
           }
         }
@@ -412,6 +579,10 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
       }
       if (l == 1) GS_STAMP(20);
       if (l == 1) GS_WSTAMP(32);
+      if (cs > 1) {      // every member needs all of h_l
+        gs_cluster_barrier(m.gs_bar, g, cs * (++nbar), m.gs_err);
+        gs_reload(dst, m.h[l] + (size_t)nb * 32, N);
+      }
       __syncthreads();
       if (tid < 64) sfeat[(tid >> 5) * 128 + l * 32 + (tid & 31)] = dst[((tid >> 5) ? cu : 0) * 32 + (tid & 31)];
       GS_STAMP(2 + l);
@@ -439,8 +610,10 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
         if (TRAIN) {
           keep = a.inj_mask ? (int)a.inj_mask[g * 128 + ju]
                             : (int)(igmc_u01(igmc_unit_hash(a.seed, step, (uint32_t)g, (uint32_t)ju)) >= 0.5f);
-          m.a1[g * 128 + ju] = av;
-          m.lmask[g * 128 + ju] = (uint8_t)keep;
+          if (cm == 0) {
+            m.a1[g * 128 + ju] = av;
+            m.lmask[g * 128 + ju] = (uint8_t)keep;
+          }
           sa1[ju] = av;
           skeep[ju] = keep ? 1.f : 0.f;
         }
@@ -454,9 +627,11 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
       s = igmc_wave_sum_f(s);
       if (lane == 0) {
         const float o = (s + P[m.off_l2b]) * a.mult;
-        a.out[g] = o;
         const float e = o - b.y[g];
-        m.err[g] = e;
+        if (cm == 0) {
+          a.out[g] = o;
+          m.err[g] = e;
+        }
         misc[0] = e;
       }
     }
@@ -472,9 +647,9 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
         const float dp = 2.f * misc[0] * a.grad_scale * a.mult;
         const float dzv = (sa1[tid] > 0.f && skeep[tid] != 0.f) ? dp * P[m.off_l2w + tid] * 2.f : 0.f;
         sdz[tid] = dzv;
-        m.dz[g * 128 + tid] = dzv;
+        if (cm == 0) m.dz[g * 128 + tid] = dzv;
       }
-      m.feat[(size_t)g * m.D + tid] = sfeat[tid];
+      if (cm == 0) m.feat[(size_t)g * m.D + tid] = sfeat[tid];
       __syncthreads();
       {   // wave w takes hidden units 32w..32w+31, lane -> 4 fan-in columns; rows with dz == 0 (ReLU / dropout:
           // ~3/4 of them) are skipped wave-uniformly
@@ -493,7 +668,7 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
       {
         const float v = (TILES[tid] + TILES[256 + tid]) + (TILES[512 + tid] + TILES[768 + tid]);
         sgf[tid] = v;
-        m.gfeat[(size_t)g * m.D + tid] = v;
+        if (cm == 0) m.gfeat[(size_t)g * m.D + tid] = v;
       }
       // dPre_3: only the two centre rows are non-zero
       for (int i = tid; i < N * 32; i += GS_THREADS) XA[i] = 0.f;
@@ -522,7 +697,8 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
           {
             const int n = tid & 31, part = tid >> 5;
             float sb = 0.f;
-            for (int row = part; row < N; row += GS_THREADS / 32) sb += src[row * 32 + n];
+            // (clustered: member cm takes the rows of its residue class, the partial slots add up)
+            for (int row = part * cs + cm; row < N; row += (GS_THREADS / 32) * cs) sb += src[row * 32 + n];
             sred[part * 32 + n] = sb;
           }
           __syncthreads();
@@ -544,7 +720,7 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
             for (int q = 0; q < 4; ++q) sW[((r * 32 + n0 + q) * 16 + (f & 15)) * 2 + (f >> 4)] = v[q];
           }
         }
-        float* wpart = m.ts_part + ((size_t)l * IGMC_WG_BLOCKS + blockIdx.x) * ts;
+        float* wpart = m.ts_part + ((size_t)l * IGMC_TS_BLOCKS + blockIdx.x) * ts;
         if (tid < 32) {
           float s = 0.f;
           for (int p = 0; p < GS_THREADS / 32; ++p) s += sred[p * 32 + tid];
@@ -557,11 +733,11 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
 #pragma unroll
           for (int nt = 0; nt < GS_WN; ++nt) wacc[m2][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         __syncthreads();
-        const int ns = sched[2 * GS_NW * GS_SMAX + GS_NW + wave];
+        const int ns = sched[2 * GS_WMAX * GS_SMAX + GS_WMAX + gw];
         if (l == 3) GS_STAMP(23);
 #pragma unroll 1
         for (int si = 0; si < ns; ++si) {
-          const int b0 = sched[(GS_NW + wave) * GS_SMAX + si] * 16;
+          const int b0 = sched[(GS_WMAX + gw) * GS_SMAX + si] * 16;
           int lane_ = lane;
           GS_OPAQUE(lane_);
           const int qd_ = lane_ >> 2, j_ = lane_ & 3, li_ = lane_ & 15, kq_ = lane_ >> 4;
@@ -571,22 +747,23 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
           for (int h2 = 0; h2 < 2; ++h2) {
             const int o = lane_ + 64 * h2, rr = o >> 3, c4 = o & 7;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b0 + rr < N) v = *(const float4*)(m.h[l - 1] + (size_t)(nb + order[b0 + rr]) * 32 + 4 * c4);
+            if (b0 + rr < N) {
+              const float* hp = m.h[l - 1] + (size_t)(nb + order[b0 + rr]) * 32 + 4 * c4;
+              if (cs > 1) v = make_float4(gs_sub(hp), gs_sub(hp + 1), gs_sub(hp + 2), gs_sub(hp + 3));   // rows of other members
+              else v = *(const float4*)hp;
+            }
             *(float4*)(HS + rr * GS_HP + 4 * c4) = v;
           }
           if (l == 3 && si == 0) GS_STAMP(25);
-          {
-            const bool live = b0 + qd_ < N;
-            const int i = order[live ? b0 + qd_ : 0];
-            if (R < GS_NR || !live) {
+          if (R < GS_NR) {
 #pragma unroll
-              for (int r = 0; r < GS_NR; ++r) {
-                *(float4*)(T + qd_ * GS_TP + r * 32 + 8 * j_) = make_float4(0.f, 0.f, 0.f, 0.f);
-                *(float4*)(T + qd_ * GS_TP + r * 32 + 8 * j_ + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-              }
+            for (int r = 0; r < GS_NR; ++r) {
+              *(float4*)(T + qd_ * GS_TP + r * 32 + 8 * j_) = make_float4(0.f, 0.f, 0.f, 0.f);
+              *(float4*)(T + qd_ * GS_TP + r * 32 + 8 * j_ + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            gs_gather<FLAGS, true>(b, src, zrow, nb, T + qd_ * GS_TP, relp + i * 8, live, R, j_);
+            IGMC_WAVE_SYNC();
           }
+          gs_gather<FLAGS, true>(b, src, zrow, nb, T, relp, order, ulist + (b0 >> 4) * 16 * GS_NR, b0, N, R, qd_, j_);
           IGMC_WAVE_SYNC();
           if (l == 3 && si == 0) GS_STAMP(26);
           // dX tile = [T' | dPre_l] @ [W_r^T ; root^T]
@@ -633,8 +810,13 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
                 v1 += gf[16 + li_];
               }
               const float x0 = HS[(kq_ * 4 + rr) * GS_HP + li_], x1 = HS[(kq_ * 4 + rr) * GS_HP + 16 + li_];
-              dst[orow * 32 + li_] = v0 * (1.f - x0 * x0);
-              dst[orow * 32 + 16 + li_] = v1 * (1.f - x1 * x1);
+              const float d0 = v0 * (1.f - x0 * x0), d1 = v1 * (1.f - x1 * x1);
+              dst[orow * 32 + li_] = d0;
+              dst[orow * 32 + 16 + li_] = d1;
+              if (cs > 1) {
+                gs_pub(m.dpre[l - 1] + (size_t)(nb + orow) * 32 + li_, d0);
+                gs_pub(m.dpre[l - 1] + (size_t)(nb + orow) * 32 + 16 + li_, d1);
+              }
             }
           }
           IGMC_WAVE_SYNC();
@@ -698,6 +880,11 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
           }
           __syncthreads();
         }
+        if (cs > 1) {    // every member needs all of dPre_{l-1}
+          gs_cluster_barrier(m.gs_bar, g, cs * (++nbar), m.gs_err);
+          gs_reload(dst, m.dpre[l - 1] + (size_t)nb * 32, N);
+          __syncthreads();
+        }
         if (l == 3) GS_STAMP(31);
         GS_STAMP(11 - l);
       }
@@ -708,7 +895,7 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
         const int m2 = wave >> 1, wn = wave & 1;
         const int code = m2 * 16 + li;
 #pragma unroll 4
-        for (int s = 0; 4 * s < N; ++s) {
+        for (int s = cm; 4 * s < N; s += cs) {
           const int row = 4 * s + kq;
           const int rc = (row < N) ? row : N - 1;
           const int cv = (cnt[rc * rlp + ((code < RL) ? (code >> 1) : 0)] >> ((code & 1) * 16)) & 0xFFFF;
@@ -726,7 +913,7 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
 
   if (TRAIN) {
     // ---- layer-0 table partial: rows c < R*L + L + 1 of [32 codes][32]
-    float* part0 = m.ts_part + (size_t)blockIdx.x * ts;
+    float* part0 = m.ts_part + (size_t)blockIdx.x * ts;        // slice 0 of [4][IGMC_TS_BLOCKS][ts]
     const int m2 = wave >> 1, wn = wave & 1;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -734,6 +921,19 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
       if (c < RL + L + 1) part0[c * 32 + wn * 16 + li] = acc0[rr];
     }
   }
+#ifndef IGMC_HIPEMU
+  if (cs > 1 && tid == 0) {
+    const int g = blockIdx.x % a.stride;
+    if (g < B) {
+      int* done = m.gs_bar + m.graph_cap;
+      if (__hip_atomic_fetch_add(done + g, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == cs - 1) {
+        // every member has passed its last barrier: the counters are free for the next launch
+        __hip_atomic_store(m.gs_bar + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(done + g, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+#endif
   GS_STAMP(12);
 }
 
@@ -761,25 +961,47 @@ int igmc_gs_layout(const ModelDev& m, const BatchDev& b, GsLayout* lay) {
   o = (o + 3) & ~3;
   lay->deg = o; o += nmax;
   lay->order = o; o += nmax;
-  lay->sched = o; o += 2 * GS_NW * GS_SMAX + 2 * GS_NW;
+  lay->sched = o; o += 2 * GS_WMAX * GS_SMAX + 2 * GS_WMAX;
   o = (o + 3) & ~3;
   lay->relp = o; o += nmax * 8;
   lay->wreg = o; o += (GS_KT + 32) * 32;
+  lay->ulist = o; o += GS_SMAX * 16 * GS_NR / 4;
   o = (o + 3) & ~3;
   lay->head = o; o += 256 + 256 + 3 * 128 + 256 + 16;
   lay->words = o;
   return (size_t)o * 4 <= 160 * 1024;
 }
 
-// The path is OPT-IN (IGMC_GRAPH_STEP=1) in round 1: it is parity-green but, at ~280 us for the ml_1m batch, not yet
-// faster than the per-layer kernels (see DESIGN.md "one workgroup per subgraph" for the phase clocks and the plan).
+// Default ON where eligible (IGMC_GRAPH_STEP=0 forces the per-layer kernels of model.hip).
 static int igmc_gs_enabled() {
   const char* e = getenv("IGMC_GRAPH_STEP");      // read on every call: tests switch it per case
-  return e ? atoi(e) : 0;
+  return e ? atoi(e) : 1;
 }
 
 int igmc_gs_eligible(const ModelDev& m, const BatchDev& b, GsLayout* lay) {
   return igmc_gs_enabled() && igmc_gs_layout(m, b, lay);
+}
+
+// workgroups per subgraph: 4 (2) when 4 (2) x the padded batch still fits one workgroup per CU with a margin
+int igmc_gs_cluster(int B) {
+#ifdef IGMC_HIPEMU
+  (void)B;
+  return 1;              // the emulator runs workgroups one after the other
+#else
+  static int cus = -1;
+  if (cus < 0) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+  }
+  int want = (cus >= 240) ? 4 : 1;        // the clustered launch needs (almost) every CU of an MI355X to itself
+  const char* e = getenv("IGMC_GS_CLUSTER");
+  if (e) want = atoi(e);
+  const int stride = (B + 7) & ~7;
+  if (want >= 4 && 4 * stride <= 224) return 4;
+  if (want >= 2 && 2 * stride <= 224) return 2;
+  return 1;
+#endif
 }
 
 int igmc_gs_grid(int B) {
@@ -801,7 +1023,10 @@ void igmc_launch_graph_step(const ModelDev& m, const BatchDev& b, const float* P
   a.out = out;
   a.lay = lay;
   a.timing = getenv("IGMC_GS_TIMING") ? 1 : 0;
-  const int grid = igmc_gs_grid(B);
+  const int cs = igmc_gs_cluster(B);
+  a.cs = cs;
+  a.stride = (cs > 1) ? ((B + 7) & ~7) : 1;
+  const int grid = (cs > 1) ? cs * a.stride : igmc_gs_grid(B);
   const size_t sm = (size_t)lay.words * 4;
   if (getenv("IGMC_GS_TRACE")) fprintf(stderr, "[igmc] k_graph_step B=%d train=%d flags=%d nmax=%d lds=%zu\n", B, training, use_flags, lay.nmax, sm);
   if (training) {
@@ -823,6 +1048,17 @@ int igmc_gs_prepare() {
   if (hipFuncSetAttribute((const void*)k_graph_step<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
 #endif
   return 0;
+}
+
+// debug aid: 1 when a cluster barrier of k_graph_step ever timed out on this model workspace
+extern "C" int igmc_debug_gs_error(const void* model_dev_gs_err) {
+  int v = 0;
+#ifndef IGMC_HIPEMU
+  if (!model_dev_gs_err) return 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpy(&v, model_dev_gs_err, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+#endif
+  return v;
 }
 
 // debug aid: phase clocks (shader cycles) of workgroup 0 of the last k_graph_step launched with IGMC_GS_TIMING set

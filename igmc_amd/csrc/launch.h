@@ -52,7 +52,7 @@ void igmc_launch_finish(const ModelDev& m, const BatchDev& b, float* p, const fl
 // graphstep.hip: one workgroup per enclosing subgraph (LDS-resident layers)
 struct GsLayout {      // LDS plan, offsets in 4-byte words
   int nmax, rlp;
-  int xa, xb, zrow, tile, hs, att, t0, cnt, rp, lab, deg, order, sched, relp, wreg, head, words;
+  int xa, xb, zrow, tile, hs, att, t0, cnt, rp, lab, deg, order, sched, relp, wreg, ulist, head, words;
 };
 struct GsArgs {
   const uint8_t* inj_mask;
@@ -60,10 +60,12 @@ struct GsArgs {
   float mult, grad_scale;
   float* out;
   int timing;
+  int cs, stride;      // workgroups per subgraph; block index stride between the members of a cluster
   GsLayout lay;
 };
 int igmc_gs_eligible(const ModelDev& m, const BatchDev& b, GsLayout* lay);
 int igmc_gs_grid(int B);
+int igmc_gs_cluster(int B);
 void igmc_launch_graph_step(const ModelDev& m, const BatchDev& b, const float* P, int B, int training, int use_flags,
                             const GsLayout& lay, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
                             float grad_scale, float* out, void* stream);

@@ -4,6 +4,7 @@
 
 #define IGMC_KCAT 160     // (num_bases + 1) * 32 : [basis-space aggregate | self] width
 #define IGMC_WG_BLOCKS 64    // grid.x of the weight-gradient kernel (per-block partials, per layer); 128: +5 us in the reduction, 32: +9 us in the products
+#define IGMC_TS_BLOCKS 256   // partial slots of the relation-space tables (one per workgroup of k_graph_step)
 #define IGMC_GATHER_BLOCKS 4096   // max grid of the row-walker kernels (4 rows = 4 waves per block)
 #define IGMC_L0_BLOCKS 256
 #define IGMC_HG 8            // graphs per workgroup in the head kernels
@@ -31,9 +32,11 @@ struct ModelDev {
   float* gatt_part;   // [3][IGMC_GATHER_BLOCKS][R*4]
   float* l0_part;     // [IGMC_L0_BLOCKS][(R*L+L+1)*32]
   float* graw;        // [3][32*160+32] + [3][R*4] + l0 rows: reduced partials
-  float* ts_part;     // [4][IGMC_WG_BLOCKS][ts_stride] relation-space tables [W_r rows | root rows | bias] per layer (or NULL)
+  float* ts_part;     // [4][IGMC_TS_BLOCKS][ts_stride] relation-space tables [W_r rows | root rows | bias] per layer (or NULL)
   float* ts_raw;      // [4][ts_stride] their sum over the workgroups
   int ts_stride;      // (R*32 + 33) * 32
+  int* gs_bar;        // [2][graph_cap] cluster barriers of k_graph_step: arrival counters, leave counters
+  int* gs_err;        // [1] set when a cluster barrier timed out
   float* arr_part;    // [4] ARR regulariser per layer
   const float* side;  // [B,S] borrowed side features or NULL
   const int64_t* ctrl;  // optional device-side step control (igmc_hip.h) or NULL

@@ -1533,7 +1533,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_partials(ModelDev m, int 
 
 // relation-space tables of graphstep.hip: ts_raw[l][i] = sum over the workgroups' partials (fixed order);
 // 64 outputs per block, the 4 waves split the partial slices
-__global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_ts(ModelDev m, int nparts) {
+__global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_ts(ModelDev m, int nparts, int stride, int B) {
   __shared__ float sred[4][64];
   const int ts = m.ts_stride, rows0 = m.R * m.L + m.L + 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1542,8 +1542,20 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_ts(ModelDev m, int nparts
   float s = 0.f;
   const bool ok = l < 4 && (l > 0 || i < rows0 * 32);
   if (ok) {
-    const float* p = m.ts_part + (size_t)l * IGMC_WG_BLOCKS * ts + i;
-    for (int k = wave; k < nparts; k += 4) s += p[(size_t)k * ts];
+    // slot of member c of subgraph g = g + c * stride (one-workgroup launches: stride = IGMC_TS_BLOCKS, cs = 1);
+    // the 4 waves split the subgraphs, 8 independent loads in flight, fixed order
+    const float* p = m.ts_part + (size_t)l * IGMC_TS_BLOCKS * ts + i;
+    const int ng = (nparts < stride) ? nparts : ((B < stride) ? B : stride), cs = (nparts + stride - 1) / stride;
+    for (int c = 0; c < cs; ++c) {
+      const float* pc = p + (size_t)c * stride * ts;
+      for (int g0 = wave; g0 < ng; g0 += 32) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (g0 + 4 * u < ng) ? pc[(size_t)(g0 + 4 * u) * ts] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+    }
   }
   sred[wave][lane] = s;
   __syncthreads();
@@ -2079,11 +2091,13 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
   GsLayout lay;
   if (l0_mfma && igmc_gs_eligible(m, b, &lay)) {
     // one workgroup per subgraph: forward, residual and backward down to the per-workgroup gradient partials
-    const int gg = igmc_gs_grid(B);
+    const int cs = igmc_gs_cluster(B);
+    const int gstride = (cs > 1) ? ((B + 7) & ~7) : IGMC_TS_BLOCKS;
+    const int gg = (cs > 1) ? cs * gstride : igmc_gs_grid(B);
     igmc_launch_graph_step(m, b, P, B, 1, use_flags, lay, inj_mask, seed, step, mult, grad_scale, out, stream);
     IGMC_PLAUNCH("k_wgrad_head", k_wgrad_head, dim3(8 * ny, 1), IGMC_BLOCK, 0, stream, b, m, (const float*)P,
                  (const float*)nullptr, 1, grad_scale, mult, 2.f, grad, 0);
-    IGMC_PLAUNCH("k_reduce_ts", k_reduce_ts, (4 * m.ts_stride + 63) / 64, IGMC_BLOCK, 0, stream, m, gg);
+    IGMC_PLAUNCH("k_reduce_ts", k_reduce_ts, (4 * m.ts_stride + 63) / 64, IGMC_BLOCK, 0, stream, m, gg, gstride, B);
     if (adam) {
       at.enabled = 1;
       at.b = b;

@@ -215,4 +215,9 @@ class StepGraph(object):
         for first in range(0, n, self.B):
             self.step(min(self.B, n - first))
         self.detach()         # captured launches keep their own copy of the control pointer
+        self.check()
         return self.total, n
+
+    def check(self):
+        """Raises if a bounded device-side wait of the step kernels timed out (synchronises the stream)."""
+        self.lib.call('igmc_model_check', self.ws.handle, C.c_void_p(torch.cuda.current_stream().cuda_stream))

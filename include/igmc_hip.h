@@ -210,6 +210,10 @@ int igmc_sse_accumulate(const float* d_out, const igmc_batch* b, double* d_acc, 
 int igmc_profile_enable(int on);
 int igmc_profile_fetch(char names[][48], float* ms, int* calls, int cap);
 
+/* Health check of the workspace (synchronises `stream`): fails when a bounded device-side wait of the
+ * one-workgroup-per-subgraph step kernel ever timed out since the last check.  No reference counterpart. */
+int igmc_model_check(igmc_model* m, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,8 +37,8 @@ def main():
     for _ in range(20):
         sg.step()
     torch.cuda.synchronize()
-    buf = np.zeros(48, np.uint64)
-    lib.cdll.igmc_debug_gs_clocks(C.c_void_p(buf.ctypes.data), 48)
+    buf = np.zeros(64, np.uint64)
+    lib.cdll.igmc_debug_gs_clocks(C.c_void_p(buf.ctypes.data), 64)
     c = buf.astype(np.int64)
     info = sg.arena.info(torch.cuda.current_stream().cuda_stream)
     print('batch nodes %d edges %d' % (info.num_nodes, info.num_edges))
@@ -51,11 +51,18 @@ def main():
           '(layer start %d)  reduce %d' % (c[25] - c[24], c[26] - c[25], c[27] - c[26], c[28] - c[27], c[29] - c[28],
                                           c[30] - c[24], c[24] - c[7], c[31] - c[30]))
     _extra(c)
+    print('setup: kernel start -> T0 staged %d | row starts/labels loaded %d | histogram %d | ranking %d | schedule %d' % (
+        c[56] - c[0], c[57] - c[56], c[58] - c[57], c[59] - c[58], c[1] - c[59]))
 
 
 def _extra(c):
     print('L1 fwd: waves finish their bundles at', [int(c[32 + w] - c[16]) for w in range(4)], '(from first bundle start of wave 0)')
     print('L3 bwd: waves finish their bundles at', [int(c[36 + w] - c[24]) for w in range(4)])
+    t0 = min(int(c[40 + 4 * m]) for m in range(4) if c[40 + 4 * m] > 0) if any(c[40 + 4 * m] > 0 for m in range(4)) else 0
+    for m in range(4):
+        if c[40 + 4 * m] > 0:
+            print('cluster member %d of subgraph 0: start %d  setup done %d  barrier-1 arrive %d  leave %d' % (
+                m, c[40 + 4 * m] - t0, c[41 + 4 * m] - t0, c[42 + 4 * m] - t0, c[43 + 4 * m] - t0))
 
 
 if __name__ == '__main__':

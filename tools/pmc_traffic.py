@@ -10,7 +10,8 @@ import json
 import re
 import sys
 
-KERNEL = 'k_rgcn_layer4<false, false>'      # forward fused R-GCN layer = bench.py's roofline kernel
+KERNEL = 'k_graph_step<false, true>'        # bench.py's roofline kernel (headline config: no edge dropout, training)
+NAME = 'k_graph_step'
 
 
 def counters(path):
@@ -28,7 +29,7 @@ def main():
     for f in ('pmc1.txt', 'pmc2.txt'):
         c.update(counters('%s/%s' % (src, f)))
     fetch, write = c['FETCH_SIZE'] * 1024.0, c['WRITE_SIZE'] * 1024.0
-    rec = dict(kernel='k_rgcn_layer_fwd', symbol=KERNEL, fetch_bytes_reported=fetch, write_bytes=write,
+    rec = dict(kernel=NAME, symbol=KERNEL, fetch_bytes_reported=fetch, write_bytes=write,
                traffic_bytes=2.0 * fetch + write,
                l2_hit_rate=c['TCC_HIT_sum'] / (c['TCC_HIT_sum'] + c['TCC_MISS_sum']),
                note='per launch; FETCH_SIZE doubled (gfx950 correction), + WRITE_SIZE; separate --pmc passes of '
