@@ -289,6 +289,17 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
   GS_STAMP(0);
   GS_CSTAMP(0);
 
+  // ---- the first subgraph's row starts / labels are requested BEFORE the layer-0 table is staged: the two
+  //      dependent round trips (node_off -> row_ptr) overlap with the table arithmetic
+  const int g_first = (cs > 1) ? blockIdx.x % a.stride : blockIdx.x;
+  int pre_nb = 0, pre_N = 0, pre_rp0 = 0, pre_rp1 = 0, pre_lab = 0;
+  if (g_first < B) {
+    pre_nb = b.node_off[g_first];
+    pre_N = b.node_off[g_first + 1] - pre_nb;
+    if (tid <= pre_N) pre_rp0 = b.row_ptr[pre_nb + tid];
+    if (tid + GS_THREADS <= pre_N) pre_rp1 = b.row_ptr[pre_nb + tid + GS_THREADS];
+    if (tid < pre_N) pre_lab = b.node_label[pre_nb + tid];
+  }
   // ---- layer-0 table, staged once per workgroup
   for (int i = tid; i < 1024; i += GS_THREADS) {
     const int c = i >> 5, f = i & 31;
@@ -307,17 +318,23 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
   if (tid < 32) zrow[tid] = 0.f;
   f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};        // layer-0 table gradient tile (code half, feature half) of this wave
   bool first_graph = true;
-  __syncthreads();
   GS_STAMP(56);
 
 #pragma unroll 1
-  for (int g = (cs > 1) ? blockIdx.x % a.stride : blockIdx.x; g < B; g += (cs > 1) ? B : gridDim.x) {
-    const int nb = b.node_off[g];
-    const int N = b.node_off[g + 1] - nb;
+  for (int g = g_first; g < B; g += (cs > 1) ? B : gridDim.x) {
+    const int nb = first_graph ? pre_nb : b.node_off[g];
+    const int N = first_graph ? pre_N : b.node_off[g + 1] - nb;
     const int cu = b.n_users[g];
     const int nbun = (N + 15) >> 4;
-    for (int i = tid; i <= N; i += GS_THREADS) rp[i] = b.row_ptr[nb + i];
-    for (int i = tid; i < N; i += GS_THREADS) slab[i] = b.node_label[nb + i];
+    if (first_graph && N < 2 * GS_THREADS) {
+      if (tid <= N) rp[tid] = pre_rp0;
+      if (tid + GS_THREADS <= N) rp[tid + GS_THREADS] = pre_rp1;
+      if (tid < N) slab[tid] = pre_lab;
+      for (int i = tid + GS_THREADS; i < N; i += GS_THREADS) slab[i] = b.node_label[nb + i];
+    } else {
+      for (int i = tid; i <= N; i += GS_THREADS) rp[i] = b.row_ptr[nb + i];
+      for (int i = tid; i < N; i += GS_THREADS) slab[i] = b.node_label[nb + i];
+    }
     for (int i = tid; i < N * rlp; i += GS_THREADS) cnt[i] = 0;
     for (int i = tid; i < N * 8; i += GS_THREADS) relp[i] = 0;
     __syncthreads();
@@ -430,9 +447,13 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
           for (int u = lane; u < nun; u += 64) {
             const int lu = ulen[u];
             int rank = 0;
-            for (int v = 0; v < nun; ++v) {
-              const int lv = ulen[v];
-              rank += (lv > lu) || (lv == lu && v < u);
+#pragma unroll 5
+            for (int v = 0; v < nun; v += 4) {       // nun = 16 R: whole int4 groups, independent broadcast reads
+              const int4 l4 = *(const int4*)(ulen + v);
+              rank += (l4.x > lu) || (l4.x == lu && v < u);
+              rank += (l4.y > lu) || (l4.y == lu && v + 1 < u);
+              rank += (l4.z > lu) || (l4.z == lu && v + 2 < u);
+              rank += (l4.w > lu) || (l4.w == lu && v + 3 < u);
             }
             const int slot = u / R, r = u - slot * R;
             ulist[bun * 16 * GS_NR + rank] = (unsigned char)((slot << 3) | r);
@@ -926,10 +947,12 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
     const int g = blockIdx.x % a.stride;
     if (g < B) {
       int* done = m.gs_bar + m.graph_cap;
-      if (__hip_atomic_fetch_add(done + g, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == cs - 1) {
+      // (relaxed: only the counters themselves are communicated; an agent-scope acq_rel here costs a cache-wide
+      //  write-back + invalidate, ~8 us)
+      if (__hip_atomic_fetch_add(done + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cs - 1) {
         // every member has passed its last barrier: the counters are free for the next launch
         __hip_atomic_store(m.gs_bar + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(done + g, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(done + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
