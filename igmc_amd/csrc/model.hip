@@ -1420,10 +1420,10 @@ __device__ __forceinline__ void head_bwd_w_body(const BatchDev& b, const ModelDe
   const bool extra = nt == 0;
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 accb1 = acc, accw2 = acc, accb2 = acc;
-  for (int g0 = 0; g0 < B; g0 += 16) {            // 4 MFMA steps (16 graphs) of loads in flight
-    float av[4], bv[4], ad[4], dpv[4];
+  for (int g0 = 0; g0 < B; g0 += 32) {            // 8 MFMA steps (32 graphs) of loads in flight
+    float av[8], bv[8], ad[8], dpv[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const int g = g0 + 4 * u + kq;
       const bool ok = g < B;
       const int gs = ok ? g : 0;
@@ -1435,7 +1435,7 @@ __device__ __forceinline__ void head_bwd_w_body(const BatchDev& b, const ModelDe
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
       if (extra) {
         accb1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], (g0 + 4 * u + kq < B) ? 1.f : 0.f, accb1, 0, 0, 0);
@@ -1754,7 +1754,17 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize(ModelDev m, const float
         g = m.graw[3 * wgs + (size_t)(l - 1) * na + rb];
       } else {
         float sacc = 0.f;
-        for (int e = lane; e < nE; e += 64) sacc += t0[(size_t)r * nE + e] * basis[bb * nE + e];
+        {   // nE <= 1024: at most 16 (table, basis) pairs per lane, all requested before the sum
+          float tv[16], bv[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const int e = lane + 64 * k;
+            tv[k] = (e < nE) ? t0[(size_t)r * nE + e] : 0.f;
+            bv[k] = (e < nE) ? basis[bb * nE + e] : 0.f;
+          }
+#pragma unroll
+          for (int k = 0; k < 16; ++k) sacc += tv[k] * bv[k];
+        }
         g = igmc_wave_sum_f(sacc);
       }
       if (arr_coef != 0.f) {
