@@ -343,10 +343,10 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
     // layer-0 histogram: a flat pass over the subgraph's contiguous CSR range (edst = destination row)
     {
       const int e0 = rp[0], e1 = rp[N];
-      for (int eb = e0 + tid; eb < e1; eb += 8 * GS_THREADS) {     // 8 entries (24 loads) in flight per thread
-        int code[8], row[8], rel[8], keep[8];
+      for (int eb = e0 + tid; eb < e1; eb += 24 * GS_THREADS) {    // 24 entries (72 loads) in flight per thread:
+        int code[24], row[24], rel[24], keep[24];                   // one round trip for a typical subgraph
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 24; ++u) {
           const int e = eb + u * GS_THREADS;
           const bool in = e < e1;
           const int es = in ? e : e0;
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
           keep[u] = FLAGS ? (b.eflag[es] & 1) : 1;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 24; ++u) {
           if (row[u] < 0) continue;
           atomicAdd(&relp[row[u] * 8 + rel[u] + 1], 1);        // run lengths count every entry, dropped or not
           if (keep[u]) atomicAdd(&cnt[row[u] * rlp + (code[u] >> 1)], 1 << ((code[u] & 1) * 16));
@@ -419,9 +419,9 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
       for (int w = 0; w < GS_WMAX; ++w) sched[2 * GS_WMAX * GS_SMAX + tid * GS_WMAX + w] = cntw[w];
     }
     __syncthreads();
+    GS_STAMP(60);
     // unit lists of the bundles this workgroup will process (either direction), one wave per bundle
     {
-      int* ulen = (int*)TILES + wave * 128;              // scratch: the tiles are idle during the set-up
       const int nun = 16 * R;
       for (int d = 0; d < 2; ++d) {
         const int ns = sched[2 * GS_WMAX * GS_SMAX + d * GS_WMAX + gw];
@@ -434,29 +434,40 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
             if (dup) continue;
           }
           const int b0 = bun * 16;
-          for (int u = lane; u < nun; u += 64) {
-            const int slot = u / R, r = u - slot * R;
-            int len = 0;
-            if (b0 + slot < N) {
-              const int* rptr = relp + order[b0 + slot] * 8;
-              len = rptr[r + 1] - rptr[r];
+          // run lengths of this lane's (up to two) units, bucketed at 31; a unit's rank = units in longer buckets +
+          // earlier units of its own bucket (ballot prefix): deterministic, no LDS traffic
+          int kb[2], un[2];
+#pragma unroll
+          for (int p2 = 0; p2 < 2; ++p2) {
+            const int u = lane + 64 * p2;
+            un[p2] = u;
+            kb[p2] = -1;
+            if (u < nun) {
+              const int slot = u / R, r = u - slot * R;
+              int len = 0;
+              if (b0 + slot < N) {
+                const int* rptr = relp + order[b0 + slot] * 8;
+                len = rptr[r + 1] - rptr[r];
+              }
+              kb[p2] = len < 31 ? len : 31;
             }
-            ulen[u] = len;
           }
-          IGMC_WAVE_SYNC();
-          for (int u = lane; u < nun; u += 64) {
-            const int lu = ulen[u];
-            int rank = 0;
-#pragma unroll 5
-            for (int v = 0; v < nun; v += 4) {       // nun = 16 R: whole int4 groups, independent broadcast reads
-              const int4 l4 = *(const int4*)(ulen + v);
-              rank += (l4.x > lu) || (l4.x == lu && v < u);
-              rank += (l4.y > lu) || (l4.y == lu && v + 1 < u);
-              rank += (l4.z > lu) || (l4.z == lu && v + 2 < u);
-              rank += (l4.w > lu) || (l4.w == lu && v + 3 < u);
+          int base = 0, rank0 = 0, rank1 = 0;
+          const unsigned long long below = (1ull << lane) - 1ull;
+          for (int bk = 31; bk >= 0; --bk) {
+            const unsigned long long m0 = __ballot(kb[0] == bk), m1 = __ballot(kb[1] == bk);
+            const int c0 = __popcll(m0), c1 = __popcll(m1);
+            if (kb[0] == bk) rank0 = base + __popcll(m0 & below);
+            if (kb[1] == bk) rank1 = base + c0 + __popcll(m1 & below);
+            base += c0 + c1;
+          }
+#pragma unroll
+          for (int p2 = 0; p2 < 2; ++p2) {
+            const int u = un[p2];
+            if (u < nun) {
+              const int slot = u / R, r = u - slot * R;
+              ulist[bun * 16 * GS_NR + (p2 ? rank1 : rank0)] = (unsigned char)((slot << 3) | r);
             }
-            const int slot = u / R, r = u - slot * R;
-            ulist[bun * 16 * GS_NR + rank] = (unsigned char)((slot << 3) | r);
           }
           IGMC_WAVE_SYNC();
         }
@@ -473,7 +484,9 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int s = 0; s < 8; ++s) t0f[nt][s] = sT0[(4 * s + kq) * 32 + nt * 16 + li];
-      for (int bun = gw; bun < nbun; bun += nwt) {
+      // (clustered launches: EVERY member computes all of h_0 -- 13 small MFMA bundles -- which is cheaper than a
+      //  cluster barrier + exchange; all members store identical values)
+      for (int bun = wave; bun < nbun; bun += GS_NW) {
         const int b0 = bun * 16;
         const int prow = (b0 + li < N) ? b0 + li : N - 1;
         const int row = order[prow];
@@ -495,19 +508,13 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
             const float v0 = gs_tanh(c0[rr]), v1 = gs_tanh(c1[rr]);
             XA[orow * 32 + li] = v0;
             XA[orow * 32 + 16 + li] = v1;
-            if (TRAIN || cs > 1) {
+            if (TRAIN) {
               gs_pub(m.h[0] + (size_t)(nb + orow) * 32 + li, v0);
               gs_pub(m.h[0] + (size_t)(nb + orow) * 32 + 16 + li, v1);
             }
           }
         }
       }
-    }
-    if (cs > 1) {        // every member needs all of h_0
-      GS_CSTAMP(2);
-      gs_cluster_barrier(m.gs_bar, g, cs * (++nbar), m.gs_err);
-      GS_CSTAMP(3);
-      gs_reload(XA, m.h[0] + (size_t)nb * 32, N);
     }
     __syncthreads();
     if (tid < 64) sfeat[(tid >> 5) * 128 + (tid & 31)] = XA[((tid >> 5) ? cu : 0) * 32 + (tid & 31)];
@@ -676,11 +683,20 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
           // ~3/4 of them) are skipped wave-uniformly
         const float* w1 = P + m.off_l1w + 4 * lane;
         float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int q = 32 * wave; q < 32 * wave + 32; ++q) {
-          const float dzv = sdz[q];
-          if (dzv != 0.f) {
-            const float4 wv = *(const float4*)(w1 + (int64_t)q * 256);
-            s4.x += dzv * wv.x; s4.y += dzv * wv.y; s4.z += dzv * wv.z; s4.w += dzv * wv.w;
+        unsigned long long nz = __ballot(lane < 32 && sdz[32 * wave + (lane & 31)] != 0.f);   // this wave's live units
+        while (nz) {                                   // wave-uniform: 8 weight rows in flight per round
+          int q[8];
+          float4 wv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            q[u] = nz ? (int)__builtin_ctzll(nz) : -1;
+            if (nz) nz &= nz - 1;
+            wv[u] = (q[u] >= 0) ? *(const float4*)(w1 + (int64_t)(32 * wave + q[u]) * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const float dzv = (q[u] >= 0) ? sdz[32 * wave + q[u]] : 0.f;
+            s4.x += dzv * wv[u].x; s4.y += dzv * wv[u].y; s4.z += dzv * wv[u].z; s4.w += dzv * wv[u].w;
           }
         }
         *(float4*)(TILES + wave * 256 + 4 * lane) = s4;
@@ -901,7 +917,7 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
           }
           __syncthreads();
         }
-        if (cs > 1) {    // every member needs all of dPre_{l-1}
+        if (cs > 1 && l > 1) {    // every member needs all of dPre_{l-1} (dPre_0 is only used row by row, below)
           gs_cluster_barrier(m.gs_bar, g, cs * (++nbar), m.gs_err);
           gs_reload(dst, m.dpre[l - 1] + (size_t)nb * 32, N);
           __syncthreads();
@@ -912,18 +928,26 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
 
       // ============================================================== layer-0 table gradient (dPre_0 is in XB)
       // T0'[c][f] = sum_i [cnt | onehot | 1](i, c) dPre_0[i][f]; wave = (code half, feature half), K = all rows
-      {
+      {   // K = the rows of THIS workgroup's bundles (their dPre_0 is in XB; clustered: the other members add theirs
+          // through their own partial slots)
         const int m2 = wave >> 1, wn = wave & 1;
         const int code = m2 * 16 + li;
-#pragma unroll 4
-        for (int s = cm; 4 * s < N; s += cs) {
-          const int row = 4 * s + kq;
-          const int rc = (row < N) ? row : N - 1;
-          const int cv = (cnt[rc * rlp + ((code < RL) ? (code >> 1) : 0)] >> ((code & 1) * 16)) & 0xFFFF;
-          float av = (code < RL) ? (float)cv : ((code == RL + slab[rc] || code == RL + L) ? 1.f : 0.f);
-          if (row >= N) av = 0.f;
-          const float bv = XB[rc * 32 + wn * 16 + li];
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc0, 0, 0, 0);
+        for (int w2 = 0; w2 < GS_NW; ++w2) {
+          const int gw2 = cm * GS_NW + w2;
+          const int ns2 = sched[2 * GS_WMAX * GS_SMAX + GS_WMAX + gw2];
+          for (int si = 0; si < ns2; ++si) {
+            const int b0 = sched[(GS_WMAX + gw2) * GS_SMAX + si] * 16;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+              const int prow = b0 + 4 * s4 + kq;
+              const int rc = order[(prow < N) ? prow : N - 1];
+              const int cv = (cnt[rc * rlp + ((code < RL) ? (code >> 1) : 0)] >> ((code & 1) * 16)) & 0xFFFF;
+              float av = (code < RL) ? (float)cv : ((code == RL + slab[rc] || code == RL + L) ? 1.f : 0.f);
+              if (prow >= N) av = 0.f;
+              const float bv = XB[rc * 32 + wn * 16 + li];
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc0, 0, 0, 0);
+            }
+          }
         }
       }
       first_graph = false;

@@ -51,8 +51,8 @@ def main():
           '(layer start %d)  reduce %d' % (c[25] - c[24], c[26] - c[25], c[27] - c[26], c[28] - c[27], c[29] - c[28],
                                           c[30] - c[24], c[24] - c[7], c[31] - c[30]))
     _extra(c)
-    print('setup: kernel start -> T0 staged %d | row starts/labels loaded %d | histogram %d | ranking %d | schedule %d' % (
-        c[56] - c[0], c[57] - c[56], c[58] - c[57], c[59] - c[58], c[1] - c[59]))
+    print('setup: kernel start -> T0 staged %d | row starts/labels loaded %d | histogram %d | ranking %d | schedule %d | unit lists %d' % (
+        c[56] - c[0], c[57] - c[56], c[58] - c[57], c[59] - c[58], c[60] - c[59], c[1] - c[60]))
 
 
 def _extra(c):
