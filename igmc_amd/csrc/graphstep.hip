@@ -771,6 +771,11 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
           for (int nt = 0; nt < GS_WN; ++nt) wacc[m2][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         __syncthreads();
         const int ns = sched[2 * GS_WMAX * GS_SMAX + GS_WMAX + gw];
+        // clustered launches give every wave at most ONE bundle per layer: the four tiles of the workgroup then stay
+        // in LDS until all waves are done, and the table product is split by OUTPUT tile (wave w: 6 of the 24 tiles,
+        // K = the 64 rows of the four bundles) -- no cross-wave reduction at all
+        const int* nsb = sched + 2 * GS_WMAX * GS_SMAX + GS_WMAX + cm * GS_NW;
+        const bool split_out = nsb[0] <= 1 && nsb[1] <= 1 && nsb[2] <= 1 && nsb[3] <= 1;
         if (l == 3) GS_STAMP(23);
 #pragma unroll 1
         for (int si = 0; si < ns; ++si) {
@@ -819,6 +824,7 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
           }
           if (l == 3 && si == 0) GS_STAMP(27);
           // weight-gradient table: K = the 16 rows of the bundle (4 k-steps), 2 x GS_WN output tiles
+          if (!split_out)
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const int prk = b0 + 4 * s + kq_;
@@ -861,61 +867,103 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
         }
         if (l == 3) GS_STAMP(30);
         if (l == 3) GS_WSTAMP(36);
-        // ---- combine the 4 waves' tables as (w0 + w1) + (w2 + w3) through LDS (tile + h-chunk regions are free now;
-        //      element q of lane x lives at [q][x]: conflict-free, identical in every wave) and emit
-        //      [dW_r (r < R) | d root] in the layout of the layer-0 table: row = r*32 + f_in (resp. R*32 + f_in)
-        __syncthreads();
-        {
-          float* buf = TILES + (wave >> 1) * (2 * GS_WN * 4 * 64);
-          if (wave & 1) {
+        if (split_out) {
+          __syncthreads();                             // the four bundle tiles / h chunks of the workgroup are complete
+          f32x4 w6[6];
 #pragma unroll
-            for (int m2 = 0; m2 < 2; ++m2)
+          for (int i6 = 0; i6 < 6; ++i6) w6[i6] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+          for (int wb = 0; wb < GS_NW; ++wb) {
+            if (nsb[wb] == 0) continue;
+            const int b0 = sched[(GS_WMAX + cm * GS_NW + wb) * GS_SMAX] * 16;
+            const float* Tb = TILES + wb * 16 * GS_TP;
+            const float* Hb = HSS + wb * 16 * GS_HP;
 #pragma unroll
-              for (int nt = 0; nt < GS_WN; ++nt)
+            for (int s4 = 0; s4 < 4; ++s4) {
+              const int prk = b0 + 4 * s4 + kq;
+              const int rowK = order[(prk < N) ? prk : N - 1];
+              const float a0 = Hb[(4 * s4 + kq) * GS_HP + li], a1 = Hb[(4 * s4 + kq) * GS_HP + 16 + li];
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) buf[((m2 * GS_WN + nt) * 4 + rr) * 64 + lane] = wacc[m2][nt][rr];
-          }
-          __syncthreads();
-          if (!(wave & 1)) {
-#pragma unroll
-            for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-              for (int nt = 0; nt < GS_WN; ++nt)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) wacc[m2][nt][rr] += buf[((m2 * GS_WN + nt) * 4 + rr) * 64 + lane];
-          }
-          __syncthreads();
-          if (wave == 2) {
-#pragma unroll
-            for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-              for (int nt = 0; nt < GS_WN; ++nt)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) TILES[((m2 * GS_WN + nt) * 4 + rr) * 64 + lane] = wacc[m2][nt][rr];
-          }
-          __syncthreads();
-          if (wave == 0) {
-            float* wp = wpart + (kq * 4) * 32 + li;          // + (row block)*1024 + m2*512 + rr*32 + (nt & 1)*16
-#pragma unroll
-            for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-              for (int nt = 0; nt < GS_WN; ++nt) {
-                const int r = nt >> 1;                        // 32-column block: relation, or GS_NR = root
-                if (r >= R && r < GS_NR) continue;
-                float* pp = wp + (r < R ? r : R) * 1024 + m2 * 512 + (nt & 1) * 16;
-                float v[4];
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) v[rr] = wacc[m2][nt][rr] + TILES[((m2 * GS_WN + nt) * 4 + rr) * 64 + lane];
-                if (first_graph) {
-#pragma unroll
-                  for (int rr = 0; rr < 4; ++rr) pp[rr * 32] = v[rr];
-                } else {
-#pragma unroll
-                  for (int rr = 0; rr < 4; ++rr) pp[rr * 32] += v[rr];
-                }
+              for (int i6 = 0; i6 < 6; ++i6) {
+                const int tt = wave * 6 + i6, m2 = tt / GS_WN, nt = tt % GS_WN;     // compile-time per (wave-uniform) i6
+                const float bv = (nt < GS_NR * 2) ? Tb[(4 * s4 + kq) * GS_TP + nt * 16 + li]
+                                                  : src[rowK * 32 + (nt - GS_NR * 2) * 16 + li];
+                w6[i6] = __builtin_amdgcn_mfma_f32_16x16x4f32(m2 ? a1 : a0, bv, w6[i6], 0, 0, 0);
               }
+            }
+          }
+#pragma unroll
+          for (int i6 = 0; i6 < 6; ++i6) {
+            const int tt = wave * 6 + i6, m2 = tt / GS_WN, nt = tt % GS_WN;
+            const int r = nt >> 1;                      // 32-column block: relation, or GS_NR = root
+            if (r >= R && r < GS_NR) continue;
+            float* pp = wpart + (kq * 4) * 32 + li + (r < R ? r : R) * 1024 + m2 * 512 + (nt & 1) * 16;
+            if (first_graph) {
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) pp[rr * 32] = w6[i6][rr];
+            } else {
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) pp[rr * 32] += w6[i6][rr];
+            }
           }
           __syncthreads();
+        } else {
+        // ---- combine the 4 waves' tables as (w0 + w1) + (w2 + w3) through LDS (tile + h-chunk regions are free now;
+          //      element q of lane x lives at [q][x]: conflict-free, identical in every wave) and emit
+          //      [dW_r (r < R) | d root] in the layout of the layer-0 table: row = r*32 + f_in (resp. R*32 + f_in)
+          __syncthreads();
+          {
+            float* buf = TILES + (wave >> 1) * (2 * GS_WN * 4 * 64);
+            if (wave & 1) {
+  #pragma unroll
+              for (int m2 = 0; m2 < 2; ++m2)
+  #pragma unroll
+                for (int nt = 0; nt < GS_WN; ++nt)
+  #pragma unroll
+                  for (int rr = 0; rr < 4; ++rr) buf[((m2 * GS_WN + nt) * 4 + rr) * 64 + lane] = wacc[m2][nt][rr];
+            }
+            __syncthreads();
+            if (!(wave & 1)) {
+  #pragma unroll
+              for (int m2 = 0; m2 < 2; ++m2)
+  #pragma unroll
+                for (int nt = 0; nt < GS_WN; ++nt)
+  #pragma unroll
+                  for (int rr = 0; rr < 4; ++rr) wacc[m2][nt][rr] += buf[((m2 * GS_WN + nt) * 4 + rr) * 64 + lane];
+            }
+            __syncthreads();
+            if (wave == 2) {
+  #pragma unroll
+              for (int m2 = 0; m2 < 2; ++m2)
+  #pragma unroll
+                for (int nt = 0; nt < GS_WN; ++nt)
+  #pragma unroll
+                  for (int rr = 0; rr < 4; ++rr) TILES[((m2 * GS_WN + nt) * 4 + rr) * 64 + lane] = wacc[m2][nt][rr];
+            }
+            __syncthreads();
+            if (wave == 0) {
+              float* wp = wpart + (kq * 4) * 32 + li;          // + (row block)*1024 + m2*512 + rr*32 + (nt & 1)*16
+  #pragma unroll
+              for (int m2 = 0; m2 < 2; ++m2)
+  #pragma unroll
+                for (int nt = 0; nt < GS_WN; ++nt) {
+                  const int r = nt >> 1;                        // 32-column block: relation, or GS_NR = root
+                  if (r >= R && r < GS_NR) continue;
+                  float* pp = wp + (r < R ? r : R) * 1024 + m2 * 512 + (nt & 1) * 16;
+                  float v[4];
+  #pragma unroll
+                  for (int rr = 0; rr < 4; ++rr) v[rr] = wacc[m2][nt][rr] + TILES[((m2 * GS_WN + nt) * 4 + rr) * 64 + lane];
+                  if (first_graph) {
+  #pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) pp[rr * 32] = v[rr];
+                  } else {
+  #pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) pp[rr * 32] += v[rr];
+                  }
+                }
+            }
+            __syncthreads();
+          }
         }
         if (cs > 1 && l > 1) {    // every member needs all of dPre_{l-1} (dPre_0 is only used row by row, below)
           gs_cluster_barrier(m.gs_bar, g, cs * (++nbar), m.gs_err);
