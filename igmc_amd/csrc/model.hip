@@ -1533,11 +1533,11 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_partials(ModelDev m, int 
 
 // relation-space tables of graphstep.hip: ts_raw[l][i] = sum over the workgroups' partials (fixed order);
 // 64 outputs per block, the 4 waves split the partial slices
-__global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_ts(ModelDev m, int nparts, int stride, int B) {
+__device__ __forceinline__ void reduce_ts_body(const ModelDev& m, int nparts, int stride, int B, int blk) {
   __shared__ float sred[4][64];
   const int ts = m.ts_stride, rows0 = m.R * m.L + m.L + 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int o = blockIdx.x * 64 + lane;
+  const int o = blk * 64 + lane;
   const int l = o / ts, i = o % ts;
   float s = 0.f;
   const bool ok = l < 4 && (l > 0 || i < rows0 * 32);
@@ -1560,6 +1560,22 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_ts(ModelDev m, int nparts
   sred[wave][lane] = s;
   __syncthreads();
   if (wave == 0 && ok) m.ts_raw[o] = (sred[0][lane] + sred[1][lane]) + (sred[2][lane] + sred[3][lane]);
+}
+
+__global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_ts(ModelDev m, int nparts, int stride, int B) {
+  reduce_ts_body(m, nparts, stride, B, blockIdx.x);
+}
+
+// Both consumers of k_graph_step's outputs in ONE launch (they are independent of each other): the first `nlin`
+// workgroups form d lin1 / d lin2 (batched product over the subgraphs), the others sum the relation-space tables.
+__global__ __launch_bounds__(IGMC_BLOCK) void k_tail_ts(BatchDev b, ModelDev m, const float* __restrict__ P,
+                                                          float grad_scale, float mult, float drop_scale,
+                                                          float* __restrict__ grad, int nlin, int nparts, int stride,
+                                                          int B) {
+  if ((int)blockIdx.x < nlin)
+    head_bwd_w_body(b, m, P, nullptr, 1, grad_scale, mult, drop_scale, grad, blockIdx.x & 7, blockIdx.x >> 3);
+  else
+    reduce_ts_body(m, nparts, stride, B, blockIdx.x - nlin);
 }
 
 struct FinishArgs {
@@ -2105,9 +2121,8 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
     const int gstride = (cs > 1) ? ((B + 7) & ~7) : IGMC_TS_BLOCKS;
     const int gg = (cs > 1) ? cs * gstride : igmc_gs_grid(B);
     igmc_launch_graph_step(m, b, P, B, 1, use_flags, lay, inj_mask, seed, step, mult, grad_scale, out, stream);
-    IGMC_PLAUNCH("k_wgrad_head", k_wgrad_head, dim3(8 * ny, 1), IGMC_BLOCK, 0, stream, b, m, (const float*)P,
-                 (const float*)nullptr, 1, grad_scale, mult, 2.f, grad, 0);
-    IGMC_PLAUNCH("k_reduce_ts", k_reduce_ts, (4 * m.ts_stride + 63) / 64, IGMC_BLOCK, 0, stream, m, gg, gstride, B);
+    IGMC_PLAUNCH("k_tail_ts", k_tail_ts, 8 * ny + (4 * m.ts_stride + 63) / 64, IGMC_BLOCK, 0, stream, b, m,
+                 (const float*)P, grad_scale, mult, 2.f, grad, 8 * ny, gg, gstride, B);
     if (adam) {
       at.enabled = 1;
       at.b = b;
