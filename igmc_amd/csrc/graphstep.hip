@@ -477,6 +477,18 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
     GS_STAMP(1);
     GS_CSTAMP(1);
 
+    // weights of the NEXT conv layer to be staged: requested a phase ahead (before layer 0 / before the cluster
+    // barrier of the previous layer), so that their round trip overlaps with compute and with the barrier
+    float4 wb4[4], wr4;
+    float watt = 0.f;
+    auto wpre = [&](int l) {
+      const float* basis = P + m.off_basis[l];
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) wb4[bb] = *(const float4*)(basis + bb * 1024 + 4 * tid);
+      wr4 = *(const float4*)(P + m.off_root[l] + 4 * tid);
+      if (tid < na) watt = P[m.off_att[l] + tid];
+    };
+    wpre(1);
     // ================================================================ layer 0: h0 = tanh([cnt | onehot(label) | 1] @ T0)
     {
       float t0f[2][8];
@@ -527,12 +539,9 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
       float* dst = (l & 1) ? XB : XA;
       // B operand of the layer, staged once: [W_0; ..; W_R-1; 0..; root], W_r = sum_b att[r,b] basis_b
       {
-        const float* basis = P + m.off_basis[l];
-        if (tid < na) s_att[tid] = P[m.off_att[l] + tid];
-        float4 b4[4];
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) b4[bb] = *(const float4*)(basis + bb * 1024 + 4 * tid);
-        const float4 r4 = *(const float4*)(P + m.off_root[l] + 4 * tid);
+        if (tid < na) s_att[tid] = watt;
+        const float4 (&b4)[4] = wb4;
+        const float4 r4 = wr4;
         __syncthreads();
         float* sW = (float*)sW2;
         const int f = tid >> 3, n0 = (4 * tid) & 31;           // 4 consecutive outputs n0..n0+3 of input feature f
@@ -607,6 +616,7 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
       }
       if (l == 1) GS_STAMP(20);
       if (l == 1) GS_WSTAMP(32);
+      if (l < 3) wpre(l + 1);
       if (cs > 1) {      // every member needs all of h_l
         gs_cluster_barrier(m.gs_bar, g, cs * (++nbar), m.gs_err);
         gs_reload(dst, m.h[l] + (size_t)nb * 32, N);
@@ -724,12 +734,9 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
         const float* src = (l & 1) ? XA : XB;          // dPre_l
         float* dst = (l & 1) ? XB : XA;                // dPre_{l-1}
         {   // B operand of the layer, staged once: [W_r^T ; root^T]: element (k = r*32 + f_out, n = f_in) = W_r[f_in][f_out]
-          const float* basis = P + m.off_basis[l];
-          if (tid < na) s_att[tid] = P[m.off_att[l] + tid];
-          float4 b4[4];
-#pragma unroll
-          for (int bb = 0; bb < 4; ++bb) b4[bb] = *(const float4*)(basis + bb * 1024 + 4 * tid);
-          const float4 r4 = *(const float4*)(P + m.off_root[l] + 4 * tid);
+          if (tid < na) s_att[tid] = watt;
+          const float4 (&b4)[4] = wb4;
+          const float4 r4 = wr4;
           // d bias_l = column sums of dPre_l (fixed order: 8 row classes, then the classes in order)
           {
             const int n = tid & 31, part = tid >> 5;
@@ -965,6 +972,7 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
             __syncthreads();
           }
         }
+        if (l > 1) wpre(l - 1);
         if (cs > 1 && l > 1) {    // every member needs all of dPre_{l-1} (dPre_0 is only used row by row, below)
           gs_cluster_barrier(m.gs_bar, g, cs * (++nbar), m.gs_err);
           gs_reload(dst, m.dpre[l - 1] + (size_t)nb * 32, N);
