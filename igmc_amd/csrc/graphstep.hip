@@ -136,22 +136,39 @@ __device__ __forceinline__ void gs_gather(const BatchDev& b, const float* src, c
 #pragma unroll 1
       for (int c0 = beg; c0 < end; c0 += 16) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (c0 + 4 * q < end) {
-            const float* p0 = gs_rowptr(gs_qbcast<0>(w[q]), src, zrow, nb, j);
-            const float* p1 = gs_rowptr(gs_qbcast<1>(w[q]), src, zrow, nb, j);
-            const float* p2 = gs_rowptr(gs_qbcast<2>(w[q]), src, zrow, nb, j);
-            const float* p3 = gs_rowptr(gs_qbcast<3>(w[q]), src, zrow, nb, j);
-            const float4 a0 = *(const float4*)p0, b0v = *(const float4*)(p0 + 4);
-            const float4 a1 = *(const float4*)p1, b1v = *(const float4*)(p1 + 4);
-            const float4 a2 = *(const float4*)p2, b2v = *(const float4*)(p2 + 4);
-            const float4 a3 = *(const float4*)p3, b3v = *(const float4*)(p3 + 4);
-            tx[0] += (a0.x + a1.x) + (a2.x + a3.x); tx[1] += (a0.y + a1.y) + (a2.y + a3.y);
-            tx[2] += (a0.z + a1.z) + (a2.z + a3.z); tx[3] += (a0.w + a1.w) + (a2.w + a3.w);
-            tx[4] += (b0v.x + b1v.x) + (b2v.x + b3v.x); tx[5] += (b0v.y + b1v.y) + (b2v.y + b3v.y);
-            tx[6] += (b0v.z + b1v.z) + (b2v.z + b3v.z); tx[7] += (b0v.w + b1v.w) + (b2v.w + b3v.w);
+        for (int h = 0; h < 2; ++h) {              // two 8-entry halves: up to 16 row loads in flight per wait
+          if (c0 + 8 * h >= end) break;
+          const uint32_t wa = w[2 * h], wb = w[2 * h + 1];
+          const bool two = c0 + 8 * h + 4 < end;   // second group of the half present (quad-uniform)
+          const float* p0 = gs_rowptr(gs_qbcast<0>(wa), src, zrow, nb, j);
+          const float* p1 = gs_rowptr(gs_qbcast<1>(wa), src, zrow, nb, j);
+          const float* p2 = gs_rowptr(gs_qbcast<2>(wa), src, zrow, nb, j);
+          const float* p3 = gs_rowptr(gs_qbcast<3>(wa), src, zrow, nb, j);
+          const float4 a0 = *(const float4*)p0, b0v = *(const float4*)(p0 + 4);
+          const float4 a1 = *(const float4*)p1, b1v = *(const float4*)(p1 + 4);
+          const float4 a2 = *(const float4*)p2, b2v = *(const float4*)(p2 + 4);
+          const float4 a3 = *(const float4*)p3, b3v = *(const float4*)(p3 + 4);
+          float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), a5 = a4, a6 = a4, a7 = a4, b4v = a4, b5v = a4, b6v = a4, b7v = a4;
+          if (two) {
+            const float* p4 = gs_rowptr(gs_qbcast<0>(wb), src, zrow, nb, j);
+            const float* p5 = gs_rowptr(gs_qbcast<1>(wb), src, zrow, nb, j);
+            const float* p6 = gs_rowptr(gs_qbcast<2>(wb), src, zrow, nb, j);
+            const float* p7 = gs_rowptr(gs_qbcast<3>(wb), src, zrow, nb, j);
+            a4 = *(const float4*)p4; b4v = *(const float4*)(p4 + 4);
+            a5 = *(const float4*)p5; b5v = *(const float4*)(p5 + 4);
+            a6 = *(const float4*)p6; b6v = *(const float4*)(p6 + 4);
+            a7 = *(const float4*)p7; b7v = *(const float4*)(p7 + 4);
           }
-          w[q] = gs_entry<FLAGS, TRANS>(b, c0 + 16 + 4 * q + j, end);
+          w[2 * h] = gs_entry<FLAGS, TRANS>(b, c0 + 16 + 8 * h + j, end);          // next iteration's entries
+          w[2 * h + 1] = gs_entry<FLAGS, TRANS>(b, c0 + 16 + 8 * h + 4 + j, end);
+          tx[0] += ((a0.x + a1.x) + (a2.x + a3.x)) + ((a4.x + a5.x) + (a6.x + a7.x));
+          tx[1] += ((a0.y + a1.y) + (a2.y + a3.y)) + ((a4.y + a5.y) + (a6.y + a7.y));
+          tx[2] += ((a0.z + a1.z) + (a2.z + a3.z)) + ((a4.z + a5.z) + (a6.z + a7.z));
+          tx[3] += ((a0.w + a1.w) + (a2.w + a3.w)) + ((a4.w + a5.w) + (a6.w + a7.w));
+          tx[4] += ((b0v.x + b1v.x) + (b2v.x + b3v.x)) + ((b4v.x + b5v.x) + (b6v.x + b7v.x));
+          tx[5] += ((b0v.y + b1v.y) + (b2v.y + b3v.y)) + ((b4v.y + b5v.y) + (b6v.y + b7v.y));
+          tx[6] += ((b0v.z + b1v.z) + (b2v.z + b3v.z)) + ((b4v.z + b5v.z) + (b6v.z + b7v.z));
+          tx[7] += ((b0v.w + b1v.w) + (b2v.w + b3v.w)) + ((b4v.w + b5v.w) + (b6v.w + b7v.w));
         }
       }
     }
