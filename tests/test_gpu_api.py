@@ -286,3 +286,36 @@ def test_full_size_headline_config_properties(monkeypatch):
     # (Adam normalises every gradient: parameters whose gradient is ~0 may step in different directions)
     diff = (runs['per_layer'][1] - runs['per_graph'][1]).abs()
     assert float(diff.max()) < 2e-3 and float(diff.mean()) < 2e-5, (float(diff.max()), float(diff.mean()))
+
+
+@pytest.mark.parametrize('batch', [100, 130])
+def test_graph_step_other_cluster_sizes(monkeypatch, batch):
+    """Batch 100 -> 2 workgroups per subgraph, batch 130 -> one workgroup per subgraph with workgroups looping over
+    subgraphs (accumulating partial tables): both must walk the per-layer kernels' trajectory."""
+    import torch
+    from igmc_amd import preprocessing
+    from igmc_amd.models import IGMC
+    from igmc_amd.stepgraph import StepGraph
+    from igmc_amd.train_eval import FlatAdam
+    from igmc_amd.util_functions import MyDynamicDataset
+    split = preprocessing.create_trainvaltest_split('ml_1m', 1234, True, verbose=False)
+    (_, _, A, tr_l, tr_u, tr_v, _, _, _, _, _, _, cv) = split
+    ds = MyDynamicDataset('data/t/full2', A, (tr_u, tr_v), tr_l, 1, 1.0, 100, None, None, cv, device=0, seed=1)
+    perm = torch.randperm(len(ds), generator=torch.Generator().manual_seed(4))[:batch * 4]
+    losses = {}
+    for name, env in (('per_layer', '0'), ('per_graph', '1')):
+        monkeypatch.setenv('IGMC_GRAPH_STEP', env)
+        model = IGMC(ds, latent_dim=[32, 32, 32, 32], num_relations=len(cv), num_bases=4, regression=True,
+                     adj_dropout=0.2, seed=1).to('cuda')
+        torch.manual_seed(1)
+        model.reset_parameters()
+        opt = FlatAdam(model, lr=1e-3)
+        sg = StepGraph(model, opt, ds, batch, 0.001, use_graph=False, overlap=False)
+        sg.begin_epoch(perm, 1)
+        out = []
+        for _ in range(4):
+            sg.step()
+            out.append(float(sg.loss[0].item()))
+        sg.check()
+        losses[name] = out
+    np.testing.assert_allclose(losses['per_layer'], losses['per_graph'], rtol=5e-5)
