@@ -152,13 +152,21 @@ def main():
         sg.step()
         return sg
 
-    for _ in range(args.warmup):
-        step()
+    def run(nsteps):                    # exactly `nsteps` optimisation steps, epoch after epoch
+        while nsteps > 0:
+            if state['i'] % steps_avail == 0:
+                state['epoch'] += 1
+                sg.begin_epoch(perm, state['epoch'])
+            chunk = min(nsteps, steps_avail - state['i'] % steps_avail)
+            sg.steps(chunk)
+            state['i'] += chunk
+            nsteps -= chunk
+
+    run(args.warmup)
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run(args.steps)
     parallel.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0

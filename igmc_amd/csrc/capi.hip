@@ -502,6 +502,9 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   d.ts_stride = (d.R * 32 + 33) * 32;
   if (d.R <= 5)
     fail |= M.get(&d.ts_part, (size_t)4 * IGMC_TS_BLOCKS * d.ts_stride) | M.get(&d.ts_raw, (size_t)4 * d.ts_stride);
+  d.gs_ll = nullptr;
+  d.gs_ll_stride = N * 32;
+  if (d.R <= 5) fail |= M.get(&d.gs_ll, 5 * d.gs_ll_stride);
   fail |= M.get(&d.gs_bar, 2 * Bc + 1);
   d.gs_err = d.gs_bar ? d.gs_bar + 2 * Bc : nullptr;
   fail |= M.get(&d.wg_part, (size_t)4 * IGMC_WG_BLOCKS * igmc_wg_stride()) |
@@ -534,6 +537,7 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   }
   HIPCHECK(hipMemset(m->done_ctr, 0, 8 * sizeof(int)));
   HIPCHECK(hipMemset(m->d.gs_bar, 0, (2 * (size_t)max_graphs + 1) * sizeof(int)));
+  if (m->d.gs_ll) HIPCHECK(hipMemset(m->d.gs_ll, 0, 5 * m->d.gs_ll_stride * sizeof(unsigned long long)));   // tag 0 = never valid
   if (igmc_model_prepare(d)) {
     M.release();
     delete m;
@@ -672,7 +676,8 @@ extern "C" int igmc_model_check(igmc_model* m, void* stream) {
     HIPCHECK(hipMemcpy(&v, m->d.gs_err, sizeof(int), hipMemcpyDeviceToHost));
     if (v) {
       HIPCHECK(hipMemset(m->d.gs_bar, 0, (2 * (size_t)m->d.graph_cap + 1) * sizeof(int)));
-      IGMC_FAIL("a workgroup-cluster barrier of k_graph_step timed out (GPU shared with another job?): results of the "
+      if (m->d.gs_ll) HIPCHECK(hipMemset(m->d.gs_ll, 0, 5 * m->d.gs_ll_stride * sizeof(unsigned long long)));
+      IGMC_FAIL("a workgroup-cluster exchange of k_graph_step timed out (GPU shared with another job?): results of the "
                 "affected steps are invalid; set IGMC_GS_CLUSTER=1 or IGMC_GRAPH_STEP=0");
     }
   }

@@ -181,14 +181,19 @@ __device__ __forceinline__ void gs_gather(const BatchDev& b, const float* src, c
 // ---- cluster of workgroups working on ONE subgraph --------------------------------------------------------
 // With B = 50 subgraphs and one workgroup each, 206 of the 256 CUs idle.  `cs` workgroups (same XCD: block index
 // = subgraph + stride * member, stride a multiple of 8) therefore share a subgraph: the bundles of every layer are
-// scheduled over all their waves, each member publishes the rows it produced (h_l / dPre_l in HBM), the members
-// meet at a flag barrier and every member reloads the whole 26 KB matrix into its LDS.  Barrier = an arrival
-// counter per subgraph (agent-scope release / acquire), spins are BOUNDED (a missing member -- which a grid of
-// <= 224 workgroups of one-per-CU size excludes on this part -- raises gs_err instead of hanging the GPU); the
-// last member to leave the kernel resets the counters.
-// Exchanged rows are written and read with AGENT-scope relaxed atomics (sc1 accesses: they meet in the coherent
-// level without any cache-wide maintenance); an agent-scope release / acquire fence pair instead writes back and
-// invalidates the whole L2 of the XCD at every barrier of every workgroup and slowed the whole kernel 2-3x.
+// scheduled over all their waves, each member publishes the rows it produced and every member loads the whole
+// [N][32] matrix back into its LDS.
+// The exchange is flag-in-data: every float travels as one 8-byte word {value, tag}, stored and loaded with
+// agent-scope (sc1) relaxed atomics -- 8-byte accesses are single-copy atomic, so a word whose tag is the tag of
+// THIS exchange carries this exchange's value, and the readers simply poll the data: one store -> load hand-off
+// instead of  stores -> wait for their completion -> arrival counter -> poll the counter -> loads  (~7 us per
+// exchange with the counter barrier, about half of it round trips that carry no data).  tag = 8 * launch sequence
+// number + exchange index + 1: the sequence number lives in HBM and is advanced by the workgroup that finishes the
+// launch LAST (by then every workgroup has read it); buffers start zeroed and 0 is never a tag.  Polls are BOUNDED:
+// a missing member -- which a grid of <= 224 workgroups of one-per-CU size excludes on this part -- raises gs_err
+// instead of hanging the GPU.
+// (sc1 accesses meet in the coherent level without any cache-wide maintenance; agent-scope release / acquire fences
+// instead write back and invalidate the whole L2 of the XCD and slowed the whole kernel 2-3x.)
 __device__ __forceinline__ void gs_pub(float* p, float v) {
 #ifndef IGMC_HIPEMU
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -203,60 +208,64 @@ __device__ __forceinline__ float gs_sub(const float* p) {
   return *p;
 #endif
 }
-// Reload of the whole [N][32] matrix after a cluster barrier: agent-scope (sc1) 16-byte loads, all of a thread's
-// requests in flight before the single wait (the relaxed-atomic dword form is serialised by the compiler: ~9 us
-// per exchange); N <= 320 rows = 2560 float4 = at most 10 per thread.
-__device__ __forceinline__ void gs_reload(float* dst, const float* gsrc, int N) {
+__device__ __forceinline__ void gs_ll_pub(unsigned long long* p, float v, uint32_t tag) {
 #ifndef IGMC_HIPEMU
-  f32x4 v0, v1, v2, v3, v4, v5, v6, v7, v8, v9;
-  const f32x4* gp = (const f32x4*)gsrc;
-  const int n4 = N * 8, t0 = (int)threadIdx.x;
-#define GS_LD(V, U)                                                                            \
-  {                                                                                            \
-    const f32x4* p = gp + ((t0 + (U) * GS_THREADS < n4) ? t0 + (U) * GS_THREADS : 0);          \
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(V) : "v"(p) : "memory");         \
-  }
-  GS_LD(v0, 0) GS_LD(v1, 1) GS_LD(v2, 2) GS_LD(v3, 3) GS_LD(v4, 4)
-  GS_LD(v5, 5) GS_LD(v6, 6) GS_LD(v7, 7) GS_LD(v8, 8) GS_LD(v9, 9)
-#undef GS_LD
-  asm volatile("s_waitcnt vmcnt(0)"
-               : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "+v"(v9)
-               :
-               : "memory");
-  f32x4* d4 = (f32x4*)dst;
-  if (t0 < n4) d4[t0] = v0;
-  if (t0 + GS_THREADS < n4) d4[t0 + GS_THREADS] = v1;
-  if (t0 + 2 * GS_THREADS < n4) d4[t0 + 2 * GS_THREADS] = v2;
-  if (t0 + 3 * GS_THREADS < n4) d4[t0 + 3 * GS_THREADS] = v3;
-  if (t0 + 4 * GS_THREADS < n4) d4[t0 + 4 * GS_THREADS] = v4;
-  if (t0 + 5 * GS_THREADS < n4) d4[t0 + 5 * GS_THREADS] = v5;
-  if (t0 + 6 * GS_THREADS < n4) d4[t0 + 6 * GS_THREADS] = v6;
-  if (t0 + 7 * GS_THREADS < n4) d4[t0 + 7 * GS_THREADS] = v7;
-  if (t0 + 8 * GS_THREADS < n4) d4[t0 + 8 * GS_THREADS] = v8;
-  if (t0 + 9 * GS_THREADS < n4) d4[t0 + 9 * GS_THREADS] = v9;
+  __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
 #else
-  for (int i = threadIdx.x; i < N * 32; i += GS_THREADS) dst[i] = gsrc[i];
+  (void)p; (void)v; (void)tag;
 #endif
 }
-
-__device__ __forceinline__ void gs_cluster_barrier(int* bar, int g, int target, int* err) {
+// All N x 32 words of an exchange into dst[N][32]: 16-byte sc1 loads (two words each), every pending request of a
+// thread in flight before the single wait; words with another tag are requested again.  N <= 320 rows = 5120 pairs =
+// at most 20 per thread.
+__device__ __forceinline__ void gs_ll_reload(float* dst, const unsigned long long* gsrc, int N, uint32_t tag, int* err) {
 #ifndef IGMC_HIPEMU
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // this wave's published rows have left the CU
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(bar + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int it = 0;
-    while (__hip_atomic_load(bar + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++it > (1 << 22)) {
-        *err = 1;
-        break;
-      }
-    }
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4* gp = (const u32x4*)gsrc;
+  float2* d2 = (float2*)dst;
+  const int n2 = N * 16, t0 = (int)threadIdx.x;
+  uint32_t pend = 0;
+#pragma unroll
+  for (int u = 0; u < 20; ++u) pend |= (t0 + u * GS_THREADS < n2) ? (1u << u) : 0u;
+  u32x4 v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, v7 = 0, v8 = 0, v9 = 0;
+  u32x4 v10 = 0, v11 = 0, v12 = 0, v13 = 0, v14 = 0, v15 = 0, v16 = 0, v17 = 0, v18 = 0, v19 = 0;
+#define GS_LD(V, U)                                                                            \
+  if (pend & (1u << (U))) {                                                                    \
+    const u32x4* p = gp + t0 + (U) * GS_THREADS;                                               \
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(V) : "v"(p) : "memory");         \
   }
-  __syncthreads();
+#define GS_CK(V, U)                                                                            \
+  if ((pend & (1u << (U))) && V.y == tag && V.w == tag) {                                      \
+    d2[t0 + (U) * GS_THREADS] = make_float2(__uint_as_float(V.x), __uint_as_float(V.z));       \
+    pend &= ~(1u << (U));                                                                      \
+  }
+  for (int it = 0;; ++it) {
+    GS_LD(v0, 0) GS_LD(v1, 1) GS_LD(v2, 2) GS_LD(v3, 3) GS_LD(v4, 4)
+    GS_LD(v5, 5) GS_LD(v6, 6) GS_LD(v7, 7) GS_LD(v8, 8) GS_LD(v9, 9)
+    GS_LD(v10, 10) GS_LD(v11, 11) GS_LD(v12, 12) GS_LD(v13, 13) GS_LD(v14, 14)
+    GS_LD(v15, 15) GS_LD(v16, 16) GS_LD(v17, 17) GS_LD(v18, 18) GS_LD(v19, 19)
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7), "+v"(v8), "+v"(v9),
+                   "+v"(v10), "+v"(v11), "+v"(v12), "+v"(v13), "+v"(v14), "+v"(v15), "+v"(v16), "+v"(v17), "+v"(v18),
+                   "+v"(v19)
+                 :
+                 : "memory");
+    GS_CK(v0, 0) GS_CK(v1, 1) GS_CK(v2, 2) GS_CK(v3, 3) GS_CK(v4, 4)
+    GS_CK(v5, 5) GS_CK(v6, 6) GS_CK(v7, 7) GS_CK(v8, 8) GS_CK(v9, 9)
+    GS_CK(v10, 10) GS_CK(v11, 11) GS_CK(v12, 12) GS_CK(v13, 13) GS_CK(v14, 14)
+    GS_CK(v15, 15) GS_CK(v16, 16) GS_CK(v17, 17) GS_CK(v18, 18) GS_CK(v19, 19)
+    if (!pend) break;
+    if (it > (1 << 20)) {
+      *err = 1;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+#undef GS_LD
+#undef GS_CK
 #else
-  (void)bar; (void)g; (void)target; (void)err;
+  (void)dst; (void)gsrc; (void)N; (void)tag; (void)err;
 #endif
 }
 
@@ -301,7 +310,12 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
   const int cs = a.cs;                               // workgroups per subgraph
   const int cm = (cs > 1) ? blockIdx.x / a.stride : 0;   // this workgroup's member index
   const int gw = cm * GS_NW + wave, nwt = cs * GS_NW; // wave of the cluster, waves of the cluster
-  int nbar = 0;                                      // cluster barriers passed so far
+  // cluster exchanges: tag of exchange x = tag0 + x (x = 0..2: h_1..h_3, 3..4: dPre_2, dPre_1)
+#ifndef IGMC_HIPEMU
+  const uint32_t tag0 = (cs > 1) ? (uint32_t)__hip_atomic_load(m.gs_bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 8u + 1u : 0u;
+#else
+  const uint32_t tag0 = 0;
+#endif
   const uint64_t step = m.ctrl ? (uint64_t)m.ctrl[IGMC_CTRL_STEP] : a.step;
   GS_STAMP(0);
   GS_CSTAMP(0);
@@ -622,7 +636,12 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
             const float v1 = gs_tanh((acc[1][0][rr] + acc[1][1][rr]) + (acc[1][2][rr] + acc[1][3][rr]) + bias1);
             dst[orow * 32 + li_] = v0;
             dst[orow * 32 + 16 + li_] = v1;
-            if (TRAIN || cs > 1) {
+            if (cs > 1) {
+              unsigned long long* xp = m.gs_ll + (size_t)(l - 1) * m.gs_ll_stride + (size_t)(nb + orow) * 32;
+              gs_ll_pub(xp + li_, v0, tag0 + (l - 1));
+              gs_ll_pub(xp + 16 + li_, v1, tag0 + (l - 1));
+            }
+            if (TRAIN) {                 // backward reads h_l row by row
               gs_pub(m.h[l] + (size_t)(nb + orow) * 32 + li_, v0);
               gs_pub(m.h[l] + (size_t)(nb + orow) * 32 + 16 + li_, v1);
             }
@@ -635,8 +654,7 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
       if (l == 1) GS_WSTAMP(32);
       if (l < 3) wpre(l + 1);
       if (cs > 1) {      // every member needs all of h_l
-        gs_cluster_barrier(m.gs_bar, g, cs * (++nbar), m.gs_err);
-        gs_reload(dst, m.h[l] + (size_t)nb * 32, N);
+        gs_ll_reload(dst, m.gs_ll + (size_t)(l - 1) * m.gs_ll_stride + (size_t)nb * 32, N, tag0 + (l - 1), m.gs_err);
       }
       __syncthreads();
       if (tid < 64) sfeat[(tid >> 5) * 128 + l * 32 + (tid & 31)] = dst[((tid >> 5) ? cu : 0) * 32 + (tid & 31)];
@@ -880,9 +898,10 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
               const float d0 = v0 * (1.f - x0 * x0), d1 = v1 * (1.f - x1 * x1);
               dst[orow * 32 + li_] = d0;
               dst[orow * 32 + 16 + li_] = d1;
-              if (cs > 1) {
-                gs_pub(m.dpre[l - 1] + (size_t)(nb + orow) * 32 + li_, d0);
-                gs_pub(m.dpre[l - 1] + (size_t)(nb + orow) * 32 + 16 + li_, d1);
+              if (cs > 1 && l > 1) {
+                unsigned long long* xp = m.gs_ll + (size_t)(6 - l) * m.gs_ll_stride + (size_t)(nb + orow) * 32;
+                gs_ll_pub(xp + li_, d0, tag0 + (6 - l));
+                gs_ll_pub(xp + 16 + li_, d1, tag0 + (6 - l));
               }
             }
           }
@@ -991,8 +1010,7 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
         }
         if (l > 1) wpre(l - 1);
         if (cs > 1 && l > 1) {    // every member needs all of dPre_{l-1} (dPre_0 is only used row by row, below)
-          gs_cluster_barrier(m.gs_bar, g, cs * (++nbar), m.gs_err);
-          gs_reload(dst, m.dpre[l - 1] + (size_t)nb * 32, N);
+          gs_ll_reload(dst, m.gs_ll + (size_t)(6 - l) * m.gs_ll_stride + (size_t)nb * 32, N, tag0 + (6 - l), m.gs_err);
           __syncthreads();
         }
         if (l == 3) GS_STAMP(31);
@@ -1041,16 +1059,11 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
   }
 #ifndef IGMC_HIPEMU
   if (cs > 1 && tid == 0) {
-    const int g = blockIdx.x % a.stride;
-    if (g < B) {
-      int* done = m.gs_bar + m.graph_cap;
-      // (relaxed: only the counters themselves are communicated; an agent-scope acq_rel here costs a cache-wide
-      //  write-back + invalidate, ~8 us)
-      if (__hip_atomic_fetch_add(done + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == cs - 1) {
-        // every member has passed its last barrier: the counters are free for the next launch
-        __hip_atomic_store(m.gs_bar + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(done + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+    // the workgroup that finishes the launch LAST advances the sequence number: every workgroup has read it by then
+    // (relaxed: only the counters themselves are communicated; the next launch starts after this one has completed)
+    if (__hip_atomic_fetch_add(m.gs_bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+      __hip_atomic_store(m.gs_bar, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(m.gs_bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 #endif

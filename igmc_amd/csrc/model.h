@@ -35,8 +35,10 @@ struct ModelDev {
   float* ts_part;     // [4][IGMC_TS_BLOCKS][ts_stride] relation-space tables [W_r rows | root rows | bias] per layer (or NULL)
   float* ts_raw;      // [4][ts_stride] their sum over the workgroups
   int ts_stride;      // (R*32 + 33) * 32
-  int* gs_bar;        // [2][graph_cap] cluster barriers of k_graph_step: arrival counters, leave counters
-  int* gs_err;        // [1] set when a cluster barrier timed out
+  int* gs_bar;        // k_graph_step clusters: [0] workgroups that finished the launch, [1] launch sequence number
+  int* gs_err;        // [1] set when a cluster exchange timed out
+  unsigned long long* gs_ll;   // [5 exchanges][node_cap][32] {value, tag} words of the cluster exchanges (R <= 5 only)
+  size_t gs_ll_stride;         // words per exchange buffer
   float* arr_part;    // [4] ARR regulariser per layer
   const float* side;  // [B,S] borrowed side features or NULL
   const int64_t* ctrl;  // optional device-side step control (igmc_hip.h) or NULL

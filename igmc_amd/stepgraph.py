@@ -69,6 +69,10 @@ class StepGraph(object):
         self.dp_path = self.world > 1 or os.environ.get('IGMC_FORCE_DP_PATH', '0') == '1'
         self.side = torch.cuda.Stream(device=self.dev) if overlap else None
         self.graphs = [None, None]
+        # several steps in ONE graph launch: consecutive launches of a replayed graph are separated by a gap of tens of
+        # microseconds on the device, a sizeable part of a ~200 us step (IGMC_GRAPH_STEPS, even, 0 disables)
+        self.multi_n = int(os.environ.get('IGMC_GRAPH_STEPS', '8')) & ~1
+        self.multi = None
         self._attached = False
         self.k = 0                      # steps done in the current epoch (parity selects the arena)
         self.steps_done = 0
@@ -208,12 +212,37 @@ class StepGraph(object):
         self.model._step += 1
         self.opt.t += 1
 
+    def steps(self, n):
+        """``n`` full-batch optimisation steps; whole groups of ``multi_n`` steps replay one multi-step graph (the
+        per-step control block is advanced on the device, so the launch sequence of a group is always the same)."""
+        n = int(n)
+        while n > 0:
+            M = self.multi_n
+            if (self.use_graph and not self.dp_path and M >= 2 and n >= M and self.k % 2 == 0 and self.steps_done >= 4):
+                if self.multi is None:
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        for i in range(M):
+                            self._enqueue(i % 2, self.B)
+                    self.multi = g
+                self.multi.replay()
+                self.k += M
+                self.steps_done += M
+                self.model._step += M
+                self.opt.t += M
+                n -= M
+            else:
+                self.step()
+                n -= 1
+
     def run_epoch(self, perm, epoch):
         """All batches of one epoch; returns (sum over batches of loss*B as a device float64 tensor, #links)."""
         self.begin_epoch(perm, epoch)
         n = self.n_links
-        for first in range(0, n, self.B):
-            self.step(min(self.B, n - first))
+        self.steps(n // self.B)
+        if n % self.B:
+            self.step(n % self.B)
         self.detach()         # captured launches keep their own copy of the control pointer
         self.check()
         return self.total, n

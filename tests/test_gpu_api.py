@@ -204,8 +204,9 @@ def test_main_script_end_to_end(tmp_path):
 
 
 def test_step_graph_paths_agree(flix, monkeypatch):
-    """The captured single-GPU step (igmc_train_step inside a hipGraph, prefetch on a second stream), the eager
-    step, and the multi-GPU launch structure (graph up to the gradients + eager all-reduce slot + step_finish)
+    """The captured single-GPU step (igmc_train_step inside a hipGraph, prefetch on a second stream; groups of 8
+    steps per graph launch by default, one step per launch with IGMC_GRAPH_STEPS=0), the eager step, and the
+    multi-GPU launch structure (graph up to the gradients + eager all-reduce slot + step_finish)
     must walk the same trajectory."""
     import torch
     from igmc_amd.models import IGMC
@@ -214,7 +215,7 @@ def test_step_graph_paths_agree(flix, monkeypatch):
     tr, te, cv = make_sets(flix, ntr=600)
     results = {}
     for name, env, kw in (('graph', {}, {}), ('eager', {}, dict(use_graph=False, overlap=False)),
-                          ('dp_path', {'IGMC_FORCE_DP_PATH': '1'}, {})):
+                          ('graph1', {'IGMC_GRAPH_STEPS': '0'}, {}), ('dp_path', {'IGMC_FORCE_DP_PATH': '1'}, {})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         torch.manual_seed(7)
@@ -228,10 +229,11 @@ def test_step_graph_paths_agree(flix, monkeypatch):
         total2, _ = sg.run_epoch(perm, 2)
         torch.cuda.synchronize()
         results[name] = (model.flat_parameters().detach().cpu().clone(), float(total2.item()), opt.t, model._step)
+        assert (sg.multi is not None) == (name == 'graph')
         for k in env:
             monkeypatch.delenv(k)
     assert results['graph'][2] == 24 and results['graph'][3] == 24
-    for other in ('eager', 'dp_path'):
+    for other in ('eager', 'graph1', 'dp_path'):
         assert torch.allclose(results['graph'][0], results[other][0], rtol=2e-4, atol=2e-6), other
         assert results['graph'][1] == pytest.approx(results[other][1], rel=1e-4)
 
