@@ -113,26 +113,41 @@ template <bool FLAGS, bool TRANS>
 __device__ __forceinline__ void gs_gather(const BatchDev& b, const float* src, const float* zrow, int nb, float* tile,
                                           const int* relp, const int* order, const unsigned char* ulist, int b0, int N,
                                           int R, int qd, int j) {
-#pragma unroll 1
-  for (int it = 0; it < R; ++it) {
+  // unit of round `it` of this quad: tile slot, relation, run [beg, end) (empty beyond the subgraph's last row)
+  auto unit = [&](int it, int& slot, int& r, int& beg, int& end) {
     const int u = ulist[qd + 16 * it];             // units of the bundle by decreasing run length: a round of 16
-    const int slot = u >> 3, r = u & 7;            // quads works on runs of similar length
-    const bool live = b0 + slot < N;
-    int beg = 0, end = 0;
-    if (live) {
+    slot = u >> 3;                                 // quads works on runs of similar length
+    r = u & 7;
+    beg = 0;
+    end = 0;
+    if (b0 + slot < N) {
       const int* rptr = relp + order[b0 + slot] * 8;
       beg = rptr[r];
       end = rptr[r + 1];
+    }
+  };
+  int slot, r, beg, end;
+  unit(0, slot, r, beg, end);
+  // 4 groups of 4 entries per iteration; the entries of group q of the NEXT iteration are requested right after
+  // group q is consumed, i.e. a whole iteration before they are needed (the index loads come from L2 / HBM); the
+  // first 16 entries of the NEXT round's run are requested at the start of the round: only round 0 waits for a
+  // global load with nothing else to do
+  uint32_t w[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) w[q] = gs_entry<FLAGS, TRANS>(b, beg + 4 * q + j, end);
+#pragma unroll 1
+  for (int it = 0; it < R; ++it) {
+    int slot2 = 0, r2 = 0, beg2 = 0, end2 = 0;
+    uint32_t wn[4] = {GS_INVALID, GS_INVALID, GS_INVALID, GS_INVALID};
+    if (it + 1 < R) {
+      unit(it + 1, slot2, r2, beg2, end2);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) wn[q] = gs_entry<FLAGS, TRANS>(b, beg2 + 4 * q + j, end2);
     }
     float tx[8];
 #pragma unroll
     for (int f = 0; f < 8; ++f) tx[f] = 0.f;
     if (beg < end) {
-      // 4 groups of 4 entries per iteration; the entries of group q of the NEXT iteration are requested right after
-      // group q is consumed, i.e. a whole iteration before they are needed (the index loads come from L2 / HBM)
-      uint32_t w[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) w[q] = gs_entry<FLAGS, TRANS>(b, beg + 4 * q + j, end);
 #pragma unroll 1
       for (int c0 = beg; c0 < end; c0 += 16) {
 #pragma unroll
@@ -175,6 +190,12 @@ __device__ __forceinline__ void gs_gather(const BatchDev& b, const float* src, c
     // rows past the end of the subgraph get zeros (they are K entries of the weight-gradient product)
     *(float4*)(tile + slot * GS_TP + r * 32 + 8 * j) = make_float4(tx[0], tx[1], tx[2], tx[3]);
     *(float4*)(tile + slot * GS_TP + r * 32 + 8 * j + 4) = make_float4(tx[4], tx[5], tx[6], tx[7]);
+    slot = slot2;
+    r = r2;
+    beg = beg2;
+    end = end2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = wn[q];
   }
 }
 
@@ -627,11 +648,15 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
           acc[1][s & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.y, acc[1][s & 3], 0, 0, 0);
         }
         if (l == 1 && si == 0) GS_STAMP(18);
+        // (the four output rows of a lane are consecutive bundle positions: one 16-byte read of their row numbers,
+        //  entries beyond N are never used)
+        const int4 orow4 = *(const int4*)(order + b0 + kq_ * 4);
+        const int orows[4] = {orow4.x, orow4.y, orow4.z, orow4.w};
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           const int p2 = b0 + kq_ * 4 + rr;
           if (p2 < N) {
-            const int orow = order[p2];
+            const int orow = orows[rr];
             const float v0 = gs_tanh((acc[0][0][rr] + acc[0][1][rr]) + (acc[0][2][rr] + acc[0][3][rr]) + bias0);
             const float v1 = gs_tanh((acc[1][0][rr] + acc[1][1][rr]) + (acc[1][2][rr] + acc[1][3][rr]) + bias1);
             dst[orow * 32 + li_] = v0;
@@ -882,11 +907,19 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
           }
           if (l == 3 && si == 0) GS_STAMP(28);
           // epilogue: + readout gradient on the centre rows, * tanh'(h_{l-1})
+          const int4 orow4 = *(const int4*)(order + b0 + kq_ * 4);
+          const int orows[4] = {orow4.x, orow4.y, orow4.z, orow4.w};
+          float hx0[4], hx1[4];                       // h_{l-1} of the four output rows, requested together
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            hx0[rr] = HS[(kq_ * 4 + rr) * GS_HP + li_];
+            hx1[rr] = HS[(kq_ * 4 + rr) * GS_HP + 16 + li_];
+          }
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
             const int p2 = b0 + kq_ * 4 + rr;
             if (p2 < N) {
-              const int orow = order[p2];
+              const int orow = orows[rr];
               float v0 = (acc[0][0][rr] + acc[0][1][rr]) + (acc[0][2][rr] + acc[0][3][rr]);
               float v1 = (acc[1][0][rr] + acc[1][1][rr]) + (acc[1][2][rr] + acc[1][3][rr]);
               if (orow == 0 || orow == cu) {
@@ -894,7 +927,7 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
                 v0 += gf[li_];
                 v1 += gf[16 + li_];
               }
-              const float x0 = HS[(kq_ * 4 + rr) * GS_HP + li_], x1 = HS[(kq_ * 4 + rr) * GS_HP + 16 + li_];
+              const float x0 = hx0[rr], x1 = hx1[rr];
               const float d0 = v0 * (1.f - x0 * x0), d1 = v1 * (1.f - x1 * x1);
               dst[orow * 32 + li_] = d0;
               dst[orow * 32 + 16 + li_] = d1;
