@@ -93,8 +93,19 @@ __device__ __forceinline__ uint32_t gs_entry(const BatchDev& b, int e, int end) 
   if (e < end && (!FLAGS || ((b.eflag[e] >> (TRANS ? 1 : 0)) & 1))) w = b.ecr[e];
   return w;
 }
-__device__ __forceinline__ const float* gs_rowptr(uint32_t wk, const float* src, const float* zrow, int nb, int j) {
-  return (wk != GS_INVALID) ? src + ((int)(wk & 0xFFFFFFu) - nb) * 32 + 8 * j : zrow;
+// BYTE offset of an entry's gather row from the gather source (padding / dropped entries: the zero row), computed
+// ONCE by the lane that holds the entry; the quad then broadcasts the finished offset (1 DPP move + 1 add per lane
+// and entry instead of mask / subtract / shift / compare / select in every lane for every entry)
+__device__ __forceinline__ int gs_entoff(uint32_t wk, int zoffb, int nb) {
+  return (wk != GS_INVALID) ? ((int)(wk & 0xFFFFFFu) - nb) * 128 : zoffb;
+}
+template <int Q>
+__device__ __forceinline__ const float* gs_qrow(const char* srcj, int off) {
+#ifdef IGMC_HIPEMU
+  return (const float*)(srcj + __shfl(off, Q, 4));
+#else
+  return (const float*)(srcj + __builtin_amdgcn_mov_dpp(off, Q * 0x55, 0xf, 0xf, true));   // quad_perm:[Q,Q,Q,Q]
+#endif
 }
 
 // Relation-space aggregate of one row by one QUAD (lane j owns features 8j..8j+7), gather source in LDS, result
@@ -126,6 +137,8 @@ __device__ __forceinline__ void gs_gather(const BatchDev& b, const float* src, c
       end = rptr[r + 1];
     }
   };
+  const char* srcj = (const char*)(src + 8 * j);
+  const int zoffb = (int)((const char*)zrow - (const char*)src);
   int slot, r, beg, end;
   unit(0, slot, r, beg, end);
   // 4 groups of 4 entries per iteration; the entries of group q of the NEXT iteration are requested right after
@@ -153,22 +166,22 @@ __device__ __forceinline__ void gs_gather(const BatchDev& b, const float* src, c
 #pragma unroll
         for (int h = 0; h < 2; ++h) {              // two 8-entry halves: up to 16 row loads in flight per wait
           if (c0 + 8 * h >= end) break;
-          const uint32_t wa = w[2 * h], wb = w[2 * h + 1];
+          const int oa = gs_entoff(w[2 * h], zoffb, nb), ob = gs_entoff(w[2 * h + 1], zoffb, nb);
           const bool two = c0 + 8 * h + 4 < end;   // second group of the half present (quad-uniform)
-          const float* p0 = gs_rowptr(gs_qbcast<0>(wa), src, zrow, nb, j);
-          const float* p1 = gs_rowptr(gs_qbcast<1>(wa), src, zrow, nb, j);
-          const float* p2 = gs_rowptr(gs_qbcast<2>(wa), src, zrow, nb, j);
-          const float* p3 = gs_rowptr(gs_qbcast<3>(wa), src, zrow, nb, j);
+          const float* p0 = gs_qrow<0>(srcj, oa);
+          const float* p1 = gs_qrow<1>(srcj, oa);
+          const float* p2 = gs_qrow<2>(srcj, oa);
+          const float* p3 = gs_qrow<3>(srcj, oa);
           const float4 a0 = *(const float4*)p0, b0v = *(const float4*)(p0 + 4);
           const float4 a1 = *(const float4*)p1, b1v = *(const float4*)(p1 + 4);
           const float4 a2 = *(const float4*)p2, b2v = *(const float4*)(p2 + 4);
           const float4 a3 = *(const float4*)p3, b3v = *(const float4*)(p3 + 4);
-          float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), a5 = a4, a6 = a4, a7 = a4, b4v = a4, b5v = a4, b6v = a4, b7v = a4;
+          float4 a4, a5, a6, a7, b4v, b5v, b6v, b7v;      // only touched when the second group exists
           if (two) {
-            const float* p4 = gs_rowptr(gs_qbcast<0>(wb), src, zrow, nb, j);
-            const float* p5 = gs_rowptr(gs_qbcast<1>(wb), src, zrow, nb, j);
-            const float* p6 = gs_rowptr(gs_qbcast<2>(wb), src, zrow, nb, j);
-            const float* p7 = gs_rowptr(gs_qbcast<3>(wb), src, zrow, nb, j);
+            const float* p4 = gs_qrow<0>(srcj, ob);
+            const float* p5 = gs_qrow<1>(srcj, ob);
+            const float* p6 = gs_qrow<2>(srcj, ob);
+            const float* p7 = gs_qrow<3>(srcj, ob);
             a4 = *(const float4*)p4; b4v = *(const float4*)(p4 + 4);
             a5 = *(const float4*)p5; b5v = *(const float4*)(p5 + 4);
             a6 = *(const float4*)p6; b6v = *(const float4*)(p6 + 4);
@@ -176,14 +189,27 @@ __device__ __forceinline__ void gs_gather(const BatchDev& b, const float* src, c
           }
           w[2 * h] = gs_entry<FLAGS, TRANS>(b, c0 + 16 + 8 * h + j, end);          // next iteration's entries
           w[2 * h + 1] = gs_entry<FLAGS, TRANS>(b, c0 + 16 + 8 * h + 4 + j, end);
-          tx[0] += ((a0.x + a1.x) + (a2.x + a3.x)) + ((a4.x + a5.x) + (a6.x + a7.x));
-          tx[1] += ((a0.y + a1.y) + (a2.y + a3.y)) + ((a4.y + a5.y) + (a6.y + a7.y));
-          tx[2] += ((a0.z + a1.z) + (a2.z + a3.z)) + ((a4.z + a5.z) + (a6.z + a7.z));
-          tx[3] += ((a0.w + a1.w) + (a2.w + a3.w)) + ((a4.w + a5.w) + (a6.w + a7.w));
-          tx[4] += ((b0v.x + b1v.x) + (b2v.x + b3v.x)) + ((b4v.x + b5v.x) + (b6v.x + b7v.x));
-          tx[5] += ((b0v.y + b1v.y) + (b2v.y + b3v.y)) + ((b4v.y + b5v.y) + (b6v.y + b7v.y));
-          tx[6] += ((b0v.z + b1v.z) + (b2v.z + b3v.z)) + ((b4v.z + b5v.z) + (b6v.z + b7v.z));
-          tx[7] += ((b0v.w + b1v.w) + (b2v.w + b3v.w)) + ((b4v.w + b5v.w) + (b6v.w + b7v.w));
+          float t[8];
+          t[0] = (a0.x + a1.x) + (a2.x + a3.x);
+          t[1] = (a0.y + a1.y) + (a2.y + a3.y);
+          t[2] = (a0.z + a1.z) + (a2.z + a3.z);
+          t[3] = (a0.w + a1.w) + (a2.w + a3.w);
+          t[4] = (b0v.x + b1v.x) + (b2v.x + b3v.x);
+          t[5] = (b0v.y + b1v.y) + (b2v.y + b3v.y);
+          t[6] = (b0v.z + b1v.z) + (b2v.z + b3v.z);
+          t[7] = (b0v.w + b1v.w) + (b2v.w + b3v.w);
+          if (two) {
+            t[0] += (a4.x + a5.x) + (a6.x + a7.x);
+            t[1] += (a4.y + a5.y) + (a6.y + a7.y);
+            t[2] += (a4.z + a5.z) + (a6.z + a7.z);
+            t[3] += (a4.w + a5.w) + (a6.w + a7.w);
+            t[4] += (b4v.x + b5v.x) + (b6v.x + b7v.x);
+            t[5] += (b4v.y + b5v.y) + (b6v.y + b7v.y);
+            t[6] += (b4v.z + b5v.z) + (b6v.z + b7v.z);
+            t[7] += (b4v.w + b5v.w) + (b6v.w + b7v.w);
+          }
+#pragma unroll
+          for (int f = 0; f < 8; ++f) tx[f] += t[f];
         }
       }
     }
