@@ -704,9 +704,12 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
       if (l == 1) GS_STAMP(20);
       if (l == 1) GS_WSTAMP(32);
       if (l < 3) wpre(l + 1);
+      if (l == 1) GS_STAMP(22);
+      if (l == 1) GS_CSTAMP(2);
       if (cs > 1) {      // every member needs all of h_l
         gs_ll_reload(dst, m.gs_ll + (size_t)(l - 1) * m.gs_ll_stride + (size_t)nb * 32, N, tag0 + (l - 1), m.gs_err);
       }
+      if (l == 1) GS_CSTAMP(3);
       __syncthreads();
       if (tid < 64) sfeat[(tid >> 5) * 128 + l * 32 + (tid & 31)] = dst[((tid >> 5) ? cu : 0) * 32 + (tid & 31)];
       GS_STAMP(2 + l);
@@ -971,29 +974,44 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
         if (l == 3) GS_WSTAMP(36);
         if (split_out) {
           __syncthreads();                             // the four bundle tiles / h chunks of the workgroup are complete
+          if (l == 3) GS_STAMP(13);
           f32x4 w6[6];
 #pragma unroll
           for (int i6 = 0; i6 < 6; ++i6) w6[i6] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          // tile tt = 6 wave + i6 of the 2 x 12 output tiles: row half m2 = wave >> 1, column tile nt = 6 (wave & 1) + i6;
+          // column tiles 0..9 are T' (relations), 10..11 dPre (root).  All 32 operands of a bundle are requested
+          // before its 24 MFMAs (issued one by one, each MFMA waits for its own LDS read: 11.5 k -> cycles per layer)
+          static_assert(GS_NR == 5 && GS_WN == 12, "tile split of the table product");
+          const int m2w = wave >> 1, wo = wave & 1;
 #pragma unroll 1
           for (int wb = 0; wb < GS_NW; ++wb) {
             if (nsb[wb] == 0) continue;
             const int b0 = sched[(GS_WMAX + cm * GS_NW + wb) * GS_SMAX] * 16;
             const float* Tb = TILES + wb * 16 * GS_TP;
             const float* Hb = HSS + wb * 16 * GS_HP;
+            float av[4], bw[4][6];
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
               const int prk = b0 + 4 * s4 + kq;
               const int rowK = order[(prk < N) ? prk : N - 1];
-              const float a0 = Hb[(4 * s4 + kq) * GS_HP + li], a1 = Hb[(4 * s4 + kq) * GS_HP + 16 + li];
+              av[s4] = Hb[(4 * s4 + kq) * GS_HP + m2w * 16 + li];
+              const float* tb = Tb + (4 * s4 + kq) * GS_TP + li;
 #pragma unroll
-              for (int i6 = 0; i6 < 6; ++i6) {
-                const int tt = wave * 6 + i6, m2 = tt / GS_WN, nt = tt % GS_WN;     // compile-time per (wave-uniform) i6
-                const float bv = (nt < GS_NR * 2) ? Tb[(4 * s4 + kq) * GS_TP + nt * 16 + li]
-                                                  : src[rowK * 32 + (nt - GS_NR * 2) * 16 + li];
-                w6[i6] = __builtin_amdgcn_mfma_f32_16x16x4f32(m2 ? a1 : a0, bv, w6[i6], 0, 0, 0);
-              }
+              for (int i6 = 0; i6 < 4; ++i6) bw[s4][i6] = tb[(wo * 6 + i6) * 16];
+              const float* pr = wo ? src + rowK * 32 + li : tb + 64;       // column tiles 10, 11 (odd waves) / 4, 5
+              bw[s4][4] = pr[0];
+              bw[s4][5] = pr[16];
             }
+#ifndef IGMC_HIPEMU
+            __builtin_amdgcn_sched_barrier(0);           // keep the requests together (the scheduler sinks them back)
+#endif
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+              for (int i6 = 0; i6 < 6; ++i6)
+                w6[i6] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bw[s4][i6], w6[i6], 0, 0, 0);
           }
+          if (l == 3) GS_STAMP(14);
 #pragma unroll
           for (int i6 = 0; i6 < 6; ++i6) {
             const int tt = wave * 6 + i6, m2 = tt / GS_WN, nt = tt % GS_WN;
@@ -1067,7 +1085,9 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
             __syncthreads();
           }
         }
+        if (l == 3) GS_STAMP(15);
         if (l > 1) wpre(l - 1);
+        if (l == 3) GS_STAMP(21);
         if (cs > 1 && l > 1) {    // every member needs all of dPre_{l-1} (dPre_0 is only used row by row, below)
           gs_ll_reload(dst, m.gs_ll + (size_t)(6 - l) * m.gs_ll_stride + (size_t)nb * 32, N, tag0 + (6 - l), m.gs_err);
           __syncthreads();

@@ -50,6 +50,9 @@ def main():
     print('L3 bwd, wave 0 first bundle: hs+zero %d  gather %d  dX %d  wgrad %d  epilogue %d | wave0 all bundles %d '
           '(layer start %d)  reduce %d' % (c[25] - c[24], c[26] - c[25], c[27] - c[26], c[28] - c[27], c[29] - c[28],
                                           c[30] - c[24], c[24] - c[7], c[31] - c[30]))
+    print('L1 fwd after the bundles: weights of the next layer requested %d | exchange + barrier %d' % (c[22] - c[20], c[3] - c[22]))
+    print('L3 bwd after the bundles: barrier %d | table product %d | partial-table stores + barrier %d | next weights '
+          'requested %d | exchange + barrier %d' % (c[13] - c[30], c[14] - c[13], c[15] - c[14], c[21] - c[15], c[31] - c[21]))
     _extra(c)
     print('setup: kernel start -> T0 staged %d | row starts/labels loaded %d | histogram %d | ranking %d | schedule %d | unit lists %d' % (
         c[56] - c[0], c[57] - c[56], c[58] - c[57], c[59] - c[58], c[60] - c[59], c[1] - c[60]))
@@ -61,7 +64,7 @@ def _extra(c):
     t0 = min(int(c[40 + 4 * m]) for m in range(4) if c[40 + 4 * m] > 0) if any(c[40 + 4 * m] > 0 for m in range(4)) else 0
     for m in range(4):
         if c[40 + 4 * m] > 0:
-            print('cluster member %d of subgraph 0: start %d  setup done %d  barrier-1 arrive %d  leave %d' % (
+            print('cluster member %d of subgraph 0: start %d  setup done %d  first exchange: rows published %d  all rows in LDS %d' % (
                 m, c[40 + 4 * m] - t0, c[41 + 4 * m] - t0, c[42 + 4 * m] - t0, c[43 + 4 * m] - t0))
 
 
