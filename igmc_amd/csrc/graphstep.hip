@@ -316,6 +316,43 @@ __device__ __forceinline__ void gs_ll_reload(float* dst, const unsigned long lon
 #endif
 }
 
+// [T | x](16 x 192) @ sW2 (192 x 32) of one bundle: GS_KS k-steps in groups of GS_KG; the operands of group g + 1 are
+// requested before the MFMAs of group g are issued (left to itself the scheduler issues every LDS read right before
+// the MFMA pair that needs it: ~52 cycles per MFMA instead of 32)
+#define GS_KG 8
+__device__ __forceinline__ void gs_transform(const float* T, const float* src, int rowA, const float2* sW2, int li,
+                                             int kq, f32x4 (&acc)[2][4]) {
+  static_assert(GS_KS % GS_KG == 0 && (GS_NR * 8) % GS_KG == 0, "k-step groups");
+  float av[2][GS_KG];
+  float2 bv[2][GS_KG];
+  auto request = [&](int g, int buf) {
+#pragma unroll
+    for (int i = 0; i < GS_KG; ++i) {
+      const int s = g * GS_KG + i;
+      av[buf][i] = (s < GS_NR * 8) ? T[li * GS_TP + 4 * s + kq] : src[rowA * 32 + 4 * (s - GS_NR * 8) + kq];
+      bv[buf][i] = sW2[(4 * s + kq) * 16 + li];
+    }
+  };
+  request(0, 0);
+#pragma unroll
+  for (int g = 0; g < GS_KS / GS_KG; ++g) {
+    if (g + 1 < GS_KS / GS_KG) request(g + 1, (g + 1) & 1);
+#ifndef IGMC_HIPEMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+    for (int i = 0; i < GS_KG; ++i) {
+      const int s = g * GS_KG + i;
+      acc[0][s & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][i], bv[g & 1][i].x, acc[0][s & 3], 0, 0, 0);
+      acc[1][s & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][i], bv[g & 1][i].y, acc[1][s & 3], 0, 0, 0);
+    }
+#ifndef IGMC_HIPEMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  }
+}
+#define GS_TRANSFORM(T, src, rowA, sW2, li, kq, acc) gs_transform(T, src, rowA, sW2, li, kq, acc)
+
 template <bool FLAGS, bool TRAIN>
 __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev m, const float* P, GsArgs a) {
   IGMC_DYN_SMEM(smem);
@@ -666,13 +703,7 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
           for (int c = 0; c < 4; ++c) acc[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < GS_KS; ++s) {
-          const float av = (s < GS_NR * 8) ? T[li_ * GS_TP + 4 * s + kq_] : src[rowA * 32 + 4 * (s - GS_NR * 8) + kq_];
-          const float2 bv = sW2[(4 * s + kq_) * 16 + li_];
-          acc[0][s & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.x, acc[0][s & 3], 0, 0, 0);
-          acc[1][s & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.y, acc[1][s & 3], 0, 0, 0);
-        }
+        GS_TRANSFORM(T, src, rowA, sW2, li_, kq_, acc);
         if (l == 1 && si == 0) GS_STAMP(18);
         // (the four output rows of a lane are consecutive bundle positions: one 16-byte read of their row numbers,
         //  entries beyond N are never used)
@@ -911,13 +942,7 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
           for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[nt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int s = 0; s < GS_KS; ++s) {
-            const float av = (s < GS_NR * 8) ? T[li_ * GS_TP + 4 * s + kq_] : src[rowA * 32 + 4 * (s - GS_NR * 8) + kq_];
-            const float2 bv = sW2[(4 * s + kq_) * 16 + li_];
-            acc[0][s & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.x, acc[0][s & 3], 0, 0, 0);
-            acc[1][s & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv.y, acc[1][s & 3], 0, 0, 0);
-          }
+          GS_TRANSFORM(T, src, rowA, sW2, li_, kq_, acc);
           if (l == 3 && si == 0) GS_STAMP(27);
           // weight-gradient table: K = the 16 rows of the bundle (4 k-steps), 2 x GS_WN output tiles
           if (!split_out)
