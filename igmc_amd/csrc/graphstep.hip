@@ -465,20 +465,30 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
           const int e = eb + u * GS_THREADS;
           const bool in = e < e1;
           const int es = in ? e : e0;
-          code[u] = b.ecode[es];
+          code[u] = b.ecode[es];                               // relation * L + label of the source node
           row[u] = in ? (int)b.edst[es] : -1;
-          rel[u] = (int)(b.ecr[es] >> 24);
+          if (FLAGS) rel[u] = (int)(b.ecr[es] >> 24);
           keep[u] = FLAGS ? (b.eflag[es] & 1) : 1;
         }
 #pragma unroll
         for (int u = 0; u < 24; ++u) {
           if (row[u] < 0) continue;
-          atomicAdd(&relp[row[u] * 8 + rel[u] + 1], 1);        // run lengths count every entry, dropped or not
+          // run lengths count every entry, dropped or not; without edge dropout they are sums of the histogram (below)
+          if (FLAGS) atomicAdd(&relp[row[u] * 8 + rel[u] + 1], 1);
           if (keep[u]) atomicAdd(&cnt[row[u] * rlp + (code[u] >> 1)], 1 << ((code[u] & 1) * 16));
         }
       }
     }
     __syncthreads();
+    if (!FLAGS) {
+      for (int i = tid; i < N * R; i += GS_THREADS) {
+        const int row_ = i / R, r = i - row_ * R;
+        int n = 0;
+        for (int c = r * L; c < r * L + L; ++c) n += (cnt[row_ * rlp + (c >> 1)] >> ((c & 1) * 16)) & 0xFFFF;
+        relp[row_ * 8 + r + 1] = n;
+      }
+      __syncthreads();
+    }
     GS_STAMP(58);
     // run lengths -> run starts; rows by decreasing degree (rank counting, ties by index) unless every bundle gets a
     // wave of its own anyway (clustered launch: the bundle order then does not matter, natural order is kept)
