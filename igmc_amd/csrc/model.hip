@@ -1543,17 +1543,22 @@ __device__ __forceinline__ void reduce_ts_body(const ModelDev& m, int nparts, in
   const bool ok = l < 4 && (l > 0 || i < rows0 * 32);
   if (ok) {
     // slot of member c of subgraph g = g + c * stride (one-workgroup launches: stride = IGMC_TS_BLOCKS, cs = 1);
-    // the 4 waves split the subgraphs, 8 independent loads in flight, fixed order
+    // the 4 waves split the subgraphs; up to 4 members x 8 subgraphs = 32 independent loads in flight per round (one
+    // round trip per round: the reduction is latency-bound), fixed order
     const float* p = m.ts_part + (size_t)l * IGMC_TS_BLOCKS * ts + i;
     const int ng = (nparts < stride) ? nparts : ((B < stride) ? B : stride), cs = (nparts + stride - 1) / stride;
-    for (int c = 0; c < cs; ++c) {
-      const float* pc = p + (size_t)c * stride * ts;
+    for (int c0 = 0; c0 < cs; c0 += 4) {
       for (int g0 = wave; g0 < ng; g0 += 32) {
-        float v[8];
+        float v[4][8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = (g0 + 4 * u < ng) ? pc[(size_t)(g0 + 4 * u) * ts] : 0.f;
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
+          for (int u = 0; u < 8; ++u)
+            v[c][u] = (c0 + c < cs && g0 + 4 * u < ng) ? p[((size_t)(c0 + c) * stride + g0 + 4 * u) * ts] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) s += v[c][u];
       }
     }
   }
@@ -1629,6 +1634,40 @@ __device__ __forceinline__ void adam_elem(float* __restrict__ p, const float* __
   p[i] = pi - step_size * a / (sqrtf(v) * inv_sqrt_bc2 + eps);
 }
 
+// Adam on [lo, hi) by one workgroup: NB elements per thread and round, all 4 NB loads requested before the first use
+// (the element-by-element loop pays one memory round trip per element: the stores of element k keep the compiler from
+// requesting element k + 1 early)
+template <int NB>
+__device__ __forceinline__ void adam_range(float* p, const float* g, float* m1, float* m2, int64_t lo, int64_t hi,
+                                           float step_size, float inv_sqrt_bc2, float beta1, float beta2, float eps,
+                                           float wd) {
+  for (int64_t i0 = lo + threadIdx.x; i0 < hi; i0 += (int64_t)NB * IGMC_BLOCK) {
+    float gv[NB], pv[NB], av[NB], vv[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const int64_t i = i0 + (int64_t)k * IGMC_BLOCK;
+      const bool in = i < hi;
+      gv[k] = in ? g[i] : 0.f;
+      pv[k] = in ? p[i] : 0.f;
+      av[k] = in ? m1[i] : 0.f;
+      vv[k] = in ? m2[i] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const int64_t i = i0 + (int64_t)k * IGMC_BLOCK;
+      if (i < hi) {
+        float gi = gv[k];
+        if (wd != 0.f) gi += wd * pv[k];
+        const float a = beta1 * av[k] + (1.f - beta1) * gi;
+        const float v = beta2 * vv[k] + (1.f - beta2) * gi * gi;
+        m1[i] = a;
+        m2[i] = v;
+        p[i] = pv[k] - step_size * a / (sqrtf(v) * inv_sqrt_bc2 + eps);
+      }
+    }
+  }
+}
+
 // optional optimiser tail of k_finalize (single-GPU fused step): Adam on the parameters whose gradient the
 // workgroup just produced (conv layers) / on a slice of the lin parameters (extra workgroups), then the LAST
 // workgroup to finish emits loss / epoch total and advances the control block.
@@ -1680,8 +1719,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize(ModelDev m, const float
     const int64_t chunk = (n_lin + nb - 1) / nb;
     const int64_t lo = m.off_l1w + (int64_t)(blockIdx.x - 4 * IGMC_FIN_NB) * chunk;
     const int64_t hi = (lo + chunk < m.n_params) ? lo + chunk : m.n_params;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += IGMC_BLOCK)
-      adam_elem(at.p, grad, at.m1, at.m2, i, at.step_size, at.inv_sqrt_bc2, at.beta1, at.beta2, at.eps, at.wd);
+    adam_range<8>(at.p, grad, at.m1, at.m2, lo, hi, at.step_size, at.inv_sqrt_bc2, at.beta1, at.beta2, at.eps, at.wd);
   } else {
     const int l = blockIdx.x / IGMC_FIN_NB, part = blockIdx.x % IGMC_FIN_NB, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1806,10 +1844,8 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize(ModelDev m, const float
       __syncthreads();
       if (s_lastl) {
         __threadfence();
-        const int64_t lo = m.off_basis[l], hi = m.off_att[l] + na;
-#pragma unroll 4
-        for (int64_t i = lo + tid; i < hi; i += IGMC_BLOCK)
-          adam_elem(at.p, grad, at.m1, at.m2, i, at.step_size, at.inv_sqrt_bc2, at.beta1, at.beta2, at.eps, at.wd);
+        adam_range<12>(at.p, grad, at.m1, at.m2, m.off_basis[l], m.off_att[l] + na, at.step_size, at.inv_sqrt_bc2,
+                       at.beta1, at.beta2, at.eps, at.wd);
         if (tid == 0) at.done[1 + l] = 0;
       }
     }
