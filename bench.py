@@ -181,7 +181,9 @@ def main():
     # ---- roofline leg: instrumented pass (HIP events around every kernel on the launch stream)
     roofline = None
     kernels = {}
-    if rank == 0 and args.profile_steps > 0:
+    if args.profile_steps > 0:
+        # EVERY rank runs the instrumented steps (under data parallelism each of them holds a gradient all-reduce,
+        # a collective all ranks must enter); rank 0 reports its own kernels
         engine.profile_enable(lib, True)
         Ns, Es = [], []
         sg.use_graph, sg.graphs = False, [None, None]   # instrumented pass launches eagerly

@@ -185,9 +185,24 @@ class StepGraph(object):
     def _capture(self, parity):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._enqueue(parity, self.B, with_finish=not self.dp_path)
-        self.graphs[parity] = g
+        if self.world <= 1:
+            with torch.cuda.graph(g):
+                self._enqueue(parity, self.B, with_finish=not self.dp_path)
+            self.graphs[parity] = g
+            return
+        # several processes: the RCCL watchdog thread of torch.distributed polls events while this thread captures, so
+        # the capture must only police THIS thread ('thread_local'); a refused capture is not fatal -- the same HIP
+        # launches then run eagerly (capturing does not execute anything, so no step is lost)
+        try:
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                self._enqueue(parity, self.B, with_finish=False)
+            self.graphs[parity] = g
+        except RuntimeError as e:
+            import sys
+            sys.stderr.write('igmc_amd: hipGraph capture refused under data parallelism (%s); launching eagerly\n'
+                             % str(e).splitlines()[0])
+            self.use_graph, self.graphs = False, [None, None]
+            torch.cuda.synchronize()
 
     def step(self, B=None):
         """One optimisation step on the next ``B`` links of the epoch permutation."""
