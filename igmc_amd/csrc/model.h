@@ -35,6 +35,9 @@ struct ModelDev {
   float* ts_part;     // [4][IGMC_TS_BLOCKS][ts_stride] relation-space tables [W_r rows | root rows | bias] per layer (or NULL)
   float* ts_raw;      // [4][ts_stride] their sum over the workgroups
   int ts_stride;      // (R*32 + 33) * 32
+  float* fin_stash;   // [4][256] per conv layer: Gram of the bases [0..15], ARR matrix M [16..31], att copy [64..64+R*4);
+                      // then [16] Adam scalars of the step -- written by k_tail_ts, read by k_finalize_ts (or NULL)
+  float* datt_part;   // [4*ts_stride/32][4] partial <dW_r, basis_b> products of 32 table elements (k_tail_ts)
   int* gs_bar;        // k_graph_step clusters: [0] workgroups that finished the launch, [1] launch sequence number
   int* gs_err;        // [1] set when a cluster exchange timed out
   unsigned long long* gs_ll;   // [5 exchanges][node_cap][32] {value, tag} words of the cluster exchanges (R <= 5 only)

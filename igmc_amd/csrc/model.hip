@@ -1533,7 +1533,11 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_partials(ModelDev m, int 
 
 // relation-space tables of graphstep.hip: ts_raw[l][i] = sum over the workgroups' partials (fixed order);
 // 64 outputs per block, the 4 waves split the partial slices
-__device__ __forceinline__ void reduce_ts_body(const ModelDev& m, int nparts, int stride, int B, int blk) {
+// Pold != NULL: wave 0 also forms, per 32 consecutive outputs (always inside one dW_r block: ts_stride and fin*32 are
+// multiples of 32), the partial dot products <dW_r, basis_b> (b = 0..3) with the CURRENT parameters -- d att[r,b] is
+// the sum of the fin partials of its block (k_finalize_ts), so that kernel never reads a basis element it does not own.
+__device__ __forceinline__ void reduce_ts_body(const ModelDev& m, int nparts, int stride, int B, int blk,
+                                               const float* __restrict__ Pold = nullptr) {
   __shared__ float sred[4][64];
   const int ts = m.ts_stride, rows0 = m.R * m.L + m.L + 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1564,7 +1568,96 @@ __device__ __forceinline__ void reduce_ts_body(const ModelDev& m, int nparts, in
   }
   sred[wave][lane] = s;
   __syncthreads();
-  if (wave == 0 && ok) m.ts_raw[o] = (sred[0][lane] + sred[1][lane]) + (sred[2][lane] + sred[3][lane]);
+  if (wave == 0) {
+    const float tot = ok ? (sred[0][lane] + sred[1][lane]) + (sred[2][lane] + sred[3][lane]) : 0.f;
+    if (ok) m.ts_raw[o] = tot;
+    if (Pold) {
+      float pb[4] = {0.f, 0.f, 0.f, 0.f};
+      if (l < 4) {
+        const int nE = ((l == 0) ? m.L : 32) * 32;
+        if (i < m.R * nE) {
+          const float* basis = Pold + m.off_basis[l] + i % nE;
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) pb[bb] = tot * basis[bb * nE];
+        }
+      }
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) pb[bb] += __shfl_xor(pb[bb], d, 64);     // stays inside a 32-lane half
+      if ((lane & 31) == 0 && l < 4) *(float4*)(m.datt_part + (size_t)(o >> 5) * 4) = make_float4(pb[0], pb[1], pb[2], pb[3]);
+    }
+  }
+}
+
+// Weights-only quantities of conv layer l for k_finalize_ts, formed while the tables are being reduced: Gram matrix of
+// the bases, ARR matrix M[b][b'] = sum_r att[r,b] c[r,b'], the ARR value, a copy of att (k_finalize_ts updates att in
+// place while other workgroups still need the old values) and, from the control block, the Adam scalars of the step.
+#define IGMC_STASH_G 0
+#define IGMC_STASH_M 16
+#define IGMC_STASH_ATT 64
+#define IGMC_STASH_LAYER 256
+#define IGMC_STASH_SCAL (4 * IGMC_STASH_LAYER)
+__device__ __forceinline__ void fin_stash_body(const ModelDev& m, const float* __restrict__ P, int l,
+                                               const int64_t* ctrl) {
+  __shared__ float sg10[4][10];
+  __shared__ float sG[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nE = ((l == 0) ? m.L : 32) * 32, R = m.R, na = R * 4;
+  const float* basis = P + m.off_basis[l];
+  const float* att = P + m.off_att[l];
+  float* st = m.fin_stash + l * IGMC_STASH_LAYER;
+  float gp[10];
+#pragma unroll
+  for (int q = 0; q < 10; ++q) gp[q] = 0.f;
+  for (int e = tid; e < nE; e += IGMC_BLOCK) {
+    const float b0 = basis[e], b1 = basis[nE + e], b2 = basis[2 * nE + e], b3 = basis[3 * nE + e];
+    gp[0] += b0 * b0; gp[1] += b0 * b1; gp[2] += b0 * b2; gp[3] += b0 * b3;
+    gp[4] += b1 * b1; gp[5] += b1 * b2; gp[6] += b1 * b3;
+    gp[7] += b2 * b2; gp[8] += b2 * b3; gp[9] += b3 * b3;
+  }
+#pragma unroll
+  for (int q = 0; q < 10; ++q) gp[q] = igmc_wave_sum_f(gp[q]);
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 10; ++q) sg10[wave][q] = gp[q];
+  }
+  if (tid >= 64 && tid < 80) {           // M[b][b'] = sum_r att[r,b] c[r,b'],  c[r] = 2 (d[r-1] - d[r]),  d[r] = att[r+1]-att[r]
+    const int bb = (tid - 64) >> 2, bp = tid & 3;
+    float sacc = 0.f;
+    for (int r = 0; r < R; ++r) {
+      const float dm = (r > 0) ? att[r * 4 + bp] - att[(r - 1) * 4 + bp] : 0.f;
+      const float dn = (r + 1 < R) ? att[(r + 1) * 4 + bp] - att[r * 4 + bp] : 0.f;
+      sacc += att[r * 4 + bb] * 2.f * (dm - dn);
+    }
+    st[IGMC_STASH_M + tid - 64] = sacc;
+  }
+  if (tid >= 128 && tid < 128 + na && na <= IGMC_STASH_LAYER - IGMC_STASH_ATT) st[IGMC_STASH_ATT + tid - 128] = att[tid - 128];
+  if (l == 0 && ctrl && tid >= 192 && tid < 198) {
+    const double* d = (const double*)ctrl;
+    const int k = tid - 192;
+    const int src = (k == 0) ? IGMC_CTRL_STEP_SIZE : (k == 1) ? IGMC_CTRL_INV_SQRT_BC2 : (k == 2) ? IGMC_CTRL_BETA1
+                  : (k == 3) ? IGMC_CTRL_BETA2 : (k == 4) ? IGMC_CTRL_EPS : IGMC_CTRL_WD;
+    m.fin_stash[IGMC_STASH_SCAL + k] = (float)d[src];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int ij[10][2] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {1, 1}, {1, 2}, {1, 3}, {2, 2}, {2, 3}, {3, 3}};
+    for (int q = 0; q < 10; ++q) {
+      const float v = (sg10[0][q] + sg10[1][q]) + (sg10[2][q] + sg10[3][q]);
+      sG[ij[q][0] * 4 + ij[q][1]] = v;
+      sG[ij[q][1] * 4 + ij[q][0]] = v;
+    }
+    float reg = 0.f;                       // reg = sum_r d[r]^T Gm d[r]   (reference train_eval.py:167-174)
+    for (int r = 0; r + 1 < R; ++r) {
+      float d[4];
+      for (int q = 0; q < 4; ++q) d[q] = att[(r + 1) * 4 + q] - att[r * 4 + q];
+      for (int p1 = 0; p1 < 4; ++p1)
+        for (int p2 = 0; p2 < 4; ++p2) reg += d[p1] * sG[p1 * 4 + p2] * d[p2];
+    }
+    m.arr_part[l] = reg;
+    for (int q = 0; q < 16; ++q) st[IGMC_STASH_G + q] = sG[q];
+  }
 }
 
 __global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_ts(ModelDev m, int nparts, int stride, int B) {
@@ -1573,14 +1666,19 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_ts(ModelDev m, int nparts
 
 // Both consumers of k_graph_step's outputs in ONE launch (they are independent of each other): the first `nlin`
 // workgroups form d lin1 / d lin2 (batched product over the subgraphs), the others sum the relation-space tables.
+// nstash = 4: the last four workgroups stash the weights-only quantities k_finalize_ts needs and the reduction also
+// forms the d att partial products (0: the tables only, for k_finalize).
 __global__ __launch_bounds__(IGMC_BLOCK) void k_tail_ts(BatchDev b, ModelDev m, const float* __restrict__ P,
                                                           float grad_scale, float mult, float drop_scale,
                                                           float* __restrict__ grad, int nlin, int nparts, int stride,
-                                                          int B) {
+                                                          int B, int nstash, const int64_t* ctrl) {
+  const int nred = (int)gridDim.x - nlin - nstash;
   if ((int)blockIdx.x < nlin)
     head_bwd_w_body(b, m, P, nullptr, 1, grad_scale, mult, drop_scale, grad, blockIdx.x & 7, blockIdx.x >> 3);
+  else if ((int)blockIdx.x < nlin + nred)
+    reduce_ts_body(m, nparts, stride, B, blockIdx.x - nlin, nstash ? P : nullptr);
   else
-    reduce_ts_body(m, nparts, stride, B, blockIdx.x - nlin);
+    fin_stash_body(m, P, blockIdx.x - nlin - nred, ctrl);
 }
 
 struct FinishArgs {
@@ -1866,6 +1964,126 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize(ModelDev m, const float
         if (at.ctrl) ctrl_advance(at.ctrl);
       }
     }
+  }
+}
+
+// Relation-space tables -> flat gradient (+ ARR) -> Adam, with NO hand-off between workgroups: k_tail_ts has already
+// formed everything that needs parameters a thread does not own (Gram / ARR matrices, the ARR value, a copy of att,
+// the <dW_r, basis_b> partials, the Adam scalars), so a thread reads the table rows of ITS column (c, f), produces the
+// gradient of basis[0..3][c][f] and root[c][f], and updates exactly those parameters in the same pass; bias and att
+// are taken by the layer's first workgroup.  Workgroups 4*IGMC_FTS_NB.. : Adam on slices of lin1 / lin2, the last one
+// loss + epoch total + control-block tick (nobody else reads the control block in this launch).
+// (k_finalize needs two in-kernel hand-offs for the same work -- layer-wide before Adam, grid-wide before the tick --
+//  each an agent-scope fence pair + an atomic round trip.)
+#define IGMC_FTS_NB 4
+__device__ __forceinline__ void fts_emit(float* __restrict__ grad, const AdamTail& at, int64_t i, float g, float pold,
+                                         float m1old, float m2old) {
+  grad[i] = g;
+  if (at.enabled) {
+    float gi = g;
+    if (at.wd != 0.f) gi += at.wd * pold;
+    const float a = at.beta1 * m1old + (1.f - at.beta1) * gi;
+    const float v = at.beta2 * m2old + (1.f - at.beta2) * gi * gi;
+    at.m1[i] = a;
+    at.m2[i] = v;
+    at.p[i] = pold - at.step_size * a / (sqrtf(v) * at.inv_sqrt_bc2 + at.eps);
+  }
+}
+
+__global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const float* P, float* __restrict__ grad,
+                                                              float arr_coef, AdamTail at, int nlin) {
+  __shared__ float smf[8];
+  const int tid = threadIdx.x;
+  const float* stash = m.fin_stash;
+  if (at.enabled && at.ctrl) {      // hipGraph replay: the Adam scalars of the step, stashed by k_tail_ts
+    at.step_size = stash[IGMC_STASH_SCAL + 0];
+    at.inv_sqrt_bc2 = stash[IGMC_STASH_SCAL + 1];
+    at.beta1 = stash[IGMC_STASH_SCAL + 2];
+    at.beta2 = stash[IGMC_STASH_SCAL + 3];
+    at.eps = stash[IGMC_STASH_SCAL + 4];
+    at.wd = stash[IGMC_STASH_SCAL + 5];
+  }
+  if ((int)blockIdx.x < 4 * IGMC_FTS_NB) {
+    const int l = blockIdx.x / IGMC_FTS_NB, part = blockIdx.x % IGMC_FTS_NB;
+    const int fin = (l == 0) ? m.L : 32, nE = fin * 32, R = m.R, na = R * 4;
+    const float* st = stash + l * IGMC_STASH_LAYER;
+    const float* t0 = m.ts_raw + (size_t)l * m.ts_stride;
+    for (int e = part * IGMC_BLOCK + tid; e < nE; e += IGMC_FTS_NB * IGMC_BLOCK) {       // one round for fin <= 32
+      int64_t idx[5];
+      float pv[5], m1v[5], m2v[5], g[5];
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        idx[q] = (q < 4) ? m.off_basis[l] + (int64_t)q * nE + e : m.off_root[l] + e;
+        pv[q] = P[idx[q]];
+        m1v[q] = at.enabled ? at.m1[idx[q]] : 0.f;
+        m2v[q] = at.enabled ? at.m2[idx[q]] : 0.f;
+        g[q] = 0.f;
+      }
+      float tv[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) tv[r] = (r < R) ? t0[(size_t)r * nE + e] : 0.f;
+      g[4] = t0[(size_t)R * nE + e];
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (r < R) {
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) g[bb] += st[IGMC_STASH_ATT + r * 4 + bb] * tv[r];
+        }
+      for (int r = 8; r < R; ++r) {          // (never taken: the tables exist for R <= 5)
+        const float tvr = t0[(size_t)r * nE + e];
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) g[bb] += st[IGMC_STASH_ATT + r * 4 + bb] * tvr;
+      }
+      if (arr_coef != 0.f) {
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+          g[bb] += arr_coef * (st[IGMC_STASH_M + bb * 4 + 0] * pv[0] + st[IGMC_STASH_M + bb * 4 + 1] * pv[1] +
+                               st[IGMC_STASH_M + bb * 4 + 2] * pv[2] + st[IGMC_STASH_M + bb * 4 + 3] * pv[3]);
+      }
+#pragma unroll
+      for (int q = 0; q < 5; ++q) fts_emit(grad, at, idx[q], g[q], pv[q], m1v[q], m2v[q]);
+    }
+    if (part == 0) {
+      if (tid < 32) {                              // d bias
+        const int64_t i = m.off_bias[l] + tid;
+        fts_emit(grad, at, i, t0[(size_t)(R * fin + fin) * 32 + tid], P[i], at.enabled ? at.m1[i] : 0.f,
+                 at.enabled ? at.m2[i] : 0.f);
+      } else if (tid >= 64 && tid < 64 + na) {     // d att[r,b] = <dW_r, basis_b> (+ ARR): fin partials, fixed order
+        const int rb = tid - 64, r = rb >> 2, bb = rb & 3;
+        const int64_t i = m.off_att[l] + rb;
+        const float pold = st[IGMC_STASH_ATT + rb];
+        const float m1o = at.enabled ? at.m1[i] : 0.f, m2o = at.enabled ? at.m2[i] : 0.f;
+        const float* dp = m.datt_part + ((size_t)l * m.ts_stride + (size_t)r * nE) / 32 * 4 + bb;
+        float g = 0.f;
+        for (int k0 = 0; k0 < fin; k0 += 32) {
+          float v[32];
+#pragma unroll
+          for (int k = 0; k < 32; ++k) v[k] = (k0 + k < fin) ? dp[(size_t)(k0 + k) * 4] : 0.f;
+#pragma unroll
+          for (int k = 0; k < 32; ++k) g += v[k];
+        }
+        if (arr_coef != 0.f) {
+          float sacc = 0.f;
+          for (int bp = 0; bp < 4; ++bp) {
+            const float a0 = st[IGMC_STASH_ATT + r * 4 + bp];
+            const float dm = (r > 0) ? a0 - st[IGMC_STASH_ATT + (r - 1) * 4 + bp] : 0.f;
+            const float dn = (r + 1 < R) ? st[IGMC_STASH_ATT + (r + 1) * 4 + bp] - a0 : 0.f;
+            sacc += 2.f * (dm - dn) * st[IGMC_STASH_G + bp * 4 + bb];
+          }
+          g += arr_coef * sacc;
+        }
+        fts_emit(grad, at, i, g, pold, m1o, m2o);
+      }
+    }
+  } else if ((int)blockIdx.x < 4 * IGMC_FTS_NB + nlin) {      // Adam on lin1 / lin2 (their gradients are final already)
+    const int64_t n_lin = m.n_params - m.off_l1w;
+    const int64_t chunk = (n_lin + nlin - 1) / nlin;
+    const int64_t lo = m.off_l1w + (int64_t)(blockIdx.x - 4 * IGMC_FTS_NB) * chunk;
+    const int64_t hi = (lo + chunk < m.n_params) ? lo + chunk : m.n_params;
+    adam_range<8>(at.p, grad, at.m1, at.m2, lo, hi, at.step_size, at.inv_sqrt_bc2, at.beta1, at.beta2, at.eps, at.wd);
+  } else {                                                     // loss, epoch total, control-block tick
+    loss_body(at.b, m, at.ARR, at.loss, at.total, smf);
+    if (tid == 0 && at.ctrl) ctrl_advance(at.ctrl);
   }
 }
 
@@ -2157,15 +2375,21 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
     const int gstride = (cs > 1) ? ((B + 7) & ~7) : IGMC_TS_BLOCKS;
     const int gg = (cs > 1) ? cs * gstride : igmc_gs_grid(B);
     igmc_launch_graph_step(m, b, P, B, 1, use_flags, lay, inj_mask, seed, step, mult, grad_scale, out, stream);
-    IGMC_PLAUNCH("k_tail_ts", k_tail_ts, 8 * ny + (4 * m.ts_stride + 63) / 64, IGMC_BLOCK, 0, stream, b, m,
-                 (const float*)P, grad_scale, mult, 2.f, grad, 8 * ny, gg, gstride, B);
+    // IGMC_FIN_MODE=0: the hand-off version of the gradient / Adam tail (k_finalize) instead of k_finalize_ts
+    const char* fe = getenv("IGMC_FIN_MODE");        // read on every call: tests switch it per case
+    const int fts = (fe ? atoi(fe) : 1) && m.fin_stash && m.datt_part && m.R <= 8;
+    IGMC_PLAUNCH("k_tail_ts", k_tail_ts, 8 * ny + (4 * m.ts_stride + 63) / 64 + (fts ? 4 : 0), IGMC_BLOCK, 0, stream, b, m,
+                 (const float*)P, grad_scale, mult, 2.f, grad, 8 * ny, gg, gstride, B, fts ? 4 : 0,
+                 (const int64_t*)(adam ? at.ctrl : nullptr));
     if (adam) {
       at.enabled = 1;
       at.b = b;
       at.ARR = ARR;
-      IGMC_PLAUNCH("k_finalize_adam", k_finalize, 4 * IGMC_FIN_NB + 32, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 1);
+      if (fts) IGMC_PLAUNCH("k_finalize_adam", k_finalize_ts, 4 * IGMC_FTS_NB + 32 + 1, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 32);
+      else IGMC_PLAUNCH("k_finalize_adam", k_finalize, 4 * IGMC_FIN_NB + 32, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 1);
     } else {
-      IGMC_PLAUNCH("k_finalize", k_finalize, 4 * IGMC_FIN_NB, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 1);
+      if (fts) IGMC_PLAUNCH("k_finalize", k_finalize_ts, 4 * IGMC_FTS_NB, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 0);
+      else IGMC_PLAUNCH("k_finalize", k_finalize, 4 * IGMC_FIN_NB, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 1);
       if (loss) igmc_launch_loss(m, b, ARR, loss, stream);
     }
     return;

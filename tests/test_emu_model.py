@@ -57,6 +57,13 @@ def test_layer_kernel_variants(be, monkeypatch, mode):
     assert res['worst_grad_err'] < 1e-4
 
 
+def test_hand_off_finalize_variant(be, monkeypatch):
+    # IGMC_FIN_MODE=0: subgraph kernel + k_finalize (in-kernel hand-offs) instead of the default k_finalize_ts
+    monkeypatch.setenv('IGMC_FIN_MODE', '0')
+    res = PC.run_model_parity(be, sub('synth_cap', 6), R=5, use_dropout=True)
+    assert res['worst_grad_err'] < 1e-4
+
+
 @pytest.mark.parametrize('n_side', [32, 10])
 def test_side_features(be, n_side):
     """--use-features path (reference models.py:186-188,208-209): lin1 widens by n_side; 32 -> MFMA head

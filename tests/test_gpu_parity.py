@@ -103,6 +103,13 @@ def test_layer_kernel_variants(be, monkeypatch, mode):
     assert res['worst_grad_err'] < 2e-3
 
 
+def test_hand_off_finalize_variant(be, monkeypatch):
+    # IGMC_FIN_MODE=0: subgraph kernel + k_finalize (in-kernel hand-offs) instead of the default k_finalize_ts
+    monkeypatch.setenv('IGMC_FIN_MODE', '0')
+    res = PC.run_model_parity(be, sub('synth_cap', 16), R=5, use_dropout=True)
+    assert res['worst_grad_err'] < 2e-3
+
+
 @pytest.mark.parametrize('n_side', [48, 10])
 def test_side_features(be, n_side):
     res = PC.run_model_parity(be, sub('flixster', 40), R=10, use_dropout=True, n_side=n_side)
