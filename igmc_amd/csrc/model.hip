@@ -1547,22 +1547,22 @@ __device__ __forceinline__ void reduce_ts_body(const ModelDev& m, int nparts, in
   const bool ok = l < 4 && (l > 0 || i < rows0 * 32);
   if (ok) {
     // slot of member c of subgraph g = g + c * stride (one-workgroup launches: stride = IGMC_TS_BLOCKS, cs = 1);
-    // the 4 waves split the subgraphs; up to 4 members x 8 subgraphs = 32 independent loads in flight per round (one
-    // round trip per round: the reduction is latency-bound), fixed order
+    // the 4 waves split the subgraphs; up to 4 members x 14 subgraphs = 56 independent loads in flight per round (one
+    // round trip per round: the reduction is latency-bound; a batch of <= 56 subgraphs is ONE round), fixed order
     const float* p = m.ts_part + (size_t)l * IGMC_TS_BLOCKS * ts + i;
     const int ng = (nparts < stride) ? nparts : ((B < stride) ? B : stride), cs = (nparts + stride - 1) / stride;
     for (int c0 = 0; c0 < cs; c0 += 4) {
-      for (int g0 = wave; g0 < ng; g0 += 32) {
-        float v[4][8];
+      for (int g0 = wave; g0 < ng; g0 += 56) {
+        float v[4][14];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-          for (int u = 0; u < 8; ++u)
+          for (int u = 0; u < 14; ++u)
             v[c][u] = (c0 + c < cs && g0 + 4 * u < ng) ? p[((size_t)(c0 + c) * stride + g0 + 4 * u) * ts] : 0.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-          for (int u = 0; u < 8; ++u) s += v[c][u];
+          for (int u = 0; u < 14; ++u) s += v[c][u];
       }
     }
   }

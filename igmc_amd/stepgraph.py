@@ -163,14 +163,23 @@ class StepGraph(object):
         fused = (not self.dp_path) and with_finish and B == self.B
         if self.side is not None:
             self.side.wait_stream(main)
-            with torch.cuda.stream(self.side):
-                self._extract(nxt, 1 - parity, self.B)
+            # launch order inside the fork: the model kernels are enqueued BEFORE the extraction branch, so that the
+            # subgraph kernel (one workgroup per CU, 224 of 256 CUs) is dispatched first and the extraction workgroups
+            # fill what is left; the other order lets ~50 extraction workgroups take CUs first and the cluster
+            # members that find no CU stall their whole cluster: 320 k -> 341 k subgraphs/s (IGMC_MAIN_FIRST=0: old order)
+            main_first = os.environ.get('IGMC_MAIN_FIRST', '1') == '1'
+            if not main_first:
+                with torch.cuda.stream(self.side):
+                    self._extract(nxt, 1 - parity, self.B)
             if fused:
                 # the step's last kernel advances ONLY the control slot of its own parity; the prefetch reads the
                 # other one, so the two branches never touch the same word
                 self._train_step(cur)
             else:
                 self._model(cur, B)
+            if main_first:
+                with torch.cuda.stream(self.side):
+                    self._extract(nxt, 1 - parity, self.B)
             main.wait_stream(self.side)
         else:
             if fused:
@@ -237,7 +246,9 @@ class StepGraph(object):
                 if self.multi is None:
                     torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    # experiment hook: capture the model branch on a high-priority stream (IGMC_HP_MAIN=1)
+                    hp = torch.cuda.Stream(device=self.dev, priority=-1) if os.environ.get('IGMC_HP_MAIN', '0') == '1' else None
+                    with torch.cuda.graph(g, stream=hp):
                         for i in range(M):
                             self._enqueue(i % 2, self.B)
                     self.multi = g
