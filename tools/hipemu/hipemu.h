@@ -8,7 +8,9 @@
 // package, bench.py or smoke(): igmc_amd refuses to run without the real
 // gfx950 library.
 //
-// Execution model: one workgroup at a time; every work-item is a ucontext fiber.
+// Execution model: one workgroup at a time; every work-item is a fiber (x86-64: a 7-instruction register/stack
+// switch -- glibc's swapcontext makes an rt_sigprocmask system call per switch, which was 40 % of the suite's time;
+// other hosts: ucontext).
 // Fibers run until they reach a collective (block barrier / wave collective),
 // where they yield to a round-robin scheduler.  Because a fiber runs far ahead
 // of its neighbours between collectives, any code that silently relies on
@@ -79,8 +81,44 @@ struct WaveState {
   float fa[WAVE], fb[WAVE], fc[WAVE][4];
 };
 
+#if defined(__x86_64__)
+#define HIPEMU_ASM_SWITCH 1
+// saves the callee-saved registers of the SysV ABI on the current stack, stores the stack pointer in *from_sp and
+// continues on to_sp (weak: the header is included by several translation units of one library)
+extern "C" void hipemu_switch(void** from_sp, void* to_sp);
+asm(R"(
+.text
+.weak hipemu_switch
+.type hipemu_switch,@function
+hipemu_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size hipemu_switch,.-hipemu_switch
+)");
+struct Ctx {
+  void* sp = nullptr;
+};
+#else
+struct Ctx {
+  ucontext_t uc;
+};
+#endif
+
 struct Fiber {
-  ucontext_t ctx;
+  Ctx ctx;
   char* stack = nullptr;
   bool done = true;
   int tid = 0;
@@ -93,7 +131,7 @@ struct BlockState {
 };
 
 struct Runtime {
-  ucontext_t sched;
+  Ctx sched;
   std::vector<Fiber> fibers;
   BlockState blk;
   int cur = -1;
@@ -110,10 +148,18 @@ inline Runtime& rt() {
   return r;
 }
 
+inline void ctx_switch(Ctx& from, Ctx& to) {
+#ifdef HIPEMU_ASM_SWITCH
+  hipemu_switch(&from.sp, to.sp);
+#else
+  swapcontext(&from.uc, &to.uc);
+#endif
+}
+
 inline void yield() {
   Runtime& r = rt();
   r.n_switch++;
-  swapcontext(&r.fibers[r.cur].ctx, &r.sched);
+  ctx_switch(r.fibers[r.cur].ctx, r.sched);
 }
 
 inline void fiber_main() {
@@ -127,7 +173,28 @@ inline void fiber_main() {
   if (w.active > 0 && w.arrived == w.active) { w.arrived = 0; w.gen++; }
   r.blk.active--;
   if (r.blk.active > 0 && r.blk.arrived == r.blk.active) { r.blk.arrived = 0; r.blk.gen++; }
-  swapcontext(&f.ctx, &r.sched);
+  ctx_switch(f.ctx, r.sched);
+  abort();                 // a finished fiber is never resumed
+}
+
+inline void fiber_prepare(Fiber& f, Ctx& link) {
+#ifdef HIPEMU_ASM_SWITCH
+  (void)link;
+  // initial frame: six callee-saved registers (zero), then the address hipemu_switch "returns" to; the entry point
+  // sees the stack as after a call (rsp = 16n + 8)
+  uintptr_t top = ((uintptr_t)f.stack + STACK) & ~(uintptr_t)15;
+  void** sp = (void**)top;
+  *--sp = nullptr;                           // return address of fiber_main (never used)
+  *--sp = (void*)(void (*)())fiber_main;
+  for (int i = 0; i < 6; ++i) *--sp = nullptr;
+  f.ctx.sp = (void*)sp;
+#else
+  getcontext(&f.ctx.uc);
+  f.ctx.uc.uc_stack.ss_sp = f.stack;
+  f.ctx.uc.uc_stack.ss_size = STACK;
+  f.ctx.uc.uc_link = &link.uc;
+  makecontext(&f.ctx.uc, (void (*)())fiber_main, 0);
+#endif
 }
 
 inline void run_block(int nthreads) {
@@ -144,11 +211,7 @@ inline void run_block(int nthreads) {
     f.done = false;
     f.tid = t;
     r.blk.waves[t / WAVE].active++;
-    getcontext(&f.ctx);
-    f.ctx.uc_stack.ss_sp = f.stack;
-    f.ctx.uc_stack.ss_size = STACK;
-    f.ctx.uc_link = &r.sched;
-    makecontext(&f.ctx, (void (*)())fiber_main, 0);
+    fiber_prepare(f, r.sched);
   }
   int remaining = nthreads;
   long idle_rounds = 0;
@@ -158,7 +221,7 @@ inline void run_block(int nthreads) {
       Fiber& f = r.fibers[t];
       if (f.done) continue;
       r.cur = t;
-      swapcontext(&r.sched, &f.ctx);
+      ctx_switch(r.sched, f.ctx);
       if (f.done) { remaining--; progressed++; }
     }
     (void)progressed;
