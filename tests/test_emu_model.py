@@ -41,6 +41,8 @@ def sub(name, n):
     ('douban_cap20', 5, 5, False, 2.0),
     ('hand', 5, 5, True, 1.0),
     ('synth_nocap:45', 3, 5, True, 1.0),   # up to 92 nodes: two 64-row passes per layer
+    ('synth_nocap:100', 4, 5, True, 1.0),  # up to 202 nodes (the ml_1m shape): 13 bundles, ranked schedule
+    ('douban:100', 6, 5, False, 1.0),
 ])
 def test_forward_backward_parity(be, name, n, R, drop, mult):
     res = PC.run_model_parity(be, sub(name, n), R=R, use_dropout=drop, multiply_by=mult)
