@@ -119,7 +119,9 @@ def main():
     lib = _lib.load()                                  # fails loudly without the gfx950 library
 
     # ---- workload (identical on every rank)
-    split = preprocessing.create_trainvaltest_split(cfg['dataset'], 1234, True, verbose=(rank == 0))
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):       # stdout carries the ONE JSON line only
+        split = preprocessing.create_trainvaltest_split(cfg['dataset'], 1234, True, verbose=(rank == 0))
     (_, _, A, tr_l, tr_u, tr_v, _, _, _, te_l, te_u, te_v, class_values) = split
     source = 'real' if preprocessing._load_real_movielens(cfg['dataset']) is not None else 'synthetic'
     torch.manual_seed(1)
