@@ -242,16 +242,18 @@ class StepGraph(object):
         n = int(n)
         while n > 0:
             M = self.multi_n
-            if (self.use_graph and not self.dp_path and M >= 2 and n >= M and self.k % 2 == 0 and self.steps_done >= 4):
-                if self.multi is None:
-                    torch.cuda.synchronize()
-                    g = torch.cuda.CUDAGraph()
-                    # experiment hook: capture the model branch on a high-priority stream (IGMC_HP_MAIN=1)
-                    hp = torch.cuda.Stream(device=self.dev, priority=-1) if os.environ.get('IGMC_HP_MAIN', '0') == '1' else None
-                    with torch.cuda.graph(g, stream=hp):
-                        for i in range(M):
-                            self._enqueue(i % 2, self.B)
-                    self.multi = g
+            multi_ok = self.use_graph and not self.dp_path and M >= 2 and self.k % 2 == 0 and self.steps_done >= 4
+            if multi_ok and self.multi is None:
+                # captured as soon as it can be (capturing executes nothing), also when fewer than M steps are asked for
+                # right now: the milliseconds a capture costs then fall into the caller's warm-up, not into its first
+                # long run
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for i in range(M):
+                        self._enqueue(i % 2, self.B)
+                self.multi = g
+            if multi_ok and n >= M:
                 self.multi.replay()
                 self.k += M
                 self.steps_done += M
