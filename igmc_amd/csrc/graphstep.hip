@@ -82,11 +82,7 @@ __device__ __forceinline__ uint32_t gs_qbcast(uint32_t v) {
 #endif
 }
 
-// Relation-space aggregate of one row by one QUAD (lane j owns features 8j..8j+7), gather source in LDS, result
-// rows T_r written straight into the wave's tile row `trow`.  The relation loop is UNIFORM over the wave (every
-// quad is in the same relation at the same time, each on its own run [rptr[r], rptr[r+1]) of its row), so there
-// is no run-change branch: per edge one DPP broadcast, one address select, two ds_read_b128 and 8 adds; the
-// index load and the row loads of the next 4-entry group are in flight while the current one is summed.
+// one CSR entry of the batch (source node | relation), GS_INVALID beyond the run or when its keep bit is clear
 template <bool FLAGS, bool TRANS>
 __device__ __forceinline__ uint32_t gs_entry(const BatchDev& b, int e, int end) {
   uint32_t w = GS_INVALID;

@@ -1660,10 +1660,6 @@ __device__ __forceinline__ void fin_stash_body(const ModelDev& m, const float* _
   }
 }
 
-__global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_ts(ModelDev m, int nparts, int stride, int B) {
-  reduce_ts_body(m, nparts, stride, B, blockIdx.x);
-}
-
 // Both consumers of k_graph_step's outputs in ONE launch (they are independent of each other): the first `nlin`
 // workgroups form d lin1 / d lin2 (batched product over the subgraphs), the others sum the relation-space tables.
 // nstash = 4: the last four workgroups stash the weights-only quantities k_finalize_ts needs and the reduction also
