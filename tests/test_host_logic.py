@@ -102,3 +102,72 @@ def test_data_parallel_host_logic_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert 'rank %d ok' % r in o
+
+
+_DP_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+import numpy as np, torch
+from igmc_amd import parallel, engine
+import parity_checks as PC
+from helpers import load_extract_golden
+rank, world = parallel.init_from_env('gloo')
+be = PC.EmuBackend()                      # kernel logic on the CPU emulation (test infrastructure)
+case = dict(load_extract_golden()['synth_cap'])
+B = 4                                     # per-rank batch; global batch = 8 links
+def part(lo, hi):
+    c = dict(case)
+    c['recs'], c['links'], c['link_labels'] = case['recs'][lo:hi], case['links'][lo:hi], case['link_labels'][lo:hi]
+    return c
+rng = np.random.default_rng(0)
+gmask = (rng.random((B * world, 128)) < 0.5).astype(np.uint8)
+def grads(c, mask, grad_scale, arr_scale, tag):
+    g, b, d = PC.extract_case(be, c, replay=True)
+    ws = engine.ModelWorkspace(be.lib, be.device, 5, 4, 4, 0, b.node_capacity, b.edge_capacity, b.max_graphs)
+    ref = PC.make_ref_model(4, 5, seed=4)
+    P = PC.flatten_params(ws, ref)
+    G, out = np.zeros_like(P), np.zeros(d['B'], np.float32)
+    lm = np.ascontiguousarray(mask.reshape(-1))
+    ws.loss_grad(P.ctypes.data, b, out.ctypes.data, G.ctypes.data, None, lin_mask=lm.ctypes.data, ARR=0.001,
+                 grad_scale=grad_scale, arr_scale=arr_scale)
+    return ws, P, G
+# this rank's shard: mean over the GLOBAL batch = sum over ranks of (local sum / (B * G)); ARR gradient scaled 1/G
+ws, P, G = grads(part(rank * B, (rank + 1) * B), gmask[rank * B:(rank + 1) * B], 1.0 / (B * world), 1.0 / world, 'dp')
+t = torch.from_numpy(G)
+parallel.all_reduce_sum_(t)               # ONE flat all-reduce (reference has no distributed code; DESIGN.md section 5)
+M1, M2 = np.zeros_like(P), np.zeros_like(P)
+ws.adam_step(P.ctypes.data, G.ctypes.data, M1.ctypes.data, M2.ctypes.data, 1, 1e-3)
+# single-process run on the whole global batch
+ws1, P1, G1 = grads(part(0, B * world), gmask, 1.0 / (B * world), 1.0, 'single')
+scale = np.abs(G1).max()
+assert np.abs(G - G1).max() < 2e-5 * scale, np.abs(G - G1).max() / scale
+M1, M2 = np.zeros_like(P1), np.zeros_like(P1)
+ws1.adam_step(P1.ctypes.data, G1.ctypes.data, M1.ctypes.data, M2.ctypes.data, 1, 1e-3)
+# Adam's first step is lr * sign(g) (up to eps): compare where the gradient is not at rounding level
+big = np.abs(G1) > 1e-3 * scale
+assert np.allclose(P[big], P1[big], rtol=0, atol=2e-6)
+# replicas stay identical: every rank holds the same parameters after the step
+chk = torch.from_numpy(P.copy()); parallel.broadcast_(chk, 0)
+assert np.array_equal(chk.numpy(), P)
+parallel.barrier()
+print('rank', rank, 'dp ok')
+'''
+
+
+def test_data_parallel_step_equals_global_batch_step_gloo(tmp_path):
+    """Two ranks (gloo), each running the kernels' logic on ITS half of a global batch with the data-parallel scale
+    arguments, one flat all-reduce, Adam: the result equals one process stepping on the whole global batch."""
+    from helpers import emu_lib
+    emu_lib()                                   # build once, not concurrently in the two workers
+    script = tmp_path / 'dp.py'
+    script.write_text(_DP_WORKER % (ROOT, ROOT))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT='29613')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert 'rank %d dp ok' % r in o
