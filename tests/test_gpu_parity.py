@@ -123,3 +123,31 @@ def test_bitwise_reproducible(be):
     r2 = PC.run_model_parity(be, sub('synth_nocap', 16), R=5, use_dropout=True)
     assert np.array_equal(r1['train_out'], r2['train_out'])
     assert np.array_equal(r1['loss'], r2['loss'])
+
+
+# ---- randomised twins of tests/test_emu_{extract,model}_random.py on the real library.  They were written at the end of
+#      round 1 with no GPU time left to run them once, so they only run on request (IGMC_RANDOM_GPU_TESTS=1) until a
+#      round has seen them pass on an MI355X; then the guard goes.
+_random_gpu = pytest.mark.skipif(__import__('os').environ.get('IGMC_RANDOM_GPU_TESTS', '0') != '1',
+                                 reason='set IGMC_RANDOM_GPU_TESTS=1 (not yet run on hardware)')
+
+
+@_random_gpu
+@pytest.mark.parametrize('h', [1, 2])
+def test_random_uncapped_extraction_matches_oracle(be, h):
+    from helpers import random_case
+    for seed in range(40):
+        case = random_case(1000 * h + seed, h)
+        _, _, d = PC.extract_case(be, case, replay=False)
+        PC.check_against_golden(d, case)
+
+
+@_random_gpu
+@pytest.mark.parametrize('h,mnph', [(1, None), (1, 6), (2, 4), (1, 12)])
+def test_random_graphs_forward_backward(be, h, mnph):
+    from helpers import random_case
+    for seed in range(6):
+        case = random_case(31000 + 17 * h + seed, h, mnph=mnph, n_links=5)
+        res = PC.run_model_parity(be, case, R=len(case['class_values']), use_dropout=bool(seed % 2),
+                                  multiply_by=1.0 + (seed % 3))
+        assert res['worst_grad_err'] < 2e-3

@@ -19,4 +19,5 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLE
 for p in pmc1 pmc2 pmc3; do python $ROOT/tools/rocprof_summary.py $ROOT/$OUT/$p --pmc > $ROOT/$OUT/$p.txt 2>&1; done
 rm -rf $ROOT/$OUT/kt $ROOT/$OUT/pmc1 $ROOT/$OUT/pmc2 $ROOT/$OUT/pmc3       # keep the summaries only (<= 64 MiB rule)
 cd $ROOT
+python $ROOT/tools/kernel_resources.py > $ROOT/$OUT/kernel_resources.txt 2>&1     # registers / LDS / waves per SIMD
 python $ROOT/tools/pmc_traffic.py $ROOT/$OUT $ROOT/$OUT/pmc_traffic.json > /dev/null 2>&1
