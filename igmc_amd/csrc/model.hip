@@ -2193,12 +2193,6 @@ static inline int igmc_slot_grid(const ModelDev& m, int B, int max_blocks) {
   return (int)(g < 8 ? 8 : g);
 }
 
-// fork: `to` waits for everything enqueued on `from` so far (an event edge; a graph edge under capture)
-static inline void igmc_edge(void* ev, void* from, void* to) {
-  hipEventRecord((hipEvent_t)ev, (hipStream_t)from);
-  hipStreamWaitEvent((hipStream_t)to, (hipEvent_t)ev, 0);
-}
-
 void igmc_launch_forward(const ModelDev& m, const ModelAux& ax, const BatchDev& b, const float* P, int B, int training,
                          int use_flags, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
                          float* out, void* stream) {
