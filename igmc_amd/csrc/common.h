@@ -5,7 +5,7 @@
 
 #ifdef IGMC_HIPEMU
 // tools/hipemu/hipemu.h is force-included (CPU emulation for kernel-logic tests only)
-#define IGMC_DYN_SMEM(name) unsigned char* name = hipemu::rt().dyn_smem
+#define IGMC_DYN_SMEM(name) unsigned char* name = hipemu::cur_block().dyn_smem
 #define IGMC_LAUNCH(kern, grid, block, shmem, stream, ...) \
   hipemu::launch(dim3(grid), dim3(block), (size_t)(shmem), [=]() { kern(__VA_ARGS__); })
 #define IGMC_WAVE_SYNC() igmc_emu_wave_sync()

@@ -256,7 +256,9 @@ __device__ __forceinline__ void gs_ll_pub(unsigned long long* p, float v, uint32
   __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
 #else
-  (void)p; (void)v; (void)tag;
+  uint32_t bits;
+  memcpy(&bits, &v, 4);
+  *p = ((unsigned long long)tag << 32) | (unsigned long long)bits;
 #endif
 }
 // All N x 32 words of an exchange into dst[N][32]: 16-byte sc1 loads (two words each), every pending request of a
@@ -308,7 +310,24 @@ __device__ __forceinline__ void gs_ll_reload(float* dst, const unsigned long lon
 #undef GS_LD
 #undef GS_CK
 #else
-  (void)dst; (void)gsrc; (void)N; (void)tag; (void)err;
+  // emulation (co-resident workgroups, see hipemu::Runtime::co_cs): poll word by word, yielding to the other
+  // work-items -- of this and of the other resident workgroups -- while the tag is not this exchange's
+  for (int k = (int)threadIdx.x; k < N * 32; k += GS_THREADS) {
+    long spins = 0;
+    for (;;) {
+      const unsigned long long w = gsrc[k];
+      if ((uint32_t)(w >> 32) == tag) {
+        const uint32_t bits = (uint32_t)w;
+        memcpy(&dst[k], &bits, 4);
+        break;
+      }
+      if (++spins > (1L << 22)) {
+        *err = 1;
+        break;
+      }
+      hipemu::yield();
+    }
+  }
 #endif
 }
 
@@ -394,7 +413,7 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
 #ifndef IGMC_HIPEMU
   const uint32_t tag0 = (cs > 1) ? (uint32_t)__hip_atomic_load(m.gs_bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * 8u + 1u : 0u;
 #else
-  const uint32_t tag0 = 0;
+  const uint32_t tag0 = (cs > 1) ? (uint32_t)m.gs_bar[1] * 8u + 1u : 0u;
 #endif
   const uint64_t step = m.ctrl ? (uint64_t)m.ctrl[IGMC_CTRL_STEP] : a.step;
   GS_STAMP(0);
@@ -1176,6 +1195,13 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
       __hip_atomic_fetch_add(m.gs_bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+#else
+  if (cs > 1 && tid == 0) {
+    if (m.gs_bar[0]++ == (int)gridDim.x - 1) {
+      m.gs_bar[0] = 0;
+      m.gs_bar[1] += 1;
+    }
+  }
 #endif
   GS_STAMP(12);
 }
@@ -1228,8 +1254,14 @@ int igmc_gs_eligible(const ModelDev& m, const BatchDev& b, GsLayout* lay) {
 // workgroups per subgraph: 4 (2) when 4 (2) x the padded batch still fits one workgroup per CU with a margin
 int igmc_gs_cluster(int B) {
 #ifdef IGMC_HIPEMU
-  (void)B;
-  return 1;              // the emulator runs workgroups one after the other
+  // the emulator runs workgroups one after the other unless a test asks for clusters (their members then run
+  // together: hipemu::Runtime::co_cs)
+  const char* ee = getenv("IGMC_GS_CLUSTER");
+  const int want_e = ee ? atoi(ee) : 1;
+  const int stride_e = (B + 7) & ~7;
+  if (want_e >= 4 && 4 * stride_e <= 224) return 4;
+  if (want_e >= 2 && 2 * stride_e <= 224) return 2;
+  return 1;
 #else
   static int cus = -1;
   if (cus < 0) {
@@ -1271,7 +1303,13 @@ void igmc_launch_graph_step(const ModelDev& m, const BatchDev& b, const float* P
   a.stride = (cs > 1) ? ((B + 7) & ~7) : 1;
   const int grid = (cs > 1) ? cs * a.stride : igmc_gs_grid(B);
   const size_t sm = (size_t)lay.words * 4;
-  if (getenv("IGMC_GS_TRACE")) fprintf(stderr, "[igmc] k_graph_step B=%d train=%d flags=%d nmax=%d lds=%zu\n", B, training, use_flags, lay.nmax, sm);
+#ifdef IGMC_HIPEMU
+  if (cs > 1) {
+    hipemu::rt().co_cs = cs;
+    hipemu::rt().co_stride = a.stride;
+  }
+#endif
+  if (getenv("IGMC_GS_TRACE")) fprintf(stderr, "[igmc] k_graph_step B=%d train=%d flags=%d nmax=%d lds=%zu cluster=%d grid=%d\n", B, training, use_flags, lay.nmax, sm, cs, grid);
   if (training) {
     if (use_flags) IGMC_PLAUNCH("k_graph_step", (k_graph_step<true, true>), grid, GS_THREADS, sm, stream, b, m, P, a);
     else IGMC_PLAUNCH("k_graph_step", (k_graph_step<false, true>), grid, GS_THREADS, sm, stream, b, m, P, a);

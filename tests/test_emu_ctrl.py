@@ -23,9 +23,12 @@ def ctrl_words(step, first, epoch, adam_t, batch, lr=1e-3, b1=0.9, b2=0.999, eps
     return w
 
 
-@pytest.mark.parametrize('graph_step', ['0', '1'])
+@pytest.mark.parametrize('graph_step', ['0', '1', '1:4'])
 def test_ctrl_path_equals_host_argument_path(monkeypatch, graph_step):
-    monkeypatch.setenv('IGMC_GRAPH_STEP', graph_step)     # per-layer kernels / one workgroup per subgraph
+    graph_step, _, cluster = graph_step.partition(':')
+    monkeypatch.setenv('IGMC_GRAPH_STEP', graph_step)     # per-layer kernels / one workgroup (or a cluster of 4) per subgraph
+    if cluster:
+        monkeypatch.setenv('IGMC_GS_CLUSTER', cluster)
     be = PC.EmuBackend()
     lib = be.lib
     case = CASES['synth_cap']

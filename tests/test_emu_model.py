@@ -59,6 +59,18 @@ def test_layer_kernel_variants(be, monkeypatch, mode):
     assert res['worst_grad_err'] < 1e-4
 
 
+@pytest.mark.parametrize('cs', ['2', '4'])
+@pytest.mark.parametrize('name,n,drop', [('synth_cap', 6, True), ('synth_nocap:100', 4, False), ('hand', 5, True)])
+def test_graph_step_clusters(be, monkeypatch, cs, name, n, drop):
+    """Workgroup clusters of the subgraph kernel (2 / 4 workgroups share a subgraph and exchange h_l / dPre_l rows as
+    tagged words): the emulator runs the members of a cluster together (hipemu::Runtime::co_cs), so the bundle
+    schedule over 8 / 16 waves, the exchange indices and tags, the per-member partial tables and their reduction are
+    checked on the CPU against the oracle like the single-workgroup path."""
+    monkeypatch.setenv('IGMC_GS_CLUSTER', cs)
+    res = PC.run_model_parity(be, sub(name, n), R=5, use_dropout=drop)
+    assert res['worst_grad_err'] < 1e-4
+
+
 def test_hand_off_finalize_variant(be, monkeypatch):
     # IGMC_FIN_MODE=0: subgraph kernel + k_finalize (in-kernel hand-offs) instead of the default k_finalize_ts
     monkeypatch.setenv('IGMC_FIN_MODE', '0')

@@ -121,7 +121,8 @@ struct Fiber {
   Ctx ctx;
   char* stack = nullptr;
   bool done = true;
-  int tid = 0;
+  int tid = 0;      // work-item index inside its workgroup
+  int blk = 0;      // resident-workgroup slot (Runtime::blocks)
 };
 
 struct BlockState {
@@ -130,15 +131,25 @@ struct BlockState {
   std::vector<WaveState> waves;
 };
 
-struct Runtime {
-  Ctx sched;
-  std::vector<Fiber> fibers;
+// one RESIDENT workgroup: its barrier / wave state, its block index and its dynamic LDS
+struct BlockCtx {
   BlockState blk;
-  int cur = -1;
   uint3_emu bidx{0, 0, 0};
-  dim3 bdim, gdim;
   unsigned char* dyn_smem = nullptr;
   size_t dyn_cap = 0;
+};
+
+struct Runtime {
+  Ctx sched;
+  std::vector<Fiber> fibers;          // [resident slot][work-item]
+  std::vector<BlockCtx> blocks;       // resident workgroups: one, unless the launch asks for clusters (below)
+  int nres = 1;
+  int cur = -1;
+  dim3 bdim, gdim;
+  // cluster launch (k_graph_step): the NEXT launch runs the workgroups b, b + co_stride, ..., (co_cs of them) of a 1-D
+  // grid TOGETHER, round-robin over all their work-items, so that they can exchange data through global memory with
+  // polling loops that call hipemu::yield(); consumed (reset to 1) by that launch
+  int co_cs = 1, co_stride = 0;
   std::function<void()> body;
   long n_switch = 0;
 };
@@ -162,17 +173,23 @@ inline void yield() {
   ctx_switch(r.fibers[r.cur].ctx, r.sched);
 }
 
+inline BlockCtx& cur_block() {
+  Runtime& r = rt();
+  return r.blocks[r.fibers[r.cur].blk];
+}
+
 inline void fiber_main() {
   Runtime& r = rt();
   r.body();
   Fiber& f = r.fibers[r.cur];
   f.done = true;
   // leaving the kernel: stop counting towards barriers / wave collectives
-  WaveState& w = r.blk.waves[f.tid / WAVE];
+  BlockState& b = r.blocks[f.blk].blk;
+  WaveState& w = b.waves[f.tid / WAVE];
   w.active--;
   if (w.active > 0 && w.arrived == w.active) { w.arrived = 0; w.gen++; }
-  r.blk.active--;
-  if (r.blk.active > 0 && r.blk.arrived == r.blk.active) { r.blk.arrived = 0; r.blk.gen++; }
+  b.active--;
+  if (b.active > 0 && b.arrived == b.active) { b.arrived = 0; b.gen++; }
   ctx_switch(f.ctx, r.sched);
   abort();                 // a finished fiber is never resumed
 }
@@ -197,37 +214,51 @@ inline void fiber_prepare(Fiber& f, Ctx& link) {
 #endif
 }
 
-inline void run_block(int nthreads) {
+// runs the r.nres resident workgroups (r.blocks[0 .. nres)) to completion, round-robin over all their work-items
+inline void run_resident(int nthreads) {
   Runtime& r = rt();
-  if ((int)r.fibers.size() < nthreads) r.fibers.resize(nthreads);
-  r.blk.nthreads = nthreads;
-  r.blk.active = nthreads;
-  r.blk.arrived = 0;
-  int nw = (nthreads + WAVE - 1) / WAVE;
-  r.blk.waves.assign(nw, WaveState());
-  for (int t = 0; t < nthreads; ++t) {
-    Fiber& f = r.fibers[t];
-    if (!f.stack) f.stack = (char*)malloc(STACK);
-    f.done = false;
-    f.tid = t;
-    r.blk.waves[t / WAVE].active++;
-    fiber_prepare(f, r.sched);
+  const int total = r.nres * nthreads;
+  if ((int)r.fibers.size() < total) r.fibers.resize(total);
+  const int nw = (nthreads + WAVE - 1) / WAVE;
+  for (int bi = 0; bi < r.nres; ++bi) {
+    BlockState& b = r.blocks[bi].blk;
+    b.nthreads = nthreads;
+    b.active = nthreads;
+    b.arrived = 0;
+    b.waves.assign(nw, WaveState());
+    for (int t = 0; t < nthreads; ++t) {
+      Fiber& f = r.fibers[bi * nthreads + t];
+      if (!f.stack) f.stack = (char*)malloc(STACK);
+      f.done = false;
+      f.tid = t;
+      f.blk = bi;
+      b.waves[t / WAVE].active++;
+      fiber_prepare(f, r.sched);
+    }
   }
-  int remaining = nthreads;
+  int remaining = total;
   long idle_rounds = 0;
   while (remaining > 0) {
-    int progressed = 0;
-    for (int t = 0; t < nthreads; ++t) {
+    for (int t = 0; t < total; ++t) {
       Fiber& f = r.fibers[t];
       if (f.done) continue;
       r.cur = t;
       ctx_switch(r.sched, f.ctx);
-      if (f.done) { remaining--; progressed++; }
+      if (f.done) remaining--;
     }
-    (void)progressed;
     if (++idle_rounds > 50000000L) { fprintf(stderr, "hipemu: deadlock suspected\n"); abort(); }
   }
   r.cur = -1;
+}
+
+inline void prepare_block(BlockCtx& b, uint3_emu idx, size_t shmem) {
+  b.bidx = idx;
+  if (shmem > b.dyn_cap) {
+    free(b.dyn_smem);
+    b.dyn_smem = (unsigned char*)aligned_alloc(64, (shmem + 63) / 64 * 64);
+    b.dyn_cap = shmem;
+  }
+  if (shmem) memset(b.dyn_smem, 0xCD, shmem);  // poison: uninitialised LDS reads show up
 }
 
 inline void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> body) {
@@ -236,18 +267,33 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> bo
   r.body = body;
   r.bdim = block;
   r.gdim = grid;
-  if (shmem > r.dyn_cap) {
-    free(r.dyn_smem);
-    r.dyn_smem = (unsigned char*)aligned_alloc(64, (shmem + 63) / 64 * 64);
-    r.dyn_cap = shmem;
-  }
+  const int cs = r.co_cs, stride = r.co_stride;
+  r.co_cs = 1;
+  r.co_stride = 0;
   int nthreads = block.x * block.y * block.z;
+  if (cs > 1) {
+    // clusters: members g, g + stride, .. of a 1-D grid are resident together (NOTE: function-scope `__shared__`
+    // variables are plain statics here and would be shared by them -- cluster kernels use dynamic LDS only)
+    if (grid.y != 1 || grid.z != 1 || stride < 1) { fprintf(stderr, "hipemu: cluster launches need a 1-D grid\n"); abort(); }
+    if ((int)r.blocks.size() < cs) r.blocks.resize(cs);
+    for (int g = 0; g < stride; ++g) {
+      r.nres = 0;
+      for (int c = 0; c < cs; ++c) {
+        const unsigned b = (unsigned)(g + c * stride);
+        if (b < grid.x) prepare_block(r.blocks[r.nres++], uint3_emu{b, 0, 0}, shmem);
+      }
+      if (r.nres) run_resident(nthreads);
+    }
+    r.nres = 1;
+    return;
+  }
+  if (r.blocks.empty()) r.blocks.resize(1);
+  r.nres = 1;
   for (unsigned bz = 0; bz < grid.z; ++bz)
     for (unsigned by = 0; by < grid.y; ++by)
       for (unsigned bx = 0; bx < grid.x; ++bx) {
-        r.bidx = uint3_emu{bx, by, bz};
-        if (shmem) memset(r.dyn_smem, 0xCD, shmem);  // poison: uninitialised LDS reads show up
-        run_block(nthreads);
+        prepare_block(r.blocks[0], uint3_emu{bx, by, bz}, shmem);
+        run_resident(nthreads);
       }
 }
 
@@ -262,8 +308,7 @@ inline uint3_emu cur_tid() {
 }
 
 inline void syncthreads() {
-  Runtime& r = rt();
-  BlockState& b = r.blk;
+  BlockState& b = cur_block().blk;
   unsigned gen = b.gen;
   b.arrived++;
   if (b.arrived == b.active) { b.arrived = 0; b.gen++; return; }
@@ -272,7 +317,8 @@ inline void syncthreads() {
 
 inline WaveState& my_wave() {
   Runtime& r = rt();
-  return r.blk.waves[r.fibers[r.cur].tid / WAVE];
+  const Fiber& f = r.fibers[r.cur];
+  return r.blocks[f.blk].blk.waves[f.tid / WAVE];
 }
 inline int lane_id() { return rt().fibers[rt().cur].tid % WAVE; }
 
@@ -287,10 +333,12 @@ inline void wave_rendezvous() {
 // number of lanes of [lo, lo+width) in this wave that are still running
 inline int group_active(int lo, int width) {
   Runtime& r = rt();
-  int wave = r.fibers[r.cur].tid / WAVE, n = 0;
+  const Fiber& f = r.fibers[r.cur];
+  const int nthreads = r.blocks[f.blk].blk.nthreads, base = f.blk * nthreads;
+  int wave = f.tid / WAVE, n = 0;
   for (int l = lo; l < lo + width; ++l) {
     int t = wave * WAVE + l;
-    if (t < r.blk.nthreads && !r.fibers[t].done) n++;
+    if (t < nthreads && !r.fibers[base + t].done) n++;
   }
   return n;
 }
@@ -339,7 +387,7 @@ template <typename T> inline T from_bits(uint64_t u) {
 }  // namespace hipemu
 
 #define threadIdx (hipemu::cur_tid())
-#define blockIdx (hipemu::rt().bidx)
+#define blockIdx (hipemu::cur_block().bidx)
 #define blockDim (hipemu::rt().bdim)
 #define gridDim (hipemu::rt().gdim)
 #define warpSize 64
