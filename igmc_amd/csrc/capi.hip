@@ -550,6 +550,16 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   return 0;
 }
 
+// debug aid (tests): host copy of the keep mask the last TRAINING forward drew / was given for the 0.5 MLP dropout
+// (reference models.py:212), uint8 [n <= max_graphs * 128].  Synchronises the device.
+extern "C" int igmc_debug_lin_mask(const igmc_model* m, uint8_t* h_out, int64_t n) {
+  if (!m || !h_out) IGMC_FAIL("null argument");
+  if (n < 0 || n > (int64_t)m->d.graph_cap * 128) IGMC_FAIL("mask size out of range");
+  HIPCHECK(hipDeviceSynchronize());
+  HIPCHECK(hipMemcpy(h_out, m->d.lmask, (size_t)n, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 extern "C" void igmc_model_destroy(igmc_model* m) {
   if (!m) return;
   for (int i = 0; i < 8; ++i) hipEventDestroy((hipEvent_t)m->ax.ev[i]);

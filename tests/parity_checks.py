@@ -126,13 +126,25 @@ def check_sampled(d, case):
     check_batch_structure(d, 2 * case['h'] + 2)
     for g, rec in enumerate(case['recs']):
         users, items, ulab, vlab, edges = graph_canonical(d, g)
-        assert len(users) == len(rec['u_nodes']) or case['h'] > 1
-        assert len(items) == len(rec['v_nodes']) or case['h'] > 1
         i, j = case['links'][g]
+        if rec is not None:
+            assert len(users) == len(rec['u_nodes']) or case['h'] > 1
+            assert len(items) == len(rec['v_nodes']) or case['h'] > 1
         if case['h'] == 1:
             cand_u = set(Acsc.indices[Acsc.indptr[j]:Acsc.indptr[j + 1]].tolist()) - {i}
             cand_v = set(A.indices[A.indptr[i]:A.indptr[i + 1]].tolist()) - {j}
             assert set(users[1:].tolist()) <= cand_u and set(items[1:].tolist()) <= cand_v
+            if rec is None:
+                # no reference record (full-size cases): the sizes the reference would produce follow from the candidate
+                # sets alone (util_functions.py:222-229: int(ratio * len), then the per-hop cap)
+                def size(c):
+                    n = len(c)
+                    if case['sample_ratio'] < 1.0:
+                        n = int(case['sample_ratio'] * n)
+                    if case['mnph'] is not None and case['mnph'] < n:
+                        n = case['mnph']
+                    return n
+                assert len(users) == 1 + size(cand_u) and len(items) == 1 + size(cand_v)
         udist = [ulab[int(u)] // 2 for u in users]
         vdist = [vlab[int(v)] // 2 for v in items]
         out = X.subgraph_extraction_labeling((i, j), A, Acsc, case['h'], 1.0, None, None, None,
@@ -248,3 +260,193 @@ def run_model_parity(be, case, R, ARR=0.001, use_dropout=True, multiply_by=1.0, 
 def pytest_approx(v, rel):
     import pytest
     return pytest.approx(v, rel=rel, abs=1e-6)
+
+
+# ====================================================================== free-running RNG paths
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+    return x ^ (x >> 31)
+
+
+def host_edge_keep(seed, step, graph, u, v, direction, p):
+    """include/igmc_rng.h: igmc_edge_hash + igmc_u01 >= p, restated on the host."""
+    s = _splitmix64((seed ^ 0x45444745) & _M64)
+    s = _splitmix64(s ^ step)
+    s = _splitmix64(s ^ ((graph << 2) | direction))
+    s = _splitmix64(s ^ ((u << 32) | v))
+    h = s >> 32
+    return np.float32(h >> 8) * np.float32(1.0 / 16777216.0) >= np.float32(p)
+
+
+def host_unit_keep(seed, step, graph, j):
+    """include/igmc_rng.h: igmc_unit_hash + igmc_u01 >= 0.5."""
+    s = _splitmix64((seed ^ 0x4D4C5044) & _M64)
+    s = _splitmix64(s ^ step)
+    s = _splitmix64(s ^ ((graph << 32) | j))
+    h = s >> 32
+    return np.float32(h >> 8) * np.float32(1.0 / 16777216.0) >= np.float32(0.5)
+
+
+def check_edge_flags(d, flags, p, force_undirected, seed, step, exact_sample=400):
+    """Free-running edge dropout (k_edge_flags; reference models.py:193-198 -> PyG dropout_adj):
+    * entry p of the dst-sorted CSR carries bit0 = keep(src -> dst), bit1 = keep(dst -> src): the two entries of an
+      undirected edge must agree on both directed draws;
+    * keep rate within 3 sigma of 1 - p; without force_undirected the two directions are independent draws
+      (|correlation| within 3 sigma of 0); with it they are ONE draw (bit0 == bit1, symmetric);
+    * a sample of entries equals the host restatement of the counter-based hash bit for bit."""
+    E = d['E']
+    assert len(flags) == E and E > 0
+    assert np.all(flags <= 3)
+    b0, b1 = (flags & 1).astype(np.int64), ((flags >> 1) & 1).astype(np.int64)
+    rev = reverse_positions(d)
+    assert np.array_equal(b1, b0[rev]), 'the two CSR entries of an edge disagree on a directed keep bit'
+    n_draws = E // 2 if force_undirected else E
+    rate = b0.mean()
+    sigma = np.sqrt(p * (1 - p) / n_draws)
+    assert abs(rate - (1 - p)) < 3 * sigma + 1e-12, (rate, 1 - p, sigma)
+    if force_undirected:
+        assert np.array_equal(b0, b1) and np.array_equal(flags, flags[rev])
+    else:
+        # each undirected edge once (src < dst): its two directions are independent Bernoulli draws
+        N = d['N']
+        dst = np.repeat(np.arange(N, dtype=np.int64), np.diff(d['row_ptr']).astype(np.int64))
+        half = d['col'].astype(np.int64) < dst
+        x, y = b0[half].astype(np.float64), b1[half].astype(np.float64)
+        if x.std() > 0 and y.std() > 0 and len(x) > 50:
+            corr = np.corrcoef(x, y)[0, 1]
+            assert abs(corr) < 3.0 / np.sqrt(len(x)), corr
+    # bit-exact against the host restatement of the hash on a sample of entries
+    N = d['N']
+    dst = np.repeat(np.arange(N, dtype=np.int64), np.diff(d['row_ptr']).astype(np.int64))
+    rng = np.random.default_rng(0)
+    for e in rng.choice(E, size=min(exact_sample, E), replace=False):
+        i, c = int(dst[e]), int(d['col'][e])
+        row_user = d['node_label'][i] % 2 == 0
+        gi, gc, gr = int(d['node_gid'][i]), int(d['node_gid'][c]), int(d['node_graph'][i])
+        u, v = (gi, gc) if row_user else (gc, gi)
+        dir_f = 2 if force_undirected else (1 if row_user else 0)       # col -> row
+        dir_t = 2 if force_undirected else (0 if row_user else 1)
+        kf = host_edge_keep(seed, step, gr, u, v, dir_f, p)
+        kt = host_edge_keep(seed, step, gr, u, v, dir_t, p)
+        assert int(flags[e]) == int(kf) | (int(kt) << 1), (e, int(flags[e]), kf, kt)
+
+
+def run_free_running_dropout(be, case, R, p=0.2, force_undirected=False, seed=11, step=7, mlp_seed=5, mlp_step=3):
+    """Edge dropout AND MLP dropout drawn by the kernels themselves (no injected masks): the drawn masks are read
+    back, checked statistically and against the host restatement of the hashes, and the model's loss / gradients
+    with them must equal the oracle's with the same masks -- for force_undirected through the oracle's own
+    ``dropout_adj(force_undirected=True)`` (mask over the row < col half, re-symmetrised, coalesced)."""
+    import torch
+    from oracle import pyg_ref
+    g, b, d = extract_case(be, case, replay=False)
+    L = 2 * case['h'] + 2
+    b.edge_dropout(p, force_undirected, seed=seed, step=step)
+    be.sync()
+    flags = b.download()['eflag']
+    check_edge_flags(d, flags, p, force_undirected, seed, step)
+    ws = engine.ModelWorkspace(be.lib, be.device, R, 4, L, 0, b.node_capacity, b.edge_capacity, b.max_graphs)
+    ref = make_ref_model(L, R, seed=3, adj_dropout=p)
+    ref.force_undirected = bool(force_undirected)
+    P = be.dev(flatten_params(ws, ref))
+    B = d['B']
+    out, grad, loss = be.dev(np.zeros(B, np.float32)), be.dev(np.zeros(ws.n_params, np.float32)), be.dev(np.zeros(2, np.float32))
+    ws.loss_grad(be.ptr(P), b, be.ptr(out), be.ptr(grad), be.ptr(loss), use_edge_flags=True, lin_mask=None,
+                 seed=mlp_seed, step=mlp_step, ARR=0.001)
+    be.sync()
+    lm = np.zeros(B * 128, np.uint8)
+    be.lib.call('igmc_debug_lin_mask', ws.handle, ctypes.c_void_p(lm.ctypes.data), B * 128)
+    lm = lm.reshape(B, 128)
+    # MLP dropout(0.5): rate within 3 sigma, bit-exact vs the host restatement of igmc_unit_hash
+    assert abs(lm.mean() - 0.5) < 3 * 0.5 / np.sqrt(lm.size), lm.mean()
+    for gi in range(0, B, max(1, B // 4)):
+        for j in (0, 1, 63, 127):
+            assert bool(lm[gi, j]) == bool(host_unit_keep(mlp_seed, mlp_step, gi, j))
+    pyg = batch_to_pyg(d, L)
+    keep = torch.from_numpy((flags & 1).astype(bool))
+    if force_undirected:
+        sel = (pyg.edge_index[0] < pyg.edge_index[1]).numpy()      # the half dropout_adj draws on
+        keep = keep[torch.from_numpy(sel)]
+    rl, ro, rg = pyg_ref.loss_and_grads(ref, pyg, ARR=0.001, edge_mask=keep, lin_mask=torch.from_numpy(lm.astype(bool)))
+    np.testing.assert_allclose(be.host(out), ro.numpy(), rtol=2e-4, atol=2e-5)
+    assert be.host(loss)[0] == pytest_approx(float(rl), 2e-4)
+    gg = unflatten_grads(ws, be.host(grad))
+    worst = 0.0
+    for key, ref_g in rg.items():
+        rgn = ref_g.numpy()
+        err = np.abs(gg[key] - rgn).max() / max(np.abs(rgn).max(), 1e-6)
+        worst = max(worst, err)
+        assert err < 2e-3, '%s: max rel-to-peak grad error %.3e' % (key, err)
+    return dict(worst_grad_err=worst, keep_rate=float((flags & 1).mean()), lin_rate=float(lm.mean()))
+
+
+def run_fused_train_trajectory(be, case, R, steps=5, batch=None, use_dropout=False, lr=1e-3, ARR=0.001, seed=4):
+    """``igmc_train_step`` (the fused single-GPU step: k_graph_step -> k_tail_ts -> k_finalize_ts with Adam, or the
+    per-layer kernels + k_finalize where the subgraph kernel is not eligible) for ``steps`` consecutive steps on
+    DIFFERENT batches with injected masks, against ``pyg_ref.train_step`` + ``torch.optim.Adam`` on the same batches
+    (reference train_eval.py:158-177).  Returns per-step losses and the final parameter / Adam-state comparison."""
+    import torch
+    from oracle import pyg_ref
+    A = case['A']
+    L = 2 * case['h'] + 2
+    n = len(case['links'])
+    B = batch or n // steps
+    assert B * steps <= n
+    g = engine.Graph(A, device=be.device, lib=be.lib)
+    b = engine.Batch(g, max_graphs=B, hop=case['h'], max_nodes_per_hop=case['mnph'])
+    ys = case['class_values'][case['link_labels']].astype(np.float32)
+    lu, lv, ly = be.dev(case['links'][:, 0].astype(np.int32)), be.dev(case['links'][:, 1].astype(np.int32)), be.dev(ys)
+    ws = engine.ModelWorkspace(be.lib, be.device, R, 4, L, 0, b.node_capacity, b.edge_capacity, B)
+    ref = make_ref_model(L, R, seed=seed, adj_dropout=0.2 if use_dropout else 0.0)
+    opt = torch.optim.Adam(ref.parameters(), lr=lr)
+    n_p = ws.n_params
+    P = be.dev(flatten_params(ws, ref))
+    M1, M2, G = be.dev(np.zeros(n_p, np.float32)), be.dev(np.zeros(n_p, np.float32)), be.dev(np.zeros(n_p, np.float32))
+    out, loss, total = be.dev(np.zeros(B, np.float32)), be.dev(np.zeros(2, np.float32)), be.dev(np.zeros(1, np.float64))
+    rng = np.random.default_rng(seed)
+    losses = []
+    for s in range(steps):
+        b.extract(be.ptr(lu), be.ptr(lv), be.ptr(ly), None, s * B, B, sample_ratio=case['sample_ratio'], seed=2, epoch=1)
+        be.sync()
+        d = b.download()
+        pyg = batch_to_pyg(d, L)
+        lm = rng.random((B, 128)) < 0.5
+        LM = be.dev(lm.astype(np.uint8).reshape(-1))
+        edge_mask = None
+        if use_dropout:
+            keep = rng.random(d['E']) >= 0.2
+            rev = reverse_positions(d)
+            b.set_edge_flags(keep.astype(np.uint8) | (keep[rev].astype(np.uint8) << 1))
+            edge_mask = torch.from_numpy(keep)
+        be.lib.call('igmc_train_step', ws.handle, engine._p(be.ptr(P)), b.handle, int(use_dropout), engine._p(be.ptr(LM)),
+                    0, 0, 1.0, ARR, engine._p(be.ptr(out)), engine._p(be.ptr(G)), engine._p(be.ptr(M1)),
+                    engine._p(be.ptr(M2)), engine._p(be.ptr(loss)), engine._p(be.ptr(total)), None, s + 1, lr, 0.9, 0.999,
+                    1e-8, 0.0, None)
+        be.sync()
+        ref_loss = pyg_ref.train_step(ref, opt, pyg, ARR=ARR, edge_mask=edge_mask, lin_mask=torch.from_numpy(lm))
+        got = float(be.host(loss)[0])
+        assert got == pytest_approx(ref_loss, 5e-4), (s, got, ref_loss)
+        losses.append((got, ref_loss))
+    be.lib.call('igmc_model_check', ws.handle, None)
+    # Adam state: exp_avg is LINEAR in the gradients -> tight, per tensor relative to its peak
+    m1 = unflatten_grads(ws, be.host(M1))
+    m2 = unflatten_grads(ws, be.host(M2))
+    names = [k for k, _ in ref.named_parameters()]
+    for i, (k, prm) in enumerate(ref.named_parameters()):
+        st = opt.state[prm]
+        ea, es = st['exp_avg'].numpy(), st['exp_avg_sq'].numpy()
+        assert np.abs(m1[k] - ea).max() <= 2e-3 * max(np.abs(ea).max(), 1e-9), k
+        assert np.abs(m2[k] - es).max() <= 4e-3 * max(np.abs(es).max(), 1e-12), k
+    got_p, want_p = be.host(P), flatten_params(ws, ref)
+    diff = np.abs(got_p - want_p)
+    tol = 2e-5 + 2e-3 * np.abs(want_p)
+    # Adam divides by sqrt(v): an element whose gradient is within float noise of zero may take its (<= lr) step in
+    # the other direction, so a handful of elements can be off by up to 2 * lr * steps; everything else must track
+    bad = diff > tol
+    assert bad.mean() < 2e-3, 'too many parameters off the oracle trajectory: %g' % bad.mean()
+    assert diff.max() <= 2.0 * lr * steps + 1e-6, diff.max()
+    return dict(losses=losses, frac_off=float(bad.mean()), max_diff=float(diff.max()), total=float(be.host(total)[0]))

@@ -129,3 +129,22 @@ def test_train_steps_follow_reference_trajectory(be):
         ref_loss = pyg_ref.train_step(ref, opt, pyg, ARR=0.001, lin_mask=torch.from_numpy(lm))
         assert be.host(loss)[0] == pytest.approx(ref_loss, rel=5e-4)
     np.testing.assert_allclose(be.host(P), PC.flatten_params(ws, ref), rtol=2e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize('name,n', [('synth_cap', 8), ('synth_nocap', 3)])
+@pytest.mark.parametrize('force_undirected', [False, True])
+def test_free_running_dropout(be, name, n, force_undirected):
+    """k_edge_flags / the MLP-dropout hash drawn by the kernels themselves (capped: subgraph kernel; uncapped: per-layer
+    kernels): mask statistics, bit-exactness vs the host restatement of include/igmc_rng.h, model parity with the drawn
+    masks incl. ``force_undirected`` through the oracle's own ``dropout_adj(force_undirected=True)``."""
+    res = PC.run_free_running_dropout(be, sub(name, n), R=5, p=0.2, force_undirected=force_undirected)
+    assert res['worst_grad_err'] < 1e-4
+
+
+@pytest.mark.parametrize('name,cluster,drop', [('synth_cap', '1', True), ('synth_cap', '4', False), ('synth_nocap', '1', True)])
+def test_fused_train_step_tracks_torch_adam(be, monkeypatch, name, cluster, drop):
+    """``igmc_train_step`` (k_graph_step -> k_tail_ts -> k_finalize_ts incl. Adam for the capped case; per-layer kernels +
+    k_finalize for the uncapped one) over 4 different batches vs ``pyg_ref.train_step`` + ``torch.optim.Adam``."""
+    monkeypatch.setenv('IGMC_GS_CLUSTER', cluster)
+    res = PC.run_fused_train_trajectory(be, sub(name, 16), R=5, steps=4, batch=4, use_dropout=drop)
+    assert res['frac_off'] < 2e-3

@@ -45,12 +45,32 @@ def test_extraction_api_known_answer():
 
 
 def test_dataset_surface(flix):
+    import torch
     tr, te, cv = make_sets(flix)
     assert len(tr) == 600 and tr.num_features == 4 and tr.__class__.__name__ == 'MyDynamicDataset'
     d = tr[3]
     assert d.x.shape[1] == 4 and d.edge_index.shape[0] == 2 and d.edge_type.shape[0] == d.edge_index.shape[1]
     assert float(d.y) == float(cv[flix[3][3]])
     assert d.x[0].tolist() == [1, 0, 0, 0]
+    # the static dataset (reference MyDataset, util_functions.py:69-110): indexable, same Data layout, and -- the
+    # flixster default cap never binds -- the SAME subgraph as the dynamic dataset / as links2subgraphs yield
+    from igmc_amd.util_functions import MyDataset, SparseColIndexer, SparseRowIndexer, links2subgraphs
+    assert te.__class__.__name__ == 'MyDataset' and len(te) == 300 and te.num_features == 4
+    s0 = te[7]
+    assert s0.x.shape[1] == 4 and s0.edge_index.shape == (2, s0.edge_type.shape[0]) and float(s0.y) == float(cv[flix[9][7]])
+    assert s0.x[0].tolist() == [1, 0, 0, 0] and int(s0.x[:, 1].sum()) == 1
+    (uf, vf, adj, trl, tru, trv, _, _, _, tel, teu, tev, _) = flix
+    st = MyDataset('data/t/train_static', adj, (tru[:600], trv[:600]), trl[:600], 1, 1.0, 10000, None, None, cv)
+    a, b = st[3], tr[3]
+    assert torch.equal(a.x, b.x) and torch.equal(a.edge_index, b.edge_index) and torch.equal(a.edge_type, b.edge_type)
+    graphs = links2subgraphs(SparseRowIndexer(adj), SparseColIndexer(adj.tocsc()), (tru[:40], trv[:40]), trl[:40], 1, 1.0,
+                             10000, None, None, cv, batch_size=16)
+    assert len(graphs) == 40
+    g3 = graphs[3]
+    assert torch.equal(g3.x, a.x) and float(g3.y) == float(a.y) and g3.edge_type.shape == a.edge_type.shape
+    # same edge multiset (links2subgraphs emits the reference's [u;v],[v;u] order, the dataset the dst-sorted CSR)
+    key = lambda e, t: sorted(zip(e[0].tolist(), e[1].tolist(), t.tolist()))
+    assert key(g3.edge_index, g3.edge_type) == key(a.edge_index, a.edge_type)
 
 
 def test_train_eval_checkpoint_roundtrip(flix, tmp_path):
@@ -177,6 +197,23 @@ def test_ensemble_eval(flix, tmp_path):
         singles.append(test_once(te, m, 50))
     ens = test_once(te, m, 50, ensemble=True, checkpoints=paths)
     assert math.isfinite(ens) and ens <= max(singles) + 1e-6
+    # oracle: mean of the checkpoints' predictions, then RMSE (reference train_eval.py:208-245), on the subgraphs
+    # the engine extracted (static test set -> the same subgraphs every pass)
+    from igmc_amd.train_eval import DataLoader
+    from oracle import pyg_ref
+    batches = [batch_to_pyg(data._materialise()['raw'], 4) for data in DataLoader(te, 50, shuffle=False)]
+    ys = torch.cat([b.y for b in batches])
+    preds, ref_singles = [], []
+    for p in paths:
+        ref = pyg_ref.IGMCRef(4, (32, 32, 32, 32), len(cv), 4, adj_dropout=0.2, fast=True)
+        ref.load_state_dict({k: v.cpu() for k, v in torch.load(p).items()})
+        out = torch.cat([pyg_ref.eval_sse(ref, b)[1] for b in batches])
+        preds.append(out)
+        ref_singles.append(math.sqrt(float(((out - ys) ** 2).mean())))
+    ref_ens = math.sqrt(float(((torch.stack(preds, 1).mean(1) - ys) ** 2).mean()))
+    assert len(ys) == 100
+    assert singles == pytest.approx(ref_singles, abs=1e-4)
+    assert ens == pytest.approx(ref_ens, abs=1e-4)
 
 
 def test_main_script_end_to_end(tmp_path):

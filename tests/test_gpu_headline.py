@@ -1,0 +1,119 @@
+"""GPU parity at the REAL headline shape (BASELINE.json configs[2]: ml_1m-shaped rating graph 6040 x 3706, hop 1,
+max-nodes-per-hop 100, batch 50 -> k_graph_step with clusters of 4 workgroups per subgraph) against the CPU oracle,
+plus the paths round 1 only checked transitively:
+
+* one full batch of 50: extraction (candidate sets, sizes, induced edges vs ``oracle/extract_ref``), eval output,
+  train output / loss / EVERY gradient vs ``oracle/pyg_ref`` (tolerances of ``parity_checks.run_model_parity``:
+  outputs rtol 2e-4 / atol 2e-5, gradients 2e-3 of the tensor's peak);
+* >= 5 consecutive steps of the fused ``igmc_train_step`` (k_graph_step -> k_tail_ts -> k_finalize_ts incl. Adam) vs
+  ``pyg_ref.train_step`` + ``torch.optim.Adam`` (reference train_eval.py:158-177);
+* the free-running counter-based dropout draws (edge dropout incl. ``force_undirected``, MLP dropout): statistics,
+  bit-exactness vs the host restatement of the hashes, model parity with the drawn masks (reference
+  models.py:193-198, :212).
+"""
+import numpy as np
+import pytest
+
+import parity_checks as PC
+from helpers import load_extract_golden
+
+pytestmark = pytest.mark.gpu
+CASES = load_extract_golden()
+
+
+@pytest.fixture(scope='module')
+def be():
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return PC.GpuBackend()
+
+
+def ml_case(dataset, mnph, n, seed=3):
+    """``n`` training links of the MovieLens-shaped graph bench.py runs on, as a parity case without reference
+    records (the reference's own extractor needs seconds per link at this size; sizes / candidate sets / induced
+    edges are checked by ``parity_checks.check_sampled``)."""
+    from igmc_amd import preprocessing
+    split = preprocessing.create_trainvaltest_split(dataset, 1234, True, verbose=False)
+    (_, _, A, tr_l, tr_u, tr_v, _, _, _, _, _, _, cv) = split
+    pick = np.random.default_rng(seed).permutation(len(tr_u))[:n]
+    links = np.stack([tr_u[pick], tr_v[pick]], 1).astype(np.int64)
+    return dict(A=A, links=links, link_labels=np.asarray(tr_l)[pick].astype(np.int64),
+                class_values=np.asarray(cv, dtype=np.float64), h=1, sample_ratio=1.0, mnph=mnph, recs=[None] * n)
+
+
+@pytest.fixture(scope='module')
+def ml1m():
+    return ml_case('ml_1m', 100, 250)
+
+
+def monti_case(name, n, seed=2):
+    """``n`` training links of a bundled real dataset (uncapped: the reference default --max-nodes-per-hop 10000)."""
+    from igmc_amd import preprocessing
+    (_, _, A, tr_l, tr_u, tr_v, _, _, _, _, _, _, cv) = preprocessing.load_data_monti(name, testing=True)
+    pick = np.random.default_rng(seed).permutation(len(tr_u))[:n]
+    return dict(A=A, links=np.stack([tr_u[pick], tr_v[pick]], 1).astype(np.int64),
+                link_labels=np.asarray(tr_l)[pick].astype(np.int64), class_values=np.asarray(cv, dtype=np.float64),
+                h=1, sample_ratio=1.0, mnph=10000, recs=[None] * n)
+
+
+def first(case, n, start=0):
+    c = dict(case)
+    c['links'], c['link_labels'], c['recs'] = case['links'][start:start + n], case['link_labels'][start:start + n], [None] * n
+    return c
+
+
+@pytest.mark.parametrize('drop', [False, True])
+def test_headline_batch_matches_oracle(be, ml1m, drop, monkeypatch, capfd):
+    """ml_1m shape, batch 50, cap 100: the production launch (cluster of 4 workgroups per subgraph) vs the oracle."""
+    monkeypatch.setenv('IGMC_GRAPH_STEP', '1')
+    monkeypatch.setenv('IGMC_GS_TRACE', '1')
+    case = first(ml1m, 50)
+    res = PC.run_model_parity(be, case, R=5, use_dropout=drop)
+    assert res['worst_grad_err'] < 2e-3
+    d = res['d']
+    assert d['B'] == 50 and 50 * 150 < d['N'] <= 50 * 202 and d['E'] > 150000       # the headline shape, not a toy
+    PC.check_sampled(d, case)
+    err = capfd.readouterr().err
+    assert 'k_graph_step B=50 train=1' in err and 'cluster=4' in err, err[-400:]
+
+
+def test_headline_fused_train_steps_track_torch_adam(be, ml1m, monkeypatch, capfd):
+    """5 steps of igmc_train_step on 5 different batches of 50 (k_tail_ts + k_finalize_ts write the weights)."""
+    monkeypatch.setenv('IGMC_GRAPH_STEP', '1')
+    monkeypatch.setenv('IGMC_GS_TRACE', '1')
+    res = PC.run_fused_train_trajectory(be, ml1m, R=5, steps=5, batch=50)
+    err = capfd.readouterr().err
+    assert err.count('k_graph_step B=50 train=1') >= 5 and 'cluster=4' in err
+    assert res['frac_off'] < 2e-3
+    # sum over steps of loss * num_graphs (reference train_eval.py:176)
+    assert res['total'] == pytest.approx(sum(50 * l for l, _ in res['losses']), rel=1e-5)
+
+
+@pytest.mark.parametrize('name,n,R,mnph,drop', [
+    ('ml1m', 250, 5, 100, True),            # subgraph kernel with edge flags
+    ('douban', 250, 5, None, True),         # per-layer kernels + k_finalize (uncapped)
+    ('flixster', 250, 10, None, False),     # R = 10
+])
+def test_fused_train_steps_other_paths(be, ml1m, name, n, R, mnph, drop):
+    case = ml1m if name == 'ml1m' else monti_case(name, n)
+    res = PC.run_fused_train_trajectory(be, case, R=R, steps=5, batch=n // 5, use_dropout=drop)
+    assert res['frac_off'] < 2e-3
+
+
+@pytest.mark.parametrize('force_undirected', [False, True])
+@pytest.mark.parametrize('name', ['ml1m', 'douban'])
+def test_free_running_dropout(be, ml1m, name, force_undirected):
+    case = first(ml1m, 50, 100) if name == 'ml1m' else monti_case('douban', 40)
+    res = PC.run_free_running_dropout(be, case, R=5, p=0.2, force_undirected=force_undirected)
+    assert res['worst_grad_err'] < 2e-3
+
+
+
+
+def test_ml100k_cap200_batch_matches_oracle(be):
+    """BASELINE.json configs[1]: ml_100k shape, cap 200, adj-dropout 0.2, batch 50."""
+    case = ml_case('ml_100k', 200, 50, seed=5)
+    res = PC.run_model_parity(be, case, R=5, use_dropout=True)
+    assert res['worst_grad_err'] < 2e-3
+    PC.check_sampled(res['d'], case)
+    assert res['d']['N'] > 50 * 200

@@ -125,14 +125,7 @@ def test_bitwise_reproducible(be):
     assert np.array_equal(r1['loss'], r2['loss'])
 
 
-# ---- randomised twins of tests/test_emu_{extract,model}_random.py on the real library.  They were written at the end of
-#      round 1 with no GPU time left to run them once, so they only run on request (IGMC_RANDOM_GPU_TESTS=1) until a
-#      round has seen them pass on an MI355X; then the guard goes.
-_random_gpu = pytest.mark.skipif(__import__('os').environ.get('IGMC_RANDOM_GPU_TESTS', '0') != '1',
-                                 reason='set IGMC_RANDOM_GPU_TESTS=1 (not yet run on hardware)')
-
-
-@_random_gpu
+# ---- randomised twins of tests/test_emu_{extract,model}_random.py on the real library
 @pytest.mark.parametrize('h', [1, 2])
 def test_random_uncapped_extraction_matches_oracle(be, h):
     from helpers import random_case
@@ -142,7 +135,6 @@ def test_random_uncapped_extraction_matches_oracle(be, h):
         PC.check_against_golden(d, case)
 
 
-@_random_gpu
 @pytest.mark.parametrize('h,mnph', [(1, None), (1, 6), (2, 4), (1, 12)])
 def test_random_graphs_forward_backward(be, h, mnph):
     from helpers import random_case
