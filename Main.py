@@ -212,6 +212,8 @@ def main(argv=None):
                                      res_dir=args.res_dir)
     if args.visualize:
         raise NotImplementedError('--visualize (networkx/matplotlib plots) is outside the accelerated path')
+    # only rank 0 writes checkpoints (inside `logger`): nobody may look for them before it is done
+    parallel.barrier()
 
     epoch_info = 'epoch {}'.format(args.epochs)
     if args.ensemble:
@@ -222,11 +224,14 @@ def main(argv=None):
         ckpt_dir = args.transfer if args.transfer else args.res_dir
         checkpoints = [os.path.join(ckpt_dir, 'model_checkpoint%d.pth' % x)
                        for x in range(start_epoch, end_epoch + 1, interval)]
-        missing = [c for c in checkpoints if not os.path.exists(c)]
+        # rank 0 decides which of the scheduled checkpoints exist and every rank uses ITS list (a rank looking at
+        # the file system on its own could ensemble a different set and all-reduce inconsistent squared errors)
+        present = parallel.broadcast_object([os.path.exists(c) for c in checkpoints] if rank == 0 else None)
+        missing = [c for c, ok in zip(checkpoints, present) if not ok]
         if missing:      # the reference's fixed schedule assumes its default epoch counts (Main.py:437-441)
             if rank == 0:
                 print('ensemble: skipping %d missing checkpoint(s): %s' % (len(missing), ', '.join(map(os.path.basename, missing))))
-            checkpoints = [c for c in checkpoints if os.path.exists(c)]
+            checkpoints = [c for c, ok in zip(checkpoints, present) if ok]
             if not checkpoints:
                 raise FileNotFoundError('--ensemble: none of the scheduled checkpoints exist in %s' % ckpt_dir)
         epoch_info = ('transfer {}, '.format(args.transfer) if args.transfer else '') + \

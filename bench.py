@@ -5,22 +5,35 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[2]): ml_1m-shaped graph, h=1, max-nodes-per-hop 100, batch 50, adj-dropout 0,
-dynamic-train.  MovieLens is not available offline, so the graph is the MovieLens-shaped synthetic generator of
-SURVEY.md 8(d) (6040 x 3706, 1 000 209 ratings, 90/10 split) unless raw_data/ml_1m/ratings.dat exists.
-Weights are random-init (reference init).  Inputs (graph, link arrays) are resident in HBM before timing.
+Workload (default = BASELINE.json configs[2], the configuration the metric is quoted on): ml_1m-shaped graph, h=1,
+max-nodes-per-hop 100, batch 50, adj-dropout 0, dynamic-train.  MovieLens is not available offline, so the graph is the
+MovieLens-shaped synthetic generator of SURVEY.md 8(d) (6040 x 3706, 1 000 209 ratings, 90/10 split) unless
+raw_data/ml_1m/ratings.dat exists.  ``--config ml_100k`` = configs[1] (cap 200, adj-dropout 0.2), ``--config
+douban|flixster|yahoo_music`` = the bundled real datasets with the reference defaults (uncapped, adj-dropout 0.2).
+Weights are random-init (reference init).  Inputs (graph, link arrays) are resident in HBM before timing; every hipGraph
+the timed steps replay is captured BEFORE the timed region (``StepGraph.prepare``).
 
 The ONE JSON line printed by rank 0 also carries
-  roofline      : the dominant kernel = k_graph_step (forward + backward of every subgraph, one workgroup cluster
-                  each; the three conv layers in both directions = 6 x the per-layer gather bytes 133*E + 132*N of
-                  SURVEY.md 8(d)) -- or, for configurations it does not take, the fused forward layer kernel
-                  k_rgcn_layer_fwd (1 x those bytes): algorithmic bytes per launch / its average duration measured
-                  with HIP events on the launch stream in a separate instrumented pass of the same steps;
-  cpu_baseline  : the oracle's restatement of the reference CPU path (scipy/python extraction + PyG-1.4.2
-                  per-edge-weight formulation in torch, all host cores) on a bounded sample of the same workload.
+  roofline      : the dominant kernel = k_graph_step (forward + backward of every subgraph, one workgroup cluster each;
+                  the three conv layers in both directions = 6 x the per-layer gather bytes 133*E + 132*N of SURVEY.md
+                  8(d)) -- or, for configurations it does not take, the fused forward layer kernel k_rgcn_layer_fwd
+                  (1 x those bytes).  ``avg_us`` is measured UNDER hipGraph replay with the extraction of the next batch
+                  overlapped (the product configuration): every k_graph_step launch clocks itself on the device
+                  (earliest workgroup start -> last workgroup end; igmc_profile_gs_clock) in a second, instrumented run
+                  of the same steps after the timed region; ``avg_us_eager_events`` = HIP events around the eagerly
+                  launched kernel (also the source of ``kernels_us``).  ``traffic`` comes from the committed rocprofv3
+                  --pmc passes of this command and is reported only while the kernel sources are the ones profiled.
+  cpu_baseline  : the oracle's restatement of the reference CPU path, structured like the reference
+                  (train_eval.py:40-45: extraction in worker processes, PyG-1.4.2 per-edge-weight formulation in torch on
+                  the host cores), on a bounded sample of the same workload; ``--config ml_100k`` times BASELINE.json
+                  configs[0] (static pre-extracted subgraphs, 1 worker).
+  rmse          : test RMSE of the checkpoint the timed steps produced, on a fixed slice of the test links, plus the same
+                  figure from the oracle on a smaller slice (the metric names "test RMSE"; parity bar 1e-4).
 """
 import argparse
+import hashlib
 import json
+import multiprocessing as mp
 import os
 import sys
 import time
@@ -35,63 +48,122 @@ if ROOT not in sys.path:
 from igmc_amd import _lib, engine, parallel, preprocessing  # noqa: E402
 from igmc_amd.models import IGMC  # noqa: E402
 from igmc_amd.stepgraph import StepGraph  # noqa: E402
-from igmc_amd.train_eval import FlatAdam  # noqa: E402
-from igmc_amd.util_functions import MyDynamicDataset  # noqa: E402
+from igmc_amd.train_eval import DataLoader, FlatAdam, eval_rmse  # noqa: E402
+from igmc_amd.util_functions import MyDataset, MyDynamicDataset  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured-achievable
 BATCH = 50
 CONFIGS = {
-    'ml_1m': dict(dataset='ml_1m', mnph=100, adj_dropout=0.0),
-    'ml_100k': dict(dataset='ml_100k', mnph=200, adj_dropout=0.2),
+    'ml_1m': dict(dataset='ml_1m', mnph=100, adj_dropout=0.0, cpu='dynamic'),
+    'ml_100k': dict(dataset='ml_100k', mnph=200, adj_dropout=0.2, cpu='static'),
+    'douban': dict(dataset='douban', mnph=10000, adj_dropout=0.2, cpu='dynamic'),
+    'flixster': dict(dataset='flixster', mnph=10000, adj_dropout=0.2, cpu='dynamic'),
+    'yahoo_music': dict(dataset='yahoo_music', mnph=10000, adj_dropout=0.2, cpu='dynamic'),
 }
+PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
 
 
-def cpu_baseline(A, tr_u, tr_v, tr_l, class_values, mnph, adj_dropout, budget_s=20.0):
-    """Reference CPU path restated by the oracle (kind='port'), timed on this box's host cores."""
+def kernel_source_sha():
+    """Identity of the kernel sources the library was built from (stamped into profiles/*pmc_traffic.json)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'igmc_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h')):
+            h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+# ------------------------------------------------------------------ CPU baseline (checker code, timed)
+_W = {}
+
+
+def _worker_extract(idx):
+    """One batch of enclosing subgraphs, extracted by the oracle's restatement of the reference extractor (runs in a
+    forked worker process, like a PyG DataLoader worker: reference train_eval.py:40-45)."""
+    from oracle import extract_ref
     import random
-    from oracle import extract_ref, pyg_ref
+    random.seed(int(idx[0]) + 1)
+    A, Acsc, tr_u, tr_v, tr_l, cv, mnph = (_W[k] for k in ('A', 'Acsc', 'tr_u', 'tr_v', 'tr_l', 'cv', 'mnph'))
+    return [extract_ref.extract((tr_u[k], tr_v[k]), A, Acsc, 1, 1.0, mnph, cv, tr_l[k]) for k in idx]
+
+
+def start_cpu_workers(A, tr_u, tr_v, tr_l, class_values, mnph):
+    """Fork the extraction workers BEFORE the GPU runtime is initialised (forking a process that holds a HIP context
+    is not safe); they idle until the CPU-baseline leg."""
+    _W.update(A=A, Acsc=A.tocsc(), tr_u=tr_u, tr_v=tr_v, tr_l=tr_l, cv=class_values, mnph=mnph)
+    n = max(1, min(os.cpu_count() or 1, 32))
+    try:
+        return mp.get_context('fork').Pool(n), n
+    except (OSError, ValueError):
+        return None, 0
+
+
+def cpu_baseline(pool, n_workers, n_links, adj_dropout, n_rel, mode, budget_s=20.0):
+    """Reference CPU path restated by the oracle (kind='port'), timed on this box's host cores.
+    mode 'dynamic' (reference --dynamic-train): subgraphs extracted on the fly by the worker processes while the main
+    process trains; mode 'static' (BASELINE.json configs[0]): subgraphs pre-extracted (not timed, like the reference's
+    cached data.pt), ONE loader worker = collation in the main process."""
+    import random
+    from oracle import pyg_ref
     ncpu = os.cpu_count() or 1
-    Acsc = A.tocsc()
     torch.manual_seed(1)
     random.seed(1)
-    model = pyg_ref.IGMCRef(4, (32, 32, 32, 32), len(class_values), 4, adj_dropout=adj_dropout, fast=False)
+    model = pyg_ref.IGMCRef(4, (32, 32, 32, 32), n_rel, 4, adj_dropout=adj_dropout, fast=False)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    rng = np.random.default_rng(0)
-    perm = rng.permutation(len(tr_u))
+    perm = np.random.default_rng(0).permutation(n_links)
+    batches = [perm[i * BATCH:(i + 1) * BATCH] for i in range(60)]
 
-    def make_batch(i):
-        idx = perm[i * BATCH:(i + 1) * BATCH]
-        graphs = [extract_ref.extract((tr_u[k], tr_v[k]), A, Acsc, 1, 1.0, mnph, class_values, tr_l[k]) for k in idx]
-        return pyg_ref.Batch.from_data_list(graphs)
-
-    def one_step(i):
-        return pyg_ref.train_step(model, opt, make_batch(i), ARR=0.001)
+    def extract(idx):
+        return _worker_extract(idx)
     # the reference uses every host core; over-subscription hurts this formulation on many-core hosts, so the
-    # baseline gets the best of a few thread counts (reported as `cores`)
-    b0 = make_batch(0)
-    best, cores = None, 1
+    # baseline gets the best of a few thread counts (reported in `sample`)
+    b0 = pyg_ref.Batch.from_data_list(extract(batches[0]))
+    best, threads = None, 1
     for th in sorted(set([min(8, ncpu), min(16, ncpu), min(32, ncpu), min(64, ncpu)])):
         torch.set_num_threads(th)
         t0 = time.perf_counter()
         pyg_ref.train_step(model, opt, b0, ARR=0.001)
         el = time.perf_counter() - t0
         if best is None or el < best:
-            best, cores = el, th
+            best, threads = el, th
         if el > 8.0:
             break
-    torch.set_num_threads(cores)
-    first = best
+    torch.set_num_threads(threads)
+    max_steps = int(max(3, min(50, budget_s / max(best, 1e-3))))
+    todo = batches[1:1 + max_steps]
+    if mode == 'static':
+        graphs = [extract(idx) for idx in todo]                     # pre-extracted: not timed
+        feed = (g for g in graphs)
+    elif pool is not None:
+        feed = pool.imap(_worker_extract, todo, chunksize=1)        # workers run ahead of the training loop
+    else:
+        feed = (extract(idx) for idx in todo)
     steps, t1 = 0, time.perf_counter()
-    while True:
-        one_step(steps + 1)
+    for graphs_b in feed:
+        pyg_ref.train_step(model, opt, pyg_ref.Batch.from_data_list(graphs_b), ARR=0.001)
         steps += 1
-        el = time.perf_counter() - t1
-        if el > budget_s or el + first > budget_s * 1.5 or steps >= 50:
+        if time.perf_counter() - t1 > budget_s:
             break
-    rate = steps * BATCH / (time.perf_counter() - t1)
-    return dict(value=rate, unit='subgraphs/s', cores=cores, kind='port',
-                sample='%d train steps of batch %d (extraction + PyG-1.4.2-formulation fwd/bwd + Adam), '
-                       'oracle/extract_ref.py + oracle/pyg_ref.py, torch threads=%d' % (steps, BATCH, cores))
+    el = time.perf_counter() - t1
+    if mode != 'static' and pool is not None:
+        pool.terminate()
+    how = ('static: %d pre-extracted batches (extraction untimed), collate + train step in ONE process' % steps
+           if mode == 'static' else
+           'dynamic: extraction in %d worker processes (oracle/extract_ref.py) feeding the training process' % n_workers)
+    return dict(value=steps * BATCH / el, unit='subgraphs/s', cores=ncpu if mode != 'static' else threads, kind='port',
+                cpu=cpu_model(), host_cores=ncpu, torch_threads=threads,
+                sample='%d train steps of batch %d in %.1f s; %s; PyG-1.4.2-formulation fwd/bwd + Adam '
+                       '(oracle/pyg_ref.py, torch threads=%d)' % (steps, BATCH, el, how, threads))
 
 
 def main():
@@ -101,11 +173,30 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--config', default='ml_1m', choices=sorted(CONFIGS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--profile-steps', type=int, default=20)
+    ap.add_argument('--profile-steps', type=int, default=40)
+    ap.add_argument('--rmse-links', type=int, default=5000)
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly (no hipGraph replay)')
     ap.add_argument('--no-overlap', action='store_true', help='extract batch t+1 on the same stream (no overlap)')
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    want_cpu = not args.no_cpu_baseline and int(os.environ.get('WORLD_SIZE', '1')) <= 1
+
+    # ---- workload (identical on every rank; pure numpy, built BEFORE any GPU call)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):       # stdout carries the ONE JSON line only
+        if cfg['dataset'] in ('douban', 'flixster', 'yahoo_music'):
+            split = preprocessing.load_data_monti(cfg['dataset'], testing=True)
+            source = 'bundled real'
+        else:
+            split = preprocessing.create_trainvaltest_split(cfg['dataset'], 1234, True,
+                                                            verbose=int(os.environ.get('RANK', '0')) == 0)
+            source = 'real' if preprocessing._load_real_movielens(cfg['dataset']) is not None else 'synthetic'
+    (_, _, A, tr_l, tr_u, tr_v, _, _, _, te_l, te_u, te_v, class_values) = split
+    pool, n_workers = (None, 0)
+    if want_cpu and cfg['cpu'] == 'dynamic':
+        pool, n_workers = start_cpu_workers(A, tr_u, tr_v, tr_l, class_values, cfg['mnph'])
+    elif want_cpu:
+        _W.update(A=A, Acsc=A.tocsc(), tr_u=tr_u, tr_v=tr_v, tr_l=tr_l, cv=class_values, mnph=cfg['mnph'])
 
     rank, world = parallel.init_from_env('nccl')
     if world != args.gpus:
@@ -118,12 +209,6 @@ def main():
         _lib.LIB_PATH = os.environ['IGMC_LIB_PATH']
     lib = _lib.load()                                  # fails loudly without the gfx950 library
 
-    # ---- workload (identical on every rank)
-    import contextlib
-    with contextlib.redirect_stdout(sys.stderr):       # stdout carries the ONE JSON line only
-        split = preprocessing.create_trainvaltest_split(cfg['dataset'], 1234, True, verbose=(rank == 0))
-    (_, _, A, tr_l, tr_u, tr_v, _, _, _, te_l, te_u, te_v, class_values) = split
-    source = 'real' if preprocessing._load_real_movielens(cfg['dataset']) is not None else 'synthetic'
     torch.manual_seed(1)
     ds = MyDynamicDataset('data/bench', A, (tr_u, tr_v), tr_l, 1, 1.0, cfg['mnph'], None, None, class_values,
                           device=local, seed=1)
@@ -133,7 +218,6 @@ def main():
     if world > 1:
         parallel.broadcast_(model.flat_parameters(), 0)
     opt = FlatAdam(model, lr=1e-3)
-    loss = None
     n = len(ds)
     gen = torch.Generator()
     gen.manual_seed(1234)
@@ -146,25 +230,28 @@ def main():
     sg = StepGraph(model, opt, ds, BATCH, 0.001, use_graph=not args.no_graph, overlap=not args.no_overlap)
     state = dict(i=0, epoch=0)
 
-    def step():
+    def new_epoch_if_needed():
         if state['i'] % steps_avail == 0:
             state['epoch'] += 1
             sg.begin_epoch(perm, state['epoch'])
+
+    def step():
+        new_epoch_if_needed()
         state['i'] += 1
         sg.step()
         return sg
 
     def run(nsteps):                    # exactly `nsteps` optimisation steps, epoch after epoch
         while nsteps > 0:
-            if state['i'] % steps_avail == 0:
-                state['epoch'] += 1
-                sg.begin_epoch(perm, state['epoch'])
+            new_epoch_if_needed()
             chunk = min(nsteps, steps_avail - state['i'] % steps_avail)
             sg.steps(chunk)
             state['i'] += chunk
             nsteps -= chunk
 
     run(args.warmup)
+    new_epoch_if_needed()
+    captured = sg.prepare()             # every graph the timed steps replay exists before t0
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -180,68 +267,150 @@ def main():
     sg.check()                                          # no device-side wait timed out during the timed steps
     final_loss = float(sg.loss[0].item())
 
-    # ---- roofline leg: instrumented pass (HIP events around every kernel on the launch stream)
-    roofline = None
-    kernels = {}
+    # ---- roofline leg
+    roofline, kernels, extraction, replay_us = None, {}, None, None
     if args.profile_steps > 0:
-        # EVERY rank runs the instrumented steps (under data parallelism each of them holds a gradient all-reduce,
-        # a collective all ranks must enter); rank 0 reports its own kernels
+        P = args.profile_steps
+        # (1) the dominant kernel UNDER REPLAY: re-capture the same graphs with the device-side launch clock compiled
+        #     into the captured arguments, replay P steps, read the clock.  EVERY rank runs these steps (each holds a
+        #     gradient all-reduce under data parallelism); rank 0 reports its own kernel.
+        if sg.use_graph:
+            lib.igmc_profile_enable(2)
+            sg.graphs, sg.multi = [None, None], None
+            new_epoch_if_needed()
+            sg.prepare()
+            import ctypes as C
+            lib.call('igmc_profile_gs_clock', sg.ws.handle, None, None, 1)
+            run(P)
+            torch.cuda.synchronize()
+            cnt, mean = C.c_int64(0), C.c_double(0.0)
+            lib.call('igmc_profile_gs_clock', sg.ws.handle, C.byref(cnt), C.byref(mean), 1)
+            if cnt.value > 0:
+                replay_us = float(mean.value)
+            lib.igmc_profile_enable(0)
+            sg.graphs, sg.multi = [None, None], None
+        # (2) every kernel with HIP events on its launch stream: eager launches, extraction still overlapped
         engine.profile_enable(lib, True)
-        Ns, Es = [], []
-        sg.use_graph, sg.graphs = False, [None, None]   # instrumented pass launches eagerly
-        for _ in range(args.profile_steps):
+        Ns, Es, ext_bytes = [], [], []
+        deg_u = np.diff(A.indptr).astype(np.int64)
+        deg_v = np.bincount(A.indices, minlength=A.shape[1]).astype(np.int64)
+        sg.use_graph = False
+        for k in range(P):
             step()
-            info = sg.arena.info(st)
-            Ns.append(info.num_nodes)
-            Es.append(info.num_edges)
+            if rank == 0 and k < 8:                     # algorithmic bytes of the extraction, exact
+                d = sg.arena.download(st)
+                tot = 0
+                for g in range(d['B']):
+                    lo, hi, nu = d['node_off'][g], d['node_off'][g + 1], d['n_users'][g]
+                    users, items = d['node_gid'][lo:lo + nu], d['node_gid'][lo + nu:hi]
+                    e_sg = int(d['row_ptr'][hi] - d['row_ptr'][lo])
+                    tot += 5 * (deg_u[users[0]] + deg_v[items[0]] + int(deg_u[users].sum())) + (hi - lo) + 9 * e_sg // 2
+                ext_bytes.append(tot)
+                Ns.append(d['N'])
+                Es.append(d['E'])
+            else:
+                info = sg.arena.info(st)
+                Ns.append(info.num_nodes)
+                Es.append(info.num_edges)
         torch.cuda.synchronize()
         rows = engine.profile_fetch(lib, 64)
         engine.profile_enable(lib, False)
         N, E = float(np.mean(Ns)), float(np.mean(Es))
-        kernels = {name: dict(us=ms / calls * 1e3, calls_per_step=calls / args.profile_steps) for name, ms, calls in rows}
+        kernels = {name: dict(us=ms / calls * 1e3, calls_per_step=calls / P) for name, ms, calls in rows}
         tot = sum(ms for _, ms, _ in rows)
         dom = 'k_graph_step' if 'k_graph_step' in kernels else (
             'k_rgcn_layer_fwd' if 'k_rgcn_layer_fwd' in kernels else 'k_rgcn_gather_fwd')
-        if dom in kernels and args.profile_steps > 0:
+        if dom in kernels:
             algo_bytes = 133.0 * E + 132.0 * N                  # one layer, one direction
             if dom == 'k_graph_step':                           # forward + backward of the 3 conv layers in one launch
                 algo_bytes *= 6.0
-            dur_s = kernels[dom]['us'] * 1e-6
-            achieved = algo_bytes / dur_s / 1e9
-            # HBM-side bytes per launch of this kernel: PMC counters cannot be read from inside this process, they come
-            # from the committed rocprofv3 --pmc passes of the same command (tools/profile_round.sh -> pmc_traffic.py)
-            traffic = None
-            tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-            if args.config == 'ml_1m' and os.path.exists(tpath):
-                trec = json.load(open(tpath))
-                if trec.get('kernel') == dom:
+            eager_us = kernels[dom]['us']
+            from_replay = bool(dom == 'k_graph_step' and replay_us)
+            avg_us = replay_us if from_replay else eager_us
+            achieved = algo_bytes / (avg_us * 1e-6) / 1e9
+            # HBM-side bytes per launch of this kernel: PMC counters cannot be read from inside this process; they come
+            # from the committed rocprofv3 --pmc passes of this command (tools/profile_round.sh -> pmc_traffic.py) and
+            # only count while the kernel sources are the profiled ones
+            traffic, traffic_src = None, None
+            if os.path.exists(PMC_TRAFFIC):
+                trec = json.load(open(PMC_TRAFFIC))
+                if trec.get('kernel') == dom and trec.get('config') == args.config and \
+                        trec.get('src_sha') == kernel_source_sha():
                     traffic = trec.get('traffic_bytes')
+                    traffic_src = '%s @ %s' % (os.path.basename(PMC_TRAFFIC), trec.get('commit', '?'))
             roofline = dict(bound='hbm', kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
-                            frac=achieved / HBM_PEAK_GBS, traffic=traffic, avg_us=kernels[dom]['us'],
-                            algorithmic_bytes=algo_bytes, nodes=N, edges=E,
-                            share_of_kernel_time=kernels[dom]['us'] * kernels[dom]['calls_per_step'] * args.profile_steps
-                            / (tot * 1e3) if tot > 0 else None)
+                            frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src, avg_us=avg_us,
+                            avg_us_source='device launch clock under hipGraph replay + overlapped extraction'
+                            if from_replay else 'HIP events, eager launches',
+                            avg_us_eager_events=eager_us, algorithmic_bytes=algo_bytes, nodes=N, edges=E,
+                            share_of_kernel_time=kernels[dom]['us'] * kernels[dom]['calls_per_step'] * P / (tot * 1e3)
+                            if tot > 0 else None)
+        ext_names = [k for k in ('k_extract_nodes', 'k_relm', 'k_emit', 'k_count', 'k_fill', 'k_extract_dense')
+                     if k in kernels]
+        if ext_bytes and ext_names:
+            ext_us = sum(kernels[k]['us'] * kernels[k]['calls_per_step'] for k in ext_names)
+            extraction = dict(algorithmic_bytes=float(np.mean(ext_bytes)), us_per_step=ext_us,
+                              effective_GBps=float(np.mean(ext_bytes)) / (ext_us * 1e-6) / 1e9, kernels=ext_names,
+                              note='sum of the extraction kernels (HIP events, eager) while the model kernels of the '
+                                   'previous batch share the chip; 5*(deg u + deg v + sum deg U_s) + n + 9*E/2 bytes')
     if world > 1:
         parallel.barrier()
 
+    # ---- RMSE of the checkpoint the steps above produced (fixed slice of the test links)
+    rmse = None
+    if args.rmse_links > 0:
+        m = min(args.rmse_links, len(te_u))
+        te = MyDataset('data/bench_test', A, (te_u[:m], te_v[:m]), te_l[:m], 1, 1.0, cfg['mnph'], None, None,
+                       class_values, device=local, seed=1)
+        model.eval()
+        val = eval_rmse(model, DataLoader(te, BATCH, shuffle=False), dev)
+        rmse = dict(value=val, test_links=m, checkpoint='seed-1 init + %d optimisation steps of this run' % state['i'])
+        if rank == 0 and want_cpu:
+            from oracle import pyg_ref                   # checker
+            mo = min(200, m)
+            small = MyDataset('data/bench_test_o', A, (te_u[:mo], te_v[:mo]), te_l[:mo], 1, 1.0, cfg['mnph'], None, None,
+                              class_values, device=local, seed=1)
+            ref = pyg_ref.IGMCRef(4, (32, 32, 32, 32), len(class_values), 4, adj_dropout=cfg['adj_dropout'], fast=True)
+            ref.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+            sse_o = sse_e = 0.0
+
+            class PB(object):
+                pass
+            for data in DataLoader(small, BATCH, shuffle=False):
+                with torch.no_grad():
+                    out_e = model(data).cpu()
+                raw = data._materialise()
+                pb = PB()
+                pb.x, pb.edge_index, pb.edge_type, pb.batch = raw['x'], raw['edge_index'], raw['edge_type'], raw['batch']
+                pb.y = data.y.cpu()
+                s, _ = pyg_ref.eval_sse(ref, pb)
+                sse_o += s
+                sse_e += float(((out_e - pb.y) ** 2).sum())
+            rmse['oracle_check'] = dict(links=mo, engine=(sse_e / mo) ** 0.5, oracle=(sse_o / mo) ** 0.5,
+                                        abs_diff=abs((sse_e / mo) ** 0.5 - (sse_o / mo) ** 0.5))
+
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and want_cpu:
         try:
-            cpu = cpu_baseline(A, tr_u, tr_v, tr_l, class_values, cfg['mnph'], cfg['adj_dropout'])
+            cpu = cpu_baseline(pool, n_workers, len(tr_u), cfg['adj_dropout'], len(class_values), cfg['cpu'])
         except MemoryError:
             cpu = None
+    elif pool is not None:
+        pool.terminate()
     if rank == 0:
         rec = {
-            'metric': 'enclosing-subgraphs/sec (train step, batch=50)',
+            'metric': 'enclosing-subgraphs/sec (train step, batch=50) + test RMSE',
             'value': value, 'unit': 'subgraphs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': '%s %s-shaped rating graph (%d x %d, %d train links), random-init weights' % (
                 source, cfg['dataset'], A.shape[0], A.shape[1], n),
             'config': {'workload': '%s, hop 1, max-nodes-per-hop %d, batch %d per GPU, adj-dropout %g, dynamic-train, '
                                    'ARR 0.001, Adam' % (cfg['dataset'], cfg['mnph'], BATCH, cfg['adj_dropout']),
-                       'parallelism': 'dp%d' % world, 'global_batch': BATCH * world},
-            'roofline': roofline, 'cpu_baseline': cpu, 'final_loss': final_loss,
-            'kernels_us': {k: round(v['us'], 2) for k, v in kernels.items()},
+                       'parallelism': 'dp%d' % world, 'global_batch': BATCH * world,
+                       'graphs_captured_before_timing': bool(captured)},
+            'roofline': roofline, 'cpu_baseline': cpu, 'rmse': rmse, 'extraction': extraction,
+            'final_loss': final_loss, 'kernels_us': {k: round(v['us'], 2) for k, v in kernels.items()},
+            'kernel_src_sha': kernel_source_sha(),
         }
         print(json.dumps(rec))
     if parallel.is_dist():

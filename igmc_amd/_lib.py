@@ -39,6 +39,7 @@ SIGNATURES = {
     'igmc_batch_download': (i32, [vp] + [vp] * 11 + [vp]),
     'igmc_batch_device_ptr': (vp, [vp, i32]),
     'igmc_batch_set_side_features': (i32, [vp, vp, i32]),
+    'igmc_batch_bind_side_source': (i32, [vp, vp, i32]),
     'igmc_model_create': (i32, [i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(vp)]),
     'igmc_model_destroy': (None, [vp]),
     'igmc_param_count': (i64, [vp]),
@@ -57,6 +58,7 @@ SIGNATURES = {
     'igmc_step_finish': (i32, [vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp]),
     'igmc_profile_enable': (i32, [i32]),
     'igmc_profile_fetch': (i32, [vp, vp, vp, i32]),
+    'igmc_profile_gs_clock': (i32, [vp, C.POINTER(i64), C.POINTER(f64), i32]),
     'igmc_model_check': (i32, [vp, vp]),
 }
 

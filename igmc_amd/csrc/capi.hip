@@ -80,6 +80,9 @@ struct igmc_batch {
   int last_B;
   const float* side;
   int n_side;
+  const float* side_src;    // dataset-wide [n_links, n_side] matrix (igmc_batch_bind_side_source); rows gathered per batch
+  float* side_buf;          // [graph_cap, n_side] owned by the arena
+  int side_buf_cols;
   const int64_t* ctrl;
   Allocs mem;
 };
@@ -113,8 +116,31 @@ void igmc_prof_begin(const char* name, void* stream) {
 }
 void igmc_prof_end(void* stream) { hipEventRecord(g_prof.back().b, (hipStream_t)stream); }
 
+// on = 1: HIP events around every kernel launch (eager launches only; igmc_profile_fetch).
+// on = 2: no events (legal inside hipGraph capture); k_graph_step launches enqueued / captured from now on clock
+//         themselves on the device (igmc_profile_gs_clock).
 extern "C" int igmc_profile_enable(int on) {
   g_igmc_prof_on = on;
+  return 0;
+}
+
+// Launch clock of k_graph_step since the last reset: launches, mean duration in microseconds (device wall clock,
+// earliest workgroup start -> last workgroup end).  Synchronises the device.
+extern "C" int igmc_profile_gs_clock(const igmc_model* m, int64_t* launches, double* mean_us, int reset) {
+  if (!m) IGMC_FAIL("null model");
+  unsigned long long ts[4];
+  HIPCHECK(hipDeviceSynchronize());
+  HIPCHECK(hipMemcpy(ts, m->d.gs_ts, sizeof(ts), hipMemcpyDeviceToHost));
+  int khz = 0;
+#ifndef IGMC_HIPEMU
+  HIPCHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, m->device));
+#endif
+  if (launches) *launches = (int64_t)ts[2];
+  if (mean_us) *mean_us = (ts[2] && khz > 0) ? (double)ts[1] / (double)ts[2] * 1e3 / (double)khz : 0.0;
+  if (reset) {
+    const unsigned long long ts0[4] = {~0ull, 0ull, 0ull, 0ull};
+    HIPCHECK(hipMemcpy(m->d.gs_ts, ts0, sizeof(ts0), hipMemcpyHostToDevice));
+  }
   return 0;
 }
 
@@ -253,6 +279,9 @@ extern "C" int igmc_batch_create(const igmc_graph* g, int max_graphs, int hop, i
   b->last_B = 0;
   b->side = nullptr;
   b->n_side = 0;
+  b->side_src = nullptr;
+  b->side_buf = nullptr;
+  b->side_buf_cols = 0;
   b->ctrl = nullptr;
   BatchDev& d = b->d;
   Allocs& M = b->mem;
@@ -308,6 +337,8 @@ extern "C" int igmc_extract_batch(const igmc_graph* g, igmc_batch* b, const int3
   if (!d_link_u || !d_link_v || !d_link_y) IGMC_FAIL("null link arrays");
   igmc_launch_extract(g->d, b->d, d_link_u, d_link_v, d_link_y, d_link_idx, first, B, 0, sample_ratio, seed, epoch,
                       b->ctrl, stream);
+  if (b->side_src)      // side features of the target nodes travel with the extraction (reference :250-253)
+    igmc_launch_side_gather(b->side_src, b->n_side, d_link_idx, first, B, b->ctrl, b->side_buf, stream);
   HIPCHECK(hipGetLastError());
   b->last_B = B;
   return 0;
@@ -448,6 +479,26 @@ extern "C" int igmc_batch_set_side_features(igmc_batch* b, const float* d_feat, 
   if (!b) IGMC_FAIL("null batch");
   b->side = d_feat;
   b->n_side = n_side;
+  b->side_src = nullptr;
+  return 0;
+}
+
+extern "C" int igmc_batch_bind_side_source(igmc_batch* b, const float* d_side_all, int n_side) {
+  if (!b) IGMC_FAIL("null batch");
+  if (!d_side_all || n_side <= 0) {      // unbind
+    b->side_src = nullptr;
+    b->side = nullptr;
+    b->n_side = 0;
+    return 0;
+  }
+  if (b->side_buf_cols < n_side) {
+    HIPCHECK(hipSetDevice(b->g->device));
+    if (b->mem.get(&b->side_buf, (size_t)b->d.graph_cap * n_side)) IGMC_FAIL("hipMalloc failed (side features)");
+    b->side_buf_cols = n_side;
+  }
+  b->side_src = d_side_all;
+  b->side = b->side_buf;
+  b->n_side = n_side;
   return 0;
 }
 
@@ -509,6 +560,7 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   d.gs_ll_stride = N * 32;
   if (d.R <= 5) fail |= M.get(&d.gs_ll, 5 * d.gs_ll_stride);
   fail |= M.get(&d.gs_bar, 2 * Bc + 1);
+  fail |= M.get(&d.gs_ts, 4);
   d.gs_err = d.gs_bar ? d.gs_bar + 2 * Bc : nullptr;
   fail |= M.get(&d.wg_part, (size_t)4 * IGMC_WG_BLOCKS * igmc_wg_stride()) |
           M.get(&d.gatt_part, (size_t)3 * IGMC_GATHER_BLOCKS * d.R * 4) |
@@ -540,6 +592,10 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   }
   HIPCHECK(hipMemset(m->done_ctr, 0, 8 * sizeof(int)));
   HIPCHECK(hipMemset(m->d.gs_bar, 0, (2 * (size_t)max_graphs + 1) * sizeof(int)));
+  {
+    const unsigned long long ts0[4] = {~0ull, 0ull, 0ull, 0ull};
+    HIPCHECK(hipMemcpy(m->d.gs_ts, ts0, sizeof(ts0), hipMemcpyHostToDevice));
+  }
   if (m->d.gs_ll) HIPCHECK(hipMemset(m->d.gs_ll, 0, 5 * m->d.gs_ll_stride * sizeof(unsigned long long)));   // tag 0 = never valid
   if (igmc_model_prepare(d)) {
     M.release();

@@ -750,6 +750,28 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_edge_flags(BatchDev b, float p, 
   }
 }
 
+// ---------------------------------------------------------------- side features of the target nodes
+// reference util_functions.py:250-253, :272-275: a subgraph carries the feature rows of its two TARGET nodes only.
+// The dataset keeps one [n_links, S] matrix (row k = [u_features[link_u[k]] | v_features[link_v[k]]]) in HBM; the rows
+// of the batch's links are gathered here, in the extraction branch, through the same (control block, permutation)
+// indexing as k_extract_nodes -- so the fused / captured training step needs no host-side index_select.
+__global__ __launch_bounds__(IGMC_BLOCK) void k_side_gather(const float* src, int S, const int32_t* link_idx, int first_arg,
+                                                             int B, const int64_t* ctrl, float* dst) {
+  const int first = ctrl ? (int)ctrl[(first_arg & 1) ? IGMC_CTRL_FIRST_ODD : IGMC_CTRL_FIRST] : first_arg;
+  for (int i = blockIdx.x * IGMC_BLOCK + threadIdx.x; i < B * S; i += gridDim.x * IGMC_BLOCK) {
+    const int g = i / S, f = i - g * S;
+    const int pos = link_idx ? link_idx[first + g] : first + g;
+    dst[i] = src[(size_t)pos * S + f];
+  }
+}
+
+void igmc_launch_side_gather(const float* src, int S, const int32_t* link_idx, int first, int B, const int64_t* ctrl,
+                             float* dst, void* stream) {
+  int grid = (B * S + IGMC_BLOCK - 1) / IGMC_BLOCK;
+  grid = grid < 1 ? 1 : (grid > 256 ? 256 : grid);
+  IGMC_PLAUNCH("k_side_gather", k_side_gather, grid, IGMC_BLOCK, 0, stream, src, S, link_idx, first, B, ctrl, dst);
+}
+
 __global__ __launch_bounds__(IGMC_BLOCK) void k_fill_u8(uint8_t* p, int64_t n, uint8_t v) {
   for (int64_t i = (int64_t)blockIdx.x * IGMC_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * IGMC_BLOCK) p[i] = v;
 }

@@ -416,6 +416,11 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
   const uint32_t tag0 = (cs > 1) ? (uint32_t)m.gs_bar[1] * 8u + 1u : 0u;
 #endif
   const uint64_t step = m.ctrl ? (uint64_t)m.ctrl[IGMC_CTRL_STEP] : a.step;
+#ifndef IGMC_HIPEMU
+  // launch clock (profiling mode 2 only): duration of THIS launch = last workgroup's end - earliest workgroup's start,
+  // on the constant-rate wall clock, measured where hipGraph replay leaves no room for events between kernels
+  if (a.ts && tid == 0) atomicMin(a.ts, (unsigned long long)wall_clock64());
+#endif
   GS_STAMP(0);
   GS_CSTAMP(0);
 
@@ -1203,6 +1208,18 @@ __global__ __launch_bounds__(GS_THREADS) void k_graph_step(BatchDev b, ModelDev 
     }
   }
 #endif
+#ifndef IGMC_HIPEMU
+  if (a.ts && tid == 0) {
+    const unsigned long long t1 = (unsigned long long)wall_clock64();
+    if (atomicAdd(a.ts + 3, 1ull) == (unsigned long long)gridDim.x - 1ull) {      // last workgroup of the launch
+      const unsigned long long t0 = __hip_atomic_load(a.ts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicAdd(a.ts + 1, t1 - t0);
+      atomicAdd(a.ts + 2, 1ull);
+      __hip_atomic_store(a.ts, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.ts + 3, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+#endif
   GS_STAMP(12);
 }
 
@@ -1298,6 +1315,7 @@ void igmc_launch_graph_step(const ModelDev& m, const BatchDev& b, const float* P
   a.out = out;
   a.lay = lay;
   a.timing = getenv("IGMC_GS_TIMING") ? 1 : 0;
+  a.ts = (g_igmc_prof_on == 2) ? m.gs_ts : nullptr;
   const int cs = igmc_gs_cluster(B);
   a.cs = cs;
   a.stride = (cs > 1) ? ((B + 7) & ~7) : 1;

@@ -60,9 +60,12 @@ struct GsArgs {
   float mult, grad_scale;
   float* out;
   int timing;
+  unsigned long long* ts;   // launch clock accumulators (ModelDev::gs_ts) or NULL
   int cs, stride;      // workgroups per subgraph; block index stride between the members of a cluster
   GsLayout lay;
 };
+void igmc_launch_side_gather(const float* src, int S, const int32_t* link_idx, int first, int B, const int64_t* ctrl,
+                             float* dst, void* stream);
 int igmc_gs_eligible(const ModelDev& m, const BatchDev& b, GsLayout* lay);
 int igmc_gs_grid(int B);
 int igmc_gs_cluster(int B);
@@ -78,7 +81,7 @@ extern int g_igmc_prof_on;
 
 #define IGMC_PLAUNCH(name, kern, grid, block, shmem, stream, ...)          \
   do {                                                                     \
-    if (g_igmc_prof_on) igmc_prof_begin(name, stream);                     \
+    if (g_igmc_prof_on == 1) igmc_prof_begin(name, stream);                \
     IGMC_LAUNCH(kern, grid, block, shmem, stream, __VA_ARGS__);            \
-    if (g_igmc_prof_on) igmc_prof_end(stream);                             \
+    if (g_igmc_prof_on == 1) igmc_prof_end(stream);                        \
   } while (0)

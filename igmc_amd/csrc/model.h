@@ -40,6 +40,9 @@ struct ModelDev {
   float* datt_part;   // [4*ts_stride/32][4] partial <dW_r, basis_b> products of 32 table elements (k_tail_ts)
   int* gs_bar;        // k_graph_step clusters: [0] workgroups that finished the launch, [1] launch sequence number
   int* gs_err;        // [1] set when a cluster exchange timed out
+  unsigned long long* gs_ts;   // [4] device-side launch clock of k_graph_step (igmc_profile_enable(2)): [0] earliest workgroup
+                               // start of the running launch (wall clock ticks), [1] sum of launch durations, [2] launches,
+                               // [3] workgroups that finished the running launch
   unsigned long long* gs_ll;   // [5 exchanges][node_cap][32] {value, tag} words of the cluster exchanges (R <= 5 only)
   size_t gs_ll_stride;         // words per exchange buffer
   float* arr_part;    // [4] ARR regulariser per layer

@@ -113,6 +113,11 @@ class Batch(object):
     def set_side_features(self, ptr, n_side):
         self.lib.call('igmc_batch_set_side_features', self.handle, _p(ptr), int(n_side))
 
+    def bind_side_source(self, ptr, n_side):
+        """Dataset-wide [n_links, n_side] side-feature matrix: every later ``extract`` gathers the batch's rows on the
+        device (``igmc_batch_bind_side_source``)."""
+        self.lib.call('igmc_batch_bind_side_source', self.handle, _p(ptr), int(n_side))
+
     def info(self, stream=None):
         info = _lib.BatchInfo()
         self.lib.call('igmc_batch_get_info', self.handle, C.byref(info), _p(stream))

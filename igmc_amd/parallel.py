@@ -74,3 +74,12 @@ def broadcast_(t, src=0):
     if is_dist() and world_size() > 1:
         dist.broadcast(t, src=src)
     return t
+
+
+def broadcast_object(obj, src=0):
+    """A small picklable object from rank ``src`` to every rank (host-side decisions that all ranks must share)."""
+    if is_dist() and world_size() > 1:
+        box = [obj]
+        dist.broadcast_object_list(box, src=src)
+        return box[0]
+    return obj

@@ -213,6 +213,28 @@ class StepGraph(object):
             self.use_graph, self.graphs = False, [None, None]
             torch.cuda.synchronize()
 
+    def prepare(self):
+        """Capture every hipGraph this object will replay (both single-step parities and the multi-step group) NOW.
+        Capturing executes nothing, so no step is skipped or repeated; callers that time a region (bench.py) call this
+        after their warm-up so that no capture (milliseconds each) falls inside the timed steps.  Needs at least one
+        eagerly executed step before it (first launches load code objects, which a capture cannot do)."""
+        if not self.use_graph or self.steps_done < 1 or not self._attached:
+            return False
+        for parity in (0, 1):
+            if self.graphs[parity] is None and self.use_graph:
+                self._capture(parity)
+        if self.use_graph and not self.dp_path and self.multi_n >= 2 and self.multi is None:
+            self._capture_multi()
+        return True
+
+    def _capture_multi(self):
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(self.multi_n):
+                self._enqueue(i % 2, self.B)
+        self.multi = g
+
     def step(self, B=None):
         """One optimisation step on the next ``B`` links of the epoch permutation."""
         B = self.B if B is None else int(B)
@@ -247,12 +269,7 @@ class StepGraph(object):
                 # captured as soon as it can be (capturing executes nothing), also when fewer than M steps are asked for
                 # right now: the milliseconds a capture costs then fall into the caller's warm-up, not into its first
                 # long run
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    for i in range(M):
-                        self._enqueue(i % 2, self.B)
-                self.multi = g
+                self._capture_multi()
             if multi_ok and n >= M:
                 self.multi.replay()
                 self.k += M

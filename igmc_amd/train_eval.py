@@ -155,6 +155,11 @@ def train_multiple_epochs(train_dataset, test_dataset, model, epochs, batch_size
                                              map_location=device))
         start_epoch = continue_from + 1
         epochs -= continue_from
+        # the epoch shuffles, the dynamic sampling keys and the dropout hashes are keyed on the loader's epoch counter
+        # and the model's step counter: a resumed run continues them instead of replaying epochs 1..
+        train_loader.epoch = continue_from
+        test_loader.epoch = continue_from
+        model._step = continue_from * len(train_loader)
 
     if torch.cuda.is_available():
         torch.cuda.synchronize()
@@ -261,9 +266,18 @@ def eval_loss(model, loader, device, regression=False, show_progress=False):
         ws.forward(flat.data_ptr(), data.arena, out.data_ptr(), training=False,
                    multiply_by=float(model.multiply_by), stream=st)
         ws.sse_accumulate(out.data_ptr(), data.arena, acc.data_ptr(), stream=st)
+    _check_workspaces(model)
     parallel.all_reduce_sum_(acc)
     sse, cnt = acc.tolist()
     return sse / max(cnt, 1.0)
+
+
+def _check_workspaces(model):
+    """A bounded device-side wait of the subgraph kernel's cluster exchange that timed out leaves partial
+    activations: never report an RMSE computed from them (synchronises the stream)."""
+    st = torch.cuda.current_stream().cuda_stream
+    for ws in model._ws.values():
+        ws.lib.call('igmc_model_check', ws.handle, engine._p(st))
 
 
 def eval_rmse(model, loader, device, show_progress=False):
@@ -283,6 +297,7 @@ def eval_loss_ensemble(model, checkpoints, loader, device, regression=False, sho
             with torch.no_grad():
                 outs.append(model(data))
         Outs.append(torch.cat(outs, 0).view(-1, 1))
+        _check_workspaces(model)
     ys = torch.cat(ys, 0)
     Outs = torch.cat(Outs, 1).mean(1)
     acc = torch.stack([F.mse_loss(Outs, ys, reduction='sum').double(),

@@ -262,7 +262,12 @@ class _EngineDataset(object):
     def arena(self, max_graphs, slot=0):
         key = (int(max_graphs), slot)
         if key not in self._arenas:
-            self._arenas[key] = engine.Batch(self.graph, int(max_graphs), self.h, self.max_nodes_per_hop)
+            a = engine.Batch(self.graph, int(max_graphs), self.h, self.max_nodes_per_hop)
+            if self._side is not None:
+                # the target nodes' feature rows are gathered by the extraction launch itself (device-side, also
+                # under hipGraph replay of the training step)
+                a.bind_side_source(self._side.data_ptr(), self.n_side_features)
+            self._arenas[key] = a
         return self._arenas[key]
 
     def extract(self, positions, first, B, epoch=0, slot=0, max_graphs=None, stream=None):
@@ -274,13 +279,12 @@ class _EngineDataset(object):
                       None if positions is None else positions.data_ptr(), first, B, self.sample_ratio,
                       self.seed, ep, st)
         side = None
-        if self._side is not None:
+        if self._side is not None:        # view of the rows the extraction launch gathered (for inspection / get())
             if positions is None:
                 idx = torch.arange(first, first + B, device=self.link_y.device)
             else:
                 idx = positions[first:first + B].long()
-            side = self._side.index_select(0, idx).contiguous()
-            arena.set_side_features(side.data_ptr(), self.n_side_features)
+            side = self._side.index_select(0, idx)
         return DeviceBatch(self, arena, B, positions, first, side)
 
     def get(self, idx):

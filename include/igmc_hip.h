@@ -110,6 +110,12 @@ void* igmc_batch_device_ptr(const igmc_batch* b, int which);
 /* Optional side features of the two target nodes (reference util_functions.py:250-253,
  * models.py:208-209): d_feat[B, n_side] fp32, borrowed for the next forward. */
 int igmc_batch_set_side_features(igmc_batch* b, const float* d_feat, int n_side);
+/* The same, resolved on the device: d_side_all[n_links, n_side] holds, for EVERY link of the dataset, the feature
+ * rows of its two target nodes ([u_features[link_u] | v_features[link_v]], reference MyDynamicDataset.get ->
+ * util_functions.py:272-275); every following igmc_extract_batch on this arena gathers the rows of the batch's
+ * links (same d_link_idx / first / control-block indexing as the extraction) into an arena-owned buffer that the
+ * model then reads -- nothing happens on the host per step, so the step stays hipGraph-capturable.  NULL unbinds. */
+int igmc_batch_bind_side_source(igmc_batch* b, const float* d_side_all, int n_side);
 
 /* ------------------------------------------------------------------ model
  * Flat fp32 parameter buffer layout (offsets in floats; query with igmc_param_offset):
@@ -209,6 +215,11 @@ int igmc_sse_accumulate(const float* d_out, const igmc_batch* b, double* d_acc, 
  * returns the number of distinct kernels recorded, or <0 on error. */
 int igmc_profile_enable(int on);
 int igmc_profile_fetch(char names[][48], float* ms, int* calls, int cap);
+/* igmc_profile_enable(2): no events (legal inside a hipGraph capture); instead every k_graph_step launch enqueued or
+ * captured from then on clocks itself on the device (earliest workgroup start -> last workgroup end, constant-rate
+ * wall clock), which is how bench.py times the dominant kernel UNDER graph replay.  Returns the launches and their
+ * mean duration since the last reset; synchronises the device. */
+int igmc_profile_gs_clock(const igmc_model* m, int64_t* launches, double* mean_us, int reset);
 
 /* Health check of the workspace (synchronises `stream`): fails when a bounded device-side wait of the
  * one-workgroup-per-subgraph step kernel ever timed out since the last check.  No reference counterpart. */

@@ -148,3 +148,34 @@ def test_fused_train_step_tracks_torch_adam(be, monkeypatch, name, cluster, drop
     monkeypatch.setenv('IGMC_GS_CLUSTER', cluster)
     res = PC.run_fused_train_trajectory(be, sub(name, 16), R=5, steps=4, batch=4, use_dropout=drop)
     assert res['frac_off'] < 2e-3
+
+
+def test_side_source_gathered_by_the_extraction_launch(be):
+    """``igmc_batch_bind_side_source``: the target nodes' feature rows (reference util_functions.py:250-253) are
+    gathered on the device by the extraction launch through the batch's own (permutation, first) indexing -- the same
+    forward as handing the gathered [B, S] rows over with ``igmc_batch_set_side_features``."""
+    from igmc_amd import engine
+    case = sub('synth_nocap', 8)
+    A, S, B = case['A'], 32, 4
+    g = engine.Graph(A, lib=be.lib)
+    n = len(case['links'])
+    lu, lv = case['links'][:, 0].astype(np.int32).copy(), case['links'][:, 1].astype(np.int32).copy()
+    ly = case['class_values'][case['link_labels']].astype(np.float32)
+    side_all = np.random.default_rng(3).standard_normal((n, S)).astype(np.float32)
+    perm = np.array([5, 2, 7, 0, 3, 1, 6, 4], np.int32)
+    ref = PC.make_ref_model(4, 5, n_side=S, seed=2)
+    outs = []
+    for mode in ('bound', 'handed'):
+        b = engine.Batch(g, B, 1, case['mnph'])
+        ws = engine.ModelWorkspace(be.lib, 0, 5, 4, 4, S, b.node_capacity, b.edge_capacity, B)
+        P = PC.flatten_params(ws, ref)
+        if mode == 'bound':
+            b.bind_side_source(side_all.ctypes.data, S)
+        b.extract(lu.ctypes.data, lv.ctypes.data, ly.ctypes.data, perm.ctypes.data, 2, B)
+        if mode == 'handed':
+            rows = np.ascontiguousarray(side_all[perm[2:2 + B]])
+            b.set_side_features(rows.ctypes.data, S)
+        out = np.zeros(B, np.float32)
+        ws.forward(P.ctypes.data, b, out.ctypes.data, training=False)
+        outs.append(out.copy())
+    assert np.array_equal(outs[0], outs[1]) and np.all(np.isfinite(outs[0])) and np.ptp(outs[0]) > 0

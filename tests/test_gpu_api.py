@@ -358,3 +358,65 @@ def test_graph_step_other_cluster_sizes(monkeypatch, batch):
         sg.check()
         losses[name] = out
     np.testing.assert_allclose(losses['per_layer'], losses['per_graph'], rtol=5e-5)
+
+
+def test_resume_continues_the_run_instead_of_replaying_it(flix, tmp_path):
+    """``continue_from`` (reference train_eval.py:56-63): weights + Adam state AND the epoch / step counters that key the
+    shuffles, the dynamic sampling and the dropout hashes are restored -- 1 epoch + resume for 1 epoch == 2 epochs."""
+    import torch
+    from igmc_amd.models import IGMC
+    from igmc_amd.train_eval import train_multiple_epochs
+    tr, te, cv = make_sets(flix, ntr=400, nte=100)
+
+    def logger(info, m, opt):
+        if m is not None:
+            torch.save(m.state_dict(), str(tmp_path / ('model_checkpoint%d.pth' % info['epoch'])))
+            torch.save(opt.state_dict(), str(tmp_path / ('optimizer_checkpoint%d.pth' % info['epoch'])))
+
+    def fresh():
+        torch.manual_seed(11)
+        return IGMC(tr, latent_dim=[32, 32, 32, 32], num_relations=len(cv), num_bases=4, regression=True,
+                    adj_dropout=0.2, seed=4)
+    m1 = fresh()
+    r1 = train_multiple_epochs(tr, te, m1, 2, 50, 1e-3, 0.1, 50, 0, ARR=0.001, logger=logger, res_dir=str(tmp_path))
+    m2 = fresh()
+    r2 = train_multiple_epochs(tr, te, m2, 2, 50, 1e-3, 0.1, 50, 0, ARR=0.001, logger=None, continue_from=1,
+                               res_dir=str(tmp_path))
+    assert torch.allclose(m1.flat_parameters(), m2.flat_parameters(), rtol=1e-5, atol=1e-7)
+    assert r1 == pytest.approx(r2, abs=1e-6)
+
+
+def test_training_with_side_features(flix):
+    """--use-features (reference models.py:186-188,208-209; Main.py:267-274): the fused / hipGraph-replayed training
+    step gathers the target nodes' feature rows on the device; it must learn, and walk the eager loop's trajectory."""
+    import torch
+    from igmc_amd.models import IGMC
+    from igmc_amd.train_eval import train_multiple_epochs
+    from igmc_amd.util_functions import MyDataset, MyDynamicDataset
+    (_, _, adj, trl, tru, trv, _, _, _, tel, teu, tev, cv) = flix
+    rng = np.random.default_rng(0)
+    uf = rng.standard_normal((adj.shape[0], 12)).astype(np.float32)
+    vf = rng.standard_normal((adj.shape[1], 20)).astype(np.float32)
+    tr = MyDynamicDataset('data/t/sf_train', adj, (tru[:400], trv[:400]), trl[:400], 1, 1.0, 10000, uf, vf, cv)
+    te = MyDataset('data/t/sf_test', adj, (teu[:100], tev[:100]), tel[:100], 1, 1.0, 10000, uf, vf, cv)
+    d = tr[5]
+    assert d.u_feature.shape == (1, 12) and d.v_feature.shape == (1, 20)
+    assert np.allclose(d.u_feature.numpy()[0], uf[tru[5]]) and np.allclose(d.v_feature.numpy()[0], vf[trv[5]])
+    finals = {}
+    for name, env in (('graph', {}), ('eager', {'IGMC_NO_GRAPH': '1', 'IGMC_NO_OVERLAP': '1'})):
+        os.environ.update(env)
+        try:
+            torch.manual_seed(3)
+            model = IGMC(tr, latent_dim=[32, 32, 32, 32], num_relations=len(cv), num_bases=4, regression=True,
+                         adj_dropout=0.0, side_features=True, n_side_features=32, seed=2)
+            logs = []
+            rmse = train_multiple_epochs(tr, te, model, 3, 50, 1e-3, 0.1, 50, 0, ARR=0.001,
+                                         logger=lambda info, m, o: logs.append(dict(info)))
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        assert math.isfinite(rmse) and logs[0]['train_loss'] > logs[-1]['train_loss']
+        assert tuple(model.lin1.weight.shape) == (128, 256 + 32)
+        finals[name] = (model.flat_parameters().detach().cpu().clone(), rmse)
+    assert torch.allclose(finals['graph'][0], finals['eager'][0], rtol=2e-4, atol=2e-6)
+    assert finals['graph'][1] == pytest.approx(finals['eager'][1], rel=1e-4)
