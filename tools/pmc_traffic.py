@@ -1,20 +1,25 @@
 """HBM-side traffic of the roofline kernel from the PMC summaries of tools/profile_round.sh.
 
-    python tools/pmc_traffic.py gpurun_out/prof profiles/r01_pmc_traffic.json
+    python tools/pmc_traffic.py gpurun_out/prof profiles/r02_pmc_traffic.json [config]
+
+The record is stamped with the hash of the kernel sources (bench.kernel_source_sha) and the commit (IGMC_COMMIT):
+bench.py reports ``roofline.traffic`` from it only while the sources it runs are the ones that were profiled.
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch (rocprofv3 derived counters over TCC_EA0_RDREQ / _WRREQ);
 on gfx950 FETCH_SIZE tallies 128-byte read requests at 64 bytes (MI355X_MICROARCH.md, HBM), so reads are doubled.
 The figure includes Infinity-Cache hits: it is fabric-side traffic of the L2s, an upper bound of HBM traffic.
 """
 import json
+import os
 import re
 import sys
 
-KERNEL = 'k_graph_step<false, true>'        # bench.py's roofline kernel (headline config: no edge dropout, training)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
 NAME = 'k_graph_step'
 
 
-def counters(path):
+def counters(path, KERNEL):
     out = {}
     for line in open(path):
         if KERNEL in line:
@@ -25,15 +30,20 @@ def counters(path):
 
 def main():
     src, dst = sys.argv[1], sys.argv[2]
+    config = sys.argv[3] if len(sys.argv) > 3 else 'ml_1m'
+    # bench.py's roofline kernel: training instantiation, with edge flags when the config has adj-dropout
+    KERNEL = 'k_graph_step<false, true>' if config == 'ml_1m' else 'k_graph_step<true, true>'
     c = {}
     for f in ('pmc1.txt', 'pmc2.txt'):
-        c.update(counters('%s/%s' % (src, f)))
+        c.update(counters('%s/%s' % (src, f), KERNEL))
+    from bench import kernel_source_sha
     fetch, write = c['FETCH_SIZE'] * 1024.0, c['WRITE_SIZE'] * 1024.0
-    rec = dict(kernel=NAME, symbol=KERNEL, fetch_bytes_reported=fetch, write_bytes=write,
+    rec = dict(kernel=NAME, symbol=KERNEL, config=config, src_sha=kernel_source_sha(),
+               commit=os.environ.get('IGMC_COMMIT', 'unknown'), fetch_bytes_reported=fetch, write_bytes=write,
                traffic_bytes=2.0 * fetch + write,
                l2_hit_rate=c['TCC_HIT_sum'] / (c['TCC_HIT_sum'] + c['TCC_MISS_sum']),
                note='per launch; FETCH_SIZE doubled (gfx950 correction), + WRITE_SIZE; separate --pmc passes of '
-                    'bench.py --no-graph --no-overlap (tools/profile_round.sh)')
+                    'bench.py in its default configuration (tools/profile_round.sh; rocprofv3 serialises dispatches while it collects counters)')
     json.dump(rec, open(dst, 'w'), indent=1)
     print(rec)
 
