@@ -84,7 +84,14 @@ def cpu_model():
 
 
 # ------------------------------------------------------------------ CPU baseline (checker code, timed)
+# Runs in a FRESH python process (`bench.py --cpu-baseline-worker <npz>`): no HIP context, its own extraction worker
+# processes -- forking workers from (or next to) a process that holds a GPU context and GBs of torch state made the
+# training process of the baseline two orders of magnitude slower.
 _W = {}
+
+
+def _worker_init():
+    torch.set_num_threads(1)
 
 
 def _worker_extract(idx):
@@ -97,57 +104,48 @@ def _worker_extract(idx):
     return [extract_ref.extract((tr_u[k], tr_v[k]), A, Acsc, 1, 1.0, mnph, cv, tr_l[k]) for k in idx]
 
 
-def start_cpu_workers(A, tr_u, tr_v, tr_l, class_values, mnph):
-    """Fork the extraction workers BEFORE the GPU runtime is initialised (forking a process that holds a HIP context
-    is not safe); they idle until the CPU-baseline leg."""
-    _W.update(A=A, Acsc=A.tocsc(), tr_u=tr_u, tr_v=tr_v, tr_l=tr_l, cv=class_values, mnph=mnph)
-    n = max(1, min(os.cpu_count() or 1, 32))
-    try:
-        return mp.get_context('fork').Pool(n), n
-    except (OSError, ValueError):
-        return None, 0
-
-
-def cpu_baseline(pool, n_workers, n_links, adj_dropout, n_rel, mode, budget_s=20.0):
+def cpu_baseline_worker(path):
     """Reference CPU path restated by the oracle (kind='port'), timed on this box's host cores.
-    mode 'dynamic' (reference --dynamic-train): subgraphs extracted on the fly by the worker processes while the main
+    mode 'dynamic' (reference --dynamic-train): subgraphs extracted on the fly by worker processes while the main
     process trains; mode 'static' (BASELINE.json configs[0]): subgraphs pre-extracted (not timed, like the reference's
     cached data.pt), ONE loader worker = collation in the main process."""
     import random
+    import scipy.sparse as ssp
     from oracle import pyg_ref
+    z = np.load(path)
+    A = ssp.csr_matrix((z['A_data'], z['A_indices'], z['A_indptr']), shape=tuple(z['A_shape']))
+    mode, adj_dropout, budget_s = str(z['mode']), float(z['adj_dropout']), float(z['budget_s'])
+    cv = z['class_values']
+    _W.update(A=A, Acsc=A.tocsc(), tr_u=z['tr_u'], tr_v=z['tr_v'], tr_l=z['tr_l'], cv=cv, mnph=int(z['mnph']))
     ncpu = os.cpu_count() or 1
+    n_workers = max(1, min(ncpu // 2, 32)) if mode == 'dynamic' else 0
+    pool = mp.get_context('fork').Pool(n_workers, initializer=_worker_init) if n_workers else None
     torch.manual_seed(1)
     random.seed(1)
-    model = pyg_ref.IGMCRef(4, (32, 32, 32, 32), n_rel, 4, adj_dropout=adj_dropout, fast=False)
+    model = pyg_ref.IGMCRef(4, (32, 32, 32, 32), len(cv), 4, adj_dropout=adj_dropout, fast=False)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    perm = np.random.default_rng(0).permutation(n_links)
+    perm = np.random.default_rng(0).permutation(len(z['tr_u']))
     batches = [perm[i * BATCH:(i + 1) * BATCH] for i in range(60)]
-
-    def extract(idx):
-        return _worker_extract(idx)
     # the reference uses every host core; over-subscription hurts this formulation on many-core hosts, so the
-    # baseline gets the best of a few thread counts (reported in `sample`)
-    b0 = pyg_ref.Batch.from_data_list(extract(batches[0]))
+    # baseline gets the best of a few thread counts, probed on a 10-graph batch
+    probe = pyg_ref.Batch.from_data_list(_worker_extract(batches[0][:10]))
     best, threads = None, 1
     for th in sorted(set([min(8, ncpu), min(16, ncpu), min(32, ncpu), min(64, ncpu)])):
         torch.set_num_threads(th)
+        pyg_ref.train_step(model, opt, probe, ARR=0.001)
         t0 = time.perf_counter()
-        pyg_ref.train_step(model, opt, b0, ARR=0.001)
+        pyg_ref.train_step(model, opt, probe, ARR=0.001)
         el = time.perf_counter() - t0
         if best is None or el < best:
             best, threads = el, th
-        if el > 8.0:
-            break
     torch.set_num_threads(threads)
-    max_steps = int(max(3, min(50, budget_s / max(best, 1e-3))))
+    max_steps = int(max(3, min(50, budget_s / max(best * 5.0, 1e-3))))
     todo = batches[1:1 + max_steps]
     if mode == 'static':
-        graphs = [extract(idx) for idx in todo]                     # pre-extracted: not timed
+        graphs = [_worker_extract(idx) for idx in todo]              # pre-extracted: not timed
         feed = (g for g in graphs)
-    elif pool is not None:
-        feed = pool.imap(_worker_extract, todo, chunksize=1)        # workers run ahead of the training loop
     else:
-        feed = (extract(idx) for idx in todo)
+        feed = pool.imap(_worker_extract, todo, chunksize=1)         # workers run ahead of the training loop
     steps, t1 = 0, time.perf_counter()
     for graphs_b in feed:
         pyg_ref.train_step(model, opt, pyg_ref.Batch.from_data_list(graphs_b), ARR=0.001)
@@ -155,15 +153,36 @@ def cpu_baseline(pool, n_workers, n_links, adj_dropout, n_rel, mode, budget_s=20
         if time.perf_counter() - t1 > budget_s:
             break
     el = time.perf_counter() - t1
-    if mode != 'static' and pool is not None:
+    if pool is not None:
         pool.terminate()
     how = ('static: %d pre-extracted batches (extraction untimed), collate + train step in ONE process' % steps
            if mode == 'static' else
            'dynamic: extraction in %d worker processes (oracle/extract_ref.py) feeding the training process' % n_workers)
-    return dict(value=steps * BATCH / el, unit='subgraphs/s', cores=ncpu if mode != 'static' else threads, kind='port',
-                cpu=cpu_model(), host_cores=ncpu, torch_threads=threads,
-                sample='%d train steps of batch %d in %.1f s; %s; PyG-1.4.2-formulation fwd/bwd + Adam '
-                       '(oracle/pyg_ref.py, torch threads=%d)' % (steps, BATCH, el, how, threads))
+    rec = dict(value=steps * BATCH / el, unit='subgraphs/s', cores=(threads + n_workers), kind='port',
+               cpu=cpu_model(), host_cores=ncpu, torch_threads=threads, extraction_workers=n_workers,
+               sample='%d train steps of batch %d in %.1f s; %s; PyG-1.4.2-formulation fwd/bwd + Adam '
+                      '(oracle/pyg_ref.py, torch threads=%d)' % (steps, BATCH, el, how, threads))
+    print('CPU_BASELINE_JSON ' + json.dumps(rec))
+
+
+def cpu_baseline(A, tr_u, tr_v, tr_l, class_values, mnph, adj_dropout, mode, budget_s=20.0):
+    import subprocess
+    import tempfile
+    A = A.tocsr()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, 'workload.npz')
+        np.savez(path, A_data=A.data, A_indices=A.indices, A_indptr=A.indptr, A_shape=np.asarray(A.shape),
+                 tr_u=np.asarray(tr_u), tr_v=np.asarray(tr_v), tr_l=np.asarray(tr_l),
+                 class_values=np.asarray(class_values, dtype=np.float64), mnph=mnph, adj_dropout=adj_dropout, mode=mode,
+                 budget_s=budget_s)
+        env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', path], env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=budget_s * 8 + 120)
+    for line in r.stdout.decode().splitlines():
+        if line.startswith('CPU_BASELINE_JSON '):
+            return json.loads(line[len('CPU_BASELINE_JSON '):])
+    sys.stderr.write('cpu baseline failed:\n' + r.stderr.decode()[-2000:] + '\n')
+    return None
 
 
 def main():
@@ -177,11 +196,14 @@ def main():
     ap.add_argument('--rmse-links', type=int, default=5000)
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly (no hipGraph replay)')
     ap.add_argument('--no-overlap', action='store_true', help='extract batch t+1 on the same stream (no overlap)')
+    ap.add_argument('--cpu-baseline-worker', default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_worker:
+        return cpu_baseline_worker(args.cpu_baseline_worker)
     cfg = CONFIGS[args.config]
     want_cpu = not args.no_cpu_baseline and int(os.environ.get('WORLD_SIZE', '1')) <= 1
 
-    # ---- workload (identical on every rank; pure numpy, built BEFORE any GPU call)
+    # ---- workload (identical on every rank)
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):       # stdout carries the ONE JSON line only
         if cfg['dataset'] in ('douban', 'flixster', 'yahoo_music'):
@@ -192,12 +214,6 @@ def main():
                                                             verbose=int(os.environ.get('RANK', '0')) == 0)
             source = 'real' if preprocessing._load_real_movielens(cfg['dataset']) is not None else 'synthetic'
     (_, _, A, tr_l, tr_u, tr_v, _, _, _, te_l, te_u, te_v, class_values) = split
-    pool, n_workers = (None, 0)
-    if want_cpu and cfg['cpu'] == 'dynamic':
-        pool, n_workers = start_cpu_workers(A, tr_u, tr_v, tr_l, class_values, cfg['mnph'])
-    elif want_cpu:
-        _W.update(A=A, Acsc=A.tocsc(), tr_u=tr_u, tr_v=tr_v, tr_l=tr_l, cv=class_values, mnph=cfg['mnph'])
-
     rank, world = parallel.init_from_env('nccl')
     if world != args.gpus:
         if rank == 0:
@@ -391,12 +407,7 @@ def main():
 
     cpu = None
     if rank == 0 and want_cpu:
-        try:
-            cpu = cpu_baseline(pool, n_workers, len(tr_u), cfg['adj_dropout'], len(class_values), cfg['cpu'])
-        except MemoryError:
-            cpu = None
-    elif pool is not None:
-        pool.terminate()
+        cpu = cpu_baseline(A, tr_u, tr_v, tr_l, class_values, cfg['mnph'], cfg['adj_dropout'], cfg['cpu'])
     if rank == 0:
         rec = {
             'metric': 'enclosing-subgraphs/sec (train step, batch=50) + test RMSE',

@@ -413,6 +413,8 @@ extern "C" int igmc_batch_set_edge_flags(igmc_batch* b, const uint8_t* h_flags, 
   if (n > b->d.edge_cap) IGMC_FAIL("too many flags");
   HIPCHECK(hipDeviceSynchronize());
   HIPCHECK(hipMemcpy(b->d.eflag, h_flags, (size_t)n, hipMemcpyHostToDevice));
+  igmc_launch_relm_flags(b->d, nullptr);        // the dense block mirrors the keep bits
+  HIPCHECK(hipDeviceSynchronize());
   return 0;
 }
 
@@ -420,7 +422,11 @@ extern "C" int igmc_batch_clear_edge_flags(igmc_batch* b) {
   if (!b) IGMC_FAIL("null batch");
   igmc_batch_info info;
   if (igmc_batch_get_info(b, &info, nullptr)) return 1;
-  if (info.num_edges > 0) HIPCHECK(hipMemset(b->d.eflag, 3, (size_t)info.num_edges));
+  if (info.num_edges > 0) {
+    HIPCHECK(hipMemset(b->d.eflag, 3, (size_t)info.num_edges));
+    igmc_launch_relm_flags(b->d, nullptr);
+    HIPCHECK(hipDeviceSynchronize());
+  }
   return 0;
 }
 
@@ -559,6 +565,14 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   d.gs_ll = nullptr;
   d.gs_ll_stride = N * 32;
   if (d.R <= 5) fail |= M.get(&d.gs_ll, 5 * d.gs_ll_stride);
+  d.g2_ex = nullptr;
+  d.g2_fx = nullptr;
+  d.g2_graphs = 0;
+  d.g2_ex_stride = (size_t)Bc * 2 * 4096;
+  if (d.R <= 5 && n_side == 0 && Bc <= 2048) {      // exchange buffers of the matrix-core subgraph kernel: 320 KB per slot
+    fail |= M.get(&d.g2_ex, 5 * d.g2_ex_stride) | M.get(&d.g2_fx, Bc * 256);
+    d.g2_graphs = (int)Bc;
+  }
   fail |= M.get(&d.gs_bar, 2 * Bc + 1);
   fail |= M.get(&d.gs_ts, 4);
   d.gs_err = d.gs_bar ? d.gs_bar + 2 * Bc : nullptr;
@@ -597,6 +611,10 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
     HIPCHECK(hipMemcpy(m->d.gs_ts, ts0, sizeof(ts0), hipMemcpyHostToDevice));
   }
   if (m->d.gs_ll) HIPCHECK(hipMemset(m->d.gs_ll, 0, 5 * m->d.gs_ll_stride * sizeof(unsigned long long)));   // tag 0 = never valid
+  if (m->d.g2_ex) {
+    HIPCHECK(hipMemset(m->d.g2_ex, 0, 5 * m->d.g2_ex_stride * sizeof(unsigned long long)));
+    HIPCHECK(hipMemset(m->d.g2_fx, 0, (size_t)max_graphs * 256 * sizeof(unsigned long long)));
+  }
   if (igmc_model_prepare(d)) {
     M.release();
     delete m;

@@ -746,8 +746,33 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_edge_flags(BatchDev b, float p, 
       const int kf = igmc_u01(igmc_edge_hash(seed, step, gr, u, v, dirF)) >= p;
       const int kt = igmc_u01(igmc_edge_hash(seed, step, gr, u, v, dirT)) >= p;
       b.eflag[e] = (uint8_t)(kf | (kt << 1));
+      if (b.relm && row_user) {      // the dense block carries the same two bits (graphstep2.hip builds its masks from it)
+        const int nb = b.node_off[gr];
+        uint8_t* q = b.relm + ((size_t)gr * b.cap_u + (size_t)(i - nb)) * b.relm_ld + ((int)(b.ecr[e] & 0xFFFFFFu) - nb - b.n_users[gr]);
+        *q = (uint8_t)((*q & 7) | (kf << 3) | (kt << 4));
+      }
     }
   }
+}
+
+// keep bits of the dense block from the per-entry flags (after flags were injected / cleared through the C ABI)
+__global__ __launch_bounds__(IGMC_BLOCK) void k_relm_flags(BatchDev b) {
+  const int N = b.totals[0];
+  const int grp = (blockIdx.x * IGMC_BLOCK + threadIdx.x) >> 4, t = threadIdx.x & 15;
+  const int ngrp = (gridDim.x * IGMC_BLOCK) >> 4;
+  for (int i = grp; i < N; i += ngrp) {
+    if (b.node_label[i] & 1) continue;              // user rows only: they hold both directions of every edge
+    const int gr = b.node_graph[i], nb = b.node_off[gr];
+    uint8_t* row = b.relm + ((size_t)gr * b.cap_u + (size_t)(i - nb)) * b.relm_ld - nb - b.n_users[gr];
+    for (int e = b.row_ptr[i] + t; e < b.row_ptr[i + 1]; e += 16) {
+      uint8_t* q = row + (int)(b.ecr[e] & 0xFFFFFFu);
+      *q = (uint8_t)((*q & 7) | ((b.eflag[e] & 3) << 3));
+    }
+  }
+}
+
+void igmc_launch_relm_flags(const BatchDev& b, void* stream) {
+  if (b.relm) IGMC_PLAUNCH("k_relm_flags", k_relm_flags, 256, IGMC_BLOCK, 0, stream, b);
 }
 
 // ---------------------------------------------------------------- side features of the target nodes

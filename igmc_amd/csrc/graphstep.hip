@@ -1339,6 +1339,7 @@ void igmc_launch_graph_step(const ModelDev& m, const BatchDev& b, const float* P
 
 // dynamic LDS above 64 KB needs an explicit opt-in on HIP
 int igmc_gs_prepare() {
+  if (igmc_g2_prepare()) return 1;
 #ifndef IGMC_HIPEMU
   const int mx = 160 * 1024;
   if (hipFuncSetAttribute((const void*)k_graph_step<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;

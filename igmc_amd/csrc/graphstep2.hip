@@ -1,0 +1,994 @@
+// graphstep2.hip -- forward + loss + backward of one enclosing subgraph by a cluster of workgroups, with the
+// relational message passing on the MATRIX CORES (gfx950 / CDNA4).
+//
+// Capped extraction leaves the induced block of every subgraph as a dense byte matrix relm[user][item] = relation + 1
+// (extract.hip: k_relm).  With at most 128 nodes per side the per-relation aggregate of a 16-row bundle
+//     T_r[i] = sum_{j : rel(i,j) = r, edge j -> i kept} x[j]          (reference models.py:199-202 -> PyG RGCNConv, aggr = add)
+// is the dense product  T_r = A_r X  with A_r the 16 x K 0/1 block of relation r:  A_r is EXACT in bf16 and X splits
+// into three bf16 terms (hi + mid + lo = x to 24 bits; every product 1.0 * bf16 is exact and the sums are f32), so the
+// gather runs as v_mfma_f32_16x16x32_bf16 at f32 accuracy: 5 relations x 4 k-steps x 3 terms x 2 feature tiles = 120
+// MFMAs (~2 k cycles) per bundle and layer pass instead of ~11 k cycles of LDS row gathers (graphstep.hip).
+//
+//  * the A fragments of a wave's bundle are built ONCE per launch from relm (8 bytes -> 8 bf16 per relation with a
+//    handful of bit tricks) and stay in registers for all six layer passes;
+//  * the gather is computed TRANSPOSED, T^T = X^T A^T (A operand = 16-byte reads of the bf16 planes [term][feature]
+//    [node], B operand = the A_r fragments): its accumulators (lane = row, 4 consecutive features) are then directly
+//    the A operand of the dense transform  out = [T_0..T_4 | x] @ [W_0; ..; W_4; root]  (f32 MFMA, k permuted the
+//    same way on the weight side) -- no tile round trip through LDS in the forward;
+//  * the transform's output layout (lane = feature, 4 consecutive rows) is node-contiguous: the bf16 terms of the
+//    next layer's planes are formed in registers and published as 8-byte {hi, mid, lo, tag} words, four nodes = two
+//    16-byte stores per lane and feature tile;
+//  * bundles are SIDE-PURE (16 consecutive user rows or 16 consecutive item rows) and statically owned by one wave of
+//    the cluster for the whole launch: user bundles only ever need the item planes and vice versa, a wave re-reads only
+//    rows it produced itself (h_l for the backward), and no degree ranking / schedule / run lists exist any more --
+//    every bundle costs the same.
+//
+// Cluster exchange: flag-in-data as in graphstep.hip (sc1 stores / loads, 8-byte single-copy atomic words), but only
+// the opposite side's rows travel, as bf16 terms (8 B per value incl. the tag, 32 KB per workgroup and exchange instead
+// of 52 KB) and in plane order, so the reader's 16-byte load = two nodes of one feature = three LDS dword writes.
+// dPre_3 is non-zero on the two target rows only and is rebuilt locally from the head's d feat: 5 exchanges per launch
+// (h_0, h_1, h_2, dPre_2, dPre_1) + the 256-float centre-node readout.
+//
+// Eligibility (else graphstep.hip / the per-layer kernels run): dense block present, R <= 5, layer-0 table <= 32 rows,
+// no side features, both sides <= 16 * (2 * cluster size) <= 128 rows.
+#include "launch.h"
+#include <stdlib.h>
+#include <stdio.h>
+
+#define G2_THREADS 256
+#define G2_NW 4
+#define G2_NR 5                   // relations the fragments are built for (R <= G2_NR)
+#define G2_KS 4                   // k-steps of 32 opposite-side nodes (K <= 128)
+#define G2_NT 3                   // bf16 terms of an f32 value
+#define G2_TP (G2_NR * 32 + 4)    // pitch of a wave's 16-row T' tile (backward)
+#define G2_XP 36                  // pitch of a wave's 16-row x / dPre / h tile
+#define G2_FXTAG 7                // exchange index of the centre-node readout
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifndef IGMC_HIPEMU
+typedef __bf16 g2_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 g2_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float g2_f32x2 __attribute__((ext_vector_type(2)));
+#endif
+
+__device__ __forceinline__ f32x4 g2_mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+#ifdef IGMC_HIPEMU
+  return igmc_emu_mfma_16x16x32_bf16(a, b, c);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(g2_bf16x8, a), __builtin_bit_cast(g2_bf16x8, b), c, 0, 0, 0);
+#endif
+}
+
+// {bf16(x) | bf16(y) << 16}, round to nearest even (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t g2_pk_bf16(float x, float y) {
+#ifdef IGMC_HIPEMU
+  return hipemu_f32_to_bf16_rne(x) | (hipemu_f32_to_bf16_rne(y) << 16);
+#else
+  g2_f32x2 v = {x, y};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, g2_bf16x2));
+#endif
+}
+// the three bf16 terms of two f32 values: hi + mid + lo == x to 24 bits (each residual is exact in f32)
+__device__ __forceinline__ void g2_split2(float x, float y, uint32_t& h, uint32_t& mi, uint32_t& lo) {
+  h = g2_pk_bf16(x, y);
+  const float rx = x - __uint_as_float(h << 16), ry = y - __uint_as_float(h & 0xFFFF0000u);
+  mi = g2_pk_bf16(rx, ry);
+  const float sx = rx - __uint_as_float(mi << 16), sy = ry - __uint_as_float(mi & 0xFFFF0000u);
+  lo = g2_pk_bf16(sx, sy);
+}
+
+// four relm bytes (bits 0..2: relation + 1, bit 3 / 4: keep flags of the two directions) -> two dwords of bf16 pairs
+// that are 1.0 where the byte's relation is r1 - 1 (and its keep bit is set)
+template <bool FLAGS>
+__device__ __forceinline__ void g2_expand4(uint32_t w, uint32_t r1, int keepbit, uint32_t& o01, uint32_t& o23) {
+  uint32_t mk = w & 0x07070707u;
+  if (FLAGS) mk &= ((w >> keepbit) & 0x01010101u) * 7u;
+  const uint32_t t = mk ^ (0x01010101u * r1);
+  const uint32_t eq = ~(t + 0x7F7F7F7Fu) & 0x80808080u;        // bit 7 of a byte set <=> the byte of t is zero (t <= 7)
+  const uint32_t mask = (eq >> 7) * 0xFFu;                      // 0xFF per matching byte
+#ifdef IGMC_HIPEMU
+  o01 = ((mask & 0xFFu) ? 0x3F80u : 0u) | ((mask & 0xFF00u) ? 0x3F800000u : 0u);
+  o23 = ((mask & 0xFF0000u) ? 0x3F80u : 0u) | ((mask & 0xFF000000u) ? 0x3F800000u : 0u);
+#else
+  o01 = __builtin_amdgcn_perm(mask, mask, 0x01010000u) & 0x3F803F80u;    // bytes [b0 b0 b1 b1]
+  o23 = __builtin_amdgcn_perm(mask, mask, 0x03030202u) & 0x3F803F80u;    // bytes [b2 b2 b3 b3]
+#endif
+}
+
+__device__ __forceinline__ float g2_tanh(float x) {
+#ifdef IGMC_HIPEMU
+  return tanhf(x);
+#else
+  return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x));
+#endif
+}
+
+// ---- exchange words ------------------------------------------------------------------------------------------------
+// plane word of one value: {hi | mid << 16, lo | tag << 16}; two nodes of one feature per 16-byte access
+__device__ __forceinline__ void g2_store16(unsigned long long* p, uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+#ifndef IGMC_HIPEMU
+  u32x4 v = {x, y, z, w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+#else
+  p[0] = ((unsigned long long)y << 32) | x;
+  p[1] = ((unsigned long long)w << 32) | z;
+#endif
+}
+__device__ __forceinline__ void g2_pub_f32(unsigned long long* p, float v, uint32_t tag) {
+#ifndef IGMC_HIPEMU
+  __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+#else
+  uint32_t bits;
+  memcpy(&bits, &v, 4);
+  *p = ((unsigned long long)tag << 32) | (unsigned long long)bits;
+#endif
+}
+
+// The planes [term][feature][node] of one side from its exchange region ex[feature][KMAX nodes]: nodes < npad (a
+// multiple of 16, <= 128) of all 32 features = 16 * npad word pairs, <= 8 per thread; every pending request of a thread
+// is in flight before the single wait, pairs whose tags are not this exchange's are requested again.
+__device__ __forceinline__ void g2_reload(uint32_t* pl, int kp, const unsigned long long* ex, int npad, uint32_t tag16,
+                                          int* err) {
+  const int hp = npad >> 1, total = 32 * hp, t0 = (int)threadIdx.x;      // pairs per feature, pairs in all
+#ifndef IGMC_HIPEMU
+  uint32_t pend = 0;
+  const u32x4* gp[8];
+  int dst[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int p = t0 + u * G2_THREADS;
+    const int f = (p < total) ? p / hp : 0, q = (p < total) ? p - f * hp : 0;
+    gp[u] = (const u32x4*)(ex + f * 128 + 2 * q);
+    dst[u] = (f * kp >> 1) + q;                    // dword index inside a term's plane
+    pend |= (p < total) ? (1u << u) : 0u;
+  }
+  u32x4 v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, v7 = 0;
+  const int tstride = 32 * kp >> 1;                // dwords per term
+#define G2_LD(V, U) \
+  if (pend & (1u << (U))) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(V) : "v"(gp[U]) : "memory");
+#define G2_CK(V, U)                                                                          \
+  if ((pend & (1u << (U))) && (V.y >> 16) == tag16 && (V.w >> 16) == tag16) {                \
+    pl[dst[U]] = (V.x & 0xFFFFu) | (V.z << 16);                                              \
+    pl[tstride + dst[U]] = (V.x >> 16) | (V.z & 0xFFFF0000u);                                \
+    pl[2 * tstride + dst[U]] = (V.y & 0xFFFFu) | (V.w << 16);                                \
+    pend &= ~(1u << (U));                                                                    \
+  }
+  for (int it = 0;; ++it) {
+    G2_LD(v0, 0) G2_LD(v1, 1) G2_LD(v2, 2) G2_LD(v3, 3) G2_LD(v4, 4) G2_LD(v5, 5) G2_LD(v6, 6) G2_LD(v7, 7)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : : "memory");
+    G2_CK(v0, 0) G2_CK(v1, 1) G2_CK(v2, 2) G2_CK(v3, 3) G2_CK(v4, 4) G2_CK(v5, 5) G2_CK(v6, 6) G2_CK(v7, 7)
+    if (!pend) break;
+    if (it > (1 << 20)) {
+      *err = 1;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+#undef G2_LD
+#undef G2_CK
+#else
+  const int tstride = 32 * kp >> 1;
+  for (int p = t0; p < total; p += G2_THREADS) {
+    const int f = p / hp, q = p - f * hp;
+    const unsigned long long* e = ex + f * 128 + 2 * q;
+    long spins = 0;
+    for (;;) {
+      const unsigned long long a = e[0], b2 = e[1];
+      if ((uint32_t)(a >> 48) == tag16 && (uint32_t)(b2 >> 48) == tag16) {
+        const uint32_t ax = (uint32_t)a, ay = (uint32_t)(a >> 32), bx = (uint32_t)b2, by = (uint32_t)(b2 >> 32);
+        const int d = (f * kp >> 1) + q;
+        pl[d] = (ax & 0xFFFFu) | (bx << 16);
+        pl[tstride + d] = (ax >> 16) | (bx & 0xFFFF0000u);
+        pl[2 * tstride + d] = (ay & 0xFFFFu) | (by << 16);
+        break;
+      }
+      if (++spins > (1L << 22)) {
+        *err = 1;
+        break;
+      }
+      hipemu::yield();
+    }
+  }
+#endif
+}
+
+// one 8-byte {f32, tag} word, polled
+__device__ __forceinline__ float g2_poll_f32(const unsigned long long* p, uint32_t tag, int* err) {
+  for (long it = 0;; ++it) {
+#ifndef IGMC_HIPEMU
+    const unsigned long long w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    const unsigned long long w = *p;
+#endif
+    if ((uint32_t)(w >> 32) == tag) return __uint_as_float((uint32_t)w);
+    if (it > (1L << 22)) {
+      *err = 1;
+      return 0.f;
+    }
+#ifndef IGMC_HIPEMU
+    __builtin_amdgcn_s_sleep(2);
+#else
+    hipemu::yield();
+#endif
+  }
+}
+
+// ---- the relation-space aggregate of one bundle on the matrix cores: acc[r][t] (lane = row, regs = features
+//      16 t + 4 (lane >> 4) + 0..3) = sum over the opposite side's nodes of A_r[row][node] * x[node][feature]
+__device__ __forceinline__ void g2_gather(const uint32_t* pl, int kp, int nks, int R, const uint32_t (&A)[G2_NR][G2_KS][4],
+                                          int li, int kq, f32x4 (&acc)[G2_NR][2]) {
+#pragma unroll
+  for (int r = 0; r < G2_NR; ++r) {
+    acc[r][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const int tstride = 32 * kp >> 1;            // dwords per term
+#pragma unroll
+  for (int s = 0; s < G2_KS; ++s) {
+    if (s < nks) {
+#pragma unroll
+      for (int sp = 0; sp < G2_NT; ++sp) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const u32x4 pf = *(const u32x4*)(pl + sp * tstride + ((16 * t + li) * kp >> 1) + 16 * s + 4 * kq);
+#pragma unroll
+          for (int r = 0; r < G2_NR; ++r) {
+            if (r < R) {
+              const u32x4 af = {A[r][s][0], A[r][s][1], A[r][s][2], A[r][s][3]};
+              acc[r][t] = g2_mfma_bf16(pf, af, acc[r][t]);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// out (lane = output feature 16 nt + li, regs = rows 4 kq + 0..3) = [T_0..T_4 | x] @ sW2: the gather's accumulators are
+// the A operand as they are (k-step (r, t, rr) covers the input features 16 t + 4 kq' + rr, kq' = 0..3, of relation r);
+// x = the bundle's own rows, read from its LDS tile.  sW2[k][16] float2: element (k, n) at [k][n & 15].{x: n < 16, y: n >= 16}.
+__device__ __forceinline__ void g2_transform(const f32x4 (&acc)[G2_NR][2], int R, const float* xrows, const float2* sW2,
+                                             int li, int kq, f32x4 (&o)[2]) {
+  f32x4 o0a = (f32x4){0.f, 0.f, 0.f, 0.f}, o0b = o0a, o1a = o0a, o1b = o0a;
+#pragma unroll
+  for (int r = 0; r < G2_NR; ++r) {
+    if (r < R) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float2 bv[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) bv[rr] = sW2[(r * 32 + 16 * t + 4 * kq + rr) * 16 + li];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const float av = acc[r][t][rr];
+          if (rr & 1) {
+            o0b = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[rr].x, o0b, 0, 0, 0);
+            o1b = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[rr].y, o1b, 0, 0, 0);
+          } else {
+            o0a = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[rr].x, o0a, 0, 0, 0);
+            o1a = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[rr].y, o1a, 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  {
+    float av[8];
+    float2 bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      av[j] = xrows[li * G2_XP + 4 * j + kq];
+      bv[j] = sW2[(G2_NR * 32 + 4 * j + kq) * 16 + li];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j & 1) {
+        o0b = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j].x, o0b, 0, 0, 0);
+        o1b = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j].y, o1b, 0, 0, 0);
+      } else {
+        o0a = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j].x, o0a, 0, 0, 0);
+        o1a = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j].y, o1a, 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    o[0][rr] = o0a[rr] + o0b[rr];
+    o[1][rr] = o1a[rr] + o1b[rr];
+  }
+}
+
+// the four rows 4 kq .. 4 kq + 3 of output feature f as exchange words: two 16-byte stores
+__device__ __forceinline__ void g2_publish4(unsigned long long* exf, int node0, const float (&v)[4], uint32_t tag16) {
+  uint32_t h0, m0, l0, h1, m1, l1;
+  g2_split2(v[0], v[1], h0, m0, l0);
+  g2_split2(v[2], v[3], h1, m1, l1);
+  const uint32_t tg = tag16 << 16;
+  g2_store16(exf + node0, (h0 & 0xFFFFu) | (m0 << 16), (l0 & 0xFFFFu) | tg, (h0 >> 16) | (m0 & 0xFFFF0000u), (l0 >> 16) | tg);
+  g2_store16(exf + node0 + 2, (h1 & 0xFFFFu) | (m1 << 16), (l1 & 0xFFFFu) | tg, (h1 >> 16) | (m1 & 0xFFFF0000u), (l1 >> 16) | tg);
+}
+
+template <bool FLAGS, bool TRAIN>
+__global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev m, const float* P, GsArgs a) {
+  IGMC_DYN_SMEM(smem);
+  float* S = (float*)smem;
+  const G2Layout lay = a.lay2;
+  const int kp = lay.kp, nsides = lay.nsides;
+  uint32_t* PLN = (uint32_t*)(S + lay.planes);          // [nsides][3 terms][32 features][kp] bf16: gather source
+  uint32_t* OHP = (uint32_t*)(S + lay.ohp);             // [nsides][8 labels][kp] bf16 one-hot label planes (layer 0)
+  unsigned char* RM = (unsigned char*)(S + lay.tile);   // [nsides][rmr][rmc] bytes: relm in the orientation of the side's
+                                                        // rows (set-up only: aliases the backward's T' tiles)
+  unsigned char* slab = (unsigned char*)(S + lay.lab);  // [2][128] node labels of both sides
+  float* XOA = S + lay.xo;                              // [2][4 waves][16][G2_XP]: the bundle's own rows of x / dPre
+  float* HSS = S + lay.hs;                              // [4][16][G2_XP] h_{l-1} rows of the bundle (backward)
+  float* TILES = S + lay.tile;                          // [4][16][G2_TP] T' rows of the bundle (backward)
+  float* HIST = S + lay.hist;                           // [4][16][G2_XP] layer-0 input [code histogram | onehot | 1]
+  float2* sW2 = (float2*)(S + lay.wreg);                // [192][16] B operand of the layer
+  float* sT0 = S + lay.t0;                              // [32][32] layer-0 table
+  float* s_att = S + lay.att;
+  float* sfeat = S + lay.head;            // [256] centre-node readout
+  float* sgf = sfeat + 256;               // [256] d feat
+  float* sa1 = sgf + 256;                 // [128]
+  float* skeep = sa1 + 128;               // [128]
+  float* sdz = skeep + 128;               // [128]
+  float* sred = sdz + 128;                // [256]
+  float* misc = sred + 256;               // [16]
+  const int R = m.R, L = m.L, RL = R * L, LF = L * 32, na = R * 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int B = b.totals[3];
+  const int ts = m.ts_stride;
+  const int cs = a.cs;
+  const int cm = (cs > 1) ? blockIdx.x / a.stride : 0;
+  const int half = 2 * cs;                              // waves of the cluster per side
+  const int gw = cm * G2_NW + wave;
+  const int side = gw / half, bi = gw - side * half;    // this wave's side (0 users, 1 items) and bundle of that side
+  const int rmr = lay.rmr, rmc = lay.rmc;
+#ifndef IGMC_HIPEMU
+  const uint32_t seq = (uint32_t)__hip_atomic_load(m.gs_bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  const uint32_t seq = (uint32_t)m.gs_bar[1];
+#endif
+  const uint32_t tag0 = seq * 8u + 1u;
+  const uint64_t step = m.ctrl ? (uint64_t)m.ctrl[IGMC_CTRL_STEP] : a.step;
+#ifndef IGMC_HIPEMU
+  if (a.ts && tid == 0) atomicMin(a.ts, (unsigned long long)wall_clock64());
+#endif
+  auto tag16 = [&](int x) { return 1u + (tag0 + (uint32_t)x) % 65535u; };
+
+  // ---- layer-0 table, staged once per workgroup
+  for (int i = tid; i < 1024; i += G2_THREADS) {
+    const int c = i >> 5, f = i & 31;
+    float s = 0.f;
+    if (c < RL) {
+      const int r = c / L, cf = (c % L) * 32 + f;
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) s += P[m.off_att[0] + r * 4 + bb] * P[m.off_basis[0] + bb * LF + cf];
+    } else if (c < RL + L) {
+      s = P[m.off_root[0] + (c - RL) * 32 + f];
+    } else if (c == RL + L) {
+      s = P[m.off_bias[0] + f];
+    }
+    sT0[i] = s;
+  }
+  f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};        // layer-0 table gradient tile (code half, feature half) of this wave
+  bool first_graph = true;
+
+#pragma unroll 1
+  for (int g = (cs > 1) ? (int)(blockIdx.x % a.stride) : (int)blockIdx.x; g < B; g += (cs > 1) ? B : (int)gridDim.x) {
+    const int nb = b.node_off[g];
+    const int N = b.node_off[g + 1] - nb;
+    const int cu = b.n_users[g], cv = N - cu;
+    const int n_own = side ? cv : cu, n_opp = side ? cu : cv;
+    const int nbs = nb + (side ? cu : 0);                    // first node of this wave's side
+    const int nbun = (n_own + 15) >> 4;
+    const bool active = bi < nbun;
+    const int row0 = 16 * bi;
+    const int nks = (n_opp + 31) >> 5;
+    const int sx = (nsides == 2) ? side : 0, so = (nsides == 2) ? 1 - side : 0;    // LDS images of own / opposite side
+    uint32_t* pl = PLN + so * (G2_NT * 32 * kp >> 1);
+    uint32_t* ohp = OHP + so * (8 * kp >> 1);
+    float* XO0 = XOA + wave * 16 * G2_XP;                     // ping
+    float* XO1 = XOA + (G2_NW + wave) * 16 * G2_XP;           // pong
+    float* HS = HSS + wave * 16 * G2_XP;
+    float* T = TILES + wave * 16 * G2_TP;
+    float* HI = HIST + wave * 16 * G2_XP;
+    // exchange regions of this subgraph: [exchange x][g][side][32 features][128 nodes]
+    unsigned long long* ex_own = m.g2_ex + ((size_t)g * 2 + side) * 4096;
+    const unsigned long long* ex_opp = m.g2_ex + ((size_t)g * 2 + (1 - side)) * 4096;
+    const size_t exs = m.g2_ex_stride;
+    unsigned long long* fx = m.g2_fx + (size_t)g * 256;
+
+    // ---- every 4096 launches the owner of a node range clears it in all exchange buffers: a 16-bit tag then never
+    //      meets a word older than 4096 launches (tags repeat after 8191)
+    if ((seq & 4095u) == 0u) {
+      for (int bb2 = bi; bb2 < 8; bb2 += half)
+        for (int x = 0; x < 5; ++x) {
+          unsigned long long* e = m.g2_ex + x * exs + ((size_t)g * 2 + side) * 4096 + 16 * bb2;
+          for (int i = lane; i < 32 * 8; i += 64) g2_store16(e + (i >> 3) * 128 + 2 * (i & 7), 0u, 0u, 0u, 0u);
+        }
+#ifndef IGMC_HIPEMU
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    }
+    // ---- set-up: labels, relm in the orientation of this workgroup's side(s), one-hot label planes, zeroed planes
+    for (int i = tid; i < 256; i += G2_THREADS) {
+      const int sd = i >> 7, k = i & 127;
+      const int n_sd = sd ? cv : cu;
+      slab[i] = (k < n_sd) ? b.node_label[nb + (sd ? cu : 0) + k] : (unsigned char)255;
+    }
+    for (int i = tid; i < nsides * (G2_NT * 32 * kp >> 1); i += G2_THREADS) PLN[i] = 0u;
+    for (int i = tid; i < nsides * (rmr * rmc >> 2); i += G2_THREADS) ((uint32_t*)RM)[i] = 0u;
+    for (int i = tid; i < 2 * G2_NW * 16 * G2_XP; i += G2_THREADS) XOA[i] = 0.f;
+    for (int i = tid; i < G2_NW * 16 * G2_XP; i += G2_THREADS) HIST[i] = 0.f;
+    __syncthreads();
+    {
+      const int ld = b.relm_ld;
+      const unsigned char* rm = b.relm + (size_t)g * b.cap_u * ld;
+      const int ldw = ld >> 2, nw = cu * ldw;
+      for (int i = tid; i < nw; i += G2_THREADS) {
+        const int u = i / ldw, c4 = (i - u * ldw) * 4;
+        const uint32_t w = ((const uint32_t*)rm)[i];
+        if (nsides == 2 || side == 0) {             // rows = users
+          if (c4 < rmc) *(uint32_t*)(RM + (size_t)u * rmc + c4) = w;
+        }
+        if (nsides == 2 || side == 1) {             // rows = items: the transposed copy
+          unsigned char* rt = RM + (size_t)((nsides == 2) ? 1 : 0) * rmr * rmc;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (c4 + q < cv) rt[(size_t)(c4 + q) * rmc + u] = (unsigned char)(w >> (8 * q));
+        }
+      }
+      // one-hot planes of the labels of the opposite side(s): plane[label][node] = 1.0 (bf16)
+      for (int i = tid; i < nsides * 8 * (kp >> 1); i += G2_THREADS) {
+        const int s2 = i / (8 * (kp >> 1)), rem = i - s2 * (8 * (kp >> 1));
+        const int lb = rem / (kp >> 1), q = rem - lb * (kp >> 1);
+        const int sd = (nsides == 2) ? s2 : 1 - side;        // the side whose labels this image holds
+        const int l0 = (2 * q < 128) ? slab[sd * 128 + 2 * q] : 255, l1 = (2 * q + 1 < 128) ? slab[sd * 128 + 2 * q + 1] : 255;
+        OHP[i] = ((l0 == lb) ? 0x3F80u : 0u) | ((l1 == lb) ? 0x3F800000u : 0u);
+      }
+    }
+    __syncthreads();
+    // ---- A fragments of this wave's bundle: A[r][s] = the 16 x 32 block (rows of the bundle) x (opposite nodes 32 s ..)
+    //      of relation r as the MFMA B operand of the transposed gather; forward and (with edge dropout) backward masks
+    uint32_t AF[G2_NR][G2_KS][4];
+    uint32_t AB[FLAGS ? G2_NR : 1][FLAGS ? G2_KS : 1][4];
+    {
+      const unsigned char* rmo = RM + (size_t)sx * rmr * rmc + (size_t)(row0 + li) * rmc;
+      const int kf = side ? 4 : 3, kb = side ? 3 : 4;     // keep bit of the edge  opposite -> own  /  own -> opposite
+#pragma unroll
+      for (int s = 0; s < G2_KS; ++s) {
+        uint32_t w0 = 0u, w1 = 0u;
+        if (active && s < nks && 32 * s + 8 * kq < rmc) {
+          const uint2 w = *(const uint2*)(rmo + 32 * s + 8 * kq);
+          w0 = w.x;
+          w1 = w.y;
+        }
+#pragma unroll
+        for (int r = 0; r < G2_NR; ++r) {
+          g2_expand4<FLAGS>(w0, (uint32_t)(r + 1), kf, AF[r][s][0], AF[r][s][1]);
+          g2_expand4<FLAGS>(w1, (uint32_t)(r + 1), kf, AF[r][s][2], AF[r][s][3]);
+          if constexpr (FLAGS) {
+            g2_expand4<true>(w0, (uint32_t)(r + 1), kb, AB[r][s][0], AB[r][s][1]);
+            g2_expand4<true>(w1, (uint32_t)(r + 1), kb, AB[r][s][2], AB[r][s][3]);
+          }
+        }
+      }
+    }
+    __syncthreads();                    // RM is dead from here on (its bytes are the backward's tiles)
+
+    // weights of the NEXT conv layer to be staged: requested a phase ahead
+    float4 wb4[4], wr4;
+    float watt = 0.f;
+    auto wpre = [&](int l) {
+      const float* basis = P + m.off_basis[l];
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) wb4[bb] = *(const float4*)(basis + bb * 1024 + 4 * tid);
+      wr4 = *(const float4*)(P + m.off_root[l] + 4 * tid);
+      if (tid < na) watt = P[m.off_att[l] + tid];
+    };
+    wpre(1);
+    // B operand of a layer: [W_0; ..; W_R-1; 0..; root] (TRANS: their transposes), W_r = sum_b att[r,b] basis_b
+    auto stage = [&](bool trans) {
+      if (tid < na) s_att[tid] = watt;
+      const float4 (&b4)[4] = wb4;
+      const float4 r4 = wr4;
+      __syncthreads();
+      float* sW = (float*)sW2;
+      const int f = tid >> 3, n0 = (4 * tid) & 31;      // W_r[f][n0 .. n0 + 3]
+#pragma unroll
+      for (int r = 0; r <= G2_NR; ++r) {
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r == G2_NR) {
+          v[0] = r4.x; v[1] = r4.y; v[2] = r4.z; v[3] = r4.w;
+        } else if (r < R) {
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) {
+            const float at = s_att[r * 4 + bb];
+            v[0] += at * b4[bb].x; v[1] += at * b4[bb].y; v[2] += at * b4[bb].z; v[3] += at * b4[bb].w;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (!trans) sW[((r * 32 + f) * 16 + ((n0 + q) & 15)) * 2 + ((n0 + q) >> 4)] = v[q];     // (k = f, n = n0 + q)
+          else sW[((r * 32 + n0 + q) * 16 + (f & 15)) * 2 + (f >> 4)] = v[q];                     // (k = n0 + q, n = f)
+        }
+      }
+    };
+    // epilogue of a forward layer: tanh, own rows -> LDS tile + h_l (this wave re-reads them in the backward),
+    // bf16 terms -> exchange x (l < 3), centre rows -> readout
+    auto fwd_out = [&](int l, const f32x4 (&o)[2], float bias0, float bias1, float* XO) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int f = 16 * nt + li;
+        float v[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int row = 4 * kq + rr;
+          v[rr] = (row0 + row < n_own) ? g2_tanh(o[nt][rr] + (nt ? bias1 : bias0)) : 0.f;
+          XO[row * G2_XP + f] = v[rr];
+          if (TRAIN && row0 + row < n_own) m.h[l][(size_t)(nbs + row0 + row) * 32 + f] = v[rr];
+        }
+        if (l < 3) g2_publish4(m.g2_ex + l * exs + ((size_t)g * 2 + side) * 4096 + f * 128, row0 + 4 * kq, v, tag16(l));
+        if (bi == 0 && kq == 0) g2_pub_f32(fx + side * 128 + l * 32 + f, v[0], tag0 + G2_FXTAG);
+      }
+    };
+
+    // ================================================================ layer 0: h0 = tanh([hist | onehot(label) | 1] @ T0)
+    if (active) {
+      // code histogram of the bundle's rows on the matrix cores: hist_r^T (labels x rows) = onehot^T A_r^T
+      f32x4 hacc[G2_NR];
+#pragma unroll
+      for (int r = 0; r < G2_NR; ++r) hacc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < G2_KS; ++s) {
+        if (s < nks) {
+          u32x4 pf = {0u, 0u, 0u, 0u};
+          if (li < 8) pf = *(const u32x4*)(ohp + (li * kp >> 1) + 16 * s + 4 * kq);
+#pragma unroll
+          for (int r = 0; r < G2_NR; ++r) {
+            if (r < R) {
+              const u32x4 af = {AF[r][s][0], AF[r][s][1], AF[r][s][2], AF[r][s][3]};
+              hacc[r] = g2_mfma_bf16(pf, af, hacc[r]);
+            }
+          }
+        }
+      }
+      // lane (row li, kq): counts of labels 4 kq + rr -> the row's input vector [hist | onehot(own label) | 1]
+#pragma unroll
+      for (int r = 0; r < G2_NR; ++r)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          if (r < R && 4 * kq + rr < L) HI[li * G2_XP + r * L + 4 * kq + rr] = hacc[r][rr];
+      if (kq == 0 && row0 + li < n_own) {
+        HI[li * G2_XP + RL + slab[side * 128 + row0 + li]] = 1.f;
+        HI[li * G2_XP + RL + L] = 1.f;
+      }
+      IGMC_WAVE_SYNC();
+      f32x4 o[2];
+      o[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      o[1] = o[0];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float av = HI[li * G2_XP + 4 * j + kq];
+        o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sT0[(4 * j + kq) * 32 + li], o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sT0[(4 * j + kq) * 32 + 16 + li], o[1], 0, 0, 0);
+      }
+      fwd_out(0, o, 0.f, 0.f, XO0);
+    }
+
+    // ================================================================ conv layers 1..3, forward
+#pragma unroll 1
+    for (int l = 1; l < 4; ++l) {
+      float* XOc = (l & 1) ? XO0 : XO1;             // x of the bundle's own rows (h_{l-1})
+      float* XOn = (l & 1) ? XO1 : XO0;             // h_l
+      stage(false);
+      const float bias0 = P[m.off_bias[l] + li], bias1 = P[m.off_bias[l] + 16 + li];
+      // the opposite side's h_{l-1} as bf16 planes
+      for (int s2 = 0; s2 < nsides; ++s2) {
+        const int sd = (nsides == 2) ? s2 : 1 - side;
+        const int n_sd = sd ? cv : cu;
+        g2_reload(PLN + s2 * (G2_NT * 32 * kp >> 1), kp, m.g2_ex + (l - 1) * exs + ((size_t)g * 2 + sd) * 4096,
+                  ((n_sd + 15) >> 4) << 4, tag16(l - 1), m.gs_err);
+      }
+      __syncthreads();
+      if (l < 3) wpre(l + 1);
+      if (active) {
+        f32x4 acc[G2_NR][2];
+        g2_gather(pl, kp, nks, R, AF, li, kq, acc);
+        f32x4 o[2];
+        g2_transform(acc, R, XOc, sW2, li, kq, o);
+        fwd_out(l, o, bias0, bias1, XOn);
+      }
+      __syncthreads();                              // planes / sW2 may be overwritten
+    }
+
+    // ================================================================ head: lin1 / ReLU / dropout / lin2 / residual
+    sfeat[tid] = g2_poll_f32(fx + tid, tag0 + G2_FXTAG, m.gs_err);
+    __syncthreads();
+    {
+      const int ju = tid >> 1, part = tid & 1;         // hidden unit, half of the fan-in
+      const float* wrow = P + m.off_l1w + (int64_t)ju * 256 + part * 128;
+      float4 w4[32];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) w4[q] = *(const float4*)(wrow + 4 * q);
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        const float4 f4 = *(const float4*)(sfeat + part * 128 + 4 * q);
+        s += w4[q].x * f4.x + w4[q].y * f4.y + w4[q].z * f4.z + w4[q].w * f4.w;
+      }
+      s += __shfl_xor(s, 1, 4);
+      if (part == 0) {
+        float av = s + P[m.off_l1b + ju];
+        av = av > 0.f ? av : 0.f;
+        int keep = 1;
+        if (TRAIN) {
+          keep = a.inj_mask ? (int)a.inj_mask[g * 128 + ju]
+                            : (int)(igmc_u01(igmc_unit_hash(a.seed, step, (uint32_t)g, (uint32_t)ju)) >= 0.5f);
+          if (cm == 0) {
+            m.a1[g * 128 + ju] = av;
+            m.lmask[g * 128 + ju] = (uint8_t)keep;
+          }
+          sa1[ju] = av;
+          skeep[ju] = keep ? 1.f : 0.f;
+        }
+        sred[ju] = (TRAIN ? (keep ? av * 2.f : 0.f) : av) * P[m.off_l2w + ju];      // F.dropout(p = 0.5): kept * 2
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      float s = sred[lane] + sred[lane + 64];
+      s = igmc_wave_sum_f(s);
+      if (lane == 0) {
+        const float o = (s + P[m.off_l2b]) * a.mult;
+        const float e = o - b.y[g];
+        if (cm == 0) {
+          a.out[g] = o;
+          m.err[g] = e;
+        }
+        misc[0] = e;
+      }
+    }
+    if (!TRAIN) {
+      __syncthreads();
+      continue;
+    }
+    if (TRAIN) {
+      __syncthreads();
+      if (tid < 128) {
+        const float dp = 2.f * misc[0] * a.grad_scale * a.mult;
+        const float dzv = (sa1[tid] > 0.f && skeep[tid] != 0.f) ? dp * P[m.off_l2w + tid] * 2.f : 0.f;
+        sdz[tid] = dzv;
+        if (cm == 0) m.dz[g * 128 + tid] = dzv;
+      }
+      if (cm == 0) m.feat[(size_t)g * m.D + tid] = sfeat[tid];
+      __syncthreads();
+      {   // d feat = dz @ lin1.weight: wave w takes hidden units 32 w .. 32 w + 31, lane -> 4 fan-in columns; rows with
+          // dz == 0 (ReLU / dropout: ~3/4 of them) are skipped wave-uniformly
+        const float* w1 = P + m.off_l1w + 4 * lane;
+        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned long long nz = __ballot(lane < 32 && sdz[32 * wave + (lane & 31)] != 0.f);
+        while (nz) {
+          int q[8];
+          float4 wv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            q[u] = nz ? (int)__builtin_ctzll(nz) : -1;
+            if (nz) nz &= nz - 1;
+            wv[u] = (q[u] >= 0) ? *(const float4*)(w1 + (int64_t)(32 * wave + q[u]) * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const float dzv = (q[u] >= 0) ? sdz[32 * wave + q[u]] : 0.f;
+            s4.x += dzv * wv[u].x; s4.y += dzv * wv[u].y; s4.z += dzv * wv[u].z; s4.w += dzv * wv[u].w;
+          }
+        }
+        *(float4*)(TILES + wave * 256 + 4 * lane) = s4;
+      }
+      __syncthreads();
+      {
+        const float v = (TILES[tid] + TILES[256 + tid]) + (TILES[512 + tid] + TILES[768 + tid]);
+        sgf[tid] = v;
+        if (cm == 0) m.gfeat[(size_t)g * m.D + tid] = v;
+      }
+      __syncthreads();
+      // ---- dPre_3: non-zero on the two centre rows only.  Own rows -> XO0 (h_3 sits in XO1), the opposite side's
+      //      planes are rebuilt locally (node 0 of every feature; everything else zero): no exchange
+      for (int i = tid; i < nsides * (G2_NT * 32 * kp >> 1); i += G2_THREADS) PLN[i] = 0u;
+      for (int i = lane; i < 16 * G2_XP; i += 64) XO0[i] = 0.f;
+      __syncthreads();
+      if (tid < 32 * nsides) {
+        const int s2 = tid >> 5, f = tid & 31;
+        const int sd = (nsides == 2) ? s2 : 1 - side;
+        const float hv = sfeat[sd * 128 + 96 + f];
+        const float d = sgf[sd * 128 + 96 + f] * (1.f - hv * hv);
+        uint32_t h, mi, lo;
+        g2_split2(d, 0.f, h, mi, lo);
+        uint32_t* p2 = PLN + s2 * (G2_NT * 32 * kp >> 1) + (f * kp >> 1);
+        p2[0] = h & 0xFFFFu;
+        p2[32 * kp >> 1] = mi & 0xFFFFu;
+        p2[2 * (32 * kp >> 1)] = lo & 0xFFFFu;
+      }
+      if (active && bi == 0 && lane < 32) {
+        const float hv = sfeat[side * 128 + 96 + lane];
+        XO0[lane] = sgf[side * 128 + 96 + lane] * (1.f - hv * hv);
+      }
+      wpre(3);
+      __syncthreads();
+
+      // ============================================================== conv layers 3..1, backward
+#pragma unroll 1
+      for (int l = 3; l >= 1; --l) {
+        float* XOc = (l & 1) ? XO0 : XO1;            // dPre_l of the bundle's own rows
+        float* XOn = (l & 1) ? XO1 : XO0;            // dPre_{l-1}
+        stage(true);
+        float* wpart = m.ts_part + ((size_t)l * IGMC_TS_BLOCKS + blockIdx.x) * ts;
+        {   // d bias_l = column sums of dPre_l over this workgroup's rows (fixed order)
+          const int n = tid & 31, part = tid >> 5;
+          float sb = 0.f;
+          for (int row = part; row < G2_NW * 16; row += G2_THREADS / 32)
+            sb += XOA[(((l & 1) ? 0 : G2_NW) + (row >> 4)) * 16 * G2_XP + (row & 15) * G2_XP + n];
+          sred[part * 32 + n] = sb;
+        }
+        __syncthreads();
+        if (tid < 32) {
+          float s = 0.f;
+          for (int p = 0; p < G2_THREADS / 32; ++p) s += sred[p * 32 + tid];
+          if (first_graph) wpart[(R * 32 + 32) * 32 + tid] = s;
+          else wpart[(R * 32 + 32) * 32 + tid] += s;
+        }
+        float hreg[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) hreg[nt][rr] = 0.f;
+        if (active) {
+          // h_{l-1} of the bundle's rows (written by this very wave in the forward): tanh' and the table product
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              const int row = 4 * kq + rr;
+              if (row0 + row < n_own) hreg[nt][rr] = m.h[l - 1][(size_t)(nbs + row0 + row) * 32 + 16 * nt + li];
+            }
+          f32x4 acc[G2_NR][2];
+          if constexpr (FLAGS) g2_gather(pl, kp, (l == 3) ? 1 : nks, R, AB, li, kq, acc);
+          else g2_gather(pl, kp, (l == 3) ? 1 : nks, R, AF, li, kq, acc);
+          // T' rows of the bundle -> LDS (B operand of the weight-gradient table): lane = row, 4 consecutive features
+#pragma unroll
+          for (int r = 0; r < G2_NR; ++r)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+              *(float4*)(T + li * G2_TP + r * 32 + 16 * t + 4 * kq) = make_float4(acc[r][t][0], acc[r][t][1], acc[r][t][2], acc[r][t][3]);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) HS[(4 * kq + rr) * G2_XP + 16 * nt + li] = hreg[nt][rr];
+          // dX = [T' | dPre_l] @ [W_r^T ; root^T], + readout gradient on the centre row, * tanh'(h_{l-1})
+          f32x4 o[2];
+          g2_transform(acc, R, XOc, sW2, li, kq, o);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const int f = 16 * nt + li;
+            float v[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              const int row = 4 * kq + rr;
+              float d = o[nt][rr];
+              if (bi == 0 && row == 0) d += sgf[side * 128 + (l - 1) * 32 + f];
+              const float x = hreg[nt][rr];
+              v[rr] = (row0 + row < n_own) ? d * (1.f - x * x) : 0.f;
+              XOn[row * G2_XP + f] = v[rr];
+            }
+            if (l > 1) g2_publish4(m.g2_ex + (6 - l) * exs + ((size_t)g * 2 + side) * 4096 + f * 128, row0 + 4 * kq, v, tag16(6 - l));
+          }
+        } else {
+          // idle wave: its tile / h rows are K entries of the workgroup's table product
+          for (int i = lane; i < 16 * G2_TP; i += 64) T[i] = 0.f;
+          for (int i = lane; i < 16 * G2_XP; i += 64) HS[i] = 0.f;
+        }
+        __syncthreads();                             // the four tiles / h chunks / dPre tiles of the workgroup are complete
+        {
+          // weight-gradient table h_{l-1}^T [T' | dPre_l], split by OUTPUT tile: wave w computes 6 of the 2 x 12 tiles
+          // (row half m2 = in-features, column tile nt: 0..9 = T' of relation nt >> 1, 10..11 = dPre -> d root) over
+          // K = the 64 rows of the workgroup's four bundles -- no cross-wave reduction
+          f32x4 w6[6];
+#pragma unroll
+          for (int i6 = 0; i6 < 6; ++i6) w6[i6] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          const int m2w = wave >> 1, wo = wave & 1;
+#pragma unroll 1
+          for (int wb = 0; wb < G2_NW; ++wb) {
+            const float* Tb = TILES + wb * 16 * G2_TP;
+            const float* Hb = HSS + wb * 16 * G2_XP;
+            const float* Db = XOA + (((l & 1) ? 0 : G2_NW) + wb) * 16 * G2_XP;
+            float av[4], bw[4][6];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+              av[s4] = Hb[(4 * s4 + kq) * G2_XP + m2w * 16 + li];
+              const float* tb = Tb + (4 * s4 + kq) * G2_TP + li;
+#pragma unroll
+              for (int i6 = 0; i6 < 4; ++i6) bw[s4][i6] = tb[(wo * 6 + i6) * 16];
+              const float* pr = wo ? Db + (4 * s4 + kq) * G2_XP + li : tb + 64;     // column tiles 10, 11 (odd waves) / 4, 5
+              bw[s4][4] = pr[0];
+              bw[s4][5] = pr[16];
+            }
+#ifndef IGMC_HIPEMU
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+              for (int i6 = 0; i6 < 6; ++i6)
+                w6[i6] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bw[s4][i6], w6[i6], 0, 0, 0);
+          }
+#pragma unroll
+          for (int i6 = 0; i6 < 6; ++i6) {
+            const int tt = wave * 6 + i6, m2 = tt / 12, nt = tt % 12;
+            const int r = nt >> 1;                      // 32-column block: relation, or G2_NR = root
+            if (r >= R && r < G2_NR) continue;
+            float* pp = wpart + (kq * 4) * 32 + li + (r < R ? r : R) * 1024 + m2 * 512 + (nt & 1) * 16;
+            if (first_graph) {
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) pp[rr * 32] = w6[i6][rr];
+            } else {
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) pp[rr * 32] += w6[i6][rr];
+            }
+          }
+        }
+        if (l > 1) {
+          wpre(l - 1);
+          for (int s2 = 0; s2 < nsides; ++s2) {
+            const int sd = (nsides == 2) ? s2 : 1 - side;
+            const int n_sd = sd ? cv : cu;
+            g2_reload(PLN + s2 * (G2_NT * 32 * kp >> 1), kp, m.g2_ex + (6 - l) * exs + ((size_t)g * 2 + sd) * 4096,
+                      ((n_sd + 15) >> 4) << 4, tag16(6 - l), m.gs_err);
+          }
+        }
+        __syncthreads();
+      }
+
+      // ============================================================== layer-0 table gradient (dPre_0 is in XO1)
+      // T0'[c][f] = sum_i [hist | onehot | 1](i, c) dPre_0[i][f] over this workgroup's rows; wave = (code half, feature half)
+      {
+        const int m2 = wave >> 1, wn = wave & 1;
+        for (int wb = 0; wb < G2_NW; ++wb) {
+          const float* Hb = HIST + wb * 16 * G2_XP;
+          const float* Db = XOA + (G2_NW + wb) * 16 * G2_XP;
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Hb[(4 * s4 + kq) * G2_XP + m2 * 16 + li],
+                                                        Db[(4 * s4 + kq) * G2_XP + wn * 16 + li], acc0, 0, 0, 0);
+        }
+      }
+      first_graph = false;
+      __syncthreads();
+    }
+  }
+
+  if (TRAIN) {
+    float* part0 = m.ts_part + (size_t)blockIdx.x * ts;        // slice 0 of [4][IGMC_TS_BLOCKS][ts]
+    const int m2 = wave >> 1, wn = wave & 1;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int c = m2 * 16 + kq * 4 + rr;
+      if (c < RL + L + 1) part0[c * 32 + wn * 16 + li] = acc0[rr];
+    }
+  }
+#ifndef IGMC_HIPEMU
+  if (tid == 0) {
+    const unsigned long long t1 = a.ts ? (unsigned long long)wall_clock64() : 0ull;
+    // the workgroup that finishes the launch LAST advances the sequence number: every workgroup has read it by then
+    if (__hip_atomic_fetch_add(m.gs_bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+      __hip_atomic_store(m.gs_bar, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(m.gs_bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.ts) {
+        const unsigned long long t0 = __hip_atomic_load(a.ts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(a.ts + 1, t1 - t0);
+        atomicAdd(a.ts + 2, 1ull);
+        __hip_atomic_store(a.ts, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+#else
+  if (tid == 0) {
+    if (m.gs_bar[0]++ == (int)gridDim.x - 1) {
+      m.gs_bar[0] = 0;
+      m.gs_bar[1] += 1;
+    }
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+// LDS plan + eligibility for a batch arena / cluster size
+int igmc_g2_layout(const ModelDev& m, const BatchDev& b, int cs, G2Layout* lay) {
+  const int RL = m.R * m.L;
+  if (m.S != 0 || m.D != 256 || m.R > G2_NR || m.L > 8 || RL + m.L + 1 > 32 || !m.ts_part || !m.g2_ex || !b.relm) return 0;
+  const int half = 2 * cs;
+  const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
+  if (cmax > 16 * half || cmax > 128) return 0;
+  if (b.graph_cap > m.g2_graphs) return 0;
+  const int kmax = ((cmax + 31) >> 5) << 5;
+  lay->kp = kmax + 8;
+  lay->nsides = (cs == 1) ? 2 : 1;
+  lay->rmr = ((cmax + 15) >> 4) << 4;
+  lay->rmc = kmax;
+  int o = 0;
+  lay->planes = o; o += lay->nsides * (G2_NT * 32 * lay->kp >> 1);
+  lay->ohp = o; o += lay->nsides * (8 * lay->kp >> 1);
+  lay->lab = o; o += 64;
+  lay->xo = o; o += 2 * G2_NW * 16 * G2_XP;
+  lay->hs = o; o += G2_NW * 16 * G2_XP;
+  int tw = G2_NW * 16 * G2_TP;
+  const int rw = lay->nsides * lay->rmr * lay->rmc / 4;
+  if (rw > tw) tw = rw;
+  if (tw < 1024) tw = 1024;
+  lay->tile = o; o += tw;
+  lay->hist = o; o += G2_NW * 16 * G2_XP;
+  lay->wreg = o; o += (G2_NR * 32 + 32) * 32;
+  lay->t0 = o; o += 1024;
+  lay->att = o; o += 64;
+  lay->head = o; o += 256 + 256 + 3 * 128 + 256 + 16;
+  lay->words = o;
+  return (size_t)o * 4 <= 160 * 1024;
+}
+
+// 1 = the matrix-core subgraph kernel takes this batch configuration (IGMC_GS_VERSION=1 forces graphstep.hip)
+int igmc_g2_eligible(const ModelDev& m, const BatchDev& b, int B, G2Layout* lay, int* cs_out) {
+  const char* e = getenv("IGMC_GS_VERSION");       // read on every call: tests switch it per case
+  if (e && atoi(e) == 1) return 0;
+  const char* en = getenv("IGMC_GRAPH_STEP");
+  if (en && atoi(en) == 0) return 0;
+  const int cs = igmc_gs_cluster(B);
+  if (!igmc_g2_layout(m, b, cs, lay)) return 0;
+  *cs_out = cs;
+  return 1;
+}
+
+void igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* P, int B, int training, int use_flags,
+                             const G2Layout& lay, int cs, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
+                             float grad_scale, float* out, void* stream) {
+  GsArgs a;
+  memset(&a, 0, sizeof(a));
+  a.inj_mask = inj_mask;
+  a.seed = seed;
+  a.step = step;
+  a.mult = mult;
+  a.grad_scale = grad_scale;
+  a.out = out;
+  a.lay2 = lay;
+  a.timing = 0;
+  a.ts = (g_igmc_prof_on == 2) ? m.gs_ts : nullptr;
+  a.cs = cs;
+  a.stride = (cs > 1) ? ((B + 7) & ~7) : 1;
+  const int grid = (cs > 1) ? cs * a.stride : igmc_gs_grid(B);
+  const size_t sm = (size_t)lay.words * 4;
+#ifdef IGMC_HIPEMU
+  if (cs > 1) {
+    hipemu::rt().co_cs = cs;
+    hipemu::rt().co_stride = a.stride;
+  }
+#endif
+  if (getenv("IGMC_GS_TRACE")) fprintf(stderr, "[igmc] k_graph_step B=%d train=%d flags=%d v2 kp=%d lds=%zu cluster=%d grid=%d\n", B, training, use_flags, lay.kp, sm, cs, grid);
+  if (training) {
+    if (use_flags) IGMC_PLAUNCH("k_graph_step", (k_graph_step2<true, true>), grid, G2_THREADS, sm, stream, b, m, P, a);
+    else IGMC_PLAUNCH("k_graph_step", (k_graph_step2<false, true>), grid, G2_THREADS, sm, stream, b, m, P, a);
+  } else {
+    if (use_flags) IGMC_PLAUNCH("k_graph_fwd", (k_graph_step2<true, false>), grid, G2_THREADS, sm, stream, b, m, P, a);
+    else IGMC_PLAUNCH("k_graph_fwd", (k_graph_step2<false, false>), grid, G2_THREADS, sm, stream, b, m, P, a);
+  }
+}
+
+int igmc_g2_prepare() {
+#ifndef IGMC_HIPEMU
+  const int mx = 160 * 1024;
+  if (hipFuncSetAttribute((const void*)k_graph_step2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_graph_step2<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_graph_step2<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_graph_step2<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+#endif
+  return 0;
+}

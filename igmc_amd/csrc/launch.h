@@ -10,6 +10,7 @@ void igmc_launch_extract(const GraphDev& g, const BatchDev& b, const int32_t* li
                          double sample_ratio, uint64_t seed, uint64_t epoch, const int64_t* ctrl, void* stream);
 void igmc_launch_edge_flags(const BatchDev& b, float p, int force_undirected, uint64_t seed, uint64_t step,
                             const int64_t* ctrl, void* stream);
+void igmc_launch_relm_flags(const BatchDev& b, void* stream);
 void igmc_launch_tick(int64_t* ctrl, void* stream);
 void igmc_launch_fill_u8(uint8_t* p, int64_t n, uint8_t v, void* stream);
 int igmc_extract_prepare(size_t smem);
@@ -54,6 +55,10 @@ struct GsLayout {      // LDS plan, offsets in 4-byte words
   int nmax, rlp;
   int xa, xb, zrow, tile, hs, att, t0, cnt, rp, lab, deg, order, sched, relp, wreg, ulist, head, words;
 };
+struct G2Layout {      // LDS plan of graphstep2.hip, offsets in 4-byte words
+  int kp, nsides, rmr, rmc;
+  int planes, ohp, lab, xo, hs, tile, hist, wreg, t0, att, head, words;
+};
 struct GsArgs {
   const uint8_t* inj_mask;
   uint64_t seed, step;
@@ -63,6 +68,7 @@ struct GsArgs {
   unsigned long long* ts;   // launch clock accumulators (ModelDev::gs_ts) or NULL
   int cs, stride;      // workgroups per subgraph; block index stride between the members of a cluster
   GsLayout lay;
+  G2Layout lay2;
 };
 void igmc_launch_side_gather(const float* src, int S, const int32_t* link_idx, int first, int B, const int64_t* ctrl,
                              float* dst, void* stream);
@@ -73,6 +79,12 @@ void igmc_launch_graph_step(const ModelDev& m, const BatchDev& b, const float* P
                             const GsLayout& lay, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
                             float grad_scale, float* out, void* stream);
 int igmc_gs_prepare();
+// graphstep2.hip: the same step with the relational aggregation on the matrix cores (dense induced block)
+int igmc_g2_eligible(const ModelDev& m, const BatchDev& b, int B, G2Layout* lay, int* cs_out);
+void igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* P, int B, int training, int use_flags,
+                             const G2Layout& lay, int cs, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
+                             float grad_scale, float* out, void* stream);
+int igmc_g2_prepare();
 
 // ---- per-kernel timing (HIP events on the launch stream; bench.py's roofline leg) ----
 void igmc_prof_begin(const char* name, void* stream);

@@ -45,6 +45,10 @@ struct ModelDev {
                                // [3] workgroups that finished the running launch
   unsigned long long* gs_ll;   // [5 exchanges][node_cap][32] {value, tag} words of the cluster exchanges (R <= 5 only)
   size_t gs_ll_stride;         // words per exchange buffer
+  unsigned long long* g2_ex;   // graphstep2: [5 exchanges][g2_graphs][2 sides][32 features][128 nodes] {hi, mid, lo, tag} words
+  size_t g2_ex_stride;         // words per exchange
+  unsigned long long* g2_fx;   // [g2_graphs][256] {f32, tag} words of the centre-node readout
+  int g2_graphs;               // subgraph slots of the two buffers above (0: not allocated)
   float* arr_part;    // [4] ARR regulariser per layer
   const float* side;  // [B,S] borrowed side features or NULL
   const int64_t* ctrl;  // optional device-side step control (igmc_hip.h) or NULL

@@ -79,6 +79,7 @@ struct WaveState {
   uint64_t slot[5][2][WAVE];
   uint64_t part[2] = {0, 0};   // lanes that took part in the current / previous full-wave exchange
   float fa[WAVE], fb[WAVE], fc[WAVE][4];
+  uint32_t ba[WAVE][4], bb[WAVE][4];     // bf16 MFMA operands (8 bf16 per lane each)
 };
 
 #if defined(__x86_64__)
@@ -485,6 +486,56 @@ static inline igmc_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, 
   }
   hipemu::wave_rendezvous();  // nobody overwrites fa/fb before all lanes have read them
   return d;
+}
+
+// ---- MFMA f32 16x16x32 bf16 (gfx950): A: lane l holds A[i=l&15][k=8*(l>>4)+e], e=0..7 (dword e/2, low half first);
+//      B: lane l holds B[k=8*(l>>4)+e][j=l&15]; C/D as the 16x16 f32 map.  Products of bf16 values are exact in f32;
+//      the k-sum is formed in double and rounded once (the hardware's internal order is not architecturally defined:
+//      tests compare at fp32 tolerances). ----
+typedef uint32_t igmc_u32x4 __attribute__((ext_vector_type(4)));
+static inline float hipemu_bf16_to_f32(uint32_t h) {
+  uint32_t u = h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static inline igmc_f32x4 igmc_emu_mfma_16x16x32_bf16(igmc_u32x4 a, igmc_u32x4 b, igmc_f32x4 c) {
+  hipemu::WaveState& w = hipemu::my_wave();
+  int lane = hipemu::lane_id();
+  for (int q = 0; q < 4; ++q) {
+    w.ba[lane][q] = a[q];
+    w.bb[lane][q] = b[q];
+  }
+  hipemu::wave_rendezvous();
+  igmc_f32x4 d;
+  int col = lane & 15;
+  for (int r = 0; r < 4; ++r) {
+    int row = (lane >> 4) * 4 + r;
+    double acc = c[r];
+    for (int kq = 0; kq < 4; ++kq)
+      for (int e = 0; e < 8; ++e) {
+        uint32_t wa = w.ba[row + 16 * kq][e >> 1], wb = w.bb[col + 16 * kq][e >> 1];
+        float fa = hipemu_bf16_to_f32((e & 1) ? (wa >> 16) : (wa & 0xFFFFu));
+        float fb = hipemu_bf16_to_f32((e & 1) ? (wb >> 16) : (wb & 0xFFFFu));
+        acc += (double)fa * (double)fb;
+      }
+    d[r] = (float)acc;
+  }
+  hipemu::wave_rendezvous();
+  return d;
+}
+// round-to-nearest-even f32 -> bf16 (the v_cvt_pk_bf16_f32 rounding), finite inputs
+static inline uint32_t hipemu_f32_to_bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+
+static inline float __uint_as_float(uint32_t u) {
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
 }
 
 // ---- host runtime subset ----
