@@ -27,7 +27,7 @@ import torch
 
 from igmc_amd import parallel
 from igmc_amd.models import IGMC
-from igmc_amd.preprocessing import create_trainvaltest_split, load_data_monti
+from igmc_amd.preprocessing import create_trainvaltest_split, load_data_monti, load_official_trainvaltest_split
 from igmc_amd.train_eval import test_once, train_multiple_epochs
 from igmc_amd.util_functions import MyDataset, MyDynamicDataset
 
@@ -147,6 +147,11 @@ def main(argv=None):
     # ---- data (reference Main.py:228-251)
     if args.data_name in ['flixster', 'douban', 'yahoo_music']:
         split = load_data_monti(args.data_name, args.testing, rating_map, post_rating_map)
+    elif args.data_name == 'ml_100k':       # reference Main.py:236-243: the official u1.base / u1.test split
+        if rank == 0:
+            print('Using official MovieLens split u1.base/u1.test with 20% validation...')
+        split = load_official_trainvaltest_split(args.data_name, args.testing, rating_map, post_rating_map, args.ratio,
+                                                 verbose=(rank == 0))
     else:
         split = create_trainvaltest_split(args.data_name, args.data_seed, args.testing, None, True, rank == 0,
                                           rating_map, post_rating_map, args.ratio)

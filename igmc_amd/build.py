@@ -5,7 +5,6 @@
 * :func:`build_emu`  -- ``tests/emu/libigmc_emu.so``: the SAME sources compiled for the host against
   ``tools/hipemu/hipemu.h``; test infrastructure for kernel-logic checks on GPU-less machines, never loaded
   by the product package.
-* :func:`build_oracle` -- ``oracle/c/libigmc_oracle.so``: the plain-C restatement of the extraction (checker).
 """
 import os
 import shutil
@@ -18,7 +17,6 @@ SOURCES = ['extract.hip', 'model.hip', 'graphstep.hip', 'graphstep2.hip', 'capi.
 HEADERS = ['common.h', 'model.h', 'launch.h', '../../include/igmc_hip.h', '../../include/igmc_rng.h']
 HIP_LIB = os.path.join(ROOT, 'igmc_amd', 'lib', 'libigmc_hip.so')
 EMU_LIB = os.path.join(ROOT, 'tests', 'emu', 'libigmc_emu.so')
-ORACLE_LIB = os.path.join(ROOT, 'oracle', 'c', 'libigmc_oracle.so')
 
 
 def _newer(target, deps):
@@ -83,24 +81,7 @@ def build_emu(force=False):
     return EMU_LIB
 
 
-def build_oracle(force=False):
-    src = os.path.join(ROOT, 'oracle', 'c', 'extract_oracle.c')
-    deps = [src, os.path.join(ROOT, 'include', 'igmc_rng.h')]
-    if not os.path.exists(src):
-        return None
-    if not force and not _newer(ORACLE_LIB, deps):
-        return ORACLE_LIB
-    cc = shutil.which('gcc') or shutil.which('cc')
-    if cc is None:
-        if os.path.exists(ORACLE_LIB):
-            return ORACLE_LIB
-        raise RuntimeError('gcc not found')
-    _run([cc, '-O2', '-std=c99', '-fPIC', '-shared', '-o', ORACLE_LIB, src])
-    return ORACLE_LIB
-
-
 if __name__ == '__main__':
     print(build_hip(force='--force' in sys.argv, verbose='-v' in sys.argv))
     if '--emu' in sys.argv:
         print(build_emu(force=True))
-    print(build_oracle())

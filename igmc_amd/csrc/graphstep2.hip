@@ -44,6 +44,21 @@
 #define G2_XP 36                  // pitch of a wave's 16-row x / dPre / h tile
 #define G2_FXTAG 7                // exchange index of the centre-node readout
 
+// phase clocks (debug aid, IGMC_GS_TIMING=1; igmc_debug_g2_clocks): thread 0 of workgroup 0 (member 0, user side) -> slots
+// 0..39, thread 0 of member 2 of the same subgraph (item side) -> slots 40..79
+__device__ unsigned long long g_g2_clk[80];
+#ifdef IGMC_HIPEMU
+#define G2_STAMP(k) do { } while (0)
+#else
+#define G2_STAMP(k)                                                                                        \
+  do {                                                                                                     \
+    if (a.timing && threadIdx.x == 0) {                                                                    \
+      if (blockIdx.x == 0) g_g2_clk[k] = __builtin_readcyclecounter();                                     \
+      else if (a.cs > 2 && (int)blockIdx.x == 2 * a.stride) g_g2_clk[40 + (k)] = __builtin_readcyclecounter(); \
+    }                                                                                                      \
+  } while (0)
+#endif
+
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #ifndef IGMC_HIPEMU
 typedef __bf16 g2_bf16x8 __attribute__((ext_vector_type(8)));
@@ -356,6 +371,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
   if (a.ts && tid == 0) atomicMin(a.ts, (unsigned long long)wall_clock64());
 #endif
   auto tag16 = [&](int x) { return 1u + (tag0 + (uint32_t)x) % 65535u; };
+  G2_STAMP(0);
 
   // ---- layer-0 table, staged once per workgroup
   for (int i = tid; i < 1024; i += G2_THREADS) {
@@ -374,6 +390,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
   }
   f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};        // layer-0 table gradient tile (code half, feature half) of this wave
   bool first_graph = true;
+  G2_STAMP(1);
 
 #pragma unroll 1
   for (int g = (cs > 1) ? (int)(blockIdx.x % a.stride) : (int)blockIdx.x; g < B; g += (cs > 1) ? B : (int)gridDim.x) {
@@ -423,6 +440,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
     for (int i = tid; i < 2 * G2_NW * 16 * G2_XP; i += G2_THREADS) XOA[i] = 0.f;
     for (int i = tid; i < G2_NW * 16 * G2_XP; i += G2_THREADS) HIST[i] = 0.f;
     __syncthreads();
+    G2_STAMP(2);
     {
       const int ld = b.relm_ld;
       const unsigned char* rm = b.relm + (size_t)g * b.cap_u * ld;
@@ -450,6 +468,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
       }
     }
     __syncthreads();
+    G2_STAMP(3);
     // ---- A fragments of this wave's bundle: A[r][s] = the 16 x 32 block (rows of the bundle) x (opposite nodes 32 s ..)
     //      of relation r as the MFMA B operand of the transposed gather; forward and (with edge dropout) backward masks
     uint32_t AF[G2_NR][G2_KS][4];
@@ -477,6 +496,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
       }
     }
     __syncthreads();                    // RM is dead from here on (its bytes are the backward's tiles)
+    G2_STAMP(4);
 
     // weights of the NEXT conv layer to be staged: requested a phase ahead
     float4 wb4[4], wr4;
@@ -577,6 +597,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
       }
       fwd_out(0, o, 0.f, 0.f, XO0);
     }
+    G2_STAMP(5);
 
     // ================================================================ conv layers 1..3, forward
 #pragma unroll 1
@@ -584,6 +605,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
       float* XOc = (l & 1) ? XO0 : XO1;             // x of the bundle's own rows (h_{l-1})
       float* XOn = (l & 1) ? XO1 : XO0;             // h_l
       stage(false);
+      G2_STAMP(6 + 3 * (l - 1));
       const float bias0 = P[m.off_bias[l] + li], bias1 = P[m.off_bias[l] + 16 + li];
       // the opposite side's h_{l-1} as bf16 planes
       for (int s2 = 0; s2 < nsides; ++s2) {
@@ -593,6 +615,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
                   ((n_sd + 15) >> 4) << 4, tag16(l - 1), m.gs_err);
       }
       __syncthreads();
+      G2_STAMP(7 + 3 * (l - 1));
       if (l < 3) wpre(l + 1);
       if (active) {
         f32x4 acc[G2_NR][2];
@@ -601,12 +624,15 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
         g2_transform(acc, R, XOc, sW2, li, kq, o);
         fwd_out(l, o, bias0, bias1, XOn);
       }
+      G2_STAMP(36 + (l - 1));
       __syncthreads();                              // planes / sW2 may be overwritten
+      G2_STAMP(8 + 3 * (l - 1));
     }
 
     // ================================================================ head: lin1 / ReLU / dropout / lin2 / residual
     sfeat[tid] = g2_poll_f32(fx + tid, tag0 + G2_FXTAG, m.gs_err);
     __syncthreads();
+    G2_STAMP(15);
     {
       const int ju = tid >> 1, part = tid & 1;         // hidden unit, half of the fan-in
       const float* wrow = P + m.off_l1w + (int64_t)ju * 256 + part * 128;
@@ -657,6 +683,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
     }
     if (TRAIN) {
       __syncthreads();
+      G2_STAMP(16);
       if (tid < 128) {
         const float dp = 2.f * misc[0] * a.grad_scale * a.mult;
         const float dzv = (sa1[tid] > 0.f && skeep[tid] != 0.f) ? dp * P[m.off_l2w + tid] * 2.f : 0.f;
@@ -694,6 +721,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
         if (cm == 0) m.gfeat[(size_t)g * m.D + tid] = v;
       }
       __syncthreads();
+      G2_STAMP(17);
       // ---- dPre_3: non-zero on the two centre rows only.  Own rows -> XO0 (h_3 sits in XO1), the opposite side's
       //      planes are rebuilt locally (node 0 of every feature; everything else zero): no exchange
       for (int i = tid; i < nsides * (G2_NT * 32 * kp >> 1); i += G2_THREADS) PLN[i] = 0u;
@@ -717,6 +745,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
       }
       wpre(3);
       __syncthreads();
+      G2_STAMP(18);
 
       // ============================================================== conv layers 3..1, backward
 #pragma unroll 1
@@ -739,6 +768,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
           if (first_graph) wpart[(R * 32 + 32) * 32 + tid] = s;
           else wpart[(R * 32 + 32) * 32 + tid] += s;
         }
+        G2_STAMP(19 + 5 * (3 - l));
         float hreg[2][4];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -789,7 +819,9 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
           for (int i = lane; i < 16 * G2_TP; i += 64) T[i] = 0.f;
           for (int i = lane; i < 16 * G2_XP; i += 64) HS[i] = 0.f;
         }
+        G2_STAMP(20 + 5 * (3 - l));
         __syncthreads();                             // the four tiles / h chunks / dPre tiles of the workgroup are complete
+        G2_STAMP(21 + 5 * (3 - l));
         {
           // weight-gradient table h_{l-1}^T [T' | dPre_l], split by OUTPUT tile: wave w computes 6 of the 2 x 12 tiles
           // (row half m2 = in-features, column tile nt: 0..9 = T' of relation nt >> 1, 10..11 = dPre -> d root) over
@@ -838,6 +870,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
             }
           }
         }
+        G2_STAMP(22 + 5 * (3 - l));
         if (l > 1) {
           wpre(l - 1);
           for (int s2 = 0; s2 < nsides; ++s2) {
@@ -848,6 +881,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
           }
         }
         __syncthreads();
+        G2_STAMP(23 + 5 * (3 - l));
       }
 
       // ============================================================== layer-0 table gradient (dPre_0 is in XO1)
@@ -865,6 +899,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
       }
       first_graph = false;
       __syncthreads();
+      G2_STAMP(34);
     }
   }
 
@@ -900,6 +935,19 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
     }
   }
 #endif
+  G2_STAMP(35);
+}
+
+// debug aid: phase clocks (shader cycles) of the last k_graph_step2 launched with IGMC_GS_TIMING set
+extern "C" int igmc_debug_g2_clocks(unsigned long long* out, int n) {
+#ifndef IGMC_HIPEMU
+  if (n > 80) n = 80;
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_g2_clk), (size_t)n * sizeof(unsigned long long)) != hipSuccess) return 1;
+#else
+  for (int i = 0; i < n; ++i) out[i] = 0;
+#endif
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -960,7 +1008,7 @@ void igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* 
   a.grad_scale = grad_scale;
   a.out = out;
   a.lay2 = lay;
-  a.timing = 0;
+  a.timing = getenv("IGMC_GS_TIMING") ? 1 : 0;
   a.ts = (g_igmc_prof_on == 2) ? m.gs_ts : nullptr;
   a.cs = cs;
   a.stride = (cs > 1) ? ((B + 7) & ~7) : 1;

@@ -265,3 +265,118 @@ def create_trainvaltest_split(dataset, seed=1234, testing=False, datasplit_path=
             dataset, source, num_users, num_items, n, len(train_labels), len(val_labels), len(test_labels)))
     return (None, None, rating_mx_train, train_labels, u_train_idx, v_train_idx, val_labels, u_val_idx, v_val_idx,
             test_labels, u_test_idx, v_test_idx, class_values)
+
+
+# ------------------------------------------------------------------------------------------ official ML-100K split
+ML100K_GENRES = 18      # u.item columns 6.. ('unknown' at column 5 is skipped, reference preprocessing.py:483)
+
+
+def _official_arrays(dataset, raw_dir=None, verbose=True):
+    """(train rows, test rows, item rows, user rows, source): ``u1.base`` / ``u1.test`` as float arrays
+    [user id, item id, rating, timestamp] (reference ``preprocessing.py:357-372``), ``u.item`` / ``u.user`` as lists of
+    string fields.  Without the files (no network here) a MovieLens-100K-SHAPED stand-in is generated -- same sizes and
+    80 000 / 20 000 proportions as the official u1 split -- and that is said loudly."""
+    base = raw_dir
+    if base is None:
+        p = _find_raw(dataset, 'u1.base')
+        base = os.path.dirname(p) if p is not None else None
+    if base is not None and os.path.exists(os.path.join(base, 'u1.base')):
+        tr = np.loadtxt(os.path.join(base, 'u1.base'), delimiter='\t', dtype=np.float64, ndmin=2)
+        te = np.loadtxt(os.path.join(base, 'u1.test'), delimiter='\t', dtype=np.float64, ndmin=2)
+        items, users = None, None
+        if os.path.exists(os.path.join(base, 'u.item')):
+            with open(os.path.join(base, 'u.item'), encoding='latin-1') as f:
+                items = [line.rstrip('\n').split('|') for line in f if line.strip()]
+        if os.path.exists(os.path.join(base, 'u.user')):
+            with open(os.path.join(base, 'u.user'), encoding='latin-1') as f:
+                users = [line.rstrip('\n').split('|') for line in f if line.strip()]
+        return tr, te, items, users, 'real'
+    if dataset not in ML_HIST:
+        raise FileNotFoundError('raw_data/%s/u1.base not found and no synthetic spec' % dataset)
+    import sys
+    sys.stderr.write('igmc_amd.preprocessing: raw_data/%s/{u1.base,u1.test} NOT FOUND -- using the MovieLens-shaped SYNTHETIC '
+                     'stand-in (80/20 split like u1); RMSEs are not comparable with published %s numbers\n' % (dataset, dataset))
+    num_users, num_items, nnz, hist = ML_HIST[dataset]
+    u, v, r = synth_ml(num_users, num_items, nnz, hist, seed=0)
+    perm = np.random.default_rng(1).permutation(len(r))
+    n_test = len(r) // 5
+    rows = np.stack([u + 1, v + 1, r, np.arange(len(r), dtype=np.float64)], 1).astype(np.float64)[perm]
+    return rows[n_test:], rows[:n_test], None, None, 'synthetic'
+
+
+def load_official_trainvaltest_split(dataset, testing=False, rating_map=None, post_rating_map=None, ratio=1.0,
+                                     raw_dir=None, verbose=True):
+    """MovieLens-100K official split (reference ``preprocessing.py:336-586``; used by reference ``Main.py:236-243`` for
+    ``ml_100k``): u1.base -> train (+ validation = the first ceil(0.2 n) of a seed-42 shuffle), u1.test -> test; ids
+    mapped to 0..n-1 in sorted order (``data_utils.map_data``); ``ratio`` keeps the earliest ``ratio * n`` training
+    ratings by timestamp; ``adj_train`` stores label + 1 (or ``post_rating_map`` + 1).  Side features as the reference:
+    users = [age / max age, gender, one-hot occupation], items = 18 genre flags (occupation columns in sorted order --
+    the reference numbers them by iterating a Python set, which is not reproducible between runs)."""
+    tr, te, items, users, source = _official_arrays(dataset, raw_dir, verbose)
+    if ratio < 1.0:
+        tr = tr[tr[:, -1].argsort()[:int(ratio * len(tr))]]
+    data = np.concatenate([tr, te], axis=0)
+    u_raw, v_raw = data[:, 0].astype(np.int32), data[:, 1].astype(np.int32)
+    ratings = data[:, 2].astype(np.float32)
+    if rating_map is not None:
+        ratings = np.array([rating_map[x] for x in ratings], dtype=np.float32)
+    u_ids, u_nodes = np.unique(u_raw, return_inverse=True)        # sorted unique ids -> 0..n-1 (map_data)
+    v_ids, v_nodes = np.unique(v_raw, return_inverse=True)
+    num_users, num_items = len(u_ids), len(v_ids)
+    ratings = ratings.astype(np.float64)
+    class_values = np.sort(np.unique(ratings))
+    lab_of = {r: i for i, r in enumerate(class_values.tolist())}
+    labels = np.full((num_users, num_items), -1, dtype=np.int32)
+    labels[u_nodes, v_nodes] = np.array([lab_of[r] for r in ratings])          # later duplicates win, like the reference
+    labels = labels.reshape(-1)
+    num_train, num_test = len(tr), len(te)
+    num_val = int(np.ceil(num_train * 0.2))
+    num_train -= num_val
+    pairs = np.stack([u_nodes, v_nodes], 1).astype(np.int64)
+    idx = pairs[:, 0] * num_items + pairs[:, 1]
+    n_tv = num_train + num_val
+    rand_idx = list(range(n_tv))
+    np.random.RandomState(42).shuffle(rand_idx)                    # == np.random.seed(42); np.random.shuffle(list)
+    idx = np.concatenate([idx[:n_tv][rand_idx], idx[n_tv:]])
+    pairs = np.concatenate([pairs[:n_tv][rand_idx], pairs[n_tv:]])
+    val_idx, train_idx, test_idx = idx[:num_val], idx[num_val:n_tv], idx[n_tv:]
+    assert len(test_idx) == num_test
+    (u_val, v_val), (u_train, v_train), (u_test, v_test) = (pairs[:num_val].T, pairs[num_val:n_tv].T, pairs[n_tv:].T)
+    train_labels, val_labels, test_labels = labels[train_idx], labels[val_idx], labels[test_idx]
+    if testing:
+        u_train, v_train = np.hstack([u_train, u_val]), np.hstack([v_train, v_val])
+        train_labels = np.hstack([train_labels, val_labels])
+        train_idx = np.hstack([train_idx, val_idx])
+    mx = np.zeros(num_users * num_items, dtype=np.float32)
+    if post_rating_map is None:
+        mx[train_idx] = labels[train_idx].astype(np.float32) + 1.
+    else:
+        mx[train_idx] = np.array([post_rating_map[r] for r in class_values[labels[train_idx]]]) + 1.
+    rating_mx_train = sp.csr_matrix(mx.reshape(num_users, num_items))
+    # ---- side features (reference :470-520)
+    u_features = v_features = None
+    if items is not None:
+        vpos = {int(i): k for k, i in enumerate(v_ids.tolist())}
+        v_features = np.zeros((num_items, ML100K_GENRES), dtype=np.float32)
+        for row in items:
+            k = vpos.get(int(row[0]))
+            if k is not None:
+                v_features[k] = [float(x) for x in row[6:6 + ML100K_GENRES]]
+        v_features = sp.csr_matrix(v_features)
+    if users is not None:
+        upos = {int(i): k for k, i in enumerate(u_ids.tolist())}
+        occ = {o: i for i, o in enumerate(sorted(set(row[3] for row in users)), start=2)}
+        age_max = max(float(row[1]) for row in users)
+        u_features = np.zeros((num_users, 2 + len(occ)), dtype=np.float32)
+        for row in users:
+            k = upos.get(int(row[0]))
+            if k is not None:
+                u_features[k, 0] = float(row[1]) / age_max
+                u_features[k, 1] = {'M': 0., 'F': 1.}[row[2]]
+                u_features[k, occ[row[3]]] = 1.
+        u_features = sp.csr_matrix(u_features)
+    if verbose:
+        print('%s official split (%s): %d users, %d items, train %d / val %d / test %d' % (
+            dataset, source, num_users, num_items, len(train_labels), len(val_labels), len(test_labels)))
+    return (u_features, v_features, rating_mx_train, train_labels, u_train, v_train, val_labels, u_val, v_val,
+            test_labels, u_test, v_test, class_values)

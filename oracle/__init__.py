@@ -24,7 +24,4 @@ Contents
                   the reference's own call sites and on the in-tree ARR code
                   (``train_eval.py:167-174``) that pins parameter names/shapes and
                   ``W = att @ basis.view(num_bases, -1)``.
-``c/``            plain-C restatement of the extraction incl. the counter-based
-                  sampler, used for bit-exact parity of the HIP extraction at full
-                  batch sizes; validated against ``extract_ref`` + golden vectors.
 """

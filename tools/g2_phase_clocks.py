@@ -1,0 +1,61 @@
+"""Debug aid: phase clocks of k_graph_step2 (IGMC_GS_TIMING=1) on the bench workload: workgroup 0 (user side, member 0) and
+member 2 (item side) of subgraph 0.   python tools/g2_phase_clocks.py [--overlap]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ['IGMC_GS_TIMING'] = '1'
+from igmc_amd import _lib, preprocessing  # noqa: E402
+from igmc_amd.models import IGMC  # noqa: E402
+from igmc_amd.stepgraph import StepGraph  # noqa: E402
+from igmc_amd.train_eval import FlatAdam  # noqa: E402
+from igmc_amd.util_functions import MyDynamicDataset  # noqa: E402
+
+NAMES = {1: 'T0 table staged', 2: 'labels + zero fills', 3: 'relm staged + one-hot planes', 4: 'A fragments built', 5: 'layer 0',
+         6: 'L1 stage W', 7: 'L1 reload h0', 8: 'L1 compute + sync', 9: 'L2 stage W', 10: 'L2 reload h1', 11: 'L2 compute + sync',
+         12: 'L3 stage W', 13: 'L3 reload h2', 14: 'L3 compute + sync', 15: 'readout polled', 16: 'head forward', 17: 'd feat',
+         18: 'dPre3 set-up', 19: 'B3 stage W^T + bias', 20: 'B3 wave compute', 21: 'B3 sync', 22: 'B3 table product', 23: 'B3 reload dPre2',
+         24: 'B2 stage W^T + bias', 25: 'B2 wave compute', 26: 'B2 sync', 27: 'B2 table product', 28: 'B2 reload dPre1',
+         29: 'B1 stage W^T + bias', 30: 'B1 wave compute', 31: 'B1 sync', 32: 'B1 table product', 33: 'B1 sync', 34: 'layer-0 table',
+         35: 'kernel end'}
+ORDER = list(range(1, 36))
+
+
+def main():
+    lib = _lib.load()
+    split = preprocessing.create_trainvaltest_split('ml_1m', 1234, True, verbose=False)
+    (_, _, A, tr_l, tr_u, tr_v, _, _, _, _, _, _, class_values) = split
+    ds = MyDynamicDataset('data/bench', A, (tr_u, tr_v), tr_l, 1, 1.0, 100, None, None, class_values, device=0, seed=1)
+    model = IGMC(ds, latent_dim=[32, 32, 32, 32], num_relations=len(class_values), num_bases=4, regression=True,
+                 adj_dropout=0.0, multiply_by=1, seed=1).to('cuda')
+    model.reset_parameters()
+    opt = FlatAdam(model, lr=1e-3)
+    ov = '--overlap' in sys.argv
+    sg = StepGraph(model, opt, ds, 50, 0.001, use_graph=False, overlap=ov)
+    perm = torch.randperm(len(ds))[:5000]
+    sg.begin_epoch(perm, 1)
+    for _ in range(20):
+        sg.step()
+    torch.cuda.synchronize()
+    buf = np.zeros(80, np.uint64)
+    lib.cdll.igmc_debug_g2_clocks(C.c_void_p(buf.ctypes.data), 80)
+    c = buf.astype(np.int64)
+    print('overlap=%s; cycles per phase: member 0 (users) | member 2 (items); stamp 36..38 = wave 0 done with its L1..L3 bundle' % ov)
+    for base, nm in ((0, 'member 0'), (40, 'member 2')):
+        print(nm, 'start offset vs member 0: %d' % (c[base] - c[0]))
+    for k in ORDER:
+        a0 = c[k] - c[k - 1]
+        a2 = c[40 + k] - c[40 + k - 1]
+        print('%-28s %8d | %8d' % (NAMES[k], a0, a2))
+    print('total                        %8d | %8d' % (c[35] - c[0], c[75] - c[40]))
+    for l in (1, 2, 3):
+        print('L%d fwd: wave 0 compute alone %d | %d' % (l, c[36 + l - 1] - c[7 + 3 * (l - 1)], c[76 + l - 1] - c[47 + 3 * (l - 1)]))
+
+
+if __name__ == '__main__':
+    main()
