@@ -43,6 +43,9 @@
 #define G2_TP (G2_NR * 32 + 4)    // pitch of a wave's 16-row T' tile (backward)
 #define G2_XP 36                  // pitch of a wave's 16-row x / dPre / h tile
 #define G2_FXTAG 7                // exchange index of the centre-node readout
+#define G2_WP 20                  // float2 per k-row of a staged weight image (16 + 4 padding: the four kq groups of a
+                                  // B-operand read then hit disjoint banks)
+#define G2_WIMG ((G2_NR * 32 + 32) * G2_WP * 2)      // floats of one staged image
 
 // phase clocks (debug aid, IGMC_GS_TIMING=1; igmc_debug_g2_clocks): thread 0 of workgroup 0 (member 0, user side) -> slots
 // 0..39, thread 0 of member 2 of the same subgraph (item side) -> slots 40..79
@@ -57,6 +60,14 @@ __device__ unsigned long long g_g2_clk[80];
       else if (a.cs > 2 && (int)blockIdx.x == 2 * a.stride) g_g2_clk[40 + (k)] = __builtin_readcyclecounter(); \
     }                                                                                                      \
   } while (0)
+#endif
+
+// keeps per-lane index arithmetic INSIDE the phase it is used in (LLVM otherwise hoists hundreds of loop-invariant LDS
+// addresses out of the layer loops and spills them)
+#ifdef IGMC_HIPEMU
+#define G2_OPAQUE(x) do { } while (0)
+#else
+#define G2_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -230,8 +241,15 @@ __device__ __forceinline__ float g2_poll_f32(const unsigned long long* p, uint32
 }
 
 // ---- the relation-space aggregate of one bundle on the matrix cores: acc[r][t] (lane = row, regs = features
-//      16 t + 4 (lane >> 4) + 0..3) = sum over the opposite side's nodes of A_r[row][node] * x[node][feature]
-__device__ __forceinline__ void g2_gather(const uint32_t* pl, int kp, int nks, int R, const uint32_t (&A)[G2_NR][G2_KS][4],
+//      16 t + 4 (lane >> 4) + 0..3) = sum over the opposite side's nodes of A_r[row][node] * x[node][feature].
+//      All G2_NR relations always run (fragments of absent relations are zero); the six plane fragments of k-step s + 1
+//      are requested before the 30 MFMAs of k-step s are issued.
+#ifdef IGMC_HIPEMU
+#define G2_SCHED_BARRIER() do { } while (0)
+#else
+#define G2_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
+__device__ __forceinline__ void g2_gather(const uint32_t* pl, int kp, int nks, const uint32_t (&A)[G2_NR][G2_KS][4],
                                           int li, int kq, f32x4 (&acc)[G2_NR][2]) {
 #pragma unroll
   for (int r = 0; r < G2_NR; ++r) {
@@ -239,73 +257,74 @@ __device__ __forceinline__ void g2_gather(const uint32_t* pl, int kp, int nks, i
     acc[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   const int tstride = 32 * kp >> 1;            // dwords per term
+  const uint32_t* base = pl + (li * kp >> 1) + 4 * kq;
+  const int toff = 16 * kp >> 1;               // second feature tile
+  u32x4 pf[2][2 * G2_NT];
+  auto request = [&](int s, int buf) {
+#pragma unroll
+    for (int sp = 0; sp < G2_NT; ++sp) {
+      pf[buf][2 * sp] = *(const u32x4*)(base + sp * tstride + 16 * s);
+      pf[buf][2 * sp + 1] = *(const u32x4*)(base + sp * tstride + toff + 16 * s);
+    }
+  };
+  request(0, 0);
 #pragma unroll
   for (int s = 0; s < G2_KS; ++s) {
     if (s < nks) {
+      if (s + 1 < G2_KS && s + 1 < nks) request(s + 1, (s + 1) & 1);
+      G2_SCHED_BARRIER();
 #pragma unroll
-      for (int sp = 0; sp < G2_NT; ++sp) {
+      for (int q = 0; q < 2 * G2_NT; ++q) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const u32x4 pf = *(const u32x4*)(pl + sp * tstride + ((16 * t + li) * kp >> 1) + 16 * s + 4 * kq);
-#pragma unroll
-          for (int r = 0; r < G2_NR; ++r) {
-            if (r < R) {
-              const u32x4 af = {A[r][s][0], A[r][s][1], A[r][s][2], A[r][s][3]};
-              acc[r][t] = g2_mfma_bf16(pf, af, acc[r][t]);
-            }
-          }
+        for (int r = 0; r < G2_NR; ++r) {
+          const u32x4 af = {A[r][s][0], A[r][s][1], A[r][s][2], A[r][s][3]};
+          acc[r][q & 1] = g2_mfma_bf16(pf[s & 1][q], af, acc[r][q & 1]);
         }
       }
+      G2_SCHED_BARRIER();
     }
   }
 }
 
-// out (lane = output feature 16 nt + li, regs = rows 4 kq + 0..3) = [T_0..T_4 | x] @ sW2: the gather's accumulators are
-// the A operand as they are (k-step (r, t, rr) covers the input features 16 t + 4 kq' + rr, kq' = 0..3, of relation r);
-// x = the bundle's own rows, read from its LDS tile.  sW2[k][16] float2: element (k, n) at [k][n & 15].{x: n < 16, y: n >= 16}.
-__device__ __forceinline__ void g2_transform(const f32x4 (&acc)[G2_NR][2], int R, const float* xrows, const float2* sW2,
-                                             int li, int kq, f32x4 (&o)[2]) {
+// out (lane = output feature 16 nt + li, regs = rows 4 kq + 0..3) = [T_0..T_4 | x] @ sW: the gather's accumulators are
+// the A operand as they are: group (blk, t) = the 4 k-steps rr = 0..3 covering the input features 16 t + 4 kq' + rr
+// (kq' = 0..3) of block blk (relation, or G2_NR = the layer's own rows x, read from the bundle's LDS tile as float4).
+// sW[k][G2_WP] float2: element (k, n) at [k][n & 15].{x: n < 16, y: n >= 16}; the B operands of group g + 1 are requested
+// before the 8 MFMAs of group g.
+__device__ __forceinline__ void g2_transform(const f32x4 (&acc)[G2_NR][2], const float* xrows, const float2* sW, int li, int kq,
+                                             f32x4 (&o)[2]) {
   f32x4 o0a = (f32x4){0.f, 0.f, 0.f, 0.f}, o0b = o0a, o1a = o0a, o1b = o0a;
+  const float4 x0 = *(const float4*)(xrows + li * G2_XP + 4 * kq), x1 = *(const float4*)(xrows + li * G2_XP + 16 + 4 * kq);
+  float2 bv[2][4];
+  const float2* wb = sW + (4 * kq) * G2_WP + li;
+  auto request = [&](int g, int buf) {
 #pragma unroll
-  for (int r = 0; r < G2_NR; ++r) {
-    if (r < R) {
+    for (int rr = 0; rr < 4; ++rr) bv[buf][rr] = wb[(g * 16 + rr) * G2_WP];
+  };
+  request(0, 0);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        float2 bv[4];
+  for (int g = 0; g < 2 * (G2_NR + 1); ++g) {
+    if (g + 1 < 2 * (G2_NR + 1)) request(g + 1, (g + 1) & 1);
+    G2_SCHED_BARRIER();
+    float av[4];
+    if (g < 2 * G2_NR) {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) bv[rr] = sW2[(r * 32 + 16 * t + 4 * kq + rr) * 16 + li];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const float av = acc[r][t][rr];
-          if (rr & 1) {
-            o0b = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[rr].x, o0b, 0, 0, 0);
-            o1b = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[rr].y, o1b, 0, 0, 0);
-          } else {
-            o0a = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[rr].x, o0a, 0, 0, 0);
-            o1a = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[rr].y, o1a, 0, 0, 0);
-          }
-        }
-      }
-    }
-  }
-  {
-    float av[8];
-    float2 bv[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      av[j] = xrows[li * G2_XP + 4 * j + kq];
-      bv[j] = sW2[(G2_NR * 32 + 4 * j + kq) * 16 + li];
+      for (int rr = 0; rr < 4; ++rr) av[rr] = acc[g >> 1][g & 1][rr];
+    } else {
+      const float4 xv = (g & 1) ? x1 : x0;
+      av[0] = xv.x; av[1] = xv.y; av[2] = xv.z; av[3] = xv.w;
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (j & 1) {
-        o0b = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j].x, o0b, 0, 0, 0);
-        o1b = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j].y, o1b, 0, 0, 0);
+    for (int rr = 0; rr < 4; ++rr) {
+      if (rr & 1) {
+        o0b = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rr], bv[g & 1][rr].x, o0b, 0, 0, 0);
+        o1b = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rr], bv[g & 1][rr].y, o1b, 0, 0, 0);
       } else {
-        o0a = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j].x, o0a, 0, 0, 0);
-        o1a = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j].y, o1a, 0, 0, 0);
+        o0a = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rr], bv[g & 1][rr].x, o0a, 0, 0, 0);
+        o1a = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rr], bv[g & 1][rr].y, o1a, 0, 0, 0);
       }
     }
+    G2_SCHED_BARRIER();
   }
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
@@ -339,9 +358,8 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
   float* HSS = S + lay.hs;                              // [4][16][G2_XP] h_{l-1} rows of the bundle (backward)
   float* TILES = S + lay.tile;                          // [4][16][G2_TP] T' rows of the bundle (backward)
   float* HIST = S + lay.hist;                           // [4][16][G2_XP] layer-0 input [code histogram | onehot | 1]
-  float2* sW2 = (float2*)(S + lay.wreg);                // [192][16] B operand of the layer
+  float2* sW2 = (float2*)(S + lay.wreg);                // [192][G2_WP] B operand of the layer
   float* sT0 = S + lay.t0;                              // [32][32] layer-0 table
-  float* s_att = S + lay.att;
   float* sfeat = S + lay.head;            // [256] centre-node readout
   float* sgf = sfeat + 256;               // [256] d feat
   float* sa1 = sgf + 256;                 // [128]
@@ -349,7 +367,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
   float* sdz = skeep + 128;               // [128]
   float* sred = sdz + 128;                // [256]
   float* misc = sred + 256;               // [16]
-  const int R = m.R, L = m.L, RL = R * L, LF = L * 32, na = R * 4;
+  const int R = m.R, L = m.L, RL = R * L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int B = b.totals[3];
@@ -373,30 +391,25 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
   auto tag16 = [&](int x) { return 1u + (tag0 + (uint32_t)x) % 65535u; };
   G2_STAMP(0);
 
-  // ---- layer-0 table, staged once per workgroup
-  for (int i = tid; i < 1024; i += G2_THREADS) {
-    const int c = i >> 5, f = i & 31;
-    float s = 0.f;
-    if (c < RL) {
-      const int r = c / L, cf = (c % L) * 32 + f;
-#pragma unroll
-      for (int bb = 0; bb < 4; ++bb) s += P[m.off_att[0] + r * 4 + bb] * P[m.off_basis[0] + bb * LF + cf];
-    } else if (c < RL + L) {
-      s = P[m.off_root[0] + (c - RL) * 32 + f];
-    } else if (c == RL + L) {
-      s = P[m.off_bias[0] + f];
-    }
-    sT0[i] = s;
+  // ---- the first subgraph's extents are requested before anything else (two dependent round trips overlap with
+  //      the staging of the layer-0 table, which k_g2_compose formed from the current weights)
+  const int g_first = (cs > 1) ? (int)(blockIdx.x % a.stride) : (int)blockIdx.x;
+  int pre_nb = 0, pre_n1 = 0, pre_cu = 0;
+  if (g_first < B) {
+    pre_nb = b.node_off[g_first];
+    pre_n1 = b.node_off[g_first + 1];
+    pre_cu = b.n_users[g_first];
   }
+  ((float4*)sT0)[tid] = ((const float4*)(m.g2_w + 6 * G2_WIMG))[tid];
   f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};        // layer-0 table gradient tile (code half, feature half) of this wave
   bool first_graph = true;
   G2_STAMP(1);
 
 #pragma unroll 1
-  for (int g = (cs > 1) ? (int)(blockIdx.x % a.stride) : (int)blockIdx.x; g < B; g += (cs > 1) ? B : (int)gridDim.x) {
-    const int nb = b.node_off[g];
-    const int N = b.node_off[g + 1] - nb;
-    const int cu = b.n_users[g], cv = N - cu;
+  for (int g = g_first; g < B; g += (cs > 1) ? B : (int)gridDim.x) {
+    const int nb = first_graph ? pre_nb : b.node_off[g];
+    const int N = (first_graph ? pre_n1 : b.node_off[g + 1]) - nb;
+    const int cu = first_graph ? pre_cu : b.n_users[g], cv = N - cu;
     const int n_own = side ? cv : cu, n_opp = side ? cu : cv;
     const int nbs = nb + (side ? cu : 0);                    // first node of this wave's side
     const int nbun = (n_own + 15) >> 4;
@@ -429,33 +442,49 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     }
-    // ---- set-up: labels, relm in the orientation of this workgroup's side(s), one-hot label planes, zeroed planes
-    for (int i = tid; i < 256; i += G2_THREADS) {
-      const int sd = i >> 7, k = i & 127;
+    // ---- set-up: labels, relm in the orientation of this workgroup's side(s), one-hot label planes, zeroed planes.
+    //      The global loads (one label per thread, <= 16 relm dwords per thread) are requested first, the LDS zero fills
+    //      (16-byte stores) run under their latency.
+    const int ld = b.relm_ld, ldw = ld >> 2;
+    int labv;
+    {
+      const int sd = tid >> 7, k = tid & 127;
       const int n_sd = sd ? cv : cu;
-      slab[i] = (k < n_sd) ? b.node_label[nb + (sd ? cu : 0) + k] : (unsigned char)255;
+      labv = (k < n_sd) ? (int)b.node_label[nb + (sd ? cu : 0) + k] : 255;
     }
-    for (int i = tid; i < nsides * (G2_NT * 32 * kp >> 1); i += G2_THREADS) PLN[i] = 0u;
-    for (int i = tid; i < nsides * (rmr * rmc >> 2); i += G2_THREADS) ((uint32_t*)RM)[i] = 0u;
-    for (int i = tid; i < 2 * G2_NW * 16 * G2_XP; i += G2_THREADS) XOA[i] = 0.f;
-    for (int i = tid; i < G2_NW * 16 * G2_XP; i += G2_THREADS) HIST[i] = 0.f;
+    uint32_t rmv[16];        // dword (tid & 31) of rows (tid >> 5) + 8 q  (ld <= 128 bytes, <= 128 rows)
+    {
+      const uint32_t* rm = (const uint32_t*)(b.relm + (size_t)g * b.cap_u * ld) + (tid >> 5) * ldw + (tid & 31);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) rmv[q] = ((tid & 31) < ldw && (tid >> 5) + 8 * q < cu) ? rm[8 * q * ldw] : 0u;
+    }
+    {
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = tid; i < nsides * (G2_NT * 32 * kp >> 3); i += G2_THREADS) ((float4*)PLN)[i] = z4;
+      for (int i = tid; i < nsides * (rmr * rmc >> 4); i += G2_THREADS) ((float4*)RM)[i] = z4;
+      for (int i = tid; i < 2 * G2_NW * 16 * G2_XP / 4; i += G2_THREADS) ((float4*)XOA)[i] = z4;
+      for (int i = tid; i < G2_NW * 16 * G2_XP / 4; i += G2_THREADS) ((float4*)HIST)[i] = z4;
+    }
+    slab[tid] = (unsigned char)labv;
     __syncthreads();
     G2_STAMP(2);
     {
-      const int ld = b.relm_ld;
-      const unsigned char* rm = b.relm + (size_t)g * b.cap_u * ld;
-      const int ldw = ld >> 2, nw = cu * ldw;
-      for (int i = tid; i < nw; i += G2_THREADS) {
-        const int u = i / ldw, c4 = (i - u * ldw) * 4;
-        const uint32_t w = ((const uint32_t*)rm)[i];
-        if (nsides == 2 || side == 0) {             // rows = users
-          if (c4 < rmc) *(uint32_t*)(RM + (size_t)u * rmc + c4) = w;
-        }
-        if (nsides == 2 || side == 1) {             // rows = items: the transposed copy
-          unsigned char* rt = RM + (size_t)((nsides == 2) ? 1 : 0) * rmr * rmc;
+      int tid_ = tid;
+      G2_OPAQUE(tid_);
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (c4 + q < cv) rt[(size_t)(c4 + q) * rmc + u] = (unsigned char)(w >> (8 * q));
+      for (int q = 0; q < 16; ++q) {
+        const int u = (tid_ >> 5) + 8 * q, c4 = (tid_ & 31) * 4;
+        if ((tid_ & 31) < ldw && u < cu) {
+          const uint32_t w = rmv[q];
+          if (nsides == 2 || side == 0) {             // rows = users
+            if (c4 < rmc) *(uint32_t*)(RM + (size_t)u * rmc + c4) = w;
+          }
+          if (nsides == 2 || side == 1) {             // rows = items: the transposed copy
+            unsigned char* rt = RM + (size_t)((nsides == 2) ? 1 : 0) * rmr * rmc;
+#pragma unroll
+            for (int q2 = 0; q2 < 4; ++q2)
+              if (c4 + q2 < cv) rt[(size_t)(c4 + q2) * rmc + u] = (unsigned char)(w >> (8 * q2));
+          }
         }
       }
       // one-hot planes of the labels of the opposite side(s): plane[label][node] = 1.0 (bf16)
@@ -498,44 +527,25 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
     __syncthreads();                    // RM is dead from here on (its bytes are the backward's tiles)
     G2_STAMP(4);
 
-    // weights of the NEXT conv layer to be staged: requested a phase ahead
-    float4 wb4[4], wr4;
-    float watt = 0.f;
-    auto wpre = [&](int l) {
-      const float* basis = P + m.off_basis[l];
+    // B operand of the next conv layer ([W_0; ..; W_4; root] or the transposes, composed once per step by
+    // k_g2_compose): requested a phase ahead, written to LDS by stage()
+    float4 wq[8];
+    auto wpre = [&](int l, int trans) {
+      const float4* src = (const float4*)(m.g2_w + (size_t)((l - 1) * 2 + trans) * G2_WIMG);
 #pragma unroll
-      for (int bb = 0; bb < 4; ++bb) wb4[bb] = *(const float4*)(basis + bb * 1024 + 4 * tid);
-      wr4 = *(const float4*)(P + m.off_root[l] + 4 * tid);
-      if (tid < na) watt = P[m.off_att[l] + tid];
-    };
-    wpre(1);
-    // B operand of a layer: [W_0; ..; W_R-1; 0..; root] (TRANS: their transposes), W_r = sum_b att[r,b] basis_b
-    auto stage = [&](bool trans) {
-      if (tid < na) s_att[tid] = watt;
-      const float4 (&b4)[4] = wb4;
-      const float4 r4 = wr4;
-      __syncthreads();
-      float* sW = (float*)sW2;
-      const int f = tid >> 3, n0 = (4 * tid) & 31;      // W_r[f][n0 .. n0 + 3]
-#pragma unroll
-      for (int r = 0; r <= G2_NR; ++r) {
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (r == G2_NR) {
-          v[0] = r4.x; v[1] = r4.y; v[2] = r4.z; v[3] = r4.w;
-        } else if (r < R) {
-#pragma unroll
-          for (int bb = 0; bb < 4; ++bb) {
-            const float at = s_att[r * 4 + bb];
-            v[0] += at * b4[bb].x; v[1] += at * b4[bb].y; v[2] += at * b4[bb].z; v[3] += at * b4[bb].w;
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (!trans) sW[((r * 32 + f) * 16 + ((n0 + q) & 15)) * 2 + ((n0 + q) >> 4)] = v[q];     // (k = f, n = n0 + q)
-          else sW[((r * 32 + n0 + q) * 16 + (f & 15)) * 2 + (f >> 4)] = v[q];                     // (k = n0 + q, n = f)
-        }
+      for (int q = 0; q < 8; ++q) {
+        const int i = tid + q * G2_THREADS;
+        wq[q] = (i < G2_WIMG / 4) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     };
+    auto stage = [&]() {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int i = tid + q * G2_THREADS;
+        if (i < G2_WIMG / 4) ((float4*)sW2)[i] = wq[q];
+      }
+    };
+    wpre(1, 0);
     // epilogue of a forward layer: tanh, own rows -> LDS tile + h_l (this wave re-reads them in the backward),
     // bf16 terms -> exchange x (l < 3), centre rows -> readout
     auto fwd_out = [&](int l, const f32x4 (&o)[2], float bias0, float bias1, float* XO) {
@@ -568,10 +578,8 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
           if (li < 8) pf = *(const u32x4*)(ohp + (li * kp >> 1) + 16 * s + 4 * kq);
 #pragma unroll
           for (int r = 0; r < G2_NR; ++r) {
-            if (r < R) {
-              const u32x4 af = {AF[r][s][0], AF[r][s][1], AF[r][s][2], AF[r][s][3]};
-              hacc[r] = g2_mfma_bf16(pf, af, hacc[r]);
-            }
+            const u32x4 af = {AF[r][s][0], AF[r][s][1], AF[r][s][2], AF[r][s][3]};
+            hacc[r] = g2_mfma_bf16(pf, af, hacc[r]);
           }
         }
       }
@@ -604,7 +612,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
     for (int l = 1; l < 4; ++l) {
       float* XOc = (l & 1) ? XO0 : XO1;             // x of the bundle's own rows (h_{l-1})
       float* XOn = (l & 1) ? XO1 : XO0;             // h_l
-      stage(false);
+      stage();
       G2_STAMP(6 + 3 * (l - 1));
       const float bias0 = P[m.off_bias[l] + li], bias1 = P[m.off_bias[l] + 16 + li];
       // the opposite side's h_{l-1} as bf16 planes
@@ -616,12 +624,15 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
       }
       __syncthreads();
       G2_STAMP(7 + 3 * (l - 1));
-      if (l < 3) wpre(l + 1);
+      if (l < 3) wpre(l + 1, 0);
       if (active) {
+        int lane_ = lane;
+        G2_OPAQUE(lane_);
+        const int li_ = lane_ & 15, kq_ = lane_ >> 4;
         f32x4 acc[G2_NR][2];
-        g2_gather(pl, kp, nks, R, AF, li, kq, acc);
+        g2_gather(pl, kp, nks, AF, li_, kq_, acc);
         f32x4 o[2];
-        g2_transform(acc, R, XOc, sW2, li, kq, o);
+        g2_transform(acc, XOc, sW2, li_, kq_, o);
         fwd_out(l, o, bias0, bias1, XOn);
       }
       G2_STAMP(36 + (l - 1));
@@ -743,7 +754,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
         const float hv = sfeat[side * 128 + 96 + lane];
         XO0[lane] = sgf[side * 128 + 96 + lane] * (1.f - hv * hv);
       }
-      wpre(3);
+      wpre(3, 1);
       __syncthreads();
       G2_STAMP(18);
 
@@ -752,7 +763,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
       for (int l = 3; l >= 1; --l) {
         float* XOc = (l & 1) ? XO0 : XO1;            // dPre_l of the bundle's own rows
         float* XOn = (l & 1) ? XO1 : XO0;            // dPre_{l-1}
-        stage(true);
+        stage();
         float* wpart = m.ts_part + ((size_t)l * IGMC_TS_BLOCKS + blockIdx.x) * ts;
         {   // d bias_l = column sums of dPre_l over this workgroup's rows (fixed order)
           const int n = tid & 31, part = tid >> 5;
@@ -783,9 +794,12 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
               const int row = 4 * kq + rr;
               if (row0 + row < n_own) hreg[nt][rr] = m.h[l - 1][(size_t)(nbs + row0 + row) * 32 + 16 * nt + li];
             }
+          int lane_ = lane;
+          G2_OPAQUE(lane_);
+          const int li_ = lane_ & 15, kq_ = lane_ >> 4;
           f32x4 acc[G2_NR][2];
-          if constexpr (FLAGS) g2_gather(pl, kp, (l == 3) ? 1 : nks, R, AB, li, kq, acc);
-          else g2_gather(pl, kp, (l == 3) ? 1 : nks, R, AF, li, kq, acc);
+          if constexpr (FLAGS) g2_gather(pl, kp, (l == 3) ? 1 : nks, AB, li_, kq_, acc);
+          else g2_gather(pl, kp, (l == 3) ? 1 : nks, AF, li_, kq_, acc);
           // T' rows of the bundle -> LDS (B operand of the weight-gradient table): lane = row, 4 consecutive features
 #pragma unroll
           for (int r = 0; r < G2_NR; ++r)
@@ -798,7 +812,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
             for (int rr = 0; rr < 4; ++rr) HS[(4 * kq + rr) * G2_XP + 16 * nt + li] = hreg[nt][rr];
           // dX = [T' | dPre_l] @ [W_r^T ; root^T], + readout gradient on the centre row, * tanh'(h_{l-1})
           f32x4 o[2];
-          g2_transform(acc, R, XOc, sW2, li, kq, o);
+          g2_transform(acc, XOc, sW2, li_, kq_, o);
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) {
             const int f = 16 * nt + li;
@@ -872,7 +886,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
         }
         G2_STAMP(22 + 5 * (3 - l));
         if (l > 1) {
-          wpre(l - 1);
+          wpre(l - 1, 1);
           for (int s2 = 0; s2 < nsides; ++s2) {
             const int sd = (nsides == 2) ? s2 : 1 - side;
             const int n_sd = sd ? cv : cu;
@@ -950,11 +964,62 @@ extern "C" int igmc_debug_g2_clocks(unsigned long long* out, int n) {
   return 0;
 }
 
+// Weights-only part of the step, formed ONCE per launch instead of by every workgroup and layer pass: the B operands
+// [W_0; ..; W_4; root] of the three conv layers (W_r = sum_b att[r,b] basis_b) in the LDS image of the forward
+// (element (k, n) at [k][n & 15].{x: n < 16, y: n >= 16}, rows padded to G2_WP float2) and of the backward (their
+// transposes), and the layer-0 table [W0[r*L + c] | root0[c] | bias0].  blockIdx.x: 2 (l - 1) + transposed, 6 = table.
+__global__ __launch_bounds__(G2_THREADS) void k_g2_compose(ModelDev m, const float* P, float* w) {
+  const int tid = threadIdx.x, R = m.R, L = m.L, RL = R * L, LF = L * 32;
+  if (blockIdx.x == 6) {
+    for (int i = tid; i < 1024; i += G2_THREADS) {
+      const int c = i >> 5, f = i & 31;
+      float s = 0.f;
+      if (c < RL) {
+        const int r = c / L, cf = (c % L) * 32 + f;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) s += P[m.off_att[0] + r * 4 + bb] * P[m.off_basis[0] + bb * LF + cf];
+      } else if (c < RL + L) {
+        s = P[m.off_root[0] + (c - RL) * 32 + f];
+      } else if (c == RL + L) {
+        s = P[m.off_bias[0] + f];
+      }
+      w[6 * G2_WIMG + i] = s;
+    }
+    return;
+  }
+  const int l = 1 + (blockIdx.x >> 1), trans = blockIdx.x & 1;
+  float* img = w + (size_t)blockIdx.x * G2_WIMG;
+  const float* basis = P + m.off_basis[l];
+  const int f = tid >> 3, n0 = (4 * tid) & 31;            // W_r[f][n0 .. n0 + 3]
+  float4 b4[4];
+#pragma unroll
+  for (int bb = 0; bb < 4; ++bb) b4[bb] = *(const float4*)(basis + bb * 1024 + 4 * tid);
+  const float4 r4 = *(const float4*)(P + m.off_root[l] + 4 * tid);
+#pragma unroll
+  for (int r = 0; r <= G2_NR; ++r) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r == G2_NR) {
+      v[0] = r4.x; v[1] = r4.y; v[2] = r4.z; v[3] = r4.w;
+    } else if (r < R) {
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) {
+        const float at = P[m.off_att[l] + r * 4 + bb];
+        v[0] += at * b4[bb].x; v[1] += at * b4[bb].y; v[2] += at * b4[bb].z; v[3] += at * b4[bb].w;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = trans ? r * 32 + n0 + q : r * 32 + f, n = trans ? f : n0 + q;
+      img[(k * G2_WP + (n & 15)) * 2 + (n >> 4)] = v[q];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 // LDS plan + eligibility for a batch arena / cluster size
 int igmc_g2_layout(const ModelDev& m, const BatchDev& b, int cs, G2Layout* lay) {
   const int RL = m.R * m.L;
-  if (m.S != 0 || m.D != 256 || m.R > G2_NR || m.L > 8 || RL + m.L + 1 > 32 || !m.ts_part || !m.g2_ex || !b.relm) return 0;
+  if (m.S != 0 || m.D != 256 || m.R > G2_NR || m.L > 8 || RL + m.L + 1 > 32 || !m.ts_part || !m.g2_ex || !m.g2_w || !b.relm) return 0;
   const int half = 2 * cs;
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
   if (cmax > 16 * half || cmax > 128) return 0;
@@ -976,7 +1041,7 @@ int igmc_g2_layout(const ModelDev& m, const BatchDev& b, int cs, G2Layout* lay) 
   if (tw < 1024) tw = 1024;
   lay->tile = o; o += tw;
   lay->hist = o; o += G2_NW * 16 * G2_XP;
-  lay->wreg = o; o += (G2_NR * 32 + 32) * 32;
+  lay->wreg = o; o += G2_WIMG;
   lay->t0 = o; o += 1024;
   lay->att = o; o += 64;
   lay->head = o; o += 256 + 256 + 3 * 128 + 256 + 16;
@@ -1014,8 +1079,9 @@ void igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* 
   a.stride = (cs > 1) ? ((B + 7) & ~7) : 1;
   const int grid = (cs > 1) ? cs * a.stride : igmc_gs_grid(B);
   const size_t sm = (size_t)lay.words * 4;
+  IGMC_PLAUNCH("k_g2_compose", k_g2_compose, 7, G2_THREADS, 0, stream, m, P, m.g2_w);
 #ifdef IGMC_HIPEMU
-  if (cs > 1) {
+  if (cs > 1) {        // (after the launch above: a launch consumes the co-residency request)
     hipemu::rt().co_cs = cs;
     hipemu::rt().co_stride = a.stride;
   }

@@ -49,6 +49,7 @@ struct ModelDev {
   size_t g2_ex_stride;         // words per exchange
   unsigned long long* g2_fx;   // [g2_graphs][256] {f32, tag} words of the centre-node readout
   int g2_graphs;               // subgraph slots of the two buffers above (0: not allocated)
+  float* g2_w;                 // [6 images of (5*32+32) x 20 float2 | 1024] composed weights of the step (k_g2_compose)
   float* arr_part;    // [4] ARR regulariser per layer
   const float* side;  // [B,S] borrowed side features or NULL
   const int64_t* ctrl;  // optional device-side step control (igmc_hip.h) or NULL
