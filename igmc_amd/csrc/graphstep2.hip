@@ -48,8 +48,8 @@
 #define G2_WIMG ((G2_NR * 32 + 32) * G2_WP * 2)      // floats of one staged image
 
 // phase clocks (debug aid, IGMC_GS_TIMING=1; igmc_debug_g2_clocks): thread 0 of workgroup 0 (member 0, user side) -> slots
-// 0..39, thread 0 of member 2 of the same subgraph (item side) -> slots 40..79
-__device__ unsigned long long g_g2_clk[80];
+// 0..39 (fine stamps of its wave 0: 40..63), thread 0 of member 2 of the same subgraph (item side) -> slots 64..103
+__device__ unsigned long long g_g2_clk[128];
 #ifdef IGMC_HIPEMU
 #define G2_STAMP(k) do { } while (0)
 #else
@@ -57,7 +57,7 @@ __device__ unsigned long long g_g2_clk[80];
   do {                                                                                                     \
     if (a.timing && threadIdx.x == 0) {                                                                    \
       if (blockIdx.x == 0) g_g2_clk[k] = __builtin_readcyclecounter();                                     \
-      else if (a.cs > 2 && (int)blockIdx.x == 2 * a.stride) g_g2_clk[40 + (k)] = __builtin_readcyclecounter(); \
+      else if (a.cs > 2 && (int)blockIdx.x == 2 * a.stride && (k) < 40) g_g2_clk[64 + (k)] = __builtin_readcyclecounter(); \
     }                                                                                                      \
   } while (0)
 #endif
@@ -351,8 +351,8 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
   const int kp = lay.kp, nsides = lay.nsides;
   uint32_t* PLN = (uint32_t*)(S + lay.planes);          // [nsides][3 terms][32 features][kp] bf16: gather source
   uint32_t* OHP = (uint32_t*)(S + lay.ohp);             // [nsides][8 labels][kp] bf16 one-hot label planes (layer 0)
-  unsigned char* RM = (unsigned char*)(S + lay.tile);   // [nsides][rmr][rmc] bytes: relm in the orientation of the side's
-                                                        // rows (set-up only: aliases the backward's T' tiles)
+  unsigned char* RM = (unsigned char*)(S + lay.tile);   // [2][rmr][rmc + 8] bytes: relm (rows = users) and its transpose
+                                                        // (rows = items); set-up only: aliases the backward's T' tiles
   unsigned char* slab = (unsigned char*)(S + lay.lab);  // [2][128] node labels of both sides
   float* XOA = S + lay.xo;                              // [2][4 waves][16][G2_XP]: the bundle's own rows of x / dPre
   float* HSS = S + lay.hs;                              // [4][16][G2_XP] h_{l-1} rows of the bundle (backward)
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
   const int half = 2 * cs;                              // waves of the cluster per side
   const int gw = cm * G2_NW + wave;
   const int side = gw / half, bi = gw - side * half;    // this wave's side (0 users, 1 items) and bundle of that side
-  const int rmr = lay.rmr, rmc = lay.rmc;
+  const int rmr = lay.rmr, rmc = lay.rmc, rmp = lay.rmc + 8;      // image rows, columns, row pitch (bytes)
 #ifndef IGMC_HIPEMU
   const uint32_t seq = (uint32_t)__hip_atomic_load(m.gs_bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
@@ -458,35 +458,44 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
 #pragma unroll
       for (int q = 0; q < 16; ++q) rmv[q] = ((tid & 31) < ldw && (tid >> 5) + 8 * q < cu) ? rm[8 * q * ldw] : 0u;
     }
+    G2_STAMP(48);
     {
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int i = tid; i < nsides * (G2_NT * 32 * kp >> 3); i += G2_THREADS) ((float4*)PLN)[i] = z4;
-      for (int i = tid; i < nsides * (rmr * rmc >> 4); i += G2_THREADS) ((float4*)RM)[i] = z4;
+      for (int i = tid; i < (2 * rmr * rmp >> 4); i += G2_THREADS) ((float4*)RM)[i] = z4;
       for (int i = tid; i < 2 * G2_NW * 16 * G2_XP / 4; i += G2_THREADS) ((float4*)XOA)[i] = z4;
       for (int i = tid; i < G2_NW * 16 * G2_XP / 4; i += G2_THREADS) ((float4*)HIST)[i] = z4;
     }
+    G2_STAMP(49);
     slab[tid] = (unsigned char)labv;
+    G2_STAMP(50);
     __syncthreads();
     G2_STAMP(2);
     {
       int tid_ = tid;
       G2_OPAQUE(tid_);
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
+      for (int q = 0; q < 16; ++q) {        // row-major image (rows = users): one dword per lane, conflict-free
         const int u = (tid_ >> 5) + 8 * q, c4 = (tid_ & 31) * 4;
-        if ((tid_ & 31) < ldw && u < cu) {
-          const uint32_t w = rmv[q];
-          if (nsides == 2 || side == 0) {             // rows = users
-            if (c4 < rmc) *(uint32_t*)(RM + (size_t)u * rmc + c4) = w;
-          }
-          if (nsides == 2 || side == 1) {             // rows = items: the transposed copy
-            unsigned char* rt = RM + (size_t)((nsides == 2) ? 1 : 0) * rmr * rmc;
-#pragma unroll
-            for (int q2 = 0; q2 < 4; ++q2)
-              if (c4 + q2 < cv) rt[(size_t)(c4 + q2) * rmc + u] = (unsigned char)(w >> (8 * q2));
-          }
+        if ((tid_ & 31) < ldw && u < cu && c4 < rmc) *(uint32_t*)(RM + (size_t)u * rmp + c4) = rmv[q];
+      }
+    }
+    if (nsides == 2 || side == 1) {
+      // the transposed image (rows = items) from the row-major one: lane = item v, dword = users 4 u4 .. 4 u4 + 3
+      // (byte reads of consecutive items are one LDS dword; the pitch rmc + 8 spreads the dword writes over 16 banks)
+      __syncthreads();
+      unsigned char* rt = RM + (size_t)rmr * rmp;
+      const int nu4 = (cu + 3) >> 2;
+      for (int i = tid; i < 128 * nu4; i += G2_THREADS) {
+        const int v = i & 127, u4 = i >> 7;
+        if (v < cv) {
+          const unsigned char* p = RM + (size_t)(4 * u4) * rmp + v;
+          const uint32_t w = (uint32_t)p[0] | ((uint32_t)p[rmp] << 8) | ((uint32_t)p[2 * rmp] << 16) | ((uint32_t)p[3 * rmp] << 24);
+          *(uint32_t*)(rt + (size_t)v * rmp + 4 * u4) = w;
         }
       }
+    }
+    {
       // one-hot planes of the labels of the opposite side(s): plane[label][node] = 1.0 (bf16)
       for (int i = tid; i < nsides * 8 * (kp >> 1); i += G2_THREADS) {
         const int s2 = i / (8 * (kp >> 1)), rem = i - s2 * (8 * (kp >> 1));
@@ -503,7 +512,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
     uint32_t AF[G2_NR][G2_KS][4];
     uint32_t AB[FLAGS ? G2_NR : 1][FLAGS ? G2_KS : 1][4];
     {
-      const unsigned char* rmo = RM + (size_t)sx * rmr * rmc + (size_t)(row0 + li) * rmc;
+      const unsigned char* rmo = RM + (size_t)side * rmr * rmp + (size_t)(row0 + li) * rmp;
       const int kf = side ? 4 : 3, kb = side ? 3 : 4;     // keep bit of the edge  opposite -> own  /  own -> opposite
 #pragma unroll
       for (int s = 0; s < G2_KS; ++s) {
@@ -583,6 +592,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
           }
         }
       }
+      G2_STAMP(51);
       // lane (row li, kq): counts of labels 4 kq + rr -> the row's input vector [hist | onehot(own label) | 1]
 #pragma unroll
       for (int r = 0; r < G2_NR; ++r)
@@ -603,6 +613,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
         o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sT0[(4 * j + kq) * 32 + li], o[0], 0, 0, 0);
         o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sT0[(4 * j + kq) * 32 + 16 + li], o[1], 0, 0, 0);
       }
+      G2_STAMP(52);
       fwd_out(0, o, 0.f, 0.f, XO0);
     }
     G2_STAMP(5);
@@ -631,8 +642,10 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
         const int li_ = lane_ & 15, kq_ = lane_ >> 4;
         f32x4 acc[G2_NR][2];
         g2_gather(pl, kp, nks, AF, li_, kq_, acc);
+        if (l == 2) G2_STAMP(40);
         f32x4 o[2];
         g2_transform(acc, XOc, sW2, li_, kq_, o);
+        if (l == 2) G2_STAMP(41);
         fwd_out(l, o, bias0, bias1, XOn);
       }
       G2_STAMP(36 + (l - 1));
@@ -657,6 +670,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
         s += w4[q].x * f4.x + w4[q].y * f4.y + w4[q].z * f4.z + w4[q].w * f4.w;
       }
       s += __shfl_xor(s, 1, 4);
+      G2_STAMP(54);
       if (part == 0) {
         float av = s + P[m.off_l1b + ju];
         av = av > 0.f ? av : 0.f;
@@ -798,8 +812,10 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
           G2_OPAQUE(lane_);
           const int li_ = lane_ & 15, kq_ = lane_ >> 4;
           f32x4 acc[G2_NR][2];
+          if (l == 2) G2_STAMP(43);
           if constexpr (FLAGS) g2_gather(pl, kp, (l == 3) ? 1 : nks, AB, li_, kq_, acc);
           else g2_gather(pl, kp, (l == 3) ? 1 : nks, AF, li_, kq_, acc);
+          if (l == 2) G2_STAMP(44);
           // T' rows of the bundle -> LDS (B operand of the weight-gradient table): lane = row, 4 consecutive features
 #pragma unroll
           for (int r = 0; r < G2_NR; ++r)
@@ -812,7 +828,9 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
             for (int rr = 0; rr < 4; ++rr) HS[(4 * kq + rr) * G2_XP + 16 * nt + li] = hreg[nt][rr];
           // dX = [T' | dPre_l] @ [W_r^T ; root^T], + readout gradient on the centre row, * tanh'(h_{l-1})
           f32x4 o[2];
+          if (l == 2) G2_STAMP(45);
           g2_transform(acc, XOc, sW2, li_, kq_, o);
+          if (l == 2) G2_STAMP(46);
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) {
             const int f = 16 * nt + li;
@@ -955,7 +973,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
 // debug aid: phase clocks (shader cycles) of the last k_graph_step2 launched with IGMC_GS_TIMING set
 extern "C" int igmc_debug_g2_clocks(unsigned long long* out, int n) {
 #ifndef IGMC_HIPEMU
-  if (n > 80) n = 80;
+  if (n > 128) n = 128;
   if (hipDeviceSynchronize() != hipSuccess) return 1;
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_g2_clk), (size_t)n * sizeof(unsigned long long)) != hipSuccess) return 1;
 #else
@@ -969,25 +987,36 @@ extern "C" int igmc_debug_g2_clocks(unsigned long long* out, int n) {
 // (element (k, n) at [k][n & 15].{x: n < 16, y: n >= 16}, rows padded to G2_WP float2) and of the backward (their
 // transposes), and the layer-0 table [W0[r*L + c] | root0[c] | bias0].  blockIdx.x: 2 (l - 1) + transposed, 6 = table.
 __global__ __launch_bounds__(G2_THREADS) void k_g2_compose(ModelDev m, const float* P, float* w) {
+  __shared__ float s_att[32];
   const int tid = threadIdx.x, R = m.R, L = m.L, RL = R * L, LF = L * 32;
+  const int l = (blockIdx.x == 6) ? 0 : 1 + (blockIdx.x >> 1), trans = blockIdx.x & 1;
+  // every global load of the block is requested before the first use (one round trip)
+  const float attv = (tid < R * 4) ? P[m.off_att[l] + tid] : 0.f;
   if (blockIdx.x == 6) {
-    for (int i = tid; i < 1024; i += G2_THREADS) {
-      const int c = i >> 5, f = i & 31;
-      float s = 0.f;
-      if (c < RL) {
-        const int r = c / L, cf = (c % L) * 32 + f;
+    float bv[4][4], rv[4];
 #pragma unroll
-        for (int bb = 0; bb < 4; ++bb) s += P[m.off_att[0] + r * 4 + bb] * P[m.off_basis[0] + bb * LF + cf];
-      } else if (c < RL + L) {
-        s = P[m.off_root[0] + (c - RL) * 32 + f];
-      } else if (c == RL + L) {
-        s = P[m.off_bias[0] + f];
+    for (int q = 0; q < 4; ++q) {
+      const int i = tid + q * G2_THREADS, c = i >> 5, f = i & 31;
+      const int cf = (c < RL) ? (c % L) * 32 + f : 0;
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb) bv[q][bb] = (c < RL) ? P[m.off_basis[0] + bb * LF + cf] : 0.f;
+      rv[q] = (c >= RL && c < RL + L) ? P[m.off_root[0] + (c - RL) * 32 + f] : ((c == RL + L) ? P[m.off_bias[0] + f] : 0.f);
+    }
+    if (tid < 32) s_att[tid] = attv;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = tid + q * G2_THREADS, c = i >> 5;
+      float sacc = rv[q];
+      if (c < RL) {
+        const int r = c / L;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) sacc += s_att[r * 4 + bb] * bv[q][bb];
       }
-      w[6 * G2_WIMG + i] = s;
+      w[6 * G2_WIMG + i] = sacc;
     }
     return;
   }
-  const int l = 1 + (blockIdx.x >> 1), trans = blockIdx.x & 1;
   float* img = w + (size_t)blockIdx.x * G2_WIMG;
   const float* basis = P + m.off_basis[l];
   const int f = tid >> 3, n0 = (4 * tid) & 31;            // W_r[f][n0 .. n0 + 3]
@@ -995,6 +1024,8 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_compose(ModelDev m, const flo
 #pragma unroll
   for (int bb = 0; bb < 4; ++bb) b4[bb] = *(const float4*)(basis + bb * 1024 + 4 * tid);
   const float4 r4 = *(const float4*)(P + m.off_root[l] + 4 * tid);
+  if (tid < 32) s_att[tid] = attv;
+  __syncthreads();
 #pragma unroll
   for (int r = 0; r <= G2_NR; ++r) {
     float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1003,7 +1034,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_compose(ModelDev m, const flo
     } else if (r < R) {
 #pragma unroll
       for (int bb = 0; bb < 4; ++bb) {
-        const float at = P[m.off_att[l] + r * 4 + bb];
+        const float at = s_att[r * 4 + bb];
         v[0] += at * b4[bb].x; v[1] += at * b4[bb].y; v[2] += at * b4[bb].z; v[3] += at * b4[bb].w;
       }
     }
@@ -1036,7 +1067,7 @@ int igmc_g2_layout(const ModelDev& m, const BatchDev& b, int cs, G2Layout* lay) 
   lay->xo = o; o += 2 * G2_NW * 16 * G2_XP;
   lay->hs = o; o += G2_NW * 16 * G2_XP;
   int tw = G2_NW * 16 * G2_TP;
-  const int rw = lay->nsides * lay->rmr * lay->rmc / 4;
+  const int rw = 2 * lay->rmr * (lay->rmc + 8) / 4;
   if (rw > tw) tw = rw;
   if (tw < 1024) tw = 1024;
   lay->tile = o; o += tw;

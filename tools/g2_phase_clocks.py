@@ -42,20 +42,32 @@ def main():
     for _ in range(20):
         sg.step()
     torch.cuda.synchronize()
-    buf = np.zeros(80, np.uint64)
-    lib.cdll.igmc_debug_g2_clocks(C.c_void_p(buf.ctypes.data), 80)
+    buf = np.zeros(128, np.uint64)
+    lib.cdll.igmc_debug_g2_clocks(C.c_void_p(buf.ctypes.data), 128)
     c = buf.astype(np.int64)
     print('overlap=%s; cycles per phase: member 0 (users) | member 2 (items); stamp 36..38 = wave 0 done with its L1..L3 bundle' % ov)
-    for base, nm in ((0, 'member 0'), (40, 'member 2')):
+    for base, nm in ((0, 'member 0'), (64, 'member 2')):
         print(nm, 'start offset vs member 0: %d' % (c[base] - c[0]))
     for k in ORDER:
         a0 = c[k] - c[k - 1]
-        a2 = c[40 + k] - c[40 + k - 1]
+        a2 = c[64 + k] - c[64 + k - 1]
         print('%-28s %8d | %8d' % (NAMES[k], a0, a2))
-    print('total                        %8d | %8d' % (c[35] - c[0], c[75] - c[40]))
+    print('total                        %8d | %8d' % (c[35] - c[0], c[99] - c[64]))
     for l in (1, 2, 3):
-        print('L%d fwd: wave 0 compute alone %d | %d' % (l, c[36 + l - 1] - c[7 + 3 * (l - 1)], c[76 + l - 1] - c[47 + 3 * (l - 1)]))
+        print('L%d fwd: wave 0 compute alone %d | %d' % (l, c[36 + l - 1] - c[7 + 3 * (l - 1)], c[100 + l - 1] - c[71 + 3 * (l - 1)]))
+    fine(c)
+
+
+def fine(c):
+    print('set-up (member 0): loop start -> loads issued %d | zero fills %d | label store %d | barrier %d' % (
+        c[48] - c[1], c[49] - c[48], c[50] - c[49], c[2] - c[50]))
+    print('layer 0: hist MFMAs %d | tile + transform %d | epilogue %d' % (c[51] - c[4], c[52] - c[51], c[5] - c[52]))
+    print('L2 fwd wave 0: gather %d | transform %d | epilogue %d' % (c[40] - c[10], c[41] - c[40], c[37] - c[41]))
+    print('B2 wave 0: h loads issued %d | gather %d | tile + HS writes %d | transform %d | epilogue %d' % (
+        c[43] - c[24], c[44] - c[43], c[45] - c[44], c[46] - c[45], c[25] - c[46]))
+    print('head: readout -> lin1 dot done %d | rest of head forward %d' % (c[54] - c[15], c[16] - c[54]))
 
 
 if __name__ == '__main__':
     main()
+
