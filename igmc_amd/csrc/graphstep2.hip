@@ -125,7 +125,7 @@ __device__ __forceinline__ float g2_tanh(float x) {
 #ifdef IGMC_HIPEMU
   return tanhf(x);
 #else
-  return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x));
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x));
 #endif
 }
 
@@ -271,8 +271,8 @@ __device__ __forceinline__ void g2_gather(const uint32_t* pl, int kp, int nks, c
 #pragma unroll
   for (int s = 0; s < G2_KS; ++s) {
     if (s < nks) {
-      if (s + 1 < G2_KS && s + 1 < nks) request(s + 1, (s + 1) & 1);
-      G2_SCHED_BARRIER();
+      if (s + 1 < G2_KS) request(s + 1, (s + 1) & 1);      // unconditional (a k-step past the side reads bytes that are
+      G2_SCHED_BARRIER();                                  // never used): a guarded request is sunk below the MFMAs
 #pragma unroll
       for (int q = 0; q < 2 * G2_NT; ++q) {
 #pragma unroll
@@ -394,12 +394,8 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
   // ---- the first subgraph's extents are requested before anything else (two dependent round trips overlap with
   //      the staging of the layer-0 table, which k_g2_compose formed from the current weights)
   const int g_first = (cs > 1) ? (int)(blockIdx.x % a.stride) : (int)blockIdx.x;
-  int pre_nb = 0, pre_n1 = 0, pre_cu = 0;
-  if (g_first < B) {
-    pre_nb = b.node_off[g_first];
-    pre_n1 = b.node_off[g_first + 1];
-    pre_cu = b.n_users[g_first];
-  }
+  const int g_pre = (g_first < b.graph_cap) ? g_first : b.graph_cap - 1;      // (a padding workgroup: any valid slot)
+  const int pre_nb = b.node_off[g_pre], pre_n1 = b.node_off[g_pre + 1], pre_cu = b.n_users[g_pre];
   ((float4*)sT0)[tid] = ((const float4*)(m.g2_w + 6 * G2_WIMG))[tid];
   f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};        // layer-0 table gradient tile (code half, feature half) of this wave
   bool first_graph = true;
@@ -407,6 +403,16 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
 
 #pragma unroll 1
   for (int g = g_first; g < B; g += (cs > 1) ? B : (int)gridDim.x) {
+    // the set-up's global loads depend on g only (labels from the per-graph scratch slots, relm rows up to the slot
+    // capacity): ONE round trip together with the subgraph's extents
+    const int ld = b.relm_ld, ldw = ld >> 2;
+    const int labv_raw = (int)b.s_lab[(size_t)g * b.slot + ((tid >> 7) ? b.cap_u : 0) + (((tid & 127) < ((tid >> 7) ? b.cap_v : b.cap_u)) ? (tid & 127) : 0)];
+    uint32_t rmv[16];        // dword (tid & 31) of rows (tid >> 5) + 8 q  (ld <= 128 bytes, <= 128 rows)
+    {
+      const uint32_t* rm = (const uint32_t*)(b.relm + (size_t)g * b.cap_u * ld) + (tid >> 5) * ldw + (tid & 31);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) rmv[q] = ((tid & 31) < ldw && (tid >> 5) + 8 * q < b.cap_u) ? rm[8 * q * ldw] : 0u;
+    }
     const int nb = first_graph ? pre_nb : b.node_off[g];
     const int N = (first_graph ? pre_n1 : b.node_off[g + 1]) - nb;
     const int cu = first_graph ? pre_cu : b.n_users[g], cv = N - cu;
@@ -445,19 +451,6 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
     // ---- set-up: labels, relm in the orientation of this workgroup's side(s), one-hot label planes, zeroed planes.
     //      The global loads (one label per thread, <= 16 relm dwords per thread) are requested first, the LDS zero fills
     //      (16-byte stores) run under their latency.
-    const int ld = b.relm_ld, ldw = ld >> 2;
-    int labv;
-    {
-      const int sd = tid >> 7, k = tid & 127;
-      const int n_sd = sd ? cv : cu;
-      labv = (k < n_sd) ? (int)b.node_label[nb + (sd ? cu : 0) + k] : 255;
-    }
-    uint32_t rmv[16];        // dword (tid & 31) of rows (tid >> 5) + 8 q  (ld <= 128 bytes, <= 128 rows)
-    {
-      const uint32_t* rm = (const uint32_t*)(b.relm + (size_t)g * b.cap_u * ld) + (tid >> 5) * ldw + (tid & 31);
-#pragma unroll
-      for (int q = 0; q < 16; ++q) rmv[q] = ((tid & 31) < ldw && (tid >> 5) + 8 * q < cu) ? rm[8 * q * ldw] : 0u;
-    }
     G2_STAMP(48);
     {
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -467,7 +460,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
       for (int i = tid; i < G2_NW * 16 * G2_XP / 4; i += G2_THREADS) ((float4*)HIST)[i] = z4;
     }
     G2_STAMP(49);
-    slab[tid] = (unsigned char)labv;
+    slab[tid] = (unsigned char)(((tid & 127) < ((tid >> 7) ? cv : cu)) ? labv_raw : 255);
     G2_STAMP(50);
     __syncthreads();
     G2_STAMP(2);
@@ -558,19 +551,23 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
     // epilogue of a forward layer: tanh, own rows -> LDS tile + h_l (this wave re-reads them in the backward),
     // bf16 terms -> exchange x (l < 3), centre rows -> readout
     auto fwd_out = [&](int l, const f32x4 (&o)[2], float bias0, float bias1, float* XO) {
+      float* hrow = m.h[l] + (size_t)(nbs + row0 + 4 * kq) * 32 + li;                 // rows 4 kq + rr, feature li (+ 16)
+      unsigned long long* exl = m.g2_ex + l * exs + ((size_t)g * 2 + side) * 4096 + (size_t)li * 128 + row0 + 4 * kq;
+      float* xo = XO + 4 * kq * G2_XP + li;
+      const uint32_t tg = tag16(l);
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        const int f = 16 * nt + li;
         float v[4];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          const int row = 4 * kq + rr;
-          v[rr] = (row0 + row < n_own) ? g2_tanh(o[nt][rr] + (nt ? bias1 : bias0)) : 0.f;
-          XO[row * G2_XP + f] = v[rr];
-          if (TRAIN && row0 + row < n_own) m.h[l][(size_t)(nbs + row0 + row) * 32 + f] = v[rr];
+          const float tv = g2_tanh(o[nt][rr] + (nt ? bias1 : bias0));
+          const bool ok = row0 + 4 * kq + rr < n_own;
+          v[rr] = ok ? tv : 0.f;
+          xo[rr * G2_XP + 16 * nt] = v[rr];
+          if (TRAIN && ok) hrow[rr * 32 + 16 * nt] = v[rr];
         }
-        if (l < 3) g2_publish4(m.g2_ex + l * exs + ((size_t)g * 2 + side) * 4096 + f * 128, row0 + 4 * kq, v, tag16(l));
-        if (bi == 0 && kq == 0) g2_pub_f32(fx + side * 128 + l * 32 + f, v[0], tag0 + G2_FXTAG);
+        if (l < 3) g2_publish4(exl + nt * 16 * 128, 0, v, tg);
+        if (bi == 0 && kq == 0) g2_pub_f32(fx + side * 128 + l * 32 + 16 * nt + li, v[0], tag0 + G2_FXTAG);
       }
     };
 
@@ -580,16 +577,19 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
       f32x4 hacc[G2_NR];
 #pragma unroll
       for (int r = 0; r < G2_NR; ++r) hacc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      u32x4 pfh[G2_KS];
 #pragma unroll
       for (int s = 0; s < G2_KS; ++s) {
-        if (s < nks) {
-          u32x4 pf = {0u, 0u, 0u, 0u};
-          if (li < 8) pf = *(const u32x4*)(ohp + (li * kp >> 1) + 16 * s + 4 * kq);
+        pfh[s] = *(const u32x4*)(ohp + ((li & 7) * kp >> 1) + 16 * s + 4 * kq);
+        if (li >= 8 || s >= nks) pfh[s] = (u32x4){0u, 0u, 0u, 0u};      // (never feed bytes from beyond the image)
+      }
+      G2_SCHED_BARRIER();
 #pragma unroll
-          for (int r = 0; r < G2_NR; ++r) {
-            const u32x4 af = {AF[r][s][0], AF[r][s][1], AF[r][s][2], AF[r][s][3]};
-            hacc[r] = g2_mfma_bf16(pf, af, hacc[r]);
-          }
+      for (int s = 0; s < G2_KS; ++s) {
+#pragma unroll
+        for (int r = 0; r < G2_NR; ++r) {
+          const u32x4 af = {AF[r][s][0], AF[r][s][1], AF[r][s][2], AF[r][s][3]};
+          hacc[r] = g2_mfma_bf16(pfh[s], af, hacc[r]);
         }
       }
       G2_STAMP(51);
@@ -635,6 +635,9 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
       }
       __syncthreads();
       G2_STAMP(7 + 3 * (l - 1));
+      float bias0_ = bias0, bias1_ = bias1;       // landed: no wait for them is left inside the epilogue (a wait there
+      G2_OPAQUE(bias0_);                          // would also drain the epilogue's own stores, one round trip each)
+      G2_OPAQUE(bias1_);
       if (l < 3) wpre(l + 1, 0);
       if (active) {
         int lane_ = lane;
@@ -646,7 +649,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
         f32x4 o[2];
         g2_transform(acc, XOc, sW2, li_, kq_, o);
         if (l == 2) G2_STAMP(41);
-        fwd_out(l, o, bias0, bias1, XOn);
+        fwd_out(l, o, bias0_, bias1_, XOn);
       }
       G2_STAMP(36 + (l - 1));
       __syncthreads();                              // planes / sW2 may be overwritten
@@ -801,13 +804,14 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
           for (int rr = 0; rr < 4; ++rr) hreg[nt][rr] = 0.f;
         if (active) {
           // h_{l-1} of the bundle's rows (written by this very wave in the forward): tanh' and the table product
+          {
+            const float* hrow = m.h[l - 1] + (size_t)(nbs + row0 + 4 * kq) * 32 + li;
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-              const int row = 4 * kq + rr;
-              if (row0 + row < n_own) hreg[nt][rr] = m.h[l - 1][(size_t)(nbs + row0 + row) * 32 + 16 * nt + li];
-            }
+              for (int rr = 0; rr < 4; ++rr)
+                if (row0 + 4 * kq + rr < n_own) hreg[nt][rr] = hrow[rr * 32 + 16 * nt];
+          }
           int lane_ = lane;
           G2_OPAQUE(lane_);
           const int li_ = lane_ & 15, kq_ = lane_ >> 4;
@@ -828,6 +832,8 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
             for (int rr = 0; rr < 4; ++rr) HS[(4 * kq + rr) * G2_XP + 16 * nt + li] = hreg[nt][rr];
           // dX = [T' | dPre_l] @ [W_r^T ; root^T], + readout gradient on the centre row, * tanh'(h_{l-1})
           f32x4 o[2];
+          unsigned long long* exb = m.g2_ex + (6 - l) * exs + ((size_t)g * 2 + side) * 4096 + (size_t)li * 128 + row0 + 4 * kq;
+          const uint32_t tgb = tag16(6 - l);
           if (l == 2) G2_STAMP(45);
           g2_transform(acc, XOc, sW2, li_, kq_, o);
           if (l == 2) G2_STAMP(46);
@@ -844,7 +850,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
               v[rr] = (row0 + row < n_own) ? d * (1.f - x * x) : 0.f;
               XOn[row * G2_XP + f] = v[rr];
             }
-            if (l > 1) g2_publish4(m.g2_ex + (6 - l) * exs + ((size_t)g * 2 + side) * 4096 + f * 128, row0 + 4 * kq, v, tag16(6 - l));
+            if (l > 1) g2_publish4(exb + nt * 16 * 128, 0, v, tgb);
           }
         } else {
           // idle wave: its tile / h rows are K entries of the workgroup's table product
