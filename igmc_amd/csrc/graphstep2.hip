@@ -343,8 +343,50 @@ __device__ __forceinline__ void g2_publish4(unsigned long long* exf, int node0, 
   g2_store16(exf + node0 + 2, (h1 & 0xFFFFu) | (m1 << 16), (l1 & 0xFFFFu) | tg, (h1 >> 16) | (m1 & 0xFFFF0000u), (l1 >> 16) | tg);
 }
 
+// Everything the kernel reads, in ONE compact argument block (the full BatchDev / ModelDev / GsArgs views are ~1.3 KB of
+// kernel arguments: loading and address-forming from them cost ~1200 scalar instructions before the first useful load).
+struct G2Args {
+  // batch
+  const int32_t* node_off;
+  const int32_t* n_users;
+  const int32_t* totals;
+  const uint8_t* s_lab;
+  const uint8_t* relm;
+  const float* y;
+  int cap_u, cap_v, slot, relm_ld, graph_cap;
+  // model
+  int R, L, D, ts_stride;
+  float* h[4];
+  float* ts_part;
+  unsigned long long* g2_ex;
+  unsigned long long* g2_fx;
+  size_t g2_ex_stride;
+  const float* g2_w;
+  int* gs_bar;
+  int* gs_err;
+  float* a1;
+  float* dz;
+  float* feat;
+  float* gfeat;
+  float* err;
+  uint8_t* lmask;
+  const int64_t* ctrl;
+  int off_bias[4];
+  int off_l1w, off_l1b, off_l2w, off_l2b;
+  // call
+  const float* P;
+  const uint8_t* inj_mask;
+  uint64_t seed, step;
+  float mult, grad_scale;
+  float* out;
+  unsigned long long* ts;
+  int timing, cs, stride;
+  G2Layout lay2;
+};
+
 template <bool FLAGS, bool TRAIN>
-__global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev m, const float* P, GsArgs a) {
+__global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
+  const float* P = a.P;
   IGMC_DYN_SMEM(smem);
   float* S = (float*)smem;
   const G2Layout lay = a.lay2;
@@ -367,11 +409,11 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
   float* sdz = skeep + 128;               // [128]
   float* sred = sdz + 128;                // [256]
   float* misc = sred + 256;               // [16]
-  const int R = m.R, L = m.L, RL = R * L;
+  const int R = a.R, L = a.L, RL = R * L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
-  const int B = b.totals[3];
-  const int ts = m.ts_stride;
+  const int B = a.totals[3];
+  const int ts = a.ts_stride;
   const int cs = a.cs;
   const int cm = (cs > 1) ? blockIdx.x / a.stride : 0;
   const int half = 2 * cs;                              // waves of the cluster per side
@@ -379,12 +421,12 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
   const int side = gw / half, bi = gw - side * half;    // this wave's side (0 users, 1 items) and bundle of that side
   const int rmr = lay.rmr, rmc = lay.rmc, rmp = lay.rmc + 8;      // image rows, columns, row pitch (bytes)
 #ifndef IGMC_HIPEMU
-  const uint32_t seq = (uint32_t)__hip_atomic_load(m.gs_bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t seq = (uint32_t)__hip_atomic_load(a.gs_bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
-  const uint32_t seq = (uint32_t)m.gs_bar[1];
+  const uint32_t seq = (uint32_t)a.gs_bar[1];
 #endif
   const uint32_t tag0 = seq * 8u + 1u;
-  const uint64_t step = m.ctrl ? (uint64_t)m.ctrl[IGMC_CTRL_STEP] : a.step;
+  const uint64_t step = a.ctrl ? (uint64_t)a.ctrl[IGMC_CTRL_STEP] : a.step;
 #ifndef IGMC_HIPEMU
   if (a.ts && tid == 0) atomicMin(a.ts, (unsigned long long)wall_clock64());
 #endif
@@ -394,9 +436,9 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
   // ---- the first subgraph's extents are requested before anything else (two dependent round trips overlap with
   //      the staging of the layer-0 table, which k_g2_compose formed from the current weights)
   const int g_first = (cs > 1) ? (int)(blockIdx.x % a.stride) : (int)blockIdx.x;
-  const int g_pre = (g_first < b.graph_cap) ? g_first : b.graph_cap - 1;      // (a padding workgroup: any valid slot)
-  const int pre_nb = b.node_off[g_pre], pre_n1 = b.node_off[g_pre + 1], pre_cu = b.n_users[g_pre];
-  ((float4*)sT0)[tid] = ((const float4*)(m.g2_w + 6 * G2_WIMG))[tid];
+  const int g_pre = (g_first < a.graph_cap) ? g_first : a.graph_cap - 1;      // (a padding workgroup: any valid slot)
+  const int pre_nb = a.node_off[g_pre], pre_n1 = a.node_off[g_pre + 1], pre_cu = a.n_users[g_pre];
+  ((float4*)sT0)[tid] = ((const float4*)(a.g2_w + 6 * G2_WIMG))[tid];
   f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};        // layer-0 table gradient tile (code half, feature half) of this wave
   bool first_graph = true;
   G2_STAMP(1);
@@ -405,17 +447,17 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
   for (int g = g_first; g < B; g += (cs > 1) ? B : (int)gridDim.x) {
     // the set-up's global loads depend on g only (labels from the per-graph scratch slots, relm rows up to the slot
     // capacity): ONE round trip together with the subgraph's extents
-    const int ld = b.relm_ld, ldw = ld >> 2;
-    const int labv_raw = (int)b.s_lab[(size_t)g * b.slot + ((tid >> 7) ? b.cap_u : 0) + (((tid & 127) < ((tid >> 7) ? b.cap_v : b.cap_u)) ? (tid & 127) : 0)];
+    const int ld = a.relm_ld, ldw = ld >> 2;
+    const int labv_raw = (int)a.s_lab[(size_t)g * a.slot + ((tid >> 7) ? a.cap_u : 0) + (((tid & 127) < ((tid >> 7) ? a.cap_v : a.cap_u)) ? (tid & 127) : 0)];
     uint32_t rmv[16];        // dword (tid & 31) of rows (tid >> 5) + 8 q  (ld <= 128 bytes, <= 128 rows)
     {
-      const uint32_t* rm = (const uint32_t*)(b.relm + (size_t)g * b.cap_u * ld) + (tid >> 5) * ldw + (tid & 31);
+      const uint32_t* rm = (const uint32_t*)(a.relm + (size_t)g * a.cap_u * ld) + (tid >> 5) * ldw + (tid & 31);
 #pragma unroll
-      for (int q = 0; q < 16; ++q) rmv[q] = ((tid & 31) < ldw && (tid >> 5) + 8 * q < b.cap_u) ? rm[8 * q * ldw] : 0u;
+      for (int q = 0; q < 16; ++q) rmv[q] = ((tid & 31) < ldw && (tid >> 5) + 8 * q < a.cap_u) ? rm[8 * q * ldw] : 0u;
     }
-    const int nb = first_graph ? pre_nb : b.node_off[g];
-    const int N = (first_graph ? pre_n1 : b.node_off[g + 1]) - nb;
-    const int cu = first_graph ? pre_cu : b.n_users[g], cv = N - cu;
+    const int nb = first_graph ? pre_nb : a.node_off[g];
+    const int N = (first_graph ? pre_n1 : a.node_off[g + 1]) - nb;
+    const int cu = first_graph ? pre_cu : a.n_users[g], cv = N - cu;
     const int n_own = side ? cv : cu, n_opp = side ? cu : cv;
     const int nbs = nb + (side ? cu : 0);                    // first node of this wave's side
     const int nbun = (n_own + 15) >> 4;
@@ -431,17 +473,17 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
     float* T = TILES + wave * 16 * G2_TP;
     float* HI = HIST + wave * 16 * G2_XP;
     // exchange regions of this subgraph: [exchange x][g][side][32 features][128 nodes]
-    unsigned long long* ex_own = m.g2_ex + ((size_t)g * 2 + side) * 4096;
-    const unsigned long long* ex_opp = m.g2_ex + ((size_t)g * 2 + (1 - side)) * 4096;
-    const size_t exs = m.g2_ex_stride;
-    unsigned long long* fx = m.g2_fx + (size_t)g * 256;
+    unsigned long long* ex_own = a.g2_ex + ((size_t)g * 2 + side) * 4096;
+    const unsigned long long* ex_opp = a.g2_ex + ((size_t)g * 2 + (1 - side)) * 4096;
+    const size_t exs = a.g2_ex_stride;
+    unsigned long long* fx = a.g2_fx + (size_t)g * 256;
 
     // ---- every 4096 launches the owner of a node range clears it in all exchange buffers: a 16-bit tag then never
     //      meets a word older than 4096 launches (tags repeat after 8191)
     if ((seq & 4095u) == 0u) {
       for (int bb2 = bi; bb2 < 8; bb2 += half)
         for (int x = 0; x < 5; ++x) {
-          unsigned long long* e = m.g2_ex + x * exs + ((size_t)g * 2 + side) * 4096 + 16 * bb2;
+          unsigned long long* e = a.g2_ex + x * exs + ((size_t)g * 2 + side) * 4096 + 16 * bb2;
           for (int i = lane; i < 32 * 8; i += 64) g2_store16(e + (i >> 3) * 128 + 2 * (i & 7), 0u, 0u, 0u, 0u);
         }
 #ifndef IGMC_HIPEMU
@@ -533,7 +575,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
     // k_g2_compose): requested a phase ahead, written to LDS by stage()
     float4 wq[8];
     auto wpre = [&](int l, int trans) {
-      const float4* src = (const float4*)(m.g2_w + (size_t)((l - 1) * 2 + trans) * G2_WIMG);
+      const float4* src = (const float4*)(a.g2_w + (size_t)((l - 1) * 2 + trans) * G2_WIMG);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int i = tid + q * G2_THREADS;
@@ -551,8 +593,8 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
     // epilogue of a forward layer: tanh, own rows -> LDS tile + h_l (this wave re-reads them in the backward),
     // bf16 terms -> exchange x (l < 3), centre rows -> readout
     auto fwd_out = [&](int l, const f32x4 (&o)[2], float bias0, float bias1, float* XO) {
-      float* hrow = m.h[l] + (size_t)(nbs + row0 + 4 * kq) * 32 + li;                 // rows 4 kq + rr, feature li (+ 16)
-      unsigned long long* exl = m.g2_ex + l * exs + ((size_t)g * 2 + side) * 4096 + (size_t)li * 128 + row0 + 4 * kq;
+      float* hrow = a.h[l] + (size_t)(nbs + row0 + 4 * kq) * 32 + li;                 // rows 4 kq + rr, feature li (+ 16)
+      unsigned long long* exl = a.g2_ex + l * exs + ((size_t)g * 2 + side) * 4096 + (size_t)li * 128 + row0 + 4 * kq;
       float* xo = XO + 4 * kq * G2_XP + li;
       const uint32_t tg = tag16(l);
 #pragma unroll
@@ -625,13 +667,13 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
       float* XOn = (l & 1) ? XO1 : XO0;             // h_l
       stage();
       G2_STAMP(6 + 3 * (l - 1));
-      const float bias0 = P[m.off_bias[l] + li], bias1 = P[m.off_bias[l] + 16 + li];
+      const float bias0 = P[a.off_bias[l] + li], bias1 = P[a.off_bias[l] + 16 + li];
       // the opposite side's h_{l-1} as bf16 planes
       for (int s2 = 0; s2 < nsides; ++s2) {
         const int sd = (nsides == 2) ? s2 : 1 - side;
         const int n_sd = sd ? cv : cu;
-        g2_reload(PLN + s2 * (G2_NT * 32 * kp >> 1), kp, m.g2_ex + (l - 1) * exs + ((size_t)g * 2 + sd) * 4096,
-                  ((n_sd + 15) >> 4) << 4, tag16(l - 1), m.gs_err);
+        g2_reload(PLN + s2 * (G2_NT * 32 * kp >> 1), kp, a.g2_ex + (l - 1) * exs + ((size_t)g * 2 + sd) * 4096,
+                  ((n_sd + 15) >> 4) << 4, tag16(l - 1), a.gs_err);
       }
       __syncthreads();
       G2_STAMP(7 + 3 * (l - 1));
@@ -657,12 +699,12 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
     }
 
     // ================================================================ head: lin1 / ReLU / dropout / lin2 / residual
-    sfeat[tid] = g2_poll_f32(fx + tid, tag0 + G2_FXTAG, m.gs_err);
+    sfeat[tid] = g2_poll_f32(fx + tid, tag0 + G2_FXTAG, a.gs_err);
     __syncthreads();
     G2_STAMP(15);
     {
       const int ju = tid >> 1, part = tid & 1;         // hidden unit, half of the fan-in
-      const float* wrow = P + m.off_l1w + (int64_t)ju * 256 + part * 128;
+      const float* wrow = P + a.off_l1w + (int64_t)ju * 256 + part * 128;
       float4 w4[32];
 #pragma unroll
       for (int q = 0; q < 32; ++q) w4[q] = *(const float4*)(wrow + 4 * q);
@@ -675,20 +717,20 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
       s += __shfl_xor(s, 1, 4);
       G2_STAMP(54);
       if (part == 0) {
-        float av = s + P[m.off_l1b + ju];
+        float av = s + P[a.off_l1b + ju];
         av = av > 0.f ? av : 0.f;
         int keep = 1;
         if (TRAIN) {
           keep = a.inj_mask ? (int)a.inj_mask[g * 128 + ju]
                             : (int)(igmc_u01(igmc_unit_hash(a.seed, step, (uint32_t)g, (uint32_t)ju)) >= 0.5f);
           if (cm == 0) {
-            m.a1[g * 128 + ju] = av;
-            m.lmask[g * 128 + ju] = (uint8_t)keep;
+            a.a1[g * 128 + ju] = av;
+            a.lmask[g * 128 + ju] = (uint8_t)keep;
           }
           sa1[ju] = av;
           skeep[ju] = keep ? 1.f : 0.f;
         }
-        sred[ju] = (TRAIN ? (keep ? av * 2.f : 0.f) : av) * P[m.off_l2w + ju];      // F.dropout(p = 0.5): kept * 2
+        sred[ju] = (TRAIN ? (keep ? av * 2.f : 0.f) : av) * P[a.off_l2w + ju];      // F.dropout(p = 0.5): kept * 2
       }
     }
     __syncthreads();
@@ -696,11 +738,11 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
       float s = sred[lane] + sred[lane + 64];
       s = igmc_wave_sum_f(s);
       if (lane == 0) {
-        const float o = (s + P[m.off_l2b]) * a.mult;
-        const float e = o - b.y[g];
+        const float o = (s + P[a.off_l2b]) * a.mult;
+        const float e = o - a.y[g];
         if (cm == 0) {
           a.out[g] = o;
-          m.err[g] = e;
+          a.err[g] = e;
         }
         misc[0] = e;
       }
@@ -714,15 +756,15 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
       G2_STAMP(16);
       if (tid < 128) {
         const float dp = 2.f * misc[0] * a.grad_scale * a.mult;
-        const float dzv = (sa1[tid] > 0.f && skeep[tid] != 0.f) ? dp * P[m.off_l2w + tid] * 2.f : 0.f;
+        const float dzv = (sa1[tid] > 0.f && skeep[tid] != 0.f) ? dp * P[a.off_l2w + tid] * 2.f : 0.f;
         sdz[tid] = dzv;
-        if (cm == 0) m.dz[g * 128 + tid] = dzv;
+        if (cm == 0) a.dz[g * 128 + tid] = dzv;
       }
-      if (cm == 0) m.feat[(size_t)g * m.D + tid] = sfeat[tid];
+      if (cm == 0) a.feat[(size_t)g * a.D + tid] = sfeat[tid];
       __syncthreads();
       {   // d feat = dz @ lin1.weight: wave w takes hidden units 32 w .. 32 w + 31, lane -> 4 fan-in columns; rows with
           // dz == 0 (ReLU / dropout: ~3/4 of them) are skipped wave-uniformly
-        const float* w1 = P + m.off_l1w + 4 * lane;
+        const float* w1 = P + a.off_l1w + 4 * lane;
         float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
         unsigned long long nz = __ballot(lane < 32 && sdz[32 * wave + (lane & 31)] != 0.f);
         while (nz) {
@@ -746,7 +788,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
       {
         const float v = (TILES[tid] + TILES[256 + tid]) + (TILES[512 + tid] + TILES[768 + tid]);
         sgf[tid] = v;
-        if (cm == 0) m.gfeat[(size_t)g * m.D + tid] = v;
+        if (cm == 0) a.gfeat[(size_t)g * a.D + tid] = v;
       }
       __syncthreads();
       G2_STAMP(17);
@@ -781,7 +823,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
         float* XOc = (l & 1) ? XO0 : XO1;            // dPre_l of the bundle's own rows
         float* XOn = (l & 1) ? XO1 : XO0;            // dPre_{l-1}
         stage();
-        float* wpart = m.ts_part + ((size_t)l * IGMC_TS_BLOCKS + blockIdx.x) * ts;
+        float* wpart = a.ts_part + ((size_t)l * IGMC_TS_BLOCKS + blockIdx.x) * ts;
         {   // d bias_l = column sums of dPre_l over this workgroup's rows (fixed order)
           const int n = tid & 31, part = tid >> 5;
           float sb = 0.f;
@@ -805,7 +847,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
         if (active) {
           // h_{l-1} of the bundle's rows (written by this very wave in the forward): tanh' and the table product
           {
-            const float* hrow = m.h[l - 1] + (size_t)(nbs + row0 + 4 * kq) * 32 + li;
+            const float* hrow = a.h[l - 1] + (size_t)(nbs + row0 + 4 * kq) * 32 + li;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -832,7 +874,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
             for (int rr = 0; rr < 4; ++rr) HS[(4 * kq + rr) * G2_XP + 16 * nt + li] = hreg[nt][rr];
           // dX = [T' | dPre_l] @ [W_r^T ; root^T], + readout gradient on the centre row, * tanh'(h_{l-1})
           f32x4 o[2];
-          unsigned long long* exb = m.g2_ex + (6 - l) * exs + ((size_t)g * 2 + side) * 4096 + (size_t)li * 128 + row0 + 4 * kq;
+          unsigned long long* exb = a.g2_ex + (6 - l) * exs + ((size_t)g * 2 + side) * 4096 + (size_t)li * 128 + row0 + 4 * kq;
           const uint32_t tgb = tag16(6 - l);
           if (l == 2) G2_STAMP(45);
           g2_transform(acc, XOc, sW2, li_, kq_, o);
@@ -914,8 +956,8 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
           for (int s2 = 0; s2 < nsides; ++s2) {
             const int sd = (nsides == 2) ? s2 : 1 - side;
             const int n_sd = sd ? cv : cu;
-            g2_reload(PLN + s2 * (G2_NT * 32 * kp >> 1), kp, m.g2_ex + (6 - l) * exs + ((size_t)g * 2 + sd) * 4096,
-                      ((n_sd + 15) >> 4) << 4, tag16(6 - l), m.gs_err);
+            g2_reload(PLN + s2 * (G2_NT * 32 * kp >> 1), kp, a.g2_ex + (6 - l) * exs + ((size_t)g * 2 + sd) * 4096,
+                      ((n_sd + 15) >> 4) << 4, tag16(6 - l), a.gs_err);
           }
         }
         __syncthreads();
@@ -942,7 +984,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
   }
 
   if (TRAIN) {
-    float* part0 = m.ts_part + (size_t)blockIdx.x * ts;        // slice 0 of [4][IGMC_TS_BLOCKS][ts]
+    float* part0 = a.ts_part + (size_t)blockIdx.x * ts;        // slice 0 of [4][IGMC_TS_BLOCKS][ts]
     const int m2 = wave >> 1, wn = wave & 1;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -954,9 +996,9 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
   if (tid == 0) {
     const unsigned long long t1 = a.ts ? (unsigned long long)wall_clock64() : 0ull;
     // the workgroup that finishes the launch LAST advances the sequence number: every workgroup has read it by then
-    if (__hip_atomic_fetch_add(m.gs_bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
-      __hip_atomic_store(m.gs_bar, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(m.gs_bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__hip_atomic_fetch_add(a.gs_bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+      __hip_atomic_store(a.gs_bar, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(a.gs_bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (a.ts) {
         const unsigned long long t0 = __hip_atomic_load(a.ts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atomicAdd(a.ts + 1, t1 - t0);
@@ -967,9 +1009,9 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(BatchDev b, ModelDev
   }
 #else
   if (tid == 0) {
-    if (m.gs_bar[0]++ == (int)gridDim.x - 1) {
-      m.gs_bar[0] = 0;
-      m.gs_bar[1] += 1;
+    if (a.gs_bar[0]++ == (int)gridDim.x - 1) {
+      a.gs_bar[0] = 0;
+      a.gs_bar[1] += 1;
     }
   }
 #endif
@@ -1101,8 +1143,20 @@ int igmc_g2_eligible(const ModelDev& m, const BatchDev& b, int B, G2Layout* lay,
 void igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* P, int B, int training, int use_flags,
                              const G2Layout& lay, int cs, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
                              float grad_scale, float* out, void* stream) {
-  GsArgs a;
+  G2Args a;
   memset(&a, 0, sizeof(a));
+  a.node_off = b.node_off; a.n_users = b.n_users; a.totals = b.totals; a.s_lab = b.s_lab; a.relm = b.relm; a.y = b.y;
+  a.cap_u = b.cap_u; a.cap_v = b.cap_v; a.slot = b.slot; a.relm_ld = b.relm_ld; a.graph_cap = b.graph_cap;
+  a.R = m.R; a.L = m.L; a.D = m.D; a.ts_stride = m.ts_stride;
+  for (int l = 0; l < 4; ++l) {
+    a.h[l] = m.h[l];
+    a.off_bias[l] = (int)m.off_bias[l];
+  }
+  a.ts_part = m.ts_part; a.g2_ex = m.g2_ex; a.g2_fx = m.g2_fx; a.g2_ex_stride = m.g2_ex_stride; a.g2_w = m.g2_w;
+  a.gs_bar = m.gs_bar; a.gs_err = m.gs_err; a.a1 = m.a1; a.dz = m.dz; a.feat = m.feat; a.gfeat = m.gfeat; a.err = m.err;
+  a.lmask = m.lmask; a.ctrl = m.ctrl;
+  a.off_l1w = (int)m.off_l1w; a.off_l1b = (int)m.off_l1b; a.off_l2w = (int)m.off_l2w; a.off_l2b = (int)m.off_l2b;
+  a.P = P;
   a.inj_mask = inj_mask;
   a.seed = seed;
   a.step = step;
@@ -1125,11 +1179,11 @@ void igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* 
 #endif
   if (getenv("IGMC_GS_TRACE")) fprintf(stderr, "[igmc] k_graph_step B=%d train=%d flags=%d v2 kp=%d lds=%zu cluster=%d grid=%d\n", B, training, use_flags, lay.kp, sm, cs, grid);
   if (training) {
-    if (use_flags) IGMC_PLAUNCH("k_graph_step", (k_graph_step2<true, true>), grid, G2_THREADS, sm, stream, b, m, P, a);
-    else IGMC_PLAUNCH("k_graph_step", (k_graph_step2<false, true>), grid, G2_THREADS, sm, stream, b, m, P, a);
+    if (use_flags) IGMC_PLAUNCH("k_graph_step", (k_graph_step2<true, true>), grid, G2_THREADS, sm, stream, a);
+    else IGMC_PLAUNCH("k_graph_step", (k_graph_step2<false, true>), grid, G2_THREADS, sm, stream, a);
   } else {
-    if (use_flags) IGMC_PLAUNCH("k_graph_fwd", (k_graph_step2<true, false>), grid, G2_THREADS, sm, stream, b, m, P, a);
-    else IGMC_PLAUNCH("k_graph_fwd", (k_graph_step2<false, false>), grid, G2_THREADS, sm, stream, b, m, P, a);
+    if (use_flags) IGMC_PLAUNCH("k_graph_fwd", (k_graph_step2<true, false>), grid, G2_THREADS, sm, stream, a);
+    else IGMC_PLAUNCH("k_graph_fwd", (k_graph_step2<false, false>), grid, G2_THREADS, sm, stream, a);
   }
 }
 
