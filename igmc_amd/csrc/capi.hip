@@ -83,6 +83,7 @@ struct igmc_batch {
   const float* side_src;    // dataset-wide [n_links, n_side] matrix (igmc_batch_bind_side_source); rows gathered per batch
   float* side_buf;          // [graph_cap, n_side] owned by the arena
   int side_buf_cols;
+  int lean;                 // igmc_batch_set_lean: extraction stops after the dense blocks (capped arenas)
   const int64_t* ctrl;
   Allocs mem;
 };
@@ -282,6 +283,7 @@ extern "C" int igmc_batch_create(const igmc_graph* g, int max_graphs, int hop, i
   b->side_src = nullptr;
   b->side_buf = nullptr;
   b->side_buf_cols = 0;
+  b->lean = 0;
   b->ctrl = nullptr;
   BatchDev& d = b->d;
   Allocs& M = b->mem;
@@ -336,7 +338,7 @@ extern "C" int igmc_extract_batch(const igmc_graph* g, igmc_batch* b, const int3
   if (B <= 0 || B > b->d.graph_cap) IGMC_FAIL("B exceeds the batch capacity");
   if (!d_link_u || !d_link_v || !d_link_y) IGMC_FAIL("null link arrays");
   igmc_launch_extract(g->d, b->d, d_link_u, d_link_v, d_link_y, d_link_idx, first, B, 0, sample_ratio, seed, epoch,
-                      b->ctrl, stream);
+                      b->ctrl, b->lean && b->d.relm, stream);
   if (b->side_src)      // side features of the target nodes travel with the extraction (reference :250-253)
     igmc_launch_side_gather(b->side_src, b->n_side, d_link_idx, first, B, b->ctrl, b->side_buf, stream);
   HIPCHECK(hipGetLastError());
@@ -377,16 +379,30 @@ extern "C" int igmc_extract_batch_replay(const igmc_graph* g, igmc_batch* b, int
   HIPCHECK(hipMemcpy(d.n_users, nu.data(), B * 4, hipMemcpyHostToDevice));
   HIPCHECK(hipMemcpy(d.n_items, nv.data(), B * 4, hipMemcpyHostToDevice));
   HIPCHECK(hipMemcpy(d.y, h_y, B * sizeof(float), hipMemcpyHostToDevice));
-  igmc_launch_extract(g->d, b->d, nullptr, nullptr, nullptr, nullptr, 0, B, 1, 1.0, 0, 0, nullptr, stream);
+  igmc_launch_extract(g->d, b->d, nullptr, nullptr, nullptr, nullptr, 0, B, 1, 1.0, 0, 0, nullptr, 0, stream);
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
   b->last_B = B;
   return 0;
 }
 
+// A lean arena carries no collated CSR after an extraction: whoever needs it (inspection, the flag kernels, the
+// per-layer model kernels) emits it first.  Emission is idempotent, and a hipGraph replay of the extraction leaves no
+// host-side trace, so a lean arena re-emits on every such call.
+static void ensure_csr(const igmc_batch* b, void* stream) {
+  if (b->lean && b->d.relm && b->last_B > 0) igmc_launch_emit(b->d, b->last_B, stream);
+}
+
+extern "C" int igmc_batch_set_lean(igmc_batch* b, int lean) {
+  if (!b) IGMC_FAIL("null batch");
+  b->lean = lean ? 1 : 0;
+  return 0;
+}
+
 extern "C" int igmc_batch_edge_dropout(igmc_batch* b, float p, int force_undirected, uint64_t seed, uint64_t step,
                                        void* stream) {
   if (!b) IGMC_FAIL("null batch");
+  ensure_csr(b, stream);        // the flag kernel walks the collated CSR (and mirrors the bits into the dense block)
   igmc_launch_edge_flags(b->d, p, force_undirected, seed, step, b->ctrl, stream);
   HIPCHECK(hipGetLastError());
   return 0;
@@ -394,6 +410,7 @@ extern "C" int igmc_batch_edge_dropout(igmc_batch* b, float p, int force_undirec
 
 extern "C" int igmc_batch_get_info(const igmc_batch* b, igmc_batch_info* out, void* stream) {
   if (!b || !out) IGMC_FAIL("null argument");
+  ensure_csr(b, stream);
   int32_t t[8];
   HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
   HIPCHECK(hipMemcpy(t, b->d.totals, sizeof(t), hipMemcpyDeviceToHost));
@@ -411,6 +428,7 @@ extern "C" int igmc_batch_get_info(const igmc_batch* b, igmc_batch_info* out, vo
 extern "C" int igmc_batch_set_edge_flags(igmc_batch* b, const uint8_t* h_flags, int64_t n) {
   if (!b || !h_flags) IGMC_FAIL("null argument");
   if (n > b->d.edge_cap) IGMC_FAIL("too many flags");
+  ensure_csr(b, nullptr);
   HIPCHECK(hipDeviceSynchronize());
   HIPCHECK(hipMemcpy(b->d.eflag, h_flags, (size_t)n, hipMemcpyHostToDevice));
   igmc_launch_relm_flags(b->d, nullptr);        // the dense block mirrors the keep bits
@@ -665,6 +683,24 @@ extern "C" int64_t igmc_param_offset(const igmc_model* m, int layer, int which, 
   return off;
 }
 
+// the per-layer kernels / graphstep.hip read the collated CSR; the matrix-core subgraph kernel does not
+static void csr_for_model(const igmc_model* m, const igmc_batch* b, int dense_capable_call, void* stream) {
+  if (!b->lean) return;
+  G2Layout lay;
+  int cs = 1;
+  const int rows0 = m->d.R * m->d.L + m->d.L + 1;
+  if (dense_capable_call && rows0 <= 32 && igmc_layer_mode() >= 2 && igmc_g2_eligible(m->d, b->d, b->last_B, &lay, &cs)) return;
+  ensure_csr(b, stream);
+}
+
+extern "C" int igmc_model_dense_path(const igmc_model* m, const igmc_batch* b, int B) {
+  if (!m || !b) return 0;
+  G2Layout lay;
+  int cs = 1;
+  const int rows0 = m->d.R * m->d.L + m->d.L + 1;
+  return (rows0 <= 32 && igmc_layer_mode() >= 2 && m->d.D % 16 == 0 && igmc_g2_eligible(m->d, b->d, B, &lay, &cs)) ? 1 : 0;
+}
+
 static int check_fit(igmc_model* m, const igmc_batch* b, std::string* why) {
   if (!m || !b) { *why = "null model or batch"; return 1; }
   if (b->last_B <= 0) { *why = "batch is empty (run igmc_extract_batch first)"; return 1; }
@@ -682,6 +718,7 @@ extern "C" int igmc_model_forward(igmc_model* m, const float* d_params, const ig
   if (check_fit(m, b, &why)) IGMC_FAIL(why);
   if (!d_params || !d_out) IGMC_FAIL("null buffer");
   m->d.side = b->side;
+  csr_for_model(m, b, !training, stream);
   igmc_launch_forward(m->d, m->ax, b->d, d_params, b->last_B, training, use_edge_flags, d_lin_mask, seed, step, multiply_by,
                       d_out, stream);
   HIPCHECK(hipGetLastError());
@@ -711,6 +748,7 @@ extern "C" int igmc_model_loss_grad(igmc_model* m, const float* d_params, const 
   if (check_fit(m, b, &why)) IGMC_FAIL(why);
   if (!d_params || !d_out || !d_grad) IGMC_FAIL("null buffer");
   m->d.side = b->side;
+  csr_for_model(m, b, 1, stream);
   igmc_launch_loss_grad(m->d, m->ax, b->d, (float*)d_params, b->last_B, use_edge_flags, d_lin_mask, seed, step,
                         multiply_by, ARR, grad_scale, arr_scale, d_out, d_grad, d_loss, nullptr, stream);
   HIPCHECK(hipGetLastError());
@@ -815,6 +853,7 @@ extern "C" int igmc_train_step(igmc_model* m, float* d_params, const igmc_batch*
     inv = (float)(1.0 / std::sqrt(bc2));
   }
   m->d.side = b->side;
+  csr_for_model(m, b, 1, stream);
   igmc_launch_train_step(m->d, m->ax, b->d, d_params, b->last_B, use_edge_flags, d_lin_mask, seed, step, multiply_by, ARR,
                          d_out, d_grad, d_exp_avg, d_exp_avg_sq, step_size, inv, beta1, beta2, eps, weight_decay, d_ctrl,
                          m->done_ctr, d_loss, d_total, stream);

@@ -278,6 +278,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_extract_nodes(ExtractArgs a) {
     a.b.n_users[g] = cu;
     a.b.n_items[g] = cv;
     a.b.edge_cnt[g] = 0;
+    if (g == 0 && a.b.relm) a.b.totals[3] = a.B;      // consumers of a lean batch (no CSR emission) read the batch size here
   }
   if (a.b.relm) {      // clear this link's dense (user, item) -> relation block (only the cu x cap_v part is used)
     uint32_t* rm = (uint32_t*)(a.b.relm + (size_t)g * a.b.cap_u * a.b.relm_ld);
@@ -479,56 +480,86 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_fill(GraphDev G, BatchDev b) {
 // long CSC columns of popular items (thousands of entries, ~4/5 of the traversal work of the generic kernels)
 // are never scanned.  Everything stays atomic-free on data => bit-reproducible.
 
-// kernel 2d: fill relm from the selected users' rows; counts the (undirected) edges of the link
+// kernel 2d: fill relm from the selected users' rows; counts the (undirected) edges of the link.
+// Work is balanced by ENTRIES, not rows: the CSR rows of the link's selected users are viewed as one concatenated
+// stream (row starts = an exclusive scan of the degrees, in LDS), block y of the link's S blocks takes the y-th of S
+// equal slices of it and every thread takes entries at stride 256 inside the slice, locating its row by a binary
+// search over the <= 256 row starts.  (One wave per ROW, as before, made the kernel as long as the longest row: an
+// active user's 2 400 ratings = 10 dependent 256-entry rounds = 35-50 us for ~8 MB of traffic.)
 __global__ __launch_bounds__(IGMC_BLOCK) void k_relm(GraphDev G, BatchDev b) {
   IGMC_DYN_SMEM(smem);
   __shared__ int sm[16];
   const int g = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int Wu = (G.n_users + 31) >> 5, Wv = (G.n_items + 31) >> 5;
-  uint32_t* sel_u = (uint32_t*)smem;
-  uint32_t* sel_v = sel_u + Wu;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int Wv = (G.n_items + 31) >> 5;
+  uint32_t* sel_v = (uint32_t*)smem;
   uint32_t* pre_v = sel_v + Wv;
-  const int cap_u = b.cap_u, cap_v = b.cap_v;
+  int* rstart = (int*)(pre_v + Wv);          // [cap_u + 1] first stream position of every selected user's row
+  int* rbase = rstart + b.cap_u + 1;         // [cap_u]     CSR position of the row's first entry
+  const int cap_u = b.cap_u;
   const size_t so = (size_t)g * b.slot;
   const int32_t* sg = b.s_gid + so;
   const int cu = b.n_users[g], cv = b.n_items[g];
   const int v0 = sg[cap_u];
   const int ld = b.relm_ld;
   uint8_t* rm = b.relm + (size_t)g * cap_u * ld;
-  rebuild_sel(sg, cap_u, cu, cv, sel_u, Wu, sel_v, Wv);
+  // row extents first (two dependent loads), the item bitmap under their latency
+  int deg = 0, base = 0;
+  if (tid < cu) {
+    const int id = sg[tid];
+    base = G.u_ptr[id];
+    deg = G.u_ptr[id + 1] - base;
+  }
+  bm_clear(sel_v, Wv);
+  __syncthreads();
+  for (int i = 1 + tid; i < cv; i += IGMC_BLOCK) atomicOr(&sel_v[sg[cap_u + i] >> 5], 1u << (sg[cap_u + i] & 31));
+  __syncthreads();
   bm_prefix(sel_v, pre_v, Wv, sm);
-  __syncthreads();                        // pre_v is read across waves below
-  const int stride = gridDim.y * (IGMC_BLOCK / 64);
-  int etot = 0;
-  for (int li = blockIdx.y * (IGMC_BLOCK / 64) + wave; li < cu; li += stride) {
-    const int id = sg[li];
-    const int beg = G.u_ptr[id], end = G.u_ptr[id + 1];
-    int c = 0;
-    for (int p0 = beg; p0 < end; p0 += 256) {
-      int j[4], rl[4];
+  int total;
+  const int ex = igmc_block_scan_excl(deg, &total, sm);        // cu <= 256 = one pass (dense path: cap_u <= 256)
+  if (tid < cu) {
+    rstart[tid] = ex;
+    rbase[tid] = base;
+  }
+  if (tid == 0) rstart[cu] = total;
+  __syncthreads();
+  const int S = gridDim.y;
+  const int lo = (int)((long long)total * blockIdx.y / S), hi = (int)((long long)total * (blockIdx.y + 1) / S);
+  int c = 0;
+  for (int e0 = lo; e0 < hi; e0 += 4 * IGMC_BLOCK) {
+    int j[4], rl[4], row[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int p = p0 + q * 64 + lane;
-        const bool valid = p < end;
-        j[q] = valid ? G.u_idx[p] : -1;
-        rl[q] = valid ? (int)G.u_rel[p] : 0;
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (j[q] < 0) continue;
-        const bool m = (j[q] == v0) ? (li != 0) : bm_test(sel_v, j[q]);
-        if (m) {
-          const int lv = (j[q] == v0) ? 0 : 1 + bm_rank(sel_v, pre_v, j[q]);
-          rm[(size_t)li * ld + lv] = (uint8_t)(rl[q] + 1);
-          ++c;
+    for (int q = 0; q < 4; ++q) {
+      const int e = e0 + q * IGMC_BLOCK + tid;
+      j[q] = -1;
+      rl[q] = 0;
+      row[q] = 0;
+      if (e < hi) {
+        int a = 0, z = cu;                     // largest row with rstart[row] <= e
+        while (z - a > 1) {
+          const int mid = (a + z) >> 1;
+          if (rstart[mid] <= e) a = mid;
+          else z = mid;
         }
+        row[q] = a;
+        const int p = rbase[a] + (e - rstart[a]);
+        j[q] = G.u_idx[p];
+        rl[q] = (int)G.u_rel[p];
       }
     }
-    c = igmc_wave_sum_i(c);
-    if (lane == 0) etot += c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (j[q] < 0) continue;
+      const bool mt = (j[q] == v0) ? (row[q] != 0) : bm_test(sel_v, j[q]);
+      if (mt) {
+        const int lv = (j[q] == v0) ? 0 : 1 + bm_rank(sel_v, pre_v, j[q]);
+        rm[(size_t)row[q] * ld + lv] = (uint8_t)(rl[q] + 1);
+        ++c;
+      }
+    }
   }
-  if (lane == 0 && etot) atomicAdd(&b.edge_cnt[g], 2 * etot);   // directed edges; integer => order-independent
+  c = igmc_wave_sum_i(c);
+  if (lane == 0 && c) atomicAdd(&b.edge_cnt[g], 2 * c);   // directed edges; integer => order-independent
 }
 
 // kernel 3d: batch offsets, degrees, row pointers and the relation-sorted CSR, all from relm
@@ -807,9 +838,18 @@ size_t igmc_extract_smem_bytes(const GraphDev& g) {
   return 4 * (Wu + Wv) * sizeof(uint32_t);
 }
 
+// CSR emission of a capped batch from its dense blocks (idempotent: everything it reads is final after k_relm)
+void igmc_launch_emit(const BatchDev& b, int B, void* stream) {
+  int S = 2048 / (B > 0 ? B : 1);
+  S = S < 1 ? 1 : (S > 16 ? 16 : S);
+  IGMC_PLAUNCH("k_emit", k_emit, dim3(B, S), IGMC_BLOCK, (size_t)b.slot * sizeof(int) + (size_t)b.cap_u * b.relm_ld, stream, b);
+}
+
+// lean != 0 (capped arenas only): stop after the dense blocks -- node sets, labels, relm, y, the batch size -- which is
+// all the matrix-core subgraph kernel reads; the collated CSR is emitted on demand (igmc_launch_emit)
 void igmc_launch_extract(const GraphDev& g, const BatchDev& b, const int32_t* link_u, const int32_t* link_v,
                          const float* link_y, const int32_t* link_idx, int first, int B, int replay,
-                         double sample_ratio, uint64_t seed, uint64_t epoch, const int64_t* ctrl, void* stream) {
+                         double sample_ratio, uint64_t seed, uint64_t epoch, const int64_t* ctrl, int lean, void* stream) {
   ExtractArgs a;
   a.ctrl = ctrl;
   a.g = g; a.b = b;
@@ -823,8 +863,10 @@ void igmc_launch_extract(const GraphDev& g, const BatchDev& b, const int32_t* li
   IGMC_PLAUNCH("k_extract_nodes", k_extract_nodes, B, IGMC_BLOCK, smem, stream, a);
   if (b.relm) {      // capped extraction (igmc_batch_create decides)
     const size_t Wu = (g.n_users + 31) >> 5, Wv = (g.n_items + 31) >> 5;
-    IGMC_PLAUNCH("k_relm", k_relm, dim3(B, S), IGMC_BLOCK, (Wu + 2 * Wv) * sizeof(uint32_t), stream, g, b);
-    IGMC_PLAUNCH("k_emit", k_emit, dim3(B, S), IGMC_BLOCK, (size_t)b.slot * sizeof(int) + (size_t)b.cap_u * b.relm_ld, stream, b);
+    int Sr = 400 / (B > 0 ? B : 1);        // entry-balanced slices: ~400 workgroups in all (one residency round)
+    Sr = Sr < 1 ? 1 : (Sr > 16 ? 16 : Sr);
+    IGMC_PLAUNCH("k_relm", k_relm, dim3(B, Sr), IGMC_BLOCK, (2 * Wv + 2 * (size_t)b.cap_u + 2) * sizeof(uint32_t), stream, g, b);
+    if (!lean) igmc_launch_emit(b, B, stream);
   } else {
     IGMC_PLAUNCH("k_count", k_count, dim3(B, S), IGMC_BLOCK, smem / 4, stream, g, b);
     IGMC_PLAUNCH("k_fill", k_fill, dim3(B, S), IGMC_BLOCK, smem / 2, stream, g, b);

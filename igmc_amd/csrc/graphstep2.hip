@@ -347,9 +347,9 @@ __device__ __forceinline__ void g2_publish4(unsigned long long* exf, int node0, 
 // kernel arguments: loading and address-forming from them cost ~1200 scalar instructions before the first useful load).
 struct G2Args {
   // batch
-  const int32_t* node_off;
   const int32_t* n_users;
-  const int32_t* totals;
+  const int32_t* n_items;
+  int B;
   const uint8_t* s_lab;
   const uint8_t* relm;
   const float* y;
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
   const int R = a.R, L = a.L, RL = R * L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
-  const int B = a.totals[3];
+  const int B = a.B;
   const int ts = a.ts_stride;
   const int cs = a.cs;
   const int cm = (cs > 1) ? blockIdx.x / a.stride : 0;
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
   //      the staging of the layer-0 table, which k_g2_compose formed from the current weights)
   const int g_first = (cs > 1) ? (int)(blockIdx.x % a.stride) : (int)blockIdx.x;
   const int g_pre = (g_first < a.graph_cap) ? g_first : a.graph_cap - 1;      // (a padding workgroup: any valid slot)
-  const int pre_nb = a.node_off[g_pre], pre_n1 = a.node_off[g_pre + 1], pre_cu = a.n_users[g_pre];
+  const int pre_cu = a.n_users[g_pre], pre_cv = a.n_items[g_pre];
   ((float4*)sT0)[tid] = ((const float4*)(a.g2_w + 6 * G2_WIMG))[tid];
   f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};        // layer-0 table gradient tile (code half, feature half) of this wave
   bool first_graph = true;
@@ -455,11 +455,10 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) rmv[q] = ((tid & 31) < ldw && (tid >> 5) + 8 * q < a.cap_u) ? rm[8 * q * ldw] : 0u;
     }
-    const int nb = first_graph ? pre_nb : a.node_off[g];
-    const int N = (first_graph ? pre_n1 : a.node_off[g + 1]) - nb;
-    const int cu = first_graph ? pre_cu : a.n_users[g], cv = N - cu;
+    const int cu = first_graph ? pre_cu : a.n_users[g], cv = first_graph ? pre_cv : a.n_items[g];
     const int n_own = side ? cv : cu, n_opp = side ? cu : cv;
-    const int nbs = nb + (side ? cu : 0);                    // first node of this wave's side
+    const int nbs = g * a.slot + (side ? a.cap_u : 0);       // first row of this wave's side in the h_l scratch (slot-based:
+                                                             // the kernel never reads the collated node offsets)
     const int nbun = (n_own + 15) >> 4;
     const bool active = bi < nbun;
     const int row0 = 16 * bi;
@@ -1145,7 +1144,7 @@ void igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* 
                              float grad_scale, float* out, void* stream) {
   G2Args a;
   memset(&a, 0, sizeof(a));
-  a.node_off = b.node_off; a.n_users = b.n_users; a.totals = b.totals; a.s_lab = b.s_lab; a.relm = b.relm; a.y = b.y;
+  a.n_users = b.n_users; a.n_items = b.n_items; a.B = B; a.s_lab = b.s_lab; a.relm = b.relm; a.y = b.y;
   a.cap_u = b.cap_u; a.cap_v = b.cap_v; a.slot = b.slot; a.relm_ld = b.relm_ld; a.graph_cap = b.graph_cap;
   a.R = m.R; a.L = m.L; a.D = m.D; a.ts_stride = m.ts_stride;
   for (int l = 0; l < 4; ++l) {

@@ -7,7 +7,8 @@
 size_t igmc_extract_smem_bytes(const GraphDev& g);
 void igmc_launch_extract(const GraphDev& g, const BatchDev& b, const int32_t* link_u, const int32_t* link_v,
                          const float* link_y, const int32_t* link_idx, int first, int B, int replay,
-                         double sample_ratio, uint64_t seed, uint64_t epoch, const int64_t* ctrl, void* stream);
+                         double sample_ratio, uint64_t seed, uint64_t epoch, const int64_t* ctrl, int lean, void* stream);
+void igmc_launch_emit(const BatchDev& b, int B, void* stream);
 void igmc_launch_edge_flags(const BatchDev& b, float p, int force_undirected, uint64_t seed, uint64_t step,
                             const int64_t* ctrl, void* stream);
 void igmc_launch_relm_flags(const BatchDev& b, void* stream);

@@ -118,6 +118,11 @@ class Batch(object):
         device (``igmc_batch_bind_side_source``)."""
         self.lib.call('igmc_batch_bind_side_source', self.handle, _p(ptr), int(n_side))
 
+    def set_lean(self, lean=True):
+        """Lean extraction: stop after the dense induced blocks (what the matrix-core subgraph kernel reads); the
+        collated CSR is emitted on demand (``igmc_batch_set_lean``)."""
+        self.lib.call('igmc_batch_set_lean', self.handle, int(bool(lean)))
+
     def info(self, stream=None):
         info = _lib.BatchInfo()
         self.lib.call('igmc_batch_get_info', self.handle, C.byref(info), _p(stream))
@@ -208,6 +213,10 @@ class ModelWorkspace(object):
         self.lib.call('igmc_model_loss_grad', self.handle, _p(params), batch.handle, int(bool(use_edge_flags)),
                       _p(lin_mask), int(seed) & (2 ** 64 - 1), int(step) & (2 ** 64 - 1), float(multiply_by),
                       float(ARR), float(grad_scale), float(arr_scale), _p(out), _p(grad), _p(loss), _p(stream))
+
+    def dense_path(self, batch, B):
+        """True when forward / loss_grad / train_step on (batch arena, B) take the matrix-core subgraph kernel."""
+        return bool(self.lib.igmc_model_dense_path(self.handle, batch.handle, int(B)))
 
     def adam_step(self, params, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8,
                   weight_decay=0.0, stream=None):

@@ -56,6 +56,11 @@ class StepGraph(object):
         self.arenas = [dataset.arena(self.B, slot='stepgraph0'), dataset.arena(self.B, slot='stepgraph1')]
         from .util_functions import DeviceBatch
         self.ws = model._workspace(DeviceBatch(dataset, self.arenas[0], self.B, self.perm, 0))
+        # the matrix-core subgraph kernel reads the dense induced blocks only: where it takes the step, the extraction
+        # branch skips the CSR emission (it is produced on demand for inspection)
+        if os.environ.get('IGMC_NO_LEAN', '0') != '1':
+            for a in self.arenas:
+                a.set_lean(self.ws.dense_path(a, self.B))
         self.out = torch.empty(self.B, dtype=torch.float32, device=self.dev)
         self.loss = torch.zeros(2, dtype=torch.float32, device=self.dev)
         self.total = torch.zeros(1, dtype=torch.float64, device=self.dev)

@@ -116,6 +116,12 @@ int igmc_batch_set_side_features(igmc_batch* b, const float* d_feat, int n_side)
  * links (same d_link_idx / first / control-block indexing as the extraction) into an arena-owned buffer that the
  * model then reads -- nothing happens on the host per step, so the step stays hipGraph-capturable.  NULL unbinds. */
 int igmc_batch_bind_side_source(igmc_batch* b, const float* d_side_all, int n_side);
+/* Lean extraction (arenas with a per-hop cap only; ignored otherwise): igmc_extract_batch stops after the node sets,
+ * labels, ratings and the dense induced blocks -- everything the matrix-core subgraph kernel reads -- and the collated
+ * CSR (reference construct_pyg_graph + Batch.from_data_list, util_functions.py:280-297) is emitted on demand by the
+ * calls that need it (get_info / download / edge flags / model calls that run the per-layer kernels).  The training
+ * loop sets it when igmc_model_dense_path() says the model will take the dense path for this arena and batch size. */
+int igmc_batch_set_lean(igmc_batch* b, int lean);
 
 /* ------------------------------------------------------------------ model
  * Flat fp32 parameter buffer layout (offsets in floats; query with igmc_param_offset):
@@ -224,6 +230,9 @@ int igmc_profile_gs_clock(const igmc_model* m, int64_t* launches, double* mean_u
 /* Health check of the workspace (synchronises `stream`): fails when a bounded device-side wait of the
  * one-workgroup-per-subgraph step kernel ever timed out since the last check.  No reference counterpart. */
 int igmc_model_check(igmc_model* m, void* stream);
+/* 1 when forward / loss_grad / train_step on (this arena, batch size B) run the matrix-core subgraph kernel, which
+ * reads the dense blocks only (see igmc_batch_set_lean); 0 otherwise.  No reference counterpart. */
+int igmc_model_dense_path(const igmc_model* m, const igmc_batch* b, int B);
 
 #ifdef __cplusplus
 }

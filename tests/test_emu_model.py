@@ -179,3 +179,33 @@ def test_side_source_gathered_by_the_extraction_launch(be):
         ws.forward(P.ctypes.data, b, out.ctypes.data, training=False)
         outs.append(out.copy())
     assert np.array_equal(outs[0], outs[1]) and np.all(np.isfinite(outs[0])) and np.ptp(outs[0]) > 0
+
+
+def test_lean_extraction_feeds_the_dense_kernel(be):
+    """A lean arena (``igmc_batch_set_lean``) skips the CSR emission; the matrix-core subgraph kernel must give the same
+    loss / gradients from the dense blocks alone, and the CSR appears on demand (download) identical to the eager one."""
+    from igmc_amd import engine
+    case = sub('synth_cap', 8)
+    A = case['A']
+    g = engine.Graph(A, lib=be.lib)
+    lu, lv = case['links'][:, 0].astype(np.int32).copy(), case['links'][:, 1].astype(np.int32).copy()
+    ly = case['class_values'][case['link_labels']].astype(np.float32)
+    ref = PC.make_ref_model(4, 5, seed=6)
+    res = {}
+    for mode in ('eager', 'lean'):
+        b = engine.Batch(g, 8, 1, case['mnph'])
+        ws = engine.ModelWorkspace(be.lib, 0, 5, 4, 4, 0, b.node_capacity, b.edge_capacity, 8)
+        assert ws.dense_path(b, 8)
+        b.set_lean(mode == 'lean')
+        b.extract(lu.ctypes.data, lv.ctypes.data, ly.ctypes.data, None, 0, 8, seed=3, epoch=1)
+        P = PC.flatten_params(ws, ref)
+        out, grad, loss = np.zeros(8, np.float32), np.zeros(ws.n_params, np.float32), np.zeros(2, np.float32)
+        lm = (np.random.default_rng(1).random((8, 128)) < 0.5).astype(np.uint8)
+        ws.loss_grad(P.ctypes.data, b, out.ctypes.data, grad.ctypes.data, loss.ctypes.data, lin_mask=lm.ctypes.data, ARR=0.001)
+        d = b.download()
+        res[mode] = (out.copy(), grad.copy(), loss.copy(), d)
+    assert np.array_equal(res['eager'][0], res['lean'][0]) and np.array_equal(res['eager'][1], res['lean'][1])
+    assert np.array_equal(res['eager'][2], res['lean'][2])
+    for k in ('node_off', 'row_ptr', 'col', 'erel', 'node_label', 'node_gid', 'y'):
+        assert np.array_equal(res['eager'][3][k], res['lean'][3][k]), k
+    PC.check_batch_structure(res['lean'][3], 4)
