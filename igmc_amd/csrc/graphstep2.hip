@@ -43,9 +43,11 @@
 #define G2_TP (G2_NR * 32 + 4)    // pitch of a wave's 16-row T' tile (backward)
 #define G2_XP 36                  // pitch of a wave's 16-row x / dPre / h tile
 #define G2_FXTAG 7                // exchange index of the centre-node readout
-#define G2_WP 20                  // float2 per k-row of a staged weight image (16 + 4 padding: the four kq groups of a
-                                  // B-operand read then hit disjoint banks)
-#define G2_WIMG ((G2_NR * 32 + 32) * G2_WP * 2)      // floats of one staged image
+// One staged weight image = the B operand of a layer's dense transform as bf16 terms, in MFMA fragment order:
+// [term (hi, mid, lo)][block (relation 0..4, 5 = root)][16-column tile nt][lane] x 8 bf16; lane (li = column n & 15,
+// kq) holds rows k(kq, e) = (e < 4 ? 4 kq + e : 16 + 4 kq + e - 4) of its block -- the order in which the gather's
+// accumulators hold the input features of a row.
+#define G2_WIMG (G2_NT * (G2_NR + 1) * 2 * 64 * 4)   // 4-byte words of one staged image (36 KB)
 
 // phase clocks (debug aid, IGMC_GS_TIMING=1; igmc_debug_g2_clocks): thread 0 of workgroup 0 (member 0, user side) -> slots
 // 0..39 (fine stamps of its wave 0: 40..63), thread 0 of member 2 of the same subgraph (item side) -> slots 64..103
@@ -286,44 +288,64 @@ __device__ __forceinline__ void g2_gather(const uint32_t* pl, int kp, int nks, c
   }
 }
 
-// out (lane = output feature 16 nt + li, regs = rows 4 kq + 0..3) = [T_0..T_4 | x] @ sW: the gather's accumulators are
-// the A operand as they are: group (blk, t) = the 4 k-steps rr = 0..3 covering the input features 16 t + 4 kq' + rr
-// (kq' = 0..3) of block blk (relation, or G2_NR = the layer's own rows x, read from the bundle's LDS tile as float4).
-// sW[k][G2_WP] float2: element (k, n) at [k][n & 15].{x: n < 16, y: n >= 16}; the B operands of group g + 1 are requested
-// before the 8 MFMAs of group g.
-__device__ __forceinline__ void g2_transform(const f32x4 (&acc)[G2_NR][2], const float* xrows, const float2* sW, int li, int kq,
+// out (lane = output feature 16 nt + li, regs = rows 4 kq + 0..3) = [T_0..T_4 | x] @ [W_0; ..; W_4; root] on the bf16 matrix
+// cores at f32 accuracy: both operands as three bf16 terms, the six products down to 2^-24 (hi*hi, hi*mid, mid*hi, hi*lo,
+// lo*hi, mid*mid; f32 MFMA runs at 1/16 of this rate: 96 x 32 cycles per bundle against 72 x 17 here).  The gather's
+// accumulators ARE the A operand: lane (row li, kq) holds the input features 4 kq + 0..3 and 16 + 4 kq + 0..3 of every
+// relation block = the 8 k-slots of one 16x16x32 step; the staged image (k_g2_compose) orders the weights the same way.
+// Block G2_NR = the layer's own rows x, read from the bundle's LDS tile.  The six B fragments of block g + 1 are
+// requested before the 12 MFMAs of block g.
+__device__ __forceinline__ void g2_transform(const f32x4 (&acc)[G2_NR][2], const float* xrows, const uint32_t* sW, int li, int kq,
                                              f32x4 (&o)[2]) {
   f32x4 o0a = (f32x4){0.f, 0.f, 0.f, 0.f}, o0b = o0a, o1a = o0a, o1b = o0a;
   const float4 x0 = *(const float4*)(xrows + li * G2_XP + 4 * kq), x1 = *(const float4*)(xrows + li * G2_XP + 16 + 4 * kq);
-  float2 bv[2][4];
-  const float2* wb = sW + (4 * kq) * G2_WP + li;
+  const u32x4* wf = (const u32x4*)sW + (kq * 16 + li);             // lane's fragment inside a [64]-lane group
+  u32x4 bf[2][2 * G2_NT];
   auto request = [&](int g, int buf) {
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) bv[buf][rr] = wb[(g * 16 + rr) * G2_WP];
+    for (int t = 0; t < G2_NT; ++t) {
+      bf[buf][2 * t] = wf[((t * (G2_NR + 1) + g) * 2 + 0) * 64];
+      bf[buf][2 * t + 1] = wf[((t * (G2_NR + 1) + g) * 2 + 1) * 64];
+    }
   };
   request(0, 0);
 #pragma unroll
-  for (int g = 0; g < 2 * (G2_NR + 1); ++g) {
-    if (g + 1 < 2 * (G2_NR + 1)) request(g + 1, (g + 1) & 1);
-    G2_SCHED_BARRIER();
-    float av[4];
-    if (g < 2 * G2_NR) {
+  for (int g = 0; g <= G2_NR; ++g) {
+    if (g < G2_NR) request(g + 1, (g + 1) & 1);
+    float v[8];
+    if (g < G2_NR) {
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) av[rr] = acc[g >> 1][g & 1][rr];
-    } else {
-      const float4 xv = (g & 1) ? x1 : x0;
-      av[0] = xv.x; av[1] = xv.y; av[2] = xv.z; av[3] = xv.w;
-    }
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      if (rr & 1) {
-        o0b = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rr], bv[g & 1][rr].x, o0b, 0, 0, 0);
-        o1b = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rr], bv[g & 1][rr].y, o1b, 0, 0, 0);
-      } else {
-        o0a = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rr], bv[g & 1][rr].x, o0a, 0, 0, 0);
-        o1a = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rr], bv[g & 1][rr].y, o1a, 0, 0, 0);
+      for (int rr = 0; rr < 4; ++rr) {
+        v[rr] = acc[g][0][rr];
+        v[4 + rr] = acc[g][1][rr];
       }
+    } else {
+      v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w;
+      v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
     }
+    u32x4 ah, am, al;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t h, mi, lo;
+      g2_split2(v[2 * q], v[2 * q + 1], h, mi, lo);
+      ah[q] = h;
+      am[q] = mi;
+      al[q] = lo;
+    }
+    G2_SCHED_BARRIER();
+    const u32x4 (&b)[2 * G2_NT] = bf[g & 1];        // [2 term + nt]
+    o0a = g2_mfma_bf16(ah, b[0], o0a);
+    o1a = g2_mfma_bf16(ah, b[1], o1a);
+    o0b = g2_mfma_bf16(ah, b[2], o0b);
+    o1b = g2_mfma_bf16(ah, b[3], o1b);
+    o0a = g2_mfma_bf16(am, b[0], o0a);
+    o1a = g2_mfma_bf16(am, b[1], o1a);
+    o0b = g2_mfma_bf16(ah, b[4], o0b);
+    o1b = g2_mfma_bf16(ah, b[5], o1b);
+    o0a = g2_mfma_bf16(al, b[0], o0a);
+    o1a = g2_mfma_bf16(al, b[1], o1a);
+    o0b = g2_mfma_bf16(am, b[2], o0b);
+    o1b = g2_mfma_bf16(am, b[3], o1b);
     G2_SCHED_BARRIER();
   }
 #pragma unroll
@@ -400,7 +422,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
   float* HSS = S + lay.hs;                              // [4][16][G2_XP] h_{l-1} rows of the bundle (backward)
   float* TILES = S + lay.tile;                          // [4][16][G2_TP] T' rows of the bundle (backward)
   float* HIST = S + lay.hist;                           // [4][16][G2_XP] layer-0 input [code histogram | onehot | 1]
-  float2* sW2 = (float2*)(S + lay.wreg);                // [192][G2_WP] B operand of the layer
+  float2* sW2 = (float2*)(S + lay.wreg);                // [G2_WIMG words] B operand of the layer as bf16 term fragments
   float* sT0 = S + lay.t0;                              // [32][32] layer-0 table
   float* sfeat = S + lay.head;            // [256] centre-node readout
   float* sgf = sfeat + 256;               // [256] d feat
@@ -572,18 +594,18 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
 
     // B operand of the next conv layer ([W_0; ..; W_4; root] or the transposes, composed once per step by
     // k_g2_compose): requested a phase ahead, written to LDS by stage()
-    float4 wq[8];
+    float4 wq[9];
     auto wpre = [&](int l, int trans) {
       const float4* src = (const float4*)(a.g2_w + (size_t)((l - 1) * 2 + trans) * G2_WIMG);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < 9; ++q) {
         const int i = tid + q * G2_THREADS;
         wq[q] = (i < G2_WIMG / 4) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     };
     auto stage = [&]() {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < 9; ++q) {
         const int i = tid + q * G2_THREADS;
         if (i < G2_WIMG / 4) ((float4*)sW2)[i] = wq[q];
       }
@@ -688,7 +710,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
         g2_gather(pl, kp, nks, AF, li_, kq_, acc);
         if (l == 2) G2_STAMP(40);
         f32x4 o[2];
-        g2_transform(acc, XOc, sW2, li_, kq_, o);
+        g2_transform(acc, XOc, (const uint32_t*)sW2, li_, kq_, o);
         if (l == 2) G2_STAMP(41);
         fwd_out(l, o, bias0_, bias1_, XOn);
       }
@@ -876,7 +898,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
           unsigned long long* exb = a.g2_ex + (6 - l) * exs + ((size_t)g * 2 + side) * 4096 + (size_t)li * 128 + row0 + 4 * kq;
           const uint32_t tgb = tag16(6 - l);
           if (l == 2) G2_STAMP(45);
-          g2_transform(acc, XOc, sW2, li_, kq_, o);
+          g2_transform(acc, XOc, (const uint32_t*)sW2, li_, kq_, o);
           if (l == 2) G2_STAMP(46);
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) {
@@ -1064,7 +1086,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_compose(ModelDev m, const flo
     }
     return;
   }
-  float* img = w + (size_t)blockIdx.x * G2_WIMG;
+  uint16_t* img = (uint16_t*)(w + (size_t)blockIdx.x * G2_WIMG);
   const float* basis = P + m.off_basis[l];
   const int f = tid >> 3, n0 = (4 * tid) & 31;            // W_r[f][n0 .. n0 + 3]
   float4 b4[4];
@@ -1087,8 +1109,15 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_compose(ModelDev m, const flo
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int k = trans ? r * 32 + n0 + q : r * 32 + f, n = trans ? f : n0 + q;
-      img[(k * G2_WP + (n & 15)) * 2 + (n >> 4)] = v[q];
+      // element (k, n) of the block's B operand: forward W_r[k = f][n = n0 + q], backward its transpose
+      const int k = trans ? n0 + q : f, n = trans ? f : n0 + q;
+      const int kq = (k & 15) >> 2, e = (k & 3) + ((k >> 4) << 2);
+      const int lane = kq * 16 + (n & 15), nt = n >> 4;
+      uint32_t h, mi, lo;
+      g2_split2(v[q], 0.f, h, mi, lo);
+      const uint32_t t3[3] = {h & 0xFFFFu, mi & 0xFFFFu, lo & 0xFFFFu};
+#pragma unroll
+      for (int t = 0; t < G2_NT; ++t) img[((size_t)(((t * (G2_NR + 1) + r) * 2 + nt) * 64 + lane)) * 8 + e] = (uint16_t)t3[t];
     }
   }
 }
