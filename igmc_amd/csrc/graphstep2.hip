@@ -154,49 +154,69 @@ __device__ __forceinline__ void g2_pub_f32(unsigned long long* p, float v, uint3
 }
 
 // The planes [term][feature][node] of one side from its exchange region ex[feature][KMAX nodes]: nodes < npad (a
-// multiple of 16, <= 128) of all 32 features = 16 * npad word pairs, <= 8 per thread; every pending request of a thread
-// is in flight before the single wait, pairs whose tags are not this exchange's are requested again.
-__device__ __forceinline__ void g2_reload(uint32_t* pl, int kp, const unsigned long long* ex, int npad, uint32_t tag16,
-                                          int* err) {
-  const int hp = npad >> 1, total = 32 * hp, t0 = (int)threadIdx.x;      // pairs per feature, pairs in all
+// multiple of 16, <= 128) of all 32 features = 16 * npad word pairs, <= 8 per thread.  Two halves, so that the round
+// trip can run under other work: g2_poll_issue requests every pair of the thread (16-byte sc1 buffer loads the compiler
+// tracks -- no inline asm, nothing to mis-schedule), g2_poll_finish consumes them; pairs whose tags are not this
+// exchange's are requested again until they are.
+struct G2Poll {
+  u32x4 v[8];
+};
 #ifndef IGMC_HIPEMU
-  uint32_t pend = 0;
-  const u32x4* gp[8];
-  int dst[8];
+__device__ __forceinline__ u32x4 g2_ld16_sc1(const unsigned long long* base, int byte_off) {
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+  return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);       // aux 16 = sc1: served by L2, bypasses this CU's L1
+}
+#endif
+__device__ __forceinline__ void g2_poll_issue(G2Poll& pq, const unsigned long long* ex, int npad) {
+#ifndef IGMC_HIPEMU
+  const int hp = npad >> 1, total = 32 * hp, t0 = (int)threadIdx.x;
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     const int p = t0 + u * G2_THREADS;
     const int f = (p < total) ? p / hp : 0, q = (p < total) ? p - f * hp : 0;
-    gp[u] = (const u32x4*)(ex + f * 128 + 2 * q);
-    dst[u] = (f * kp >> 1) + q;                    // dword index inside a term's plane
-    pend |= (p < total) ? (1u << u) : 0u;
+    pq.v[u] = g2_ld16_sc1(ex, (f * 128 + 2 * q) * 8);
   }
-  u32x4 v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, v7 = 0;
-  const int tstride = 32 * kp >> 1;                // dwords per term
-#define G2_LD(V, U) \
-  if (pend & (1u << (U))) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(V) : "v"(gp[U]) : "memory");
-#define G2_CK(V, U)                                                                          \
-  if ((pend & (1u << (U))) && (V.y >> 16) == tag16 && (V.w >> 16) == tag16) {                \
-    pl[dst[U]] = (V.x & 0xFFFFu) | (V.z << 16);                                              \
-    pl[tstride + dst[U]] = (V.x >> 16) | (V.z & 0xFFFF0000u);                                \
-    pl[2 * tstride + dst[U]] = (V.y & 0xFFFFu) | (V.w << 16);                                \
-    pend &= ~(1u << (U));                                                                    \
-  }
+#else
+  (void)pq; (void)ex; (void)npad;
+#endif
+}
+__device__ __forceinline__ void g2_poll_finish(G2Poll& pq, uint32_t* pl, int kp, const unsigned long long* ex, int npad,
+                                               uint32_t tag16, int* err) {
+  const int hp = npad >> 1, total = 32 * hp, t0 = (int)threadIdx.x;      // pairs per feature, pairs in all
+  const int tstride = 32 * kp >> 1;                                       // dwords per term
+#ifndef IGMC_HIPEMU
+  uint32_t pend = 0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) pend |= (t0 + u * G2_THREADS < total) ? (1u << u) : 0u;
   for (int it = 0;; ++it) {
-    G2_LD(v0, 0) G2_LD(v1, 1) G2_LD(v2, 2) G2_LD(v3, 3) G2_LD(v4, 4) G2_LD(v5, 5) G2_LD(v6, 6) G2_LD(v7, 7)
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : : "memory");
-    G2_CK(v0, 0) G2_CK(v1, 1) G2_CK(v2, 2) G2_CK(v3, 3) G2_CK(v4, 4) G2_CK(v5, 5) G2_CK(v6, 6) G2_CK(v7, 7)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const u32x4 V = pq.v[u];
+      if ((pend & (1u << u)) && (V.y >> 16) == tag16 && (V.w >> 16) == tag16) {
+        const int p = t0 + u * G2_THREADS, f = p / hp, q = p - f * hp;
+        const int d = (f * kp >> 1) + q;                                   // dword index inside a term's plane
+        pl[d] = (V.x & 0xFFFFu) | (V.z << 16);
+        pl[tstride + d] = (V.x >> 16) | (V.z & 0xFFFF0000u);
+        pl[2 * tstride + d] = (V.y & 0xFFFFu) | (V.w << 16);
+        pend &= ~(1u << u);
+      }
+    }
     if (!pend) break;
     if (it > (1 << 20)) {
       *err = 1;
       break;
     }
     __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (pend & (1u << u)) {
+        const int p = t0 + u * G2_THREADS, f = p / hp, q = p - f * hp;
+        pq.v[u] = g2_ld16_sc1(ex, (f * 128 + 2 * q) * 8);
+      }
+    }
   }
-#undef G2_LD
-#undef G2_CK
 #else
-  const int tstride = 32 * kp >> 1;
+  (void)pq;
   for (int p = t0; p < total; p += G2_THREADS) {
     const int f = p / hp, q = p - f * hp;
     const unsigned long long* e = ex + f * 128 + 2 * q;
@@ -219,6 +239,12 @@ __device__ __forceinline__ void g2_reload(uint32_t* pl, int kp, const unsigned l
     }
   }
 #endif
+}
+__device__ __forceinline__ void g2_reload(uint32_t* pl, int kp, const unsigned long long* ex, int npad, uint32_t tag16,
+                                          int* err) {
+  G2Poll pq;
+  g2_poll_issue(pq, ex, npad);
+  g2_poll_finish(pq, pl, kp, ex, npad, tag16, err);
 }
 
 // one 8-byte {f32, tag} word, polled
@@ -460,6 +486,20 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
   const int g_first = (cs > 1) ? (int)(blockIdx.x % a.stride) : (int)blockIdx.x;
   const int g_pre = (g_first < a.graph_cap) ? g_first : a.graph_cap - 1;      // (a padding workgroup: any valid slot)
   const int pre_cu = a.n_users[g_pre], pre_cv = a.n_items[g_pre];
+  // ... and so are the set-up's global loads, which depend on the subgraph slot only (labels from the per-graph scratch
+  // slots, relm rows up to the slot capacity): ONE round trip, under the kernel's scalar prologue
+  const int ld = a.relm_ld, ldw = ld >> 2;
+  auto load_label = [&](int g2) {
+    return (int)a.s_lab[(size_t)g2 * a.slot + ((tid >> 7) ? a.cap_u : 0) + (((tid & 127) < ((tid >> 7) ? a.cap_v : a.cap_u)) ? (tid & 127) : 0)];
+  };
+  uint32_t rmv[16];          // dword (tid & 31) of rows (tid >> 5) + 8 q  (ld <= 128 bytes, <= 128 rows)
+  auto load_relm = [&](int g2) {
+    const uint32_t* rm = (const uint32_t*)(a.relm + (size_t)g2 * a.cap_u * ld) + (tid >> 5) * ldw + (tid & 31);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) rmv[q] = ((tid & 31) < ldw && (tid >> 5) + 8 * q < a.cap_u) ? rm[8 * q * ldw] : 0u;
+  };
+  int labv_raw = load_label(g_pre);
+  load_relm(g_pre);
   ((float4*)sT0)[tid] = ((const float4*)(a.g2_w + 6 * G2_WIMG))[tid];
   f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};        // layer-0 table gradient tile (code half, feature half) of this wave
   bool first_graph = true;
@@ -467,15 +507,9 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
 
 #pragma unroll 1
   for (int g = g_first; g < B; g += (cs > 1) ? B : (int)gridDim.x) {
-    // the set-up's global loads depend on g only (labels from the per-graph scratch slots, relm rows up to the slot
-    // capacity): ONE round trip together with the subgraph's extents
-    const int ld = a.relm_ld, ldw = ld >> 2;
-    const int labv_raw = (int)a.s_lab[(size_t)g * a.slot + ((tid >> 7) ? a.cap_u : 0) + (((tid & 127) < ((tid >> 7) ? a.cap_v : a.cap_u)) ? (tid & 127) : 0)];
-    uint32_t rmv[16];        // dword (tid & 31) of rows (tid >> 5) + 8 q  (ld <= 128 bytes, <= 128 rows)
-    {
-      const uint32_t* rm = (const uint32_t*)(a.relm + (size_t)g * a.cap_u * ld) + (tid >> 5) * ldw + (tid & 31);
-#pragma unroll
-      for (int q = 0; q < 16; ++q) rmv[q] = ((tid & 31) < ldw && (tid >> 5) + 8 * q < a.cap_u) ? rm[8 * q * ldw] : 0u;
+    if (!first_graph) {
+      labv_raw = load_label(g);
+      load_relm(g);
     }
     const int cu = first_graph ? pre_cu : a.n_users[g], cv = first_graph ? pre_cv : a.n_items[g];
     const int n_own = side ? cv : cu, n_opp = side ? cu : cv;
@@ -923,6 +957,8 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
         G2_STAMP(20 + 5 * (3 - l));
         __syncthreads();                             // the four tiles / h chunks / dPre tiles of the workgroup are complete
         G2_STAMP(21 + 5 * (3 - l));
+        G2Poll pq;
+        const int npad_opp = ((n_opp + 15) >> 4) << 4;
         {
           // weight-gradient table h_{l-1}^T [T' | dPre_l], split by OUTPUT tile: wave w computes 6 of the 2 x 12 tiles
           // (row half m2 = in-features, column tile nt: 0..9 = T' of relation nt >> 1, 10..11 = dPre -> d root) over
@@ -933,6 +969,9 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
           const int m2w = wave >> 1, wo = wave & 1;
 #pragma unroll 1
           for (int wb = 0; wb < G2_NW; ++wb) {
+            // the exchange of dPre_{l-1} runs UNDER the table product: its words are requested half way through (the
+            // other members published them before their own barrier) and consumed after it
+            if (wb == 2 && l > 1 && nsides == 1) g2_poll_issue(pq, a.g2_ex + (6 - l) * exs + ((size_t)g * 2 + (1 - side)) * 4096, npad_opp);
             const float* Tb = TILES + wb * 16 * G2_TP;
             const float* Hb = HSS + wb * 16 * G2_XP;
             const float* Db = XOA + (((l & 1) ? 0 : G2_NW) + wb) * 16 * G2_XP;
@@ -974,11 +1013,14 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
         G2_STAMP(22 + 5 * (3 - l));
         if (l > 1) {
           wpre(l - 1, 1);
-          for (int s2 = 0; s2 < nsides; ++s2) {
-            const int sd = (nsides == 2) ? s2 : 1 - side;
-            const int n_sd = sd ? cv : cu;
-            g2_reload(PLN + s2 * (G2_NT * 32 * kp >> 1), kp, a.g2_ex + (6 - l) * exs + ((size_t)g * 2 + sd) * 4096,
-                      ((n_sd + 15) >> 4) << 4, tag16(6 - l), a.gs_err);
+          if (nsides == 1) {
+            g2_poll_finish(pq, PLN, kp, a.g2_ex + (6 - l) * exs + ((size_t)g * 2 + (1 - side)) * 4096, npad_opp, tag16(6 - l), a.gs_err);
+          } else {
+            for (int s2 = 0; s2 < nsides; ++s2) {
+              const int n_sd = s2 ? cv : cu;
+              g2_reload(PLN + s2 * (G2_NT * 32 * kp >> 1), kp, a.g2_ex + (6 - l) * exs + ((size_t)g * 2 + s2) * 4096,
+                        ((n_sd + 15) >> 4) << 4, tag16(6 - l), a.gs_err);
+            }
           }
         }
         __syncthreads();
