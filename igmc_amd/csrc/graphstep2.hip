@@ -169,13 +169,11 @@ __device__ __forceinline__ u32x4 g2_ld16_sc1(const unsigned long long* base, int
 #endif
 __device__ __forceinline__ void g2_poll_issue(G2Poll& pq, const unsigned long long* ex, int npad) {
 #ifndef IGMC_HIPEMU
-  const int hp = npad >> 1, total = 32 * hp, t0 = (int)threadIdx.x;
+  // pair p = thread + 256 u  ->  feature p >> 6, node pair p & 63 (pairs past npad are never consumed)
+  const int t0 = (int)threadIdx.x;
+  (void)npad;
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int p = t0 + u * G2_THREADS;
-    const int f = (p < total) ? p / hp : 0, q = (p < total) ? p - f * hp : 0;
-    pq.v[u] = g2_ld16_sc1(ex, (f * 128 + 2 * q) * 8);
-  }
+  for (int u = 0; u < 8; ++u) pq.v[u] = g2_ld16_sc1(ex, (t0 + u * G2_THREADS) * 16);
 #else
   (void)pq; (void)ex; (void)npad;
 #endif
@@ -185,16 +183,16 @@ __device__ __forceinline__ void g2_poll_finish(G2Poll& pq, uint32_t* pl, int kp,
   const int hp = npad >> 1, total = 32 * hp, t0 = (int)threadIdx.x;      // pairs per feature, pairs in all
   const int tstride = 32 * kp >> 1;                                       // dwords per term
 #ifndef IGMC_HIPEMU
-  uint32_t pend = 0;
-#pragma unroll
-  for (int u = 0; u < 8; ++u) pend |= (t0 + u * G2_THREADS < total) ? (1u << u) : 0u;
+  (void)total;
+  const int q0 = t0 & 63;                                                 // this thread's node pair (of 64 per feature)
+  uint32_t pend = (q0 < hp) ? 0xFFu : 0u;
+  const int d0 = ((t0 >> 6) * kp >> 1) + q0;                              // feature (t0 >> 6) + 4 u
   for (int it = 0;; ++it) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const u32x4 V = pq.v[u];
       if ((pend & (1u << u)) && (V.y >> 16) == tag16 && (V.w >> 16) == tag16) {
-        const int p = t0 + u * G2_THREADS, f = p / hp, q = p - f * hp;
-        const int d = (f * kp >> 1) + q;                                   // dword index inside a term's plane
+        const int d = d0 + u * (4 * kp >> 1);                              // dword index inside a term's plane
         pl[d] = (V.x & 0xFFFFu) | (V.z << 16);
         pl[tstride + d] = (V.x >> 16) | (V.z & 0xFFFF0000u);
         pl[2 * tstride + d] = (V.y & 0xFFFFu) | (V.w << 16);
@@ -208,12 +206,8 @@ __device__ __forceinline__ void g2_poll_finish(G2Poll& pq, uint32_t* pl, int kp,
     }
     __builtin_amdgcn_s_sleep(2);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (pend & (1u << u)) {
-        const int p = t0 + u * G2_THREADS, f = p / hp, q = p - f * hp;
-        pq.v[u] = g2_ld16_sc1(ex, (f * 128 + 2 * q) * 8);
-      }
-    }
+    for (int u = 0; u < 8; ++u)
+      if (pend & (1u << u)) pq.v[u] = g2_ld16_sc1(ex, (t0 + u * G2_THREADS) * 16);
   }
 #else
   (void)pq;
@@ -465,8 +459,6 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
   const int cs = a.cs;
   const int cm = (cs > 1) ? blockIdx.x / a.stride : 0;
   const int half = 2 * cs;                              // waves of the cluster per side
-  const int gw = cm * G2_NW + wave;
-  const int side = gw / half, bi = gw - side * half;    // this wave's side (0 users, 1 items) and bundle of that side
   const int rmr = lay.rmr, rmc = lay.rmc, rmp = lay.rmc + 8;      // image rows, columns, row pitch (bytes)
 #ifndef IGMC_HIPEMU
   const uint32_t seq = (uint32_t)__hip_atomic_load(a.gs_bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -498,8 +490,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) rmv[q] = ((tid & 31) < ldw && (tid >> 5) + 8 * q < a.cap_u) ? rm[8 * q * ldw] : 0u;
   };
-  int labv_raw = load_label(g_pre);
-  load_relm(g_pre);
+  int labv_raw = 0;
   ((float4*)sT0)[tid] = ((const float4*)(a.g2_w + 6 * G2_WIMG))[tid];
   f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};        // layer-0 table gradient tile (code half, feature half) of this wave
   bool first_graph = true;
@@ -507,10 +498,17 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
 
 #pragma unroll 1
   for (int g = g_first; g < B; g += (cs > 1) ? B : (int)gridDim.x) {
-    if (!first_graph) {
-      labv_raw = load_label(g);
-      load_relm(g);
-    }
+    // per-lane indices are re-derived from an opaque copy of the thread index INSIDE the subgraph loop: everything
+    // computed from them then stays inside it (hoisted out of the loop, hundreds of loop-invariant addresses occupy --
+    // and spill -- registers for the whole kernel)
+    int tid_g = threadIdx.x;
+    G2_OPAQUE(tid_g);
+    const int tid = tid_g, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int gw = cm * G2_NW + wave;
+    const int side = gw / half, bi = gw - side * half;    // this wave's side (0 users, 1 items) and bundle of that side
+    labv_raw = load_label(g);
+    load_relm(g);
     const int cu = first_graph ? pre_cu : a.n_users[g], cv = first_graph ? pre_cv : a.n_items[g];
     const int n_own = side ? cv : cu, n_opp = side ? cu : cv;
     const int nbs = g * a.slot + (side ? a.cap_u : 0);       // first row of this wave's side in the h_l scratch (slot-based:
