@@ -59,7 +59,7 @@ __device__ unsigned long long g_g2_clk[128];
   do {                                                                                                     \
     if (a.timing && threadIdx.x == 0) {                                                                    \
       if (blockIdx.x == 0) g_g2_clk[k] = __builtin_readcyclecounter();                                     \
-      else if (a.cs > 2 && (int)blockIdx.x == 2 * a.stride && (k) < 40) g_g2_clk[64 + (k)] = __builtin_readcyclecounter(); \
+      else if (a.cs > 2 && (int)blockIdx.x == 2 && (k) < 40) g_g2_clk[64 + (k)] = __builtin_readcyclecounter(); \
     }                                                                                                      \
   } while (0)
 #endif
@@ -457,7 +457,12 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
   const int B = a.B;
   const int ts = a.ts_stride;
   const int cs = a.cs;
-  const int cm = (cs > 1) ? blockIdx.x / a.stride : 0;
+  // The members of a cluster are CONSECUTIVE workgroups (subgraph = blockIdx / cs): workgroups are handed to the CUs in
+  // index order, so with any number >= cs of free CUs the first clusters are complete, finish and make room for the
+  // next -- a partly resident chip (another kernel holding CUs) slows the launch down but cannot leave every resident
+  // member waiting for a non-resident one.  (Members need not share an XCD: sc1 words are served from the coherent
+  // level wherever they were written.)  The bounded polls stay as the backstop.
+  const int cm = (cs > 1) ? (int)(blockIdx.x % cs) : 0;
   const int half = 2 * cs;                              // waves of the cluster per side
   const int rmr = lay.rmr, rmc = lay.rmc, rmp = lay.rmc + 8;      // image rows, columns, row pitch (bytes)
 #ifndef IGMC_HIPEMU
@@ -475,7 +480,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
 
   // ---- the first subgraph's extents are requested before anything else (two dependent round trips overlap with
   //      the staging of the layer-0 table, which k_g2_compose formed from the current weights)
-  const int g_first = (cs > 1) ? (int)(blockIdx.x % a.stride) : (int)blockIdx.x;
+  const int g_first = (cs > 1) ? (int)(blockIdx.x / cs) : (int)blockIdx.x;
   const int g_pre = (g_first < a.graph_cap) ? g_first : a.graph_cap - 1;      // (a padding workgroup: any valid slot)
   const int pre_cu = a.n_users[g_pre], pre_cv = a.n_items[g_pre];
   // ... and so are the set-up's global loads, which depend on the subgraph slot only (labels from the per-graph scratch
@@ -492,6 +497,8 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
   };
   int labv_raw = 0;
   ((float4*)sT0)[tid] = ((const float4*)(a.g2_w + 6 * G2_WIMG))[tid];
+  // partial-table slot of this workgroup: member c of subgraph g -> g + c * stride (what k_tail_ts sums)
+  const int tslot = (cs > 1) ? g_first + cm * a.stride : (int)blockIdx.x;
   f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};        // layer-0 table gradient tile (code half, feature half) of this wave
   bool first_graph = true;
   G2_STAMP(1);
@@ -876,7 +883,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
         float* XOc = (l & 1) ? XO0 : XO1;            // dPre_l of the bundle's own rows
         float* XOn = (l & 1) ? XO1 : XO0;            // dPre_{l-1}
         stage();
-        float* wpart = a.ts_part + ((size_t)l * IGMC_TS_BLOCKS + blockIdx.x) * ts;
+        float* wpart = a.ts_part + ((size_t)l * IGMC_TS_BLOCKS + tslot) * ts;
         {   // d bias_l = column sums of dPre_l over this workgroup's rows (fixed order)
           const int n = tid & 31, part = tid >> 5;
           float sb = 0.f;
@@ -1045,7 +1052,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
   }
 
   if (TRAIN) {
-    float* part0 = a.ts_part + (size_t)blockIdx.x * ts;        // slice 0 of [4][IGMC_TS_BLOCKS][ts]
+    float* part0 = a.ts_part + (size_t)tslot * ts;             // slice 0 of [4][IGMC_TS_BLOCKS][ts]
     const int m2 = wave >> 1, wn = wave & 1;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -1236,13 +1243,13 @@ void igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* 
   a.ts = (g_igmc_prof_on == 2) ? m.gs_ts : nullptr;
   a.cs = cs;
   a.stride = (cs > 1) ? ((B + 7) & ~7) : 1;
-  const int grid = (cs > 1) ? cs * a.stride : igmc_gs_grid(B);
+  const int grid = (cs > 1) ? cs * B : igmc_gs_grid(B);
   const size_t sm = (size_t)lay.words * 4;
   IGMC_PLAUNCH("k_g2_compose", k_g2_compose, 7, G2_THREADS, 0, stream, m, P, m.g2_w);
 #ifdef IGMC_HIPEMU
   if (cs > 1) {        // (after the launch above: a launch consumes the co-residency request)
     hipemu::rt().co_cs = cs;
-    hipemu::rt().co_stride = a.stride;
+    hipemu::rt().co_stride = -1;       // members of a cluster = consecutive workgroups
   }
 #endif
   if (getenv("IGMC_GS_TRACE")) fprintf(stderr, "[igmc] k_graph_step B=%d train=%d flags=%d v2 kp=%d lds=%zu cluster=%d grid=%d\n", B, training, use_flags, lay.kp, sm, cs, grid);

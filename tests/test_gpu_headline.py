@@ -117,3 +117,43 @@ def test_ml100k_cap200_batch_matches_oracle(be):
     assert res['worst_grad_err'] < 2e-3
     PC.check_sampled(res['d'], case)
     assert res['d']['N'] > 50 * 200
+
+
+def test_training_steps_survive_a_competing_full_chip_kernel(ml1m):
+    """The cluster exchange of the subgraph kernel needs its members resident together.  Members are consecutive
+    workgroups, so a chip that is partly held by ANOTHER kernel (here: a stream of large GEMMs on a second stream, all 256
+    CUs busy) only delays clusters -- complete ones finish and free their CUs -- and never strands them: the steps must
+    produce bit-identical parameters to an undisturbed run and no bounded wait may time out (igmc_model_check)."""
+    import torch
+    from igmc_amd.models import IGMC
+    from igmc_amd.stepgraph import StepGraph
+    from igmc_amd.train_eval import FlatAdam
+    from igmc_amd.util_functions import MyDynamicDataset
+    A, links, labels, cv = ml1m['A'], ml1m['links'], ml1m['link_labels'], ml1m['class_values']
+    ds = MyDynamicDataset('data/t/hog', A, (links[:, 0], links[:, 1]), labels, 1, 1.0, 100, None, None, cv, device=0, seed=1)
+    perm = torch.arange(len(ds))
+    out = {}
+    for mode in ('quiet', 'loaded'):
+        torch.manual_seed(3)
+        model = IGMC(ds, latent_dim=[32, 32, 32, 32], num_relations=5, num_bases=4, regression=True, adj_dropout=0.0,
+                     seed=1).to('cuda')
+        model.reset_parameters()
+        opt = FlatAdam(model, lr=1e-3)
+        sg = StepGraph(model, opt, ds, 50, 0.001, use_graph=False, overlap=True)
+        assert sg.ws.dense_path(sg.arenas[0], 50)
+        hog = torch.cuda.Stream()
+        stop = None
+        if mode == 'loaded':
+            x = torch.randn(8192, 8192, device='cuda', dtype=torch.bfloat16)
+            with torch.cuda.stream(hog):
+                for _ in range(40):              # ~ tens of milliseconds of full-chip GEMM queued beside the steps
+                    x = (x @ x).clamp_(-1, 1)
+            stop = x
+        sg.begin_epoch(perm, 1)
+        for _ in range(5):
+            sg.step()
+        sg.check()                               # raises if a bounded device-side wait timed out
+        torch.cuda.synchronize()
+        out[mode] = model.flat_parameters().detach().cpu().clone()
+        del stop
+    assert torch.equal(out['quiet'], out['loaded'])

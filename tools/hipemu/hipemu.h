@@ -275,12 +275,14 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> bo
   if (cs > 1) {
     // clusters: members g, g + stride, .. of a 1-D grid are resident together (NOTE: function-scope `__shared__`
     // variables are plain statics here and would be shared by them -- cluster kernels use dynamic LDS only)
-    if (grid.y != 1 || grid.z != 1 || stride < 1) { fprintf(stderr, "hipemu: cluster launches need a 1-D grid\n"); abort(); }
+    // (stride < 0: the members of cluster g are the consecutive workgroups g * cs .. g * cs + cs - 1)
+    if (grid.y != 1 || grid.z != 1 || stride == 0) { fprintf(stderr, "hipemu: cluster launches need a 1-D grid\n"); abort(); }
     if ((int)r.blocks.size() < cs) r.blocks.resize(cs);
-    for (int g = 0; g < stride; ++g) {
+    const int ngroups = (stride < 0) ? ((int)grid.x + cs - 1) / cs : stride;
+    for (int g = 0; g < ngroups; ++g) {
       r.nres = 0;
       for (int c = 0; c < cs; ++c) {
-        const unsigned b = (unsigned)(g + c * stride);
+        const unsigned b = (stride < 0) ? (unsigned)(g * cs + c) : (unsigned)(g + c * stride);
         if (b < grid.x) prepare_block(r.blocks[r.nres++], uint3_emu{b, 0, 0}, shmem);
       }
       if (r.nres) run_resident(nthreads);
