@@ -32,7 +32,7 @@ def main():
     src, dst = sys.argv[1], sys.argv[2]
     config = sys.argv[3] if len(sys.argv) > 3 else 'ml_1m'
     # bench.py's roofline kernel: training instantiation, with edge flags when the config has adj-dropout
-    KERNEL = 'k_graph_step<false, true>' if config == 'ml_1m' else 'k_graph_step<true, true>'
+    KERNEL = 'k_graph_step2<false, true>' if config == 'ml_1m' else 'k_graph_step2<true, true>'
     c = {}
     for f in ('pmc1.txt', 'pmc2.txt'):
         c.update(counters('%s/%s' % (src, f), KERNEL))
