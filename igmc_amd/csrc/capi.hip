@@ -386,6 +386,22 @@ extern "C" int igmc_extract_batch_replay(const igmc_graph* g, igmc_batch* b, int
   return 0;
 }
 
+extern "C" int igmc_extract_batch_cached(const igmc_graph* g, igmc_batch* b, const int64_t* d_uoff, const int32_t* d_unodes,
+                                         const uint8_t* d_udist, const int64_t* d_voff, const int32_t* d_vnodes,
+                                         const uint8_t* d_vdist, const float* d_link_y, const int32_t* d_link_idx, int first,
+                                         int B, void* stream) {
+  if (!g || !b || b->g != g) IGMC_FAIL("batch does not belong to this graph");
+  if (B <= 0 || B > b->d.graph_cap) IGMC_FAIL("B exceeds the batch capacity");
+  if (!d_uoff || !d_unodes || !d_udist || !d_voff || !d_vnodes || !d_vdist || !d_link_y) IGMC_FAIL("null cache arrays");
+  igmc_launch_load_nodes(b->d, d_uoff, d_unodes, d_udist, d_voff, d_vnodes, d_vdist, d_link_y, d_link_idx, first, B, b->ctrl,
+                         stream);
+  igmc_launch_extract(g->d, b->d, nullptr, nullptr, nullptr, nullptr, 0, B, 1, 1.0, 0, 0, nullptr, b->lean && b->d.relm, stream);
+  if (b->side_src) igmc_launch_side_gather(b->side_src, b->n_side, d_link_idx, first, B, b->ctrl, b->side_buf, stream);
+  HIPCHECK(hipGetLastError());
+  b->last_B = B;
+  return 0;
+}
+
 // A lean arena carries no collated CSR after an extraction: whoever needs it (inspection, the flag kernels, the
 // per-layer model kernels) emits it first.  Emission is idempotent, and a hipGraph replay of the extraction leaves no
 // host-side trace, so a lean arena re-emits on every such call.

@@ -806,6 +806,46 @@ void igmc_launch_relm_flags(const BatchDev& b, void* stream) {
   if (b.relm) IGMC_PLAUNCH("k_relm_flags", k_relm_flags, 256, IGMC_BLOCK, 0, stream, b);
 }
 
+// ---------------------------------------------------------------- static (cached) subgraphs
+// reference MyDataset (util_functions.py:69-110): the enclosing subgraphs of a dataset are extracted ONCE and kept.  The
+// native cache keeps, per link, the node sets with their hop distances (packed arrays resident in HBM, also saved under
+// <root>/processed/); a batch loads the lists of its links into the arena's per-graph slots and the replay stages
+// (induced edges, labels, collation / dense blocks) run as for any other batch -- asynchronous, capturable.
+__global__ __launch_bounds__(IGMC_BLOCK) void k_load_nodes(BatchDev b, const int64_t* uoff, const int32_t* unodes,
+                                                            const uint8_t* udist, const int64_t* voff, const int32_t* vnodes,
+                                                            const uint8_t* vdist, const float* link_y, const int32_t* link_idx,
+                                                            int first_arg, const int64_t* ctrl) {
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int first = ctrl ? (int)ctrl[(first_arg & 1) ? IGMC_CTRL_FIRST_ODD : IGMC_CTRL_FIRST] : first_arg;
+  const int pos = link_idx ? link_idx[first + g] : first + g;
+  const int64_t u0 = uoff[pos], v0 = voff[pos];
+  int cu = (int)(uoff[pos + 1] - u0), cv = (int)(voff[pos + 1] - v0);
+  cu = cu < b.cap_u ? cu : b.cap_u;        // (a cache built for this arena geometry never exceeds it)
+  cv = cv < b.cap_v ? cv : b.cap_v;
+  int32_t* tl = b.t_list + (size_t)g * b.slot;
+  uint8_t* td = b.t_dist + (size_t)g * b.slot;
+  for (int i = tid; i < cu; i += IGMC_BLOCK) {
+    tl[i] = unodes[u0 + i];
+    td[i] = udist[u0 + i];
+  }
+  for (int i = tid; i < cv; i += IGMC_BLOCK) {
+    tl[b.cap_u + i] = vnodes[v0 + i];
+    td[b.cap_u + i] = vdist[v0 + i];
+  }
+  if (tid == 0) {
+    b.n_users[g] = cu;
+    b.n_items[g] = cv;
+    b.y[g] = link_y[pos];
+  }
+}
+
+void igmc_launch_load_nodes(const BatchDev& b, const int64_t* uoff, const int32_t* unodes, const uint8_t* udist,
+                            const int64_t* voff, const int32_t* vnodes, const uint8_t* vdist, const float* link_y,
+                            const int32_t* link_idx, int first, int B, const int64_t* ctrl, void* stream) {
+  IGMC_PLAUNCH("k_load_nodes", k_load_nodes, B, IGMC_BLOCK, 0, stream, b, uoff, unodes, udist, voff, vnodes, vdist, link_y,
+               link_idx, first, ctrl);
+}
+
 // ---------------------------------------------------------------- side features of the target nodes
 // reference util_functions.py:250-253, :272-275: a subgraph carries the feature rows of its two TARGET nodes only.
 // The dataset keeps one [n_links, S] matrix (row k = [u_features[link_u[k]] | v_features[link_v[k]]]) in HBM; the rows

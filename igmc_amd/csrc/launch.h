@@ -9,6 +9,9 @@ void igmc_launch_extract(const GraphDev& g, const BatchDev& b, const int32_t* li
                          const float* link_y, const int32_t* link_idx, int first, int B, int replay,
                          double sample_ratio, uint64_t seed, uint64_t epoch, const int64_t* ctrl, int lean, void* stream);
 void igmc_launch_emit(const BatchDev& b, int B, void* stream);
+void igmc_launch_load_nodes(const BatchDev& b, const int64_t* uoff, const int32_t* unodes, const uint8_t* udist,
+                            const int64_t* voff, const int32_t* vnodes, const uint8_t* vdist, const float* link_y,
+                            const int32_t* link_idx, int first, int B, const int64_t* ctrl, void* stream);
 void igmc_launch_edge_flags(const BatchDev& b, float p, int force_undirected, uint64_t seed, uint64_t step,
                             const int64_t* ctrl, void* stream);
 void igmc_launch_relm_flags(const BatchDev& b, void* stream);

@@ -83,6 +83,14 @@ class Batch(object):
                       int(epoch) & (2 ** 64 - 1), _p(stream))
         self.B = int(B)
 
+    def extract_cached(self, cache, link_y, link_idx, first, B, stream=None):
+        """Batch ``link_idx[first:first+B]`` from a device-resident node-set cache (``igmc_extract_batch_cached``);
+        ``cache`` = dict of device addresses uoff, unodes, udist, voff, vnodes, vdist."""
+        self.lib.call('igmc_extract_batch_cached', self.graph.handle, self.handle, _p(cache['uoff']), _p(cache['unodes']),
+                      _p(cache['udist']), _p(cache['voff']), _p(cache['vnodes']), _p(cache['vdist']), _p(link_y),
+                      _p(link_idx), int(first), int(B), _p(stream))
+        self.B = int(B)
+
     def extract_replay(self, u_lists, v_lists, u_dists, v_dists, ys, stream=None):
         """Parity mode: node sets given per graph (target first)."""
         B = len(u_lists)

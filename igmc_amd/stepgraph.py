@@ -104,8 +104,12 @@ class StepGraph(object):
         """Extraction (+ edge dropout) of the batch whose offset is in control slot ``slot`` (even/odd) into
         ``arena`` on the current stream."""
         m, st = self.model, torch.cuda.current_stream().cuda_stream
-        arena.extract(self.ds.link_u.data_ptr(), self.ds.link_v.data_ptr(), self.ds.link_y.data_ptr(),
-                      self.perm.data_ptr(), slot, B, self.ds.sample_ratio, self.ds.seed, 0, st)
+        cache = getattr(self.ds, '_cache', None)
+        if cache is not None:       # static dataset (reference MyDataset): node sets from the HBM-resident cache
+            arena.extract_cached(cache, self.ds.link_y.data_ptr(), self.perm.data_ptr(), slot, B, st)
+        else:
+            arena.extract(self.ds.link_u.data_ptr(), self.ds.link_v.data_ptr(), self.ds.link_y.data_ptr(),
+                          self.perm.data_ptr(), slot, B, self.ds.sample_ratio, self.ds.seed, 0, st)
         if m.adj_dropout > 0:
             arena.edge_dropout(m.adj_dropout, m.force_undirected, m.seed, slot, st)
 

@@ -81,6 +81,16 @@ int igmc_extract_batch_replay(const igmc_graph* g, igmc_batch* b, int B,
                               const int32_t* h_vnodes, const uint8_t* h_vdist, const int32_t* h_voff,
                               const float* h_y, void* stream);
 
+/* Static dataset (reference MyDataset + links2subgraphs, util_functions.py:69-110, :148-205: subgraphs extracted once
+ * and cached in <root>/processed/data.pt).  The native cache = the node sets of every link with their hop distances,
+ * packed in HBM: d_uoff / d_voff [n_links + 1] offsets into d_unodes / d_vnodes (global ids, target first) and d_udist /
+ * d_vdist.  The batch d_link_idx[first .. first + B - 1] is rebuilt from it: induced edges, labels and collation run on
+ * the GPU as in igmc_extract_batch (asynchronous; honours the control block and the lean mode). */
+int igmc_extract_batch_cached(const igmc_graph* g, igmc_batch* b,
+                              const int64_t* d_uoff, const int32_t* d_unodes, const uint8_t* d_udist,
+                              const int64_t* d_voff, const int32_t* d_vnodes, const uint8_t* d_vdist,
+                              const float* d_link_y, const int32_t* d_link_idx, int first, int B, void* stream);
+
 /* Edge dropout (reference models.py:193-198 -> PyG dropout_adj): fills the per-entry keep
  * flags (bit0: edge col->row kept, bit1: edge row->col kept) from a counter-based hash of
  * (seed, step, graph, user id, item id, direction).  p = drop probability. */

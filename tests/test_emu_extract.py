@@ -56,3 +56,43 @@ def test_arena_overflow_is_reported(be):
     with pytest.raises(RuntimeError):
         lu = np.zeros(3, np.int32)
         b.extract(lu, lu, np.zeros(3, np.float32), None, 0, 3)
+
+
+def test_cached_node_sets_rebuild_the_same_batches():
+    """``igmc_extract_batch_cached`` (static dataset, reference MyDataset): node sets + hop distances kept per link in
+    packed arrays; any batch (permuted positions) rebuilt from them equals the free-running extraction of those links."""
+    import numpy as np
+    import parity_checks as PC
+    from helpers import load_extract_golden
+    from igmc_amd import engine
+    be = PC.EmuBackend()
+    for name in ('synth_cap', 'flixster_h2', 'synth_nocap'):
+        case = load_extract_golden()[name]
+        n = len(case['links'])
+        g = engine.Graph(case['A'], lib=be.lib)
+        lu = case['links'][:, 0].astype(np.int32).copy()
+        lv = case['links'][:, 1].astype(np.int32).copy()
+        ly = case['class_values'][case['link_labels']].astype(np.float32)
+        b = engine.Batch(g, n, case['h'], case['mnph'])
+        b.extract(lu.ctypes.data, lv.ctypes.data, ly.ctypes.data, None, 0, n, sample_ratio=case['sample_ratio'], seed=4, epoch=0)
+        d = b.download()
+        uoff, voff = np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64)
+        un, vn, ud, vd = [], [], [], []
+        for k in range(n):
+            lo, hi, nu = d['node_off'][k], d['node_off'][k + 1], d['n_users'][k]
+            un.append(d['node_gid'][lo:lo + nu]); vn.append(d['node_gid'][lo + nu:hi])
+            ud.append(d['node_label'][lo:lo + nu] // 2); vd.append(d['node_label'][lo + nu:hi] // 2)
+            uoff[k + 1], voff[k + 1] = uoff[k] + nu, voff[k] + (hi - lo - nu)
+        arrs = dict(uoff=uoff, voff=voff, unodes=np.concatenate(un).astype(np.int32), vnodes=np.concatenate(vn).astype(np.int32),
+                    udist=np.concatenate(ud).astype(np.uint8), vdist=np.concatenate(vd).astype(np.uint8))
+        cache = {k: v.ctypes.data for k, v in arrs.items()}
+        perm = np.random.default_rng(1).permutation(n).astype(np.int32)
+        B = min(4, n - 1)
+        b2 = engine.Batch(g, B, case['h'], case['mnph'])
+        b2.extract_cached(cache, ly.ctypes.data, perm.ctypes.data, 1, B)
+        d2 = b2.download()
+        b3 = engine.Batch(g, B, case['h'], case['mnph'])
+        b3.extract(lu.ctypes.data, lv.ctypes.data, ly.ctypes.data, perm.ctypes.data, 1, B, sample_ratio=case['sample_ratio'], seed=4, epoch=0)
+        d3 = b3.download()
+        for key in ('node_off', 'n_users', 'node_label', 'node_gid', 'row_ptr', 'col', 'erel', 'y'):
+            assert np.array_equal(d2[key], d3[key]), (name, key)

@@ -426,3 +426,103 @@ def test_training_with_side_features(flix):
         finals[name] = (model.flat_parameters().detach().cpu().clone(), rmse)
     assert torch.allclose(finals['graph'][0], finals['eager'][0], rtol=2e-4, atol=2e-6)
     assert finals['graph'][1] == pytest.approx(finals['eager'][1], rel=1e-4)
+
+
+@pytest.mark.parametrize('data_name,multiply_by', [('flixster', 1), ('douban', 1), ('yahoo_music', 20)])
+def test_transfer_eval_end_to_end(tmp_path, monkeypatch, data_name, multiply_by):
+    """BASELINE.json configs[4] / reference run_transfer_exps.sh + Main.py:442-470: a 5-relation checkpoint set (as an
+    ml_100k run leaves it: model_checkpoint{10,20,30,40}.pth) evaluated on another dataset through ``--transfer``: the
+    target's ratings are regrouped into 5 relations (post_rating_map, Main.py:162-177), predictions are multiplied
+    (--multiply-by, models.py:215) and the four checkpoints ensembled.  The RMSE ``Main.main`` reports must equal the
+    oracle's (same checkpoints, same subgraphs, mean of predictions) within 1e-4."""
+    import importlib
+    import torch
+    from helpers import ROOT
+    from igmc_amd import preprocessing
+    from igmc_amd.models import IGMC
+    from igmc_amd.train_eval import DataLoader
+    from igmc_amd.util_functions import MyDataset
+    from oracle import pyg_ref
+    monkeypatch.chdir(tmp_path)
+    src = tmp_path / 'ml_100k_ckpt'
+    src.mkdir()
+
+    class _DS(object):
+        num_features = 4
+    paths = []
+    for i, ep in enumerate((10, 20, 30, 40)):
+        torch.manual_seed(100 + i)
+        m = IGMC(_DS(), latent_dim=[32, 32, 32, 32], num_relations=5, num_bases=4, regression=True)
+        m.reset_parameters()
+        p = str(src / ('model_checkpoint%d.pth' % ep))
+        torch.save(m.state_dict(), p)
+        paths.append(p)
+    sys_path_main = importlib.import_module('Main') if ROOT in __import__('sys').path else None
+    assert sys_path_main is not None
+    argv = ['--data-name', data_name, '--epochs', '40', '--testing', '--no-train', '--ensemble', '--transfer', str(src),
+            '--num-relations', '5', '--multiply-by', str(multiply_by), '--max-test-num', '200']
+    rmse = sys_path_main.main(argv)
+    log = (tmp_path / 'results' / ('%s_testmode' % data_name) / 'log.txt').read_text()
+    assert 'transfer' in log and 'ensemble' in log
+    # ---- oracle on the identical inputs
+    class _A(object):
+        pass
+    a = _A()
+    a.standard_rating, a.transfer, a.data_name, a.num_relations = False, str(src), data_name, 5
+    rating_map, post_rating_map = sys_path_main.rating_maps(a)
+    split = preprocessing.load_data_monti(data_name, True, rating_map, post_rating_map)
+    (_, _, adj, _, _, _, _, _, _, tel, teu, tev, cv) = split
+    assert int(adj.data.max()) <= 5                                   # relations regrouped onto the source model's 5
+    te = MyDataset('data/x/test', adj, (teu, tev), tel, 1, 1.0, 10000, None, None, cv, max_num=200, seed=1)
+    batches = []
+    for data in DataLoader(te, 50, shuffle=False):
+        raw = data._materialise()['raw']
+        batches.append(batch_to_pyg(raw, 4))
+    ys = torch.cat([b.y for b in batches])
+    preds = []
+    for p in paths:
+        ref = pyg_ref.IGMCRef(4, (32, 32, 32, 32), 5, 4, adj_dropout=0.2, multiply_by=multiply_by, fast=True)
+        ref.load_state_dict({k: v.cpu() for k, v in torch.load(p).items()})
+        preds.append(torch.cat([pyg_ref.eval_sse(ref, b)[1] for b in batches]))
+    ref_rmse = math.sqrt(float(((torch.stack(preds, 1).mean(1) - ys) ** 2).mean()))
+    assert len(ys) == 200
+    assert rmse == pytest.approx(ref_rmse, abs=1e-4 * max(1.0, multiply_by))
+
+
+def test_static_dataset_cache(flix, tmp_path):
+    """reference MyDataset (util_functions.py:69-110): subgraphs extracted once, cached under <root>/processed/, reused by
+    later constructions; batches rebuilt from the cache equal the re-derived ones; a static dataset trains through the
+    fused step (node sets served from HBM), with the trajectory of the re-deriving dataset."""
+    import torch
+    from igmc_amd.models import IGMC
+    from igmc_amd.train_eval import DataLoader, train_multiple_epochs
+    from igmc_amd.util_functions import MyDataset
+    (_, _, adj, trl, tru, trv, _, _, _, tel, teu, tev, cv) = flix
+    root = str(tmp_path / 'static_train')
+    mk = lambda **kw: MyDataset(root, adj, (tru[:300], trv[:300]), trl[:300], 1, 1.0, 12, None, None, cv, seed=3, **kw)
+    ds = mk()
+    path = ds.processed_paths[0]
+    assert os.path.exists(path) and path.endswith(os.path.join('processed', 'data.igmc.npz')) and ds._cache is not None
+    z = np.load(path)
+    assert len(z['uoff']) == 301 and z['unodes'].dtype == np.int32 and z['udist'].dtype == np.uint8
+    mtime = os.path.getmtime(path)
+    ds2 = mk()                                         # second construction: loaded, not rebuilt
+    assert os.path.getmtime(path) == mtime and ds2._cache is not None
+    ds3 = mk(cache=False)                              # re-deriving variant
+    assert ds3._cache is None
+    for a, b in zip(DataLoader(ds2, 50, shuffle=False), DataLoader(ds3, 50, shuffle=False)):
+        ra, rb = a._materialise()['raw'], b._materialise()['raw']
+        for key in ('node_off', 'node_gid', 'node_label', 'row_ptr', 'col', 'erel', 'y'):
+            assert np.array_equal(ra[key], rb[key]), key
+    # a different geometry invalidates the cache (fingerprint), it is rebuilt instead of being misused
+    ds4 = MyDataset(root, adj, (tru[:300], trv[:300]), trl[:300], 1, 1.0, 20, None, None, cv, seed=3)
+    assert os.path.getmtime(path) >= mtime and ds4._cache is not None and len(ds4) == 300
+    # training on the static dataset == training on the re-deriving one
+    te = MyDataset(str(tmp_path / 'static_test'), adj, (teu[:100], tev[:100]), tel[:100], 1, 1.0, 12, None, None, cv, seed=3)
+    finals = []
+    for d in (mk(), mk(cache=False)):
+        torch.manual_seed(5)
+        model = IGMC(d, latent_dim=[32, 32, 32, 32], num_relations=len(cv), num_bases=4, regression=True, adj_dropout=0.0, seed=2)
+        r = train_multiple_epochs(d, te, model, 2, 50, 1e-3, 0.1, 50, 0, ARR=0.001)
+        finals.append((model.flat_parameters().detach().cpu().clone(), r))
+    assert torch.equal(finals[0][0], finals[1][0]) and finals[0][1] == finals[1][1]

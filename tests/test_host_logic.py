@@ -171,3 +171,70 @@ def test_data_parallel_step_equals_global_batch_step_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert 'rank %d dp ok' % r in o
+
+
+_DP_RAGGED_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+import numpy as np, torch
+from igmc_amd import parallel, engine
+import parity_checks as PC
+from helpers import load_extract_golden
+rank, world = parallel.init_from_env('gloo')
+be = PC.EmuBackend()
+case = dict(load_extract_golden()['synth_cap'])
+n, B = 13, 4                              # 13 links over 2 ranks, per-rank batch 4: shards of 7 = one full batch + 3
+perm = torch.randperm(n, generator=torch.Generator().manual_seed(3))
+mine = parallel.shard_positions(perm, rank, world, pad=True)
+assert len(mine) == 7                     # padded: equal step counts on both ranks
+last = [int(x) for x in mine[B:]]         # the ragged last batch of THIS rank (3 links)
+every = [int(x) for r in range(world) for x in parallel.shard_positions(perm, r, world, pad=True)[B:]]
+assert len(last) == 3 and len(every) == 6
+def pick(idx):
+    c = dict(case)
+    c['recs'] = [case['recs'][i] for i in idx]
+    c['links'], c['link_labels'] = case['links'][idx], case['link_labels'][idx]
+    return c
+rng = np.random.default_rng(1)
+gmask = {i: (rng.random(128) < 0.5).astype(np.uint8) for i in range(n)}
+def grads(idx, grad_scale, arr_scale):
+    c = pick(idx)
+    g, b, d = PC.extract_case(be, c, replay=True)
+    ws = engine.ModelWorkspace(be.lib, be.device, 5, 4, 4, 0, b.node_capacity, b.edge_capacity, b.max_graphs)
+    ref = PC.make_ref_model(4, 5, seed=4)
+    P = PC.flatten_params(ws, ref)
+    G, out = np.zeros_like(P), np.zeros(d['B'], np.float32)
+    lm = np.ascontiguousarray(np.stack([gmask[i] for i in idx]).reshape(-1))
+    ws.loss_grad(P.ctypes.data, b, out.ctypes.data, G.ctypes.data, None, lin_mask=lm.ctypes.data, ARR=0.001,
+                 grad_scale=grad_scale, arr_scale=arr_scale)
+    return G
+# what StepGraph passes for a ragged batch of B' links per rank: grad_scale = 1 / (B' * world), ARR scaled 1 / world
+G = grads(last, 1.0 / (len(last) * world), 1.0 / world)
+t = torch.from_numpy(G)
+parallel.all_reduce_sum_(t)
+G1 = grads(every, 1.0 / len(every), 1.0)  # one process on the multiset of the global ragged batch (the pad link twice)
+scale = np.abs(G1).max()
+assert np.abs(G - G1).max() < 2e-5 * scale, np.abs(G - G1).max() / scale
+parallel.barrier()
+print('rank', rank, 'ragged ok')
+'''
+
+
+def test_data_parallel_ragged_last_batch_gloo(tmp_path):
+    """The last batch of an epoch under data parallelism: shards are padded to equal lengths (wrap-around), every rank
+    steps on the same, smaller batch size B' and scales by 1 / (B' * world): the all-reduced gradient is the exact mean
+    over the global ragged batch (the wrapped link counted where it was dealt)."""
+    from helpers import emu_lib
+    emu_lib()
+    script = tmp_path / 'dpr.py'
+    script.write_text(_DP_RAGGED_WORKER % (ROOT, ROOT))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT='29617')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert 'rank %d ragged ok' % r in o
