@@ -194,6 +194,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-steps', type=int, default=40)
     ap.add_argument('--rmse-links', type=int, default=5000)
+    ap.add_argument('--dp-steps', type=int, default=96,
+                    help='steps per launch structure of the dp_structure leg (N=1 only; 0 = skip)')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly (no hipGraph replay)')
     ap.add_argument('--no-overlap', action='store_true', help='extract batch t+1 on the same stream (no overlap)')
     ap.add_argument('--cpu-baseline-worker', default=None, help=argparse.SUPPRESS)
@@ -282,6 +284,35 @@ def main():
     value = args.steps * BATCH * world / dt
     sg.check()                                          # no device-side wait timed out during the timed steps
     final_loss = float(sg.loss[0].item())
+
+    # ---- launch structure of a data-parallel step, measured on ONE GPU (no collective latency in it): the same steps
+    # with the multi-GPU structure forced -- graph{model || extraction} -> [all-reduce, absent at world 1] -> Adam launch,
+    # one graph launch per step -- and with IGMC_DP_CAPTURE_ALLREDUCE's structure (weight update inside the graph, 8 steps
+    # per launch).  dp_structure_us = what the eager tail costs per step before any RCCL latency.
+    dp_structure = None
+    if world == 1 and sg.use_graph and args.dp_steps > 0:
+        def timed_us(nsteps):
+            new_epoch_if_needed()
+            sg.prepare()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run(nsteps)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / nsteps * 1e6
+        D = args.dp_steps
+        single_us = timed_us(D)
+        res = {}
+        for name, cap in (('dp', False), ('dp_captured', True)):
+            sg.graphs, sg.multi = [None, None], None
+            sg.dp_path, sg.dp_capture = True, cap
+            timed_us(8)
+            res[name] = timed_us(D)
+        sg.graphs, sg.multi = [None, None], None
+        sg.dp_path, sg.dp_capture = False, False
+        dp_structure = dict(steps=D, single_gpu_us=single_us, dp_us=res['dp'], dp_captured_us=res['dp_captured'],
+                            dp_structure_us=res['dp'] - single_us,
+                            note='world size 1: launch structure only, no RCCL kernel in it')
+        sg.check()
 
     # ---- roofline leg
     roofline, kernels, extraction, replay_us = None, {}, None, None
@@ -420,6 +451,7 @@ def main():
                        'parallelism': 'dp%d' % world, 'global_batch': BATCH * world,
                        'graphs_captured_before_timing': bool(captured)},
             'roofline': roofline, 'cpu_baseline': cpu, 'rmse': rmse, 'extraction': extraction,
+            'dp_structure_us': dp_structure['dp_structure_us'] if dp_structure else None, 'dp_structure': dp_structure,
             'final_loss': final_loss, 'kernels_us': {k: round(v['us'], 2) for k, v in kernels.items()},
             'kernel_src_sha': kernel_source_sha(),
         }

@@ -71,6 +71,7 @@ struct igmc_graph {
   GraphDev d;
   int64_t nnz;
   int max_rel;
+  int max_deg_u, max_deg_v;     // longest user row / item column (bounds the hop-1 subgraph sides)
   Allocs mem;
 };
 
@@ -223,6 +224,9 @@ extern "C" int igmc_graph_create(int n_users, int n_items, int64_t nnz, const in
   g->device = device;
   g->nnz = nz;
   g->max_rel = max_rel;
+  g->max_deg_u = g->max_deg_v = 0;
+  for (int u = 0; u < n_users; ++u) g->max_deg_u = std::max(g->max_deg_u, uptr[u + 1] - uptr[u]);
+  for (int v = 0; v < n_items; ++v) g->max_deg_v = std::max(g->max_deg_v, vptr[v + 1] - vptr[v]);
   int32_t *d_uptr, *d_uidx, *d_vptr, *d_vidx;
   uint8_t *d_urel, *d_vrel;
   if (g->mem.get(&d_uptr, n_users + 1) || g->mem.get(&d_uidx, nz) || g->mem.get(&d_urel, nz) ||
@@ -263,11 +267,16 @@ extern "C" int igmc_batch_create(const igmc_graph* g, int max_graphs, int hop, i
   const size_t smem = igmc_extract_smem_bytes(g->d);
   if (smem > 150 * 1024) IGMC_FAIL("graph too large for the LDS bitmaps (users+items must be < ~300k)");
   if (igmc_extract_prepare(smem)) IGMC_FAIL("hipFuncSetAttribute failed");
-  auto side_cap = [&](int n) -> int64_t {
+  // slot capacity of one side: the target plus, per hop, at most max_nodes_per_hop new nodes; the hop-1 fringe of a
+  // side is the neighbourhood of ONE node of the other side, so the longest row / column of the rating matrix bounds
+  // it as well (an uncapped run on a sparse graph -- the Monti datasets -- then still gets slots small enough for the
+  // dense induced blocks and the subgraph kernel)
+  auto side_cap = [&](int n, int opposite_max_deg) -> int64_t {
     int64_t per = (max_nodes_per_hop < 0) ? (int64_t)n : std::min<int64_t>(max_nodes_per_hop, n);
+    if (hop == 1) per = std::min<int64_t>(per, opposite_max_deg);
     return std::min<int64_t>(n, 1 + (int64_t)hop * per);
   };
-  const int64_t cap_u = side_cap(g->d.n_users), cap_v = side_cap(g->d.n_items);
+  const int64_t cap_u = side_cap(g->d.n_users, g->max_deg_v), cap_v = side_cap(g->d.n_items, g->max_deg_u);
   const int64_t slot = cap_u + cap_v;
   const int64_t node_cap = (int64_t)max_graphs * slot;
   const int64_t per_graph_e = std::min<int64_t>(2 * cap_u * cap_v, 2 * g->nnz);
@@ -302,7 +311,8 @@ extern "C" int igmc_batch_create(const igmc_graph* g, int max_graphs, int hop, i
   d.max_rel = g->max_rel;
   d.relm_ld = (int)((cap_v + 3) & ~(size_t)3);
   // dense path: rows of the block fit one 256-entry super-chunk and block + row starts fit the default LDS window
-  if (cap_u <= 256 && cap_v <= 256 && cap_u * (size_t)d.relm_ld + slot * 4 <= 60 * 1024) fail |= M.get(&d.relm, (size_t)Bc * cap_u * d.relm_ld);   // dense induced block per link
+  // (a byte of the block holds relation + 1 in bits 0-2 and the two keep bits of edge dropout in bits 3-4: <= 7 relations)
+  if (g->max_rel + 1 <= 7 && cap_u <= 256 && cap_v <= 256 && cap_u * (size_t)d.relm_ld + slot * 4 <= 60 * 1024) fail |= M.get(&d.relm, (size_t)Bc * cap_u * d.relm_ld);   // dense induced block per link
   fail |= M.get(&d.s_gid, Bc * slot) | M.get(&d.s_lab, Bc * slot) | M.get(&d.s_deg, Bc * slot) |
           M.get(&d.t_list, Bc * slot) | M.get(&d.t_dist, Bc * slot);
   if (fail) {
@@ -418,8 +428,13 @@ extern "C" int igmc_batch_set_lean(igmc_batch* b, int lean) {
 extern "C" int igmc_batch_edge_dropout(igmc_batch* b, float p, int force_undirected, uint64_t seed, uint64_t step,
                                        void* stream) {
   if (!b) IGMC_FAIL("null batch");
-  ensure_csr(b, stream);        // the flag kernel walks the collated CSR (and mirrors the bits into the dense block)
-  igmc_launch_edge_flags(b->d, p, force_undirected, seed, step, b->ctrl, stream);
+  if (b->lean && b->d.relm && b->last_B > 0) {
+    // lean arena: the same draws taken on the dense blocks; a CSR emitted later derives its flags from them
+    igmc_launch_relm_dropout(b->d, b->last_B, p, force_undirected, seed, step, b->ctrl, stream);
+  } else {
+    // the flag kernel walks the collated CSR (and mirrors the bits into the dense block)
+    igmc_launch_edge_flags(b->d, p, force_undirected, seed, step, b->ctrl, stream);
+  }
   HIPCHECK(hipGetLastError());
   return 0;
 }

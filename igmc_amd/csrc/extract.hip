@@ -553,7 +553,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_relm(GraphDev G, BatchDev b) {
       const bool mt = (j[q] == v0) ? (row[q] != 0) : bm_test(sel_v, j[q]);
       if (mt) {
         const int lv = (j[q] == v0) ? 0 : 1 + bm_rank(sel_v, pre_v, j[q]);
-        rm[(size_t)row[q] * ld + lv] = (uint8_t)(rl[q] + 1);
+        rm[(size_t)row[q] * ld + lv] = (uint8_t)((rl[q] + 1) | 0x18);      // relation + 1, both directions kept
         ++c;
       }
     }
@@ -668,14 +668,18 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_emit(BatchDev b) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (q * 64 >= len) break;
-        const bool mt = val[q] == rel + 1;
+        const bool mt = (val[q] & 7) == rel + 1;
         const unsigned long long bal = __ballot(mt);
         if (mt) {
           const int pos = o + __popcll(bal & ((1ull << lane) - 1ull));
           b.ecr[pos] = (uint32_t)(nbase + q * 64 + lane) | ((uint32_t)rel << 24);
           b.ecode[pos] = (uint16_t)(rel * L + lab[q]);
           b.edst[pos] = (uint16_t)r;
-          b.eflag[pos] = 3;
+          // keep flags of the entry (bit 0: column -> row, bit 1: row -> column) from the block's bits 3 / 4, which are
+          // those of the USER row; an item row sees the two directions swapped.  All kept unless a dense edge dropout
+          // (k_relm_dropout, lean arenas) ran before this emission.
+          const int fl = (val[q] >> 3) & 3;
+          b.eflag[pos] = (uint8_t)(is_u ? fl : ((fl >> 1) | ((fl & 1) << 1)));
         }
         o += __popcll(bal);
       }
@@ -800,6 +804,44 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_relm_flags(BatchDev b) {
       *q = (uint8_t)((*q & 7) | ((b.eflag[e] & 3) << 3));
     }
   }
+}
+
+// edge dropout of a lean arena: the Bernoulli draws of k_edge_flags (same key: graph, user id, item id, direction), taken
+// straight from the dense blocks -- no CSR needed.  grid (B, 4): a workgroup takes every 4th dword column group.
+__global__ __launch_bounds__(IGMC_BLOCK) void k_relm_dropout(BatchDev b, float p, int force_undirected, uint64_t seed,
+                                                              uint64_t step_arg, const int64_t* ctrl) {
+  const uint64_t step = ctrl ? (((uint64_t)ctrl[IGMC_CTRL_EPOCH] << 32) ^
+                                (uint64_t)(ctrl[(step_arg & 1) ? IGMC_CTRL_FIRST_ODD : IGMC_CTRL_FIRST] /
+                                           (ctrl[IGMC_CTRL_BATCH] > 0 ? ctrl[IGMC_CTRL_BATCH] : 1)))
+                             : step_arg;
+  const int g = blockIdx.x;
+  const int cu = b.n_users[g], cv = b.n_items[g];
+  const int ld = b.relm_ld, ldw = ld >> 2, cw = (cv + 3) >> 2;
+  const int32_t* sg = b.s_gid + (size_t)g * b.slot;
+  uint32_t* rm = (uint32_t*)(b.relm + (size_t)g * b.cap_u * ld);
+  const int n = cu * cw;
+  for (int i = blockIdx.y * IGMC_BLOCK + threadIdx.x; i < n; i += gridDim.y * IGMC_BLOCK) {
+    const int row = i / cw, k = i - row * cw;
+    uint32_t w = rm[row * ldw + k];
+    if (!w) continue;
+    const uint32_t u = (uint32_t)sg[row];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t by = (w >> (8 * q)) & 0xFFu;
+      if (!(by & 7u)) continue;
+      const uint32_t v = (uint32_t)sg[b.cap_u + 4 * k + q];
+      // user row: column -> row is item -> user (direction 1), row -> column is user -> item (direction 0)
+      const uint32_t kf = igmc_u01(igmc_edge_hash(seed, step, (uint32_t)g, u, v, force_undirected ? 2u : 1u)) >= p;
+      const uint32_t kt = igmc_u01(igmc_edge_hash(seed, step, (uint32_t)g, u, v, force_undirected ? 2u : 0u)) >= p;
+      w = (w & ~(0x18u << (8 * q))) | (((kf << 3) | (kt << 4)) << (8 * q));
+    }
+    rm[row * ldw + k] = w;
+  }
+}
+
+void igmc_launch_relm_dropout(const BatchDev& b, int B, float p, int force_undirected, uint64_t seed, uint64_t step,
+                              const int64_t* ctrl, void* stream) {
+  IGMC_PLAUNCH("k_relm_dropout", k_relm_dropout, dim3(B, 4), IGMC_BLOCK, 0, stream, b, p, force_undirected, seed, step, ctrl);
 }
 
 void igmc_launch_relm_flags(const BatchDev& b, void* stream) {

@@ -72,6 +72,10 @@ class StepGraph(object):
         # the multi-GPU launch structure (graph up to the gradients, eager all-reduce + step_finish) can be forced on
         # one GPU to test it: IGMC_FORCE_DP_PATH=1
         self.dp_path = self.world > 1 or os.environ.get('IGMC_FORCE_DP_PATH', '0') == '1'
+        # IGMC_DP_CAPTURE_ALLREDUCE=1: under data parallelism the flat RCCL all-reduce and the Adam launch are captured
+        # INTO the step graph (and 8 steps into one launch, like on one GPU) instead of being enqueued eagerly after every
+        # replay.  Opt-in: a captured collective could not be validated on more than one GPU where this was written.
+        self.dp_capture = os.environ.get('IGMC_DP_CAPTURE_ALLREDUCE', '0') == '1'
         self.side = torch.cuda.Stream(device=self.dev) if overlap else None
         self.graphs = [None, None]
         # several steps in ONE graph launch: consecutive launches of a replayed graph are separated by a gap of tens of
@@ -169,7 +173,7 @@ class StepGraph(object):
         """model(batch in arenas[parity]) || extract(next batch -> arenas[1-parity]); then finish."""
         cur, nxt = self.arenas[parity], self.arenas[1 - parity]
         main = torch.cuda.current_stream()
-        fused = (not self.dp_path) and with_finish and B == self.B
+        fused = (not self.dp_path) and with_finish and B == self.B      # igmc_train_step: gradients + Adam, minimum launches
         if self.side is not None:
             self.side.wait_stream(main)
             # launch order inside the fork: the model kernels are enqueued BEFORE the extraction branch, so that the
@@ -205,13 +209,26 @@ class StepGraph(object):
         g = torch.cuda.CUDAGraph()
         if self.world <= 1:
             with torch.cuda.graph(g):
-                self._enqueue(parity, self.B, with_finish=not self.dp_path)
+                self._enqueue(parity, self.B, with_finish=self._finish_in_graph())
             self.graphs[parity] = g
             return
         # several processes: the RCCL watchdog thread of torch.distributed polls events while this thread captures, so
         # the capture must only police THIS thread ('thread_local'); a refused capture is not fatal -- the same HIP
         # launches then run eagerly (capturing does not execute anything, so no step is lost)
         try:
+            if self.dp_capture:
+                try:
+                    with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                        self._enqueue(parity, self.B, with_finish=True)      # all-reduce + Adam inside the graph
+                    self.graphs[parity] = g
+                    return
+                except RuntimeError as e:
+                    import sys
+                    sys.stderr.write('igmc_amd: RCCL all-reduce not capturable (%s); all-reduce stays eager\n'
+                                     % str(e).splitlines()[0])
+                    self.dp_capture = False
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode='thread_local'):
                 self._enqueue(parity, self.B, with_finish=False)
             self.graphs[parity] = g
@@ -221,6 +238,11 @@ class StepGraph(object):
                              % str(e).splitlines()[0])
             self.use_graph, self.graphs = False, [None, None]
             torch.cuda.synchronize()
+
+    def _finish_in_graph(self):
+        """True when a captured step holds its own weight update (single GPU, or data parallelism with the collective
+        captured); False = the graph ends at the local gradients and all-reduce + Adam are enqueued after each replay."""
+        return (not self.dp_path) or self.dp_capture
 
     def prepare(self):
         """Capture every hipGraph this object will replay (both single-step parities and the multi-step group) NOW.
@@ -232,17 +254,30 @@ class StepGraph(object):
         for parity in (0, 1):
             if self.graphs[parity] is None and self.use_graph:
                 self._capture(parity)
-        if self.use_graph and not self.dp_path and self.multi_n >= 2 and self.multi is None:
+        if self.use_graph and self._finish_in_graph() and self.multi_n >= 2 and self.multi is None:
             self._capture_multi()
         return True
 
     def _capture_multi(self):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for i in range(self.multi_n):
-                self._enqueue(i % 2, self.B)
-        self.multi = g
+        if self.world <= 1:
+            with torch.cuda.graph(g):
+                for i in range(self.multi_n):
+                    self._enqueue(i % 2, self.B)
+            self.multi = g
+            return
+        try:
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                for i in range(self.multi_n):
+                    self._enqueue(i % 2, self.B)
+            self.multi = g
+        except RuntimeError as e:
+            import sys
+            sys.stderr.write('igmc_amd: multi-step capture refused under data parallelism (%s); one step per launch\n'
+                             % str(e).splitlines()[0])
+            self.multi_n = 0
+            torch.cuda.synchronize()
 
     def step(self, B=None):
         """One optimisation step on the next ``B`` links of the epoch permutation."""
@@ -258,7 +293,7 @@ class StepGraph(object):
                 self._capture(parity)     # capturing does not execute: nothing is skipped or repeated
             if self.graphs[parity] is not None:
                 self.graphs[parity].replay()
-                if self.dp_path:
+                if not self._finish_in_graph():
                     self._finish(self.arenas[parity])
             else:
                 self._enqueue(parity, B)
@@ -273,12 +308,14 @@ class StepGraph(object):
         n = int(n)
         while n > 0:
             M = self.multi_n
-            multi_ok = self.use_graph and not self.dp_path and M >= 2 and self.k % 2 == 0 and self.steps_done >= 4
+            multi_ok = (self.use_graph and self._finish_in_graph() and M >= 2 and self.k % 2 == 0 and
+                        self.steps_done >= 4)
             if multi_ok and self.multi is None:
                 # captured as soon as it can be (capturing executes nothing), also when fewer than M steps are asked for
                 # right now: the milliseconds a capture costs then fall into the caller's warm-up, not into its first
                 # long run
                 self._capture_multi()
+                multi_ok = self.multi is not None
             if multi_ok and n >= M:
                 self.multi.replay()
                 self.k += M

@@ -56,12 +56,14 @@ class GpuBackend(object):
         self.torch.cuda.synchronize()
 
 
-def extract_case(be, case, replay, max_graphs=None, seed=0, epoch=0):
+def extract_case(be, case, replay, max_graphs=None, seed=0, epoch=0, lean=False):
     """Run the engine extraction on a golden case; returns (graph, batch, downloaded dict)."""
     A = case['A']
     g = engine.Graph(A, device=be.device, lib=be.lib)
     B = len(case['recs'])
     b = engine.Batch(g, max_graphs=max_graphs or B, hop=case['h'], max_nodes_per_hop=case['mnph'])
+    if lean:
+        b.set_lean(True)      # dense blocks only; the CSR is emitted when something asks for it (download)
     ys = case['class_values'][case['link_labels']].astype(np.float32)
     if replay:
         ul, vl, ud, vd = [], [], [], []
@@ -336,15 +338,17 @@ def check_edge_flags(d, flags, p, force_undirected, seed, step, exact_sample=400
         assert int(flags[e]) == int(kf) | (int(kt) << 1), (e, int(flags[e]), kf, kt)
 
 
-def run_free_running_dropout(be, case, R, p=0.2, force_undirected=False, seed=11, step=7, mlp_seed=5, mlp_step=3):
+def run_free_running_dropout(be, case, R, p=0.2, force_undirected=False, seed=11, step=7, mlp_seed=5, mlp_step=3,
+                             lean=False):
     """Edge dropout AND MLP dropout drawn by the kernels themselves (no injected masks): the drawn masks are read
     back, checked statistically and against the host restatement of the hashes, and the model's loss / gradients
     with them must equal the oracle's with the same masks -- for force_undirected through the oracle's own
     ``dropout_adj(force_undirected=True)`` (mask over the row < col half, re-symmetrised, coalesced)."""
     import torch
     from oracle import pyg_ref
-    g, b, d = extract_case(be, case, replay=False)
+    g, b, d = extract_case(be, case, replay=False, lean=lean)
     L = 2 * case['h'] + 2
+    # (a lean arena draws on the dense blocks -- k_relm_dropout -- and the CSR read back below takes its flags from them)
     b.edge_dropout(p, force_undirected, seed=seed, step=step)
     be.sync()
     flags = b.download()['eflag']

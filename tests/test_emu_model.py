@@ -209,3 +209,39 @@ def test_lean_extraction_feeds_the_dense_kernel(be):
     for k in ('node_off', 'row_ptr', 'col', 'erel', 'node_label', 'node_gid', 'y'):
         assert np.array_equal(res['eager'][3][k], res['lean'][3][k]), k
     PC.check_batch_structure(res['lean'][3], 4)
+
+
+def test_uncapped_sparse_graph_takes_the_dense_kernel(be, monkeypatch):
+    """No per-hop cap (the reference default for the Monti datasets): the slot capacity of a hop-1 arena is bounded by
+    the longest row / column of the rating matrix, so a sparse graph (douban: at most 111 raters per item, 108 items per
+    user) still gets dense induced blocks and the matrix-core subgraph kernel -- checked against the oracle with
+    injected edge-dropout and MLP-dropout masks like every other path."""
+    import scipy.sparse as sp
+    from igmc_amd import engine
+    monkeypatch.setenv('IGMC_GS_CLUSTER', '4')      # what an MI355X picks for batches of <= 56 links (4 x 32 rows a side)
+    case = sub('douban', 6)
+    assert case['mnph'] is None or case['mnph'] < 0 or case['mnph'] >= 10000
+    A = sp.csr_matrix(case['A'])
+    A.eliminate_zeros()
+    max_row = int(np.diff(A.indptr).max())
+    max_col = int(np.diff(A.tocsc().indptr).max())
+    assert max(max_row, max_col) < 128
+    g = engine.Graph(case['A'], lib=be.lib)
+    b = engine.Batch(g, 6, 1, case['mnph'])
+    ws = engine.ModelWorkspace(be.lib, 0, 5, 4, 4, 0, b.node_capacity, b.edge_capacity, 6)
+    assert b.node_capacity == 6 * ((1 + max_col) + (1 + max_row))
+    assert ws.dense_path(b, 6)
+    res = PC.run_model_parity(be, case, R=5, use_dropout=True)
+    assert res['worst_grad_err'] < 1e-4
+    assert res['ws'].dense_path(res['batch'], 6)
+
+
+@pytest.mark.parametrize('force_undirected', [False, True])
+def test_free_running_dropout_on_a_lean_arena(be, force_undirected):
+    """Edge dropout of a lean arena is drawn on the dense blocks (k_relm_dropout, no CSR): the flags of the CSR emitted
+    afterwards must be the same counter-based draws as k_edge_flags makes (host restatement, bit for bit), and the
+    subgraph kernel's loss / gradients with them must match the oracle."""
+    res = PC.run_free_running_dropout(be, sub('synth_cap', 12), R=5, force_undirected=force_undirected, lean=True)
+    assert res['worst_grad_err'] < 1e-4
+    eager = PC.run_free_running_dropout(be, sub('synth_cap', 12), R=5, force_undirected=force_undirected, lean=False)
+    assert eager['keep_rate'] == res['keep_rate']

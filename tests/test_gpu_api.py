@@ -252,7 +252,9 @@ def test_step_graph_paths_agree(flix, monkeypatch):
     tr, te, cv = make_sets(flix, ntr=600)
     results = {}
     for name, env, kw in (('graph', {}, {}), ('eager', {}, dict(use_graph=False, overlap=False)),
-                          ('graph1', {'IGMC_GRAPH_STEPS': '0'}, {}), ('dp_path', {'IGMC_FORCE_DP_PATH': '1'}, {})):
+                          ('graph1', {'IGMC_GRAPH_STEPS': '0'}, {}), ('dp_path', {'IGMC_FORCE_DP_PATH': '1'}, {}),
+                          # multi-GPU structure with the weight update (and, at world > 1, the all-reduce) captured
+                          ('dp_captured', {'IGMC_FORCE_DP_PATH': '1', 'IGMC_DP_CAPTURE_ALLREDUCE': '1'}, {})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         torch.manual_seed(7)
@@ -266,11 +268,11 @@ def test_step_graph_paths_agree(flix, monkeypatch):
         total2, _ = sg.run_epoch(perm, 2)
         torch.cuda.synchronize()
         results[name] = (model.flat_parameters().detach().cpu().clone(), float(total2.item()), opt.t, model._step)
-        assert (sg.multi is not None) == (name == 'graph')
+        assert (sg.multi is not None) == (name in ('graph', 'dp_captured'))
         for k in env:
             monkeypatch.delenv(k)
     assert results['graph'][2] == 24 and results['graph'][3] == 24
-    for other in ('eager', 'graph1', 'dp_path'):
+    for other in ('eager', 'graph1', 'dp_path', 'dp_captured'):
         assert torch.allclose(results['graph'][0], results[other][0], rtol=2e-4, atol=2e-6), other
         assert results['graph'][1] == pytest.approx(results[other][1], rel=1e-4)
     # the SAME kernels on the same inputs, only launched differently (8 steps per hipGraph launch / one per launch /
@@ -279,6 +281,7 @@ def test_step_graph_paths_agree(flix, monkeypatch):
     for other in ('eager', 'graph1'):
         assert torch.equal(results['graph'][0], results[other][0]), other
         assert results['graph'][1] == results[other][1], other
+    assert torch.equal(results['dp_path'][0], results['dp_captured'][0])
 
 
 def test_full_size_headline_config_properties(monkeypatch):

@@ -100,11 +100,26 @@ def test_fused_train_steps_other_paths(be, ml1m, name, n, R, mnph, drop):
     assert res['frac_off'] < 2e-3
 
 
+@pytest.mark.parametrize('lean', [False, True])
 @pytest.mark.parametrize('force_undirected', [False, True])
 @pytest.mark.parametrize('name', ['ml1m', 'douban'])
-def test_free_running_dropout(be, ml1m, name, force_undirected):
+def test_free_running_dropout(be, ml1m, name, force_undirected, lean):
+    # lean: the arena keeps the dense blocks only and the draws are taken on them (k_relm_dropout); the CSR read back by
+    # the check takes its flags from the blocks.  douban is uncapped: its slots are bounded by the longest row / column.
     case = first(ml1m, 50, 100) if name == 'ml1m' else monti_case('douban', 40)
-    res = PC.run_free_running_dropout(be, case, R=5, p=0.2, force_undirected=force_undirected)
+    res = PC.run_free_running_dropout(be, case, R=5, p=0.2, force_undirected=force_undirected, lean=lean)
+    assert res['worst_grad_err'] < 2e-3
+
+
+def test_uncapped_douban_takes_the_subgraph_kernel(be):
+    """The reference's default for the Monti datasets is no per-hop cap (--max-nodes-per-hop 10000): douban's longest row /
+    column (< 128) bounds the slots, so the matrix-core subgraph kernel takes its batches of 50."""
+    from igmc_amd import engine
+    case = monti_case('douban', 50)
+    g, b, d = PC.extract_case(be, case, replay=False)
+    ws = engine.ModelWorkspace(be.lib, be.device, 5, 4, 4, 0, b.node_capacity, b.edge_capacity, b.max_graphs)
+    assert ws.dense_path(b, 50)
+    res = PC.run_model_parity(be, case, R=5, use_dropout=True)
     assert res['worst_grad_err'] < 2e-3
 
 
