@@ -763,18 +763,36 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
     __syncthreads();
     G2_STAMP(15);
     {
-      const int ju = tid >> 1, part = tid & 1;         // hidden unit, half of the fan-in
-      const float* wrow = P + a.off_l1w + (int64_t)ju * 256 + part * 128;
-      float4 w4[32];
+      // lin1 (256 -> 128): wave w takes hidden units 32 w .. 32 w + 31.  One weight row (1 KB, 8 cache lines) per load
+      // instruction, lane = 4 consecutive fan-in columns; the 32 per-lane partial dot products are then reduced over the
+      // 64 lanes by a transposing butterfly (each step halves the values a lane holds): lanes 2 j, 2 j + 1 end up with
+      // unit 32 w + j.  (A lane per row-half -- 64 cache lines per load instruction -- kept the head at ~10 k cycles.)
+      const int ju = tid >> 1, part = tid & 1;         // hidden unit of this lane pair after the reduction
+      const float4 f4 = *(const float4*)(sfeat + 4 * lane);
+      const float* wrow = P + a.off_l1w + (int64_t)(32 * wave) * 256 + 4 * lane;
+      float v[32];
 #pragma unroll
-      for (int q = 0; q < 32; ++q) w4[q] = *(const float4*)(wrow + 4 * q);
-      float s = 0.f;
+      for (int hh = 0; hh < 2; ++hh) {       // two batches of 16 rows: all 16 requests leave before the first use
+        float4 w4[16];
 #pragma unroll
-      for (int q = 0; q < 32; ++q) {
-        const float4 f4 = *(const float4*)(sfeat + part * 128 + 4 * q);
-        s += w4[q].x * f4.x + w4[q].y * f4.y + w4[q].z * f4.z + w4[q].w * f4.w;
+        for (int q = 0; q < 16; ++q) w4[q] = *(const float4*)(wrow + (16 * hh + q) * 256);
+        G2_SCHED_BARRIER();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[16 * hh + q] = (w4[q].x * f4.x + w4[q].y * f4.y) + (w4[q].z * f4.z + w4[q].w * f4.w);
+        G2_SCHED_BARRIER();
       }
-      s += __shfl_xor(s, 1, 4);
+      // (one literal stage per halving: a loop over the stages is not unrolled and turns v[] into select chains)
+#define G2_BFLY(H)                                                                   \
+      {                                                                              \
+        const bool up = (lane & (2 * (H))) != 0;                                     \
+        _Pragma("unroll") for (int i = 0; i < (H); ++i) {                            \
+          const float send = up ? v[i] : v[i + (H)], keep = up ? v[i + (H)] : v[i];  \
+          v[i] = keep + __shfl_xor(send, 2 * (H));                                   \
+        }                                                                            \
+      }
+      G2_BFLY(16) G2_BFLY(8) G2_BFLY(4) G2_BFLY(2) G2_BFLY(1)
+#undef G2_BFLY
+      const float s = v[0] + __shfl_xor(v[0], 1);
       G2_STAMP(54);
       if (part == 0) {
         float av = s + P[a.off_l1b + ju];
@@ -854,7 +872,9 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
       G2_STAMP(17);
       // ---- dPre_3: non-zero on the two centre rows only.  Own rows -> XO0 (h_3 sits in XO1), the opposite side's
       //      planes are rebuilt locally (node 0 of every feature; everything else zero): no exchange
-      for (int i = tid; i < nsides * (G2_NT * 32 * kp >> 1); i += G2_THREADS) PLN[i] = 0u;
+      //      (only the first k-step -- nodes 0..31 of every term / feature row -- is read by layer 3's gather; the rest of
+      //      the planes still holds h_2: finite values that the next exchange overwrites)
+      for (int i = tid; i < nsides * G2_NT * 32 * 16; i += G2_THREADS) PLN[(i >> 4) * (kp >> 1) + (i & 15)] = 0u;
       for (int i = lane; i < 16 * G2_XP; i += 64) XO0[i] = 0.f;
       __syncthreads();
       if (tid < 32 * nsides) {
@@ -1101,14 +1121,17 @@ extern "C" int igmc_debug_g2_clocks(unsigned long long* out, int n) {
 // Weights-only part of the step, formed ONCE per launch instead of by every workgroup and layer pass: the B operands
 // [W_0; ..; W_4; root] of the three conv layers (W_r = sum_b att[r,b] basis_b) in the LDS image of the forward
 // (element (k, n) at [k][n & 15].{x: n < 16, y: n >= 16}, rows padded to G2_WP float2) and of the backward (their
-// transposes), and the layer-0 table [W0[r*L + c] | root0[c] | bias0].  blockIdx.x: 2 (l - 1) + transposed, 6 = table.
+// transposes), and the layer-0 table [W0[r*L + c] | root0[c] | bias0].  37 small workgroups: the launch is as long as one
+// round trip to the weights plus three 8-byte stores per thread.
 __global__ __launch_bounds__(G2_THREADS) void k_g2_compose(ModelDev m, const float* P, float* w) {
   __shared__ float s_att[32];
   const int tid = threadIdx.x, R = m.R, L = m.L, RL = R * L, LF = L * 32;
-  const int l = (blockIdx.x == 6) ? 0 : 1 + (blockIdx.x >> 1), trans = blockIdx.x & 1;
+  // blockIdx.x: 2 * (3 layers x 6 matrices) image blocks (bit 0 = transposed), then the layer-0 table block
+  const int tableb = 2 * 3 * (G2_NR + 1);
+  const int l = ((int)blockIdx.x == tableb) ? 0 : 1 + (int)(blockIdx.x >> 1) / (G2_NR + 1), trans = blockIdx.x & 1;
   // every global load of the block is requested before the first use (one round trip)
-  const float attv = (tid < R * 4) ? P[m.off_att[l] + tid] : 0.f;
-  if (blockIdx.x == 6) {
+  if ((int)blockIdx.x == tableb) {
+    const float attv = (tid < R * 4) ? P[m.off_att[0] + tid] : 0.f;
     float bv[4][4], rv[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1133,40 +1156,50 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_compose(ModelDev m, const flo
     }
     return;
   }
-  uint16_t* img = (uint16_t*)(w + (size_t)blockIdx.x * G2_WIMG);
-  const float* basis = P + m.off_basis[l];
-  const int f = tid >> 3, n0 = (4 * tid) & 31;            // W_r[f][n0 .. n0 + 3]
-  float4 b4[4];
-#pragma unroll
-  for (int bb = 0; bb < 4; ++bb) b4[bb] = *(const float4*)(basis + bb * 1024 + 4 * tid);
-  const float4 r4 = *(const float4*)(P + m.off_root[l] + 4 * tid);
-  if (tid < 32) s_att[tid] = attv;
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r <= G2_NR; ++r) {
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (r == G2_NR) {
+  // image blocks: one relation (G2_NR = the root matrix) of one image per workgroup; a thread takes the four
+  // consecutive k of one column n, which are four consecutive bf16 of one lane's fragment: one 8-byte store per term
+  uint16_t* img = (uint16_t*)(w + (size_t)(blockIdx.x >> 1) / (G2_NR + 1) * 2 * G2_WIMG + (size_t)trans * G2_WIMG);
+  const int r = (blockIdx.x >> 1) % (G2_NR + 1);
+  const int n = tid & 31, kg = tid >> 5;                  // element (k = 4 kg + q, n) of the block's B operand
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (r == G2_NR) {
+    const float* root = P + m.off_root[l];
+    if (trans) {
+      const float4 r4 = *(const float4*)(root + n * 32 + 4 * kg);
       v[0] = r4.x; v[1] = r4.y; v[2] = r4.z; v[3] = r4.w;
-    } else if (r < R) {
+    } else {
 #pragma unroll
-      for (int bb = 0; bb < 4; ++bb) {
-        const float at = s_att[r * 4 + bb];
-        v[0] += at * b4[bb].x; v[1] += at * b4[bb].y; v[2] += at * b4[bb].z; v[3] += at * b4[bb].w;
+      for (int q = 0; q < 4; ++q) v[q] = root[(4 * kg + q) * 32 + n];
+    }
+  } else if (r < R) {
+    const float* basis = P + m.off_basis[l];
+    float bq[4][4];
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb) {
+      if (trans) {
+        const float4 b4 = *(const float4*)(basis + bb * 1024 + n * 32 + 4 * kg);
+        bq[bb][0] = b4.x; bq[bb][1] = b4.y; bq[bb][2] = b4.z; bq[bb][3] = b4.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[bb][q] = basis[bb * 1024 + (4 * kg + q) * 32 + n];
       }
     }
+    float at[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      // element (k, n) of the block's B operand: forward W_r[k = f][n = n0 + q], backward its transpose
-      const int k = trans ? n0 + q : f, n = trans ? f : n0 + q;
-      const int kq = (k & 15) >> 2, e = (k & 3) + ((k >> 4) << 2);
-      const int lane = kq * 16 + (n & 15), nt = n >> 4;
-      uint32_t h, mi, lo;
-      g2_split2(v[q], 0.f, h, mi, lo);
-      const uint32_t t3[3] = {h & 0xFFFFu, mi & 0xFFFFu, lo & 0xFFFFu};
+    for (int bb = 0; bb < 4; ++bb) at[bb] = P[m.off_att[l] + r * 4 + bb];
 #pragma unroll
-      for (int t = 0; t < G2_NT; ++t) img[((size_t)(((t * (G2_NR + 1) + r) * 2 + nt) * 64 + lane)) * 8 + e] = (uint16_t)t3[t];
-    }
+    for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] += at[bb] * bq[bb][q];
   }
+  uint32_t h01, m01, l01, h23, m23, l23;
+  g2_split2(v[0], v[1], h01, m01, l01);
+  g2_split2(v[2], v[3], h23, m23, l23);
+  const int lane = (kg & 3) * 16 + (n & 15), nt = n >> 4, e0 = 4 * (kg >> 2);
+  const uint32_t t3[3][2] = {{h01, h23}, {m01, m23}, {l01, l23}};
+#pragma unroll
+  for (int t = 0; t < G2_NT; ++t)
+    *(uint2*)(img + ((size_t)(((t * (G2_NR + 1) + r) * 2 + nt) * 64 + lane)) * 8 + e0) = make_uint2(t3[t][0], t3[t][1]);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -1245,7 +1278,7 @@ void igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* 
   a.stride = (cs > 1) ? ((B + 7) & ~7) : 1;
   const int grid = (cs > 1) ? cs * B : igmc_gs_grid(B);
   const size_t sm = (size_t)lay.words * 4;
-  IGMC_PLAUNCH("k_g2_compose", k_g2_compose, 7, G2_THREADS, 0, stream, m, P, m.g2_w);
+  IGMC_PLAUNCH("k_g2_compose", k_g2_compose, 2 * 3 * (G2_NR + 1) + 1, G2_THREADS, 0, stream, m, P, m.g2_w);
 #ifdef IGMC_HIPEMU
   if (cs > 1) {        // (after the launch above: a launch consumes the co-residency request)
     hipemu::rt().co_cs = cs;
