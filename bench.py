@@ -269,7 +269,7 @@ def main():
 
     run(args.warmup)
     new_epoch_if_needed()
-    captured = sg.prepare()             # every graph the timed steps replay exists before t0
+    captured = sg.prepare(steps_hint=args.steps)   # every graph the timed steps replay exists before t0
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -81,6 +81,7 @@ class StepGraph(object):
         # several steps in ONE graph launch: consecutive launches of a replayed graph are separated by a gap of tens of
         # microseconds on the device, a sizeable part of a ~200 us step (IGMC_GRAPH_STEPS, even, 0 disables)
         self.multi_n = int(os.environ.get('IGMC_GRAPH_STEPS', '8')) & ~1
+        self.multi_base = self.multi_n
         self.multi = None
         self._attached = False
         self.k = 0                      # steps done in the current epoch (parity selects the arena)
@@ -244,13 +245,23 @@ class StepGraph(object):
         captured); False = the graph ends at the local gradients and all-reduce + Adam are enqueued after each replay."""
         return (not self.dp_path) or self.dp_capture
 
-    def prepare(self):
+    def prepare(self, steps_hint=None):
         """Capture every hipGraph this object will replay (both single-step parities and the multi-step group) NOW.
+        ``steps_hint``: the caller is about to run exactly that many steps -- the group size becomes the largest even
+        divisor of it in [IGMC_GRAPH_STEPS, 2 * IGMC_GRAPH_STEPS] (if any), so that the run is whole groups only (a step
+        replayed on its own pays a graph-launch gap of its own).
         Capturing executes nothing, so no step is skipped or repeated; callers that time a region (bench.py) call this
         after their warm-up so that no capture (milliseconds each) falls inside the timed steps.  Needs at least one
         eagerly executed step before it (first launches load code objects, which a capture cannot do)."""
         if not self.use_graph or self.steps_done < 1 or not self._attached:
             return False
+        if steps_hint and self.multi_n >= 2:
+            base = self.multi_base
+            for m in range(2 * base, base - 1, -2):
+                if int(steps_hint) % m == 0:
+                    if m != self.multi_n:
+                        self.multi_n, self.multi = m, None      # (a group captured during warm-up had the default size)
+                    break
         for parity in (0, 1):
             if self.graphs[parity] is None and self.use_graph:
                 self._capture(parity)
