@@ -33,10 +33,24 @@ struct ExtractArgs {
   const float* link_y;
   const int32_t* link_idx;
   int first, B, replay;
+  int split;             // 1: grid (B, 2), one workgroup per SIDE of a link (hop 1: the two fringes are independent)
   double sample_ratio;
   uint64_t seed, epoch;
   const int64_t* ctrl;   // optional device-side step control (first / epoch), see igmc_hip.h
 };
+
+// LDS request of the kernels of the extraction branch, rounded UP to IGMC_EXTRACT_LDS_PAD bytes (default 16 KB): the
+// branch runs beside k_graph_step2, whose workgroups leave ~7 KB of a CU's 160 KB free -- small extraction workgroups
+// would be co-scheduled onto those CUs and slow the one wave per SIMD of a cluster member (and with it the whole
+// cluster); padded, they only fit the CUs the subgraph kernel does not occupy.
+static size_t extract_lds(size_t need) {
+  static long pad = -1;
+  if (pad < 0) {
+    const char* e = getenv("IGMC_EXTRACT_LDS_PAD");
+    pad = e ? atol(e) : 16384;
+  }
+  return need < (size_t)pad ? (size_t)pad : need;
+}
 
 // ---------------------------------------------------------------- bitmap helpers
 __device__ __forceinline__ void bm_clear(uint32_t* a, int W) {
@@ -177,9 +191,12 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_extract_nodes(ExtractArgs a) {
   uint8_t* sl = a.b.s_lab + so;
   int32_t* sd = a.b.s_deg + so;
 
+  // hop 1 (a.split): the user side of a link (raters of the target item) and its item side (items of the target user)
+  // never meet before the dense block is formed, so each gets its own workgroup -- half the dependent chain
+  const bool do_u = !a.split || blockIdx.y == 0, do_v = !a.split || blockIdx.y == 1;
   int cu, cv, u0, v0;
-  bm_clear(sel_u, Wu);
-  bm_clear(sel_v, Wv);
+  if (do_u) bm_clear(sel_u, Wu);
+  if (do_v) bm_clear(sel_v, Wv);
   if (!a.replay) {
     // with a control block attached the host `first` selects the even / odd slot (see igmc_hip.h): a prefetch of
     // the next batch on another stream reads the slot the concurrent step never writes
@@ -188,46 +205,61 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_extract_nodes(ExtractArgs a) {
     const int pos = a.link_idx ? a.link_idx[first + g] : first + g;
     u0 = a.link_u[pos];
     v0 = a.link_v[pos];
-    bm_clear(vis_u, Wu);
-    bm_clear(vis_v, Wv);
+    if (do_u) bm_clear(vis_u, Wu);
+    if (do_v) bm_clear(vis_v, Wv);
     __syncthreads();
     if (tid == 0) {
-      vis_u[u0 >> 5] |= 1u << (u0 & 31);
-      vis_v[v0 >> 5] |= 1u << (v0 & 31);
-      tl[0] = u0;
-      td[0] = 0;
-      tl[cap_u] = v0;
-      td[cap_u] = 0;
-      a.b.y[g] = a.link_y[pos];
+      if (do_u) {
+        vis_u[u0 >> 5] |= 1u << (u0 & 31);
+        tl[0] = u0;
+        td[0] = 0;
+        a.b.y[g] = a.link_y[pos];
+      }
+      if (do_v) {
+        vis_v[v0 >> 5] |= 1u << (v0 & 31);
+        tl[cap_u] = v0;
+        td[cap_u] = 0;
+      }
     }
     cu = 1;
     cv = 1;
     int fu_lo = 0, fu_hi = 1, fv_lo = 0, fv_hi = 1;
     __syncthreads();
     for (int dist = 1; dist <= a.b.hop; ++dist) {
-      bm_clear(new_u, Wu);
-      bm_clear(new_v, Wv);
+      if (do_u) bm_clear(new_u, Wu);
+      if (do_v) bm_clear(new_v, Wv);
       __syncthreads();
-      // simultaneous swap (reference :217): users' rows give item candidates and vice versa
-      expand_fringe(tl, fu_lo, fu_hi, a.g.u_ptr, a.g.u_idx, new_v);
-      expand_fringe(tl + cap_u, fv_lo, fv_hi, a.g.v_ptr, a.g.v_idx, new_u);
+      // simultaneous swap (reference :217): users' rows give item candidates and vice versa.  (Split launch, hop 1: the
+      // fringes are the targets themselves, read from the link arrays -- the other side's list belongs to another workgroup.)
+      if (a.split) {
+        if (do_v) expand_fringe(&u0, 0, 1, a.g.u_ptr, a.g.u_idx, new_v);
+        if (do_u) expand_fringe(&v0, 0, 1, a.g.v_ptr, a.g.v_idx, new_u);
+      } else {
+        expand_fringe(tl, fu_lo, fu_hi, a.g.u_ptr, a.g.u_idx, new_v);
+        expand_fringe(tl + cap_u, fv_lo, fv_hi, a.g.v_ptr, a.g.v_idx, new_u);
+      }
       __syncthreads();
       int c = 0;
-      for (int w = tid; w < Wu; w += IGMC_BLOCK) {
-        const uint32_t x = new_u[w] & ~vis_u[w];
-        new_u[w] = x;
-        vis_u[w] |= x;   // visited updated before sampling (reference :220-221)
-        c += __popc(x);
+      int cnt_u = 0, cnt_v = 0;
+      if (do_u) {
+        for (int w = tid; w < Wu; w += IGMC_BLOCK) {
+          const uint32_t x = new_u[w] & ~vis_u[w];
+          new_u[w] = x;
+          vis_u[w] |= x;   // visited updated before sampling (reference :220-221)
+          c += __popc(x);
+        }
+        cnt_u = igmc_block_sum_i(c, sm);
       }
-      const int cnt_u = igmc_block_sum_i(c, sm);
       c = 0;
-      for (int w = tid; w < Wv; w += IGMC_BLOCK) {
-        const uint32_t x = new_v[w] & ~vis_v[w];
-        new_v[w] = x;
-        vis_v[w] |= x;
-        c += __popc(x);
+      if (do_v) {
+        for (int w = tid; w < Wv; w += IGMC_BLOCK) {
+          const uint32_t x = new_v[w] & ~vis_v[w];
+          new_v[w] = x;
+          vis_v[w] |= x;
+          c += __popc(x);
+        }
+        cnt_v = igmc_block_sum_i(c, sm);
       }
-      const int cnt_v = igmc_block_sum_i(c, sm);
       int ku = cnt_u, kv = cnt_v;
       if (a.sample_ratio < 1.0) {   // int(sample_ratio*len), reference :222-224
         ku = (int)(a.sample_ratio * (double)cnt_u);
@@ -238,11 +270,11 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_extract_nodes(ExtractArgs a) {
         if (a.b.max_nodes_per_hop < kv) kv = a.b.max_nodes_per_hop;
       }
       const uint64_t link_uid = (uint64_t)(uint32_t)pos;
-      sample_fringe(new_u, Wu, cnt_u, ku, igmc_sample_salt(a.seed, epoch, link_uid, dist, 0), hist, sm);
-      sample_fringe(new_v, Wv, cnt_v, kv, igmc_sample_salt(a.seed, epoch, link_uid, dist, 1), hist, sm);
-      if (ku == 0 && kv == 0) break;   // reference :230-231
-      const int ncu = append_fringe(new_u, sel_u, Wu, tl, td, cu, dist, sm);
-      const int ncv = append_fringe(new_v, sel_v, Wv, tl + cap_u, td + cap_u, cv, dist, sm);
+      if (do_u) sample_fringe(new_u, Wu, cnt_u, ku, igmc_sample_salt(a.seed, epoch, link_uid, dist, 0), hist, sm);
+      if (do_v) sample_fringe(new_v, Wv, cnt_v, kv, igmc_sample_salt(a.seed, epoch, link_uid, dist, 1), hist, sm);
+      if (ku == 0 && kv == 0) break;   // reference :230-231 (a split launch has one hop: nothing follows either way)
+      const int ncu = do_u ? append_fringe(new_u, sel_u, Wu, tl, td, cu, dist, sm) : cu;
+      const int ncv = do_v ? append_fringe(new_v, sel_v, Wv, tl + cap_u, td + cap_u, cv, dist, sm) : cv;
       fu_lo = cu; fu_hi = ncu; cu = ncu;
       fv_lo = cv; fv_hi = ncv; cv = ncv;
       __syncthreads();
@@ -259,28 +291,32 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_extract_nodes(ExtractArgs a) {
   __syncthreads();
 
   // local index = 1 + rank among the selected ids (ascending); targets are local 0
-  bm_prefix(sel_u, pre_u, Wu, sm);
-  bm_prefix(sel_v, pre_v, Wv, sm);
+  if (do_u) bm_prefix(sel_u, pre_u, Wu, sm);
+  if (do_v) bm_prefix(sel_v, pre_v, Wv, sm);
   __syncthreads();
-  for (int i = tid; i < cu; i += IGMC_BLOCK) {
-    const int id = tl[i];
-    const int li = (i == 0) ? 0 : 1 + bm_rank(sel_u, pre_u, id);
-    sg[li] = id;
-    sl[li] = (uint8_t)(2 * td[i]);             // reference :245
-  }
-  for (int i = tid; i < cv; i += IGMC_BLOCK) {
-    const int id = tl[cap_u + i];
-    const int li = (i == 0) ? 0 : 1 + bm_rank(sel_v, pre_v, id);
-    sg[cap_u + li] = id;
-    sl[cap_u + li] = (uint8_t)(2 * td[cap_u + i] + 1);
-  }
+  if (do_u)
+    for (int i = tid; i < cu; i += IGMC_BLOCK) {
+      const int id = tl[i];
+      const int li = (i == 0) ? 0 : 1 + bm_rank(sel_u, pre_u, id);
+      sg[li] = id;
+      sl[li] = (uint8_t)(2 * td[i]);             // reference :245
+    }
+  if (do_v)
+    for (int i = tid; i < cv; i += IGMC_BLOCK) {
+      const int id = tl[cap_u + i];
+      const int li = (i == 0) ? 0 : 1 + bm_rank(sel_v, pre_v, id);
+      sg[cap_u + li] = id;
+      sl[cap_u + li] = (uint8_t)(2 * td[cap_u + i] + 1);
+    }
   if (tid == 0) {
-    a.b.n_users[g] = cu;
-    a.b.n_items[g] = cv;
-    a.b.edge_cnt[g] = 0;
-    if (g == 0 && a.b.relm) a.b.totals[3] = a.B;      // consumers of a lean batch (no CSR emission) read the batch size here
+    if (do_u) {
+      a.b.n_users[g] = cu;
+      a.b.edge_cnt[g] = 0;
+      if (g == 0 && a.b.relm) a.b.totals[3] = a.B;      // consumers of a lean batch (no CSR emission) read the batch size here
+    }
+    if (do_v) a.b.n_items[g] = cv;
   }
-  if (a.b.relm) {      // clear this link's dense (user, item) -> relation block (only the cu x cap_v part is used)
+  if (a.b.relm && do_u) {      // clear this link's dense (user, item) -> relation block (only the cu x cap_v part is used)
     uint32_t* rm = (uint32_t*)(a.b.relm + (size_t)g * a.b.cap_u * a.b.relm_ld);
     const int nw = (cu * a.b.relm_ld) >> 2;
     for (int i = tid; i < nw; i += IGMC_BLOCK) rm[i] = 0u;
@@ -841,7 +877,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_relm_dropout(BatchDev b, float p
 
 void igmc_launch_relm_dropout(const BatchDev& b, int B, float p, int force_undirected, uint64_t seed, uint64_t step,
                               const int64_t* ctrl, void* stream) {
-  IGMC_PLAUNCH("k_relm_dropout", k_relm_dropout, dim3(B, 4), IGMC_BLOCK, 0, stream, b, p, force_undirected, seed, step, ctrl);
+  IGMC_PLAUNCH("k_relm_dropout", k_relm_dropout, dim3(B, 4), IGMC_BLOCK, extract_lds(0), stream, b, p, force_undirected, seed, step, ctrl);
 }
 
 void igmc_launch_relm_flags(const BatchDev& b, void* stream) {
@@ -884,7 +920,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_load_nodes(BatchDev b, const int
 void igmc_launch_load_nodes(const BatchDev& b, const int64_t* uoff, const int32_t* unodes, const uint8_t* udist,
                             const int64_t* voff, const int32_t* vnodes, const uint8_t* vdist, const float* link_y,
                             const int32_t* link_idx, int first, int B, const int64_t* ctrl, void* stream) {
-  IGMC_PLAUNCH("k_load_nodes", k_load_nodes, B, IGMC_BLOCK, 0, stream, b, uoff, unodes, udist, voff, vnodes, vdist, link_y,
+  IGMC_PLAUNCH("k_load_nodes", k_load_nodes, B, IGMC_BLOCK, extract_lds(0), stream, b, uoff, unodes, udist, voff, vnodes, vdist, link_y,
                link_idx, first, ctrl);
 }
 
@@ -942,12 +978,14 @@ void igmc_launch_extract(const GraphDev& g, const BatchDev& b, const int32_t* li
   // S workgroups per link for the row passes: fill the chip even at batch 50
   int S = 2048 / (B > 0 ? B : 1);
   S = S < 1 ? 1 : (S > 16 ? 16 : S);
-  IGMC_PLAUNCH("k_extract_nodes", k_extract_nodes, B, IGMC_BLOCK, smem, stream, a);
+  const char* se = getenv("IGMC_EXTRACT_SPLIT");       // debug switch: 0 = one workgroup per link also at hop 1
+  a.split = (b.hop == 1 && !replay && !(se && atoi(se) == 0)) ? 1 : 0;
+  IGMC_PLAUNCH("k_extract_nodes", k_extract_nodes, dim3(B, a.split ? 2 : 1), IGMC_BLOCK, extract_lds(smem), stream, a);
   if (b.relm) {      // capped extraction (igmc_batch_create decides)
     const size_t Wu = (g.n_users + 31) >> 5, Wv = (g.n_items + 31) >> 5;
     int Sr = 400 / (B > 0 ? B : 1);        // entry-balanced slices: ~400 workgroups in all (one residency round)
     Sr = Sr < 1 ? 1 : (Sr > 16 ? 16 : Sr);
-    IGMC_PLAUNCH("k_relm", k_relm, dim3(B, Sr), IGMC_BLOCK, (2 * Wv + 2 * (size_t)b.cap_u + 2) * sizeof(uint32_t), stream, g, b);
+    IGMC_PLAUNCH("k_relm", k_relm, dim3(B, Sr), IGMC_BLOCK, extract_lds((2 * Wv + 2 * (size_t)b.cap_u + 2) * sizeof(uint32_t)), stream, g, b);
     if (!lean) igmc_launch_emit(b, B, stream);
   } else {
     IGMC_PLAUNCH("k_count", k_count, dim3(B, S), IGMC_BLOCK, smem / 4, stream, g, b);

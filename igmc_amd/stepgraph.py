@@ -245,17 +245,21 @@ class StepGraph(object):
         captured); False = the graph ends at the local gradients and all-reduce + Adam are enqueued after each replay."""
         return (not self.dp_path) or self.dp_capture
 
-    def prepare(self, steps_hint=None):
+    def prepare(self, steps_hint=None, group=None):
         """Capture every hipGraph this object will replay (both single-step parities and the multi-step group) NOW.
         ``steps_hint``: the caller is about to run exactly that many steps -- the group size becomes the largest even
         divisor of it in [IGMC_GRAPH_STEPS, 2 * IGMC_GRAPH_STEPS] (if any), so that the run is whole groups only (a step
-        replayed on its own pays a graph-launch gap of its own).
+        replayed on its own pays a graph-launch gap of its own).  ``group``: that many steps per graph launch.
         Capturing executes nothing, so no step is skipped or repeated; callers that time a region (bench.py) call this
         after their warm-up so that no capture (milliseconds each) falls inside the timed steps.  Needs at least one
         eagerly executed step before it (first launches load code objects, which a capture cannot do)."""
         if not self.use_graph or self.steps_done < 1 or not self._attached:
             return False
-        if steps_hint and self.multi_n >= 2:
+        if group is not None and self.multi_n >= 2 and int(group) >= 2:
+            group = int(group) & ~1                              # explicit group size (steps per graph launch)
+            if group != self.multi_n:
+                self.multi_n, self.multi = group, None
+        elif steps_hint and self.multi_n >= 2:
             base = self.multi_base
             for m in range(2 * base, base - 1, -2):
                 if int(steps_hint) % m == 0:
@@ -320,7 +324,7 @@ class StepGraph(object):
         while n > 0:
             M = self.multi_n
             multi_ok = (self.use_graph and self._finish_in_graph() and M >= 2 and self.k % 2 == 0 and
-                        self.steps_done >= 4)
+                        (self.steps_done >= 4 or self.multi is not None))
             if multi_ok and self.multi is None:
                 # captured as soon as it can be (capturing executes nothing), also when fewer than M steps are asked for
                 # right now: the milliseconds a capture costs then fall into the caller's warm-up, not into its first

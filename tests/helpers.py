@@ -14,7 +14,8 @@ if ROOT not in sys.path:
 def emu_lib():
     """Host emulation build of the HIP sources (kernel-logic tests only; never the product path)."""
     from igmc_amd import _lib, build
-    path = build.build_emu()
+    # IGMC_EMU_LIB: a sanitizer build of the same sources (tools/sanitize_emu.sh runs part of the suite under UBSan)
+    path = os.environ.get('IGMC_EMU_LIB') or build.build_emu()
     return _lib.bind(ctypes.CDLL(path), path)
 
 
