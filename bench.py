@@ -214,7 +214,7 @@ def main():
         else:
             split = preprocessing.create_trainvaltest_split(cfg['dataset'], 1234, True,
                                                             verbose=int(os.environ.get('RANK', '0')) == 0)
-            source = 'real' if preprocessing._load_real_movielens(cfg['dataset']) is not None else 'synthetic'
+            source = 'real' if preprocessing._find_raw(cfg['dataset'], 'ratings.dat' if cfg['dataset'] != 'ml_100k' else 'u.data') else 'synthetic'
     (_, _, A, tr_l, tr_u, tr_v, _, _, _, te_l, te_u, te_v, class_values) = split
     rank, world = parallel.init_from_env('nccl')
     if world != args.gpus:

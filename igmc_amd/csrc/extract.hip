@@ -39,19 +39,6 @@ struct ExtractArgs {
   const int64_t* ctrl;   // optional device-side step control (first / epoch), see igmc_hip.h
 };
 
-// LDS request of the kernels of the extraction branch, rounded UP to IGMC_EXTRACT_LDS_PAD bytes (default 16 KB): the
-// branch runs beside k_graph_step2, whose workgroups leave ~7 KB of a CU's 160 KB free -- small extraction workgroups
-// would be co-scheduled onto those CUs and slow the one wave per SIMD of a cluster member (and with it the whole
-// cluster); padded, they only fit the CUs the subgraph kernel does not occupy.
-static size_t extract_lds(size_t need) {
-  static long pad = -1;
-  if (pad < 0) {
-    const char* e = getenv("IGMC_EXTRACT_LDS_PAD");
-    pad = e ? atol(e) : 16384;
-  }
-  return need < (size_t)pad ? (size_t)pad : need;
-}
-
 // ---------------------------------------------------------------- bitmap helpers
 __device__ __forceinline__ void bm_clear(uint32_t* a, int W) {
   for (int w = threadIdx.x; w < W; w += IGMC_BLOCK) a[w] = 0u;
@@ -877,7 +864,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_relm_dropout(BatchDev b, float p
 
 void igmc_launch_relm_dropout(const BatchDev& b, int B, float p, int force_undirected, uint64_t seed, uint64_t step,
                               const int64_t* ctrl, void* stream) {
-  IGMC_PLAUNCH("k_relm_dropout", k_relm_dropout, dim3(B, 4), IGMC_BLOCK, extract_lds(0), stream, b, p, force_undirected, seed, step, ctrl);
+  IGMC_PLAUNCH("k_relm_dropout", k_relm_dropout, dim3(B, 4), IGMC_BLOCK, 0, stream, b, p, force_undirected, seed, step, ctrl);
 }
 
 void igmc_launch_relm_flags(const BatchDev& b, void* stream) {
@@ -920,7 +907,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_load_nodes(BatchDev b, const int
 void igmc_launch_load_nodes(const BatchDev& b, const int64_t* uoff, const int32_t* unodes, const uint8_t* udist,
                             const int64_t* voff, const int32_t* vnodes, const uint8_t* vdist, const float* link_y,
                             const int32_t* link_idx, int first, int B, const int64_t* ctrl, void* stream) {
-  IGMC_PLAUNCH("k_load_nodes", k_load_nodes, B, IGMC_BLOCK, extract_lds(0), stream, b, uoff, unodes, udist, voff, vnodes, vdist, link_y,
+  IGMC_PLAUNCH("k_load_nodes", k_load_nodes, B, IGMC_BLOCK, 0, stream, b, uoff, unodes, udist, voff, vnodes, vdist, link_y,
                link_idx, first, ctrl);
 }
 
@@ -980,12 +967,12 @@ void igmc_launch_extract(const GraphDev& g, const BatchDev& b, const int32_t* li
   S = S < 1 ? 1 : (S > 16 ? 16 : S);
   const char* se = getenv("IGMC_EXTRACT_SPLIT");       // debug switch: 0 = one workgroup per link also at hop 1
   a.split = (b.hop == 1 && !replay && !(se && atoi(se) == 0)) ? 1 : 0;
-  IGMC_PLAUNCH("k_extract_nodes", k_extract_nodes, dim3(B, a.split ? 2 : 1), IGMC_BLOCK, extract_lds(smem), stream, a);
+  IGMC_PLAUNCH("k_extract_nodes", k_extract_nodes, dim3(B, a.split ? 2 : 1), IGMC_BLOCK, smem, stream, a);
   if (b.relm) {      // capped extraction (igmc_batch_create decides)
     const size_t Wu = (g.n_users + 31) >> 5, Wv = (g.n_items + 31) >> 5;
     int Sr = 400 / (B > 0 ? B : 1);        // entry-balanced slices: ~400 workgroups in all (one residency round)
     Sr = Sr < 1 ? 1 : (Sr > 16 ? 16 : Sr);
-    IGMC_PLAUNCH("k_relm", k_relm, dim3(B, Sr), IGMC_BLOCK, extract_lds((2 * Wv + 2 * (size_t)b.cap_u + 2) * sizeof(uint32_t)), stream, g, b);
+    IGMC_PLAUNCH("k_relm", k_relm, dim3(B, Sr), IGMC_BLOCK, (2 * Wv + 2 * (size_t)b.cap_u + 2) * sizeof(uint32_t), stream, g, b);
     if (!lean) igmc_launch_emit(b, B, stream);
   } else {
     IGMC_PLAUNCH("k_count", k_count, dim3(B, S), IGMC_BLOCK, smem / 4, stream, g, b);

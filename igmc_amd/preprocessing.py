@@ -197,23 +197,110 @@ def synth_ml(n_users, n_items, nnz, hist, seed=0):
     return u, v, r
 
 
-def _load_real_movielens(dataset):
-    """Real files when an operator provides them (plain parsers; ids remapped to 0..n-1)."""
-    if dataset == 'ml_1m':
-        p = _find_raw('ml_1m', 'ratings.dat')
-        if p is None:
-            return None
-        raw = np.loadtxt(p, delimiter=':', usecols=(0, 2, 4), dtype=np.int64)
-    elif dataset == 'ml_100k':
+def _py_shuffle_perm(n, seed):
+    """The permutation ``random.seed(seed); random.shuffle(rows)`` applies to a list of ``n`` rows (reference
+    ``data_utils.py:155-157``: "shuffle here like cf-nade paper with python's own random class"): the Fisher-Yates
+    walk depends on the generator and the length only."""
+    import random
+    idx = list(range(n))
+    rnd = random.Random(seed)
+    rnd.shuffle(idx)
+    return np.asarray(idx, dtype=np.int64)
+
+
+def _onehot_blocks(columns):
+    """One-hot block per column, values numbered in ``np.unique`` order, blocks side by side (reference
+    ``data_utils.py:283-301``)."""
+    dicts, cntr = [], 0
+    for col in columns:
+        feats = np.unique(np.asarray(col)).tolist()
+        dicts.append({f: i for i, f in enumerate(feats, start=cntr)})
+        cntr += len(feats)
+    return dicts, cntr
+
+
+def _maybe_int(values):
+    """pandas' type inference for a text column: integers when every field parses as one, else strings."""
+    try:
+        return [int(x) for x in values]
+    except ValueError:
+        return list(values)
+
+
+def _load_real_movielens(dataset, seed=1234):
+    """MovieLens raw files an operator dropped into ``raw_data/<dataset>/`` (reference ``data_utils.load_data``,
+    ``data_utils.py:88-380``; nothing is downloaded here).  Returns ``(num_users, num_items, u, v, ratings, u_features,
+    v_features)`` with the rows in the reference's shuffled order (python ``random`` with ``seed``), ids mapped to
+    0..n-1 in sorted order (``map_data``), or ``None`` when the files are absent.
+
+    * ``ml_100k``: ``u.data`` (tab separated) + ``u.item`` (18 genre flags) + ``u.user`` ([age, gender, one-hot
+      occupation]);  * ``ml_1m``: ``ratings.dat`` / ``movies.dat`` / ``users.dat`` (``::`` separated; genres one-hot, users
+      one-hot gender | age | occupation | zip-code);  * ``ml_10m``: ``ratings.dat`` only.
+    Genre (ml_1m) and occupation (ml_100k) columns are numbered in SORTED order -- the reference numbers them by
+    iterating a Python set of strings, which differs between interpreter runs."""
+    u_features = v_features = None
+    if dataset == 'ml_100k':
         p = _find_raw('ml_100k', 'u.data')
         if p is None:
             return None
-        raw = np.loadtxt(p, usecols=(0, 1, 2), dtype=np.int64)
+        raw = np.loadtxt(p, delimiter='\t', dtype=np.float64, ndmin=2)
+    elif dataset in ('ml_1m', 'ml_10m'):
+        p = _find_raw(dataset, 'ratings.dat')
+        if p is None:
+            return None
+        with open(p) as f:
+            raw = np.array([[float(x) for x in line.split('::')] for line in f if line.strip()], dtype=np.float64)
     else:
         return None
-    _, u = np.unique(raw[:, 0], return_inverse=True)
-    _, v = np.unique(raw[:, 1], return_inverse=True)
-    return u.astype(np.int64), v.astype(np.int64), raw[:, 2].astype(np.float64)
+    raw = raw[_py_shuffle_perm(len(raw), seed)]
+    u_ids, u = np.unique(raw[:, 0].astype(np.int64), return_inverse=True)
+    v_ids, v = np.unique(raw[:, 1].astype(np.int64), return_inverse=True)
+    num_users, num_items = len(u_ids), len(v_ids)
+    upos = {int(i): k for k, i in enumerate(u_ids.tolist())}
+    vpos = {int(i): k for k, i in enumerate(v_ids.tolist())}
+    base = os.path.dirname(p)
+    if dataset == 'ml_100k' and os.path.exists(os.path.join(base, 'u.item')) and os.path.exists(os.path.join(base, 'u.user')):
+        v_features = np.zeros((num_items, ML100K_GENRES), dtype=np.float32)
+        with open(os.path.join(base, 'u.item'), encoding='latin-1') as f:
+            for line in f:
+                row = line.rstrip('\n').split('|')
+                if len(row) > 6 and int(row[0]) in vpos:
+                    v_features[vpos[int(row[0])]] = [float(x) for x in row[6:6 + ML100K_GENRES]]
+        with open(os.path.join(base, 'u.user'), encoding='latin-1') as f:
+            users = [line.rstrip('\n').split('|') for line in f if line.strip()]
+        occ = {o: i for i, o in enumerate(sorted(set(r[3] for r in users)), start=2)}
+        u_features = np.zeros((num_users, 2 + len(occ)), dtype=np.float32)
+        for r in users:
+            k = upos.get(int(r[0]))
+            if k is not None:
+                u_features[k, 0] = float(r[1])                     # raw age (data_utils.py:207; the official-split
+                u_features[k, 1] = {'M': 0., 'F': 1.}[r[2]]        # loader normalises it, this one does not)
+                u_features[k, occ[r[3]]] = 1.
+    elif dataset == 'ml_1m' and os.path.exists(os.path.join(base, 'movies.dat')) and os.path.exists(os.path.join(base, 'users.dat')):
+        with open(os.path.join(base, 'movies.dat'), encoding='latin-1') as f:
+            movies = [line.rstrip('\n').split('::') for line in f if line.strip()]
+        genres = sorted(set(g for m in movies for g in m[2].split('|')))
+        gpos = {g: i for i, g in enumerate(genres)}
+        v_features = np.zeros((num_items, len(genres)), dtype=np.float32)
+        for m in movies:
+            k = vpos.get(int(m[0]))
+            if k is not None:
+                for g in m[2].split('|'):
+                    v_features[k, gpos[g]] = 1.
+        with open(os.path.join(base, 'users.dat'), encoding='latin-1') as f:
+            users = [line.rstrip('\n').split('::') for line in f if line.strip()]
+        cols = [[r[1] for r in users], [int(r[2]) for r in users], [int(r[3]) for r in users],
+                _maybe_int([r[4] for r in users])]
+        dicts, nf = _onehot_blocks(cols)
+        u_features = np.zeros((num_users, nf), dtype=np.float32)
+        for j, r in enumerate(users):
+            k = upos.get(int(r[0]))
+            if k is not None:
+                for c in range(4):
+                    u_features[k, dicts[c][cols[c][j]]] = 1.
+    if u_features is not None:
+        u_features, v_features = sp.csr_matrix(u_features), sp.csr_matrix(v_features)
+    return num_users, num_items, u.astype(np.int64), v.astype(np.int64), raw[:, 2].astype(np.float64), u_features, v_features
 
 
 def create_trainvaltest_split(dataset, seed=1234, testing=False, datasplit_path=None, datasplit_from_file=False,
@@ -221,10 +308,11 @@ def create_trainvaltest_split(dataset, seed=1234, testing=False, datasplit_path=
     """Random split with the reference's proportions (``preprocessing.py:159-197``): test = ceil(0.1 n),
     val = ceil(0.9*0.05 n), the rest train; ``testing`` merges val into train.  Data = real MovieLens files if
     present, else the synthetic generator (``data`` field of every report says which)."""
-    real = _load_real_movielens(dataset)
+    real = _load_real_movielens(dataset, seed)
+    u_features = v_features = None
     if real is not None:
-        u_nodes, v_nodes, ratings = real
-        num_users, num_items = int(u_nodes.max()) + 1, int(v_nodes.max()) + 1
+        # rows already in the reference's shuffled order (python `random` with `seed`, data_utils.py:155-157)
+        num_users, num_items, u_nodes, v_nodes, ratings, u_features, v_features = real
         source = 'real'
     else:
         if dataset not in ML_HIST:
@@ -232,9 +320,9 @@ def create_trainvaltest_split(dataset, seed=1234, testing=False, datasplit_path=
         num_users, num_items, nnz, hist = ML_HIST[dataset]
         u_nodes, v_nodes, ratings = synth_ml(num_users, num_items, nnz, hist, seed=synth_seed)
         source = 'synthetic'
-    # the reference shuffles inside load_data (data_utils.py) with `seed`; same role here
-    perm = np.random.default_rng(seed).permutation(len(ratings))
-    u_nodes, v_nodes, ratings = u_nodes[perm], v_nodes[perm], ratings[perm]
+        # the reference shuffles inside load_data (data_utils.py) with `seed`; same role here
+        perm = np.random.default_rng(seed).permutation(len(ratings))
+        u_nodes, v_nodes, ratings = u_nodes[perm], v_nodes[perm], ratings[perm]
     if rating_map is not None:
         ratings = np.array([rating_map[x] for x in ratings], dtype=np.float64)
     class_values = np.sort(np.unique(ratings))
@@ -263,8 +351,8 @@ def create_trainvaltest_split(dataset, seed=1234, testing=False, datasplit_path=
     if verbose:
         print('%s (%s): %d users, %d items, %d ratings, train %d / val %d / test %d' % (
             dataset, source, num_users, num_items, n, len(train_labels), len(val_labels), len(test_labels)))
-    return (None, None, rating_mx_train, train_labels, u_train_idx, v_train_idx, val_labels, u_val_idx, v_val_idx,
-            test_labels, u_test_idx, v_test_idx, class_values)
+    return (u_features, v_features, rating_mx_train, train_labels, u_train_idx, v_train_idx, val_labels, u_val_idx,
+            v_val_idx, test_labels, u_test_idx, v_test_idx, class_values)
 
 
 # ------------------------------------------------------------------------------------------ official ML-100K split
