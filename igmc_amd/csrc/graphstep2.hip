@@ -826,6 +826,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
       }
     }
     if (!TRAIN) {
+      first_graph = false;      // (a looping workgroup must not reuse the first subgraph's prefetched extents)
       __syncthreads();
       continue;
     }

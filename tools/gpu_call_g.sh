@@ -5,7 +5,7 @@ ROOT=$(pwd)
 O=$ROOT/gpurun_out/g
 mkdir -p $O
 export PYTHONPATH=$ROOT
-( timeout 900 python -m pytest tests/test_gpu_headline.py tests/test_gpu_parity.py -m gpu -q -x 2>&1 | tail -8 ) > $O/gpu_tests.log
+( timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -8 ) > $O/gpu_tests.log
 ( timeout 300 python tools/g2_phase_clocks.py 2>&1 ) > $O/phase_clocks.txt
 ( timeout 300 python bench.py --no-cpu-baseline --dp-steps 0 ) > $O/bench_ml1m_200.json 2> $O/bench_ml1m_200.err
 ( timeout 300 python bench.py --no-cpu-baseline --steps 20 --warmup 5 --dp-steps 0 ) > $O/bench_ml1m_driver.json 2> $O/bench_ml1m_driver.err
