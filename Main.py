@@ -72,6 +72,10 @@ def build_parser():
     p.add_argument('--test-freq', type=int, default=1, metavar='N')
     p.add_argument('--ARR', type=float, default=0.001)
     # transfer learning, ensemble, visualization
+    p.add_argument('--dgcnn-rs', action='store_true', default=False,
+                   help='train DGCNN_RS (sort-pool readout, reference models.py:123-167) instead of IGMC')
+    p.add_argument('--k', type=float, default=0.6,
+                   help='sort-pool size of DGCNN_RS: a percentile of the subgraph sizes if < 1 (reference Main.py:369)')
     p.add_argument('--transfer', default='')
     p.add_argument('--num-relations', type=int, default=5)
     p.add_argument('--multiply-by', type=int, default=1)
@@ -201,10 +205,21 @@ def main(argv=None):
         num_relations, multiply_by = args.num_relations, args.multiply_by
     else:
         num_relations, multiply_by = len(class_values), 1
-    model = IGMC(train_graphs, latent_dim=[32, 32, 32, 32], num_relations=num_relations, num_bases=4,
-                 regression=True, adj_dropout=args.adj_dropout, force_undirected=args.force_undirected,
-                 side_features=args.use_features, n_side_features=n_features, multiply_by=multiply_by,
-                 seed=args.seed)
+    if args.dgcnn_rs:
+        # the reference keeps this model behind `if False` (Main.py:364-380); --dgcnn-rs is the switch it never had
+        from igmc_amd.models import DGCNN_RS
+        model = DGCNN_RS(train_graphs, latent_dim=[32, 32, 32, 1], k=args.k, num_relations=len(class_values),
+                         num_bases=4, regression=True, adj_dropout=args.adj_dropout,
+                         force_undirected=args.force_undirected, seed=args.seed)
+        if not args.transfer and rank == 0:     # record the k used in sortpooling (reference Main.py:376-380)
+            with open(os.path.join(args.res_dir, 'cmd_input.txt'), 'a') as f:
+                f.write(' --k ' + str(model.k) + '\n')
+                print('k is saved.')
+    else:
+        model = IGMC(train_graphs, latent_dim=[32, 32, 32, 32], num_relations=num_relations, num_bases=4,
+                     regression=True, adj_dropout=args.adj_dropout, force_undirected=args.force_undirected,
+                     side_features=args.use_features, n_side_features=n_features, multiply_by=multiply_by,
+                     seed=args.seed)
     if rank == 0:
         print('Total number of parameters is {}'.format(sum(p.numel() for p in model.parameters())))
 

@@ -1,5 +1,6 @@
 // capi.hip -- C-ABI host layer of libigmc_hip.so (see include/igmc_hip.h for the contract).
 #include "launch.h"
+#include "sortpool.h"
 
 #include <algorithm>
 #include <climits>
@@ -632,6 +633,7 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
           M.get(&d.graw, (size_t)3 * igmc_wg_stride() + 3 * d.R * 4 + rows0 * 32) | M.get(&d.arr_part, 4);
   d.side = nullptr;
   d.ctrl = nullptr;
+  d.dcat[0] = d.dcat[1] = d.dcat[2] = nullptr;
   fail |= M.get(&m->done_ctr, 8);      // [0] step-wide, [1..4] per conv layer (k_finalize)
   if (fail) {
     M.release();
@@ -892,5 +894,138 @@ extern "C" int igmc_train_step(igmc_model* m, float* d_params, const igmc_batch*
   m->last_B = b->last_B;
   m->last_training = 1;
   m->last_flags = use_edge_flags;
+  return 0;
+}
+
+// ------------------------------------------------------------------ sort-pool readout family (DGCNN_RS)
+struct igmc_sortpool {
+  igmc_model* m;
+  SpDev d;
+  float* pe;        // engine-layout copy of the conv parameters (layer 3 zero-padded to 32 columns)
+  float* ge;        // engine-layout gradient scratch
+  Allocs mem;
+};
+
+extern "C" int igmc_sortpool_create(igmc_model* m, int k, int max_nodes_per_graph, igmc_sortpool** out) {
+  if (!m || !out) IGMC_FAIL("null argument");
+  if (k < 10) IGMC_FAIL("sort-pool k must be >= 10 (reference models.py:73)");
+  if (m->d.S != 0) IGMC_FAIL("the sort-pool readout takes no side features");
+  if (max_nodes_per_graph < 2 || max_nodes_per_graph > 4096) IGMC_FAIL("subgraphs of 2..4096 nodes");
+  HIPCHECK(hipSetDevice(m->device));
+  igmc_sortpool* sp = new igmc_sortpool();
+  sp->m = m;
+  SpDev& d = sp->d;
+  const ModelDev& md = m->d;
+  d.k = k;
+  d.Q1 = k / 2;                       // int((k - 2) / 2 + 1), reference models.py:83
+  d.Q2 = d.Q1 - 5 + 1;
+  if (d.Q2 < 1) { delete sp; IGMC_FAIL("k too small for Conv1d(16, 32, 5)"); }
+  d.dense = d.Q2 * 32;
+  d.nmax = max_nodes_per_graph;
+  d.P = 1;
+  while (d.P < d.nmax) d.P <<= 1;
+  // true layout: layers 0..2 at the engine offsets, then layer 3 with one output column
+  int64_t off = md.off_basis[3];
+  d.t_basis3 = off; off += 4 * 32;
+  d.t_root3 = off;  off += 32;
+  d.t_bias3 = off;  off += 1;
+  d.t_att3 = off;   off += (int64_t)md.R * 4;
+  d.t_conv_end = off;
+  d.t_c1w = off; off += 16 * 97 + 16;
+  d.t_c2w = off; off += 32 * 16 * 5 + 32;
+  d.t_l1w = off; off += (int64_t)128 * d.dense;
+  d.t_l1b = off; off += 128;
+  d.t_l2w = off; off += 128;
+  d.t_l2b = off; off += 1;
+  d.n_params = off;
+  if (!igmc_sp_lds_ok(d)) { delete sp; IGMC_FAIL("k / subgraph size too large for the LDS plan of the sort-pool kernels"); }
+  Allocs& M = sp->mem;
+  const size_t Bc = (size_t)md.graph_cap, N = (size_t)md.node_cap;
+  int fail = 0;
+  fail |= M.get(&d.sel, Bc * k) | M.get(&d.y1, Bc * 16 * k) | M.get(&d.flat, Bc * d.dense) | M.get(&d.a1, Bc * 128) |
+          M.get(&d.lmask, Bc * 128) | M.get(&d.dz, Bc * 128) | M.get(&d.dout, Bc) |
+          M.get(&d.part_c1, Bc * (16 * 97 + 16)) | M.get(&d.part_c2, Bc * (32 * 16 * 5 + 32));
+  for (int l = 0; l < 3; ++l) fail |= M.get(&d.dcat[l], N * 32);
+  fail |= M.get(&sp->pe, (size_t)md.n_params) | M.get(&sp->ge, (size_t)md.n_params);
+  if (fail) {
+    M.release();
+    delete sp;
+    IGMC_FAIL("hipMalloc failed (sort-pool workspace)");
+  }
+  HIPCHECK(hipMemset(sp->pe, 0, (size_t)md.n_params * sizeof(float)));
+  HIPCHECK(hipMemset(sp->ge, 0, (size_t)md.n_params * sizeof(float)));
+  if (igmc_sp_prepare(d)) { M.release(); delete sp; IGMC_FAIL("hipFuncSetAttribute failed"); }
+  *out = sp;
+  return 0;
+}
+
+extern "C" void igmc_sortpool_destroy(igmc_sortpool* sp) {
+  if (!sp) return;
+  sp->mem.release();
+  delete sp;
+}
+
+// [0..16): basis, root, bias, att of conv layers 0..3; then conv1.weight, conv1.bias, conv2.weight, conv2.bias,
+// lin1.weight, lin1.bias, lin2.weight, lin2.bias; [24] = number of parameters, [25] = dense width, [26] = k
+extern "C" int igmc_sortpool_layout(const igmc_sortpool* sp, int64_t* out27) {
+  if (!sp || !out27) IGMC_FAIL("null argument");
+  const ModelDev& md = sp->m->d;
+  const SpDev& d = sp->d;
+  for (int l = 0; l < 3; ++l) {
+    out27[4 * l + 0] = md.off_basis[l]; out27[4 * l + 1] = md.off_root[l];
+    out27[4 * l + 2] = md.off_bias[l];  out27[4 * l + 3] = md.off_att[l];
+  }
+  out27[12] = d.t_basis3; out27[13] = d.t_root3; out27[14] = d.t_bias3; out27[15] = d.t_att3;
+  out27[16] = d.t_c1w; out27[17] = d.t_c1w + 16 * 97; out27[18] = d.t_c2w; out27[19] = d.t_c2w + 32 * 16 * 5;
+  out27[20] = d.t_l1w; out27[21] = d.t_l1b; out27[22] = d.t_l2w; out27[23] = d.t_l2b;
+  out27[24] = d.n_params; out27[25] = d.dense; out27[26] = d.k;
+  return 0;
+}
+
+static int sp_check(igmc_sortpool* sp, const igmc_batch* b, std::string* why) {
+  if (!sp) { *why = "null sort-pool workspace"; return 1; }
+  if (check_fit(sp->m, b, why)) return 1;
+  if (b->d.slot > sp->d.nmax) { *why = "subgraph slots larger than the sort-pool workspace was created for"; return 1; }
+  if (igmc_layer_mode() == 0) { *why = "IGMC_LAYER_MODE=0 has no dense readout gradient"; return 1; }
+  return 0;
+}
+
+// reference DGCNN_RS.forward (models.py:142-167) on an extracted batch
+extern "C" int igmc_sortpool_forward(igmc_sortpool* sp, const float* d_params, const igmc_batch* b, int training,
+                                     int use_edge_flags, const uint8_t* d_lin_mask, uint64_t seed, uint64_t step,
+                                     float* d_out, void* stream) {
+  std::string why;
+  if (sp_check(sp, b, &why)) IGMC_FAIL(why);
+  if (!d_params || !d_out) IGMC_FAIL("null buffer");
+  igmc_model* m = sp->m;
+  ensure_csr(b, stream);
+  igmc_launch_sp_pack(m->d, sp->d, d_params, sp->pe, stream);
+  igmc_launch_conv_forward(m->d, b->d, sp->pe, b->last_B, training, use_edge_flags, stream);
+  igmc_launch_sp_forward(m->d, sp->d, b->d, d_params, b->last_B, training, d_lin_mask, seed, step, d_out, stream);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+// forward + MSE (+ ARR over the conv layers, reference train_eval.py:162-174) + backward: d_grad in the true layout
+extern "C" int igmc_sortpool_loss_grad(igmc_sortpool* sp, const float* d_params, const igmc_batch* b, int use_edge_flags,
+                                       const uint8_t* d_lin_mask, uint64_t seed, uint64_t step, float ARR,
+                                       float grad_scale, float arr_scale, float* d_out, float* d_grad, float* d_loss,
+                                       void* stream) {
+  std::string why;
+  if (sp_check(sp, b, &why)) IGMC_FAIL(why);
+  if (!d_params || !d_out || !d_grad) IGMC_FAIL("null buffer");
+  igmc_model* m = sp->m;
+  const int B = b->last_B;
+  ensure_csr(b, stream);
+  igmc_launch_sp_pack(m->d, sp->d, d_params, sp->pe, stream);
+  igmc_launch_conv_forward(m->d, b->d, sp->pe, B, 1, use_edge_flags, stream);
+  igmc_launch_sp_forward(m->d, sp->d, b->d, d_params, B, 1, d_lin_mask, seed, step, d_out, stream);
+  igmc_launch_sp_backward(m->d, sp->d, b->d, d_params, B, grad_scale > 0.f ? grad_scale : 1.f / (float)B, stream);
+  ModelDev md = m->d;
+  for (int l = 0; l < 3; ++l) md.dcat[l] = sp->d.dcat[l];
+  igmc_launch_conv_backward(md, b->d, sp->pe, B, use_edge_flags, ARR * arr_scale, sp->ge, stream);
+  igmc_launch_sp_wgrad(m->d, sp->d, b->d, B, sp->ge, d_grad, stream);
+  if (d_loss) igmc_launch_loss(m->d, b->d, ARR, d_loss, stream);
+  HIPCHECK(hipGetLastError());
   return 0;
 }

@@ -32,6 +32,10 @@ struct ModelAux {
 void igmc_launch_forward(const ModelDev& m, const ModelAux& ax, const BatchDev& b, const float* P, int B, int training,
                          int use_flags, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
                          float* out, void* stream);
+void igmc_launch_conv_forward(const ModelDev& m, const BatchDev& b, const float* P, int B, int training, int use_flags,
+                              void* stream);
+void igmc_launch_conv_backward(const ModelDev& m, const BatchDev& b, const float* P, int B, int use_flags, float arr_coef,
+                               float* grad, void* stream);
 void igmc_launch_backward(const ModelDev& m, const ModelAux& ax, const BatchDev& b, const float* P, int B, int use_flags,
                           const float* gout, int from_err, float grad_scale, float mult, float drop_scale,
                           float arr_coef, float* grad, void* stream);

@@ -51,6 +51,8 @@ struct ModelDev {
   int g2_graphs;               // subgraph slots of the two buffers above (0: not allocated)
   float* g2_w;                 // [6 images of (5*32+32) x 20 float2 | 1024] composed weights of the step (k_g2_compose)
   float* arr_part;    // [4] ARR regulariser per layer
+  const float* dcat[3];   // sort-pool readout (sortpool.hip): dense d loss / d h_l [Ncap,32] of layers 0..2 added to EVERY row
+                          // in the conv backward; NULL = centre-node readout (gfeat on the two target rows)
   const float* side;  // [B,S] borrowed side features or NULL
   const int64_t* ctrl;  // optional device-side step control (igmc_hip.h) or NULL
 };

@@ -490,7 +490,8 @@ __global__ __launch_bounds__(1024) void k_rgcn_layer(BatchDev b, ModelDev m, con
           if (zero_out) zero_out[(size_t)orow * 32 + n] = 0.f;
         } else {
           const int lab = b.node_label[orow];
-          if (lab < 2) v += m.gfeat[(size_t)b.node_graph[orow] * m.D + lab * 128 + (l - 1) * 32 + n];
+          if (m.dcat[l - 1]) v += m.dcat[l - 1][(size_t)orow * 32 + n];
+          else if (lab < 2) v += m.gfeat[(size_t)b.node_graph[orow] * m.D + lab * 128 + (l - 1) * 32 + n];
           const float xv = m.h[l - 1][(size_t)orow * 32 + n];
           m.dpre[l - 1][(size_t)orow * 32 + n] = v * (1.f - xv * xv);
         }
@@ -626,7 +627,8 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_layer4(BatchDev b, ModelDev
           if (zero_out) zero_out[(size_t)orow * 32 + n] = 0.f;
         } else {
           const int lab = epi_lab[h2];
-          if (lab < 2) v += m.gfeat[(size_t)epi_g[h2] * m.D + lab * 128 + (l - 1) * 32 + n];
+          if (m.dcat[l - 1]) v += m.dcat[l - 1][(size_t)orow * 32 + n];
+          else if (lab < 2) v += m.gfeat[(size_t)epi_g[h2] * m.D + lab * 128 + (l - 1) * 32 + n];
           const float xv = epi_x[h2];
           m.dpre[l - 1][(size_t)orow * 32 + n] = v * (1.f - xv * xv);
         }
@@ -786,7 +788,8 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_layer_s(BatchDev b, ModelDe
           if (zero_out) zero_out[(size_t)orow * 32 + n] = 0.f;
         } else {
           const int lab = epi_lab[h2];
-          if (lab < 2) v += m.gfeat[(size_t)epi_g[h2] * m.D + lab * 128 + (l - 1) * 32 + n];
+          if (m.dcat[l - 1]) v += m.dcat[l - 1][(size_t)orow * 32 + n];
+          else if (lab < 2) v += m.gfeat[(size_t)epi_g[h2] * m.D + lab * 128 + (l - 1) * 32 + n];
           const float xv = epi_x[h2];
           m.dpre[l - 1][(size_t)orow * 32 + n] = v * (1.f - xv * xv);
         }
@@ -2209,6 +2212,25 @@ void igmc_launch_forward(const ModelDev& m, const ModelAux& ax, const BatchDev& 
       return;
     }
   }
+  igmc_launch_conv_forward(m, b, P, B, training, use_flags, stream);
+  const int hgrid = (B + IGMC_HG - 1) / IGMC_HG;
+  const size_t fs = (size_t)IGMC_HG * m.D * sizeof(float);
+  if (m.D % 16 == 0)
+    IGMC_PLAUNCH("k_head_fwd", k_head_fwd_mfma, (B + 15) / 16, 512, 0, stream, b, m, P, training, inj_mask, seed, step,
+                 mult, out);
+  else if (fs <= 48 * 1024)
+    IGMC_PLAUNCH("k_head_fwd", (k_head_fwd<true>), hgrid, 512, fs, stream, b, m, P, training, inj_mask, seed, step,
+                 mult, out);
+  else
+    IGMC_PLAUNCH("k_head_fwd", (k_head_fwd<false>), hgrid, 512, 0, stream, b, m, P, training, inj_mask, seed, step,
+                 mult, out);
+  (void)ax;
+}
+
+// The four conv layers alone (h_0..h_3 left in HBM): the per-layer kernels, whatever the readout that follows
+// (centre-node readout of IGMC: igmc_launch_forward; sort-pool readout of DGCNN_RS: sortpool.hip)
+void igmc_launch_conv_forward(const ModelDev& m, const BatchDev& b, const float* P, int B, int training, int use_flags,
+                              void* stream) {
   const size_t l0s = (size_t)(m.R * m.L * 32 + m.L * 32 + 32) * sizeof(float) + (size_t)4 * m.R * m.L * sizeof(int);
   const int g16 = igmc_xcd_grid(m, B, 4, IGMC_GATHER_BLOCKS);   // one wave per row, 4 rows per block
   const int g64 = igmc_rows_grid(m.node_cap, 64, 512);
@@ -2250,19 +2272,8 @@ void igmc_launch_forward(const ModelDev& m, const ModelAux& ax, const BatchDev& 
                    (const float*)m.h[l - 1], P + m.off_basis[l], P + m.off_bias[l], m.h[l], zo);
     }
   }
-  const int hgrid = (B + IGMC_HG - 1) / IGMC_HG;
-  const size_t fs = (size_t)IGMC_HG * m.D * sizeof(float);
-  if (m.D % 16 == 0)
-    IGMC_PLAUNCH("k_head_fwd", k_head_fwd_mfma, (B + 15) / 16, 512, 0, stream, b, m, P, training, inj_mask, seed, step,
-                 mult, out);
-  else if (fs <= 48 * 1024)
-    IGMC_PLAUNCH("k_head_fwd", (k_head_fwd<true>), hgrid, 512, fs, stream, b, m, P, training, inj_mask, seed, step,
-                 mult, out);
-  else
-    IGMC_PLAUNCH("k_head_fwd", (k_head_fwd<false>), hgrid, 512, 0, stream, b, m, P, training, inj_mask, seed, step,
-                 mult, out);
+  // training: the products Y_l = h_{l-1} @ [basis_0 | .. | basis_3] the backward's att gradient reads
   if (training) IGMC_PLAUNCH("k_dense_y_all", k_dense_y_all, dim3(g64, 3), IGMC_BLOCK, ysz, stream, b, m, P);
-  (void)ax;
 }
 
 void igmc_launch_backward(const ModelDev& m, const ModelAux& ax, const BatchDev& b, const float* P, int B, int use_flags,
@@ -2276,6 +2287,7 @@ void igmc_launch_backward(const ModelDev& m, const ModelAux& ax, const BatchDev&
   const int l0_mfma = rows0 <= 32;       // layer-0 table gradient rides in the MFMA weight-gradient kernel
   void* s2 = stream;      // single stream: see the note at k_wgrad
   (void)ax;
+  (void)g16; (void)g64; (void)na; (void)l0_mfma;
   if (m.D % 16 == 0)
     IGMC_PLAUNCH("k_head_bwd_a", k_head_bwd_a_mfma, dim3((B + 15) / 16, (m.D / 16 + 7) / 8), 512, 0, stream, b, m, P,
                  gout, from_err, grad_scale, mult, drop_scale, m.dpre[3]);
@@ -2288,6 +2300,19 @@ void igmc_launch_backward(const ModelDev& m, const ModelAux& ax, const BatchDev&
   else
     IGMC_PLAUNCH("k_head_bwd_w", k_head_bwd_w, dim3(17, (m.D + 255) / 256), IGMC_BLOCK, 0, s2, b, m, P, gout, from_err,
                  grad_scale, mult, drop_scale, grad);
+  igmc_launch_conv_backward(m, b, P, B, use_flags, arr_coef, grad, stream);
+}
+
+// Backward of the four conv layers from dPre_3 (in m.dpre[3]) and the readout's gradient w.r.t. h_0..h_2 (gfeat on the
+// target rows, or the dense m.dcat[l]): dPre_2..0, weight-gradient partials, their reduction, gradient (+ ARR) of the conv
+// parameters into `grad` (k_finalize without Adam).
+void igmc_launch_conv_backward(const ModelDev& m, const BatchDev& b, const float* P, int B, int use_flags, float arr_coef,
+                               float* grad, void* stream) {
+  const int g16 = igmc_xcd_grid(m, B, 4, IGMC_GATHER_BLOCKS);
+  const int g64 = igmc_rows_grid(m.node_cap, 64, 512);
+  const int na = m.R * 4;
+  const int rows0 = m.R * m.L + m.L + 1;
+  const int l0_mfma = rows0 <= 32;
   const int gt = igmc_xcd_grid(m, B, 16, 2048);
   const size_t bsm = (size_t)(16 * IGMC_TP + 2048 + m.R * 4 + 64 * m.R * 4) * sizeof(float);
   const int mode = igmc_layer_mode();

@@ -263,3 +263,40 @@ def profile_fetch(lib, cap=64):
     calls = (C.c_int * cap)()
     n = lib.igmc_profile_fetch(C.cast(names, C.c_void_p), C.cast(ms, C.c_void_p), C.cast(calls, C.c_void_p), cap)
     return [(names[i].value.decode(), float(ms[i]), int(calls[i])) for i in range(max(n, 0))]
+
+
+class SortPoolWorkspace(object):
+    """Sort-pool readout (DGCNN_RS, reference ``models.py:63-167``) on top of a :class:`ModelWorkspace`'s conv kernels."""
+
+    KEYS = ['convs.%d.%s' % (l, k) for l in range(4) for k in ('basis', 'root', 'bias', 'att')] + [
+        'conv1d_params1.weight', 'conv1d_params1.bias', 'conv1d_params2.weight', 'conv1d_params2.bias',
+        'lin1.weight', 'lin1.bias', 'lin2.weight', 'lin2.bias']
+
+    def __init__(self, ws, k, max_nodes_per_graph):
+        self.ws, self.lib = ws, ws.lib
+        h = C.c_void_p()
+        self.lib.call('igmc_sortpool_create', ws.handle, int(k), int(max_nodes_per_graph), C.byref(h))
+        self.handle = h
+        lay = (C.c_int64 * 27)()
+        self.lib.call('igmc_sortpool_layout', h, C.cast(lay, C.c_void_p))
+        self.offsets = dict(zip(self.KEYS, [int(x) for x in lay[:24]]))
+        self.n_params, self.dense, self.k = int(lay[24]), int(lay[25]), int(lay[26])
+
+    def __del__(self):
+        try:
+            self.lib.cdll.igmc_sortpool_destroy(self.handle)
+        except Exception:
+            pass
+
+    def forward(self, params, batch, out, training=False, use_edge_flags=False, lin_mask=None, seed=0, step=0, stream=None):
+        self.lib.call('igmc_sortpool_forward', self.handle, _p(params), batch.handle, int(bool(training)),
+                      int(bool(use_edge_flags)), _p(lin_mask), int(seed) & (2 ** 64 - 1), int(step) & (2 ** 64 - 1),
+                      _p(out), _p(stream))
+
+    def loss_grad(self, params, batch, out, grad, loss, use_edge_flags=False, lin_mask=None, seed=0, step=0, ARR=0.0,
+                  grad_scale=None, arr_scale=1.0, stream=None):
+        if grad_scale is None:
+            grad_scale = 1.0 / batch.B
+        self.lib.call('igmc_sortpool_loss_grad', self.handle, _p(params), batch.handle, int(bool(use_edge_flags)),
+                      _p(lin_mask), int(seed) & (2 ** 64 - 1), int(step) & (2 ** 64 - 1), float(ARR), float(grad_scale),
+                      float(arr_scale), _p(out), _p(grad), _p(loss), _p(stream))

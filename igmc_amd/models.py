@@ -222,13 +222,171 @@ class _NoCtx(object):
     pass
 
 
+class DGCNN_RS(IGMC):
+    """DGCNN with R-GCN convolutions (reference ``models.py:123-167`` on the ``DGCNN`` base ``:63-120``; the variant the
+    reference keeps behind ``if False`` at ``Main.py:364-380``): four R-GCN layers with ``latent_dim = [32, 32, 32, 1]``,
+    ``global_sort_pool(k)`` over the 97 concatenated channels, ``Conv1d(1, 16, 97, 97)`` / ``MaxPool1d(2, 2)`` /
+    ``Conv1d(16, 32, 5, 1)``, ``lin1`` / dropout / ``lin2``.
+
+    Same constructor arguments, attributes and ``state_dict`` keys / shapes as the reference
+    (``convs.{l}.{basis,att,root,bias}``, ``conv1d_params{1,2}.{weight,bias}``, ``lin{1,2}.{weight,bias}``).  The conv
+    layers are the per-layer HIP kernels of IGMC (the 32 -> 1 layer as a zero-padded 32 -> 32 one), the readout and its
+    backward are ``igmc_amd/csrc/sortpool.hip``.  Training goes through ``train_eval`` with ``FlatAdam``
+    (``fused_loss_grad``); the differentiable-forward route of ``IGMC`` is not provided for this family."""
+
+    def __init__(self, dataset, gconv=RGCNConv, latent_dim=[32, 32, 32, 1], k=30, num_relations=5, num_bases=2,
+                 regression=False, adj_dropout=0.2, force_undirected=False, seed=0):
+        nn.Module.__init__(self)
+        if list(latent_dim) != [32, 32, 32, 1]:
+            raise NotImplementedError('the gfx950 kernels are built for latent_dim=[32,32,32,1] (reference Main.py:368)')
+        if num_bases != 4:
+            raise NotImplementedError('the gfx950 kernels are built for num_bases=4 (reference Main.py:371)')
+        if not regression:
+            raise NotImplementedError('only regression=True (what reference Main.py:372 uses) is accelerated')
+        if gconv is not RGCNConv and getattr(gconv, '__name__', '') != 'RGCNConv':
+            raise NotImplementedError('DGCNN_RS uses RGCNConv')
+        _lib.load()
+        self.regression = regression
+        self.adj_dropout, self.force_undirected = adj_dropout, force_undirected
+        self.multiply_by, self.side_features, self.n_side_features = 1, False, 0
+        self.num_relations, self.num_bases = int(num_relations), int(num_bases)
+        self.num_features = int(dataset.num_features)
+        self.seed = int(seed)
+        self._step = 0
+        if k < 1:       # percentile of the subgraph sizes -> number of pooled nodes (reference models.py:70-73)
+            node_nums = sorted(self._subgraph_sizes(dataset))
+            k = node_nums[int(math.ceil(k * len(node_nums))) - 1]
+            k = max(10, k)
+        self.k = int(k)
+        print('k used in sortpooling is:', self.k)
+        self.convs = nn.ModuleList()
+        self.convs.append(RGCNConv(self.num_features, latent_dim[0], num_relations, num_bases))
+        for i in range(0, len(latent_dim) - 1):
+            self.convs.append(RGCNConv(latent_dim[i], latent_dim[i + 1], num_relations, num_bases))
+        self.total_latent_dim = sum(latent_dim)
+        self.conv1d_params1 = nn.Conv1d(1, 16, self.total_latent_dim, self.total_latent_dim)
+        self.maxpool1d = nn.MaxPool1d(2, 2)
+        self.conv1d_params2 = nn.Conv1d(16, 32, 5, 1)
+        dense_dim = int((self.k - 2) / 2 + 1)
+        self.dense_dim = (dense_dim - 5 + 1) * 32
+        if self.dense_dim < 32:
+            raise ValueError('k = %d leaves nothing after Conv1d(16, 32, 5)' % self.k)
+        self.lin1 = nn.Linear(self.dense_dim, 128)
+        self.lin2 = nn.Linear(128, 1)
+        self._ws, self._sp = {}, {}
+        self._flat = None
+        self._flat_grad = None
+        self._flatten()
+
+    @staticmethod
+    def _subgraph_sizes(dataset, max_samples=1000):
+        """``[g.num_nodes for g in dataset]`` of the reference, on an evenly spaced sample of at most ``max_samples``
+        links (the reference walks the whole dataset: minutes of extraction for a number that is a percentile)."""
+        n = len(dataset)
+        step = max(1, n // max_samples)
+        return [int(dataset[i].num_nodes) for i in range(0, n, step)]
+
+    def _layout(self):
+        out, off = [], 0
+        for l, conv in enumerate(self.convs):
+            for key in ('basis', 'root', 'bias', 'att'):
+                p = getattr(conv, key)
+                out.append(('convs.%d.%s' % (l, key), off, p.numel(), tuple(p.shape)))
+                off += p.numel()
+        for mod, name in ((self.conv1d_params1, 'conv1d_params1'), (self.conv1d_params2, 'conv1d_params2'),
+                          (self.lin1, 'lin1'), (self.lin2, 'lin2')):
+            for key in ('weight', 'bias'):
+                p = getattr(mod, key)
+                out.append(('%s.%s' % (name, key), off, p.numel(), tuple(p.shape)))
+                off += p.numel()
+        return out, off
+
+    def reset_parameters(self):
+        """reference ``models.py:87-93``"""
+        for conv in self.convs:
+            conv.reset_parameters()
+        self.conv1d_params1.reset_parameters()
+        self.conv1d_params2.reset_parameters()
+        self.lin1.reset_parameters()
+        self.lin2.reset_parameters()
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._sp = {}
+        return out
+
+    def _sortpool(self, data):
+        """(conv workspace, sort-pool workspace) for this batch arena."""
+        if self._flat.device.type != 'cuda':
+            raise RuntimeError('igmc_amd.DGCNN_RS runs on an MI355X only: call model.to("cuda") (there is no CPU path)')
+        arena = data.arena
+        key = (arena.node_capacity, arena.edge_capacity, arena.max_graphs, arena.num_labels)
+        sp = self._sp.get(key)
+        if sp is None:
+            if arena.num_labels != self.num_features:
+                raise ValueError('dataset hop (num_features=%d) does not match the model (%d)' % (
+                    arena.num_labels, self.num_features))
+            ws = engine.ModelWorkspace(_lib.load(), self._flat.device.index or 0, self.num_relations, self.num_bases,
+                                       self.num_features, 0, arena.node_capacity, arena.edge_capacity, arena.max_graphs)
+            sp = engine.SortPoolWorkspace(ws, self.k, max(2, arena.node_capacity // arena.max_graphs))
+            mine = {k: o for (k, o, n, s) in self._views}
+            if mine != sp.offsets or sp.n_params != self._flat.numel() or sp.dense != self.dense_dim:
+                raise AssertionError('flat parameter layout differs between Python and the C ABI')
+            self._ws[key], self._sp[key] = ws, sp
+        return sp
+
+    def _workspace(self, data):
+        return self._sortpool(data).ws
+
+    def forward_into(self, data, out, training=False, stream=None):
+        """``out[:B]`` <- model(batch) (what ``train_eval.eval_loss`` calls; no host synchronisation)."""
+        sp = self._sortpool(data)
+        st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        use_flags = bool(training and self.adj_dropout > 0)
+        if training:
+            self._step += 1
+            if use_flags:
+                data.arena.edge_dropout(self.adj_dropout, self.force_undirected, self.seed, self._step, st)
+        sp.forward(self._flat.data_ptr(), data.arena, out.data_ptr(), training=training, use_edge_flags=use_flags,
+                   seed=self.seed, step=self._step, stream=st)
+
+    def forward(self, data):
+        if not isinstance(data, DeviceBatch):
+            raise TypeError('igmc_amd.DGCNN_RS consumes device-resident batches (igmc_amd.train_eval.DataLoader); '
+                            'got %s' % type(data).__name__)
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError('DGCNN_RS trains through train_eval with FlatAdam (fused_loss_grad); wrap '
+                                      'inference in torch.no_grad()')
+        out = torch.empty(data.num_graphs, dtype=torch.float32, device=self._flat.device)
+        self.forward_into(data, out, training=bool(self.training))
+        return out
+
+    def fused_loss_grad(self, data, ARR=0.0, grad_scale=None, arr_scale=1.0, lin_mask=None, loss=None, out=None):
+        """One step's loss and gradient (reference ``train_eval.py:158-175``): MSE + ARR over ``self.convs``; the
+        gradient lands in ``flat_grad()``.  Returns the 2-float device tensor [loss, sum of squared errors]."""
+        sp = self._sortpool(data)
+        st = torch.cuda.current_stream().cuda_stream
+        dev = self._flat.device
+        loss = loss if loss is not None else torch.zeros(2, dtype=torch.float32, device=dev)
+        out = out if out is not None else torch.empty(data.num_graphs, dtype=torch.float32, device=dev)
+        use_flags = self.adj_dropout > 0
+        self._step += 1
+        if use_flags:
+            data.arena.edge_dropout(self.adj_dropout, self.force_undirected, self.seed, self._step, st)
+        sp.loss_grad(self._flat.data_ptr(), data.arena, out.data_ptr(), self.flat_grad().data_ptr(), loss.data_ptr(),
+                     use_edge_flags=use_flags, lin_mask=lin_mask, seed=self.seed, step=self._step, ARR=float(ARR),
+                     grad_scale=grad_scale, arr_scale=arr_scale, stream=st)
+        return loss
+
+
 class GNN(IGMC):
     """Placeholder for the reference's GCN baseline (``models.py:12-60``; dead code behind ``if False`` at
     ``Main.py:364``).  Not part of the accelerated path."""
 
     def __init__(self, *a, **k):
-        raise NotImplementedError('GNN/DGCNN/DGCNN_RS are dead code in the reference (Main.py:364) and out of scope')
+        raise NotImplementedError('GNN / DGCNN (GCNConv message passing) are dead, broken code in the reference '
+                                  '(Main.py:364; edge_type used before assignment, models.py:40,98); the R-GCN variant '
+                                  'is igmc_amd.models.DGCNN_RS')
 
 
 DGCNN = GNN
-DGCNN_RS = GNN

@@ -244,6 +244,28 @@ int igmc_model_check(igmc_model* m, void* stream);
  * reads the dense blocks only (see igmc_batch_set_lean); 0 otherwise.  No reference counterpart. */
 int igmc_model_dense_path(const igmc_model* m, const igmc_batch* b, int B);
 
+/* ---- Sort-pool readout family: DGCNN_RS (reference models.py:123-167 on the DGCNN base :63-120; Main.py:364-380).
+ * Four R-GCN layers with latent_dim [32, 32, 32, 1] (the conv kernels of igmc_model), concat (97 channels),
+ * global_sort_pool(k) (PyG 1.4.2: nodes of a graph by the last channel, descending; first k rows, zero padding),
+ * Conv1d(1,16,97,97) + ReLU, MaxPool1d(2,2), Conv1d(16,32,5,1) + ReLU, lin1 (dense -> 128) + ReLU, dropout(0.5), lin2.
+ * Parameters live in ONE flat buffer in the "true" layout reported by igmc_sortpool_layout (offsets of
+ * convs.{0..3}.{basis,root,bias,att}, conv1d_params1.{weight,bias}, conv1d_params2.{weight,bias}, lin1.{weight,bias},
+ * lin2.{weight,bias}; [24] parameter count, [25] dense width 32 * (k/2 - 4), [26] k).  `m` supplies the conv workspace
+ * (create it with n_side = 0); max_nodes_per_graph >= the arena's slot size (users + items of one subgraph). */
+typedef struct igmc_sortpool igmc_sortpool;
+int igmc_sortpool_create(igmc_model* m, int k, int max_nodes_per_graph, igmc_sortpool** out);
+void igmc_sortpool_destroy(igmc_sortpool* sp);
+int igmc_sortpool_layout(const igmc_sortpool* sp, int64_t* out27);
+/* replaces DGCNN_RS.forward (models.py:142-167); training != 0: dropout active, activations kept for the backward */
+int igmc_sortpool_forward(igmc_sortpool* sp, const float* d_params, const igmc_batch* b, int training,
+                          int use_edge_flags, const uint8_t* d_lin_mask, uint64_t seed, uint64_t step,
+                          float* d_out, void* stream);
+/* replaces out = model(data); loss = mse (+ ARR over model.convs, train_eval.py:162-174); loss.backward():
+ * d_grad (true layout) is overwritten, d_loss[0] = loss, d_loss[1] = sum of squared errors. */
+int igmc_sortpool_loss_grad(igmc_sortpool* sp, const float* d_params, const igmc_batch* b, int use_edge_flags,
+                            const uint8_t* d_lin_mask, uint64_t seed, uint64_t step, float ARR, float grad_scale,
+                            float arr_scale, float* d_out, float* d_grad, float* d_loss, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

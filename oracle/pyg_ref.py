@@ -204,6 +204,68 @@ class IGMCRef(torch.nn.Module):
         return x[:, 0] * self.multiply_by
 
 
+def global_sort_pool(x, batch, k):
+    """PyG 1.4.2 ``torch_geometric.nn.glob.sort.global_sort_pool``: per graph, nodes sorted by the LAST channel
+    (descending), the first ``k`` rows kept, graphs with fewer nodes padded with zero rows; returns ``[B, k * D]``.
+    (The original pads with ``x.min() - 1``, sorts, and zeroes every element equal to the fill value afterwards --
+    the same thing; ties are taken in node order here: ``stable=True``.)"""
+    B = int(batch.max()) + 1
+    D = x.shape[1]
+    out = x.new_zeros(B, k, D)
+    for g in range(B):
+        rows = x[batch == g]
+        order = torch.sort(rows[:, -1], descending=True, stable=True)[1][:k]
+        out[g, :len(order)] = rows[order]
+    return out.view(B, k * D)
+
+
+class DGCNNRSRef(torch.nn.Module):
+    """``models.DGCNN_RS`` (ref ``models.py:123-167`` on the ``DGCNN`` base ``:63-120``): R-GCN layers with
+    latent_dim [32, 32, 32, 1], sort-pool readout, Conv1d / MaxPool1d / Conv1d, 2-layer MLP."""
+
+    def __init__(self, num_features, latent_dim=(32, 32, 32, 1), k=30, num_relations=5, num_bases=4, adj_dropout=0.2,
+                 force_undirected=False, fast=False):
+        super().__init__()
+        self.adj_dropout, self.force_undirected, self.fast = adj_dropout, force_undirected, fast
+        self.k = int(k)
+        self.convs = torch.nn.ModuleList()
+        dims = [num_features] + list(latent_dim)
+        for i in range(len(latent_dim)):
+            self.convs.append(RGCNConvRef(dims[i], dims[i + 1], num_relations, num_bases))
+        total = sum(latent_dim)
+        self.conv1d_params1 = torch.nn.Conv1d(1, 16, total, total)
+        self.maxpool1d = torch.nn.MaxPool1d(2, 2)
+        self.conv1d_params2 = torch.nn.Conv1d(16, 32, 5, 1)
+        dense_dim = int((self.k - 2) / 2 + 1)
+        self.dense_dim = (dense_dim - 5 + 1) * 32
+        self.lin1 = torch.nn.Linear(self.dense_dim, 128)
+        self.lin2 = torch.nn.Linear(128, 1)
+
+    def forward(self, data, edge_mask=None, lin_mask=None):
+        x, edge_index, edge_type, batch = data.x, data.edge_index, data.edge_type, data.batch
+        if self.adj_dropout > 0:
+            edge_index, edge_type = dropout_adj(
+                edge_index, edge_type, p=self.adj_dropout, force_undirected=self.force_undirected,
+                num_nodes=len(x), training=self.training, mask=edge_mask)
+        states = []
+        for conv in self.convs:
+            x = torch.tanh(conv(x, edge_index, edge_type, fast=self.fast))
+            states.append(x)
+        x = global_sort_pool(torch.cat(states, 1), batch, self.k).unsqueeze(1)
+        x = F.relu(self.conv1d_params1(x))
+        x = self.maxpool1d(x)
+        x = F.relu(self.conv1d_params2(x))
+        x = x.view(len(x), -1)
+        x = F.relu(self.lin1(x))
+        if self.training:
+            if lin_mask is not None:
+                x = x * lin_mask.to(x.dtype) * 2.0
+            else:
+                x = F.dropout(x, p=0.5, training=True)
+        x = self.lin2(x)
+        return x[:, 0]
+
+
 def arr_loss(model):
     """Adjacent-rating regulariser, ref ``train_eval.py:167-174`` (without the ARR factor)."""
     total = 0

@@ -454,3 +454,73 @@ def run_fused_train_trajectory(be, case, R, steps=5, batch=None, use_dropout=Fal
     assert bad.mean() < 2e-3, 'too many parameters off the oracle trajectory: %g' % bad.mean()
     assert diff.max() <= 2.0 * lr * steps + 1e-6, diff.max()
     return dict(losses=losses, frac_off=float(bad.mean()), max_diff=float(diff.max()), total=float(be.host(total)[0]))
+
+
+# ====================================================================== DGCNN_RS (sort-pool readout family)
+def run_dgcnn_parity(be, case, R, k=12, use_dropout=True, ARR=0.001, seed=3, rtol=2e-4, atol=2e-5):
+    """``igmc_sortpool_forward`` / ``igmc_sortpool_loss_grad`` (conv kernels of model.hip + sortpool.hip) on one
+    extracted batch vs ``pyg_ref.DGCNNRSRef`` (reference models.py:123-167 restated) on IDENTICAL subgraphs, weights and
+    dropout masks: eval outputs, training outputs, loss and every gradient."""
+    import torch
+    from oracle import pyg_ref
+    g, b, d = extract_case(be, case, replay=False)
+    L = 2 * case['h'] + 2
+    B = d['B']
+    ws = engine.ModelWorkspace(be.lib, be.device, R, 4, L, 0, b.node_capacity, b.edge_capacity, b.max_graphs)
+    sp = engine.SortPoolWorkspace(ws, k, max(2, b.node_capacity // b.max_graphs))
+    torch.manual_seed(seed)
+    ref = pyg_ref.DGCNNRSRef(L, (32, 32, 32, 1), k, R, 4, adj_dropout=0.2 if use_dropout else 0.0, fast=True)
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    sd = {key: v.detach().cpu().numpy().astype(np.float32) for key, v in ref.state_dict().items()}
+    flat = np.zeros(sp.n_params, np.float32)
+    for key, off in sp.offsets.items():
+        a = sd[key].reshape(-1)
+        flat[off:off + a.size] = a
+    assert sum(v.size for v in sd.values()) == sp.n_params
+    P = be.dev(flat)
+    out = be.dev(np.zeros(B, np.float32))
+    pyg = batch_to_pyg(d, L)
+    # ---- evaluation forward
+    sp.forward(be.ptr(P), b, be.ptr(out), training=False)
+    ref.eval()
+    with torch.no_grad():
+        ro = ref(pyg)
+    np.testing.assert_allclose(be.host(out), ro.numpy(), rtol=rtol, atol=atol)
+    # ---- training step with injected masks
+    rng = np.random.default_rng(seed)
+    lin_mask = rng.random((B, 128)) < 0.5
+    edge_mask = None
+    if use_dropout:
+        keep = rng.random(d['E']) >= 0.2
+        rev = reverse_positions(d)
+        b.set_edge_flags((keep.astype(np.uint8) | (keep[rev].astype(np.uint8) << 1)))
+        edge_mask = torch.from_numpy(keep)
+    lm = be.dev(lin_mask.astype(np.uint8).reshape(-1))
+    grad = be.dev(np.zeros(sp.n_params, np.float32))
+    loss = be.dev(np.zeros(2, np.float32))
+    sp.loss_grad(be.ptr(P), b, be.ptr(out), be.ptr(grad), be.ptr(loss), use_edge_flags=use_dropout, lin_mask=be.ptr(lm), ARR=ARR)
+    ref.train()
+    ref.zero_grad()
+    to = ref(pyg, edge_mask=edge_mask, lin_mask=torch.from_numpy(lin_mask))
+    rl = F_mse(to, pyg.y) + ARR * pyg_ref.arr_loss(ref)
+    rl.backward()
+    np.testing.assert_allclose(be.host(out), to.detach().numpy(), rtol=rtol, atol=atol)
+    assert be.host(loss)[0] == pytest_approx(float(rl.detach()), 2e-4)
+    gflat = be.host(grad)
+    worst = 0.0
+    for key, p in ref.named_parameters():
+        rgn = p.grad.detach().numpy()
+        off = sp.offsets[key]
+        got = gflat[off:off + rgn.size].reshape(rgn.shape)
+        scale = max(np.abs(rgn).max(), 1e-6)
+        err = np.abs(got - rgn).max() / scale
+        worst = max(worst, err)
+        assert err < 2e-3, '%s: max rel-to-peak grad error %.3e' % (key, err)
+    return dict(worst_grad_err=worst, eval_out=be.host(out), loss=be.host(loss))
+
+
+def F_mse(a, b):
+    import torch
+    return torch.nn.functional.mse_loss(a, b.view(-1).to(a.dtype))
