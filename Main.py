@@ -22,10 +22,17 @@ import random
 import sys
 from shutil import rmtree
 
-import numpy as np
-import torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from igmc_amd.hostcpu import limit_host_threads  # noqa: E402
 
-from igmc_amd import parallel
+limit_host_threads()          # before numpy / torch: pools sized for the container's CPU quota, not the visible CPUs
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+torch.set_num_threads(int(os.environ['OMP_NUM_THREADS']))
+
+from igmc_amd import parallel  # noqa: E402
 from igmc_amd.models import IGMC
 from igmc_amd.preprocessing import create_trainvaltest_split, load_data_monti, load_official_trainvaltest_split
 from igmc_amd.train_eval import test_once, train_multiple_epochs

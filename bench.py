@@ -38,12 +38,22 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+from igmc_amd.hostcpu import cpu_budget as _cpu_budget, limit_host_threads  # noqa: E402  (no numpy / torch inside)
+
+# The GPU process needs ONE busy host thread; OpenMP / BLAS pools sized by the 256 VISIBLE CPUs exhaust the container's
+# CPU quota (16 here) and get the whole process throttled for tens of ms inside the timed region (igmc_amd/hostcpu.py).
+if '--cpu-baseline-worker' not in sys.argv:
+    limit_host_threads()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+if '--cpu-baseline-worker' not in sys.argv:
+    torch.set_num_threads(int(os.environ['OMP_NUM_THREADS']))
 
 from igmc_amd import _lib, engine, parallel, preprocessing  # noqa: E402
 from igmc_amd.models import IGMC  # noqa: E402
@@ -117,7 +127,7 @@ def cpu_baseline_worker(path):
     mode, adj_dropout, budget_s = str(z['mode']), float(z['adj_dropout']), float(z['budget_s'])
     cv = z['class_values']
     _W.update(A=A, Acsc=A.tocsc(), tr_u=z['tr_u'], tr_v=z['tr_v'], tr_l=z['tr_l'], cv=cv, mnph=int(z['mnph']))
-    ncpu = os.cpu_count() or 1
+    ncpu = _cpu_budget()          # the CPUs this container is GRANTED (cgroup quota), not the 256 it can see
     n_workers = max(1, min(ncpu // 2, 32)) if mode == 'dynamic' else 0
     pool = mp.get_context('fork').Pool(n_workers, initializer=_worker_init) if n_workers else None
     torch.manual_seed(1)
@@ -159,7 +169,8 @@ def cpu_baseline_worker(path):
            if mode == 'static' else
            'dynamic: extraction in %d worker processes (oracle/extract_ref.py) feeding the training process' % n_workers)
     rec = dict(value=steps * BATCH / el, unit='subgraphs/s', cores=(threads + n_workers), kind='port',
-               cpu=cpu_model(), host_cores=ncpu, torch_threads=threads, extraction_workers=n_workers,
+               cpu=cpu_model(), host_cores=ncpu, visible_cpus=os.cpu_count(), torch_threads=threads,
+               extraction_workers=n_workers,
                sample='%d train steps of batch %d in %.1f s; %s; PyG-1.4.2-formulation fwd/bwd + Adam '
                       '(oracle/pyg_ref.py, torch threads=%d)' % (steps, BATCH, el, how, threads))
     print('CPU_BASELINE_JSON ' + json.dumps(rec))
@@ -176,6 +187,8 @@ def cpu_baseline(A, tr_u, tr_v, tr_l, class_values, mnph, adj_dropout, mode, bud
                  class_values=np.asarray(class_values, dtype=np.float64), mnph=mnph, adj_dropout=adj_dropout, mode=mode,
                  budget_s=budget_s)
         env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+        for k in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'NUMEXPR_NUM_THREADS'):
+            env.pop(k, None)          # (the GPU process limits its own pools; the baseline sizes itself)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', path], env=env,
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=budget_s * 8 + 120)
     for line in r.stdout.decode().splitlines():
@@ -293,11 +306,17 @@ def main():
     captured = sg.prepare(steps_hint=None if captured else args.steps) or captured   # every graph exists before t0
     parallel.barrier()
     torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
     t0 = time.perf_counter()
     run(args.steps)
+    t_enq = time.perf_counter() - t0                   # host time to enqueue the K steps (diagnostic)
+    ev1.record()
     parallel.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1)                     # the same K steps by the GPU's clock (diagnostic: a host stall
+                                                       # inside the timed region shows up as dt >> gpu_ms)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -473,6 +492,7 @@ def main():
                        'graphs_captured_before_timing': bool(captured)},
             'roofline': roofline, 'cpu_baseline': cpu, 'rmse': rmse, 'extraction': extraction,
             'dp_structure_us': dp_structure['dp_structure_us'] if dp_structure else None, 'dp_structure': dp_structure,
+            'timing_check': {'wall_ms': dt * 1e3, 'gpu_event_ms': gpu_ms, 'host_enqueue_ms': t_enq * 1e3},
             'final_loss': final_loss, 'kernels_us': {k: round(v['us'], 2) for k, v in kernels.items()},
             'kernel_src_sha': kernel_source_sha(),
         }

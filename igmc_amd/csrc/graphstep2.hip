@@ -422,7 +422,7 @@ struct G2Args {
   float mult, grad_scale;
   float* out;
   unsigned long long* ts;
-  int timing, cs, stride;
+  int timing, cs, stride, self_seq;
   G2Layout lay2;
 };
 
@@ -496,7 +496,8 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
     for (int q = 0; q < 16; ++q) rmv[q] = ((tid & 31) < ldw && (tid >> 5) + 8 * q < a.cap_u) ? rm[8 * q * ldw] : 0u;
   };
   int labv_raw = 0;
-  ((float4*)sT0)[tid] = ((const float4*)(a.g2_w + 6 * G2_WIMG))[tid];
+  // layer-0 table: requested here, written to LDS at the end of the set-up (no wait for it in the prologue)
+  const float4 t0v = ((const float4*)(a.g2_w + 6 * G2_WIMG))[tid];
   // partial-table slot of this workgroup: member c of subgraph g -> g + c * stride (what k_tail_ts sums)
   const int tslot = (cs > 1) ? g_first + cm * a.stride : (int)blockIdx.x;
   f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};        // layer-0 table gradient tile (code half, feature half) of this wave
@@ -628,6 +629,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
         }
       }
     }
+    if (first_graph) ((float4*)sT0)[tid] = t0v;
     __syncthreads();                    // RM is dead from here on (its bytes are the backward's tiles)
     G2_STAMP(4);
 
@@ -1081,10 +1083,12 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
       if (c < RL + L + 1) part0[c * 32 + wn * 16 + li] = acc0[rr];
     }
   }
+  // The launch sequence number (exchange tags) advances once per launch, after every workgroup has read it: a training
+  // launch leaves that to the next kernel on the stream (k_tail_ts, one store) unless a.self_seq says otherwise; else the
+  // workgroup that finishes LAST does it here (an atomic round trip at the end of every workgroup).
 #ifndef IGMC_HIPEMU
-  if (tid == 0) {
+  if (tid == 0 && a.self_seq) {
     const unsigned long long t1 = a.ts ? (unsigned long long)wall_clock64() : 0ull;
-    // the workgroup that finishes the launch LAST advances the sequence number: every workgroup has read it by then
     if (__hip_atomic_fetch_add(a.gs_bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
       __hip_atomic_store(a.gs_bar, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(a.gs_bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1097,7 +1101,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
     }
   }
 #else
-  if (tid == 0) {
+  if (tid == 0 && a.self_seq) {
     if (a.gs_bar[0]++ == (int)gridDim.x - 1) {
       a.gs_bar[0] = 0;
       a.gs_bar[1] += 1;
@@ -1249,9 +1253,10 @@ int igmc_g2_eligible(const ModelDev& m, const BatchDev& b, int B, G2Layout* lay,
   return 1;
 }
 
-void igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* P, int B, int training, int use_flags,
-                             const G2Layout& lay, int cs, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
-                             float grad_scale, float* out, void* stream) {
+// returns 1 when the launch leaves the advance of the launch sequence number to the caller's next kernel (k_tail_ts)
+int igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* P, int B, int training, int use_flags,
+                            const G2Layout& lay, int cs, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
+                            float grad_scale, float* out, void* stream) {
   G2Args a;
   memset(&a, 0, sizeof(a));
   a.n_users = b.n_users; a.n_items = b.n_items; a.B = B; a.s_lab = b.s_lab; a.relm = b.relm; a.y = b.y;
@@ -1275,6 +1280,8 @@ void igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* 
   a.lay2 = lay;
   a.timing = getenv("IGMC_GS_TIMING") ? 1 : 0;
   a.ts = (g_igmc_prof_on == 2) ? m.gs_ts : nullptr;
+  // (the device-side launch clock rides in the last workgroup's counter; evaluation launches have no following kernel)
+  a.self_seq = (!training || a.ts || getenv("IGMC_G2_SELF_SEQ")) ? 1 : 0;
   a.cs = cs;
   a.stride = (cs > 1) ? ((B + 7) & ~7) : 1;
   const int grid = (cs > 1) ? cs * B : igmc_gs_grid(B);
@@ -1294,6 +1301,7 @@ void igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* 
     if (use_flags) IGMC_PLAUNCH("k_graph_fwd", (k_graph_step2<true, false>), grid, G2_THREADS, sm, stream, a);
     else IGMC_PLAUNCH("k_graph_fwd", (k_graph_step2<false, false>), grid, G2_THREADS, sm, stream, a);
   }
+  return a.self_seq ? 0 : 1;
 }
 
 int igmc_g2_prepare() {

@@ -91,7 +91,7 @@ void igmc_launch_graph_step(const ModelDev& m, const BatchDev& b, const float* P
 int igmc_gs_prepare();
 // graphstep2.hip: the same step with the relational aggregation on the matrix cores (dense induced block)
 int igmc_g2_eligible(const ModelDev& m, const BatchDev& b, int B, G2Layout* lay, int* cs_out);
-void igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* P, int B, int training, int use_flags,
+int igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* P, int B, int training, int use_flags,
                              const G2Layout& lay, int cs, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
                              float grad_scale, float* out, void* stream);
 int igmc_g2_prepare();

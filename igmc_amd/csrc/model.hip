@@ -1670,8 +1670,9 @@ __device__ __forceinline__ void fin_stash_body(const ModelDev& m, const float* _
 __global__ __launch_bounds__(IGMC_BLOCK) void k_tail_ts(BatchDev b, ModelDev m, const float* __restrict__ P,
                                                           float grad_scale, float mult, float drop_scale,
                                                           float* __restrict__ grad, int nlin, int nparts, int stride,
-                                                          int B, int nstash, const int64_t* ctrl) {
+                                                          int B, int nstash, const int64_t* ctrl, int bump_seq) {
   const int nred = (int)gridDim.x - nlin - nstash;
+  if (bump_seq && blockIdx.x == 0 && threadIdx.x == 0) m.gs_bar[1] += 1;      // (every workgroup of k_graph_step2 is done)
   if ((int)blockIdx.x < nlin)
     head_bwd_w_body(b, m, P, nullptr, 1, grad_scale, mult, drop_scale, grad, blockIdx.x & 7, blockIdx.x >> 3);
   else if ((int)blockIdx.x < nlin + nred)
@@ -2398,14 +2399,15 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
     const int cs = igmc_gs_cluster(B);
     const int gstride = (cs > 1) ? ((B + 7) & ~7) : IGMC_TS_BLOCKS;
     const int gg = (cs > 1) ? cs * gstride : igmc_gs_grid(B);
-    if (v2) igmc_launch_graph_step2(m, b, P, B, 1, use_flags, lay2, cs2, inj_mask, seed, step, mult, grad_scale, out, stream);
+    int bump_seq = 0;       // 1: k_tail_ts advances the launch sequence number of the subgraph kernel's exchange tags
+    if (v2) bump_seq = igmc_launch_graph_step2(m, b, P, B, 1, use_flags, lay2, cs2, inj_mask, seed, step, mult, grad_scale, out, stream);
     else igmc_launch_graph_step(m, b, P, B, 1, use_flags, lay, inj_mask, seed, step, mult, grad_scale, out, stream);
     // IGMC_FIN_MODE=0: the hand-off version of the gradient / Adam tail (k_finalize) instead of k_finalize_ts
     const char* fe = getenv("IGMC_FIN_MODE");        // read on every call: tests switch it per case
     const int fts = (fe ? atoi(fe) : 1) && m.fin_stash && m.datt_part && m.R <= 8;
     IGMC_PLAUNCH("k_tail_ts", k_tail_ts, 8 * ny + (4 * m.ts_stride + 63) / 64 + (fts ? 4 : 0), IGMC_BLOCK, 0, stream, b, m,
                  (const float*)P, grad_scale, mult, 2.f, grad, 8 * ny, gg, gstride, B, fts ? 4 : 0,
-                 (const int64_t*)(adam ? at.ctrl : nullptr));
+                 (const int64_t*)(adam ? at.ctrl : nullptr), bump_seq);
     if (adam) {
       at.enabled = 1;
       at.b = b;

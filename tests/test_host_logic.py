@@ -238,3 +238,18 @@ def test_data_parallel_ragged_last_batch_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert 'rank %d ragged ok' % r in o
+
+
+def test_host_cpu_budget_and_thread_limit(tmp_path):
+    """igmc_amd.hostcpu: the CPU budget honours a cgroup quota (here: whatever this container has), the thread limit is set
+    before numpy / torch are imported and never overrides a value the user exported."""
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "from igmc_amd import hostcpu\n"
+            "assert 'torch' not in sys.modules and 'numpy' not in sys.modules\n"
+            "n = hostcpu.cpu_budget(); assert 1 <= n <= (os.cpu_count() or 1)\n"
+            "t = hostcpu.limit_host_threads(); assert 1 <= t <= 4 and os.environ['OMP_NUM_THREADS'] == str(t)\n"
+            "os.environ['OMP_NUM_THREADS'] = '7'; assert hostcpu.limit_host_threads() == 7\n"
+            "print('ok', n, t)\n" % ROOT)
+    env = {k: v for k, v in os.environ.items() if not k.endswith('_NUM_THREADS')}
+    r = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0 and r.stdout.decode().startswith('ok'), r.stdout.decode()

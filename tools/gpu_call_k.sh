@@ -22,11 +22,11 @@ except Exception as e:
 PY
 }
 ARGS=""
-run chain A=1
-run nochain IGMC_NO_CHAIN=1
-run chain2 A=1
+run base A=1
+run selfseq IGMC_G2_SELF_SEQ=1
+run base2 A=1
 ARGS="--steps 20 --warmup 5"
-run driver_chain A=1
-run driver_nochain IGMC_NO_CHAIN=1
+run driver A=1
+run driver_selfseq IGMC_G2_SELF_SEQ=1
 ARGS="--steps 400 --warmup 20"
-run chain400 A=1
+run base400 A=1
