@@ -432,14 +432,18 @@ def main():
                             avg_us_eager_events=eager_us, algorithmic_bytes=algo_bytes, nodes=N, edges=E,
                             share_of_kernel_time=kernels[dom]['us'] * kernels[dom]['calls_per_step'] * P / (tot * 1e3)
                             if tot > 0 else None)
-        ext_names = [k for k in ('k_extract_nodes', 'k_relm', 'k_emit', 'k_count', 'k_fill', 'k_extract_dense')
-                     if k in kernels]
+        # (a lean arena's extraction stops at the dense blocks; k_emit then only runs for this pass's own inspection calls)
+        lean = bool(sg.ws.dense_path(sg.arenas[0], BATCH)) and os.environ.get('IGMC_NO_LEAN', '0') != '1'
+        ext_names = [k for k in ('k_extract_nodes', 'k_relm', 'k_relm_dropout', 'k_emit', 'k_count', 'k_fill', 'k_edge_flags')
+                     if k in kernels and not (lean and k in ('k_emit', 'k_edge_flags'))]
         if ext_bytes and ext_names:
             ext_us = sum(kernels[k]['us'] * kernels[k]['calls_per_step'] for k in ext_names)
             extraction = dict(algorithmic_bytes=float(np.mean(ext_bytes)), us_per_step=ext_us,
                               effective_GBps=float(np.mean(ext_bytes)) / (ext_us * 1e-6) / 1e9, kernels=ext_names,
-                              note='sum of the extraction kernels (HIP events, eager) while the model kernels of the '
-                                   'previous batch share the chip; 5*(deg u + deg v + sum deg U_s) + n + 9*E/2 bytes')
+                              lean=lean,
+                              note='sum of the extraction (+ edge dropout) kernels of the branch (HIP events, eager) while '
+                                   'the model kernels of the previous batch share the chip; 5*(deg u + deg v + sum deg U_s) '
+                                   '+ n + 9*E/2 bytes')
     if world > 1:
         parallel.barrier()
 
