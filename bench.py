@@ -337,10 +337,11 @@ def main():
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             run(nsteps)
+            t2 = time.perf_counter()
             torch.cuda.synchronize()
-            return (time.perf_counter() - t1) / nsteps * 1e6
+            return (time.perf_counter() - t1) / nsteps * 1e6, (t2 - t1) / nsteps * 1e6
         D = args.dp_steps
-        single_us = timed_us(D)
+        single_us, single_host = timed_us(D)
         res = {}
         for name, cap in (('dp', False), ('dp_captured', True)):
             sg.graphs, sg.multi = [None, None], None
@@ -349,9 +350,12 @@ def main():
             res[name] = timed_us(D)
         sg.graphs, sg.multi = [None, None], None
         sg.dp_path, sg.dp_capture = False, False
-        dp_structure = dict(steps=D, single_gpu_us=single_us, dp_us=res['dp'], dp_captured_us=res['dp_captured'],
-                            dp_structure_us=res['dp'] - single_us,
-                            note='world size 1: launch structure only, no RCCL kernel in it')
+        dp_structure = dict(steps=D, single_gpu_us=single_us, dp_us=res['dp'][0], dp_captured_us=res['dp_captured'][0],
+                            dp_structure_us=res['dp'][0] - single_us,
+                            host_enqueue_us_per_step=dict(single_gpu=single_host, dp=res['dp'][1],
+                                                          dp_captured=res['dp_captured'][1]),
+                            note='world size 1: launch structure only, no RCCL call in it; host_enqueue = host time '
+                                 'spent enqueuing a step (the GPU starves when it exceeds the step time)')
         sg.check()
 
     # ---- roofline leg
