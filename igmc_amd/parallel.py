@@ -60,7 +60,8 @@ def shard_positions(perm, rank_, world, pad=True):
 
 def all_reduce_sum_(t):
     """In-place sum over ranks of ONE flat tensor (the gradient buffer / the eval accumulators)."""
-    if is_dist() and world_size() > 1:
+    # (IGMC_DP_ALLREDUCE_ALWAYS=1: also in a 1-rank group -- lets one GPU exercise the collective's enqueue / capture path)
+    if is_dist() and (world_size() > 1 or os.environ.get('IGMC_DP_ALLREDUCE_ALWAYS', '0') == '1'):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 

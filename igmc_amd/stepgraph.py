@@ -146,7 +146,7 @@ class StepGraph(object):
     def _finish(self, arena):
         m, st = self.model, torch.cuda.current_stream().cuda_stream
         flat, grad = m.flat_parameters(), m.flat_grad()
-        if self.world > 1:
+        if self.world > 1 or (self.dp_path and parallel.is_dist()):
             parallel.all_reduce_sum_(grad)
         # Adam + loss + epoch total + control-block advance in ONE launch (the step's last kernel)
         g = self.opt.param_groups[0]
@@ -208,7 +208,7 @@ class StepGraph(object):
     def _capture(self, parity):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        if self.world <= 1:
+        if self.world <= 1 and not (self.dp_path and parallel.is_dist()):
             with torch.cuda.graph(g):
                 self._enqueue(parity, self.B, with_finish=self._finish_in_graph())
             self.graphs[parity] = g
@@ -276,7 +276,7 @@ class StepGraph(object):
     def _capture_multi(self):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        if self.world <= 1:
+        if self.world <= 1 and not (self.dp_path and parallel.is_dist()):
             with torch.cuda.graph(g):
                 for i in range(self.multi_n):
                     self._enqueue(i % 2, self.B)

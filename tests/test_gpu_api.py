@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import batch_to_pyg, load_extract_golden
+from helpers import ROOT, batch_to_pyg, load_extract_golden
 
 pytestmark = pytest.mark.gpu
 CASES = load_extract_golden()
@@ -529,3 +529,52 @@ def test_static_dataset_cache(flix, tmp_path):
         r = train_multiple_epochs(d, te, model, 2, 50, 1e-3, 0.1, 50, 0, ARR=0.001)
         finals.append((model.flat_parameters().detach().cpu().clone(), r))
     assert torch.equal(finals[0][0], finals[1][0]) and finals[0][1] == finals[1][1]
+
+
+def test_captured_all_reduce_structure_with_a_one_rank_rccl_group(tmp_path):
+    """IGMC_DP_CAPTURE_ALLREDUCE=1 with a REAL torch.distributed 'nccl' (= RCCL) process group of one rank: the flat
+    all-reduce is enqueued inside the captured step (thread-local capture next to the RCCL watchdog), 8 steps replay per
+    launch, and the trajectory equals the eager data-parallel structure's.  (A one-GPU box cannot say anything about
+    more ranks; this pins the capture / replay mechanics the multi-GPU run relies on.)"""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / 'dp1.py'
+    script.write_text(r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from igmc_amd import preprocessing
+from igmc_amd.models import IGMC
+from igmc_amd.stepgraph import StepGraph
+from igmc_amd.train_eval import FlatAdam
+from igmc_amd.util_functions import MyDynamicDataset
+torch.cuda.set_device(0)
+dist.init_process_group(backend='nccl', init_method='tcp://127.0.0.1:29641', rank=0, world_size=1)
+(_, _, adj, trl, tru, trv, _, _, _, _, _, _, cv) = preprocessing.load_data_monti('douban', testing=True)
+tr = MyDynamicDataset('data/t/dp1', adj, (tru[:1200], trv[:1200]), trl[:1200], 1, 1.0, 10000, None, None, cv)
+res = {}
+for name, cap in (('eager_tail', '0'), ('captured', '1')):
+    os.environ['IGMC_DP_CAPTURE_ALLREDUCE'] = cap
+    torch.manual_seed(7)
+    model = IGMC(tr, latent_dim=[32, 32, 32, 32], num_relations=len(cv), num_bases=4, regression=True,
+                 adj_dropout=0.2, seed=3).to('cuda')
+    model.reset_parameters()
+    opt = FlatAdam(model, lr=1e-3)
+    sg = StepGraph(model, opt, tr, 50, 0.001)
+    assert sg.dp_path
+    perm = torch.randperm(len(tr), generator=torch.Generator().manual_seed(5))
+    sg.run_epoch(perm, 1)
+    total, n = sg.run_epoch(perm, 2)
+    torch.cuda.synchronize()
+    res[name] = (model.flat_parameters().detach().cpu().clone(), float(total.item()), sg.multi is not None, sg.dp_capture)
+assert res['captured'][2] and res['captured'][3], 'the all-reduce was not captured: %%r' %% (res['captured'][2:],)
+assert not res['eager_tail'][2]
+assert torch.equal(res['eager_tail'][0], res['captured'][0]) and res['eager_tail'][1] == res['captured'][1]
+dist.destroy_process_group()
+print('captured all-reduce ok')
+''' % ROOT)
+    env = dict(os.environ, IGMC_FORCE_DP_PATH='1', IGMC_DP_ALLREDUCE_ALWAYS='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and 'captured all-reduce ok' in out, out[-3000:]
