@@ -46,3 +46,29 @@ def test_sort_pool_order_and_padding(be):
         want = np.zeros((4, 5), np.float32)
         want[:len(order)] = rows[order]
         assert np.array_equal(out[g], want)
+
+
+def test_sort_pool_error_behaviour(be, monkeypatch):
+    """The C ABI refuses what it cannot run and says why (non-zero return + igmc_last_error -> RuntimeError)."""
+    from igmc_amd import engine
+    case = sub('synth_cap', 4)
+    g, b, d = PC.extract_case(be, case, replay=False)
+    ws = engine.ModelWorkspace(be.lib, 0, 5, 4, 4, 0, b.node_capacity, b.edge_capacity, b.max_graphs)
+    slot = b.node_capacity // b.max_graphs
+    with pytest.raises(RuntimeError, match='k must be >= 10'):
+        engine.SortPoolWorkspace(ws, 9, slot)
+    ws_side = engine.ModelWorkspace(be.lib, 0, 5, 4, 4, 6, b.node_capacity, b.edge_capacity, b.max_graphs)
+    with pytest.raises(RuntimeError, match='no side features'):
+        engine.SortPoolWorkspace(ws_side, 12, slot)
+    sp_small = engine.SortPoolWorkspace(ws, 12, max(2, slot // 2))      # created for smaller subgraphs than the arena holds
+    P = np.zeros(sp_small.n_params, np.float32)
+    out = np.zeros(4, np.float32)
+    with pytest.raises(RuntimeError, match='slots larger'):
+        sp_small.forward(P.ctypes.data, b, out.ctypes.data)
+    sp = engine.SortPoolWorkspace(ws, 12, slot)
+    monkeypatch.setenv('IGMC_LAYER_MODE', '0')
+    with pytest.raises(RuntimeError, match='IGMC_LAYER_MODE=0'):
+        sp.forward(P.ctypes.data, b, out.ctypes.data)
+    monkeypatch.delenv('IGMC_LAYER_MODE')
+    with pytest.raises(RuntimeError, match='null buffer'):
+        sp.forward(None, b, out.ctypes.data)
