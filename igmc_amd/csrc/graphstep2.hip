@@ -487,7 +487,11 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
   // slots, relm rows up to the slot capacity): ONE round trip, under the kernel's scalar prologue
   const int ld = a.relm_ld, ldw = ld >> 2;
   auto load_label = [&](int g2) {
-    return (int)a.s_lab[(size_t)g2 * a.slot + ((tid >> 7) ? a.cap_u : 0) + (((tid & 127) < ((tid >> 7) ? a.cap_v : a.cap_u)) ? (tid & 127) : 0)];
+    // (capacity of the lane's side by arithmetic on the two VALUES: a per-lane select between the two kernel-argument
+    //  fields compiles to a vector load from the argument segment + a vmcnt(0) wait in front of every other load)
+    const int hi = tid >> 7, t7 = tid & 127;
+    const int capx = a.cap_u + hi * (a.cap_v - a.cap_u);
+    return (int)a.s_lab[(size_t)g2 * a.slot + hi * a.cap_u + ((t7 < capx) ? t7 : 0)];
   };
   uint32_t rmv[16];          // dword (tid & 31) of rows (tid >> 5) + 8 q  (ld <= 128 bytes, <= 128 rows)
   auto load_relm = [&](int g2) {
