@@ -410,7 +410,8 @@ def main():
         kernels = {name: dict(us=ms / calls * 1e3, calls_per_step=calls / P) for name, ms, calls in rows}
         tot = sum(ms for _, ms, _ in rows)
         dom = 'k_graph_step' if 'k_graph_step' in kernels else (
-            'k_rgcn_layer_fwd' if 'k_rgcn_layer_fwd' in kernels else 'k_rgcn_gather_fwd')
+            'k_dl_layer_fwd' if 'k_dl_layer_fwd' in kernels else (
+                'k_rgcn_layer_fwd' if 'k_rgcn_layer_fwd' in kernels else 'k_rgcn_gather_fwd'))
         if dom in kernels:
             algo_bytes = 133.0 * E + 132.0 * N                  # one layer, one direction
             if dom == 'k_graph_step':                           # forward + backward of the 3 conv layers in one launch

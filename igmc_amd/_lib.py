@@ -51,6 +51,7 @@ SIGNATURES = {
     'igmc_model_backward': (i32, [vp, vp, vp, vp, f32, vp, vp]),
     'igmc_model_loss_grad': (i32, [vp, vp, vp, i32, vp, u64, u64, f32, f32, f32, f32, vp, vp, vp, vp]),
     'igmc_adam_step': (i32, [vp, vp, vp, vp, i64, i64, f32, f32, f32, f32, f32, vp]),
+    'igmc_model_dense_layers': (i32, [vp, vp, i32]),
     'igmc_sortpool_create': (i32, [vp, i32, i32, vp]),
     'igmc_sortpool_destroy': (None, [vp]),
     'igmc_sortpool_layout': (i32, [vp, vp]),

@@ -309,11 +309,20 @@ extern "C" int igmc_batch_create(const igmc_graph* g, int max_graphs, int hop, i
   fail |= M.get(&d.slot_tab, d.slot_cap) | M.get(&d.slot_off, Bc + 1) | M.get(&d.slot_cnt, Bc);
   fail |= M.get(&d.y, Bc) | M.get(&d.totals, 8);
   d.relm = nullptr;
+  d.relmT = nullptr;
+  d.relmT_ld = (int)((cap_u + 3) & ~(size_t)3);
   d.max_rel = g->max_rel;
   d.relm_ld = (int)((cap_v + 3) & ~(size_t)3);
   // dense path: rows of the block fit one 256-entry super-chunk and block + row starts fit the default LDS window
   // (a byte of the block holds relation + 1 in bits 0-2 and the two keep bits of edge dropout in bits 3-4: <= 7 relations)
   if (g->max_rel + 1 <= 7 && cap_u <= 256 && cap_v <= 256 && cap_u * (size_t)d.relm_ld + slot * 4 <= 60 * 1024) fail |= M.get(&d.relm, (size_t)Bc * cap_u * d.relm_ld);   // dense induced block per link
+  // slots too large for the subgraph kernel (> 128 nodes a side) but with a dense block: the transposed copy feeds the
+  // item-side workgroups of the dense per-layer kernels (denselayer.hip)
+  // (IGMC_DL_ALWAYS=1: also for small slots -- lets tests run those kernels on small cases)
+  {
+    const char* da = getenv("IGMC_DL_ALWAYS");
+    if (d.relm && (cap_u > 128 || cap_v > 128 || (da && atoi(da) == 1))) fail |= M.get(&d.relmT, (size_t)Bc * cap_v * d.relmT_ld);
+  }
   fail |= M.get(&d.s_gid, Bc * slot) | M.get(&d.s_lab, Bc * slot) | M.get(&d.s_deg, Bc * slot) |
           M.get(&d.t_list, Bc * slot) | M.get(&d.t_dist, Bc * slot);
   if (fail) {
@@ -724,6 +733,12 @@ static void csr_for_model(const igmc_model* m, const igmc_batch* b, int dense_ca
   const int rows0 = m->d.R * m->d.L + m->d.L + 1;
   if (dense_capable_call && rows0 <= 32 && igmc_layer_mode() >= 2 && igmc_g2_eligible(m->d, b->d, b->last_B, &lay, &cs)) return;
   ensure_csr(b, stream);
+}
+
+// 1 when the dense per-layer kernels (k_dl_layer) take the conv layers of this arena
+extern "C" int igmc_model_dense_layers(const igmc_model* m, const igmc_batch* b, int B) {
+  if (!m || !b) return 0;
+  return (igmc_layer_mode() == 2 && igmc_dl_eligible(m->d, b->d, B)) ? 1 : 0;
 }
 
 extern "C" int igmc_model_dense_path(const igmc_model* m, const igmc_batch* b, int B) {

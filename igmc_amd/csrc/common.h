@@ -92,6 +92,9 @@ struct BatchDev {
   uint8_t* relm;         // [Bcap * cap_u * cap_v] dense (user local, item local) -> relation+1 (0 = no edge); NULL when
                          // the slots are too large (uncapped extraction): then the CSC-scanning kernels are used
   int relm_ld;           // row stride of relm (cap_v rounded up to 4 so that every block is dword-aligned)
+  uint8_t* relmT;        // [Bcap * cap_v * relmT_ld] the same bytes transposed (item local, user local): item-side rows for
+                         // the dense per-layer kernels (denselayer path, slots of 129..256 nodes a side); NULL otherwise
+  int relmT_ld;          // row stride of relmT (cap_u rounded up to 4)
   int max_rel;           // largest relation id of the rating graph
   int cap_u, cap_v, slot;
   int node_cap, edge_cap, graph_cap;

@@ -303,6 +303,11 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_extract_nodes(ExtractArgs a) {
     }
     if (do_v) a.b.n_items[g] = cv;
   }
+  if (a.b.relmT && do_v) {     // ... and of the transposed copy the cv x cap_u part
+    uint32_t* rt = (uint32_t*)(a.b.relmT + (size_t)g * a.b.cap_v * a.b.relmT_ld);
+    const int nw = (cv * a.b.relmT_ld) >> 2;
+    for (int i = tid; i < nw; i += IGMC_BLOCK) rt[i] = 0u;
+  }
   if (a.b.relm && do_u) {      // clear this link's dense (user, item) -> relation block (only the cu x cap_v part is used)
     uint32_t* rm = (uint32_t*)(a.b.relm + (size_t)g * a.b.cap_u * a.b.relm_ld);
     const int nw = (cu * a.b.relm_ld) >> 2;
@@ -577,6 +582,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_relm(GraphDev G, BatchDev b) {
       if (mt) {
         const int lv = (j[q] == v0) ? 0 : 1 + bm_rank(sel_v, pre_v, j[q]);
         rm[(size_t)row[q] * ld + lv] = (uint8_t)((rl[q] + 1) | 0x18);      // relation + 1, both directions kept
+        if (b.relmT) b.relmT[((size_t)g * b.cap_v + lv) * b.relmT_ld + row[q]] = (uint8_t)((rl[q] + 1) | 0x18);
         ++c;
       }
     }
@@ -808,6 +814,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_edge_flags(BatchDev b, float p, 
         const int nb = b.node_off[gr];
         uint8_t* q = b.relm + ((size_t)gr * b.cap_u + (size_t)(i - nb)) * b.relm_ld + ((int)(b.ecr[e] & 0xFFFFFFu) - nb - b.n_users[gr]);
         *q = (uint8_t)((*q & 7) | (kf << 3) | (kt << 4));
+        if (b.relmT) b.relmT[((size_t)gr * b.cap_v + ((int)(b.ecr[e] & 0xFFFFFFu) - nb - b.n_users[gr])) * b.relmT_ld + (i - nb)] = *q;
       }
     }
   }
@@ -825,6 +832,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_relm_flags(BatchDev b) {
     for (int e = b.row_ptr[i] + t; e < b.row_ptr[i + 1]; e += 16) {
       uint8_t* q = row + (int)(b.ecr[e] & 0xFFFFFFu);
       *q = (uint8_t)((*q & 7) | ((b.eflag[e] & 3) << 3));
+      if (b.relmT) b.relmT[((size_t)gr * b.cap_v + ((int)(b.ecr[e] & 0xFFFFFFu) - nb - b.n_users[gr])) * b.relmT_ld + (i - nb)] = *q;
     }
   }
 }
@@ -857,6 +865,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_relm_dropout(BatchDev b, float p
       const uint32_t kf = igmc_u01(igmc_edge_hash(seed, step, (uint32_t)g, u, v, force_undirected ? 2u : 1u)) >= p;
       const uint32_t kt = igmc_u01(igmc_edge_hash(seed, step, (uint32_t)g, u, v, force_undirected ? 2u : 0u)) >= p;
       w = (w & ~(0x18u << (8 * q))) | (((kf << 3) | (kt << 4)) << (8 * q));
+      if (b.relmT) b.relmT[((size_t)g * b.cap_v + 4 * k + q) * b.relmT_ld + row] = (uint8_t)((w >> (8 * q)) & 0xFFu);
     }
     rm[row * ldw + k] = w;
   }

@@ -1308,13 +1308,302 @@ int igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* P
   return a.self_seq ? 0 : 1;
 }
 
+int igmc_dl_prepare();
 int igmc_g2_prepare() {
+  if (igmc_dl_prepare()) return 1;
 #ifndef IGMC_HIPEMU
   const int mx = 160 * 1024;
   if (hipFuncSetAttribute((const void*)k_graph_step2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_graph_step2<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_graph_step2<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_graph_step2<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+#endif
+  return 0;
+}
+
+// =====================================================================================================================
+// Dense per-layer kernels ("denselayer" path): slots of 129..256 nodes a side (BASELINE config 2: ml_100k, cap 200).
+// Too large for the one-launch subgraph kernel above (fragments / planes of K <= 128 fill its registers and LDS), but the
+// dense induced block still turns the relational aggregation of a layer into MFMA products:
+//   one workgroup = 64 consecutive rows (4 bundles) of ONE side of ONE subgraph, one LAYER PASS per launch;
+//   the opposite side's input rows (h_{l-1} forward, dPre_l backward; <= 256 x 32 f32 from HBM / L2) are split into the
+//   three bf16 planes in LDS, the bundle's 16 relm rows sit in LDS as bytes and the A_r fragments are expanded from them
+//   per k-step (g2_expand4) -- no fragment residency, K loops at run time;
+//   gather T_r = A_r X and transform [T_r | x] @ [W_r; root] are g2's (same plane / image layouts, images of k_g2_compose).
+// They REPLACE k_rgcn_layer4 forward / backward inside the per-layer sequence of model.hip and keep its contract: forward
+// writes h_l; backward writes dPre_{l-1}, the basis-space aggregate G = sum_r att[r,b] T'_r (what the weight-gradient
+// kernel multiplies with X^T) and the per-workgroup d att partials <Y_b, T'_r>.  Item-side workgroups read the
+// transposed block relmT the extraction keeps for such arenas.
+struct DlArgs {
+  const int32_t* n_users;
+  const int32_t* n_items;
+  const int32_t* node_off;
+  const uint8_t* relm;
+  const uint8_t* relmT;
+  int cap_u, cap_v, relm_ld, relmT_ld, nq, R, D, l, kp;
+  const float* in;         // forward: h_{l-1}; backward: dPre_l                       [N, 32]
+  const float* hprev;      // backward: h_{l-1}
+  float* out;              // forward: h_l; backward: dPre_{l-1}
+  float* zero_out;         // forward, top layer of a training step: dPre_3 rows cleared (or NULL)
+  float* gagg;             // backward: G [N, 128]
+  const float* Y;          // backward: h_{l-1} @ [basis_0 | .. | basis_3]             [N, 128]
+  float* gatt_part;        // backward: [grid][R * 4] partial <Y_b, T'_r>
+  const float* gfeat;      // backward: readout gradient on the target rows [B, D] ...
+  const float* dcat;       // ... or dense [N, 32] (sort-pool readout)
+  const float* img;        // the layer's weight image (forward) / transposed image (backward)
+  const float* bias;       // forward
+  const float* att;        // backward: [R, 4]
+};
+
+#define DL_NW 8                   // waves (= 16-row bundles) per workgroup of the dense layer kernel
+#define DL_THREADS (64 * DL_NW)
+template <bool FLAGS, bool BWD>
+__global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
+  IGMC_DYN_SMEM(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int bid = blockIdx.x;
+  const int g = bid / (2 * a.nq), rem = bid - g * 2 * a.nq, side = rem / a.nq, q = rem - side * a.nq;
+  const int cu = a.n_users[g], cv = a.n_items[g];
+  const int n_own = side ? cv : cu, n_opp = side ? cu : cv;
+  const int R = a.R;
+  if (16 * DL_NW * q >= n_own) {                 // nothing of this side in the workgroup's rows (uniform)
+    if (BWD && tid < R * 4) a.gatt_part[(size_t)bid * R * 4 + tid] = 0.f;
+    return;
+  }
+  const int nb = a.node_off[g];
+  const int own0 = nb + (side ? cu : 0), opp0 = nb + (side ? 0 : cu);
+  const int kp = a.kp, rmp = kp;                 // plane pitch (bf16) = relm row pitch (bytes) = 32 * max k-steps + 8
+  const int nks = (n_opp + 31) >> 5;
+  uint32_t* PLN = (uint32_t*)smem;                                   // [3][32][kp] bf16
+  unsigned char* RMW = (unsigned char*)(PLN + (G2_NT * 32 * kp >> 1));   // [DL_NW waves][16 rows][rmp] bytes
+  float* XOA = (float*)(RMW + DL_NW * 16 * rmp);                     // [DL_NW][16][G2_XP]
+  float2* sW2 = (float2*)(XOA + DL_NW * 16 * G2_XP);                 // [G2_WIMG words]
+  float* sred = (float*)sW2 + G2_WIMG;                               // [DL_NW][32] + att [32]
+  float* s_att = sred + DL_NW * 32;
+  const int row0 = 16 * DL_NW * q + 16 * wave;
+  const bool active = row0 < n_own;
+  // ---- weight image: requested first (9 x 16 bytes per thread), stored after the other staging work
+  constexpr int NWQ = (G2_WIMG / 4 + DL_THREADS - 1) / DL_THREADS;
+  float4 wq[NWQ];
+#pragma unroll
+  for (int u = 0; u < NWQ; ++u) {
+    const int i = tid + u * DL_THREADS;
+    wq[u] = (i < G2_WIMG / 4) ? ((const float4*)a.img)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (BWD && tid < 32) s_att[tid] = (tid < R * 4) ? a.att[tid] : 0.f;
+  // ---- the opposite side's rows as bf16 planes: a thread takes two nodes x four features
+  {
+    const int tstride = 32 * kp >> 1;
+    const int npair = 16 * nks;                  // node pairs covered by the k-steps
+    for (int i = tid; i < npair * 8; i += DL_THREADS) {
+      const int jp = i >> 3, fq = i & 7;
+      float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+      if (2 * jp < n_opp) x0 = *(const float4*)(a.in + (size_t)(opp0 + 2 * jp) * 32 + 4 * fq);
+      if (2 * jp + 1 < n_opp) x1 = *(const float4*)(a.in + (size_t)(opp0 + 2 * jp + 1) * 32 + 4 * fq);
+      const float v0[4] = {x0.x, x0.y, x0.z, x0.w}, v1[4] = {x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        uint32_t h, mi, lo;
+        g2_split2(v0[c], v1[c], h, mi, lo);
+        uint32_t* p = PLN + ((4 * fq + c) * kp >> 1) + jp;
+        p[0] = h;
+        p[tstride] = mi;
+        p[2 * tstride] = lo;
+      }
+    }
+  }
+  // ---- this wave's 16 rows of the dense block (bytes; rows past the side and columns past the block are zero)
+  {
+    const int ldb = side ? a.relmT_ld : a.relm_ld, ldw = ldb >> 2;
+    const uint8_t* src = side ? a.relmT + (size_t)g * a.cap_v * a.relmT_ld : a.relm + (size_t)g * a.cap_u * a.relm_ld;
+    uint32_t* dst = (uint32_t*)(RMW + (size_t)wave * 16 * rmp);
+    const int rw = rmp >> 2;
+    for (int i = lane; i < 16 * rw; i += 64) {
+      const int r = i / rw, c = i - r * rw;
+      uint32_t w = 0u;
+      if (row0 + r < n_own && c < ldw && 4 * c < 32 * nks) w = ((const uint32_t*)(src + (size_t)(row0 + r) * ldb))[c];
+      dst[i] = w;
+    }
+  }
+  // ---- own rows of the layer input (the root / self term of the transform)
+  {
+    float* XO = XOA + wave * 16 * G2_XP;
+    for (int i = lane; i < 16 * 8; i += 64) {
+      const int r = i >> 3, c4 = i & 7;
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + r < n_own) x = *(const float4*)(a.in + (size_t)(own0 + row0 + r) * 32 + 4 * c4);
+      *(float4*)(XO + r * G2_XP + 4 * c4) = x;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NWQ; ++u) {
+    const int i = tid + u * DL_THREADS;
+    if (i < G2_WIMG / 4) ((float4*)sW2)[i] = wq[u];
+  }
+  __syncthreads();
+  float gsum[G2_NR * 4];
+#pragma unroll
+  for (int i = 0; i < G2_NR * 4; ++i) gsum[i] = 0.f;
+  if (active) {
+    // ---- T_r^T = X^T A_r^T over the k-steps of the opposite side; fragments expanded per k-step from the row's bytes
+    f32x4 acc[G2_NR][2];
+#pragma unroll
+    for (int r = 0; r < G2_NR; ++r) {
+      acc[r][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const unsigned char* rmo = RMW + (size_t)(wave * 16 + li) * rmp + 8 * kq;
+    const int tstride = 32 * kp >> 1, toff = 16 * kp >> 1;
+    const uint32_t* base = PLN + (li * kp >> 1) + 4 * kq;
+    // keep bit of the direction this pass walks: forward = edge opposite -> own, backward = own -> opposite
+    const int kbit = BWD ? (side ? 3 : 4) : (side ? 4 : 3);
+#pragma unroll 1
+    for (int s = 0; s < nks; ++s) {
+      const uint2 w = *(const uint2*)(rmo + 32 * s);
+      u32x4 pf[2 * G2_NT];
+#pragma unroll
+      for (int sp = 0; sp < G2_NT; ++sp) {
+        pf[2 * sp] = *(const u32x4*)(base + sp * tstride + 16 * s);
+        pf[2 * sp + 1] = *(const u32x4*)(base + sp * tstride + toff + 16 * s);
+      }
+#pragma unroll
+      for (int r = 0; r < G2_NR; ++r) {
+        u32x4 af;
+        uint32_t a0, a1, a2, a3;
+        g2_expand4<FLAGS>(w.x, (uint32_t)(r + 1), kbit, a0, a1);
+        g2_expand4<FLAGS>(w.y, (uint32_t)(r + 1), kbit, a2, a3);
+        af[0] = a0; af[1] = a1; af[2] = a2; af[3] = a3;
+#pragma unroll
+        for (int qq = 0; qq < 2 * G2_NT; ++qq) acc[r][qq & 1] = g2_mfma_bf16(pf[qq], af, acc[r][qq & 1]);
+      }
+    }
+    const int row = row0 + li;                       // this lane's row in the gather's accumulators
+    if (BWD) {
+      // ---- basis-space aggregate G (what the weight-gradient kernel multiplies with X^T) and the d att partials
+      if (row < n_own) {
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const float4 y4 = *(const float4*)(a.Y + (size_t)(own0 + row) * 128 + bb * 32 + 16 * t + 4 * kq);
+            const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+            float gv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < G2_NR; ++r) {
+              const float at = s_att[r * 4 + bb];
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) {
+                gv[rr] += at * acc[r][t][rr];
+                gsum[r * 4 + bb] += yv[rr] * acc[r][t][rr];
+              }
+            }
+            *(float4*)(a.gagg + (size_t)(own0 + row) * 128 + bb * 32 + 16 * t + 4 * kq) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+          }
+      }
+    }
+    // ---- dense transform + epilogue (lane = output feature 16 nt + li, registers = rows 4 kq + rr)
+    f32x4 o[2];
+    g2_transform(acc, XOA + wave * 16 * G2_XP, (const uint32_t*)sW2, li, kq, o);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int f = 16 * nt + li;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int rw = row0 + 4 * kq + rr;
+        if (rw < n_own) {
+          const size_t at = (size_t)(own0 + rw) * 32 + f;
+          if (!BWD) {
+            a.out[at] = g2_tanh(o[nt][rr] + a.bias[f]);
+            if (a.zero_out) a.zero_out[at] = 0.f;
+          } else {
+            float d = o[nt][rr];
+            if (a.dcat) d += a.dcat[at];
+            else if (rw == 0 && a.gfeat) d += a.gfeat[(size_t)g * a.D + side * 128 + (a.l - 1) * 32 + f];
+            const float x = a.hprev[at];
+            a.out[at] = d * (1.f - x * x);
+          }
+        }
+      }
+    }
+  }
+  if (BWD) {
+    // d att partial of the workgroup: lanes -> wave (fixed order), waves -> workgroup
+#pragma unroll
+    for (int i = 0; i < G2_NR * 4; ++i) {
+      const float s = igmc_wave_sum_f(gsum[i]);
+      if (lane == 0) sred[wave * 32 + i] = s;
+    }
+    __syncthreads();
+    if (tid < R * 4) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < DL_NW; ++w) s += sred[w * 32 + tid];
+      a.gatt_part[(size_t)bid * R * 4 + tid] = s;
+    }
+  }
+}
+
+static size_t dl_lds(int kp) {
+  return ((size_t)(G2_NT * 32 * kp >> 1) + (size_t)DL_NW * 4 * kp + (size_t)DL_NW * 16 * G2_XP + G2_WIMG + DL_NW * 32 + 32) * 4;
+}
+
+// 1 = the dense per-layer kernels take the conv layers of this arena (IGMC_DL=0 switches them off)
+int igmc_dl_eligible(const ModelDev& m, const BatchDev& b, int B) {
+  const char* e = getenv("IGMC_DL");
+  if (e && atoi(e) == 0) return 0;
+  if (!b.relm || !b.relmT || !m.g2_w || m.R > G2_NR) return 0;
+  const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
+  if (cmax > 256 || B * 2 * ((cmax + 16 * DL_NW - 1) / (16 * DL_NW)) > IGMC_GATHER_BLOCKS) return 0;
+  return dl_lds(32 * ((cmax + 31) >> 5) + 8) <= (size_t)160 * 1024;
+}
+
+int igmc_dl_grid(const BatchDev& b, int B) {
+  const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
+  return B * 2 * ((cmax + 16 * DL_NW - 1) / (16 * DL_NW));
+}
+
+void igmc_launch_g2_compose(const ModelDev& m, const float* P, void* stream) {
+  IGMC_PLAUNCH("k_g2_compose", k_g2_compose, 2 * 3 * (G2_NR + 1) + 1, G2_THREADS, 0, stream, m, P, m.g2_w);
+}
+
+// one conv layer pass: forward (bwd = 0: h_{l-1} -> h_l) or backward (dPre_l -> dPre_{l-1}, G, d att partials)
+void igmc_launch_dl_layer(const ModelDev& m, const BatchDev& b, const float* P, int B, int l, int bwd, int use_flags,
+                          float* zero_out, void* stream) {
+  DlArgs a;
+  memset(&a, 0, sizeof(a));
+  const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
+  a.n_users = b.n_users; a.n_items = b.n_items; a.node_off = b.node_off; a.relm = b.relm; a.relmT = b.relmT;
+  a.cap_u = b.cap_u; a.cap_v = b.cap_v; a.relm_ld = b.relm_ld; a.relmT_ld = b.relmT_ld;
+  a.nq = (cmax + 16 * DL_NW - 1) / (16 * DL_NW); a.R = m.R; a.D = m.D; a.l = l; a.kp = 32 * ((cmax + 31) >> 5) + 8;
+  a.in = bwd ? m.dpre[l] : m.h[l - 1];
+  a.hprev = m.h[l - 1];
+  a.out = bwd ? m.dpre[l - 1] : m.h[l];
+  a.zero_out = zero_out;
+  a.gagg = bwd ? m.gagg[l - 1] : nullptr;
+  a.Y = bwd ? m.Y[l - 1] : nullptr;
+  a.gatt_part = bwd ? m.gatt_part + (size_t)(l - 1) * IGMC_GATHER_BLOCKS * m.R * 4 : nullptr;
+  a.gfeat = m.gfeat; a.dcat = bwd ? m.dcat[l - 1] : nullptr;
+  a.img = m.g2_w + (size_t)((l - 1) * 2 + (bwd ? 1 : 0)) * G2_WIMG;
+  a.bias = P + m.off_bias[l]; a.att = P + m.off_att[l];
+  const int grid = B * 2 * a.nq;
+  const size_t sm = dl_lds(a.kp);
+  if (bwd) {
+    if (use_flags) IGMC_PLAUNCH("k_dl_layer_bwd", (k_dl_layer<true, true>), grid, DL_THREADS, sm, stream, a);
+    else IGMC_PLAUNCH("k_dl_layer_bwd", (k_dl_layer<false, true>), grid, DL_THREADS, sm, stream, a);
+  } else {
+    if (use_flags) IGMC_PLAUNCH("k_dl_layer_fwd", (k_dl_layer<true, false>), grid, DL_THREADS, sm, stream, a);
+    else IGMC_PLAUNCH("k_dl_layer_fwd", (k_dl_layer<false, false>), grid, DL_THREADS, sm, stream, a);
+  }
+}
+
+int igmc_dl_prepare() {
+#ifndef IGMC_HIPEMU
+  const int mx = 160 * 1024;
+  if (hipFuncSetAttribute((const void*)k_dl_layer<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_dl_layer<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_dl_layer<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_dl_layer<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
 #endif
   return 0;
 }

@@ -91,6 +91,12 @@ void igmc_launch_graph_step(const ModelDev& m, const BatchDev& b, const float* P
 int igmc_gs_prepare();
 // graphstep2.hip: the same step with the relational aggregation on the matrix cores (dense induced block)
 int igmc_g2_eligible(const ModelDev& m, const BatchDev& b, int B, G2Layout* lay, int* cs_out);
+// dense per-layer kernels (graphstep2.hip): slots of 129..256 nodes a side with a dense block + its transposed copy
+int igmc_dl_eligible(const ModelDev& m, const BatchDev& b, int B);
+int igmc_dl_grid(const BatchDev& b, int B);
+void igmc_launch_g2_compose(const ModelDev& m, const float* P, void* stream);
+void igmc_launch_dl_layer(const ModelDev& m, const BatchDev& b, const float* P, int B, int l, int bwd, int use_flags,
+                          float* zero_out, void* stream);
 int igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* P, int B, int training, int use_flags,
                              const G2Layout& lay, int cs, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
                              float grad_scale, float* out, void* stream);

@@ -2249,10 +2249,15 @@ void igmc_launch_conv_forward(const ModelDev& m, const BatchDev& b, const float*
   const size_t gs = (size_t)(m.R * 4) * sizeof(float);
   const size_t ds = (size_t)IGMC_KCAT * (32 + 4) * sizeof(float);
   const size_t fsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4) * sizeof(float);
+  // slots of 129..256 nodes a side with a dense block: the conv layers on the matrix cores (graphstep2.hip, k_dl_layer)
+  const int dl = mode == 2 && igmc_dl_eligible(m, b, B);
   for (int l = 1; l < 4; ++l) {
     // the top layer's launch also clears dPre_3 (only its target rows are written by the head backward)
     float* zo = (training && l == 3) ? m.dpre[3] : nullptr;
-    if (mode == 1) {
+    if (dl) {
+      if (l == 1) igmc_launch_g2_compose(m, P, stream);       // the step's weight images (both orientations)
+      igmc_launch_dl_layer(m, b, P, B, l, 0, use_flags, zo, stream);
+    } else if (mode == 1) {
       if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer<true, false>), gt, 1024, fsm, stream, b, m, P, l, zo);
       else IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer<false, false>), gt, 1024, fsm, stream, b, m, P, l, zo);
     } else if (mode == 2) {
@@ -2320,9 +2325,12 @@ void igmc_launch_conv_backward(const ModelDev& m, const BatchDev& b, const float
   const size_t gsa = (size_t)(m.R * 4 + 16 * m.R * 4) * sizeof(float);
   const size_t ds = (size_t)IGMC_KCAT * (32 + 4) * sizeof(float);
   const size_t bsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4 + 16 * m.R * 4) * sizeof(float);
+  const int dl = mode == 2 && igmc_dl_eligible(m, b, B);     // (the images of this step were composed by the forward)
   for (int l = 3; l >= 1; --l) {
     // transposed gather of dPre_l (+ d att partials), then [G | dPre_l] @ [basis^T ; root^T] + backward epilogue
-    if (mode == 1) {
+    if (dl) {
+      igmc_launch_dl_layer(m, b, P, B, l, 1, use_flags, nullptr, stream);
+    } else if (mode == 1) {
       if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer<true, true>), gt, 1024, bsm, stream, b, m, P, l, (float*)nullptr);
       else IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer<false, true>), gt, 1024, bsm, stream, b, m, P, l, (float*)nullptr);
     } else if (mode == 2) {
@@ -2354,7 +2362,8 @@ void igmc_launch_conv_backward(const ModelDev& m, const BatchDev& b, const float
     const int wgs2 = igmc_wg_stride(), n0 = rows0 * 32;
     const int nblk = ((l0_mfma ? 4 : 3) * wgs2 + 63) / 64 + (l0_mfma ? 0 : (n0 + 63) / 64) + (3 * na + 3) / 4;
     IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk, IGMC_BLOCK, 0, stream, m,
-                 mode == 0 ? g16 : (mode == 3 ? igmc_slot_grid(m, B, 2048) : gt), l0_mfma, IGMC_WG_BLOCKS);
+                 dl ? igmc_dl_grid(b, B) : (mode == 0 ? g16 : (mode == 3 ? igmc_slot_grid(m, B, 2048) : gt)), l0_mfma,
+                 IGMC_WG_BLOCKS);
   }
   {
     AdamTail none;
@@ -2428,10 +2437,15 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
   else IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<false, true>), g16, IGMC_BLOCK, l0s, stream, b, m, (const float*)P, m.h[0]);
   const size_t fsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4) * sizeof(float);
   const size_t bsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4 + 16 * m.R * 4) * sizeof(float);
-  const int gl = (lmode == 3) ? igmc_slot_grid(m, B, 2048) : gt;      // grid of the layer kernels
+  // slots of 129..256 nodes a side with a dense block: the conv layers on the matrix cores (graphstep2.hip, k_dl_layer)
+  const int dl = lmode == 2 && igmc_dl_eligible(m, b, B);
+  const int gl = dl ? igmc_dl_grid(b, B) : ((lmode == 3) ? igmc_slot_grid(m, B, 2048) : gt);      // grid of the layer kernels
   for (int l = 1; l < 4; ++l) {
     float* zo = (l == 3) ? m.dpre[3] : nullptr;
-    if (lmode == 3) {
+    if (dl) {
+      if (l == 1) igmc_launch_g2_compose(m, (const float*)P, stream);
+      igmc_launch_dl_layer(m, b, (const float*)P, B, l, 0, use_flags, zo, stream);
+    } else if (lmode == 3) {
       if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer_s<true, false>), gl, IGMC_BLOCK, fsm4, stream, b, m, (const float*)P, l, zo);
       else IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer_s<false, false>), gl, IGMC_BLOCK, fsm4, stream, b, m, (const float*)P, l, zo);
     } else {
@@ -2443,7 +2457,9 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
   IGMC_PLAUNCH("k_head_train", k_head_train, dim3(hb > gy ? hb : gy, 4), 512, ysz, stream, b, m, (const float*)P, inj_mask,
                seed, step, mult, grad_scale, out);
   for (int l = 3; l >= 1; --l) {
-    if (lmode == 3) {
+    if (dl) {
+      igmc_launch_dl_layer(m, b, (const float*)P, B, l, 1, use_flags, nullptr, stream);
+    } else if (lmode == 3) {
       if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer_s<true, true>), gl, IGMC_BLOCK, bsm4, stream, b, m, (const float*)P, l, (float*)nullptr);
       else IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer_s<false, true>), gl, IGMC_BLOCK, bsm4, stream, b, m, (const float*)P, l, (float*)nullptr);
     } else {

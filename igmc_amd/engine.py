@@ -126,6 +126,10 @@ class Batch(object):
         device (``igmc_batch_bind_side_source``)."""
         self.lib.call('igmc_batch_bind_side_source', self.handle, _p(ptr), int(n_side))
 
+    def dense_layers(self, ws):
+        """True when the dense per-layer kernels take the conv layers of this arena with workspace ``ws``."""
+        return bool(self.lib.cdll.igmc_model_dense_layers(ws.handle, self.handle, int(self.B or self.max_graphs)))
+
     def set_lean(self, lean=True):
         """Lean extraction: stop after the dense induced blocks (what the matrix-core subgraph kernel reads); the
         collated CSR is emitted on demand (``igmc_batch_set_lean``)."""

@@ -244,6 +244,10 @@ int igmc_model_check(igmc_model* m, void* stream);
  * reads the dense blocks only (see igmc_batch_set_lean); 0 otherwise.  No reference counterpart. */
 int igmc_model_dense_path(const igmc_model* m, const igmc_batch* b, int B);
 
+/* 1 when the arena's slots (129..256 nodes a side, dense block + transposed copy) send the conv layers of the per-layer
+ * sequence to the matrix-core layer kernels (k_dl_layer) instead of the CSR row walkers. */
+int igmc_model_dense_layers(const igmc_model* m, const igmc_batch* b, int B);
+
 /* ---- Sort-pool readout family: DGCNN_RS (reference models.py:123-167 on the DGCNN base :63-120; Main.py:364-380).
  * Four R-GCN layers with latent_dim [32, 32, 32, 1] (the conv kernels of igmc_model), concat (97 channels),
  * global_sort_pool(k) (PyG 1.4.2: nodes of a graph by the last channel, descending; first k rows, zero padding),

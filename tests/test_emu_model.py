@@ -245,3 +245,25 @@ def test_free_running_dropout_on_a_lean_arena(be, force_undirected):
     assert res['worst_grad_err'] < 1e-4
     eager = PC.run_free_running_dropout(be, sub('synth_cap', 12), R=5, force_undirected=force_undirected, lean=False)
     assert eager['keep_rate'] == res['keep_rate']
+
+
+@pytest.mark.parametrize('name,n,drop', [('synth_cap', 6, True), ('synth_nocap:100', 4, True), ('synth_nocap:100', 4, False),
+                                         ('hand', 5, True), ('douban:100', 6, False)])
+def test_dense_per_layer_kernels(be, monkeypatch, name, n, drop):
+    """k_dl_layer (graphstep2.hip): the conv layers of the per-layer sequence on the matrix cores, for arenas whose slots
+    are too large for the subgraph kernel (ml_100k, cap 200) -- here forced onto small cases (IGMC_DL_ALWAYS allocates the
+    transposed block, IGMC_GRAPH_STEP=0 keeps the subgraph kernels away): forward, loss and every gradient vs the oracle."""
+    monkeypatch.setenv('IGMC_DL_ALWAYS', '1')
+    monkeypatch.setenv('IGMC_GRAPH_STEP', '0')
+    res = PC.run_model_parity(be, sub(name, n), R=5, use_dropout=drop)
+    assert res['worst_grad_err'] < 1e-4
+    assert res['batch'].dense_layers(res['ws'])
+
+
+def test_dense_per_layer_kernels_in_the_fused_train_step(be, monkeypatch):
+    """... and inside igmc_train_step (the per-layer sequence with the multi-role launches + fused Adam): five steps on
+    different batches track pyg_ref.train_step + torch.optim.Adam."""
+    monkeypatch.setenv('IGMC_DL_ALWAYS', '1')
+    monkeypatch.setenv('IGMC_GRAPH_STEP', '0')
+    res = PC.run_fused_train_trajectory(be, sub('synth_cap', 15), R=5, steps=5, batch=3, use_dropout=True)
+    assert res['frac_off'] < 2e-3
