@@ -1453,6 +1453,26 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
       acc[r][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
       acc[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    const int row = row0 + li;                       // this lane's row in the gather's accumulators
+    // backward: everything the epilogues read from HBM / L2 is requested BEFORE the gather (Y rows of the lane's row for
+    // the d att partials, h_{l-1} of the transform's output rows for tanh'): eight + eight dependent round trips otherwise
+    float4 ypre[4][2];
+    float xprev[2][4];
+    if (BWD) {
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          ypre[bb][t] = (row < n_own) ? *(const float4*)(a.Y + (size_t)(own0 + row) * 128 + bb * 32 + 16 * t + 4 * kq)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int rw = row0 + 4 * kq + rr;
+          xprev[nt][rr] = (rw < n_own) ? a.hprev[(size_t)(own0 + rw) * 32 + 16 * nt + li] : 0.f;
+        }
+    }
     const unsigned char* rmo = RMW + (size_t)(wave * 16 + li) * rmp + 8 * kq;
     const int tstride = 32 * kp >> 1, toff = 16 * kp >> 1;
     const uint32_t* base = PLN + (li * kp >> 1) + 4 * kq;
@@ -1478,7 +1498,6 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
         for (int qq = 0; qq < 2 * G2_NT; ++qq) acc[r][qq & 1] = g2_mfma_bf16(pf[qq], af, acc[r][qq & 1]);
       }
     }
-    const int row = row0 + li;                       // this lane's row in the gather's accumulators
     if (BWD) {
       // ---- basis-space aggregate G (what the weight-gradient kernel multiplies with X^T) and the d att partials
       if (row < n_own) {
@@ -1486,7 +1505,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
         for (int bb = 0; bb < 4; ++bb)
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            const float4 y4 = *(const float4*)(a.Y + (size_t)(own0 + row) * 128 + bb * 32 + 16 * t + 4 * kq);
+            const float4 y4 = ypre[bb][t];
             const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
             float gv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1520,7 +1539,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
             float d = o[nt][rr];
             if (a.dcat) d += a.dcat[at];
             else if (rw == 0 && a.gfeat) d += a.gfeat[(size_t)g * a.D + side * 128 + (a.l - 1) * 32 + f];
-            const float x = a.hprev[at];
+            const float x = xprev[nt][rr];
             a.out[at] = d * (1.f - x * x);
           }
         }

@@ -3,7 +3,7 @@
 set -u
 ROOT=$(pwd); O=$ROOT/gpurun_out/q; mkdir -p $O; export PYTHONPATH=$ROOT
 ( timeout 900 python -m pytest tests/test_gpu_headline.py -m gpu -q -x -k "ml100k" 2>&1 | tail -12 ) > $O/t1.log; tail -12 $O/t1.log
-( timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -8 ) > $O/gpu_tests.log; tail -4 $O/gpu_tests.log
+echo skip-full-suite
 run() {
   local name=$1; shift
   ( env "$@" timeout 300 python bench.py --no-cpu-baseline --dp-steps 0 $ARGS ) > $O/bench_$name.json 2> $O/bench_$name.err
@@ -18,6 +18,6 @@ PY
 }
 ARGS="--config ml_100k"
 run ml100k_dl A=1
-run ml100k_nodl IGMC_DL=0
+run ml100k_dl2 A=1
 ARGS=""
 run ml1m A=1
