@@ -732,6 +732,9 @@ static void csr_for_model(const igmc_model* m, const igmc_batch* b, int dense_ca
   int cs = 1;
   const int rows0 = m->d.R * m->d.L + m->d.L + 1;
   if (dense_capable_call && rows0 <= 32 && igmc_layer_mode() >= 2 && igmc_g2_eligible(m->d, b->d, b->last_B, &lay, &cs)) return;
+  // dense per-layer path: it needs the node arrays only, and a lean extraction of such an arena (one with the transposed
+  // block) has left them behind (k_emit_nodes in the extraction branch)
+  if (igmc_layer_mode() == 2 && igmc_dl_eligible(m->d, b->d, b->last_B) && b->d.relm && b->last_B > 0) return;
   ensure_csr(b, stream);
 }
 

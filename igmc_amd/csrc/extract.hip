@@ -716,6 +716,52 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_emit(BatchDev b) {
   }
 }
 
+// Node part of the emission alone (batch offsets, per-node label / id / graph, totals): what the model kernels that work
+// on the dense blocks need of the collated batch (dense per-layer path: no edge list is read anywhere in the step).
+__global__ __launch_bounds__(IGMC_BLOCK) void k_emit_nodes(BatchDev b) {
+  __shared__ int sm[16];
+  const int g = blockIdx.x, B = gridDim.x;
+  const int tid = threadIdx.x;
+  int nb = 0, eb = 0, totn = 0, tote = 0;
+  for (int base = 0; base < B; base += IGMC_BLOCK) {
+    const int i = base + tid;
+    const int n = (i < B) ? b.n_users[i] + b.n_items[i] : 0;
+    const int e = (i < B) ? b.edge_cnt[i] : 0;
+    nb += igmc_block_sum_i(i < g ? n : 0, sm);
+    eb += igmc_block_sum_i(i < g ? e : 0, sm);
+    totn += igmc_block_sum_i(n, sm);
+    tote += igmc_block_sum_i(e, sm);
+  }
+  const int ovf = (totn > b.node_cap) || (tote > b.edge_cap);
+  if (tid == 0) {
+    b.node_off[g] = nb;
+    b.edge_off[g] = eb;
+    if (g == 0) {
+      b.node_off[B] = totn;
+      b.edge_off[B] = tote;
+      b.totals[0] = ovf ? 0 : totn;
+      b.totals[1] = ovf ? 0 : tote;
+      b.totals[2] = ovf;
+      b.totals[3] = B;
+      b.totals[4] = totn;
+      b.totals[5] = tote;
+    }
+  }
+  if (ovf) return;
+  const size_t so = (size_t)g * b.slot;
+  const int cu = b.n_users[g], nn = cu + b.n_items[g];
+  for (int n = tid; n < nn; n += IGMC_BLOCK) {
+    const int s = (n < cu) ? n : b.cap_u + (n - cu);
+    b.node_label[nb + n] = b.s_lab[so + s];
+    b.node_gid[nb + n] = b.s_gid[so + s];
+    b.node_graph[nb + n] = g;
+  }
+}
+
+void igmc_launch_emit_nodes(const BatchDev& b, int B, void* stream) {
+  IGMC_PLAUNCH("k_emit_nodes", k_emit_nodes, B, IGMC_BLOCK, 0, stream, b);
+}
+
 // ---------------------------------------------------------------- row segments ("slots") of the batch
 // One workgroup per graph: rows are placed by decreasing slot-group size (16, 8, 4, 2, 1), ties in row order,
 // so that every group is aligned to its own size and never straddles a 16-slot tile.  Deterministic.
@@ -983,6 +1029,7 @@ void igmc_launch_extract(const GraphDev& g, const BatchDev& b, const int32_t* li
     Sr = Sr < 1 ? 1 : (Sr > 16 ? 16 : Sr);
     IGMC_PLAUNCH("k_relm", k_relm, dim3(B, Sr), IGMC_BLOCK, (2 * Wv + 2 * (size_t)b.cap_u + 2) * sizeof(uint32_t), stream, g, b);
     if (!lean) igmc_launch_emit(b, B, stream);
+    else if (b.relmT) igmc_launch_emit_nodes(b, B, stream);      // dense per-layer path: node arrays only, in this branch
   } else {
     IGMC_PLAUNCH("k_count", k_count, dim3(B, S), IGMC_BLOCK, smem / 4, stream, g, b);
     IGMC_PLAUNCH("k_fill", k_fill, dim3(B, S), IGMC_BLOCK, smem / 2, stream, g, b);

@@ -1563,6 +1563,152 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
   }
 }
 
+// Layer 0 of the dense per-layer path (one-hot input): per row the histogram of (relation, label of the neighbour) over
+// its kept in-edges -- one-hot label planes x the relation masks on the matrix cores, as in k_graph_step2 -- then
+// h_0 = tanh([hist | onehot(own label) | 1] @ T0) with the composed layer-0 table (k_g2_compose).  STORE (training): the
+// histogram also goes to cnt0[node][R * L] (uint16), what the layer-0 weight gradient is formed from.  No edge list.
+struct Dl0Args {
+  const int32_t* n_users;
+  const int32_t* n_items;
+  const int32_t* node_off;
+  const uint8_t* node_label;
+  const uint8_t* relm;
+  const uint8_t* relmT;
+  int cap_u, cap_v, relm_ld, relmT_ld, nq, R, L, kp;
+  const float* t0;         // composed layer-0 table [32][32]
+  float* out;              // h_0 [N, 32]
+  uint16_t* cnt0;          // [N, R * L] or NULL
+};
+
+template <bool FLAGS, bool STORE>
+__global__ __launch_bounds__(DL_THREADS) void k_dl_layer0(Dl0Args a) {
+  IGMC_DYN_SMEM(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int bid = blockIdx.x;
+  const int g = bid / (2 * a.nq), rem = bid - g * 2 * a.nq, side = rem / a.nq, q = rem - side * a.nq;
+  const int cu = a.n_users[g], cv = a.n_items[g];
+  const int n_own = side ? cv : cu, n_opp = side ? cu : cv;
+  if (16 * DL_NW * q >= n_own) return;
+  const int R = a.R, L = a.L, RL = R * L;
+  const int nb = a.node_off[g];
+  const int own0 = nb + (side ? cu : 0), opp0 = nb + (side ? 0 : cu);
+  const int kp = a.kp, rmp = kp;
+  const int nks = (n_opp + 31) >> 5;
+  uint32_t* OHP = (uint32_t*)smem;                                       // [8 labels][kp] bf16 one-hot planes
+  unsigned char* RMW = (unsigned char*)(OHP + (8 * kp >> 1));            // [DL_NW][16][rmp] bytes
+  float* HI = (float*)(RMW + DL_NW * 16 * rmp);                          // [DL_NW][16][G2_XP] input rows [hist | onehot | 1]
+  float* sT0 = HI + DL_NW * 16 * G2_XP;                                  // [32][32]
+  const int row0 = 16 * DL_NW * q + 16 * wave;
+  const bool active = row0 < n_own;
+  for (int i = tid; i < 256; i += DL_THREADS) ((float4*)sT0)[i] = ((const float4*)a.t0)[i];
+  for (int i = tid; i < 8 * 16 * nks; i += DL_THREADS) {
+    const int lb = i / (16 * nks), jp = i - lb * 16 * nks;
+    const int l0 = (2 * jp < n_opp) ? (int)a.node_label[opp0 + 2 * jp] : 255;
+    const int l1 = (2 * jp + 1 < n_opp) ? (int)a.node_label[opp0 + 2 * jp + 1] : 255;
+    OHP[(lb * kp >> 1) + jp] = ((l0 == lb) ? 0x3F80u : 0u) | ((l1 == lb) ? 0x3F800000u : 0u);
+  }
+  {
+    const int ldb = side ? a.relmT_ld : a.relm_ld, ldw = ldb >> 2;
+    const uint8_t* src = side ? a.relmT + (size_t)g * a.cap_v * a.relmT_ld : a.relm + (size_t)g * a.cap_u * a.relm_ld;
+    uint32_t* dst = (uint32_t*)(RMW + (size_t)wave * 16 * rmp);
+    const int rw = rmp >> 2;
+    for (int i = lane; i < 16 * rw; i += 64) {
+      const int r = i / rw, c = i - r * rw;
+      uint32_t w = 0u;
+      if (row0 + r < n_own && c < ldw && 4 * c < 32 * nks) w = ((const uint32_t*)(src + (size_t)(row0 + r) * ldb))[c];
+      dst[i] = w;
+    }
+  }
+  float* hi = HI + wave * 16 * G2_XP;
+  for (int i = lane; i < 16 * G2_XP; i += 64) hi[i] = 0.f;
+  __syncthreads();
+  if (active) {
+    f32x4 hacc[G2_NR];
+#pragma unroll
+    for (int r = 0; r < G2_NR; ++r) hacc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned char* rmo = RMW + (size_t)(wave * 16 + li) * rmp + 8 * kq;
+    const uint32_t* ohp = OHP + ((li & 7) * kp >> 1) + 4 * kq;
+    const int kbit = side ? 4 : 3;                       // keep bit of the edge opposite -> own
+#pragma unroll 1
+    for (int s = 0; s < nks; ++s) {
+      const uint2 w = *(const uint2*)(rmo + 32 * s);
+      u32x4 pfh = *(const u32x4*)(ohp + 16 * s);
+      if (li >= 8) pfh = (u32x4){0u, 0u, 0u, 0u};        // (label rows 8..15 of the 16-row operand do not exist)
+#pragma unroll
+      for (int r = 0; r < G2_NR; ++r) {
+        u32x4 af;
+        uint32_t a0, a1, a2, a3;
+        g2_expand4<FLAGS>(w.x, (uint32_t)(r + 1), kbit, a0, a1);
+        g2_expand4<FLAGS>(w.y, (uint32_t)(r + 1), kbit, a2, a3);
+        af[0] = a0; af[1] = a1; af[2] = a2; af[3] = a3;
+        hacc[r] = g2_mfma_bf16(pfh, af, hacc[r]);
+      }
+    }
+    // lane (row li, kq): counts of the neighbour labels 4 kq + rr, per relation
+    const int row = row0 + li;
+#pragma unroll
+    for (int r = 0; r < G2_NR; ++r)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int c = 4 * kq + rr;
+        if (r < R && c < L) {
+          hi[li * G2_XP + r * L + c] = hacc[r][rr];
+          if (STORE && row < n_own) a.cnt0[(size_t)(own0 + row) * RL + r * L + c] = (uint16_t)(int)(hacc[r][rr] + 0.5f);
+        }
+      }
+    if (kq == 0 && row < n_own) {
+      hi[li * G2_XP + RL + (int)a.node_label[own0 + row]] = 1.f;
+      hi[li * G2_XP + RL + L] = 1.f;
+    }
+  }
+  __syncthreads();
+  if (active) {
+    // h_0[row][f], f = 8 kq .. 8 kq + 7: RL + L + 1 <= 32 table rows
+    const int row = row0 + li;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+    for (int c = 0; c <= RL + L; ++c) {
+      const float x = hi[li * G2_XP + c];
+      const float4 t0 = *(const float4*)(sT0 + c * 32 + 8 * kq), t1 = *(const float4*)(sT0 + c * 32 + 8 * kq + 4);
+      o[0] += x * t0.x; o[1] += x * t0.y; o[2] += x * t0.z; o[3] += x * t0.w;
+      o[4] += x * t1.x; o[5] += x * t1.y; o[6] += x * t1.z; o[7] += x * t1.w;
+    }
+    if (row < n_own) {
+      float* dst = a.out + (size_t)(own0 + row) * 32 + 8 * kq;
+      *(float4*)dst = make_float4(g2_tanh(o[0]), g2_tanh(o[1]), g2_tanh(o[2]), g2_tanh(o[3]));
+      *(float4*)(dst + 4) = make_float4(g2_tanh(o[4]), g2_tanh(o[5]), g2_tanh(o[6]), g2_tanh(o[7]));
+    }
+  }
+}
+
+static size_t dl0_lds(int kp) {
+  return ((size_t)(8 * kp >> 1) + (size_t)DL_NW * 4 * kp + (size_t)DL_NW * 16 * G2_XP + 1024) * 4;
+}
+
+void igmc_launch_dl_layer0(const ModelDev& m, const BatchDev& b, int B, int training, int use_flags, void* stream) {
+  Dl0Args a;
+  memset(&a, 0, sizeof(a));
+  const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
+  a.n_users = b.n_users; a.n_items = b.n_items; a.node_off = b.node_off; a.node_label = b.node_label;
+  a.relm = b.relm; a.relmT = b.relmT;
+  a.cap_u = b.cap_u; a.cap_v = b.cap_v; a.relm_ld = b.relm_ld; a.relmT_ld = b.relmT_ld;
+  a.nq = (cmax + 16 * DL_NW - 1) / (16 * DL_NW); a.R = m.R; a.L = m.L; a.kp = 32 * ((cmax + 31) >> 5) + 8;
+  a.t0 = m.g2_w + 6 * G2_WIMG;
+  a.out = m.h[0];
+  a.cnt0 = training ? m.cnt0 : nullptr;
+  const int grid = B * 2 * a.nq;
+  const size_t sm = dl0_lds(a.kp);
+  if (training) {
+    if (use_flags) IGMC_PLAUNCH("k_dl_layer0", (k_dl_layer0<true, true>), grid, DL_THREADS, sm, stream, a);
+    else IGMC_PLAUNCH("k_dl_layer0", (k_dl_layer0<false, true>), grid, DL_THREADS, sm, stream, a);
+  } else {
+    if (use_flags) IGMC_PLAUNCH("k_dl_layer0", (k_dl_layer0<true, false>), grid, DL_THREADS, sm, stream, a);
+    else IGMC_PLAUNCH("k_dl_layer0", (k_dl_layer0<false, false>), grid, DL_THREADS, sm, stream, a);
+  }
+}
+
 static size_t dl_lds(int kp) {
   return ((size_t)(G2_NT * 32 * kp >> 1) + (size_t)DL_NW * 4 * kp + (size_t)DL_NW * 16 * G2_XP + G2_WIMG + DL_NW * 32 + 32) * 4;
 }
@@ -1571,7 +1717,7 @@ static size_t dl_lds(int kp) {
 int igmc_dl_eligible(const ModelDev& m, const BatchDev& b, int B) {
   const char* e = getenv("IGMC_DL");
   if (e && atoi(e) == 0) return 0;
-  if (!b.relm || !b.relmT || !m.g2_w || m.R > G2_NR) return 0;
+  if (!b.relm || !b.relmT || !m.g2_w || m.R > G2_NR || m.L > 8 || m.R * m.L + m.L + 1 > 32) return 0;
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
   if (cmax > 256 || B * 2 * ((cmax + 16 * DL_NW - 1) / (16 * DL_NW)) > IGMC_GATHER_BLOCKS) return 0;
   return dl_lds(32 * ((cmax + 31) >> 5) + 8) <= (size_t)160 * 1024;
@@ -1623,6 +1769,10 @@ int igmc_dl_prepare() {
   if (hipFuncSetAttribute((const void*)k_dl_layer<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_dl_layer<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_dl_layer<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_dl_layer0<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_dl_layer0<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_dl_layer0<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_dl_layer0<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
 #endif
   return 0;
 }

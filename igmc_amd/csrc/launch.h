@@ -9,6 +9,7 @@ void igmc_launch_extract(const GraphDev& g, const BatchDev& b, const int32_t* li
                          const float* link_y, const int32_t* link_idx, int first, int B, int replay,
                          double sample_ratio, uint64_t seed, uint64_t epoch, const int64_t* ctrl, int lean, void* stream);
 void igmc_launch_emit(const BatchDev& b, int B, void* stream);
+void igmc_launch_emit_nodes(const BatchDev& b, int B, void* stream);
 void igmc_launch_load_nodes(const BatchDev& b, const int64_t* uoff, const int32_t* unodes, const uint8_t* udist,
                             const int64_t* voff, const int32_t* vnodes, const uint8_t* vdist, const float* link_y,
                             const int32_t* link_idx, int first, int B, const int64_t* ctrl, void* stream);
@@ -95,6 +96,7 @@ int igmc_g2_eligible(const ModelDev& m, const BatchDev& b, int B, G2Layout* lay,
 int igmc_dl_eligible(const ModelDev& m, const BatchDev& b, int B);
 int igmc_dl_grid(const BatchDev& b, int B);
 void igmc_launch_g2_compose(const ModelDev& m, const float* P, void* stream);
+void igmc_launch_dl_layer0(const ModelDev& m, const BatchDev& b, int B, int training, int use_flags, void* stream);
 void igmc_launch_dl_layer(const ModelDev& m, const BatchDev& b, const float* P, int B, int l, int bwd, int use_flags,
                           float* zero_out, void* stream);
 int igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* P, int B, int training, int use_flags,

@@ -2235,7 +2235,13 @@ void igmc_launch_conv_forward(const ModelDev& m, const BatchDev& b, const float*
   const size_t l0s = (size_t)(m.R * m.L * 32 + m.L * 32 + 32) * sizeof(float) + (size_t)4 * m.R * m.L * sizeof(int);
   const int g16 = igmc_xcd_grid(m, B, 4, IGMC_GATHER_BLOCKS);   // one wave per row, 4 rows per block
   const int g64 = igmc_rows_grid(m.node_cap, 64, 512);
-  if (training) {
+  // slots of 129..256 nodes a side with a dense block: every conv layer on the matrix cores (graphstep2.hip, k_dl_layer0 /
+  // k_dl_layer) from the blocks alone -- no edge list is read
+  const int dl = igmc_layer_mode() == 2 && igmc_dl_eligible(m, b, B);
+  if (dl) {
+    igmc_launch_g2_compose(m, P, stream);                 // the step's weight images + layer-0 table
+    igmc_launch_dl_layer0(m, b, B, training, use_flags, stream);
+  } else if (training) {
     if (use_flags) IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<true, true>), g16, IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
     else IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<false, true>), g16, IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
   } else {
@@ -2249,13 +2255,10 @@ void igmc_launch_conv_forward(const ModelDev& m, const BatchDev& b, const float*
   const size_t gs = (size_t)(m.R * 4) * sizeof(float);
   const size_t ds = (size_t)IGMC_KCAT * (32 + 4) * sizeof(float);
   const size_t fsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4) * sizeof(float);
-  // slots of 129..256 nodes a side with a dense block: the conv layers on the matrix cores (graphstep2.hip, k_dl_layer)
-  const int dl = mode == 2 && igmc_dl_eligible(m, b, B);
   for (int l = 1; l < 4; ++l) {
     // the top layer's launch also clears dPre_3 (only its target rows are written by the head backward)
     float* zo = (training && l == 3) ? m.dpre[3] : nullptr;
     if (dl) {
-      if (l == 1) igmc_launch_g2_compose(m, P, stream);       // the step's weight images (both orientations)
       igmc_launch_dl_layer(m, b, P, B, l, 0, use_flags, zo, stream);
     } else if (mode == 1) {
       if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer<true, false>), gt, 1024, fsm, stream, b, m, P, l, zo);
@@ -2433,17 +2436,20 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
   const size_t l0s = (size_t)(m.R * m.L * 32 + m.L * 32 + 32) * sizeof(float) + (size_t)4 * m.R * m.L * sizeof(int);
   const int g16 = igmc_xcd_grid(m, B, 4, IGMC_GATHER_BLOCKS);
   const int gt = igmc_xcd_grid(m, B, 16, 2048);
-  if (use_flags) IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<true, true>), g16, IGMC_BLOCK, l0s, stream, b, m, (const float*)P, m.h[0]);
+  // slots of 129..256 nodes a side with a dense block: every conv layer on the matrix cores (graphstep2.hip, k_dl_layer0 /
+  // k_dl_layer) from the blocks alone -- no edge list is read
+  const int dl = lmode == 2 && igmc_dl_eligible(m, b, B);
+  if (dl) {
+    igmc_launch_g2_compose(m, (const float*)P, stream);
+    igmc_launch_dl_layer0(m, b, B, 1, use_flags, stream);
+  } else if (use_flags) IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<true, true>), g16, IGMC_BLOCK, l0s, stream, b, m, (const float*)P, m.h[0]);
   else IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<false, true>), g16, IGMC_BLOCK, l0s, stream, b, m, (const float*)P, m.h[0]);
   const size_t fsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4) * sizeof(float);
   const size_t bsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4 + 16 * m.R * 4) * sizeof(float);
-  // slots of 129..256 nodes a side with a dense block: the conv layers on the matrix cores (graphstep2.hip, k_dl_layer)
-  const int dl = lmode == 2 && igmc_dl_eligible(m, b, B);
   const int gl = dl ? igmc_dl_grid(b, B) : ((lmode == 3) ? igmc_slot_grid(m, B, 2048) : gt);      // grid of the layer kernels
   for (int l = 1; l < 4; ++l) {
     float* zo = (l == 3) ? m.dpre[3] : nullptr;
     if (dl) {
-      if (l == 1) igmc_launch_g2_compose(m, (const float*)P, stream);
       igmc_launch_dl_layer(m, b, (const float*)P, B, l, 0, use_flags, zo, stream);
     } else if (lmode == 3) {
       if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer_s<true, false>), gl, IGMC_BLOCK, fsm4, stream, b, m, (const float*)P, l, zo);

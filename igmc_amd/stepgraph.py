@@ -60,7 +60,7 @@ class StepGraph(object):
         # branch skips the CSR emission (it is produced on demand for inspection)
         if os.environ.get('IGMC_NO_LEAN', '0') != '1':
             for a in self.arenas:
-                a.set_lean(self.ws.dense_path(a, self.B))
+                a.set_lean(self.ws.dense_path(a, self.B) or a.dense_layers(self.ws))
         self.out = torch.empty(self.B, dtype=torch.float32, device=self.dev)
         self.loss = torch.zeros(2, dtype=torch.float32, device=self.dev)
         self.total = torch.zeros(1, dtype=torch.float64, device=self.dev)

@@ -194,12 +194,12 @@ def reverse_positions(d):
 
 
 def run_model_parity(be, case, R, ARR=0.001, use_dropout=True, multiply_by=1.0, seed=3, check_eval=True,
-                     rtol=2e-4, atol=2e-5, n_side=0):
+                     rtol=2e-4, atol=2e-5, n_side=0, lean=False):
     """Engine forward / loss+grad on one extracted batch vs the PyG-1.4.2 restatement (oracle/pyg_ref.py)
     on IDENTICAL inputs: same subgraphs, same weights, same dropout masks."""
     import torch
     from oracle import pyg_ref
-    g, b, d = extract_case(be, case, replay=False)
+    g, b, d = extract_case(be, case, replay=False, lean=lean)
     L = 2 * case['h'] + 2
     ws = engine.ModelWorkspace(be.lib, be.device, R, 4, L, n_side, b.node_capacity, b.edge_capacity, b.max_graphs)
     ref = make_ref_model(L, R, n_side=n_side, seed=seed, adj_dropout=0.2 if use_dropout else 0.0,

@@ -249,13 +249,16 @@ def test_free_running_dropout_on_a_lean_arena(be, force_undirected):
 
 @pytest.mark.parametrize('name,n,drop', [('synth_cap', 6, True), ('synth_nocap:100', 4, True), ('synth_nocap:100', 4, False),
                                          ('hand', 5, True), ('douban:100', 6, False)])
-def test_dense_per_layer_kernels(be, monkeypatch, name, n, drop):
+@pytest.mark.parametrize('lean', [False, True])
+def test_dense_per_layer_kernels(be, monkeypatch, name, n, drop, lean):
     """k_dl_layer (graphstep2.hip): the conv layers of the per-layer sequence on the matrix cores, for arenas whose slots
     are too large for the subgraph kernel (ml_100k, cap 200) -- here forced onto small cases (IGMC_DL_ALWAYS allocates the
     transposed block, IGMC_GRAPH_STEP=0 keeps the subgraph kernels away): forward, loss and every gradient vs the oracle."""
     monkeypatch.setenv('IGMC_DL_ALWAYS', '1')
     monkeypatch.setenv('IGMC_GRAPH_STEP', '0')
-    res = PC.run_model_parity(be, sub(name, n), R=5, use_dropout=drop)
+    # (lean: the arena stops at the dense blocks; the model calls emit the node arrays only -- layer 0 included, nothing in
+    #  the step reads an edge list)
+    res = PC.run_model_parity(be, sub(name, n), R=5, use_dropout=drop, lean=lean)
     assert res['worst_grad_err'] < 1e-4
     assert res['batch'].dense_layers(res['ws'])
 

@@ -3,7 +3,7 @@
 set -u
 ROOT=$(pwd); O=$ROOT/gpurun_out/q; mkdir -p $O; export PYTHONPATH=$ROOT
 ( timeout 900 python -m pytest tests/test_gpu_headline.py -m gpu -q -x -k "ml100k" 2>&1 | tail -12 ) > $O/t1.log; tail -12 $O/t1.log
-echo skip-full-suite
+( timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -8 ) > $O/gpu_tests.log; tail -4 $O/gpu_tests.log
 run() {
   local name=$1; shift
   ( env "$@" timeout 300 python bench.py --no-cpu-baseline --dp-steps 0 $ARGS ) > $O/bench_$name.json 2> $O/bench_$name.err
