@@ -125,13 +125,32 @@ def test_uncapped_douban_takes_the_subgraph_kernel(be):
 
 
 
-def test_ml100k_cap200_batch_matches_oracle(be):
-    """BASELINE.json configs[1]: ml_100k shape, cap 200, adj-dropout 0.2, batch 50."""
+@pytest.mark.parametrize('lean', [False, True])
+def test_ml100k_cap200_batch_matches_oracle(be, lean):
+    """BASELINE.json configs[1]: ml_100k shape, cap 200, adj-dropout 0.2, batch 50 -- slots of 201 nodes a side: the dense
+    per-layer kernels (k_dl_layer0 / k_dl_layer on the matrix cores; lean: no edge list anywhere in the step)."""
     case = ml_case('ml_100k', 200, 50, seed=5)
-    res = PC.run_model_parity(be, case, R=5, use_dropout=True)
+    res = PC.run_model_parity(be, case, R=5, use_dropout=True, lean=lean)
     assert res['worst_grad_err'] < 2e-3
+    assert res['batch'].dense_layers(res['ws'])
     PC.check_sampled(res['d'], case)
     assert res['d']['N'] > 50 * 200
+
+
+@pytest.mark.parametrize('force_undirected', [False, True])
+def test_ml100k_cap200_free_running_dropout_on_the_dense_blocks(be, force_undirected):
+    """Edge dropout drawn on the dense blocks of a lean cap-200 arena (k_relm_dropout keeps the transposed copy in step):
+    flags vs the host restatement of the hash, model vs the oracle with those flags."""
+    case = ml_case('ml_100k', 200, 50, seed=6)
+    res = PC.run_free_running_dropout(be, case, R=5, p=0.2, force_undirected=force_undirected, lean=True)
+    assert res['worst_grad_err'] < 2e-3
+
+
+def test_ml100k_cap200_fused_train_steps_track_torch_adam(be):
+    """... and five fused train steps (igmc_train_step on the dense per-layer path) vs pyg_ref.train_step + torch Adam."""
+    case = ml_case('ml_100k', 200, 50, seed=7)
+    res = PC.run_fused_train_trajectory(be, case, R=5, steps=5, batch=10, use_dropout=True)
+    assert res['frac_off'] < 2e-3
 
 
 def test_training_steps_survive_a_competing_full_chip_kernel(ml1m):
