@@ -632,6 +632,8 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   if (d.R <= 5 && n_side == 0 && Bc <= 2048) {      // exchange buffers of the matrix-core subgraph kernel: 320 KB per slot
     fail |= M.get(&d.g2_ex, 5 * d.g2_ex_stride) | M.get(&d.g2_fx, Bc * 256) | M.get(&d.g2_w, (size_t)6 * 9216 + 1024);
     d.g2_graphs = (int)Bc;
+  } else if (d.R <= 5) {
+    fail |= M.get(&d.g2_w, (size_t)6 * 9216 + 1024);      // weight images alone: the dense per-layer kernels (any head)
   }
   fail |= M.get(&d.gs_bar, 2 * Bc + 1);
   fail |= M.get(&d.gs_ts, 4);

@@ -270,3 +270,12 @@ def test_dense_per_layer_kernels_in_the_fused_train_step(be, monkeypatch):
     monkeypatch.setenv('IGMC_GRAPH_STEP', '0')
     res = PC.run_fused_train_trajectory(be, sub('synth_cap', 15), R=5, steps=5, batch=3, use_dropout=True)
     assert res['frac_off'] < 2e-3
+
+
+def test_dense_per_layer_kernels_with_side_features(be, monkeypatch):
+    """The dense per-layer kernels only replace the conv layers: a model with side features (centre-node readout + the
+    two targets' feature rows, reference models.py:208-209) takes them too."""
+    monkeypatch.setenv('IGMC_DL_ALWAYS', '1')
+    res = PC.run_model_parity(be, sub('synth_cap', 6), R=5, use_dropout=True, n_side=10)
+    assert res['worst_grad_err'] < 1e-4
+    assert res['batch'].dense_layers(res['ws'])
