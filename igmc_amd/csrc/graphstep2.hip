@@ -34,6 +34,7 @@
 #include "launch.h"
 #include <stdlib.h>
 #include <stdio.h>
+#include <string.h>
 
 #define G2_THREADS 256
 #define G2_NW 4
@@ -1355,6 +1356,15 @@ struct DlArgs {
   const float* att;        // backward: [R, 4]
 };
 
+// acc += a * b as ONE scalar VALU fma.  The d att partials of k_dl_layer<BWD> are 160 of these per lane; left to the
+// compiler they become v_pk_fma_f32 / v_pk_mul_f32 chains whose operand pairs are assembled with v_mov and op_sel, and on
+// gfx950 that code gave run-to-run different sums on identical inputs (same launch repeated: G and dPre bit-identical, a
+// few partials off by 1e-2 relative; always the low halves of the packed chains).  Scalar fmas are reproducible.
+#ifdef IGMC_HIPEMU
+#define DL_FMAC(acc_, a_, b_) ((acc_) += (a_) * (b_))
+#else
+#define DL_FMAC(acc_, a_, b_) asm("v_fmac_f32 %0, %1, %2" : "+v"(acc_) : "v"(a_), "v"(b_))
+#endif
 #define DL_NW 8                   // waves (= 16-row bundles) per workgroup of the dense layer kernel
 #define DL_THREADS (64 * DL_NW)
 template <bool FLAGS, bool BWD>
@@ -1514,7 +1524,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
 #pragma unroll
               for (int rr = 0; rr < 4; ++rr) {
                 gv[rr] += at * acc[r][t][rr];
-                gsum[r * 4 + bb] += yv[rr] * acc[r][t][rr];
+                DL_FMAC(gsum[r * 4 + bb], yv[rr], acc[r][t][rr]);
               }
             }
             *(float4*)(a.gagg + (size_t)(own0 + row) * 128 + bb * 32 + 16 * t + 4 * kq) = make_float4(gv[0], gv[1], gv[2], gv[3]);

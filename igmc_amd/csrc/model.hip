@@ -1485,9 +1485,18 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_wgrad_head(BatchDev b, ModelDev 
 // graw layout: [3][5152] conv1..3 (32x160 + 32) | [3][R*4] d att | [(R*L+L+1)*32] layer-0 table
 // Sections A (weight-gradient partials) and C (layer-0 tables): 64 outputs x 4 partial-slices per block;
 // section B (d att, few outputs x many partials): one wave per output.  Fixed summation order.
+__device__ __forceinline__ void fin_stash_body(const ModelDev& m, const float* __restrict__ P, int l, const int64_t* ctrl);
+
+// nstash = 4: four extra workgroups stash the weights-only quantities of the conv layers for k_finalize_ts (basis-space
+// mode), like the stash role of k_tail_ts.
 __global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_partials(ModelDev m, int n_gatt_parts, int l0_mfma,
-                                                                  int n_wg_parts) {
+                                                                  int n_wg_parts, const float* __restrict__ P,
+                                                                  const int64_t* ctrl, int nstash) {
   __shared__ float sred[4][64];
+  if (nstash && (int)blockIdx.x >= (int)gridDim.x - nstash) {
+    fin_stash_body(m, P, (int)blockIdx.x - ((int)gridDim.x - nstash), ctrl);
+    return;
+  }
   const int wgs = 32 * IGMC_KCAT + 32, na = m.R * 4, rows0 = m.R * m.L + m.L + 1, n0 = rows0 * 32;
   const int nlay = l0_mfma ? 4 : 3;
   const int nblkA = (nlay * wgs + 63) / 64, nblkB = (3 * na + 3) / 4, nblkC = l0_mfma ? 0 : (n0 + 63) / 64;
@@ -1991,7 +2000,10 @@ __device__ __forceinline__ void fts_emit(float* __restrict__ grad, const AdamTai
 }
 
 __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const float* P, float* __restrict__ grad,
-                                                              float arr_coef, AdamTail at, int nlin) {
+                                                              float arr_coef, AdamTail at, int nlin, int bs) {
+  // bs != 0: the per-layer path's sources -- conv layers 1..3 in BASIS space (graw: d basis_b, d root, d bias straight
+  // from the weight-gradient kernel, d att from the layer kernels' partials), layer 0 as its relation-space table in graw;
+  // the stash comes from k_reduce_partials.  bs == 0: the relation-space tables of the subgraph kernels (ts_raw).
   __shared__ float smf[8];
   const int tid = threadIdx.x;
   const float* stash = m.fin_stash;
@@ -2007,7 +2019,26 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
     const int l = blockIdx.x / IGMC_FTS_NB, part = blockIdx.x % IGMC_FTS_NB;
     const int fin = (l == 0) ? m.L : 32, nE = fin * 32, R = m.R, na = R * 4;
     const float* st = stash + l * IGMC_STASH_LAYER;
-    const float* t0 = m.ts_raw + (size_t)l * m.ts_stride;
+    const int wgs = 32 * IGMC_KCAT + 32;
+    const bool table = !bs || l == 0;
+    const float* t0 = bs ? m.graw + 3 * wgs + 3 * na : m.ts_raw + (size_t)l * m.ts_stride;
+    const float* raw = m.graw + (size_t)(l >= 1 ? l - 1 : 0) * wgs;
+    // basis-space mode, layer 0: d att[r,b] = <dW_r, basis_b> needs every basis element of the layer BEFORE its owner
+    // (a thread of this very workgroup: nE <= 256) updates it -> formed first, then a barrier
+    __shared__ float s_gatt0[128];
+    if (bs && l == 0) {
+      if (part == 0) {          // one wave per entry, lanes over the nE elements, fixed order
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int rb = wave; rb < na; rb += IGMC_BLOCK / 64) {
+          const int r = rb >> 2, bb = rb & 3;
+          float sacc = 0.f;
+          for (int e = lane; e < nE; e += 64) sacc += t0[(size_t)r * nE + e] * P[m.off_basis[0] + (int64_t)bb * nE + e];
+          sacc = igmc_wave_sum_f(sacc);
+          if (lane == 0) s_gatt0[rb] = sacc;
+        }
+      }
+      __syncthreads();
+    }
     for (int e = part * IGMC_BLOCK + tid; e < nE; e += IGMC_FTS_NB * IGMC_BLOCK) {       // one round for fin <= 32
       int64_t idx[5];
       float pv[5], m1v[5], m2v[5], g[5];
@@ -2019,20 +2050,26 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
         m2v[q] = at.enabled ? at.m2[idx[q]] : 0.f;
         g[q] = 0.f;
       }
-      float tv[8];
+      if (table) {
+        float tv[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) tv[r] = (r < R) ? t0[(size_t)r * nE + e] : 0.f;
-      g[4] = t0[(size_t)R * nE + e];
+        for (int r = 0; r < 8; ++r) tv[r] = (r < R) ? t0[(size_t)r * nE + e] : 0.f;
+        g[4] = t0[(size_t)R * nE + e];
 #pragma unroll
-      for (int r = 0; r < 8; ++r)
-        if (r < R) {
+        for (int r = 0; r < 8; ++r)
+          if (r < R) {
 #pragma unroll
-          for (int bb = 0; bb < 4; ++bb) g[bb] += st[IGMC_STASH_ATT + r * 4 + bb] * tv[r];
+            for (int bb = 0; bb < 4; ++bb) g[bb] += st[IGMC_STASH_ATT + r * 4 + bb] * tv[r];
+          }
+        for (int r = 8; r < R; ++r) {          // (more than 8 relations: basis-space mode only)
+          const float tvr = t0[(size_t)r * nE + e];
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) g[bb] += st[IGMC_STASH_ATT + r * 4 + bb] * tvr;
         }
-      for (int r = 8; r < R; ++r) {          // (never taken: the tables exist for R <= 5)
-        const float tvr = t0[(size_t)r * nE + e];
+      } else {
 #pragma unroll
-        for (int bb = 0; bb < 4; ++bb) g[bb] += st[IGMC_STASH_ATT + r * 4 + bb] * tvr;
+        for (int bb = 0; bb < 4; ++bb) g[bb] = raw[(e >> 5) * IGMC_KCAT + bb * 32 + (e & 31)];
+        g[4] = raw[(e >> 5) * IGMC_KCAT + 128 + (e & 31)];
       }
       if (arr_coef != 0.f) {
 #pragma unroll
@@ -2046,21 +2083,25 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
     if (part == 0) {
       if (tid < 32) {                              // d bias
         const int64_t i = m.off_bias[l] + tid;
-        fts_emit(grad, at, i, t0[(size_t)(R * fin + fin) * 32 + tid], P[i], at.enabled ? at.m1[i] : 0.f,
-                 at.enabled ? at.m2[i] : 0.f);
+        fts_emit(grad, at, i, table ? t0[(size_t)(R * fin + fin) * 32 + tid] : raw[32 * IGMC_KCAT + tid], P[i],
+                 at.enabled ? at.m1[i] : 0.f, at.enabled ? at.m2[i] : 0.f);
       } else if (tid >= 64 && tid < 64 + na) {     // d att[r,b] = <dW_r, basis_b> (+ ARR): fin partials, fixed order
         const int rb = tid - 64, r = rb >> 2, bb = rb & 3;
         const int64_t i = m.off_att[l] + rb;
         const float pold = st[IGMC_STASH_ATT + rb];
         const float m1o = at.enabled ? at.m1[i] : 0.f, m2o = at.enabled ? at.m2[i] : 0.f;
-        const float* dp = m.datt_part + ((size_t)l * m.ts_stride + (size_t)r * nE) / 32 * 4 + bb;
         float g = 0.f;
-        for (int k0 = 0; k0 < fin; k0 += 32) {
-          float v[32];
+        if (bs) {
+          g = (l == 0) ? s_gatt0[rb] : m.graw[3 * wgs + (size_t)(l - 1) * na + rb];
+        } else {
+          const float* dp = m.datt_part + ((size_t)l * m.ts_stride + (size_t)r * nE) / 32 * 4 + bb;
+          for (int k0 = 0; k0 < fin; k0 += 32) {
+            float v[32];
 #pragma unroll
-          for (int k = 0; k < 32; ++k) v[k] = (k0 + k < fin) ? dp[(size_t)(k0 + k) * 4] : 0.f;
+            for (int k = 0; k < 32; ++k) v[k] = (k0 + k < fin) ? dp[(size_t)(k0 + k) * 4] : 0.f;
 #pragma unroll
-          for (int k = 0; k < 32; ++k) g += v[k];
+            for (int k = 0; k < 32; ++k) g += v[k];
+          }
         }
         if (arr_coef != 0.f) {
           float sacc = 0.f;
@@ -2366,7 +2407,7 @@ void igmc_launch_conv_backward(const ModelDev& m, const BatchDev& b, const float
     const int nblk = ((l0_mfma ? 4 : 3) * wgs2 + 63) / 64 + (l0_mfma ? 0 : (n0 + 63) / 64) + (3 * na + 3) / 4;
     IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk, IGMC_BLOCK, 0, stream, m,
                  dl ? igmc_dl_grid(b, B) : (mode == 0 ? g16 : (mode == 3 ? igmc_slot_grid(m, B, 2048) : gt)), l0_mfma,
-                 IGMC_WG_BLOCKS);
+                 IGMC_WG_BLOCKS, (const float*)nullptr, (const int64_t*)nullptr, 0);
   }
   {
     AdamTail none;
@@ -2424,10 +2465,10 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
       at.enabled = 1;
       at.b = b;
       at.ARR = ARR;
-      if (fts) IGMC_PLAUNCH("k_finalize_adam", k_finalize_ts, 4 * IGMC_FTS_NB + 32 + 1, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 32);
+      if (fts) IGMC_PLAUNCH("k_finalize_adam", k_finalize_ts, 4 * IGMC_FTS_NB + 32 + 1, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 32, 0);
       else IGMC_PLAUNCH("k_finalize_adam", k_finalize, 4 * IGMC_FIN_NB + 32, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 1);
     } else {
-      if (fts) IGMC_PLAUNCH("k_finalize", k_finalize_ts, 4 * IGMC_FTS_NB, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 0);
+      if (fts) IGMC_PLAUNCH("k_finalize", k_finalize_ts, 4 * IGMC_FTS_NB, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 0, 0);
       else IGMC_PLAUNCH("k_finalize", k_finalize, 4 * IGMC_FIN_NB, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 1);
       if (loss) igmc_launch_loss(m, b, ARR, loss, stream);
     }
@@ -2446,7 +2487,7 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
   else IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<false, true>), g16, IGMC_BLOCK, l0s, stream, b, m, (const float*)P, m.h[0]);
   const size_t fsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4) * sizeof(float);
   const size_t bsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4 + 16 * m.R * 4) * sizeof(float);
-  const int gl = dl ? igmc_dl_grid(b, B) : ((lmode == 3) ? igmc_slot_grid(m, B, 2048) : gt);      // grid of the layer kernels
+  const int gl = (dl && !getenv("IGMC_DL_NOBWD")) ? igmc_dl_grid(b, B) : ((lmode == 3) ? igmc_slot_grid(m, B, 2048) : gt);      // grid of the layer kernels
   for (int l = 1; l < 4; ++l) {
     float* zo = (l == 3) ? m.dpre[3] : nullptr;
     if (dl) {
@@ -2462,8 +2503,9 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
   const size_t ysz = (size_t)32 * (128 + 4) * sizeof(float);
   IGMC_PLAUNCH("k_head_train", k_head_train, dim3(hb > gy ? hb : gy, 4), 512, ysz, stream, b, m, (const float*)P, inj_mask,
                seed, step, mult, grad_scale, out);
+  const int dlb = dl && !getenv("IGMC_DL_NOBWD");      // (debug: dense forward + row-walker backward)
   for (int l = 3; l >= 1; --l) {
-    if (dl) {
+    if (dlb) {
       igmc_launch_dl_layer(m, b, (const float*)P, B, l, 1, use_flags, nullptr, stream);
     } else if (lmode == 3) {
       if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer_s<true, true>), gl, IGMC_BLOCK, bsm4, stream, b, m, (const float*)P, l, (float*)nullptr);
@@ -2484,7 +2526,24 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
   {
     const int wgs2 = igmc_wg_stride(), n0 = rows0 * 32, na = m.R * 4;
     const int nblk = (nsl * wgs2 + 63) / 64 + (l0_mfma ? 0 : (n0 + 63) / 64) + (3 * na + 3) / 4;
-    IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk, IGMC_BLOCK, 0, stream, m, gl, l0_mfma, IGMC_WG_BLOCKS);
+    // gradient / Adam tail without hand-offs (k_finalize_ts in basis-space mode) where the stash fits: R <= 32 and the
+    // layer-0 table inside the MFMA weight-gradient kernel; IGMC_FIN_MODE=0: the hand-off version (k_finalize)
+    const char* fe = getenv("IGMC_FIN_MODE");
+    const int fbs = (fe ? atoi(fe) : 1) && m.fin_stash && m.R <= 32 && l0_mfma;
+    IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk + (fbs ? 4 : 0), IGMC_BLOCK, 0, stream, m, gl, l0_mfma,
+                 IGMC_WG_BLOCKS, (const float*)P, (const int64_t*)(adam ? at.ctrl : nullptr), fbs ? 4 : 0);
+    if (fbs) {
+      if (adam) {
+        at.enabled = 1;
+        at.b = b;
+        at.ARR = ARR;
+        IGMC_PLAUNCH("k_finalize_adam", k_finalize_ts, 4 * IGMC_FTS_NB + 32 + 1, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 32, 1);
+      } else {
+        IGMC_PLAUNCH("k_finalize", k_finalize_ts, 4 * IGMC_FTS_NB, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 0, 1);
+        if (loss) igmc_launch_loss(m, b, ARR, loss, stream);
+      }
+      return;
+    }
   }
   if (adam) {
     at.enabled = 1;

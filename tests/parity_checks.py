@@ -443,7 +443,8 @@ def run_fused_train_trajectory(be, case, R, steps=5, batch=None, use_dropout=Fal
     for i, (k, prm) in enumerate(ref.named_parameters()):
         st = opt.state[prm]
         ea, es = st['exp_avg'].numpy(), st['exp_avg_sq'].numpy()
-        assert np.abs(m1[k] - ea).max() <= 2e-3 * max(np.abs(ea).max(), 1e-9), k
+        assert np.abs(m1[k] - ea).max() <= 2e-3 * max(np.abs(ea).max(), 1e-9), (k, float(np.abs(m1[k] - ea).max()),
+                                                                                   float(np.abs(ea).max()))
         assert np.abs(m2[k] - es).max() <= 4e-3 * max(np.abs(es).max(), 1e-12), k
     got_p, want_p = be.host(P), flatten_params(ws, ref)
     diff = np.abs(got_p - want_p)
@@ -453,7 +454,8 @@ def run_fused_train_trajectory(be, case, R, steps=5, batch=None, use_dropout=Fal
     bad = diff > tol
     assert bad.mean() < 2e-3, 'too many parameters off the oracle trajectory: %g' % bad.mean()
     assert diff.max() <= 2.0 * lr * steps + 1e-6, diff.max()
-    return dict(losses=losses, frac_off=float(bad.mean()), max_diff=float(diff.max()), total=float(be.host(total)[0]))
+    return dict(losses=losses, frac_off=float(bad.mean()), max_diff=float(diff.max()), total=float(be.host(total)[0]),
+                params=got_p, m1=be.host(M1), m2=be.host(M2), ws=ws)
 
 
 # ====================================================================== DGCNN_RS (sort-pool readout family)

@@ -153,6 +153,21 @@ def test_ml100k_cap200_fused_train_steps_track_torch_adam(be):
     assert res['frac_off'] < 2e-3
 
 
+def test_ml100k_cap200_fused_train_steps_are_bit_reproducible(be):
+    """The same fused steps, run several times from the same state, give the same bits: every reduction on the path has
+    a fixed order (no float atomics).  Guards the d att partials of k_dl_layer: compiled as packed-f32 chains they were
+    NOT reproducible on gfx950 (profiles/r02_dl_packed_f32_nondeterminism.txt)."""
+    case = ml_case('ml_100k', 200, 50, seed=7)
+    first = None
+    for i in range(6):
+        res = PC.run_fused_train_trajectory(be, case, R=5, steps=2, batch=10, use_dropout=True)
+        if first is None:
+            first = res
+            continue
+        for k in ('params', 'm1', 'm2'):
+            assert np.array_equal(first[k], res[k]), (i, k, float(np.abs(first[k] - res[k]).max()))
+
+
 def test_training_steps_survive_a_competing_full_chip_kernel(ml1m):
     """The cluster exchange of the subgraph kernel needs its members resident together.  Members are consecutive
     workgroups, so a chip that is partly held by ANOTHER kernel (here: a stream of large GEMMs on a second stream, all 256
