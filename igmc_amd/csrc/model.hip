@@ -1232,6 +1232,7 @@ __global__ __launch_bounds__(512) void k_head_train(BatchDev b, ModelDev m, cons
   IGMC_DYN_SMEM(smem);
   if (blockIdx.y > 0) {
     const int ly = blockIdx.y - 1;
+    if ((int)blockIdx.x * 128 >= b.totals[0]) return;       // sized by the arena's node capacity: no tile, no staging
     dense_body<0, 32, 128, EPI_NONE, W_YCAT, 512>(b, nullptr, m.h[ly], P + m.off_basis[ly + 1], nullptr, nullptr,
                                                   m.Y[ly], nullptr, nullptr, 0, 0, nullptr, (float*)smem);
     return;
@@ -1242,41 +1243,90 @@ __global__ __launch_bounds__(512) void k_head_train(BatchDev b, ModelDev m, cons
   __shared__ float spart[8][16];
   __shared__ float serr[16];
   __shared__ float sdz[16][132];
+  // Four workgroups carry this role at batch 50, so its duration is the number of DEPENDENT memory round trips, not a
+  // throughput: everything a later stage reads from memory (labels, lin2, the lin1 columns of the d feat product, the
+  // top-layer rows of the target nodes) is requested up front, next to the operands of lin1.
   const uint64_t step = m.ctrl ? (uint64_t)m.ctrl[IGMC_CTRL_STEP] : step_arg;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int n0 = wave * 16;
   const int ga = (row0 + li < B) ? row0 + li : B - 1;
-  const float* wrow = P + m.off_l1w + (int64_t)(n0 + li) * D;
-  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int n = n0 + li;
+  const float* wrow = P + m.off_l1w + (int64_t)n * D;
   const int nch = D / 16;
-  for (int s0 = 0; s0 < nch; s0 += 8) {
-    float4 a4[8], b4[8];
+  // targets' node rows of this lane's graphs (A rows of lin1: graph ga; epilogue of d feat: graphs row0 + 4 kq + rr)
+  const int nu_a = b.node_off[ga], nv_a = nu_a + b.n_users[ga];
+  int nu_e[4], nv_e[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int k0 = ((s0 + u < nch) ? s0 + u : nch - 1) * 16 + 4 * kq;
-      a4[u] = *(const float4*)head_feat_ptr(b, m, ga, k0);
-      b4[u] = *(const float4*)(wrow + k0);
+  for (int rr = 0; rr < 4; ++rr) {
+    const int g = row0 + kq * 4 + rr, gs = g < B ? g : B - 1;
+    nu_e[rr] = b.node_off[gs];
+    nv_e[rr] = nu_e[rr] + b.n_users[gs];
+  }
+  auto feat_ptr = [&](int k0) -> const float* {
+    if (k0 < 256) return m.h[(k0 >> 5) & 3] + (size_t)((k0 >> 7) ? nv_a : nu_a) * 32 + (k0 & 31);
+    return m.side + (size_t)ga * m.S + (k0 - 256);
+  };
+  f32x4 acc4[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc4[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 a4[16], b4[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int k0 = ((u < nch) ? u : nch - 1) * 16 + 4 * kq;
+    a4[u] = *(const float4*)feat_ptr(k0);
+    b4[u] = *(const float4*)(wrow + k0);
+  }
+  const float b1 = P[m.off_l1b + n], w2 = P[m.off_l2w + n];
+  const float l2b = P[m.off_l2b];
+  const float yv = (threadIdx.x < 16 && row0 + (int)threadIdx.x < B) ? b.y[row0 + threadIdx.x] : 0.f;
+  // d feat = dz @ lin1.weight: column tile nt = wave + 8 it; its 32 x 4 weight values and (tiles 6, 7 of a side = the top
+  // layer's slice of the concatenation) h_3 of the target rows
+  float bvp[2][8][4];
+  float hvp[2][4];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int c0 = (wave + 8 * it) * 16;
+    const bool on = c0 < 256;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int mm = 0; mm < 4; ++mm)
+        bvp[it][u][mm] = (c0 < D) ? P[m.off_l1w + (int64_t)(u * 16 + 4 * kq + mm) * D + c0 + li] : 0.f;
+    const int k = c0 + li;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      hvp[it][rr] = 0.f;
+      if (on && ((k >> 5) & 3) == 3) hvp[it][rr] = m.h[3][(size_t)((k >> 7) ? nv_e[rr] : nu_e[rr]) * 32 + (k & 31)];
+    }
+  }
+  for (int s0 = 0; s0 < nch; s0 += 16) {
+    if (s0 > 0) {                                   // side features: D > 256
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int k0 = ((s0 + u < nch) ? s0 + u : nch - 1) * 16 + 4 * kq;
+        a4[u] = *(const float4*)feat_ptr(k0);
+        b4[u] = *(const float4*)(wrow + k0);
+      }
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       if (s0 + u >= nch) continue;
       const int k0 = (s0 + u) * 16 + 4 * kq;
       if (wave == 0 && row0 + li < B) *(float4*)(m.feat + (size_t)ga * D + k0) = a4[u];
+      f32x4& acc = acc4[u & 3];                     // four independent chains instead of 64 dependent MFMAs
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u].x, b4[u].x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u].y, b4[u].y, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u].z, b4[u].z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u].w, b4[u].w, acc, 0, 0, 0);
     }
   }
-  const int n = n0 + li;
-  const float b1 = P[m.off_l1b + n], w2 = P[m.off_l2w + n];
   float av[4];
   int kp[4];
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     const int r = kq * 4 + rr, g = row0 + r;
-    float a = acc[rr] + b1;
+    float a = ((acc4[0][rr] + acc4[1][rr]) + (acc4[2][rr] + acc4[3][rr])) + b1;
     a = a > 0.f ? a : 0.f;
     av[rr] = a;
     kp[rr] = 0;
@@ -1297,9 +1347,9 @@ __global__ __launch_bounds__(512) void k_head_train(BatchDev b, ModelDev m, cons
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) s += spart[w][threadIdx.x];
-      const float o = (s + P[m.off_l2b]) * mult;
+      const float o = (s + l2b) * mult;
       out[g] = o;
-      e = o - b.y[g];
+      e = o - yv;
       m.err[g] = e;
     }
     serr[threadIdx.x] = e;
@@ -1316,36 +1366,35 @@ __global__ __launch_bounds__(512) void k_head_train(BatchDev b, ModelDev m, cons
   }
   __syncthreads();
   // ---- d feat = dz @ lin1.weight  (16 x 128 @ 128 x D), column tiles strided over the 8 waves
-  for (int nt = wave; nt * 16 < D; nt += 8) {
+  for (int nt = wave, it = 0; nt * 16 < D; nt += 8, ++it) {
     const int c0 = nt * 16;
-    f32x4 g4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 g4a = (f32x4){0.f, 0.f, 0.f, 0.f}, g4b = g4a;
+    if (it < 2) {
 #pragma unroll
-    for (int s2 = 0; s2 < 8; s2 += 4) {
-      float bv[4][4];
+      for (int u = 0; u < 8; ++u)
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+        for (int mm = 0; mm < 4; ++mm) {
+          f32x4& g4 = (u & 1) ? g4b : g4a;
+          g4 = __builtin_amdgcn_mfma_f32_16x16x4f32(sdz[li][u * 16 + 4 * kq + mm], bvp[it][u][mm], g4, 0, 0, 0);
+        }
+    } else {
+      for (int u = 0; u < 8; ++u)
 #pragma unroll
         for (int mm = 0; mm < 4; ++mm)
-          bv[u][mm] = P[m.off_l1w + (int64_t)((s2 + u) * 16 + 4 * kq + mm) * D + c0 + li];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int mm = 0; mm < 4; ++mm)
-          g4 = __builtin_amdgcn_mfma_f32_16x16x4f32(sdz[li][(s2 + u) * 16 + 4 * kq + mm], bv[u][mm], g4, 0, 0, 0);
+          g4a = __builtin_amdgcn_mfma_f32_16x16x4f32(sdz[li][u * 16 + 4 * kq + mm],
+                                                     P[m.off_l1w + (int64_t)(u * 16 + 4 * kq + mm) * D + c0 + li], g4a, 0, 0, 0);
     }
     const int k = c0 + li;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int g = row0 + kq * 4 + rr;
       if (g >= B) continue;
-      const float v = g4[rr];
+      const float v = g4a[rr] + g4b[rr];
       m.gfeat[(size_t)g * D + k] = v;
       if (k < 256 && ((k >> 5) & 3) == 3) {
-        const int side = k >> 7, f = k & 31;
-        const int nu = b.node_off[g], nv = nu + b.n_users[g];
-        const size_t node = (size_t)(side ? nv : nu);
-        const float hv = m.h[3][node * 32 + f];
-        m.dpre[3][node * 32 + f] = v * (1.f - hv * hv);
+        const size_t node = (size_t)((k >> 7) ? nv_e[rr] : nu_e[rr]);
+        const float hv = hvp[it & 1][rr];
+        m.dpre[3][node * 32 + (k & 31)] = v * (1.f - hv * hv);
       }
     }
   }
