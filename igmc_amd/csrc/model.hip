@@ -832,44 +832,61 @@ __device__ __forceinline__ void wgrad_body(const BatchDev& b, const ModelDev& m,
     for (int nt = 0; nt < 10; ++nt) acc[m2][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float bsum[2] = {0.f, 0.f};
   const int ntile = (N + 15) >> 4;
-  for (int tile = blockIdx.x * 4 + wave; tile < ntile; tile += gridDim.x * 4) {
+  // A tile = 16 rows = four row-groups (row 4 rg + kq feeds k-slot kq of MFMA step rg).  All operands of a tile are
+  // requested at once and the next tile's before this tile's 80 MFMAs, as 16-byte loads: lane li takes the B columns
+  // 8 li .. 8 li + 7 of G (tile nt <-> column 8 li + nt) and 2 li, 2 li + 1 of dPre -- the column order inside the
+  // product is free, the copy-out below undoes it (4 loads per row-group instead of 11 four-byte ones).
+  struct WgTile {
+    float2 a2[4];
+    float4 ga[4], gb[4];
+    float2 d2[4];
+  };
+  auto load_tile = [&](int tile, WgTile& t) {
     const int row0 = tile * 16;
 #pragma unroll
-    for (int r2 = 0; r2 < 4; r2 += 2) {          // two row-groups (22 loads) in flight before their 40 MFMAs
-      float2 a2[2];
-      float bv[2][10];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int row = row0 + 4 * (r2 + u) + kq;
-        const bool ok = row < N;
-        const int rs = ok ? row : 0;
-        if (!is_l0) {
-          a2[u] = *(const float2*)(X + (size_t)rs * 32 + 2 * li);
-        } else {
-          const int lab = b.node_label[rs];
-          const int c0 = 2 * li, c1 = 2 * li + 1;
-          a2[u].x = (c0 < RL) ? (float)m.cnt0[(size_t)rs * RL + c0] : ((c0 == RL + lab || c0 == RL + m.L) ? 1.f : 0.f);
-          a2[u].y = (c1 < RL) ? (float)m.cnt0[(size_t)rs * RL + c1] : ((c1 == RL + lab || c1 == RL + m.L) ? 1.f : 0.f);
+    for (int rg = 0; rg < 4; ++rg) {
+      const int row = row0 + 4 * rg + kq;
+      const bool ok = row < N;
+      const int rs = ok ? row : 0;
+      t.ga[rg] = make_float4(0.f, 0.f, 0.f, 0.f);
+      t.gb[rg] = t.ga[rg];
+      if (!is_l0) {
+        t.a2[rg] = *(const float2*)(X + (size_t)rs * 32 + 2 * li);
+        if (ok) {
+          t.ga[rg] = *(const float4*)(D1 + (size_t)rs * 128 + 8 * li);
+          t.gb[rg] = *(const float4*)(D1 + (size_t)rs * 128 + 8 * li + 4);
         }
-        if (!ok) { a2[u].x = 0.f; a2[u].y = 0.f; }
-#pragma unroll
-        for (int nt = 0; nt < 10; ++nt) {
-          bv[u][nt] = 0.f;
-          if (is_l0 && nt < 8) continue;
-          if (ok) bv[u][nt] = (nt < 8) ? D1[(size_t)rs * 128 + nt * 16 + li] : D2[(size_t)rs * 32 + (nt - 8) * 16 + li];
-        }
+      } else {
+        const int lab = b.node_label[rs];
+        const int c0 = 2 * li, c1 = 2 * li + 1;
+        t.a2[rg].x = (c0 < RL) ? (float)m.cnt0[(size_t)rs * RL + c0] : ((c0 == RL + lab || c0 == RL + m.L) ? 1.f : 0.f);
+        t.a2[rg].y = (c1 < RL) ? (float)m.cnt0[(size_t)rs * RL + c1] : ((c1 == RL + lab || c1 == RL + m.L) ? 1.f : 0.f);
       }
+      if (!ok) { t.a2[rg].x = 0.f; t.a2[rg].y = 0.f; }
+      t.d2[rg] = ok ? *(const float2*)(D2 + (size_t)rs * 32 + 2 * li) : make_float2(0.f, 0.f);
+    }
+  };
+  const int tstep = gridDim.x * 4;
+  int tile = blockIdx.x * 4 + wave;
+  WgTile cur;
+  if (tile < ntile) load_tile(tile, cur);
+  for (; tile < ntile; tile += tstep) {
+    WgTile nxt;
+    const bool more = tile + tstep < ntile;
+    if (more) load_tile(tile + tstep, nxt);
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+    for (int rg = 0; rg < 4; ++rg) {
+      const float bv[10] = {cur.ga[rg].x, cur.ga[rg].y, cur.ga[rg].z, cur.ga[rg].w, cur.gb[rg].x,
+                            cur.gb[rg].y, cur.gb[rg].z, cur.gb[rg].w, cur.d2[rg].x, cur.d2[rg].y};
 #pragma unroll
-        for (int nt = 0; nt < 10; ++nt) {
-          if (is_l0 && nt < 8) continue;
-          if (nt >= 8) bsum[nt - 8] += bv[u][nt];
-          acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[u].x, bv[u][nt], acc[0][nt], 0, 0, 0);
-          acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[u].y, bv[u][nt], acc[1][nt], 0, 0, 0);
-        }
+      for (int nt = 0; nt < 10; ++nt) {
+        if (is_l0 && nt < 8) continue;
+        if (nt >= 8) bsum[nt - 8] += bv[nt];
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a2[rg].x, bv[nt], acc[0][nt], 0, 0, 0);
+        acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a2[rg].y, bv[nt], acc[1][nt], 0, 0, 0);
       }
     }
+    if (more) cur = nxt;
   }
   // d bias: reduce the 4 row-slots (kq) of each column
 #pragma unroll
@@ -877,7 +894,7 @@ __device__ __forceinline__ void wgrad_body(const BatchDev& b, const ModelDev& m,
     bsum[q] += __shfl_xor(bsum[q], 16, 64);
     bsum[q] += __shfl_xor(bsum[q], 32, 64);
   }
-  // deterministic cross-wave reduction through LDS, wave 0 first
+  // deterministic cross-wave reduction through LDS, wave 0 first (LDS keeps the product's column order: tile-major)
   for (int w = 0; w < 4; ++w) {
     if (wave == w) {
 #pragma unroll
@@ -901,7 +918,18 @@ __device__ __forceinline__ void wgrad_body(const BatchDev& b, const ModelDev& m,
     }
     __syncthreads();
   }
-  for (int i = threadIdx.x; i < 32 * IGMC_KCAT + 32; i += IGMC_BLOCK) part[i] = sacc[i];
+  for (int i = threadIdx.x; i < 32 * IGMC_KCAT + 32; i += IGMC_BLOCK) {
+    int src;
+    if (i < 32 * IGMC_KCAT) {
+      const int f = i / IGMC_KCAT, n = i - f * IGMC_KCAT;
+      const int np = (n < 128) ? (n & 7) * 16 + (n >> 3) : (8 + ((n - 128) & 1)) * 16 + ((n - 128) >> 1);
+      src = f * IGMC_KCAT + np;
+    } else {
+      const int c = i - 32 * IGMC_KCAT;
+      src = 32 * IGMC_KCAT + (c & 1) * 16 + (c >> 1);
+    }
+    part[i] = sacc[src];
+  }
 }
 
 __global__ __launch_bounds__(IGMC_BLOCK) void k_wgrad(BatchDev b, ModelDev m, int ly_base) {
