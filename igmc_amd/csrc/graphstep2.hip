@@ -1367,6 +1367,8 @@ struct DlArgs {
 #endif
 #define DL_NW 8                   // waves (= 16-row bundles) per workgroup of the dense layer kernel
 #define DL_THREADS (64 * DL_NW)
+#define DL_PIT 2                  // plane-staging items per thread: 128 * k-steps / DL_THREADS, k-steps <= 8
+#define DL_RIT 17                 // block-row dwords per lane: 16 rows x (32 * k-steps + 8) / 4 / 64, k-steps <= 8
 template <bool FLAGS, bool BWD>
 __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
   IGMC_DYN_SMEM(smem);
@@ -1393,29 +1395,64 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
   float* s_att = sred + DL_NW * 32;
   const int row0 = 16 * DL_NW * q + 16 * wave;
   const bool active = row0 < n_own;
-  // ---- weight image: requested first (9 x 16 bytes per thread), stored after the other staging work
+  // ---- staging.  A workgroup is one residency round of the launch, so its duration is its chain of memory round trips:
+  // EVERY load of the staging work is requested here, before the first use (clamped addresses instead of predicates: no
+  // branches, values zeroed afterwards), and the scheduling barrier keeps the compiler from sinking them to their uses.
   constexpr int NWQ = (G2_WIMG / 4 + DL_THREADS - 1) / DL_THREADS;
-  float4 wq[NWQ];
-#pragma unroll
+  f32x4 wq[NWQ];                                   // weight image (5 x 16 bytes per thread; a native vector type: a
+#pragma unroll                                     // float4 struct copy is a memcpy the optimiser leaves in scratch)
   for (int u = 0; u < NWQ; ++u) {
     const int i = tid + u * DL_THREADS;
-    wq[u] = (i < G2_WIMG / 4) ? ((const float4*)a.img)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    wq[u] = ((const f32x4*)a.img)[i < G2_WIMG / 4 ? i : G2_WIMG / 4 - 1];
+  }
+  const int npair = 16 * nks;                      // node pairs covered by the k-steps (<= 16 * 8)
+  float4 x0[DL_PIT], x1[DL_PIT];                   // opposite side's rows: a thread takes two nodes x four features
+#pragma unroll
+  for (int u = 0; u < DL_PIT; ++u) {
+    const int i = tid + u * DL_THREADS, jp = i >> 3, fq = i & 7;
+    const int j0 = 2 * jp < n_opp ? 2 * jp : n_opp - 1, j1 = 2 * jp + 1 < n_opp ? 2 * jp + 1 : n_opp - 1;
+    x0[u] = *(const float4*)(a.in + (size_t)(opp0 + j0) * 32 + 4 * fq);
+    x1[u] = *(const float4*)(a.in + (size_t)(opp0 + j1) * 32 + 4 * fq);
+  }
+  const int ldb = side ? a.relmT_ld : a.relm_ld, ldw = ldb >> 2;
+  const uint8_t* rsrc = side ? a.relmT + (size_t)g * a.cap_v * a.relmT_ld : a.relm + (size_t)g * a.cap_u * a.relm_ld;
+  const int rw = rmp >> 2;
+  uint32_t rmq[DL_RIT];                            // this wave's 16 rows of the dense block, dwords lane + 64 u
+#pragma unroll
+  for (int u = 0; u < DL_RIT; ++u) {
+    const int i = lane + 64 * u, r = i / rw, c = i - r * rw;
+    const int rc = row0 + r < n_own ? row0 + r : n_own - 1, cc = c < ldw ? c : ldw - 1;
+    rmq[u] = ((const uint32_t*)(rsrc + (size_t)rc * ldb))[cc];
+  }
+  float4 xq[2];                                    // own rows of the layer input (root / self term of the transform)
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = lane + 64 * u, r = i >> 3, c4 = i & 7;
+    const int rc = row0 + r < n_own ? row0 + r : n_own - 1;
+    xq[u] = *(const float4*)(a.in + (size_t)(own0 + rc) * 32 + 4 * c4);
+  }
+  float biasv[2] = {0.f, 0.f};
+  if (!BWD) {
+    biasv[0] = a.bias[li];
+    biasv[1] = a.bias[16 + li];
   }
   if (BWD && tid < 32) s_att[tid] = (tid < R * 4) ? a.att[tid] : 0.f;
-  // ---- the opposite side's rows as bf16 planes: a thread takes two nodes x four features
+#ifndef IGMC_HIPEMU
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  // ---- planes: three bf16 terms of two nodes' features per word
   {
     const int tstride = 32 * kp >> 1;
-    const int npair = 16 * nks;                  // node pairs covered by the k-steps
-    for (int i = tid; i < npair * 8; i += DL_THREADS) {
-      const int jp = i >> 3, fq = i & 7;
-      float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
-      if (2 * jp < n_opp) x0 = *(const float4*)(a.in + (size_t)(opp0 + 2 * jp) * 32 + 4 * fq);
-      if (2 * jp + 1 < n_opp) x1 = *(const float4*)(a.in + (size_t)(opp0 + 2 * jp + 1) * 32 + 4 * fq);
-      const float v0[4] = {x0.x, x0.y, x0.z, x0.w}, v1[4] = {x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+    for (int u = 0; u < DL_PIT; ++u) {
+      const int i = tid + u * DL_THREADS, jp = i >> 3, fq = i & 7;
+      if (i >= npair * 8) continue;
+      const bool k0 = 2 * jp < n_opp, k1 = 2 * jp + 1 < n_opp;
+      const float v0[4] = {x0[u].x, x0[u].y, x0[u].z, x0[u].w}, v1[4] = {x1[u].x, x1[u].y, x1[u].z, x1[u].w};
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         uint32_t h, mi, lo;
-        g2_split2(v0[c], v1[c], h, mi, lo);
+        g2_split2(k0 ? v0[c] : 0.f, k1 ? v1[c] : 0.f, h, mi, lo);
         uint32_t* p = PLN + ((4 * fq + c) * kp >> 1) + jp;
         p[0] = h;
         p[tstride] = mi;
@@ -1423,33 +1460,27 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
       }
     }
   }
-  // ---- this wave's 16 rows of the dense block (bytes; rows past the side and columns past the block are zero)
+  // ---- the wave's block rows (bytes; rows past the side and columns past the block are zero)
   {
-    const int ldb = side ? a.relmT_ld : a.relm_ld, ldw = ldb >> 2;
-    const uint8_t* src = side ? a.relmT + (size_t)g * a.cap_v * a.relmT_ld : a.relm + (size_t)g * a.cap_u * a.relm_ld;
     uint32_t* dst = (uint32_t*)(RMW + (size_t)wave * 16 * rmp);
-    const int rw = rmp >> 2;
-    for (int i = lane; i < 16 * rw; i += 64) {
-      const int r = i / rw, c = i - r * rw;
-      uint32_t w = 0u;
-      if (row0 + r < n_own && c < ldw && 4 * c < 32 * nks) w = ((const uint32_t*)(src + (size_t)(row0 + r) * ldb))[c];
-      dst[i] = w;
+#pragma unroll
+    for (int u = 0; u < DL_RIT; ++u) {
+      const int i = lane + 64 * u, r = i / rw, c = i - r * rw;
+      if (i < 16 * rw) dst[i] = (row0 + r < n_own && c < ldw && 4 * c < 32 * nks) ? rmq[u] : 0u;
     }
   }
-  // ---- own rows of the layer input (the root / self term of the transform)
   {
     float* XO = XOA + wave * 16 * G2_XP;
-    for (int i = lane; i < 16 * 8; i += 64) {
-      const int r = i >> 3, c4 = i & 7;
-      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row0 + r < n_own) x = *(const float4*)(a.in + (size_t)(own0 + row0 + r) * 32 + 4 * c4);
-      *(float4*)(XO + r * G2_XP + 4 * c4) = x;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = lane + 64 * u, r = i >> 3, c4 = i & 7;
+      *(float4*)(XO + r * G2_XP + 4 * c4) = (row0 + r < n_own) ? xq[u] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 #pragma unroll
   for (int u = 0; u < NWQ; ++u) {
     const int i = tid + u * DL_THREADS;
-    if (i < G2_WIMG / 4) ((float4*)sW2)[i] = wq[u];
+    if (i < G2_WIMG / 4) ((f32x4*)sW2)[i] = wq[u];
   }
   __syncthreads();
   float gsum[G2_NR * 4];
@@ -1467,20 +1498,24 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
     // backward: everything the epilogues read from HBM / L2 is requested BEFORE the gather (Y rows of the lane's row for
     // the d att partials, h_{l-1} of the transform's output rows for tanh'): eight + eight dependent round trips otherwise
     float4 ypre[4][2];
-    float xprev[2][4];
+    float xprev[2][4], addv[2][4];
     if (BWD) {
+      const int rowc = row < n_own ? row : n_own - 1;
 #pragma unroll
       for (int bb = 0; bb < 4; ++bb)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-          ypre[bb][t] = (row < n_own) ? *(const float4*)(a.Y + (size_t)(own0 + row) * 128 + bb * 32 + 16 * t + 4 * kq)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+          ypre[bb][t] = *(const float4*)(a.Y + (size_t)(own0 + rowc) * 128 + bb * 32 + 16 * t + 4 * kq);
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          const int rw = row0 + 4 * kq + rr;
-          xprev[nt][rr] = (rw < n_own) ? a.hprev[(size_t)(own0 + rw) * 32 + 16 * nt + li] : 0.f;
+          const int rw = row0 + 4 * kq + rr, rwc = rw < n_own ? rw : n_own - 1;
+          xprev[nt][rr] = a.hprev[(size_t)(own0 + rwc) * 32 + 16 * nt + li];
+          // what is added to the transform's output: the readout gradient (dense: sort-pool; else the target row only)
+          addv[nt][rr] = 0.f;
+          if (a.dcat) addv[nt][rr] = a.dcat[(size_t)(own0 + rwc) * 32 + 16 * nt + li];
+          else if (rw == 0 && a.gfeat) addv[nt][rr] = a.gfeat[(size_t)g * a.D + side * 128 + (a.l - 1) * 32 + 16 * nt + li];
         }
     }
     const unsigned char* rmo = RMW + (size_t)(wave * 16 + li) * rmp + 8 * kq;
@@ -1543,12 +1578,10 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
         if (rw < n_own) {
           const size_t at = (size_t)(own0 + rw) * 32 + f;
           if (!BWD) {
-            a.out[at] = g2_tanh(o[nt][rr] + a.bias[f]);
+            a.out[at] = g2_tanh(o[nt][rr] + biasv[nt]);
             if (a.zero_out) a.zero_out[at] = 0.f;
           } else {
-            float d = o[nt][rr];
-            if (a.dcat) d += a.dcat[at];
-            else if (rw == 0 && a.gfeat) d += a.gfeat[(size_t)g * a.D + side * 128 + (a.l - 1) * 32 + f];
+            const float d = o[nt][rr] + addv[nt][rr];
             const float x = xprev[nt][rr];
             a.out[at] = d * (1.f - x * x);
           }
@@ -1558,10 +1591,19 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
   }
   if (BWD) {
     // d att partial of the workgroup: lanes -> wave (fixed order), waves -> workgroup
+    // the 20 butterflies side by side: one LDS-crossbar round trip per step for all of them (one after the other they are
+    // 120 dependent round trips, ~4 us of this kernel); same order of additions per value
 #pragma unroll
-    for (int i = 0; i < G2_NR * 4; ++i) {
-      const float s = igmc_wave_sum_f(gsum[i]);
-      if (lane == 0) sred[wave * 32 + i] = s;
+    for (int d = 32; d >= 1; d >>= 1) {
+      float t[G2_NR * 4];
+#pragma unroll
+      for (int i = 0; i < G2_NR * 4; ++i) t[i] = __shfl_xor(gsum[i], d, 64);
+#pragma unroll
+      for (int i = 0; i < G2_NR * 4; ++i) gsum[i] += t[i];
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < G2_NR * 4; ++i) sred[wave * 32 + i] = gsum[i];
     }
     __syncthreads();
     if (tid < R * 4) {
@@ -1612,22 +1654,33 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer0(Dl0Args a) {
   const int row0 = 16 * DL_NW * q + 16 * wave;
   const bool active = row0 < n_own;
   for (int i = tid; i < 256; i += DL_THREADS) ((float4*)sT0)[i] = ((const float4*)a.t0)[i];
-  for (int i = tid; i < 8 * 16 * nks; i += DL_THREADS) {
-    const int lb = i / (16 * nks), jp = i - lb * 16 * nks;
+  // one thread per node pair of the opposite side (<= 160): its two labels once, the eight plane words from them
+  const int own_lab = (row0 + li < n_own) ? (int)a.node_label[own0 + row0 + li] : 0;      // (used after the gather)
+  for (int jp = tid; jp < 16 * nks; jp += DL_THREADS) {
     const int l0 = (2 * jp < n_opp) ? (int)a.node_label[opp0 + 2 * jp] : 255;
     const int l1 = (2 * jp + 1 < n_opp) ? (int)a.node_label[opp0 + 2 * jp + 1] : 255;
-    OHP[(lb * kp >> 1) + jp] = ((l0 == lb) ? 0x3F80u : 0u) | ((l1 == lb) ? 0x3F800000u : 0u);
+#pragma unroll
+    for (int lb = 0; lb < 8; ++lb) OHP[(lb * kp >> 1) + jp] = ((l0 == lb) ? 0x3F80u : 0u) | ((l1 == lb) ? 0x3F800000u : 0u);
   }
   {
     const int ldb = side ? a.relmT_ld : a.relm_ld, ldw = ldb >> 2;
     const uint8_t* src = side ? a.relmT + (size_t)g * a.cap_v * a.relmT_ld : a.relm + (size_t)g * a.cap_u * a.relm_ld;
     uint32_t* dst = (uint32_t*)(RMW + (size_t)wave * 16 * rmp);
     const int rw = rmp >> 2;
-    for (int i = lane; i < 16 * rw; i += 64) {
-      const int r = i / rw, c = i - r * rw;
-      uint32_t w = 0u;
-      if (row0 + r < n_own && c < ldw && 4 * c < 32 * nks) w = ((const uint32_t*)(src + (size_t)(row0 + r) * ldb))[c];
-      dst[i] = w;
+    uint32_t rmq[DL_RIT];                          // all requested before the first use (see k_dl_layer)
+#pragma unroll
+    for (int u = 0; u < DL_RIT; ++u) {
+      const int i = lane + 64 * u, r = i / rw, c = i - r * rw;
+      const int rc = row0 + r < n_own ? row0 + r : n_own - 1, cc = c < ldw ? c : ldw - 1;
+      rmq[u] = ((const uint32_t*)(src + (size_t)rc * ldb))[cc];
+    }
+#ifndef IGMC_HIPEMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+    for (int u = 0; u < DL_RIT; ++u) {
+      const int i = lane + 64 * u, r = i / rw, c = i - r * rw;
+      if (i < 16 * rw) dst[i] = (row0 + r < n_own && c < ldw && 4 * c < 32 * nks) ? rmq[u] : 0u;
     }
   }
   float* hi = HI + wave * 16 * G2_XP;
@@ -1668,7 +1721,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer0(Dl0Args a) {
         }
       }
     if (kq == 0 && row < n_own) {
-      hi[li * G2_XP + RL + (int)a.node_label[own0 + row]] = 1.f;
+      hi[li * G2_XP + RL + own_lab] = 1.f;
       hi[li * G2_XP + RL + L] = 1.f;
     }
   }
