@@ -1295,37 +1295,42 @@ __global__ __launch_bounds__(512) void k_head_train(BatchDev b, ModelDev m, cons
     if (k0 < 256) return m.h[(k0 >> 5) & 3] + (size_t)((k0 >> 7) ? nv_a : nu_a) * 32 + (k0 & 31);
     return m.side + (size_t)ga * m.S + (k0 - 256);
   };
+  // addresses as (uniform base) + (32-bit byte offset of the lane): one offset register serves every load of a kind and
+  // the bases live in scalar registers -- the role is VALU-bound, not memory-bound, once its loads are batched (8 waves
+  // on each of 4 CUs; address arithmetic was a third of its instructions)
+  auto ld4 = [](const float* base, uint32_t byte) { return *(const float4*)((const char*)base + byte); };
+  auto ld1 = [](const float* base, uint32_t byte) { return *(const float*)((const char*)base + byte); };
+  const uint32_t offU = ((uint32_t)nu_a * 32u + 4u * kq) * 4u, offV = ((uint32_t)nv_a * 32u + 4u * kq) * 4u;
+  const uint32_t offW = ((uint32_t)n * (uint32_t)D + 4u * kq) * 4u;
   f32x4 acc4[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) acc4[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float4 a4[16], b4[16];
 #pragma unroll
-  for (int u = 0; u < 16; ++u) {
-    const int k0 = ((u < nch) ? u : nch - 1) * 16 + 4 * kq;
-    a4[u] = *(const float4*)feat_ptr(k0);
-    b4[u] = *(const float4*)(wrow + k0);
+  for (int u = 0; u < 16; ++u) {                    // chunks 0..15 = the 256 conv features (D >= 256): k0 = 16 u + 4 kq
+    a4[u] = ld4(m.h[(u >> 1) & 3] + (u & 1) * 16, (u >> 3) ? offV : offU);
+    b4[u] = ld4(P + m.off_l1w + u * 16, offW);
   }
   const float b1 = P[m.off_l1b + n], w2 = P[m.off_l2w + n];
   const float l2b = P[m.off_l2b];
   const float yv = (threadIdx.x < 16 && row0 + (int)threadIdx.x < B) ? b.y[row0 + threadIdx.x] : 0.f;
-  // d feat = dz @ lin1.weight: column tile nt = wave + 8 it; its 32 x 4 weight values and (tiles 6, 7 of a side = the top
-  // layer's slice of the concatenation) h_3 of the target rows
+  // d feat = dz @ lin1.weight: column tile nt = wave + 8 it (< 16: inside the conv features); its 32 x 4 weight values
+  // and (tiles 6, 7 of a side = the top layer's slice of the concatenation) h_3 of the target rows
   float bvp[2][8][4];
   float hvp[2][4];
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int c0 = (wave + 8 * it) * 16;
-    const bool on = c0 < 256;
+    const uint32_t offB = ((uint32_t)(4 * kq) * (uint32_t)D + (uint32_t)(c0 + li)) * 4u;
 #pragma unroll
     for (int u = 0; u < 8; ++u)
 #pragma unroll
-      for (int mm = 0; mm < 4; ++mm)
-        bvp[it][u][mm] = (c0 < D) ? P[m.off_l1w + (int64_t)(u * 16 + 4 * kq + mm) * D + c0 + li] : 0.f;
+      for (int mm = 0; mm < 4; ++mm) bvp[it][u][mm] = ld1(P + m.off_l1w + (size_t)(u * 16 + mm) * D, offB);
     const int k = c0 + li;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       hvp[it][rr] = 0.f;
-      if (on && ((k >> 5) & 3) == 3) hvp[it][rr] = m.h[3][(size_t)((k >> 7) ? nv_e[rr] : nu_e[rr]) * 32 + (k & 31)];
+      if (((k >> 5) & 3) == 3) hvp[it][rr] = ld1(m.h[3], ((uint32_t)((k >> 7) ? nv_e[rr] : nu_e[rr]) * 32u + (uint32_t)(k & 31)) * 4u);
     }
   }
   for (int s0 = 0; s0 < nch; s0 += 16) {
