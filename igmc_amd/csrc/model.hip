@@ -1506,17 +1506,37 @@ __device__ __forceinline__ void head_bwd_w_body(const BatchDev& b, const ModelDe
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 accb1 = acc, accw2 = acc, accb2 = acc;
   for (int g0 = 0; g0 < B; g0 += 32) {            // 8 MFMA steps (32 graphs) of loads in flight
+    // every operand of the 8 steps is requested before the first use, at clamped addresses (a predicated load is a branch
+    // and a wait; lmask -> a1 was a dependent pair): the wave with the extra products sits on the critical path of the
+    // launch (k_tail_ts / k_wgrad_head), 32 serial round trips before
     float av[8], bv[8], ad[8], dpv[8];
+    uint32_t mk[8];                     // (one register each: packed bytes would need every value right after its load)
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int g = g0 + 4 * u + kq;
-      const bool ok = g < B;
-      const int gs = ok ? g : 0;
-      av[u] = ok ? m.dz[gs * 128 + j0 + li] : 0.f;
-      bv[u] = ok ? m.feat[(size_t)gs * D + n0 + li] : 0.f;
+      const int gs = g < B ? g : B - 1;
+      av[u] = m.dz[gs * 128 + j0 + li];
+      bv[u] = m.feat[(size_t)gs * D + n0 + li];
+      dpv[u] = 0.f;
+      ad[u] = 0.f;
+      mk[u] = 0;
       if (extra) {
-        dpv[u] = ok ? (from_err ? 2.f * m.err[gs] * grad_scale : gout[gs]) * mult : 0.f;
-        ad[u] = (ok && m.lmask[gs * 128 + j0 + li]) ? m.a1[gs * 128 + j0 + li] * drop_scale : 0.f;
+        dpv[u] = from_err ? m.err[gs] : gout[gs];
+        ad[u] = m.a1[gs * 128 + j0 + li];
+        mk[u] = m.lmask[gs * 128 + j0 + li];
+      }
+    }
+#ifndef IGMC_HIPEMU
+    __builtin_amdgcn_sched_barrier(0);        // (keeps the uses below from being hoisted between the loads)
+    asm volatile("" : "+v"(mk[0]), "+v"(mk[1]), "+v"(mk[2]), "+v"(mk[3]), "+v"(mk[4]), "+v"(mk[5]), "+v"(mk[6]), "+v"(mk[7]));
+#endif
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool ok = g0 + 4 * u + kq < B;
+      if (!ok) { av[u] = 0.f; bv[u] = 0.f; }
+      if (extra) {
+        dpv[u] = ok ? (from_err ? 2.f * dpv[u] * grad_scale : dpv[u]) * mult : 0.f;
+        ad[u] = (ok && mk[u]) ? ad[u] * drop_scale : 0.f;
       }
     }
 #pragma unroll
@@ -1835,11 +1855,11 @@ __device__ __forceinline__ void adam_range(float* p, const float* g, float* m1, 
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
       const int64_t i = i0 + (int64_t)k * IGMC_BLOCK;
-      const bool in = i < hi;
-      gv[k] = in ? g[i] : 0.f;
-      pv[k] = in ? p[i] : 0.f;
-      av[k] = in ? m1[i] : 0.f;
-      vv[k] = in ? m2[i] : 0.f;
+      const int64_t ic = i < hi ? i : hi - 1;      // clamped, not predicated: the 4 NB loads go out back to back
+      gv[k] = g[ic];
+      pv[k] = p[ic];
+      av[k] = m1[ic];
+      vv[k] = m2[ic];
     }
 #pragma unroll
     for (int k = 0; k < NB; ++k) {

@@ -17,6 +17,6 @@ PY
 }
 ARGS="--config ml_100k"; run ml100k A=1
 ARGS="--config flixster"; run flixster A=1
-ARGS="--config yahoo_music"; run yahoo A=1
+ARGS=""; run ml1m_a A=1
 ARGS="--config ml_100k"; run ml100k_b A=1
 ARGS=""; run ml1m A=1
