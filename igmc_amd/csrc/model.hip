@@ -1612,11 +1612,32 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_partials(ModelDev m, int 
     if (o < nout) {
       if (secA) {
         const int l = o / wgs, i = o % wgs;
+        // 16 partials of a wave per round trip (clamped addresses; same order of additions)
         const float* p = m.wg_part + (size_t)l * IGMC_WG_BLOCKS * wgs + i;
-        for (int k = wave; k < n_wg_parts; k += 4) s += p[(size_t)k * wgs];
+        for (int k0 = wave; k0 < n_wg_parts; k0 += 64) {
+          float v[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const int k = k0 + 4 * u;
+            v[u] = p[(size_t)(k < n_wg_parts ? k : n_wg_parts - 1) * wgs];
+          }
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            if (k0 + 4 * u < n_wg_parts) s += v[u];
+        }
       } else {
         const float* p = m.l0_part + o;
-        for (int k = wave; k < IGMC_L0_BLOCKS; k += 4) s += p[(size_t)k * n0];
+        for (int k0 = wave; k0 < IGMC_L0_BLOCKS; k0 += 64) {
+          float v[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const int k = k0 + 4 * u;
+            v[u] = p[(size_t)(k < IGMC_L0_BLOCKS ? k : IGMC_L0_BLOCKS - 1) * n0];
+          }
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            if (k0 + 4 * u < IGMC_L0_BLOCKS) s += v[u];
+        }
       }
     }
     sred[wave][lane] = s;
@@ -1638,7 +1659,17 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_partials(ModelDev m, int 
       const int l = o / na, i = o % na;
       const float* p = m.gatt_part + (size_t)l * IGMC_GATHER_BLOCKS * na + i;
       float s = 0.f;
-      for (int k = lane; k < n_gatt_parts; k += 64) s += p[(size_t)k * na];
+      for (int k0 = lane; k0 < n_gatt_parts; k0 += 64 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int k = k0 + 64 * u;
+          v[u] = p[(size_t)(k < n_gatt_parts ? k : n_gatt_parts - 1) * na];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (k0 + 64 * u < n_gatt_parts) s += v[u];
+      }
       s = igmc_wave_sum_f(s);
       if (lane == 0) m.graw[3 * wgs + o] = s;
     }
@@ -2129,14 +2160,56 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
     // (a thread of this very workgroup: nE <= 256) updates it -> formed first, then a barrier
     __shared__ float s_gatt0[128];
     if (bs && l == 0) {
-      if (part == 0) {          // one wave per entry, lanes over the nE elements, fixed order
+      if (part == 0) {
+        // a thread owns element e = tid (strided by the workgroup for fin > 8) of every product: the R table values and
+        // the 4 basis values of e requested together, the na = 4 R wave sums taken side by side (a round trip and six
+        // crossbar steps in all; entry after entry it was 5 dependent rounds of both), waves combined in fixed order
+        __shared__ float s_gpart[IGMC_BLOCK / 64][32];
         const int lane = tid & 63, wave = tid >> 6;
-        for (int rb = wave; rb < na; rb += IGMC_BLOCK / 64) {
-          const int r = rb >> 2, bb = rb & 3;
-          float sacc = 0.f;
-          for (int e = lane; e < nE; e += 64) sacc += t0[(size_t)r * nE + e] * P[m.off_basis[0] + (int64_t)bb * nE + e];
-          sacc = igmc_wave_sum_f(sacc);
-          if (lane == 0) s_gatt0[rb] = sacc;
+        if (R <= 8) {
+          float acc[32];
+#pragma unroll
+          for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+          for (int e0 = 0; e0 < nE; e0 += IGMC_BLOCK) {
+            const int e = e0 + tid, ec = e < nE ? e : nE - 1;
+            float tv[8], bq[4];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) tv[r] = t0[(size_t)(r < R ? r : R - 1) * nE + ec];
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) bq[bb] = P[m.off_basis[0] + (int64_t)bb * nE + ec];
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+#pragma unroll
+              for (int bb = 0; bb < 4; ++bb)
+                if (r < R && e < nE) acc[r * 4 + bb] += tv[r] * bq[bb];
+          }
+#pragma unroll
+          for (int d = 32; d >= 1; d >>= 1) {
+            float t[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) t[i] = __shfl_xor(acc[i], d, 64);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) acc[i] += t[i];
+          }
+          if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) s_gpart[wave][i] = acc[i];
+          }
+          __syncthreads();
+          if (tid < na) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int w = 0; w < IGMC_BLOCK / 64; ++w) sacc += s_gpart[w][tid];
+            s_gatt0[tid] = sacc;
+          }
+        } else {                  // more than 8 relations: one wave per entry, lanes over the nE elements
+          for (int rb = wave; rb < na; rb += IGMC_BLOCK / 64) {
+            const int r = rb >> 2, bb = rb & 3;
+            float sacc = 0.f;
+            for (int e = lane; e < nE; e += 64) sacc += t0[(size_t)r * nE + e] * P[m.off_basis[0] + (int64_t)bb * nE + e];
+            sacc = igmc_wave_sum_f(sacc);
+            if (lane == 0) s_gatt0[rb] = sacc;
+          }
         }
       }
       __syncthreads();
