@@ -32,8 +32,12 @@ def cpu_budget():
 
 def limit_host_threads(max_threads=4):
     """Size the OpenMP / BLAS pools of this process for a GPU-driving process: at most ``max_threads`` and at most a
-    quarter of the CPU budget.  Respects values the user already exported.  Returns the thread count chosen."""
-    nt = max(1, min(int(max_threads), cpu_budget() // 4 or 1))
+    quarter of this rank's share of the CPU budget.  Respects values the user already exported.  Returns the thread count chosen."""
+    try:        # one process per GPU: the ranks of this node share the budget
+        ranks = max(1, int(os.environ.get('LOCAL_WORLD_SIZE') or os.environ.get('WORLD_SIZE') or 1))
+    except ValueError:
+        ranks = 1
+    nt = max(1, min(int(max_threads), cpu_budget() // (4 * ranks) or 1))
     for k in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'NUMEXPR_NUM_THREADS'):
         os.environ.setdefault(k, str(nt))
     return int(os.environ['OMP_NUM_THREADS'])

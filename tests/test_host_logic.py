@@ -249,7 +249,11 @@ def test_host_cpu_budget_and_thread_limit(tmp_path):
             "n = hostcpu.cpu_budget(); assert 1 <= n <= (os.cpu_count() or 1)\n"
             "t = hostcpu.limit_host_threads(); assert 1 <= t <= 4 and os.environ['OMP_NUM_THREADS'] == str(t)\n"
             "os.environ['OMP_NUM_THREADS'] = '7'; assert hostcpu.limit_host_threads() == 7\n"
-            "print('ok', n, t)\n" % ROOT)
+            "for k in list(os.environ):\n"
+            "    if k.endswith('_NUM_THREADS'): del os.environ[k]\n"
+            "os.environ['LOCAL_WORLD_SIZE'] = '8'      # eight ranks share the node's budget\n"
+            "t8 = hostcpu.limit_host_threads(); assert 1 <= t8 <= max(1, n // 32)\n"
+            "print('ok', n, t, t8)\n" % ROOT)
     env = {k: v for k, v in os.environ.items() if not k.endswith('_NUM_THREADS')}
     r = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0 and r.stdout.decode().startswith('ok'), r.stdout.decode()
