@@ -620,7 +620,8 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   d.datt_part = nullptr;
   if (d.R <= 5)
     fail |= M.get(&d.ts_part, (size_t)4 * IGMC_TS_BLOCKS * d.ts_stride) | M.get(&d.ts_raw, (size_t)4 * d.ts_stride) |
-            M.get(&d.fin_stash, (size_t)4 * 256 + 16) | M.get(&d.datt_part, (size_t)4 * d.ts_stride / 32 * 4);
+            M.get(&d.datt_part, (size_t)4 * d.ts_stride / 32 * 4);
+  if (d.R <= 32) fail |= M.get(&d.fin_stash, (size_t)4 * 256 + 16);     // weights-only stash of k_finalize_ts (both modes)
   d.gs_ll = nullptr;
   d.gs_ll_stride = N * 32;
   if (d.R <= 5) fail |= M.get(&d.gs_ll, 5 * d.gs_ll_stride);

@@ -3,7 +3,9 @@
 #include "common.h"
 
 #define IGMC_KCAT 160     // (num_bases + 1) * 32 : [basis-space aggregate | self] width
-#define IGMC_WG_BLOCKS 64    // grid.x of the weight-gradient kernel (per-block partials, per layer); 128: +5 us in the reduction, 32: +9 us in the products
+#ifndef IGMC_WG_BLOCKS
+#define IGMC_WG_BLOCKS 64    // grid.x of the weight-gradient kernel (per-block partials, per layer); 128: ml_100k +1.7 %, flixster -2 %; 32: +9 us in the products
+#endif
 #define IGMC_TS_BLOCKS 256   // partial slots of the relation-space tables (one per workgroup of k_graph_step)
 #define IGMC_GATHER_BLOCKS 4096   // max grid of the row-walker kernels (4 rows = 4 waves per block)
 #define IGMC_L0_BLOCKS 256

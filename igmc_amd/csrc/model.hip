@@ -2701,10 +2701,11 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
   {
     const int wgs2 = igmc_wg_stride(), n0 = rows0 * 32, na = m.R * 4;
     const int nblk = (nsl * wgs2 + 63) / 64 + (l0_mfma ? 0 : (n0 + 63) / 64) + (3 * na + 3) / 4;
-    // gradient / Adam tail without hand-offs (k_finalize_ts in basis-space mode) where the stash fits: R <= 32 and the
-    // layer-0 table inside the MFMA weight-gradient kernel; IGMC_FIN_MODE=0: the hand-off version (k_finalize)
+    // gradient / Adam tail without hand-offs (k_finalize_ts in basis-space mode) where the stash fits: R <= 32 (the
+    // layer-0 table comes from the MFMA weight-gradient kernel or from k_l0_bwd's partials: same place, same layout);
+    // IGMC_FIN_MODE=0: the hand-off version (k_finalize)
     const char* fe = getenv("IGMC_FIN_MODE");
-    const int fbs = (fe ? atoi(fe) : 1) && m.fin_stash && m.R <= 32 && l0_mfma;
+    const int fbs = (fe ? atoi(fe) : 1) && m.fin_stash && m.R <= 32;
     IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk + (fbs ? 4 : 0), IGMC_BLOCK, 0, stream, m, gl, l0_mfma,
                  IGMC_WG_BLOCKS, (const float*)P, (const int64_t*)(adam ? at.ctrl : nullptr), fbs ? 4 : 0);
     if (fbs) {
