@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel trace of BASELINE config 2 (ml_100k, cap 200) under graph replay
+# kernel trace of BASELINE config 2 (was tools/gpu_call_s.sh) (ml_100k, cap 200) under graph replay
 set -u
 ROOT=$(pwd); export TMPDIR=/tmp; mkdir -p $ROOT/gpurun_out/s
 BENCH="python $ROOT/bench.py --config ml_100k --steps 100 --warmup 10 --no-cpu-baseline --profile-steps 0 --rmse-links 0 --dp-steps 0"
