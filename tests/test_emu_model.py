@@ -250,7 +250,8 @@ def test_free_running_dropout_on_a_lean_arena(be, force_undirected):
 
 
 @pytest.mark.parametrize('name,n,drop', [('synth_cap', 6, True), ('synth_nocap:100', 4, True), ('synth_nocap:100', 4, False),
-                                         ('hand', 5, True), ('douban:100', 6, False)])
+                                         ('hand', 5, True), ('douban:100', 6, False),
+                                         ('synth_nocap:200', 4, True)])      # > 128 rows a side: two workgroups per side
 @pytest.mark.parametrize('lean', [False, True])
 def test_dense_per_layer_kernels(be, monkeypatch, name, n, drop, lean):
     """k_dl_layer (graphstep2.hip): the conv layers of the per-layer sequence on the matrix cores, for arenas whose slots
@@ -263,6 +264,11 @@ def test_dense_per_layer_kernels(be, monkeypatch, name, n, drop, lean):
     res = PC.run_model_parity(be, sub(name, n), R=5, use_dropout=drop, lean=lean)
     assert res['worst_grad_err'] < 1e-4
     assert res['batch'].dense_layers(res['ws'])
+    if name.endswith(':200'):
+        d = res['d']
+        sizes = np.diff(np.asarray(d['node_off']))
+        nu = np.asarray(d['n_users'])
+        assert max(nu.max(), (sizes - nu).max()) > 128, 'this case is meant to need a second workgroup per side'
 
 
 def test_dense_per_layer_kernels_in_the_fused_train_step(be, monkeypatch):
