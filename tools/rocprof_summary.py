@@ -4,6 +4,7 @@
 
 kernel trace : calls / avg / min / max / share per kernel   (rocprofv3 --kernel-trace --stats)
 --pmc        : per-kernel average of every collected counter per dispatch (rocprofv3 --pmc ...)
+--timeline   : start / end of every dispatch (ns from the first one), ascending
 """
 import glob
 import os
@@ -64,12 +65,25 @@ def pmc(con):
         print('%-46s %s' % (k[:46], '  '.join(items)))
 
 
+def timeline(con):
+    """--timeline: every kernel dispatch as 'start_ns end_ns name' (ascending start), for gap analysis."""
+    tabs = names(con, 'table') + names(con, 'view')
+    disp, sym = first(tabs, 'rocpd_kernel_dispatch'), first(tabs, 'rocpd_info_kernel_symbol')
+    rows = con.execute('select d.start, d.end, s.kernel_name from %s d join %s s on d.kernel_id = s.id order by d.start'
+                       % (disp, sym)).fetchall()
+    t0 = rows[0][0] if rows else 0
+    for a, b, n in rows:
+        print('%d %d %s' % (a - t0, b - t0, n.split('(')[0][:40]))
+
+
 def main():
     if len(sys.argv) < 2:
         raise SystemExit(__doc__)
     con = sqlite3.connect(find_db(sys.argv[1]))
     if '--pmc' in sys.argv:
         pmc(con)
+    elif '--timeline' in sys.argv:
+        timeline(con)
     else:
         kernel_stats(con)
 
