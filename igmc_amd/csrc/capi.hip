@@ -838,6 +838,18 @@ extern "C" int igmc_ctrl_tick(int64_t* d_ctrl, void* stream) {
   HIPCHECK(hipGetLastError());
   return 0;
 }
+extern "C" int igmc_batch_gate(igmc_batch* b, int parity, void* stream) {
+  if (!b || !b->ctrl) IGMC_FAIL("igmc_batch_gate: no control block attached");
+  igmc_launch_gate(const_cast<int64_t*>(b->ctrl), parity & 1, stream);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+extern "C" int igmc_batch_mark_ready(igmc_batch* b, int parity, void* stream) {
+  if (!b || !b->ctrl) IGMC_FAIL("igmc_batch_mark_ready: no control block attached");
+  igmc_launch_mark_ready(const_cast<int64_t*>(b->ctrl), parity & 1, stream);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
 extern "C" int igmc_batch_set_ctrl(igmc_batch* b, const int64_t* d_ctrl) {
   if (!b) IGMC_FAIL("null batch");
   b->ctrl = d_ctrl;

@@ -981,6 +981,38 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_side_gather(const float* src, in
   }
 }
 
+// Free-running prefetch (igmc_hip.h, device-side step control): one-thread kernels on the extraction stream.
+// k_gate_consumed: the arena of `parity` may be overwritten once the step that consumed its batch has advanced the cursor.
+#define IGMC_SYNC_SPINS 4000000
+__global__ void k_gate_consumed(int64_t* ctrl, int parity) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int cs = parity ? IGMC_CTRL_FIRST_ODD : IGMC_CTRL_FIRST, rs = IGMC_CTRL_READY + parity;
+#ifndef IGMC_HIPEMU
+  int n = 0;
+  while (__hip_atomic_load((long long*)ctrl + cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+         __hip_atomic_load((long long*)ctrl + rs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+    __builtin_amdgcn_s_sleep(8);
+    if (++n > IGMC_SYNC_SPINS) {
+      __hip_atomic_store((long long*)ctrl + IGMC_CTRL_SYNC_ERR, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+#else
+  (void)cs; (void)rs;
+#endif
+}
+__global__ void k_mark_ready(int64_t* ctrl, int parity) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int cs = parity ? IGMC_CTRL_FIRST_ODD : IGMC_CTRL_FIRST, rs = IGMC_CTRL_READY + parity;
+#ifndef IGMC_HIPEMU
+  __hip_atomic_store((long long*)ctrl + rs, (long long)ctrl[cs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  ctrl[rs] = ctrl[cs];
+#endif
+}
+void igmc_launch_gate(int64_t* ctrl, int parity, void* stream) { IGMC_PLAUNCH("k_gate_consumed", k_gate_consumed, 1, 64, 0, stream, ctrl, parity); }
+void igmc_launch_mark_ready(int64_t* ctrl, int parity, void* stream) { IGMC_PLAUNCH("k_mark_ready", k_mark_ready, 1, 64, 0, stream, ctrl, parity); }
+
 void igmc_launch_side_gather(const float* src, int S, const int32_t* link_idx, int first, int B, const int64_t* ctrl,
                              float* dst, void* stream) {
   int grid = (B * S + IGMC_BLOCK - 1) / IGMC_BLOCK;

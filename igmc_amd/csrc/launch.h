@@ -19,6 +19,8 @@ void igmc_launch_relm_flags(const BatchDev& b, void* stream);
 void igmc_launch_relm_dropout(const BatchDev& b, int B, float p, int force_undirected, uint64_t seed, uint64_t step,
                               const int64_t* ctrl, void* stream);
 void igmc_launch_tick(int64_t* ctrl, void* stream);
+void igmc_launch_gate(int64_t* ctrl, int parity, void* stream);
+void igmc_launch_mark_ready(int64_t* ctrl, int parity, void* stream);
 void igmc_launch_fill_u8(uint8_t* p, int64_t n, uint8_t v, void* stream);
 int igmc_extract_prepare(size_t smem);
 

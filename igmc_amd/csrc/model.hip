@@ -2299,7 +2299,29 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
     adam_range<8>(at.p, grad, at.m1, at.m2, lo, hi, at.step_size, at.inv_sqrt_bc2, at.beta1, at.beta2, at.eps, at.wd);
   } else {                                                     // loss, epoch total, control-block tick
     loss_body(at.b, m, at.ARR, at.loss, at.total, smf);
-    if (tid == 0 && at.ctrl) ctrl_advance(at.ctrl);
+    if (tid == 0 && at.ctrl) {
+      const int64_t k = at.ctrl[IGMC_CTRL_K];
+      const bool free_run = at.ctrl[IGMC_CTRL_FREE_RUN] != 0;
+      ctrl_advance(at.ctrl);
+#ifndef IGMC_HIPEMU
+      if (free_run) {
+        // free-running prefetch (igmc_hip.h): the next step's batch must sit in its arena before this step ends -- there
+        // is no stream dependency behind this kernel that would wait for the extraction chain
+        const int pn = (int)((k + 1) & 1);
+        const long long want = (long long)at.ctrl[pn ? IGMC_CTRL_FIRST_ODD : IGMC_CTRL_FIRST];
+        int n = 0;
+        while (__hip_atomic_load((long long*)at.ctrl + IGMC_CTRL_READY + pn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++n > 4000000) {
+            __hip_atomic_store((long long*)at.ctrl + IGMC_CTRL_SYNC_ERR, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+#else
+      (void)k; (void)free_run;
+#endif
+    }
   }
 }
 

@@ -25,9 +25,11 @@ import torch
 from . import _lib, parallel
 
 
-def _ctrl_words(step, first, epoch, adam_t, batch, lr, beta1, beta2, eps, wd):
+def _ctrl_words(step, first, epoch, adam_t, batch, lr, beta1, beta2, eps, wd, free_run=False):
     """Control block describing the NEXT step to run (the step's last kernel advances it)."""
     w = np.zeros(_lib.CTRL['WORDS'], dtype=np.int64)
+    w[_lib.CTRL['FREE_RUN']] = 1 if free_run else 0
+    w[_lib.CTRL['READY']] = w[_lib.CTRL['READY_ODD']] = -1      # no batch sits in either arena yet
     w[_lib.CTRL['STEP']], w[_lib.CTRL['FIRST']], w[_lib.CTRL['EPOCH']] = step, first, epoch
     w[_lib.CTRL['FIRST_ODD']], w[_lib.CTRL['K']] = first + batch, 0     # batch k starts at slot[k & 1]
     w[_lib.CTRL['ADAM_T']], w[_lib.CTRL['BATCH']] = adam_t, batch
@@ -77,6 +79,17 @@ class StepGraph(object):
         # replay.  Opt-in: a captured collective could not be validated on more than one GPU where this was written.
         self.dp_capture = os.environ.get('IGMC_DP_CAPTURE_ALLREDUCE', '0') == '1'
         self.side = torch.cuda.Stream(device=self.dev) if overlap else None
+        # Free-running prefetch (igmc_hip.h, device-side step control): inside a multi-step graph the model chain and the
+        # extraction chain are forked ONCE and joined ONCE; per step they hand-shake through the control block (the fused
+        # step's last kernel waits for ready[next parity], a gate kernel in front of each extraction waits for the cursor
+        # of its arena to move).  A cross-stream dependency of a hipGraph resolves ~9 us after its producer has finished
+        # (profiles/r02_step_timeline.txt): per step that was the whole gap budget of the main chain.
+        self.free_run = bool(
+            self.side is not None and use_graph and not self.dp_path
+            and os.environ.get('IGMC_FREE_RUN', '0') == '1'
+            and os.environ.get('IGMC_FIN_MODE', '1') != '0'
+            and os.environ.get('IGMC_MAIN_FIRST', '1') == '1'
+            and all(self.ws.dense_path(a, self.B) for a in self.arenas))
         self.graphs = [None, None]
         # several steps in ONE graph launch: consecutive launches of a replayed graph are separated by a gap of tens of
         # microseconds on the device, a sizeable part of a ~200 us step (IGMC_GRAPH_STEPS, even, 0 disables)
@@ -117,6 +130,8 @@ class StepGraph(object):
                           self.perm.data_ptr(), slot, B, self.ds.sample_ratio, self.ds.seed, 0, st)
         if m.adj_dropout > 0:
             arena.edge_dropout(m.adj_dropout, m.force_undirected, m.seed, slot, st)
+        if self.free_run:
+            self.lib.call('igmc_batch_mark_ready', arena.handle, int(slot) & 1, C.c_void_p(st))
 
     def begin_epoch(self, perm, epoch):
         """``perm``: this rank's link positions for the epoch (1-D int tensor, any device)."""
@@ -125,7 +140,7 @@ class StepGraph(object):
         self.perm[n:n + 2 * self.B].copy_(self.perm[:2 * self.B] if n >= 2 * self.B else self.perm[n - 1].expand(2 * self.B))
         g = self.opt.param_groups[0]
         w = _ctrl_words(self.model._step + 1, 0, epoch if self.ds.dynamic else 0, self.opt.t + 1, self.B, g['lr'],
-                        g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'])
+                        g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], free_run=self.free_run)
         self.ctrl.copy_(torch.from_numpy(w))
         self.total.zero_()
         self.n_links = n
@@ -205,6 +220,22 @@ class StepGraph(object):
         if with_finish and not fused:
             self._finish(cur)
 
+    def _enqueue_free_running(self, M):
+        """M fused steps (starting at an even step) and the M extractions they prefetch as two chains with ONE fork and ONE
+        join: step i runs on arena i % 2, the side chain extracts batch i + 1 into arena (i + 1) % 2 behind a gate that
+        waits for step i - 1 to have consumed that arena (free-running prefetch, igmc_hip.h)."""
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)
+        for i in range(M):
+            self._train_step(self.arenas[i % 2])
+        with torch.cuda.stream(self.side):
+            st = torch.cuda.current_stream().cuda_stream
+            for i in range(M):
+                p = (i + 1) % 2
+                self.lib.call('igmc_batch_gate', self.arenas[p].handle, p, C.c_void_p(st))
+                self._extract(self.arenas[p], p, self.B)
+        main.wait_stream(self.side)
+
     def _capture(self, parity):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -276,6 +307,11 @@ class StepGraph(object):
     def _capture_multi(self):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
+        if self.free_run:
+            with torch.cuda.graph(g):
+                self._enqueue_free_running(self.multi_n)
+            self.multi = g
+            return
         if self.world <= 1 and not (self.dp_path and parallel.is_dist()):
             with torch.cuda.graph(g):
                 for i in range(self.multi_n):
@@ -356,3 +392,6 @@ class StepGraph(object):
     def check(self):
         """Raises if a bounded device-side wait of the step kernels timed out (synchronises the stream)."""
         self.lib.call('igmc_model_check', self.ws.handle, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if self.free_run and int(self.ctrl[_lib.CTRL['SYNC_ERR']].item()) != 0:
+            raise RuntimeError('a bounded wait of the free-running prefetch timed out (GPU shared with another job?): '
+                               'results of the affected steps are invalid; set IGMC_FREE_RUN=0')

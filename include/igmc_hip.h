@@ -198,8 +198,21 @@ int igmc_adam_step(float* d_params, const float* d_grad, float* d_exp_avg, float
 enum { IGMC_CTRL_STEP = 0, IGMC_CTRL_FIRST = 1, IGMC_CTRL_EPOCH = 2, IGMC_CTRL_ADAM_T = 3, IGMC_CTRL_BATCH = 4,
        IGMC_CTRL_DONE = 5, IGMC_CTRL_FIRST_ODD = 6, IGMC_CTRL_K = 7,
        IGMC_CTRL_LR = 8, IGMC_CTRL_BETA1 = 9, IGMC_CTRL_BETA2 = 10, IGMC_CTRL_EPS = 11, IGMC_CTRL_WD = 12,
-       IGMC_CTRL_STEP_SIZE = 13, IGMC_CTRL_INV_SQRT_BC2 = 14, IGMC_CTRL_WORDS = 16 };
+       IGMC_CTRL_STEP_SIZE = 13, IGMC_CTRL_INV_SQRT_BC2 = 14, IGMC_CTRL_FREE_RUN = 15, IGMC_CTRL_READY = 16,
+       IGMC_CTRL_READY_ODD = 17, IGMC_CTRL_SYNC_ERR = 18, IGMC_CTRL_WORDS = 24 };
 int igmc_ctrl_tick(int64_t* d_ctrl, void* stream);
+/* Free-running prefetch (no reference counterpart).  With [15] free_run != 0 the model chain and the extraction chain
+ * of a multi-step graph need no stream dependency per step; they hand-shake through the control block itself:
+ *   [16] ready_even / [17] ready_odd = `first` of the batch that sits completely extracted in the arena of that parity;
+ *   igmc_batch_mark_ready(b, parity) (enqueue it behind the extraction [+ edge dropout] of that arena) sets
+ *        ready[parity] = slot[parity];
+ *   igmc_batch_gate(b, parity) (enqueue it in front of the NEXT extraction into that arena) waits until
+ *        slot[parity] != ready[parity], i.e. until the step that consumed the arena's batch has advanced the cursor;
+ *   the last kernel of a fused training step (igmc_train_step) waits until ready[(k+1) & 1] == slot[(k+1) & 1] before it
+ *        ends, so the next step's kernels find their batch in place.
+ * Waits are bounded; a wait that runs out sets [18] sync_err (the host checks it with the stream synchronised). */
+int igmc_batch_gate(igmc_batch* b, int parity, void* stream);
+int igmc_batch_mark_ready(igmc_batch* b, int parity, void* stream);
 int igmc_batch_set_ctrl(igmc_batch* b, const int64_t* d_ctrl);
 int igmc_model_set_ctrl(igmc_model* m, const int64_t* d_ctrl);
 /* Adam + loss/epoch-total epilogue in ONE launch (the step's last kernel): updates d_params like

@@ -206,3 +206,43 @@ def test_training_steps_survive_a_competing_full_chip_kernel(ml1m):
         out[mode] = model.flat_parameters().detach().cpu().clone()
         del stop
     assert torch.equal(out['quiet'], out['loaded'])
+
+
+@pytest.mark.parametrize('drop', [0.0, 0.2])
+def test_free_running_prefetch_walks_the_same_trajectory(ml1m, monkeypatch, drop):
+    """IGMC_FREE_RUN=1: inside a multi-step graph the model chain and the extraction chain are forked once and joined once
+    and hand-shake through the control block (gate kernel / ready words / wait at the end of the fused step) instead of
+    through two stream dependencies per step.  Same kernels on the same batches: parameters, Adam state and epoch totals
+    must be bit-identical to the fork / join structure, over two epochs of 24 steps (3 graph launches of 8 each), and no
+    bounded wait may run out."""
+    import torch
+    from igmc_amd.models import IGMC
+    from igmc_amd.stepgraph import StepGraph
+    from igmc_amd.train_eval import FlatAdam
+    from igmc_amd.util_functions import MyDynamicDataset
+    A, cv = ml1m['A'], ml1m['class_values']
+    rng = np.random.default_rng(11)
+    coo = A.tocoo()
+    pick = rng.permutation(coo.nnz)[:1200]
+    u, v, y = coo.row[pick], coo.col[pick], (coo.data[pick] - 1).astype(np.int64)
+    ds = MyDynamicDataset('data/t/freerun', A, (u, v), y, 1, 1.0, 100, None, None, cv, device=0, seed=1)
+    perm = torch.randperm(len(ds), generator=torch.Generator().manual_seed(5))
+    out = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('IGMC_FREE_RUN', mode)
+        torch.manual_seed(3)
+        model = IGMC(ds, latent_dim=[32, 32, 32, 32], num_relations=5, num_bases=4, regression=True, adj_dropout=drop,
+                     seed=1).to('cuda')
+        model.reset_parameters()
+        opt = FlatAdam(model, lr=1e-3)
+        sg = StepGraph(model, opt, ds, 50, 0.001)
+        assert sg.ws.dense_path(sg.arenas[0], 50) and sg.free_run == (mode == '1')
+        t1, n1 = sg.run_epoch(perm, 1)
+        t1 = float(t1.item())
+        t2, _ = sg.run_epoch(perm, 2)
+        torch.cuda.synchronize()
+        assert sg.multi is not None and n1 == 1200 and opt.t == 48
+        out[mode] = (model.flat_parameters().detach().cpu().clone(), opt.exp_avg.detach().cpu().clone(),
+                     opt.exp_avg_sq.detach().cpu().clone(), t1, float(t2.item()))
+    for a, b in zip(out['0'], out['1']):
+        assert (torch.equal(a, b) if torch.is_tensor(a) else a == b)
