@@ -86,7 +86,7 @@ class StepGraph(object):
         # (profiles/r02_step_timeline.txt): per step that was the whole gap budget of the main chain.
         self.free_run = bool(
             self.side is not None and use_graph and not self.dp_path
-            and os.environ.get('IGMC_FREE_RUN', '0') == '1'
+            and os.environ.get('IGMC_FREE_RUN', '1') == '1'
             and os.environ.get('IGMC_FIN_MODE', '1') != '0'
             and os.environ.get('IGMC_MAIN_FIRST', '1') == '1'
             and all(self.ws.dense_path(a, self.B) for a in self.arenas))
