@@ -82,14 +82,17 @@ class StepGraph(object):
         # Free-running prefetch (igmc_hip.h, device-side step control): inside a multi-step graph the model chain and the
         # extraction chain are forked ONCE and joined ONCE; per step they hand-shake through the control block (the fused
         # step's last kernel waits for ready[next parity], a gate kernel in front of each extraction waits for the cursor
-        # of its arena to move).  A cross-stream dependency of a hipGraph resolves ~9 us after its producer has finished
+        # of its arena to move).  Paths whose fused step ends in k_finalize_ts: the subgraph kernel and the dense per-layer
+        # kernels.  A cross-stream dependency of a hipGraph resolves ~9 us after its producer has finished
         # (profiles/r02_step_timeline.txt): per step that was the whole gap budget of the main chain.
         self.free_run = bool(
             self.side is not None and use_graph and not self.dp_path
             and os.environ.get('IGMC_FREE_RUN', '1') == '1'
             and os.environ.get('IGMC_FIN_MODE', '1') != '0'
             and os.environ.get('IGMC_MAIN_FIRST', '1') == '1'
-            and all(self.ws.dense_path(a, self.B) for a in self.arenas))
+            # (the fused step must END in k_finalize_ts, the kernel that holds the wait: readout width a multiple of 16)
+            and int(getattr(getattr(model, 'lin1', None), 'in_features', 0)) % 16 == 0
+            and all(self.ws.dense_path(a, self.B) or a.dense_layers(self.ws) for a in self.arenas))
         self.graphs = [None, None]
         # several steps in ONE graph launch: consecutive launches of a replayed graph are separated by a gap of tens of
         # microseconds on the device, a sizeable part of a ~200 us step (IGMC_GRAPH_STEPS, even, 0 disables)
