@@ -246,3 +246,35 @@ def test_free_running_prefetch_walks_the_same_trajectory(ml1m, monkeypatch, drop
                      opt.exp_avg_sq.detach().cpu().clone(), t1, float(t2.item()))
     for a, b in zip(out['0'], out['1']):
         assert (torch.equal(a, b) if torch.is_tensor(a) else a == b)
+
+
+def test_free_running_prefetch_on_the_dense_per_layer_path(monkeypatch):
+    """... and where the dense per-layer kernels take the step (config 2 shape: ml_100k, cap 200, edge dropout 0.2): the
+    fused per-layer sequence ends in the same k_finalize_ts, so the same hand-shake applies."""
+    import torch
+    from igmc_amd import preprocessing
+    from igmc_amd.models import IGMC
+    from igmc_amd.stepgraph import StepGraph
+    from igmc_amd.train_eval import FlatAdam
+    from igmc_amd.util_functions import MyDynamicDataset
+    (_, _, A, tr_l, tr_u, tr_v, _, _, _, _, _, _, cv) = preprocessing.create_trainvaltest_split('ml_100k', 1234, True, verbose=False)
+    pick = np.random.default_rng(3).permutation(len(tr_u))[:1000]
+    ds = MyDynamicDataset('data/t/frdl', A, (tr_u[pick], tr_v[pick]), np.asarray(tr_l)[pick], 1, 1.0, 200, None, None, cv,
+                          device=0, seed=1)
+    perm = torch.randperm(len(ds), generator=torch.Generator().manual_seed(5))
+    out = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('IGMC_FREE_RUN', mode)
+        torch.manual_seed(3)
+        model = IGMC(ds, latent_dim=[32, 32, 32, 32], num_relations=5, num_bases=4, regression=True, adj_dropout=0.2,
+                     seed=1).to('cuda')
+        model.reset_parameters()
+        opt = FlatAdam(model, lr=1e-3)
+        sg = StepGraph(model, opt, ds, 50, 0.001)
+        assert sg.arenas[0].dense_layers(sg.ws) and sg.free_run == (mode == '1')
+        sg.run_epoch(perm, 1)
+        t2, _ = sg.run_epoch(perm, 2)
+        torch.cuda.synchronize()
+        assert sg.multi is not None
+        out[mode] = (model.flat_parameters().detach().cpu().clone(), float(t2.item()))
+    assert torch.equal(out['0'][0], out['1'][0]) and out['0'][1] == out['1'][1]
