@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 ROOT=$(pwd)
 BENCH="python $ROOT/bench.py --config $CFG --steps 100 --warmup 10 --no-cpu-baseline --profile-steps 0 --rmse-links 0 --dp-steps 0"
 cd /tmp
-# Every pass below runs with IGMC_FREE_RUN=0 (fork / join per step): counter collection serialises the dispatches, which
+# Every pass below runs with IGMC_FREE_RUN=0 (the default anyway) (fork / join per step): counter collection serialises the dispatches, which
 # the free-running prefetch (two chains of one graph that wait for each other on the device) cannot survive, and under the
 # tracer its chains can fall into lock-step (profiles/r02_step_timeline.txt).  Same kernels either way.
 export IGMC_FREE_RUN=0
