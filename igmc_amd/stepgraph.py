@@ -85,7 +85,7 @@ class StepGraph(object):
         # of its arena to move).  Paths whose fused step ends in k_finalize_ts: the subgraph kernel and the dense per-layer
         # kernels.  A cross-stream dependency of a hipGraph resolves ~9 us after its producer has finished
         # (profiles/r02_step_timeline.txt): per step that was the whole gap budget of the main chain.
-        # OPT-IN (IGMC_FREE_RUN=1): +4 % at the headline, parameters bit-identical to the fork / join structure in 7 of 8
+        # OPT-IN (IGMC_FREE_RUN=1): +4 % at the headline, parameters bit-identical to the fork / join structure in 6 of 7
         # two-epoch comparisons on the GPU -- but ONE run of the edge-dropout variant diverged in the last GPU seconds of
         # round 2 and its cause is not found yet, so fork + join per step stays the default.
         self.free_run = bool(

@@ -209,7 +209,7 @@ def test_training_steps_survive_a_competing_full_chip_kernel(ml1m):
 
 
 FREE_RUN_TESTS = pytest.mark.skipif(__import__('os').environ.get('IGMC_TEST_FREE_RUN', '0') != '1',
-                                    reason='free-running prefetch is opt-in (IGMC_FREE_RUN=1): one of eight two-epoch '
+                                    reason='free-running prefetch is opt-in (IGMC_FREE_RUN=1): one of seven two-epoch '
                                            'comparisons diverged on the GPU (edge-dropout variant), cause open; '
                                            'IGMC_TEST_FREE_RUN=1 runs these')
 
