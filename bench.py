@@ -70,7 +70,9 @@ CONFIGS = {
     'flixster': dict(dataset='flixster', mnph=10000, adj_dropout=0.2, cpu='dynamic'),
     'yahoo_music': dict(dataset='yahoo_music', mnph=10000, adj_dropout=0.2, cpu='dynamic'),
 }
-PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
+# timer label of the HIP-event profile -> kernel symbol in the code object (what rocprofv3 lists)
+SYMBOLS = {'k_dl_layer_fwd': 'k_dl_layer<FLAGS, false>', 'k_rgcn_layer_fwd': 'k_rgcn_layer4<FLAGS, false>'}
 
 
 def kernel_source_sha():
@@ -281,29 +283,20 @@ def main():
             nsteps -= chunk
 
     # Warm-up = exactly W steps: one eager step (first launches load code objects, which a capture cannot do), then the
-    # graphs are captured and the other W - 1 steps REPLAY them, so that the graph the timed steps replay has been
-    # launched before t0 where the step counts allow it (the first launch of an instantiated hipGraph costs ~140 us more
-    # than the following ones, hipGraphUpload or not: profiles/r02_callB_graph_first_replay.txt).  Group size M (steps per
-    # graph launch, even, dividing K): estimated cost K/M * 15 us of launch gaps + 140 us if no warm-up group primes it.
+    # graph is captured (group size M with 2 M dividing K: a graph launch is a pair of groups = 2 M steps) and the other
+    # W - 1 steps replay it where they fill a launch, else they are launched eagerly.  (The first launch of an instantiated
+    # hipGraph costs ~140 us more than the following ones, hipGraphUpload or not: profiles/r02_callB_graph_first_replay.txt;
+    # with the driver's W = 5 it falls inside the timed region.)
     captured = False
-    if sg.use_graph and args.warmup >= 1 and sg.multi_n >= 2 and not sg.dp_path:
+    if sg.use_graph and args.warmup >= 1:
         run(1)
-        best = None
-        for M in range(2, 2 * sg.multi_base + 1, 2):
-            if args.steps % M:
-                continue
-            primed = (args.warmup - 1) >= M and (args.warmup - 1) % M == 0
-            cost = args.steps / M * 15.0 + (0.0 if primed else 140.0)
-            if best is None or cost < best[0]:
-                best = (cost, M)
-        state['i'] = 0                                   # fresh epoch: graph groups start at an even step index
         new_epoch_if_needed()
-        captured = sg.prepare(group=best[1]) if best else sg.prepare(steps_hint=args.steps)
+        captured = sg.prepare(steps_hint=args.steps)
         run(args.warmup - 1)
     else:
         run(args.warmup)
     new_epoch_if_needed()
-    captured = sg.prepare(steps_hint=None if captured else args.steps) or captured   # every graph exists before t0
+    captured = sg.prepare(steps_hint=args.steps) or captured      # aligned with the current position; graph exists before t0
     parallel.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -322,74 +315,120 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     value = args.steps * BATCH * world / dt
-    sg.check()                                          # no device-side wait timed out during the timed steps
+    sg.check()                                          # no device-side wait timed out, no stamp mismatch
     final_loss = float(sg.loss[0].item())
+    group_steps = sg.M
 
-    # ---- launch structure of a data-parallel step, measured on ONE GPU (no collective latency in it): the same steps
-    # with the multi-GPU structure forced -- graph{model || extraction} -> [all-reduce, absent at world 1] -> Adam launch,
-    # one graph launch per step -- and with IGMC_DP_CAPTURE_ALLREDUCE's structure (weight update inside the graph, 8 steps
-    # per launch).  dp_structure_us = what the eager tail costs per step before any RCCL latency.
+    # ---- data parallelism, self-validation (world > 1): the ranks RCCL sees on the library's communicator, equality of the
+    # replicas after the timed steps (every rank applied the same all-reduced gradients: parameter checksums must agree bit
+    # for bit), and the all-reduce alone timed on the step's stream
+    dp_check = None
+    if sg.comm is not None:
+        import ctypes as C
+        rk, ws_ = sg.comm.info()
+        flat = model.flat_parameters()
+        chk = torch.stack([flat.double().sum(), flat.double().abs().sum()])
+        lo, hi = chk.clone(), chk.clone()
+        if world > 1:
+            torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+            torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        scratch = torch.zeros_like(model.flat_grad())
+        for _ in range(5):
+            sg.comm.all_reduce_(scratch, st)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            sg.comm.all_reduce_(scratch, st)
+        e1.record()
+        torch.cuda.synchronize()
+        dp_check = dict(rccl_rank=rk, rccl_world=ws_, launcher_rank=rank, launcher_world=world,
+                        ranks_agree=bool(rk == rank and ws_ == world),
+                        replicas_identical=bool(torch.equal(lo, hi)), param_checksum=float(chk[0].item()),
+                        allreduce_us=e0.elapsed_time(e1) / 50 * 1e3, allreduce_floats=int(scratch.numel()),
+                        allreduce_in_graph=bool(sg.graph is not None))
+
+    # ---- launch structure of a data-parallel step, measured on ONE GPU: the same steps with the multi-GPU step forced --
+    # gradient kernels -> igmc_allreduce_grads on a ONE-RANK RCCL communicator -> Adam launch, captured into the same groups.
+    # dp_structure_us = what that structure costs per step over the fused single-GPU step (no inter-GPU latency in it).
     dp_structure = None
     if world == 1 and sg.use_graph and args.dp_steps > 0:
-        def timed_us(nsteps):
-            new_epoch_if_needed()
-            sg.prepare()
+        def timed_us(sgx, nsteps):
+            sgx.begin_epoch(perm, 1)
+            if sgx.steps_done < 1:
+                sgx.steps(1)
+            sgx.prepare(steps_hint=nsteps)
+            sgx.steps(2 * sgx.M)                         # primes the graph
+            sgx.prepare(steps_hint=nsteps)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            run(nsteps)
+            sgx.steps(nsteps)
             t2 = time.perf_counter()
             torch.cuda.synchronize()
-            return (time.perf_counter() - t1) / nsteps * 1e6, (t2 - t1) / nsteps * 1e6
+            t3 = time.perf_counter()
+            sgx.detach()
+            return (t3 - t1) / nsteps * 1e6, (t2 - t1) / nsteps * 1e6
         D = args.dp_steps
-        single_us, single_host = timed_us(D)
-        res = {}
-        for name, cap in (('dp', False), ('dp_captured', True)):
-            sg.graphs, sg.multi = [None, None], None
-            sg.dp_path, sg.dp_capture = True, cap
-            timed_us(8)
-            res[name] = timed_us(D)
-        sg.graphs, sg.multi = [None, None], None
-        sg.dp_path, sg.dp_capture = False, False
-        dp_structure = dict(steps=D, single_gpu_us=single_us, dp_us=res['dp'][0], dp_captured_us=res['dp_captured'][0],
-                            dp_structure_us=res['dp'][0] - single_us,
-                            host_enqueue_us_per_step=dict(single_gpu=single_host, dp=res['dp'][1],
-                                                          dp_captured=res['dp_captured'][1]),
-                            note='world size 1: launch structure only, no RCCL call in it; host_enqueue = host time '
-                                 'spent enqueuing a step (the GPU starves when it exceeds the step time)')
+        sg.detach()
+        single_us, single_host = timed_us(sg, D)
+        os.environ['IGMC_FORCE_DP_PATH'], os.environ['IGMC_DP_ALLREDUCE_ALWAYS'] = '1', '1'
+        try:
+            sg_dp = StepGraph(model, opt, ds, BATCH, 0.001)
+            dp_us, dp_host = timed_us(sg_dp, D)
+            in_graph = sg_dp.graph is not None
+            sg_dp.check()
+        finally:
+            del os.environ['IGMC_FORCE_DP_PATH'], os.environ['IGMC_DP_ALLREDUCE_ALWAYS']
+        dp_structure = dict(steps=D, single_gpu_us=single_us, dp_us=dp_us, dp_structure_us=dp_us - single_us,
+                            allreduce_in_graph=bool(in_graph),
+                            host_enqueue_us_per_step=dict(single_gpu=single_host, dp=dp_host),
+                            note='world size 1: gradient kernels -> RCCL all-reduce on a one-rank communicator '
+                                 '(igmc_allreduce_grads) -> Adam launch, captured into the same groups as the fused '
+                                 'single-GPU step; no inter-GPU latency in it')
+        state['i'] = 0
         sg.check()
 
     # ---- roofline leg
     roofline, kernels, extraction, replay_us = None, {}, None, None
     if args.profile_steps > 0:
         P = args.profile_steps
-        # (1) the dominant kernel UNDER REPLAY: re-capture the same graphs with the device-side launch clock compiled
-        #     into the captured arguments, replay P steps, read the clock.  EVERY rank runs these steps (each holds a
-        #     gradient all-reduce under data parallelism); rank 0 reports its own kernel.
+        # (1) the dominant kernel UNDER REPLAY: re-capture the same graph with the device-side launch clock compiled
+        #     into the captured arguments, replay whole launches, read the clock.  EVERY rank runs these steps (each holds
+        #     a gradient all-reduce under data parallelism); rank 0 reports its own kernel.
         if sg.use_graph:
+            import ctypes as C
             lib.igmc_profile_enable(2)
-            sg.graphs, sg.multi = [None, None], None
+            sg.graph = None
             new_epoch_if_needed()
             sg.prepare()
-            import ctypes as C
+            Pr = max(1, -(-P // (2 * sg.M))) * 2 * sg.M
             lib.call('igmc_profile_gs_clock', sg.ws.handle, None, None, 1)
-            run(P)
+            run(Pr)
             torch.cuda.synchronize()
             cnt, mean = C.c_int64(0), C.c_double(0.0)
             lib.call('igmc_profile_gs_clock', sg.ws.handle, C.byref(cnt), C.byref(mean), 1)
             if cnt.value > 0:
                 replay_us = float(mean.value)
             lib.igmc_profile_enable(0)
-            sg.graphs, sg.multi = [None, None], None
-        # (2) every kernel with HIP events on its launch stream: eager launches, extraction still overlapped
+            sg.graph = None
+        # (2) every kernel with HIP events on its launch stream: the same launch structure enqueued eagerly (the extraction
+        #     of the next group still runs beside the model kernels), then a few single steps whose batches are inspected
         engine.profile_enable(lib, True)
         Ns, Es, ext_bytes = [], [], []
         deg_u = np.diff(A.indptr).astype(np.int64)
         deg_v = np.bincount(A.indices, minlength=A.shape[1]).astype(np.int64)
-        sg.use_graph = False
-        for k in range(P):
+        was_graph, sg.use_graph = sg.use_graph, False
+        new_epoch_if_needed()
+        Pe = max(1, P // (2 * sg.M)) * 2 * sg.M
+        run(Pe)
+        torch.cuda.synchronize()
+        rows = engine.profile_fetch(lib, 64)
+        engine.profile_enable(lib, False)
+        for k in range(8):
             step()
-            if rank == 0 and k < 8:                     # algorithmic bytes of the extraction, exact
-                d = sg.arena.download(st)
+            d = sg.arena.download(st)
+            if rank == 0:                               # algorithmic bytes of the extraction, exact
                 tot = 0
                 for g in range(d['B']):
                     lo, hi, nu = d['node_off'][g], d['node_off'][g + 1], d['n_users'][g]
@@ -397,15 +436,11 @@ def main():
                     e_sg = int(d['row_ptr'][hi] - d['row_ptr'][lo])
                     tot += 5 * (deg_u[users[0]] + deg_v[items[0]] + int(deg_u[users].sum())) + (hi - lo) + 9 * e_sg // 2
                 ext_bytes.append(tot)
-                Ns.append(d['N'])
-                Es.append(d['E'])
-            else:
-                info = sg.arena.info(st)
-                Ns.append(info.num_nodes)
-                Es.append(info.num_edges)
+            Ns.append(d['N'])
+            Es.append(d['E'])
         torch.cuda.synchronize()
-        rows = engine.profile_fetch(lib, 64)
-        engine.profile_enable(lib, False)
+        sg.use_graph = was_graph
+        P = Pe
         N, E = float(np.mean(Ns)), float(np.mean(Es))
         kernels = {name: dict(us=ms / calls * 1e3, calls_per_step=calls / P) for name, ms, calls in rows}
         tot = sum(ms for _, ms, _ in rows)
@@ -426,11 +461,14 @@ def main():
             traffic, traffic_src = None, None
             if os.path.exists(PMC_TRAFFIC):
                 trec = json.load(open(PMC_TRAFFIC))
-                if trec.get('kernel') == dom and trec.get('config') == args.config and \
+                if trec.get('kernel') in (dom, SYMBOLS.get(dom)) and trec.get('config') == args.config and \
                         trec.get('src_sha') == kernel_source_sha():
                     traffic = trec.get('traffic_bytes')
                     traffic_src = '%s @ %s' % (os.path.basename(PMC_TRAFFIC), trec.get('commit', '?'))
-            roofline = dict(bound='hbm', kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
+            symbol = SYMBOLS.get(dom, dom)
+            if dom == 'k_graph_step':
+                symbol = 'k_graph_step2<%s, true>' % ('true' if cfg['adj_dropout'] > 0 else 'false')
+            roofline = dict(bound='hbm', kernel=symbol, timer_label=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
                             frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src, avg_us=avg_us,
                             avg_us_source='device launch clock under hipGraph replay + overlapped extraction'
                             if from_replay else 'HIP events, eager launches',
@@ -446,9 +484,9 @@ def main():
             extraction = dict(algorithmic_bytes=float(np.mean(ext_bytes)), us_per_step=ext_us,
                               effective_GBps=float(np.mean(ext_bytes)) / (ext_us * 1e-6) / 1e9, kernels=ext_names,
                               lean=lean,
-                              note='sum of the extraction (+ edge dropout) kernels of the branch (HIP events, eager) while '
-                                   'the model kernels of the previous batch share the chip; 5*(deg u + deg v + sum deg U_s) '
-                                   '+ n + 9*E/2 bytes')
+                              note='sum of the extraction (+ edge dropout) kernels per batch (HIP events, eagerly launched '
+                                   'groups: the extraction chain of the next group runs beside the model chain); '
+                                   '5*(deg u + deg v + sum deg U_s) + n + 9*E/2 bytes')
     if world > 1:
         parallel.barrier()
 
@@ -498,9 +536,10 @@ def main():
             'config': {'workload': '%s, hop 1, max-nodes-per-hop %d, batch %d per GPU, adj-dropout %g, dynamic-train, '
                                    'ARR 0.001, Adam' % (cfg['dataset'], cfg['mnph'], BATCH, cfg['adj_dropout']),
                        'parallelism': 'dp%d' % world, 'global_batch': BATCH * world,
-                       'graphs_captured_before_timing': bool(captured)},
+                       'graphs_captured_before_timing': bool(captured), 'steps_per_graph_launch': 2 * group_steps},
             'roofline': roofline, 'cpu_baseline': cpu, 'rmse': rmse, 'extraction': extraction,
             'dp_structure_us': dp_structure['dp_structure_us'] if dp_structure else None, 'dp_structure': dp_structure,
+            'dp_check': dp_check,
             'timing_check': {'wall_ms': dt * 1e3, 'gpu_event_ms': gpu_ms, 'host_enqueue_ms': t_enq * 1e3},
             'final_loss': final_loss, 'kernels_us': {k: round(v['us'], 2) for k, v in kernels.items()},
             'kernel_src_sha': kernel_source_sha(),

@@ -307,7 +307,7 @@ extern "C" int igmc_batch_create(const igmc_graph* g, int max_graphs, int hop, i
           M.get(&d.edst, edge_cap);
   d.slot_cap = node_cap + edge_cap / 8 + 16 * (int64_t)Bc;      // >= sum of igmc_row_slots + per-graph padding
   fail |= M.get(&d.slot_tab, d.slot_cap) | M.get(&d.slot_off, Bc + 1) | M.get(&d.slot_cnt, Bc);
-  fail |= M.get(&d.y, Bc) | M.get(&d.totals, 8);
+  fail |= M.get(&d.y, Bc) | M.get(&d.totals, 8) | M.get(&d.stamp, 4);
   d.relm = nullptr;
   d.relmT = nullptr;
   d.relmT_ld = (int)((cap_u + 3) & ~(size_t)3);
@@ -331,6 +331,7 @@ extern "C" int igmc_batch_create(const igmc_graph* g, int max_graphs, int hop, i
     IGMC_FAIL("hipMalloc failed (batch arena)");
   }
   HIPCHECK(hipMemset(d.totals, 0, 8 * sizeof(int32_t)));
+  HIPCHECK(hipMemset(d.stamp, 0xFF, 4 * sizeof(int64_t)));        // -1: no batch of a known cursor in the arena
   d.cap_u = (int)cap_u;
   d.cap_v = (int)cap_v;
   d.slot = (int)slot;
@@ -399,6 +400,7 @@ extern "C" int igmc_extract_batch_replay(const igmc_graph* g, igmc_batch* b, int
   HIPCHECK(hipMemcpy(d.n_users, nu.data(), B * 4, hipMemcpyHostToDevice));
   HIPCHECK(hipMemcpy(d.n_items, nv.data(), B * 4, hipMemcpyHostToDevice));
   HIPCHECK(hipMemcpy(d.y, h_y, B * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHECK(hipMemset(d.stamp, 0xFF, 4 * sizeof(int64_t)));        // node sets from the host: no cursor to compare with
   igmc_launch_extract(g->d, b->d, nullptr, nullptr, nullptr, nullptr, 0, B, 1, 1.0, 0, 0, nullptr, 0, stream);
   HIPCHECK(hipGetLastError());
   HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
@@ -838,15 +840,9 @@ extern "C" int igmc_ctrl_tick(int64_t* d_ctrl, void* stream) {
   HIPCHECK(hipGetLastError());
   return 0;
 }
-extern "C" int igmc_batch_gate(igmc_batch* b, int parity, void* stream) {
-  if (!b || !b->ctrl) IGMC_FAIL("igmc_batch_gate: no control block attached");
-  igmc_launch_gate(const_cast<int64_t*>(b->ctrl), parity & 1, stream);
-  HIPCHECK(hipGetLastError());
-  return 0;
-}
-extern "C" int igmc_batch_mark_ready(igmc_batch* b, int parity, void* stream) {
-  if (!b || !b->ctrl) IGMC_FAIL("igmc_batch_mark_ready: no control block attached");
-  igmc_launch_mark_ready(const_cast<int64_t*>(b->ctrl), parity & 1, stream);
+extern "C" int igmc_ctrl_regroup(int64_t* d_ctrl, int M, int64_t first_cur, int64_t first_next, void* stream) {
+  if (!d_ctrl || M < 1 || first_cur < 0 || first_next < 0) IGMC_FAIL("bad arguments");
+  igmc_launch_regroup(d_ctrl, M, first_cur, first_next, stream);
   HIPCHECK(hipGetLastError());
   return 0;
 }
@@ -897,7 +893,7 @@ extern "C" int igmc_step_finish(igmc_model* m, const igmc_batch* b, float* d_par
     inv = (float)(1.0 / std::sqrt(bc2));
   }
   igmc_launch_finish(m->d, b->d, d_params, d_grad, d_exp_avg, d_exp_avg_sq, step_size, inv, beta1, beta2, eps,
-                     weight_decay, d_ctrl, ARR, d_loss, d_total, stream);
+                     weight_decay, d_ctrl, ARR, d_loss, d_total, m->last_flags, stream);
   HIPCHECK(hipGetLastError());
   return 0;
 }
@@ -927,6 +923,132 @@ extern "C" int igmc_train_step(igmc_model* m, float* d_params, const igmc_batch*
   m->last_B = b->last_B;
   m->last_training = 1;
   m->last_flags = use_edge_flags;
+  return 0;
+}
+
+// ------------------------------------------------------------------ gradient exchange (RCCL behind the C ABI)
+struct igmc_comm {
+  void* nccl;        // ncclComm_t (NULL in the emulation build: one rank only)
+  int rank, world, device;
+};
+#ifndef IGMC_HIPEMU
+#include <dlfcn.h>
+// RCCL's entry points, resolved at the first use.  The few types needed are restated here (rccl.h: ncclUniqueId = 128
+// opaque bytes; ncclFloat = 7, ncclSum = 0; results: 0 = success) so that the build needs no RCCL headers.
+struct NcclId { char internal[128]; };
+struct RcclApi {
+  int (*GetUniqueId)(NcclId*);
+  int (*CommInitRank)(void**, int, NcclId, int);
+  int (*CommDestroy)(void*);
+  int (*CommCount)(const void*, int*);
+  int (*CommUserRank)(const void*, int*);
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+  const char* (*GetErrorString)(int);
+  bool ok = false;
+};
+static RcclApi g_rccl;
+static int rccl_load(std::string* why) {
+  if (g_rccl.ok) return 0;
+  void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);      // the copy the process already holds, if any (same soname)
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) { *why = std::string("cannot load librccl.so.1: ") + dlerror(); return 1; }
+  struct { const char* name; void** slot; } syms[] = {
+      {"ncclGetUniqueId", (void**)&g_rccl.GetUniqueId}, {"ncclCommInitRank", (void**)&g_rccl.CommInitRank},
+      {"ncclCommDestroy", (void**)&g_rccl.CommDestroy}, {"ncclCommCount", (void**)&g_rccl.CommCount},
+      {"ncclCommUserRank", (void**)&g_rccl.CommUserRank}, {"ncclAllReduce", (void**)&g_rccl.AllReduce},
+      {"ncclGetErrorString", (void**)&g_rccl.GetErrorString}};
+  for (auto& sy : syms) {
+    *sy.slot = dlsym(h, sy.name);
+    if (!*sy.slot) { *why = std::string("librccl.so.1 lacks ") + sy.name; return 1; }
+  }
+  g_rccl.ok = true;
+  return 0;
+}
+#define RCCLCHECK(expr)                                                                              \
+  do {                                                                                               \
+    int r_ = (expr);                                                                                 \
+    if (r_ != 0) {                                                                                   \
+      g_err = std::string(__func__) + ": " #expr " -> " + g_rccl.GetErrorString(r_);                 \
+      return 1;                                                                                      \
+    }                                                                                                \
+  } while (0)
+#endif
+
+__global__ __launch_bounds__(IGMC_BLOCK) void k_scale_flat(float* p, int64_t n, float s) {
+  for (int64_t i = (int64_t)blockIdx.x * IGMC_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * IGMC_BLOCK) p[i] *= s;
+}
+
+extern "C" int igmc_comm_unique_id(uint8_t* h_id128) {
+  if (!h_id128) IGMC_FAIL("null id buffer");
+#ifndef IGMC_HIPEMU
+  std::string why;
+  if (rccl_load(&why)) IGMC_FAIL(why);
+  NcclId id;
+  RCCLCHECK(g_rccl.GetUniqueId(&id));
+  memcpy(h_id128, id.internal, 128);
+#else
+  memset(h_id128, 0, 128);
+#endif
+  return 0;
+}
+
+extern "C" int igmc_comm_create(const uint8_t* h_id128, int rank, int world, int device, igmc_comm** out) {
+  if (!h_id128 || !out || world < 1 || rank < 0 || rank >= world) IGMC_FAIL("bad arguments");
+  igmc_comm* c = new igmc_comm();
+  c->nccl = nullptr;
+  c->rank = rank;
+  c->world = world;
+  c->device = device;
+#ifndef IGMC_HIPEMU
+  std::string why;
+  if (rccl_load(&why)) { delete c; IGMC_FAIL(why); }
+  HIPCHECK(hipSetDevice(device));
+  NcclId id;
+  memcpy(id.internal, h_id128, 128);
+  const int r = g_rccl.CommInitRank(&c->nccl, world, id, rank);
+  if (r != 0) {
+    delete c;
+    IGMC_FAIL(std::string("ncclCommInitRank -> ") + g_rccl.GetErrorString(r));
+  }
+#else
+  if (world != 1) { delete c; IGMC_FAIL("the emulation build has no RCCL: one rank only"); }
+#endif
+  *out = c;
+  return 0;
+}
+
+extern "C" void igmc_comm_destroy(igmc_comm* c) {
+  if (!c) return;
+#ifndef IGMC_HIPEMU
+  if (c->nccl && g_rccl.ok) g_rccl.CommDestroy(c->nccl);
+#endif
+  delete c;
+}
+
+extern "C" int igmc_comm_info(const igmc_comm* c, int* rank, int* world) {
+  if (!c) IGMC_FAIL("null communicator");
+  int r = c->rank, w = c->world;
+#ifndef IGMC_HIPEMU
+  if (c->nccl) {
+    RCCLCHECK(g_rccl.CommUserRank(c->nccl, &r));
+    RCCLCHECK(g_rccl.CommCount(c->nccl, &w));
+  }
+#endif
+  if (rank) *rank = r;
+  if (world) *world = w;
+  return 0;
+}
+
+extern "C" int igmc_allreduce_grads(igmc_comm* c, float* d_flat_grad, int64_t n, float scale, void* stream) {
+  if (!c || !d_flat_grad || n <= 0) IGMC_FAIL("bad arguments");
+#ifndef IGMC_HIPEMU
+  RCCLCHECK(g_rccl.AllReduce(d_flat_grad, d_flat_grad, (size_t)n, /*ncclFloat*/ 7, /*ncclSum*/ 0, c->nccl, (hipStream_t)stream));
+#endif
+  if (scale != 1.0f) {
+    int grid = (int)((n + IGMC_BLOCK - 1) / IGMC_BLOCK);
+    IGMC_PLAUNCH("k_scale_flat", k_scale_flat, grid > 1024 ? 1024 : grid, IGMC_BLOCK, 0, stream, d_flat_grad, n, scale);
+    HIPCHECK(hipGetLastError());
+  }
   return 0;
 }
 

@@ -99,7 +99,30 @@ struct BatchDev {
   int cap_u, cap_v, slot;
   int node_cap, edge_cap, graph_cap;
   int hop, max_nodes_per_hop, num_labels;
+  int64_t* stamp;        // [4]: 0 = the `first` the node-set kernel of the batch in this arena resolved, 1 = the key of its
+                         // edge dropout (-1 = none); compared by the tick of the step that consumes the arena (igmc_hip.h)
 };
+
+// ------------------------------------------------------------------ device-side step control (igmc_hip.h)
+// Control words are read with agent-scope loads: they are written by the step's last kernel on one stream while kernels of
+// the extraction chain on another stream read their own words of the same cache lines.
+__device__ __forceinline__ int64_t igmc_ctrl_ld(const int64_t* p) {
+#ifdef IGMC_HIPEMU
+  return *p;
+#else
+  return (int64_t)__hip_atomic_load((const long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+// selector sel = q | (i << 1)  ->  offset into the link permutation of batch i of the group of parity q
+__device__ __forceinline__ int igmc_ctrl_first(const int64_t* ctrl, int sel) {
+  return (int)(igmc_ctrl_ld(ctrl + ((sel & 1) ? IGMC_CTRL_FIRST_ODD : IGMC_CTRL_FIRST)) +
+               (int64_t)(sel >> 1) * igmc_ctrl_ld(ctrl + IGMC_CTRL_BATCH));
+}
+// key of the edge-dropout draws of the batch that starts at `first`: (epoch, batch index)
+__device__ __forceinline__ uint64_t igmc_ctrl_drop_key(const int64_t* ctrl, int first) {
+  const int64_t B = igmc_ctrl_ld(ctrl + IGMC_CTRL_BATCH);
+  return ((uint64_t)igmc_ctrl_ld(ctrl + IGMC_CTRL_EPOCH) << 32) ^ (uint64_t)((int64_t)first / (B > 0 ? B : 1));
+}
 
 // ------------------------------------------------------------------ small device helpers
 __device__ __forceinline__ int igmc_lane() { return threadIdx.x & 63; }

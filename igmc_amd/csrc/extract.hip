@@ -185,11 +185,15 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_extract_nodes(ExtractArgs a) {
   if (do_u) bm_clear(sel_u, Wu);
   if (do_v) bm_clear(sel_v, Wv);
   if (!a.replay) {
-    // with a control block attached the host `first` selects the even / odd slot (see igmc_hip.h): a prefetch of
-    // the next batch on another stream reads the slot the concurrent step never writes
-    const int first = a.ctrl ? (int)a.ctrl[(a.first & 1) ? IGMC_CTRL_FIRST_ODD : IGMC_CTRL_FIRST] : a.first;
-    const uint64_t epoch = a.ctrl ? (uint64_t)a.ctrl[IGMC_CTRL_EPOCH] : a.epoch;
+    // with a control block attached the host `first` is a selector q | (i << 1): batch i of the group of parity q (see
+    // igmc_hip.h) -- a prefetch of the next group on another stream reads the cursor the concurrent steps never write
+    const int first = a.ctrl ? igmc_ctrl_first(a.ctrl, a.first) : a.first;
+    const uint64_t epoch = a.ctrl ? (uint64_t)igmc_ctrl_ld(a.ctrl + IGMC_CTRL_EPOCH) : a.epoch;
     const int pos = a.link_idx ? a.link_idx[first + g] : first + g;
+    if (g == 0 && tid == 0 && do_u) {      // stamp of the batch in this arena (checked by the tick of the consuming step)
+      a.b.stamp[0] = a.ctrl ? (int64_t)first : -1;      // (no control block: nothing to compare with)
+      a.b.stamp[1] = -1;
+    }
     u0 = a.link_u[pos];
     v0 = a.link_v[pos];
     if (do_u) bm_clear(vis_u, Wu);
@@ -836,11 +840,9 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_slots(BatchDev b) {
 // (shared by the two directions when force_undirected).  16 lanes per CSR row.
 __global__ __launch_bounds__(IGMC_BLOCK) void k_edge_flags(BatchDev b, float p, int force_undirected,
                                                             uint64_t seed, uint64_t step_arg, const int64_t* ctrl) {
-  // control block: key by (epoch, batch index) of the selected slot -- race-free under prefetching
-  const uint64_t step = ctrl ? (((uint64_t)ctrl[IGMC_CTRL_EPOCH] << 32) ^
-                                (uint64_t)(ctrl[(step_arg & 1) ? IGMC_CTRL_FIRST_ODD : IGMC_CTRL_FIRST] /
-                                           (ctrl[IGMC_CTRL_BATCH] > 0 ? ctrl[IGMC_CTRL_BATCH] : 1)))
-                             : step_arg;
+  // control block: key by (epoch, batch index) of the selected batch -- race-free under prefetching
+  const uint64_t step = ctrl ? igmc_ctrl_drop_key(ctrl, igmc_ctrl_first(ctrl, (int)step_arg)) : step_arg;
+  if (blockIdx.x == 0 && threadIdx.x == 0) b.stamp[1] = ctrl ? (int64_t)step : -1;
   const int N = b.totals[0];
   const int grp = (blockIdx.x * IGMC_BLOCK + threadIdx.x) >> 4, t = threadIdx.x & 15;
   const int ngrp = (gridDim.x * IGMC_BLOCK) >> 4;
@@ -887,10 +889,8 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_relm_flags(BatchDev b) {
 // straight from the dense blocks -- no CSR needed.  grid (B, 4): a workgroup takes every 4th dword column group.
 __global__ __launch_bounds__(IGMC_BLOCK) void k_relm_dropout(BatchDev b, float p, int force_undirected, uint64_t seed,
                                                               uint64_t step_arg, const int64_t* ctrl) {
-  const uint64_t step = ctrl ? (((uint64_t)ctrl[IGMC_CTRL_EPOCH] << 32) ^
-                                (uint64_t)(ctrl[(step_arg & 1) ? IGMC_CTRL_FIRST_ODD : IGMC_CTRL_FIRST] /
-                                           (ctrl[IGMC_CTRL_BATCH] > 0 ? ctrl[IGMC_CTRL_BATCH] : 1)))
-                             : step_arg;
+  const uint64_t step = ctrl ? igmc_ctrl_drop_key(ctrl, igmc_ctrl_first(ctrl, (int)step_arg)) : step_arg;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) b.stamp[1] = ctrl ? (int64_t)step : -1;
   const int g = blockIdx.x;
   const int cu = b.n_users[g], cv = b.n_items[g];
   const int ld = b.relm_ld, ldw = ld >> 2, cw = (cv + 3) >> 2;
@@ -936,8 +936,12 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_load_nodes(BatchDev b, const int
                                                             const uint8_t* vdist, const float* link_y, const int32_t* link_idx,
                                                             int first_arg, const int64_t* ctrl) {
   const int g = blockIdx.x, tid = threadIdx.x;
-  const int first = ctrl ? (int)ctrl[(first_arg & 1) ? IGMC_CTRL_FIRST_ODD : IGMC_CTRL_FIRST] : first_arg;
+  const int first = ctrl ? igmc_ctrl_first(ctrl, first_arg) : first_arg;
   const int pos = link_idx ? link_idx[first + g] : first + g;
+  if (g == 0 && tid == 0) {
+    b.stamp[0] = ctrl ? (int64_t)first : -1;
+    b.stamp[1] = -1;
+  }
   const int64_t u0 = uoff[pos], v0 = voff[pos];
   int cu = (int)(uoff[pos + 1] - u0), cv = (int)(voff[pos + 1] - v0);
   cu = cu < b.cap_u ? cu : b.cap_u;        // (a cache built for this arena geometry never exceeds it)
@@ -973,45 +977,13 @@ void igmc_launch_load_nodes(const BatchDev& b, const int64_t* uoff, const int32_
 // indexing as k_extract_nodes -- so the fused / captured training step needs no host-side index_select.
 __global__ __launch_bounds__(IGMC_BLOCK) void k_side_gather(const float* src, int S, const int32_t* link_idx, int first_arg,
                                                              int B, const int64_t* ctrl, float* dst) {
-  const int first = ctrl ? (int)ctrl[(first_arg & 1) ? IGMC_CTRL_FIRST_ODD : IGMC_CTRL_FIRST] : first_arg;
+  const int first = ctrl ? igmc_ctrl_first(ctrl, first_arg) : first_arg;
   for (int i = blockIdx.x * IGMC_BLOCK + threadIdx.x; i < B * S; i += gridDim.x * IGMC_BLOCK) {
     const int g = i / S, f = i - g * S;
     const int pos = link_idx ? link_idx[first + g] : first + g;
     dst[i] = src[(size_t)pos * S + f];
   }
 }
-
-// Free-running prefetch (igmc_hip.h, device-side step control): one-thread kernels on the extraction stream.
-// k_gate_consumed: the arena of `parity` may be overwritten once the step that consumed its batch has advanced the cursor.
-#define IGMC_SYNC_SPINS 4000000
-__global__ void k_gate_consumed(int64_t* ctrl, int parity) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const int cs = parity ? IGMC_CTRL_FIRST_ODD : IGMC_CTRL_FIRST, rs = IGMC_CTRL_READY + parity;
-#ifndef IGMC_HIPEMU
-  int n = 0;
-  while (__hip_atomic_load((long long*)ctrl + cs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-         __hip_atomic_load((long long*)ctrl + rs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-    __builtin_amdgcn_s_sleep(8);
-    if (++n > IGMC_SYNC_SPINS) {
-      __hip_atomic_store((long long*)ctrl + IGMC_CTRL_SYNC_ERR, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      break;
-    }
-  }
-#else
-  (void)cs; (void)rs;
-#endif
-}
-__global__ void k_mark_ready(int64_t* ctrl, int parity) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const int cs = parity ? IGMC_CTRL_FIRST_ODD : IGMC_CTRL_FIRST, rs = IGMC_CTRL_READY + parity;
-#ifndef IGMC_HIPEMU
-  __hip_atomic_store((long long*)ctrl + rs, (long long)ctrl[cs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-  ctrl[rs] = ctrl[cs];
-#endif
-}
-void igmc_launch_gate(int64_t* ctrl, int parity, void* stream) { IGMC_PLAUNCH("k_gate_consumed", k_gate_consumed, 1, 64, 0, stream, ctrl, parity); }
-void igmc_launch_mark_ready(int64_t* ctrl, int parity, void* stream) { IGMC_PLAUNCH("k_mark_ready", k_mark_ready, 1, 64, 0, stream, ctrl, parity); }
 
 void igmc_launch_side_gather(const float* src, int S, const int32_t* link_idx, int first, int B, const int64_t* ctrl,
                              float* dst, void* stream) {

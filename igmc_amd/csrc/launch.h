@@ -19,8 +19,7 @@ void igmc_launch_relm_flags(const BatchDev& b, void* stream);
 void igmc_launch_relm_dropout(const BatchDev& b, int B, float p, int force_undirected, uint64_t seed, uint64_t step,
                               const int64_t* ctrl, void* stream);
 void igmc_launch_tick(int64_t* ctrl, void* stream);
-void igmc_launch_gate(int64_t* ctrl, int parity, void* stream);
-void igmc_launch_mark_ready(int64_t* ctrl, int parity, void* stream);
+void igmc_launch_regroup(int64_t* ctrl, int M, int64_t first_cur, int64_t first_next, void* stream);
 void igmc_launch_fill_u8(uint8_t* p, int64_t n, uint8_t v, void* stream);
 int igmc_extract_prepare(size_t smem);
 
@@ -61,7 +60,7 @@ void igmc_launch_adam(float* p, const float* g, float* m1, float* m2, int64_t n,
                       void* stream);
 void igmc_launch_finish(const ModelDev& m, const BatchDev& b, float* p, const float* g, float* m1, float* m2,
                         float step_size, float inv_sqrt_bc2, float beta1, float beta2, float eps, float wd,
-                        int64_t* ctrl, float ARR, float* loss, double* total, void* stream);
+                        int64_t* ctrl, float ARR, float* loss, double* total, int use_flags, void* stream);
 
 // graphstep.hip: one workgroup per enclosing subgraph (LDS-resident layers)
 struct GsLayout {      // LDS plan, offsets in 4-byte words

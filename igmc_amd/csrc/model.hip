@@ -1825,6 +1825,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_tail_ts(BatchDev b, ModelDev m, 
 
 struct FinishArgs {
   int enabled;
+  int use_flags;      // the step ran under edge dropout (the tick then also checks the arena's dropout stamp)
   BatchDev b;
   ModelDev m;
   float ARR;
@@ -1832,16 +1833,39 @@ struct FinishArgs {
   double* total;
 };
 
+// End of a step (igmc_hip.h, device-side step control): counters, Adam bias corrections, and -- at the end of a GROUP of M
+// steps -- the cursor of the group's parity moves on by two groups and the parity flips.  Only the cursor of the group that
+// just finished is written: the one a concurrent prefetch of the next group reads never changes while it may be read.
 __device__ __forceinline__ void ctrl_advance(int64_t* ctrl) {
   double* d = (double*)ctrl;
-  const int64_t k = ctrl[IGMC_CTRL_K];
+  const int64_t M = ctrl[IGMC_CTRL_GROUP] > 0 ? ctrl[IGMC_CTRL_GROUP] : 1;
+  const int64_t gq = ctrl[IGMC_CTRL_GQ] & 1, gk = ctrl[IGMC_CTRL_GK] + 1;
   ctrl[IGMC_CTRL_STEP] += 1;
-  ctrl[(k & 1) ? IGMC_CTRL_FIRST_ODD : IGMC_CTRL_FIRST] += 2 * ctrl[IGMC_CTRL_BATCH];   // the slot step k used
-  ctrl[IGMC_CTRL_K] = k + 1;
+  ctrl[IGMC_CTRL_K] += 1;
+  if (gk >= M) {
+    ctrl[gq ? IGMC_CTRL_FIRST_ODD : IGMC_CTRL_FIRST] += 2 * M * ctrl[IGMC_CTRL_BATCH];
+    ctrl[IGMC_CTRL_GK] = 0;
+    ctrl[IGMC_CTRL_GQ] = gq ^ 1;
+  } else {
+    ctrl[IGMC_CTRL_GK] = gk;
+  }
   ctrl[IGMC_CTRL_ADAM_T] += 1;
   const double t = (double)ctrl[IGMC_CTRL_ADAM_T];
   d[IGMC_CTRL_STEP_SIZE] = d[IGMC_CTRL_LR] / (1.0 - pow(d[IGMC_CTRL_BETA1], t));
   d[IGMC_CTRL_INV_SQRT_BC2] = 1.0 / sqrt(1.0 - pow(d[IGMC_CTRL_BETA2], t));
+}
+// ... after checking that the arena the step consumed held the batch of its cursor (and, under edge dropout, that batch's
+// draws): every extraction stamps its arena with the `first` it resolved.  A mismatch means a batch extracted from a stale
+// cursor or an arena overwritten too early; it sets sync_err instead of training on silently.
+__device__ __forceinline__ void ctrl_check_and_advance(int64_t* ctrl, const BatchDev& b, int use_flags) {
+  const int64_t gq = ctrl[IGMC_CTRL_GQ] & 1;
+  const int64_t want = ctrl[gq ? IGMC_CTRL_FIRST_ODD : IGMC_CTRL_FIRST] + ctrl[IGMC_CTRL_GK] * ctrl[IGMC_CTRL_BATCH];
+  const int64_t got = b.stamp[0];
+  int bad = 0;
+  if (got >= 0 && got != want) bad |= 2;
+  if (use_flags && got >= 0 && b.stamp[1] >= 0 && (uint64_t)b.stamp[1] != igmc_ctrl_drop_key(ctrl, (int)want)) bad |= 4;
+  if (bad) ctrl[IGMC_CTRL_SYNC_ERR] |= bad;
+  ctrl_advance(ctrl);
 }
 
 // loss[0] = mean_g err^2 + ARR * sum_l reg_l   (reference train_eval.py:162-174); loss[1] = sum err^2
@@ -1923,6 +1947,7 @@ struct AdamTail {
   float ARR;
   float* loss;
   double* total;
+  int use_flags;      // the step ran under edge dropout (the tick then also checks the arena's dropout stamp)
 };
 
 // IGMC_FIN_NB workgroups per conv layer: turn the reduced partials into the flat gradient, add the
@@ -2103,7 +2128,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize(ModelDev m, const float
       loss_body(at.b, m, at.ARR, at.loss, at.total, smf);
       if (threadIdx.x == 0) {
         *at.done = 0;
-        if (at.ctrl) ctrl_advance(at.ctrl);
+        if (at.ctrl) ctrl_check_and_advance(at.ctrl, at.b, at.use_flags);
       }
     }
   }
@@ -2299,29 +2324,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
     adam_range<8>(at.p, grad, at.m1, at.m2, lo, hi, at.step_size, at.inv_sqrt_bc2, at.beta1, at.beta2, at.eps, at.wd);
   } else {                                                     // loss, epoch total, control-block tick
     loss_body(at.b, m, at.ARR, at.loss, at.total, smf);
-    if (tid == 0 && at.ctrl) {
-      const int64_t k = at.ctrl[IGMC_CTRL_K];
-      const bool free_run = at.ctrl[IGMC_CTRL_FREE_RUN] != 0;
-      ctrl_advance(at.ctrl);
-#ifndef IGMC_HIPEMU
-      if (free_run) {
-        // free-running prefetch (igmc_hip.h): the next step's batch must sit in its arena before this step ends -- there
-        // is no stream dependency behind this kernel that would wait for the extraction chain
-        const int pn = (int)((k + 1) & 1);
-        const long long want = (long long)at.ctrl[pn ? IGMC_CTRL_FIRST_ODD : IGMC_CTRL_FIRST];
-        int n = 0;
-        while (__hip_atomic_load((long long*)at.ctrl + IGMC_CTRL_READY + pn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
-          __builtin_amdgcn_s_sleep(8);
-          if (++n > 4000000) {
-            __hip_atomic_store((long long*)at.ctrl + IGMC_CTRL_SYNC_ERR, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-          }
-        }
-      }
-#else
-      (void)k; (void)free_run;
-#endif
-    }
+    if (tid == 0 && at.ctrl) ctrl_check_and_advance(at.ctrl, at.b, at.use_flags);
   }
 }
 
@@ -2350,6 +2353,15 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_sse_acc(BatchDev b, const float*
 // the device-side step control (igmc_hip.h) for the next replay of the step graph.
 __global__ void k_tick(int64_t* ctrl) {
   if (threadIdx.x == 0 && blockIdx.x == 0) ctrl_advance(ctrl);
+}
+// a new group of M steps starts at the current position (igmc_ctrl_regroup)
+__global__ void k_regroup(int64_t* ctrl, int M, int64_t first_cur, int64_t first_next) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  ctrl[IGMC_CTRL_GROUP] = M > 0 ? M : 1;
+  ctrl[IGMC_CTRL_GK] = 0;
+  ctrl[IGMC_CTRL_GQ] = 0;
+  ctrl[IGMC_CTRL_FIRST] = first_cur;
+  ctrl[IGMC_CTRL_FIRST_ODD] = first_next;
 }
 
 __global__ __launch_bounds__(IGMC_BLOCK) void k_adam(float* __restrict__ p, const float* __restrict__ g,
@@ -2385,7 +2397,8 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_adam(float* __restrict__ p, cons
       int* done = (int*)&ctrl[IGMC_CTRL_DONE];
       if (atomicAdd(done, 1) == (int)gridDim.x - 1) {
         *done = 0;
-        ctrl_advance(ctrl);
+        if (fin.enabled) ctrl_check_and_advance(ctrl, fin.b, fin.use_flags);
+        else ctrl_advance(ctrl);
       }
     }
   }
@@ -2629,12 +2642,13 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
   AdamTail at;
   memset(&at, 0, sizeof(at));
   if (adam) at = *adam;
+  at.use_flags = use_flags;
   if (!fast_head) {      // generic sequence
     igmc_launch_forward(m, ax, b, P, B, 1, use_flags, inj_mask, seed, step, mult, out, stream);
     igmc_launch_backward(m, ax, b, P, B, use_flags, nullptr, 1, grad_scale, mult, 2.f, ARR * arr_scale, grad, stream);
     if (adam) {
       igmc_launch_finish(m, b, at.p, grad, at.m1, at.m2, at.step_size, at.inv_sqrt_bc2, at.beta1, at.beta2, at.eps, at.wd,
-                         at.ctrl, ARR, at.loss, at.total, stream);
+                         at.ctrl, ARR, at.loss, at.total, use_flags, stream);
     } else if (loss) {
       igmc_launch_loss(m, b, ARR, loss, stream);
     }
@@ -2777,6 +2791,9 @@ void igmc_launch_sse(const BatchDev& b, const float* out, double* acc, void* str
 }
 
 void igmc_launch_tick(int64_t* ctrl, void* stream) { IGMC_PLAUNCH("k_tick", k_tick, 1, 64, 0, stream, ctrl); }
+void igmc_launch_regroup(int64_t* ctrl, int M, int64_t first_cur, int64_t first_next, void* stream) {
+  IGMC_PLAUNCH("k_regroup", k_regroup, 1, 64, 0, stream, ctrl, M, first_cur, first_next);
+}
 
 static int adam_grid(int64_t n) {
   int grid = (int)((n + IGMC_BLOCK - 1) / IGMC_BLOCK);
@@ -2796,9 +2813,10 @@ void igmc_launch_adam(float* p, const float* g, float* m1, float* m2, int64_t n,
 // Adam + loss + epoch total (+ control-block tick) in ONE launch
 void igmc_launch_finish(const ModelDev& m, const BatchDev& b, float* p, const float* g, float* m1, float* m2,
                         float step_size, float inv_sqrt_bc2, float beta1, float beta2, float eps, float wd,
-                        int64_t* ctrl, float ARR, float* loss, double* total, void* stream) {
+                        int64_t* ctrl, float ARR, float* loss, double* total, int use_flags, void* stream) {
   FinishArgs fin;
   fin.enabled = 1;
+  fin.use_flags = use_flags;
   fin.b = b;
   fin.m = m;
   fin.ARR = ARR;

@@ -66,6 +66,61 @@ def all_reduce_sum_(t):
     return t
 
 
+class GradComm(object):
+    """The library's own RCCL communicator for the flat-gradient all-reduce (``include/igmc_hip.h``, gradient exchange):
+    the collective is enqueued through the C ABI on the step's stream, so it is captured into the step's hipGraph like
+    any kernel.  The 128-byte RCCL id travels from rank 0 over whatever ``torch.distributed`` backend is up."""
+
+    def __init__(self, lib, device):
+        import ctypes as C
+        self.lib, self.C = lib, C
+        r, w = rank(), world_size()
+        buf = (C.c_uint8 * 128)()
+        if r == 0:
+            lib.call('igmc_comm_unique_id', C.cast(buf, C.c_void_p))
+        ident = broadcast_object(bytes(buf), 0)
+        buf = (C.c_uint8 * 128).from_buffer_copy(ident)
+        h = C.c_void_p()
+        lib.call('igmc_comm_create', C.cast(buf, C.c_void_p), r, w, int(device), C.byref(h))
+        self.handle = h
+
+    def info(self):
+        """(rank, world size) as RCCL sees them."""
+        r, w = self.C.c_int(-1), self.C.c_int(-1)
+        self.lib.call('igmc_comm_info', self.handle, self.C.byref(r), self.C.byref(w))
+        return r.value, w.value
+
+    def all_reduce_(self, t, stream, scale=1.0):
+        self.lib.call('igmc_allreduce_grads', self.handle, self.C.c_void_p(t.data_ptr()), t.numel(), float(scale),
+                      self.C.c_void_p(stream))
+        return t
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.cdll.igmc_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_grad_comms = {}
+
+
+def grad_comm(lib, device):
+    """One communicator per (process, device); needed when there is more than one rank, or with
+    ``IGMC_DP_ALLREDUCE_ALWAYS=1`` (a one-rank communicator: lets one GPU exercise the collective's enqueue / capture)."""
+    if world_size() <= 1 and os.environ.get('IGMC_DP_ALLREDUCE_ALWAYS', '0') != '1':
+        return None
+    key = int(device)
+    if key not in _grad_comms:
+        _grad_comms[key] = GradComm(lib, device)
+    return _grad_comms[key]
+
+
 def barrier():
     if is_dist() and world_size() > 1:
         dist.barrier()

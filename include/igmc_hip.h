@@ -183,36 +183,34 @@ int igmc_adam_step(float* d_params, const float* d_grad, float* d_exp_avg, float
                    float weight_decay, void* stream);
 
 /* ------------------------------------------------------------------ device-side step control
- * A hipGraph replay cannot change kernel arguments, so the per-step scalars can live in HBM instead:
- * d_ctrl is an int64[IGMC_CTRL_WORDS] device buffer (slots 8.. hold doubles, bit-cast):
- *   [0] step   [1] first_even   [2] epoch   [3] adam_t   [4] batch size   [5] internal arrival counter (keep 0)
- *   [6] first_odd   [7] k = steps done in this epoch
- * first_even / first_odd = offset into the link permutation of the batch of the even / odd steps: the batch of
- * step k starts at slot[k & 1]; a tick (end of step k) does slot[k & 1] += 2*batch, so the OTHER slot -- the one
- * a concurrent prefetch of batch k+1 reads -- is never written while it may be read.
+ * A hipGraph replay cannot change kernel arguments, so the per-step scalars live in HBM instead:
+ * d_ctrl is an int64[IGMC_CTRL_WORDS] device buffer (slots 8..14 hold doubles, bit-cast):
+ *   [0] step   [1] cursor_0   [2] epoch   [3] adam_t   [4] batch size B   [5] internal arrival counter (keep 0)
+ *   [6] cursor_1   [7] k = steps done in this epoch
  *   [8] lr  [9] beta1  [10] beta2  [11] eps  [12] weight_decay   [13] lr/(1-beta1^t)  [14] 1/sqrt(1-beta2^t)
- * igmc_ctrl_tick advances it on the device: step+=1, slot[k&1]+=2*batch, k+=1, adam_t+=1, slots 13/14 recomputed.
- * Once attached, igmc_extract_batch reads first from slot[<host first> & 1] (the host value becomes the slot
- * SELECTOR) and ctrl.epoch; igmc_batch_edge_dropout keys its hash by (epoch, first/batch) of slot[<host step> & 1];
- * the forward's MLP dropout uses ctrl.step.  NULL detaches. */
+ *   [15] M = steps per GROUP (0 is read as 1)   [16] gk = steps done in the current group   [17] gq = parity of the
+ *   current group   [18] sync_err (bit 1: a step consumed an arena whose stamp is not the batch of its cursor; bit 2:
+ *   ... whose edge-dropout key is not that batch's)
+ * Steps run in GROUPS of M: the batches of a group sit in M arenas (one set per group parity), extracted while the
+ * previous group trained.  cursor_q = offset into the link permutation of the FIRST batch of the group of parity q; batch i
+ * of that group starts at cursor_q + i * B.  A tick (end of a step, igmc_ctrl_tick or the step's last kernel) does
+ * step += 1, k += 1, adam_t += 1, slots 13/14 recomputed, gk += 1 and -- when gk reaches M -- cursor_gq += 2 * M * B,
+ * gk = 0, gq ^= 1: the cursor a concurrent prefetch of the NEXT group reads (cursor_{1-gq}) is never written while it may
+ * be read.  M = 1 is the plain even / odd double buffer.
+ * Once attached (igmc_batch_set_ctrl), the host `first` of igmc_extract_batch / igmc_extract_batch_cached and the host
+ * `step` of igmc_batch_edge_dropout become a SELECTOR sel = q | (i << 1): first = cursor_q + i * B, epoch = ctrl.epoch,
+ * dropout key = (epoch, first / B); the forward's MLP dropout uses ctrl.step.  Every extraction stamps its arena with the
+ * `first` (and every edge dropout with the key) it resolved; the tick of the step that consumed the arena compares the
+ * stamp with cursor_gq + gk * B and raises sync_err on a mismatch (igmc_model_check reports it).  NULL detaches. */
 enum { IGMC_CTRL_STEP = 0, IGMC_CTRL_FIRST = 1, IGMC_CTRL_EPOCH = 2, IGMC_CTRL_ADAM_T = 3, IGMC_CTRL_BATCH = 4,
        IGMC_CTRL_DONE = 5, IGMC_CTRL_FIRST_ODD = 6, IGMC_CTRL_K = 7,
        IGMC_CTRL_LR = 8, IGMC_CTRL_BETA1 = 9, IGMC_CTRL_BETA2 = 10, IGMC_CTRL_EPS = 11, IGMC_CTRL_WD = 12,
-       IGMC_CTRL_STEP_SIZE = 13, IGMC_CTRL_INV_SQRT_BC2 = 14, IGMC_CTRL_FREE_RUN = 15, IGMC_CTRL_READY = 16,
-       IGMC_CTRL_READY_ODD = 17, IGMC_CTRL_SYNC_ERR = 18, IGMC_CTRL_WORDS = 24 };
+       IGMC_CTRL_STEP_SIZE = 13, IGMC_CTRL_INV_SQRT_BC2 = 14, IGMC_CTRL_GROUP = 15, IGMC_CTRL_GK = 16,
+       IGMC_CTRL_GQ = 17, IGMC_CTRL_SYNC_ERR = 18, IGMC_CTRL_WORDS = 24 };
 int igmc_ctrl_tick(int64_t* d_ctrl, void* stream);
-/* Free-running prefetch (no reference counterpart).  With [15] free_run != 0 the model chain and the extraction chain
- * of a multi-step graph need no stream dependency per step; they hand-shake through the control block itself:
- *   [16] ready_even / [17] ready_odd = `first` of the batch that sits completely extracted in the arena of that parity;
- *   igmc_batch_mark_ready(b, parity) (enqueue it behind the extraction [+ edge dropout] of that arena) sets
- *        ready[parity] = slot[parity];
- *   igmc_batch_gate(b, parity) (enqueue it in front of the NEXT extraction into that arena) waits until
- *        slot[parity] != ready[parity], i.e. until the step that consumed the arena's batch has advanced the cursor;
- *   the last kernel of a fused training step (igmc_train_step) waits until ready[(k+1) & 1] == slot[(k+1) & 1] before it
- *        ends, so the next step's kernels find their batch in place.
- * Waits are bounded; a wait that runs out sets [18] sync_err (the host checks it with the stream synchronised). */
-int igmc_batch_gate(igmc_batch* b, int parity, void* stream);
-int igmc_batch_mark_ready(igmc_batch* b, int parity, void* stream);
+/* Starts a new group at the current position (no reference counterpart): M steps per group, gk = 0, gq = 0,
+ * cursor_0 = first_cur (the batch of the next step), cursor_1 = first_next (first batch of the group after it). */
+int igmc_ctrl_regroup(int64_t* d_ctrl, int M, int64_t first_cur, int64_t first_next, void* stream);
 int igmc_batch_set_ctrl(igmc_batch* b, const int64_t* d_ctrl);
 int igmc_model_set_ctrl(igmc_model* m, const int64_t* d_ctrl);
 /* Adam + loss/epoch-total epilogue in ONE launch (the step's last kernel): updates d_params like
@@ -235,6 +233,26 @@ int igmc_train_step(igmc_model* m, float* d_params, const igmc_batch* b, int use
                     float eps, float weight_decay, void* stream);
 int igmc_adam_step_ctrl(float* d_params, const float* d_grad, float* d_exp_avg, float* d_exp_avg_sq,
                         int64_t n, const int64_t* d_ctrl, void* stream);
+
+/* ------------------------------------------------------------------ gradient exchange (data parallelism)
+ * The reference has no distributed code (single process, single device: train_eval.py:20); the hot path shards by LINKS
+ * (SURVEY.md 8(e)): one process per GPU, graph + parameters replicated, and the only exchange of a step is ONE sum
+ * all-reduce of the flat gradient buffer (49 233 floats at R = 5) between the gradient kernels and the Adam kernel.
+ * It is an RCCL ncclAllReduce enqueued on the caller's stream -- capturable into the step's hipGraph like any kernel --
+ * on a communicator owned by this library (RCCL is resolved with dlopen("librccl.so.1") at the first use: a process
+ * that never creates a communicator never loads it).
+ *   igmc_comm_unique_id : rank 0 draws the 128-byte RCCL id; the caller hands it to the other ranks (any transport)
+ *   igmc_comm_create    : collective over the `world` ranks; `device` = this rank's GPU.  world == 1 is valid.
+ *   igmc_comm_info      : rank / size AS SEEN BY RCCL (bench.py checks them against the launcher's)
+ *   igmc_allreduce_grads: d_flat_grad[i] = scale * sum over ranks of d_flat_grad[i], in place, asynchronous on `stream`.
+ *                         The gradient kernels already scale by 1/(B * world) (igmc_model_loss_grad), so scale = 1.
+ */
+typedef struct igmc_comm igmc_comm;
+int igmc_comm_unique_id(uint8_t* h_id128);
+int igmc_comm_create(const uint8_t* h_id128, int rank, int world, int device, igmc_comm** out);
+void igmc_comm_destroy(igmc_comm* c);
+int igmc_comm_info(const igmc_comm* c, int* rank, int* world);
+int igmc_allreduce_grads(igmc_comm* c, float* d_flat_grad, int64_t n, float scale, void* stream);
 
 /* Eval reduction helper (reference train_eval.py:195): d_acc[0] += sum_g (out-y)^2, d_acc[1] += B. */
 int igmc_sse_accumulate(const float* d_out, const igmc_batch* b, double* d_acc, void* stream);

@@ -107,3 +107,110 @@ def test_ctrl_path_equals_host_argument_path(monkeypatch, graph_step):
         # lr is a float argument on the host path and a double in the control block: last-ulp differences only
         for x, y in zip(a[2:], b[2:]):
             np.testing.assert_allclose(x, y, rtol=2e-5, atol=1e-7)
+
+
+def group_ctrl_words(step, epoch, adam_t, batch, group, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8, wd=0.0):
+    from igmc_amd.stepgraph import _ctrl_words
+    return _ctrl_words(step, epoch, adam_t, batch, group, lr, b1, b2, eps, wd)
+
+
+def test_group_control_walks_the_same_batches():
+    """Steps in GROUPS of M (igmc_hip.h, device-side step control; igmc_amd/stepgraph.py): the batches of a group sit in M
+    arenas, the next group's are extracted through selectors q | (i << 1) into the other arena set -- before, between
+    and after the steps of the running group, the cursor they resolve never moves meanwhile --, the tick of a group's
+    last step moves that group's cursor on by two groups and flips the parity.  Same links, same sampling, same dropout
+    draws, same parameters as the host-argument path, and no stamp mismatch; a batch extracted from the wrong cursor is
+    caught by the consuming step's tick."""
+    be = PC.EmuBackend()
+    lib = be.lib
+    case = CASES['synth_cap']
+    g = engine.Graph(case['A'], lib=lib)
+    n = len(case['links'])
+    lu = case['links'][:, 0].astype(np.int32).copy()
+    lv = case['links'][:, 1].astype(np.int32).copy()
+    ly = case['class_values'][case['link_labels']].astype(np.float32)
+    B, M, T = 2, 3, 8                                   # two full groups + two steps of the third
+    rng = np.random.default_rng(1)      # (few links in the fixture: the epoch "permutation" visits them several times)
+    perm = np.concatenate([rng.permutation(n) for _ in range(-(-B * (T + 2 * M) // n))]).astype(np.int32)
+    sets = [[engine.Batch(g, B, 1, case['mnph']) for _ in range(M)] for _ in range(2)]
+    ref_b = engine.Batch(g, B, 1, case['mnph'])
+    ws = engine.ModelWorkspace(lib, 0, 5, 4, 4, 0, ref_b.node_capacity, ref_b.edge_capacity, B)
+    P0 = PC.flatten_params(ws, PC.make_ref_model(4, 5, seed=4))
+
+    def run_host():
+        P, M1, M2 = P0.copy(), np.zeros_like(P0), np.zeros_like(P0)
+        G, out, loss = np.zeros_like(P0), np.zeros(B, np.float32), np.zeros(2, np.float32)
+        lib.call('igmc_model_set_ctrl', ws.handle, None)
+        rec = []
+        for t in range(T):
+            ref_b.extract(lu, lv, ly, perm, t * B, B, 1.0, 7, 3)
+            ref_b.edge_dropout(0.2, False, 7, (3 << 32) ^ t)
+            ws.loss_grad(P.ctypes.data, ref_b, out.ctypes.data, G.ctypes.data, loss.ctypes.data, use_edge_flags=True,
+                         seed=7, step=11 + t, ARR=0.001)
+            ws.adam_step(P.ctypes.data, G.ctypes.data, M1.ctypes.data, M2.ctypes.data, t + 1, 1e-3)
+            d = ref_b.download()
+            rec.append((d['node_gid'].copy(), d['eflag'].copy(), out.copy(), loss.copy(), P.copy()))
+        return rec
+
+    def run_groups(corrupt=False):
+        P, M1, M2 = P0.copy(), np.zeros_like(P0), np.zeros_like(P0)
+        G, out, loss = np.zeros_like(P0), np.zeros(B, np.float32), np.zeros(2, np.float32)
+        total = np.zeros(1, np.float64)
+        ctrl = group_ctrl_words(step=11, epoch=3, adam_t=1, batch=B, group=M)
+        cp = C.c_void_p(ctrl.ctypes.data)
+        for s in sets:
+            for a in s:
+                lib.call('igmc_batch_set_ctrl', a.handle, cp)
+        lib.call('igmc_model_set_ctrl', ws.handle, cp)
+
+        def extract(q, i):
+            sets[q][i].extract(lu, lv, ly, perm, q | (i << 1), B, 1.0, 7, 999)        # epoch argument ignored
+            sets[q][i].edge_dropout(0.2, False, 7, q | (i << 1))
+
+        def train(arena):
+            lib.call('igmc_train_step', ws.handle, C.c_void_p(P.ctypes.data), arena.handle, 1, None, 7, 0, 1.0, 0.001,
+                     C.c_void_p(out.ctypes.data), C.c_void_p(G.ctypes.data), C.c_void_p(M1.ctypes.data),
+                     C.c_void_p(M2.ctypes.data), C.c_void_p(loss.ctypes.data), C.c_void_p(total.ctypes.data), cp, 1,
+                     1e-3, 0.9, 0.999, 1e-8, 0.0, None)
+
+        for i in range(M):
+            extract(0, i)
+        rec, gq, t = [], 0, 0
+        while t < T:
+            steps = min(M, T - t)
+            for i in range(0, M, 2):                    # part of the prefetch before the group's steps ...
+                extract(1 - gq, i)
+            for i in range(steps):
+                if i == 1:
+                    for j in range(1, M, 4):            # ... part between them ...
+                        extract(1 - gq, j)
+                if corrupt and t + i == 4:
+                    sets[gq][i].extract(lu, lv, ly, perm, gq | (((i + 1) % M) << 1), B, 1.0, 7, 999)
+                train(sets[gq][i])
+                d = sets[gq][i].download()
+                rec.append((d['node_gid'].copy(), d['eflag'].copy(), out.copy(), loss.copy(), P.copy()))
+            for j in range(3, M, 4):                    # ... and the rest after the last tick of the group
+                extract(1 - gq, j)
+            t += steps
+            if steps == M:
+                gq ^= 1
+        for s in sets:
+            for a in s:
+                lib.call('igmc_batch_set_ctrl', a.handle, None)
+        lib.call('igmc_model_set_ctrl', ws.handle, None)
+        return rec, ctrl, total
+
+    host = run_host()
+    rec, ctrl, total = run_groups()
+    K = _lib.CTRL
+    assert ctrl[K['SYNC_ERR']] == 0
+    assert ctrl[K['STEP']] == 11 + T and ctrl[K['K']] == T and ctrl[K['ADAM_T']] == 1 + T
+    assert ctrl[K['GQ']] == (T // M) & 1 and ctrl[K['GK']] == T % M
+    assert ctrl[K['FIRST']] == 2 * M * B and ctrl[K['FIRST_ODD']] == 3 * M * B      # each parity finished one group
+    assert total[0] == pytest.approx(sum(float(r[3][0]) * B for r in rec), rel=1e-6)
+    for a, b in zip(host, rec):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        for x, y in zip(a[2:], b[2:]):
+            np.testing.assert_allclose(x, y, rtol=2e-5, atol=1e-7)
+    _, ctrl_bad, _ = run_groups(corrupt=True)
+    assert ctrl_bad[K['SYNC_ERR']] & 2

@@ -241,20 +241,20 @@ def test_main_script_end_to_end(tmp_path):
 
 
 def test_step_graph_paths_agree(flix, monkeypatch):
-    """The captured single-GPU step (igmc_train_step inside a hipGraph, prefetch on a second stream; groups of 8
-    steps per graph launch by default, one step per launch with IGMC_GRAPH_STEPS=0), the eager step, and the
-    multi-GPU launch structure (graph up to the gradients + eager all-reduce slot + step_finish)
-    must walk the same trajectory."""
+    """The captured single-GPU step (igmc_train_step inside a hipGraph, the next group's extraction on a second stream;
+    groups of 4 steps per graph launch here, one step per launch with IGMC_GROUP_STEPS=1), the eager step, and the
+    multi-GPU step (gradient kernels -> igmc_allreduce_grads on a one-rank RCCL communicator -> igmc_step_finish, captured
+    into the same groups) must walk the same trajectory.  flixster has R = 10: the per-layer kernels take these steps."""
     import torch
     from igmc_amd.models import IGMC
     from igmc_amd.stepgraph import StepGraph
     from igmc_amd.train_eval import FlatAdam
     tr, te, cv = make_sets(flix, ntr=600)
     results = {}
-    for name, env, kw in (('graph', {}, {}), ('eager', {}, dict(use_graph=False, overlap=False)),
-                          ('graph1', {'IGMC_GRAPH_STEPS': '0'}, {}), ('dp_path', {'IGMC_FORCE_DP_PATH': '1'}, {}),
-                          # multi-GPU structure with the weight update (and, at world > 1, the all-reduce) captured
-                          ('dp_captured', {'IGMC_FORCE_DP_PATH': '1', 'IGMC_DP_CAPTURE_ALLREDUCE': '1'}, {})):
+    for name, env, kw in (('graph', {}, dict(group=4)), ('eager', {}, dict(use_graph=False, overlap=False, group=4)),
+                          ('graph1', {'IGMC_GROUP_STEPS': '1'}, {}), ('dp_path', {'IGMC_FORCE_DP_PATH': '1'}, dict(group=4)),
+                          # ... with the all-reduce of a REAL (one-rank) RCCL communicator enqueued inside the captured group
+                          ('dp_comm', {'IGMC_FORCE_DP_PATH': '1', 'IGMC_DP_ALLREDUCE_ALWAYS': '1'}, dict(group=4))):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         torch.manual_seed(7)
@@ -268,20 +268,24 @@ def test_step_graph_paths_agree(flix, monkeypatch):
         total2, _ = sg.run_epoch(perm, 2)
         torch.cuda.synchronize()
         results[name] = (model.flat_parameters().detach().cpu().clone(), float(total2.item()), opt.t, model._step)
-        assert (sg.multi is not None) == (name in ('graph', 'dp_captured'))
+        assert any(g is not None for g in sg.graphs) == (name != 'eager'), name
+        assert (sg.comm is not None) == (name == 'dp_comm')
+        if sg.comm is not None:
+            assert sg.comm.info() == (0, 1)
         for k in env:
             monkeypatch.delenv(k)
     assert results['graph'][2] == 24 and results['graph'][3] == 24
-    for other in ('eager', 'graph1', 'dp_path', 'dp_captured'):
+    for other in ('eager', 'graph1', 'dp_path', 'dp_comm'):
         assert torch.allclose(results['graph'][0], results[other][0], rtol=2e-4, atol=2e-6), other
         assert results['graph'][1] == pytest.approx(results[other][1], rel=1e-4)
-    # the SAME kernels on the same inputs, only launched differently (8 steps per hipGraph launch / one per launch /
+    # the SAME kernels on the same inputs, only launched differently (4 steps per hipGraph launch / one per launch /
     # eagerly without overlap): no atomics on floats anywhere => the trajectories are bit-identical.  (Two training logs
     # of round 1 that diverged after a few epochs therefore came from different flags, not from the launch structure.)
     for other in ('eager', 'graph1'):
         assert torch.equal(results['graph'][0], results[other][0]), other
         assert results['graph'][1] == results[other][1], other
-    assert torch.equal(results['dp_path'][0], results['dp_captured'][0])
+    # a sum over ONE rank is the identity: the collective inside the graph changes nothing
+    assert torch.equal(results['dp_path'][0], results['dp_comm'][0])
 
 
 def test_full_size_headline_config_properties(monkeypatch):
@@ -531,11 +535,12 @@ def test_static_dataset_cache(flix, tmp_path):
     assert torch.equal(finals[0][0], finals[1][0]) and finals[0][1] == finals[1][1]
 
 
-def test_captured_all_reduce_structure_with_a_one_rank_rccl_group(tmp_path):
-    """IGMC_DP_CAPTURE_ALLREDUCE=1 with a REAL torch.distributed 'nccl' (= RCCL) process group of one rank: the flat
-    all-reduce is enqueued inside the captured step (thread-local capture next to the RCCL watchdog), 8 steps replay per
-    launch, and the trajectory equals the eager data-parallel structure's.  (A one-GPU box cannot say anything about
-    more ranks; this pins the capture / replay mechanics the multi-GPU run relies on.)"""
+def test_captured_all_reduce_next_to_a_torch_distributed_process_group(tmp_path):
+    """The multi-GPU configuration of bench.py / Main.py on one GPU: a REAL torch.distributed 'nccl' (= RCCL) process
+    group of one rank is up (its watchdog thread polls events while the step graph is captured: thread-local capture
+    mode), the library's own communicator is created from an id that travels over it, igmc_allreduce_grads is enqueued
+    inside the captured groups, and the trajectory equals the eagerly launched one.  (A one-GPU box cannot say anything
+    about more ranks; this pins the capture / replay mechanics the multi-GPU run relies on.)"""
     import os
     import subprocess
     import sys
@@ -554,23 +559,22 @@ dist.init_process_group(backend='nccl', init_method='tcp://127.0.0.1:29641', ran
 (_, _, adj, trl, tru, trv, _, _, _, _, _, _, cv) = preprocessing.load_data_monti('douban', testing=True)
 tr = MyDynamicDataset('data/t/dp1', adj, (tru[:1200], trv[:1200]), trl[:1200], 1, 1.0, 10000, None, None, cv)
 res = {}
-for name, cap in (('eager_tail', '0'), ('captured', '1')):
-    os.environ['IGMC_DP_CAPTURE_ALLREDUCE'] = cap
+for name, kw in (('eager', dict(use_graph=False, overlap=False)), ('captured', {})):
     torch.manual_seed(7)
     model = IGMC(tr, latent_dim=[32, 32, 32, 32], num_relations=len(cv), num_bases=4, regression=True,
                  adj_dropout=0.2, seed=3).to('cuda')
     model.reset_parameters()
     opt = FlatAdam(model, lr=1e-3)
-    sg = StepGraph(model, opt, tr, 50, 0.001)
-    assert sg.dp_path
+    sg = StepGraph(model, opt, tr, 50, 0.001, group=8, **kw)
+    assert sg.dp_path and sg.comm is not None and sg.comm.info() == (0, 1)
     perm = torch.randperm(len(tr), generator=torch.Generator().manual_seed(5))
     sg.run_epoch(perm, 1)
     total, n = sg.run_epoch(perm, 2)
     torch.cuda.synchronize()
-    res[name] = (model.flat_parameters().detach().cpu().clone(), float(total.item()), sg.multi is not None, sg.dp_capture)
-assert res['captured'][2] and res['captured'][3], 'the all-reduce was not captured: %%r' %% (res['captured'][2:],)
-assert not res['eager_tail'][2]
-assert torch.equal(res['eager_tail'][0], res['captured'][0]) and res['eager_tail'][1] == res['captured'][1]
+    res[name] = (model.flat_parameters().detach().cpu().clone(), float(total.item()), any(g is not None for g in sg.graphs))
+assert res['captured'][2], 'the groups (with the all-reduce inside) were not captured'
+assert not res['eager'][2]
+assert torch.equal(res['eager'][0], res['captured'][0]) and res['eager'][1] == res['captured'][1]
 dist.destroy_process_group()
 print('captured all-reduce ok')
 ''' % ROOT)

@@ -208,81 +208,87 @@ def test_training_steps_survive_a_competing_full_chip_kernel(ml1m):
     assert torch.equal(out['quiet'], out['loaded'])
 
 
-FREE_RUN_TESTS = pytest.mark.skipif(__import__('os').environ.get('IGMC_TEST_FREE_RUN', '0') != '1',
-                                    reason='free-running prefetch is opt-in (IGMC_FREE_RUN=1): one of seven two-epoch '
-                                           'comparisons diverged on the GPU (edge-dropout variant), cause open; '
-                                           'IGMC_TEST_FREE_RUN=1 runs these')
-
-
-@FREE_RUN_TESTS
-@pytest.mark.parametrize('drop', [0.0, 0.2])
-def test_free_running_prefetch_walks_the_same_trajectory(ml1m, monkeypatch, drop):
-    """IGMC_FREE_RUN=1: inside a multi-step graph the model chain and the extraction chain are forked once and joined once
-    and hand-shake through the control block (gate kernel / ready words / wait at the end of the fused step) instead of
-    through two stream dependencies per step.  Same kernels on the same batches: parameters, Adam state and epoch totals
-    must be bit-identical to the fork / join structure, over two epochs of 24 steps (3 graph launches of 8 each), and no
-    bounded wait may run out."""
+def _trajectory(ds, drop, perm, epochs=2, **sg_kw):
+    """Two epochs of StepGraph on ``ds``: parameters, Adam moments, epoch totals (bit-comparable)."""
     import torch
     from igmc_amd.models import IGMC
     from igmc_amd.stepgraph import StepGraph
     from igmc_amd.train_eval import FlatAdam
+    torch.manual_seed(3)
+    model = IGMC(ds, latent_dim=[32, 32, 32, 32], num_relations=5, num_bases=4, regression=True, adj_dropout=drop,
+                 seed=1).to('cuda')
+    model.reset_parameters()
+    opt = FlatAdam(model, lr=1e-3)
+    sg = StepGraph(model, opt, ds, 50, 0.001, **sg_kw)
+    totals = []
+    for ep in range(1, epochs + 1):
+        t, n = sg.run_epoch(perm, ep)          # (run_epoch ends in check(): no stamp mismatch, no timed-out wait)
+        totals.append(float(t.item()))
+    torch.cuda.synchronize()
+    return sg, (model.flat_parameters().detach().cpu().clone(), opt.exp_avg.detach().cpu().clone(),
+                opt.exp_avg_sq.detach().cpu().clone(), totals, opt.t)
+
+
+def _assert_same(a, b, what):
+    import torch
+    for i, (x, y) in enumerate(zip(a, b)):
+        if torch.is_tensor(x):
+            assert torch.equal(x, y), '%s: tensor %d differs in %d of %d elements, max |d| %.3e' % (
+                what, i, int((x != y).sum()), x.numel(), float((x - y).abs().max()))
+        else:
+            assert x == y, '%s: %r != %r' % (what, x, y)
+
+
+@pytest.mark.parametrize('data', ['ml_1m', 'douban'])
+@pytest.mark.parametrize('drop', [0.0, 0.2])
+def test_step_graph_is_bit_reproducible_and_structure_independent(ml1m, monkeypatch, drop, data):
+    """The DEFAULT training structure (groups of steps per hipGraph launch, next group's extraction on a second stream,
+    lean arenas, edge dropout drawn on the dense blocks inside the graph) at the headline shape and on douban:
+    * run twice from the same seed -> parameters, Adam moments and epoch totals bit-equal (no float atomics, no race);
+    * groups of 8 per launch == groups of 4 == every step launched eagerly on one stream: the same kernels on the same
+      batches, whatever launches them.
+    Two epochs of 24 steps each (1200 links): the first epoch of a process holds an eager first step + a re-grouping, both
+    epochs hold whole groups replayed from the graph and an eagerly launched remainder."""
+    import torch
     from igmc_amd.util_functions import MyDynamicDataset
-    A, cv = ml1m['A'], ml1m['class_values']
-    rng = np.random.default_rng(11)
-    coo = A.tocoo()
-    pick = rng.permutation(coo.nnz)[:1200]
-    u, v, y = coo.row[pick], coo.col[pick], (coo.data[pick] - 1).astype(np.int64)
-    ds = MyDynamicDataset('data/t/freerun', A, (u, v), y, 1, 1.0, 100, None, None, cv, device=0, seed=1)
+    if data == 'ml_1m':
+        A, cv = ml1m['A'], ml1m['class_values']
+        rng = np.random.default_rng(11)
+        coo = A.tocoo()
+        pick = rng.permutation(coo.nnz)[:1200]
+        u, v, y = coo.row[pick], coo.col[pick], (coo.data[pick] - 1).astype(np.int64)
+        ds = MyDynamicDataset('data/t/repro', A, (u, v), y, 1, 1.0, 100, None, None, cv, device=0, seed=1)
+    else:
+        from igmc_amd import preprocessing
+        (_, _, A, tr_l, tr_u, tr_v, _, _, _, _, _, _, cv) = preprocessing.load_data_monti('douban', testing=True)
+        ds = MyDynamicDataset('data/t/repro_d', A, (tr_u[:1200], tr_v[:1200]), tr_l[:1200], 1, 1.0, 10000, None, None, cv,
+                              device=0, seed=1)
     perm = torch.randperm(len(ds), generator=torch.Generator().manual_seed(5))
-    out = {}
-    for mode in ('0', '1'):
-        monkeypatch.setenv('IGMC_FREE_RUN', mode)
-        torch.manual_seed(3)
-        model = IGMC(ds, latent_dim=[32, 32, 32, 32], num_relations=5, num_bases=4, regression=True, adj_dropout=drop,
-                     seed=1).to('cuda')
-        model.reset_parameters()
-        opt = FlatAdam(model, lr=1e-3)
-        sg = StepGraph(model, opt, ds, 50, 0.001)
-        assert sg.ws.dense_path(sg.arenas[0], 50) and sg.free_run == (mode == '1')
-        t1, n1 = sg.run_epoch(perm, 1)
-        t1 = float(t1.item())
-        t2, _ = sg.run_epoch(perm, 2)
-        torch.cuda.synchronize()
-        assert sg.multi is not None and n1 == 1200 and opt.t == 48
-        out[mode] = (model.flat_parameters().detach().cpu().clone(), opt.exp_avg.detach().cpu().clone(),
-                     opt.exp_avg_sq.detach().cpu().clone(), t1, float(t2.item()))
-    for a, b in zip(out['0'], out['1']):
-        assert (torch.equal(a, b) if torch.is_tensor(a) else a == b)
+    sg, ref = _trajectory(ds, drop, perm, group=8)
+    assert sg.ws.dense_path(sg.arenas[0], 50) and any(g is not None for g in sg.graphs) and ref[4] == 48
+    for rep in range(2):
+        _, again = _trajectory(ds, drop, perm, group=8)
+        _assert_same(ref, again, 'groups of 8, repeat %d' % rep)
+    _, g4 = _trajectory(ds, drop, perm, group=4)
+    _assert_same(ref, g4, 'groups of 4 vs groups of 8')
+    sg_e, eager = _trajectory(ds, drop, perm, use_graph=False, overlap=False, group=8)
+    assert not any(g is not None for g in sg_e.graphs)
+    _assert_same(ref, eager, 'eager one-stream launches vs groups of 8')
 
 
-@FREE_RUN_TESTS
-def test_free_running_prefetch_on_the_dense_per_layer_path(monkeypatch):
-    """... and where the dense per-layer kernels take the step (config 2 shape: ml_100k, cap 200, edge dropout 0.2): the
-    fused per-layer sequence ends in the same k_finalize_ts, so the same hand-shake applies."""
+def test_step_graph_on_the_dense_per_layer_path_is_reproducible():
+    """... and where the dense per-layer kernels take the step (config 2 shape: ml_100k, cap 200, edge dropout 0.2)."""
     import torch
     from igmc_amd import preprocessing
-    from igmc_amd.models import IGMC
-    from igmc_amd.stepgraph import StepGraph
-    from igmc_amd.train_eval import FlatAdam
     from igmc_amd.util_functions import MyDynamicDataset
     (_, _, A, tr_l, tr_u, tr_v, _, _, _, _, _, _, cv) = preprocessing.create_trainvaltest_split('ml_100k', 1234, True, verbose=False)
     pick = np.random.default_rng(3).permutation(len(tr_u))[:1000]
     ds = MyDynamicDataset('data/t/frdl', A, (tr_u[pick], tr_v[pick]), np.asarray(tr_l)[pick], 1, 1.0, 200, None, None, cv,
                           device=0, seed=1)
     perm = torch.randperm(len(ds), generator=torch.Generator().manual_seed(5))
-    out = {}
-    for mode in ('0', '1'):
-        monkeypatch.setenv('IGMC_FREE_RUN', mode)
-        torch.manual_seed(3)
-        model = IGMC(ds, latent_dim=[32, 32, 32, 32], num_relations=5, num_bases=4, regression=True, adj_dropout=0.2,
-                     seed=1).to('cuda')
-        model.reset_parameters()
-        opt = FlatAdam(model, lr=1e-3)
-        sg = StepGraph(model, opt, ds, 50, 0.001)
-        assert sg.arenas[0].dense_layers(sg.ws) and sg.free_run == (mode == '1')
-        sg.run_epoch(perm, 1)
-        t2, _ = sg.run_epoch(perm, 2)
-        torch.cuda.synchronize()
-        assert sg.multi is not None
-        out[mode] = (model.flat_parameters().detach().cpu().clone(), float(t2.item()))
-    assert torch.equal(out['0'][0], out['1'][0]) and out['0'][1] == out['1'][1]
+    sg, ref = _trajectory(ds, 0.2, perm, group=8)
+    assert sg.arenas[0].dense_layers(sg.ws) and any(g is not None for g in sg.graphs)
+    _, again = _trajectory(ds, 0.2, perm, group=8)
+    _assert_same(ref, again, 'dense per-layer path, repeat')
+    _, eager = _trajectory(ds, 0.2, perm, use_graph=False, overlap=False, group=8)
+    _assert_same(ref, eager, 'dense per-layer path, eager vs graph')
