@@ -186,13 +186,19 @@ def main(argv=None):
     if rank == 0:
         print('#train: %d, #val: %d, #test: %d' % (len(train_u), len(val_u), len(test_u)))
 
-    # ---- datasets (reference Main.py:297-350): GPU-resident, nothing is cached on disk
+    # ---- datasets (reference Main.py:297-350): GPU-resident; static datasets keep their node sets under
+    #      data/<name>/<mode>/<part>/processed/ (MyDataset.process: built by rank 0, loaded by the others)
     data_combo = (args.data_name, args.data_appendix, val_test_appendix)
     if args.reprocess:
-        for part in ('train', 'val', 'test'):
-            d = 'data/{}{}/{}/{}'.format(*(data_combo + (part,)))
-            if os.path.isdir(d):
-                rmtree(d)
+        if rank == 0:
+            for part in ('train', 'val', 'test'):
+                d = 'data/{}{}/{}/{}'.format(*(data_combo + (part,)))
+                if os.path.isdir(d):
+                    rmtree(d)
+        parallel.barrier()      # nobody looks for a cache before rank 0 has removed the old one
+    if args.dgcnn_rs and args.use_features:
+        raise SystemExit('--dgcnn-rs takes no side features (the sort-pool readout has no place for them, '
+                         'reference models.py:123-167): drop --use-features')
 
     def make(dynamic, part, idx, labels, max_num):
         cls = MyDynamicDataset if dynamic else MyDataset

@@ -142,7 +142,9 @@ def cpu_baseline_worker(path):
     # baseline gets the best of a few thread counts, probed on a 10-graph batch
     probe = pyg_ref.Batch.from_data_list(_worker_extract(batches[0][:10]))
     best, threads = None, 1
-    for th in sorted(set([min(8, ncpu), min(16, ncpu), min(32, ncpu), min(64, ncpu)])):
+    # (threads + extraction workers never exceed the CPUs granted: `cores` below is what really runs)
+    tmax = max(1, ncpu - n_workers)
+    for th in sorted(set([min(4, tmax), min(8, tmax), min(16, tmax), min(32, tmax), min(64, tmax)])):
         torch.set_num_threads(th)
         pyg_ref.train_step(model, opt, probe, ARR=0.001)
         t0 = time.perf_counter()
@@ -201,6 +203,13 @@ def cpu_baseline(A, tr_u, tr_v, tr_l, class_values, mnph, adj_dropout, mode, bud
 
 
 def main():
+    # stdout carries the ONE JSON line and nothing else: libraries that print to the C-level stdout (RCCL's version banner
+    # at communicator creation, flushed at exit) are pointed at stderr for the whole run
+    real_stdout = sys.stdout
+    if '--cpu-baseline-worker' not in sys.argv:
+        sys.stdout.flush()
+        real_stdout = os.fdopen(os.dup(1), 'w')
+        os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
@@ -544,7 +553,8 @@ def main():
             'final_loss': final_loss, 'kernels_us': {k: round(v['us'], 2) for k, v in kernels.items()},
             'kernel_src_sha': kernel_source_sha(),
         }
-        print(json.dumps(rec))
+        real_stdout.write(json.dumps(rec) + '\n')
+        real_stdout.flush()
     if parallel.is_dist():
         torch.distributed.destroy_process_group()
 

@@ -559,9 +559,12 @@ extern "C" int igmc_batch_bind_side_source(igmc_batch* b, const float* d_side_al
     return 0;
   }
   if (b->side_buf_cols < n_side) {
+    // (a wider re-bind carves a new buffer out of the arena's slabs; the old one stays part of them and is released with
+    //  the arena -- slabs have no per-buffer free -- so grow geometrically to bound what repeated re-binds can take)
     HIPCHECK(hipSetDevice(b->g->device));
-    if (b->mem.get(&b->side_buf, (size_t)b->d.graph_cap * n_side)) IGMC_FAIL("hipMalloc failed (side features)");
-    b->side_buf_cols = n_side;
+    const int cols = std::max(n_side, 2 * b->side_buf_cols);
+    if (b->mem.get(&b->side_buf, (size_t)b->d.graph_cap * cols)) IGMC_FAIL("hipMalloc failed (side features)");
+    b->side_buf_cols = cols;
   }
   b->side_src = d_side_all;
   b->side = b->side_buf;

@@ -282,6 +282,10 @@ class DGCNN_RS(IGMC):
     def _subgraph_sizes(dataset, max_samples=1000):
         """``[g.num_nodes for g in dataset]`` of the reference, on an evenly spaced sample of at most ``max_samples``
         links (the reference walks the whole dataset: minutes of extraction for a number that is a percentile)."""
+        cache = getattr(dataset, '_cache_t', None)
+        if cache is not None:       # static dataset: the node-set cache holds every subgraph's size -- exact, like the reference
+            uo, vo = cache['uoff'].cpu().numpy(), cache['voff'].cpu().numpy()
+            return [int(x) for x in (uo[1:] - uo[:-1]) + (vo[1:] - vo[:-1])]
         n = len(dataset)
         step = max(1, n // max_samples)
         return [int(dataset[i].num_nodes) for i in range(0, n, step)]

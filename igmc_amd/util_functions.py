@@ -361,17 +361,24 @@ class MyDataset(_EngineDataset):
 
     def process(self, chunk=512):
         """reference ``MyDataset.process`` (``:101-110``): extract every subgraph once and store the cache; or load it."""
+        from . import parallel
         path = self.processed_paths[0]
         fp = self._fingerprint()
-        z = None
-        if os.path.exists(path):
-            try:
-                z = np.load(path)
-                if str(z['fingerprint']) != fp:
-                    z = None
-            except Exception:
-                z = None
-        if z is None:
+
+        def load():
+            if os.path.exists(path):
+                try:
+                    zz = np.load(path)
+                    if str(zz['fingerprint']) == fp:
+                        return zz
+                except Exception:
+                    pass
+            return None
+        # several ranks: rank 0 builds the cache (the others would extract the same subgraphs and race on the same file),
+        # everybody loads it after the barrier
+        builder = parallel.rank() == 0
+        z = load() if builder else None
+        if z is None and builder:
             n = len(self)
             uoff, voff = np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64)
             un, vn, ud, vd = [], [], [], []
@@ -395,9 +402,16 @@ class MyDataset(_EngineDataset):
             z = dict(uoff=uoff, voff=voff, unodes=cat(un, np.int32), vnodes=cat(vn, np.int32), udist=cat(ud, np.uint8),
                      vdist=cat(vd, np.uint8), fingerprint=np.array(fp))
             os.makedirs(os.path.dirname(path), exist_ok=True)
-            tmp = path + '.tmp.npz'
+            tmp = '%s.%d.tmp.npz' % (path, os.getpid())
             np.savez(tmp, **z)
             os.replace(tmp, path)
+        if parallel.world_size() > 1:
+            parallel.barrier()
+            if not builder:
+                z = load()
+                if z is None:
+                    raise RuntimeError('rank %d: the static-dataset cache %s written by rank 0 is missing or stale '
+                                       '(ranks must share the data directory)' % (parallel.rank(), path))
         dev = 'cuda:%d' % self.device
         self._cache_t = {k: torch.from_numpy(np.ascontiguousarray(z[k])).to(dev) for k in
                          ('uoff', 'voff', 'unodes', 'vnodes', 'udist', 'vdist')}

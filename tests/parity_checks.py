@@ -2,6 +2,8 @@
 GPU tests (real gfx950 library through the same C ABI).  A ``Backend`` hides where buffers live."""
 import ctypes
 
+import os
+
 import numpy as np
 
 from helpers import batch_to_pyg, golden_canonical, graph_canonical
@@ -193,12 +195,21 @@ def reverse_positions(d):
     return np.array([pos[(int(t), int(s))] for s, t in zip(src, dst)], dtype=np.int64)
 
 
+# Tolerances of the fp32 model parity (engine vs oracle/pyg_ref on identical subgraphs, weights and masks), set from what
+# the MI355X shows (profiles/r03_parity_observed.txt lists the worst case of every GPU test): <= 10x the observed worst.
+OUT_RTOL, OUT_ATOL = 2e-4, 2e-5      # outputs (rating units)
+LOSS_RTOL = 2e-4
+GRAD_TOL = 2e-3                      # every gradient tensor, max error relative to the tensor's peak
+
+
 def run_model_parity(be, case, R, ARR=0.001, use_dropout=True, multiply_by=1.0, seed=3, check_eval=True,
-                     rtol=2e-4, atol=2e-5, n_side=0, lean=False):
+                     rtol=None, atol=None, n_side=0, lean=False):
     """Engine forward / loss+grad on one extracted batch vs the PyG-1.4.2 restatement (oracle/pyg_ref.py)
     on IDENTICAL inputs: same subgraphs, same weights, same dropout masks."""
     import torch
     from oracle import pyg_ref
+    rtol = OUT_RTOL if rtol is None else rtol
+    atol = OUT_ATOL if atol is None else atol
     g, b, d = extract_case(be, case, replay=False, lean=lean)
     L = 2 * case['h'] + 2
     ws = engine.ModelWorkspace(be.lib, be.device, R, 4, L, n_side, b.node_capacity, b.edge_capacity, b.max_graphs)
@@ -221,6 +232,7 @@ def run_model_parity(be, case, R, ARR=0.001, use_dropout=True, multiply_by=1.0, 
         ws.forward(be.ptr(P), b, be.ptr(out), training=False, multiply_by=multiply_by)
         sse, ref_out = pyg_ref.eval_sse(ref, pyg)
         got = be.host(out)
+        res['eval_err'] = rel_err(got, ref_out.numpy())
         np.testing.assert_allclose(got, ref_out.numpy(), rtol=rtol, atol=atol)
         res['eval_out'] = got
         acc = be.dev(np.zeros(2, np.float64))
@@ -244,19 +256,50 @@ def run_model_parity(be, case, R, ARR=0.001, use_dropout=True, multiply_by=1.0, 
     rl, ro, rg = pyg_ref.loss_and_grads(ref, pyg, ARR=ARR, edge_mask=edge_mask,
                                         lin_mask=torch.from_numpy(lin_mask))
     got_out, got_loss = be.host(out), be.host(loss)
-    np.testing.assert_allclose(got_out, ro.numpy(), rtol=rtol, atol=atol)
-    assert got_loss[0] == pytest_approx(float(rl), 2e-4)
     gg = unflatten_grads(ws, be.host(grad))
-    worst = 0.0
+    worst, worst_key = 0.0, ''
     for key, ref_g in rg.items():
         rgn = ref_g.numpy()
         scale = max(np.abs(rgn).max(), 1e-6)
         err = np.abs(gg[key] - rgn).max() / scale
-        worst = max(worst, err)
-        assert err < 2e-3, '%s: max rel-to-peak grad error %.3e' % (key, err)
+        if err > worst:
+            worst, worst_key = err, key
+    record_observed('model_parity', R=R, B=int(B), N=int(d['N']), E=int(d['E']), dropout=bool(use_dropout), lean=bool(lean),
+                    eval_out_rel=res.get('eval_err'), train_out_rel=rel_err(got_out, ro.numpy()),
+                    loss_rel=abs(float(got_loss[0]) - float(rl)) / max(abs(float(rl)), 1e-12), worst_grad_rel=worst,
+                    worst_grad_tensor=worst_key)
+    np.testing.assert_allclose(got_out, ro.numpy(), rtol=rtol, atol=atol)
+    assert got_loss[0] == pytest_approx(float(rl), LOSS_RTOL)
+    assert worst < GRAD_TOL, '%s: max rel-to-peak grad error %.3e' % (worst_key, worst)
     res.update(train_out=got_out, loss=got_loss, worst_grad_err=worst, ws=ws, batch=b, graph=g, P=P, flat=flat,
                ref=ref, d=d, side=side_buf)
     return res
+
+
+def record_observed(kind, **vals):
+    """Append the observed worst errors of a parity check to a JSON-lines log (``IGMC_PARITY_LOG``, default
+    ``gpurun_out/parity_observed.jsonl`` when that directory exists): the asserted tolerances are set from what the GPU
+    actually shows (profiles/r03_parity_observed.txt), not from a guess."""
+    import json
+    path = os.environ.get('IGMC_PARITY_LOG')
+    if path is None:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+        if not os.path.isdir(d):
+            return
+        path = os.path.join(d, 'parity_observed.jsonl')
+    rec = dict(kind=kind, test=os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0])
+    rec.update({k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in vals.items()})
+    try:
+        with open(path, 'a') as f:
+            f.write(json.dumps(rec) + '\n')
+    except OSError:
+        pass
+
+
+def rel_err(got, ref):
+    """max |got - ref| / max(|ref|_inf, tiny): error relative to the tensor's peak."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-12)) if ref.size else 0.0
 
 
 def pytest_approx(v, rel):
@@ -376,16 +419,27 @@ def run_free_running_dropout(be, case, R, p=0.2, force_undirected=False, seed=11
         sel = (pyg.edge_index[0] < pyg.edge_index[1]).numpy()      # the half dropout_adj draws on
         keep = keep[torch.from_numpy(sel)]
     rl, ro, rg = pyg_ref.loss_and_grads(ref, pyg, ARR=0.001, edge_mask=keep, lin_mask=torch.from_numpy(lm.astype(bool)))
-    np.testing.assert_allclose(be.host(out), ro.numpy(), rtol=2e-4, atol=2e-5)
-    assert be.host(loss)[0] == pytest_approx(float(rl), 2e-4)
     gg = unflatten_grads(ws, be.host(grad))
-    worst = 0.0
+    worst, worst_key = 0.0, ''
     for key, ref_g in rg.items():
         rgn = ref_g.numpy()
         err = np.abs(gg[key] - rgn).max() / max(np.abs(rgn).max(), 1e-6)
-        worst = max(worst, err)
-        assert err < 2e-3, '%s: max rel-to-peak grad error %.3e' % (key, err)
+        if err > worst:
+            worst, worst_key = err, key
+    record_observed('free_running_dropout', R=R, B=int(B), N=int(d['N']), E=int(d['E']), lean=bool(lean),
+                    force_undirected=bool(force_undirected), train_out_rel=rel_err(be.host(out), ro.numpy()),
+                    loss_rel=abs(float(be.host(loss)[0]) - float(rl)) / max(abs(float(rl)), 1e-12), worst_grad_rel=worst,
+                    worst_grad_tensor=worst_key)
+    np.testing.assert_allclose(be.host(out), ro.numpy(), rtol=OUT_RTOL, atol=OUT_ATOL)
+    assert be.host(loss)[0] == pytest_approx(float(rl), LOSS_RTOL)
+    assert worst < GRAD_TOL, '%s: max rel-to-peak grad error %.3e' % (worst_key, worst)
     return dict(worst_grad_err=worst, keep_rate=float((flags & 1).mean()), lin_rate=float(lm.mean()))
+
+
+# fused multi-step trajectory vs pyg_ref.train_step + torch.optim.Adam (same provenance as the tolerances above)
+TRAJ_LOSS_RTOL = 5e-4
+TRAJ_M1_TOL, TRAJ_M2_TOL = 2e-3, 4e-3          # Adam moments, relative to the tensor's peak
+TRAJ_P_ATOL, TRAJ_P_RTOL, TRAJ_FRAC_OFF = 2e-5, 2e-3, 2e-3
 
 
 def run_fused_train_trajectory(be, case, R, steps=5, batch=None, use_dropout=False, lr=1e-3, ARR=0.001, seed=4):
@@ -433,26 +487,30 @@ def run_fused_train_trajectory(be, case, R, steps=5, batch=None, use_dropout=Fal
         be.sync()
         ref_loss = pyg_ref.train_step(ref, opt, pyg, ARR=ARR, edge_mask=edge_mask, lin_mask=torch.from_numpy(lm))
         got = float(be.host(loss)[0])
-        assert got == pytest_approx(ref_loss, 5e-4), (s, got, ref_loss)
         losses.append((got, ref_loss))
     be.lib.call('igmc_model_check', ws.handle, None)
     # Adam state: exp_avg is LINEAR in the gradients -> tight, per tensor relative to its peak
     m1 = unflatten_grads(ws, be.host(M1))
     m2 = unflatten_grads(ws, be.host(M2))
-    names = [k for k, _ in ref.named_parameters()]
+    worst_m1 = worst_m2 = 0.0
     for i, (k, prm) in enumerate(ref.named_parameters()):
         st = opt.state[prm]
         ea, es = st['exp_avg'].numpy(), st['exp_avg_sq'].numpy()
-        assert np.abs(m1[k] - ea).max() <= 2e-3 * max(np.abs(ea).max(), 1e-9), (k, float(np.abs(m1[k] - ea).max()),
-                                                                                   float(np.abs(ea).max()))
-        assert np.abs(m2[k] - es).max() <= 4e-3 * max(np.abs(es).max(), 1e-12), k
+        worst_m1 = max(worst_m1, float(np.abs(m1[k] - ea).max() / max(np.abs(ea).max(), 1e-9)))
+        worst_m2 = max(worst_m2, float(np.abs(m2[k] - es).max() / max(np.abs(es).max(), 1e-12)))
     got_p, want_p = be.host(P), flatten_params(ws, ref)
     diff = np.abs(got_p - want_p)
-    tol = 2e-5 + 2e-3 * np.abs(want_p)
+    tol = TRAJ_P_ATOL + TRAJ_P_RTOL * np.abs(want_p)
     # Adam divides by sqrt(v): an element whose gradient is within float noise of zero may take its (<= lr) step in
     # the other direction, so a handful of elements can be off by up to 2 * lr * steps; everything else must track
     bad = diff > tol
-    assert bad.mean() < 2e-3, 'too many parameters off the oracle trajectory: %g' % bad.mean()
+    loss_rel = max(abs(a - b) / max(abs(b), 1e-12) for a, b in losses)
+    record_observed('fused_trajectory', R=R, steps=steps, batch=int(B), dropout=bool(use_dropout), loss_rel=loss_rel,
+                    exp_avg_rel=worst_m1, exp_avg_sq_rel=worst_m2, params_frac_off=float(bad.mean()),
+                    params_max_diff=float(diff.max()), lr_steps=lr * steps)
+    assert loss_rel < TRAJ_LOSS_RTOL, losses
+    assert worst_m1 <= TRAJ_M1_TOL and worst_m2 <= TRAJ_M2_TOL, (worst_m1, worst_m2)
+    assert bad.mean() < TRAJ_FRAC_OFF, 'too many parameters off the oracle trajectory: %g' % bad.mean()
     assert diff.max() <= 2.0 * lr * steps + 1e-6, diff.max()
     return dict(losses=losses, frac_off=float(bad.mean()), max_diff=float(diff.max()), total=float(be.host(total)[0]),
                 params=got_p, m1=be.host(M1), m2=be.host(M2), ws=ws)
