@@ -53,6 +53,8 @@
 // phase clocks (debug aid, IGMC_GS_TIMING=1; igmc_debug_g2_clocks): thread 0 of workgroup 0 (member 0, user side) -> slots
 // 0..39 (fine stamps of its wave 0: 40..63), thread 0 of member 2 of the same subgraph (item side) -> slots 64..103
 __device__ unsigned long long g_g2_clk[128];
+// ... and (same switch) start / end of EVERY workgroup on the constant-rate wall clock + its XCC id: [wg][0..2]
+__device__ unsigned long long g_g2_wg[1024][3];
 #ifdef IGMC_HIPEMU
 #define G2_STAMP(k) do { } while (0)
 #else
@@ -478,6 +480,12 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
 #endif
   auto tag16 = [&](int x) { return 1u + (tag0 + (uint32_t)x) % 65535u; };
   G2_STAMP(0);
+#ifndef IGMC_HIPEMU
+  if (a.timing && tid == 0 && blockIdx.x < 1024) {
+    g_g2_wg[blockIdx.x][0] = (unsigned long long)wall_clock64();
+    g_g2_wg[blockIdx.x][2] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID
+  }
+#endif
 
   // ---- the first subgraph's extents are requested before anything else (two dependent round trips overlap with
   //      the staging of the layer-0 table, which k_g2_compose formed from the current weights)
@@ -1114,6 +1122,21 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
   }
 #endif
   G2_STAMP(35);
+#ifndef IGMC_HIPEMU
+  if (a.timing && tid == 0 && blockIdx.x < 1024) g_g2_wg[blockIdx.x][1] = (unsigned long long)wall_clock64();
+#endif
+}
+
+// debug aid: start / end (wall clock, 100 MHz) and XCC of every workgroup of the last k_graph_step2 launched with IGMC_GS_TIMING
+extern "C" int igmc_debug_g2_wg_clocks(unsigned long long* out, int n_wg) {
+#ifndef IGMC_HIPEMU
+  if (n_wg > 1024) n_wg = 1024;
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_g2_wg), (size_t)n_wg * 3 * sizeof(unsigned long long)) != hipSuccess) return 1;
+#else
+  for (int i = 0; i < 3 * n_wg; ++i) out[i] = 0;
+#endif
+  return 0;
 }
 
 // debug aid: phase clocks (shader cycles) of the last k_graph_step2 launched with IGMC_GS_TIMING set

@@ -197,9 +197,10 @@ def reverse_positions(d):
 
 # Tolerances of the fp32 model parity (engine vs oracle/pyg_ref on identical subgraphs, weights and masks), set from what
 # the MI355X shows (profiles/r03_parity_observed.txt lists the worst case of every GPU test): <= 10x the observed worst.
-OUT_RTOL, OUT_ATOL = 2e-4, 2e-5      # outputs (rating units)
-LOSS_RTOL = 2e-4
-GRAD_TOL = 2e-3                      # every gradient tensor, max error relative to the tensor's peak
+# Observed worst on the GPU: outputs 2.0e-6, loss 2.9e-7, gradients 4.6e-6 (round 2 asserted 2e-4 / 2e-4 / 2e-3).
+OUT_TOL = 2e-5                       # outputs, max error relative to the batch's peak |output| (rating units)
+LOSS_RTOL = 3e-6
+GRAD_TOL = 5e-5                      # every gradient tensor, max error relative to the tensor's peak
 
 
 def run_model_parity(be, case, R, ARR=0.001, use_dropout=True, multiply_by=1.0, seed=3, check_eval=True,
@@ -208,8 +209,7 @@ def run_model_parity(be, case, R, ARR=0.001, use_dropout=True, multiply_by=1.0, 
     on IDENTICAL inputs: same subgraphs, same weights, same dropout masks."""
     import torch
     from oracle import pyg_ref
-    rtol = OUT_RTOL if rtol is None else rtol
-    atol = OUT_ATOL if atol is None else atol
+    out_tol = OUT_TOL if rtol is None else rtol
     g, b, d = extract_case(be, case, replay=False, lean=lean)
     L = 2 * case['h'] + 2
     ws = engine.ModelWorkspace(be.lib, be.device, R, 4, L, n_side, b.node_capacity, b.edge_capacity, b.max_graphs)
@@ -233,7 +233,7 @@ def run_model_parity(be, case, R, ARR=0.001, use_dropout=True, multiply_by=1.0, 
         sse, ref_out = pyg_ref.eval_sse(ref, pyg)
         got = be.host(out)
         res['eval_err'] = rel_err(got, ref_out.numpy())
-        np.testing.assert_allclose(got, ref_out.numpy(), rtol=rtol, atol=atol)
+        assert res['eval_err'] < out_tol, 'eval outputs: max error relative to the peak %.3e' % res['eval_err']
         res['eval_out'] = got
         acc = be.dev(np.zeros(2, np.float64))
         ws.sse_accumulate(be.ptr(out), b, be.ptr(acc))
@@ -268,7 +268,7 @@ def run_model_parity(be, case, R, ARR=0.001, use_dropout=True, multiply_by=1.0, 
                     eval_out_rel=res.get('eval_err'), train_out_rel=rel_err(got_out, ro.numpy()),
                     loss_rel=abs(float(got_loss[0]) - float(rl)) / max(abs(float(rl)), 1e-12), worst_grad_rel=worst,
                     worst_grad_tensor=worst_key)
-    np.testing.assert_allclose(got_out, ro.numpy(), rtol=rtol, atol=atol)
+    assert rel_err(got_out, ro.numpy()) < out_tol, 'train outputs: max error relative to the peak %.3e' % rel_err(got_out, ro.numpy())
     assert got_loss[0] == pytest_approx(float(rl), LOSS_RTOL)
     assert worst < GRAD_TOL, '%s: max rel-to-peak grad error %.3e' % (worst_key, worst)
     res.update(train_out=got_out, loss=got_loss, worst_grad_err=worst, ws=ws, batch=b, graph=g, P=P, flat=flat,
@@ -430,16 +430,19 @@ def run_free_running_dropout(be, case, R, p=0.2, force_undirected=False, seed=11
                     force_undirected=bool(force_undirected), train_out_rel=rel_err(be.host(out), ro.numpy()),
                     loss_rel=abs(float(be.host(loss)[0]) - float(rl)) / max(abs(float(rl)), 1e-12), worst_grad_rel=worst,
                     worst_grad_tensor=worst_key)
-    np.testing.assert_allclose(be.host(out), ro.numpy(), rtol=OUT_RTOL, atol=OUT_ATOL)
+    assert rel_err(be.host(out), ro.numpy()) < OUT_TOL
     assert be.host(loss)[0] == pytest_approx(float(rl), LOSS_RTOL)
     assert worst < GRAD_TOL, '%s: max rel-to-peak grad error %.3e' % (worst_key, worst)
     return dict(worst_grad_err=worst, keep_rate=float((flags & 1).mean()), lin_rate=float(lm.mean()))
 
 
 # fused multi-step trajectory vs pyg_ref.train_step + torch.optim.Adam (same provenance as the tolerances above)
-TRAJ_LOSS_RTOL = 5e-4
-TRAJ_M1_TOL, TRAJ_M2_TOL = 2e-3, 4e-3          # Adam moments, relative to the tensor's peak
-TRAJ_P_ATOL, TRAJ_P_RTOL, TRAJ_FRAC_OFF = 2e-5, 2e-3, 2e-3
+# Observed worst on the GPU (5-10 steps): loss 2.9e-7, exp_avg 1.2e-5, exp_avg_sq 3.4e-5, 2e-5 of the parameters further than
+# 2e-5 + 2e-3 |p| from the oracle's, largest parameter difference 3.1e-5 (round 2 asserted 5e-4 / 2e-3 / 4e-3 / 2e-3 / 2 lr steps)
+TRAJ_LOSS_RTOL = 3e-6
+TRAJ_M1_TOL, TRAJ_M2_TOL = 1.2e-4, 3.5e-4      # Adam moments, relative to the tensor's peak
+TRAJ_P_ATOL, TRAJ_P_RTOL, TRAJ_FRAC_OFF = 2e-5, 2e-3, 2e-4
+TRAJ_P_MAX = 3e-4                              # largest parameter difference after the steps
 
 
 def run_fused_train_trajectory(be, case, R, steps=5, batch=None, use_dropout=False, lr=1e-3, ARR=0.001, seed=4):
@@ -511,13 +514,16 @@ def run_fused_train_trajectory(be, case, R, steps=5, batch=None, use_dropout=Fal
     assert loss_rel < TRAJ_LOSS_RTOL, losses
     assert worst_m1 <= TRAJ_M1_TOL and worst_m2 <= TRAJ_M2_TOL, (worst_m1, worst_m2)
     assert bad.mean() < TRAJ_FRAC_OFF, 'too many parameters off the oracle trajectory: %g' % bad.mean()
-    assert diff.max() <= 2.0 * lr * steps + 1e-6, diff.max()
+    assert diff.max() <= TRAJ_P_MAX, diff.max()
     return dict(losses=losses, frac_off=float(bad.mean()), max_diff=float(diff.max()), total=float(be.host(total)[0]),
                 params=got_p, m1=be.host(M1), m2=be.host(M2), ws=ws)
 
 
 # ====================================================================== DGCNN_RS (sort-pool readout family)
-def run_dgcnn_parity(be, case, R, k=12, use_dropout=True, ARR=0.001, seed=3, rtol=2e-4, atol=2e-5):
+DGCNN_OUT_TOL, DGCNN_LOSS_RTOL, DGCNN_GRAD_TOL = 2e-4, 2e-4, 2e-3      # (sort-pool family: set from the GPU's record below)
+
+
+def run_dgcnn_parity(be, case, R, k=12, use_dropout=True, ARR=0.001, seed=3, rtol=None, atol=None):
     """``igmc_sortpool_forward`` / ``igmc_sortpool_loss_grad`` (conv kernels of model.hip + sortpool.hip) on one
     extracted batch vs ``pyg_ref.DGCNNRSRef`` (reference models.py:123-167 restated) on IDENTICAL subgraphs, weights and
     dropout masks: eval outputs, training outputs, loss and every gradient."""
@@ -547,7 +553,8 @@ def run_dgcnn_parity(be, case, R, k=12, use_dropout=True, ARR=0.001, seed=3, rto
     ref.eval()
     with torch.no_grad():
         ro = ref(pyg)
-    np.testing.assert_allclose(be.host(out), ro.numpy(), rtol=rtol, atol=atol)
+    eval_rel = rel_err(be.host(out), ro.numpy())
+    assert eval_rel < DGCNN_OUT_TOL, eval_rel
     # ---- training step with injected masks
     rng = np.random.default_rng(seed)
     lin_mask = rng.random((B, 128)) < 0.5
@@ -566,18 +573,23 @@ def run_dgcnn_parity(be, case, R, k=12, use_dropout=True, ARR=0.001, seed=3, rto
     to = ref(pyg, edge_mask=edge_mask, lin_mask=torch.from_numpy(lin_mask))
     rl = F_mse(to, pyg.y) + ARR * pyg_ref.arr_loss(ref)
     rl.backward()
-    np.testing.assert_allclose(be.host(out), to.detach().numpy(), rtol=rtol, atol=atol)
-    assert be.host(loss)[0] == pytest_approx(float(rl.detach()), 2e-4)
     gflat = be.host(grad)
-    worst = 0.0
+    worst, worst_key = 0.0, ''
     for key, p in ref.named_parameters():
         rgn = p.grad.detach().numpy()
         off = sp.offsets[key]
         got = gflat[off:off + rgn.size].reshape(rgn.shape)
         scale = max(np.abs(rgn).max(), 1e-6)
         err = np.abs(got - rgn).max() / scale
-        worst = max(worst, err)
-        assert err < 2e-3, '%s: max rel-to-peak grad error %.3e' % (key, err)
+        if err > worst:
+            worst, worst_key = err, key
+    train_rel = rel_err(be.host(out), to.detach().numpy())
+    loss_rel = abs(float(be.host(loss)[0]) - float(rl.detach())) / max(abs(float(rl.detach())), 1e-12)
+    record_observed('dgcnn_parity', R=R, B=int(B), k=int(k), dropout=bool(use_dropout), eval_out_rel=eval_rel,
+                    train_out_rel=train_rel, loss_rel=loss_rel, worst_grad_rel=worst, worst_grad_tensor=worst_key)
+    assert train_rel < DGCNN_OUT_TOL, train_rel
+    assert loss_rel < DGCNN_LOSS_RTOL, loss_rel
+    assert worst < DGCNN_GRAD_TOL, '%s: max rel-to-peak grad error %.3e' % (worst_key, worst)
     return dict(worst_grad_err=worst, eval_out=be.host(out), loss=be.host(loss))
 
 

@@ -4,7 +4,7 @@ plus the paths round 1 only checked transitively:
 
 * one full batch of 50: extraction (candidate sets, sizes, induced edges vs ``oracle/extract_ref``), eval output,
   train output / loss / EVERY gradient vs ``oracle/pyg_ref`` (tolerances of ``parity_checks.run_model_parity``:
-  outputs rtol 2e-4 / atol 2e-5, gradients 2e-3 of the tensor's peak);
+  outputs 2e-5 and gradients 5e-5 of the tensor's peak, loss 3e-6 -- 10x the worst the GPU shows, profiles/r03_parity_observed.txt);
 * >= 5 consecutive steps of the fused ``igmc_train_step`` (k_graph_step -> k_tail_ts -> k_finalize_ts incl. Adam) vs
   ``pyg_ref.train_step`` + ``torch.optim.Adam`` (reference train_eval.py:158-177);
 * the free-running counter-based dropout draws (edge dropout incl. ``force_undirected``, MLP dropout): statistics,
@@ -69,7 +69,7 @@ def test_headline_batch_matches_oracle(be, ml1m, drop, monkeypatch, capfd):
     monkeypatch.setenv('IGMC_GS_TRACE', '1')
     case = first(ml1m, 50)
     res = PC.run_model_parity(be, case, R=5, use_dropout=drop)
-    assert res['worst_grad_err'] < 2e-3
+    assert res['worst_grad_err'] < PC.GRAD_TOL
     d = res['d']
     assert d['B'] == 50 and 50 * 150 < d['N'] <= 50 * 202 and d['E'] > 150000       # the headline shape, not a toy
     PC.check_sampled(d, case)
@@ -84,7 +84,7 @@ def test_headline_fused_train_steps_track_torch_adam(be, ml1m, monkeypatch, capf
     res = PC.run_fused_train_trajectory(be, ml1m, R=5, steps=5, batch=50)
     err = capfd.readouterr().err
     assert err.count('k_graph_step B=50 train=1') >= 5 and 'cluster=4' in err
-    assert res['frac_off'] < 2e-3
+    assert res['frac_off'] < PC.TRAJ_FRAC_OFF
     # sum over steps of loss * num_graphs (reference train_eval.py:176)
     assert res['total'] == pytest.approx(sum(50 * l for l, _ in res['losses']), rel=1e-5)
 
@@ -97,7 +97,7 @@ def test_headline_fused_train_steps_track_torch_adam(be, ml1m, monkeypatch, capf
 def test_fused_train_steps_other_paths(be, ml1m, name, n, R, mnph, drop):
     case = ml1m if name == 'ml1m' else monti_case(name, n)
     res = PC.run_fused_train_trajectory(be, case, R=R, steps=5, batch=n // 5, use_dropout=drop)
-    assert res['frac_off'] < 2e-3
+    assert res['frac_off'] < PC.TRAJ_FRAC_OFF
 
 
 @pytest.mark.parametrize('lean', [False, True])
@@ -108,7 +108,7 @@ def test_free_running_dropout(be, ml1m, name, force_undirected, lean):
     # the check takes its flags from the blocks.  douban is uncapped: its slots are bounded by the longest row / column.
     case = first(ml1m, 50, 100) if name == 'ml1m' else monti_case('douban', 40)
     res = PC.run_free_running_dropout(be, case, R=5, p=0.2, force_undirected=force_undirected, lean=lean)
-    assert res['worst_grad_err'] < 2e-3
+    assert res['worst_grad_err'] < PC.GRAD_TOL
 
 
 def test_uncapped_douban_takes_the_subgraph_kernel(be):
@@ -120,7 +120,7 @@ def test_uncapped_douban_takes_the_subgraph_kernel(be):
     ws = engine.ModelWorkspace(be.lib, be.device, 5, 4, 4, 0, b.node_capacity, b.edge_capacity, b.max_graphs)
     assert ws.dense_path(b, 50)
     res = PC.run_model_parity(be, case, R=5, use_dropout=True)
-    assert res['worst_grad_err'] < 2e-3
+    assert res['worst_grad_err'] < PC.GRAD_TOL
 
 
 
@@ -131,7 +131,7 @@ def test_ml100k_cap200_batch_matches_oracle(be, lean):
     per-layer kernels (k_dl_layer0 / k_dl_layer on the matrix cores; lean: no edge list anywhere in the step)."""
     case = ml_case('ml_100k', 200, 50, seed=5)
     res = PC.run_model_parity(be, case, R=5, use_dropout=True, lean=lean)
-    assert res['worst_grad_err'] < 2e-3
+    assert res['worst_grad_err'] < PC.GRAD_TOL
     assert res['batch'].dense_layers(res['ws'])
     PC.check_sampled(res['d'], case)
     assert res['d']['N'] > 50 * 200
@@ -143,14 +143,14 @@ def test_ml100k_cap200_free_running_dropout_on_the_dense_blocks(be, force_undire
     flags vs the host restatement of the hash, model vs the oracle with those flags."""
     case = ml_case('ml_100k', 200, 50, seed=6)
     res = PC.run_free_running_dropout(be, case, R=5, p=0.2, force_undirected=force_undirected, lean=True)
-    assert res['worst_grad_err'] < 2e-3
+    assert res['worst_grad_err'] < PC.GRAD_TOL
 
 
 def test_ml100k_cap200_fused_train_steps_track_torch_adam(be):
     """... and five fused train steps (igmc_train_step on the dense per-layer path) vs pyg_ref.train_step + torch Adam."""
     case = ml_case('ml_100k', 200, 50, seed=7)
     res = PC.run_fused_train_trajectory(be, case, R=5, steps=5, batch=10, use_dropout=True)
-    assert res['frac_off'] < 2e-3
+    assert res['frac_off'] < PC.TRAJ_FRAC_OFF
 
 
 def test_ml100k_cap200_fused_train_steps_are_bit_reproducible(be):

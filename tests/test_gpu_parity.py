@@ -2,8 +2,8 @@
 
 * extraction vs the committed reference goldens (bit-exact sets / labels / edges);
 * model forward / loss+gradient vs the PyG-1.4.2 restatement on identical subgraphs, weights and
-  dropout masks (fp32 tolerances written in parity_checks.run_model_parity: outputs rtol 2e-4,
-  gradients 2e-3 of the tensor's peak);
+  dropout masks (fp32 tolerances written in parity_checks: outputs 2e-5, loss 3e-6,
+  gradients 5e-5 of the tensor's peak: 10x the worst the GPU shows, profiles/r03_parity_observed.txt);
 * full-size (ml_1m-like, batch 50, mnph 100) structural properties + parity vs the oracle.
 """
 import numpy as np
@@ -85,14 +85,14 @@ def test_sampler_free_run(be, name):
 ])
 def test_model_forward_backward_parity(be, name, n, R, drop, mult):
     res = PC.run_model_parity(be, sub(name, n), R=R, use_dropout=drop, multiply_by=mult)
-    assert res['worst_grad_err'] < 2e-3
+    assert res['worst_grad_err'] < PC.GRAD_TOL
 
 
 @pytest.mark.parametrize('name,n,R,drop', [('synth_cap', 16, 5, True), ('synth_nocap:100', 16, 5, False)])
 def test_capped_cases_per_layer_kernels(be, monkeypatch, name, n, R, drop):
     monkeypatch.setenv('IGMC_GRAPH_STEP', '0')        # the default path also on batches the graph kernel could take
     res = PC.run_model_parity(be, sub(name, n), R=R, use_dropout=drop)
-    assert res['worst_grad_err'] < 2e-3
+    assert res['worst_grad_err'] < PC.GRAD_TOL
 
 
 @pytest.mark.parametrize('mode', ['0', '1', '3'])
@@ -100,20 +100,20 @@ def test_layer_kernel_variants(be, monkeypatch, mode):
     monkeypatch.setenv('IGMC_LAYER_MODE', mode)
     monkeypatch.setenv('IGMC_GRAPH_STEP', '0')
     res = PC.run_model_parity(be, sub('synth_nocap:100', 16), R=5, use_dropout=True)
-    assert res['worst_grad_err'] < 2e-3
+    assert res['worst_grad_err'] < PC.GRAD_TOL
 
 
 def test_hand_off_finalize_variant(be, monkeypatch):
     # IGMC_FIN_MODE=0: subgraph kernel + k_finalize (in-kernel hand-offs) instead of the default k_finalize_ts
     monkeypatch.setenv('IGMC_FIN_MODE', '0')
     res = PC.run_model_parity(be, sub('synth_cap', 16), R=5, use_dropout=True)
-    assert res['worst_grad_err'] < 2e-3
+    assert res['worst_grad_err'] < PC.GRAD_TOL
 
 
 @pytest.mark.parametrize('n_side', [48, 10])
 def test_side_features(be, n_side):
     res = PC.run_model_parity(be, sub('flixster', 40), R=10, use_dropout=True, n_side=n_side)
-    assert res['worst_grad_err'] < 2e-3
+    assert res['worst_grad_err'] < PC.GRAD_TOL
 
 
 def test_bitwise_reproducible(be):
@@ -142,4 +142,4 @@ def test_random_graphs_forward_backward(be, h, mnph):
         case = random_case(31000 + 17 * h + seed, h, mnph=mnph, n_links=5)
         res = PC.run_model_parity(be, case, R=len(case['class_values']), use_dropout=bool(seed % 2),
                                   multiply_by=1.0 + (seed % 3))
-        assert res['worst_grad_err'] < 2e-3
+        assert res['worst_grad_err'] < PC.GRAD_TOL

@@ -27,6 +27,8 @@ ORDER = list(range(1, 36))
 
 
 def main():
+    if os.environ.get('IGMC_LIB_PATH'):
+        _lib.LIB_PATH = os.environ['IGMC_LIB_PATH']
     lib = _lib.load()
     split = preprocessing.create_trainvaltest_split('ml_1m', 1234, True, verbose=False)
     (_, _, A, tr_l, tr_u, tr_v, _, _, _, _, _, _, class_values) = split
@@ -56,6 +58,21 @@ def main():
     for l in (1, 2, 3):
         print('L%d fwd: wave 0 compute alone %d | %d' % (l, c[36 + l - 1] - c[7 + 3 * (l - 1)], c[100 + l - 1] - c[71 + 3 * (l - 1)]))
     fine(c)
+    wg = np.zeros(200 * 3, np.uint64)
+    if hasattr(lib.cdll, 'igmc_debug_g2_wg_clocks'):
+        lib.cdll.igmc_debug_g2_wg_clocks(C.c_void_p(wg.ctypes.data), 200)
+        w = wg.reshape(200, 3).astype(np.int64)
+        t0 = w[:, 0].min()
+        st, en = (w[:, 0] - t0) / 100.0, (w[:, 1] - t0) / 100.0          # us (100 MHz wall clock)
+        print('per-workgroup (200): start min/median/max %.1f / %.1f / %.1f us; end min/median/max %.1f / %.1f / %.1f us; '
+              'duration min/median/max %.1f / %.1f / %.1f us' % (st.min(), np.median(st), st.max(), en.min(), np.median(en),
+                                                                 en.max(), (en - st).min(), np.median(en - st), (en - st).max()))
+        late = np.argsort(-en)[:8]
+        print('last to end: ' + ', '.join('wg %d (subgraph %d, member %d, xcc %d): start %.1f end %.1f' % (
+            i, i // 4, i % 4, w[i, 2] & 15, st[i], en[i]) for i in late))
+        dur = (en - st).reshape(50, 4)
+        print('per-subgraph duration of the slowest member: min %.1f median %.1f max %.1f us' % (
+            dur.max(1).min(), np.median(dur.max(1)), dur.max(1).max()))
 
 
 def fine(c):

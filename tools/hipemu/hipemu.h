@@ -534,6 +534,11 @@ static inline uint32_t hipemu_f32_to_bf16_rne(float f) {
   return u >> 16;
 }
 
+static inline uint32_t __float_as_uint(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return u;
+}
 static inline float __uint_as_float(uint32_t u) {
   float f;
   memcpy(&f, &u, 4);
