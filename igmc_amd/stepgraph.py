@@ -68,41 +68,18 @@ def _group_size(steps_hint, default):
     return default
 
 
-class StepGraph(object):
-    """Runs training steps of ``batch_size`` links of ``dataset`` through the fused path."""
+class GroupPipeline(object):
+    """Host logic of the grouped step pipeline -- which extraction / step / re-grouping is launched when --, independent of
+    what launches them.  A backend supplies ``_arena(q, i)``, ``_extract(arena, sel, B)``, ``_enqueue_step(arena, B)``,
+    ``_dev_regroup(first_cur, first_next)``, ``_fork()`` / ``_join()`` (two chains: model steps || extraction of the next
+    group), ``_capture()`` (a replayable graph of ``_enqueue_pair`` or None) and ``_count(n)``.  :class:`StepGraph` is the
+    HIP backend; the CPU tests drive the same logic with the emulation build of the kernels under ``gloo``."""
 
-    def __init__(self, model, optimizer, dataset, batch_size, ARR, use_graph=None, overlap=None, group=None):
-        self.model, self.opt, self.ds = model, optimizer, dataset
+    def _init_pipeline(self, batch_size, group, use_graph):
         self.B = int(batch_size)
-        self.ARR = float(ARR)
-        self.lib = _lib.load()
-        self.world = parallel.world_size()
-        flat = model.flat_parameters()
-        self.dev = flat.device
-        self.ctrl = torch.zeros(_lib.CTRL['WORDS'], dtype=torch.int64, device=self.dev)
-        # permutation buffer, padded so that the (discarded) prefetch of the group after the last one stays in range
-        self.pad = 2 * MAX_GROUP * self.B
-        self.perm = torch.zeros(max(len(dataset), 1) + self.pad, dtype=torch.int32, device=self.dev)
-        env = os.environ.get('IGMC_GROUP_STEPS', os.environ.get('IGMC_GRAPH_STEPS', '32'))
-        self.M_default = max(1, min(MAX_GROUP, int(group if group is not None else env)))
+        self.M_default = max(1, min(MAX_GROUP, int(group)))
         self.M = self.M_default
-        self.sets = [[], []]                   # arenas of the even / odd groups (created on first use)
-        self.ws = None
-        self._attached = False
-        self._arena(0, 0)
-        self.out = torch.empty(self.B, dtype=torch.float32, device=self.dev)
-        self.loss = torch.zeros(2, dtype=torch.float32, device=self.dev)
-        self.total = torch.zeros(1, dtype=torch.float64, device=self.dev)
-        if use_graph is None:
-            use_graph = os.environ.get('IGMC_NO_GRAPH', '0') != '1'
-        if overlap is None:
-            overlap = os.environ.get('IGMC_NO_OVERLAP', '0') != '1'
-        self.use_graph, self.overlap = use_graph, overlap
-        # the multi-GPU step (gradient kernels -> all-reduce -> Adam launch) can be forced on one GPU to test it
-        self.dp_path = self.world > 1 or os.environ.get('IGMC_FORCE_DP_PATH', '0') == '1'
-        self.side = torch.cuda.Stream(device=self.dev) if overlap else None
-        # gradient exchange: the library's own RCCL communicator (igmc_allreduce_grads), enqueued on the step's stream
-        self.comm = parallel.grad_comm(self.lib, self.dev.index if self.dev.index is not None else 0) if self.dp_path else None
+        self.use_graph = bool(use_graph)
         self.graph = None
         self.n_links = 0
         self.k = 0                      # steps done in the current epoch
@@ -110,6 +87,122 @@ class StepGraph(object):
         self.avail = 0                  # batches 0 .. avail-1 of the current group sit extracted in its arenas
         self.steps_done = 0
         self._last = None
+
+    def _reset_epoch(self, n_links):
+        self.n_links = int(n_links)
+        self.k, self.gq, self.gk, self.avail = 0, 0, 0, 0
+
+    def _fill_group(self):
+        """Eager extraction of the batches of the current group that lie inside the epoch (group parity 0, from batch 0)."""
+        assert self.gq == 0 and self.gk == 0
+        cnt = min(self.M, max(0, self.n_links // self.B - self.k))
+        for i in range(cnt):
+            self._extract(self._arena(0, i), i << 1, self.B)
+        self.avail = cnt
+
+    def _regroup(self):
+        """A new group starts at the current position: cursors re-based on the device, its batches extracted eagerly."""
+        self._dev_regroup(self.k * self.B, (self.k + self.M) * self.B)
+        self.gq, self.gk = 0, 0
+        self._fill_group()
+
+    def _enqueue_group(self, q):
+        """M steps on the arenas of parity ``q`` || extraction of the next group's M batches into the other set."""
+        cur = [self._arena(q, i) for i in range(self.M)]
+        nxt = [self._arena(1 - q, i) for i in range(self.M)]
+        self._fork()
+        # the model kernels are enqueued BEFORE the extraction branch: the subgraph kernel (one workgroup per CU on 200 of
+        # 256 CUs) is dispatched first and the extraction workgroups fill what is left
+        for i in range(self.M):
+            self._enqueue_step(cur[i], self.B)
+        self._side(lambda: [self._extract(nxt[i], (1 - q) | (i << 1), self.B) for i in range(self.M)])
+        self._join()
+
+    def _enqueue_pair(self):
+        """One graph launch: the group of parity 0, then the group of parity 1 (2 M steps)."""
+        self._enqueue_group(0)
+        self._enqueue_group(1)
+
+    def _advance(self, n):
+        self.k += n
+        self.steps_done += n
+        self._count(n)
+
+    def _single(self, B=None):
+        """One eagerly launched step on the next batch (``B`` links: the ragged last batch of an epoch)."""
+        full = B is None or int(B) == self.B
+        B = self.B if B is None else int(B)
+        arena = self._arena(self.gq, self.gk)
+        if self.gk >= self.avail or not full:
+            self._extract(arena, self.gq | (self.gk << 1), B)      # (a prefetch assumed a full batch)
+            self.avail = self.gk + 1 if full else self.avail
+        self._enqueue_step(arena, B)
+        self._last = arena
+        self._advance(1)
+        self.gk += 1
+        if self.gk >= self.M:
+            self.gq, self.gk, self.avail = self.gq ^ 1, 0, 0
+
+    def step(self, B=None):
+        """One optimisation step on the next ``B`` links of the epoch permutation (eager launches)."""
+        self._single(B)
+
+    def steps(self, n):
+        """``n`` full-batch optimisation steps: whole pairs of groups replay one graph launch each (the control block is
+        advanced on the device, so the launch sequence is always the same), the rest is launched eagerly."""
+        n = int(n)
+        while n > 0:
+            M = self.M
+            if n >= 2 * M and (self.steps_done >= 1 or not self.use_graph) and self.n_links // self.B - self.k >= 2 * M:
+                if self.gq != 0 or self.gk != 0 or self.avail < M:
+                    self._regroup()
+                g = self._capture() if self.use_graph else None
+                if g is not None:
+                    g.replay()
+                else:
+                    self._enqueue_pair()
+                self._last = self._arena(1, M - 1)
+                self._advance(2 * M)
+                self.gq, self.gk, self.avail = 0, 0, M
+                n -= 2 * M
+            else:
+                self._single()
+                n -= 1
+
+
+class StepGraph(GroupPipeline):
+    """Runs training steps of ``batch_size`` links of ``dataset`` through the fused path (HIP backend of the pipeline)."""
+
+    def __init__(self, model, optimizer, dataset, batch_size, ARR, use_graph=None, overlap=None, group=None):
+        self.model, self.opt, self.ds = model, optimizer, dataset
+        self.ARR = float(ARR)
+        self.lib = _lib.load()
+        self.world = parallel.world_size()
+        flat = model.flat_parameters()
+        self.dev = flat.device
+        env = os.environ.get('IGMC_GROUP_STEPS', os.environ.get('IGMC_GRAPH_STEPS', '32'))
+        if use_graph is None:
+            use_graph = os.environ.get('IGMC_NO_GRAPH', '0') != '1'
+        if overlap is None:
+            overlap = os.environ.get('IGMC_NO_OVERLAP', '0') != '1'
+        self._init_pipeline(batch_size, group if group is not None else env, use_graph)
+        self.overlap = overlap
+        self.ctrl = torch.zeros(_lib.CTRL['WORDS'], dtype=torch.int64, device=self.dev)
+        # permutation buffer, padded so that the (discarded) prefetch of the group after the last one stays in range
+        self.pad = 2 * MAX_GROUP * self.B
+        self.perm = torch.zeros(max(len(dataset), 1) + self.pad, dtype=torch.int32, device=self.dev)
+        self.sets = [[], []]                   # arenas of the even / odd groups (created on first use)
+        self.ws = None
+        self._attached = False
+        self._arena(0, 0)
+        self.out = torch.empty(self.B, dtype=torch.float32, device=self.dev)
+        self.loss = torch.zeros(2, dtype=torch.float32, device=self.dev)
+        self.total = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        # the multi-GPU step (gradient kernels -> all-reduce -> Adam launch) can be forced on one GPU to test it
+        self.dp_path = self.world > 1 or os.environ.get('IGMC_FORCE_DP_PATH', '0') == '1'
+        self.side = torch.cuda.Stream(device=self.dev) if overlap else None
+        # gradient exchange: the library's own RCCL communicator (igmc_allreduce_grads), enqueued on the step's stream
+        self.comm = parallel.grad_comm(self.lib, self.dev.index if self.dev.index is not None else 0) if self.dp_path else None
 
     # ------------------------------------------------------------------ arenas
     def _arena(self, q, i):
@@ -175,27 +268,34 @@ class StepGraph(object):
                         g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'])
         self.ctrl.copy_(torch.from_numpy(w))
         self.total.zero_()
-        self.n_links = n
-        self.k, self.gq, self.gk, self.avail = 0, 0, 0, 0
+        self._reset_epoch(n)
         if not self._attached:
             self._attach()
         self._fill_group()              # the first group of the epoch has nobody to prefetch it
 
-    def _fill_group(self):
-        """Eager extraction of the batches of the current group that lie inside the epoch (group parity 0, from batch 0)."""
-        assert self.gq == 0 and self.gk == 0
-        cnt = min(self.M, max(0, self.n_links // self.B - self.k))
-        for i in range(cnt):
-            self._extract(self._arena(0, i), i << 1, self.B)
-        self.avail = cnt
+    # ------------------------------------------------------------------ backend hooks of the pipeline
+    def _dev_regroup(self, first_cur, first_next):
+        self.lib.call('igmc_ctrl_regroup', C.c_void_p(self.ctrl.data_ptr()), self.M, first_cur, first_next,
+                      C.c_void_p(torch.cuda.current_stream().cuda_stream))
 
-    def _regroup(self):
-        """A new group starts at the current position: cursors re-based on the device, its batches extracted eagerly."""
-        st = torch.cuda.current_stream().cuda_stream
-        self.lib.call('igmc_ctrl_regroup', C.c_void_p(self.ctrl.data_ptr()), self.M, self.k * self.B,
-                      (self.k + self.M) * self.B, C.c_void_p(st))
-        self.gq, self.gk = 0, 0
-        self._fill_group()
+    def _fork(self):
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream())
+
+    def _side(self, fn):
+        if self.side is not None:
+            with torch.cuda.stream(self.side):
+                fn()
+        else:
+            fn()
+
+    def _join(self):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+    def _count(self, n):
+        self.model._step += n
+        self.opt.t += n
 
     # ------------------------------------------------------------------ one step
     def _model(self, arena, B):
@@ -239,31 +339,6 @@ class StepGraph(object):
         else:
             self._model(arena, B)
             self._finish(arena)
-
-    def _enqueue_group(self, q):
-        """M steps on the arenas of parity ``q`` || extraction of the next group's M batches into the other set."""
-        main = torch.cuda.current_stream()
-        cur = [self._arena(q, i) for i in range(self.M)]
-        nxt = [self._arena(1 - q, i) for i in range(self.M)]
-        if self.side is not None:
-            self.side.wait_stream(main)
-        # the model kernels are enqueued BEFORE the extraction branch: the subgraph kernel (one workgroup per CU on 200 of
-        # 256 CUs) is dispatched first and the extraction workgroups fill what is left
-        for i in range(self.M):
-            self._enqueue_step(cur[i], self.B)
-        if self.side is not None:
-            with torch.cuda.stream(self.side):
-                for i in range(self.M):
-                    self._extract(nxt[i], (1 - q) | (i << 1), self.B)
-            main.wait_stream(self.side)
-        else:
-            for i in range(self.M):
-                self._extract(nxt[i], (1 - q) | (i << 1), self.B)
-
-    def _enqueue_pair(self):
-        """One graph launch: the group of parity 0, then the group of parity 1 (2 M steps)."""
-        self._enqueue_group(0)
-        self._enqueue_group(1)
 
     @property
     def graphs(self):                   # (compatibility of older call sites: the captured graphs)
@@ -315,54 +390,6 @@ class StepGraph(object):
             self._regroup()
         self._capture()
         return self.use_graph
-
-    # ------------------------------------------------------------------ running steps
-    def _advance(self, n):
-        self.k += n
-        self.steps_done += n
-        self.model._step += n
-        self.opt.t += n
-
-    def _single(self, B=None):
-        """One eagerly launched step on the next batch (``B`` links: the ragged last batch of an epoch)."""
-        full = B is None or int(B) == self.B
-        B = self.B if B is None else int(B)
-        arena = self._arena(self.gq, self.gk)
-        if self.gk >= self.avail or not full:
-            self._extract(arena, self.gq | (self.gk << 1), B)      # (a prefetch assumed a full batch)
-            self.avail = self.gk + 1 if full else self.avail
-        self._enqueue_step(arena, B)
-        self._last = arena
-        self._advance(1)
-        self.gk += 1
-        if self.gk >= self.M:
-            self.gq, self.gk, self.avail = self.gq ^ 1, 0, 0
-
-    def step(self, B=None):
-        """One optimisation step on the next ``B`` links of the epoch permutation (eager launches)."""
-        self._single(B)
-
-    def steps(self, n):
-        """``n`` full-batch optimisation steps: whole pairs of groups replay one graph launch each (the control block is
-        advanced on the device, so the launch sequence is always the same), the rest is launched eagerly."""
-        n = int(n)
-        while n > 0:
-            M = self.M
-            if n >= 2 * M and (self.steps_done >= 1 or not self.use_graph) and self.n_links // self.B - self.k >= 2 * M:
-                if self.gq != 0 or self.gk != 0 or self.avail < M:
-                    self._regroup()
-                g = self._capture() if self.use_graph else None
-                if g is not None:
-                    g.replay()
-                else:
-                    self._enqueue_pair()
-                self._last = self._arena(1, M - 1)
-                self._advance(2 * M)
-                self.gq, self.gk, self.avail = 0, 0, M
-                n -= 2 * M
-            else:
-                self._single()
-                n -= 1
 
     def run_epoch(self, perm, epoch):
         """All batches of one epoch; returns (sum over batches of loss*B as a device float64 tensor, #links)."""

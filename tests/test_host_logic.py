@@ -257,3 +257,149 @@ def test_host_cpu_budget_and_thread_limit(tmp_path):
     env = {k: v for k, v in os.environ.items() if not k.endswith('_NUM_THREADS')}
     r = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0 and r.stdout.decode().startswith('ok'), r.stdout.decode()
+
+
+_DP_PIPELINE_WORKER = r'''
+import ctypes as C, os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'tests'))
+import numpy as np, torch
+from igmc_amd import _lib, engine, parallel, stepgraph
+import parity_checks as PC
+from helpers import load_extract_golden
+rank, world = parallel.init_from_env('gloo')
+be = PC.EmuBackend()                      # kernel logic on the CPU emulation (test infrastructure)
+lib = be.lib
+case = load_extract_golden()['synth_cap']
+lu = case['links'][:, 0].astype(np.int32).copy()
+lv = case['links'][:, 1].astype(np.int32).copy()
+ly = case['class_values'][case['link_labels']].astype(np.float32)
+n_all, B, M, ARR, lr, seed, step0 = len(lu), 2, 1, 0.001, 1e-3, 7, 11
+graph = engine.Graph(case['A'], lib=lib)
+vp = lambda a: C.c_void_p(a.ctypes.data)
+
+
+class EmuPipeline(stepgraph.GroupPipeline):
+    """The product's host logic (igmc_amd.stepgraph.GroupPipeline: groups, pairs, re-grouping, remainder, ragged batch)
+    over the emulation build of the kernels, with the data-parallel step of StepGraph: gradient kernels -> ONE flat
+    all-reduce -> igmc_step_finish (Adam + loss + tick)."""
+
+    def __init__(self):
+        self._init_pipeline(B, M, use_graph=False)
+        self.ctrl = np.zeros(_lib.CTRL['WORDS'], np.int64)
+        self.sets = [[], []]
+        probe = engine.Batch(graph, B, 1, case['mnph'])
+        self.ws = engine.ModelWorkspace(lib, 0, 5, 4, 4, 0, probe.node_capacity, probe.edge_capacity, B)
+        lib.call('igmc_model_set_ctrl', self.ws.handle, vp(self.ctrl))
+        self.P = PC.flatten_params(self.ws, PC.make_ref_model(4, 5, seed=4))
+        self.M1, self.M2, self.G = np.zeros_like(self.P), np.zeros_like(self.P), np.zeros_like(self.P)
+        self.out, self.loss, self.total = np.zeros(B, np.float32), np.zeros(2, np.float32), np.zeros(1, np.float64)
+        self.collectives = 0
+
+    def _arena(self, q, i):
+        while len(self.sets[q]) <= i:
+            a = engine.Batch(graph, B, 1, case['mnph'])
+            lib.call('igmc_batch_set_ctrl', a.handle, vp(self.ctrl))
+            self.sets[q].append(a)
+        return self.sets[q][i]
+
+    def _extract(self, arena, sel, nb):
+        arena.extract(lu, lv, ly, self.perm, sel, nb, 1.0, seed, 999)
+
+    def _enqueue_step(self, arena, nb):
+        self.ws.loss_grad(self.P.ctypes.data, arena, self.out.ctypes.data, self.G.ctypes.data, None, seed=seed, step=0,
+                          ARR=ARR, grad_scale=1.0 / (nb * world), arr_scale=1.0 / world)
+        parallel.all_reduce_sum_(torch.from_numpy(self.G))           # in place on the numpy buffer
+        self.collectives += 1
+        lib.call('igmc_step_finish', self.ws.handle, arena.handle, vp(self.P), vp(self.G), vp(self.M1), vp(self.M2), ARR,
+                 vp(self.loss), vp(self.total), vp(self.ctrl), 1, lr, 0.9, 0.999, 1e-8, 0.0, None)
+
+    def _dev_regroup(self, first_cur, first_next):
+        lib.call('igmc_ctrl_regroup', vp(self.ctrl), self.M, first_cur, first_next, None)
+
+    def _fork(self):
+        pass
+
+    def _side(self, fn):
+        fn()
+
+    def _join(self):
+        pass
+
+    def _capture(self):
+        return None
+
+    def _count(self, n):
+        pass
+
+    def run_epoch(self, perm, epoch):
+        pad = 2 * stepgraph.MAX_GROUP * B
+        self.perm = np.concatenate([perm, perm[np.arange(pad) %% len(perm)]]).astype(np.int32)
+        self.ctrl[:] = stepgraph._ctrl_words(step0, epoch, 1, B, self.M, lr, 0.9, 0.999, 1e-8, 0.0)
+        self._reset_epoch(len(perm))
+        self._fill_group()
+        self.steps(len(perm) // B)
+        if len(perm) %% B:
+            self.step(len(perm) %% B)
+
+
+perm_all = torch.randperm(n_all, generator=torch.Generator().manual_seed(3))[:14]
+mine = parallel.shard_positions(perm_all, rank, world, pad=True).numpy().astype(np.int32)
+assert len(mine) == 7                      # 14 links over 2 ranks, batch 2: a PAIR of groups (2 steps), a remainder step
+                                           # launched on its own, and a ragged last batch of 1 link per rank
+pipe = EmuPipeline()
+pipe.run_epoch(mine, 3)
+K = _lib.CTRL
+assert pipe.ctrl[K['SYNC_ERR']] == 0 and pipe.ctrl[K['K']] == 4 and pipe.collectives == 4
+# replicas stay bit-identical: every rank applied the same all-reduced gradients
+both = [torch.zeros(len(pipe.P)) for _ in range(world)]
+torch.distributed.all_gather(both, torch.from_numpy(pipe.P.copy()))
+assert torch.equal(both[0], both[1])
+tot = torch.tensor([float(pipe.total[0])], dtype=torch.float64)
+parallel.all_reduce_sum_(tot)
+assert np.isfinite(tot.item()) and tot.item() > 0
+if rank == 0:
+    # the same epoch by direct C-ABI calls with host arguments (no control block, no pipeline): step t = both ranks'
+    # batches t one after the other, gradients summed, Adam -- what the pipeline must have walked
+    ws = pipe.ws
+    lib.call('igmc_model_set_ctrl', ws.handle, None)
+    b = engine.Batch(graph, B, 1, case['mnph'])
+    P = PC.flatten_params(ws, PC.make_ref_model(4, 5, seed=4))
+    M1, M2 = np.zeros_like(P), np.zeros_like(P)
+    shards = [parallel.shard_positions(perm_all, r, world, pad=True).numpy().astype(np.int32) for r in range(world)]
+    out = np.zeros(B, np.float32)
+    for t, (first, nb) in enumerate(((0, 2), (2, 2), (4, 2), (6, 1))):
+        Gs = []
+        for r in range(world):
+            G = np.zeros_like(P)
+            b.extract(lu, lv, ly, shards[r], first, nb, 1.0, seed, 3)
+            ws.loss_grad(P.ctypes.data, b, out.ctypes.data, G.ctypes.data, None, seed=seed, step=step0 + t, ARR=ARR,
+                         grad_scale=1.0 / (nb * world), arr_scale=1.0 / world)
+            Gs.append(G)
+        G = Gs[0] + Gs[1]
+        ws.adam_step(P.ctypes.data, G.ctypes.data, M1.ctypes.data, M2.ctypes.data, t + 1, lr)
+    # (lr is a float argument there and a double in the control block: last-ulp differences only)
+    np.testing.assert_allclose(pipe.P, P, rtol=2e-5, atol=1e-7)
+parallel.barrier()
+print('rank', rank, 'pipeline ok')
+'''
+
+
+def test_data_parallel_group_pipeline_gloo(tmp_path):
+    """StepGraph's host logic (GroupPipeline) under data parallelism, two ranks over gloo, kernels on the emulator: a pair of
+    groups, the remainder and the ragged last batch of an epoch with ONE flat all-reduce per step between the gradient
+    kernels and the Adam / tick kernel.  Replicas end bit-identical, no stamp mismatch, the collective counts agree, and
+    the result equals the same epoch walked by direct host-argument calls."""
+    from helpers import emu_lib
+    emu_lib()
+    script = tmp_path / 'dpp.py'
+    script.write_text(_DP_PIPELINE_WORKER % (ROOT, ROOT))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT='29617')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o[-3000:]
+        assert 'rank %d pipeline ok' % r in o
