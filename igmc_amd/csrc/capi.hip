@@ -617,7 +617,7 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   fail |= M.get(&d.feat, Bc * d.D) | M.get(&d.a1, Bc * 128) | M.get(&d.lmask, Bc * 128) | M.get(&d.dz, Bc * 128) |
           M.get(&d.gfeat, Bc * d.D) | M.get(&d.err, Bc) | M.get(&d.cnt0, N * d.R * d.L);
   const size_t rows0 = (size_t)d.R * d.L + d.L + 1;
-  // relation-space gradient tables of the one-workgroup-per-subgraph path (graphstep.hip), R <= 5 only
+  // relation-space gradient tables of the subgraph kernel (graphstep2.hip), R <= 5 only
   d.ts_part = nullptr;
   d.ts_raw = nullptr;
   d.ts_stride = (d.R * 32 + 33) * 32;
@@ -627,9 +627,6 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
     fail |= M.get(&d.ts_part, (size_t)4 * IGMC_TS_BLOCKS * d.ts_stride) | M.get(&d.ts_raw, (size_t)4 * d.ts_stride) |
             M.get(&d.datt_part, (size_t)4 * d.ts_stride / 32 * 4);
   if (d.R <= 32) fail |= M.get(&d.fin_stash, (size_t)4 * 256 + 16);     // weights-only stash of k_finalize_ts (both modes)
-  d.gs_ll = nullptr;
-  d.gs_ll_stride = N * 32;
-  if (d.R <= 5) fail |= M.get(&d.gs_ll, 5 * d.gs_ll_stride);
   d.g2_ex = nullptr;
   d.g2_fx = nullptr;
   d.g2_w = nullptr;
@@ -679,7 +676,6 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
     const unsigned long long ts0[4] = {~0ull, 0ull, 0ull, 0ull};
     HIPCHECK(hipMemcpy(m->d.gs_ts, ts0, sizeof(ts0), hipMemcpyHostToDevice));
   }
-  if (m->d.gs_ll) HIPCHECK(hipMemset(m->d.gs_ll, 0, 5 * m->d.gs_ll_stride * sizeof(unsigned long long)));   // tag 0 = never valid
   if (m->d.g2_ex) {
     HIPCHECK(hipMemset(m->d.g2_ex, 0, 5 * m->d.g2_ex_stride * sizeof(unsigned long long)));
     HIPCHECK(hipMemset(m->d.g2_fx, 0, (size_t)max_graphs * 256 * sizeof(unsigned long long)));
@@ -733,7 +729,7 @@ extern "C" int64_t igmc_param_offset(const igmc_model* m, int layer, int which, 
   return off;
 }
 
-// the per-layer kernels / graphstep.hip read the collated CSR; the matrix-core subgraph kernel does not
+// the per-layer row-walker kernels read the collated CSR; the matrix-core subgraph kernel does not
 static void csr_for_model(const igmc_model* m, const igmc_batch* b, int dense_capable_call, void* stream) {
   if (!b->lean) return;
   G2Layout lay;
@@ -867,8 +863,7 @@ extern "C" int igmc_model_check(igmc_model* m, void* stream) {
     HIPCHECK(hipMemcpy(&v, m->d.gs_err, sizeof(int), hipMemcpyDeviceToHost));
     if (v) {
       HIPCHECK(hipMemset(m->d.gs_bar, 0, (2 * (size_t)m->d.graph_cap + 1) * sizeof(int)));
-      if (m->d.gs_ll) HIPCHECK(hipMemset(m->d.gs_ll, 0, 5 * m->d.gs_ll_stride * sizeof(unsigned long long)));
-      IGMC_FAIL("a workgroup-cluster exchange of k_graph_step timed out (GPU shared with another job?): results of the "
+      IGMC_FAIL("a workgroup-cluster exchange of k_graph_step2 timed out (GPU shared with another job?): results of the "
                 "affected steps are invalid; set IGMC_GS_CLUSTER=1 or IGMC_GRAPH_STEP=0");
     }
   }

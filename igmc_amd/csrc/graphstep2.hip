@@ -29,7 +29,7 @@
 // dPre_3 is non-zero on the two target rows only and is rebuilt locally from the head's d feat: 5 exchanges per launch
 // (h_0, h_1, h_2, dPre_2, dPre_1) + the 256-float centre-node readout.
 //
-// Eligibility (else graphstep.hip / the per-layer kernels run): dense block present, R <= 5, layer-0 table <= 32 rows,
+// Eligibility (else the per-layer kernels run): dense block present, R <= 5, layer-0 table <= 32 rows,
 // no side features, both sides <= 16 * (2 * cluster size) <= 128 rows.
 #include "launch.h"
 #include <stdlib.h>
@@ -1236,6 +1236,41 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_compose(ModelDev m, const flo
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+// workgroups per subgraph: 4 (2) when 4 (2) x the padded batch still fits one workgroup per CU with a margin
+int igmc_gs_cluster(int B) {
+#ifdef IGMC_HIPEMU
+  // the emulator runs workgroups one after the other unless a test asks for clusters (their members then run
+  // together: hipemu::Runtime::co_cs)
+  const char* ee = getenv("IGMC_GS_CLUSTER");
+  const int want_e = ee ? atoi(ee) : 1;
+  const int stride_e = (B + 7) & ~7;
+  if (want_e >= 4 && 4 * stride_e <= 224) return 4;
+  if (want_e >= 2 && 2 * stride_e <= 224) return 2;
+  return 1;
+#else
+  static int cus = -1;
+  if (cus < 0) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 0;
+  }
+  int want = (cus >= 240) ? 4 : 1;        // the clustered launch needs (almost) every CU of an MI355X to itself
+  const char* e = getenv("IGMC_GS_CLUSTER");
+  if (e) want = atoi(e);
+  const int stride = (B + 7) & ~7;
+  if (want >= 4 && 4 * stride <= 224) return 4;
+  if (want >= 2 && 2 * stride <= 224) return 2;
+  return 1;
+#endif
+}
+
+int igmc_gs_grid(int B) {
+  int cap = IGMC_WG_BLOCKS;
+  const char* e = getenv("IGMC_GS_GRID");      // test hook: fewer workgroups than graphs (accumulating partials)
+  if (e && atoi(e) > 0 && atoi(e) < cap) cap = atoi(e);
+  return B < cap ? B : cap;
+}
+
 // LDS plan + eligibility for a batch arena / cluster size
 int igmc_g2_layout(const ModelDev& m, const BatchDev& b, int cs, G2Layout* lay) {
   const int RL = m.R * m.L;
@@ -1269,11 +1304,9 @@ int igmc_g2_layout(const ModelDev& m, const BatchDev& b, int cs, G2Layout* lay) 
   return (size_t)o * 4 <= 160 * 1024;
 }
 
-// 1 = the matrix-core subgraph kernel takes this batch configuration (IGMC_GS_VERSION=1 forces graphstep.hip)
+// 1 = the matrix-core subgraph kernel takes this batch configuration (IGMC_GRAPH_STEP=0 forces the per-layer kernels)
 int igmc_g2_eligible(const ModelDev& m, const BatchDev& b, int B, G2Layout* lay, int* cs_out) {
-  const char* e = getenv("IGMC_GS_VERSION");       // read on every call: tests switch it per case
-  if (e && atoi(e) == 1) return 0;
-  const char* en = getenv("IGMC_GRAPH_STEP");
+  const char* en = getenv("IGMC_GRAPH_STEP");      // read on every call: tests switch it per case
   if (en && atoi(en) == 0) return 0;
   const int cs = igmc_gs_cluster(B);
   if (!igmc_g2_layout(m, b, cs, lay)) return 0;
@@ -1333,6 +1366,7 @@ int igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* P
 }
 
 int igmc_dl_prepare();
+int igmc_gs_prepare() { return igmc_g2_prepare(); }
 int igmc_g2_prepare() {
   if (igmc_dl_prepare()) return 1;
 #ifndef IGMC_HIPEMU

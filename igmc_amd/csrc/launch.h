@@ -62,36 +62,16 @@ void igmc_launch_finish(const ModelDev& m, const BatchDev& b, float* p, const fl
                         float step_size, float inv_sqrt_bc2, float beta1, float beta2, float eps, float wd,
                         int64_t* ctrl, float ARR, float* loss, double* total, int use_flags, void* stream);
 
-// graphstep.hip: one workgroup per enclosing subgraph (LDS-resident layers)
-struct GsLayout {      // LDS plan, offsets in 4-byte words
-  int nmax, rlp;
-  int xa, xb, zrow, tile, hs, att, t0, cnt, rp, lab, deg, order, sched, relp, wreg, ulist, head, words;
-};
+// graphstep2.hip: one cluster of workgroups per enclosing subgraph, relational aggregation on the matrix cores
 struct G2Layout {      // LDS plan of graphstep2.hip, offsets in 4-byte words
   int kp, nsides, rmr, rmc;
   int planes, ohp, lab, xo, hs, tile, hist, wreg, t0, att, head, words;
 };
-struct GsArgs {
-  const uint8_t* inj_mask;
-  uint64_t seed, step;
-  float mult, grad_scale;
-  float* out;
-  int timing;
-  unsigned long long* ts;   // launch clock accumulators (ModelDev::gs_ts) or NULL
-  int cs, stride;      // workgroups per subgraph; block index stride between the members of a cluster
-  GsLayout lay;
-  G2Layout lay2;
-};
 void igmc_launch_side_gather(const float* src, int S, const int32_t* link_idx, int first, int B, const int64_t* ctrl,
                              float* dst, void* stream);
-int igmc_gs_eligible(const ModelDev& m, const BatchDev& b, GsLayout* lay);
 int igmc_gs_grid(int B);
 int igmc_gs_cluster(int B);
-void igmc_launch_graph_step(const ModelDev& m, const BatchDev& b, const float* P, int B, int training, int use_flags,
-                            const GsLayout& lay, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
-                            float grad_scale, float* out, void* stream);
 int igmc_gs_prepare();
-// graphstep2.hip: the same step with the relational aggregation on the matrix cores (dense induced block)
 int igmc_g2_eligible(const ModelDev& m, const BatchDev& b, int B, G2Layout* lay, int* cs_out);
 // dense per-layer kernels (graphstep2.hip): slots of 129..256 nodes a side with a dense block + its transposed copy
 int igmc_dl_eligible(const ModelDev& m, const BatchDev& b, int B);

@@ -45,8 +45,6 @@ struct ModelDev {
   unsigned long long* gs_ts;   // [4] device-side launch clock of k_graph_step (igmc_profile_enable(2)): [0] earliest workgroup
                                // start of the running launch (wall clock ticks), [1] sum of launch durations, [2] launches,
                                // [3] workgroups that finished the running launch
-  unsigned long long* gs_ll;   // [5 exchanges][node_cap][32] {value, tag} words of the cluster exchanges (R <= 5 only)
-  size_t gs_ll_stride;         // words per exchange buffer
   unsigned long long* g2_ex;   // graphstep2: [5 exchanges][g2_graphs][2 sides][32 features][128 nodes] {hi, mid, lo, tag} words
   size_t g2_ex_stride;         // words per exchange
   unsigned long long* g2_fx;   // [g2_graphs][256] {f32, tag} words of the centre-node readout

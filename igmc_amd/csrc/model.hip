@@ -2452,15 +2452,10 @@ void igmc_launch_forward(const ModelDev& m, const ModelAux& ax, const BatchDev& 
                          int use_flags, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
                          float* out, void* stream) {
   {
-    GsLayout lay;
     G2Layout lay2;
     int cs2 = 1;
     if (!training && igmc_layer_mode() >= 2 && m.R * m.L + m.L + 1 <= 32 && igmc_g2_eligible(m, b, B, &lay2, &cs2)) {
       igmc_launch_graph_step2(m, b, P, B, 0, use_flags, lay2, cs2, nullptr, seed, step, mult, 0.f, out, stream);
-      return;
-    }
-    if (!training && igmc_layer_mode() >= 2 && igmc_gs_eligible(m, b, &lay)) {   // one workgroup per subgraph
-      igmc_launch_graph_step(m, b, P, B, 0, use_flags, lay, nullptr, seed, step, mult, 0.f, out, stream);
       return;
     }
   }
@@ -2654,18 +2649,15 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
     }
     return;
   }
-  GsLayout lay;
   G2Layout lay2;
   int cs2 = 1;
-  const int v2 = l0_mfma && igmc_g2_eligible(m, b, B, &lay2, &cs2);
-  if (v2 || (l0_mfma && igmc_gs_eligible(m, b, &lay))) {
+  if (l0_mfma && igmc_g2_eligible(m, b, B, &lay2, &cs2)) {
     // one workgroup (cluster) per subgraph: forward, residual and backward down to the per-workgroup gradient partials
     const int cs = igmc_gs_cluster(B);
     const int gstride = (cs > 1) ? ((B + 7) & ~7) : IGMC_TS_BLOCKS;
     const int gg = (cs > 1) ? cs * gstride : igmc_gs_grid(B);
     int bump_seq = 0;       // 1: k_tail_ts advances the launch sequence number of the subgraph kernel's exchange tags
-    if (v2) bump_seq = igmc_launch_graph_step2(m, b, P, B, 1, use_flags, lay2, cs2, inj_mask, seed, step, mult, grad_scale, out, stream);
-    else igmc_launch_graph_step(m, b, P, B, 1, use_flags, lay, inj_mask, seed, step, mult, grad_scale, out, stream);
+    bump_seq = igmc_launch_graph_step2(m, b, P, B, 1, use_flags, lay2, cs2, inj_mask, seed, step, mult, grad_scale, out, stream);
     // IGMC_FIN_MODE=0: the hand-off version of the gradient / Adam tail (k_finalize) instead of k_finalize_ts
     const char* fe = getenv("IGMC_FIN_MODE");        // read on every call: tests switch it per case
     const int fts = (fe ? atoi(fe) : 1) && m.fin_stash && m.datt_part && m.R <= 8;

@@ -10,7 +10,7 @@ CXX=/opt/rocm/lib/llvm/bin/clang++
 RTDIR=$($CXX -print-resource-dir)/lib/linux
 OUT=/tmp/igmc_san
 mkdir -p $OUT
-SRCS="igmc_amd/csrc/extract.hip igmc_amd/csrc/model.hip igmc_amd/csrc/graphstep.hip igmc_amd/csrc/graphstep2.hip igmc_amd/csrc/sortpool.hip igmc_amd/csrc/capi.hip"
+SRCS="igmc_amd/csrc/extract.hip igmc_amd/csrc/model.hip igmc_amd/csrc/graphstep2.hip igmc_amd/csrc/sortpool.hip igmc_amd/csrc/capi.hip"
 if [ "$KIND" = asan ]; then
   FLAGS="-fsanitize=address -fno-omit-frame-pointer"
   RT=$RTDIR/libclang_rt.asan-x86_64.so
