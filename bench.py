@@ -220,6 +220,7 @@ def main():
     ap.add_argument('--rmse-links', type=int, default=5000)
     ap.add_argument('--dp-steps', type=int, default=96,
                     help='steps per launch structure of the dp_structure leg (N=1 only; 0 = skip)')
+    ap.add_argument('--dgcnn-rs', action='store_true', help='the sort-pool readout family (reference models.py:123-167) instead of IGMC')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly (no hipGraph replay)')
     ap.add_argument('--no-overlap', action='store_true', help='extract batch t+1 on the same stream (no overlap)')
     ap.add_argument('--cpu-baseline-worker', default=None, help=argparse.SUPPRESS)
@@ -254,8 +255,13 @@ def main():
     torch.manual_seed(1)
     ds = MyDynamicDataset('data/bench', A, (tr_u, tr_v), tr_l, 1, 1.0, cfg['mnph'], None, None, class_values,
                           device=local, seed=1)
-    model = IGMC(ds, latent_dim=[32, 32, 32, 32], num_relations=len(class_values), num_bases=4, regression=True,
-                 adj_dropout=cfg['adj_dropout'], multiply_by=1, seed=1).to(dev)
+    if args.dgcnn_rs:
+        from igmc_amd.models import DGCNN_RS
+        model = DGCNN_RS(ds, latent_dim=[32, 32, 32, 1], k=0.6, num_relations=len(class_values), num_bases=4,
+                         regression=True, adj_dropout=cfg['adj_dropout'], seed=1).to(dev)
+    else:
+        model = IGMC(ds, latent_dim=[32, 32, 32, 32], num_relations=len(class_values), num_bases=4, regression=True,
+                     adj_dropout=cfg['adj_dropout'], multiply_by=1, seed=1).to(dev)
     model.reset_parameters()
     if world > 1:
         parallel.broadcast_(model.flat_parameters(), 0)
@@ -293,9 +299,11 @@ def main():
 
     # Warm-up = exactly W steps: one eager step (first launches load code objects, which a capture cannot do), then the
     # graph is captured (group size M with 2 M dividing K: a graph launch is a pair of groups = 2 M steps) and the other
-    # W - 1 steps replay it where they fill a launch, else they are launched eagerly.  (The first launch of an instantiated
-    # hipGraph costs ~140 us more than the following ones, hipGraphUpload or not: profiles/r02_callB_graph_first_replay.txt;
-    # with the driver's W = 5 it falls inside the timed region.)
+    # W - 1 steps replay it where they fill a launch, else they are launched eagerly.  The first launch of an instantiated
+    # hipGraph costs ~140 us more than the following ones (hipGraphUpload or not: profiles/r02_callB_graph_first_replay.txt),
+    # a one-time cost like a kernel's code-object load: StepGraph.prepare() pays it before t0 by launching the fresh graph
+    # once and UNDOING it (parameters, Adam moments, control block restored; the group's batches extracted again), so the
+    # training state at t0 is exactly the state after the W warm-up steps.
     captured = False
     if sg.use_graph and args.warmup >= 1:
         run(1)
@@ -508,7 +516,7 @@ def main():
         model.eval()
         val = eval_rmse(model, DataLoader(te, BATCH, shuffle=False), dev)
         rmse = dict(value=val, test_links=m, checkpoint='seed-1 init + %d optimisation steps of this run' % state['i'])
-        if rank == 0 and want_cpu:
+        if rank == 0 and want_cpu and not args.dgcnn_rs:
             from oracle import pyg_ref                   # checker
             mo = min(200, m)
             small = MyDataset('data/bench_test_o', A, (te_u[:mo], te_v[:mo]), te_l[:mo], 1, 1.0, cfg['mnph'], None, None,
@@ -533,7 +541,7 @@ def main():
                                         abs_diff=abs((sse_e / mo) ** 0.5 - (sse_o / mo) ** 0.5))
 
     cpu = None
-    if rank == 0 and want_cpu:
+    if rank == 0 and want_cpu and not args.dgcnn_rs:
         cpu = cpu_baseline(A, tr_u, tr_v, tr_l, class_values, cfg['mnph'], cfg['adj_dropout'], cfg['cpu'])
     if rank == 0:
         rec = {
@@ -542,8 +550,9 @@ def main():
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': '%s %s-shaped rating graph (%d x %d, %d train links), random-init weights' % (
                 source, cfg['dataset'], A.shape[0], A.shape[1], n),
-            'config': {'workload': '%s, hop 1, max-nodes-per-hop %d, batch %d per GPU, adj-dropout %g, dynamic-train, '
-                                   'ARR 0.001, Adam' % (cfg['dataset'], cfg['mnph'], BATCH, cfg['adj_dropout']),
+            'config': {'workload': '%s%s, hop 1, max-nodes-per-hop %d, batch %d per GPU, adj-dropout %g, dynamic-train, '
+                                   'ARR 0.001, Adam' % (cfg['dataset'], ' (DGCNN_RS)' if args.dgcnn_rs else '', cfg['mnph'], BATCH,
+                                                        cfg['adj_dropout']),
                        'parallelism': 'dp%d' % world, 'global_batch': BATCH * world,
                        'graphs_captured_before_timing': bool(captured), 'steps_per_graph_launch': 2 * group_steps},
             'roofline': roofline, 'cpu_baseline': cpu, 'rmse': rmse, 'extraction': extraction,

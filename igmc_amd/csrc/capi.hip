@@ -1180,5 +1180,27 @@ extern "C" int igmc_sortpool_loss_grad(igmc_sortpool* sp, const float* d_params,
   igmc_launch_sp_wgrad(m->d, sp->d, b->d, B, sp->ge, d_grad, stream);
   if (d_loss) igmc_launch_loss(m->d, b->d, ARR, d_loss, stream);
   HIPCHECK(hipGetLastError());
+  m->last_flags = use_edge_flags;
+  return 0;
+}
+
+extern "C" int igmc_sortpool_step_finish(igmc_sortpool* sp, const igmc_batch* b, float* d_params, const float* d_grad,
+                                         float* d_exp_avg, float* d_exp_avg_sq, float ARR, float* d_loss, double* d_total,
+                                         int64_t* d_ctrl, int64_t step, float lr, float beta1, float beta2, float eps,
+                                         float weight_decay, void* stream) {
+  if (!sp || !b || !d_params || !d_grad || !d_exp_avg || !d_exp_avg_sq || !d_loss) IGMC_FAIL("bad arguments");
+  if (!d_ctrl && step < 1) IGMC_FAIL("step must be >= 1");
+  float step_size = 0.f, inv = 0.f;
+  if (!d_ctrl) {
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    step_size = (float)((double)lr / bc1);
+    inv = (float)(1.0 / std::sqrt(bc2));
+  }
+  ModelDev md = sp->m->d;
+  md.n_params = sp->d.n_params;          // Adam runs over the sort-pool family's own flat buffer
+  igmc_launch_finish(md, b->d, d_params, d_grad, d_exp_avg, d_exp_avg_sq, step_size, inv, beta1, beta2, eps, weight_decay,
+                     d_ctrl, ARR, d_loss, d_total, sp->m->last_flags, stream);
+  HIPCHECK(hipGetLastError());
   return 0;
 }

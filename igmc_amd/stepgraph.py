@@ -188,11 +188,13 @@ class StepGraph(GroupPipeline):
         self._init_pipeline(batch_size, group if group is not None else env, use_graph)
         self.overlap = overlap
         self.ctrl = torch.zeros(_lib.CTRL['WORDS'], dtype=torch.int64, device=self.dev)
-        # permutation buffer, padded so that the (discarded) prefetch of the group after the last one stays in range
-        self.pad = 2 * MAX_GROUP * self.B
+        # permutation buffer, padded so that the (discarded) prefetch of the group after the last one stays in range: a
+        # launch that starts at step k <= n/B - 2 M reads positions below (k + 3 M) B <= n + M B
+        self.pad = 4 * MAX_GROUP * self.B          # (twice that: a launch started anywhere inside the epoch stays in range)
         self.perm = torch.zeros(max(len(dataset), 1) + self.pad, dtype=torch.int32, device=self.dev)
         self.sets = [[], []]                   # arenas of the even / odd groups (created on first use)
         self.ws = None
+        self.sp = None                         # sort-pool readout family (DGCNN_RS): its own step kernels
         self._attached = False
         self._arena(0, 0)
         self.out = torch.empty(self.B, dtype=torch.float32, device=self.dev)
@@ -212,10 +214,13 @@ class StepGraph(GroupPipeline):
             a = self.ds.arena(self.B, slot='stepgraph%d.%d' % (q, len(self.sets[q])))
             self.sets[q].append(a)
             if self.ws is None:
-                self.ws = self.model._workspace(DeviceBatch(self.ds, a, self.B, self.perm, 0))
+                probe = DeviceBatch(self.ds, a, self.B, self.perm, 0)
+                if hasattr(self.model, '_sortpool'):
+                    self.sp = self.model._sortpool(probe)
+                self.ws = self.model._workspace(probe)
             # the matrix-core subgraph kernel reads the dense induced blocks only: where it takes the step, the
             # extraction skips the CSR emission (it is produced on demand for inspection)
-            if os.environ.get('IGMC_NO_LEAN', '0') != '1':
+            if self.sp is None and os.environ.get('IGMC_NO_LEAN', '0') != '1':
                 a.set_lean(self.ws.dense_path(a, self.B) or a.dense_layers(self.ws))
             self.lib.call('igmc_batch_set_ctrl', a.handle, C.c_void_p(self.ctrl.data_ptr()) if self._attached else None)
         return self.sets[q][i]
@@ -332,9 +337,28 @@ class StepGraph(GroupPipeline):
                       C.c_void_p(self.ctrl.data_ptr()), 1, g['lr'], g['betas'][0], g['betas'][1], g['eps'],
                       g['weight_decay'], C.c_void_p(st))
 
+    def _sortpool_step(self, arena, B):
+        """DGCNN_RS (reference models.py:123-167): conv kernels + sort-pool readout forward / backward -> [all-reduce] ->
+        Adam + loss + tick (igmc_sortpool_step_finish), every scalar from the control block: capturable like IGMC's."""
+        m, st = self.model, torch.cuda.current_stream().cuda_stream
+        flat, grad = m.flat_parameters(), m.flat_grad()
+        self.sp.loss_grad(flat.data_ptr(), arena, self.out.data_ptr(), grad.data_ptr(), None,
+                          use_edge_flags=m.adj_dropout > 0, seed=m.seed, step=0, ARR=self.ARR,
+                          grad_scale=1.0 / (B * self.world), arr_scale=1.0 / self.world, stream=st)
+        if self.comm is not None:
+            self.comm.all_reduce_(grad, st)
+        g = self.opt.param_groups[0]
+        self.lib.call('igmc_sortpool_step_finish', self.sp.handle, arena.handle, C.c_void_p(flat.data_ptr()),
+                      C.c_void_p(grad.data_ptr()), C.c_void_p(self.opt.exp_avg.data_ptr()),
+                      C.c_void_p(self.opt.exp_avg_sq.data_ptr()), self.ARR, C.c_void_p(self.loss.data_ptr()),
+                      C.c_void_p(self.total.data_ptr()), C.c_void_p(self.ctrl.data_ptr()), 1, g['lr'],
+                      g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'], C.c_void_p(st))
+
     def _enqueue_step(self, arena, B):
         """The kernels of one optimisation step on the batch in ``arena`` (current stream)."""
-        if not self.dp_path and B == self.B:
+        if self.sp is not None:
+            self._sortpool_step(arena, B)
+        elif not self.dp_path and B == self.B:
             self._train_step(arena)          # gradients + Adam in the minimum number of launches
         else:
             self._model(arena, B)
@@ -368,14 +392,15 @@ class StepGraph(GroupPipeline):
             torch.cuda.synchronize()
         return self.graph
 
-    def prepare(self, steps_hint=None, group=None):
+    def prepare(self, steps_hint=None, group=None, prime=True):
         """Capture every hipGraph this object will replay NOW and align the groups with the current position.
         ``steps_hint``: the caller is about to run exactly that many steps -- the group size M is chosen with 2 M dividing
         it, so that the run is whole graph launches.  ``group``: M (a graph launch holds 2 M steps).
         Capturing executes nothing; aligning re-extracts the batches of the group that starts at the current position
         (the steady state of an epoch: every group trains on batches extracted while the previous one ran).  Callers that
         time a region (bench.py) call this after their warm-up so that neither falls inside the timed steps.  Needs at
-        least one eagerly executed step before it (first launches load code objects, which a capture cannot do)."""
+        least one eagerly executed step before it (first launches load code objects, which a capture cannot do).
+        ``prime``: a graph captured by this call is launched once with its effects undone (``_prime``)."""
         if not self.use_graph or self.steps_done < 1 or not self._attached:
             return False
         M = self.M
@@ -388,8 +413,27 @@ class StepGraph(GroupPipeline):
             self.avail = 0
         if self.gq != 0 or self.gk != 0 or self.avail < self.M:
             self._regroup()
+        fresh = self.graph is None
         self._capture()
+        # (a launch reads link positions up to 3 M batches ahead of its first step: only where steps() would launch it too)
+        if fresh and self.graph is not None and prime and self.avail >= self.M and \
+                self.n_links // self.B - self.k >= 2 * self.M:
+            self._prime()
         return self.use_graph
+
+    def _prime(self):
+        """First launch of the freshly instantiated graph with its effects undone.  The first launch of a hipGraph costs
+        ~140 us more than the following ones (profiles/r02_callB_graph_first_replay.txt) -- a one-time cost like the code
+        object load of a kernel's first launch.  The launch runs 2 M real steps; parameters, Adam moments, control block and
+        epoch total are restored afterwards and the current group's batches are extracted again, so the training state is
+        exactly what it was (host-side step counters are not touched)."""
+        m = self.model
+        keep = [t.clone() for t in (m.flat_parameters(), self.opt.exp_avg, self.opt.exp_avg_sq, self.ctrl, self.total, self.loss)]
+        self.graph.replay()
+        torch.cuda.synchronize()
+        for t, k in zip((m.flat_parameters(), self.opt.exp_avg, self.opt.exp_avg_sq, self.ctrl, self.total, self.loss), keep):
+            t.copy_(k)
+        self._regroup()
 
     def run_epoch(self, perm, epoch):
         """All batches of one epoch; returns (sum over batches of loss*B as a device float64 tensor, #links)."""

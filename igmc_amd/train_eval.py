@@ -216,29 +216,9 @@ def train(model, optimizer, loader, device, regression=False, ARR=0, show_progre
         raise NotImplementedError('only the regression objective (what the reference runs) is implemented')
     G = parallel.world_size()
     n_total = 0
-    if isinstance(optimizer, FlatAdam) and hasattr(model, 'fused_loss_grad'):
-        # ---- model families without a captured step (DGCNN_RS): loss + gradient kernels, flat all-reduce, fused Adam;
-        #      eager launches, no host synchronisation inside the epoch
-        dev = model.flat_parameters().device
-        total = torch.zeros(1, dtype=torch.float64, device=dev)
-        loss = torch.zeros(2, dtype=torch.float32, device=dev)
-        for data in loader:
-            Bn = num_graphs(data)
-            model.fused_loss_grad(data, ARR, grad_scale=1.0 / (Bn * G), arr_scale=1.0 / G, loss=loss)
-            if G > 1:
-                parallel.all_reduce_sum_(model.flat_grad())
-            optimizer.step()
-            total += loss[0].double() * Bn
-            n_total += Bn
-        _check_workspaces(model)
-        if G > 1:
-            cnt = torch.tensor([float(n_total)], dtype=torch.float64, device=dev)
-            parallel.all_reduce_sum_(total)
-            parallel.all_reduce_sum_(cnt)
-            return float(total.item() / cnt.item())
-        return float(total.item()) / max(len(loader.dataset), 1)
     if isinstance(optimizer, FlatAdam):
-        # ---- fused path: no autograd, no host sync inside the epoch; the step is replayed as a hipGraph
+        # ---- fused path (IGMC and the sort-pool family DGCNN_RS): no autograd, no host sync inside the epoch; the steps
+        #      are replayed as hipGraphs, groups at a time
         sg = getattr(loader, '_stepgraph', None)
         if sg is None or sg.model is not model or sg.opt is not optimizer or sg.ARR != float(ARR):
             if sg is not None:

@@ -301,6 +301,15 @@ int igmc_sortpool_loss_grad(igmc_sortpool* sp, const float* d_params, const igmc
                             const uint8_t* d_lin_mask, uint64_t seed, uint64_t step, float ARR, float grad_scale,
                             float arr_scale, float* d_out, float* d_grad, float* d_loss, void* stream);
 
+/* optimizer.step() + loss bookkeeping of a sort-pool step in ONE launch, like igmc_step_finish for IGMC: Adam over the
+ * sort-pool family's flat buffer (igmc_sortpool_layout [24] parameters), d_loss[0..1], d_total[0] += loss * num_graphs and,
+ * with d_ctrl, the Adam scalars from / the tick of the control block -- so that the step is hipGraph-capturable
+ * (call igmc_sortpool_loss_grad with d_loss = NULL). */
+int igmc_sortpool_step_finish(igmc_sortpool* sp, const igmc_batch* b, float* d_params, const float* d_grad,
+                              float* d_exp_avg, float* d_exp_avg_sq, float ARR, float* d_loss, double* d_total,
+                              int64_t* d_ctrl, int64_t step, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,3 +93,36 @@ def test_dgcnn_rs_python_surface_trains():
             o = ref(pb)
         sse += float(((o - data.y.cpu().view(-1)) ** 2).sum())
     assert abs(rmse - math.sqrt(sse / len(te))) < 1e-4
+
+
+def test_dgcnn_rs_steps_replay_from_the_step_graph():
+    """The sort-pool family trains through the same grouped step graph as IGMC (conv kernels + sort-pool forward / backward ->
+    igmc_sortpool_step_finish: Adam, loss, control-block tick): groups of 4 replayed from the hipGraph == the same launches
+    made eagerly on one stream, bit for bit (parameters, Adam moments, epoch totals), over two epochs with edge dropout."""
+    import torch
+    from igmc_amd import preprocessing
+    from igmc_amd.models import DGCNN_RS
+    from igmc_amd.stepgraph import StepGraph
+    from igmc_amd.train_eval import FlatAdam
+    from igmc_amd.util_functions import MyDynamicDataset
+    (_, _, adj, trl, tru, trv, _, _, _, _, _, _, cv) = preprocessing.load_data_monti('douban', testing=True)
+    tr = MyDynamicDataset('data/t/dg_graph', adj, (tru[:1000], trv[:1000]), trl[:1000], 1, 1.0, 10000, None, None, cv, seed=2)
+    perm = torch.randperm(len(tr), generator=torch.Generator().manual_seed(5))
+    res = {}
+    for name, kw in (('graph', dict(group=4)), ('eager', dict(group=4, use_graph=False, overlap=False))):
+        torch.manual_seed(3)
+        model = DGCNN_RS(tr, latent_dim=[32, 32, 32, 1], k=30, num_relations=len(cv), num_bases=4, regression=True,
+                         adj_dropout=0.2, seed=1).to('cuda')
+        model.reset_parameters()
+        opt = FlatAdam(model, lr=1e-3)
+        sg = StepGraph(model, opt, tr, 50, 0.001, **kw)
+        assert sg.sp is not None
+        totals = [float(sg.run_epoch(perm, ep)[0].item()) for ep in (1, 2)]
+        torch.cuda.synchronize()
+        assert (sg.graph is not None) == (name == 'graph') and opt.t == 40
+        res[name] = (model.flat_parameters().detach().cpu().clone(), opt.exp_avg.detach().cpu().clone(),
+                     opt.exp_avg_sq.detach().cpu().clone(), totals)
+    assert all(np.isfinite(res['graph'][3])) and res['graph'][3][1] < res['graph'][3][0]
+    for a, b in zip(res['graph'][:3], res['eager'][:3]):
+        assert torch.equal(a, b)
+    assert res['graph'][3] == res['eager'][3]

@@ -332,7 +332,7 @@ class EmuPipeline(stepgraph.GroupPipeline):
         pass
 
     def run_epoch(self, perm, epoch):
-        pad = 2 * stepgraph.MAX_GROUP * B
+        pad = 4 * stepgraph.MAX_GROUP * B
         self.perm = np.concatenate([perm, perm[np.arange(pad) %% len(perm)]]).astype(np.int32)
         self.ctrl[:] = stepgraph._ctrl_words(step0, epoch, 1, B, self.M, lr, 0.9, 0.999, 1e-8, 0.0)
         self._reset_epoch(len(perm))
