@@ -33,6 +33,9 @@ SIGNATURES = {
     'igmc_extract_batch': (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f64, u64, u64, vp]),
     'igmc_extract_batch_replay': (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     'igmc_extract_batch_cached': (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
+    'igmc_batch_set_create': (i32, [vp, i32, C.POINTER(vp)]),
+    'igmc_batch_set_destroy': (None, [vp]),
+    'igmc_extract_group': (i32, [vp, vp, i32, vp, vp, vp, vp, i32, i32, f64, u64, f32, i32, u64, vp]),
     'igmc_batch_edge_dropout': (i32, [vp, f32, i32, u64, u64, vp]),
     'igmc_batch_set_edge_flags': (i32, [vp, vp, i64]),
     'igmc_batch_clear_edge_flags': (i32, [vp]),

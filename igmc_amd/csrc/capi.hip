@@ -424,6 +424,66 @@ extern "C" int igmc_extract_batch_cached(const igmc_graph* g, igmc_batch* b, con
   return 0;
 }
 
+// ---- a group of arenas extracted in one launch per stage
+struct igmc_batch_set {
+  std::vector<igmc_batch*> arenas;
+  BatchDev* d_views;        // device array of the arenas' views
+};
+
+extern "C" int igmc_batch_set_create(igmc_batch* const* batches, int count, igmc_batch_set** out) {
+  if (!batches || count < 1 || !out) IGMC_FAIL("bad arguments");
+  std::vector<BatchDev> views;
+  for (int i = 0; i < count; ++i) {
+    const igmc_batch* b = batches[i];
+    if (!b) IGMC_FAIL("null arena");
+    const BatchDev &d = b->d, &d0 = batches[0]->d;
+    if (b->g != batches[0]->g || d.cap_u != d0.cap_u || d.cap_v != d0.cap_v || d.graph_cap != d0.graph_cap || d.hop != d0.hop ||
+        d.max_nodes_per_hop != d0.max_nodes_per_hop || (d.relm != nullptr) != (d0.relm != nullptr) ||
+        (d.relmT != nullptr) != (d0.relmT != nullptr))
+      IGMC_FAIL("the arenas of a set must share graph and geometry");
+    if (!d.relm) IGMC_FAIL("group extraction needs arenas with dense induced blocks");
+    views.push_back(d);
+  }
+  HIPCHECK(hipSetDevice(batches[0]->g->device));
+  igmc_batch_set* s = new igmc_batch_set();
+  s->arenas.assign(batches, batches + count);
+  s->d_views = nullptr;
+  if (hipMalloc((void**)&s->d_views, views.size() * sizeof(BatchDev)) != hipSuccess) {
+    delete s;
+    IGMC_FAIL("hipMalloc failed (arena set)");
+  }
+  HIPCHECK(hipMemcpy(s->d_views, views.data(), views.size() * sizeof(BatchDev), hipMemcpyHostToDevice));
+  *out = s;
+  return 0;
+}
+
+extern "C" void igmc_batch_set_destroy(igmc_batch_set* s) {
+  if (!s) return;
+  if (s->d_views) hipFree(s->d_views);
+  delete s;
+}
+
+extern "C" int igmc_extract_group(const igmc_graph* g, igmc_batch_set* s, int count, const int32_t* d_link_u,
+                                  const int32_t* d_link_v, const float* d_link_y, const int32_t* d_link_idx, int sel0,
+                                  int B, double sample_ratio, uint64_t seed, float drop_p, int force_undirected,
+                                  uint64_t drop_seed, void* stream) {
+  if (!g || !s || count < 1 || count > (int)s->arenas.size()) IGMC_FAIL("bad arguments");
+  if (!d_link_u || !d_link_v || !d_link_y) IGMC_FAIL("null link arrays");
+  const igmc_batch* b0 = s->arenas[0];
+  if (b0->g != g) IGMC_FAIL("the set does not belong to this graph");
+  if (B <= 0 || B > b0->d.graph_cap) IGMC_FAIL("B exceeds the batch capacity");
+  for (int i = 0; i < count; ++i) {
+    const igmc_batch* b = s->arenas[i];
+    if (!b->lean || !b->ctrl || b->ctrl != b0->ctrl || b->side_src)
+      IGMC_FAIL("group extraction needs lean arenas with one control block attached and no side-feature source");
+  }
+  igmc_launch_extract_set(g->d, s->d_views, b0->d, count, d_link_u, d_link_v, d_link_y, d_link_idx, sel0, B, sample_ratio,
+                          seed, b0->ctrl, drop_p, force_undirected, drop_seed, stream);
+  HIPCHECK(hipGetLastError());
+  for (int i = 0; i < count; ++i) s->arenas[i]->last_B = B;
+  return 0;
+}
+
 // A lean arena carries no collated CSR after an extraction: whoever needs it (inspection, the flag kernels, the
 // per-layer model kernels) emits it first.  Emission is idempotent, and a hipGraph replay of the extraction leaves no
 // host-side trace, so a lean arena re-emits on every such call.

@@ -154,7 +154,7 @@ __device__ int append_fringe(const uint32_t* bm, uint32_t* sel, int W, int32_t* 
 }
 
 // ---------------------------------------------------------------- kernel 1
-__global__ __launch_bounds__(IGMC_BLOCK) void k_extract_nodes(ExtractArgs a) {
+__device__ __forceinline__ void extract_nodes_body(const ExtractArgs& a) {
   IGMC_DYN_SMEM(smem);
   __shared__ int hist[256];
   __shared__ int sm[16];
@@ -317,6 +317,16 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_extract_nodes(ExtractArgs a) {
     const int nw = (cu * a.b.relm_ld) >> 2;
     for (int i = tid; i < nw; i += IGMC_BLOCK) rm[i] = 0u;
   }
+}
+
+__global__ __launch_bounds__(IGMC_BLOCK) void k_extract_nodes(ExtractArgs a) { extract_nodes_body(a); }
+// ... for a whole GROUP of batches in one launch (igmc_extract_group): blockIdx.z = batch i of the group, its arena =
+// set[i], its selector = a.first + 2 i (selector q | (i << 1), igmc_hip.h).  Extraction is a dependent chain per workgroup,
+// so its throughput is the number of workgroups in flight: M batches in one launch take about as long as two or three.
+__global__ __launch_bounds__(IGMC_BLOCK) void k_extract_nodes_set(ExtractArgs a, const BatchDev* __restrict__ set) {
+  a.b = set[blockIdx.z];
+  a.first += 2 * (int)blockIdx.z;
+  extract_nodes_body(a);
 }
 
 
@@ -518,7 +528,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_fill(GraphDev G, BatchDev b) {
 // equal slices of it and every thread takes entries at stride 256 inside the slice, locating its row by a binary
 // search over the <= 256 row starts.  (One wave per ROW, as before, made the kernel as long as the longest row: an
 // active user's 2 400 ratings = 10 dependent 256-entry rounds = 35-50 us for ~8 MB of traffic.)
-__global__ __launch_bounds__(IGMC_BLOCK) void k_relm(GraphDev G, BatchDev b) {
+__device__ __forceinline__ void relm_body(const GraphDev& G, const BatchDev& b) {
   IGMC_DYN_SMEM(smem);
   __shared__ int sm[16];
   const int g = blockIdx.x;
@@ -594,6 +604,9 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_relm(GraphDev G, BatchDev b) {
   c = igmc_wave_sum_i(c);
   if (lane == 0 && c) atomicAdd(&b.edge_cnt[g], 2 * c);   // directed edges; integer => order-independent
 }
+__global__ __launch_bounds__(IGMC_BLOCK) void k_relm(GraphDev G, BatchDev b) { relm_body(G, b); }
+__global__ __launch_bounds__(IGMC_BLOCK) void k_relm_set(GraphDev G, const BatchDev* __restrict__ set) { relm_body(G, set[blockIdx.z]); }
+
 
 // kernel 3d: batch offsets, degrees, row pointers and the relation-sorted CSR, all from relm
 __global__ __launch_bounds__(IGMC_BLOCK) void k_emit(BatchDev b) {
@@ -722,7 +735,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_emit(BatchDev b) {
 
 // Node part of the emission alone (batch offsets, per-node label / id / graph, totals): what the model kernels that work
 // on the dense blocks need of the collated batch (dense per-layer path: no edge list is read anywhere in the step).
-__global__ __launch_bounds__(IGMC_BLOCK) void k_emit_nodes(BatchDev b) {
+__device__ __forceinline__ void emit_nodes_body(const BatchDev& b) {
   __shared__ int sm[16];
   const int g = blockIdx.x, B = gridDim.x;
   const int tid = threadIdx.x;
@@ -761,6 +774,9 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_emit_nodes(BatchDev b) {
     b.node_graph[nb + n] = g;
   }
 }
+__global__ __launch_bounds__(IGMC_BLOCK) void k_emit_nodes(BatchDev b) { emit_nodes_body(b); }
+__global__ __launch_bounds__(IGMC_BLOCK) void k_emit_nodes_set(const BatchDev* __restrict__ set) { emit_nodes_body(set[blockIdx.z]); }
+
 
 void igmc_launch_emit_nodes(const BatchDev& b, int B, void* stream) {
   IGMC_PLAUNCH("k_emit_nodes", k_emit_nodes, B, IGMC_BLOCK, 0, stream, b);
@@ -887,8 +903,8 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_relm_flags(BatchDev b) {
 
 // edge dropout of a lean arena: the Bernoulli draws of k_edge_flags (same key: graph, user id, item id, direction), taken
 // straight from the dense blocks -- no CSR needed.  grid (B, 4): a workgroup takes every 4th dword column group.
-__global__ __launch_bounds__(IGMC_BLOCK) void k_relm_dropout(BatchDev b, float p, int force_undirected, uint64_t seed,
-                                                              uint64_t step_arg, const int64_t* ctrl) {
+__device__ __forceinline__ void relm_dropout_body(const BatchDev& b, float p, int force_undirected, uint64_t seed,
+                                                  uint64_t step_arg, const int64_t* ctrl) {
   const uint64_t step = ctrl ? igmc_ctrl_drop_key(ctrl, igmc_ctrl_first(ctrl, (int)step_arg)) : step_arg;
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) b.stamp[1] = ctrl ? (int64_t)step : -1;
   const int g = blockIdx.x;
@@ -916,6 +932,15 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_relm_dropout(BatchDev b, float p
     rm[row * ldw + k] = w;
   }
 }
+__global__ __launch_bounds__(IGMC_BLOCK) void k_relm_dropout(BatchDev b, float p, int force_undirected, uint64_t seed,
+                                                              uint64_t step_arg, const int64_t* ctrl) {
+  relm_dropout_body(b, p, force_undirected, seed, step_arg, ctrl);
+}
+__global__ __launch_bounds__(IGMC_BLOCK) void k_relm_dropout_set(const BatchDev* __restrict__ set, float p, int force_undirected,
+                                                                  uint64_t seed, uint64_t sel0, const int64_t* ctrl) {
+  relm_dropout_body(set[blockIdx.z], p, force_undirected, seed, sel0 + 2 * blockIdx.z, ctrl);
+}
+
 
 void igmc_launch_relm_dropout(const BatchDev& b, int B, float p, int force_undirected, uint64_t seed, uint64_t step,
                               const int64_t* ctrl, void* stream) {
@@ -1039,6 +1064,32 @@ void igmc_launch_extract(const GraphDev& g, const BatchDev& b, const int32_t* li
     IGMC_PLAUNCH("k_fill", k_fill, dim3(B, S), IGMC_BLOCK, smem / 2, stream, g, b);
   }
   if (igmc_layer_mode() == 3) IGMC_PLAUNCH("k_slots", k_slots, B, IGMC_BLOCK, 0, stream, b);    // row segments (opt-in)
+}
+
+// Extraction (+ edge dropout on the dense blocks) of `count` batches of one group in ONE launch per stage: arenas set[0 ..
+// count) (a device array of identical geometry `b0`: lean, dense blocks, control block attached), selectors sel0 + 2 i.
+void igmc_launch_extract_set(const GraphDev& g, const BatchDev* d_set, const BatchDev& b0, int count, const int32_t* link_u,
+                             const int32_t* link_v, const float* link_y, const int32_t* link_idx, int sel0, int B,
+                             double sample_ratio, uint64_t seed, const int64_t* ctrl, float drop_p, int force_undirected,
+                             uint64_t drop_seed, void* stream) {
+  ExtractArgs a;
+  a.ctrl = ctrl;
+  a.g = g; a.b = b0;
+  a.link_u = link_u; a.link_v = link_v; a.link_y = link_y; a.link_idx = link_idx;
+  a.first = sel0; a.B = B; a.replay = 0;
+  a.sample_ratio = sample_ratio; a.seed = seed; a.epoch = 0;
+  const size_t smem = igmc_extract_smem_bytes(g);
+  const char* se = getenv("IGMC_EXTRACT_SPLIT");
+  a.split = (b0.hop == 1 && !(se && atoi(se) == 0)) ? 1 : 0;
+  IGMC_PLAUNCH("k_extract_nodes", k_extract_nodes_set, dim3(B, a.split ? 2 : 1, count), IGMC_BLOCK, smem, stream, a, d_set);
+  const size_t Wv = (g.n_items + 31) >> 5;
+  int Sr = 400 / (B > 0 ? B : 1);
+  Sr = Sr < 1 ? 1 : (Sr > 16 ? 16 : Sr);
+  IGMC_PLAUNCH("k_relm", k_relm_set, dim3(B, Sr, count), IGMC_BLOCK, (2 * Wv + 2 * (size_t)b0.cap_u + 2) * sizeof(uint32_t), stream, g, d_set);
+  if (b0.relmT) IGMC_PLAUNCH("k_emit_nodes", k_emit_nodes_set, dim3(B, 1, count), IGMC_BLOCK, 0, stream, d_set);
+  if (drop_p > 0.f)
+    IGMC_PLAUNCH("k_relm_dropout", k_relm_dropout_set, dim3(B, 4, count), IGMC_BLOCK, 0, stream, d_set, drop_p, force_undirected,
+                 drop_seed, (uint64_t)sel0, ctrl);
 }
 
 void igmc_launch_edge_flags(const BatchDev& b, float p, int force_undirected, uint64_t seed, uint64_t step,

@@ -8,6 +8,10 @@ size_t igmc_extract_smem_bytes(const GraphDev& g);
 void igmc_launch_extract(const GraphDev& g, const BatchDev& b, const int32_t* link_u, const int32_t* link_v,
                          const float* link_y, const int32_t* link_idx, int first, int B, int replay,
                          double sample_ratio, uint64_t seed, uint64_t epoch, const int64_t* ctrl, int lean, void* stream);
+void igmc_launch_extract_set(const GraphDev& g, const BatchDev* d_set, const BatchDev& b0, int count, const int32_t* link_u,
+                             const int32_t* link_v, const float* link_y, const int32_t* link_idx, int sel0, int B,
+                             double sample_ratio, uint64_t seed, const int64_t* ctrl, float drop_p, int force_undirected,
+                             uint64_t drop_seed, void* stream);
 void igmc_launch_emit(const BatchDev& b, int B, void* stream);
 void igmc_launch_emit_nodes(const BatchDev& b, int B, void* stream);
 void igmc_launch_load_nodes(const BatchDev& b, const int64_t* uoff, const int32_t* unodes, const uint8_t* udist,

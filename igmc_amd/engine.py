@@ -173,6 +173,39 @@ class Batch(object):
             pass
 
 
+class BatchSet(object):
+    """A group of arenas of one geometry that ``igmc_extract_group`` fills in one launch per stage."""
+
+    def __init__(self, arenas):
+        self.arenas = list(arenas)
+        self.lib = self.arenas[0].lib
+        hs = (C.c_void_p * len(self.arenas))(*[a.handle for a in self.arenas])
+        h = C.c_void_p()
+        self.lib.call('igmc_batch_set_create', C.cast(hs, C.c_void_p), len(self.arenas), C.byref(h))
+        self.handle = h
+
+    def extract(self, count, link_u, link_v, link_y, link_idx, sel0, B, sample_ratio=1.0, seed=0, drop_p=0.0,
+                force_undirected=False, drop_seed=0, stream=None):
+        """Batches sel0 + 2 i (i < count; selectors of the device-side step control) into arenas 0 .. count-1, followed by
+        their edge dropout when ``drop_p`` > 0."""
+        self.lib.call('igmc_extract_group', self.arenas[0].graph.handle, self.handle, int(count), _p(link_u), _p(link_v),
+                      _p(link_y), _p(link_idx), int(sel0), int(B), float(sample_ratio), int(seed) & (2 ** 64 - 1),
+                      float(drop_p), int(bool(force_undirected)), int(drop_seed) & (2 ** 64 - 1), _p(stream))
+        for a in self.arenas[:count]:
+            a.B = int(B)
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.cdll.igmc_batch_set_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ModelWorkspace(object):
     """Model geometry + activation/gradient workspace; knows the flat parameter layout."""
 

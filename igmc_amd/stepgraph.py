@@ -40,6 +40,7 @@ import torch
 from . import _lib, parallel
 
 MAX_GROUP = 32
+GROUP_EXTRACT_CHUNK = 2      # batches per extraction launch (igmc_extract_group; measured: profiles/r03_extract_chunk_sweep.txt); 0 / 1 = arena by arena
 
 
 def _ctrl_words(step, epoch, adam_t, batch, group, lr, beta1, beta2, eps, wd):
@@ -92,12 +93,22 @@ class GroupPipeline(object):
         self.n_links = int(n_links)
         self.k, self.gq, self.gk, self.avail = 0, 0, 0, 0
 
+    def _extract_many(self, q, count):
+        """Batches 0 .. count-1 of the group of parity ``q`` into its arenas: ONE launch per extraction stage for all of them
+        where the backend can (extraction is a dependent chain per link -- its throughput is the number of links in flight),
+        else arena by arena."""
+        if count > 0 and not self._extract_group(q, count):
+            for i in range(count):
+                self._extract(self._arena(q, i), q | (i << 1), self.B)
+
+    def _extract_group(self, q, count):
+        return False
+
     def _fill_group(self):
         """Eager extraction of the batches of the current group that lie inside the epoch (group parity 0, from batch 0)."""
         assert self.gq == 0 and self.gk == 0
         cnt = min(self.M, max(0, self.n_links // self.B - self.k))
-        for i in range(cnt):
-            self._extract(self._arena(0, i), i << 1, self.B)
+        self._extract_many(0, cnt)
         self.avail = cnt
 
     def _regroup(self):
@@ -109,13 +120,14 @@ class GroupPipeline(object):
     def _enqueue_group(self, q):
         """M steps on the arenas of parity ``q`` || extraction of the next group's M batches into the other set."""
         cur = [self._arena(q, i) for i in range(self.M)]
-        nxt = [self._arena(1 - q, i) for i in range(self.M)]
+        for i in range(self.M):
+            self._arena(1 - q, i)
         self._fork()
         # the model kernels are enqueued BEFORE the extraction branch: the subgraph kernel (one workgroup per CU on 200 of
         # 256 CUs) is dispatched first and the extraction workgroups fill what is left
         for i in range(self.M):
             self._enqueue_step(cur[i], self.B)
-        self._side(lambda: [self._extract(nxt[i], (1 - q) | (i << 1), self.B) for i in range(self.M)])
+        self._side(lambda: self._extract_many(1 - q, self.M))
         self._join()
 
     def _enqueue_pair(self):
@@ -196,6 +208,8 @@ class StepGraph(GroupPipeline):
         self.ws = None
         self.sp = None                         # sort-pool readout family (DGCNN_RS): its own step kernels
         self._attached = False
+        self._lean = True                      # every arena so far extracts lean (dense blocks only)
+        self._sets = {}                        # engine.BatchSet per group parity (group extraction)
         self._arena(0, 0)
         self.out = torch.empty(self.B, dtype=torch.float32, device=self.dev)
         self.loss = torch.zeros(2, dtype=torch.float32, device=self.dev)
@@ -220,8 +234,11 @@ class StepGraph(GroupPipeline):
                 self.ws = self.model._workspace(probe)
             # the matrix-core subgraph kernel reads the dense induced blocks only: where it takes the step, the
             # extraction skips the CSR emission (it is produced on demand for inspection)
+            lean = False
             if self.sp is None and os.environ.get('IGMC_NO_LEAN', '0') != '1':
-                a.set_lean(self.ws.dense_path(a, self.B) or a.dense_layers(self.ws))
+                lean = bool(self.ws.dense_path(a, self.B) or a.dense_layers(self.ws))
+                a.set_lean(lean)
+            self._lean = self._lean and lean
             self.lib.call('igmc_batch_set_ctrl', a.handle, C.c_void_p(self.ctrl.data_ptr()) if self._attached else None)
         return self.sets[q][i]
 
@@ -261,6 +278,50 @@ class StepGraph(GroupPipeline):
                           self.perm.data_ptr(), sel, B, self.ds.sample_ratio, self.ds.seed, 0, st)
         if m.adj_dropout > 0:
             arena.edge_dropout(m.adj_dropout, m.force_undirected, m.seed, sel, st)
+
+    def _chunk(self):
+        """Batches per extraction launch: a whole group in ONE launch keeps the subgraph kernel's clusters off the chip while
+        it runs (thousands of small workgroups), one batch per launch runs beside 60 % of the steps; chunks in between."""
+        c = int(os.environ.get('IGMC_GROUP_EXTRACT_CHUNK', str(GROUP_EXTRACT_CHUNK)))
+        return max(0, min(c, self.M))
+
+    def _batch_sets(self, q, count=0):
+        """The arena set of group parity ``q`` as engine.BatchSets of ``_chunk()`` arenas each (created outside any capture),
+        or None where group extraction does not apply."""
+        c = self._chunk()
+        if c < 2 or getattr(self.ds, '_cache', None) is not None or getattr(self.ds, '_side', None) is not None or \
+                not self._attached:
+            return None
+        n = max(count, self.M)
+        arenas = [self._arena(q, i) for i in range(n)]
+        if not self._lean:
+            return None
+        key = (q, c)
+        sets = self._sets.get(key)
+        if sets is None or sum(len(b.arenas) for b in sets) < n:
+            from . import engine
+            sets = self._sets[key] = [engine.BatchSet(arenas[i0:i0 + c]) for i0 in range(0, n, c)]
+        return sets
+
+    def _extract_group(self, q, count):
+        """igmc_extract_group: chunks of the group in one launch per stage (dynamic datasets, lean arenas with dense blocks,
+        no side features); False = not applicable here."""
+        m = self.model
+        sets = self._batch_sets(q, count)
+        if sets is None:
+            return False
+        st = torch.cuda.current_stream().cuda_stream
+        i0 = 0
+        for bs in sets:
+            n = min(len(bs.arenas), count - i0)
+            if n <= 0:
+                break
+            bs.extract(n, self.ds.link_u.data_ptr(), self.ds.link_v.data_ptr(), self.ds.link_y.data_ptr(),
+                       self.perm.data_ptr(), q | (i0 << 1), self.B, self.ds.sample_ratio, self.ds.seed,
+                       drop_p=m.adj_dropout if m.adj_dropout > 0 else 0.0, force_undirected=m.force_undirected,
+                       drop_seed=m.seed, stream=st)
+            i0 += n
+        return True
 
     def begin_epoch(self, perm, epoch):
         """``perm``: this rank's link positions for the epoch (1-D int tensor, any device)."""
@@ -371,8 +432,9 @@ class StepGraph(GroupPipeline):
     def _capture(self):
         if self.graph is not None or not self.use_graph:
             return self.graph
-        for qq in (0, 1):                   # (arenas are created on first use: never inside a capture)
+        for qq in (0, 1):                   # (arenas and arena sets are created on first use: never inside a capture)
             self._arena(qq, self.M - 1)
+            self._batch_sets(qq)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         dist = parallel.is_dist()

@@ -91,6 +91,21 @@ int igmc_extract_batch_cached(const igmc_graph* g, igmc_batch* b,
                               const int64_t* d_voff, const int32_t* d_vnodes, const uint8_t* d_vdist,
                               const float* d_link_y, const int32_t* d_link_idx, int first, int B, void* stream);
 
+/* A GROUP of batches extracted in one launch per stage (no reference counterpart: the reference extracts subgraph by subgraph
+ * in worker processes, util_functions.py:138-145).  Extraction is a dependent chain per link, so its throughput is the number
+ * of links in flight: the batches sel0 + 2 i (i = 0 .. count-1; selectors q | (i << 1) of the device-side step control) go
+ * into the arenas of `set` with the kernels of igmc_extract_batch launched ONCE over all of them, followed -- drop_p > 0 --
+ * by their edge dropout (igmc_batch_edge_dropout with step = the batch's selector).  Every arena of the set must belong to
+ * `g`, share one geometry, carry dense induced blocks, be lean (igmc_batch_set_lean), have the same control block attached
+ * and no side-feature source; anything else is an error (callers then extract arena by arena). */
+typedef struct igmc_batch_set igmc_batch_set;
+int igmc_batch_set_create(igmc_batch* const* batches, int count, igmc_batch_set** out);
+void igmc_batch_set_destroy(igmc_batch_set* s);
+int igmc_extract_group(const igmc_graph* g, igmc_batch_set* s, int count,
+                       const int32_t* d_link_u, const int32_t* d_link_v, const float* d_link_y,
+                       const int32_t* d_link_idx, int sel0, int B, double sample_ratio, uint64_t seed,
+                       float drop_p, int force_undirected, uint64_t drop_seed, void* stream);
+
 /* Edge dropout (reference models.py:193-198 -> PyG dropout_adj): fills the per-entry keep
  * flags (bit0: edge col->row kept, bit1: edge row->col kept) from a counter-based hash of
  * (seed, step, graph, user id, item id, direction).  p = drop probability. */

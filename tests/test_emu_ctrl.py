@@ -152,7 +152,7 @@ def test_group_control_walks_the_same_batches():
             rec.append((d['node_gid'].copy(), d['eflag'].copy(), out.copy(), loss.copy(), P.copy()))
         return rec
 
-    def run_groups(corrupt=False):
+    def run_groups(corrupt=False, grouped=False):
         P, M1, M2 = P0.copy(), np.zeros_like(P0), np.zeros_like(P0)
         G, out, loss = np.zeros_like(P0), np.zeros(B, np.float32), np.zeros(2, np.float32)
         total = np.zeros(1, np.float64)
@@ -167,21 +167,34 @@ def test_group_control_walks_the_same_batches():
             sets[q][i].extract(lu, lv, ly, perm, q | (i << 1), B, 1.0, 7, 999)        # epoch argument ignored
             sets[q][i].edge_dropout(0.2, False, 7, q | (i << 1))
 
+        bsets = None
+        if grouped:      # igmc_extract_group: the whole group (extraction + dropout on the dense blocks) in one launch per stage
+            for s in sets:
+                for a in s:
+                    a.set_lean(True)
+            bsets = [engine.BatchSet(s) for s in sets]
+
         def train(arena):
             lib.call('igmc_train_step', ws.handle, C.c_void_p(P.ctypes.data), arena.handle, 1, None, 7, 0, 1.0, 0.001,
                      C.c_void_p(out.ctypes.data), C.c_void_p(G.ctypes.data), C.c_void_p(M1.ctypes.data),
                      C.c_void_p(M2.ctypes.data), C.c_void_p(loss.ctypes.data), C.c_void_p(total.ctypes.data), cp, 1,
                      1e-3, 0.9, 0.999, 1e-8, 0.0, None)
 
-        for i in range(M):
-            extract(0, i)
+        if grouped:
+            bsets[0].extract(M, lu, lv, ly, perm, 0, B, 1.0, 7, drop_p=0.2, drop_seed=7)
+        else:
+            for i in range(M):
+                extract(0, i)
         rec, gq, t = [], 0, 0
         while t < T:
             steps = min(M, T - t)
+            if grouped:
+                bsets[1 - gq].extract(M, lu, lv, ly, perm, 1 - gq, B, 1.0, 7, drop_p=0.2, drop_seed=7)
             for i in range(0, M, 2):                    # part of the prefetch before the group's steps ...
-                extract(1 - gq, i)
+                if not grouped:
+                    extract(1 - gq, i)
             for i in range(steps):
-                if i == 1:
+                if i == 1 and not grouped:
                     for j in range(1, M, 4):            # ... part between them ...
                         extract(1 - gq, j)
                 if corrupt and t + i == 4:
@@ -190,13 +203,15 @@ def test_group_control_walks_the_same_batches():
                 d = sets[gq][i].download()
                 rec.append((d['node_gid'].copy(), d['eflag'].copy(), out.copy(), loss.copy(), P.copy()))
             for j in range(3, M, 4):                    # ... and the rest after the last tick of the group
-                extract(1 - gq, j)
+                if not grouped:
+                    extract(1 - gq, j)
             t += steps
             if steps == M:
                 gq ^= 1
         for s in sets:
             for a in s:
                 lib.call('igmc_batch_set_ctrl', a.handle, None)
+                a.set_lean(False)
         lib.call('igmc_model_set_ctrl', ws.handle, None)
         return rec, ctrl, total
 
@@ -214,3 +229,10 @@ def test_group_control_walks_the_same_batches():
             np.testing.assert_allclose(x, y, rtol=2e-5, atol=1e-7)
     _, ctrl_bad, _ = run_groups(corrupt=True)
     assert ctrl_bad[K['SYNC_ERR']] & 2
+    # igmc_extract_group (every batch of a group in one launch per extraction stage, edge dropout included) walks the very
+    # same trajectory: same node sets, same keep flags, same parameters, bit for bit
+    rec_g, ctrl_g, _ = run_groups(grouped=True)
+    assert ctrl_g[K['SYNC_ERR']] == 0
+    for a, b in zip(rec, rec_g):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
