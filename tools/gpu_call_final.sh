@@ -1,27 +1,28 @@
 #!/bin/bash
-# Round-end GPU session: full GPU suite, smoke, bench lines (driver-style with CPU baseline, 200 steps, douban, ml_100k),
-# rocprofv3 kernel trace + PMC passes of the headline configuration.   IGMC_COMMIT=<hash> bash tools/gpu_call_final.sh
-set -u
-ROOT=$(pwd)
-O=$ROOT/gpurun_out/final
-mkdir -p $O
-export PYTHONPATH=$ROOT
-( timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -15 ) > $O/gpu_tests.log
-( timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -3 ) > $O/smoke.log
-( timeout 400 python bench.py --steps 20 --warmup 5 ) > $O/bench_ml1m_driver.json 2> $O/bench_ml1m_driver.err
-( timeout 300 python bench.py --no-cpu-baseline ) > $O/bench_ml1m_200.json 2> $O/bench_ml1m_200.err
-( timeout 400 python bench.py --config douban ) > $O/bench_douban.json 2> $O/bench_douban.err
-( timeout 400 python bench.py --config ml_100k ) > $O/bench_ml100k.json 2> $O/bench_ml100k.err
-bash tools/profile_round.sh ml_1m
-tail -3 $O/gpu_tests.log; cat $O/smoke.log
-for f in $O/bench_ml1m_driver.json $O/bench_ml1m_200.json $O/bench_douban.json $O/bench_ml100k.json; do python - $f <<'PY'
-import json,sys
-try:
-    d=json.load(open(sys.argv[1])); r=d['roofline'] or {}
-    print(sys.argv[1].split('/')[-1], round(d['value']), 'us/step %.1f'%(d['ms_per_step']*1e3), r.get('kernel'), 'avg_us', r.get('avg_us'), 'frac', r.get('frac'), 'traffic', r.get('traffic'), d['kernels_us'])
-    print('   cpu', (d.get('cpu_baseline') or {}).get('value'), 'rmse', (d.get('rmse') or {}).get('value'), 'dp', d.get('dp_structure_us'), 'ext', (d.get('extraction') or {}).get('us_per_step'))
-except Exception as e:
-    print('ERR', e); print(open(sys.argv[1].replace('.json','.err')).read()[-1500:])
-PY
+# Round-end GPU session: suite, smoke, the bench lines DESIGN.md quotes, the profiling recipe (kernel trace + PMC passes)
+cd "$(dirname "$0")/.." || exit 1
+O=gpurun_out/${1:-final}; mkdir -p $O
+export TMPDIR=/tmp
+timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log; tail -5 $O/pytest.log
+timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; tail -2 $O/smoke.log
+timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err                      # the driver's default form (200 / 20, all legs)
+timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver.json 2> $O/bench_driver.err
+for c in douban ml_100k flixster yahoo_music; do
+  st=200; [ $c = yahoo_music ] && st=64
+  timeout 400 python bench.py --config $c --steps $st --warmup 20 --no-cpu-baseline --dp-steps 0 > $O/bench_$c.json 2> $O/bench_$c.err
 done
-head -14 gpurun_out/prof/kernel_stats.txt; cat gpurun_out/prof/pmc_traffic.json
+timeout 200 python tools/g2_phase_clocks.py > $O/phase_clocks.txt 2>&1
+timeout 200 python tools/g2_phase_clocks.py --overlap > $O/phase_clocks_overlap.txt 2>&1
+IGMC_COMMIT=${IGMC_COMMIT:-unknown} bash tools/profile_round.sh ml_1m > $O/profile_round.log 2>&1
+cp gpurun_out/prof/*.txt gpurun_out/prof/*.json $O/ 2>/dev/null
+python - "$O" <<'PY'
+import json,glob,sys
+for f in sorted(glob.glob(sys.argv[1]+'/bench_*.json')):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1])
+        r=d.get('roofline') or {}
+        print(f.split('/')[-1], round(d['value']), 'sg/s', round(d['ms_per_step']*1e3,2),'us/step', 'frac', r.get('frac'), 'avg_us', r.get('avg_us'), 'traffic', r.get('traffic'), (d.get('cpu_baseline') or {}).get('value'), (d.get('rmse') or {}).get('value'), d.get('dp_structure_us'))
+    except Exception as e:
+        print(f, 'ERR', e, open(f.replace('.json','.err')).read()[-800:])
+PY
+head -12 $O/kernel_stats.txt

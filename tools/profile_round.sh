@@ -10,15 +10,11 @@ export TMPDIR=/tmp
 ROOT=$(pwd)
 BENCH="python $ROOT/bench.py --config $CFG --steps 100 --warmup 10 --no-cpu-baseline --profile-steps 0 --rmse-links 0 --dp-steps 0"
 cd /tmp
-# Every pass below runs with IGMC_FREE_RUN=0 (the default anyway) (fork / join per step): counter collection serialises the dispatches, which
-# the free-running prefetch (two chains of one graph that wait for each other on the device) cannot survive, and under the
-# tracer its chains can fall into lock-step (profiles/r02_step_timeline.txt).  Same kernels either way.
-export IGMC_FREE_RUN=0
 # 1. kernel trace (graph replay + overlap)
 timeout 300 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/kt -- $BENCH > $ROOT/$OUT/kt.log 2>&1
 { echo "# commit ${IGMC_COMMIT:-unknown}; rocprofv3 --kernel-trace --stats -- $BENCH"; python $ROOT/tools/rocprof_summary.py $ROOT/$OUT/kt; } > $ROOT/$OUT/kernel_stats.txt 2>&1
-# 2. PMC passes (own runs, kernel-trace only; rocprofv3 serialises the dispatches while it collects counters -- so the
-#    free-running prefetch, whose chains wait for each other inside a graph, is switched off for them: same kernels)
+# 2. PMC passes (own runs, kernel-trace only; rocprofv3 serialises the dispatches while it collects counters -- the grouped
+#    step graph has no device-side waits between its two chains, so that changes timing only)
 PB="python $ROOT/bench.py --config $CFG --steps 40 --warmup 10 --no-cpu-baseline --profile-steps 0 --rmse-links 0 --dp-steps 0"
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT -d $ROOT/$OUT/pmc1 -- $PB > $ROOT/$OUT/pmc1.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $ROOT/$OUT/pmc2 -- $PB > $ROOT/$OUT/pmc2.log 2>&1
