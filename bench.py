@@ -514,8 +514,15 @@ def main():
         te = MyDataset('data/bench_test', A, (te_u[:m], te_v[:m]), te_l[:m], 1, 1.0, cfg['mnph'], None, None,
                        class_values, device=local, seed=1)
         model.eval()
-        val = eval_rmse(model, DataLoader(te, BATCH, shuffle=False), dev)
-        rmse = dict(value=val, test_links=m, checkpoint='seed-1 init + %d optimisation steps of this run' % state['i'])
+        tl = DataLoader(te, BATCH, shuffle=False)
+        val = eval_rmse(model, tl, dev)
+        torch.cuda.synchronize()
+        te0 = time.perf_counter()
+        val2 = eval_rmse(model, tl, dev)              # (the second evaluation replays the captured graph from its first step)
+        te1 = time.perf_counter()
+        rmse = dict(value=val, test_links=m, checkpoint='seed-1 init + %d optimisation steps of this run' % state['i'],
+                    repeat_identical=bool(val == val2), eval_subgraphs_per_s=m * world / (te1 - te0),
+                    eval_path='EvalGraph (train_eval.eval_loss: forward + squared-error accumulation per step, grouped pipeline)')
         if rank == 0 and want_cpu and not args.dgcnn_rs:
             from oracle import pyg_ref                   # checker
             mo = min(200, m)

@@ -184,6 +184,8 @@ class GroupPipeline(object):
 
 class StepGraph(GroupPipeline):
     """Runs training steps of ``batch_size`` links of ``dataset`` through the fused path (HIP backend of the pipeline)."""
+    SLOT = 'stepgraph'          # name of the arenas in the dataset's arena table
+    TRAINING = True             # edge dropout drawn behind every extraction, gradient exchange under data parallelism
 
     def __init__(self, model, optimizer, dataset, batch_size, ARR, use_graph=None, overlap=None, group=None):
         self.model, self.opt, self.ds = model, optimizer, dataset
@@ -215,7 +217,7 @@ class StepGraph(GroupPipeline):
         self.loss = torch.zeros(2, dtype=torch.float32, device=self.dev)
         self.total = torch.zeros(1, dtype=torch.float64, device=self.dev)
         # the multi-GPU step (gradient kernels -> all-reduce -> Adam launch) can be forced on one GPU to test it
-        self.dp_path = self.world > 1 or os.environ.get('IGMC_FORCE_DP_PATH', '0') == '1'
+        self.dp_path = self.TRAINING and (self.world > 1 or os.environ.get('IGMC_FORCE_DP_PATH', '0') == '1')
         self.side = torch.cuda.Stream(device=self.dev) if overlap else None
         # gradient exchange: the library's own RCCL communicator (igmc_allreduce_grads), enqueued on the step's stream
         self.comm = parallel.grad_comm(self.lib, self.dev.index if self.dev.index is not None else 0) if self.dp_path else None
@@ -225,7 +227,7 @@ class StepGraph(GroupPipeline):
         """Arena i of the set of group parity q."""
         from .util_functions import DeviceBatch
         while len(self.sets[q]) <= i:
-            a = self.ds.arena(self.B, slot='stepgraph%d.%d' % (q, len(self.sets[q])))
+            a = self.ds.arena(self.B, slot='%s%d.%d' % (self.SLOT, q, len(self.sets[q])))
             self.sets[q].append(a)
             if self.ws is None:
                 probe = DeviceBatch(self.ds, a, self.B, self.perm, 0)
@@ -276,7 +278,7 @@ class StepGraph(GroupPipeline):
         else:
             arena.extract(self.ds.link_u.data_ptr(), self.ds.link_v.data_ptr(), self.ds.link_y.data_ptr(),
                           self.perm.data_ptr(), sel, B, self.ds.sample_ratio, self.ds.seed, 0, st)
-        if m.adj_dropout > 0:
+        if self.TRAINING and m.adj_dropout > 0:
             arena.edge_dropout(m.adj_dropout, m.force_undirected, m.seed, sel, st)
 
     def _chunk(self):
@@ -318,7 +320,7 @@ class StepGraph(GroupPipeline):
                 break
             bs.extract(n, self.ds.link_u.data_ptr(), self.ds.link_v.data_ptr(), self.ds.link_y.data_ptr(),
                        self.perm.data_ptr(), q | (i0 << 1), self.B, self.ds.sample_ratio, self.ds.seed,
-                       drop_p=m.adj_dropout if m.adj_dropout > 0 else 0.0, force_undirected=m.force_undirected,
+                       drop_p=m.adj_dropout if (self.TRAINING and m.adj_dropout > 0) else 0.0, force_undirected=m.force_undirected,
                        drop_seed=m.seed, stream=st)
             i0 += n
         return True
@@ -329,9 +331,9 @@ class StepGraph(GroupPipeline):
         self.perm[:n].copy_(perm.to(dtype=torch.int32), non_blocking=False)
         wrap = torch.arange(self.pad, device=self.dev) % max(n, 1)
         self.perm[n:n + self.pad].copy_(self.perm[:max(n, 1)].index_select(0, wrap))
-        g = self.opt.param_groups[0]
-        w = _ctrl_words(self.model._step + 1, epoch if self.ds.dynamic else 0, self.opt.t + 1, self.B, self.M, g['lr'],
-                        g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'])
+        g = self.opt.param_groups[0] if self.opt is not None else dict(lr=0.0, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+        w = _ctrl_words(self.model._step + 1, epoch if self.ds.dynamic else 0, (self.opt.t if self.opt is not None else 0) + 1,
+                        self.B, self.M, g['lr'], g['betas'][0], g['betas'][1], g['eps'], g['weight_decay'])
         self.ctrl.copy_(torch.from_numpy(w))
         self.total.zero_()
         self._reset_epoch(n)
@@ -521,3 +523,39 @@ class StepGraph(GroupPipeline):
                 what.append('a step trained on edge-dropout draws keyed by another batch')
             raise RuntimeError('device-side step control: %s (sync_err=%d); results of the affected steps are invalid'
                                % ('; '.join(what) or 'error', err))
+
+
+class EvalGraph(StepGraph):
+    """``eval_loss`` (reference ``train_eval.py:182-199``) through the same grouped pipeline: a step = forward of a batch +
+    accumulation of its squared errors + tick; the next group's batches are extracted meanwhile (no edge dropout, no
+    gradient exchange).  Same kernels on the same batches in the same order as the eager loop: the sums are bit-identical."""
+    SLOT = 'evalgraph'
+    TRAINING = False
+
+    def __init__(self, model, dataset, batch_size, use_graph=None, overlap=None, group=None):
+        StepGraph.__init__(self, model, None, dataset, batch_size, 0.0, use_graph=use_graph, overlap=overlap, group=group)
+        if self.sp is not None:
+            raise NotImplementedError('the sort-pool family evaluates through its own forward (train_eval.eval_loss)')
+        self.acc = torch.zeros(2, dtype=torch.float64, device=self.dev)
+
+    def _enqueue_step(self, arena, B):
+        m, st = self.model, torch.cuda.current_stream().cuda_stream
+        self.ws.forward(m.flat_parameters().data_ptr(), arena, self.out.data_ptr(), training=False,
+                        multiply_by=float(m.multiply_by), stream=st)
+        self.ws.sse_accumulate(self.out.data_ptr(), arena, self.acc.data_ptr(), stream=st)
+        self.lib.call('igmc_ctrl_tick', C.c_void_p(self.ctrl.data_ptr()), C.c_void_p(st))
+
+    def _count(self, n):
+        pass
+
+    def run(self, perm, epoch):
+        """Sum of squared errors and link count over ``perm`` (this rank's positions): device float64[2]."""
+        self.acc.zero_()
+        self.begin_epoch(perm, epoch)
+        n = self.n_links
+        self.steps(n // self.B)
+        if n % self.B:
+            self.step(n % self.B)
+        self.detach()
+        self.check()
+        return self.acc

@@ -22,7 +22,7 @@ import torch.nn.functional as F
 
 from . import _lib, engine, parallel
 from .models import IGMC
-from .stepgraph import StepGraph
+from .stepgraph import EvalGraph, StepGraph
 from .util_functions import DeviceBatch
 
 device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
@@ -256,6 +256,21 @@ def eval_loss(model, loader, device, regression=False, show_progress=False):
     if not regression:
         raise NotImplementedError('only the regression objective (what the reference runs) is implemented')
     flat = model.flat_parameters()
+    nb = loader._n_local() // loader.batch_size
+    if not hasattr(model, 'forward_into') and nb >= 8 and os.environ.get('IGMC_NO_EVAL_GRAPH', '0') != '1':
+        # the same grouped pipeline as training: forward + squared-error accumulation per step, extraction of the next
+        # group beside it, pairs of groups replayed from a hipGraph (bit-identical to the loop below)
+        eg = getattr(loader, '_evalgraph', None)
+        if eg is None or eg.model is not model:
+            if eg is not None:
+                eg.detach()
+            eg = EvalGraph(model, loader.dataset, loader.batch_size, group=min(32, max(1, nb // 2)))
+            loader._evalgraph = eg
+        acc = eg.run(loader.epoch_positions(), loader.epoch).clone()
+        _check_workspaces(model)
+        parallel.all_reduce_sum_(acc)
+        sse, cnt = acc.tolist()
+        return sse / max(cnt, 1.0)
     acc = torch.zeros(2, dtype=torch.float64, device=flat.device)
     out = None
     for data in loader:

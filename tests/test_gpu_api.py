@@ -582,3 +582,37 @@ print('captured all-reduce ok')
     r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode()
     assert r.returncode == 0 and 'captured all-reduce ok' in out, out[-3000:]
+
+
+def test_eval_through_the_grouped_pipeline_equals_the_eager_loop(flix, monkeypatch):
+    """eval_loss (reference train_eval.py:182-199) through EvalGraph -- forward + squared-error accumulation per step, the
+    next group's batches extracted beside it, pairs of groups replayed from a hipGraph -- gives the same sum as the eager
+    batch-by-batch loop, bit for bit; twice in a row (second call replays the captured graph from its first step), on a
+    static (cached) test set and on a dynamic one, with a ragged last batch."""
+    import torch
+    from igmc_amd.models import IGMC
+    from igmc_amd.train_eval import DataLoader, eval_loss
+    from igmc_amd import preprocessing
+    from igmc_amd.util_functions import MyDataset, MyDynamicDataset
+    (_, _, adj, trl, tru, trv, _, _, _, tel, teu, tev, cv) = preprocessing.load_data_monti('douban', testing=True)
+    sets = [MyDataset(None, adj, (teu[:1230], tev[:1230]), tel[:1230], 1, 1.0, 10000, None, None, cv, seed=2),
+            MyDynamicDataset('data/t/evg', adj, (teu[:1230], tev[:1230]), tel[:1230], 1, 1.0, 40, None, None, cv, seed=2)]
+    torch.manual_seed(4)
+    model = IGMC(sets[0], latent_dim=[32, 32, 32, 32], num_relations=len(cv), num_bases=4, regression=True,
+                 adj_dropout=0.2, seed=3).to('cuda')
+    model.reset_parameters()
+    for ds in sets:
+        vals = {}
+        for mode in ('graph', 'eager'):
+            if mode == 'eager':
+                monkeypatch.setenv('IGMC_NO_EVAL_GRAPH', '1')
+            loader = DataLoader(ds, 50, shuffle=False)
+            vals[mode] = [eval_loss(model, loader, 'cuda', regression=True) for _ in range(2)]
+            if mode == 'graph':
+                eg = loader._evalgraph
+                assert eg.graph is not None and eg.M == 12 and eg.steps_done == 2 * 25
+            monkeypatch.delenv('IGMC_NO_EVAL_GRAPH', raising=False)
+        assert vals['graph'][0] == vals['eager'][0], (vals, type(ds).__name__)
+        if not ds.dynamic:            # (a dynamic test set is re-sampled per evaluation: the loader's epoch counter keys it)
+            assert vals['graph'][0] == vals['graph'][1]
+        assert vals['graph'][1] == vals['eager'][1]
