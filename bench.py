@@ -521,7 +521,7 @@ def main():
         val2 = eval_rmse(model, tl, dev)              # (the second evaluation replays the captured graph from its first step)
         te1 = time.perf_counter()
         rmse = dict(value=val, test_links=m, checkpoint='seed-1 init + %d optimisation steps of this run' % state['i'],
-                    repeat_identical=bool(val == val2), eval_subgraphs_per_s=m * world / (te1 - te0),
+                    repeat_identical=bool(val == val2), eval_subgraphs_per_s=m / (te1 - te0),
                     eval_path='EvalGraph (train_eval.eval_loss: forward + squared-error accumulation per step, grouped pipeline)')
         if rank == 0 and want_cpu and not args.dgcnn_rs:
             from oracle import pyg_ref                   # checker
