@@ -305,8 +305,6 @@ extern "C" int igmc_batch_create(const igmc_graph* g, int max_graphs, int hop, i
           M.get(&d.row_ptr, node_cap + 1);
   fail |= M.get(&d.ecr, edge_cap) | M.get(&d.ecode, edge_cap) | M.get(&d.eflag, edge_cap) |
           M.get(&d.edst, edge_cap);
-  d.slot_cap = node_cap + edge_cap / 8 + 16 * (int64_t)Bc;      // >= sum of igmc_row_slots + per-graph padding
-  fail |= M.get(&d.slot_tab, d.slot_cap) | M.get(&d.slot_off, Bc + 1) | M.get(&d.slot_cnt, Bc);
   fail |= M.get(&d.y, Bc) | M.get(&d.totals, 8) | M.get(&d.stamp, 4);
   d.relm = nullptr;
   d.relmT = nullptr;
@@ -795,17 +793,17 @@ static void csr_for_model(const igmc_model* m, const igmc_batch* b, int dense_ca
   G2Layout lay;
   int cs = 1;
   const int rows0 = m->d.R * m->d.L + m->d.L + 1;
-  if (dense_capable_call && rows0 <= 32 && igmc_layer_mode() >= 2 && igmc_g2_eligible(m->d, b->d, b->last_B, &lay, &cs)) return;
+  if (dense_capable_call && rows0 <= 32 && igmc_g2_eligible(m->d, b->d, b->last_B, &lay, &cs)) return;
   // dense per-layer path: it needs the node arrays only, and a lean extraction of such an arena (one with the transposed
   // block) has left them behind (k_emit_nodes in the extraction branch)
-  if (igmc_layer_mode() == 2 && igmc_dl_eligible(m->d, b->d, b->last_B) && b->d.relm && b->last_B > 0) return;
+  if (igmc_dl_eligible(m->d, b->d, b->last_B) && b->d.relm && b->last_B > 0) return;
   ensure_csr(b, stream);
 }
 
 // 1 when the dense per-layer kernels (k_dl_layer) take the conv layers of this arena
 extern "C" int igmc_model_dense_layers(const igmc_model* m, const igmc_batch* b, int B) {
   if (!m || !b) return 0;
-  return (igmc_layer_mode() == 2 && igmc_dl_eligible(m->d, b->d, B)) ? 1 : 0;
+  return (igmc_dl_eligible(m->d, b->d, B)) ? 1 : 0;
 }
 
 extern "C" int igmc_model_dense_path(const igmc_model* m, const igmc_batch* b, int B) {
@@ -813,7 +811,7 @@ extern "C" int igmc_model_dense_path(const igmc_model* m, const igmc_batch* b, i
   G2Layout lay;
   int cs = 1;
   const int rows0 = m->d.R * m->d.L + m->d.L + 1;
-  return (rows0 <= 32 && igmc_layer_mode() >= 2 && m->d.D % 16 == 0 && igmc_g2_eligible(m->d, b->d, B, &lay, &cs)) ? 1 : 0;
+  return (rows0 <= 32 && m->d.D % 16 == 0 && igmc_g2_eligible(m->d, b->d, B, &lay, &cs)) ? 1 : 0;
 }
 
 static int check_fit(igmc_model* m, const igmc_batch* b, std::string* why) {
@@ -1199,7 +1197,6 @@ static int sp_check(igmc_sortpool* sp, const igmc_batch* b, std::string* why) {
   if (!sp) { *why = "null sort-pool workspace"; return 1; }
   if (check_fit(sp->m, b, why)) return 1;
   if (b->d.slot > sp->d.nmax) { *why = "subgraph slots larger than the sort-pool workspace was created for"; return 1; }
-  if (igmc_layer_mode() == 0) { *why = "IGMC_LAYER_MODE=0 has no dense readout gradient"; return 1; }
   return 0;
 }
 

@@ -36,18 +36,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define IGMC_BLOCK 256
 
 // ------------------------------------------------------------------ device views
-#define IGMC_SEG 32             // entries per row segment (two gather chunks)
-#define IGMC_SLOT_EMPTY 0xFFFFFFFFu
-// slots owned by a row of `deg` entries: pow2ceil(min(16, max(1, ceil(deg / 16))))
-__host__ __device__ inline int igmc_row_slots(int deg) {
-  int c = (deg + IGMC_SEG - 1) / IGMC_SEG;
-  if (c < 1) c = 1;
-  if (c > 16) c = 16;
-  int p = 1;
-  while (p < c) p <<= 1;
-  return p;
-}
-
 struct GraphDev {
   int n_users, n_items;
   const int32_t* u_ptr;   // [n_users+1]  CSR  user -> items, rows sorted by (relation, item)
@@ -72,13 +60,6 @@ struct BatchDev {
   int32_t* row_ptr;      // [Ncap+1] dst-sorted CSR over all nodes of the batch
   uint32_t* ecr;         // [Ecap]   source node (batch-global index, 24 bits) | relation id << 24
   uint16_t* ecode;       // [Ecap]   relation * num_labels + label(source)  (layer-0 table index)
-  // row SEGMENTS ("slots") for the edge-balanced layer kernels: a row of d entries is cut into ceil(d/16)
-  // segments (<= 16; the last one takes the remainder) and owns pow2ceil(#segments) consecutive slots of ONE
-  // 16-slot tile (rows are ordered by that size inside their graph, so the packing is exact)
-  uint32_t* slot_tab;    // [slot_cap] row (24 bits) | segment << 24 | (#segments - 1) << 28 ; 0xFFFFFFFF = empty
-  int32_t* slot_off;     // [Bcap+1] first slot of every graph (multiples of 16)
-  int32_t* slot_cnt;     // [Bcap]   slots of every graph (multiple of 16)
-  int64_t slot_cap;
   uint16_t* edst;        // [Ecap]   destination row of the entry, local to its subgraph (flat per-edge passes)
   uint8_t* eflag;        // [Ecap]   bit0: edge col->row kept, bit1: edge row->col kept
   float* y;              // [Bcap]

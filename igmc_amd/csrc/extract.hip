@@ -450,12 +450,11 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_fill(GraphDev G, BatchDev b) {
   const int nn = cu + cv;
   const int stride = gridDim.y * (IGMC_BLOCK / 64);
   const int my_first = blockIdx.y * (IGMC_BLOCK / 64) + wave;
-  int running = 0, nslots = 0;
+  int running = 0;
   for (int base = 0; base < nn; base += IGMC_BLOCK) {
     const int n = base + tid;
     const int s = (n < cu) ? n : cap_u + (n - cu);
     const int deg = (n < nn) ? sd[s] : 0;
-    if (n < nn) nslots += igmc_row_slots(deg);
     int tot;
     const int ex = igmc_block_scan_excl(deg, &tot, sm);
     if (n < nn) {
@@ -470,8 +469,6 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_fill(GraphDev G, BatchDev b) {
     }
     running += tot;
   }
-  nslots = igmc_block_sum_i(nslots, sm);
-  if (blockIdx.y == 0 && tid == 0) b.slot_cnt[g] = (nslots + 15) & ~15;
   __syncthreads();
 
   for (int r = my_first; r < nn; r += stride) {
@@ -658,7 +655,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_emit(BatchDev b) {
   }
   __syncthreads();
   // ---- degrees (one thread per row / column), row pointers, slots of the graph
-  int running = 0, nslots = 0;
+  int running = 0;
   for (int base = 0; base < nn; base += IGMC_BLOCK) {
     const int n = base + tid;
     int deg = 0;
@@ -671,7 +668,6 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_emit(BatchDev b) {
       const int vl = n - cu;
       for (int u = 0; u < cu; ++u) deg += rm[u * ld + vl] != 0;
     }
-    if (n < nn) nslots += igmc_row_slots(deg);
     int tot;
     const int ex = igmc_block_scan_excl(deg, &tot, sm);
     if (n < nn) {
@@ -687,8 +683,6 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_emit(BatchDev b) {
     }
     running += tot;
   }
-  nslots = igmc_block_sum_i(nslots, sm);
-  if (blockIdx.y == 0 && tid == 0) b.slot_cnt[g] = (nslots + 15) & ~15;
   __syncthreads();
   // ---- emission: a row's bytes are read once (<= 4 per lane), then one ballot-compaction pass per relation
   const int stride = gridDim.y * (IGMC_BLOCK / 64);
@@ -780,75 +774,6 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_emit_nodes_set(const BatchDev* _
 
 void igmc_launch_emit_nodes(const BatchDev& b, int B, void* stream) {
   IGMC_PLAUNCH("k_emit_nodes", k_emit_nodes, B, IGMC_BLOCK, 0, stream, b);
-}
-
-// ---------------------------------------------------------------- row segments ("slots") of the batch
-// One workgroup per graph: rows are placed by decreasing slot-group size (16, 8, 4, 2, 1), ties in row order,
-// so that every group is aligned to its own size and never straddles a 16-slot tile.  Deterministic.
-__global__ __launch_bounds__(IGMC_BLOCK) void k_slots(BatchDev b) {
-  __shared__ int sm[16];
-  __shared__ int cbase[5];
-  const int g = blockIdx.x, B = gridDim.x, tid = threadIdx.x;
-  if (b.totals[2]) {            // arena overflow: no batch
-    if (g == 0 && tid == 0) { b.slot_off[0] = 0; b.slot_off[B] = 0; b.totals[6] = 0; }
-    return;
-  }
-  int so = 0, tot = 0;
-  for (int base = 0; base < B; base += IGMC_BLOCK) {
-    const int i = base + tid;
-    const int c = (i < B) ? b.slot_cnt[i] : 0;
-    so += igmc_block_sum_i(i < g ? c : 0, sm);
-    tot += igmc_block_sum_i(c, sm);
-  }
-  if (tid == 0) {
-    b.slot_off[g] = so;
-    if (g == 0) {
-      b.slot_off[B] = tot;
-      b.totals[6] = tot >> 4;
-    }
-  }
-  const int nb = b.node_off[g], N = b.node_off[g + 1] - nb;
-  // pass 1: rows per size class
-  int cnt[5] = {0, 0, 0, 0, 0};
-  for (int base = 0; base < N; base += IGMC_BLOCK) {
-    const int n = base + tid;
-    const int sz = (n < N) ? igmc_row_slots(b.row_ptr[nb + n + 1] - b.row_ptr[nb + n]) : 0;
-#pragma unroll
-    for (int c = 0; c < 5; ++c) cnt[c] += igmc_block_sum_i(sz == (16 >> c) ? 1 : 0, sm);
-  }
-  if (tid == 0) {
-    int p = so;
-    for (int c = 0; c < 5; ++c) {
-      cbase[c] = p;
-      p += cnt[c] * (16 >> c);
-    }
-  }
-  __syncthreads();
-  const int used = cnt[0] * 16 + cnt[1] * 8 + cnt[2] * 4 + cnt[3] * 2 + cnt[4];
-  // pass 2: placement (rank inside the class = number of earlier rows of the class)
-  int run[5] = {0, 0, 0, 0, 0};
-  for (int base = 0; base < N; base += IGMC_BLOCK) {
-    const int n = base + tid;
-    const int deg = (n < N) ? b.row_ptr[nb + n + 1] - b.row_ptr[nb + n] : 0;
-    const int sz = (n < N) ? igmc_row_slots(deg) : 0;
-    int nseg = (deg + IGMC_SEG - 1) / IGMC_SEG;
-    nseg = nseg < 1 ? 1 : (nseg > 16 ? 16 : nseg);
-#pragma unroll
-    for (int c = 0; c < 5; ++c) {
-      const int mine = (sz == (16 >> c)) ? 1 : 0;
-      int t2;
-      const int ex = igmc_block_scan_excl(mine, &t2, sm);
-      if (mine) {
-        const int pos = cbase[c] + (run[c] + ex) * (16 >> c);
-        for (int k = 0; k < sz; ++k)
-          b.slot_tab[pos + k] = (k < nseg) ? ((uint32_t)(nb + n) | ((uint32_t)k << 24) | ((uint32_t)(nseg - 1) << 28))
-                                           : IGMC_SLOT_EMPTY;
-      }
-      run[c] += t2;
-    }
-  }
-  const int end = so + b.slot_cnt[g];
-  for (int p = so + used + tid; p < end; p += IGMC_BLOCK) b.slot_tab[p] = IGMC_SLOT_EMPTY;
 }
 
 // ---------------------------------------------------------------- edge dropout flags
@@ -1063,7 +988,6 @@ void igmc_launch_extract(const GraphDev& g, const BatchDev& b, const int32_t* li
     IGMC_PLAUNCH("k_count", k_count, dim3(B, S), IGMC_BLOCK, smem / 4, stream, g, b);
     IGMC_PLAUNCH("k_fill", k_fill, dim3(B, S), IGMC_BLOCK, smem / 2, stream, g, b);
   }
-  if (igmc_layer_mode() == 3) IGMC_PLAUNCH("k_slots", k_slots, B, IGMC_BLOCK, 0, stream, b);    // row segments (opt-in)
 }
 
 // Extraction (+ edge dropout on the dense blocks) of `count` batches of one group in ONE launch per stage: arenas set[0 ..

@@ -23,7 +23,6 @@
 //     each (blockIdx.y = layer), and loss / epoch-total / control-block tick ride in the Adam kernel.
 #include "model.h"
 #include <stdlib.h>
-#define IGMC_LAYER_MODE_DEFAULT 2
 
 // ---- XCD affinity -------------------------------------------------------------------------------------
 // MI355X has 8 XCDs with private, mutually non-coherent 4 MiB L2s, and workgroup b of a launch runs on XCD
@@ -238,49 +237,6 @@ __device__ __forceinline__ void gather_row(const BatchDev& b, const float* __res
   }
 }
 
-// =================================================================== basis-space gather (layers 1..3)
-// FLAGS: honour edge keep flags; TRANS: use the transposed-edge keep bit (backward);
-// ATTG: additionally accumulate d att via relation runs (needs Y = x @ [basis_0..3]).
-template <bool FLAGS, bool TRANS, bool ATTG>
-__global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_gather(BatchDev b, int R, const float* __restrict__ in,
-                                                              const float* __restrict__ att,
-                                                              float* __restrict__ out,
-                                                              const float* __restrict__ Y,
-                                                              float* __restrict__ gatt_part) {
-  IGMC_DYN_SMEM(smem);
-  float* s_att = (float*)smem;              // [R][4]
-  float* s_gatt = s_att + R * 4;            // [16 groups][R*4]   (ATTG only)
-  for (int i = threadIdx.x; i < R * 4; i += IGMC_BLOCK) s_att[i] = att[i];
-  if (ATTG)
-    for (int i = threadIdx.x; i < 16 * R * 4; i += IGMC_BLOCK) s_gatt[i] = 0.f;
-  __syncthreads();
-  const int N = b.totals[0];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int grp = lane >> 4, t = lane & 15;
-  float* my_gatt = s_gatt + (wave * 4 + grp) * R * 4;
-  for (int i = blockIdx.x * 4 + wave; i < N; i += gridDim.x * 4) {
-    float ax[4], ay[4];
-    gather_row<FLAGS, TRANS, ATTG>(b, in, s_att, my_gatt, Y, i, b.row_ptr[i], b.row_ptr[i + 1], lane, ax, ay);
-    if (grp == 0) {
-#pragma unroll
-      for (int bb = 0; bb < 4; ++bb) {
-        float2 o;
-        o.x = ax[bb];
-        o.y = ay[bb];
-        *(float2*)(out + (size_t)i * 128 + bb * 32 + 2 * t) = o;
-      }
-    }
-  }
-  if (ATTG) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < R * 4; i += IGMC_BLOCK) {
-      float s = 0.f;
-      for (int g = 0; g < 16; ++g) s += s_gatt[g * R * 4 + i];
-      gatt_part[(size_t)blockIdx.x * R * 4 + i] = s;
-    }
-  }
-}
-
 // =================================================================== dense row transform on f32 MFMA
 // OUT[N,NO] = epilogue([A1[N,K1] | A2[N,K2]] @ W[K1+K2, NO]).  One wave = 16 rows x NO columns,
 // v_mfma_f32_16x16x4_f32; W is staged once per block in LDS (pitch NO+4: conflict-free b32 reads).
@@ -361,29 +317,6 @@ __device__ __forceinline__ void dense_body(const BatchDev& b, const float* __res
   }
 }
 
-// h_l = tanh([agg | h_{l-1}] @ [basis_l ; root_l] + bias_l); optionally clears another [N,32] buffer
-__global__ __launch_bounds__(IGMC_BLOCK) void k_dense_fwd(BatchDev b, const float* __restrict__ agg,
-                                                            const float* __restrict__ x,
-                                                            const float* __restrict__ basis,
-                                                            const float* __restrict__ bias, float* __restrict__ out,
-                                                            float* __restrict__ zero_out) {
-  IGMC_DYN_SMEM(smem);
-  dense_body<128, 32, 32, EPI_BIAS_TANH, W_PLAIN>(b, agg, x, basis, nullptr, bias, out, nullptr, nullptr, 0, 0,
-                                                  zero_out, (float*)smem);
-}
-
-// dPre_{l-1} = ([G | dPre_l] @ [basis_l^T ; root_l^T] + readout gradient on target rows) * (1 - h_{l-1}^2)
-__global__ __launch_bounds__(IGMC_BLOCK) void k_dense_bwd(BatchDev b, const float* __restrict__ gagg,
-                                                            const float* __restrict__ dcur,
-                                                            const float* __restrict__ basis,
-                                                            const float* __restrict__ root, float* __restrict__ dnext,
-                                                            const float* __restrict__ xin,
-                                                            const float* __restrict__ gfeat, int D, int rlayer) {
-  IGMC_DYN_SMEM(smem);
-  dense_body<128, 32, 32, EPI_BWD, W_BWD_T>(b, gagg, dcur, basis, root, nullptr, dnext, xin, gfeat, D, rlayer,
-                                            nullptr, (float*)smem);
-}
-
 // Y_l = h_{l-1} @ [basis_0|..|basis_3] for l = 1..3 in ONE launch (blockIdx.y = l-1)
 __global__ __launch_bounds__(IGMC_BLOCK) void k_dense_y_all(BatchDev b, ModelDev m, const float* __restrict__ P) {
   IGMC_DYN_SMEM(smem);
@@ -393,125 +326,14 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_dense_y_all(BatchDev b, ModelDev
 }
 
 // =================================================================== fused R-GCN layer (gather + dense)
-// One 1024-thread workgroup per tile of 16 rows: wave w gathers row w of the tile in basis space straight into
-// an LDS tile [16][A(128) | self(32)], then 8 waves multiply the tile with the layer's [basis ; root] operand
-// on f32 MFMA (2 column tiles x 4 K-slices; B fragments are loaded ONCE per workgroup into registers) and the
-// epilogue (bias + tanh, or the tanh' / readout-gradient backward epilogue) writes the 128-byte output rows.
-// Forward never materialises the 512-byte basis-space rows in HBM; backward writes them once (the weight
-// gradient needs them).  Removes one launch per layer and direction (each >= 4.7 us on this part).
+// One 256-thread workgroup per tile of 16 rows: wave w walks rows 4w..4w+3 of the tile in basis space straight into an LDS
+// tile [16][A(128) | self(32)], ONE 16-lane group per row (all 2400 waves of an ml_1m batch are resident at once), then
+// the 4 waves multiply the tile with the layer's [basis ; root] operand on f32 MFMA (2 column tiles x 2 K-slices of 80,
+// 20 MFMAs each) and the epilogue (bias + tanh, or the tanh' / readout-gradient backward epilogue) writes the 128-byte
+// output rows.  Forward never materialises the 512-byte basis-space rows in HBM; backward writes them once (the weight
+// gradient needs them).  (Rounds 1-2 kept three more formulations selectable -- separate gather + dense kernels,
+// 16-wave tiles, tiles of row segments: all measured slower, removed in round 3.)
 #define IGMC_TP 164
-template <bool FLAGS, bool BWD>
-__global__ __launch_bounds__(1024) void k_rgcn_layer(BatchDev b, ModelDev m, const float* __restrict__ P, int l,
-                                                      float* __restrict__ zero_out) {
-  IGMC_DYN_SMEM(smem);
-  const int R = m.R;
-  float* tile = (float*)smem;               // [16][IGMC_TP]
-  float* red = tile + 16 * IGMC_TP;         // [4 k-slices][2 col tiles][64 lanes * 4]
-  float* s_att = red + 2048;                // [R][4]
-  float* s_gatt = s_att + R * 4;            // BWD: [64 groups][R*4]
-  const float* __restrict__ in = BWD ? m.dpre[l] : m.h[l - 1];
-  const float* __restrict__ Yl = BWD ? m.Y[l - 1] : nullptr;
-  const float* att = P + m.off_att[l];
-  const float* basis = P + m.off_basis[l];
-  const float* root = P + m.off_root[l];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int grp = lane >> 4, t = lane & 15;
-  const int li = lane & 15, kq = lane >> 4;
-  for (int i = tid; i < R * 4; i += 1024) s_att[i] = att[i];
-  if (BWD)
-    for (int i = tid; i < 64 * R * 4; i += 1024) s_gatt[i] = 0.f;
-  // B fragments of this wave's (column tile, K-slice), loaded once: k = ks*40 + 4j + kq, n = nt*16 + li
-  const int nt = wave & 1, ks = (wave >> 1) & 3;
-  float bw[10];
-  if (wave < 8) {
-#pragma unroll
-    for (int j = 0; j < 10; ++j) {
-      const int k = ks * 40 + 4 * j + kq, n = nt * 16 + li;
-      if (!BWD) bw[j] = basis[k * 32 + n];                 // [basis ; root] contiguous: rows 0..159
-      else bw[j] = (k < 128) ? basis[((k >> 5) * 32 + n) * 32 + (k & 31)] : root[n * 32 + (k - 128)];
-    }
-  }
-  __syncthreads();
-  const int N = b.totals[0];
-  float* my_gatt = s_gatt + (wave * 4 + grp) * R * 4;
-  for (int tl = blockIdx.x; tl * 16 < N; tl += gridDim.x) {
-    const int i = tl * 16 + wave;
-    // ---- phase 1: one row per wave -> LDS tile
-    if (i < N) {
-      float ax[4], ay[4];
-      gather_row<FLAGS, BWD, BWD>(b, in, s_att, my_gatt, Yl, i, b.row_ptr[i], b.row_ptr[i + 1], lane, ax, ay);
-      if (grp == 0) {
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-          tile[wave * IGMC_TP + bb * 32 + 2 * t] = ax[bb];
-          tile[wave * IGMC_TP + bb * 32 + 2 * t + 1] = ay[bb];
-          if (BWD) {
-            float2 o;
-            o.x = ax[bb];
-            o.y = ay[bb];
-            *(float2*)(m.gagg[l - 1] + (size_t)i * 128 + bb * 32 + 2 * t) = o;
-          }
-        }
-        const float2 xs = *(const float2*)(in + (size_t)i * 32 + 2 * t);
-        tile[wave * IGMC_TP + 128 + 2 * t] = xs.x;
-        tile[wave * IGMC_TP + 128 + 2 * t + 1] = xs.y;
-      }
-    } else if (grp == 0) {
-#pragma unroll
-      for (int q = 0; q < 5; ++q) {
-        tile[wave * IGMC_TP + q * 32 + 2 * t] = 0.f;
-        tile[wave * IGMC_TP + q * 32 + 2 * t + 1] = 0.f;
-      }
-    }
-    __syncthreads();
-    // ---- phase 2: [16 x 160] @ [160 x 32] on MFMA, 10 k-steps per wave
-    if (wave < 8) {
-      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < 10; ++j) {
-        const float a = tile[li * IGMC_TP + ks * 40 + 4 * j + kq];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[j], acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) red[(ks * 2 + nt) * 256 + lane * 4 + rr] = acc[rr];
-    }
-    __syncthreads();
-    // ---- phase 3: combine the 4 K-slices + epilogue (512 outputs)
-    if (tid < 512) {
-      const int ont = tid >> 8, idx = tid & 255, ol = idx >> 2, rr = idx & 3;
-      const float v0 = (red[(0 * 2 + ont) * 256 + idx] + red[(1 * 2 + ont) * 256 + idx]) +
-                       (red[(2 * 2 + ont) * 256 + idx] + red[(3 * 2 + ont) * 256 + idx]);
-      const int orow = tl * 16 + (ol >> 4) * 4 + rr, n = ont * 16 + (ol & 15);
-      if (orow < N) {
-        float v = v0;
-        if (!BWD) {
-          v = tanhf(v + P[m.off_bias[l] + n]);
-          m.h[l][(size_t)orow * 32 + n] = v;
-          if (zero_out) zero_out[(size_t)orow * 32 + n] = 0.f;
-        } else {
-          const int lab = b.node_label[orow];
-          if (m.dcat[l - 1]) v += m.dcat[l - 1][(size_t)orow * 32 + n];
-          else if (lab < 2) v += m.gfeat[(size_t)b.node_graph[orow] * m.D + lab * 128 + (l - 1) * 32 + n];
-          const float xv = m.h[l - 1][(size_t)orow * 32 + n];
-          m.dpre[l - 1][(size_t)orow * 32 + n] = v * (1.f - xv * xv);
-        }
-      }
-    }
-    __syncthreads();
-  }
-  if (BWD) {
-    float* gp = m.gatt_part + ((size_t)(l - 1) * IGMC_GATHER_BLOCKS + blockIdx.x) * R * 4;
-    for (int i = tid; i < R * 4; i += 1024) {
-      float sacc = 0.f;
-      for (int g = 0; g < 64; ++g) sacc += s_gatt[g * R * 4 + i];
-      gp[i] = sacc;
-    }
-  }
-}
-
-// Variant with 256-thread workgroups: wave w walks rows 4w..4w+3 of the tile, ONE 16-lane group per row (all
-// 2400 waves of an ml_1m batch are resident at once), then the 4 waves share the MFMA phase
-// (2 column tiles x 2 K-slices of 80, 20 MFMAs each).
 template <bool FLAGS, bool BWD>
 __global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_layer4(BatchDev b, ModelDev m, const float* __restrict__ P, int l,
                                                              float* __restrict__ zero_out) {
@@ -620,167 +442,6 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_layer4(BatchDev b, ModelDev
       const float v0 = red[(0 * 2 + ont) * 256 + idx] + red[(1 * 2 + ont) * 256 + idx];
       const int orow = trow0 + (ol >> 4) * 4 + rr, n = ont * 16 + (ol & 15);
       if (orow < seg.hi) {
-        float v = v0;
-        if (!BWD) {
-          v = tanhf(v + epi_b[h2]);
-          m.h[l][(size_t)orow * 32 + n] = v;
-          if (zero_out) zero_out[(size_t)orow * 32 + n] = 0.f;
-        } else {
-          const int lab = epi_lab[h2];
-          if (m.dcat[l - 1]) v += m.dcat[l - 1][(size_t)orow * 32 + n];
-          else if (lab < 2) v += m.gfeat[(size_t)epi_g[h2] * m.D + lab * 128 + (l - 1) * 32 + n];
-          const float xv = epi_x[h2];
-          m.dpre[l - 1][(size_t)orow * 32 + n] = v * (1.f - xv * xv);
-        }
-      }
-    }
-    __syncthreads();
-  }
-  if (BWD) {
-    float* gp = m.gatt_part + ((size_t)(l - 1) * IGMC_GATHER_BLOCKS + blockIdx.x) * R * 4;
-    for (int i = tid; i < R * 4; i += IGMC_BLOCK) {
-      float sacc = 0.f;
-      for (int g = 0; g < 16; ++g) sacc += s_gatt[g * R * 4 + i];
-      gp[i] = sacc;
-    }
-  }
-}
-
-// Edge-balanced variant (IGMC_LAYER_MODE=3, opt-in): the 16 tile slots are row SEGMENTS of at most 16 entries (slot table of the
-// batch, built by k_slots), so every 16-lane group does exactly one chunk of gather work per tile -- the 2 us per
-// extra sequential chunk of the ~100-entry rows (profiles/: 23.7 us -> 11.5 us with rows cut at 16 entries) is
-// gone.  The segments of a row sit in consecutive slots of the SAME tile; they are summed in LDS before the MFMA
-// phase, and only the row's first slot takes part in the epilogue.
-__device__ __forceinline__ XcdSeg igmc_xcd_slot_segment(const BatchDev& b) {
-  XcdSeg s;
-  const int B = b.totals[3];
-  const int x = blockIdx.x & 7;
-  s.j = blockIdx.x >> 3;
-  s.nj = (gridDim.x + 7 - x) >> 3;
-  s.lo = b.slot_off[(x * B) >> 3];
-  s.hi = b.slot_off[((x + 1) * B) >> 3];
-  return s;
-}
-
-template <bool FLAGS, bool BWD>
-__global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_layer_s(BatchDev b, ModelDev m, const float* __restrict__ P, int l,
-                                                              float* __restrict__ zero_out) {
-  IGMC_DYN_SMEM(smem);
-  const int R = m.R;
-  float* tile = (float*)smem;               // [16][IGMC_TP]
-  float* red = tile + 16 * IGMC_TP;         // [2 k-slices][2 col tiles][64 lanes * 4]
-  float* s_att = red + 1024;                // [R][4]
-  float* s_gatt = s_att + R * 4;            // BWD: [16 groups][R*4]
-  const float* __restrict__ in = BWD ? m.dpre[l] : m.h[l - 1];
-  const float* __restrict__ Yl = BWD ? m.Y[l - 1] : nullptr;
-  const float* att = P + m.off_att[l];
-  const float* basis = P + m.off_basis[l];
-  const float* root = P + m.off_root[l];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int grp = lane >> 4, t = lane & 15;
-  const int li = lane & 15, kq = lane >> 4;
-  for (int i = tid; i < R * 4; i += IGMC_BLOCK) s_att[i] = att[i];
-  if (BWD)
-    for (int i = tid; i < 16 * R * 4; i += IGMC_BLOCK) s_gatt[i] = 0.f;
-  const int nt = wave & 1, ks = wave >> 1;
-  float bw[20];
-#pragma unroll
-  for (int j = 0; j < 20; ++j) {
-    const int k = ks * 80 + 4 * j + kq, n = nt * 16 + li;
-    if (!BWD) bw[j] = basis[k * 32 + n];
-    else bw[j] = (k < 128) ? basis[((k >> 5) * 32 + n) * 32 + (k & 31)] : root[n * 32 + (k - 128)];
-  }
-  __syncthreads();
-  const int trow = wave * 4 + grp;            // slot of the tile owned by this 16-lane group
-  float* my_gatt = s_gatt + trow * R * 4;
-  const XcdSeg seg = igmc_xcd_slot_segment(b);
-  for (int tl = seg.j; seg.lo + tl * 16 < seg.hi; tl += seg.nj) {
-    const int base = seg.lo + tl * 16;        // first slot of the tile
-    const uint32_t ent = b.slot_tab[base + trow];
-    const bool live = ent != IGMC_SLOT_EMPTY;
-    const int i = (int)(ent & 0xFFFFFFu), sg = (int)((ent >> 24) & 15u), nseg = (int)(ent >> 28) + 1;
-    // everything that does not depend on the gather is requested FIRST: row bounds, the self row and the epilogue
-    // operands of this thread's two outputs
-    int beg = 0, end = 0;
-    float2 xs;
-    xs.x = 0.f;
-    xs.y = 0.f;
-    if (live) {
-      const int rb = b.row_ptr[i], re = b.row_ptr[i + 1];
-      beg = rb + sg * IGMC_SEG;
-      end = (sg == 15 || beg + IGMC_SEG > re) ? re : beg + IGMC_SEG;
-      if (sg == 0) xs = *(const float2*)(in + (size_t)i * 32 + 2 * t);
-    }
-    float epi_x[2] = {0.f, 0.f}, epi_b[2] = {0.f, 0.f};
-    int epi_lab[2] = {9, 9}, epi_g[2] = {0, 0}, epi_row[2] = {-1, -1};
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-      const int o = tid + h2 * IGMC_BLOCK;
-      const int ol = (o & 255) >> 2, rr = o & 3;
-      const int srow = (ol >> 4) * 4 + rr, n = (o >> 8) * 16 + (ol & 15);
-      const uint32_t e2 = b.slot_tab[base + srow];
-      if (e2 != IGMC_SLOT_EMPTY && ((e2 >> 24) & 15u) == 0u) {
-        const int orow = (int)(e2 & 0xFFFFFFu);
-        epi_row[h2] = orow;
-        if (BWD) {
-          epi_lab[h2] = b.node_label[orow];
-          epi_g[h2] = b.node_graph[orow];
-          epi_x[h2] = m.h[l - 1][(size_t)orow * 32 + n];
-        }
-      }
-      if (!BWD) epi_b[h2] = P[m.off_bias[l] + n];
-    }
-    {
-      float ax[4] = {0.f, 0.f, 0.f, 0.f}, ay[4] = {0.f, 0.f, 0.f, 0.f};
-      if (live) gather_row<FLAGS, BWD, BWD, 1>(b, in, s_att, my_gatt, Yl, i, beg, end, lane, ax, ay);
-#pragma unroll
-      for (int bb = 0; bb < 4; ++bb) {
-        tile[trow * IGMC_TP + bb * 32 + 2 * t] = ax[bb];
-        tile[trow * IGMC_TP + bb * 32 + 2 * t + 1] = ay[bb];
-      }
-      tile[trow * IGMC_TP + 128 + 2 * t] = xs.x;
-      tile[trow * IGMC_TP + 128 + 2 * t + 1] = xs.y;
-    }
-    __syncthreads();
-    // the first slot of a row adds the row's other segments (same tile), and in the backward pass writes the
-    // basis-space row the weight gradient needs
-    if (live && sg == 0) {
-      float2 a2[4];
-#pragma unroll
-      for (int bb = 0; bb < 4; ++bb) a2[bb] = *(const float2*)(tile + trow * IGMC_TP + bb * 32 + 2 * t);
-      for (int k = 1; k < nseg; ++k) {
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-          const float2 v = *(const float2*)(tile + (trow + k) * IGMC_TP + bb * 32 + 2 * t);
-          a2[bb].x += v.x;
-          a2[bb].y += v.y;
-        }
-      }
-#pragma unroll
-      for (int bb = 0; bb < 4; ++bb) {
-        if (nseg > 1) *(float2*)(tile + trow * IGMC_TP + bb * 32 + 2 * t) = a2[bb];
-        if (BWD) *(float2*)(m.gagg[l - 1] + (size_t)i * 128 + bb * 32 + 2 * t) = a2[bb];
-      }
-    }
-    __syncthreads();
-    {
-      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < 20; ++j) {
-        const float a = tile[li * IGMC_TP + ks * 80 + 4 * j + kq];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw[j], acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) red[(ks * 2 + nt) * 256 + lane * 4 + rr] = acc[rr];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2) {
-      const int o = tid + h2 * IGMC_BLOCK;
-      const int ont = o >> 8, idx = o & 255, ol = idx >> 2;
-      const float v0 = red[(0 * 2 + ont) * 256 + idx] + red[(1 * 2 + ont) * 256 + idx];
-      const int orow = epi_row[h2], n = ont * 16 + (ol & 15);
-      if (orow >= 0) {
         float v = v0;
         if (!BWD) {
           v = tanhf(v + epi_b[h2]);
@@ -2407,13 +2068,6 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_adam(float* __restrict__ p, cons
 // =================================================================== host launch sequences
 #include "launch.h"
 
-// R-GCN layer formulation: 0 = gather kernel + dense kernel, 1 = fused (16 waves / tile), 2 = fused (4 waves / tile),
-// 3 = fused, tiles of row segments (edge-balanced; measured slower: one more dependent hop and 2x the tiles)
-int igmc_layer_mode() {
-  const char* e = getenv("IGMC_LAYER_MODE");        // read on every call: tests switch it per case
-  return e ? atoi(e) : IGMC_LAYER_MODE_DEFAULT;
-}
-
 // grid for row-parallel kernels: enough workgroups for the capacity, capped, and a multiple of 8 (>= 8) so
 // that every XCD residue owns workgroups (XCD-affine segments, see igmc_xcd_segment)
 static inline int igmc_rows_grid(int cap_rows, int rows_per_block, int max_blocks) {
@@ -2434,27 +2088,13 @@ static inline int igmc_xcd_grid(const ModelDev& m, int B, int rows_per_block, in
   return (int)(g < 8 ? 8 : g);
 }
 
-// grid for the slot-tile kernels: 8 x (tiles of the largest XCD segment, estimated at 2.25 slots per node; a
-// larger batch just makes the workgroups loop)
-static inline int igmc_slot_grid(const ModelDev& m, int B, int max_blocks) {
-  const int slot = (m.node_cap + m.graph_cap - 1) / m.graph_cap;
-  const long tiles_per_graph = ((long)slot * 9 / 4 + 15) / 16;
-  long g = 8 * (long)((B + 7) / 8) * tiles_per_graph;
-  {
-    const char* e = getenv("IGMC_SLOT_GRID");       // tuning hook
-    if (e && atoi(e) >= 8) g = atoi(e) & ~7;
-  }
-  if (g > max_blocks) g = max_blocks & ~7;
-  return (int)(g < 8 ? 8 : g);
-}
-
 void igmc_launch_forward(const ModelDev& m, const ModelAux& ax, const BatchDev& b, const float* P, int B, int training,
                          int use_flags, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
                          float* out, void* stream) {
   {
     G2Layout lay2;
     int cs2 = 1;
-    if (!training && igmc_layer_mode() >= 2 && m.R * m.L + m.L + 1 <= 32 && igmc_g2_eligible(m, b, B, &lay2, &cs2)) {
+    if (!training && m.R * m.L + m.L + 1 <= 32 && igmc_g2_eligible(m, b, B, &lay2, &cs2)) {
       igmc_launch_graph_step2(m, b, P, B, 0, use_flags, lay2, cs2, nullptr, seed, step, mult, 0.f, out, stream);
       return;
     }
@@ -2483,7 +2123,7 @@ void igmc_launch_conv_forward(const ModelDev& m, const BatchDev& b, const float*
   const int g64 = igmc_rows_grid(m.node_cap, 64, 512);
   // slots of 129..256 nodes a side with a dense block: every conv layer on the matrix cores (graphstep2.hip, k_dl_layer0 /
   // k_dl_layer) from the blocks alone -- no edge list is read
-  const int dl = igmc_layer_mode() == 2 && igmc_dl_eligible(m, b, B);
+  const int dl = igmc_dl_eligible(m, b, B);
   if (dl) {
     igmc_launch_g2_compose(m, P, stream);                 // the step's weight images + layer-0 table
     igmc_launch_dl_layer0(m, b, B, training, use_flags, stream);
@@ -2496,35 +2136,15 @@ void igmc_launch_conv_forward(const ModelDev& m, const BatchDev& b, const float*
   }
   const size_t ysz = (size_t)32 * (128 + 4) * sizeof(float);
   const int gt = igmc_xcd_grid(m, B, 16, 2048);                        // fused layer: 16 rows per workgroup
-  const size_t fsm = (size_t)(16 * IGMC_TP + 2048 + m.R * 4) * sizeof(float);
-  const int mode = igmc_layer_mode();
-  const size_t gs = (size_t)(m.R * 4) * sizeof(float);
-  const size_t ds = (size_t)IGMC_KCAT * (32 + 4) * sizeof(float);
   const size_t fsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4) * sizeof(float);
   for (int l = 1; l < 4; ++l) {
     // the top layer's launch also clears dPre_3 (only its target rows are written by the head backward)
     float* zo = (training && l == 3) ? m.dpre[3] : nullptr;
     if (dl) {
       igmc_launch_dl_layer(m, b, P, B, l, 0, use_flags, zo, stream);
-    } else if (mode == 1) {
-      if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer<true, false>), gt, 1024, fsm, stream, b, m, P, l, zo);
-      else IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer<false, false>), gt, 1024, fsm, stream, b, m, P, l, zo);
-    } else if (mode == 2) {
+    } else {
       if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer4<true, false>), gt, IGMC_BLOCK, fsm4, stream, b, m, P, l, zo);
       else IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer4<false, false>), gt, IGMC_BLOCK, fsm4, stream, b, m, P, l, zo);
-    } else if (mode == 3) {
-      const int gs3 = igmc_slot_grid(m, B, 2048);
-      if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer_s<true, false>), gs3, IGMC_BLOCK, fsm4, stream, b, m, P, l, zo);
-      else IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer_s<false, false>), gs3, IGMC_BLOCK, fsm4, stream, b, m, P, l, zo);
-    } else {
-      if (use_flags)
-        IGMC_PLAUNCH("k_rgcn_gather_fwd", (k_rgcn_gather<true, false, false>), g16, IGMC_BLOCK, gs, stream, b, m.R,
-                     (const float*)m.h[l - 1], P + m.off_att[l], m.agg, (const float*)nullptr, (float*)nullptr);
-      else
-        IGMC_PLAUNCH("k_rgcn_gather_fwd", (k_rgcn_gather<false, false, false>), g16, IGMC_BLOCK, gs, stream, b, m.R,
-                     (const float*)m.h[l - 1], P + m.off_att[l], m.agg, (const float*)nullptr, (float*)nullptr);
-      IGMC_PLAUNCH("k_dense_fwd", k_dense_fwd, g64, IGMC_BLOCK, ds, stream, b, (const float*)m.agg,
-                   (const float*)m.h[l - 1], P + m.off_basis[l], P + m.off_bias[l], m.h[l], zo);
     }
   }
   // training: the products Y_l = h_{l-1} @ [basis_0 | .. | basis_3] the backward's att gradient reads
@@ -2569,37 +2189,15 @@ void igmc_launch_conv_backward(const ModelDev& m, const BatchDev& b, const float
   const int rows0 = m.R * m.L + m.L + 1;
   const int l0_mfma = rows0 <= 32;
   const int gt = igmc_xcd_grid(m, B, 16, 2048);
-  const size_t bsm = (size_t)(16 * IGMC_TP + 2048 + m.R * 4 + 64 * m.R * 4) * sizeof(float);
-  const int mode = igmc_layer_mode();
-  const size_t gsa = (size_t)(m.R * 4 + 16 * m.R * 4) * sizeof(float);
-  const size_t ds = (size_t)IGMC_KCAT * (32 + 4) * sizeof(float);
   const size_t bsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4 + 16 * m.R * 4) * sizeof(float);
-  const int dl = mode == 2 && igmc_dl_eligible(m, b, B);     // (the images of this step were composed by the forward)
+  const int dl = igmc_dl_eligible(m, b, B);     // (the images of this step were composed by the forward)
   for (int l = 3; l >= 1; --l) {
     // transposed gather of dPre_l (+ d att partials), then [G | dPre_l] @ [basis^T ; root^T] + backward epilogue
     if (dl) {
       igmc_launch_dl_layer(m, b, P, B, l, 1, use_flags, nullptr, stream);
-    } else if (mode == 1) {
-      if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer<true, true>), gt, 1024, bsm, stream, b, m, P, l, (float*)nullptr);
-      else IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer<false, true>), gt, 1024, bsm, stream, b, m, P, l, (float*)nullptr);
-    } else if (mode == 2) {
+    } else {
       if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer4<true, true>), gt, IGMC_BLOCK, bsm4, stream, b, m, P, l, (float*)nullptr);
       else IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer4<false, true>), gt, IGMC_BLOCK, bsm4, stream, b, m, P, l, (float*)nullptr);
-    } else if (mode == 3) {
-      const int gs3 = igmc_slot_grid(m, B, 2048);
-      if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer_s<true, true>), gs3, IGMC_BLOCK, bsm4, stream, b, m, P, l, (float*)nullptr);
-      else IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer_s<false, true>), gs3, IGMC_BLOCK, bsm4, stream, b, m, P, l, (float*)nullptr);
-    } else {
-      float* gp = m.gatt_part + (size_t)(l - 1) * IGMC_GATHER_BLOCKS * na;
-      if (use_flags)
-        IGMC_PLAUNCH("k_rgcn_gather_bwd", (k_rgcn_gather<true, true, true>), g16, IGMC_BLOCK, gsa, stream, b, m.R,
-                     (const float*)m.dpre[l], P + m.off_att[l], m.gagg[l - 1], (const float*)m.Y[l - 1], gp);
-      else
-        IGMC_PLAUNCH("k_rgcn_gather_bwd", (k_rgcn_gather<false, true, true>), g16, IGMC_BLOCK, gsa, stream, b, m.R,
-                     (const float*)m.dpre[l], P + m.off_att[l], m.gagg[l - 1], (const float*)m.Y[l - 1], gp);
-      IGMC_PLAUNCH("k_dense_bwd", k_dense_bwd, g64, IGMC_BLOCK, ds, stream, b, (const float*)m.gagg[l - 1],
-                   (const float*)m.dpre[l], P + m.off_basis[l], P + m.off_root[l], m.dpre[l - 1],
-                   (const float*)m.h[l - 1], (const float*)m.gfeat, m.D, l - 1);
     }
   }
   const float* d0 = m.dpre[0];
@@ -2611,7 +2209,7 @@ void igmc_launch_conv_backward(const ModelDev& m, const BatchDev& b, const float
     const int wgs2 = igmc_wg_stride(), n0 = rows0 * 32;
     const int nblk = ((l0_mfma ? 4 : 3) * wgs2 + 63) / 64 + (l0_mfma ? 0 : (n0 + 63) / 64) + (3 * na + 3) / 4;
     IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk, IGMC_BLOCK, 0, stream, m,
-                 dl ? igmc_dl_grid(b, B) : (mode == 0 ? g16 : (mode == 3 ? igmc_slot_grid(m, B, 2048) : gt)), l0_mfma,
+                 dl ? igmc_dl_grid(b, B) : gt, l0_mfma,
                  IGMC_WG_BLOCKS, (const float*)nullptr, (const int64_t*)nullptr, 0);
   }
   {
@@ -2632,8 +2230,7 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
   const int gy = igmc_rows_grid(m.node_cap, 128, 512);
   const int hb = (B + 15) / 16;
   const int ny = (m.D / 16 + 3) / 4;
-  const int lmode = igmc_layer_mode();
-  const bool fast_head = (m.D % 16 == 0) && (lmode == 2 || lmode == 3) && 8 * ny <= IGMC_WG_BLOCKS;
+  const bool fast_head = (m.D % 16 == 0) && 8 * ny <= IGMC_WG_BLOCKS;
   AdamTail at;
   memset(&at, 0, sizeof(at));
   if (adam) at = *adam;
@@ -2682,7 +2279,7 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
   const int gt = igmc_xcd_grid(m, B, 16, 2048);
   // slots of 129..256 nodes a side with a dense block: every conv layer on the matrix cores (graphstep2.hip, k_dl_layer0 /
   // k_dl_layer) from the blocks alone -- no edge list is read
-  const int dl = lmode == 2 && igmc_dl_eligible(m, b, B);
+  const int dl = igmc_dl_eligible(m, b, B);
   if (dl) {
     igmc_launch_g2_compose(m, (const float*)P, stream);
     igmc_launch_dl_layer0(m, b, B, 1, use_flags, stream);
@@ -2690,14 +2287,11 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
   else IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<false, true>), g16, IGMC_BLOCK, l0s, stream, b, m, (const float*)P, m.h[0]);
   const size_t fsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4) * sizeof(float);
   const size_t bsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4 + 16 * m.R * 4) * sizeof(float);
-  const int gl = (dl && !getenv("IGMC_DL_NOBWD")) ? igmc_dl_grid(b, B) : ((lmode == 3) ? igmc_slot_grid(m, B, 2048) : gt);      // grid of the layer kernels
+  const int gl = (dl && !getenv("IGMC_DL_NOBWD")) ? igmc_dl_grid(b, B) : gt;      // grid of the layer kernels
   for (int l = 1; l < 4; ++l) {
     float* zo = (l == 3) ? m.dpre[3] : nullptr;
     if (dl) {
       igmc_launch_dl_layer(m, b, (const float*)P, B, l, 0, use_flags, zo, stream);
-    } else if (lmode == 3) {
-      if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer_s<true, false>), gl, IGMC_BLOCK, fsm4, stream, b, m, (const float*)P, l, zo);
-      else IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer_s<false, false>), gl, IGMC_BLOCK, fsm4, stream, b, m, (const float*)P, l, zo);
     } else {
       if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer4<true, false>), gt, IGMC_BLOCK, fsm4, stream, b, m, (const float*)P, l, zo);
       else IGMC_PLAUNCH("k_rgcn_layer_fwd", (k_rgcn_layer4<false, false>), gt, IGMC_BLOCK, fsm4, stream, b, m, (const float*)P, l, zo);
@@ -2710,9 +2304,6 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
   for (int l = 3; l >= 1; --l) {
     if (dlb) {
       igmc_launch_dl_layer(m, b, (const float*)P, B, l, 1, use_flags, nullptr, stream);
-    } else if (lmode == 3) {
-      if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer_s<true, true>), gl, IGMC_BLOCK, bsm4, stream, b, m, (const float*)P, l, (float*)nullptr);
-      else IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer_s<false, true>), gl, IGMC_BLOCK, bsm4, stream, b, m, (const float*)P, l, (float*)nullptr);
     } else {
       if (use_flags) IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer4<true, true>), gt, IGMC_BLOCK, bsm4, stream, b, m, (const float*)P, l, (float*)nullptr);
       else IGMC_PLAUNCH("k_rgcn_layer_bwd", (k_rgcn_layer4<false, true>), gt, IGMC_BLOCK, bsm4, stream, b, m, (const float*)P, l, (float*)nullptr);
@@ -2818,14 +2409,14 @@ void igmc_launch_finish(const ModelDev& m, const BatchDev& b, float* p, const fl
                (int64_t)m.n_params, step_size, inv_sqrt_bc2, beta1, beta2, eps, wd, ctrl, ctrl ? 1 : 0, fin);
 }
 
-// dynamic LDS above 64 KB needs an explicit opt-in on HIP (many relations -> large d-att tables)
 int igmc_model_prepare(const ModelDev& m) {
 #ifndef IGMC_HIPEMU
-  const int bsm = (int)((size_t)(16 * IGMC_TP + 2048 + m.R * 4 + 64 * m.R * 4) * sizeof(float));
-  if (bsm > 48 * 1024) {
-    if (bsm > 150 * 1024) return 1;
-    if (hipFuncSetAttribute((const void*)k_rgcn_layer<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bsm) != hipSuccess) return 1;
-    if (hipFuncSetAttribute((const void*)k_rgcn_layer<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bsm) != hipSuccess) return 1;
+  // dynamic LDS above 48 KB needs an explicit opt-in on HIP (many relations -> large d-att tables in the backward)
+  const int bsm4 = (int)((size_t)(16 * IGMC_TP + 1024 + m.R * 4 + 16 * m.R * 4) * sizeof(float));
+  if (bsm4 > 48 * 1024) {
+    if (bsm4 > 150 * 1024) return 1;
+    if (hipFuncSetAttribute((const void*)k_rgcn_layer4<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bsm4) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void*)k_rgcn_layer4<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bsm4) != hipSuccess) return 1;
   }
 #endif
   (void)m;

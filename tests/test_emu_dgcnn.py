@@ -66,9 +66,5 @@ def test_sort_pool_error_behaviour(be, monkeypatch):
     with pytest.raises(RuntimeError, match='slots larger'):
         sp_small.forward(P.ctypes.data, b, out.ctypes.data)
     sp = engine.SortPoolWorkspace(ws, 12, slot)
-    monkeypatch.setenv('IGMC_LAYER_MODE', '0')
-    with pytest.raises(RuntimeError, match='IGMC_LAYER_MODE=0'):
-        sp.forward(P.ctypes.data, b, out.ctypes.data)
-    monkeypatch.delenv('IGMC_LAYER_MODE')
     with pytest.raises(RuntimeError, match='null buffer'):
         sp.forward(None, b, out.ctypes.data)

@@ -49,16 +49,6 @@ def test_forward_backward_parity(be, name, n, R, drop, mult):
     assert res['worst_grad_err'] < 1e-4
 
 
-@pytest.mark.parametrize('mode', ['0', '1', '3'])
-def test_layer_kernel_variants(be, monkeypatch, mode):
-    # IGMC_LAYER_MODE: 0 = gather + dense kernels, 1 = fused 16-wave tiles, 3 = fused tiles of row segments
-    # (2, the default, is what every other test runs)
-    monkeypatch.setenv('IGMC_LAYER_MODE', mode)
-    monkeypatch.setenv('IGMC_GRAPH_STEP', '0')
-    res = PC.run_model_parity(be, sub('synth_nocap', 3), R=5, use_dropout=True)
-    assert res['worst_grad_err'] < 1e-4
-
-
 @pytest.mark.parametrize('cs', ['2', '4'])
 @pytest.mark.parametrize('name,n,drop', [('synth_cap', 6, True), ('synth_nocap:100', 4, False), ('hand', 5, True)])
 def test_graph_step_clusters(be, monkeypatch, cs, name, n, drop):

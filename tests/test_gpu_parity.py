@@ -95,14 +95,6 @@ def test_capped_cases_per_layer_kernels(be, monkeypatch, name, n, R, drop):
     assert res['worst_grad_err'] < PC.GRAD_TOL
 
 
-@pytest.mark.parametrize('mode', ['0', '1', '3'])
-def test_layer_kernel_variants(be, monkeypatch, mode):
-    monkeypatch.setenv('IGMC_LAYER_MODE', mode)
-    monkeypatch.setenv('IGMC_GRAPH_STEP', '0')
-    res = PC.run_model_parity(be, sub('synth_nocap:100', 16), R=5, use_dropout=True)
-    assert res['worst_grad_err'] < PC.GRAD_TOL
-
-
 def test_hand_off_finalize_variant(be, monkeypatch):
     # IGMC_FIN_MODE=0: subgraph kernel + k_finalize (in-kernel hand-offs) instead of the default k_finalize_ts
     monkeypatch.setenv('IGMC_FIN_MODE', '0')
