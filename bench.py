@@ -367,7 +367,8 @@ def main():
                         allreduce_in_graph=bool(sg.graph is not None))
 
     # ---- launch structure of a data-parallel step, measured on ONE GPU: the same steps with the multi-GPU step forced --
-    # gradient kernels -> igmc_allreduce_grads on a ONE-RANK RCCL communicator -> Adam launch, captured into the same groups.
+    # igmc_train_step_dp: the single-GPU step's kernels + ONE grouped all-reduce (a ONE-RANK RCCL communicator here) of the
+    # step's reduced gradient sources between their reduction and the gradient / Adam kernel, captured into the same groups.
     # dp_structure_us = what that structure costs per step over the fused single-GPU step (no inter-GPU latency in it).
     dp_structure = None
     if world == 1 and sg.use_graph and args.dp_steps > 0:
@@ -400,9 +401,10 @@ def main():
         dp_structure = dict(steps=D, single_gpu_us=single_us, dp_us=dp_us, dp_structure_us=dp_us - single_us,
                             allreduce_in_graph=bool(in_graph),
                             host_enqueue_us_per_step=dict(single_gpu=single_host, dp=dp_host),
-                            note='world size 1: gradient kernels -> RCCL all-reduce on a one-rank communicator '
-                                 '(igmc_allreduce_grads) -> Adam launch, captured into the same groups as the fused '
-                                 'single-GPU step; no inter-GPU latency in it')
+                            note='world size 1: igmc_train_step_dp = the single-GPU step with a grouped RCCL all-reduce '
+                                 '(one-rank communicator) of the reduced gradient sources + lin gradients between their '
+                                 'reduction and the gradient / Adam kernel, captured into the same groups; no inter-GPU '
+                                 'latency in it')
         state['i'] = 0
         sg.check()
 

@@ -67,6 +67,9 @@ SIGNATURES = {
     'igmc_comm_destroy': (None, [vp]),
     'igmc_comm_info': (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
     'igmc_allreduce_grads': (i32, [vp, vp, i64, f32, vp]),
+    'igmc_comm_create_host': (i32, [vp, vp, i32, i32, C.POINTER(vp)]),
+    'igmc_train_step_dp': (i32, [vp, vp, vp, vp, i32, vp, u64, u64, f32, f32, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32,
+                                 f32, f32, vp]),
     'igmc_ctrl_tick': (i32, [vp, vp]),
     'igmc_ctrl_regroup': (i32, [vp, i32, i64, i64, vp]),
     'igmc_batch_set_ctrl': (i32, [vp, vp]),
@@ -85,6 +88,7 @@ BUF = dict(NODE_OFF=0, N_USERS=1, NODE_LABEL=2, NODE_GID=3, NODE_GRAPH=4, ROW_PT
            EFLAG=8, Y=9, TOTALS=10)
 CTRL = dict(STEP=0, FIRST=1, EPOCH=2, ADAM_T=3, BATCH=4, DONE=5, FIRST_ODD=6, K=7, LR=8, BETA1=9, BETA2=10, EPS=11, WD=12, STEP_SIZE=13,
             INV_SQRT_BC2=14, GROUP=15, GK=16, GQ=17, SYNC_ERR=18, WORDS=24)
+ALLREDUCE_FN = C.CFUNCTYPE(i32, vp, vp, i64, vp)      # igmc_allreduce_fn (igmc_comm_create_host)
 P = dict(BASIS=0, ROOT=1, BIAS=2, ATT=3, LIN1_W=4, LIN1_B=5, LIN2_W=6, LIN2_B=7)
 
 

@@ -682,8 +682,11 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   d.fin_stash = nullptr;
   d.datt_part = nullptr;
   if (d.R <= 5)
-    fail |= M.get(&d.ts_part, (size_t)4 * IGMC_TS_BLOCKS * d.ts_stride) | M.get(&d.ts_raw, (size_t)4 * d.ts_stride) |
-            M.get(&d.datt_part, (size_t)4 * d.ts_stride / 32 * 4);
+  {   // (sums + d att partials in ONE allocation: a data-parallel step exchanges them as one span)
+    fail |= M.get(&d.ts_part, (size_t)4 * IGMC_TS_BLOCKS * d.ts_stride) |
+            M.get(&d.ts_raw, (size_t)4 * d.ts_stride + (size_t)4 * d.ts_stride / 32 * 4);
+    if (!fail) d.datt_part = d.ts_raw + (size_t)4 * d.ts_stride;
+  }
   if (d.R <= 32) fail |= M.get(&d.fin_stash, (size_t)4 * 256 + 16);     // weights-only stash of k_finalize_ts (both modes)
   d.g2_ex = nullptr;
   d.g2_fx = nullptr;
@@ -984,8 +987,10 @@ extern "C" int igmc_train_step(igmc_model* m, float* d_params, const igmc_batch*
 
 // ------------------------------------------------------------------ gradient exchange (RCCL behind the C ABI)
 struct igmc_comm {
-  void* nccl;        // ncclComm_t (NULL in the emulation build: one rank only)
+  void* nccl;        // ncclComm_t (NULL: host-callback communicator, or the emulation build's single rank)
   int rank, world, device;
+  igmc_allreduce_fn host_fn;      // igmc_comm_create_host: the caller's own sum over the ranks
+  void* host_user;
 };
 #ifndef IGMC_HIPEMU
 #include <dlfcn.h>
@@ -999,6 +1004,8 @@ struct RcclApi {
   int (*CommCount)(const void*, int*);
   int (*CommUserRank)(const void*, int*);
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+  int (*GroupStart)();
+  int (*GroupEnd)();
   const char* (*GetErrorString)(int);
   bool ok = false;
 };
@@ -1012,6 +1019,7 @@ static int rccl_load(std::string* why) {
       {"ncclGetUniqueId", (void**)&g_rccl.GetUniqueId}, {"ncclCommInitRank", (void**)&g_rccl.CommInitRank},
       {"ncclCommDestroy", (void**)&g_rccl.CommDestroy}, {"ncclCommCount", (void**)&g_rccl.CommCount},
       {"ncclCommUserRank", (void**)&g_rccl.CommUserRank}, {"ncclAllReduce", (void**)&g_rccl.AllReduce},
+      {"ncclGroupStart", (void**)&g_rccl.GroupStart}, {"ncclGroupEnd", (void**)&g_rccl.GroupEnd},
       {"ncclGetErrorString", (void**)&g_rccl.GetErrorString}};
   for (auto& sy : syms) {
     *sy.slot = dlsym(h, sy.name);
@@ -1055,6 +1063,8 @@ extern "C" int igmc_comm_create(const uint8_t* h_id128, int rank, int world, int
   c->rank = rank;
   c->world = world;
   c->device = device;
+  c->host_fn = nullptr;
+  c->host_user = nullptr;
 #ifndef IGMC_HIPEMU
   std::string why;
   if (rccl_load(&why)) { delete c; IGMC_FAIL(why); }
@@ -1069,6 +1079,19 @@ extern "C" int igmc_comm_create(const uint8_t* h_id128, int rank, int world, int
 #else
   if (world != 1) { delete c; IGMC_FAIL("the emulation build has no RCCL: one rank only"); }
 #endif
+  *out = c;
+  return 0;
+}
+
+extern "C" int igmc_comm_create_host(igmc_allreduce_fn fn, void* user, int rank, int world, igmc_comm** out) {
+  if (!fn || !out || world < 1 || rank < 0 || rank >= world) IGMC_FAIL("bad arguments");
+  igmc_comm* c = new igmc_comm();
+  c->nccl = nullptr;
+  c->rank = rank;
+  c->world = world;
+  c->device = -1;
+  c->host_fn = fn;
+  c->host_user = user;
   *out = c;
   return 0;
 }
@@ -1095,16 +1118,80 @@ extern "C" int igmc_comm_info(const igmc_comm* c, int* rank, int* world) {
   return 0;
 }
 
+// sum of up to two spans over the ranks, in place: ONE grouped collective (RCCL), or the host callback once per span
+static int comm_sum2(void* user, float* a, int64_t na, float* b, int64_t nb, void* stream) {
+  igmc_comm* c = (igmc_comm*)user;
+  if (c->host_fn) {
+    if (a && na > 0 && c->host_fn(c->host_user, a, na, stream)) { g_err = "comm_sum2: the host all-reduce callback failed"; return 1; }
+    if (b && nb > 0 && c->host_fn(c->host_user, b, nb, stream)) { g_err = "comm_sum2: the host all-reduce callback failed"; return 1; }
+    return 0;
+  }
+#ifndef IGMC_HIPEMU
+  if (!c->nccl) return 0;
+  const bool two = a && na > 0 && b && nb > 0;
+  if (two) RCCLCHECK(g_rccl.GroupStart());
+  if (a && na > 0) RCCLCHECK(g_rccl.AllReduce(a, a, (size_t)na, /*ncclFloat*/ 7, /*ncclSum*/ 0, c->nccl, (hipStream_t)stream));
+  if (b && nb > 0) RCCLCHECK(g_rccl.AllReduce(b, b, (size_t)nb, 7, 0, c->nccl, (hipStream_t)stream));
+  if (two) RCCLCHECK(g_rccl.GroupEnd());
+#endif
+  return 0;
+}
+
 extern "C" int igmc_allreduce_grads(igmc_comm* c, float* d_flat_grad, int64_t n, float scale, void* stream) {
   if (!c || !d_flat_grad || n <= 0) IGMC_FAIL("bad arguments");
-#ifndef IGMC_HIPEMU
-  RCCLCHECK(g_rccl.AllReduce(d_flat_grad, d_flat_grad, (size_t)n, /*ncclFloat*/ 7, /*ncclSum*/ 0, c->nccl, (hipStream_t)stream));
-#endif
+  if (comm_sum2(c, d_flat_grad, n, nullptr, 0, stream)) return 1;
   if (scale != 1.0f) {
     int grid = (int)((n + IGMC_BLOCK - 1) / IGMC_BLOCK);
     IGMC_PLAUNCH("k_scale_flat", k_scale_flat, grid > 1024 ? 1024 : grid, IGMC_BLOCK, 0, stream, d_flat_grad, n, scale);
     HIPCHECK(hipGetLastError());
   }
+  return 0;
+}
+
+// One optimisation step of a data-parallel job (reference train_eval.py:157-177 per rank, gradients averaged over the
+// ranks): igmc_train_step with the exchange INSIDE the step.  Where the step keeps its gradient sources in reduced form
+// (igmc_step_exchange_inside: the subgraph kernel's tables, the per-layer path's basis-space sums) those are summed over
+// the ranks between their reduction and the gradient / Adam kernel -- the kernels of the single-GPU step, one grouped
+// collective more; elsewhere the flat gradient is formed, all-reduced and handed to the Adam kernel.  comm == NULL: one rank.
+extern "C" int igmc_train_step_dp(igmc_model* m, igmc_comm* comm, float* d_params, const igmc_batch* b, int use_edge_flags,
+                                  const uint8_t* d_lin_mask, uint64_t seed, uint64_t step, float multiply_by, float ARR,
+                                  float* d_out, float* d_grad, float* d_exp_avg, float* d_exp_avg_sq, float* d_loss,
+                                  double* d_total, int64_t* d_ctrl, int64_t adam_t, float lr, float beta1, float beta2,
+                                  float eps, float weight_decay, void* stream) {
+  std::string why;
+  if (check_fit(m, b, &why)) IGMC_FAIL(why);
+  if (!d_params || !d_out || !d_grad || !d_exp_avg || !d_exp_avg_sq || !d_loss) IGMC_FAIL("null buffer");
+  if (!d_ctrl && adam_t < 1) IGMC_FAIL("adam_t must be >= 1");
+  float step_size = 0.f, inv = 0.f;
+  if (!d_ctrl) {
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)adam_t);
+    const double bc2 = 1.0 - std::pow((double)beta2, (double)adam_t);
+    step_size = (float)((double)lr / bc1);
+    inv = (float)(1.0 / std::sqrt(bc2));
+  }
+  const int world = comm ? comm->world : 1;
+  const int B = b->last_B;
+  const float gscale = 1.0f / ((float)B * (float)world);
+  m->d.side = b->side;
+  csr_for_model(m, b, 1, stream);
+  if (igmc_step_exchange_inside(m->d, b->d, B)) {
+    StepExchange x = {comm_sum2, comm};
+    // (the ARR term depends on the weights only: every rank adds it in full AFTER the exchange)
+    if (igmc_launch_train_step(m->d, m->ax, b->d, d_params, B, use_edge_flags, d_lin_mask, seed, step, multiply_by, ARR, d_out,
+                               d_grad, d_exp_avg, d_exp_avg_sq, step_size, inv, beta1, beta2, eps, weight_decay, d_ctrl,
+                               m->done_ctr, d_loss, d_total, stream, gscale, comm ? &x : nullptr))
+      return 1;
+  } else {
+    igmc_launch_loss_grad(m->d, m->ax, b->d, d_params, B, use_edge_flags, d_lin_mask, seed, step, multiply_by, ARR, gscale,
+                          1.0f / (float)world, d_out, d_grad, nullptr, nullptr, stream);
+    if (comm && comm_sum2(comm, d_grad, m->d.n_params, nullptr, 0, stream)) return 1;
+    igmc_launch_finish(m->d, b->d, d_params, d_grad, d_exp_avg, d_exp_avg_sq, step_size, inv, beta1, beta2, eps,
+                       weight_decay, d_ctrl, ARR, d_loss, d_total, use_edge_flags, stream);
+  }
+  HIPCHECK(hipGetLastError());
+  m->last_B = B;
+  m->last_training = 1;
+  m->last_flags = use_edge_flags;
   return 0;
 }
 

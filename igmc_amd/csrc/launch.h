@@ -46,15 +46,27 @@ void igmc_launch_backward(const ModelDev& m, const ModelAux& ax, const BatchDev&
                           const float* gout, int from_err, float grad_scale, float mult, float drop_scale,
                           float arr_coef, float* grad, void* stream);
 struct AdamTail;
-void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev& b, float* P, int B, int use_flags,
-                           const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult, float ARR,
-                           float grad_scale, float arr_scale, float* out, float* grad, float* loss, const AdamTail* adam,
-                           void* stream);
-void igmc_launch_train_step(const ModelDev& m, const ModelAux& ax, const BatchDev& b, float* P, int B, int use_flags,
-                            const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult, float ARR, float* out,
-                            float* grad, float* m1, float* m2, float step_size, float inv_sqrt_bc2, float beta1,
-                            float beta2, float eps, float wd, int64_t* ctrl, int* done, float* loss, double* total,
-                            void* stream);
+// Data-parallel step: the REDUCED gradient sources of the step (relation-space tables + d att partials of the subgraph
+// kernel, or the basis-space partial sums of the per-layer path; plus the lin1 / lin2 gradients in `grad`) are summed over
+// the ranks between their reduction and the gradient / Adam kernel -- the step keeps its single-GPU kernels, the exchange
+// is one grouped collective of two spans.  sum() returns 0 on success.
+struct StepExchange {
+  int (*sum)(void* user, float* a, int64_t na, float* b, int64_t nb, void* stream);
+  void* user;
+};
+// 1 = a step on this arena keeps its gradient sources in exchangeable form (igmc_launch_loss_grad honours `xch`)
+int igmc_step_exchange_inside(const ModelDev& m, const BatchDev& b, int B);
+// returns 0, or the exchange's error code
+int igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev& b, float* P, int B, int use_flags,
+                          const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult, float ARR,
+                          float grad_scale, float arr_scale, float* out, float* grad, float* loss, const AdamTail* adam,
+                          void* stream, const StepExchange* xch = nullptr);
+// (grad_scale 0: 1 / B; xch: see StepExchange -- only where igmc_step_exchange_inside() says so)
+int igmc_launch_train_step(const ModelDev& m, const ModelAux& ax, const BatchDev& b, float* P, int B, int use_flags,
+                           const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult, float ARR, float* out,
+                           float* grad, float* m1, float* m2, float step_size, float inv_sqrt_bc2, float beta1,
+                           float beta2, float eps, float wd, int64_t* ctrl, int* done, float* loss, double* total,
+                           void* stream, float grad_scale = 0.f, const StepExchange* xch = nullptr);
 void igmc_launch_loss(const ModelDev& m, const BatchDev& b, float ARR, float* loss, void* stream);
 void igmc_launch_sse(const BatchDev& b, const float* out, double* acc, void* stream);
 int igmc_model_prepare(const ModelDev& m);

@@ -2221,16 +2221,32 @@ void igmc_launch_conv_backward(const ModelDev& m, const BatchDev& b, const float
 
 // Fused-step sequence (loss + gradients [+ Adam]) with the multi-role launches:
 //   l0_fwd, 3 x layer_fwd, {head fwd+bwd | Y}, 3 x layer_bwd, {weight grads | lin grads}, reduce, finalize[+Adam]
-void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev& b, float* P, int B, int use_flags,
-                           const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult, float ARR,
-                           float grad_scale, float arr_scale, float* out, float* grad, float* loss, const AdamTail* adam,
-                           void* stream) {
+static inline int igmc_fin_mode() {
+  const char* fe = getenv("IGMC_FIN_MODE");        // 0: the hand-off version of the gradient / Adam tail (k_finalize); read
+  return fe ? atoi(fe) : 1;                        // on every call: tests switch it per case
+}
+
+int igmc_step_exchange_inside(const ModelDev& m, const BatchDev& b, int B) {
+  const int ny = (m.D / 16 + 3) / 4;
+  if (!((m.D % 16 == 0) && 8 * ny <= IGMC_WG_BLOCKS)) return 0;          // generic sequence: flat gradient only
+  G2Layout lay2;
+  int cs2 = 1;
+  if (m.R * m.L + m.L + 1 <= 32 && igmc_g2_eligible(m, b, B, &lay2, &cs2))
+    return igmc_fin_mode() && m.fin_stash && m.datt_part && m.R <= 8;
+  return igmc_fin_mode() && m.fin_stash && m.R <= 32;
+}
+
+int igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev& b, float* P, int B, int use_flags,
+                          const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult, float ARR,
+                          float grad_scale, float arr_scale, float* out, float* grad, float* loss, const AdamTail* adam,
+                          void* stream, const StepExchange* xch) {
   const int rows0 = m.R * m.L + m.L + 1;
   const int l0_mfma = rows0 <= 32;
   const int gy = igmc_rows_grid(m.node_cap, 128, 512);
   const int hb = (B + 15) / 16;
   const int ny = (m.D / 16 + 3) / 4;
   const bool fast_head = (m.D % 16 == 0) && 8 * ny <= IGMC_WG_BLOCKS;
+  const int64_t n_lin = m.n_params - m.off_l1w;      // lin1 / lin2 are the tail of the flat parameter vector
   AdamTail at;
   memset(&at, 0, sizeof(at));
   if (adam) at = *adam;
@@ -2244,7 +2260,7 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
     } else if (loss) {
       igmc_launch_loss(m, b, ARR, loss, stream);
     }
-    return;
+    return 0;
   }
   G2Layout lay2;
   int cs2 = 1;
@@ -2256,11 +2272,15 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
     int bump_seq = 0;       // 1: k_tail_ts advances the launch sequence number of the subgraph kernel's exchange tags
     bump_seq = igmc_launch_graph_step2(m, b, P, B, 1, use_flags, lay2, cs2, inj_mask, seed, step, mult, grad_scale, out, stream);
     // IGMC_FIN_MODE=0: the hand-off version of the gradient / Adam tail (k_finalize) instead of k_finalize_ts
-    const char* fe = getenv("IGMC_FIN_MODE");        // read on every call: tests switch it per case
-    const int fts = (fe ? atoi(fe) : 1) && m.fin_stash && m.datt_part && m.R <= 8;
+    const int fts = igmc_fin_mode() && m.fin_stash && m.datt_part && m.R <= 8;
     IGMC_PLAUNCH("k_tail_ts", k_tail_ts, 8 * ny + (4 * m.ts_stride + 63) / 64 + (fts ? 4 : 0), IGMC_BLOCK, 0, stream, b, m,
                  (const float*)P, grad_scale, mult, 2.f, grad, 8 * ny, gg, gstride, B, fts ? 4 : 0,
                  (const int64_t*)(adam ? at.ctrl : nullptr), bump_seq);
+    if (xch && fts) {      // tables + d att partials (one allocation) and the lin gradients, summed over the ranks
+      const int rc = xch->sum(xch->user, m.ts_raw, (int64_t)4 * m.ts_stride + (int64_t)4 * m.ts_stride / 32 * 4,
+                              grad + m.off_l1w, n_lin, stream);
+      if (rc) return rc;
+    }
     if (adam) {
       at.enabled = 1;
       at.b = b;
@@ -2272,7 +2292,7 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
       else IGMC_PLAUNCH("k_finalize", k_finalize, 4 * IGMC_FIN_NB, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 1);
       if (loss) igmc_launch_loss(m, b, ARR, loss, stream);
     }
-    return;
+    return 0;
   }
   const size_t l0s = (size_t)(m.R * m.L * 32 + m.L * 32 + 32) * sizeof(float) + (size_t)4 * m.R * m.L * sizeof(int);
   const int g16 = igmc_xcd_grid(m, B, 4, IGMC_GATHER_BLOCKS);
@@ -2323,10 +2343,13 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
     // gradient / Adam tail without hand-offs (k_finalize_ts in basis-space mode) where the stash fits: R <= 32 (the
     // layer-0 table comes from the MFMA weight-gradient kernel or from k_l0_bwd's partials: same place, same layout);
     // IGMC_FIN_MODE=0: the hand-off version (k_finalize)
-    const char* fe = getenv("IGMC_FIN_MODE");
-    const int fbs = (fe ? atoi(fe) : 1) && m.fin_stash && m.R <= 32;
+    const int fbs = igmc_fin_mode() && m.fin_stash && m.R <= 32;
     IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk + (fbs ? 4 : 0), IGMC_BLOCK, 0, stream, m, gl, l0_mfma,
                  IGMC_WG_BLOCKS, (const float*)P, (const int64_t*)(adam ? at.ctrl : nullptr), fbs ? 4 : 0);
+    if (xch && fbs) {      // the reduced basis-space sums (+ layer-0 table, d att) and the lin gradients, over the ranks
+      const int rc = xch->sum(xch->user, m.graw, (int64_t)3 * wgs2 + 3 * na + n0, grad + m.off_l1w, n_lin, stream);
+      if (rc) return rc;
+    }
     if (fbs) {
       if (adam) {
         at.enabled = 1;
@@ -2337,7 +2360,7 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
         IGMC_PLAUNCH("k_finalize", k_finalize_ts, 4 * IGMC_FTS_NB, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 0, 1);
         if (loss) igmc_launch_loss(m, b, ARR, loss, stream);
       }
-      return;
+      return 0;
     }
   }
   if (adam) {
@@ -2349,20 +2372,21 @@ void igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev
     IGMC_PLAUNCH("k_finalize", k_finalize, 4 * IGMC_FIN_NB, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 0);
     if (loss) igmc_launch_loss(m, b, ARR, loss, stream);
   }
+  return 0;
 }
 
-void igmc_launch_train_step(const ModelDev& m, const ModelAux& ax, const BatchDev& b, float* P, int B, int use_flags,
-                            const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult, float ARR, float* out,
-                            float* grad, float* m1, float* m2, float step_size, float inv_sqrt_bc2, float beta1,
-                            float beta2, float eps, float wd, int64_t* ctrl, int* done, float* loss, double* total,
-                            void* stream) {
+int igmc_launch_train_step(const ModelDev& m, const ModelAux& ax, const BatchDev& b, float* P, int B, int use_flags,
+                           const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult, float ARR, float* out,
+                           float* grad, float* m1, float* m2, float step_size, float inv_sqrt_bc2, float beta1,
+                           float beta2, float eps, float wd, int64_t* ctrl, int* done, float* loss, double* total,
+                           void* stream, float grad_scale, const StepExchange* xch) {
   AdamTail at;
   memset(&at, 0, sizeof(at));
   at.p = P; at.m1 = m1; at.m2 = m2;
   at.step_size = step_size; at.inv_sqrt_bc2 = inv_sqrt_bc2; at.beta1 = beta1; at.beta2 = beta2; at.eps = eps; at.wd = wd;
   at.ctrl = ctrl; at.done = done; at.loss = loss; at.total = total;
-  igmc_launch_loss_grad(m, ax, b, P, B, use_flags, inj_mask, seed, step, mult, ARR, 1.0f / (float)B, 1.0f, out, grad,
-                        nullptr, &at, stream);
+  return igmc_launch_loss_grad(m, ax, b, P, B, use_flags, inj_mask, seed, step, mult, ARR,
+                               grad_scale != 0.f ? grad_scale : 1.0f / (float)B, 1.0f, out, grad, nullptr, &at, stream, xch);
 }
 
 void igmc_launch_loss(const ModelDev& m, const BatchDev& b, float ARR, float* loss, void* stream) {

@@ -4,9 +4,10 @@
 The reference has no distributed code (single process, single device: ``train_eval.py:20``).  The hot path
 shards by LINKS: the rating graph (~9 MB) and the 197 KB parameter / optimiser state are replicated, rank k
 takes ``perm[k::G]`` of the (identical) epoch permutation, extracts and trains its own batches, and the only
-exchange is ONE all-reduce of the single flat gradient buffer per step (latency-bound at 197 KB, so never one
-call per tensor) followed by the identical fused Adam on every rank.  Evaluation all-reduces (sum of squared
-errors, count) once.
+exchange is ONE collective per step (latency-bound at ~200 KB, so never one call per tensor): the step's reduced
+gradient sources -- or, where a step keeps none, the flat gradient -- summed over the ranks INSIDE the step
+(``igmc_train_step_dp``), then the identical gradient / Adam kernel on every rank.  Evaluation all-reduces (sum of
+squared errors, count) once.
 """
 import os
 
@@ -99,6 +100,40 @@ class GradComm(object):
         if getattr(self, 'handle', None):
             self.lib.cdll.igmc_comm_destroy(self.handle)
             self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HostComm(object):
+    """A communicator whose sum is the caller's (``igmc_comm_create_host``): ``fn(ptr, n, stream)`` must leave the sum over
+    the ranks in the ``n`` floats at ``ptr``.  For a host that already owns a process group; the CPU-side tests drive the
+    library's data-parallel step over ``gloo`` with it."""
+
+    def __init__(self, lib, fn, rank_, world):
+        import ctypes as C
+        from . import _lib
+        self.lib, self.C = lib, C
+
+        def _cb(user, ptr, n, stream):
+            try:
+                fn(ptr, n, stream)
+                return 0
+            except Exception:          # (an exception cannot cross the C frame: reported as the call's failure)
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb = _lib.ALLREDUCE_FN(_cb)          # (kept alive as long as the communicator)
+        h = C.c_void_p()
+        lib.call('igmc_comm_create_host', C.cast(self._cb, C.c_void_p), None, int(rank_), int(world), C.byref(h))
+        self.handle = h
+
+    info = GradComm.info
+    all_reduce_ = GradComm.all_reduce_
+    close = GradComm.close
 
     def __del__(self):
         try:

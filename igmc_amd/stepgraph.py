@@ -400,6 +400,21 @@ class StepGraph(GroupPipeline):
                       C.c_void_p(self.ctrl.data_ptr()), 1, g['lr'], g['betas'][0], g['betas'][1], g['eps'],
                       g['weight_decay'], C.c_void_p(st))
 
+    def _train_step_dp(self, arena):
+        """Data parallel: ``igmc_train_step_dp`` -- the single-GPU step's kernels with the exchange of the step's reduced
+        gradient sources between their reduction and the gradient / Adam kernel (one grouped RCCL call on this stream)."""
+        m, st = self.model, torch.cuda.current_stream().cuda_stream
+        flat, grad = m.flat_parameters(), m.flat_grad()
+        g = self.opt.param_groups[0]
+        self.lib.call('igmc_train_step_dp', self.ws.handle, self.comm.handle if self.comm is not None else None,
+                      C.c_void_p(flat.data_ptr()), arena.handle,
+                      int(m.adj_dropout > 0), None, m.seed & (2 ** 64 - 1), 0, float(m.multiply_by), self.ARR,
+                      C.c_void_p(self.out.data_ptr()), C.c_void_p(grad.data_ptr()),
+                      C.c_void_p(self.opt.exp_avg.data_ptr()), C.c_void_p(self.opt.exp_avg_sq.data_ptr()),
+                      C.c_void_p(self.loss.data_ptr()), C.c_void_p(self.total.data_ptr()),
+                      C.c_void_p(self.ctrl.data_ptr()), 1, g['lr'], g['betas'][0], g['betas'][1], g['eps'],
+                      g['weight_decay'], C.c_void_p(st))
+
     def _sortpool_step(self, arena, B):
         """DGCNN_RS (reference models.py:123-167): conv kernels + sort-pool readout forward / backward -> [all-reduce] ->
         Adam + loss + tick (igmc_sortpool_step_finish), every scalar from the control block: capturable like IGMC's."""
@@ -421,6 +436,8 @@ class StepGraph(GroupPipeline):
         """The kernels of one optimisation step on the batch in ``arena`` (current stream)."""
         if self.sp is not None:
             self._sortpool_step(arena, B)
+        elif self.dp_path and os.environ.get('IGMC_DP_FLAT', '0') != '1':
+            self._train_step_dp(arena)       # the exchange inside the step (IGMC_DP_FLAT=1: the three-call sequence below)
         elif not self.dp_path and B == self.B:
             self._train_step(arena)          # gradients + Adam in the minimum number of launches
         else:

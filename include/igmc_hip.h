@@ -261,13 +261,31 @@ int igmc_adam_step_ctrl(float* d_params, const float* d_grad, float* d_exp_avg, 
  *   igmc_comm_info      : rank / size AS SEEN BY RCCL (bench.py checks them against the launcher's)
  *   igmc_allreduce_grads: d_flat_grad[i] = scale * sum over ranks of d_flat_grad[i], in place, asynchronous on `stream`.
  *                         The gradient kernels already scale by 1/(B * world) (igmc_model_loss_grad), so scale = 1.
+ *   igmc_comm_create_host: a communicator whose sum is the CALLER's: fn(user, d_buf, n, stream) must leave the sum over the
+ *                         `world` ranks in d_buf (in place, ordered on `stream`), return 0 on success.  For a host that already
+ *                         owns a process group (torch.distributed, MPI): the library's steps then run on it unchanged.
+ *   igmc_train_step_dp  : igmc_train_step of a data-parallel job, the exchange INSIDE the step: the step's reduced gradient
+ *                         sources (the subgraph kernel's relation-space tables, or the per-layer path's basis-space sums, plus
+ *                         the lin1 / lin2 gradients: about the size of the flat gradient) are summed over the ranks between
+ *                         their reduction and the gradient / Adam kernel, as ONE grouped collective -- the kernels of the
+ *                         single-GPU step and nothing else; arenas whose step keeps no such form (generic sequence) form the
+ *                         flat gradient, all-reduce it and run the Adam kernel.  Loss terms are scaled by 1/(B * world), the
+ *                         ARR term is added by every rank after the exchange.  comm == NULL: one rank (= igmc_train_step).
+ *                         d_loss / d_total stay per rank (this rank's batches), as in igmc_train_step.
  */
 typedef struct igmc_comm igmc_comm;
+typedef int (*igmc_allreduce_fn)(void* user, float* d_buf, int64_t n, void* stream);
 int igmc_comm_unique_id(uint8_t* h_id128);
 int igmc_comm_create(const uint8_t* h_id128, int rank, int world, int device, igmc_comm** out);
+int igmc_comm_create_host(igmc_allreduce_fn fn, void* user, int rank, int world, igmc_comm** out);
 void igmc_comm_destroy(igmc_comm* c);
 int igmc_comm_info(const igmc_comm* c, int* rank, int* world);
 int igmc_allreduce_grads(igmc_comm* c, float* d_flat_grad, int64_t n, float scale, void* stream);
+int igmc_train_step_dp(igmc_model* m, igmc_comm* comm, float* d_params, const igmc_batch* b, int use_edge_flags,
+                       const uint8_t* d_lin_mask, uint64_t seed, uint64_t step, float multiply_by, float ARR, float* d_out,
+                       float* d_grad, float* d_exp_avg, float* d_exp_avg_sq, float* d_loss, double* d_total,
+                       int64_t* d_ctrl, int64_t adam_t, float lr, float beta1, float beta2, float eps, float weight_decay,
+                       void* stream);
 
 /* Eval reduction helper (reference train_eval.py:195): d_acc[0] += sum_g (out-y)^2, d_acc[1] += B. */
 int igmc_sse_accumulate(const float* d_out, const igmc_batch* b, double* d_acc, void* stream);

@@ -243,8 +243,10 @@ def test_main_script_end_to_end(tmp_path):
 def test_step_graph_paths_agree(flix, monkeypatch):
     """The captured single-GPU step (igmc_train_step inside a hipGraph, the next group's extraction on a second stream;
     groups of 4 steps per graph launch here, one step per launch with IGMC_GROUP_STEPS=1), the eager step, and the
-    multi-GPU step (gradient kernels -> igmc_allreduce_grads on a one-rank RCCL communicator -> igmc_step_finish, captured
-    into the same groups) must walk the same trajectory.  flixster has R = 10: the per-layer kernels take these steps."""
+    multi-GPU step (igmc_train_step_dp: the single-GPU step's kernels with the exchange of the reduced gradient sources on a
+    one-rank RCCL communicator between the reduction and the gradient / Adam kernel, captured into the same groups; dp_flat:
+    gradient kernels -> igmc_allreduce_grads -> igmc_step_finish) must walk the same trajectory.  flixster has R = 10: the
+    per-layer kernels take these steps."""
     import torch
     from igmc_amd.models import IGMC
     from igmc_amd.stepgraph import StepGraph
@@ -254,7 +256,9 @@ def test_step_graph_paths_agree(flix, monkeypatch):
     for name, env, kw in (('graph', {}, dict(group=4)), ('eager', {}, dict(use_graph=False, overlap=False, group=4)),
                           ('graph1', {'IGMC_GROUP_STEPS': '1'}, {}), ('dp_path', {'IGMC_FORCE_DP_PATH': '1'}, dict(group=4)),
                           # ... with the all-reduce of a REAL (one-rank) RCCL communicator enqueued inside the captured group
-                          ('dp_comm', {'IGMC_FORCE_DP_PATH': '1', 'IGMC_DP_ALLREDUCE_ALWAYS': '1'}, dict(group=4))):
+                          ('dp_comm', {'IGMC_FORCE_DP_PATH': '1', 'IGMC_DP_ALLREDUCE_ALWAYS': '1'}, dict(group=4)),
+                          ('dp_flat', {'IGMC_FORCE_DP_PATH': '1', 'IGMC_DP_ALLREDUCE_ALWAYS': '1', 'IGMC_DP_FLAT': '1'},
+                           dict(group=4))):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         torch.manual_seed(7)
@@ -269,13 +273,13 @@ def test_step_graph_paths_agree(flix, monkeypatch):
         torch.cuda.synchronize()
         results[name] = (model.flat_parameters().detach().cpu().clone(), float(total2.item()), opt.t, model._step)
         assert any(g is not None for g in sg.graphs) == (name != 'eager'), name
-        assert (sg.comm is not None) == (name == 'dp_comm')
+        assert (sg.comm is not None) == (name in ('dp_comm', 'dp_flat'))
         if sg.comm is not None:
             assert sg.comm.info() == (0, 1)
         for k in env:
             monkeypatch.delenv(k)
     assert results['graph'][2] == 24 and results['graph'][3] == 24
-    for other in ('eager', 'graph1', 'dp_path', 'dp_comm'):
+    for other in ('eager', 'graph1', 'dp_path', 'dp_comm', 'dp_flat'):
         assert torch.allclose(results['graph'][0], results[other][0], rtol=2e-4, atol=2e-6), other
         assert results['graph'][1] == pytest.approx(results[other][1], rel=1e-4)
     # the SAME kernels on the same inputs, only launched differently (4 steps per hipGraph launch / one per launch /
@@ -284,8 +288,10 @@ def test_step_graph_paths_agree(flix, monkeypatch):
     for other in ('eager', 'graph1'):
         assert torch.equal(results['graph'][0], results[other][0]), other
         assert results['graph'][1] == results[other][1], other
-    # a sum over ONE rank is the identity: the collective inside the graph changes nothing
-    assert torch.equal(results['dp_path'][0], results['dp_comm'][0])
+    # a sum over ONE rank is the identity, and the data-parallel step IS the single-GPU step plus that sum: bit-identical
+    for other in ('dp_path', 'dp_comm'):
+        assert torch.equal(results['graph'][0], results[other][0]), other
+        assert results['graph'][1] == results[other][1], other
 
 
 def test_full_size_headline_config_properties(monkeypatch):

@@ -274,6 +274,13 @@ def test_step_graph_is_bit_reproducible_and_structure_independent(ml1m, monkeypa
     sg_e, eager = _trajectory(ds, drop, perm, use_graph=False, overlap=False, group=8)
     assert not any(g is not None for g in sg_e.graphs)
     _assert_same(ref, eager, 'eager one-stream launches vs groups of 8')
+    # ... == the data-parallel step (igmc_train_step_dp) on a one-rank RCCL communicator: the subgraph kernel's tables and
+    # the lin gradients go through a grouped all-reduce captured between k_tail_ts and k_finalize_ts -- a sum over one rank
+    monkeypatch.setenv('IGMC_FORCE_DP_PATH', '1')
+    monkeypatch.setenv('IGMC_DP_ALLREDUCE_ALWAYS', '1')
+    sg_d, dp = _trajectory(ds, drop, perm, group=8)
+    assert sg_d.dp_path and sg_d.comm is not None and sg_d.comm.info() == (0, 1)
+    _assert_same(ref, dp, 'data-parallel step on a one-rank communicator vs the single-GPU step')
 
 
 def test_step_graph_on_the_dense_per_layer_path_is_reproducible():

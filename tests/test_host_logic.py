@@ -267,6 +267,8 @@ from igmc_amd import _lib, engine, parallel, stepgraph
 import parity_checks as PC
 from helpers import load_extract_golden
 rank, world = parallel.init_from_env('gloo')
+MODE = os.environ['DP_MODE']              # flat: gradient kernels -> flat all-reduce -> igmc_step_finish (three calls);
+                                          # inside / inside_layers: igmc_train_step_dp (subgraph kernel / per-layer kernels)
 be = PC.EmuBackend()                      # kernel logic on the CPU emulation (test infrastructure)
 lib = be.lib
 case = load_extract_golden()['synth_cap']
@@ -294,6 +296,15 @@ class EmuPipeline(stepgraph.GroupPipeline):
         self.M1, self.M2, self.G = np.zeros_like(self.P), np.zeros_like(self.P), np.zeros_like(self.P)
         self.out, self.loss, self.total = np.zeros(B, np.float32), np.zeros(2, np.float32), np.zeros(1, np.float64)
         self.collectives = 0
+        self.spans = set()
+
+        def host_sum(ptr, n, stream):          # sum over the ranks of the n floats at ptr, in place
+            buf = np.ctypeslib.as_array((C.c_float * n).from_address(ptr))
+            parallel.all_reduce_sum_(torch.from_numpy(buf))
+            self.collectives += 1
+            self.spans.add(n)
+        self.comm = parallel.HostComm(lib, host_sum, rank, world)
+        assert self.comm.info() == (rank, world)
 
     def _arena(self, q, i):
         while len(self.sets[q]) <= i:
@@ -306,6 +317,13 @@ class EmuPipeline(stepgraph.GroupPipeline):
         arena.extract(lu, lv, ly, self.perm, sel, nb, 1.0, seed, 999)
 
     def _enqueue_step(self, arena, nb):
+        if MODE != 'flat':
+            # the product's data-parallel step (igmc_train_step_dp): the exchange INSIDE the step, here over gloo through a
+            # host-callback communicator (igmc_comm_create_host)
+            lib.call('igmc_train_step_dp', self.ws.handle, self.comm.handle, vp(self.P), arena.handle, 0, None, seed, 0, 1.0,
+                     ARR, vp(self.out), vp(self.G), vp(self.M1), vp(self.M2), vp(self.loss), vp(self.total), vp(self.ctrl),
+                     1, lr, 0.9, 0.999, 1e-8, 0.0, None)
+            return
         self.ws.loss_grad(self.P.ctypes.data, arena, self.out.ctypes.data, self.G.ctypes.data, None, seed=seed, step=0,
                           ARR=ARR, grad_scale=1.0 / (nb * world), arr_scale=1.0 / world)
         parallel.all_reduce_sum_(torch.from_numpy(self.G))           # in place on the numpy buffer
@@ -349,7 +367,16 @@ assert len(mine) == 7                      # 14 links over 2 ranks, batch 2: a P
 pipe = EmuPipeline()
 pipe.run_epoch(mine, 3)
 K = _lib.CTRL
-assert pipe.ctrl[K['SYNC_ERR']] == 0 and pipe.ctrl[K['K']] == 4 and pipe.collectives == 4
+assert pipe.ctrl[K['SYNC_ERR']] == 0 and pipe.ctrl[K['K']] == 4
+n_lin = 128 * 256 + 128 + 128 + 1
+if MODE == 'flat':
+    assert pipe.collectives == 4
+else:
+    # two spans per step: the step's reduced gradient sources (tables + d att partials, or basis-space sums) and lin1 / lin2
+    assert pipe.collectives == 8 and len(pipe.spans) == 2 and n_lin in pipe.spans, (pipe.collectives, pipe.spans)
+    ts = (5 * 32 + 33) * 32
+    src = 4 * ts + 4 * ts // 32 * 4 if MODE == 'inside' else max(pipe.spans - {n_lin})
+    assert src in pipe.spans and (MODE == 'inside' or src < 4 * ts), pipe.spans
 # replicas stay bit-identical: every rank applied the same all-reduced gradients
 both = [torch.zeros(len(pipe.P)) for _ in range(world)]
 torch.distributed.all_gather(both, torch.from_numpy(pipe.P.copy()))
@@ -384,11 +411,14 @@ print('rank', rank, 'pipeline ok')
 '''
 
 
-def test_data_parallel_group_pipeline_gloo(tmp_path):
+@pytest.mark.parametrize('mode', ['inside', 'inside_layers', 'flat'])
+def test_data_parallel_group_pipeline_gloo(tmp_path, mode):
     """StepGraph's host logic (GroupPipeline) under data parallelism, two ranks over gloo, kernels on the emulator: a pair of
-    groups, the remainder and the ragged last batch of an epoch with ONE flat all-reduce per step between the gradient
-    kernels and the Adam / tick kernel.  Replicas end bit-identical, no stamp mismatch, the collective counts agree, and
-    the result equals the same epoch walked by direct host-argument calls."""
+    groups, the remainder and the ragged last batch of an epoch.  `inside`: the product's step, igmc_train_step_dp -- the
+    subgraph kernel's tables (`inside_layers`: the per-layer path's basis-space sums) and the lin gradients summed over the
+    ranks between their reduction and the gradient / Adam kernel, through a host-callback communicator; `flat`: gradient
+    kernels, ONE flat all-reduce, Adam / tick kernel as three calls.  Replicas end bit-identical, no stamp mismatch, the
+    collective counts and spans agree, and the result equals the same epoch walked by direct host-argument calls."""
     from helpers import emu_lib
     emu_lib()
     script = tmp_path / 'dpp.py'
@@ -396,7 +426,8 @@ def test_data_parallel_group_pipeline_gloo(tmp_path):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT='29617')
+                   MASTER_PORT=str(29617 + ['inside', 'inside_layers', 'flat'].index(mode)), DP_MODE=mode,
+                   IGMC_GRAPH_STEP='0' if mode == 'inside_layers' else '1')
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
