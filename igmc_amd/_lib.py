@@ -78,6 +78,7 @@ SIGNATURES = {
     'igmc_train_step': (i32, [vp, vp, vp, i32, vp, u64, u64, f32, f32, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32,
                               f32, f32, vp]),
     'igmc_step_finish': (i32, [vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp]),
+    'igmc_model_weights_unchanged': (i32, [vp, i32]),
     'igmc_profile_enable': (i32, [i32]),
     'igmc_profile_fetch': (i32, [vp, vp, vp, i32]),
     'igmc_profile_gs_clock': (i32, [vp, C.POINTER(i64), C.POINTER(f64), i32]),

@@ -96,8 +96,44 @@ struct igmc_model {
   ModelAux ax;
   int* done_ctr;
   int last_B, last_training, last_flags;
+  // weight images (g2_w) of the subgraph / dense-layer kernels: whose parameters they hold, and the caller's one-shot
+  // assertion that those parameters have not changed since the previous call (igmc_model_weights_unchanged)
+  int img_valid, img_hint;
+  const float* img_params;
   Allocs mem;
 };
+
+extern int g_igmc_compose_count;      // graphstep2.hip: launches of k_g2_compose so far
+
+// One call's view of the images: the compose launch is skipped when the caller asserted unchanged parameters AND the
+// library knows the images in place are those of the previous call's (possibly updated) parameters.
+struct ImgScope {
+  igmc_model* m;
+  const float* p;
+  int cur, before;
+  ImgScope(igmc_model* m_, const float* p_) : m(m_), p(p_) {
+    cur = m->img_hint && m->img_valid && m->img_params == p;
+    m->img_hint = 0;
+    m->d.img_current = cur;
+    before = g_igmc_compose_count;
+  }
+  void done_unchanged() {       // the call left the parameters as they were
+    m->img_valid = cur || g_igmc_compose_count != before;
+    m->img_params = p;
+    m->d.img_current = 0;
+  }
+  void done_updated(int emitted) {      // the call updated the parameters (images: only if its last kernel wrote them)
+    m->img_valid = emitted;
+    m->img_params = p;
+    m->d.img_current = 0;
+  }
+};
+
+extern "C" int igmc_model_weights_unchanged(igmc_model* m, int on) {
+  if (!m) IGMC_FAIL("null model");
+  m->img_hint = on ? 1 : 0;
+  return 0;
+}
 
 extern "C" const char* igmc_last_error(void) { return g_err.c_str(); }
 extern "C" int igmc_version(void) { return 100; }
@@ -644,7 +680,13 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   m->last_B = 0;
   m->last_training = 0;
   m->last_flags = 0;
+  m->img_valid = 0;
+  m->img_hint = 0;
+  m->img_params = nullptr;
   ModelDev& d = m->d;
+  d.img_current = 0;
+  d.adam_m1 = nullptr;
+  d.adam_m2 = nullptr;
   d.R = num_relations;
   d.Bs = 4;
   d.L = num_labels;
@@ -835,8 +877,10 @@ extern "C" int igmc_model_forward(igmc_model* m, const float* d_params, const ig
   if (!d_params || !d_out) IGMC_FAIL("null buffer");
   m->d.side = b->side;
   csr_for_model(m, b, !training, stream);
+  ImgScope img(m, d_params);
   igmc_launch_forward(m->d, m->ax, b->d, d_params, b->last_B, training, use_edge_flags, d_lin_mask, seed, step, multiply_by,
                       d_out, stream);
+  img.done_unchanged();
   HIPCHECK(hipGetLastError());
   m->last_B = b->last_B;
   m->last_training = training;
@@ -865,8 +909,10 @@ extern "C" int igmc_model_loss_grad(igmc_model* m, const float* d_params, const 
   if (!d_params || !d_out || !d_grad) IGMC_FAIL("null buffer");
   m->d.side = b->side;
   csr_for_model(m, b, 1, stream);
+  ImgScope img(m, d_params);
   igmc_launch_loss_grad(m->d, m->ax, b->d, (float*)d_params, b->last_B, use_edge_flags, d_lin_mask, seed, step,
                         multiply_by, ARR, grad_scale, arr_scale, d_out, d_grad, d_loss, nullptr, stream);
+  img.done_unchanged();
   HIPCHECK(hipGetLastError());
   m->last_B = b->last_B;
   m->last_training = 1;
@@ -953,6 +999,8 @@ extern "C" int igmc_step_finish(igmc_model* m, const igmc_batch* b, float* d_par
   }
   igmc_launch_finish(m->d, b->d, d_params, d_grad, d_exp_avg, d_exp_avg_sq, step_size, inv, beta1, beta2, eps,
                      weight_decay, d_ctrl, ARR, d_loss, d_total, m->last_flags, stream);
+  m->img_valid = 0;      // (the parameters moved, the weight images did not)
+  m->img_hint = 0;
   HIPCHECK(hipGetLastError());
   return 0;
 }
@@ -975,9 +1023,12 @@ extern "C" int igmc_train_step(igmc_model* m, float* d_params, const igmc_batch*
   }
   m->d.side = b->side;
   csr_for_model(m, b, 1, stream);
+  ImgScope img(m, d_params);
+  int emitted = 0;
   igmc_launch_train_step(m->d, m->ax, b->d, d_params, b->last_B, use_edge_flags, d_lin_mask, seed, step, multiply_by, ARR,
                          d_out, d_grad, d_exp_avg, d_exp_avg_sq, step_size, inv, beta1, beta2, eps, weight_decay, d_ctrl,
-                         m->done_ctr, d_loss, d_total, stream);
+                         m->done_ctr, d_loss, d_total, stream, 0.f, nullptr, &emitted);
+  img.done_updated(emitted);
   HIPCHECK(hipGetLastError());
   m->last_B = b->last_B;
   m->last_training = 1;
@@ -1174,19 +1225,24 @@ extern "C" int igmc_train_step_dp(igmc_model* m, igmc_comm* comm, float* d_param
   const float gscale = 1.0f / ((float)B * (float)world);
   m->d.side = b->side;
   csr_for_model(m, b, 1, stream);
+  ImgScope img(m, d_params);
+  int emitted = 0;
   if (igmc_step_exchange_inside(m->d, b->d, B)) {
     StepExchange x = {comm_sum2, comm};
     // (the ARR term depends on the weights only: every rank adds it in full AFTER the exchange)
-    if (igmc_launch_train_step(m->d, m->ax, b->d, d_params, B, use_edge_flags, d_lin_mask, seed, step, multiply_by, ARR, d_out,
-                               d_grad, d_exp_avg, d_exp_avg_sq, step_size, inv, beta1, beta2, eps, weight_decay, d_ctrl,
-                               m->done_ctr, d_loss, d_total, stream, gscale, comm ? &x : nullptr))
-      return 1;
+    const int rc = igmc_launch_train_step(m->d, m->ax, b->d, d_params, B, use_edge_flags, d_lin_mask, seed, step, multiply_by,
+                                          ARR, d_out, d_grad, d_exp_avg, d_exp_avg_sq, step_size, inv, beta1, beta2, eps,
+                                          weight_decay, d_ctrl, m->done_ctr, d_loss, d_total, stream, gscale,
+                                          comm ? &x : nullptr, &emitted);
+    img.done_updated(emitted);
+    if (rc) return 1;
   } else {
     igmc_launch_loss_grad(m->d, m->ax, b->d, d_params, B, use_edge_flags, d_lin_mask, seed, step, multiply_by, ARR, gscale,
                           1.0f / (float)world, d_out, d_grad, nullptr, nullptr, stream);
     if (comm && comm_sum2(comm, d_grad, m->d.n_params, nullptr, 0, stream)) return 1;
     igmc_launch_finish(m->d, b->d, d_params, d_grad, d_exp_avg, d_exp_avg_sq, step_size, inv, beta1, beta2, eps,
                        weight_decay, d_ctrl, ARR, d_loss, d_total, use_edge_flags, stream);
+    img.done_updated(0);
   }
   HIPCHECK(hipGetLastError());
   m->last_B = B;

@@ -32,23 +32,18 @@
 // Eligibility (else the per-layer kernels run): dense block present, R <= 5, layer-0 table <= 32 rows,
 // no side features, both sides <= 16 * (2 * cluster size) <= 128 rows.
 #include "launch.h"
+#include "g2_image.h"
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
 #define G2_THREADS 256
 #define G2_NW 4
-#define G2_NR 5                   // relations the fragments are built for (R <= G2_NR)
 #define G2_KS 4                   // k-steps of 32 opposite-side nodes (K <= 128)
-#define G2_NT 3                   // bf16 terms of an f32 value
 #define G2_TP (G2_NR * 32 + 4)    // pitch of a wave's 16-row T' tile (backward)
 #define G2_XP 36                  // pitch of a wave's 16-row x / dPre / h tile
 #define G2_FXTAG 7                // exchange index of the centre-node readout
-// One staged weight image = the B operand of a layer's dense transform as bf16 terms, in MFMA fragment order:
-// [term (hi, mid, lo)][block (relation 0..4, 5 = root)][16-column tile nt][lane] x 8 bf16; lane (li = column n & 15,
-// kq) holds rows k(kq, e) = (e < 4 ? 4 kq + e : 16 + 4 kq + e - 4) of its block -- the order in which the gather's
-// accumulators hold the input features of a row.
-#define G2_WIMG (G2_NT * (G2_NR + 1) * 2 * 64 * 4)   // 4-byte words of one staged image (36 KB)
+// (layout of the staged weight images: g2_image.h)
 
 // phase clocks (debug aid, IGMC_GS_TIMING=1; igmc_debug_g2_clocks): thread 0 of workgroup 0 (member 0, user side) -> slots
 // 0..39 (fine stamps of its wave 0: 40..63), thread 0 of member 2 of the same subgraph (item side) -> slots 64..103
@@ -78,8 +73,6 @@ __device__ unsigned long long g_g2_wg[1024][3];
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #ifndef IGMC_HIPEMU
 typedef __bf16 g2_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 g2_bf16x2 __attribute__((ext_vector_type(2)));
-typedef float g2_f32x2 __attribute__((ext_vector_type(2)));
 #endif
 
 __device__ __forceinline__ f32x4 g2_mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
@@ -88,24 +81,6 @@ __device__ __forceinline__ f32x4 g2_mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
 #else
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(g2_bf16x8, a), __builtin_bit_cast(g2_bf16x8, b), c, 0, 0, 0);
 #endif
-}
-
-// {bf16(x) | bf16(y) << 16}, round to nearest even (v_cvt_pk_bf16_f32)
-__device__ __forceinline__ uint32_t g2_pk_bf16(float x, float y) {
-#ifdef IGMC_HIPEMU
-  return hipemu_f32_to_bf16_rne(x) | (hipemu_f32_to_bf16_rne(y) << 16);
-#else
-  g2_f32x2 v = {x, y};
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, g2_bf16x2));
-#endif
-}
-// the three bf16 terms of two f32 values: hi + mid + lo == x to 24 bits (each residual is exact in f32)
-__device__ __forceinline__ void g2_split2(float x, float y, uint32_t& h, uint32_t& mi, uint32_t& lo) {
-  h = g2_pk_bf16(x, y);
-  const float rx = x - __uint_as_float(h << 16), ry = y - __uint_as_float(h & 0xFFFF0000u);
-  mi = g2_pk_bf16(rx, ry);
-  const float sx = rx - __uint_as_float(mi << 16), sy = ry - __uint_as_float(mi & 0xFFFF0000u);
-  lo = g2_pk_bf16(sx, sy);
 }
 
 // four relm bytes (bits 0..2: relation + 1, bit 3 / 4: keep flags of the two directions) -> two dwords of bf16 pairs
@@ -1182,8 +1157,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_compose(ModelDev m, const flo
       float sacc = rv[q];
       if (c < RL) {
         const int r = c / L;
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) sacc += s_att[r * 4 + bb] * bv[q][bb];
+        sacc = g2_wsum(s_att[r * 4], s_att[r * 4 + 1], s_att[r * 4 + 2], s_att[r * 4 + 3], bv[q][0], bv[q][1], bv[q][2], bv[q][3]);
       }
       w[6 * G2_WIMG + i] = sacc;
     }
@@ -1221,9 +1195,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_compose(ModelDev m, const flo
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb) at[bb] = P[m.off_att[l] + r * 4 + bb];
 #pragma unroll
-    for (int bb = 0; bb < 4; ++bb)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] += at[bb] * bq[bb][q];
+    for (int q = 0; q < 4; ++q) v[q] = g2_wsum(at[0], at[1], at[2], at[3], bq[0][q], bq[1][q], bq[2][q], bq[3][q]);
   }
   uint32_t h01, m01, l01, h23, m23, l23;
   g2_split2(v[0], v[1], h01, m01, l01);
@@ -1315,6 +1287,8 @@ int igmc_g2_eligible(const ModelDev& m, const BatchDev& b, int B, G2Layout* lay,
 }
 
 // returns 1 when the launch leaves the advance of the launch sequence number to the caller's next kernel (k_tail_ts)
+int g_igmc_compose_count = 0;      // launches of k_g2_compose so far (capi.hip: did a call refresh the weight images)
+
 int igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* P, int B, int training, int use_flags,
                             const G2Layout& lay, int cs, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
                             float grad_scale, float* out, void* stream) {
@@ -1347,7 +1321,10 @@ int igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* P
   a.stride = (cs > 1) ? ((B + 7) & ~7) : 1;
   const int grid = (cs > 1) ? cs * B : igmc_gs_grid(B);
   const size_t sm = (size_t)lay.words * 4;
-  IGMC_PLAUNCH("k_g2_compose", k_g2_compose, 2 * 3 * (G2_NR + 1) + 1, G2_THREADS, 0, stream, m, P, m.g2_w);
+  if (!m.img_current) {
+    IGMC_PLAUNCH("k_g2_compose", k_g2_compose, 2 * 3 * (G2_NR + 1) + 1, G2_THREADS, 0, stream, m, P, m.g2_w);
+    ++g_igmc_compose_count;
+  }
 #ifdef IGMC_HIPEMU
   if (cs > 1) {        // (after the launch above: a launch consumes the co-residency request)
     hipemu::rt().co_cs = cs;
@@ -1849,6 +1826,8 @@ int igmc_dl_grid(const BatchDev& b, int B) {
 }
 
 void igmc_launch_g2_compose(const ModelDev& m, const float* P, void* stream) {
+  if (m.img_current) return;      // (igmc_model_weights_unchanged: the images of these parameters are in place)
+  ++g_igmc_compose_count;
   IGMC_PLAUNCH("k_g2_compose", k_g2_compose, 2 * 3 * (G2_NR + 1) + 1, G2_THREADS, 0, stream, m, P, m.g2_w);
 }
 

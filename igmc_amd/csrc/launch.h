@@ -60,13 +60,14 @@ int igmc_step_exchange_inside(const ModelDev& m, const BatchDev& b, int B);
 int igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev& b, float* P, int B, int use_flags,
                           const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult, float ARR,
                           float grad_scale, float arr_scale, float* out, float* grad, float* loss, const AdamTail* adam,
-                          void* stream, const StepExchange* xch = nullptr);
-// (grad_scale 0: 1 / B; xch: see StepExchange -- only where igmc_step_exchange_inside() says so)
+                          void* stream, const StepExchange* xch = nullptr, int* img_emitted = nullptr);
+// (grad_scale 0: 1 / B; xch: see StepExchange -- only where igmc_step_exchange_inside() says so; *img_emitted = 1 when the
+//  step's last kernel also left the weight images of the updated parameters in m.g2_w)
 int igmc_launch_train_step(const ModelDev& m, const ModelAux& ax, const BatchDev& b, float* P, int B, int use_flags,
                            const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult, float ARR, float* out,
                            float* grad, float* m1, float* m2, float step_size, float inv_sqrt_bc2, float beta1,
                            float beta2, float eps, float wd, int64_t* ctrl, int* done, float* loss, double* total,
-                           void* stream, float grad_scale = 0.f, const StepExchange* xch = nullptr);
+                           void* stream, float grad_scale = 0.f, const StepExchange* xch = nullptr, int* img_emitted = nullptr);
 void igmc_launch_loss(const ModelDev& m, const BatchDev& b, float ARR, float* loss, void* stream);
 void igmc_launch_sse(const BatchDev& b, const float* out, double* acc, void* stream);
 int igmc_model_prepare(const ModelDev& m);

@@ -22,6 +22,7 @@
 //     kernel), the three Y products and the three weight-gradient products are batched into one launch
 //     each (blockIdx.y = layer), and loss / epoch-total / control-block tick ride in the Adam kernel.
 #include "model.h"
+#include "g2_image.h"
 #include <stdlib.h>
 
 // ---- XCD affinity -------------------------------------------------------------------------------------
@@ -1402,6 +1403,8 @@ __device__ __forceinline__ void reduce_ts_body(const ModelDev& m, int nparts, in
 #define IGMC_STASH_G 0
 #define IGMC_STASH_M 16
 #define IGMC_STASH_ATT 64
+#define IGMC_STASH_ATTM1 192      // Adam moments of att before the step (R <= 8; k_finalize_ts with img: every workgroup of
+#define IGMC_STASH_ATTM2 224      // the layer forms the new att, while the owner updates the moments in place)
 #define IGMC_STASH_LAYER 256
 #define IGMC_STASH_SCAL (4 * IGMC_STASH_LAYER)
 __device__ __forceinline__ void fin_stash_body(const ModelDev& m, const float* __restrict__ P, int l,
@@ -1438,7 +1441,13 @@ __device__ __forceinline__ void fin_stash_body(const ModelDev& m, const float* _
     }
     st[IGMC_STASH_M + tid - 64] = sacc;
   }
-  if (tid >= 128 && tid < 128 + na && na <= IGMC_STASH_LAYER - IGMC_STASH_ATT) st[IGMC_STASH_ATT + tid - 128] = att[tid - 128];
+  if (tid >= 128 && tid < 128 + na && na <= IGMC_STASH_LAYER - IGMC_STASH_ATT) {
+    st[IGMC_STASH_ATT + tid - 128] = att[tid - 128];
+    if (m.adam_m1 && na <= 32) {
+      st[IGMC_STASH_ATTM1 + tid - 128] = m.adam_m1[m.off_att[l] + tid - 128];
+      st[IGMC_STASH_ATTM2 + tid - 128] = m.adam_m2[m.off_att[l] + tid - 128];
+    }
+  }
   if (l == 0 && ctrl && tid >= 192 && tid < 198) {
     const double* d = (const double*)ctrl;
     const int k = tid - 192;
@@ -1804,22 +1813,32 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize(ModelDev m, const float
 // (k_finalize needs two in-kernel hand-offs for the same work -- layer-wide before Adam, grid-wide before the tick --
 //  each an agent-scope fence pair + an atomic round trip.)
 #define IGMC_FTS_NB 4
-__device__ __forceinline__ void fts_emit(float* __restrict__ grad, const AdamTail& at, int64_t i, float g, float pold,
-                                         float m1old, float m2old) {
-  grad[i] = g;
-  if (at.enabled) {
-    float gi = g;
-    if (at.wd != 0.f) gi += at.wd * pold;
-    const float a = at.beta1 * m1old + (1.f - at.beta1) * gi;
-    const float v = at.beta2 * m2old + (1.f - at.beta2) * gi * gi;
+// gradient g of parameter i -> flat gradient, Adam moments, parameter; returns the parameter's value after the step.
+// store = false: the value only (a workgroup that needs a neighbour's updated parameter forms it itself; the owner stores)
+__device__ __forceinline__ float fts_emit(float* __restrict__ grad, const AdamTail& at, int64_t i, float g, float pold,
+                                          float m1old, float m2old, bool store = true) {
+  if (store) grad[i] = g;
+  if (!at.enabled) return pold;
+  float gi = g;
+  if (at.wd != 0.f) gi += at.wd * pold;
+  const float a = at.beta1 * m1old + (1.f - at.beta1) * gi;
+  const float v = at.beta2 * m2old + (1.f - at.beta2) * gi * gi;
+  const float pnew = pold - at.step_size * a / (sqrtf(v) * at.inv_sqrt_bc2 + at.eps);
+  if (store) {
     at.m1[i] = a;
     at.m2[i] = v;
-    at.p[i] = pold - at.step_size * a / (sqrtf(v) * at.inv_sqrt_bc2 + at.eps);
+    at.p[i] = pnew;
   }
+  return pnew;
 }
 
+// img != 0 (with Adam): the weight images of the UPDATED parameters are written too -- what k_g2_compose would form from
+// them for the next step's subgraph / dense-layer kernels (g2_image.h): a thread holds the new basis_0..3[c][f] and
+// root[c][f] of its column; the layer's new att (20 values) is formed by EVERY workgroup of the layer (the owner stores it),
+// so W_r[c][f] = sum_b att[r,b] basis_b[c][f] needs nothing from another workgroup.  The next step then starts with the
+// subgraph kernel: one launch and one round trip to the weights less per step.
 __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const float* P, float* __restrict__ grad,
-                                                              float arr_coef, AdamTail at, int nlin, int bs) {
+                                                              float arr_coef, AdamTail at, int nlin, int bs, int img) {
   // bs != 0: the per-layer path's sources -- conv layers 1..3 in BASIS space (graw: d basis_b, d root, d bias straight
   // from the weight-gradient kernel, d att from the layer kernels' partials), layer 0 as its relation-space table in graw;
   // the stash comes from k_reduce_partials.  bs == 0: the relation-space tables of the subgraph kernels (ts_raw).
@@ -1900,6 +1919,10 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
       }
       __syncthreads();
     }
+    __shared__ float s_attn[32];                // the layer's att after the step (img)
+    float pn[5] = {0.f, 0.f, 0.f, 0.f, 0.f};    // this thread's basis_0..3[c][f], root[c][f] after the step (img)
+    int e_img = -1;
+    const bool emit = img && at.enabled && m.g2_w && R <= G2_NR && fin <= 32;
     for (int e = part * IGMC_BLOCK + tid; e < nE; e += IGMC_FTS_NB * IGMC_BLOCK) {       // one round for fin <= 32
       int64_t idx[5];
       float pv[5], m1v[5], m2v[5], g[5];
@@ -1939,18 +1962,22 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
                                st[IGMC_STASH_M + bb * 4 + 2] * pv[2] + st[IGMC_STASH_M + bb * 4 + 3] * pv[3]);
       }
 #pragma unroll
-      for (int q = 0; q < 5; ++q) fts_emit(grad, at, idx[q], g[q], pv[q], m1v[q], m2v[q]);
+      for (int q = 0; q < 5; ++q) pn[q] = fts_emit(grad, at, idx[q], g[q], pv[q], m1v[q], m2v[q]);
+      e_img = e;
     }
-    if (part == 0) {
-      if (tid < 32) {                              // d bias
+    if (part == 0 || emit) {
+      if (tid < 32 && part == 0) {                 // d bias
         const int64_t i = m.off_bias[l] + tid;
-        fts_emit(grad, at, i, table ? t0[(size_t)(R * fin + fin) * 32 + tid] : raw[32 * IGMC_KCAT + tid], P[i],
-                 at.enabled ? at.m1[i] : 0.f, at.enabled ? at.m2[i] : 0.f);
+        const float bnew = fts_emit(grad, at, i, table ? t0[(size_t)(R * fin + fin) * 32 + tid] : raw[32 * IGMC_KCAT + tid],
+                                    P[i], at.enabled ? at.m1[i] : 0.f, at.enabled ? at.m2[i] : 0.f);
+        if (emit && l == 0) m.g2_w[6 * G2_WIMG + (R * fin + fin) * 32 + tid] = bnew;       // layer-0 table: bias row
       } else if (tid >= 64 && tid < 64 + na) {     // d att[r,b] = <dW_r, basis_b> (+ ARR): fin partials, fixed order
         const int rb = tid - 64, r = rb >> 2, bb = rb & 3;
         const int64_t i = m.off_att[l] + rb;
         const float pold = st[IGMC_STASH_ATT + rb];
-        const float m1o = at.enabled ? at.m1[i] : 0.f, m2o = at.enabled ? at.m2[i] : 0.f;
+        // (img: the moments before the step come from the stash -- the owner workgroup updates them in place meanwhile)
+        const float m1o = !at.enabled ? 0.f : emit ? st[IGMC_STASH_ATTM1 + rb] : at.m1[i];
+        const float m2o = !at.enabled ? 0.f : emit ? st[IGMC_STASH_ATTM2 + rb] : at.m2[i];
         float g = 0.f;
         if (bs) {
           g = (l == 0) ? s_gatt0[rb] : m.graw[3 * wgs + (size_t)(l - 1) * na + rb];
@@ -1974,7 +2001,38 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
           }
           g += arr_coef * sacc;
         }
-        fts_emit(grad, at, i, g, pold, m1o, m2o);
+        const float anew = fts_emit(grad, at, i, g, pold, m1o, m2o, part == 0);
+        if (emit) s_attn[rb] = anew;
+      }
+    }
+    if (emit) {
+      __syncthreads();
+      if (e_img >= 0) {
+        const int c = e_img >> 5, f = e_img & 31;
+        if (l == 0) {       // layer-0 table [W_0[r * L + c] | root_0[c] | bias_0] (rows past R L + L stay zero: first compose)
+          float* t0w = m.g2_w + 6 * G2_WIMG;
+          for (int r = 0; r < R; ++r)
+            t0w[(r * fin + c) * 32 + f] = g2_wsum(s_attn[r * 4], s_attn[r * 4 + 1], s_attn[r * 4 + 2], s_attn[r * 4 + 3],
+                                                  pn[0], pn[1], pn[2], pn[3]);
+          t0w[(R * fin + c) * 32 + f] = pn[4];
+        } else {            // forward image: element (k = c, n = f); transposed image: element (k = f, n = c)
+          uint16_t* imf = (uint16_t*)(m.g2_w + (size_t)(l - 1) * 2 * G2_WIMG);
+          uint16_t* imt = (uint16_t*)(m.g2_w + (size_t)(l - 1) * 2 * G2_WIMG + G2_WIMG);
+#pragma unroll
+          for (int r = 0; r <= G2_NR; ++r) {
+            if (r >= R && r < G2_NR) continue;     // (blocks of relations the model does not have stay zero)
+            const float v = (r == G2_NR) ? pn[4]
+                          : g2_wsum(s_attn[r * 4], s_attn[r * 4 + 1], s_attn[r * 4 + 2], s_attn[r * 4 + 3], pn[0], pn[1], pn[2], pn[3]);
+            uint32_t h, mi, lo;
+            g2_split2(v, 0.f, h, mi, lo);
+            const uint32_t t3[3] = {h, mi, lo};
+#pragma unroll
+            for (int t = 0; t < G2_NT; ++t) {
+              imf[g2_img_index(t, r, c, f)] = (uint16_t)t3[t];
+              imt[g2_img_index(t, r, f, c)] = (uint16_t)t3[t];
+            }
+          }
+        }
       }
     }
   } else if ((int)blockIdx.x < 4 * IGMC_FTS_NB + nlin) {      // Adam on lin1 / lin2 (their gradients are final already)
@@ -2236,11 +2294,18 @@ int igmc_step_exchange_inside(const ModelDev& m, const BatchDev& b, int B) {
   return igmc_fin_mode() && m.fin_stash && m.R <= 32;
 }
 
-int igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev& b, float* P, int B, int use_flags,
+int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchDev& b, float* P, int B, int use_flags,
                           const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult, float ARR,
                           float grad_scale, float arr_scale, float* out, float* grad, float* loss, const AdamTail* adam,
-                          void* stream, const StepExchange* xch) {
+                          void* stream, const StepExchange* xch, int* img_emitted) {
+  ModelDev m = m_in;
+  m.adam_m1 = adam ? adam->m1 : nullptr;       // (the stash roles keep att's moments of before the step)
+  m.adam_m2 = adam ? adam->m2 : nullptr;
+  if (img_emitted) *img_emitted = 0;
   const int rows0 = m.R * m.L + m.L + 1;
+  // the gradient / Adam kernel also leaves the weight images of the updated parameters (IGMC_EMIT_IMAGES=0: never)
+  const char* ee = getenv("IGMC_EMIT_IMAGES");
+  const int img = adam && !(ee && atoi(ee) == 0) && m.g2_w && m.R <= G2_NR && rows0 <= 32;
   const int l0_mfma = rows0 <= 32;
   const int gy = igmc_rows_grid(m.node_cap, 128, 512);
   const int hb = (B + 15) / 16;
@@ -2285,10 +2350,12 @@ int igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev&
       at.enabled = 1;
       at.b = b;
       at.ARR = ARR;
-      if (fts) IGMC_PLAUNCH("k_finalize_adam", k_finalize_ts, 4 * IGMC_FTS_NB + 32 + 1, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 32, 0);
-      else IGMC_PLAUNCH("k_finalize_adam", k_finalize, 4 * IGMC_FIN_NB + 32, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 1);
+      if (fts) {
+        IGMC_PLAUNCH("k_finalize_adam", k_finalize_ts, 4 * IGMC_FTS_NB + 32 + 1, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 32, 0, img);
+        if (img_emitted) *img_emitted = img;
+      } else IGMC_PLAUNCH("k_finalize_adam", k_finalize, 4 * IGMC_FIN_NB + 32, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 1);
     } else {
-      if (fts) IGMC_PLAUNCH("k_finalize", k_finalize_ts, 4 * IGMC_FTS_NB, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 0, 0);
+      if (fts) IGMC_PLAUNCH("k_finalize", k_finalize_ts, 4 * IGMC_FTS_NB, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 0, 0, 0);
       else IGMC_PLAUNCH("k_finalize", k_finalize, 4 * IGMC_FIN_NB, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 1);
       if (loss) igmc_launch_loss(m, b, ARR, loss, stream);
     }
@@ -2355,9 +2422,10 @@ int igmc_launch_loss_grad(const ModelDev& m, const ModelAux& ax, const BatchDev&
         at.enabled = 1;
         at.b = b;
         at.ARR = ARR;
-        IGMC_PLAUNCH("k_finalize_adam", k_finalize_ts, 4 * IGMC_FTS_NB + 32 + 1, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 32, 1);
+        IGMC_PLAUNCH("k_finalize_adam", k_finalize_ts, 4 * IGMC_FTS_NB + 32 + 1, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 32, 1, img);
+        if (img_emitted) *img_emitted = img;
       } else {
-        IGMC_PLAUNCH("k_finalize", k_finalize_ts, 4 * IGMC_FTS_NB, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 0, 1);
+        IGMC_PLAUNCH("k_finalize", k_finalize_ts, 4 * IGMC_FTS_NB, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 0, 1, 0);
         if (loss) igmc_launch_loss(m, b, ARR, loss, stream);
       }
       return 0;
@@ -2379,14 +2447,15 @@ int igmc_launch_train_step(const ModelDev& m, const ModelAux& ax, const BatchDev
                            const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult, float ARR, float* out,
                            float* grad, float* m1, float* m2, float step_size, float inv_sqrt_bc2, float beta1,
                            float beta2, float eps, float wd, int64_t* ctrl, int* done, float* loss, double* total,
-                           void* stream, float grad_scale, const StepExchange* xch) {
+                           void* stream, float grad_scale, const StepExchange* xch, int* img_emitted) {
   AdamTail at;
   memset(&at, 0, sizeof(at));
   at.p = P; at.m1 = m1; at.m2 = m2;
   at.step_size = step_size; at.inv_sqrt_bc2 = inv_sqrt_bc2; at.beta1 = beta1; at.beta2 = beta2; at.eps = eps; at.wd = wd;
   at.ctrl = ctrl; at.done = done; at.loss = loss; at.total = total;
   return igmc_launch_loss_grad(m, ax, b, P, B, use_flags, inj_mask, seed, step, mult, ARR,
-                               grad_scale != 0.f ? grad_scale : 1.0f / (float)B, 1.0f, out, grad, nullptr, &at, stream, xch);
+                               grad_scale != 0.f ? grad_scale : 1.0f / (float)B, 1.0f, out, grad, nullptr, &at, stream, xch,
+                               img_emitted);
 }
 
 void igmc_launch_loss(const ModelDev& m, const BatchDev& b, float ARR, float* loss, void* stream) {

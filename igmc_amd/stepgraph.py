@@ -126,9 +126,16 @@ class GroupPipeline(object):
         # the model kernels are enqueued BEFORE the extraction branch: the subgraph kernel (one workgroup per CU on 200 of
         # 256 CUs) is dispatched first and the extraction workgroups fill what is left
         for i in range(self.M):
+            if q == 1 or i > 0:
+                # inside a pair of groups nothing but the previous step touches the parameters: that step left the weight
+                # images of its updated parameters behind, this one starts with the subgraph kernel
+                self._hint_unchanged()
             self._enqueue_step(cur[i], self.B)
         self._side(lambda: self._extract_many(1 - q, self.M))
         self._join()
+
+    def _hint_unchanged(self):
+        """Backends that keep weight images tell the library that the parameters are those of the previous step."""
 
     def _enqueue_pair(self):
         """One graph launch: the group of parity 0, then the group of parity 1 (2 M steps)."""
@@ -364,6 +371,10 @@ class StepGraph(GroupPipeline):
     def _count(self, n):
         self.model._step += n
         self.opt.t += n
+
+    def _hint_unchanged(self):
+        if self.sp is None and os.environ.get('IGMC_EMIT_IMAGES', '1') != '0':
+            self.lib.call('igmc_model_weights_unchanged', self.ws.handle, 1)
 
     # ------------------------------------------------------------------ one step
     def _model(self, arena, B):

@@ -246,6 +246,18 @@ int igmc_train_step(igmc_model* m, float* d_params, const igmc_batch* b, int use
                     float* d_out, float* d_grad, float* d_exp_avg, float* d_exp_avg_sq, float* d_loss,
                     double* d_total, int64_t* d_ctrl, int64_t adam_t, float lr, float beta1, float beta2,
                     float eps, float weight_decay, void* stream);
+
+/* Weight images.  The subgraph kernel and the dense per-layer kernels read each conv layer's weights as staged images
+ * (W_r = sum_b att[r,b] basis_b per relation, split into bf16 terms in MFMA fragment order; the layer-0 table), composed
+ * from d_params by a small kernel at the start of every forward / step.  igmc_train_step[_dp]'s last kernel (gradient +
+ * Adam) ALSO writes the images of the parameters it has just updated, and an evaluation leaves the images of its
+ * parameters behind -- so a caller that knows d_params has not been touched since the PREVIOUS call on this model (the
+ * next step of a training loop, the next batch of an evaluation) says so, and that call starts with the subgraph kernel:
+ * one launch less per step.  One-shot: applies to the next igmc_model_forward / igmc_model_loss_grad / igmc_train_step /
+ * igmc_train_step_dp on `m` only, and only if the library itself left the images of the same d_params pointer behind
+ * (else it composes as usual).  Never assert it after changing the parameters by other means (igmc_adam_step, a
+ * checkpoint load, a broadcast).  Reference: there is none -- PyG's RGCNConv forms W_r on every forward (models.py:200). */
+int igmc_model_weights_unchanged(igmc_model* m, int on);
 int igmc_adam_step_ctrl(float* d_params, const float* d_grad, float* d_exp_avg, float* d_exp_avg_sq,
                         int64_t n, const int64_t* d_ctrl, void* stream);
 

@@ -236,3 +236,81 @@ def test_group_control_walks_the_same_batches():
     for a, b in zip(rec, rec_g):
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize('paths', ['1', '1:4', '0', '0then1', '1then0'])
+def test_weight_images_left_by_the_step_equal_the_composed_ones(monkeypatch, paths):
+    """igmc_train_step's gradient / Adam kernel also writes the weight images of the parameters it has just updated
+    (k_finalize_ts, img), and a caller that asserts unchanged parameters (igmc_model_weights_unchanged) skips k_g2_compose
+    at the next call.  Five steps + an evaluation forward with the assertion before every call but the first must give
+    exactly what the same calls give when every one of them composes the images from the parameters -- for the subgraph
+    kernel's tail (relation-space tables; one workgroup or a cluster of 4 per subgraph), the per-layer kernels' tail
+    (basis-space sums), and steps that alternate between the two (images written by one tail, consumed after the other)."""
+    be = PC.EmuBackend()
+    lib = be.lib
+    case = CASES['synth_cap']
+    g = engine.Graph(case['A'], lib=lib)
+    lu = case['links'][:, 0].astype(np.int32).copy()
+    lv = case['links'][:, 1].astype(np.int32).copy()
+    ly = case['class_values'][case['link_labels']].astype(np.float32)
+    rng = np.random.default_rng(1)
+    perm = np.concatenate([rng.permutation(len(lu)) for _ in range(3)]).astype(np.int32)      # (six batches of 4)
+    B = 4
+    batch = engine.Batch(g, B, 1, case['mnph'])
+    ws = engine.ModelWorkspace(lib, 0, 5, 4, 4, 0, batch.node_capacity, batch.edge_capacity, B)
+    P0 = PC.flatten_params(ws, PC.make_ref_model(4, 5, seed=4))
+    vp = lambda a: C.c_void_p(a.ctypes.data)
+
+    def env_of(i):
+        seq = {'0then1': '01010', '1then0': '10101'}.get(paths)
+        gs, _, cl = (seq[i] if seq else paths).partition(':')
+        monkeypatch.setenv('IGMC_GRAPH_STEP', gs)
+        if cl:
+            monkeypatch.setenv('IGMC_GS_CLUSTER', cl)
+
+    def run(hint, emit):
+        monkeypatch.setenv('IGMC_EMIT_IMAGES', '1' if emit else '0')
+        engine.profile_fetch(lib)
+        engine.profile_enable(lib, True)
+        lib.call('igmc_model_set_ctrl', ws.handle, None)
+        P, M1, M2, G = P0.copy(), np.zeros_like(P0), np.zeros_like(P0), np.zeros_like(P0)
+        out, loss, total = np.zeros(B, np.float32), np.zeros(2, np.float32), np.zeros(1, np.float64)
+        rec = []
+        for i in range(5):
+            env_of(i)
+            batch.extract(lu, lv, ly, perm, i * B, B, 1.0, 7, 3)
+            batch.edge_dropout(0.2, False, 7, (3 << 32) ^ i)
+            if hint and i > 0:
+                lib.call('igmc_model_weights_unchanged', ws.handle, 1)
+            lib.call('igmc_train_step', ws.handle, vp(P), batch.handle, 1, None, 7, 11 + i, 1.0, 0.001, vp(out), vp(G),
+                     vp(M1), vp(M2), vp(loss), vp(total), None, i + 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, None)
+            rec.append((out.copy(), loss.copy(), P.copy(), M1.copy(), M2.copy()))
+        env_of(4)
+        batch.extract(lu, lv, ly, perm, 5 * B, B, 1.0, 7, 3)
+        ev = []
+        for rep in range(2):           # evaluation on the trained weights: the second forward also rides on the first's images
+            if hint:
+                lib.call('igmc_model_weights_unchanged', ws.handle, 1)
+            ws.forward(P.ctypes.data, batch, out.ctypes.data, training=False)
+            ev.append(out.copy())
+        engine.profile_enable(lib, False)
+        composes = sum(c for n, _, c in engine.profile_fetch(lib) if n == 'k_g2_compose')
+        return rec, ev, composes
+
+    ref, ref_ev, n_ref = run(False, False)
+    uses = {'1': 7, '1:4': 7, '0': 0, '0then1': 2, '1then0': 5}[paths]      # calls of the seven that read the images
+    ev_uses = paths in ('1', '1:4', '1then0')                                # ... the two evaluation forwards among them
+    assert n_ref == uses
+    for what, (rec, ev, n) in (('emit, composed anyway', run(False, True)), ('emit + skip', run(True, True)),
+                               ('assertion without emission', run(True, False))):
+        # with both the emission and the caller's assertion only the very first call composes (not even that one when a step
+        # on the per-layer kernels came first: its tail left the images); without the emission an asserted call still
+        # composes after a step (the parameters moved), but not after a forward
+        assert n == {'emit, composed anyway': uses, 'emit + skip': 1 if ev_uses else 0,
+                     'assertion without emission': uses - (1 if ev_uses else 0)}[what], (what, n)
+        for i, (a, b) in enumerate(zip(ref, rec)):
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), (what, 'step', i)
+        for a, b in zip(ref_ev, ev):
+            assert np.array_equal(a, b), (what, 'eval')
+    assert np.array_equal(ref_ev[0], ref_ev[1])

@@ -296,6 +296,7 @@ class EmuPipeline(stepgraph.GroupPipeline):
         self.M1, self.M2, self.G = np.zeros_like(self.P), np.zeros_like(self.P), np.zeros_like(self.P)
         self.out, self.loss, self.total = np.zeros(B, np.float32), np.zeros(2, np.float32), np.zeros(1, np.float64)
         self.collectives = 0
+        self.hints = 0
         self.spans = set()
 
         def host_sum(ptr, n, stream):          # sum over the ranks of the n floats at ptr, in place
@@ -334,6 +335,10 @@ class EmuPipeline(stepgraph.GroupPipeline):
     def _dev_regroup(self, first_cur, first_next):
         lib.call('igmc_ctrl_regroup', vp(self.ctrl), self.M, first_cur, first_next, None)
 
+    def _hint_unchanged(self):             # (StepGraph's: inside a pair of groups the parameters are the previous step's)
+        lib.call('igmc_model_weights_unchanged', self.ws.handle, 1)
+        self.hints += 1
+
     def _fork(self):
         pass
 
@@ -368,6 +373,7 @@ pipe = EmuPipeline()
 pipe.run_epoch(mine, 3)
 K = _lib.CTRL
 assert pipe.ctrl[K['SYNC_ERR']] == 0 and pipe.ctrl[K['K']] == 4
+assert pipe.hints == 1                     # one pair of groups of M = 1: its second step rides on the first one's images
 n_lin = 128 * 256 + 128 + 128 + 1
 if MODE == 'flat':
     assert pipe.collectives == 4
