@@ -1388,6 +1388,12 @@ struct DlArgs {
   const float* img;        // the layer's weight image (forward) / transposed image (backward)
   const float* bias;       // forward
   const float* att;        // backward: [R, 4]
+  // backward with relation-space tables (TS): the workgroup's partial table h_{l-1}^T [T'_r | dPre_l] (+ d bias_l) instead
+  // of G / the d att partials -- what k_tail_ts sums and k_finalize_ts turns into gradients, as after k_graph_step2
+  float* ts_part;          // [4][IGMC_TS_BLOCKS][ts_stride]
+  int ts_stride, slot_stride, L;
+  const uint16_t* cnt0;    // l == 1: [N, R * L] neighbour-label histograms of layer 0 (k_dl_layer0) ...
+  const uint8_t* node_label;   // ... and the nodes' own labels: the layer-0 table gradient is formed here too
 };
 
 // acc += a * b as ONE scalar VALU fma.  The d att partials of k_dl_layer<BWD> are 160 of these per lane; left to the
@@ -1403,8 +1409,17 @@ struct DlArgs {
 #define DL_THREADS (64 * DL_NW)
 #define DL_PIT 2                  // plane-staging items per thread: 128 * k-steps / DL_THREADS, k-steps <= 8
 #define DL_RIT 17                 // block-row dwords per lane: 16 rows x (32 * k-steps + 8) / 4 / 64, k-steps <= 8
-template <bool FLAGS, bool BWD>
+// LDS plan (4-byte words): [own rows XOA][TS: h_{l-1} rows HSA, d bias scratch][planes | block rows | weight image][sums]
+// -- with TS the T' tiles of the table product ALIAS planes / block rows / image (all dead after the transform)
+__host__ __device__ static inline int dl_words_x() { return DL_NW * 16 * G2_XP; }
+__host__ __device__ static inline int dl_words_front(bool ts) { return dl_words_x() * (ts ? 2 : 1) + (ts ? 16 * 32 : 0); }
+__host__ __device__ static inline int dl_words_mid(int kp, bool ts) {
+  const int w = (G2_NT * 32 * kp >> 1) + DL_NW * 4 * kp + G2_WIMG, t = DL_NW * 16 * G2_TP;
+  return (ts && t > w) ? t : w;
+}
+template <bool FLAGS, bool BWD, bool TS>
 __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
+  static_assert(!TS || BWD, "tables are a product of the backward pass");
   IGMC_DYN_SMEM(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
@@ -1413,19 +1428,33 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
   const int cu = a.n_users[g], cv = a.n_items[g];
   const int n_own = side ? cv : cu, n_opp = side ? cu : cv;
   const int R = a.R;
+  const int ts = a.ts_stride;
+  // partial-table slot of this workgroup: member c = side * nq + q of subgraph g -> g + c * stride (k_tail_ts's order)
+  float* wpart = TS ? a.ts_part + ((size_t)a.l * IGMC_TS_BLOCKS + g + (size_t)rem * a.slot_stride) * ts : nullptr;
+  float* part0 = TS ? a.ts_part + ((size_t)g + (size_t)rem * a.slot_stride) * ts : nullptr;
+  const int rows0 = R * a.L + a.L + 1;
   if (16 * DL_NW * q >= n_own) {                 // nothing of this side in the workgroup's rows (uniform)
-    if (BWD && tid < R * 4) a.gatt_part[(size_t)bid * R * 4 + tid] = 0.f;
+    if (BWD && !TS && tid < R * 4) a.gatt_part[(size_t)bid * R * 4 + tid] = 0.f;
+    if (TS) {                                    // an all-zero partial table (the reduction reads every slot)
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = tid; i < (ts >> 2); i += DL_THREADS) ((float4*)wpart)[i] = z4;
+      if (a.l == 1)
+        for (int i = tid; i < rows0 * 8; i += DL_THREADS) ((float4*)part0)[i] = z4;
+    }
     return;
   }
   const int nb = a.node_off[g];
   const int own0 = nb + (side ? cu : 0), opp0 = nb + (side ? 0 : cu);
   const int kp = a.kp, rmp = kp;                 // plane pitch (bf16) = relm row pitch (bytes) = 32 * max k-steps + 8
   const int nks = (n_opp + 31) >> 5;
-  uint32_t* PLN = (uint32_t*)smem;                                   // [3][32][kp] bf16
+  float* XOA = (float*)smem;                                         // [DL_NW][16][G2_XP]
+  float* HSA = XOA + dl_words_x();                                   // TS: [DL_NW][16][G2_XP] h_{l-1} rows of the bundles
+  float* sbias = HSA + dl_words_x();                                 // TS: [16][32] d bias partial sums
+  uint32_t* PLN = (uint32_t*)(XOA + dl_words_front(TS));             // [3][32][kp] bf16
   unsigned char* RMW = (unsigned char*)(PLN + (G2_NT * 32 * kp >> 1));   // [DL_NW waves][16 rows][rmp] bytes
-  float* XOA = (float*)(RMW + DL_NW * 16 * rmp);                     // [DL_NW][16][G2_XP]
-  float2* sW2 = (float2*)(XOA + DL_NW * 16 * G2_XP);                 // [G2_WIMG words]
-  float* sred = (float*)sW2 + G2_WIMG;                               // [DL_NW][32] + att [32]
+  float2* sW2 = (float2*)(RMW + DL_NW * 16 * rmp);                   // [G2_WIMG words]
+  float* TIL = (float*)PLN;                                          // TS: [DL_NW][16][G2_TP] T' tiles (aliases the above)
+  float* sred = (float*)PLN + dl_words_mid(kp, TS);                  // [DL_NW][32] + att [32]
   float* s_att = sred + DL_NW * 32;
   const int row0 = 16 * DL_NW * q + 16 * wave;
   const bool active = row0 < n_own;
@@ -1470,7 +1499,20 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
     biasv[0] = a.bias[li];
     biasv[1] = a.bias[16 + li];
   }
-  if (BWD && tid < 32) s_att[tid] = (tid < R * 4) ? a.att[tid] : 0.f;
+  if (BWD && !TS && tid < 32) s_att[tid] = (tid < R * 4) ? a.att[tid] : 0.f;
+  // TS, layer 1: the rows' layer-0 inputs [neighbour-label histogram | own label | 1] for the layer-0 table gradient
+  const int RL = R * a.L;
+  uint16_t c0q[5];                                 // histogram entries lane + 64 u of the wave's 16 rows (R L <= 20)
+  int own_lab = 0;
+  if (TS && a.l == 1) {
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int i = lane + 64 * u, r = i / RL, c = i - r * RL;
+      const int rc = (r < 16 && row0 + r < n_own) ? row0 + r : n_own - 1;
+      c0q[u] = a.cnt0[(size_t)(own0 + rc) * RL + (r < 16 ? c : 0)];
+    }
+    own_lab = (int)a.node_label[own0 + (row0 + li < n_own ? row0 + li : n_own - 1)];
+  }
 #ifndef IGMC_HIPEMU
   __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -1517,29 +1559,45 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
     if (i < G2_WIMG / 4) ((f32x4*)sW2)[i] = wq[u];
   }
   __syncthreads();
-  float gsum[G2_NR * 4];
+  if (TS) {       // d bias_l = column sums of dPre_l over the workgroup's rows (fixed order): 16 partial sums per column ...
+    const int n = tid & 31, part = tid >> 5;
+    float sb = 0.f;
+    for (int row = part; row < DL_NW * 16; row += DL_THREADS / 32) sb += XOA[(row >> 4) * 16 * G2_XP + (row & 15) * G2_XP + n];
+    sbias[part * 32 + n] = sb;
+  }
+  float gsum[TS ? 1 : G2_NR * 4];
 #pragma unroll
-  for (int i = 0; i < G2_NR * 4; ++i) gsum[i] = 0.f;
+  for (int i = 0; i < (TS ? 1 : G2_NR * 4); ++i) gsum[i] = 0.f;
+  f32x4 acc[G2_NR][2];                             // T_r (forward) / T'_r (backward) of the bundle: lane = row li
+#pragma unroll
+  for (int r = 0; r < G2_NR; ++r) {
+    acc[r][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  float xprev[2][4], dv[2][4];                     // backward: h_{l-1} / dPre_{l-1} of rows 4 kq + rr, feature 16 nt + li
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      xprev[nt][rr] = 0.f;
+      dv[nt][rr] = 0.f;
+    }
   if (active) {
     // ---- T_r^T = X^T A_r^T over the k-steps of the opposite side; fragments expanded per k-step from the row's bytes
-    f32x4 acc[G2_NR][2];
-#pragma unroll
-    for (int r = 0; r < G2_NR; ++r) {
-      acc[r][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      acc[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
     const int row = row0 + li;                       // this lane's row in the gather's accumulators
     // backward: everything the epilogues read from HBM / L2 is requested BEFORE the gather (Y rows of the lane's row for
     // the d att partials, h_{l-1} of the transform's output rows for tanh'): eight + eight dependent round trips otherwise
-    float4 ypre[4][2];
-    float xprev[2][4], addv[2][4];
+    float4 ypre[TS ? 1 : 4][2];
+    float addv[2][4];
     if (BWD) {
       const int rowc = row < n_own ? row : n_own - 1;
+      if (!TS) {
 #pragma unroll
-      for (int bb = 0; bb < 4; ++bb)
+        for (int bb = 0; bb < 4; ++bb)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-          ypre[bb][t] = *(const float4*)(a.Y + (size_t)(own0 + rowc) * 128 + bb * 32 + 16 * t + 4 * kq);
+          for (int t = 0; t < 2; ++t)
+            ypre[bb][t] = *(const float4*)(a.Y + (size_t)(own0 + rowc) * 128 + bb * 32 + 16 * t + 4 * kq);
+      }
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -1577,7 +1635,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
         for (int qq = 0; qq < 2 * G2_NT; ++qq) acc[r][qq & 1] = g2_mfma_bf16(pf[qq], af, acc[r][qq & 1]);
       }
     }
-    if (BWD) {
+    if (BWD && !TS) {
       // ---- basis-space aggregate G (what the weight-gradient kernel multiplies with X^T) and the d att partials
       if (row < n_own) {
 #pragma unroll
@@ -1617,13 +1675,127 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
           } else {
             const float d = o[nt][rr] + addv[nt][rr];
             const float x = xprev[nt][rr];
-            a.out[at] = d * (1.f - x * x);
+            dv[nt][rr] = d * (1.f - x * x);
+            a.out[at] = dv[nt][rr];
           }
+        } else if (BWD) {
+          xprev[nt][rr] = 0.f;                       // (rows past the side: zero K entries of the table product)
         }
       }
     }
   }
-  if (BWD) {
+  if (TS) {
+    // ---- weight-gradient table h_{l-1}^T [T'_0 .. T'_4 | dPre_l] over the workgroup's rows, as in k_graph_step2: the
+    // bundles' T' tiles and h rows go to LDS (the tiles over planes / block rows / weight image: every wave is done with
+    // them at the barrier), then the 2 x 12 output tiles are split over the 8 waves (3 each), K = the active bundles' rows
+    // -- no cross-wave reduction, one plain store per value (one subgraph per workgroup)
+    __syncthreads();
+    if (tid < 32) {                                // ... (d bias) summed in a fixed order
+      float s = 0.f;
+#pragma unroll
+      for (int p = 0; p < DL_THREADS / 32; ++p) s += sbias[p * 32 + tid];
+      wpart[(R * 32 + 32) * 32 + tid] = s;
+    }
+    float* T = TIL + wave * 16 * G2_TP;
+    float* HS = HSA + wave * 16 * G2_XP;
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < G2_NR; ++r)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          *(float4*)(T + li * G2_TP + r * 32 + 16 * t + 4 * kq) = make_float4(acc[r][t][0], acc[r][t][1], acc[r][t][2], acc[r][t][3]);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) HS[(4 * kq + rr) * G2_XP + 16 * nt + li] = xprev[nt][rr];
+    }
+    __syncthreads();
+    const int nbun = (n_own - 16 * DL_NW * q + 15) >> 4;
+    const int nact = nbun < DL_NW ? nbun : DL_NW;  // bundles of this workgroup that hold rows
+    {
+      f32x4 w3[3];
+#pragma unroll
+      for (int i3 = 0; i3 < 3; ++i3) w3[i3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int m2w = wave >> 2, nt0 = 3 * (wave & 3);       // in-feature half, first of the wave's three column tiles
+#pragma unroll 1
+      for (int wb = 0; wb < nact; ++wb) {
+        const float* Tb = TIL + wb * 16 * G2_TP;
+        const float* Hb = HSA + wb * 16 * G2_XP;
+        const float* Db = XOA + wb * 16 * G2_XP;
+        float av[4], bw[4][3];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          av[s4] = Hb[(4 * s4 + kq) * G2_XP + m2w * 16 + li];
+#pragma unroll
+          for (int i3 = 0; i3 < 3; ++i3) {
+            const int nt = nt0 + i3;                 // column tile: 0..9 = T' of relation nt >> 1, 10..11 = dPre_l (d root)
+            bw[s4][i3] = (nt < 2 * G2_NR) ? Tb[(4 * s4 + kq) * G2_TP + nt * 16 + li]
+                                          : Db[(4 * s4 + kq) * G2_XP + (nt - 2 * G2_NR) * 16 + li];
+          }
+        }
+#ifndef IGMC_HIPEMU
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int i3 = 0; i3 < 3; ++i3) w3[i3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bw[s4][i3], w3[i3], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i3 = 0; i3 < 3; ++i3) {
+        const int nt = nt0 + i3, r = nt >> 1;        // 32-column block: relation, or G2_NR = root
+        if (r >= R && r < G2_NR) continue;
+        float* pp = wpart + (kq * 4) * 32 + li + (r < R ? r : R) * 1024 + m2w * 512 + (nt & 1) * 16;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) pp[rr * 32] = w3[i3][rr];
+      }
+    }
+    if (a.l == 1) {
+      // ---- layer-0 table gradient T0'[c][f] = sum_i [hist | onehot | 1](i, c) dPre_0[i][f] over the workgroup's rows:
+      // the rows' inputs and dPre_0 (this launch's output, still in registers) as tiles over the T' tiles (dead now)
+      __syncthreads();
+      float* HI = TIL + wave * 16 * G2_XP;                              // [DL_NW][16][G2_XP] inputs
+      float* D0 = TIL + (DL_NW + wave) * 16 * G2_XP;                    // [DL_NW][16][G2_XP] dPre_0
+      if (active) {
+        for (int i = lane; i < 16 * G2_XP; i += 64) HI[i] = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) D0[(4 * kq + rr) * G2_XP + 16 * nt + li] = dv[nt][rr];
+      }
+      __syncthreads();                               // (HI zero fill before the scattered writes below)
+      if (active) {
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          const int i = lane + 64 * u, r = i / RL, c = i - r * RL;
+          if (r < 16 && row0 + r < n_own) HI[r * G2_XP + c] = (float)c0q[u];
+        }
+        if (kq == 0 && row0 + li < n_own) {
+          HI[li * G2_XP + RL + own_lab] = 1.f;
+          HI[li * G2_XP + RL + a.L] = 1.f;
+        }
+      }
+      __syncthreads();
+      if (wave < 4) {
+        const int m2 = wave >> 1, wn = wave & 1;     // code half, feature half
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int wb = 0; wb < nact; ++wb) {
+          const float* Hb = TIL + wb * 16 * G2_XP;
+          const float* Db = TIL + (DL_NW + wb) * 16 * G2_XP;
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Hb[(4 * s4 + kq) * G2_XP + m2 * 16 + li],
+                                                        Db[(4 * s4 + kq) * G2_XP + wn * 16 + li], acc0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int c = m2 * 16 + kq * 4 + rr;
+          if (c < rows0) part0[c * 32 + wn * 16 + li] = acc0[rr];
+        }
+      }
+    }
+  }
+  if (BWD && !TS) {
     // d att partial of the workgroup: lanes -> wave (fixed order), waves -> workgroup
     // the 20 butterflies side by side: one LDS-crossbar round trip per step for all of them (one after the other they are
     // 120 dependent round trips, ~4 us of this kernel); same order of additions per value
@@ -1647,6 +1819,121 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
       a.gatt_part[(size_t)bid * R * 4 + tid] = s;
     }
   }
+}
+
+// Training head of the dense per-layer path, ONE workgroup per subgraph (k_graph_step2's head as a launch of its own): the
+// 256 conv features of the two target rows -> lin1 / ReLU / dropout / lin2 / residual -> dz, d feat and dPre_3 on the
+// target rows.  (k_head_train's head role takes 16 subgraphs per workgroup on the f32 matrix cores: four workgroups at
+// batch 50, 19 us of dependent round trips; 50 workgroups of one subgraph each are done in a third of that.)  D = 256.
+__global__ __launch_bounds__(256) void k_head_sub(BatchDev b, ModelDev m, const float* __restrict__ P,
+                                                    const uint8_t* __restrict__ inj_mask, uint64_t seed, uint64_t step_arg,
+                                                    float mult, float grad_scale, float* __restrict__ out) {
+  __shared__ float sfeat[256], sgf[256], sa1[128], skeep[128], sdz[128], sred[128], part4[4 * 256], misc[4];
+  const int g = blockIdx.x;
+  if (g >= b.totals[3]) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t step = m.ctrl ? (uint64_t)m.ctrl[IGMC_CTRL_STEP] : step_arg;
+  const int nu = b.node_off[g], nv = nu + b.n_users[g];
+  const size_t trow = (size_t)((tid >> 7) ? nv : nu) * 32 + (tid & 31);          // feature tid: side, layer, column
+  const float fv = m.h[(tid >> 5) & 3][trow];
+  const float yv = b.y[g], l2b = P[m.off_l2b];
+  const float l1b = P[m.off_l1b + (tid >> 1)], l2w = P[m.off_l2w + (tid >> 1)], l2w_t = P[m.off_l2w + (tid & 127)];
+  sfeat[tid] = fv;
+  m.feat[(size_t)g * 256 + tid] = fv;
+  __syncthreads();
+  {
+    // lin1 (256 -> 128): wave w takes hidden units 32 w .. 32 w + 31; one weight row (1 KB) per load instruction, lane = 4
+    // fan-in columns; the 32 per-lane partial dot products are reduced over the 64 lanes by a transposing butterfly
+    const int ju = tid >> 1, part = tid & 1;
+    const float4 f4 = *(const float4*)(sfeat + 4 * lane);
+    const float* wrow = P + m.off_l1w + (int64_t)(32 * wave) * 256 + 4 * lane;
+    float v[32];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      float4 w4[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) w4[q] = *(const float4*)(wrow + (16 * hh + q) * 256);
+      G2_SCHED_BARRIER();
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[16 * hh + q] = (w4[q].x * f4.x + w4[q].y * f4.y) + (w4[q].z * f4.z + w4[q].w * f4.w);
+      G2_SCHED_BARRIER();
+    }
+#define G2_BFLY(H)                                                                   \
+    {                                                                                \
+      const bool up = (lane & (2 * (H))) != 0;                                       \
+      _Pragma("unroll") for (int i = 0; i < (H); ++i) {                              \
+        const float send = up ? v[i] : v[i + (H)], keep = up ? v[i + (H)] : v[i];    \
+        v[i] = keep + __shfl_xor(send, 2 * (H));                                     \
+      }                                                                              \
+    }
+    G2_BFLY(16) G2_BFLY(8) G2_BFLY(4) G2_BFLY(2) G2_BFLY(1)
+#undef G2_BFLY
+    const float s = v[0] + __shfl_xor(v[0], 1);
+    if (part == 0) {
+      float av = s + l1b;
+      av = av > 0.f ? av : 0.f;
+      const int keep = inj_mask ? (int)inj_mask[g * 128 + ju]
+                                : (int)(igmc_u01(igmc_unit_hash(seed, step, (uint32_t)g, (uint32_t)ju)) >= 0.5f);
+      m.a1[g * 128 + ju] = av;
+      m.lmask[g * 128 + ju] = (uint8_t)keep;
+      sa1[ju] = av;
+      skeep[ju] = keep ? 1.f : 0.f;
+      sred[ju] = (keep ? av * 2.f : 0.f) * l2w;       // F.dropout(p = 0.5): kept * 2
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float s = sred[lane] + sred[lane + 64];
+    s = igmc_wave_sum_f(s);
+    if (lane == 0) {
+      const float o = (s + l2b) * mult;
+      out[g] = o;
+      m.err[g] = o - yv;
+      misc[0] = o - yv;
+    }
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const float dp = 2.f * misc[0] * grad_scale * mult;
+    const float dzv = (sa1[tid] > 0.f && skeep[tid] != 0.f) ? dp * l2w_t * 2.f : 0.f;
+    sdz[tid] = dzv;
+    m.dz[g * 128 + tid] = dzv;
+  }
+  __syncthreads();
+  {   // d feat = dz @ lin1.weight: wave w takes hidden units 32 w .. 32 w + 31, lane -> 4 fan-in columns; rows with
+      // dz == 0 (ReLU / dropout: ~3/4 of them) are skipped wave-uniformly
+    const float* w1 = P + m.off_l1w + 4 * lane;
+    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned long long nz = __ballot(lane < 32 && sdz[32 * wave + (lane & 31)] != 0.f);
+    while (nz) {
+      int q[8];
+      float4 wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        q[u] = nz ? (int)__builtin_ctzll(nz) : -1;
+        if (nz) nz &= nz - 1;
+        wv[u] = (q[u] >= 0) ? *(const float4*)(w1 + (int64_t)(32 * wave + q[u]) * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float dzv = (q[u] >= 0) ? sdz[32 * wave + q[u]] : 0.f;
+        s4.x += dzv * wv[u].x; s4.y += dzv * wv[u].y; s4.z += dzv * wv[u].z; s4.w += dzv * wv[u].w;
+      }
+    }
+    *(float4*)(part4 + wave * 256 + 4 * lane) = s4;
+  }
+  __syncthreads();
+  {
+    const float v = (part4[tid] + part4[256 + tid]) + (part4[512 + tid] + part4[768 + tid]);
+    m.gfeat[(size_t)g * 256 + tid] = v;
+    if (((tid >> 5) & 3) == 3) m.dpre[3][trow] = v * (1.f - fv * fv);      // dPre_3: non-zero on the two target rows only
+  }
+  (void)sgf;
+}
+
+void igmc_launch_head_sub(const ModelDev& m, const BatchDev& b, const float* P, int B, const uint8_t* inj_mask, uint64_t seed,
+                          uint64_t step, float mult, float grad_scale, float* out, void* stream) {
+  IGMC_PLAUNCH("k_head_sub", k_head_sub, B, 256, 0, stream, b, m, P, inj_mask, seed, step, mult, grad_scale, out);
 }
 
 // Layer 0 of the dense per-layer path (one-hot input): per row the histogram of (relation, label of the neighbour) over
@@ -1806,8 +2093,8 @@ void igmc_launch_dl_layer0(const ModelDev& m, const BatchDev& b, int B, int trai
   }
 }
 
-static size_t dl_lds(int kp) {
-  return ((size_t)(G2_NT * 32 * kp >> 1) + (size_t)DL_NW * 4 * kp + (size_t)DL_NW * 16 * G2_XP + G2_WIMG + DL_NW * 32 + 32) * 4;
+static size_t dl_lds(int kp, bool ts = false) {
+  return ((size_t)dl_words_front(ts) + (size_t)dl_words_mid(kp, ts) + DL_NW * 32 + 32) * 4;
 }
 
 // 1 = the dense per-layer kernels take the conv layers of this arena (IGMC_DL=0 switches them off)
@@ -1818,6 +2105,18 @@ int igmc_dl_eligible(const ModelDev& m, const BatchDev& b, int B) {
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
   if (cmax > 256 || B * 2 * ((cmax + 16 * DL_NW - 1) / (16 * DL_NW)) > IGMC_GATHER_BLOCKS) return 0;
   return dl_lds(32 * ((cmax + 31) >> 5) + 8) <= (size_t)160 * 1024;
+}
+
+// 1 = the backward passes of this arena can leave relation-space tables (k_dl_layer<*, true, true>): the tail of the
+// subgraph kernel (k_tail_ts -> k_finalize_ts) then replaces G / Y / the weight-gradient products (IGMC_DL_TS=0: never)
+int igmc_dl_ts_eligible(const ModelDev& m, const BatchDev& b, int B) {
+  const char* e = getenv("IGMC_DL_TS");
+  if (e && atoi(e) == 0) return 0;
+  if (!igmc_dl_eligible(m, b, B) || !m.ts_part || !m.cnt0) return 0;
+  const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
+  const int nq = (cmax + 16 * DL_NW - 1) / (16 * DL_NW), stride = (B + 7) & ~7;
+  if (2 * nq * stride > IGMC_TS_BLOCKS || m.R * m.L > 20) return 0;
+  return dl_lds(32 * ((cmax + 31) >> 5) + 8, true) <= (size_t)160 * 1024;
 }
 
 int igmc_dl_grid(const BatchDev& b, int B) {
@@ -1833,7 +2132,7 @@ void igmc_launch_g2_compose(const ModelDev& m, const float* P, void* stream) {
 
 // one conv layer pass: forward (bwd = 0: h_{l-1} -> h_l) or backward (dPre_l -> dPre_{l-1}, G, d att partials)
 void igmc_launch_dl_layer(const ModelDev& m, const BatchDev& b, const float* P, int B, int l, int bwd, int use_flags,
-                          float* zero_out, void* stream) {
+                          float* zero_out, void* stream, int tables) {
   DlArgs a;
   memset(&a, 0, sizeof(a));
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
@@ -1850,24 +2149,36 @@ void igmc_launch_dl_layer(const ModelDev& m, const BatchDev& b, const float* P, 
   a.gfeat = m.gfeat; a.dcat = bwd ? m.dcat[l - 1] : nullptr;
   a.img = m.g2_w + (size_t)((l - 1) * 2 + (bwd ? 1 : 0)) * G2_WIMG;
   a.bias = P + m.off_bias[l]; a.att = P + m.off_att[l];
+  a.L = m.L;
   const int grid = B * 2 * a.nq;
+  if (bwd && tables) {       // relation-space tables instead of G / d att partials (igmc_dl_ts_eligible)
+    a.ts_part = m.ts_part; a.ts_stride = m.ts_stride; a.slot_stride = (B + 7) & ~7;
+    a.cnt0 = m.cnt0; a.node_label = b.node_label;
+    a.gagg = nullptr; a.Y = nullptr; a.gatt_part = nullptr;
+    const size_t smt = dl_lds(a.kp, true);
+    if (use_flags) IGMC_PLAUNCH("k_dl_layer_bwd", (k_dl_layer<true, true, true>), grid, DL_THREADS, smt, stream, a);
+    else IGMC_PLAUNCH("k_dl_layer_bwd", (k_dl_layer<false, true, true>), grid, DL_THREADS, smt, stream, a);
+    return;
+  }
   const size_t sm = dl_lds(a.kp);
   if (bwd) {
-    if (use_flags) IGMC_PLAUNCH("k_dl_layer_bwd", (k_dl_layer<true, true>), grid, DL_THREADS, sm, stream, a);
-    else IGMC_PLAUNCH("k_dl_layer_bwd", (k_dl_layer<false, true>), grid, DL_THREADS, sm, stream, a);
+    if (use_flags) IGMC_PLAUNCH("k_dl_layer_bwd", (k_dl_layer<true, true, false>), grid, DL_THREADS, sm, stream, a);
+    else IGMC_PLAUNCH("k_dl_layer_bwd", (k_dl_layer<false, true, false>), grid, DL_THREADS, sm, stream, a);
   } else {
-    if (use_flags) IGMC_PLAUNCH("k_dl_layer_fwd", (k_dl_layer<true, false>), grid, DL_THREADS, sm, stream, a);
-    else IGMC_PLAUNCH("k_dl_layer_fwd", (k_dl_layer<false, false>), grid, DL_THREADS, sm, stream, a);
+    if (use_flags) IGMC_PLAUNCH("k_dl_layer_fwd", (k_dl_layer<true, false, false>), grid, DL_THREADS, sm, stream, a);
+    else IGMC_PLAUNCH("k_dl_layer_fwd", (k_dl_layer<false, false, false>), grid, DL_THREADS, sm, stream, a);
   }
 }
 
 int igmc_dl_prepare() {
 #ifndef IGMC_HIPEMU
   const int mx = 160 * 1024;
-  if (hipFuncSetAttribute((const void*)k_dl_layer<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
-  if (hipFuncSetAttribute((const void*)k_dl_layer<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
-  if (hipFuncSetAttribute((const void*)k_dl_layer<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
-  if (hipFuncSetAttribute((const void*)k_dl_layer<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_dl_layer<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_dl_layer<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_dl_layer<true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_dl_layer<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_dl_layer<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_dl_layer<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_dl_layer0<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_dl_layer0<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_dl_layer0<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;

@@ -2385,6 +2385,38 @@ int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchD
     }
   }
   const size_t ysz = (size_t)32 * (128 + 4) * sizeof(float);
+  // dense layers whose backward passes leave relation-space tables (igmc_dl_ts_eligible): the tail of the subgraph kernel
+  // -- k_tail_ts sums the workgroups' tables and forms d lin1 / d lin2, k_finalize_ts turns them into gradients (+ Adam) --
+  // replaces the Y products, G, the weight-gradient products and their reduction
+  const int fts = igmc_fin_mode() && m.fin_stash && m.datt_part && m.R <= 8;
+  if (dl && l0_mfma && fts && !getenv("IGMC_DL_NOBWD") && igmc_dl_ts_eligible(m, b, B)) {
+    if (m.D == 256 && !getenv("IGMC_HEAD_TRAIN"))           // one workgroup per subgraph
+      igmc_launch_head_sub(m, b, (const float*)P, B, inj_mask, seed, step, mult, grad_scale, out, stream);
+    else                                                      // (head role only: 16 subgraphs per workgroup)
+      IGMC_PLAUNCH("k_head_train", k_head_train, dim3(hb, 1), 512, ysz, stream, b, m, (const float*)P, inj_mask, seed, step,
+                   mult, grad_scale, out);
+    for (int l = 3; l >= 1; --l) igmc_launch_dl_layer(m, b, (const float*)P, B, l, 1, use_flags, nullptr, stream, 1);
+    const int gstride = (B + 7) & ~7, gg = igmc_dl_grid(b, B) / B * gstride;
+    IGMC_PLAUNCH("k_tail_ts", k_tail_ts, 8 * ny + (4 * m.ts_stride + 63) / 64 + 4, IGMC_BLOCK, 0, stream, b, m,
+                 (const float*)P, grad_scale, mult, 2.f, grad, 8 * ny, gg, gstride, B, 4,
+                 (const int64_t*)(adam ? at.ctrl : nullptr), 0);
+    if (xch) {
+      const int rc = xch->sum(xch->user, m.ts_raw, (int64_t)4 * m.ts_stride + (int64_t)4 * m.ts_stride / 32 * 4,
+                              grad + m.off_l1w, n_lin, stream);
+      if (rc) return rc;
+    }
+    if (adam) {
+      at.enabled = 1;
+      at.b = b;
+      at.ARR = ARR;
+      IGMC_PLAUNCH("k_finalize_adam", k_finalize_ts, 4 * IGMC_FTS_NB + 32 + 1, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 32, 0, img);
+      if (img_emitted) *img_emitted = img;
+    } else {
+      IGMC_PLAUNCH("k_finalize", k_finalize_ts, 4 * IGMC_FTS_NB, IGMC_BLOCK, 0, stream, m, (const float*)P, grad, ARR * arr_scale, at, 0, 0, 0);
+      if (loss) igmc_launch_loss(m, b, ARR, loss, stream);
+    }
+    return 0;
+  }
   IGMC_PLAUNCH("k_head_train", k_head_train, dim3(hb > gy ? hb : gy, 4), 512, ysz, stream, b, m, (const float*)P, inj_mask,
                seed, step, mult, grad_scale, out);
   const int dlb = dl && !getenv("IGMC_DL_NOBWD");      // (debug: dense forward + row-walker backward)
