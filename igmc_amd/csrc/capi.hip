@@ -734,7 +734,10 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   d.g2_fx = nullptr;
   d.g2_w = nullptr;
   d.g2_graphs = 0;
-  d.g2_ex_stride = (size_t)Bc * 2 * 4096;
+  // exchange regions [32 features][nodes a side]: 128 nodes for the subgraph kernel (slots <= 256 nodes), 256 for the
+  // one-launch forward of the dense layers (larger slots)
+  d.ex_nodes = (N > 256 * Bc || getenv("IGMC_DL_ALWAYS")) ? 256 : 128;      // (IGMC_DL_ALWAYS: tests force the dense layers onto small arenas)
+  d.g2_ex_stride = (size_t)Bc * 2 * 32 * d.ex_nodes;
   if (d.R <= 5 && n_side == 0 && Bc <= 2048) {      // exchange buffers of the matrix-core subgraph kernel: 320 KB per slot
     fail |= M.get(&d.g2_ex, 5 * d.g2_ex_stride) | M.get(&d.g2_fx, Bc * 256) | M.get(&d.g2_w, (size_t)6 * 9216 + 1024);
     d.g2_graphs = (int)Bc;

@@ -1821,6 +1821,368 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
   }
 }
 
+// =====================================================================================================================
+// The forward of the dense per-layer path as ONE launch: layer 0 and the three conv layers of k_dl_layer0 / k_dl_layer with
+// the members of a subgraph (2 nq workgroups: row blocks of 128 x two sides) handing h_l to each other through tagged
+// exchange words, as the members of k_graph_step2's clusters do.  A per-layer launch spends 12 of its 16 us outside the
+// matrix cores (launch, staging round trips, the launch's tail); here the block rows are staged once, a layer's weight
+// image is requested a layer ahead, the opposite side's rows arrive as bf16 terms already in plane order, and a layer
+// boundary is one poll of the exchange.  Exchange regions: [exchange x][subgraph][side][32 features][DLX_K nodes].
+#define DLX_K 256
+struct DlfArgs {
+  const int32_t* n_users;
+  const int32_t* n_items;
+  const int32_t* node_off;
+  const uint8_t* node_label;
+  const uint8_t* relm;
+  const uint8_t* relmT;
+  int cap_u, cap_v, relm_ld, relmT_ld, nq, R, L, kp;
+  float* h[4];
+  float* zero_out;               // training: dPre_3 rows cleared (or NULL)
+  uint16_t* cnt0;                // training: [N, R * L] (or NULL)
+  const float* g2_w;             // forward / transposed images of layers 1..3, then the layer-0 table
+  const float* P;
+  int off_bias[4];
+  unsigned long long* ex;
+  size_t ex_stride;              // words per exchange
+  int* gs_bar;
+  int* gs_err;
+  int self_seq;                  // 1: the last workgroup advances the launch sequence number (no kernel follows that would)
+};
+
+// planes [term][feature][node] of one side from its exchange region ex[feature][DLX_K]: nodes < npad (a multiple of 16) of
+// all 32 features, 8 word pairs per thread of a 512-thread workgroup, polled until their tags are this exchange's
+__device__ __forceinline__ void dlx_reload(uint32_t* pl, int kp, const unsigned long long* ex, int npad, uint32_t tag16,
+                                           int* err) {
+  const int hp = npad >> 1, t0 = (int)threadIdx.x;
+  const int tstride = 32 * kp >> 1;
+#ifndef IGMC_HIPEMU
+  // pair p = thread + 512 u -> feature p >> 7, node pair p & 127
+  const int q0 = t0 & 127;
+  uint32_t pend = (q0 < hp) ? 0xFFu : 0u;
+  const int d0 = ((t0 >> 7) * kp >> 1) + q0;                               // feature (t0 >> 7) + 4 u
+  u32x4 v[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) v[u] = g2_ld16_sc1(ex, (t0 + u * DL_THREADS) * 16);
+  for (int it = 0;; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const u32x4 V = v[u];
+      if ((pend & (1u << u)) && (V.y >> 16) == tag16 && (V.w >> 16) == tag16) {
+        const int d = d0 + u * (4 * kp >> 1);
+        pl[d] = (V.x & 0xFFFFu) | (V.z << 16);
+        pl[tstride + d] = (V.x >> 16) | (V.z & 0xFFFF0000u);
+        pl[2 * tstride + d] = (V.y & 0xFFFFu) | (V.w << 16);
+        pend &= ~(1u << u);
+      }
+    }
+    if (!pend) break;
+    if (it > (1 << 20)) {
+      *err = 1;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (pend & (1u << u)) v[u] = g2_ld16_sc1(ex, (t0 + u * DL_THREADS) * 16);
+  }
+#else
+  for (int p = t0; p < 32 * hp; p += DL_THREADS) {
+    const int f = p / hp, q = p - f * hp;
+    const unsigned long long* e = ex + f * DLX_K + 2 * q;
+    long spins = 0;
+    for (;;) {
+      const unsigned long long a = e[0], b2 = e[1];
+      if ((uint32_t)(a >> 48) == tag16 && (uint32_t)(b2 >> 48) == tag16) {
+        const uint32_t ax = (uint32_t)a, ay = (uint32_t)(a >> 32), bx = (uint32_t)b2, by = (uint32_t)(b2 >> 32);
+        const int d = (f * kp >> 1) + q;
+        pl[d] = (ax & 0xFFFFu) | (bx << 16);
+        pl[tstride + d] = (ax >> 16) | (bx & 0xFFFF0000u);
+        pl[2 * tstride + d] = (ay & 0xFFFFu) | (by << 16);
+        break;
+      }
+      if (++spins > (1L << 22)) {
+        *err = 1;
+        break;
+      }
+      hipemu::yield();
+    }
+  }
+#endif
+}
+
+// launch sequence number of the exchange tags: advanced once per launch chain, after every workgroup has read it
+__device__ __forceinline__ void dlx_seq_done(int* gs_bar, int self_seq) {
+  if (threadIdx.x != 0 || !self_seq) return;
+#ifndef IGMC_HIPEMU
+  if (__hip_atomic_fetch_add(gs_bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+    __hip_atomic_store(gs_bar, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(gs_bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#else
+  if (gs_bar[0]++ == (int)gridDim.x - 1) {
+    gs_bar[0] = 0;
+    gs_bar[1] += 1;
+  }
+#endif
+}
+
+__host__ __device__ static inline int dlf_words(int kp) {
+  return 2 * DL_NW * 16 * G2_XP + (G2_NT * 32 * kp >> 1) + DL_NW * 4 * kp + G2_WIMG;
+}
+
+template <bool FLAGS, bool STORE>
+__global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
+  IGMC_DYN_SMEM(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int bid = blockIdx.x;
+  const int g = bid / (2 * a.nq), rem = bid - g * 2 * a.nq, side = rem / a.nq, q = rem - side * a.nq;
+  const int cu = a.n_users[g], cv = a.n_items[g];
+  const int n_own = side ? cv : cu, n_opp = side ? cu : cv;
+#ifndef IGMC_HIPEMU
+  const uint32_t seq = (uint32_t)__hip_atomic_load(a.gs_bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  const uint32_t seq = (uint32_t)a.gs_bar[1];
+#endif
+  const uint32_t tag0 = seq * 8u + 1u;
+  auto tag16 = [&](int x) { return 1u + (tag0 + (uint32_t)x) % 65535u; };
+  if (16 * DL_NW * q >= n_own) {                 // nothing of this side in the workgroup's rows: nobody waits for it
+    dlx_seq_done(a.gs_bar, a.self_seq);
+    return;
+  }
+  const int R = a.R, L = a.L, RL = R * L;
+  const int nb = a.node_off[g];
+  const int own0 = nb + (side ? cu : 0), opp0 = nb + (side ? 0 : cu);
+  const int kp = a.kp, rmp = kp;
+  const int nks = (n_opp + 31) >> 5;
+  const int npad_opp = ((n_opp + 15) >> 4) << 4;
+  float* XO0 = (float*)smem;                                              // [DL_NW][16][G2_XP] ping
+  float* XO1 = XO0 + DL_NW * 16 * G2_XP;                                  // pong
+  uint32_t* PLN = (uint32_t*)(XO1 + DL_NW * 16 * G2_XP);                  // [3][32][kp] bf16
+  unsigned char* RMW = (unsigned char*)(PLN + (G2_NT * 32 * kp >> 1));    // [DL_NW][16][rmp] bytes
+  float2* sW2 = (float2*)(RMW + DL_NW * 16 * rmp);                        // [G2_WIMG words]
+  // layer 0 only, inside the image's space: one-hot label planes, the rows' inputs, the layer-0 table
+  uint32_t* OHP = (uint32_t*)sW2;                                         // [8 labels][kp] bf16
+  float* HIA = (float*)(OHP + (8 * kp >> 1));                             // [DL_NW][16][G2_XP]
+  float* sT0 = HIA + DL_NW * 16 * G2_XP;                                  // [32][32]
+  const int row0 = 16 * DL_NW * q + 16 * wave;
+  const bool active = row0 < n_own;
+  const size_t exs = a.ex_stride;
+  unsigned long long* ex_own = a.ex + ((size_t)g * 2 + side) * (32 * DLX_K);
+  const unsigned long long* ex_opp = a.ex + ((size_t)g * 2 + (1 - side)) * (32 * DLX_K);
+
+  // ---- every 4096 launches the owner of a row range clears it in all exchange buffers: a 16-bit tag then never meets a
+  //      word older than 4096 launches (tags repeat after 8191)
+  if ((seq & 4095u) == 0u) {
+    for (int x = 0; x < 5; ++x) {
+      unsigned long long* e = a.ex + x * exs + ((size_t)g * 2 + side) * (32 * DLX_K) + 16 * DL_NW * q;
+      for (int i = tid; i < 32 * 8 * DL_NW; i += DL_THREADS) g2_store16(e + (i / (8 * DL_NW)) * DLX_K + 2 * (i % (8 * DL_NW)), 0u, 0u, 0u, 0u);
+    }
+#ifndef IGMC_HIPEMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  }
+
+  // ---- staging: every global load of the set-up is requested before the first use
+  const int ldb = side ? a.relmT_ld : a.relm_ld, ldw = ldb >> 2;
+  const uint8_t* rsrc = side ? a.relmT + (size_t)g * a.cap_v * a.relmT_ld : a.relm + (size_t)g * a.cap_u * a.relm_ld;
+  const int rw = rmp >> 2;
+  uint32_t rmq[DL_RIT];
+#pragma unroll
+  for (int u = 0; u < DL_RIT; ++u) {
+    const int i = lane + 64 * u, r = i / rw, c = i - r * rw;
+    const int rc = row0 + r < n_own ? row0 + r : n_own - 1, cc = c < ldw ? c : ldw - 1;
+    rmq[u] = ((const uint32_t*)(rsrc + (size_t)rc * ldb))[cc];
+  }
+  const int own_lab = (int)a.node_label[own0 + (row0 + li < n_own ? row0 + li : n_own - 1)];
+  int l0 = 255, l1 = 255;                         // labels of the opposite side's node pair tid (< 16 nks <= 128)
+  if (tid < 16 * nks) {
+    l0 = (2 * tid < n_opp) ? (int)a.node_label[opp0 + 2 * tid] : 255;
+    l1 = (2 * tid + 1 < n_opp) ? (int)a.node_label[opp0 + 2 * tid + 1] : 255;
+  }
+  const float2 t0v = ((const float2*)(a.g2_w + 6 * G2_WIMG))[tid];      // layer-0 table: 1024 floats
+  constexpr int NWQ = (G2_WIMG / 4 + DL_THREADS - 1) / DL_THREADS;
+  f32x4 wq[NWQ];                                  // a layer's weight image, requested a layer ahead
+  auto wpre = [&](int l) {
+    const f32x4* src = (const f32x4*)(a.g2_w + (size_t)((l - 1) * 2) * G2_WIMG);
+#pragma unroll
+    for (int u = 0; u < NWQ; ++u) {
+      const int i = tid + u * DL_THREADS;
+      wq[u] = src[i < G2_WIMG / 4 ? i : G2_WIMG / 4 - 1];
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int u = 0; u < NWQ; ++u) {
+      const int i = tid + u * DL_THREADS;
+      if (i < G2_WIMG / 4) ((f32x4*)sW2)[i] = wq[u];
+    }
+  };
+#ifndef IGMC_HIPEMU
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  {   // zero fills under the loads' latency: planes (k-steps past the published rows must read zeros), both row tiles, inputs
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < (G2_NT * 32 * kp >> 3); i += DL_THREADS) ((float4*)PLN)[i] = z4;
+    for (int i = tid; i < 2 * DL_NW * 16 * G2_XP / 4; i += DL_THREADS) ((float4*)XO0)[i] = z4;
+    for (int i = tid; i < DL_NW * 16 * G2_XP / 4; i += DL_THREADS) ((float4*)HIA)[i] = z4;
+  }
+  if (tid < 16 * nks) {
+#pragma unroll
+    for (int lb = 0; lb < 8; ++lb) OHP[(lb * kp >> 1) + tid] = ((l0 == lb) ? 0x3F80u : 0u) | ((l1 == lb) ? 0x3F800000u : 0u);
+  }
+  {
+    uint32_t* dst = (uint32_t*)(RMW + (size_t)wave * 16 * rmp);
+#pragma unroll
+    for (int u = 0; u < DL_RIT; ++u) {
+      const int i = lane + 64 * u, r = i / rw, c = i - r * rw;
+      if (i < 16 * rw) dst[i] = (row0 + r < n_own && c < ldw && 4 * c < 32 * nks) ? rmq[u] : 0u;
+    }
+  }
+  ((float2*)sT0)[tid] = t0v;
+  wpre(1);
+  __syncthreads();
+
+  const unsigned char* rmo = RMW + (size_t)(wave * 16 + li) * rmp + 8 * kq;
+  const int kbit = side ? 4 : 3;                   // keep bit of the edge opposite -> own
+  // epilogue of a layer: the bundle's rows -> LDS tile (next layer's own rows), h_l, exchange x = l (bf16 terms)
+  auto fwd_out = [&](int l, const float (&v)[2][4], float* XO) {
+    float* hrow = a.h[l] + (size_t)(own0 + row0 + 4 * kq) * 32 + li;
+    unsigned long long* exl = ex_own + l * exs + (size_t)li * DLX_K + row0 + 4 * kq;
+    const uint32_t tg = tag16(l);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      float w[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const bool ok = row0 + 4 * kq + rr < n_own;
+        w[rr] = ok ? v[nt][rr] : 0.f;
+        XO[(4 * kq + rr) * G2_XP + 16 * nt + li] = w[rr];
+        if (ok) {
+          hrow[rr * 32 + 16 * nt] = w[rr];
+          if (l == 3 && a.zero_out) a.zero_out[(size_t)(own0 + row0 + 4 * kq + rr) * 32 + 16 * nt + li] = 0.f;
+        }
+      }
+      if (l < 3) g2_publish4(exl + (size_t)nt * 16 * DLX_K, 0, w, tg);
+    }
+  };
+
+  // ================================================================ layer 0: h_0 = tanh([hist | onehot(label) | 1] @ T0)
+  if (active) {
+    f32x4 hacc[G2_NR];
+#pragma unroll
+    for (int r = 0; r < G2_NR; ++r) hacc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const uint32_t* ohp = OHP + ((li & 7) * kp >> 1) + 4 * kq;
+#pragma unroll 1
+    for (int s = 0; s < nks; ++s) {
+      const uint2 w = *(const uint2*)(rmo + 32 * s);
+      u32x4 pfh = *(const u32x4*)(ohp + 16 * s);
+      if (li >= 8) pfh = (u32x4){0u, 0u, 0u, 0u};        // (label rows 8..15 of the 16-row operand do not exist)
+#pragma unroll
+      for (int r = 0; r < G2_NR; ++r) {
+        u32x4 af;
+        uint32_t a0, a1, a2, a3;
+        g2_expand4<FLAGS>(w.x, (uint32_t)(r + 1), kbit, a0, a1);
+        g2_expand4<FLAGS>(w.y, (uint32_t)(r + 1), kbit, a2, a3);
+        af[0] = a0; af[1] = a1; af[2] = a2; af[3] = a3;
+        hacc[r] = g2_mfma_bf16(pfh, af, hacc[r]);
+      }
+    }
+    float* hi = HIA + wave * 16 * G2_XP;
+    const int row = row0 + li;
+#pragma unroll
+    for (int r = 0; r < G2_NR; ++r)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int c = 4 * kq + rr;
+        if (r < R && c < L) {
+          hi[li * G2_XP + r * L + c] = hacc[r][rr];
+          if (STORE && row < n_own) a.cnt0[(size_t)(own0 + row) * RL + r * L + c] = (uint16_t)(int)(hacc[r][rr] + 0.5f);
+        }
+      }
+    if (kq == 0 && row < n_own) {
+      hi[li * G2_XP + RL + own_lab] = 1.f;
+      hi[li * G2_XP + RL + L] = 1.f;
+    }
+    IGMC_WAVE_SYNC();                                // (the tile is this wave's own: no workgroup barrier)
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.f;
+    for (int c = 0; c <= RL + L; ++c) {
+      const float x = hi[li * G2_XP + c];
+      const float4 t0 = *(const float4*)(sT0 + c * 32 + 8 * kq), t1 = *(const float4*)(sT0 + c * 32 + 8 * kq + 4);
+      o[0] += x * t0.x; o[1] += x * t0.y; o[2] += x * t0.z; o[3] += x * t0.w;
+      o[4] += x * t1.x; o[5] += x * t1.y; o[6] += x * t1.z; o[7] += x * t1.w;
+    }
+    // lane (row li, features 8 kq .. 8 kq + 7) -> the epilogue's layout (feature 16 nt + li, rows 4 kq + rr) through the tile
+    float* xo = XO1 + wave * 16 * G2_XP;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xo[li * G2_XP + 8 * kq + j] = g2_tanh(o[j]);
+    IGMC_WAVE_SYNC();
+    float v[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) v[nt][rr] = xo[(4 * kq + rr) * G2_XP + 16 * nt + li];
+    fwd_out(0, v, XO0 + wave * 16 * G2_XP);
+  }
+  __syncthreads();                                   // the image's space (one-hot planes, inputs, table) is free
+
+  // ================================================================ conv layers 1..3
+#pragma unroll 1
+  for (int l = 1; l < 4; ++l) {
+    float* XOc = ((l & 1) ? XO0 : XO1) + wave * 16 * G2_XP;      // h_{l-1} of the bundle's rows
+    float* XOn = ((l & 1) ? XO1 : XO0) + wave * 16 * G2_XP;      // h_l
+    stage();
+    const float bias0 = a.P[a.off_bias[l] + li], bias1 = a.P[a.off_bias[l] + 16 + li];
+    dlx_reload(PLN, kp, ex_opp + (l - 1) * exs, npad_opp, tag16(l - 1), a.gs_err);
+    __syncthreads();
+    if (l < 3) wpre(l + 1);
+    if (active) {
+      f32x4 acc[G2_NR][2];
+#pragma unroll
+      for (int r = 0; r < G2_NR; ++r) {
+        acc[r][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      const int tstride = 32 * kp >> 1, toff = 16 * kp >> 1;
+      const uint32_t* base = PLN + (li * kp >> 1) + 4 * kq;
+#pragma unroll 1
+      for (int s = 0; s < nks; ++s) {
+        const uint2 w = *(const uint2*)(rmo + 32 * s);
+        u32x4 pf[2 * G2_NT];
+#pragma unroll
+        for (int sp = 0; sp < G2_NT; ++sp) {
+          pf[2 * sp] = *(const u32x4*)(base + sp * tstride + 16 * s);
+          pf[2 * sp + 1] = *(const u32x4*)(base + sp * tstride + toff + 16 * s);
+        }
+#pragma unroll
+        for (int r = 0; r < G2_NR; ++r) {
+          u32x4 af;
+          uint32_t a0, a1, a2, a3;
+          g2_expand4<FLAGS>(w.x, (uint32_t)(r + 1), kbit, a0, a1);
+          g2_expand4<FLAGS>(w.y, (uint32_t)(r + 1), kbit, a2, a3);
+          af[0] = a0; af[1] = a1; af[2] = a2; af[3] = a3;
+#pragma unroll
+          for (int qq = 0; qq < 2 * G2_NT; ++qq) acc[r][qq & 1] = g2_mfma_bf16(pf[qq], af, acc[r][qq & 1]);
+        }
+      }
+      f32x4 o[2];
+      g2_transform(acc, XOc, (const uint32_t*)sW2, li, kq, o);
+      float v[2][4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        v[0][rr] = g2_tanh(o[0][rr] + bias0);
+        v[1][rr] = g2_tanh(o[1][rr] + bias1);
+      }
+      fwd_out(l, v, XOn);
+    }
+    __syncthreads();                                 // planes / image may be overwritten
+  }
+  dlx_seq_done(a.gs_bar, a.self_seq);
+}
+
 // Training head of the dense per-layer path, ONE workgroup per subgraph (k_graph_step2's head as a launch of its own): the
 // 256 conv features of the two target rows -> lin1 / ReLU / dropout / lin2 / residual -> dz, d feat and dPre_3 on the
 // target rows.  (k_head_train's head role takes 16 subgraphs per workgroup on the f32 matrix cores: four workgroups at
@@ -2170,6 +2532,52 @@ void igmc_launch_dl_layer(const ModelDev& m, const BatchDev& b, const float* P, 
   }
 }
 
+// 1 = the forward of this arena's dense layers runs as ONE launch (k_dl_fwd): exchange regions for 256 nodes a side, every
+// workgroup of the launch resident at once (IGMC_DL_FUSED=0: the per-layer launches)
+int igmc_dl_fwd_eligible(const ModelDev& m, const BatchDev& b, int B) {
+  const char* e = getenv("IGMC_DL_FUSED");
+  if (e && atoi(e) == 0) return 0;
+  if (!igmc_dl_eligible(m, b, B) || !m.g2_ex || m.ex_nodes < DLX_K || b.graph_cap > m.g2_graphs || m.S != 0) return 0;
+  const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
+  const int nq = (cmax + 16 * DL_NW - 1) / (16 * DL_NW);
+  if (B * 2 * nq > 224) return 0;                  // (one workgroup per CU, all of them resident: the members wait for each other)
+  return (size_t)dlf_words(32 * ((cmax + 31) >> 5) + 8) * 4 <= (size_t)160 * 1024;
+}
+
+void igmc_launch_dl_fwd(const ModelDev& m, const BatchDev& b, const float* P, int B, int training, int use_flags,
+                        float* zero_out, int self_seq, void* stream) {
+  DlfArgs a;
+  memset(&a, 0, sizeof(a));
+  const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
+  a.n_users = b.n_users; a.n_items = b.n_items; a.node_off = b.node_off; a.node_label = b.node_label;
+  a.relm = b.relm; a.relmT = b.relmT;
+  a.cap_u = b.cap_u; a.cap_v = b.cap_v; a.relm_ld = b.relm_ld; a.relmT_ld = b.relmT_ld;
+  a.nq = (cmax + 16 * DL_NW - 1) / (16 * DL_NW); a.R = m.R; a.L = m.L; a.kp = 32 * ((cmax + 31) >> 5) + 8;
+  for (int l = 0; l < 4; ++l) {
+    a.h[l] = m.h[l];
+    a.off_bias[l] = (int)m.off_bias[l];
+  }
+  a.zero_out = zero_out;
+  a.cnt0 = training ? m.cnt0 : nullptr;
+  a.g2_w = m.g2_w; a.P = P;
+  a.ex = m.g2_ex; a.ex_stride = m.g2_ex_stride;
+  a.gs_bar = m.gs_bar; a.gs_err = m.gs_err;
+  a.self_seq = self_seq;
+  const int grid = B * 2 * a.nq;
+  const size_t sm = (size_t)dlf_words(a.kp) * 4;
+#ifdef IGMC_HIPEMU
+  hipemu::rt().co_cs = 2 * a.nq;                   // the members of a subgraph run together
+  hipemu::rt().co_stride = -1;                     // (= consecutive workgroups)
+#endif
+  if (training) {
+    if (use_flags) IGMC_PLAUNCH("k_dl_fwd", (k_dl_fwd<true, true>), grid, DL_THREADS, sm, stream, a);
+    else IGMC_PLAUNCH("k_dl_fwd", (k_dl_fwd<false, true>), grid, DL_THREADS, sm, stream, a);
+  } else {
+    if (use_flags) IGMC_PLAUNCH("k_dl_fwd", (k_dl_fwd<true, false>), grid, DL_THREADS, sm, stream, a);
+    else IGMC_PLAUNCH("k_dl_fwd", (k_dl_fwd<false, false>), grid, DL_THREADS, sm, stream, a);
+  }
+}
+
 int igmc_dl_prepare() {
 #ifndef IGMC_HIPEMU
   const int mx = 160 * 1024;
@@ -2179,6 +2587,10 @@ int igmc_dl_prepare() {
   if (hipFuncSetAttribute((const void*)k_dl_layer<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_dl_layer<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_dl_layer<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_dl_fwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_dl_fwd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_dl_fwd<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_dl_fwd<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_dl_layer0<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_dl_layer0<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_dl_layer0<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;

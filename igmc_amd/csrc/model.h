@@ -50,6 +50,7 @@ struct ModelDev {
   unsigned long long* g2_fx;   // [g2_graphs][256] {f32, tag} words of the centre-node readout
   int g2_graphs;               // subgraph slots of the two buffers above (0: not allocated)
   float* g2_w;                 // [6 images of (5*32+32) x 20 float2 | 1024] composed weights of the step (k_g2_compose)
+  int ex_nodes;                // nodes a side the exchange regions of g2_ex hold: 128 (k_graph_step2) or 256 (k_dl_fwd)
   int img_current;             // host side, per call: g2_w holds the images of the call's parameters (compose is skipped)
   const float* adam_m1;        // per call (fused step with Adam): the moments, for the stash of att's old moments
   const float* adam_m2;

@@ -2367,7 +2367,15 @@ int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchD
   // slots of 129..256 nodes a side with a dense block: every conv layer on the matrix cores (graphstep2.hip, k_dl_layer0 /
   // k_dl_layer) from the blocks alone -- no edge list is read
   const int dl = igmc_dl_eligible(m, b, B);
-  if (dl) {
+  // ... and all four of them as ONE launch where the members of a subgraph can hand h_l to each other (k_dl_fwd); the launch
+  // sequence number of its exchange tags is advanced by k_tail_ts (tables path) -- else by the launch's last workgroup
+  const int fts_pre = igmc_fin_mode() && m.fin_stash && m.datt_part && m.R <= 8;
+  const int dlts = dl && l0_mfma && fts_pre && !getenv("IGMC_DL_NOBWD") && igmc_dl_ts_eligible(m, b, B);
+  const int dlf = dl && igmc_dl_fwd_eligible(m, b, B);
+  if (dlf) {
+    igmc_launch_g2_compose(m, (const float*)P, stream);
+    igmc_launch_dl_fwd(m, b, (const float*)P, B, 1, use_flags, m.dpre[3], dlts ? 0 : 1, stream);
+  } else if (dl) {
     igmc_launch_g2_compose(m, (const float*)P, stream);
     igmc_launch_dl_layer0(m, b, B, 1, use_flags, stream);
   } else if (use_flags) IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<true, true>), g16, IGMC_BLOCK, l0s, stream, b, m, (const float*)P, m.h[0]);
@@ -2375,7 +2383,7 @@ int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchD
   const size_t fsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4) * sizeof(float);
   const size_t bsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4 + 16 * m.R * 4) * sizeof(float);
   const int gl = (dl && !getenv("IGMC_DL_NOBWD")) ? igmc_dl_grid(b, B) : gt;      // grid of the layer kernels
-  for (int l = 1; l < 4; ++l) {
+  for (int l = 1; l < 4 && !dlf; ++l) {
     float* zo = (l == 3) ? m.dpre[3] : nullptr;
     if (dl) {
       igmc_launch_dl_layer(m, b, (const float*)P, B, l, 0, use_flags, zo, stream);
@@ -2388,8 +2396,7 @@ int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchD
   // dense layers whose backward passes leave relation-space tables (igmc_dl_ts_eligible): the tail of the subgraph kernel
   // -- k_tail_ts sums the workgroups' tables and forms d lin1 / d lin2, k_finalize_ts turns them into gradients (+ Adam) --
   // replaces the Y products, G, the weight-gradient products and their reduction
-  const int fts = igmc_fin_mode() && m.fin_stash && m.datt_part && m.R <= 8;
-  if (dl && l0_mfma && fts && !getenv("IGMC_DL_NOBWD") && igmc_dl_ts_eligible(m, b, B)) {
+  if (dlts) {
     if (m.D == 256 && !getenv("IGMC_HEAD_TRAIN"))           // one workgroup per subgraph
       igmc_launch_head_sub(m, b, (const float*)P, B, inj_mask, seed, step, mult, grad_scale, out, stream);
     else                                                      // (head role only: 16 subgraphs per workgroup)
@@ -2399,7 +2406,7 @@ int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchD
     const int gstride = (B + 7) & ~7, gg = igmc_dl_grid(b, B) / B * gstride;
     IGMC_PLAUNCH("k_tail_ts", k_tail_ts, 8 * ny + (4 * m.ts_stride + 63) / 64 + 4, IGMC_BLOCK, 0, stream, b, m,
                  (const float*)P, grad_scale, mult, 2.f, grad, 8 * ny, gg, gstride, B, 4,
-                 (const int64_t*)(adam ? at.ctrl : nullptr), 0);
+                 (const int64_t*)(adam ? at.ctrl : nullptr), dlf ? 1 : 0);
     if (xch) {
       const int rc = xch->sum(xch->user, m.ts_raw, (int64_t)4 * m.ts_stride + (int64_t)4 * m.ts_stride / 32 * 4,
                               grad + m.off_l1w, n_lin, stream);
