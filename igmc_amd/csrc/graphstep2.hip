@@ -2183,6 +2183,351 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
   dlx_seq_done(a.gs_bar, a.self_seq);
 }
 
+// ... and the backward of the three conv layers as ONE launch (relation-space tables: see k_dl_layer<*, true, true>): dPre_l
+// travels between the members through exchanges 3 and 4, the block rows are staged once, dPre_3 (non-zero on the two target
+// rows only) is built in place from the head's output, and nothing but the tables leaves the launch.
+struct DlbArgs {
+  const int32_t* n_users;
+  const int32_t* n_items;
+  const int32_t* node_off;
+  const uint8_t* node_label;
+  const uint8_t* relm;
+  const uint8_t* relmT;
+  int cap_u, cap_v, relm_ld, relmT_ld, nq, R, L, D, kp;
+  const float* h[3];             // h_0 .. h_2
+  const float* dpre3;            // [N, 32]: the head's dPre_3 (target rows)
+  const float* gfeat;            // [B, D] readout gradient on the target rows
+  const float* g2_w;
+  const uint16_t* cnt0;
+  float* ts_part;
+  int ts_stride, slot_stride;
+  unsigned long long* ex;
+  size_t ex_stride;
+  int* gs_bar;
+  int* gs_err;
+};
+
+__host__ __device__ static inline int dlb_words(int kp) {
+  const int mid = (G2_NT * 32 * kp >> 1) + G2_WIMG, til = DL_NW * 16 * G2_TP;
+  return 2 * DL_NW * 16 * G2_XP + DL_NW * 4 * kp + (mid > til ? mid : til);
+}
+
+template <bool FLAGS>
+__global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
+  IGMC_DYN_SMEM(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int bid = blockIdx.x;
+  const int g = bid / (2 * a.nq), rem = bid - g * 2 * a.nq, side = rem / a.nq, q = rem - side * a.nq;
+  const int cu = a.n_users[g], cv = a.n_items[g];
+  const int n_own = side ? cv : cu, n_opp = side ? cu : cv;
+  const int R = a.R, L = a.L, RL = R * L, rows0 = RL + L + 1;
+  const int ts = a.ts_stride;
+  const size_t slot = (size_t)g + (size_t)rem * a.slot_stride;
+  float* part0 = a.ts_part + slot * ts;
+  if (16 * DL_NW * q >= n_own) {                 // nothing of this side in the workgroup's rows: all-zero partial tables
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int l = 1; l < 4; ++l) {
+      float* wp = a.ts_part + ((size_t)l * IGMC_TS_BLOCKS + slot) * ts;
+      for (int i = tid; i < (ts >> 2); i += DL_THREADS) ((float4*)wp)[i] = z4;
+    }
+    for (int i = tid; i < rows0 * 8; i += DL_THREADS) ((float4*)part0)[i] = z4;
+    return;
+  }
+#ifndef IGMC_HIPEMU
+  const uint32_t seq = (uint32_t)__hip_atomic_load(a.gs_bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  const uint32_t seq = (uint32_t)a.gs_bar[1];
+#endif
+  const uint32_t tag0 = seq * 8u + 1u;
+  auto tag16 = [&](int x) { return 1u + (tag0 + (uint32_t)x) % 65535u; };
+  const int nb = a.node_off[g];
+  const int own0 = nb + (side ? cu : 0), opp0 = nb + (side ? 0 : cu);
+  const int kp = a.kp, rmp = kp;
+  const int nks = (n_opp + 31) >> 5;
+  const int npad_opp = ((n_opp + 15) >> 4) << 4;
+  float* XOA = (float*)smem;                                              // [DL_NW][16][G2_XP] dPre_l of the rows
+  float* HSA = XOA + DL_NW * 16 * G2_XP;                                  // [DL_NW][16][G2_XP] h_{l-1} of the rows
+  float* sbias = HSA;                                                     // (d bias scratch: dead before the h rows land)
+  unsigned char* RMW = (unsigned char*)(HSA + DL_NW * 16 * G2_XP);        // [DL_NW][16][rmp] bytes
+  uint32_t* PLN = (uint32_t*)(RMW + DL_NW * 16 * rmp);                    // [3][32][kp] bf16
+  float2* sW2 = (float2*)(PLN + (G2_NT * 32 * kp >> 1));                  // [G2_WIMG words]
+  float* TIL = (float*)PLN;                                               // [DL_NW][16][G2_TP] T' tiles (alias planes + image)
+  const int row0 = 16 * DL_NW * q + 16 * wave;
+  const bool active = row0 < n_own;
+  const size_t exs = a.ex_stride;
+  unsigned long long* ex_own = a.ex + ((size_t)g * 2 + side) * (32 * DLX_K);
+  const unsigned long long* ex_opp = a.ex + ((size_t)g * 2 + (1 - side)) * (32 * DLX_K);
+
+  // ---- staging: block rows, the target rows of dPre_3, the layer-0 inputs of the rows (layer-0 table gradient), image 3
+  const int ldb = side ? a.relmT_ld : a.relm_ld, ldw = ldb >> 2;
+  const uint8_t* rsrc = side ? a.relmT + (size_t)g * a.cap_v * a.relmT_ld : a.relm + (size_t)g * a.cap_u * a.relm_ld;
+  const int rw = rmp >> 2;
+  uint32_t rmq[DL_RIT];
+#pragma unroll
+  for (int u = 0; u < DL_RIT; ++u) {
+    const int i = lane + 64 * u, r = i / rw, c = i - r * rw;
+    const int rc = row0 + r < n_own ? row0 + r : n_own - 1, cc = c < ldw ? c : ldw - 1;
+    rmq[u] = ((const uint32_t*)(rsrc + (size_t)rc * ldb))[cc];
+  }
+  const float d3 = (tid < 64) ? a.dpre3[(size_t)((tid >> 5) ? own0 : opp0) * 32 + (tid & 31)] : 0.f;   // opposite | own target row
+  uint16_t c0q[5];
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const int i = lane + 64 * u, r = i / RL, c = i - r * RL;
+    const int rc = (r < 16 && row0 + r < n_own) ? row0 + r : n_own - 1;
+    c0q[u] = a.cnt0[(size_t)(own0 + rc) * RL + (r < 16 ? c : 0)];
+  }
+  const int own_lab = (int)a.node_label[own0 + (row0 + li < n_own ? row0 + li : n_own - 1)];
+  constexpr int NWQ = (G2_WIMG / 4 + DL_THREADS - 1) / DL_THREADS;
+  f32x4 wq[NWQ];                                  // a layer's transposed weight image: requested at the top of the layer,
+  auto wpre = [&](int l) {                        // stored behind the exchange poll (held across a layer it costs 38 spills)
+    const f32x4* src = (const f32x4*)(a.g2_w + (size_t)((l - 1) * 2 + 1) * G2_WIMG);
+#pragma unroll
+    for (int u = 0; u < NWQ; ++u) {
+      const int i = tid + u * DL_THREADS;
+      wq[u] = src[i < G2_WIMG / 4 ? i : G2_WIMG / 4 - 1];
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int u = 0; u < NWQ; ++u) {
+      const int i = tid + u * DL_THREADS;
+      if (i < G2_WIMG / 4) ((f32x4*)sW2)[i] = wq[u];
+    }
+  };
+#ifndef IGMC_HIPEMU
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  {   // planes (dPre_3: node 0 of the opposite side only; k-steps past the published rows read zeros later) and row tiles
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < (G2_NT * 32 * kp >> 3); i += DL_THREADS) ((float4*)PLN)[i] = z4;
+    for (int i = tid; i < 2 * DL_NW * 16 * G2_XP / 4; i += DL_THREADS) ((float4*)XOA)[i] = z4;
+  }
+  {
+    uint32_t* dst = (uint32_t*)(RMW + (size_t)wave * 16 * rmp);
+#pragma unroll
+    for (int u = 0; u < DL_RIT; ++u) {
+      const int i = lane + 64 * u, r = i / rw, c = i - r * rw;
+      if (i < 16 * rw) dst[i] = (row0 + r < n_own && c < ldw && 4 * c < 32 * nks) ? rmq[u] : 0u;
+    }
+  }
+  __syncthreads();
+  if (tid < 32) {                                  // dPre_3 of the opposite side's target node: the three terms of node 0
+    uint32_t h, mi, lo;
+    g2_split2(d3, 0.f, h, mi, lo);
+    uint32_t* p2 = PLN + (tid * kp >> 1);
+    p2[0] = h & 0xFFFFu;
+    p2[32 * kp >> 1] = mi & 0xFFFFu;
+    p2[2 * (32 * kp >> 1)] = lo & 0xFFFFu;
+  } else if (tid < 64 && q == 0) {
+    XOA[tid & 31] = d3;                            // own target row = row 0 of the side's first bundle
+  }
+  // (no barrier: the layer loop starts with one)
+
+  const unsigned char* rmo = RMW + (size_t)(wave * 16 + li) * rmp + 8 * kq;
+  const int kbit = side ? 3 : 4;                   // keep bit of the edge own -> opposite
+  const int nbun = (n_own - 16 * DL_NW * q + 15) >> 4;
+  const int nact = nbun < DL_NW ? nbun : DL_NW;    // bundles of this workgroup that hold rows
+  float* XO = XOA + wave * 16 * G2_XP;
+  float* T = TIL + wave * 16 * G2_TP;
+  float* HS = HSA + wave * 16 * G2_XP;
+  float dv[2][4];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) dv[nt][rr] = 0.f;
+
+#pragma unroll 1
+  for (int l = 3; l >= 1; --l) {
+    float* wpart = a.ts_part + ((size_t)l * IGMC_TS_BLOCKS + slot) * ts;
+    wpre(l);
+    if (l < 3) dlx_reload(PLN, kp, ex_opp + (5 - l) * exs, npad_opp, tag16(5 - l), a.gs_err);
+    stage();
+    __syncthreads();                               // planes, image, dPre_l of the rows are in place
+    {   // d bias_l = column sums of dPre_l over the workgroup's rows (fixed order)
+      const int n = tid & 31, part = tid >> 5;
+      float sb = 0.f;
+      for (int row = part; row < DL_NW * 16; row += DL_THREADS / 32) sb += XOA[(row >> 4) * 16 * G2_XP + (row & 15) * G2_XP + n];
+      sbias[part * 32 + n] = sb;
+    }
+    __syncthreads();
+    if (tid < 32) {
+      float s2 = 0.f;
+#pragma unroll
+      for (int p = 0; p < DL_THREADS / 32; ++p) s2 += sbias[p * 32 + tid];
+      wpart[(R * 32 + 32) * 32 + tid] = s2;
+    }
+    f32x4 acc[G2_NR][2];
+#pragma unroll
+    for (int r = 0; r < G2_NR; ++r) {
+      acc[r][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    float xprev[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) xprev[nt][rr] = 0.f;
+    if (active) {
+      float addv[2][4];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int rw2 = row0 + 4 * kq + rr, rwc = rw2 < n_own ? rw2 : n_own - 1;
+          xprev[nt][rr] = a.h[l - 1][(size_t)(own0 + rwc) * 32 + 16 * nt + li];
+          addv[nt][rr] = (rw2 == 0) ? a.gfeat[(size_t)g * a.D + side * 128 + (l - 1) * 32 + 16 * nt + li] : 0.f;
+        }
+      const int tstride = 32 * kp >> 1, toff = 16 * kp >> 1;
+      const uint32_t* base = PLN + (li * kp >> 1) + 4 * kq;
+      const int nke = (l == 3) ? 1 : nks;           // dPre_3 lives on node 0: one k-step
+#pragma unroll 1
+      for (int s = 0; s < nke; ++s) {
+        const uint2 w = *(const uint2*)(rmo + 32 * s);
+        u32x4 pf[2 * G2_NT];
+#pragma unroll
+        for (int sp = 0; sp < G2_NT; ++sp) {
+          pf[2 * sp] = *(const u32x4*)(base + sp * tstride + 16 * s);
+          pf[2 * sp + 1] = *(const u32x4*)(base + sp * tstride + toff + 16 * s);
+        }
+#pragma unroll
+        for (int r = 0; r < G2_NR; ++r) {
+          u32x4 af;
+          uint32_t a0, a1, a2, a3;
+          g2_expand4<FLAGS>(w.x, (uint32_t)(r + 1), kbit, a0, a1);
+          g2_expand4<FLAGS>(w.y, (uint32_t)(r + 1), kbit, a2, a3);
+          af[0] = a0; af[1] = a1; af[2] = a2; af[3] = a3;
+#pragma unroll
+          for (int qq = 0; qq < 2 * G2_NT; ++qq) acc[r][qq & 1] = g2_mfma_bf16(pf[qq], af, acc[r][qq & 1]);
+        }
+      }
+      f32x4 o[2];
+      g2_transform(acc, XO, (const uint32_t*)sW2, li, kq, o);
+      unsigned long long* exb = ex_own + (6 - l) * exs + (size_t)li * DLX_K + row0 + 4 * kq;
+      const uint32_t tgb = tag16(6 - l);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const bool ok = row0 + 4 * kq + rr < n_own;
+          const float x = xprev[nt][rr];
+          dv[nt][rr] = ok ? (o[nt][rr] + addv[nt][rr]) * (1.f - x * x) : 0.f;
+          if (!ok) xprev[nt][rr] = 0.f;             // (rows past the side: zero K entries of the table product)
+        }
+        if (l > 1) g2_publish4(exb + (size_t)nt * 16 * DLX_K, 0, dv[nt], tgb);
+      }
+    }
+    __syncthreads();                               // every wave is done with planes / image: the T' tiles take their space
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < G2_NR; ++r)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          *(float4*)(T + li * G2_TP + r * 32 + 16 * t + 4 * kq) = make_float4(acc[r][t][0], acc[r][t][1], acc[r][t][2], acc[r][t][3]);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) HS[(4 * kq + rr) * G2_XP + 16 * nt + li] = xprev[nt][rr];
+    }
+    __syncthreads();
+    {   // table h_{l-1}^T [T'_0 .. T'_4 | dPre_l]: 2 x 12 output tiles over the 8 waves, K = the active bundles' rows
+      f32x4 w3[3];
+#pragma unroll
+      for (int i3 = 0; i3 < 3; ++i3) w3[i3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int m2w = wave >> 2, nt0 = 3 * (wave & 3);
+#pragma unroll 1
+      for (int wb = 0; wb < nact; ++wb) {
+        const float* Tb = TIL + wb * 16 * G2_TP;
+        const float* Hb = HSA + wb * 16 * G2_XP;
+        const float* Db = XOA + wb * 16 * G2_XP;
+        float av[4], bw[4][3];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          av[s4] = Hb[(4 * s4 + kq) * G2_XP + m2w * 16 + li];
+#pragma unroll
+          for (int i3 = 0; i3 < 3; ++i3) {
+            const int nt = nt0 + i3;
+            bw[s4][i3] = (nt < 2 * G2_NR) ? Tb[(4 * s4 + kq) * G2_TP + nt * 16 + li]
+                                          : Db[(4 * s4 + kq) * G2_XP + (nt - 2 * G2_NR) * 16 + li];
+          }
+        }
+#ifndef IGMC_HIPEMU
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int i3 = 0; i3 < 3; ++i3) w3[i3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bw[s4][i3], w3[i3], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i3 = 0; i3 < 3; ++i3) {
+        const int nt = nt0 + i3, r = nt >> 1;
+        if (r >= R && r < G2_NR) continue;
+        float* pp = wpart + (kq * 4) * 32 + li + (r < R ? r : R) * 1024 + m2w * 512 + (nt & 1) * 16;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) pp[rr * 32] = w3[i3][rr];
+      }
+    }
+    __syncthreads();                               // tiles, h rows and dPre_l are consumed
+    if (l > 1) {
+      // dPre_{l-1} of the rows becomes the next layer's own rows; the planes' first k-steps were tiles: zero what the next
+      // reload does not cover
+      if (active) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) XO[(4 * kq + rr) * G2_XP + 16 * nt + li] = dv[nt][rr];
+      }
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = tid; i < (G2_NT * 32 * kp >> 3); i += DL_THREADS) ((float4*)PLN)[i] = z4;
+      __syncthreads();                             // (the zero fill is complete before the reload writes into it)
+    }
+  }
+  // ---- layer-0 table gradient T0'[c][f] = sum_i [hist | onehot | 1](i, c) dPre_0[i][f] over the workgroup's rows
+  {
+    float* HI = TIL + wave * 16 * G2_XP;
+    float* D0 = TIL + (DL_NW + wave) * 16 * G2_XP;
+    if (active) {
+      for (int i = lane; i < 16 * G2_XP; i += 64) HI[i] = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) D0[(4 * kq + rr) * G2_XP + 16 * nt + li] = dv[nt][rr];
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const int i = lane + 64 * u, r = i / RL, c = i - r * RL;
+        if (r < 16 && row0 + r < n_own) HI[r * G2_XP + c] = (float)c0q[u];
+      }
+      if (kq == 0 && row0 + li < n_own) {
+        HI[li * G2_XP + RL + own_lab] = 1.f;
+        HI[li * G2_XP + RL + L] = 1.f;
+      }
+    }
+    __syncthreads();
+    if (wave < 4) {
+      const int m2 = wave >> 1, wn = wave & 1;
+      f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int wb = 0; wb < nact; ++wb) {
+        const float* Hb = TIL + wb * 16 * G2_XP;
+        const float* Db = TIL + (DL_NW + wb) * 16 * G2_XP;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Hb[(4 * s4 + kq) * G2_XP + m2 * 16 + li],
+                                                      Db[(4 * s4 + kq) * G2_XP + wn * 16 + li], acc0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int c = m2 * 16 + kq * 4 + rr;
+        if (c < rows0) part0[c * 32 + wn * 16 + li] = acc0[rr];
+      }
+    }
+  }
+}
+
 // Training head of the dense per-layer path, ONE workgroup per subgraph (k_graph_step2's head as a launch of its own): the
 // 256 conv features of the two target rows -> lin1 / ReLU / dropout / lin2 / residual -> dz, d feat and dPre_3 on the
 // target rows.  (k_head_train's head role takes 16 subgraphs per workgroup on the f32 matrix cores: four workgroups at
@@ -2578,6 +2923,38 @@ void igmc_launch_dl_fwd(const ModelDev& m, const BatchDev& b, const float* P, in
   }
 }
 
+// (k_dl_bwd: same conditions as k_dl_fwd -- whose launch precedes it and maintains the exchange regions -- plus the tables')
+int igmc_dl_bwd_eligible(const ModelDev& m, const BatchDev& b, int B) {
+  if (!igmc_dl_fwd_eligible(m, b, B) || !igmc_dl_ts_eligible(m, b, B) || m.D != 256) return 0;
+  const char* e = getenv("IGMC_DL_FUSED");
+  if (e && atoi(e) == 1) return 0;                 // (1: the forward only)
+  const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
+  return (size_t)dlb_words(32 * ((cmax + 31) >> 5) + 8) * 4 <= (size_t)160 * 1024;
+}
+
+void igmc_launch_dl_bwd(const ModelDev& m, const BatchDev& b, int B, int use_flags, void* stream) {
+  DlbArgs a;
+  memset(&a, 0, sizeof(a));
+  const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
+  a.n_users = b.n_users; a.n_items = b.n_items; a.node_off = b.node_off; a.node_label = b.node_label;
+  a.relm = b.relm; a.relmT = b.relmT;
+  a.cap_u = b.cap_u; a.cap_v = b.cap_v; a.relm_ld = b.relm_ld; a.relmT_ld = b.relmT_ld;
+  a.nq = (cmax + 16 * DL_NW - 1) / (16 * DL_NW); a.R = m.R; a.L = m.L; a.D = m.D; a.kp = 32 * ((cmax + 31) >> 5) + 8;
+  for (int l = 0; l < 3; ++l) a.h[l] = m.h[l];
+  a.dpre3 = m.dpre[3]; a.gfeat = m.gfeat; a.g2_w = m.g2_w; a.cnt0 = m.cnt0;
+  a.ts_part = m.ts_part; a.ts_stride = m.ts_stride; a.slot_stride = (B + 7) & ~7;
+  a.ex = m.g2_ex; a.ex_stride = m.g2_ex_stride;
+  a.gs_bar = m.gs_bar; a.gs_err = m.gs_err;
+  const int grid = B * 2 * a.nq;
+  const size_t sm = (size_t)dlb_words(a.kp) * 4;
+#ifdef IGMC_HIPEMU
+  hipemu::rt().co_cs = 2 * a.nq;
+  hipemu::rt().co_stride = -1;
+#endif
+  if (use_flags) IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<true>), grid, DL_THREADS, sm, stream, a);
+  else IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<false>), grid, DL_THREADS, sm, stream, a);
+}
+
 int igmc_dl_prepare() {
 #ifndef IGMC_HIPEMU
   const int mx = 160 * 1024;
@@ -2587,6 +2964,8 @@ int igmc_dl_prepare() {
   if (hipFuncSetAttribute((const void*)k_dl_layer<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_dl_layer<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_dl_layer<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_dl_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+  if (hipFuncSetAttribute((const void*)k_dl_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_dl_fwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_dl_fwd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_dl_fwd<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;

@@ -2182,7 +2182,11 @@ void igmc_launch_conv_forward(const ModelDev& m, const BatchDev& b, const float*
   // slots of 129..256 nodes a side with a dense block: every conv layer on the matrix cores (graphstep2.hip, k_dl_layer0 /
   // k_dl_layer) from the blocks alone -- no edge list is read
   const int dl = igmc_dl_eligible(m, b, B);
-  if (dl) {
+  const int dlf = dl && igmc_dl_fwd_eligible(m, b, B);
+  if (dlf) {                                              // all four layers in ONE launch (k_dl_fwd); nothing follows that
+    igmc_launch_g2_compose(m, P, stream);                 // would advance its exchange tags: its last workgroup does
+    igmc_launch_dl_fwd(m, b, P, B, training, use_flags, training ? m.dpre[3] : nullptr, 1, stream);
+  } else if (dl) {
     igmc_launch_g2_compose(m, P, stream);                 // the step's weight images + layer-0 table
     igmc_launch_dl_layer0(m, b, B, training, use_flags, stream);
   } else if (training) {
@@ -2195,7 +2199,7 @@ void igmc_launch_conv_forward(const ModelDev& m, const BatchDev& b, const float*
   const size_t ysz = (size_t)32 * (128 + 4) * sizeof(float);
   const int gt = igmc_xcd_grid(m, B, 16, 2048);                        // fused layer: 16 rows per workgroup
   const size_t fsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4) * sizeof(float);
-  for (int l = 1; l < 4; ++l) {
+  for (int l = 1; l < 4 && !dlf; ++l) {
     // the top layer's launch also clears dPre_3 (only its target rows are written by the head backward)
     float* zo = (training && l == 3) ? m.dpre[3] : nullptr;
     if (dl) {
@@ -2402,7 +2406,10 @@ int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchD
     else                                                      // (head role only: 16 subgraphs per workgroup)
       IGMC_PLAUNCH("k_head_train", k_head_train, dim3(hb, 1), 512, ysz, stream, b, m, (const float*)P, inj_mask, seed, step,
                    mult, grad_scale, out);
-    for (int l = 3; l >= 1; --l) igmc_launch_dl_layer(m, b, (const float*)P, B, l, 1, use_flags, nullptr, stream, 1);
+    if (dlf && m.D == 256 && !getenv("IGMC_HEAD_TRAIN") && igmc_dl_bwd_eligible(m, b, B))
+      igmc_launch_dl_bwd(m, b, B, use_flags, stream);         // the three backward layers as ONE launch
+    else
+      for (int l = 3; l >= 1; --l) igmc_launch_dl_layer(m, b, (const float*)P, B, l, 1, use_flags, nullptr, stream, 1);
     const int gstride = (B + 7) & ~7, gg = igmc_dl_grid(b, B) / B * gstride;
     IGMC_PLAUNCH("k_tail_ts", k_tail_ts, 8 * ny + (4 * m.ts_stride + 63) / 64 + 4, IGMC_BLOCK, 0, stream, b, m,
                  (const float*)P, grad_scale, mult, 2.f, grad, 8 * ny, gg, gstride, B, 4,
