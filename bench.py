@@ -72,7 +72,8 @@ CONFIGS = {
 }
 PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
 # timer label of the HIP-event profile -> kernel symbol in the code object (what rocprofv3 lists)
-SYMBOLS = {'k_dl_layer_fwd': 'k_dl_layer<FLAGS, false>', 'k_rgcn_layer_fwd': 'k_rgcn_layer4<FLAGS, false>'}
+SYMBOLS = {'k_dl_layer_fwd': 'k_dl_layer<FLAGS, false, false>', 'k_rgcn_layer_fwd': 'k_rgcn_layer4<FLAGS, false>',
+           'k_dl_bwd': 'k_dl_bwd<FLAGS>', 'k_dl_fwd': 'k_dl_fwd<FLAGS, true>'}
 
 
 def kernel_source_sha():
@@ -463,13 +464,14 @@ def main():
         N, E = float(np.mean(Ns)), float(np.mean(Es))
         kernels = {name: dict(us=ms / calls * 1e3, calls_per_step=calls / P) for name, ms, calls in rows}
         tot = sum(ms for _, ms, _ in rows)
-        dom = 'k_graph_step' if 'k_graph_step' in kernels else (
-            'k_dl_layer_fwd' if 'k_dl_layer_fwd' in kernels else (
-                'k_rgcn_layer_fwd' if 'k_rgcn_layer_fwd' in kernels else 'k_rgcn_gather_fwd'))
+        dom = next((k for k in ('k_graph_step', 'k_dl_bwd', 'k_dl_fwd', 'k_dl_layer_fwd', 'k_rgcn_layer_fwd') if k in kernels),
+                   'k_rgcn_gather_fwd')
         if dom in kernels:
             algo_bytes = 133.0 * E + 132.0 * N                  # one layer, one direction
             if dom == 'k_graph_step':                           # forward + backward of the 3 conv layers in one launch
                 algo_bytes *= 6.0
+            elif dom in ('k_dl_bwd', 'k_dl_fwd'):               # the 3 conv layers of one direction in one launch
+                algo_bytes *= 3.0
             eager_us = kernels[dom]['us']
             from_replay = bool(dom == 'k_graph_step' and replay_us)
             avg_us = replay_us if from_replay else eager_us

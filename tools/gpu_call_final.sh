@@ -1,9 +1,17 @@
 #!/bin/bash
-# Round-end GPU session: suite, smoke, the bench lines DESIGN.md quotes, the profiling recipe (kernel trace + PMC passes)
+# Round-end GPU session: the profiling recipe first (kernel trace + PMC passes: bench.py's roofline.traffic is read from the
+# summary of THIS kernel source), then the suite, smoke and the bench lines DESIGN.md quotes
 cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out/${1:-final}; mkdir -p $O
 export TMPDIR=/tmp
-timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log; tail -5 $O/pytest.log
+IGMC_COMMIT=${IGMC_COMMIT:-unknown} bash tools/profile_round.sh ml_1m > $O/profile_round.log 2>&1
+cp gpurun_out/prof/*.txt gpurun_out/prof/*.json $O/ 2>/dev/null
+cp gpurun_out/prof/pmc_traffic.json profiles/r03_pmc_traffic.json 2>/dev/null        # (same file is committed afterwards)
+# kernel trace of config 2 (ml_100k, cap 200)
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $OLDPWD/$O/kt100k -- python $OLDPWD/bench.py --config ml_100k --steps 100 --warmup 10 --no-cpu-baseline --profile-steps 0 --rmse-links 0 --dp-steps 0 > $OLDPWD/$O/kt100k.log 2>&1 )
+{ echo "# commit ${IGMC_COMMIT:-unknown}; rocprofv3 --kernel-trace --stats -- python bench.py --config ml_100k --steps 100 --warmup 10 --no-cpu-baseline --profile-steps 0 --rmse-links 0 --dp-steps 0"; python tools/rocprof_summary.py $O/kt100k; } > $O/kernel_stats_ml100k.txt 2>&1
+rm -rf $O/kt100k
+timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log; head -4 $O/pytest.log
 timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; tail -2 $O/smoke.log
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err                      # the driver's default form (200 / 20, all legs)
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver.json 2> $O/bench_driver.err
@@ -11,10 +19,9 @@ for c in douban ml_100k flixster yahoo_music; do
   st=200; [ $c = yahoo_music ] && st=64
   timeout 400 python bench.py --config $c --steps $st --warmup 20 --no-cpu-baseline --dp-steps 0 > $O/bench_$c.json 2> $O/bench_$c.err
 done
+timeout 300 python bench.py --dgcnn-rs --config douban --steps 200 --warmup 20 --no-cpu-baseline --dp-steps 0 --rmse-links 0 > $O/bench_dgcnn_douban.json 2> $O/bench_dgcnn_douban.err
 timeout 200 python tools/g2_phase_clocks.py > $O/phase_clocks.txt 2>&1
 timeout 200 python tools/g2_phase_clocks.py --overlap > $O/phase_clocks_overlap.txt 2>&1
-IGMC_COMMIT=${IGMC_COMMIT:-unknown} bash tools/profile_round.sh ml_1m > $O/profile_round.log 2>&1
-cp gpurun_out/prof/*.txt gpurun_out/prof/*.json $O/ 2>/dev/null
 python - "$O" <<'PY'
 import json,glob,sys
 for f in sorted(glob.glob(sys.argv[1]+'/bench_*.json')):
@@ -25,4 +32,4 @@ for f in sorted(glob.glob(sys.argv[1]+'/bench_*.json')):
     except Exception as e:
         print(f, 'ERR', e, open(f.replace('.json','.err')).read()[-800:])
 PY
-head -12 $O/kernel_stats.txt
+head -12 $O/kernel_stats.txt; head -14 $O/kernel_stats_ml100k.txt
