@@ -520,7 +520,9 @@ def run_fused_train_trajectory(be, case, R, steps=5, batch=None, use_dropout=Fal
 
 
 # ====================================================================== DGCNN_RS (sort-pool readout family)
-DGCNN_OUT_TOL, DGCNN_LOSS_RTOL, DGCNN_GRAD_TOL = 2e-4, 2e-4, 2e-3      # (sort-pool family: set from the GPU's record below)
+# (sort-pool family: <= 10 x the worst the GPU shows over its cases -- outputs 1.2e-6, loss 1.4e-7, gradients 2.2e-6 of the
+#  tensor's peak; profiles/r03_parity_observed.txt)
+DGCNN_OUT_TOL, DGCNN_LOSS_RTOL, DGCNN_GRAD_TOL = 1.2e-5, 1.5e-6, 2.2e-5
 
 
 def run_dgcnn_parity(be, case, R, k=12, use_dropout=True, ARR=0.001, seed=3, rtol=None, atol=None):

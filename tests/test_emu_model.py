@@ -270,6 +270,25 @@ def test_dense_per_layer_kernels_in_the_fused_train_step(be, monkeypatch):
     assert res['frac_off'] < 2e-3
 
 
+def test_dense_layers_launch_forms_agree_bit_for_bit(be, monkeypatch):
+    """k_dl_fwd / k_dl_bwd (one launch per direction, members of a subgraph exchanging rows), the forward alone as one
+    launch, one launch per layer pass: the same arithmetic in the same order, bit-identical parameters after the steps.
+    The case has two workgroups per side (more than 128 rows)."""
+    monkeypatch.setenv('IGMC_DL_ALWAYS', '1')
+    monkeypatch.setenv('IGMC_GRAPH_STEP', '0')
+    runs = {}
+    for fused in ('2', '1', '0'):
+        monkeypatch.setenv('IGMC_DL_FUSED', fused)
+        runs[fused] = PC.run_fused_train_trajectory(be, sub('synth_nocap:200', 8), R=5, steps=2, batch=4, use_dropout=True)
+        assert runs[fused]['frac_off'] < 2e-3
+    for other in ('1', '0'):
+        for k in ('params', 'm1', 'm2'):
+            assert np.array_equal(runs['2'][k], runs[other][k]), (other, k)
+    monkeypatch.setenv('IGMC_DL_TS', '0')          # the G / Y form of the backward: another order of the sums
+    gy = PC.run_fused_train_trajectory(be, sub('synth_nocap:200', 8), R=5, steps=2, batch=4, use_dropout=True)
+    assert gy['frac_off'] < 2e-3 and not np.array_equal(gy['params'], runs['2']['params'])
+
+
 def test_dense_per_layer_kernels_with_side_features(be, monkeypatch):
     """The dense per-layer kernels only replace the conv layers: a model with side features (centre-node readout + the
     two targets' feature rows, reference models.py:208-209) takes them too."""
