@@ -314,3 +314,32 @@ def test_weight_images_left_by_the_step_equal_the_composed_ones(monkeypatch, pat
         for a, b in zip(ref_ev, ev):
             assert np.array_equal(a, b), (what, 'eval')
     assert np.array_equal(ref_ev[0], ref_ev[1])
+
+
+def test_host_callback_communicator_reports_a_failing_callback():
+    """igmc_comm_create_host: the caller's sum runs inside igmc_allreduce_grads / igmc_train_step_dp; a callback that fails
+    (an exception cannot cross the C frame) makes the call fail with the library's error, not silently skip the exchange."""
+    from igmc_amd import parallel
+    be = PC.EmuBackend()
+    lib = be.lib
+    seen = []
+
+    def good(ptr, n, stream):
+        buf = np.ctypeslib.as_array((C.c_float * n).from_address(ptr))
+        seen.append(n)
+        buf *= 2.0                         # "two ranks holding the same values"
+
+    comm = parallel.HostComm(lib, good, 0, 2)
+    assert comm.info() == (0, 2)
+    x = np.arange(5, dtype=np.float32)
+    lib.call('igmc_allreduce_grads', comm.handle, C.c_void_p(x.ctypes.data), 5, 0.5, None)
+    assert seen == [5] and np.array_equal(x, np.arange(5, dtype=np.float32))      # summed, then scaled by 1 / world
+
+    def bad(ptr, n, stream):
+        raise ValueError('no peers')
+
+    comm2 = parallel.HostComm(lib, bad, 0, 2)
+    with pytest.raises(RuntimeError, match='host all-reduce callback failed'):
+        lib.call('igmc_allreduce_grads', comm2.handle, C.c_void_p(x.ctypes.data), 5, 1.0, None)
+    with pytest.raises(RuntimeError, match='bad arguments'):
+        lib.call('igmc_comm_create_host', None, None, 0, 2, C.byref(C.c_void_p()))
