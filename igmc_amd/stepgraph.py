@@ -104,6 +104,10 @@ class GroupPipeline(object):
     def _extract_group(self, q, count):
         return False
 
+    def _extract_plan(self, q, count):
+        """The extraction of batches 0 .. count-1 of the group of parity ``q`` as a list of launches (callables), in order."""
+        return [lambda: self._extract_many(q, count)]
+
     def _fill_group(self):
         """Eager extraction of the batches of the current group that lie inside the epoch (group parity 0, from batch 0)."""
         assert self.gq == 0 and self.gk == 0
@@ -122,20 +126,47 @@ class GroupPipeline(object):
         cur = [self._arena(q, i) for i in range(self.M)]
         for i in range(self.M):
             self._arena(1 - q, i)
+        # PACED extraction (default): launch j of the next group's extraction may start when step j * per of this group
+        # starts (= when the step before it has finished) -- never in the middle of a step.  The subgraph kernel needs a CU
+        # to itself (one wave per SIMD with the whole register file): dispatched together with an extraction launch it takes
+        # its 200 CUs first and the extraction workgroups fill the other 56; an extraction launch that is already spread over
+        # the chip when the subgraph kernel arrives makes its workgroups wait for whole CUs to drain (+13 us on such steps).
+        # Default where the subgraph kernel takes the steps (same-box: its launches 63.2 -> 60.8 us, step 87.8 -> 87.3 us);
+        # elsewhere the extraction chain runs free beside the group's steps (the longer chain of the cap-200 arenas, confined
+        # to the CUs the dense-layer launches leave, would reach the group's join late: 125.8 -> 129.9 us).  IGMC_EXTRACT_PACED=0|1.
+        plan = self._extract_plan(1 - q, self.M)
+        paced = os.environ.get('IGMC_EXTRACT_PACED', '1' if self._paced_default() else '0') != '0' and len(plan) > 1
+        per = max(1, self.M // max(1, len(plan)))
         self._fork()
-        # the model kernels are enqueued BEFORE the extraction branch: the subgraph kernel (one workgroup per CU on 200 of
-        # 256 CUs) is dispatched first and the extraction workgroups fill what is left
+        nxt = 0
         for i in range(self.M):
+            mark = self._mark() if (paced and nxt < len(plan) and i == nxt * per and i > 0) else None
             if q == 1 or i > 0:
                 # inside a pair of groups nothing but the previous step touches the parameters: that step left the weight
                 # images of its updated parameters behind, this one starts with the subgraph kernel
                 self._hint_unchanged()
+            # (the model kernels are enqueued BEFORE the extraction launch that becomes ready with them)
             self._enqueue_step(cur[i], self.B)
-        self._side(lambda: self._extract_many(1 - q, self.M))
+            if paced and nxt < len(plan) and i == nxt * per:
+                self._side_after(mark, plan[nxt])
+                nxt += 1
+        for fn in plan[nxt:]:
+            self._side(fn)
         self._join()
 
     def _hint_unchanged(self):
         """Backends that keep weight images tell the library that the parameters are those of the previous step."""
+
+    def _paced_default(self):
+        return False
+
+    def _mark(self):
+        """A point of the main chain the extraction chain can wait for (backends with two chains)."""
+        return None
+
+    def _side_after(self, mark, fn):
+        """``fn`` on the extraction chain, not before ``mark`` (None: no further dependency)."""
+        self._side(fn)
 
     def _enqueue_pair(self):
         """One graph launch: the group of parity 0, then the group of parity 1 (2 M steps)."""
@@ -331,6 +362,42 @@ class StepGraph(GroupPipeline):
                        drop_seed=m.seed, stream=st)
             i0 += n
         return True
+
+    def _extract_plan(self, q, count):
+        m = self.model
+        sets = self._batch_sets(q, count)
+        if sets is None:
+            return [(lambda i=i: self._extract(self._arena(q, i), q | (i << 1), self.B)) for i in range(count)]
+        plan, i0 = [], 0
+        for bs in sets:
+            n = min(len(bs.arenas), count - i0)
+            if n <= 0:
+                break
+
+            def launch(bs=bs, n=n, i0=i0):
+                bs.extract(n, self.ds.link_u.data_ptr(), self.ds.link_v.data_ptr(), self.ds.link_y.data_ptr(),
+                           self.perm.data_ptr(), q | (i0 << 1), self.B, self.ds.sample_ratio, self.ds.seed,
+                           drop_p=m.adj_dropout if (self.TRAINING and m.adj_dropout > 0) else 0.0,
+                           force_undirected=m.force_undirected, drop_seed=m.seed,
+                           stream=torch.cuda.current_stream().cuda_stream)
+            plan.append(launch)
+            i0 += n
+        return plan
+
+    def _paced_default(self):
+        return self.sp is None and bool(self.ws.dense_path(self._arena(0, 0), self.B))
+
+    def _mark(self):
+        if self.side is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def _side_after(self, mark, fn):
+        if self.side is not None and mark is not None:
+            self.side.wait_event(mark)
+        self._side(fn)
 
     def begin_epoch(self, perm, epoch):
         """``perm``: this rank's link positions for the epoch (1-D int tensor, any device)."""
