@@ -1299,7 +1299,7 @@ extern "C" int igmc_sortpool_create(igmc_model* m, int k, int max_nodes_per_grap
   Allocs& M = sp->mem;
   const size_t Bc = (size_t)md.graph_cap, N = (size_t)md.node_cap;
   int fail = 0;
-  fail |= M.get(&d.sel, Bc * k) | M.get(&d.y1, Bc * 16 * k) | M.get(&d.flat, Bc * d.dense) | M.get(&d.a1, Bc * 128) |
+  fail |= M.get(&d.sel, Bc * k) | M.get(&d.y1, Bc * 16 * k) | M.get(&d.flat, Bc * d.dense) | M.get(&d.dflat, Bc * d.dense) | M.get(&d.lin_part, 8 * Bc) | M.get(&d.lin_ctr, Bc / 16 + 1) | M.get(&d.a1, Bc * 128) |
           M.get(&d.lmask, Bc * 128) | M.get(&d.dz, Bc * 128) | M.get(&d.dout, Bc) |
           M.get(&d.part_c1, Bc * (16 * 97 + 16)) | M.get(&d.part_c2, Bc * (32 * 16 * 5 + 32));
   for (int l = 0; l < 3; ++l) fail |= M.get(&d.dcat[l], N * 32);
@@ -1309,6 +1309,7 @@ extern "C" int igmc_sortpool_create(igmc_model* m, int k, int max_nodes_per_grap
     delete sp;
     IGMC_FAIL("hipMalloc failed (sort-pool workspace)");
   }
+  HIPCHECK(hipMemset(d.lin_ctr, 0, (Bc / 16 + 1) * sizeof(int)));        // arrival counters: zero between launches
   HIPCHECK(hipMemset(sp->pe, 0, (size_t)md.n_params * sizeof(float)));
   HIPCHECK(hipMemset(sp->ge, 0, (size_t)md.n_params * sizeof(float)));
   if (igmc_sp_prepare(d)) { M.release(); delete sp; IGMC_FAIL("hipFuncSetAttribute failed"); }

@@ -15,6 +15,9 @@ struct SpDev {
   float* a1;                // [Bcap][128]    relu(lin1)
   uint8_t* lmask;           // [Bcap][128]
   float* dz;                // [Bcap][128]
+  float* dflat;             // [Bcap][dense]  d loss / d flat through conv2's ReLU (k_sp_dflat)
+  float* lin_part;          // [8][Bcap]      lin2 partial dot products of the 16-unit tiles (k_sp_lin_fwd)
+  int* lin_ctr;             // [Bcap/16 + 1]  arrivals per row tile (zero between launches)
   float* dout;              // [Bcap]
   float* part_c1;           // [Bcap][16*97+16]
   float* part_c2;           // [Bcap][32*16*5+32]

@@ -22,6 +22,8 @@
 #include <stdio.h>
 
 #define SP_THREADS 256
+#define SP_WG 1024       // threads of the per-subgraph kernels (k_sp_fwd, k_sp_bwd): their loops over LDS are latency-bound
+                         // chains -- four waves per SIMD hide what one wave per SIMD exposes
 #define SP_C 97          // channels of a pooled row
 #define SP_C1 16         // conv1 output channels
 #define SP_C2 32         // conv2 output channels
@@ -79,14 +81,14 @@ __device__ void sp_select(const BatchDev& b, const ModelDev& m, const SpDev& sp,
   const int n0 = b.node_off[g], n = b.node_off[g + 1] - n0;
   int P = 1;
   while (P < n) P <<= 1;
-  for (int i = tid; i < P; i += SP_THREADS) {
+  for (int i = tid; i < P; i += SP_WG) {
     keys[i] = (i < n) ? m.h[3][(size_t)(n0 + i) * 32] : -3.0e38f;
     idx[i] = (i < n) ? i : 0x7fffffff;
   }
   __syncthreads();
   for (int size = 2; size <= P; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = tid; t < (P >> 1); t += SP_THREADS) {
+      for (int t = tid; t < (P >> 1); t += SP_WG) {
         const int lo = ((t / stride) * (stride << 1)) + (t % stride), hi = lo + stride;
         const bool up = ((lo & size) == 0);                  // this sub-sequence is sorted "before-first"
         const float ka = keys[lo], kb = keys[hi];
@@ -100,14 +102,14 @@ __device__ void sp_select(const BatchDev& b, const ModelDev& m, const SpDev& sp,
       __syncthreads();
     }
   }
-  for (int p = tid; p < sp.k; p += SP_THREADS) sel_out[p] = (p < n) ? n0 + idx[p] : -1;
+  for (int p = tid; p < sp.k; p += SP_WG) sel_out[p] = (p < n) ? n0 + idx[p] : -1;
   __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------- forward
 // dynamic LDS: keys[P] | idx[P] | sel[k] | w1[16*97+16] | w2[32*80+32] | y1[16*k] | z[16*Q1] | y2[32*Q2] | a1[128] | red[8]
 template <bool TRAIN>
-__global__ __launch_bounds__(SP_THREADS) void k_sp_fwd(BatchDev b, ModelDev m, SpDev sp, const float* __restrict__ Pd,
+__global__ __launch_bounds__(SP_WG) void k_sp_fwd(BatchDev b, ModelDev m, SpDev sp, const float* __restrict__ Pd,
                                                         const uint8_t* __restrict__ inj_mask, uint64_t seed,
                                                         uint64_t step_arg, float* __restrict__ out) {
   IGMC_DYN_SMEM(smem);
@@ -124,12 +126,12 @@ __global__ __launch_bounds__(SP_THREADS) void k_sp_fwd(BatchDev b, ModelDev m, S
   float* a1s = y2 + SP_C2 * Q2;
   float* red = a1s + 128;
   const uint64_t step = m.ctrl ? (uint64_t)m.ctrl[IGMC_CTRL_STEP] : step_arg;
-  for (int i = tid; i < SP_C1 * SP_C + SP_C1; i += SP_THREADS) w1[i] = Pd[sp.t_c1w + i];      // weight [16][97] then bias [16]
-  for (int i = tid; i < SP_C2 * SP_C1 * SP_KW + SP_C2; i += SP_THREADS) w2[i] = Pd[sp.t_c2w + i];
+  for (int i = tid; i < SP_C1 * SP_C + SP_C1; i += SP_WG) w1[i] = Pd[sp.t_c1w + i];      // weight [16][97] then bias [16]
+  for (int i = tid; i < SP_C2 * SP_C1 * SP_KW + SP_C2; i += SP_WG) w2[i] = Pd[sp.t_c2w + i];
   sp_select(b, m, sp, g, keys, idx, sel);
-  for (int p = tid; p < k; p += SP_THREADS) sp.sel[(size_t)g * k + p] = sel[p];
+  for (int p = tid; p < k; p += SP_WG) sp.sel[(size_t)g * k + p] = sel[p];
   // conv1 (one pooled row per thread: its 97 channels are read once) + ReLU
-  for (int p = tid; p < k; p += SP_THREADS) {
+  for (int p = tid; p < k; p += SP_WG) {
     const int i = sel[p];
     float acc[SP_C1];
 #pragma unroll
@@ -149,13 +151,13 @@ __global__ __launch_bounds__(SP_THREADS) void k_sp_fwd(BatchDev b, ModelDev m, S
     }
   }
   __syncthreads();
-  for (int i = tid; i < SP_C1 * Q1; i += SP_THREADS) {            // MaxPool1d(2, 2)
+  for (int i = tid; i < SP_C1 * Q1; i += SP_WG) {            // MaxPool1d(2, 2)
     const int ic = i / Q1, q = i - ic * Q1;
     const float a = y1[ic * k + 2 * q], c = y1[ic * k + 2 * q + 1];
     z[i] = a >= c ? a : c;
   }
   __syncthreads();
-  for (int i = tid; i < SP_C2 * Q2; i += SP_THREADS) {            // conv2 + ReLU; flatten index = oc2 * Q2 + q
+  for (int i = tid; i < SP_C2 * Q2; i += SP_WG) {            // conv2 + ReLU; flatten index = oc2 * Q2 + q
     const int oc = i / Q2, q = i - oc * Q2;
     float acc = w2[SP_C2 * SP_C1 * SP_KW + oc];
     for (int ic = 0; ic < SP_C1; ++ic)
@@ -163,44 +165,152 @@ __global__ __launch_bounds__(SP_THREADS) void k_sp_fwd(BatchDev b, ModelDev m, S
       for (int t = 0; t < SP_KW; ++t) acc += w2[(oc * SP_C1 + ic) * SP_KW + t] * z[ic * Q1 + q + t];
     const float v = acc > 0.f ? acc : 0.f;
     y2[i] = v;
-    if (TRAIN) sp.flat[(size_t)g * dense + i] = v;
+    sp.flat[(size_t)g * dense + i] = v;             // lin1 / lin2 run batched over the subgraphs (k_sp_lin_fwd)
   }
-  __syncthreads();
-  // lin1 (dense -> 128): wave w takes units w, w + 4, ..; lanes stride over the fan-in (coalesced rows)
-  for (int j = wave; j < 128; j += SP_THREADS / 64) {
-    const float* wrow = Pd + sp.t_l1w + (size_t)j * dense;
-    float s = 0.f;
-    for (int i = lane; i < dense; i += 64) s += wrow[i] * y2[i];
-    s = igmc_wave_sum_f(s);
-    if (lane == 0) {
-      float av = s + Pd[sp.t_l1b + j];
-      av = av > 0.f ? av : 0.f;
-      int keep = 1;
-      if (TRAIN) {
-        keep = inj_mask ? (int)inj_mask[g * 128 + j]
-                        : (int)(igmc_u01(igmc_unit_hash(seed, step, (uint32_t)g, (uint32_t)j)) >= 0.5f);
-        sp.a1[g * 128 + j] = av;
-        sp.lmask[g * 128 + j] = (uint8_t)keep;
-      }
-      a1s[j] = (TRAIN ? (keep ? av * 2.f : 0.f) : av) * Pd[sp.t_l2w + j];        // F.dropout(p = 0.5): kept * 2
+  (void)a1s; (void)red; (void)lane; (void)wave; (void)inj_mask; (void)seed; (void)step; (void)out;
+}
+
+// lin1 (dense -> 128) + ReLU + dropout + lin2, batched over the subgraphs on the f32 matrix cores: workgroup = (16 subgraphs)
+// x (16 hidden units), its four waves split the fan-in (one round of <= 13 16-wide chunks each: every load of a wave is in
+// flight at once), partial accumulators meet in LDS.  lin2 needs all 128 units of a subgraph: every workgroup leaves its
+// 16-unit partial dot product, the LAST of the eight of a row tile to finish adds them in index order (a fixed order whoever
+// is last).  One workgroup per subgraph streamed the 426 KB of lin1.weight through each: 208 of the 247 us of the old
+// k_sp_fwd; four workgroups of 8 waves walking the whole fan-in: 60 us.
+template <bool TRAIN>
+__global__ __launch_bounds__(SP_THREADS) void k_sp_lin_fwd(BatchDev b, ModelDev m, SpDev sp, const float* __restrict__ Pd,
+                                                             const uint8_t* __restrict__ inj_mask, uint64_t seed,
+                                                             uint64_t step_arg, float* __restrict__ out) {
+  __shared__ float sacc[4][64][4];
+  __shared__ int s_last;
+  const int B = b.totals[3], dense = sp.dense;
+  const int mt = blockIdx.x, nt = blockIdx.y;
+  const int row0 = mt * 16;
+  if (row0 >= B) return;
+  const uint64_t step = m.ctrl ? (uint64_t)m.ctrl[IGMC_CTRL_STEP] : step_arg;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int ga = (row0 + li < B) ? row0 + li : B - 1;
+  const int n = nt * 16 + li;
+  const float* arow = sp.flat + (size_t)ga * dense + 4 * kq;
+  const float* wrow = Pd + sp.t_l1w + (size_t)n * dense + 4 * kq;
+  const float b1 = Pd[sp.t_l1b + n], w2 = Pd[sp.t_l2w + n], l2b = Pd[sp.t_l2b];
+  const int nch = dense / 16, per = (nch + 3) / 4;
+  f32x4 acc4[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  for (int c0 = wave * per; c0 < nch && c0 < (wave + 1) * per; c0 += 13) {
+    float4 a4[13], b4[13];
+    const int cend = (wave + 1) * per < nch ? (wave + 1) * per : nch;
+#pragma unroll
+    for (int u = 0; u < 13; ++u) {
+      const int c = (c0 + u < cend) ? c0 + u : cend - 1;
+      a4[u] = *(const float4*)(arow + 16 * c);
+      b4[u] = *(const float4*)(wrow + 16 * c);
+    }
+#pragma unroll
+    for (int u = 0; u < 13; ++u) {
+      if (c0 + u >= cend) continue;
+      f32x4& acc = acc4[u & 1];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u].x, b4[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u].y, b4[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u].z, b4[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u].w, b4[u].w, acc, 0, 0, 0);
     }
   }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) sacc[wave][lane][rr] = acc4[0][rr] + acc4[1][rr];
   __syncthreads();
   if (wave == 0) {
-    float s = a1s[lane] + a1s[lane + 64];
-    s = igmc_wave_sum_f(s);
-    if (lane == 0) {
-      const float o = s + Pd[sp.t_l2b];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = kq * 4 + rr, g = row0 + r;
+      float a = ((sacc[0][lane][rr] + sacc[1][lane][rr]) + (sacc[2][lane][rr] + sacc[3][lane][rr])) + b1;
+      a = a > 0.f ? a : 0.f;
+      int keep = 1;
+      if (TRAIN && g < B) {
+        keep = inj_mask ? (int)inj_mask[g * 128 + n]
+                        : (int)(igmc_u01(igmc_unit_hash(seed, step, (uint32_t)g, (uint32_t)n)) >= 0.5f);
+        sp.a1[g * 128 + n] = a;
+        sp.lmask[g * 128 + n] = (uint8_t)keep;
+      }
+      const float p = igmc_group16_sum_f((TRAIN ? (keep ? a * 2.f : 0.f) : a) * w2);      // F.dropout(p = 0.5): kept * 2
+      if (li == 0 && g < B) sp.lin_part[(size_t)nt * b.graph_cap + g] = p;
+    }
+  }
+  // the last workgroup of the row tile to get here has every partial in sight
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    s_last = (atomicAdd(sp.lin_ctr + mt, 1) == (int)gridDim.y - 1);
+  }
+  __syncthreads();
+  if (s_last) {
+    __threadfence();
+    if (tid < 16 && row0 + tid < B) {
+      const int g = row0 + tid;
+      float s2 = 0.f;
+      for (int t = 0; t < (int)gridDim.y; ++t) s2 += sp.lin_part[(size_t)t * b.graph_cap + g];
+      const float o = s2 + l2b;
       out[g] = o;
       m.err[g] = o - b.y[g];
     }
+    if (tid == 0) sp.lin_ctr[mt] = 0;
   }
-  (void)red;
+}
+
+// d flat = dz @ lin1.weight through conv2's ReLU, batched over the subgraphs on the f32 matrix cores: workgroup = (16
+// subgraphs) x (four 16-column tiles of the 32 Q2 columns), K = the 128 hidden units; dz is formed on the fly from the
+// forward's a1 / mask / residual (the first column tile also stores it, and d out, for the weight-gradient kernel)
+__global__ __launch_bounds__(SP_THREADS) void k_sp_dflat(BatchDev b, ModelDev m, SpDev sp, const float* __restrict__ Pd,
+                                                          float grad_scale) {
+  const int B = b.totals[3], dense = sp.dense;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int row0 = blockIdx.x * 16;
+  const int nt = blockIdx.y * 4 + wave;
+  if (row0 >= B || nt * 16 >= dense) return;
+  const int ga = (row0 + li < B) ? row0 + li : B - 1;
+  const int i0 = nt * 16;
+  const float dout = 2.f * m.err[ga] * grad_scale;                  // d (mean squared error) / d out
+  f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+  float4 dz4[8];
+  float bw[8][4];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {                     // hidden units 16 c + 4 kq .. + 3
+    const int j = 16 * c + 4 * kq;
+    const float4 av = *(const float4*)(sp.a1 + (size_t)ga * 128 + j);
+    const uint32_t mk = *(const uint32_t*)(sp.lmask + (size_t)ga * 128 + j);
+    const float4 w2 = *(const float4*)(Pd + sp.t_l2w + j);
+    dz4[c].x = (row0 + li < B && av.x > 0.f && (mk & 0xFFu)) ? dout * w2.x * 2.f : 0.f;
+    dz4[c].y = (row0 + li < B && av.y > 0.f && (mk & 0xFF00u)) ? dout * w2.y * 2.f : 0.f;
+    dz4[c].z = (row0 + li < B && av.z > 0.f && (mk & 0xFF0000u)) ? dout * w2.z * 2.f : 0.f;
+    dz4[c].w = (row0 + li < B && av.w > 0.f && (mk & 0xFF000000u)) ? dout * w2.w * 2.f : 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bw[c][t] = Pd[sp.t_l1w + (size_t)(j + t) * dense + i0 + li];
+  }
+  if (nt == 0 && row0 + li < B) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) *(float4*)(sp.dz + (size_t)ga * 128 + 16 * c + 4 * kq) = dz4[c];
+    if (kq == 0) sp.dout[ga] = dout;
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    f32x4& acc = (c & 1) ? acc1 : acc0;
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dz4[c].x, bw[c][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dz4[c].y, bw[c][1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dz4[c].z, bw[c][2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dz4[c].w, bw[c][3], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int g = row0 + 4 * kq + rr;
+    if (g >= B) continue;
+    const size_t at = (size_t)g * dense + i0 + li;
+    sp.dflat[at] = (sp.flat[at] > 0.f) ? acc0[rr] + acc1[rr] : 0.f;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- backward
-// dynamic LDS: sel[k] | rank[nmax] | w1[16*97] | w2[32*80] | y1[16*k] | z[16*Q1] | dy2[32*Q2] | dzp[16*Q1] | dy1[16*k] | dz[128]
-__global__ __launch_bounds__(SP_THREADS) void k_sp_bwd(BatchDev b, ModelDev m, SpDev sp, const float* __restrict__ Pd,
+// dynamic LDS: sel[k] | rank[nmax] | w1[16*97] | w2[32*80] | y1[16*k] | z[16*Q1] | dy2[32*Q2] | dzp[16*Q1] | dy1[16*k] | dz[128] | xs[k*98]
+__global__ __launch_bounds__(SP_WG) void k_sp_bwd(BatchDev b, ModelDev m, SpDev sp, const float* __restrict__ Pd,
                                                         float grad_scale) {
   IGMC_DYN_SMEM(smem);
   const int g = blockIdx.x, tid = threadIdx.x;
@@ -216,51 +326,36 @@ __global__ __launch_bounds__(SP_THREADS) void k_sp_bwd(BatchDev b, ModelDev m, S
   float* dzp = dy2 + SP_C2 * Q2;
   float* dy1 = dzp + SP_C1 * Q1;
   float* dzs = dy1 + SP_C1 * k;
-  for (int i = tid; i < SP_C1 * SP_C; i += SP_THREADS) w1[i] = Pd[sp.t_c1w + i];
-  for (int i = tid; i < SP_C2 * SP_C1 * SP_KW; i += SP_THREADS) w2[i] = Pd[sp.t_c2w + i];
-  for (int i = tid; i < n; i += SP_THREADS) rank[i] = -1;
-  for (int p = tid; p < k; p += SP_THREADS) sel[p] = sp.sel[(size_t)g * k + p];
-  for (int i = tid; i < SP_C1 * k; i += SP_THREADS) y1[i] = sp.y1[(size_t)g * SP_C1 * k + i];
-  const float dout = 2.f * m.err[g] * grad_scale;                  // d (mean squared error) / d out
-  if (tid == 0) sp.dout[g] = dout;
-  if (tid < 128) {
-    const float av = sp.a1[g * 128 + tid];
-    const float dzv = (av > 0.f && sp.lmask[g * 128 + tid]) ? dout * Pd[sp.t_l2w + tid] * 2.f : 0.f;
-    dzs[tid] = dzv;
-    sp.dz[g * 128 + tid] = dzv;
-  }
+  for (int i = tid; i < SP_C1 * SP_C; i += SP_WG) w1[i] = Pd[sp.t_c1w + i];
+  for (int i = tid; i < SP_C2 * SP_C1 * SP_KW; i += SP_WG) w2[i] = Pd[sp.t_c2w + i];
+  for (int i = tid; i < n; i += SP_WG) rank[i] = -1;
+  for (int p = tid; p < k; p += SP_WG) sel[p] = sp.sel[(size_t)g * k + p];
+  for (int i = tid; i < SP_C1 * k; i += SP_WG) y1[i] = sp.y1[(size_t)g * SP_C1 * k + i];
+  // (dz, d out and d flat: k_sp_dflat, batched over the subgraphs)
+  for (int i = tid; i < dense; i += SP_WG) dy2[i] = sp.dflat[(size_t)g * dense + i];
   __syncthreads();
-  for (int p = tid; p < k; p += SP_THREADS)
+  for (int p = tid; p < k; p += SP_WG)
     if (sel[p] >= 0) rank[sel[p] - n0] = p;
-  for (int i = tid; i < SP_C1 * Q1; i += SP_THREADS) {
+  for (int i = tid; i < SP_C1 * Q1; i += SP_WG) {
     const int ic = i / Q1, q = i - ic * Q1;
     const float a = y1[ic * k + 2 * q], c = y1[ic * k + 2 * q + 1];
     z[i] = a >= c ? a : c;
   }
-  // d flat = dz @ lin1.weight, through conv2's ReLU
-  for (int i = tid; i < dense; i += SP_THREADS) {
-    float s = 0.f;
-    for (int j = 0; j < 128; ++j) {
-      const float dzv = dzs[j];
-      if (dzv != 0.f) s += dzv * Pd[sp.t_l1w + (size_t)j * dense + i];
-    }
-    dy2[i] = (sp.flat[(size_t)g * dense + i] > 0.f) ? s : 0.f;
-  }
   __syncthreads();
   // conv2: weight / bias gradient of this graph, gradient w.r.t. the pooled sequence
   float* pc2 = sp.part_c2 + (size_t)g * (SP_C2 * SP_C1 * SP_KW + SP_C2);
-  for (int i = tid; i < SP_C2 * SP_C1 * SP_KW; i += SP_THREADS) {
+  for (int i = tid; i < SP_C2 * SP_C1 * SP_KW; i += SP_WG) {
     const int oc = i / (SP_C1 * SP_KW), rem = i - oc * (SP_C1 * SP_KW), ic = rem / SP_KW, t = rem - ic * SP_KW;
     float s = 0.f;
     for (int q = 0; q < Q2; ++q) s += dy2[oc * Q2 + q] * z[ic * Q1 + q + t];
     pc2[i] = s;
   }
-  for (int oc = tid; oc < SP_C2; oc += SP_THREADS) {
+  for (int oc = tid; oc < SP_C2; oc += SP_WG) {
     float s = 0.f;
     for (int q = 0; q < Q2; ++q) s += dy2[oc * Q2 + q];
     pc2[SP_C2 * SP_C1 * SP_KW + oc] = s;
   }
-  for (int i = tid; i < SP_C1 * Q1; i += SP_THREADS) {
+  for (int i = tid; i < SP_C1 * Q1; i += SP_WG) {
     const int ic = i / Q1, qp = i - ic * Q1;
     float s = 0.f;
     for (int oc = 0; oc < SP_C2; ++oc)
@@ -273,7 +368,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sp_bwd(BatchDev b, ModelDev m, S
   }
   __syncthreads();
   // max-pool (the first maximum takes the gradient, like torch) and conv1's ReLU
-  for (int i = tid; i < SP_C1 * k; i += SP_THREADS) {
+  for (int i = tid; i < SP_C1 * k; i += SP_WG) {
     const int oc = i / k, p = i - oc * k, q = p >> 1;
     float d = 0.f;
     if (q < Q1) {
@@ -284,24 +379,30 @@ __global__ __launch_bounds__(SP_THREADS) void k_sp_bwd(BatchDev b, ModelDev m, S
     dy1[i] = d;
   }
   __syncthreads();
-  // conv1: weight / bias gradient of this graph
+  // conv1: weight / bias gradient of this graph.  The pooled rows come from LDS (staged once, coalesced): read from global memory inside the p loop they were 360 serial round trips per thread, 100 us of this kernel.
+  float* xs = dzs + 128;                             // [k][SP_C + 1]
+  for (int i = tid; i < k * 128; i += SP_WG) {
+    const int p = i >> 7, c = i & 127;
+    if (c < SP_C) xs[p * (SP_C + 1) + c] = (sel[p] >= 0) ? sp_cat(m, sel[p], c) : 0.f;
+  }
+  __syncthreads();
   float* pc1 = sp.part_c1 + (size_t)g * (SP_C1 * SP_C + SP_C1);
-  for (int i = tid; i < SP_C1 * SP_C; i += SP_THREADS) {
+  for (int i = tid; i < SP_C1 * SP_C; i += SP_WG) {
     const int oc = i / SP_C, j = i - oc * SP_C;
     float s = 0.f;
     for (int p = 0; p < k; ++p) {
       const float d = dy1[oc * k + p];
-      if (d != 0.f && sel[p] >= 0) s += d * sp_cat(m, sel[p], j);
+      if (d != 0.f && sel[p] >= 0) s += d * xs[p * (SP_C + 1) + j];
     }
     pc1[i] = s;
   }
-  for (int oc = tid; oc < SP_C1; oc += SP_THREADS) {
+  for (int oc = tid; oc < SP_C1; oc += SP_WG) {
     float s = 0.f;
     for (int p = 0; p < k; ++p) s += dy1[oc * k + p];
     pc1[SP_C1 * SP_C + oc] = s;
   }
   // gradient w.r.t. the node states: every node of the graph is written exactly once (zeros when it was not pooled)
-  for (int i = tid; i < n * 128; i += SP_THREADS) {
+  for (int i = tid; i < n * 128; i += SP_WG) {
     const int node = i >> 7, c = i & 127;             // c < 96: channel of h_0..h_2; c >= 96: column c - 96 of dPre_3
     const int p = rank[node];
     const size_t row = (size_t)(n0 + node) * 32;
@@ -319,42 +420,62 @@ __global__ __launch_bounds__(SP_THREADS) void k_sp_bwd(BatchDev b, ModelDev m, S
       m.dpre[3][row + (c - 96)] = v;
     }
   }
+  (void)dzs; (void)grad_scale;
 }
 
 // ---------------------------------------------------------------------------------------------- weight gradients over the batch
 // blocks [0, nb1): lin1.weight tiles (one element per thread: sum over the graphs of dz[g][j] * flat[g][i]);
-// then one block each for: conv1 partial sums, conv2 partial sums, lin1.bias + lin2
+// then the conv1 / conv2 partial sums (one output per thread) and one block for lin1.bias + lin2
 __global__ __launch_bounds__(SP_THREADS) void k_sp_wgrad(BatchDev b, SpDev sp, int B, int nb1, float* __restrict__ Gd) {
   const int tid = threadIdx.x;
   const int dense = sp.dense;
   if ((int)blockIdx.x < nb1) {
-    const int64_t e = (int64_t)blockIdx.x * SP_THREADS + tid;
-    if (e < (int64_t)128 * dense) {
-      const int j = (int)(e / dense), i = (int)(e - (int64_t)j * dense);
-      float s = 0.f;
-      for (int g = 0; g < B; ++g) {
-        const float dzv = sp.dz[g * 128 + j];
-        if (dzv != 0.f) s += dzv * sp.flat[(size_t)g * dense + i];
+    // d lin1.weight[j][i] = sum_g dz[g][j] flat[g][i]: 8 x (dense / 16) output tiles, one per wave, K = the subgraphs
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    const int tile = blockIdx.x * 4 + wave, ntn = dense / 16;
+    if (tile >= 8 * ntn) return;
+    const int j0 = (tile / ntn) * 16, i0 = (tile % ntn) * 16;
+    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    for (int g0 = 0; g0 < B; g0 += 32) {              // 8 MFMA steps (32 subgraphs) of loads in flight
+      float av[8], bv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int g = g0 + 4 * u + kq, gc = g < B ? g : B - 1;
+        av[u] = sp.dz[(size_t)gc * 128 + j0 + li];
+        bv[u] = sp.flat[(size_t)gc * dense + i0 + li];
+        if (g >= B) av[u] = 0.f;
       }
-      Gd[sp.t_l1w + e] = s;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        f32x4& acc = (u & 1) ? acc1 : acc0;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+      }
     }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+      Gd[sp.t_l1w + (size_t)(j0 + 4 * kq + rr) * dense + i0 + li] = acc0[rr] + acc1[rr];
     return;
   }
   const int role = blockIdx.x - nb1;
-  if (role == 0) {
-    const int n1 = SP_C1 * SP_C + SP_C1;
-    for (int i = tid; i < n1; i += SP_THREADS) {
-      float s = 0.f;
-      for (int g = 0; g < B; ++g) s += sp.part_c1[(size_t)g * n1 + i];
-      Gd[sp.t_c1w + i] = s;
+  const int n1 = SP_C1 * SP_C + SP_C1, n2 = SP_C2 * SP_C1 * SP_KW + SP_C2;
+  const int nbc1 = (n1 + SP_THREADS - 1) / SP_THREADS, nbc2 = (n2 + SP_THREADS - 1) / SP_THREADS;
+  if (role < nbc1 + nbc2) {
+    // conv1 / conv2: one output per thread, the subgraphs' partials summed in index order (16 loads in flight per round;
+    // ONE workgroup looping over all outputs and subgraphs was 550 serial loads per thread, 120 us)
+    const bool c1 = role < nbc1;
+    const int i = (c1 ? role : role - nbc1) * SP_THREADS + tid, nn = c1 ? n1 : n2;
+    if (i >= nn) return;
+    const float* part = (c1 ? sp.part_c1 : sp.part_c2) + i;
+    float s = 0.f;
+    for (int g0 = 0; g0 < B; g0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = part[(size_t)(g0 + u < B ? g0 + u : B - 1) * nn];
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (g0 + u < B) s += v[u];
     }
-  } else if (role == 1) {
-    const int n2 = SP_C2 * SP_C1 * SP_KW + SP_C2;
-    for (int i = tid; i < n2; i += SP_THREADS) {
-      float s = 0.f;
-      for (int g = 0; g < B; ++g) s += sp.part_c2[(size_t)g * n2 + i];
-      Gd[sp.t_c2w + i] = s;
-    }
+    Gd[(c1 ? sp.t_c1w : sp.t_c2w) + i] = s;
   } else {
     if (tid < 128) {
       float sb = 0.f, sw = 0.f;
@@ -382,7 +503,7 @@ static size_t sp_fwd_lds(const SpDev& sp) {
 }
 static size_t sp_bwd_lds(const SpDev& sp) {
   return (size_t)(sp.k + sp.nmax + SP_C1 * SP_C + SP_C2 * SP_C1 * SP_KW + SP_C1 * sp.k + SP_C1 * sp.Q1 + SP_C2 * sp.Q2 +
-                  SP_C1 * sp.Q1 + SP_C1 * sp.k + 128) * 4;
+                  SP_C1 * sp.Q1 + SP_C1 * sp.k + 128 + sp.k * (SP_C + 1)) * 4;
 }
 
 int igmc_sp_lds_ok(const SpDev& sp) { return sp_fwd_lds(sp) <= 160 * 1024 && sp_bwd_lds(sp) <= 160 * 1024; }
@@ -406,18 +527,26 @@ void igmc_launch_sp_pack(const ModelDev& m, const SpDev& sp, const float* Pd, fl
 void igmc_launch_sp_forward(const ModelDev& m, const SpDev& sp, const BatchDev& b, const float* Pd, int B, int training,
                             const uint8_t* inj_mask, uint64_t seed, uint64_t step, float* out, void* stream) {
   const size_t sm = sp_fwd_lds(sp);
-  if (training) IGMC_PLAUNCH("k_sp_fwd", (k_sp_fwd<true>), B, SP_THREADS, sm, stream, b, m, sp, Pd, inj_mask, seed, step, out);
-  else IGMC_PLAUNCH("k_sp_fwd", (k_sp_fwd<false>), B, SP_THREADS, sm, stream, b, m, sp, Pd, inj_mask, seed, step, out);
+  if (training) {
+    IGMC_PLAUNCH("k_sp_fwd", (k_sp_fwd<true>), B, SP_WG, sm, stream, b, m, sp, Pd, inj_mask, seed, step, out);
+    IGMC_PLAUNCH("k_sp_lin_fwd", (k_sp_lin_fwd<true>), dim3((B + 15) / 16, 8), SP_THREADS, 0, stream, b, m, sp, Pd, inj_mask, seed, step, out);
+  } else {
+    IGMC_PLAUNCH("k_sp_fwd", (k_sp_fwd<false>), B, SP_WG, sm, stream, b, m, sp, Pd, inj_mask, seed, step, out);
+    IGMC_PLAUNCH("k_sp_lin_fwd", (k_sp_lin_fwd<false>), dim3((B + 15) / 16, 8), SP_THREADS, 0, stream, b, m, sp, Pd, inj_mask, seed, step, out);
+  }
 }
 
 void igmc_launch_sp_backward(const ModelDev& m, const SpDev& sp, const BatchDev& b, const float* Pd, int B, float grad_scale,
                              void* stream) {
-  IGMC_PLAUNCH("k_sp_bwd", k_sp_bwd, B, SP_THREADS, sp_bwd_lds(sp), stream, b, m, sp, Pd, grad_scale);
+  IGMC_PLAUNCH("k_sp_dflat", k_sp_dflat, dim3((B + 15) / 16, (sp.dense / 16 + 3) / 4), SP_THREADS, 0, stream, b, m, sp, Pd,
+               grad_scale);
+  IGMC_PLAUNCH("k_sp_bwd", k_sp_bwd, B, SP_WG, sp_bwd_lds(sp), stream, b, m, sp, Pd, grad_scale);
 }
 
 void igmc_launch_sp_wgrad(const ModelDev& m, const SpDev& sp, const BatchDev& b, int B, const float* ge, float* Gd,
                           void* stream) {
-  const int nb1 = (int)(((int64_t)128 * sp.dense + SP_THREADS - 1) / SP_THREADS);
-  IGMC_PLAUNCH("k_sp_wgrad", k_sp_wgrad, nb1 + 3, SP_THREADS, 0, stream, b, sp, B, nb1, Gd);
+  const int nb1 = (8 * (sp.dense / 16) + 3) / 4;        // d lin1.weight: one 16 x 16 output tile per wave
+  const int nbc = (SP_C1 * SP_C + SP_C1 + SP_THREADS - 1) / SP_THREADS + (SP_C2 * SP_C1 * SP_KW + SP_C2 + SP_THREADS - 1) / SP_THREADS;
+  IGMC_PLAUNCH("k_sp_wgrad", k_sp_wgrad, nb1 + nbc + 1, SP_THREADS, 0, stream, b, sp, B, nb1, Gd);
   IGMC_PLAUNCH("k_sp_unpack", k_sp_unpack, 64, SP_THREADS, 0, stream, m, sp, ge, Gd);
 }
