@@ -232,7 +232,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sp_lin_fwd(BatchDev b, ModelDev 
         sp.lmask[g * 128 + n] = (uint8_t)keep;
       }
       const float p = igmc_group16_sum_f((TRAIN ? (keep ? a * 2.f : 0.f) : a) * w2);      // F.dropout(p = 0.5): kept * 2
-      if (li == 0 && g < B) sp.lin_part[(size_t)nt * b.graph_cap + g] = p;
+      if (li == 0 && g < B) sp.lin_part[(size_t)nt * m.graph_cap + g] = p;
     }
   }
   // the last workgroup of the row tile to get here has every partial in sight
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sp_lin_fwd(BatchDev b, ModelDev 
     if (tid < 16 && row0 + tid < B) {
       const int g = row0 + tid;
       float s2 = 0.f;
-      for (int t = 0; t < (int)gridDim.y; ++t) s2 += sp.lin_part[(size_t)t * b.graph_cap + g];
+      for (int t = 0; t < (int)gridDim.y; ++t) s2 += sp.lin_part[(size_t)t * m.graph_cap + g];
       const float o = s2 + l2b;
       out[g] = o;
       m.err[g] = o - b.y[g];
