@@ -145,14 +145,47 @@ class HostComm(object):
 _grad_comms = {}
 
 
+class _DevSpan(object):
+    """``n`` float32 values at a device address, for ``torch.as_tensor`` (no copy)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = dict(shape=(int(n),), typestr='<f4', data=(int(ptr), False), version=2)
+
+
+def process_group_comm(lib, device):
+    """A communicator whose sum is the process group's ``torch.distributed`` already has (``igmc_comm_create_host``):
+    ``IGMC_DP_HOST_COMM=1``.  With the ``nccl`` backend the all-reduce is enqueued by torch on the current stream; with
+    ``gloo`` the span is staged through the host (the stream is synchronised: not capturable -- the caller launches its
+    steps eagerly).  For hosts without RCCL, and for running the data-parallel step with several ranks on ONE GPU (RCCL
+    refuses two ranks on a device), which is how the two-rank GPU test runs."""
+    dev = torch.device('cuda', int(device))
+    backend = dist.get_backend()
+
+    def host_sum(ptr, n, stream):
+        t = torch.as_tensor(_DevSpan(ptr, n), device=dev)
+        if backend == 'gloo':
+            torch.cuda.current_stream(dev).synchronize()
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return HostComm(lib, host_sum, rank(), world_size())
+
+
 def grad_comm(lib, device):
     """One communicator per (process, device); needed when there is more than one rank, or with
-    ``IGMC_DP_ALLREDUCE_ALWAYS=1`` (a one-rank communicator: lets one GPU exercise the collective's enqueue / capture)."""
+    ``IGMC_DP_ALLREDUCE_ALWAYS=1`` (a one-rank communicator: lets one GPU exercise the collective's enqueue / capture).
+    ``IGMC_DP_HOST_COMM=1``: the exchange goes through ``torch.distributed``'s process group instead of the library's own
+    RCCL communicator (:func:`process_group_comm`)."""
     if world_size() <= 1 and os.environ.get('IGMC_DP_ALLREDUCE_ALWAYS', '0') != '1':
         return None
     key = int(device)
     if key not in _grad_comms:
-        _grad_comms[key] = GradComm(lib, device)
+        if os.environ.get('IGMC_DP_HOST_COMM', '0') == '1' and is_dist():
+            _grad_comms[key] = process_group_comm(lib, device)
+        else:
+            _grad_comms[key] = GradComm(lib, device)
     return _grad_comms[key]
 
 

@@ -541,6 +541,87 @@ def test_static_dataset_cache(flix, tmp_path):
     assert torch.equal(finals[0][0], finals[1][0]) and finals[0][1] == finals[1][1]
 
 
+def test_two_ranks_on_one_gpu(tmp_path):
+    """The data-parallel step (igmc_train_step_dp: the subgraph kernel's tables + lin gradients summed over the ranks between
+    k_tail_ts and k_finalize_ts) with TWO ranks on real kernels.  RCCL refuses two ranks on one device, so the exchange
+    goes through torch.distributed's gloo group (IGMC_DP_HOST_COMM=1: a host-callback communicator staged through the
+    host, steps launched eagerly) -- everything else is the product path (StepGraph's group pipeline, the ragged last
+    batch).
+    (a) Both ranks walk the SAME links: the mean over two identical half-batches is the single-GPU gradient, and because
+        1 / (2 B) is exactly half of 1 / B every intermediate is an exact half -- the trajectory must equal the single-GPU
+        step's bit for bit.
+    (b) Links sharded perm[k::2] (three full batches and a ragged one per rank): replicas bit-identical, losses finite,
+        two spans exchanged per step."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / 'dp2.py'
+    script.write_text(r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from igmc_amd import parallel, preprocessing
+from igmc_amd.models import IGMC
+from igmc_amd.stepgraph import StepGraph
+from igmc_amd.train_eval import FlatAdam
+from igmc_amd.util_functions import MyDynamicDataset
+rank, world = int(os.environ['RANK']), 2
+torch.cuda.set_device(0)
+dist.init_process_group(backend='gloo', init_method='tcp://127.0.0.1:29643', rank=rank, world_size=world)
+(_, _, adj, trl, tru, trv, _, _, _, _, _, _, cv) = preprocessing.load_data_monti('douban', testing=True)
+n = 2 * (50 * 3 + 7)
+tr = MyDynamicDataset('data/t/dp2_%%d' %% rank, adj, (tru[:n], trv[:n]), trl[:n], 1, 1.0, 10000, None, None, cv)
+def fresh():
+    torch.manual_seed(7)
+    model = IGMC(tr, latent_dim=[32, 32, 32, 32], num_relations=len(cv), num_bases=4, regression=True, adj_dropout=0.2,
+                 seed=3).to('cuda')
+    model.reset_parameters()
+    return model, FlatAdam(model, lr=1e-3)
+def state(model, opt):
+    torch.cuda.synchronize()
+    return [t.detach().cpu().clone() for t in (model.flat_parameters(), opt.exp_avg, opt.exp_avg_sq)]
+perm = torch.randperm(n, generator=torch.Generator().manual_seed(5))
+half = perm[:150]                    # three full batches (the ragged batch of a single-GPU epoch runs other kernels: _model / _finish)
+# ---- (a) the same links on both ranks == the single-GPU step
+model, opt = fresh()
+sg = StepGraph(model, opt, tr, 50, 0.001, use_graph=False, overlap=False, group=2)
+assert sg.dp_path and sg.world == 2 and sg.comm is not None and sg.comm.info() == (rank, 2)
+tot_dp, _ = sg.run_epoch(half, 1)
+dp = state(model, opt) + [float(tot_dp.item())]
+model1, opt1 = fresh()
+sg1 = StepGraph(model1, opt1, tr, 50, 0.001, use_graph=False, overlap=False, group=2)
+sg1.dp_path, sg1.comm, sg1.world = False, None, 1          # the single-GPU step in this very process
+tot_1, _ = sg1.run_epoch(half, 1)
+one = state(model1, opt1) + [float(tot_1.item())]
+for i, (x, y) in enumerate(zip(dp, one)):
+    same = torch.equal(x, y) if torch.is_tensor(x) else x == y
+    assert same, ('two identical half-batches vs the single-GPU step', i,
+                  float((x - y).abs().max()) if torch.is_tensor(x) else (x, y))
+# ---- (b) sharded links, ragged last batch
+model, opt = fresh()
+sg = StepGraph(model, opt, tr, 50, 0.001, use_graph=False, overlap=False, group=2)
+mine = parallel.shard_positions(perm, rank, world, pad=True)
+assert len(mine) == 157
+total, cnt = sg.run_epoch(mine, 1)
+P = state(model, opt)[0]
+both = [torch.zeros_like(P) for _ in range(world)]
+dist.all_gather(both, P)
+assert torch.equal(both[0], both[1]), 'replicas differ'
+assert np.isfinite(float(total.item())) and float(total.item()) > 0 and opt.t == 4
+assert not torch.equal(P, dp[0])
+print('rank', rank, 'dp2 ok')
+dist.destroy_process_group()
+''' % ROOT)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', IGMC_DP_HOST_COMM='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o[-3000:]
+        assert 'rank %d dp2 ok' % r in o
+
+
 def test_captured_all_reduce_next_to_a_torch_distributed_process_group(tmp_path):
     """The multi-GPU configuration of bench.py / Main.py on one GPU: a REAL torch.distributed 'nccl' (= RCCL) process
     group of one rank is up (its watchdog thread polls events while the step graph is captured: thread-local capture
