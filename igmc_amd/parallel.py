@@ -185,7 +185,28 @@ def grad_comm(lib, device):
         if os.environ.get('IGMC_DP_HOST_COMM', '0') == '1' and is_dist():
             _grad_comms[key] = process_group_comm(lib, device)
         else:
-            _grad_comms[key] = GradComm(lib, device)
+            comm, why = None, ''
+            try:
+                comm = GradComm(lib, device)
+            except RuntimeError as e:          # (RCCL missing, or it refuses this set of ranks)
+                why = str(e)
+            # every rank must end up on the same transport: agree on it over the process group that is already up
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32)
+            if is_dist() and world_size() > 1:
+                if dist.get_backend() == 'nccl':
+                    ok = ok.to(torch.device('cuda', key))
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                _grad_comms[key] = comm
+            elif is_dist():
+                if comm is not None:
+                    comm.close()
+                import sys
+                print('[igmc] the library\'s RCCL communicator could not be created on every rank (%s): the gradient exchange '
+                      'goes through torch.distributed\'s process group' % (why or 'another rank failed'), file=sys.stderr)
+                _grad_comms[key] = process_group_comm(lib, device)
+            else:
+                raise RuntimeError(why)
     return _grad_comms[key]
 
 

@@ -541,7 +541,8 @@ def test_static_dataset_cache(flix, tmp_path):
     assert torch.equal(finals[0][0], finals[1][0]) and finals[0][1] == finals[1][1]
 
 
-def test_two_ranks_on_one_gpu(tmp_path):
+@pytest.mark.parametrize('transport', ['host_comm', 'fallback'])
+def test_two_ranks_on_one_gpu(tmp_path, transport):
     """The data-parallel step (igmc_train_step_dp: the subgraph kernel's tables + lin gradients summed over the ranks between
     k_tail_ts and k_finalize_ts) with TWO ranks on real kernels.  RCCL refuses two ranks on one device, so the exchange
     goes through torch.distributed's gloo group (IGMC_DP_HOST_COMM=1: a host-callback communicator staged through the
@@ -551,7 +552,9 @@ def test_two_ranks_on_one_gpu(tmp_path):
         1 / (2 B) is exactly half of 1 / B every intermediate is an exact half -- the trajectory must equal the single-GPU
         step's bit for bit.
     (b) Links sharded perm[k::2] (three full batches and a ragged one per rank): replicas bit-identical, losses finite,
-        two spans exchanged per step."""
+        two spans exchanged per step.
+    `fallback`: without the switch the library tries its own RCCL communicator first, RCCL refuses ("Duplicate GPU"), the
+    ranks agree on that over the process group and all of them fall back to it (parallel.grad_comm)."""
     import os
     import subprocess
     import sys
@@ -567,7 +570,7 @@ from igmc_amd.train_eval import FlatAdam
 from igmc_amd.util_functions import MyDynamicDataset
 rank, world = int(os.environ['RANK']), 2
 torch.cuda.set_device(0)
-dist.init_process_group(backend='gloo', init_method='tcp://127.0.0.1:29643', rank=rank, world_size=world)
+dist.init_process_group(backend='gloo', init_method='tcp://127.0.0.1:%%s' %% os.environ.get('DP2_PORT', '29643'), rank=rank, world_size=world)
 (_, _, adj, trl, tru, trv, _, _, _, _, _, _, cv) = preprocessing.load_data_monti('douban', testing=True)
 n = 2 * (50 * 3 + 7)
 tr = MyDynamicDataset('data/t/dp2_%%d' %% rank, adj, (tru[:n], trv[:n]), trl[:n], 1, 1.0, 10000, None, None, cv)
@@ -614,12 +617,17 @@ dist.destroy_process_group()
 ''' % ROOT)
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', IGMC_DP_HOST_COMM='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', HSA_ENABLE_IPC_MODE_LEGACY='0', DP2_PORT='29643' if transport == 'host_comm' else '29644')
+        if transport == 'host_comm':
+            env['IGMC_DP_HOST_COMM'] = '1'
+        else:
+            env.pop('IGMC_DP_HOST_COMM', None)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o[-3000:]
         assert 'rank %d dp2 ok' % r in o
+        assert ('could not be created on every rank' in o) == (transport == 'fallback'), o[-2000:]
 
 
 def test_captured_all_reduce_next_to_a_torch_distributed_process_group(tmp_path):
