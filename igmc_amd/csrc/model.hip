@@ -2146,6 +2146,17 @@ static inline int igmc_xcd_grid(const ModelDev& m, int B, int rows_per_block, in
   return (int)(g < 8 ? 8 : g);
 }
 
+// grid of k_l0_fwd: every workgroup composes the layer-0 table W0[r * L + c] (R L x 32 values, 4 fmas + 5 loads each) before
+// it walks rows; with many relations (yahoo_music: 284 table rows) thousands of 4-row workgroups spend their time on that
+// -- there a workgroup takes 8 rows per table row of work it has to amortise (IGMC_L0_ROWS overrides)
+static inline int igmc_l0_grid(const ModelDev& m, int B) {
+  int rows = 4;
+  if (m.R * m.L > 32) rows = (m.R * m.L) / 8;
+  const char* e = getenv("IGMC_L0_ROWS");
+  if (e && atoi(e) >= 4) rows = atoi(e);
+  return igmc_xcd_grid(m, B, rows, IGMC_GATHER_BLOCKS);
+}
+
 void igmc_launch_forward(const ModelDev& m, const ModelAux& ax, const BatchDev& b, const float* P, int B, int training,
                          int use_flags, const uint8_t* inj_mask, uint64_t seed, uint64_t step, float mult,
                          float* out, void* stream) {
@@ -2190,11 +2201,11 @@ void igmc_launch_conv_forward(const ModelDev& m, const BatchDev& b, const float*
     igmc_launch_g2_compose(m, P, stream);                 // the step's weight images + layer-0 table
     igmc_launch_dl_layer0(m, b, B, training, use_flags, stream);
   } else if (training) {
-    if (use_flags) IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<true, true>), g16, IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
-    else IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<false, true>), g16, IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
+    if (use_flags) IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<true, true>), igmc_l0_grid(m, B), IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
+    else IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<false, true>), igmc_l0_grid(m, B), IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
   } else {
-    if (use_flags) IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<true, false>), g16, IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
-    else IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<false, false>), g16, IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
+    if (use_flags) IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<true, false>), igmc_l0_grid(m, B), IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
+    else IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<false, false>), igmc_l0_grid(m, B), IGMC_BLOCK, l0s, stream, b, m, P, m.h[0]);
   }
   const size_t ysz = (size_t)32 * (128 + 4) * sizeof(float);
   const int gt = igmc_xcd_grid(m, B, 16, 2048);                        // fused layer: 16 rows per workgroup
@@ -2382,8 +2393,8 @@ int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchD
   } else if (dl) {
     igmc_launch_g2_compose(m, (const float*)P, stream);
     igmc_launch_dl_layer0(m, b, B, 1, use_flags, stream);
-  } else if (use_flags) IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<true, true>), g16, IGMC_BLOCK, l0s, stream, b, m, (const float*)P, m.h[0]);
-  else IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<false, true>), g16, IGMC_BLOCK, l0s, stream, b, m, (const float*)P, m.h[0]);
+  } else if (use_flags) IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<true, true>), igmc_l0_grid(m, B), IGMC_BLOCK, l0s, stream, b, m, (const float*)P, m.h[0]);
+  else IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<false, true>), igmc_l0_grid(m, B), IGMC_BLOCK, l0s, stream, b, m, (const float*)P, m.h[0]);
   const size_t fsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4) * sizeof(float);
   const size_t bsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4 + 16 * m.R * 4) * sizeof(float);
   const int gl = (dl && !getenv("IGMC_DL_NOBWD")) ? igmc_dl_grid(b, B) : gt;      // grid of the layer kernels
