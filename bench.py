@@ -487,8 +487,13 @@ def main():
                     traffic = trec.get('traffic_bytes')
                     traffic_src = '%s @ %s' % (os.path.basename(PMC_TRAFFIC), trec.get('commit', '?'))
             symbol = SYMBOLS.get(dom, dom)
+            flags = 'true' if cfg['adj_dropout'] > 0 else 'false'
             if dom == 'k_graph_step':
-                symbol = 'k_graph_step2<%s, true>' % ('true' if cfg['adj_dropout'] > 0 else 'false')
+                symbol = 'k_graph_step2<%s, true>' % flags
+            elif dom == 'k_dl_bwd':
+                symbol = 'k_dl_bwd<%s>' % flags
+            elif dom == 'k_dl_fwd':
+                symbol = 'k_dl_fwd<%s, true>' % flags
             roofline = dict(bound='hbm', kernel=symbol, timer_label=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
                             frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src, avg_us=avg_us,
                             avg_us_source='device launch clock under hipGraph replay + overlapped extraction'
