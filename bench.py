@@ -70,7 +70,7 @@ CONFIGS = {
     'flixster': dict(dataset='flixster', mnph=10000, adj_dropout=0.2, cpu='dynamic'),
     'yahoo_music': dict(dataset='yahoo_music', mnph=10000, adj_dropout=0.2, cpu='dynamic'),
 }
-PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
+PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')      # (ml_1m; other configs: r03_pmc_traffic_<config>.json)
 # timer label of the HIP-event profile -> kernel symbol in the code object (what rocprofv3 lists)
 SYMBOLS = {'k_dl_layer_fwd': 'k_dl_layer<FLAGS, false, false>', 'k_rgcn_layer_fwd': 'k_rgcn_layer4<FLAGS, false>',
            'k_dl_bwd': 'k_dl_bwd<FLAGS>', 'k_dl_fwd': 'k_dl_fwd<FLAGS, true>'}
@@ -480,12 +480,13 @@ def main():
             # from the committed rocprofv3 --pmc passes of this command (tools/profile_round.sh -> pmc_traffic.py) and
             # only count while the kernel sources are the profiled ones
             traffic, traffic_src = None, None
-            if os.path.exists(PMC_TRAFFIC):
-                trec = json.load(open(PMC_TRAFFIC))
+            pmc_path = PMC_TRAFFIC if args.config == 'ml_1m' else PMC_TRAFFIC.replace('.json', '_%s.json' % args.config)
+            if os.path.exists(pmc_path):
+                trec = json.load(open(pmc_path))
                 if trec.get('kernel') in (dom, SYMBOLS.get(dom)) and trec.get('config') == args.config and \
                         trec.get('src_sha') == kernel_source_sha():
                     traffic = trec.get('traffic_bytes')
-                    traffic_src = '%s @ %s' % (os.path.basename(PMC_TRAFFIC), trec.get('commit', '?'))
+                    traffic_src = '%s @ %s' % (os.path.basename(pmc_path), trec.get('commit', '?'))
             symbol = SYMBOLS.get(dom, dom)
             flags = 'true' if cfg['adj_dropout'] > 0 else 'false'
             if dom == 'k_graph_step':
