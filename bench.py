@@ -302,8 +302,8 @@ def main():
     # graph is captured (group size M with 2 M dividing K: a graph launch is a pair of groups = 2 M steps) and the other
     # W - 1 steps replay it where they fill a launch, else they are launched eagerly.  The first launch of an instantiated
     # hipGraph costs ~140 us more than the following ones (hipGraphUpload or not: profiles/r02_callB_graph_first_replay.txt),
-    # a one-time cost like a kernel's code-object load: StepGraph.prepare() pays it before t0 by launching the fresh graph
-    # once and UNDOING it (parameters, Adam moments, control block restored; the group's batches extracted again), so the
+    # a one-time cost like a kernel's code-object load (the second launch still ~30 us): StepGraph.prepare() pays it before t0
+    # by launching the fresh graph three times and UNDOING it (parameters, Adam moments, control block restored; the group's batches extracted again), so the
     # training state at t0 is exactly the state after the W warm-up steps.
     captured = False
     if sg.use_graph and args.warmup >= 1:
