@@ -242,11 +242,13 @@ def main():
                                                             verbose=int(os.environ.get('RANK', '0')) == 0)
             source = 'real' if preprocessing._find_raw(cfg['dataset'], 'ratings.dat' if cfg['dataset'] != 'ml_100k' else 'u.data') else 'synthetic'
     (_, _, A, tr_l, tr_u, tr_v, _, _, _, te_l, te_u, te_v, class_values) = split
-    rank, world = parallel.init_from_env('nccl')
+    # (IGMC_DIST_BACKEND=gloo + IGMC_LOCAL_DEVICE=0 + IGMC_DP_HOST_COMM=1: a dry run of the multi-rank path with every rank
+    #  on ONE GPU -- RCCL refuses that -- to exercise this file's N > 1 logic; its throughput means nothing)
+    rank, world = parallel.init_from_env(os.environ.get('IGMC_DIST_BACKEND', 'nccl'))
     if world != args.gpus:
         if rank == 0:
             sys.stderr.write('warning: --gpus %d but WORLD_SIZE %d (using WORLD_SIZE)\n' % (args.gpus, world))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    local = int(os.environ.get('IGMC_LOCAL_DEVICE', os.environ.get('LOCAL_RANK', '0')))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if os.environ.get('IGMC_LIB_PATH'):                # debug hook: time an experimental build of the library

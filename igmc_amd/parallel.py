@@ -170,7 +170,9 @@ def process_group_comm(lib, device):
             t.copy_(h)
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return HostComm(lib, host_sum, rank(), world_size())
+    c = HostComm(lib, host_sum, rank(), world_size())
+    c.capturable = backend != 'gloo'          # (the gloo route synchronises the stream: its steps cannot be captured)
+    return c
 
 
 def grad_comm(lib, device):

@@ -259,6 +259,8 @@ class StepGraph(GroupPipeline):
         self.side = torch.cuda.Stream(device=self.dev) if overlap else None
         # gradient exchange: the library's own RCCL communicator (igmc_allreduce_grads), enqueued on the step's stream
         self.comm = parallel.grad_comm(self.lib, self.dev.index if self.dev.index is not None else 0) if self.dp_path else None
+        if self.comm is not None and not getattr(self.comm, 'capturable', True):
+            self.use_graph = False             # (an exchange that synchronises the stream: eager launches)
 
     # ------------------------------------------------------------------ arenas
     def _arena(self, q, i):
