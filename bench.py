@@ -363,7 +363,12 @@ def main():
             sg.comm.all_reduce_(scratch, st)
         e1.record()
         torch.cuda.synchronize()
-        dp_check = dict(rccl_rank=rk, rccl_world=ws_, launcher_rank=rank, launcher_world=world,
+        # (rccl_* only when RCCL IS the transport: a host-callback communicator over gloo reports under comm_*)
+        is_rccl = isinstance(sg.comm, parallel.GradComm)
+        transport = 'rccl' if is_rccl else getattr(sg.comm, 'transport', 'host-callback:' + str(torch.distributed.get_backend()
+                                                                                                   if world > 1 else 'none'))
+        dp_check = dict(transport=transport, rccl_rank=rk if is_rccl else None, rccl_world=ws_ if is_rccl else None,
+                        comm_rank=rk, comm_world=ws_, launcher_rank=rank, launcher_world=world,
                         ranks_agree=bool(rk == rank and ws_ == world),
                         replicas_identical=bool(torch.equal(lo, hi)), param_checksum=float(chk[0].item()),
                         allreduce_us=e0.elapsed_time(e1) / 50 * 1e3, allreduce_floats=int(scratch.numel()),

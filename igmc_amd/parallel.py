@@ -77,9 +77,18 @@ class GradComm(object):
         self.lib, self.C = lib, C
         r, w = rank(), world_size()
         buf = (C.c_uint8 * 128)()
+        # Rank 0's id request is the fallible step (RCCL missing): EVERY rank takes part in the one broadcast of
+        # (status, id) whatever happened there, so a failure on rank 0 cannot leave the others waiting for an id while
+        # rank 0 has moved on to the next collective.
+        status = 'ok'
         if r == 0:
-            lib.call('igmc_comm_unique_id', C.cast(buf, C.c_void_p))
-        ident = broadcast_object(bytes(buf), 0)
+            try:
+                lib.call('igmc_comm_unique_id', C.cast(buf, C.c_void_p))
+            except RuntimeError as e:
+                status = str(e) or 'igmc_comm_unique_id failed'
+        status, ident = broadcast_object((status, bytes(buf)), 0)
+        if status != 'ok':
+            raise RuntimeError('rank 0 could not create the RCCL id: ' + status)
         buf = (C.c_uint8 * 128).from_buffer_copy(ident)
         h = C.c_void_p()
         lib.call('igmc_comm_create', C.cast(buf, C.c_void_p), r, w, int(device), C.byref(h))
@@ -162,14 +171,19 @@ def process_group_comm(lib, device):
     backend = dist.get_backend()
 
     def host_sum(ptr, n, stream):
+        # the contract of igmc_allreduce_fn: the sum is ordered on ``stream`` (the step's stream), which need not be
+        # torch's current one -- work is enqueued on / synchronised against THAT stream
         t = torch.as_tensor(_DevSpan(ptr, n), device=dev)
-        if backend == 'gloo':
-            torch.cuda.current_stream(dev).synchronize()
-            h = t.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.SUM)
-            t.copy_(h)
-        else:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        s = torch.cuda.ExternalStream(int(stream), device=dev) if stream else torch.cuda.current_stream(dev)
+        with torch.cuda.stream(s):
+            if backend == 'gloo':
+                s.synchronize()
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                t.copy_(h)
+                s.synchronize()
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
     c = HostComm(lib, host_sum, rank(), world_size())
     c.capturable = backend != 'gloo'          # (the gloo route synchronises the stream: its steps cannot be captured)
     return c

@@ -591,7 +591,11 @@ class StepGraph(GroupPipeline):
         m = self.model
         keep = [t.clone() for t in (m.flat_parameters(), self.opt.exp_avg, self.opt.exp_avg_sq, self.ctrl, self.total, self.loss)]
         # (three launches: the first costs ~140 us more than a steady-state launch, the second still ~30 us)
-        for _ in range(max(1, int(os.environ.get('IGMC_PRIME_LAUNCHES', '3')))):
+        # Every launch moves the device cursors on by 2 M batches and prefetches one group further: launch L reads link
+        # positions below (k + (2 L + 1) M) B, which must stay inside the padded permutation buffer.
+        room = (self.n_links // self.B - self.k + self.pad // self.B) // self.M
+        launches = min(max(1, int(os.environ.get('IGMC_PRIME_LAUNCHES', '3'))), (room - 1) // 2)
+        for _ in range(launches):
             self.graph.replay()
             torch.cuda.synchronize()
         for t, k in zip((m.flat_parameters(), self.opt.exp_avg, self.opt.exp_avg_sq, self.ctrl, self.total, self.loss), keep):

@@ -378,35 +378,44 @@ class MyDataset(_EngineDataset):
         # everybody loads it after the barrier
         builder = parallel.rank() == 0
         z = load() if builder else None
+        failure = None
         if z is None and builder:
-            n = len(self)
-            uoff, voff = np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64)
-            un, vn, ud, vd = [], [], [], []
-            for first in range(0, n, chunk):
-                B = min(chunk, n - first)
-                arena = self.arena(chunk, slot='process')
-                st = torch.cuda.current_stream().cuda_stream
-                arena.extract(self.link_u.data_ptr(), self.link_v.data_ptr(), self.link_y.data_ptr(), None, first, B,
-                              self.sample_ratio, self.seed, 0, st)
-                d = arena.download(st)
-                for g in range(B):
-                    lo, hi, nu = int(d['node_off'][g]), int(d['node_off'][g + 1]), int(d['n_users'][g])
-                    un.append(d['node_gid'][lo:lo + nu])
-                    vn.append(d['node_gid'][lo + nu:hi])
-                    ud.append(d['node_label'][lo:lo + nu] // 2)
-                    vd.append(d['node_label'][lo + nu:hi] // 2)
-                    uoff[first + g + 1] = uoff[first + g] + nu
-                    voff[first + g + 1] = voff[first + g] + (hi - lo - nu)
-            self._arenas.pop((chunk, 'process'), None)
-            cat = lambda xs, dt: np.ascontiguousarray(np.concatenate(xs).astype(dt)) if xs else np.zeros(0, dt)
-            z = dict(uoff=uoff, voff=voff, unodes=cat(un, np.int32), vnodes=cat(vn, np.int32), udist=cat(ud, np.uint8),
-                     vdist=cat(vd, np.uint8), fingerprint=np.array(fp))
-            os.makedirs(os.path.dirname(path), exist_ok=True)
-            tmp = '%s.%d.tmp.npz' % (path, os.getpid())
-            np.savez(tmp, **z)
-            os.replace(tmp, path)
+            try:            # (a failure here must reach the ranks waiting below, not leave them at a barrier: ADVICE r3)
+                n = len(self)
+                uoff, voff = np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64)
+                un, vn, ud, vd = [], [], [], []
+                for first in range(0, n, chunk):
+                    B = min(chunk, n - first)
+                    arena = self.arena(chunk, slot='process')
+                    st = torch.cuda.current_stream().cuda_stream
+                    arena.extract(self.link_u.data_ptr(), self.link_v.data_ptr(), self.link_y.data_ptr(), None, first, B,
+                                  self.sample_ratio, self.seed, 0, st)
+                    d = arena.download(st)
+                    for g in range(B):
+                        lo, hi, nu = int(d['node_off'][g]), int(d['node_off'][g + 1]), int(d['n_users'][g])
+                        un.append(d['node_gid'][lo:lo + nu])
+                        vn.append(d['node_gid'][lo + nu:hi])
+                        ud.append(d['node_label'][lo:lo + nu] // 2)
+                        vd.append(d['node_label'][lo + nu:hi] // 2)
+                        uoff[first + g + 1] = uoff[first + g] + nu
+                        voff[first + g + 1] = voff[first + g] + (hi - lo - nu)
+                self._arenas.pop((chunk, 'process'), None)
+                cat = lambda xs, dt: np.ascontiguousarray(np.concatenate(xs).astype(dt)) if xs else np.zeros(0, dt)
+                z = dict(uoff=uoff, voff=voff, unodes=cat(un, np.int32), vnodes=cat(vn, np.int32), udist=cat(ud, np.uint8),
+                         vdist=cat(vd, np.uint8), fingerprint=np.array(fp))
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                tmp = '%s.%d.tmp.npz' % (path, os.getpid())
+                np.savez(tmp, **z)
+                os.replace(tmp, path)
+            except Exception as e:
+                if parallel.world_size() <= 1:
+                    raise
+                failure = '%s: %s' % (type(e).__name__, e)
         if parallel.world_size() > 1:
-            parallel.barrier()
+            # rank 0's verdict doubles as the barrier: every rank raises when the build failed
+            failure = parallel.broadcast_object(failure, 0)
+            if failure is not None:
+                raise RuntimeError('rank 0 could not build the static-dataset cache %s (%s)' % (path, failure))
             if not builder:
                 z = load()
                 if z is None:

@@ -598,3 +598,238 @@ def run_dgcnn_parity(be, case, R, k=12, use_dropout=True, ARR=0.001, seed=3, rto
 def F_mse(a, b):
     import torch
     return torch.nn.functional.mse_loss(a, b.view(-1).to(a.dtype))
+
+
+# ====================================================================== fixtures of the reference's own models.py / train_eval.py
+def fixture_case(mg):
+    """Extraction case (graph, links, recorded node lists) of a ``tests/golden/model_golden.npz`` entry.  The graph is
+    rebuilt here -- synthetic graphs are deterministic, flixster is bundled -- and its fingerprint compared."""
+    import hashlib
+    import scipy.sparse as ssp
+    from igmc_amd import preprocessing
+    name = mg.case
+    if name.startswith('headline'):
+        A = preprocessing.create_trainvaltest_split('ml_1m', 1234, True, verbose=False)[2]
+        mnph = 100
+    elif name in ('igmc_r5', 'igmc_side'):
+        u, v, r = preprocessing.synth_ml(300, 200, 9000, preprocessing.ML_HIST['ml_100k'][3], seed=3)
+        A, mnph = ssp.csr_matrix((r.astype(np.float32), (u, v)), shape=(300, 200)), 15
+    else:
+        A, mnph = preprocessing.load_data_monti('flixster', testing=True)[2], 10000
+    S = ssp.csr_matrix(A)
+    S.sort_indices()
+    h = hashlib.sha256()
+    for a in (S.indptr.astype(np.int64), S.indices.astype(np.int64), S.data.astype(np.float32)):
+        h.update(np.ascontiguousarray(a).tobytes())
+    assert np.frombuffer(h.digest()[:8], np.uint64)[0] == mg['graph_fingerprint'], 'not the graph of the fixture'
+    uo, vo = mg['u_off'], mg['v_off']
+    recs = []
+    for g in range(len(uo) - 1):
+        un, vn = mg['u_nodes'][uo[g]:uo[g + 1]].astype(np.int64), mg['v_nodes'][vo[g]:vo[g + 1]].astype(np.int64)
+        labels = np.concatenate([np.where(np.arange(len(un)) == 0, 0, 2), np.where(np.arange(len(vn)) == 0, 1, 3)])
+        recs.append(dict(u_nodes=un, v_nodes=vn, labels=labels.astype(np.int64)))
+    return dict(A=A, links=mg['links'].astype(np.int64), link_labels=mg['link_labels'].astype(np.int64),
+                class_values=mg['class_values'], h=1, sample_ratio=1.0, mnph=mnph, recs=recs)
+
+
+def reference_edges(case, first, B):
+    """Directed edges of graphs ``first .. first+B`` in the REFERENCE's collated order (construct_pyg_graph:
+    ``[u; v]`` then ``[v; u]`` per graph, util_functions.py:283) as keys ``(graph, side of src, src gid, dst gid)``;
+    rebuilt from the recorded node lists by the pinned extraction oracle."""
+    from oracle import extract_ref as X
+    A, Acsc = case['A'], case['A'].tocsc()
+    keys = []
+    for g in range(B):
+        rec = case['recs'][first + g]
+        un, vn = rec['u_nodes'], rec['v_nodes']
+        nu = len(un)
+        out = X.subgraph_extraction_labeling(tuple(case['links'][first + g]), A, Acsc, 1, 1.0, None, None, None,
+                                             case['class_values'], case['link_labels'][first + g],
+                                             node_lists=(un, vn, [0] + [1] * (nu - 1), [0] + [1] * (len(vn) - 1)))
+        u, v = out[0], out[1] - nu
+        keys += [(g, 0, int(un[a]), int(vn[b])) for a, b in zip(u, v)]       # user -> item
+        keys += [(g, 1, int(vn[b]), int(un[a])) for a, b in zip(u, v)]       # item -> user
+    return keys
+
+
+def engine_edge_flags(d, ref_keys, keep, force_undirected):
+    """Keep flags per entry of the engine's dst-sorted CSR (bit 0: src -> dst kept, bit 1: dst -> src kept) from a keep
+    mask drawn over the REFERENCE's edge order (all directed edges, or the ``row < col`` = user -> item half under
+    ``force_undirected``: PyG ``dropout_adj`` as called at reference models.py:193-198)."""
+    if force_undirected:
+        half = [k for k in ref_keys if k[1] == 0]
+        assert len(half) == len(keep)
+        kept = {(g, s, t) for (g, _, s, t), kp in zip(half, keep) if kp}
+        look = lambda g, side, s, t: (g, s, t) in kept if side == 0 else (g, t, s) in kept
+        lookr = look
+    else:
+        assert len(ref_keys) == len(keep)
+        kd = {k: bool(kp) for k, kp in zip(ref_keys, keep)}
+        look = lambda g, side, s, t: kd[(g, side, s, t)]
+    N = d['N']
+    dst = np.repeat(np.arange(N, dtype=np.int64), np.diff(d['row_ptr']).astype(np.int64))
+    flags = np.zeros(d['E'], np.uint8)
+    for p in range(d['E']):
+        i, c = int(dst[p]), int(d['col'][p])
+        g = int(d['node_graph'][i])
+        side_src = int(d['node_label'][c] % 2)
+        s, t = int(d['node_gid'][c]), int(d['node_gid'][i])
+        fwd = look(g, side_src, s, t)
+        bwd = look(g, 1 - side_src, t, s)
+        flags[p] = int(fwd) | (int(bwd) << 1)
+    return flags
+
+
+def run_reference_fixture(be, mg, batch_size, tol_scale=1.0, trajectory=True):
+    """The engine on the SAME subgraphs, weights and dropout masks as the reference's own ``models.py`` /
+    ``train_eval.py`` run recorded in ``tests/golden/model_golden.npz``: eval outputs, first-step outputs and every
+    gradient, then the fused ``igmc_train_step`` over the epoch's batches against the parameters the reference's
+    ``train`` + ``torch.optim.Adam`` left, and its returned epoch loss."""
+    case = fixture_case(mg)
+    R, n_side, L = mg.R, mg.n_side, 4
+    n_batches = mg.n_steps()
+    g = engine.Graph(case['A'], device=be.device, lib=be.lib)
+    b = engine.Batch(g, max_graphs=batch_size, hop=1, max_nodes_per_hop=case['mnph'])
+    ws = engine.ModelWorkspace(be.lib, be.device, R, 4, L, n_side, b.node_capacity, b.edge_capacity, b.max_graphs)
+    init = {k: v.numpy() for k, v in mg.state('init').items()}
+    flat = np.zeros(ws.n_params, np.float32)
+    for key, off, shape in ws.layout():
+        flat[off:off + int(np.prod(shape))] = init[key].reshape(-1)
+    P = be.dev(flat)
+    n_p = ws.n_params
+    M1, M2, G = be.dev(np.zeros(n_p, np.float32)), be.dev(np.zeros(n_p, np.float32)), be.dev(np.zeros(n_p, np.float32))
+    out, loss = be.dev(np.zeros(batch_size, np.float32)), be.dev(np.zeros(2, np.float32))
+    total = be.dev(np.zeros(1, np.float64))
+    ys_all = case['class_values'][case['link_labels']].astype(np.float32)
+    res = dict(eval_rel=0.0)
+    side_bufs = []
+
+    def load_batch(s):
+        first = s * batch_size
+        recs = case['recs'][first:first + batch_size]
+        ul, vl = [r['u_nodes'] for r in recs], [r['v_nodes'] for r in recs]
+        ud = [np.r_[0, np.ones(len(u) - 1, np.int64)] for u in ul]
+        vd = [np.r_[0, np.ones(len(v) - 1, np.int64)] for v in vl]
+        b.extract_replay(ul, vl, ud, vd, ys_all[first:first + batch_size])
+        be.sync()
+        d = b.download()
+        if n_side:
+            uf = mg['u_features'][case['links'][first:first + batch_size, 0]]
+            vf = mg['v_features'][case['links'][first:first + batch_size, 1]]
+            sb = be.dev(np.concatenate([uf, vf], 1).astype(np.float32))
+            side_bufs.append(sb)
+            b.set_side_features(be.ptr(sb), n_side)
+        flags = None
+        em = mg.edge_mask(s)
+        if em is not None:
+            flags = engine_edge_flags(d, reference_edges(case, first, len(recs)), em, mg.force_undirected)
+            b.set_edge_flags(flags)
+        lm = be.dev(mg.lin_mask(s, (len(recs), 128)).astype(np.uint8).reshape(-1))
+        return d, flags is not None, lm
+
+    # ---- eval-mode forward of every batch with the initial parameters
+    for s in range(n_batches):
+        d, _, _ = load_batch(s)
+        ws.forward(be.ptr(P), b, be.ptr(out), training=False, multiply_by=mg.multiply_by)
+        res['eval_rel'] = max(res['eval_rel'], rel_err(be.host(out)[:d['B']], mg['eval_out/%d' % s]))
+    assert res['eval_rel'] < OUT_TOL * tol_scale, res['eval_rel']
+    # ---- first step: outputs + every gradient
+    d, use_flags, lm = load_batch(0)
+    grad = be.dev(np.zeros(n_p, np.float32))
+    ws.loss_grad(be.ptr(P), b, be.ptr(out), be.ptr(grad), be.ptr(loss), use_edge_flags=use_flags, lin_mask=be.ptr(lm),
+                 multiply_by=mg.multiply_by, ARR=mg.ARR)
+    res['train_out_rel'] = rel_err(be.host(out)[:d['B']], mg['train/out/0'])
+    gg = unflatten_grads(ws, be.host(grad))
+    ref_g = {k: v.numpy() for k, v in mg.state('train/grad0').items()}
+    worst, worst_key = 0.0, ''
+    for key, rgn in ref_g.items():
+        err = np.abs(gg[key] - rgn).max() / max(np.abs(rgn).max(), 1e-6)
+        if err > worst:
+            worst, worst_key = float(err), key
+    res.update(worst_grad_rel=worst, worst_grad_tensor=worst_key, N=int(d['N']), E=int(d['E']))
+    if n_batches == 1:          # one batch: the reference's returned epoch loss IS the step's loss
+        res['loss_rel'] = abs(float(be.host(loss)[0]) - float(mg['train/epoch_loss'])) / abs(float(mg['train/epoch_loss']))
+        assert res['loss_rel'] < LOSS_RTOL * tol_scale, res['loss_rel']
+    assert res['train_out_rel'] < OUT_TOL * tol_scale, res['train_out_rel']
+    assert worst < GRAD_TOL * tol_scale, '%s: max rel-to-peak grad error %.3e' % (worst_key, worst)
+    # ---- the epoch through the fused step (loss bookkeeping + Adam inside the kernels) vs the reference's train()
+    if trajectory:
+        tot = 0.0
+        for s in range(n_batches):
+            d, use_flags, lm = load_batch(s)
+            be.lib.call('igmc_train_step', ws.handle, engine._p(be.ptr(P)), b.handle, int(use_flags), engine._p(be.ptr(lm)),
+                        0, 0, float(mg.multiply_by), mg.ARR, engine._p(be.ptr(out)), engine._p(be.ptr(G)),
+                        engine._p(be.ptr(M1)), engine._p(be.ptr(M2)), engine._p(be.ptr(loss)), engine._p(be.ptr(total)), None,
+                        s + 1, mg.lr, 0.9, 0.999, 1e-8, 0.0, None)
+            be.sync()
+            tot += float(be.host(loss)[0]) * d['B']
+            assert rel_err(be.host(out)[:d['B']], mg['train/out/%d' % s]) < 5 * OUT_TOL * tol_scale
+        be.lib.call('igmc_model_check', ws.handle, None)
+        n = n_batches * batch_size
+        res['epoch_loss_rel'] = abs(tot / n - float(mg['train/epoch_loss'])) / abs(float(mg['train/epoch_loss']))
+        assert res['epoch_loss_rel'] < TRAJ_LOSS_RTOL * tol_scale, res['epoch_loss_rel']
+        assert float(be.host(total)[0]) == pytest_approx(tot, 1e-5)
+        post = {k: v.numpy() for k, v in mg.state('post').items()}
+        want = np.zeros(n_p, np.float32)
+        for key, off, shape in ws.layout():
+            want[off:off + int(np.prod(shape))] = post[key].reshape(-1)
+        diff = np.abs(be.host(P) - want)
+        bad = diff > TRAJ_P_ATOL + TRAJ_P_RTOL * np.abs(want)
+        res.update(params_frac_off=float(bad.mean()), params_max_diff=float(diff.max()))
+        assert bad.mean() < TRAJ_FRAC_OFF and diff.max() <= TRAJ_P_MAX, (bad.mean(), diff.max())
+    record_observed('reference_fixture', case=mg.case, **{k: v for k, v in res.items()})
+    return res
+
+
+def run_reference_fixture_dgcnn(be, mg, batch_size):
+    """Sort-pool family: the engine (conv kernels + sortpool.hip) on the subgraphs / weights / masks of the reference's own
+    ``DGCNN_RS`` run (``models.py:123-167``): eval outputs of every batch, first-step outputs and every gradient."""
+    case = fixture_case(mg)
+    R, L, k = mg.R, 4, int(mg['k'])
+    g = engine.Graph(case['A'], device=be.device, lib=be.lib)
+    b = engine.Batch(g, max_graphs=batch_size, hop=1, max_nodes_per_hop=case['mnph'])
+    ws = engine.ModelWorkspace(be.lib, be.device, R, 4, L, 0, b.node_capacity, b.edge_capacity, b.max_graphs)
+    sp = engine.SortPoolWorkspace(ws, k, max(2, b.node_capacity // b.max_graphs))
+    init = {key: v.numpy() for key, v in mg.state('init').items()}
+    flat = np.zeros(sp.n_params, np.float32)
+    for key, off in sp.offsets.items():
+        flat[off:off + init[key].size] = init[key].reshape(-1)
+    assert sum(v.size for v in init.values()) == sp.n_params
+    P = be.dev(flat)
+    out, loss = be.dev(np.zeros(batch_size, np.float32)), be.dev(np.zeros(2, np.float32))
+    ys_all = case['class_values'][case['link_labels']].astype(np.float32)
+
+    def load_batch(s):
+        first = s * batch_size
+        recs = case['recs'][first:first + batch_size]
+        ul, vl = [r['u_nodes'] for r in recs], [r['v_nodes'] for r in recs]
+        b.extract_replay(ul, vl, [np.r_[0, np.ones(len(u) - 1, np.int64)] for u in ul],
+                         [np.r_[0, np.ones(len(v) - 1, np.int64)] for v in vl], ys_all[first:first + batch_size])
+        be.sync()
+        return b.download(), first, len(recs)
+
+    res = dict(eval_rel=0.0)
+    for s in range(mg.n_steps()):
+        d, _, _ = load_batch(s)
+        sp.forward(be.ptr(P), b, be.ptr(out), training=False)
+        res['eval_rel'] = max(res['eval_rel'], rel_err(be.host(out)[:d['B']], mg['eval_out/%d' % s]))
+    assert res['eval_rel'] < DGCNN_OUT_TOL, res['eval_rel']
+    d, first, nb = load_batch(0)
+    b.set_edge_flags(engine_edge_flags(d, reference_edges(case, first, nb), mg.edge_mask(0), mg.force_undirected))
+    lm = be.dev(mg.lin_mask(0, (nb, 128)).astype(np.uint8).reshape(-1))
+    grad = be.dev(np.zeros(sp.n_params, np.float32))
+    sp.loss_grad(be.ptr(P), b, be.ptr(out), be.ptr(grad), be.ptr(loss), use_edge_flags=True, lin_mask=be.ptr(lm), ARR=mg.ARR)
+    res['train_out_rel'] = rel_err(be.host(out)[:d['B']], mg['train/out/0'])
+    gflat = be.host(grad)
+    worst, worst_key = 0.0, ''
+    for key, v in mg.state('train/grad0').items():
+        rgn = v.numpy()
+        off = sp.offsets[key]
+        err = np.abs(gflat[off:off + rgn.size].reshape(rgn.shape) - rgn).max() / max(np.abs(rgn).max(), 1e-6)
+        if err > worst:
+            worst, worst_key = float(err), key
+    res.update(worst_grad_rel=worst, worst_grad_tensor=worst_key, k=k)
+    record_observed('reference_fixture', case=mg.case, **res)
+    assert res['train_out_rel'] < DGCNN_OUT_TOL, res['train_out_rel']
+    assert worst < DGCNN_GRAD_TOL, '%s: max rel-to-peak grad error %.3e' % (worst_key, worst)
+    return res

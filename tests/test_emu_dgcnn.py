@@ -68,3 +68,11 @@ def test_sort_pool_error_behaviour(be, monkeypatch):
     sp = engine.SortPoolWorkspace(ws, 12, slot)
     with pytest.raises(RuntimeError, match='null buffer'):
         sp.forward(None, b, out.ctypes.data)
+
+
+def test_sortpool_kernels_against_the_reference_models_py_fixture(be):
+    """``DGCNN_RS`` as the reference's own ``models.py:123-167`` ran it (``tests/golden/model_golden.npz``): k from the
+    percentile form, eval outputs, first-step outputs and every gradient on the recorded subgraphs / masks."""
+    from helpers import load_model_golden
+    res = PC.run_reference_fixture_dgcnn(be, load_model_golden('dgcnn_rs'), 8)
+    assert res['k'] == 40

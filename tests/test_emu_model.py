@@ -296,3 +296,14 @@ def test_dense_per_layer_kernels_with_side_features(be, monkeypatch):
     res = PC.run_model_parity(be, sub('synth_cap', 6), R=5, use_dropout=True, n_side=10)
     assert res['worst_grad_err'] < 1e-4
     assert res['batch'].dense_layers(res['ws'])
+
+
+@pytest.mark.parametrize('case', ['igmc_r5', 'igmc_side', 'igmc_r10'])
+def test_kernels_against_the_reference_models_py_fixtures(be, case):
+    """The kernel logic against outputs of the reference's OWN ``models.py`` / ``train_eval.py``
+    (``tests/golden/model_golden.npz``, ``make_model_golden.py``): same subgraphs (recorded node lists replayed), weights,
+    edge / MLP dropout masks; eval outputs, first-step outputs + every gradient, then the epoch through the fused step
+    against the parameters the reference's ``train`` + Adam left and its returned epoch loss."""
+    from helpers import load_model_golden
+    res = PC.run_reference_fixture(be, load_model_golden(case), 8)
+    assert res['worst_grad_rel'] < PC.GRAD_TOL and res['params_frac_off'] == 0.0

@@ -126,3 +126,11 @@ def test_dgcnn_rs_steps_replay_from_the_step_graph():
     for a, b in zip(res['graph'][:3], res['eager'][:3]):
         assert torch.equal(a, b)
     assert res['graph'][3] == res['eager'][3]
+
+
+def test_dgcnn_rs_matches_the_reference_fixture(be):
+    """The sort-pool family against the reference's own ``DGCNN_RS`` (``models.py:123-167``) run recorded in
+    ``tests/golden/model_golden.npz``."""
+    from helpers import load_model_golden
+    res = PC.run_reference_fixture_dgcnn(be, load_model_golden('dgcnn_rs'), 8)
+    assert res['k'] == 40

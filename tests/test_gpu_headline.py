@@ -323,3 +323,29 @@ def test_step_graph_on_the_dense_per_layer_path_is_reproducible():
     _assert_same(ref, again, 'dense per-layer path, repeat')
     _, eager = _trajectory(ds, 0.2, perm, use_graph=False, overlap=False, group=8)
     _assert_same(ref, eager, 'dense per-layer path, eager vs graph')
+
+
+# ---------------------------------------------------------------------- against the reference's OWN models.py / train_eval.py
+@pytest.mark.parametrize('tag', ['nodrop', 'drop'])
+def test_headline_batch_matches_the_reference_fixture(be, tag, monkeypatch, capfd):
+    """BASELINE.json configs[2] shape (ml_1m-shaped graph, cap 100, ONE batch of 50) against the fixture the UNMODIFIED
+    reference ``models.py`` / ``train_eval.py`` produced (``tests/golden/make_model_golden.py``): the node lists its
+    extractor chose are replayed, then eval outputs, train outputs, the step's loss (= the epoch loss its ``train``
+    returned), EVERY gradient, and the parameters after its ``train`` + Adam step -- tolerances of this file's oracle
+    checks (outputs 2e-5, loss 3e-6, gradients 5e-5 of the tensor's peak)."""
+    from helpers import load_model_golden
+    monkeypatch.setenv('IGMC_GRAPH_STEP', '1')
+    monkeypatch.setenv('IGMC_GS_TRACE', '1')
+    res = PC.run_reference_fixture(be, load_model_golden('headline_' + tag), 50)
+    assert res['N'] > 50 * 150 and res['E'] > 150000
+    err = capfd.readouterr().err
+    assert 'k_graph_step B=50 train=1' in err and 'cluster=4' in err, err[-400:]
+
+
+@pytest.mark.parametrize('case', ['igmc_r5', 'igmc_side', 'igmc_r10'])
+def test_small_batches_match_the_reference_fixtures(be, case):
+    """R = 5 with edge dropout, side features + multiply_by + force_undirected, R = 10 (flixster): three batches of 8
+    each, the whole epoch of the reference's ``train`` (loss bookkeeping + Adam) through the fused step."""
+    from helpers import load_model_golden
+    res = PC.run_reference_fixture(be, load_model_golden(case), 8)
+    assert res['params_frac_off'] < PC.TRAJ_FRAC_OFF
