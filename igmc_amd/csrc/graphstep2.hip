@@ -33,6 +33,7 @@
 // no side features, both sides <= 16 * (2 * cluster size) <= 128 rows.
 #include "launch.h"
 #include "g2_image.h"
+#include "head_sub.h"
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
@@ -2531,116 +2532,22 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
 // Training head of the dense per-layer path, ONE workgroup per subgraph (k_graph_step2's head as a launch of its own): the
 // 256 conv features of the two target rows -> lin1 / ReLU / dropout / lin2 / residual -> dz, d feat and dPre_3 on the
 // target rows.  (k_head_train's head role takes 16 subgraphs per workgroup on the f32 matrix cores: four workgroups at
-// batch 50, 19 us of dependent round trips; 50 workgroups of one subgraph each are done in a third of that.)  D = 256.
+// batch 50, 19 us of dependent round trips; 50 workgroups of one subgraph each are done in a third of that.)  Side features
+// (--use-features, reference models.py:208-209) ride along: D = 256 + S, the body is head_sub.h.
 __global__ __launch_bounds__(256) void k_head_sub(BatchDev b, ModelDev m, const float* __restrict__ P,
                                                     const uint8_t* __restrict__ inj_mask, uint64_t seed, uint64_t step_arg,
                                                     float mult, float grad_scale, float* __restrict__ out) {
-  __shared__ float sfeat[256], sgf[256], sa1[128], skeep[128], sdz[128], sred[128], part4[4 * 256], misc[4];
+  IGMC_DYN_SMEM(smem);
   const int g = blockIdx.x;
   if (g >= b.totals[3]) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t step = m.ctrl ? (uint64_t)m.ctrl[IGMC_CTRL_STEP] : step_arg;
-  const int nu = b.node_off[g], nv = nu + b.n_users[g];
-  const size_t trow = (size_t)((tid >> 7) ? nv : nu) * 32 + (tid & 31);          // feature tid: side, layer, column
-  const float fv = m.h[(tid >> 5) & 3][trow];
-  const float yv = b.y[g], l2b = P[m.off_l2b];
-  const float l1b = P[m.off_l1b + (tid >> 1)], l2w = P[m.off_l2w + (tid >> 1)], l2w_t = P[m.off_l2w + (tid & 127)];
-  sfeat[tid] = fv;
-  m.feat[(size_t)g * 256 + tid] = fv;
-  __syncthreads();
-  {
-    // lin1 (256 -> 128): wave w takes hidden units 32 w .. 32 w + 31; one weight row (1 KB) per load instruction, lane = 4
-    // fan-in columns; the 32 per-lane partial dot products are reduced over the 64 lanes by a transposing butterfly
-    const int ju = tid >> 1, part = tid & 1;
-    const float4 f4 = *(const float4*)(sfeat + 4 * lane);
-    const float* wrow = P + m.off_l1w + (int64_t)(32 * wave) * 256 + 4 * lane;
-    float v[32];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      float4 w4[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) w4[q] = *(const float4*)(wrow + (16 * hh + q) * 256);
-      G2_SCHED_BARRIER();
-#pragma unroll
-      for (int q = 0; q < 16; ++q) v[16 * hh + q] = (w4[q].x * f4.x + w4[q].y * f4.y) + (w4[q].z * f4.z + w4[q].w * f4.w);
-      G2_SCHED_BARRIER();
-    }
-#define G2_BFLY(H)                                                                   \
-    {                                                                                \
-      const bool up = (lane & (2 * (H))) != 0;                                       \
-      _Pragma("unroll") for (int i = 0; i < (H); ++i) {                              \
-        const float send = up ? v[i] : v[i + (H)], keep = up ? v[i + (H)] : v[i];    \
-        v[i] = keep + __shfl_xor(send, 2 * (H));                                     \
-      }                                                                              \
-    }
-    G2_BFLY(16) G2_BFLY(8) G2_BFLY(4) G2_BFLY(2) G2_BFLY(1)
-#undef G2_BFLY
-    const float s = v[0] + __shfl_xor(v[0], 1);
-    if (part == 0) {
-      float av = s + l1b;
-      av = av > 0.f ? av : 0.f;
-      const int keep = inj_mask ? (int)inj_mask[g * 128 + ju]
-                                : (int)(igmc_u01(igmc_unit_hash(seed, step, (uint32_t)g, (uint32_t)ju)) >= 0.5f);
-      m.a1[g * 128 + ju] = av;
-      m.lmask[g * 128 + ju] = (uint8_t)keep;
-      sa1[ju] = av;
-      skeep[ju] = keep ? 1.f : 0.f;
-      sred[ju] = (keep ? av * 2.f : 0.f) * l2w;       // F.dropout(p = 0.5): kept * 2
-    }
-  }
-  __syncthreads();
-  if (wave == 0) {
-    float s = sred[lane] + sred[lane + 64];
-    s = igmc_wave_sum_f(s);
-    if (lane == 0) {
-      const float o = (s + l2b) * mult;
-      out[g] = o;
-      m.err[g] = o - yv;
-      misc[0] = o - yv;
-    }
-  }
-  __syncthreads();
-  if (tid < 128) {
-    const float dp = 2.f * misc[0] * grad_scale * mult;
-    const float dzv = (sa1[tid] > 0.f && skeep[tid] != 0.f) ? dp * l2w_t * 2.f : 0.f;
-    sdz[tid] = dzv;
-    m.dz[g * 128 + tid] = dzv;
-  }
-  __syncthreads();
-  {   // d feat = dz @ lin1.weight: wave w takes hidden units 32 w .. 32 w + 31, lane -> 4 fan-in columns; rows with
-      // dz == 0 (ReLU / dropout: ~3/4 of them) are skipped wave-uniformly
-    const float* w1 = P + m.off_l1w + 4 * lane;
-    float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned long long nz = __ballot(lane < 32 && sdz[32 * wave + (lane & 31)] != 0.f);
-    while (nz) {
-      int q[8];
-      float4 wv[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        q[u] = nz ? (int)__builtin_ctzll(nz) : -1;
-        if (nz) nz &= nz - 1;
-        wv[u] = (q[u] >= 0) ? *(const float4*)(w1 + (int64_t)(32 * wave + q[u]) * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float dzv = (q[u] >= 0) ? sdz[32 * wave + q[u]] : 0.f;
-        s4.x += dzv * wv[u].x; s4.y += dzv * wv[u].y; s4.z += dzv * wv[u].z; s4.w += dzv * wv[u].w;
-      }
-    }
-    *(float4*)(part4 + wave * 256 + 4 * lane) = s4;
-  }
-  __syncthreads();
-  {
-    const float v = (part4[tid] + part4[256 + tid]) + (part4[512 + tid] + part4[768 + tid]);
-    m.gfeat[(size_t)g * 256 + tid] = v;
-    if (((tid >> 5) & 3) == 3) m.dpre[3][trow] = v * (1.f - fv * fv);      // dPre_3: non-zero on the two target rows only
-  }
-  (void)sgf;
+  head_sub_body<true>(b, m, P, g, (int)threadIdx.x, (float*)smem, inj_mask, seed, step, mult, grad_scale, out);
 }
 
 void igmc_launch_head_sub(const ModelDev& m, const BatchDev& b, const float* P, int B, const uint8_t* inj_mask, uint64_t seed,
                           uint64_t step, float mult, float grad_scale, float* out, void* stream) {
-  IGMC_PLAUNCH("k_head_sub", k_head_sub, B, 256, 0, stream, b, m, P, inj_mask, seed, step, mult, grad_scale, out);
+  IGMC_PLAUNCH("k_head_sub", k_head_sub, B, 256, (size_t)igmc_head_sub_lds_floats(m.D) * sizeof(float), stream, b, m, P, inj_mask,
+               seed, step, mult, grad_scale, out);
 }
 
 // Layer 0 of the dense per-layer path (one-hot input): per row the histogram of (relation, label of the neighbour) over
@@ -2925,7 +2832,7 @@ void igmc_launch_dl_fwd(const ModelDev& m, const BatchDev& b, const float* P, in
 
 // (k_dl_bwd: same conditions as k_dl_fwd -- whose launch precedes it and maintains the exchange regions -- plus the tables')
 int igmc_dl_bwd_eligible(const ModelDev& m, const BatchDev& b, int B) {
-  if (!igmc_dl_fwd_eligible(m, b, B) || !igmc_dl_ts_eligible(m, b, B) || m.D != 256) return 0;
+  if (!igmc_dl_fwd_eligible(m, b, B) || !igmc_dl_ts_eligible(m, b, B)) return 0;
   const char* e = getenv("IGMC_DL_FUSED");
   if (e && atoi(e) == 1) return 0;                 // (1: the forward only)
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;

@@ -2412,12 +2412,12 @@ int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchD
   // -- k_tail_ts sums the workgroups' tables and forms d lin1 / d lin2, k_finalize_ts turns them into gradients (+ Adam) --
   // replaces the Y products, G, the weight-gradient products and their reduction
   if (dlts) {
-    if (m.D == 256 && !getenv("IGMC_HEAD_TRAIN"))           // one workgroup per subgraph
+    if (!getenv("IGMC_HEAD_TRAIN"))                           // one workgroup per subgraph (side features included)
       igmc_launch_head_sub(m, b, (const float*)P, B, inj_mask, seed, step, mult, grad_scale, out, stream);
     else                                                      // (head role only: 16 subgraphs per workgroup)
       IGMC_PLAUNCH("k_head_train", k_head_train, dim3(hb, 1), 512, ysz, stream, b, m, (const float*)P, inj_mask, seed, step,
                    mult, grad_scale, out);
-    if (dlf && m.D == 256 && !getenv("IGMC_HEAD_TRAIN") && igmc_dl_bwd_eligible(m, b, B))
+    if (dlf && !getenv("IGMC_HEAD_TRAIN") && igmc_dl_bwd_eligible(m, b, B))
       igmc_launch_dl_bwd(m, b, B, use_flags, stream);         // the three backward layers as ONE launch
     else
       for (int l = 3; l >= 1; --l) igmc_launch_dl_layer(m, b, (const float*)P, B, l, 1, use_flags, nullptr, stream, 1);

@@ -172,11 +172,17 @@ class ModelGolden(object):
         self.R, self.n_side, self.force_undirected = int(self.R), int(self.n_side), bool(self.force_undirected)
         self.ARR, self.lr, self.p_edge = [float(x) for x in z[case + '/train/hyper']]
 
+    def _key(self, key):
+        k = self.case + '/' + key
+        if k not in self.z.files and self.case.startswith('headline_'):      # geometry of the two headline runs: shared
+            k = 'headline/' + key
+        return k
+
     def __getitem__(self, key):
-        return self.z[self.case + '/' + key]
+        return self.z[self._key(key)]
 
     def has(self, key):
-        return (self.case + '/' + key) in self.z.files
+        return self._key(key) in self.z.files
 
     def state(self, prefix):
         import torch

@@ -296,6 +296,13 @@ def test_dense_per_layer_kernels_with_side_features(be, monkeypatch):
     res = PC.run_model_parity(be, sub('synth_cap', 6), R=5, use_dropout=True, n_side=10)
     assert res['worst_grad_err'] < 1e-4
     assert res['batch'].dense_layers(res['ws'])
+    # a width the one-launch-per-direction sequence takes (D = 256 + 16): k_dl_fwd -> k_head_sub with the side columns in its
+    # lin1 rows -> k_dl_bwd -> the table tail
+    monkeypatch.setenv('IGMC_GRAPH_STEP', '0')
+    monkeypatch.setenv('IGMC_GS_TRACE', '1')
+    res = PC.run_model_parity(be, sub('synth_nocap:200', 4), R=5, use_dropout=True, n_side=16)
+    assert res['worst_grad_err'] < 1e-4
+    assert res['batch'].dense_layers(res['ws'])
 
 
 @pytest.mark.parametrize('case', ['igmc_r5', 'igmc_side', 'igmc_r10'])
