@@ -1345,45 +1345,59 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_partials(ModelDev m, int 
 // the sum of the fin partials of its block (k_finalize_ts), so that kernel never reads a basis element it does not own.
 __device__ __forceinline__ void reduce_ts_body(const ModelDev& m, int nparts, int stride, int B, int blk,
                                                const float* __restrict__ Pold = nullptr) {
-  __shared__ float sred[4][64];
+  // 64 outputs a workgroup as 16 float4 columns x 16 partial groups: thread (column o4 = lane & 15, group pg = 4 wave +
+  // (lane >> 4)) sums the partial slots pg, pg + 16, .. of its four outputs (<= 14 sixteen-byte loads, all requested before
+  // the first add: ONE round trip; a wave's load instruction covers four 256-byte runs), the 16 groups are then added in
+  // index order through LDS -- a fixed order, so the result does not depend on the launch.  ~90 registers a thread: every
+  // workgroup of the launch is resident at once (the 56-loads-a-thread form needed 292 and took two residency rounds).
+  __shared__ float4 sred4[16][16];
   const int ts = m.ts_stride, rows0 = m.R * m.L + m.L + 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int o = blk * 64 + lane;
-  const int l = o / ts, i = o % ts;
-  float s = 0.f;
-  const bool ok = l < 4 && (l > 0 || i < rows0 * 32);
-  if (ok) {
-    // slot of member c of subgraph g = g + c * stride (one-workgroup launches: stride = IGMC_TS_BLOCKS, cs = 1);
-    // the 4 waves split the subgraphs; up to 4 members x 14 subgraphs = 56 independent loads in flight per round (one
-    // round trip per round: the reduction is latency-bound; a batch of <= 56 subgraphs is ONE round), fixed order
-    const float* p = m.ts_part + (size_t)l * IGMC_TS_BLOCKS * ts + i;
+  const int o4 = lane & 15, pg = wave * 4 + (lane >> 4);
+  const int o0 = blk * 64 + 4 * o4;                     // first of the thread's four outputs (ts is a multiple of 32: the four share a layer)
+  const int l = o0 / ts, i0 = o0 % ts;
+  const bool ok4 = l < 4 && (l > 0 || i0 < rows0 * 32);
+  float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok4) {
+    // slot of member c of subgraph g = g + c * stride (one-workgroup launches: stride = IGMC_TS_BLOCKS, cs = 1); the valid
+    // slots in the order (c, g) are numbered q = c * ng + g
+    const float* p = m.ts_part + (size_t)l * IGMC_TS_BLOCKS * ts + i0;
     const int ng = (nparts < stride) ? nparts : ((B < stride) ? B : stride), cs = (nparts + stride - 1) / stride;
-    for (int c0 = 0; c0 < cs; c0 += 4) {
-      for (int g0 = wave; g0 < ng; g0 += 56) {
-        float v[4][14];
+    const int nq = cs * ng;
+    for (int q0 = pg; q0 < nq; q0 += 16 * 14) {
+      float4 v[14];
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int u = 0; u < 14; ++u)
-            v[c][u] = (c0 + c < cs && g0 + 4 * u < ng) ? p[((size_t)(c0 + c) * stride + g0 + 4 * u) * ts] : 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int u = 0; u < 14; ++u) s += v[c][u];
+      for (int u = 0; u < 14; ++u) {
+        const int q = q0 + 16 * u, qc = q < nq ? q : nq - 1;
+        const int c = qc / ng, g = qc - c * ng;
+        v[u] = *(const float4*)(p + (size_t)(c * stride + g) * ts);
       }
+#pragma unroll
+      for (int u = 0; u < 14; ++u)
+        if (q0 + 16 * u < nq) {
+          s4.x += v[u].x; s4.y += v[u].y; s4.z += v[u].z; s4.w += v[u].w;
+        }
     }
   }
-  sred[wave][lane] = s;
+  sred4[pg][o4] = s4;
   __syncthreads();
   if (wave == 0) {
-    const float tot = ok ? (sred[0][lane] + sred[1][lane]) + (sred[2][lane] + sred[3][lane]) : 0.f;
+    // lane -> output blk * 64 + lane: component (lane & 3) of column (lane >> 2), the 16 groups in index order
+    const float* sr = (const float*)sred4;
+    float tot = 0.f;
+#pragma unroll
+    for (int g16 = 0; g16 < 16; ++g16) tot += sr[(g16 * 16 + (lane >> 2)) * 4 + (lane & 3)];
+    const int o = blk * 64 + lane;
+    const int lo_ = o / ts, i = o % ts;
+    const bool ok = lo_ < 4 && (lo_ > 0 || i < rows0 * 32);
+    if (!ok) tot = 0.f;
     if (ok) m.ts_raw[o] = tot;
     if (Pold) {
       float pb[4] = {0.f, 0.f, 0.f, 0.f};
-      if (l < 4) {
-        const int nE = ((l == 0) ? m.L : 32) * 32;
+      if (lo_ < 4) {
+        const int nE = ((lo_ == 0) ? m.L : 32) * 32;
         if (i < m.R * nE) {
-          const float* basis = Pold + m.off_basis[l] + i % nE;
+          const float* basis = Pold + m.off_basis[lo_] + i % nE;
 #pragma unroll
           for (int bb = 0; bb < 4; ++bb) pb[bb] = tot * basis[bb * nE];
         }
@@ -1392,7 +1406,7 @@ __device__ __forceinline__ void reduce_ts_body(const ModelDev& m, int nparts, in
       for (int bb = 0; bb < 4; ++bb)
 #pragma unroll
         for (int d = 16; d >= 1; d >>= 1) pb[bb] += __shfl_xor(pb[bb], d, 64);     // stays inside a 32-lane half
-      if ((lane & 31) == 0 && l < 4) *(float4*)(m.datt_part + (size_t)(o >> 5) * 4) = make_float4(pb[0], pb[1], pb[2], pb[3]);
+      if ((lane & 31) == 0 && lo_ < 4) *(float4*)(m.datt_part + (size_t)(o >> 5) * 4) = make_float4(pb[0], pb[1], pb[2], pb[3]);
     }
   }
 }
