@@ -203,6 +203,56 @@ def cpu_baseline(A, tr_u, tr_v, tr_l, class_values, mnph, adj_dropout, mode, bud
     return None
 
 
+def floor_us(lib, shape, class_values, cfg, dev, local, steps=40):
+    """Device launch clock of the subgraph kernel on a batch of edgeless two-node subgraphs (see the roofline leg)."""
+    import ctypes as C
+    import scipy.sparse as ssp
+    rng = np.random.default_rng(7)
+    n = 50 * 64
+    u = rng.integers(1, shape[0], n).astype(np.int64)
+    v = rng.integers(1, shape[1], n).astype(np.int64)
+    A0 = ssp.csr_matrix((np.array([1.0], np.float32), (np.array([0]), np.array([0]))), shape=shape)
+    ds0 = MyDynamicDataset('data/bench_floor', A0, (u, v), np.zeros(n, np.int64), 1, 1.0, cfg['mnph'], None, None, class_values,
+                           device=local, seed=1)
+    m0 = IGMC(ds0, latent_dim=[32, 32, 32, 32], num_relations=len(class_values), num_bases=4, regression=True,
+              adj_dropout=cfg['adj_dropout'], multiply_by=1, seed=1).to(dev)
+    m0.reset_parameters()
+    o0 = FlatAdam(m0, lr=1e-3)
+    sg0 = StepGraph(m0, o0, ds0, BATCH, 0.001, use_graph=True, overlap=True)
+    sg0.begin_epoch(torch.arange(n), 1)
+    sg0.steps(1)
+    lib.igmc_profile_enable(2)
+    sg0.prepare(group=10)
+    lib.call('igmc_profile_gs_clock', sg0.ws.handle, None, None, 1)
+    sg0.steps(steps)
+    torch.cuda.synchronize()
+    cnt, mean = C.c_int64(0), C.c_double(0.0)
+    lib.call('igmc_profile_gs_clock', sg0.ws.handle, C.byref(cnt), C.byref(mean), 1)
+    lib.igmc_profile_enable(0)
+    sg0.detach()
+    sg0.check()
+    return float(mean.value) if cnt.value > 0 else None
+
+
+def run_secondary(configs=('ml_100k', 'douban', 'flixster'), steps=100, warmup=10):
+    """Short runs of the other configurations (fresh processes of this file): value, us / step, dominant kernel."""
+    import subprocess
+    out = {}
+    for c in configs:
+        cmd = [sys.executable, os.path.abspath(__file__), '--config', c, '--steps', str(steps), '--warmup', str(warmup),
+               '--no-cpu-baseline', '--dp-steps', '0', '--rmse-links', '0', '--profile-steps', '16', '--no-secondary']
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+            d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+            rf = d.get('roofline') or {}
+            out[c] = dict(value=d['value'], us_per_step=d['ms_per_step'] * 1e3, steps=steps, warmup=warmup,
+                          workload=d['config']['workload'], dominant_kernel=rf.get('kernel'), kernel_us=rf.get('avg_us'),
+                          frac=rf.get('frac'), floor_us=rf.get('floor_us'), kernels_us=d.get('kernels_us'))
+        except Exception as e:
+            out[c] = dict(error=repr(e)[:300])
+    return out
+
+
 def main():
     # stdout carries the ONE JSON line and nothing else: libraries that print to the C-level stdout (RCCL's version banner
     # at communicator creation, flushed at exit) are pointed at stderr for the whole run
@@ -224,6 +274,9 @@ def main():
     ap.add_argument('--dgcnn-rs', action='store_true', help='the sort-pool readout family (reference models.py:123-167) instead of IGMC')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly (no hipGraph replay)')
     ap.add_argument('--no-overlap', action='store_true', help='extract batch t+1 on the same stream (no overlap)')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='skip the short runs of the other configurations the default run appends (secondary)')
+    ap.add_argument('--no-floor', action='store_true', help='skip the latency-floor leg of the roofline (edgeless batch)')
     ap.add_argument('--cpu-baseline-worker', default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -365,8 +418,9 @@ def main():
         torch.cuda.synchronize()
         # (rccl_* only when RCCL IS the transport: a host-callback communicator over gloo reports under comm_*)
         is_rccl = isinstance(sg.comm, parallel.GradComm)
-        transport = 'rccl' if is_rccl else getattr(sg.comm, 'transport', 'host-callback:' + str(torch.distributed.get_backend()
-                                                                                                   if world > 1 else 'none'))
+        transport = getattr(sg.comm, 'transport', 'rccl' if is_rccl else 'host-callback')
+        if hasattr(sg.comm, 'check'):
+            sg.comm.check(st)
         dp_check = dict(transport=transport, rccl_rank=rk if is_rccl else None, rccl_world=ws_ if is_rccl else None,
                         comm_rank=rk, comm_world=ws_, launcher_rank=rank, launcher_world=world,
                         ranks_agree=bool(rk == rank and ws_ == world),
@@ -442,7 +496,7 @@ def main():
         # (2) every kernel with HIP events on its launch stream: the same launch structure enqueued eagerly (the extraction
         #     of the next group still runs beside the model kernels), then a few single steps whose batches are inspected
         engine.profile_enable(lib, True)
-        Ns, Es, ext_bytes = [], [], []
+        Ns, Es, ext_bytes, bundles = [], [], [], []
         deg_u = np.diff(A.indptr).astype(np.int64)
         deg_v = np.bincount(A.indices, minlength=A.shape[1]).astype(np.int64)
         was_graph, sg.use_graph = sg.use_graph, False
@@ -465,6 +519,9 @@ def main():
                 ext_bytes.append(tot)
             Ns.append(d['N'])
             Es.append(d['E'])
+            nu_ = np.asarray(d['n_users'][:d['B']], np.int64)
+            nv_ = np.diff(np.asarray(d['node_off'][:d['B'] + 1], np.int64)) - nu_
+            bundles.append(int(((nu_ + 15) // 16).sum() + ((nv_ + 15) // 16).sum()))
         torch.cuda.synchronize()
         sg.use_graph = was_graph
         P = Pe
@@ -509,6 +566,16 @@ def main():
                             avg_us_eager_events=eager_us, algorithmic_bytes=algo_bytes, nodes=N, edges=E,
                             share_of_kernel_time=kernels[dom]['us'] * kernels[dom]['calls_per_step'] * P / (tot * 1e3)
                             if tot > 0 else None)
+            if dom == 'k_graph_step' and bundles:
+                # matrix-core work of the launch: per 16-row bundle and layer pass 120 gather + 72 transform
+                # v_mfma_f32_16x16x32_bf16 (six passes), 20 for the layer-0 histogram; per pass of the backward 24
+                # v_mfma_f32_16x16x4_f32 for the table product.  An HBM-bound path: the figure says how far from the matrix
+                # cores' peak the kernel runs (it is a latency chain, not a throughput)
+                nb = float(np.mean(bundles))
+                bf16_flop = nb * (6 * (120 + 72) + 20) * 2.0 * 16 * 16 * 32
+                roofline['mfma'] = dict(bf16_flop_per_launch=bf16_flop, tflops=bf16_flop / (avg_us * 1e-6) / 1e12,
+                                        frac_of_dense_bf16_peak=bf16_flop / (avg_us * 1e-6) / 1e12 / 2500.0,
+                                        bundles=nb, peak_tflops=2500.0)
         # (a lean arena's extraction stops at the dense blocks; k_emit then only runs for this pass's own inspection calls)
         lean = bool(sg.ws.dense_path(sg.arenas[0], BATCH)) and os.environ.get('IGMC_NO_LEAN', '0') != '1'
         ext_names = [k for k in ('k_extract_nodes', 'k_relm', 'k_relm_dropout', 'k_emit', 'k_count', 'k_fill', 'k_edge_flags')
@@ -523,6 +590,23 @@ def main():
                                    '5*(deg u + deg v + sum deg U_s) + n + 9*E/2 bytes')
     if world > 1:
         parallel.barrier()
+
+    # ---- latency floor of the dominant kernel: the SAME kernel on a batch of 50 edgeless two-node subgraphs (an empty rating
+    #      graph of the same shape: every enclosing subgraph is its two target nodes) -- what a launch costs before any edge
+    #      is gathered: set-up, six layer passes with their exchanges, head.  `frac` of a small-graph configuration (douban)
+    #      reads against this floor, not against the bytes.
+    if roofline is not None and roofline.get('timer_label') == 'k_graph_step' and world == 1 and not args.no_floor and sg.use_graph:
+        try:
+            roofline['floor_us'] = floor_us(lib, A.shape, class_values, cfg, dev, local)
+            roofline['floor_note'] = 'device launch clock of the same kernel under replay on edgeless two-node subgraphs (batch 50)'
+        except Exception as e:          # (a diagnostic leg: never fails the run)
+            sys.stderr.write('floor leg failed: %r\n' % (e,))
+
+    # ---- the other configurations, short runs of this very file (N = 1, default configuration only): BASELINE.json
+    #      configs[1] (ml_100k cap 200) and the bundled real datasets, so that one driver-run line carries them
+    secondary = None
+    if world == 1 and args.config == 'ml_1m' and not args.no_secondary and not args.dgcnn_rs:
+        secondary = run_secondary()
 
     # ---- RMSE of the checkpoint the steps above produced (fixed slice of the test links)
     rmse = None
@@ -581,7 +665,7 @@ def main():
                        'graphs_captured_before_timing': bool(captured), 'steps_per_graph_launch': 2 * group_steps},
             'roofline': roofline, 'cpu_baseline': cpu, 'rmse': rmse, 'extraction': extraction,
             'dp_structure_us': dp_structure['dp_structure_us'] if dp_structure else None, 'dp_structure': dp_structure,
-            'dp_check': dp_check,
+            'dp_check': dp_check, 'secondary': secondary,
             'timing_check': {'wall_ms': dt * 1e3, 'gpu_event_ms': gpu_ms, 'host_enqueue_ms': t_enq * 1e3},
             'final_loss': final_loss, 'kernels_us': {k: round(v['us'], 2) for k, v in kernels.items()},
             'kernel_src_sha': kernel_source_sha(),

@@ -68,6 +68,10 @@ SIGNATURES = {
     'igmc_comm_info': (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
     'igmc_allreduce_grads': (i32, [vp, vp, i64, f32, vp]),
     'igmc_comm_create_host': (i32, [vp, vp, i32, i32, C.POINTER(vp)]),
+    'igmc_comm_peer_alloc': (i32, [i32, i32, i32, i64, C.POINTER(vp), vp]),
+    'igmc_comm_peer_connect': (i32, [vp, vp]),
+    'igmc_comm_check': (i32, [vp, vp]),
+    'igmc_comm_kind': (i32, [vp]),
     'igmc_train_step_dp': (i32, [vp, vp, vp, vp, i32, vp, u64, u64, f32, f32, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32,
                                  f32, f32, vp]),
     'igmc_ctrl_tick': (i32, [vp, vp]),

@@ -1040,11 +1040,18 @@ extern "C" int igmc_train_step(igmc_model* m, float* d_params, const igmc_batch*
 }
 
 // ------------------------------------------------------------------ gradient exchange (RCCL behind the C ABI)
+#define IGMC_MAX_PEERS 16
 struct igmc_comm {
-  void* nccl;        // ncclComm_t (NULL: host-callback communicator, or the emulation build's single rank)
+  void* nccl;        // ncclComm_t (NULL: host-callback / peer communicator, or the emulation build's single rank)
   int rank, world, device;
   igmc_allreduce_fn host_fn;      // igmc_comm_create_host: the caller's own sum over the ranks
   void* host_user;
+  // peer communicator (igmc_comm_peer_alloc / _connect): every rank publishes into its OWN buffer, mapped by the others
+  unsigned long long* pub[IGMC_MAX_PEERS];      // [2 slots][cap] {f32, tag} words of rank r (pub[rank] = the local buffer)
+  int64_t cap;                                  // floats a slot holds
+  int* d_state;                                 // device: [0] launch sequence number, [1] workgroups done, [2] poll timed out
+  int peer;                                     // 1 = peer communicator
+  int connected;
 };
 #ifndef IGMC_HIPEMU
 #include <dlfcn.h>
@@ -1119,6 +1126,8 @@ extern "C" int igmc_comm_create(const uint8_t* h_id128, int rank, int world, int
   c->device = device;
   c->host_fn = nullptr;
   c->host_user = nullptr;
+  c->peer = 0;
+  c->d_state = nullptr;
 #ifndef IGMC_HIPEMU
   std::string why;
   if (rccl_load(&why)) { delete c; IGMC_FAIL(why); }
@@ -1146,7 +1155,192 @@ extern "C" int igmc_comm_create_host(igmc_allreduce_fn fn, void* user, int rank,
   c->device = -1;
   c->host_fn = fn;
   c->host_user = user;
+  c->peer = 0;
+  c->d_state = nullptr;
   *out = c;
+  return 0;
+}
+
+// ---- peer communicator: a one-shot all-reduce over peer-mapped buffers ------------------------------------------------
+// The exchange of a step is ~60 k floats between a handful of GPUs of ONE node: a ring collective pays 2 (G - 1) hops of
+// launch + link latency for it, while every rank can simply READ the other ranks' values -- xGMI is point to point.  Every
+// rank owns a publish buffer (hipMalloc + hipIpcGetMemHandle, mapped by the others with hipIpcOpenMemHandle); a launch
+// of k_peer_allreduce writes the rank's span into its own buffer as 8-byte {value, tag} words (flag in data: single-copy
+// atomic, system scope), then reads the same words of EVERY rank in rank order -- polling a word until its tag is this
+// launch's -- and leaves the sum in place.  Same order on every rank: bit-identical replicas.  No barrier, no second
+// launch: about one xGMI round trip.  Two slots alternate: a rank can only be ONE launch ahead of the slowest one (it
+// cannot finish launch s + 1 before every rank published s + 1, i.e. finished reading s), so slot s & 1 is never
+// overwritten while someone still reads it.  The launch sequence number lives in device memory and is advanced by the
+// launch's last workgroup -- a hipGraph replay carries no host-side counter.  Bounded polls raise d_state[2].
+struct PeerArgs {
+  unsigned long long* pub[IGMC_MAX_PEERS];
+  int world, rank;
+  int64_t cap;
+  int* state;
+  float* a;
+  int64_t na;
+  float* b;
+  int64_t nb;
+};
+__global__ __launch_bounds__(IGMC_BLOCK) void k_peer_allreduce(PeerArgs p) {
+#ifndef IGMC_HIPEMU
+  const uint32_t seq = (uint32_t)__hip_atomic_load(p.state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  const uint32_t seq = (uint32_t)p.state[0];
+#endif
+  const unsigned long long tag = (unsigned long long)seq << 32;
+  const int64_t n = p.na + p.nb, base = (int64_t)(seq & 1u) * p.cap;
+  const int64_t T = (int64_t)gridDim.x * IGMC_BLOCK, t0 = (int64_t)blockIdx.x * IGMC_BLOCK + threadIdx.x;
+  unsigned long long* mine = p.pub[p.rank] + base;
+  for (int64_t i = t0; i < n; i += T) {
+    const float v = (i < p.na) ? p.a[i] : p.b[i - p.na];
+    const unsigned long long w = tag | (unsigned long long)__float_as_uint(v);
+#ifndef IGMC_HIPEMU
+    __hip_atomic_store(mine + i, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+    mine[i] = w;
+#endif
+  }
+  for (int64_t i = t0; i < n; i += T) {
+    float s = 0.f;
+    for (int r = 0; r < p.world; ++r) {
+      const unsigned long long* src = p.pub[r] + base + i;
+      unsigned long long w = 0;
+      for (long it = 0;; ++it) {
+#ifndef IGMC_HIPEMU
+        w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+        w = *src;
+#endif
+        if ((w >> 32) == (unsigned long long)seq) break;
+        if (it > (1L << 22)) {
+          p.state[2] = 1;
+          break;
+        }
+#ifndef IGMC_HIPEMU
+        __builtin_amdgcn_s_sleep(4);
+#endif
+      }
+      s += __uint_as_float((uint32_t)w);
+    }
+    if (i < p.na) p.a[i] = s;
+    else p.b[i - p.na] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#ifndef IGMC_HIPEMU
+    if (__hip_atomic_fetch_add(p.state + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+      __hip_atomic_store(p.state + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(p.state, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#else
+    if (p.state[1]++ == (int)gridDim.x - 1) {
+      p.state[1] = 0;
+      p.state[0] += 1;
+    }
+#endif
+  }
+}
+
+extern "C" int igmc_comm_peer_alloc(int rank, int world, int device, int64_t max_floats, igmc_comm** out, uint8_t* h_handle64) {
+  if (!out || !h_handle64 || world < 1 || world > IGMC_MAX_PEERS || rank < 0 || rank >= world || max_floats < 1) IGMC_FAIL("bad arguments");
+  igmc_comm* c = new igmc_comm();
+  c->nccl = nullptr;
+  c->rank = rank;
+  c->world = world;
+  c->device = device;
+  c->host_fn = nullptr;
+  c->host_user = nullptr;
+  c->peer = 1;
+  c->connected = 0;
+  c->cap = (max_floats + 63) & ~(int64_t)63;
+  for (int r = 0; r < IGMC_MAX_PEERS; ++r) c->pub[r] = nullptr;
+  memset(h_handle64, 0, 64);
+#ifndef IGMC_HIPEMU
+  HIPCHECK(hipSetDevice(device));
+  HIPCHECK(hipMalloc((void**)&c->pub[rank], (size_t)2 * c->cap * sizeof(unsigned long long)));
+  HIPCHECK(hipMemset(c->pub[rank], 0, (size_t)2 * c->cap * sizeof(unsigned long long)));      // tag 0 is never a launch's
+  HIPCHECK(hipMalloc((void**)&c->d_state, 4 * sizeof(int)));
+  const int init[4] = {1, 0, 0, 0};
+  HIPCHECK(hipMemcpy(c->d_state, init, sizeof(init), hipMemcpyHostToDevice));
+  hipIpcMemHandle_t h;
+  static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle larger than the 64 bytes of the C ABI");
+  HIPCHECK(hipIpcGetMemHandle(&h, c->pub[rank]));
+  memcpy(h_handle64, &h, sizeof(h));
+  HIPCHECK(hipDeviceSynchronize());
+#else
+  if (world != 1) { delete c; IGMC_FAIL("the emulation build has one rank only"); }
+  c->pub[rank] = (unsigned long long*)calloc((size_t)2 * c->cap, sizeof(unsigned long long));
+  c->d_state = (int*)calloc(4, sizeof(int));
+  c->d_state[0] = 1;
+#endif
+  *out = c;
+  return 0;
+}
+
+extern "C" int igmc_comm_peer_connect(igmc_comm* c, const uint8_t* h_handles) {
+  if (!c || !c->peer || !h_handles) IGMC_FAIL("not a peer communicator");
+#ifndef IGMC_HIPEMU
+  HIPCHECK(hipSetDevice(c->device));
+  for (int r = 0; r < c->world; ++r) {
+    if (r == c->rank) continue;
+    hipIpcMemHandle_t h;
+    memcpy(&h, h_handles + (size_t)r * 64, sizeof(h));
+    void* ptr = nullptr;
+    HIPCHECK(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+    c->pub[r] = (unsigned long long*)ptr;
+  }
+#endif
+  c->connected = 1;
+  return 0;
+}
+
+// 0 = the communicator's device-side state is sane; synchronises `stream`.  A peer communicator whose bounded poll ran out
+// (a rank that never published: not co-resident, crashed, or peer memory that is not visible) reports it here.
+extern "C" int igmc_comm_check(igmc_comm* c, void* stream) {
+  if (!c) IGMC_FAIL("null communicator");
+#ifndef IGMC_HIPEMU
+  HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+  if (c->peer && c->d_state) {
+    int st[4];
+    HIPCHECK(hipMemcpy(st, c->d_state, sizeof(st), hipMemcpyDeviceToHost));
+    if (st[2]) IGMC_FAIL("peer all-reduce: a poll for another rank's words timed out (results of that launch are invalid)");
+  }
+#endif
+  return 0;
+}
+
+// 0 none (one rank), 1 RCCL, 2 host callback, 3 peer-mapped buffers
+extern "C" int igmc_comm_kind(const igmc_comm* c) {
+  if (!c) return 0;
+  if (c->peer) return 3;
+  if (c->host_fn) return 2;
+  return c->nccl ? 1 : 0;
+}
+
+static int peer_sum2(igmc_comm* c, float* a, int64_t na, float* b, int64_t nb, void* stream) {
+  if (!c->connected) { g_err = "peer communicator is not connected (igmc_comm_peer_connect)"; return 1; }
+  if (!a) na = 0;
+  if (!b) nb = 0;
+  // spans beyond a slot go in pieces (each piece is a launch of its own: the sequence number advances per launch)
+  while (na + nb > 0) {
+    PeerArgs p;
+    memset(&p, 0, sizeof(p));
+    for (int r = 0; r < c->world; ++r) p.pub[r] = c->pub[r];
+    p.world = c->world; p.rank = c->rank; p.cap = c->cap; p.state = c->d_state;
+    const int64_t ta = na < c->cap ? na : c->cap;
+    const int64_t tb = (nb < c->cap - ta) ? nb : c->cap - ta;
+    p.a = a; p.na = ta; p.b = b; p.nb = tb;
+    int grid = (int)((ta + tb + 4 * IGMC_BLOCK - 1) / (4 * IGMC_BLOCK));      // four words a thread; few workgroups: every
+    if (grid > 64) grid = 64;                                                  // rank's launch must be on its chip at once
+    if (grid < 1) grid = 1;
+    IGMC_PLAUNCH("k_peer_allreduce", k_peer_allreduce, grid, IGMC_BLOCK, 0, stream, p);
+    a += ta; na -= ta;
+    b += tb; nb -= tb;
+  }
+#ifndef IGMC_HIPEMU
+  if (hipGetLastError() != hipSuccess) { g_err = "k_peer_allreduce launch failed"; return 1; }
+#endif
   return 0;
 }
 
@@ -1154,6 +1348,19 @@ extern "C" void igmc_comm_destroy(igmc_comm* c) {
   if (!c) return;
 #ifndef IGMC_HIPEMU
   if (c->nccl && g_rccl.ok) g_rccl.CommDestroy(c->nccl);
+  if (c->peer) {
+    for (int r = 0; r < c->world; ++r)
+      if (c->pub[r]) {
+        if (r == c->rank) hipFree(c->pub[r]);
+        else hipIpcCloseMemHandle(c->pub[r]);
+      }
+    if (c->d_state) hipFree(c->d_state);
+  }
+#else
+  if (c->peer) {
+    free(c->pub[c->rank]);
+    free(c->d_state);
+  }
 #endif
   delete c;
 }
@@ -1175,6 +1382,7 @@ extern "C" int igmc_comm_info(const igmc_comm* c, int* rank, int* world) {
 // sum of up to two spans over the ranks, in place: ONE grouped collective (RCCL), or the host callback once per span
 static int comm_sum2(void* user, float* a, int64_t na, float* b, int64_t nb, void* stream) {
   igmc_comm* c = (igmc_comm*)user;
+  if (c->peer) return peer_sum2(c, a, na, b, nb, stream);
   if (c->host_fn) {
     if (a && na > 0 && c->host_fn(c->host_user, a, na, stream)) { g_err = "comm_sum2: the host all-reduce callback failed"; return 1; }
     if (b && nb > 0 && c->host_fn(c->host_user, b, nb, stream)) { g_err = "comm_sum2: the host all-reduce callback failed"; return 1; }

@@ -71,6 +71,7 @@ class GradComm(object):
     """The library's own RCCL communicator for the flat-gradient all-reduce (``include/igmc_hip.h``, gradient exchange):
     the collective is enqueued through the C ABI on the step's stream, so it is captured into the step's hipGraph like
     any kernel.  The 128-byte RCCL id travels from rank 0 over whatever ``torch.distributed`` backend is up."""
+    transport = 'rccl'
 
     def __init__(self, lib, device):
         import ctypes as C
@@ -96,6 +97,67 @@ class GradComm(object):
 
     def info(self):
         """(rank, world size) as RCCL sees them."""
+        r, w = self.C.c_int(-1), self.C.c_int(-1)
+        self.lib.call('igmc_comm_info', self.handle, self.C.byref(r), self.C.byref(w))
+        return r.value, w.value
+
+    def all_reduce_(self, t, stream, scale=1.0):
+        self.lib.call('igmc_allreduce_grads', self.handle, self.C.c_void_p(t.data_ptr()), t.numel(), float(scale),
+                      self.C.c_void_p(stream))
+        return t
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.cdll.igmc_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PeerComm(object):
+    """A communicator whose sum is a one-shot all-reduce over PEER-MAPPED buffers (``igmc_comm_peer_alloc`` /
+    ``igmc_comm_peer_connect``): every rank publishes its span into its own device buffer, mapped by the other ranks of
+    the node through HIP IPC, and reads every rank's words in rank order -- one launch, about one xGMI round trip instead
+    of a ring's 2 (G - 1) hops, bit-identical replicas, capturable into the step's hipGraph.  The 64-byte IPC handles
+    travel over whatever ``torch.distributed`` backend is up.  The constructor finishes with a SELF-TEST exchange (rank
+    r contributes r + 1 everywhere): a node whose peer memory is not visible, or ranks that cannot be on their chips at
+    once, fail here (bounded polls) instead of inside a training step."""
+    transport = 'p2p'
+    capturable = True
+
+    def __init__(self, lib, device, max_floats=1 << 18):
+        import ctypes as C
+        self.lib, self.C = lib, C
+        r, w = rank(), world_size()
+        h = C.c_void_p()
+        handle = (C.c_uint8 * 64)()
+        lib.call('igmc_comm_peer_alloc', r, w, int(device), int(max_floats), C.byref(h), C.cast(handle, C.c_void_p))
+        self.handle = h
+        handles = [bytes(handle)]
+        if is_dist() and w > 1:
+            handles = [None] * w
+            dist.all_gather_object(handles, bytes(handle))
+        blob = (C.c_uint8 * (64 * w)).from_buffer_copy(b''.join(handles))
+        lib.call('igmc_comm_peer_connect', self.handle, C.cast(blob, C.c_void_p))
+        # self-test (also the first use of the mapped pointers): sum of r + 1 over the ranks, two launches = both slots
+        dev = torch.device('cuda', int(device))
+        st = torch.cuda.current_stream(dev).cuda_stream
+        for k in range(2):
+            t = torch.full((1000 + 37 * k,), float(r + 1), dtype=torch.float32, device=dev)
+            self.all_reduce_(t, st)
+            self.check(st)
+            want = w * (w + 1) / 2.0
+            if not bool((t == want).all().item()):
+                raise RuntimeError('peer all-reduce self-test: wrong sums (%r, expected %g)' % (t[:4].tolist(), want))
+
+    def check(self, stream):
+        self.lib.call('igmc_comm_check', self.handle, self.C.c_void_p(stream))
+
+    def info(self):
         r, w = self.C.c_int(-1), self.C.c_int(-1)
         self.lib.call('igmc_comm_info', self.handle, self.C.byref(r), self.C.byref(w))
         return r.value, w.value
@@ -186,44 +248,65 @@ def process_group_comm(lib, device):
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
     c = HostComm(lib, host_sum, rank(), world_size())
     c.capturable = backend != 'gloo'          # (the gloo route synchronises the stream: its steps cannot be captured)
+    c.transport = 'host-callback:' + str(backend)
     return c
+
+
+def _agree(ok, device):
+    """True iff `ok` holds on EVERY rank (every rank must end up on the same transport)."""
+    if not (is_dist() and world_size() > 1):
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    if dist.get_backend() == 'nccl':
+        t = t.to(torch.device('cuda', int(device)))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item()) == 1
 
 
 def grad_comm(lib, device):
     """One communicator per (process, device); needed when there is more than one rank, or with
-    ``IGMC_DP_ALLREDUCE_ALWAYS=1`` (a one-rank communicator: lets one GPU exercise the collective's enqueue / capture).
-    ``IGMC_DP_HOST_COMM=1``: the exchange goes through ``torch.distributed``'s process group instead of the library's own
-    RCCL communicator (:func:`process_group_comm`)."""
+    ``IGMC_DP_ALLREDUCE_ALWAYS=1`` (a one-rank communicator: lets one GPU exercise the exchange's enqueue / capture).
+    ``IGMC_DP_TRANSPORT`` picks the exchange: ``p2p`` (one-shot all-reduce over peer-mapped buffers, :class:`PeerComm`),
+    ``rccl`` (the library's own RCCL communicator, :class:`GradComm`), ``host`` (the process group ``torch.distributed``
+    already has, :func:`process_group_comm`; ``IGMC_DP_HOST_COMM=1`` is the older spelling).  Default ``auto``: the first of
+    p2p -> rccl -> host that EVERY rank can set up -- p2p includes a self-test exchange, RCCL refuses e.g. two ranks on one
+    device -- with a line on stderr saying why an earlier one was passed over."""
     if world_size() <= 1 and os.environ.get('IGMC_DP_ALLREDUCE_ALWAYS', '0') != '1':
         return None
     key = int(device)
-    if key not in _grad_comms:
-        if os.environ.get('IGMC_DP_HOST_COMM', '0') == '1' and is_dist():
-            _grad_comms[key] = process_group_comm(lib, device)
-        else:
-            comm, why = None, ''
-            try:
-                comm = GradComm(lib, device)
-            except RuntimeError as e:          # (RCCL missing, or it refuses this set of ranks)
-                why = str(e)
-            # every rank must end up on the same transport: agree on it over the process group that is already up
-            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32)
-            if is_dist() and world_size() > 1:
-                if dist.get_backend() == 'nccl':
-                    ok = ok.to(torch.device('cuda', key))
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 1:
-                _grad_comms[key] = comm
-            elif is_dist():
-                if comm is not None:
-                    comm.close()
-                import sys
-                print('[igmc] the library\'s RCCL communicator could not be created on every rank (%s): the gradient exchange '
-                      'goes through torch.distributed\'s process group' % (why or 'another rank failed'), file=sys.stderr)
-                _grad_comms[key] = process_group_comm(lib, device)
+    if key in _grad_comms:
+        return _grad_comms[key]
+    want = os.environ.get('IGMC_DP_TRANSPORT', 'host' if os.environ.get('IGMC_DP_HOST_COMM', '0') == '1' else 'auto')
+    if want not in ('auto', 'p2p', 'rccl', 'host'):
+        raise ValueError('IGMC_DP_TRANSPORT=%r (auto, p2p, rccl or host)' % want)
+    import sys
+    tried = []
+    order = ('p2p', 'rccl', 'host') if want == 'auto' else (want,)
+    if want == 'auto' and os.environ.get('IGMC_DP_NO_P2P', '0') == '1':
+        order = ('rccl', 'host')
+    for kind in order:
+        comm, why = None, ''
+        if kind == 'host':
+            if not is_dist():
+                why = 'no torch.distributed process group'
             else:
-                raise RuntimeError(why)
-    return _grad_comms[key]
+                comm = process_group_comm(lib, device)
+        else:
+            try:
+                comm = PeerComm(lib, device) if kind == 'p2p' else GradComm(lib, device)
+            except RuntimeError as e:          # (RCCL missing / refusing this set of ranks; IPC or the self-test failing)
+                why = str(e)
+        if _agree(comm is not None, device):
+            if tried:
+                print('[igmc] gradient exchange over %s (%s)' % (kind, '; '.join(tried)), file=sys.stderr)
+            _grad_comms[key] = comm
+            return comm
+        if comm is not None:
+            comm.close()
+        tried.append('%s could not be set up on every rank: %s' % (kind, why or 'another rank failed'))
+        if want != 'auto':
+            break
+    raise RuntimeError('no gradient exchange: ' + '; '.join(tried))
 
 
 def barrier():

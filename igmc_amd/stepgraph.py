@@ -617,6 +617,8 @@ class StepGraph(GroupPipeline):
         """Raises if a bounded device-side wait of the step kernels timed out, or if a step consumed an arena that did not
         hold the batch of its cursor (synchronises the stream)."""
         self.lib.call('igmc_model_check', self.ws.handle, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if self.comm is not None and hasattr(self.comm, 'check'):       # (peer exchange: a bounded poll that ran out)
+            self.comm.check(torch.cuda.current_stream().cuda_stream)
         err = int(self.ctrl[_lib.CTRL['SYNC_ERR']].item())
         if err:
             what = []

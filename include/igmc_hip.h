@@ -284,12 +284,24 @@ int igmc_adam_step_ctrl(float* d_params, const float* d_grad, float* d_exp_avg, 
  *                         flat gradient, all-reduce it and run the Adam kernel.  Loss terms are scaled by 1/(B * world), the
  *                         ARR term is added by every rank after the exchange.  comm == NULL: one rank (= igmc_train_step).
  *                         d_loss / d_total stay per rank (this rank's batches), as in igmc_train_step.
+ *   igmc_comm_peer_alloc / igmc_comm_peer_connect: a communicator whose sum is a ONE-SHOT all-reduce over peer-mapped
+ *                         buffers (the ranks of ONE node): every rank publishes its span into its own device buffer as
+ *                         {value, tag} words and reads every rank's words in rank order -- one launch, about one xGMI round
+ *                         trip, bit-identical replicas, capturable.  _alloc creates the rank's buffer (slots of `max_floats`)
+ *                         and returns its 64-byte IPC handle; the caller hands the handles of all ranks (world x 64 bytes,
+ *                         rank order, any transport) to _connect.  Used like any other communicator afterwards.
+ *   igmc_comm_check     : synchronises `stream`; fails if a bounded poll of the peer exchange ran out (a rank that never
+ *                         published); igmc_comm_kind: 0 one rank, 1 RCCL, 2 host callback, 3 peer-mapped buffers.
  */
 typedef struct igmc_comm igmc_comm;
 typedef int (*igmc_allreduce_fn)(void* user, float* d_buf, int64_t n, void* stream);
 int igmc_comm_unique_id(uint8_t* h_id128);
 int igmc_comm_create(const uint8_t* h_id128, int rank, int world, int device, igmc_comm** out);
 int igmc_comm_create_host(igmc_allreduce_fn fn, void* user, int rank, int world, igmc_comm** out);
+int igmc_comm_peer_alloc(int rank, int world, int device, int64_t max_floats, igmc_comm** out, uint8_t* h_handle64);
+int igmc_comm_peer_connect(igmc_comm* c, const uint8_t* h_handles);
+int igmc_comm_check(igmc_comm* c, void* stream);
+int igmc_comm_kind(const igmc_comm* c);
 void igmc_comm_destroy(igmc_comm* c);
 int igmc_comm_info(const igmc_comm* c, int* rank, int* world);
 int igmc_allreduce_grads(igmc_comm* c, float* d_flat_grad, int64_t n, float scale, void* stream);

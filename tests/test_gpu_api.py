@@ -541,7 +541,7 @@ def test_static_dataset_cache(flix, tmp_path):
     assert torch.equal(finals[0][0], finals[1][0]) and finals[0][1] == finals[1][1]
 
 
-@pytest.mark.parametrize('transport', ['host_comm', 'fallback'])
+@pytest.mark.parametrize('transport', ['p2p', 'host_comm', 'fallback'])
 def test_two_ranks_on_one_gpu(tmp_path, transport):
     """The data-parallel step (igmc_train_step_dp: the subgraph kernel's tables + lin gradients summed over the ranks between
     k_tail_ts and k_finalize_ts) with TWO ranks on real kernels.  RCCL refuses two ranks on one device, so the exchange
@@ -553,8 +553,11 @@ def test_two_ranks_on_one_gpu(tmp_path, transport):
         step's bit for bit.
     (b) Links sharded perm[k::2] (three full batches and a ragged one per rank): replicas bit-identical, losses finite,
         two spans exchanged per step.
-    `fallback`: without the switch the library tries its own RCCL communicator first, RCCL refuses ("Duplicate GPU"), the
-    ranks agree on that over the process group and all of them fall back to it (parallel.grad_comm)."""
+    `p2p`: the exchange is the library's one-shot all-reduce over peer-mapped buffers (igmc_comm_peer_*: HIP IPC handles work
+    between two processes on ONE device), steps captured into the group graphs -- the product's multi-GPU transport on real
+    kernels; the same two checks, plus the transport's name.
+    `fallback`: p2p ruled out, the library tries its own RCCL communicator, RCCL refuses ("Duplicate GPU"), the ranks agree
+    on that over the process group and all of them fall back to it (parallel.grad_comm)."""
     import os
     import subprocess
     import sys
@@ -589,6 +592,7 @@ half = perm[:150]                    # three full batches (the ragged batch of a
 model, opt = fresh()
 sg = StepGraph(model, opt, tr, 50, 0.001, use_graph=False, overlap=False, group=2)
 assert sg.dp_path and sg.world == 2 and sg.comm is not None and sg.comm.info() == (rank, 2)
+assert sg.comm.transport.startswith(os.environ['DP2_EXPECT']), sg.comm.transport
 tot_dp, _ = sg.run_epoch(half, 1)
 dp = state(model, opt) + [float(tot_dp.item())]
 model1, opt1 = fresh()
@@ -612,22 +616,49 @@ dist.all_gather(both, P)
 assert torch.equal(both[0], both[1]), 'replicas differ'
 assert np.isfinite(float(total.item())) and float(total.item()) > 0 and opt.t == 4
 assert not torch.equal(P, dp[0])
+if sg.comm.transport == 'p2p':
+    # ---- (c) the same sharded epoch with the steps CAPTURED (pairs of one-step groups replayed from the hipGraph, the peer
+    #      exchange inside them: its launch sequence number lives on the device) == the eager launches, bit for bit
+    model, opt = fresh()
+    sgc = StepGraph(model, opt, tr, 50, 0.001, group=1)
+    assert sgc.use_graph and sgc.comm is sg.comm
+    sgc.run_epoch(mine, 1)
+    assert sgc.graph is not None, 'the steps were not captured'
+    Pc = state(model, opt)[0]
+    assert torch.equal(Pc, P), ('captured vs eager', float((Pc - P).abs().max()))
+    # ... and the exchange alone, timed on the step's stream (two ranks on one device: an upper bound)
+    t = torch.zeros(61000, device='cuda')
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(5):
+        sg.comm.all_reduce_(t, st)
+    torch.cuda.synchronize()
+    dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        sg.comm.all_reduce_(t, st)
+    e1.record()
+    sg.comm.check(st)
+    print('rank', rank, 'p2p all-reduce of 61000 floats: %%.1f us' %% (e0.elapsed_time(e1) / 50 * 1e3))
 print('rank', rank, 'dp2 ok')
 dist.destroy_process_group()
 ''' % ROOT)
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', HSA_ENABLE_IPC_MODE_LEGACY='0', DP2_PORT='29643' if transport == 'host_comm' else '29644')
-        if transport == 'host_comm':
-            env['IGMC_DP_HOST_COMM'] = '1'
-        else:
-            env.pop('IGMC_DP_HOST_COMM', None)
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', HSA_ENABLE_IPC_MODE_LEGACY='0',
+                   DP2_PORT={'host_comm': '29643', 'fallback': '29644', 'p2p': '29645'}[transport],
+                   DP2_EXPECT={'host_comm': 'host-callback:gloo', 'fallback': 'host-callback:gloo', 'p2p': 'p2p'}[transport])
+        env.pop('IGMC_DP_HOST_COMM', None)
+        env['IGMC_DP_TRANSPORT'] = {'host_comm': 'host', 'p2p': 'p2p'}.get(transport, 'auto')
+        if transport == 'fallback':
+            env['IGMC_DP_NO_P2P'] = '1'          # (auto would take p2p: rule it out to walk rccl -> host)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o[-3000:]
         assert 'rank %d dp2 ok' % r in o
-        assert ('could not be created on every rank' in o) == (transport == 'fallback'), o[-2000:]
+        print(o[-300:])
+        assert ('rccl could not be set up on every rank' in o) == (transport == 'fallback'), o[-2000:]
 
 
 def test_captured_all_reduce_next_to_a_torch_distributed_process_group(tmp_path):
