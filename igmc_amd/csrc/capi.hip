@@ -1052,6 +1052,7 @@ struct igmc_comm {
   int* d_state;                                 // device: [0] launch sequence number, [1] workgroups done, [2] poll timed out
   int peer;                                     // 1 = peer communicator
   int connected;
+  int fine;                                     // the local buffer is fine-grained device memory
 };
 #ifndef IGMC_HIPEMU
 #include <dlfcn.h>
@@ -1258,14 +1259,28 @@ extern "C" int igmc_comm_peer_alloc(int rank, int world, int device, int64_t max
   memset(h_handle64, 0, 64);
 #ifndef IGMC_HIPEMU
   HIPCHECK(hipSetDevice(device));
-  HIPCHECK(hipMalloc((void**)&c->pub[rank], (size_t)2 * c->cap * sizeof(unsigned long long)));
-  HIPCHECK(hipMemset(c->pub[rank], 0, (size_t)2 * c->cap * sizeof(unsigned long long)));      // tag 0 is never a launch's
+  // FINE-GRAINED device memory where the runtime can share it (coherent between devices while kernels run: what RCCL's
+  // own buffers are); else ordinary device memory -- the words are written and read with system-scope accesses either way
+  const size_t bytes = (size_t)2 * c->cap * sizeof(unsigned long long);
+  hipIpcMemHandle_t h;
+  static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle larger than the 64 bytes of the C ABI");
+  bool fine = hipExtMallocWithFlags((void**)&c->pub[rank], bytes, hipDeviceMallocFinegrained) == hipSuccess;
+  if (fine && hipIpcGetMemHandle(&h, c->pub[rank]) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(c->pub[rank]);
+    c->pub[rank] = nullptr;
+    fine = false;
+  }
+  if (!fine) {
+    (void)hipGetLastError();
+    HIPCHECK(hipMalloc((void**)&c->pub[rank], bytes));
+    HIPCHECK(hipIpcGetMemHandle(&h, c->pub[rank]));
+  }
+  c->fine = fine ? 1 : 0;
+  HIPCHECK(hipMemset(c->pub[rank], 0, bytes));      // tag 0 is never a launch's
   HIPCHECK(hipMalloc((void**)&c->d_state, 4 * sizeof(int)));
   const int init[4] = {1, 0, 0, 0};
   HIPCHECK(hipMemcpy(c->d_state, init, sizeof(init), hipMemcpyHostToDevice));
-  hipIpcMemHandle_t h;
-  static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle larger than the 64 bytes of the C ABI");
-  HIPCHECK(hipIpcGetMemHandle(&h, c->pub[rank]));
   memcpy(h_handle64, &h, sizeof(h));
   HIPCHECK(hipDeviceSynchronize());
 #else
@@ -1310,10 +1325,10 @@ extern "C" int igmc_comm_check(igmc_comm* c, void* stream) {
   return 0;
 }
 
-// 0 none (one rank), 1 RCCL, 2 host callback, 3 peer-mapped buffers
+// 0 none (one rank), 1 RCCL, 2 host callback, 3 peer-mapped buffers (4: in fine-grained device memory)
 extern "C" int igmc_comm_kind(const igmc_comm* c) {
   if (!c) return 0;
-  if (c->peer) return 3;
+  if (c->peer) return c->fine ? 4 : 3;
   if (c->host_fn) return 2;
   return c->nccl ? 1 : 0;
 }

@@ -143,6 +143,7 @@ class PeerComm(object):
             dist.all_gather_object(handles, bytes(handle))
         blob = (C.c_uint8 * (64 * w)).from_buffer_copy(b''.join(handles))
         lib.call('igmc_comm_peer_connect', self.handle, C.cast(blob, C.c_void_p))
+        self.fine_grained = lib.cdll.igmc_comm_kind(self.handle) == 4
         # self-test (also the first use of the mapped pointers): sum of r + 1 over the ranks, two launches = both slots
         dev = torch.device('cuda', int(device))
         st = torch.cuda.current_stream(dev).cuda_stream

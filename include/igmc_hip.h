@@ -291,7 +291,7 @@ int igmc_adam_step_ctrl(float* d_params, const float* d_grad, float* d_exp_avg, 
  *                         and returns its 64-byte IPC handle; the caller hands the handles of all ranks (world x 64 bytes,
  *                         rank order, any transport) to _connect.  Used like any other communicator afterwards.
  *   igmc_comm_check     : synchronises `stream`; fails if a bounded poll of the peer exchange ran out (a rank that never
- *                         published); igmc_comm_kind: 0 one rank, 1 RCCL, 2 host callback, 3 peer-mapped buffers.
+ *                         published); igmc_comm_kind: 0 one rank, 1 RCCL, 2 host callback, 3 peer-mapped buffers (4: in fine-grained memory).
  */
 typedef struct igmc_comm igmc_comm;
 typedef int (*igmc_allreduce_fn)(void* user, float* d_buf, int64_t n, void* stream);

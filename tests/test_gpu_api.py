@@ -639,7 +639,7 @@ if sg.comm.transport == 'p2p':
         sg.comm.all_reduce_(t, st)
     e1.record()
     sg.comm.check(st)
-    print('rank', rank, 'p2p all-reduce of 61000 floats: %%.1f us' %% (e0.elapsed_time(e1) / 50 * 1e3))
+    print('rank', rank, 'p2p all-reduce of 61000 floats: %%.1f us' %% (e0.elapsed_time(e1) / 50 * 1e3), 'fine-grained buffers:', sg.comm.fine_grained)
 print('rank', rank, 'dp2 ok')
 dist.destroy_process_group()
 ''' % ROOT)
