@@ -272,6 +272,7 @@ def main():
     ap.add_argument('--dp-steps', type=int, default=96,
                     help='steps per launch structure of the dp_structure leg (N=1 only; 0 = skip)')
     ap.add_argument('--dgcnn-rs', action='store_true', help='the sort-pool readout family (reference models.py:123-167) instead of IGMC')
+    ap.add_argument('--group', type=int, default=0, help='steps per group M (a graph launch = 2 M steps); 0 = the largest M with 2 M | steps')
     ap.add_argument('--no-graph', action='store_true', help='launch every kernel eagerly (no hipGraph replay)')
     ap.add_argument('--no-overlap', action='store_true', help='extract batch t+1 on the same stream (no overlap)')
     ap.add_argument('--no-secondary', action='store_true',
@@ -364,12 +365,12 @@ def main():
     if sg.use_graph and args.warmup >= 1:
         run(1)
         new_epoch_if_needed()
-        captured = sg.prepare(steps_hint=args.steps)
+        captured = sg.prepare(steps_hint=args.steps, group=args.group or None)
         run(args.warmup - 1)
     else:
         run(args.warmup)
     new_epoch_if_needed()
-    captured = sg.prepare(steps_hint=args.steps) or captured      # aligned with the current position; graph exists before t0
+    captured = sg.prepare(steps_hint=args.steps, group=args.group or None) or captured      # aligned with the current position; graph exists before t0
     parallel.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

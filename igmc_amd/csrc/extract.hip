@@ -974,8 +974,7 @@ void igmc_launch_extract(const GraphDev& g, const BatchDev& b, const int32_t* li
   // S workgroups per link for the row passes: fill the chip even at batch 50
   int S = 2048 / (B > 0 ? B : 1);
   S = S < 1 ? 1 : (S > 16 ? 16 : S);
-  const char* se = getenv("IGMC_EXTRACT_SPLIT");       // debug switch: 0 = one workgroup per link also at hop 1
-  a.split = (b.hop == 1 && !replay && !(se && atoi(se) == 0)) ? 1 : 0;
+  a.split = (b.hop == 1 && !replay) ? 1 : 0;
   IGMC_PLAUNCH("k_extract_nodes", k_extract_nodes, dim3(B, a.split ? 2 : 1), IGMC_BLOCK, smem, stream, a);
   if (b.relm) {      // capped extraction (igmc_batch_create decides)
     const size_t Wu = (g.n_users + 31) >> 5, Wv = (g.n_items + 31) >> 5;
@@ -1003,8 +1002,7 @@ void igmc_launch_extract_set(const GraphDev& g, const BatchDev* d_set, const Bat
   a.first = sel0; a.B = B; a.replay = 0;
   a.sample_ratio = sample_ratio; a.seed = seed; a.epoch = 0;
   const size_t smem = igmc_extract_smem_bytes(g);
-  const char* se = getenv("IGMC_EXTRACT_SPLIT");
-  a.split = (b0.hop == 1 && !(se && atoi(se) == 0)) ? 1 : 0;
+  a.split = (b0.hop == 1) ? 1 : 0;
   IGMC_PLAUNCH("k_extract_nodes", k_extract_nodes_set, dim3(B, a.split ? 2 : 1, count), IGMC_BLOCK, smem, stream, a, d_set);
   const size_t Wv = (g.n_items + 31) >> 5;
   int Sr = 400 / (B > 0 ? B : 1);

@@ -1317,7 +1317,7 @@ int igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* P
   a.timing = getenv("IGMC_GS_TIMING") ? 1 : 0;
   a.ts = (g_igmc_prof_on == 2) ? m.gs_ts : nullptr;
   // (the device-side launch clock rides in the last workgroup's counter; evaluation launches have no following kernel)
-  a.self_seq = (!training || a.ts || getenv("IGMC_G2_SELF_SEQ")) ? 1 : 0;
+  a.self_seq = (!training || a.ts) ? 1 : 0;
   a.cs = cs;
   a.stride = (cs > 1) ? ((B + 7) & ~7) : 1;
   const int grid = (cs > 1) ? cs * B : igmc_gs_grid(B);

@@ -2162,12 +2162,10 @@ static inline int igmc_xcd_grid(const ModelDev& m, int B, int rows_per_block, in
 
 // grid of k_l0_fwd: every workgroup composes the layer-0 table W0[r * L + c] (R L x 32 values, 4 fmas + 5 loads each) before
 // it walks rows; with many relations (yahoo_music: 284 table rows) thousands of 4-row workgroups spend their time on that
-// -- there a workgroup takes 8 rows per table row of work it has to amortise (IGMC_L0_ROWS overrides)
+// -- there a workgroup takes 8 rows per table row of work it has to amortise
 static inline int igmc_l0_grid(const ModelDev& m, int B) {
   int rows = 4;
   if (m.R * m.L > 32) rows = (m.R * m.L) / 8;
-  const char* e = getenv("IGMC_L0_ROWS");
-  if (e && atoi(e) >= 4) rows = atoi(e);
   return igmc_xcd_grid(m, B, rows, IGMC_GATHER_BLOCKS);
 }
 
@@ -2332,9 +2330,8 @@ int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchD
   m.adam_m2 = adam ? adam->m2 : nullptr;
   if (img_emitted) *img_emitted = 0;
   const int rows0 = m.R * m.L + m.L + 1;
-  // the gradient / Adam kernel also leaves the weight images of the updated parameters (IGMC_EMIT_IMAGES=0: never)
-  const char* ee = getenv("IGMC_EMIT_IMAGES");
-  const int img = adam && !(ee && atoi(ee) == 0) && m.g2_w && m.R <= G2_NR && rows0 <= 32;
+  // the gradient / Adam kernel also leaves the weight images of the updated parameters
+  const int img = adam && m.g2_w && m.R <= G2_NR && rows0 <= 32;
   const int l0_mfma = rows0 <= 32;
   const int gy = igmc_rows_grid(m.node_cap, 128, 512);
   const int hb = (B + 15) / 16;
@@ -2399,7 +2396,7 @@ int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchD
   // ... and all four of them as ONE launch where the members of a subgraph can hand h_l to each other (k_dl_fwd); the launch
   // sequence number of its exchange tags is advanced by k_tail_ts (tables path) -- else by the launch's last workgroup
   const int fts_pre = igmc_fin_mode() && m.fin_stash && m.datt_part && m.R <= 8;
-  const int dlts = dl && l0_mfma && fts_pre && !getenv("IGMC_DL_NOBWD") && igmc_dl_ts_eligible(m, b, B);
+  const int dlts = dl && l0_mfma && fts_pre && igmc_dl_ts_eligible(m, b, B);
   const int dlf = dl && igmc_dl_fwd_eligible(m, b, B);
   if (dlf) {
     igmc_launch_g2_compose(m, (const float*)P, stream);
@@ -2411,7 +2408,7 @@ int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchD
   else IGMC_PLAUNCH("k_l0_fwd", (k_l0_fwd<false, true>), igmc_l0_grid(m, B), IGMC_BLOCK, l0s, stream, b, m, (const float*)P, m.h[0]);
   const size_t fsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4) * sizeof(float);
   const size_t bsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4 + 16 * m.R * 4) * sizeof(float);
-  const int gl = (dl && !getenv("IGMC_DL_NOBWD")) ? igmc_dl_grid(b, B) : gt;      // grid of the layer kernels
+  const int gl = dl ? igmc_dl_grid(b, B) : gt;      // grid of the layer kernels
   for (int l = 1; l < 4 && !dlf; ++l) {
     float* zo = (l == 3) ? m.dpre[3] : nullptr;
     if (dl) {
@@ -2426,12 +2423,9 @@ int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchD
   // -- k_tail_ts sums the workgroups' tables and forms d lin1 / d lin2, k_finalize_ts turns them into gradients (+ Adam) --
   // replaces the Y products, G, the weight-gradient products and their reduction
   if (dlts) {
-    if (!getenv("IGMC_HEAD_TRAIN"))                           // one workgroup per subgraph (side features included)
-      igmc_launch_head_sub(m, b, (const float*)P, B, inj_mask, seed, step, mult, grad_scale, out, stream);
-    else                                                      // (head role only: 16 subgraphs per workgroup)
-      IGMC_PLAUNCH("k_head_train", k_head_train, dim3(hb, 1), 512, ysz, stream, b, m, (const float*)P, inj_mask, seed, step,
-                   mult, grad_scale, out);
-    if (dlf && !getenv("IGMC_HEAD_TRAIN") && igmc_dl_bwd_eligible(m, b, B))
+    // the head: one workgroup per subgraph (side features included)
+    igmc_launch_head_sub(m, b, (const float*)P, B, inj_mask, seed, step, mult, grad_scale, out, stream);
+    if (dlf && igmc_dl_bwd_eligible(m, b, B))
       igmc_launch_dl_bwd(m, b, B, use_flags, stream);         // the three backward layers as ONE launch
     else
       for (int l = 3; l >= 1; --l) igmc_launch_dl_layer(m, b, (const float*)P, B, l, 1, use_flags, nullptr, stream, 1);
@@ -2458,7 +2452,7 @@ int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchD
   }
   IGMC_PLAUNCH("k_head_train", k_head_train, dim3(hb > gy ? hb : gy, 4), 512, ysz, stream, b, m, (const float*)P, inj_mask,
                seed, step, mult, grad_scale, out);
-  const int dlb = dl && !getenv("IGMC_DL_NOBWD");      // (debug: dense forward + row-walker backward)
+  const int dlb = dl;
   for (int l = 3; l >= 1; --l) {
     if (dlb) {
       igmc_launch_dl_layer(m, b, (const float*)P, B, l, 1, use_flags, nullptr, stream);

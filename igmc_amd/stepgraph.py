@@ -442,7 +442,7 @@ class StepGraph(GroupPipeline):
         self.opt.t += n
 
     def _hint_unchanged(self):
-        if self.sp is None and os.environ.get('IGMC_EMIT_IMAGES', '1') != '0':
+        if self.sp is None:
             self.lib.call('igmc_model_weights_unchanged', self.ws.handle, 1)
 
     # ------------------------------------------------------------------ one step

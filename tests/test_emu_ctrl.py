@@ -268,8 +268,7 @@ def test_weight_images_left_by_the_step_equal_the_composed_ones(monkeypatch, pat
         if cl:
             monkeypatch.setenv('IGMC_GS_CLUSTER', cl)
 
-    def run(hint, emit):
-        monkeypatch.setenv('IGMC_EMIT_IMAGES', '1' if emit else '0')
+    def run(hint):
         engine.profile_fetch(lib)
         engine.profile_enable(lib, True)
         lib.call('igmc_model_set_ctrl', ws.handle, None)
@@ -297,22 +296,19 @@ def test_weight_images_left_by_the_step_equal_the_composed_ones(monkeypatch, pat
         composes = sum(c for n, _, c in engine.profile_fetch(lib) if n == 'k_g2_compose')
         return rec, ev, composes
 
-    ref, ref_ev, n_ref = run(False, False)
+    ref, ref_ev, n_ref = run(False)
     uses = {'1': 7, '1:4': 7, '0': 0, '0then1': 2, '1then0': 5}[paths]      # calls of the seven that read the images
     ev_uses = paths in ('1', '1:4', '1then0')                                # ... the two evaluation forwards among them
-    assert n_ref == uses
-    for what, (rec, ev, n) in (('emit, composed anyway', run(False, True)), ('emit + skip', run(True, True)),
-                               ('assertion without emission', run(True, False))):
-        # with both the emission and the caller's assertion only the very first call composes (not even that one when a step
-        # on the per-layer kernels came first: its tail left the images); without the emission an asserted call still
-        # composes after a step (the parameters moved), but not after a forward
-        assert n == {'emit, composed anyway': uses, 'emit + skip': 1 if ev_uses else 0,
-                     'assertion without emission': uses - (1 if ev_uses else 0)}[what], (what, n)
-        for i, (a, b) in enumerate(zip(ref, rec)):
-            for x, y in zip(a, b):
-                assert np.array_equal(x, y), (what, 'step', i)
-        for a, b in zip(ref_ev, ev):
-            assert np.array_equal(a, b), (what, 'eval')
+    assert n_ref == uses              # (the step's tail leaves the images; without the caller's assertion every call composes anyway)
+    rec, ev, n = run(True)
+    # with the caller's assertion only the very first call composes (not even that one when a step on the per-layer kernels
+    # came first: its tail left the images)
+    assert n == (1 if ev_uses else 0), n
+    for i, (a, b) in enumerate(zip(ref, rec)):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), ('step', i)
+    for a, b in zip(ref_ev, ev):
+        assert np.array_equal(a, b), 'eval'
     assert np.array_equal(ref_ev[0], ref_ev[1])
 
 
