@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'igmc_amd', 'csrc')
 SOURCES = ['extract.hip', 'model.hip', 'graphstep2.hip', 'sortpool.hip', 'capi.hip']
-HEADERS = ['common.h', 'model.h', 'launch.h', 'sortpool.h', 'g2_image.h', '../../include/igmc_hip.h', '../../include/igmc_rng.h']
+HEADERS = ['common.h', 'model.h', 'launch.h', 'sortpool.h', 'g2_image.h', 'g2_prims.h', 'head_sub.h', '../../include/igmc_hip.h', '../../include/igmc_rng.h']
 HIP_LIB = os.path.join(ROOT, 'igmc_amd', 'lib', 'libigmc_hip.so')
 EMU_LIB = os.path.join(ROOT, 'tests', 'emu', 'libigmc_emu.so')
 

@@ -1,0 +1,342 @@
+// g2_prims.h -- the gfx950 primitives of graphstep2.hip: matrix-core step, byte-compare expansion, fast tanh, tagged
+// exchange words (sc1 stores / compiler-tracked sc1 buffer loads, polled), launch-sequence and clock helpers -- each with
+// its stand-in for the CPU emulation build (tools/hipemu, IGMC_HIPEMU: test infrastructure for the kernel LOGIC; what the
+// stand-ins replace is verified by the GPU suite only).  The kernels in graphstep2.hip are written against these names and
+// carry no build switch themselves.  (internal; included once, by graphstep2.hip, after g_g2_clk / g_g2_wg)
+#pragma once
+
+#ifdef IGMC_HIPEMU
+#define G2_STAMP(k) do { } while (0)
+#else
+#define G2_STAMP(k)                                                                                        \
+  do {                                                                                                     \
+    if (a.timing && threadIdx.x == 0) {                                                                    \
+      if (blockIdx.x == 0) g_g2_clk[k] = __builtin_readcyclecounter();                                     \
+      else if (a.cs > 2 && (int)blockIdx.x == 2 && (k) < 40) g_g2_clk[64 + (k)] = __builtin_readcyclecounter(); \
+    }                                                                                                      \
+  } while (0)
+#endif
+
+// keeps per-lane index arithmetic INSIDE the phase it is used in (LLVM otherwise hoists hundreds of loop-invariant LDS
+// addresses out of the layer loops and spills them)
+#ifdef IGMC_HIPEMU
+#define G2_OPAQUE(x) do { } while (0)
+#else
+#define G2_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifndef IGMC_HIPEMU
+typedef __bf16 g2_bf16x8 __attribute__((ext_vector_type(8)));
+#endif
+
+__device__ __forceinline__ f32x4 g2_mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+#ifdef IGMC_HIPEMU
+  return igmc_emu_mfma_16x16x32_bf16(a, b, c);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(g2_bf16x8, a), __builtin_bit_cast(g2_bf16x8, b), c, 0, 0, 0);
+#endif
+}
+
+// four relm bytes (bits 0..2: relation + 1, bit 3 / 4: keep flags of the two directions) -> two dwords of bf16 pairs
+// that are 1.0 where the byte's relation is r1 - 1 (and its keep bit is set)
+template <bool FLAGS>
+__device__ __forceinline__ void g2_expand4(uint32_t w, uint32_t r1, int keepbit, uint32_t& o01, uint32_t& o23) {
+  uint32_t mk = w & 0x07070707u;
+  if (FLAGS) mk &= ((w >> keepbit) & 0x01010101u) * 7u;
+  const uint32_t t = mk ^ (0x01010101u * r1);
+  const uint32_t eq = ~(t + 0x7F7F7F7Fu) & 0x80808080u;        // bit 7 of a byte set <=> the byte of t is zero (t <= 7)
+  const uint32_t mask = (eq >> 7) * 0xFFu;                      // 0xFF per matching byte
+#ifdef IGMC_HIPEMU
+  o01 = ((mask & 0xFFu) ? 0x3F80u : 0u) | ((mask & 0xFF00u) ? 0x3F800000u : 0u);
+  o23 = ((mask & 0xFF0000u) ? 0x3F80u : 0u) | ((mask & 0xFF000000u) ? 0x3F800000u : 0u);
+#else
+  o01 = __builtin_amdgcn_perm(mask, mask, 0x01010000u) & 0x3F803F80u;    // bytes [b0 b0 b1 b1]
+  o23 = __builtin_amdgcn_perm(mask, mask, 0x03030202u) & 0x3F803F80u;    // bytes [b2 b2 b3 b3]
+#endif
+}
+
+__device__ __forceinline__ float g2_tanh(float x) {
+#ifdef IGMC_HIPEMU
+  return tanhf(x);
+#else
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x));
+#endif
+}
+
+// ---- exchange words ------------------------------------------------------------------------------------------------
+// plane word of one value: {hi | mid << 16, lo | tag << 16}; two nodes of one feature per 16-byte access
+__device__ __forceinline__ void g2_store16(unsigned long long* p, uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+#ifndef IGMC_HIPEMU
+  u32x4 v = {x, y, z, w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+#else
+  p[0] = ((unsigned long long)y << 32) | x;
+  p[1] = ((unsigned long long)w << 32) | z;
+#endif
+}
+__device__ __forceinline__ void g2_pub_f32(unsigned long long* p, float v, uint32_t tag) {
+#ifndef IGMC_HIPEMU
+  __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+#else
+  uint32_t bits;
+  memcpy(&bits, &v, 4);
+  *p = ((unsigned long long)tag << 32) | (unsigned long long)bits;
+#endif
+}
+
+// The planes [term][feature][node] of one side from its exchange region ex[feature][KMAX nodes]: nodes < npad (a
+// multiple of 16, <= 128) of all 32 features = 16 * npad word pairs, <= 8 per thread.  Two halves, so that the round
+// trip can run under other work: g2_poll_issue requests every pair of the thread (16-byte sc1 buffer loads the compiler
+// tracks -- no inline asm, nothing to mis-schedule), g2_poll_finish consumes them; pairs whose tags are not this
+// exchange's are requested again until they are.
+struct G2Poll {
+  u32x4 v[8];
+};
+#ifndef IGMC_HIPEMU
+__device__ __forceinline__ u32x4 g2_ld16_sc1(const unsigned long long* base, int byte_off) {
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+  return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);       // aux 16 = sc1: served by L2, bypasses this CU's L1
+}
+#endif
+__device__ __forceinline__ void g2_poll_issue(G2Poll& pq, const unsigned long long* ex, int npad) {
+#ifndef IGMC_HIPEMU
+  // pair p = thread + 256 u  ->  feature p >> 6, node pair p & 63 (pairs past npad are never consumed)
+  const int t0 = (int)threadIdx.x;
+  (void)npad;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) pq.v[u] = g2_ld16_sc1(ex, (t0 + u * G2_THREADS) * 16);
+#else
+  (void)pq; (void)ex; (void)npad;
+#endif
+}
+__device__ __forceinline__ void g2_poll_finish(G2Poll& pq, uint32_t* pl, int kp, const unsigned long long* ex, int npad,
+                                               uint32_t tag16, int* err) {
+  const int hp = npad >> 1, total = 32 * hp, t0 = (int)threadIdx.x;      // pairs per feature, pairs in all
+  const int tstride = 32 * kp >> 1;                                       // dwords per term
+#ifndef IGMC_HIPEMU
+  (void)total;
+  const int q0 = t0 & 63;                                                 // this thread's node pair (of 64 per feature)
+  uint32_t pend = (q0 < hp) ? 0xFFu : 0u;
+  const int d0 = ((t0 >> 6) * kp >> 1) + q0;                              // feature (t0 >> 6) + 4 u
+  for (int it = 0;; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const u32x4 V = pq.v[u];
+      if ((pend & (1u << u)) && (V.y >> 16) == tag16 && (V.w >> 16) == tag16) {
+        const int d = d0 + u * (4 * kp >> 1);                              // dword index inside a term's plane
+        pl[d] = (V.x & 0xFFFFu) | (V.z << 16);
+        pl[tstride + d] = (V.x >> 16) | (V.z & 0xFFFF0000u);
+        pl[2 * tstride + d] = (V.y & 0xFFFFu) | (V.w << 16);
+        pend &= ~(1u << u);
+      }
+    }
+    if (!pend) break;
+    if (it > (1 << 20)) {
+      *err = 1;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (pend & (1u << u)) pq.v[u] = g2_ld16_sc1(ex, (t0 + u * G2_THREADS) * 16);
+  }
+#else
+  (void)pq;
+  for (int p = t0; p < total; p += G2_THREADS) {
+    const int f = p / hp, q = p - f * hp;
+    const unsigned long long* e = ex + f * 128 + 2 * q;
+    long spins = 0;
+    for (;;) {
+      const unsigned long long a = e[0], b2 = e[1];
+      if ((uint32_t)(a >> 48) == tag16 && (uint32_t)(b2 >> 48) == tag16) {
+        const uint32_t ax = (uint32_t)a, ay = (uint32_t)(a >> 32), bx = (uint32_t)b2, by = (uint32_t)(b2 >> 32);
+        const int d = (f * kp >> 1) + q;
+        pl[d] = (ax & 0xFFFFu) | (bx << 16);
+        pl[tstride + d] = (ax >> 16) | (bx & 0xFFFF0000u);
+        pl[2 * tstride + d] = (ay & 0xFFFFu) | (by << 16);
+        break;
+      }
+      if (++spins > (1L << 22)) {
+        *err = 1;
+        break;
+      }
+      hipemu::yield();
+    }
+  }
+#endif
+}
+__device__ __forceinline__ void g2_reload(uint32_t* pl, int kp, const unsigned long long* ex, int npad, uint32_t tag16,
+                                          int* err) {
+  G2Poll pq;
+  g2_poll_issue(pq, ex, npad);
+  g2_poll_finish(pq, pl, kp, ex, npad, tag16, err);
+}
+
+// one 8-byte {f32, tag} word, polled
+__device__ __forceinline__ float g2_poll_f32(const unsigned long long* p, uint32_t tag, int* err) {
+  for (long it = 0;; ++it) {
+#ifndef IGMC_HIPEMU
+    const unsigned long long w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    const unsigned long long w = *p;
+#endif
+    if ((uint32_t)(w >> 32) == tag) return __uint_as_float((uint32_t)w);
+    if (it > (1L << 22)) {
+      *err = 1;
+      return 0.f;
+    }
+#ifndef IGMC_HIPEMU
+    __builtin_amdgcn_s_sleep(2);
+#else
+    hipemu::yield();
+#endif
+  }
+}
+
+#ifdef IGMC_HIPEMU
+#define G2_SCHED_BARRIER() do { } while (0)
+#else
+#define G2_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+// ---- launch sequence number of the exchange tags, scheduling / wait points, clocks ---------------------------------------
+__device__ __forceinline__ uint32_t g2_ld_seq(const int* gs_bar) {
+#ifndef IGMC_HIPEMU
+  return (uint32_t)__hip_atomic_load(gs_bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  return (uint32_t)gs_bar[1];
+#endif
+}
+// one arrival per workgroup; true in the LAST one, which has reset the counter and advanced the sequence number
+__device__ __forceinline__ bool g2_last_workgroup_advances(int* gs_bar) {
+#ifndef IGMC_HIPEMU
+  if (__hip_atomic_fetch_add(gs_bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (int)gridDim.x - 1) return false;
+  __hip_atomic_store(gs_bar, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(gs_bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+#else
+  if (gs_bar[0]++ != (int)gridDim.x - 1) return false;
+  gs_bar[0] = 0;
+  gs_bar[1] += 1;
+  return true;
+#endif
+}
+__device__ __forceinline__ void g2_wait_vm0() {
+#ifndef IGMC_HIPEMU
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+__device__ __forceinline__ unsigned long long g2_wall_clock() {
+#ifndef IGMC_HIPEMU
+  return (unsigned long long)wall_clock64();
+#else
+  return 0ull;
+#endif
+}
+__device__ __forceinline__ unsigned long long g2_xcc_id() {
+#ifndef IGMC_HIPEMU
+  return (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID
+#else
+  return 0ull;
+#endif
+}
+// device-side launch clock (igmc_profile_enable(2)): ts[0] = earliest workgroup start of the running launch, closed by the
+// launch's last workgroup into ts[1] (sum of durations) / ts[2] (launches)
+__device__ __forceinline__ void g2_clock_open(unsigned long long* ts) {
+#ifndef IGMC_HIPEMU
+  atomicMin(ts, (unsigned long long)wall_clock64());
+#else
+  (void)ts;
+#endif
+}
+__device__ __forceinline__ void g2_clock_close(unsigned long long* ts, unsigned long long t1) {
+#ifndef IGMC_HIPEMU
+  const unsigned long long t0 = __hip_atomic_load(ts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  atomicAdd(ts + 1, t1 - t0);
+  atomicAdd(ts + 2, 1ull);
+  __hip_atomic_store(ts, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  (void)ts; (void)t1;
+#endif
+}
+
+// one multiply-add that stays ONE v_fmac_f32 (the compiler's packed-f32 chains gave run-to-run different sums on gfx950:
+// see the note at its use in graphstep2.hip)
+#ifdef IGMC_HIPEMU
+#define DL_FMAC(acc_, a_, b_) ((acc_) += (a_) * (b_))
+#else
+#define DL_FMAC(acc_, a_, b_) asm("v_fmac_f32 %0, %1, %2" : "+v"(acc_) : "v"(a_), "v"(b_))
+#endif
+
+// ---- exchange of the dense-layer kernels (k_dl_fwd / k_dl_bwd): regions of DLX_K nodes a side, 512-thread workgroups -----
+#define DLX_K 256
+#define DL_THREADS_PRIM 512
+// planes [term][feature][node] of one side from its exchange region ex[feature][DLX_K]: nodes < npad (a multiple of 16) of
+// all 32 features, 8 word pairs per thread of a 512-thread workgroup, polled until their tags are this exchange's
+__device__ __forceinline__ void dlx_reload(uint32_t* pl, int kp, const unsigned long long* ex, int npad, uint32_t tag16,
+                                           int* err) {
+  const int hp = npad >> 1, t0 = (int)threadIdx.x;
+  const int tstride = 32 * kp >> 1;
+#ifndef IGMC_HIPEMU
+  // pair p = thread + 512 u -> feature p >> 7, node pair p & 127
+  const int q0 = t0 & 127;
+  uint32_t pend = (q0 < hp) ? 0xFFu : 0u;
+  const int d0 = ((t0 >> 7) * kp >> 1) + q0;                               // feature (t0 >> 7) + 4 u
+  u32x4 v[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) v[u] = g2_ld16_sc1(ex, (t0 + u * DL_THREADS_PRIM) * 16);
+  for (int it = 0;; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const u32x4 V = v[u];
+      if ((pend & (1u << u)) && (V.y >> 16) == tag16 && (V.w >> 16) == tag16) {
+        const int d = d0 + u * (4 * kp >> 1);
+        pl[d] = (V.x & 0xFFFFu) | (V.z << 16);
+        pl[tstride + d] = (V.x >> 16) | (V.z & 0xFFFF0000u);
+        pl[2 * tstride + d] = (V.y & 0xFFFFu) | (V.w << 16);
+        pend &= ~(1u << u);
+      }
+    }
+    if (!pend) break;
+    if (it > (1 << 20)) {
+      *err = 1;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (pend & (1u << u)) v[u] = g2_ld16_sc1(ex, (t0 + u * DL_THREADS_PRIM) * 16);
+  }
+#else
+  for (int p = t0; p < 32 * hp; p += DL_THREADS_PRIM) {
+    const int f = p / hp, q = p - f * hp;
+    const unsigned long long* e = ex + f * DLX_K + 2 * q;
+    long spins = 0;
+    for (;;) {
+      const unsigned long long a = e[0], b2 = e[1];
+      if ((uint32_t)(a >> 48) == tag16 && (uint32_t)(b2 >> 48) == tag16) {
+        const uint32_t ax = (uint32_t)a, ay = (uint32_t)(a >> 32), bx = (uint32_t)b2, by = (uint32_t)(b2 >> 32);
+        const int d = (f * kp >> 1) + q;
+        pl[d] = (ax & 0xFFFFu) | (bx << 16);
+        pl[tstride + d] = (ax >> 16) | (bx & 0xFFFF0000u);
+        pl[2 * tstride + d] = (ay & 0xFFFFu) | (by << 16);
+        break;
+      }
+      if (++spins > (1L << 22)) {
+        *err = 1;
+        break;
+      }
+      hipemu::yield();
+    }
+  }
+#endif
+}
+
+// launch sequence number of the exchange tags: advanced once per launch chain, after every workgroup has read it
+__device__ __forceinline__ void dlx_seq_done(int* gs_bar, int self_seq) {
+  if (threadIdx.x != 0 || !self_seq) return;
+  (void)g2_last_workgroup_advances(gs_bar);
+}
+

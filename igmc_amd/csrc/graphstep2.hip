@@ -51,205 +51,12 @@
 __device__ unsigned long long g_g2_clk[128];
 // ... and (same switch) start / end of EVERY workgroup on the constant-rate wall clock + its XCC id: [wg][0..2]
 __device__ unsigned long long g_g2_wg[1024][3];
-#ifdef IGMC_HIPEMU
-#define G2_STAMP(k) do { } while (0)
-#else
-#define G2_STAMP(k)                                                                                        \
-  do {                                                                                                     \
-    if (a.timing && threadIdx.x == 0) {                                                                    \
-      if (blockIdx.x == 0) g_g2_clk[k] = __builtin_readcyclecounter();                                     \
-      else if (a.cs > 2 && (int)blockIdx.x == 2 && (k) < 40) g_g2_clk[64 + (k)] = __builtin_readcyclecounter(); \
-    }                                                                                                      \
-  } while (0)
-#endif
-
-// keeps per-lane index arithmetic INSIDE the phase it is used in (LLVM otherwise hoists hundreds of loop-invariant LDS
-// addresses out of the layer loops and spills them)
-#ifdef IGMC_HIPEMU
-#define G2_OPAQUE(x) do { } while (0)
-#else
-#define G2_OPAQUE(x) asm volatile("" : "+v"(x))
-#endif
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-#ifndef IGMC_HIPEMU
-typedef __bf16 g2_bf16x8 __attribute__((ext_vector_type(8)));
-#endif
-
-__device__ __forceinline__ f32x4 g2_mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
-#ifdef IGMC_HIPEMU
-  return igmc_emu_mfma_16x16x32_bf16(a, b, c);
-#else
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(g2_bf16x8, a), __builtin_bit_cast(g2_bf16x8, b), c, 0, 0, 0);
-#endif
-}
-
-// four relm bytes (bits 0..2: relation + 1, bit 3 / 4: keep flags of the two directions) -> two dwords of bf16 pairs
-// that are 1.0 where the byte's relation is r1 - 1 (and its keep bit is set)
-template <bool FLAGS>
-__device__ __forceinline__ void g2_expand4(uint32_t w, uint32_t r1, int keepbit, uint32_t& o01, uint32_t& o23) {
-  uint32_t mk = w & 0x07070707u;
-  if (FLAGS) mk &= ((w >> keepbit) & 0x01010101u) * 7u;
-  const uint32_t t = mk ^ (0x01010101u * r1);
-  const uint32_t eq = ~(t + 0x7F7F7F7Fu) & 0x80808080u;        // bit 7 of a byte set <=> the byte of t is zero (t <= 7)
-  const uint32_t mask = (eq >> 7) * 0xFFu;                      // 0xFF per matching byte
-#ifdef IGMC_HIPEMU
-  o01 = ((mask & 0xFFu) ? 0x3F80u : 0u) | ((mask & 0xFF00u) ? 0x3F800000u : 0u);
-  o23 = ((mask & 0xFF0000u) ? 0x3F80u : 0u) | ((mask & 0xFF000000u) ? 0x3F800000u : 0u);
-#else
-  o01 = __builtin_amdgcn_perm(mask, mask, 0x01010000u) & 0x3F803F80u;    // bytes [b0 b0 b1 b1]
-  o23 = __builtin_amdgcn_perm(mask, mask, 0x03030202u) & 0x3F803F80u;    // bytes [b2 b2 b3 b3]
-#endif
-}
-
-__device__ __forceinline__ float g2_tanh(float x) {
-#ifdef IGMC_HIPEMU
-  return tanhf(x);
-#else
-  return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x));
-#endif
-}
-
-// ---- exchange words ------------------------------------------------------------------------------------------------
-// plane word of one value: {hi | mid << 16, lo | tag << 16}; two nodes of one feature per 16-byte access
-__device__ __forceinline__ void g2_store16(unsigned long long* p, uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
-#ifndef IGMC_HIPEMU
-  u32x4 v = {x, y, z, w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
-#else
-  p[0] = ((unsigned long long)y << 32) | x;
-  p[1] = ((unsigned long long)w << 32) | z;
-#endif
-}
-__device__ __forceinline__ void g2_pub_f32(unsigned long long* p, float v, uint32_t tag) {
-#ifndef IGMC_HIPEMU
-  __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
-#else
-  uint32_t bits;
-  memcpy(&bits, &v, 4);
-  *p = ((unsigned long long)tag << 32) | (unsigned long long)bits;
-#endif
-}
-
-// The planes [term][feature][node] of one side from its exchange region ex[feature][KMAX nodes]: nodes < npad (a
-// multiple of 16, <= 128) of all 32 features = 16 * npad word pairs, <= 8 per thread.  Two halves, so that the round
-// trip can run under other work: g2_poll_issue requests every pair of the thread (16-byte sc1 buffer loads the compiler
-// tracks -- no inline asm, nothing to mis-schedule), g2_poll_finish consumes them; pairs whose tags are not this
-// exchange's are requested again until they are.
-struct G2Poll {
-  u32x4 v[8];
-};
-#ifndef IGMC_HIPEMU
-__device__ __forceinline__ u32x4 g2_ld16_sc1(const unsigned long long* base, int byte_off) {
-  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
-  return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);       // aux 16 = sc1: served by L2, bypasses this CU's L1
-}
-#endif
-__device__ __forceinline__ void g2_poll_issue(G2Poll& pq, const unsigned long long* ex, int npad) {
-#ifndef IGMC_HIPEMU
-  // pair p = thread + 256 u  ->  feature p >> 6, node pair p & 63 (pairs past npad are never consumed)
-  const int t0 = (int)threadIdx.x;
-  (void)npad;
-#pragma unroll
-  for (int u = 0; u < 8; ++u) pq.v[u] = g2_ld16_sc1(ex, (t0 + u * G2_THREADS) * 16);
-#else
-  (void)pq; (void)ex; (void)npad;
-#endif
-}
-__device__ __forceinline__ void g2_poll_finish(G2Poll& pq, uint32_t* pl, int kp, const unsigned long long* ex, int npad,
-                                               uint32_t tag16, int* err) {
-  const int hp = npad >> 1, total = 32 * hp, t0 = (int)threadIdx.x;      // pairs per feature, pairs in all
-  const int tstride = 32 * kp >> 1;                                       // dwords per term
-#ifndef IGMC_HIPEMU
-  (void)total;
-  const int q0 = t0 & 63;                                                 // this thread's node pair (of 64 per feature)
-  uint32_t pend = (q0 < hp) ? 0xFFu : 0u;
-  const int d0 = ((t0 >> 6) * kp >> 1) + q0;                              // feature (t0 >> 6) + 4 u
-  for (int it = 0;; ++it) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const u32x4 V = pq.v[u];
-      if ((pend & (1u << u)) && (V.y >> 16) == tag16 && (V.w >> 16) == tag16) {
-        const int d = d0 + u * (4 * kp >> 1);                              // dword index inside a term's plane
-        pl[d] = (V.x & 0xFFFFu) | (V.z << 16);
-        pl[tstride + d] = (V.x >> 16) | (V.z & 0xFFFF0000u);
-        pl[2 * tstride + d] = (V.y & 0xFFFFu) | (V.w << 16);
-        pend &= ~(1u << u);
-      }
-    }
-    if (!pend) break;
-    if (it > (1 << 20)) {
-      *err = 1;
-      break;
-    }
-    __builtin_amdgcn_s_sleep(2);
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (pend & (1u << u)) pq.v[u] = g2_ld16_sc1(ex, (t0 + u * G2_THREADS) * 16);
-  }
-#else
-  (void)pq;
-  for (int p = t0; p < total; p += G2_THREADS) {
-    const int f = p / hp, q = p - f * hp;
-    const unsigned long long* e = ex + f * 128 + 2 * q;
-    long spins = 0;
-    for (;;) {
-      const unsigned long long a = e[0], b2 = e[1];
-      if ((uint32_t)(a >> 48) == tag16 && (uint32_t)(b2 >> 48) == tag16) {
-        const uint32_t ax = (uint32_t)a, ay = (uint32_t)(a >> 32), bx = (uint32_t)b2, by = (uint32_t)(b2 >> 32);
-        const int d = (f * kp >> 1) + q;
-        pl[d] = (ax & 0xFFFFu) | (bx << 16);
-        pl[tstride + d] = (ax >> 16) | (bx & 0xFFFF0000u);
-        pl[2 * tstride + d] = (ay & 0xFFFFu) | (by << 16);
-        break;
-      }
-      if (++spins > (1L << 22)) {
-        *err = 1;
-        break;
-      }
-      hipemu::yield();
-    }
-  }
-#endif
-}
-__device__ __forceinline__ void g2_reload(uint32_t* pl, int kp, const unsigned long long* ex, int npad, uint32_t tag16,
-                                          int* err) {
-  G2Poll pq;
-  g2_poll_issue(pq, ex, npad);
-  g2_poll_finish(pq, pl, kp, ex, npad, tag16, err);
-}
-
-// one 8-byte {f32, tag} word, polled
-__device__ __forceinline__ float g2_poll_f32(const unsigned long long* p, uint32_t tag, int* err) {
-  for (long it = 0;; ++it) {
-#ifndef IGMC_HIPEMU
-    const unsigned long long w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    const unsigned long long w = *p;
-#endif
-    if ((uint32_t)(w >> 32) == tag) return __uint_as_float((uint32_t)w);
-    if (it > (1L << 22)) {
-      *err = 1;
-      return 0.f;
-    }
-#ifndef IGMC_HIPEMU
-    __builtin_amdgcn_s_sleep(2);
-#else
-    hipemu::yield();
-#endif
-  }
-}
+#include "g2_prims.h"      // the gfx950 primitives of this file (and their stand-ins for the CPU emulation build)
 
 // ---- the relation-space aggregate of one bundle on the matrix cores: acc[r][t] (lane = row, regs = features
 //      16 t + 4 (lane >> 4) + 0..3) = sum over the opposite side's nodes of A_r[row][node] * x[node][feature].
 //      All G2_NR relations always run (fragments of absent relations are zero); the six plane fragments of k-step s + 1
 //      are requested before the 30 MFMAs of k-step s are issued.
-#ifdef IGMC_HIPEMU
-#define G2_SCHED_BARRIER() do { } while (0)
-#else
-#define G2_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
-#endif
 __device__ __forceinline__ void g2_gather(const uint32_t* pl, int kp, int nks, const uint32_t (&A)[G2_NR][G2_KS][4],
                                           int li, int kq, f32x4 (&acc)[G2_NR][2]) {
 #pragma unroll
@@ -444,24 +251,16 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
   const int cm = (cs > 1) ? (int)(blockIdx.x % cs) : 0;
   const int half = 2 * cs;                              // waves of the cluster per side
   const int rmr = lay.rmr, rmc = lay.rmc, rmp = lay.rmc + 8;      // image rows, columns, row pitch (bytes)
-#ifndef IGMC_HIPEMU
-  const uint32_t seq = (uint32_t)__hip_atomic_load(a.gs_bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-  const uint32_t seq = (uint32_t)a.gs_bar[1];
-#endif
+  const uint32_t seq = g2_ld_seq(a.gs_bar);
   const uint32_t tag0 = seq * 8u + 1u;
   const uint64_t step = a.ctrl ? (uint64_t)a.ctrl[IGMC_CTRL_STEP] : a.step;
-#ifndef IGMC_HIPEMU
-  if (a.ts && tid == 0) atomicMin(a.ts, (unsigned long long)wall_clock64());
-#endif
+  if (a.ts && tid == 0) g2_clock_open(a.ts);
   auto tag16 = [&](int x) { return 1u + (tag0 + (uint32_t)x) % 65535u; };
   G2_STAMP(0);
-#ifndef IGMC_HIPEMU
   if (a.timing && tid == 0 && blockIdx.x < 1024) {
-    g_g2_wg[blockIdx.x][0] = (unsigned long long)wall_clock64();
-    g_g2_wg[blockIdx.x][2] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID
+    g_g2_wg[blockIdx.x][0] = g2_wall_clock();
+    g_g2_wg[blockIdx.x][2] = g2_xcc_id();
   }
-#endif
 
   // ---- the first subgraph's extents are requested before anything else (two dependent round trips overlap with
   //      the staging of the layer-0 table, which k_g2_compose formed from the current weights)
@@ -536,9 +335,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
           unsigned long long* e = a.g2_ex + x * exs + ((size_t)g * 2 + side) * 4096 + 16 * bb2;
           for (int i = lane; i < 32 * 8; i += 64) g2_store16(e + (i >> 3) * 128 + 2 * (i & 7), 0u, 0u, 0u, 0u);
         }
-#ifndef IGMC_HIPEMU
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+      g2_wait_vm0();
     }
     // ---- set-up: labels, relm in the orientation of this workgroup's side(s), one-hot label planes, zeroed planes.
     //      The global loads (one label per thread, <= 16 relm dwords per thread) are requested first, the LDS zero fills
@@ -1003,9 +800,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
               bw[s4][4] = pr[0];
               bw[s4][5] = pr[16];
             }
-#ifndef IGMC_HIPEMU
-            __builtin_amdgcn_sched_barrier(0);
-#endif
+            G2_SCHED_BARRIER();
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
@@ -1075,32 +870,12 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
   // The launch sequence number (exchange tags) advances once per launch, after every workgroup has read it: a training
   // launch leaves that to the next kernel on the stream (k_tail_ts, one store) unless a.self_seq says otherwise; else the
   // workgroup that finishes LAST does it here (an atomic round trip at the end of every workgroup).
-#ifndef IGMC_HIPEMU
   if (tid == 0 && a.self_seq) {
-    const unsigned long long t1 = a.ts ? (unsigned long long)wall_clock64() : 0ull;
-    if (__hip_atomic_fetch_add(a.gs_bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
-      __hip_atomic_store(a.gs_bar, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(a.gs_bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (a.ts) {
-        const unsigned long long t0 = __hip_atomic_load(a.ts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        atomicAdd(a.ts + 1, t1 - t0);
-        atomicAdd(a.ts + 2, 1ull);
-        __hip_atomic_store(a.ts, ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
+    const unsigned long long t1 = a.ts ? g2_wall_clock() : 0ull;
+    if (g2_last_workgroup_advances(a.gs_bar) && a.ts) g2_clock_close(a.ts, t1);
   }
-#else
-  if (tid == 0 && a.self_seq) {
-    if (a.gs_bar[0]++ == (int)gridDim.x - 1) {
-      a.gs_bar[0] = 0;
-      a.gs_bar[1] += 1;
-    }
-  }
-#endif
   G2_STAMP(35);
-#ifndef IGMC_HIPEMU
-  if (a.timing && tid == 0 && blockIdx.x < 1024) g_g2_wg[blockIdx.x][1] = (unsigned long long)wall_clock64();
-#endif
+  if (a.timing && tid == 0 && blockIdx.x < 1024) g_g2_wg[blockIdx.x][1] = g2_wall_clock();
 }
 
 // debug aid: start / end (wall clock, 100 MHz) and XCC of every workgroup of the last k_graph_step2 launched with IGMC_GS_TIMING
@@ -1401,13 +1176,10 @@ struct DlArgs {
 // compiler they become v_pk_fma_f32 / v_pk_mul_f32 chains whose operand pairs are assembled with v_mov and op_sel, and on
 // gfx950 that code gave run-to-run different sums on identical inputs (same launch repeated: G and dPre bit-identical, a
 // few partials off by 1e-2 relative; always the low halves of the packed chains).  Scalar fmas are reproducible.
-#ifdef IGMC_HIPEMU
-#define DL_FMAC(acc_, a_, b_) ((acc_) += (a_) * (b_))
-#else
-#define DL_FMAC(acc_, a_, b_) asm("v_fmac_f32 %0, %1, %2" : "+v"(acc_) : "v"(a_), "v"(b_))
-#endif
+// (DL_FMAC: g2_prims.h)
 #define DL_NW 8                   // waves (= 16-row bundles) per workgroup of the dense layer kernel
 #define DL_THREADS (64 * DL_NW)
+static_assert(DL_THREADS == DL_THREADS_PRIM, "dlx_reload (g2_prims.h) is written for this workgroup size");
 #define DL_PIT 2                  // plane-staging items per thread: 128 * k-steps / DL_THREADS, k-steps <= 8
 #define DL_RIT 17                 // block-row dwords per lane: 16 rows x (32 * k-steps + 8) / 4 / 64, k-steps <= 8
 // LDS plan (4-byte words): [own rows XOA][TS: h_{l-1} rows HSA, d bias scratch][planes | block rows | weight image][sums]
@@ -1514,9 +1286,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
     }
     own_lab = (int)a.node_label[own0 + (row0 + li < n_own ? row0 + li : n_own - 1)];
   }
-#ifndef IGMC_HIPEMU
-  __builtin_amdgcn_sched_barrier(0);
-#endif
+  G2_SCHED_BARRIER();
   // ---- planes: three bf16 terms of two nodes' features per word
   {
     const int tstride = 32 * kp >> 1;
@@ -1734,9 +1504,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
                                           : Db[(4 * s4 + kq) * G2_XP + (nt - 2 * G2_NR) * 16 + li];
           }
         }
-#ifndef IGMC_HIPEMU
-        __builtin_amdgcn_sched_barrier(0);
-#endif
+        G2_SCHED_BARRIER();
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
@@ -1828,8 +1596,8 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
 // exchange words, as the members of k_graph_step2's clusters do.  A per-layer launch spends 12 of its 16 us outside the
 // matrix cores (launch, staging round trips, the launch's tail); here the block rows are staged once, a layer's weight
 // image is requested a layer ahead, the opposite side's rows arrive as bf16 terms already in plane order, and a layer
-// boundary is one poll of the exchange.  Exchange regions: [exchange x][subgraph][side][32 features][DLX_K nodes].
-#define DLX_K 256
+// boundary is one poll of the exchange.  Exchange regions: [exchange x][subgraph][side][32 features][DLX_K nodes]
+// (DLX_K = 256: g2_prims.h).
 struct DlfArgs {
   const int32_t* n_users;
   const int32_t* n_items;
@@ -1851,83 +1619,6 @@ struct DlfArgs {
   int self_seq;                  // 1: the last workgroup advances the launch sequence number (no kernel follows that would)
 };
 
-// planes [term][feature][node] of one side from its exchange region ex[feature][DLX_K]: nodes < npad (a multiple of 16) of
-// all 32 features, 8 word pairs per thread of a 512-thread workgroup, polled until their tags are this exchange's
-__device__ __forceinline__ void dlx_reload(uint32_t* pl, int kp, const unsigned long long* ex, int npad, uint32_t tag16,
-                                           int* err) {
-  const int hp = npad >> 1, t0 = (int)threadIdx.x;
-  const int tstride = 32 * kp >> 1;
-#ifndef IGMC_HIPEMU
-  // pair p = thread + 512 u -> feature p >> 7, node pair p & 127
-  const int q0 = t0 & 127;
-  uint32_t pend = (q0 < hp) ? 0xFFu : 0u;
-  const int d0 = ((t0 >> 7) * kp >> 1) + q0;                               // feature (t0 >> 7) + 4 u
-  u32x4 v[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) v[u] = g2_ld16_sc1(ex, (t0 + u * DL_THREADS) * 16);
-  for (int it = 0;; ++it) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const u32x4 V = v[u];
-      if ((pend & (1u << u)) && (V.y >> 16) == tag16 && (V.w >> 16) == tag16) {
-        const int d = d0 + u * (4 * kp >> 1);
-        pl[d] = (V.x & 0xFFFFu) | (V.z << 16);
-        pl[tstride + d] = (V.x >> 16) | (V.z & 0xFFFF0000u);
-        pl[2 * tstride + d] = (V.y & 0xFFFFu) | (V.w << 16);
-        pend &= ~(1u << u);
-      }
-    }
-    if (!pend) break;
-    if (it > (1 << 20)) {
-      *err = 1;
-      break;
-    }
-    __builtin_amdgcn_s_sleep(2);
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (pend & (1u << u)) v[u] = g2_ld16_sc1(ex, (t0 + u * DL_THREADS) * 16);
-  }
-#else
-  for (int p = t0; p < 32 * hp; p += DL_THREADS) {
-    const int f = p / hp, q = p - f * hp;
-    const unsigned long long* e = ex + f * DLX_K + 2 * q;
-    long spins = 0;
-    for (;;) {
-      const unsigned long long a = e[0], b2 = e[1];
-      if ((uint32_t)(a >> 48) == tag16 && (uint32_t)(b2 >> 48) == tag16) {
-        const uint32_t ax = (uint32_t)a, ay = (uint32_t)(a >> 32), bx = (uint32_t)b2, by = (uint32_t)(b2 >> 32);
-        const int d = (f * kp >> 1) + q;
-        pl[d] = (ax & 0xFFFFu) | (bx << 16);
-        pl[tstride + d] = (ax >> 16) | (bx & 0xFFFF0000u);
-        pl[2 * tstride + d] = (ay & 0xFFFFu) | (by << 16);
-        break;
-      }
-      if (++spins > (1L << 22)) {
-        *err = 1;
-        break;
-      }
-      hipemu::yield();
-    }
-  }
-#endif
-}
-
-// launch sequence number of the exchange tags: advanced once per launch chain, after every workgroup has read it
-__device__ __forceinline__ void dlx_seq_done(int* gs_bar, int self_seq) {
-  if (threadIdx.x != 0 || !self_seq) return;
-#ifndef IGMC_HIPEMU
-  if (__hip_atomic_fetch_add(gs_bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
-    __hip_atomic_store(gs_bar, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(gs_bar + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-#else
-  if (gs_bar[0]++ == (int)gridDim.x - 1) {
-    gs_bar[0] = 0;
-    gs_bar[1] += 1;
-  }
-#endif
-}
-
 __host__ __device__ static inline int dlf_words(int kp) {
   return 2 * DL_NW * 16 * G2_XP + (G2_NT * 32 * kp >> 1) + DL_NW * 4 * kp + G2_WIMG;
 }
@@ -1941,11 +1632,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
   const int g = bid / (2 * a.nq), rem = bid - g * 2 * a.nq, side = rem / a.nq, q = rem - side * a.nq;
   const int cu = a.n_users[g], cv = a.n_items[g];
   const int n_own = side ? cv : cu, n_opp = side ? cu : cv;
-#ifndef IGMC_HIPEMU
-  const uint32_t seq = (uint32_t)__hip_atomic_load(a.gs_bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-  const uint32_t seq = (uint32_t)a.gs_bar[1];
-#endif
+  const uint32_t seq = g2_ld_seq(a.gs_bar);
   const uint32_t tag0 = seq * 8u + 1u;
   auto tag16 = [&](int x) { return 1u + (tag0 + (uint32_t)x) % 65535u; };
   if (16 * DL_NW * q >= n_own) {                 // nothing of this side in the workgroup's rows: nobody waits for it
@@ -1980,9 +1667,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
       unsigned long long* e = a.ex + x * exs + ((size_t)g * 2 + side) * (32 * DLX_K) + 16 * DL_NW * q;
       for (int i = tid; i < 32 * 8 * DL_NW; i += DL_THREADS) g2_store16(e + (i / (8 * DL_NW)) * DLX_K + 2 * (i % (8 * DL_NW)), 0u, 0u, 0u, 0u);
     }
-#ifndef IGMC_HIPEMU
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+    g2_wait_vm0();
   }
 
   // ---- staging: every global load of the set-up is requested before the first use
@@ -2020,9 +1705,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
       if (i < G2_WIMG / 4) ((f32x4*)sW2)[i] = wq[u];
     }
   };
-#ifndef IGMC_HIPEMU
-  __builtin_amdgcn_sched_barrier(0);
-#endif
+  G2_SCHED_BARRIER();
   {   // zero fills under the loads' latency: planes (k-steps past the published rows must read zeros), both row tiles, inputs
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < (G2_NT * 32 * kp >> 3); i += DL_THREADS) ((float4*)PLN)[i] = z4;
@@ -2235,11 +1918,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
     for (int i = tid; i < rows0 * 8; i += DL_THREADS) ((float4*)part0)[i] = z4;
     return;
   }
-#ifndef IGMC_HIPEMU
-  const uint32_t seq = (uint32_t)__hip_atomic_load(a.gs_bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-  const uint32_t seq = (uint32_t)a.gs_bar[1];
-#endif
+  const uint32_t seq = g2_ld_seq(a.gs_bar);
   const uint32_t tag0 = seq * 8u + 1u;
   auto tag16 = [&](int x) { return 1u + (tag0 + (uint32_t)x) % 65535u; };
   const int nb = a.node_off[g];
@@ -2297,9 +1976,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
       if (i < G2_WIMG / 4) ((f32x4*)sW2)[i] = wq[u];
     }
   };
-#ifndef IGMC_HIPEMU
-  __builtin_amdgcn_sched_barrier(0);
-#endif
+  G2_SCHED_BARRIER();
   {   // planes (dPre_3: node 0 of the opposite side only; k-steps past the published rows read zeros later) and row tiles
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < (G2_NT * 32 * kp >> 3); i += DL_THREADS) ((float4*)PLN)[i] = z4;
@@ -2453,9 +2130,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
                                           : Db[(4 * s4 + kq) * G2_XP + (nt - 2 * G2_NR) * 16 + li];
           }
         }
-#ifndef IGMC_HIPEMU
-        __builtin_amdgcn_sched_barrier(0);
-#endif
+        G2_SCHED_BARRIER();
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
@@ -2609,9 +2284,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer0(Dl0Args a) {
       const int rc = row0 + r < n_own ? row0 + r : n_own - 1, cc = c < ldw ? c : ldw - 1;
       rmq[u] = ((const uint32_t*)(src + (size_t)rc * ldb))[cc];
     }
-#ifndef IGMC_HIPEMU
-    __builtin_amdgcn_sched_barrier(0);
-#endif
+    G2_SCHED_BARRIER();
 #pragma unroll
     for (int u = 0; u < DL_RIT; ++u) {
       const int i = lane + 64 * u, r = i / rw, c = i - r * rw;
