@@ -66,10 +66,19 @@ __device__ __forceinline__ float g2_tanh(float x) {
 
 // ---- exchange words ------------------------------------------------------------------------------------------------
 // plane word of one value: {hi | mid << 16, lo | tag << 16}; two nodes of one feature per 16-byte access
+// The store is a COMPILER-TRACKED sc1 buffer store (descriptor base = the wave's first lane's address, per-lane byte offset
+// behind it: every call site hands the lowest address to the first active lane).  As inline asm the compiler's vmcnt
+// bookkeeping did not see it: every wait for a load issued BEFORE an epilogue's publishes -- the next layer's weight image
+// in stage() -- then also waited for the oldest stores behind that load (profiles/r04_g2_tracked_stores_ab.txt).
 __device__ __forceinline__ void g2_store16(unsigned long long* p, uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
 #ifndef IGMC_HIPEMU
-  u32x4 v = {x, y, z, w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+  const u32x4 v = {x, y, z, w};
+  const unsigned long long pa = (unsigned long long)p;
+  const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pa);
+  const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pa >> 32));
+  const unsigned long long base = ((unsigned long long)bhi << 32) | blo;
+  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(pa - base), 0, 16);      // aux 16 = sc1: written through to the coherent level
 #else
   p[0] = ((unsigned long long)y << 32) | x;
   p[1] = ((unsigned long long)w << 32) | z;
