@@ -385,6 +385,18 @@ extern "C" void igmc_batch_destroy(igmc_batch* b) {
   delete b;
 }
 
+// The transposed copy of the dense blocks for an arena whose slots would not get one by size (<= 128 nodes a side): what
+// the dense-layer kernels (k_dl_fwd / k_dl_bwd / k_dl_layer) read on the item side.  For models the subgraph kernel does
+// not take although the blocks exist -- the sort-pool family, side features -- so that their conv layers run on the matrix
+// cores instead of the CSR row walkers.  A no-op without dense blocks; a batch already in the arena is dropped.
+extern "C" int igmc_batch_want_transposed(igmc_batch* b) {
+  if (!b) IGMC_FAIL("null arena");
+  if (b->d.relmT || !b->d.relm) return 0;
+  if (b->mem.get(&b->d.relmT, (size_t)b->d.graph_cap * b->d.cap_v * b->d.relmT_ld)) IGMC_FAIL("hipMalloc failed (transposed blocks)");
+  b->last_B = 0;      // (a batch extracted before has no transposed blocks: the arena counts as empty until the next extraction)
+  return 0;
+}
+
 extern "C" int igmc_extract_batch(const igmc_graph* g, igmc_batch* b, const int32_t* d_link_u,
                                   const int32_t* d_link_v, const float* d_link_y, const int32_t* d_link_idx,
                                   int first, int B, double sample_ratio, uint64_t seed, uint64_t epoch,
@@ -734,11 +746,11 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   d.g2_fx = nullptr;
   d.g2_w = nullptr;
   d.g2_graphs = 0;
-  // exchange regions [32 features][nodes a side]: 128 nodes for the subgraph kernel (slots <= 256 nodes), 256 for the
-  // one-launch forward of the dense layers (larger slots)
-  d.ex_nodes = (N > 256 * Bc || getenv("IGMC_DL_ALWAYS")) ? 256 : 128;      // (IGMC_DL_ALWAYS: tests force the dense layers onto small arenas)
+  // exchange regions [32 features][256 nodes a side] of the one-launch dense layers (k_dl_fwd / k_dl_bwd); the subgraph
+  // kernel uses the first 128 nodes of a region.  655 KB per subgraph slot: HBM is not what this path is short of.
+  d.ex_nodes = 256;
   d.g2_ex_stride = (size_t)Bc * 2 * 32 * d.ex_nodes;
-  if (d.R <= 5 && n_side == 0 && Bc <= 2048) {      // exchange buffers of the matrix-core subgraph kernel: 320 KB per slot
+  if (d.R <= 5 && Bc <= 2048) {
     fail |= M.get(&d.g2_ex, 5 * d.g2_ex_stride) | M.get(&d.g2_fx, Bc * 256) | M.get(&d.g2_w, (size_t)6 * 9216 + 1024);
     d.g2_graphs = (int)Bc;
   } else if (d.R <= 5) {

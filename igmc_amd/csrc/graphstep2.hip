@@ -2462,7 +2462,7 @@ void igmc_launch_dl_layer(const ModelDev& m, const BatchDev& b, const float* P, 
 int igmc_dl_fwd_eligible(const ModelDev& m, const BatchDev& b, int B) {
   const char* e = getenv("IGMC_DL_FUSED");
   if (e && atoi(e) == 0) return 0;
-  if (!igmc_dl_eligible(m, b, B) || !m.g2_ex || m.ex_nodes < DLX_K || b.graph_cap > m.g2_graphs || m.S != 0) return 0;
+  if (!igmc_dl_eligible(m, b, B) || !m.g2_ex || m.ex_nodes < DLX_K || b.graph_cap > m.g2_graphs) return 0;
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
   const int nq = (cmax + 16 * DL_NW - 1) / (16 * DL_NW);
   if (B * 2 * nq > 224) return 0;                  // (one workgroup per CU, all of them resident: the members wait for each other)

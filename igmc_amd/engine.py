@@ -130,6 +130,10 @@ class Batch(object):
         """True when the dense per-layer kernels take the conv layers of this arena with workspace ``ws``."""
         return bool(self.lib.cdll.igmc_model_dense_layers(ws.handle, self.handle, int(self.B or self.max_graphs)))
 
+    def want_transposed(self):
+        """Keep the transposed dense blocks too (dense-layer kernels for models the subgraph kernel does not take)."""
+        self.lib.call('igmc_batch_want_transposed', self.handle)
+
     def set_lean(self, lean=True):
         """Lean extraction: stop after the dense induced blocks (what the matrix-core subgraph kernel reads); the
         collated CSR is emitted on demand (``igmc_batch_set_lean``)."""

@@ -268,6 +268,10 @@ class StepGraph(GroupPipeline):
         from .util_functions import DeviceBatch
         while len(self.sets[q]) <= i:
             a = self.ds.arena(self.B, slot='%s%d.%d' % (self.SLOT, q, len(self.sets[q])))
+            # models the subgraph kernel does not take although the dense blocks exist (sort-pool readout, side features):
+            # with the transposed blocks their conv layers run on the matrix cores (k_dl_*) instead of walking CSR rows
+            if hasattr(self.model, '_sortpool') or getattr(self.model, 'side_features', False):
+                a.want_transposed()
             self.sets[q].append(a)
             if self.ws is None:
                 probe = DeviceBatch(self.ds, a, self.B, self.perm, 0)

@@ -147,6 +147,11 @@ int igmc_batch_bind_side_source(igmc_batch* b, const float* d_side_all, int n_si
  * calls that need it (get_info / download / edge flags / model calls that run the per-layer kernels).  The training
  * loop sets it when igmc_model_dense_path() says the model will take the dense path for this arena and batch size. */
 int igmc_batch_set_lean(igmc_batch* b, int lean);
+/* Keep the transposed copy of the dense induced blocks too (arenas get one by themselves when a side exceeds 128 nodes):
+ * the item-side operand of the dense-layer kernels, for models the subgraph kernel does not take although the blocks exist
+ * (sort-pool readout, side features) -- their conv layers then run on the matrix cores instead of walking CSR rows.
+ * No-op without dense blocks; a batch already in the arena is dropped (extract again).  No reference counterpart. */
+int igmc_batch_want_transposed(igmc_batch* b);
 
 /* ------------------------------------------------------------------ model
  * Flat fp32 parameter buffer layout (offsets in floats; query with igmc_param_offset):
