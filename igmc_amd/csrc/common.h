@@ -3,6 +3,13 @@
 #include <stdint.h>
 #include <stddef.h>
 
+// A byte of the dense induced block of a subgraph (extract.hip: k_relm; read by the subgraph / dense-layer kernels):
+// bits 0..3 = relation + 1 (0: no edge; R <= 15), bits 4 / 5 = keep flags of the two directions under edge dropout
+#define IGMC_RELM_CODE 0x0Fu
+#define IGMC_RELM_KF 4
+#define IGMC_RELM_KT 5
+#define IGMC_RELM_KEEP 0x30u
+
 #ifdef IGMC_HIPEMU
 // tools/hipemu/hipemu.h is force-included (CPU emulation for kernel-logic tests only)
 #define IGMC_DYN_SMEM(name) unsigned char* name = hipemu::cur_block().dyn_smem

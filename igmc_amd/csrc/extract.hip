@@ -592,8 +592,8 @@ __device__ __forceinline__ void relm_body(const GraphDev& G, const BatchDev& b) 
       const bool mt = (j[q] == v0) ? (row[q] != 0) : bm_test(sel_v, j[q]);
       if (mt) {
         const int lv = (j[q] == v0) ? 0 : 1 + bm_rank(sel_v, pre_v, j[q]);
-        rm[(size_t)row[q] * ld + lv] = (uint8_t)((rl[q] + 1) | 0x18);      // relation + 1, both directions kept
-        if (b.relmT) b.relmT[((size_t)g * b.cap_v + lv) * b.relmT_ld + row[q]] = (uint8_t)((rl[q] + 1) | 0x18);
+        rm[(size_t)row[q] * ld + lv] = (uint8_t)((rl[q] + 1) | IGMC_RELM_KEEP);      // relation + 1, both directions kept
+        if (b.relmT) b.relmT[((size_t)g * b.cap_v + lv) * b.relmT_ld + row[q]] = (uint8_t)((rl[q] + 1) | IGMC_RELM_KEEP);
         ++c;
       }
     }
@@ -708,17 +708,17 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_emit(BatchDev b) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         if (q * 64 >= len) break;
-        const bool mt = (val[q] & 7) == rel + 1;
+        const bool mt = (val[q] & IGMC_RELM_CODE) == rel + 1;
         const unsigned long long bal = __ballot(mt);
         if (mt) {
           const int pos = o + __popcll(bal & ((1ull << lane) - 1ull));
           b.ecr[pos] = (uint32_t)(nbase + q * 64 + lane) | ((uint32_t)rel << 24);
           b.ecode[pos] = (uint16_t)(rel * L + lab[q]);
           b.edst[pos] = (uint16_t)r;
-          // keep flags of the entry (bit 0: column -> row, bit 1: row -> column) from the block's bits 3 / 4, which are
+          // keep flags of the entry (bit 0: column -> row, bit 1: row -> column) from the block's two keep bits, which are
           // those of the USER row; an item row sees the two directions swapped.  All kept unless a dense edge dropout
           // (k_relm_dropout, lean arenas) ran before this emission.
-          const int fl = (val[q] >> 3) & 3;
+          const int fl = (val[q] >> IGMC_RELM_KF) & 3;
           b.eflag[pos] = (uint8_t)(is_u ? fl : ((fl >> 1) | ((fl & 1) << 1)));
         }
         o += __popcll(bal);
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_edge_flags(BatchDev b, float p, 
       if (b.relm && row_user) {      // the dense block carries the same two bits (graphstep2.hip builds its masks from it)
         const int nb = b.node_off[gr];
         uint8_t* q = b.relm + ((size_t)gr * b.cap_u + (size_t)(i - nb)) * b.relm_ld + ((int)(b.ecr[e] & 0xFFFFFFu) - nb - b.n_users[gr]);
-        *q = (uint8_t)((*q & 7) | (kf << 3) | (kt << 4));
+        *q = (uint8_t)((*q & IGMC_RELM_CODE) | (kf << IGMC_RELM_KF) | (kt << IGMC_RELM_KT));
         if (b.relmT) b.relmT[((size_t)gr * b.cap_v + ((int)(b.ecr[e] & 0xFFFFFFu) - nb - b.n_users[gr])) * b.relmT_ld + (i - nb)] = *q;
       }
     }
@@ -820,7 +820,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_relm_flags(BatchDev b) {
     uint8_t* row = b.relm + ((size_t)gr * b.cap_u + (size_t)(i - nb)) * b.relm_ld - nb - b.n_users[gr];
     for (int e = b.row_ptr[i] + t; e < b.row_ptr[i + 1]; e += 16) {
       uint8_t* q = row + (int)(b.ecr[e] & 0xFFFFFFu);
-      *q = (uint8_t)((*q & 7) | ((b.eflag[e] & 3) << 3));
+      *q = (uint8_t)((*q & IGMC_RELM_CODE) | ((b.eflag[e] & 3) << IGMC_RELM_KF));
       if (b.relmT) b.relmT[((size_t)gr * b.cap_v + ((int)(b.ecr[e] & 0xFFFFFFu) - nb - b.n_users[gr])) * b.relmT_ld + (i - nb)] = *q;
     }
   }
@@ -851,7 +851,7 @@ __device__ __forceinline__ void relm_dropout_body(const BatchDev& b, float p, in
       // user row: column -> row is item -> user (direction 1), row -> column is user -> item (direction 0)
       const uint32_t kf = igmc_u01(igmc_edge_hash(seed, step, (uint32_t)g, u, v, force_undirected ? 2u : 1u)) >= p;
       const uint32_t kt = igmc_u01(igmc_edge_hash(seed, step, (uint32_t)g, u, v, force_undirected ? 2u : 0u)) >= p;
-      w = (w & ~(0x18u << (8 * q))) | (((kf << 3) | (kt << 4)) << (8 * q));
+      w = (w & ~(IGMC_RELM_KEEP << (8 * q))) | (((kf << IGMC_RELM_KF) | (kt << IGMC_RELM_KT)) << (8 * q));
       if (b.relmT) b.relmT[((size_t)g * b.cap_v + 4 * k + q) * b.relmT_ld + row] = (uint8_t)((w >> (8 * q)) & 0xFFu);
     }
     rm[row * ldw + k] = w;

@@ -38,14 +38,14 @@ __device__ __forceinline__ f32x4 g2_mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
 #endif
 }
 
-// four relm bytes (bits 0..2: relation + 1, bit 3 / 4: keep flags of the two directions) -> two dwords of bf16 pairs
+// four relm bytes (common.h: bits 0..3 = relation + 1, bits 4 / 5 = keep flags of the two directions) -> two dwords of bf16 pairs
 // that are 1.0 where the byte's relation is r1 - 1 (and its keep bit is set)
 template <bool FLAGS>
 __device__ __forceinline__ void g2_expand4(uint32_t w, uint32_t r1, int keepbit, uint32_t& o01, uint32_t& o23) {
-  uint32_t mk = w & 0x07070707u;
-  if (FLAGS) mk &= ((w >> keepbit) & 0x01010101u) * 7u;
+  uint32_t mk = w & (0x01010101u * IGMC_RELM_CODE);
+  if (FLAGS) mk &= ((w >> keepbit) & 0x01010101u) * IGMC_RELM_CODE;
   const uint32_t t = mk ^ (0x01010101u * r1);
-  const uint32_t eq = ~(t + 0x7F7F7F7Fu) & 0x80808080u;        // bit 7 of a byte set <=> the byte of t is zero (t <= 7)
+  const uint32_t eq = ~(t + 0x7F7F7F7Fu) & 0x80808080u;        // bit 7 of a byte set <=> the byte of t is zero (t <= 15)
   const uint32_t mask = (eq >> 7) * 0xFFu;                      // 0xFF per matching byte
 #ifdef IGMC_HIPEMU
   o01 = ((mask & 0xFFu) ? 0x3F80u : 0u) | ((mask & 0xFF00u) ? 0x3F800000u : 0u);

@@ -395,7 +395,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
     uint32_t AB[FLAGS ? G2_NR : 1][FLAGS ? G2_KS : 1][4];
     {
       const unsigned char* rmo = RM + (size_t)side * rmr * rmp + (size_t)(row0 + li) * rmp;
-      const int kf = side ? 4 : 3, kb = side ? 3 : 4;     // keep bit of the edge  opposite -> own  /  own -> opposite
+      const int kf = side ? IGMC_RELM_KT : IGMC_RELM_KF, kb = side ? IGMC_RELM_KF : IGMC_RELM_KT;     // keep bit of the edge  opposite -> own  /  own -> opposite
 #pragma unroll
       for (int s = 0; s < G2_KS; ++s) {
         uint32_t w0 = 0u, w1 = 0u;
@@ -1385,7 +1385,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
     const int tstride = 32 * kp >> 1, toff = 16 * kp >> 1;
     const uint32_t* base = PLN + (li * kp >> 1) + 4 * kq;
     // keep bit of the direction this pass walks: forward = edge opposite -> own, backward = own -> opposite
-    const int kbit = BWD ? (side ? 3 : 4) : (side ? 4 : 3);
+    const int kbit = BWD ? (side ? IGMC_RELM_KF : IGMC_RELM_KT) : (side ? IGMC_RELM_KT : IGMC_RELM_KF);
 #pragma unroll 1
     for (int s = 0; s < nks; ++s) {
       const uint2 w = *(const uint2*)(rmo + 32 * s);
@@ -1729,7 +1729,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
   __syncthreads();
 
   const unsigned char* rmo = RMW + (size_t)(wave * 16 + li) * rmp + 8 * kq;
-  const int kbit = side ? 4 : 3;                   // keep bit of the edge opposite -> own
+  const int kbit = side ? IGMC_RELM_KT : IGMC_RELM_KF;                   // keep bit of the edge opposite -> own
   // epilogue of a layer: the bundle's rows -> LDS tile (next layer's own rows), h_l, exchange x = l (bf16 terms)
   auto fwd_out = [&](int l, const float (&v)[2][4], float* XO) {
     float* hrow = a.h[l] + (size_t)(own0 + row0 + 4 * kq) * 32 + li;
@@ -2004,7 +2004,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
   // (no barrier: the layer loop starts with one)
 
   const unsigned char* rmo = RMW + (size_t)(wave * 16 + li) * rmp + 8 * kq;
-  const int kbit = side ? 3 : 4;                   // keep bit of the edge own -> opposite
+  const int kbit = side ? IGMC_RELM_KF : IGMC_RELM_KT;                   // keep bit of the edge own -> opposite
   const int nbun = (n_own - 16 * DL_NW * q + 15) >> 4;
   const int nact = nbun < DL_NW ? nbun : DL_NW;    // bundles of this workgroup that hold rows
   float* XO = XOA + wave * 16 * G2_XP;
@@ -2300,7 +2300,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer0(Dl0Args a) {
     for (int r = 0; r < G2_NR; ++r) hacc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const unsigned char* rmo = RMW + (size_t)(wave * 16 + li) * rmp + 8 * kq;
     const uint32_t* ohp = OHP + ((li & 7) * kp >> 1) + 4 * kq;
-    const int kbit = side ? 4 : 3;                       // keep bit of the edge opposite -> own
+    const int kbit = side ? IGMC_RELM_KT : IGMC_RELM_KF;                       // keep bit of the edge opposite -> own
 #pragma unroll 1
     for (int s = 0; s < nks; ++s) {
       const uint2 w = *(const uint2*)(rmo + 32 * s);
