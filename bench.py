@@ -73,7 +73,7 @@ CONFIGS = {
 PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')      # (ml_1m; other configs: r04_pmc_traffic_<config>.json)
 # timer label of the HIP-event profile -> kernel symbol in the code object (what rocprofv3 lists)
 SYMBOLS = {'k_dl_layer_fwd': 'k_dl_layer<FLAGS, false, false>', 'k_rgcn_layer_fwd': 'k_rgcn_layer4<FLAGS, false>',
-           'k_dl_bwd': 'k_dl_bwd<FLAGS>', 'k_dl_fwd': 'k_dl_fwd<FLAGS, true>'}
+           'k_dl_bwd': 'k_dl_bwd<FLAGS, NG>', 'k_dl_fwd': 'k_dl_fwd<FLAGS, true, NG>'}
 
 
 def kernel_source_sha():
@@ -556,10 +556,10 @@ def main():
             flags = 'true' if cfg['adj_dropout'] > 0 else 'false'
             if dom == 'k_graph_step':
                 symbol = 'k_graph_step2<%s, true>' % flags
-            elif dom == 'k_dl_bwd':
-                symbol = 'k_dl_bwd<%s>' % flags
+            elif dom == 'k_dl_bwd':       # (NG: relation groups of five, graphstep2.hip)
+                symbol = 'k_dl_bwd<%s, %d>' % (flags, (len(class_values) + 4) // 5)
             elif dom == 'k_dl_fwd':
-                symbol = 'k_dl_fwd<%s, true>' % flags
+                symbol = 'k_dl_fwd<%s, true, %d>' % (flags, (len(class_values) + 4) // 5)
             roofline = dict(bound='hbm', kernel=symbol, timer_label=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
                             frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src, avg_us=avg_us,
                             avg_us_source='device launch clock under hipGraph replay + overlapped extraction'

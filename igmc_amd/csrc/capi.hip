@@ -1,6 +1,7 @@
 // capi.hip -- C-ABI host layer of libigmc_hip.so (see include/igmc_hip.h for the contract).
 #include "launch.h"
 #include "sortpool.h"
+#include "g2_image.h"
 
 #include <algorithm>
 #include <climits>
@@ -735,7 +736,7 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   d.ts_stride = (d.R * 32 + 33) * 32;
   d.fin_stash = nullptr;
   d.datt_part = nullptr;
-  if (d.R <= 5)
+  if (d.R <= G2_NR * G2_NG_MAX)
   {   // (sums + d att partials in ONE allocation: a data-parallel step exchanges them as one span)
     fail |= M.get(&d.ts_part, (size_t)4 * IGMC_TS_BLOCKS * d.ts_stride) |
             M.get(&d.ts_raw, (size_t)4 * d.ts_stride + (size_t)4 * d.ts_stride / 32 * 4);
@@ -750,11 +751,12 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   // kernel uses the first 128 nodes of a region.  655 KB per subgraph slot: HBM is not what this path is short of.
   d.ex_nodes = 256;
   d.g2_ex_stride = (size_t)Bc * 2 * 32 * d.ex_nodes;
-  if (d.R <= 5 && Bc <= 2048) {
-    fail |= M.get(&d.g2_ex, 5 * d.g2_ex_stride) | M.get(&d.g2_fx, Bc * 256) | M.get(&d.g2_w, (size_t)6 * 9216 + 1024);
+  const int wide = d.R <= G2_NR * G2_NG_MAX;      // relation groups of the dense-layer kernels (g2_image.h)
+  if (wide && Bc <= 2048) {
+    fail |= M.get(&d.g2_ex, 5 * d.g2_ex_stride) | M.get(&d.g2_fx, Bc * 256) | M.get(&d.g2_w, g2_w_words(d.R));
     d.g2_graphs = (int)Bc;
-  } else if (d.R <= 5) {
-    fail |= M.get(&d.g2_w, (size_t)6 * 9216 + 1024);      // weight images alone: the dense per-layer kernels (any head)
+  } else if (wide) {
+    fail |= M.get(&d.g2_w, g2_w_words(d.R));      // weight images alone: the dense per-layer kernels (any head)
   }
   fail |= M.get(&d.gs_bar, 2 * Bc + 1);
   fail |= M.get(&d.gs_ts, 4);
@@ -857,13 +859,14 @@ static void csr_for_model(const igmc_model* m, const igmc_batch* b, int dense_ca
   // dense per-layer path: it needs the node arrays only, and a lean extraction of such an arena (one with the transposed
   // block) has left them behind (k_emit_nodes in the extraction branch)
   if (igmc_dl_eligible(m->d, b->d, b->last_B) && b->d.relm && b->last_B > 0) return;
+  if (dense_capable_call && igmc_dl_wide(m->d, b->d, b->last_B) && b->last_B > 0) return;      // (relation groups: same)
   ensure_csr(b, stream);
 }
 
 // 1 when the dense per-layer kernels (k_dl_layer) take the conv layers of this arena
 extern "C" int igmc_model_dense_layers(const igmc_model* m, const igmc_batch* b, int B) {
   if (!m || !b) return 0;
-  return (igmc_dl_eligible(m->d, b->d, B)) ? 1 : 0;
+  return (igmc_dl_eligible(m->d, b->d, B) || igmc_dl_wide(m->d, b->d, B)) ? 1 : 0;
 }
 
 extern "C" int igmc_model_dense_path(const igmc_model* m, const igmc_batch* b, int B) {

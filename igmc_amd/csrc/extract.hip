@@ -846,7 +846,7 @@ __device__ __forceinline__ void relm_dropout_body(const BatchDev& b, float p, in
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const uint32_t by = (w >> (8 * q)) & 0xFFu;
-      if (!(by & 7u)) continue;
+      if (!(by & IGMC_RELM_CODE)) continue;
       const uint32_t v = (uint32_t)sg[b.cap_u + 4 * k + q];
       // user row: column -> row is item -> user (direction 1), row -> column is user -> item (direction 0)
       const uint32_t kf = igmc_u01(igmc_edge_hash(seed, step, (uint32_t)g, u, v, force_undirected ? 2u : 1u)) >= p;

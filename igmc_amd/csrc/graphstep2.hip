@@ -908,44 +908,50 @@ extern "C" int igmc_debug_g2_clocks(unsigned long long* out, int n) {
 // transposes), and the layer-0 table [W0[r*L + c] | root0[c] | bias0].  37 small workgroups: the launch is as long as one
 // round trip to the weights plus three 8-byte stores per thread.
 __global__ __launch_bounds__(G2_THREADS) void k_g2_compose(ModelDev m, const float* P, float* w) {
-  __shared__ float s_att[32];
+  __shared__ float s_att[4 * G2_NR * G2_NG_MAX];
   const int tid = threadIdx.x, R = m.R, L = m.L, RL = R * L, LF = L * 32;
-  // blockIdx.x: 2 * (3 layers x 6 matrices) image blocks (bit 0 = transposed), then the layer-0 table block
-  const int tableb = 2 * 3 * (G2_NR + 1);
-  const int l = ((int)blockIdx.x == tableb) ? 0 : 1 + (int)(blockIdx.x >> 1) / (G2_NR + 1), trans = blockIdx.x & 1;
+  // blockIdx.x: 2 * (3 layers x relation groups x 6 matrices) image blocks (bit 0 = transposed), then the layer-0 table blocks
+  // (32 rows each)
+  const int ng = g2_groups(R);
+  const int tableb = 2 * 3 * ng * (G2_NR + 1);
+  const int mi = (int)(blockIdx.x >> 1);                   // matrix of the images: (layer, group, block)
+  const int l = ((int)blockIdx.x >= tableb) ? 0 : 1 + mi / (ng * (G2_NR + 1)), trans = blockIdx.x & 1;
   // every global load of the block is requested before the first use (one round trip)
-  if ((int)blockIdx.x == tableb) {
+  if ((int)blockIdx.x >= tableb) {
+    const int c0 = 32 * ((int)blockIdx.x - tableb);        // first table row of this block
     const float attv = (tid < R * 4) ? P[m.off_att[0] + tid] : 0.f;
     float bv[4][4], rv[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int i = tid + q * G2_THREADS, c = i >> 5, f = i & 31;
+      const int i = tid + q * G2_THREADS, c = c0 + (i >> 5), f = i & 31;
       const int cf = (c < RL) ? (c % L) * 32 + f : 0;
 #pragma unroll
       for (int bb = 0; bb < 4; ++bb) bv[q][bb] = (c < RL) ? P[m.off_basis[0] + bb * LF + cf] : 0.f;
       rv[q] = (c >= RL && c < RL + L) ? P[m.off_root[0] + (c - RL) * 32 + f] : ((c == RL + L) ? P[m.off_bias[0] + f] : 0.f);
     }
-    if (tid < 32) s_att[tid] = attv;
+    if (tid < 4 * G2_NR * G2_NG_MAX) s_att[tid] = attv;
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int i = tid + q * G2_THREADS, c = i >> 5;
+      const int i = tid + q * G2_THREADS, c = c0 + (i >> 5);
       float sacc = rv[q];
       if (c < RL) {
         const int r = c / L;
         sacc = g2_wsum(s_att[r * 4], s_att[r * 4 + 1], s_att[r * 4 + 2], s_att[r * 4 + 3], bv[q][0], bv[q][1], bv[q][2], bv[q][3]);
       }
-      w[6 * G2_WIMG + i] = sacc;
+      w[g2_t0_off(ng) + (size_t)c0 * 32 + i] = sacc;
     }
     return;
   }
   // image blocks: one relation (G2_NR = the root matrix) of one image per workgroup; a thread takes the four
   // consecutive k of one column n, which are four consecutive bf16 of one lane's fragment: one 8-byte store per term
-  uint16_t* img = (uint16_t*)(w + (size_t)(blockIdx.x >> 1) / (G2_NR + 1) * 2 * G2_WIMG + (size_t)trans * G2_WIMG);
-  const int r = (blockIdx.x >> 1) % (G2_NR + 1);
+  const int grp = (mi / (G2_NR + 1)) % ng, blk = mi % (G2_NR + 1);
+  uint16_t* img = (uint16_t*)(w + g2_img_off(ng, l, trans, grp));
+  // block blk of group grp: relation G2_NR grp + blk; block G2_NR = root (group 0) / zero (the other groups)
+  const int r = (blk == G2_NR) ? ((grp == 0) ? -1 : R) : G2_NR * grp + blk;
   const int n = tid & 31, kg = tid >> 5;                  // element (k = 4 kg + q, n) of the block's B operand
   float v[4] = {0.f, 0.f, 0.f, 0.f};
-  if (r == G2_NR) {
+  if (r < 0) {
     const float* root = P + m.off_root[l];
     if (trans) {
       const float4 r4 = *(const float4*)(root + n * 32 + 4 * kg);
@@ -980,7 +986,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_compose(ModelDev m, const flo
   const uint32_t t3[3][2] = {{h01, h23}, {m01, m23}, {l01, l23}};
 #pragma unroll
   for (int t = 0; t < G2_NT; ++t)
-    *(uint2*)(img + ((size_t)(((t * (G2_NR + 1) + r) * 2 + nt) * 64 + lane)) * 8 + e0) = make_uint2(t3[t][0], t3[t][1]);
+    *(uint2*)(img + ((size_t)(((t * (G2_NR + 1) + blk) * 2 + nt) * 64 + lane)) * 8 + e0) = make_uint2(t3[t][0], t3[t][1]);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -1098,7 +1104,7 @@ int igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* P
   const int grid = (cs > 1) ? cs * B : igmc_gs_grid(B);
   const size_t sm = (size_t)lay.words * 4;
   if (!m.img_current) {
-    IGMC_PLAUNCH("k_g2_compose", k_g2_compose, 2 * 3 * (G2_NR + 1) + 1, G2_THREADS, 0, stream, m, P, m.g2_w);
+    IGMC_PLAUNCH("k_g2_compose", k_g2_compose, 2 * 3 * g2_groups(m.R) * (G2_NR + 1) + g2_t0_rows(m.R) / 32, G2_THREADS, 0, stream, m, P, m.g2_w);
     ++g_igmc_compose_count;
   }
 #ifdef IGMC_HIPEMU
@@ -1619,12 +1625,17 @@ struct DlfArgs {
   int self_seq;                  // 1: the last workgroup advances the launch sequence number (no kernel follows that would)
 };
 
-__host__ __device__ static inline int dlf_words(int kp) {
-  return 2 * DL_NW * 16 * G2_XP + (G2_NT * 32 * kp >> 1) + DL_NW * 4 * kp + G2_WIMG;
+// NG = relation groups (g2_image.h): NG > 1 takes the relations five at a time -- gather of group g, then the transform with
+// group g's image accumulating into the same output; one image is staged at a time (the next one is requested while the
+// current group's matrix work runs) -- and lays the 64-row layer-0 table behind the image.
+#define DLF_HP2 52                // pitch of a row's layer-0 input [hist | onehot | 1] with NG > 1 (R L + L + 1 <= 48)
+__host__ __device__ static inline int dlf_words(int kp, int ng = 1) {
+  return 2 * DL_NW * 16 * G2_XP + (G2_NT * 32 * kp >> 1) + DL_NW * 4 * kp + G2_WIMG + (ng > 1 ? 64 * 32 : 0);
 }
 
-template <bool FLAGS, bool STORE>
+template <bool FLAGS, bool STORE, int NG>
 __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
+  constexpr int HP = (NG == 1) ? G2_XP : DLF_HP2;
   IGMC_DYN_SMEM(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
@@ -1652,8 +1663,8 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
   float2* sW2 = (float2*)(RMW + DL_NW * 16 * rmp);                        // [G2_WIMG words]
   // layer 0 only, inside the image's space: one-hot label planes, the rows' inputs, the layer-0 table
   uint32_t* OHP = (uint32_t*)sW2;                                         // [8 labels][kp] bf16
-  float* HIA = (float*)(OHP + (8 * kp >> 1));                             // [DL_NW][16][G2_XP]
-  float* sT0 = HIA + DL_NW * 16 * G2_XP;                                  // [32][32]
+  float* HIA = (float*)(OHP + (8 * kp >> 1));                             // [DL_NW][16][HP]
+  float* sT0 = (NG == 1) ? HIA + DL_NW * 16 * G2_XP : (float*)sW2 + G2_WIMG;      // [32][32] / behind the image: [64][32]
   const int row0 = 16 * DL_NW * q + 16 * wave;
   const bool active = row0 < n_own;
   const size_t exs = a.ex_stride;
@@ -1687,11 +1698,13 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
     l0 = (2 * tid < n_opp) ? (int)a.node_label[opp0 + 2 * tid] : 255;
     l1 = (2 * tid + 1 < n_opp) ? (int)a.node_label[opp0 + 2 * tid + 1] : 255;
   }
-  const float2 t0v = ((const float2*)(a.g2_w + 6 * G2_WIMG))[tid];      // layer-0 table: 1024 floats
+  // layer-0 table: 1024 (NG = 1: eight bytes a thread) / 2048 floats
+  const float2 t0v = ((const float2*)(a.g2_w + g2_t0_off(NG)))[tid];
+  const float2 t0w = (NG > 1) ? ((const float2*)(a.g2_w + g2_t0_off(NG)))[DL_THREADS + tid] : make_float2(0.f, 0.f);
   constexpr int NWQ = (G2_WIMG / 4 + DL_THREADS - 1) / DL_THREADS;
   f32x4 wq[NWQ];                                  // a layer's weight image, requested a layer ahead
-  auto wpre = [&](int l) {
-    const f32x4* src = (const f32x4*)(a.g2_w + (size_t)((l - 1) * 2) * G2_WIMG);
+  auto wpre = [&](int l, int grp) {
+    const f32x4* src = (const f32x4*)(a.g2_w + g2_img_off(NG, l, 0, grp));
 #pragma unroll
     for (int u = 0; u < NWQ; ++u) {
       const int i = tid + u * DL_THREADS;
@@ -1710,7 +1723,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < (G2_NT * 32 * kp >> 3); i += DL_THREADS) ((float4*)PLN)[i] = z4;
     for (int i = tid; i < 2 * DL_NW * 16 * G2_XP / 4; i += DL_THREADS) ((float4*)XO0)[i] = z4;
-    for (int i = tid; i < DL_NW * 16 * G2_XP / 4; i += DL_THREADS) ((float4*)HIA)[i] = z4;
+    for (int i = tid; i < DL_NW * 16 * HP / 4; i += DL_THREADS) ((float4*)HIA)[i] = z4;
   }
   if (tid < 16 * nks) {
 #pragma unroll
@@ -1725,7 +1738,8 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
     }
   }
   ((float2*)sT0)[tid] = t0v;
-  wpre(1);
+  if (NG > 1) ((float2*)sT0)[DL_THREADS + tid] = t0w;
+  wpre(1, 0);
   __syncthreads();
 
   const unsigned char* rmo = RMW + (size_t)(wave * 16 + li) * rmp + 8 * kq;
@@ -1754,47 +1768,51 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
 
   // ================================================================ layer 0: h_0 = tanh([hist | onehot(label) | 1] @ T0)
   if (active) {
-    f32x4 hacc[G2_NR];
-#pragma unroll
-    for (int r = 0; r < G2_NR; ++r) hacc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const uint32_t* ohp = OHP + ((li & 7) * kp >> 1) + 4 * kq;
-#pragma unroll 1
-    for (int s = 0; s < nks; ++s) {
-      const uint2 w = *(const uint2*)(rmo + 32 * s);
-      u32x4 pfh = *(const u32x4*)(ohp + 16 * s);
-      if (li >= 8) pfh = (u32x4){0u, 0u, 0u, 0u};        // (label rows 8..15 of the 16-row operand do not exist)
-#pragma unroll
-      for (int r = 0; r < G2_NR; ++r) {
-        u32x4 af;
-        uint32_t a0, a1, a2, a3;
-        g2_expand4<FLAGS>(w.x, (uint32_t)(r + 1), kbit, a0, a1);
-        g2_expand4<FLAGS>(w.y, (uint32_t)(r + 1), kbit, a2, a3);
-        af[0] = a0; af[1] = a1; af[2] = a2; af[3] = a3;
-        hacc[r] = g2_mfma_bf16(pfh, af, hacc[r]);
-      }
-    }
-    float* hi = HIA + wave * 16 * G2_XP;
+    float* hi = HIA + wave * 16 * HP;
     const int row = row0 + li;
+#pragma unroll 1
+    for (int grp = 0; grp < NG; ++grp) {
+      const uint32_t rb = (uint32_t)(G2_NR * grp);
+      f32x4 hacc[G2_NR];
 #pragma unroll
-    for (int r = 0; r < G2_NR; ++r)
+      for (int r = 0; r < G2_NR; ++r) hacc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int s = 0; s < nks; ++s) {
+        const uint2 w = *(const uint2*)(rmo + 32 * s);
+        u32x4 pfh = *(const u32x4*)(ohp + 16 * s);
+        if (li >= 8) pfh = (u32x4){0u, 0u, 0u, 0u};        // (label rows 8..15 of the 16-row operand do not exist)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int c = 4 * kq + rr;
-        if (r < R && c < L) {
-          hi[li * G2_XP + r * L + c] = hacc[r][rr];
-          if (STORE && row < n_own) a.cnt0[(size_t)(own0 + row) * RL + r * L + c] = (uint16_t)(int)(hacc[r][rr] + 0.5f);
+        for (int r = 0; r < G2_NR; ++r) {
+          u32x4 af;
+          uint32_t a0, a1, a2, a3;
+          g2_expand4<FLAGS>(w.x, rb + (uint32_t)(r + 1), kbit, a0, a1);
+          g2_expand4<FLAGS>(w.y, rb + (uint32_t)(r + 1), kbit, a2, a3);
+          af[0] = a0; af[1] = a1; af[2] = a2; af[3] = a3;
+          hacc[r] = g2_mfma_bf16(pfh, af, hacc[r]);
         }
       }
+#pragma unroll
+      for (int r = 0; r < G2_NR; ++r)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int c = 4 * kq + rr, rg = (int)rb + r;
+          if (rg < R && c < L) {
+            hi[li * HP + rg * L + c] = hacc[r][rr];
+            if (STORE && row < n_own) a.cnt0[(size_t)(own0 + row) * RL + rg * L + c] = (uint16_t)(int)(hacc[r][rr] + 0.5f);
+          }
+        }
+    }
     if (kq == 0 && row < n_own) {
-      hi[li * G2_XP + RL + own_lab] = 1.f;
-      hi[li * G2_XP + RL + L] = 1.f;
+      hi[li * HP + RL + own_lab] = 1.f;
+      hi[li * HP + RL + L] = 1.f;
     }
     IGMC_WAVE_SYNC();                                // (the tile is this wave's own: no workgroup barrier)
     float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = 0.f;
     for (int c = 0; c <= RL + L; ++c) {
-      const float x = hi[li * G2_XP + c];
+      const float x = hi[li * HP + c];
       const float4 t0 = *(const float4*)(sT0 + c * 32 + 8 * kq), t1 = *(const float4*)(sT0 + c * 32 + 8 * kq + 4);
       o[0] += x * t0.x; o[1] += x * t0.y; o[2] += x * t0.z; o[3] += x * t0.w;
       o[4] += x * t1.x; o[5] += x * t1.y; o[6] += x * t1.z; o[7] += x * t1.w;
@@ -1822,38 +1840,60 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
     const float bias0 = a.P[a.off_bias[l] + li], bias1 = a.P[a.off_bias[l] + 16 + li];
     dlx_reload(PLN, kp, ex_opp + (l - 1) * exs, npad_opp, tag16(l - 1), a.gs_err);
     __syncthreads();
-    if (l < 3) wpre(l + 1);
-    if (active) {
-      f32x4 acc[G2_NR][2];
-#pragma unroll
-      for (int r = 0; r < G2_NR; ++r) {
-        acc[r][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        acc[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-      const int tstride = 32 * kp >> 1, toff = 16 * kp >> 1;
-      const uint32_t* base = PLN + (li * kp >> 1) + 4 * kq;
+    f32x4 o[2];
+    o[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    o[1] = o[0];
 #pragma unroll 1
-      for (int s = 0; s < nks; ++s) {
-        const uint2 w = *(const uint2*)(rmo + 32 * s);
-        u32x4 pf[2 * G2_NT];
-#pragma unroll
-        for (int sp = 0; sp < G2_NT; ++sp) {
-          pf[2 * sp] = *(const u32x4*)(base + sp * tstride + 16 * s);
-          pf[2 * sp + 1] = *(const u32x4*)(base + sp * tstride + toff + 16 * s);
-        }
+    for (int grp = 0; grp < NG; ++grp) {
+      const uint32_t rb = (uint32_t)(G2_NR * grp);
+      if (grp > 0) {                                 // the next group's image takes the place of the last one
+        __syncthreads();
+        stage();
+        __syncthreads();
+      }
+      if (grp + 1 < NG) wpre(l, grp + 1);
+      else if (l < 3) wpre(l + 1, 0);
+      if (active) {
+        f32x4 acc[G2_NR][2];
 #pragma unroll
         for (int r = 0; r < G2_NR; ++r) {
-          u32x4 af;
-          uint32_t a0, a1, a2, a3;
-          g2_expand4<FLAGS>(w.x, (uint32_t)(r + 1), kbit, a0, a1);
-          g2_expand4<FLAGS>(w.y, (uint32_t)(r + 1), kbit, a2, a3);
-          af[0] = a0; af[1] = a1; af[2] = a2; af[3] = a3;
+          acc[r][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          acc[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const int tstride = 32 * kp >> 1, toff = 16 * kp >> 1;
+        const uint32_t* base = PLN + (li * kp >> 1) + 4 * kq;
+#pragma unroll 1
+        for (int s = 0; s < nks; ++s) {
+          const uint2 w = *(const uint2*)(rmo + 32 * s);
+          u32x4 pf[2 * G2_NT];
 #pragma unroll
-          for (int qq = 0; qq < 2 * G2_NT; ++qq) acc[r][qq & 1] = g2_mfma_bf16(pf[qq], af, acc[r][qq & 1]);
+          for (int sp = 0; sp < G2_NT; ++sp) {
+            pf[2 * sp] = *(const u32x4*)(base + sp * tstride + 16 * s);
+            pf[2 * sp + 1] = *(const u32x4*)(base + sp * tstride + toff + 16 * s);
+          }
+#pragma unroll
+          for (int r = 0; r < G2_NR; ++r) {
+            u32x4 af;
+            uint32_t a0, a1, a2, a3;
+            g2_expand4<FLAGS>(w.x, rb + (uint32_t)(r + 1), kbit, a0, a1);
+            g2_expand4<FLAGS>(w.y, rb + (uint32_t)(r + 1), kbit, a2, a3);
+            af[0] = a0; af[1] = a1; af[2] = a2; af[3] = a3;
+#pragma unroll
+            for (int qq = 0; qq < 2 * G2_NT; ++qq) acc[r][qq & 1] = g2_mfma_bf16(pf[qq], af, acc[r][qq & 1]);
+          }
+        }
+        f32x4 og[2];
+        g2_transform(acc, XOc, (const uint32_t*)sW2, li, kq, og);      // (group > 0: block G2_NR of the image is zero)
+        if (NG == 1) {
+          o[0] = og[0];
+          o[1] = og[1];
+        } else {
+          o[0] += og[0];
+          o[1] += og[1];
         }
       }
-      f32x4 o[2];
-      g2_transform(acc, XOc, (const uint32_t*)sW2, li, kq, o);
+    }
+    if (active) {
       float v[2][4];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
@@ -1896,8 +1936,13 @@ __host__ __device__ static inline int dlb_words(int kp) {
   return 2 * DL_NW * 16 * G2_XP + DL_NW * 4 * kp + (mid > til ? mid : til);
 }
 
-template <bool FLAGS>
+// NG > 1 (relation groups, g2_image.h): a layer runs group after group -- gather, transform (accumulating dX), T' tiles, the
+// group's blocks of the table -- and because the tiles take the planes' space, the planes of dPre_l are read again from the
+// exchange words (still in place: L2-resident) before the next group's gather.
+template <bool FLAGS, int NG>
 __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
+  constexpr int HP = (NG == 1) ? G2_XP : DLF_HP2;           // pitch of a row's layer-0 input
+  constexpr int C0N = (NG == 1) ? 5 : 11;                   // histogram entries a lane holds: 16 R L / 64
   IGMC_DYN_SMEM(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
@@ -1951,9 +1996,9 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
     rmq[u] = ((const uint32_t*)(rsrc + (size_t)rc * ldb))[cc];
   }
   const float d3 = (tid < 64) ? a.dpre3[(size_t)((tid >> 5) ? own0 : opp0) * 32 + (tid & 31)] : 0.f;   // opposite | own target row
-  uint16_t c0q[5];
+  uint16_t c0q[C0N];
 #pragma unroll
-  for (int u = 0; u < 5; ++u) {
+  for (int u = 0; u < C0N; ++u) {
     const int i = lane + 64 * u, r = i / RL, c = i - r * RL;
     const int rc = (r < 16 && row0 + r < n_own) ? row0 + r : n_own - 1;
     c0q[u] = a.cnt0[(size_t)(own0 + rc) * RL + (r < 16 ? c : 0)];
@@ -1961,8 +2006,8 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
   const int own_lab = (int)a.node_label[own0 + (row0 + li < n_own ? row0 + li : n_own - 1)];
   constexpr int NWQ = (G2_WIMG / 4 + DL_THREADS - 1) / DL_THREADS;
   f32x4 wq[NWQ];                                  // a layer's transposed weight image: requested at the top of the layer,
-  auto wpre = [&](int l) {                        // stored behind the exchange poll (held across a layer it costs 38 spills)
-    const f32x4* src = (const f32x4*)(a.g2_w + (size_t)((l - 1) * 2 + 1) * G2_WIMG);
+  auto wpre = [&](int l, int grp) {               // stored behind the exchange poll (held across a layer it costs 38 spills)
+    const f32x4* src = (const f32x4*)(a.g2_w + g2_img_off(NG, l, 1, grp));
 #pragma unroll
     for (int u = 0; u < NWQ; ++u) {
       const int i = tid + u * DL_THREADS;
@@ -2019,153 +2064,186 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
 #pragma unroll 1
   for (int l = 3; l >= 1; --l) {
     float* wpart = a.ts_part + ((size_t)l * IGMC_TS_BLOCKS + slot) * ts;
-    wpre(l);
-    if (l < 3) dlx_reload(PLN, kp, ex_opp + (5 - l) * exs, npad_opp, tag16(5 - l), a.gs_err);
-    stage();
-    __syncthreads();                               // planes, image, dPre_l of the rows are in place
-    {   // d bias_l = column sums of dPre_l over the workgroup's rows (fixed order)
-      const int n = tid & 31, part = tid >> 5;
-      float sb = 0.f;
-      for (int row = part; row < DL_NW * 16; row += DL_THREADS / 32) sb += XOA[(row >> 4) * 16 * G2_XP + (row & 15) * G2_XP + n];
-      sbias[part * 32 + n] = sb;
-    }
-    __syncthreads();
-    if (tid < 32) {
-      float s2 = 0.f;
-#pragma unroll
-      for (int p = 0; p < DL_THREADS / 32; ++p) s2 += sbias[p * 32 + tid];
-      wpart[(R * 32 + 32) * 32 + tid] = s2;
-    }
-    f32x4 acc[G2_NR][2];
-#pragma unroll
-    for (int r = 0; r < G2_NR; ++r) {
-      acc[r][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      acc[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    float xprev[2][4];
+    float xprev[2][4], addv[2][4];
+    f32x4 o[2];
+    o[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    o[1] = o[0];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) xprev[nt][rr] = 0.f;
-    if (active) {
-      float addv[2][4];
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int rw2 = row0 + 4 * kq + rr, rwc = rw2 < n_own ? rw2 : n_own - 1;
-          xprev[nt][rr] = a.h[l - 1][(size_t)(own0 + rwc) * 32 + 16 * nt + li];
-          addv[nt][rr] = (rw2 == 0) ? a.gfeat[(size_t)g * a.D + side * 128 + (l - 1) * 32 + 16 * nt + li] : 0.f;
-        }
-      const int tstride = 32 * kp >> 1, toff = 16 * kp >> 1;
-      const uint32_t* base = PLN + (li * kp >> 1) + 4 * kq;
-      const int nke = (l == 3) ? 1 : nks;           // dPre_3 lives on node 0: one k-step
+      for (int rr = 0; rr < 4; ++rr) {
+        xprev[nt][rr] = 0.f;
+        addv[nt][rr] = 0.f;
+      }
 #pragma unroll 1
-      for (int s = 0; s < nke; ++s) {
-        const uint2 w = *(const uint2*)(rmo + 32 * s);
-        u32x4 pf[2 * G2_NT];
-#pragma unroll
-        for (int sp = 0; sp < G2_NT; ++sp) {
-          pf[2 * sp] = *(const u32x4*)(base + sp * tstride + 16 * s);
-          pf[2 * sp + 1] = *(const u32x4*)(base + sp * tstride + toff + 16 * s);
+    for (int grp = 0; grp < NG; ++grp) {
+      const uint32_t rb = (uint32_t)(G2_NR * grp);
+      wpre(l, grp);
+      if (l < 3) dlx_reload(PLN, kp, ex_opp + (5 - l) * exs, npad_opp, tag16(5 - l), a.gs_err);
+      else if (grp > 0 && tid < 32) {                // dPre_3 of the opposite side's target node again (the tiles took its place)
+        uint32_t h, mi, lo;
+        g2_split2(d3, 0.f, h, mi, lo);
+        uint32_t* p2 = PLN + (tid * kp >> 1);
+        p2[0] = h & 0xFFFFu;
+        p2[32 * kp >> 1] = mi & 0xFFFFu;
+        p2[2 * (32 * kp >> 1)] = lo & 0xFFFFu;
+      }
+      stage();
+      __syncthreads();                               // planes, image, dPre_l of the rows are in place
+      if (grp == 0) {   // d bias_l = column sums of dPre_l over the workgroup's rows (fixed order)
+        {
+          const int n = tid & 31, part = tid >> 5;
+          float sb = 0.f;
+          for (int row = part; row < DL_NW * 16; row += DL_THREADS / 32) sb += XOA[(row >> 4) * 16 * G2_XP + (row & 15) * G2_XP + n];
+          sbias[part * 32 + n] = sb;
         }
+        __syncthreads();
+        if (tid < 32) {
+          float s2 = 0.f;
 #pragma unroll
-        for (int r = 0; r < G2_NR; ++r) {
-          u32x4 af;
-          uint32_t a0, a1, a2, a3;
-          g2_expand4<FLAGS>(w.x, (uint32_t)(r + 1), kbit, a0, a1);
-          g2_expand4<FLAGS>(w.y, (uint32_t)(r + 1), kbit, a2, a3);
-          af[0] = a0; af[1] = a1; af[2] = a2; af[3] = a3;
-#pragma unroll
-          for (int qq = 0; qq < 2 * G2_NT; ++qq) acc[r][qq & 1] = g2_mfma_bf16(pf[qq], af, acc[r][qq & 1]);
+          for (int p = 0; p < DL_THREADS / 32; ++p) s2 += sbias[p * 32 + tid];
+          wpart[(R * 32 + 32) * 32 + tid] = s2;
         }
       }
-      f32x4 o[2];
-      g2_transform(acc, XO, (const uint32_t*)sW2, li, kq, o);
-      unsigned long long* exb = ex_own + (6 - l) * exs + (size_t)li * DLX_K + row0 + 4 * kq;
-      const uint32_t tgb = tag16(6 - l);
+      f32x4 acc[G2_NR][2];
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const bool ok = row0 + 4 * kq + rr < n_own;
-          const float x = xprev[nt][rr];
-          dv[nt][rr] = ok ? (o[nt][rr] + addv[nt][rr]) * (1.f - x * x) : 0.f;
-          if (!ok) xprev[nt][rr] = 0.f;             // (rows past the side: zero K entries of the table product)
-        }
-        if (l > 1) g2_publish4(exb + (size_t)nt * 16 * DLX_K, 0, dv[nt], tgb);
+      for (int r = 0; r < G2_NR; ++r) {
+        acc[r][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
-    }
-    __syncthreads();                               // every wave is done with planes / image: the T' tiles take their space
-    if (active) {
+      if (active) {
+        if (grp == 0) {
 #pragma unroll
-      for (int r = 0; r < G2_NR; ++r)
+          for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-          *(float4*)(T + li * G2_TP + r * 32 + 16 * t + 4 * kq) = make_float4(acc[r][t][0], acc[r][t][1], acc[r][t][2], acc[r][t][3]);
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) HS[(4 * kq + rr) * G2_XP + 16 * nt + li] = xprev[nt][rr];
-    }
-    __syncthreads();
-    {   // table h_{l-1}^T [T'_0 .. T'_4 | dPre_l]: 2 x 12 output tiles over the 8 waves, K = the active bundles' rows
-      f32x4 w3[3];
-#pragma unroll
-      for (int i3 = 0; i3 < 3; ++i3) w3[i3] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const int m2w = wave >> 2, nt0 = 3 * (wave & 3);
+            for (int rr = 0; rr < 4; ++rr) {
+              const int rw2 = row0 + 4 * kq + rr, rwc = rw2 < n_own ? rw2 : n_own - 1;
+              const float hv = a.h[l - 1][(size_t)(own0 + rwc) * 32 + 16 * nt + li];
+              xprev[nt][rr] = (rw2 < n_own) ? hv : 0.f;      // (rows past the side: zero K entries of the table product)
+              addv[nt][rr] = (rw2 == 0) ? a.gfeat[(size_t)g * a.D + side * 128 + (l - 1) * 32 + 16 * nt + li] : 0.f;
+            }
+        }
+        const int tstride = 32 * kp >> 1, toff = 16 * kp >> 1;
+        const uint32_t* base = PLN + (li * kp >> 1) + 4 * kq;
+        const int nke = (l == 3) ? 1 : nks;           // dPre_3 lives on node 0: one k-step
 #pragma unroll 1
-      for (int wb = 0; wb < nact; ++wb) {
-        const float* Tb = TIL + wb * 16 * G2_TP;
-        const float* Hb = HSA + wb * 16 * G2_XP;
-        const float* Db = XOA + wb * 16 * G2_XP;
-        float av[4], bw[4][3];
+        for (int s = 0; s < nke; ++s) {
+          const uint2 w = *(const uint2*)(rmo + 32 * s);
+          u32x4 pf[2 * G2_NT];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-          av[s4] = Hb[(4 * s4 + kq) * G2_XP + m2w * 16 + li];
+          for (int sp = 0; sp < G2_NT; ++sp) {
+            pf[2 * sp] = *(const u32x4*)(base + sp * tstride + 16 * s);
+            pf[2 * sp + 1] = *(const u32x4*)(base + sp * tstride + toff + 16 * s);
+          }
 #pragma unroll
-          for (int i3 = 0; i3 < 3; ++i3) {
-            const int nt = nt0 + i3;
-            bw[s4][i3] = (nt < 2 * G2_NR) ? Tb[(4 * s4 + kq) * G2_TP + nt * 16 + li]
-                                          : Db[(4 * s4 + kq) * G2_XP + (nt - 2 * G2_NR) * 16 + li];
+          for (int r = 0; r < G2_NR; ++r) {
+            u32x4 af;
+            uint32_t a0, a1, a2, a3;
+            g2_expand4<FLAGS>(w.x, rb + (uint32_t)(r + 1), kbit, a0, a1);
+            g2_expand4<FLAGS>(w.y, rb + (uint32_t)(r + 1), kbit, a2, a3);
+            af[0] = a0; af[1] = a1; af[2] = a2; af[3] = a3;
+#pragma unroll
+            for (int qq = 0; qq < 2 * G2_NT; ++qq) acc[r][qq & 1] = g2_mfma_bf16(pf[qq], af, acc[r][qq & 1]);
           }
         }
-        G2_SCHED_BARRIER();
+        f32x4 og[2];
+        g2_transform(acc, XO, (const uint32_t*)sW2, li, kq, og);       // (group > 0: block G2_NR of the image is zero)
+        if (NG == 1) {
+          o[0] = og[0];
+          o[1] = og[1];
+        } else {
+          o[0] += og[0];
+          o[1] += og[1];
+        }
+        if (grp == NG - 1) {
+          unsigned long long* exb = ex_own + (6 - l) * exs + (size_t)li * DLX_K + row0 + 4 * kq;
+          const uint32_t tgb = tag16(6 - l);
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
+          for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
-          for (int i3 = 0; i3 < 3; ++i3) w3[i3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bw[s4][i3], w3[i3], 0, 0, 0);
+            for (int rr = 0; rr < 4; ++rr) {
+              const bool ok = row0 + 4 * kq + rr < n_own;
+              const float x = xprev[nt][rr];
+              dv[nt][rr] = ok ? (o[nt][rr] + addv[nt][rr]) * (1.f - x * x) : 0.f;
+            }
+            if (l > 1) g2_publish4(exb + (size_t)nt * 16 * DLX_K, 0, dv[nt], tgb);
+          }
+        }
       }
-#pragma unroll
-      for (int i3 = 0; i3 < 3; ++i3) {
-        const int nt = nt0 + i3, r = nt >> 1;
-        if (r >= R && r < G2_NR) continue;
-        float* pp = wpart + (kq * 4) * 32 + li + (r < R ? r : R) * 1024 + m2w * 512 + (nt & 1) * 16;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) pp[rr * 32] = w3[i3][rr];
-      }
-    }
-    __syncthreads();                               // tiles, h rows and dPre_l are consumed
-    if (l > 1) {
-      // dPre_{l-1} of the rows becomes the next layer's own rows; the planes' first k-steps were tiles: zero what the next
-      // reload does not cover
+      __syncthreads();                               // every wave is done with planes / image: the T' tiles take their space
       if (active) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int r = 0; r < G2_NR; ++r)
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) XO[(4 * kq + rr) * G2_XP + 16 * nt + li] = dv[nt][rr];
+          for (int t = 0; t < 2; ++t)
+            *(float4*)(T + li * G2_TP + r * 32 + 16 * t + 4 * kq) = make_float4(acc[r][t][0], acc[r][t][1], acc[r][t][2], acc[r][t][3]);
+        if (grp == 0) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) HS[(4 * kq + rr) * G2_XP + 16 * nt + li] = xprev[nt][rr];
+        }
       }
-      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int i = tid; i < (G2_NT * 32 * kp >> 3); i += DL_THREADS) ((float4*)PLN)[i] = z4;
-      __syncthreads();                             // (the zero fill is complete before the reload writes into it)
+      __syncthreads();
+      {   // table h_{l-1}^T [T'_0 .. T'_4 | dPre_l] of the group: 2 x 12 output tiles over the 8 waves, K = the active bundles' rows
+        f32x4 w3[3];
+#pragma unroll
+        for (int i3 = 0; i3 < 3; ++i3) w3[i3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int m2w = wave >> 2, nt0 = 3 * (wave & 3);
+#pragma unroll 1
+        for (int wb = 0; wb < nact; ++wb) {
+          const float* Tb = TIL + wb * 16 * G2_TP;
+          const float* Hb = HSA + wb * 16 * G2_XP;
+          const float* Db = XOA + wb * 16 * G2_XP;
+          float av[4], bw[4][3];
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            av[s4] = Hb[(4 * s4 + kq) * G2_XP + m2w * 16 + li];
+#pragma unroll
+            for (int i3 = 0; i3 < 3; ++i3) {
+              const int nt = nt0 + i3;
+              bw[s4][i3] = (nt < 2 * G2_NR) ? Tb[(4 * s4 + kq) * G2_TP + nt * 16 + li]
+                                            : Db[(4 * s4 + kq) * G2_XP + (nt - 2 * G2_NR) * 16 + li];
+            }
+          }
+          G2_SCHED_BARRIER();
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int i3 = 0; i3 < 3; ++i3) w3[i3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bw[s4][i3], w3[i3], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i3 = 0; i3 < 3; ++i3) {
+          const int nt = nt0 + i3, r = nt >> 1;         // 32-column block: relation rb + r, or G2_NR = dPre_l (d root: group 0)
+          const int rg = (int)rb + r;
+          if (r < G2_NR ? rg >= R : grp > 0) continue;
+          float* pp = wpart + (kq * 4) * 32 + li + (r < G2_NR ? rg : R) * 1024 + m2w * 512 + (nt & 1) * 16;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) pp[rr * 32] = w3[i3][rr];
+        }
+      }
+      __syncthreads();                               // tiles, h rows and dPre_l are consumed
+      if (l > 1 || grp + 1 < NG) {
+        // dPre_{l-1} of the rows becomes the next layer's own rows (after the layer's last group); the planes' first k-steps
+        // were tiles: zero what the next reload does not cover
+        if (active && grp == NG - 1) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) XO[(4 * kq + rr) * G2_XP + 16 * nt + li] = dv[nt][rr];
+        }
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < (G2_NT * 32 * kp >> 3); i += DL_THREADS) ((float4*)PLN)[i] = z4;
+        __syncthreads();                             // (the zero fill is complete before the reload writes into it)
+      }
     }
   }
   // ---- layer-0 table gradient T0'[c][f] = sum_i [hist | onehot | 1](i, c) dPre_0[i][f] over the workgroup's rows
   {
-    float* HI = TIL + wave * 16 * G2_XP;
-    float* D0 = TIL + (DL_NW + wave) * 16 * G2_XP;
+    float* HI = TIL + wave * 16 * HP;
+    float* D0 = TIL + DL_NW * 16 * HP + wave * 16 * G2_XP;
     if (active) {
-      for (int i = lane; i < 16 * G2_XP; i += 64) HI[i] = 0.f;
+      for (int i = lane; i < 16 * HP; i += 64) HI[i] = 0.f;
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -2174,25 +2252,25 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
     __syncthreads();
     if (active) {
 #pragma unroll
-      for (int u = 0; u < 5; ++u) {
+      for (int u = 0; u < C0N; ++u) {
         const int i = lane + 64 * u, r = i / RL, c = i - r * RL;
-        if (r < 16 && row0 + r < n_own) HI[r * G2_XP + c] = (float)c0q[u];
+        if (r < 16 && row0 + r < n_own) HI[r * HP + c] = (float)c0q[u];
       }
       if (kq == 0 && row0 + li < n_own) {
-        HI[li * G2_XP + RL + own_lab] = 1.f;
-        HI[li * G2_XP + RL + L] = 1.f;
+        HI[li * HP + RL + own_lab] = 1.f;
+        HI[li * HP + RL + L] = 1.f;
       }
     }
     __syncthreads();
-    if (wave < 4) {
+    if (wave < 4 * NG) {                             // (code rows m2 * 16 .., feature half wn): 32 / 64 table rows
       const int m2 = wave >> 1, wn = wave & 1;
       f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
       for (int wb = 0; wb < nact; ++wb) {
-        const float* Hb = TIL + wb * 16 * G2_XP;
-        const float* Db = TIL + (DL_NW + wb) * 16 * G2_XP;
+        const float* Hb = TIL + wb * 16 * HP;
+        const float* Db = TIL + DL_NW * 16 * HP + wb * 16 * G2_XP;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Hb[(4 * s4 + kq) * G2_XP + m2 * 16 + li],
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Hb[(4 * s4 + kq) * HP + m2 * 16 + li],
                                                       Db[(4 * s4 + kq) * G2_XP + wn * 16 + li], acc0, 0, 0, 0);
       }
 #pragma unroll
@@ -2385,12 +2463,18 @@ static size_t dl_lds(int kp, bool ts = false) {
 }
 
 // 1 = the dense per-layer kernels take the conv layers of this arena (IGMC_DL=0 switches them off)
-int igmc_dl_eligible(const ModelDev& m, const BatchDev& b, int B) {
+static int dl_base_ok(const ModelDev& m, const BatchDev& b, int B, int wide) {
   const char* e = getenv("IGMC_DL");
   if (e && atoi(e) == 0) return 0;
-  if (!b.relm || !b.relmT || !m.g2_w || m.R > G2_NR || m.L > 8 || m.R * m.L + m.L + 1 > 32) return 0;
+  if (!b.relm || !b.relmT || !m.g2_w || m.L > 8) return 0;
+  const int rows0 = m.R * m.L + m.L + 1;
+  if (wide ? (m.R <= G2_NR || m.R > G2_NR * G2_NG_MAX || rows0 > 48) : (m.R > G2_NR || rows0 > 32)) return 0;
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
-  if (cmax > 256 || B * 2 * ((cmax + 16 * DL_NW - 1) / (16 * DL_NW)) > IGMC_GATHER_BLOCKS) return 0;
+  return cmax <= 256 && B * 2 * ((cmax + 16 * DL_NW - 1) / (16 * DL_NW)) <= IGMC_GATHER_BLOCKS;
+}
+int igmc_dl_eligible(const ModelDev& m, const BatchDev& b, int B) {
+  if (!dl_base_ok(m, b, B, 0)) return 0;
+  const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
   return dl_lds(32 * ((cmax + 31) >> 5) + 8) <= (size_t)160 * 1024;
 }
 
@@ -2414,7 +2498,7 @@ int igmc_dl_grid(const BatchDev& b, int B) {
 void igmc_launch_g2_compose(const ModelDev& m, const float* P, void* stream) {
   if (m.img_current) return;      // (igmc_model_weights_unchanged: the images of these parameters are in place)
   ++g_igmc_compose_count;
-  IGMC_PLAUNCH("k_g2_compose", k_g2_compose, 2 * 3 * (G2_NR + 1) + 1, G2_THREADS, 0, stream, m, P, m.g2_w);
+  IGMC_PLAUNCH("k_g2_compose", k_g2_compose, 2 * 3 * g2_groups(m.R) * (G2_NR + 1) + g2_t0_rows(m.R) / 32, G2_THREADS, 0, stream, m, P, m.g2_w);
 }
 
 // one conv layer pass: forward (bwd = 0: h_{l-1} -> h_l) or backward (dPre_l -> dPre_{l-1}, G, d att partials)
@@ -2489,21 +2573,49 @@ void igmc_launch_dl_fwd(const ModelDev& m, const BatchDev& b, const float* P, in
   a.gs_bar = m.gs_bar; a.gs_err = m.gs_err;
   a.self_seq = self_seq;
   const int grid = B * 2 * a.nq;
-  const size_t sm = (size_t)dlf_words(a.kp) * 4;
+  const int ng = g2_groups(m.R);
+  const size_t sm = (size_t)dlf_words(a.kp, ng) * 4;
 #ifdef IGMC_HIPEMU
   hipemu::rt().co_cs = 2 * a.nq;                   // the members of a subgraph run together
   hipemu::rt().co_stride = -1;                     // (= consecutive workgroups)
 #endif
-  if (training) {
-    if (use_flags) IGMC_PLAUNCH("k_dl_fwd", (k_dl_fwd<true, true>), grid, DL_THREADS, sm, stream, a);
-    else IGMC_PLAUNCH("k_dl_fwd", (k_dl_fwd<false, true>), grid, DL_THREADS, sm, stream, a);
+  if (ng == 1) {
+    if (training) {
+      if (use_flags) IGMC_PLAUNCH("k_dl_fwd", (k_dl_fwd<true, true, 1>), grid, DL_THREADS, sm, stream, a);
+      else IGMC_PLAUNCH("k_dl_fwd", (k_dl_fwd<false, true, 1>), grid, DL_THREADS, sm, stream, a);
+    } else {
+      if (use_flags) IGMC_PLAUNCH("k_dl_fwd", (k_dl_fwd<true, false, 1>), grid, DL_THREADS, sm, stream, a);
+      else IGMC_PLAUNCH("k_dl_fwd", (k_dl_fwd<false, false, 1>), grid, DL_THREADS, sm, stream, a);
+    }
   } else {
-    if (use_flags) IGMC_PLAUNCH("k_dl_fwd", (k_dl_fwd<true, false>), grid, DL_THREADS, sm, stream, a);
-    else IGMC_PLAUNCH("k_dl_fwd", (k_dl_fwd<false, false>), grid, DL_THREADS, sm, stream, a);
+    if (training) {
+      if (use_flags) IGMC_PLAUNCH("k_dl_fwd", (k_dl_fwd<true, true, 2>), grid, DL_THREADS, sm, stream, a);
+      else IGMC_PLAUNCH("k_dl_fwd", (k_dl_fwd<false, true, 2>), grid, DL_THREADS, sm, stream, a);
+    } else {
+      if (use_flags) IGMC_PLAUNCH("k_dl_fwd", (k_dl_fwd<true, false, 2>), grid, DL_THREADS, sm, stream, a);
+      else IGMC_PLAUNCH("k_dl_fwd", (k_dl_fwd<false, false, 2>), grid, DL_THREADS, sm, stream, a);
+    }
   }
 }
 
 // (k_dl_bwd: same conditions as k_dl_fwd -- whose launch precedes it and maintains the exchange regions -- plus the tables')
+// 1 = more than G2_NR relations (<= G2_NR * G2_NG_MAX, layer-0 table <= 48 rows) on the one-launch dense kernels, which take the
+// relations in groups: k_dl_fwd / k_head_sub / k_dl_bwd<*, NG> with the relation-space tables behind them -- all of it or
+// nothing (the per-layer kernels k_dl_layer0 / k_dl_layer stop at G2_NR relations)
+int igmc_dl_wide(const ModelDev& m, const BatchDev& b, int B) {
+  if (!dl_base_ok(m, b, B, 1)) return 0;
+  const char* e = getenv("IGMC_DL_FUSED");
+  if (e && atoi(e) != 2) return 0;
+  const char* et = getenv("IGMC_DL_TS");
+  if (et && atoi(et) == 0) return 0;
+  if (!m.g2_ex || m.ex_nodes < DLX_K || b.graph_cap > m.g2_graphs || !m.ts_part || !m.cnt0) return 0;
+  const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
+  const int nq = (cmax + 16 * DL_NW - 1) / (16 * DL_NW), stride = (B + 7) & ~7, kp = 32 * ((cmax + 31) >> 5) + 8;
+  if (B * 2 * nq > 224 || 2 * nq * stride > IGMC_TS_BLOCKS) return 0;
+  const int ng = g2_groups(m.R);
+  return (size_t)dlf_words(kp, ng) * 4 <= (size_t)160 * 1024 && (size_t)dlb_words(kp) * 4 <= (size_t)160 * 1024;
+}
+
 int igmc_dl_bwd_eligible(const ModelDev& m, const BatchDev& b, int B) {
   if (!igmc_dl_fwd_eligible(m, b, B) || !igmc_dl_ts_eligible(m, b, B)) return 0;
   const char* e = getenv("IGMC_DL_FUSED");
@@ -2531,8 +2643,13 @@ void igmc_launch_dl_bwd(const ModelDev& m, const BatchDev& b, int B, int use_fla
   hipemu::rt().co_cs = 2 * a.nq;
   hipemu::rt().co_stride = -1;
 #endif
-  if (use_flags) IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<true>), grid, DL_THREADS, sm, stream, a);
-  else IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<false>), grid, DL_THREADS, sm, stream, a);
+  if (g2_groups(m.R) == 1) {
+    if (use_flags) IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<true, 1>), grid, DL_THREADS, sm, stream, a);
+    else IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<false, 1>), grid, DL_THREADS, sm, stream, a);
+  } else {
+    if (use_flags) IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<true, 2>), grid, DL_THREADS, sm, stream, a);
+    else IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<false, 2>), grid, DL_THREADS, sm, stream, a);
+  }
 }
 
 int igmc_dl_prepare() {
@@ -2544,12 +2661,11 @@ int igmc_dl_prepare() {
   if (hipFuncSetAttribute((const void*)k_dl_layer<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_dl_layer<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_dl_layer<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
-  if (hipFuncSetAttribute((const void*)k_dl_bwd<true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
-  if (hipFuncSetAttribute((const void*)k_dl_bwd<false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
-  if (hipFuncSetAttribute((const void*)k_dl_fwd<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
-  if (hipFuncSetAttribute((const void*)k_dl_fwd<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
-  if (hipFuncSetAttribute((const void*)k_dl_fwd<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
-  if (hipFuncSetAttribute((const void*)k_dl_fwd<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+#define DL_MAXLDS(k) if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1
+  DL_MAXLDS((k_dl_bwd<true, 1>)); DL_MAXLDS((k_dl_bwd<false, 1>)); DL_MAXLDS((k_dl_bwd<true, 2>)); DL_MAXLDS((k_dl_bwd<false, 2>));
+  DL_MAXLDS((k_dl_fwd<true, true, 1>)); DL_MAXLDS((k_dl_fwd<false, true, 1>)); DL_MAXLDS((k_dl_fwd<true, false, 1>)); DL_MAXLDS((k_dl_fwd<false, false, 1>));
+  DL_MAXLDS((k_dl_fwd<true, true, 2>)); DL_MAXLDS((k_dl_fwd<false, true, 2>)); DL_MAXLDS((k_dl_fwd<true, false, 2>)); DL_MAXLDS((k_dl_fwd<false, false, 2>));
+#undef DL_MAXLDS
   if (hipFuncSetAttribute((const void*)k_dl_layer0<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_dl_layer0<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_dl_layer0<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;

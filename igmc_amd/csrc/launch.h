@@ -97,6 +97,7 @@ void igmc_launch_dl_layer0(const ModelDev& m, const BatchDev& b, int B, int trai
 int igmc_dl_ts_eligible(const ModelDev& m, const BatchDev& b, int B);
 int igmc_dl_fwd_eligible(const ModelDev& m, const BatchDev& b, int B);
 int igmc_dl_bwd_eligible(const ModelDev& m, const BatchDev& b, int B);
+int igmc_dl_wide(const ModelDev& m, const BatchDev& b, int B);
 void igmc_launch_dl_bwd(const ModelDev& m, const BatchDev& b, int B, int use_flags, void* stream);
 void igmc_launch_dl_fwd(const ModelDev& m, const BatchDev& b, const float* P, int B, int training, int use_flags,
                         float* zero_out, int self_seq, void* stream);

@@ -2204,8 +2204,10 @@ void igmc_launch_conv_forward(const ModelDev& m, const BatchDev& b, const float*
   const int g64 = igmc_rows_grid(m.node_cap, 64, 512);
   // slots of 129..256 nodes a side with a dense block: every conv layer on the matrix cores (graphstep2.hip, k_dl_layer0 /
   // k_dl_layer) from the blocks alone -- no edge list is read
-  const int dl = igmc_dl_eligible(m, b, B);
-  const int dlf = dl && igmc_dl_fwd_eligible(m, b, B);
+  // (more than five relations: the one-launch forward takes them in groups, igmc_dl_wide)
+  const int wide = igmc_dl_wide(m, b, B);
+  const int dl = wide || igmc_dl_eligible(m, b, B);
+  const int dlf = wide || (dl && igmc_dl_fwd_eligible(m, b, B));
   if (dlf) {                                              // all four layers in ONE launch (k_dl_fwd); nothing follows that
     igmc_launch_g2_compose(m, P, stream);                 // would advance its exchange tags: its last workgroup does
     igmc_launch_dl_fwd(m, b, P, B, training, use_flags, training ? m.dpre[3] : nullptr, 1, stream);
@@ -2392,12 +2394,14 @@ int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchD
   const int gt = igmc_xcd_grid(m, B, 16, 2048);
   // slots of 129..256 nodes a side with a dense block: every conv layer on the matrix cores (graphstep2.hip, k_dl_layer0 /
   // k_dl_layer) from the blocks alone -- no edge list is read
-  const int dl = igmc_dl_eligible(m, b, B);
   // ... and all four of them as ONE launch where the members of a subgraph can hand h_l to each other (k_dl_fwd); the launch
   // sequence number of its exchange tags is advanced by k_tail_ts (tables path) -- else by the launch's last workgroup
-  const int fts_pre = igmc_fin_mode() && m.fin_stash && m.datt_part && m.R <= 8;
-  const int dlts = dl && l0_mfma && fts_pre && igmc_dl_ts_eligible(m, b, B);
-  const int dlf = dl && igmc_dl_fwd_eligible(m, b, B);
+  const int fts_pre = igmc_fin_mode() && m.fin_stash && m.datt_part && m.R <= G2_NR * G2_NG_MAX;
+  // more than five relations (igmc_dl_wide): the one-launch forward / backward in relation groups + the tables' tail, or nothing
+  const int wide = fts_pre && igmc_dl_wide(m, b, B);
+  const int dl = wide || igmc_dl_eligible(m, b, B);
+  const int dlts = wide || (dl && l0_mfma && fts_pre && m.R <= 8 && igmc_dl_ts_eligible(m, b, B));
+  const int dlf = wide || (dl && igmc_dl_fwd_eligible(m, b, B));
   if (dlf) {
     igmc_launch_g2_compose(m, (const float*)P, stream);
     igmc_launch_dl_fwd(m, b, (const float*)P, B, 1, use_flags, m.dpre[3], dlts ? 0 : 1, stream);
@@ -2425,7 +2429,7 @@ int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchD
   if (dlts) {
     // the head: one workgroup per subgraph (side features included)
     igmc_launch_head_sub(m, b, (const float*)P, B, inj_mask, seed, step, mult, grad_scale, out, stream);
-    if (dlf && igmc_dl_bwd_eligible(m, b, B))
+    if (wide || (dlf && igmc_dl_bwd_eligible(m, b, B)))
       igmc_launch_dl_bwd(m, b, B, use_flags, stream);         // the three backward layers as ONE launch
     else
       for (int l = 3; l >= 1; --l) igmc_launch_dl_layer(m, b, (const float*)P, B, l, 1, use_flags, nullptr, stream, 1);

@@ -446,6 +446,20 @@ TRAJ_P_MAX = 3e-4                              # largest parameter difference af
 
 
 def run_fused_train_trajectory(be, case, R, steps=5, batch=None, use_dropout=False, lr=1e-3, ARR=0.001, seed=4):
+    """The trajectory check below with the ORACLE on one torch thread: the order of its CPU scatter-adds then does not depend
+    on the host (128 / 8 / 1 threads moved flixster's exp_avg deviation between 8e-6 and 1.3e-4 with the engine's bits
+    unchanged -- one parameter whose gradient is within float noise of zero takes its Adam step the other way:
+    profiles/r04_flixster_trajectory_oracle_spread.txt)."""
+    import torch
+    nt = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        return _run_fused_train_trajectory(be, case, R, steps, batch, use_dropout, lr, ARR, seed)
+    finally:
+        torch.set_num_threads(nt)
+
+
+def _run_fused_train_trajectory(be, case, R, steps=5, batch=None, use_dropout=False, lr=1e-3, ARR=0.001, seed=4):
     """``igmc_train_step`` (the fused single-GPU step: k_graph_step -> k_tail_ts -> k_finalize_ts with Adam, or the
     per-layer kernels + k_finalize where the subgraph kernel is not eligible) for ``steps`` consecutive steps on
     DIFFERENT batches with injected masks, against ``pyg_ref.train_step`` + ``torch.optim.Adam`` on the same batches

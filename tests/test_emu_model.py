@@ -314,3 +314,33 @@ def test_kernels_against_the_reference_models_py_fixtures(be, case):
     from helpers import load_model_golden
     res = PC.run_reference_fixture(be, load_model_golden(case), 8)
     assert res['worst_grad_rel'] < PC.GRAD_TOL and res['params_frac_off'] == 0.0
+
+
+@pytest.mark.parametrize('drop,lean', [(False, False), (True, True)])
+def test_dense_layers_with_ten_relations(be, monkeypatch, drop, lean):
+    """More than five relations on the matrix cores (flixster: ten rating levels, reference Main.py:387
+    num_relations = len(class_values)): k_dl_fwd / k_dl_bwd take the relations in groups of five -- one weight image per group,
+    a 64-row layer-0 table -- and the relation-space tables' tail turns them into gradients.  Forward, loss and every
+    gradient vs the oracle."""
+    monkeypatch.setenv('IGMC_DL_ALWAYS', '1')
+    res = PC.run_model_parity(be, sub('flixster', 5), R=10, use_dropout=drop, lean=lean)
+    assert res['worst_grad_err'] < 1e-4
+    assert res['batch'].dense_layers(res['ws'])
+
+
+def test_ten_relations_in_the_fused_train_step(be, monkeypatch):
+    """... and inside igmc_train_step: four steps on different batches track pyg_ref.train_step + torch.optim.Adam."""
+    monkeypatch.setenv('IGMC_DL_ALWAYS', '1')
+    monkeypatch.setenv('IGMC_GS_TRACE', '1')
+    res = PC.run_fused_train_trajectory(be, sub('flixster', 16), R=10, steps=4, batch=4, use_dropout=True)
+    assert res['frac_off'] < 2e-3
+
+
+def test_free_running_dropout_on_a_lean_arena_with_ten_relations(be, monkeypatch):
+    """... with relation codes past 7 in the block bytes (flixster): every edge takes part in the draws on the dense blocks
+    (the same flags as the eager CSR draws), and the relation-group kernels with them match the oracle."""
+    monkeypatch.setenv('IGMC_DL_ALWAYS', '1')
+    res = PC.run_free_running_dropout(be, sub('flixster', 16), R=10, force_undirected=False, lean=True)
+    assert res['worst_grad_err'] < 1e-4
+    eager = PC.run_free_running_dropout(be, sub('flixster', 16), R=10, force_undirected=False, lean=False)
+    assert eager['keep_rate'] == res['keep_rate']

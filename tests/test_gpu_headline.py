@@ -125,6 +125,32 @@ def test_uncapped_douban_takes_the_subgraph_kernel(be):
 
 
 
+@pytest.mark.parametrize('drop,lean', [(False, False), (True, True)])
+def test_flixster_ten_relations_take_the_dense_layers(be, drop, lean):
+    """flixster (ten rating levels, reference Main.py:387; slots of up to 155 items a side): k_dl_fwd / k_dl_bwd take the
+    relations in two groups of five on the matrix cores; forward, loss and every gradient vs the oracle."""
+    case = monti_case('flixster', 50)
+    res = PC.run_model_parity(be, case, R=10, use_dropout=drop, lean=lean)
+    assert res['worst_grad_err'] < PC.GRAD_TOL
+    assert res['batch'].dense_layers(res['ws'])
+
+
+@pytest.mark.parametrize('force_undirected', [False, True])
+def test_flixster_free_running_dropout_on_the_dense_blocks(be, force_undirected):
+    case = monti_case('flixster', 40)
+    res = PC.run_free_running_dropout(be, case, R=10, p=0.2, force_undirected=force_undirected, lean=True)
+    assert res['worst_grad_err'] < PC.GRAD_TOL
+
+
+def test_flixster_fused_train_steps_are_bit_reproducible(be):
+    """Five fused steps on the relation-group kernels, twice from the same state: the same bits (fixed-order reductions)."""
+    case = monti_case('flixster', 250)
+    runs = [PC.run_fused_train_trajectory(be, case, R=10, steps=5, batch=50, use_dropout=True) for _ in range(2)]
+    assert runs[0]['frac_off'] < PC.TRAJ_FRAC_OFF
+    for k in ('params', 'm1', 'm2'):
+        assert np.array_equal(runs[0][k], runs[1][k]), k
+
+
 @pytest.mark.parametrize('lean', [False, True])
 def test_ml100k_cap200_batch_matches_oracle(be, lean):
     """BASELINE.json configs[1]: ml_100k shape, cap 200, adj-dropout 0.2, batch 50 -- slots of 201 nodes a side: the dense
