@@ -17,6 +17,18 @@
   } while (0)
 #endif
 
+// ... and of the one-launch dense layers (IGMC_DL_TIMING=<workgroup + 1>; igmc_debug_g2_clocks): k_dl_fwd -> slots 0..39,
+// k_dl_bwd -> slots 40..127
+#ifdef IGMC_HIPEMU
+#define DL_STAMP(k) do { } while (0)
+#else
+#define DL_STAMP(k)                                                                               \
+  do {                                                                                            \
+    if (a.timing && threadIdx.x == 0 && (int)blockIdx.x == a.timing - 1 && (k) < 128)             \
+      g_g2_clk[k] = __builtin_readcyclecounter();                                                 \
+  } while (0)
+#endif
+
 // keeps per-lane index arithmetic INSIDE the phase it is used in (LLVM otherwise hoists hundreds of loop-invariant LDS
 // addresses out of the layer loops and spills them)
 #ifdef IGMC_HIPEMU

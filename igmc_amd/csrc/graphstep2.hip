@@ -1623,6 +1623,7 @@ struct DlfArgs {
   int* gs_bar;
   int* gs_err;
   int self_seq;                  // 1: the last workgroup advances the launch sequence number (no kernel follows that would)
+  int timing;                    // debug aid: workgroup + 1 whose phase clocks are recorded (DL_STAMP)
 };
 
 // NG = relation groups (g2_image.h): NG > 1 takes the relations five at a time -- gather of group g, then the transform with
@@ -1650,6 +1651,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
     dlx_seq_done(a.gs_bar, a.self_seq);
     return;
   }
+  DL_STAMP(0);
   const int R = a.R, L = a.L, RL = R * L;
   const int nb = a.node_off[g];
   const int own0 = nb + (side ? cu : 0), opp0 = nb + (side ? 0 : cu);
@@ -1741,6 +1743,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
   if (NG > 1) ((float2*)sT0)[DL_THREADS + tid] = t0w;
   wpre(1, 0);
   __syncthreads();
+  DL_STAMP(1);
 
   const unsigned char* rmo = RMW + (size_t)(wave * 16 + li) * rmp + 8 * kq;
   const int kbit = side ? IGMC_RELM_KT : IGMC_RELM_KF;                   // keep bit of the edge opposite -> own
@@ -1830,6 +1833,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
     fwd_out(0, v, XO0 + wave * 16 * G2_XP);
   }
   __syncthreads();                                   // the image's space (one-hot planes, inputs, table) is free
+  DL_STAMP(2);
 
   // ================================================================ conv layers 1..3
 #pragma unroll 1
@@ -1838,8 +1842,10 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
     float* XOn = ((l & 1) ? XO1 : XO0) + wave * 16 * G2_XP;      // h_l
     stage();
     const float bias0 = a.P[a.off_bias[l] + li], bias1 = a.P[a.off_bias[l] + 16 + li];
+    DL_STAMP(3 + (l - 1) * 9);
     dlx_reload(PLN, kp, ex_opp + (l - 1) * exs, npad_opp, tag16(l - 1), a.gs_err);
     __syncthreads();
+    DL_STAMP(4 + (l - 1) * 9);
     f32x4 o[2];
     o[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     o[1] = o[0];
@@ -1853,6 +1859,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
       }
       if (grp + 1 < NG) wpre(l, grp + 1);
       else if (l < 3) wpre(l + 1, 0);
+      DL_STAMP(5 + (l - 1) * 9 + 3 * grp);
       if (active) {
         f32x4 acc[G2_NR][2];
 #pragma unroll
@@ -1882,8 +1889,10 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
             for (int qq = 0; qq < 2 * G2_NT; ++qq) acc[r][qq & 1] = g2_mfma_bf16(pf[qq], af, acc[r][qq & 1]);
           }
         }
+        DL_STAMP(6 + (l - 1) * 9 + 3 * grp);
         f32x4 og[2];
         g2_transform(acc, XOc, (const uint32_t*)sW2, li, kq, og);      // (group > 0: block G2_NR of the image is zero)
+        DL_STAMP(7 + (l - 1) * 9 + 3 * grp);
         if (NG == 1) {
           o[0] = og[0];
           o[1] = og[1];
@@ -1902,8 +1911,10 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
       }
       fwd_out(l, v, XOn);
     }
+    DL_STAMP(11 + (l - 1) * 9);
     __syncthreads();                                 // planes / image may be overwritten
   }
+  DL_STAMP(30);
   dlx_seq_done(a.gs_bar, a.self_seq);
 }
 
@@ -1929,16 +1940,19 @@ struct DlbArgs {
   size_t ex_stride;
   int* gs_bar;
   int* gs_err;
+  int timing;
 };
 
-__host__ __device__ static inline int dlb_words(int kp) {
+// (ng > 1: the T' tiles of FOUR bundles at a time, over the image alone -- the planes stay in place for the next group)
+__host__ __device__ static inline int dlb_words(int kp, int ng = 1) {
   const int mid = (G2_NT * 32 * kp >> 1) + G2_WIMG, til = DL_NW * 16 * G2_TP;
+  if (ng > 1) return 2 * DL_NW * 16 * G2_XP + DL_NW * 4 * kp + (G2_NT * 32 * kp >> 1) + (DL_NW / 2) * 16 * G2_TP;
   return 2 * DL_NW * 16 * G2_XP + DL_NW * 4 * kp + (mid > til ? mid : til);
 }
 
 // NG > 1 (relation groups, g2_image.h): a layer runs group after group -- gather, transform (accumulating dX), T' tiles, the
-// group's blocks of the table -- and because the tiles take the planes' space, the planes of dPre_l are read again from the
-// exchange words (still in place: L2-resident) before the next group's gather.
+// group's blocks of the table.  The next group's gather needs the planes again, so here the tiles take the place of the
+// IMAGE only: four bundles' tiles at a time (two rounds of the table product for a workgroup with more than four bundles).
 template <bool FLAGS, int NG>
 __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
   constexpr int HP = (NG == 1) ? G2_XP : DLF_HP2;           // pitch of a row's layer-0 input
@@ -1963,6 +1977,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
     for (int i = tid; i < rows0 * 8; i += DL_THREADS) ((float4*)part0)[i] = z4;
     return;
   }
+  DL_STAMP(40);
   const uint32_t seq = g2_ld_seq(a.gs_bar);
   const uint32_t tag0 = seq * 8u + 1u;
   auto tag16 = [&](int x) { return 1u + (tag0 + (uint32_t)x) % 65535u; };
@@ -1977,7 +1992,8 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
   unsigned char* RMW = (unsigned char*)(HSA + DL_NW * 16 * G2_XP);        // [DL_NW][16][rmp] bytes
   uint32_t* PLN = (uint32_t*)(RMW + DL_NW * 16 * rmp);                    // [3][32][kp] bf16
   float2* sW2 = (float2*)(PLN + (G2_NT * 32 * kp >> 1));                  // [G2_WIMG words]
-  float* TIL = (float*)PLN;                                               // [DL_NW][16][G2_TP] T' tiles (alias planes + image)
+  // T' tiles: [DL_NW][16][G2_TP] over planes + image (NG = 1) / [DL_NW / 2][16][G2_TP] over the image (NG > 1)
+  float* TIL = (NG == 1) ? (float*)PLN : (float*)sW2;
   const int row0 = 16 * DL_NW * q + 16 * wave;
   const bool active = row0 < n_own;
   const size_t exs = a.ex_stride;
@@ -1996,13 +2012,11 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
     rmq[u] = ((const uint32_t*)(rsrc + (size_t)rc * ldb))[cc];
   }
   const float d3 = (tid < 64) ? a.dpre3[(size_t)((tid >> 5) ? own0 : opp0) * 32 + (tid & 31)] : 0.f;   // opposite | own target row
+  // (the rows' neighbour-label histograms -- the layer-0 table's inputs -- are requested under the LAST table product: held
+  //  from here they cost registers, and spills, through all three layers)
   uint16_t c0q[C0N];
 #pragma unroll
-  for (int u = 0; u < C0N; ++u) {
-    const int i = lane + 64 * u, r = i / RL, c = i - r * RL;
-    const int rc = (r < 16 && row0 + r < n_own) ? row0 + r : n_own - 1;
-    c0q[u] = a.cnt0[(size_t)(own0 + rc) * RL + (r < 16 ? c : 0)];
-  }
+  for (int u = 0; u < C0N; ++u) c0q[u] = 0;
   const int own_lab = (int)a.node_label[own0 + (row0 + li < n_own ? row0 + li : n_own - 1)];
   constexpr int NWQ = (G2_WIMG / 4 + DL_THREADS - 1) / DL_THREADS;
   f32x4 wq[NWQ];                                  // a layer's transposed weight image: requested at the top of the layer,
@@ -2053,7 +2067,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
   const int nbun = (n_own - 16 * DL_NW * q + 15) >> 4;
   const int nact = nbun < DL_NW ? nbun : DL_NW;    // bundles of this workgroup that hold rows
   float* XO = XOA + wave * 16 * G2_XP;
-  float* T = TIL + wave * 16 * G2_TP;
+  float* T = TIL + ((NG == 1) ? wave : (wave & 3)) * 16 * G2_TP;
   float* HS = HSA + wave * 16 * G2_XP;
   float dv[2][4];
 #pragma unroll
@@ -2075,21 +2089,41 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
         xprev[nt][rr] = 0.f;
         addv[nt][rr] = 0.f;
       }
+    if (active) {   // h_{l-1} of the rows and the readout gradient: requested ahead of the exchange poll / the image
+      int lane_ = lane;
+      G2_OPAQUE(lane_);
+      const int li_ = lane_ & 15, kq_ = lane_ >> 4;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int rw2 = row0 + 4 * kq_ + rr, rwc = rw2 < n_own ? rw2 : n_own - 1;
+          const float hv = a.h[l - 1][(size_t)(own0 + rwc) * 32 + 16 * nt + li_];
+          xprev[nt][rr] = (rw2 < n_own) ? hv : 0.f;      // (rows past the side: zero K entries of the table product)
+          addv[nt][rr] = (rw2 == 0) ? a.gfeat[(size_t)g * a.D + side * 128 + (l - 1) * 32 + 16 * nt + li_] : 0.f;
+        }
+    }
 #pragma unroll 1
     for (int grp = 0; grp < NG; ++grp) {
       const uint32_t rb = (uint32_t)(G2_NR * grp);
+      const int sk = 42 + ((3 - l) * NG + grp) * 7;      // (phase clocks)
+      // per-lane indices re-derived from an opaque copy of the thread index: what is computed from them stays inside the
+      // group's pass (hoisted above the layer loop, the loop-invariant addresses occupy -- and spill -- registers throughout)
+      int tid_g = threadIdx.x;
+      G2_OPAQUE(tid_g);
+      const int tid = tid_g, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+      const int row0 = 16 * DL_NW * q + 16 * wave;
+      const bool active = row0 < n_own;
+      const unsigned char* rmo = RMW + (size_t)(wave * 16 + li) * rmp + 8 * kq;
+      float* XO = XOA + wave * 16 * G2_XP;
+      float* T = TIL + ((NG == 1) ? wave : (wave & 3)) * 16 * G2_TP;
+      float* HS = HSA + wave * 16 * G2_XP;
+      DL_STAMP(sk);
       wpre(l, grp);
-      if (l < 3) dlx_reload(PLN, kp, ex_opp + (5 - l) * exs, npad_opp, tag16(5 - l), a.gs_err);
-      else if (grp > 0 && tid < 32) {                // dPre_3 of the opposite side's target node again (the tiles took its place)
-        uint32_t h, mi, lo;
-        g2_split2(d3, 0.f, h, mi, lo);
-        uint32_t* p2 = PLN + (tid * kp >> 1);
-        p2[0] = h & 0xFFFFu;
-        p2[32 * kp >> 1] = mi & 0xFFFFu;
-        p2[2 * (32 * kp >> 1)] = lo & 0xFFFFu;
-      }
+      if (l < 3 && grp == 0) dlx_reload(PLN, kp, ex_opp + (5 - l) * exs, npad_opp, tag16(5 - l), a.gs_err);
       stage();
       __syncthreads();                               // planes, image, dPre_l of the rows are in place
+      DL_STAMP(sk + 1);
       if (grp == 0) {   // d bias_l = column sums of dPre_l over the workgroup's rows (fixed order)
         {
           const int n = tid & 31, part = tid >> 5;
@@ -2105,6 +2139,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
           wpart[(R * 32 + 32) * 32 + tid] = s2;
         }
       }
+      DL_STAMP(sk + 2);
       f32x4 acc[G2_NR][2];
 #pragma unroll
       for (int r = 0; r < G2_NR; ++r) {
@@ -2112,17 +2147,6 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
         acc[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
       if (active) {
-        if (grp == 0) {
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-              const int rw2 = row0 + 4 * kq + rr, rwc = rw2 < n_own ? rw2 : n_own - 1;
-              const float hv = a.h[l - 1][(size_t)(own0 + rwc) * 32 + 16 * nt + li];
-              xprev[nt][rr] = (rw2 < n_own) ? hv : 0.f;      // (rows past the side: zero K entries of the table product)
-              addv[nt][rr] = (rw2 == 0) ? a.gfeat[(size_t)g * a.D + side * 128 + (l - 1) * 32 + 16 * nt + li] : 0.f;
-            }
-        }
         const int tstride = 32 * kp >> 1, toff = 16 * kp >> 1;
         const uint32_t* base = PLN + (li * kp >> 1) + 4 * kq;
         const int nke = (l == 3) ? 1 : nks;           // dPre_3 lives on node 0: one k-step
@@ -2146,6 +2170,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
             for (int qq = 0; qq < 2 * G2_NT; ++qq) acc[r][qq & 1] = g2_mfma_bf16(pf[qq], af, acc[r][qq & 1]);
           }
         }
+        DL_STAMP(sk + 3);
         f32x4 og[2];
         g2_transform(acc, XO, (const uint32_t*)sW2, li, kq, og);       // (group > 0: block G2_NR of the image is zero)
         if (NG == 1) {
@@ -2167,50 +2192,72 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
               dv[nt][rr] = ok ? (o[nt][rr] + addv[nt][rr]) * (1.f - x * x) : 0.f;
             }
             if (l > 1) g2_publish4(exb + (size_t)nt * 16 * DLX_K, 0, dv[nt], tgb);
+            if (NG > 1 && l > 1) {                   // dPre_{l-1} of the rows becomes the next layer's own rows: nobody reads
+#pragma unroll                                       // this tile any more (the d root block belongs to group 0's product)
+              for (int rr = 0; rr < 4; ++rr) XO[(4 * kq + rr) * G2_XP + 16 * nt + li] = dv[nt][rr];
+            }
           }
         }
       }
+      DL_STAMP(sk + 4);
       __syncthreads();                               // every wave is done with planes / image: the T' tiles take their space
-      if (active) {
+      DL_STAMP(sk + 5);
+      if (l == 1 && grp == NG - 1) {
+        int lane_ = lane;                            // (opaque: the address arithmetic stays here, not above the layer loop)
+        G2_OPAQUE(lane_);
 #pragma unroll
-        for (int r = 0; r < G2_NR; ++r)
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-            *(float4*)(T + li * G2_TP + r * 32 + 16 * t + 4 * kq) = make_float4(acc[r][t][0], acc[r][t][1], acc[r][t][2], acc[r][t][3]);
-        if (grp == 0) {
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) HS[(4 * kq + rr) * G2_XP + 16 * nt + li] = xprev[nt][rr];
+        for (int u = 0; u < C0N; ++u) {
+          const int i = lane_ + 64 * u, r = i / RL, c = i - r * RL;
+          const int rc = (r < 16 && row0 + r < n_own) ? row0 + r : n_own - 1;
+          c0q[u] = a.cnt0[(size_t)(own0 + rc) * RL + (r < 16 ? c : 0)];
         }
       }
-      __syncthreads();
+      if (active && grp == 0) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) HS[(4 * kq + rr) * G2_XP + 16 * nt + li] = xprev[nt][rr];
+      }
       {   // table h_{l-1}^T [T'_0 .. T'_4 | dPre_l] of the group: 2 x 12 output tiles over the 8 waves, K = the active bundles' rows
         f32x4 w3[3];
 #pragma unroll
         for (int i3 = 0; i3 < 3; ++i3) w3[i3] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int m2w = wave >> 2, nt0 = 3 * (wave & 3);
+        constexpr int TB = (NG == 1) ? DL_NW : DL_NW / 2;      // bundles whose tiles are in LDS at a time
 #pragma unroll 1
-        for (int wb = 0; wb < nact; ++wb) {
-          const float* Tb = TIL + wb * 16 * G2_TP;
-          const float* Hb = HSA + wb * 16 * G2_XP;
-          const float* Db = XOA + wb * 16 * G2_XP;
-          float av[4], bw[4][3];
+        for (int wb0 = 0; wb0 < nact; wb0 += TB) {
+          if (wb0 > 0) __syncthreads();              // (the last round's tiles are consumed)
+          if (active && wave >= wb0 && wave < wb0 + TB) {
 #pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4) {
-            av[s4] = Hb[(4 * s4 + kq) * G2_XP + m2w * 16 + li];
+            for (int r = 0; r < G2_NR; ++r)
 #pragma unroll
-            for (int i3 = 0; i3 < 3; ++i3) {
-              const int nt = nt0 + i3;
-              bw[s4][i3] = (nt < 2 * G2_NR) ? Tb[(4 * s4 + kq) * G2_TP + nt * 16 + li]
-                                            : Db[(4 * s4 + kq) * G2_XP + (nt - 2 * G2_NR) * 16 + li];
-            }
+              for (int t = 0; t < 2; ++t)
+                *(float4*)(T + li * G2_TP + r * 32 + 16 * t + 4 * kq) = make_float4(acc[r][t][0], acc[r][t][1], acc[r][t][2], acc[r][t][3]);
           }
-          G2_SCHED_BARRIER();
+          __syncthreads();
+          const int wb1 = (wb0 + TB < nact) ? wb0 + TB : nact;
+#pragma unroll 1
+          for (int wb = wb0; wb < wb1; ++wb) {
+            const float* Tb = TIL + (wb - wb0) * 16 * G2_TP;
+            const float* Hb = HSA + wb * 16 * G2_XP;
+            const float* Db = XOA + wb * 16 * G2_XP;
+            float av[4], bw[4][3];
 #pragma unroll
-          for (int s4 = 0; s4 < 4; ++s4)
+            for (int s4 = 0; s4 < 4; ++s4) {
+              av[s4] = Hb[(4 * s4 + kq) * G2_XP + m2w * 16 + li];
 #pragma unroll
-            for (int i3 = 0; i3 < 3; ++i3) w3[i3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bw[s4][i3], w3[i3], 0, 0, 0);
+              for (int i3 = 0; i3 < 3; ++i3) {
+                const int nt = nt0 + i3;
+                bw[s4][i3] = (nt < 2 * G2_NR) ? Tb[(4 * s4 + kq) * G2_TP + nt * 16 + li]
+                                              : Db[(4 * s4 + kq) * G2_XP + (nt - 2 * G2_NR) * 16 + li];
+              }
+            }
+            G2_SCHED_BARRIER();
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+              for (int i3 = 0; i3 < 3; ++i3) w3[i3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bw[s4][i3], w3[i3], 0, 0, 0);
+          }
         }
 #pragma unroll
         for (int i3 = 0; i3 < 3; ++i3) {
@@ -2222,26 +2269,31 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
           for (int rr = 0; rr < 4; ++rr) pp[rr * 32] = w3[i3][rr];
         }
       }
+      DL_STAMP(sk + 6);
       __syncthreads();                               // tiles, h rows and dPre_l are consumed
-      if (l > 1 || grp + 1 < NG) {
-        // dPre_{l-1} of the rows becomes the next layer's own rows (after the layer's last group); the planes' first k-steps
-        // were tiles: zero what the next reload does not cover
-        if (active && grp == NG - 1) {
+      if (NG == 1) {
+        if (l > 1) {
+          // dPre_{l-1} of the rows becomes the next layer's own rows; the planes' first k-steps were tiles: zero what the
+          // next reload does not cover
+          if (active) {
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) XO[(4 * kq + rr) * G2_XP + 16 * nt + li] = dv[nt][rr];
+              for (int rr = 0; rr < 4; ++rr) XO[(4 * kq + rr) * G2_XP + 16 * nt + li] = dv[nt][rr];
+          }
+          const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int i = tid; i < (G2_NT * 32 * kp >> 3); i += DL_THREADS) ((float4*)PLN)[i] = z4;
+          __syncthreads();                           // (the zero fill is complete before the reload writes into it)
         }
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = tid; i < (G2_NT * 32 * kp >> 3); i += DL_THREADS) ((float4*)PLN)[i] = z4;
-        __syncthreads();                             // (the zero fill is complete before the reload writes into it)
-      }
+      }                                              // (NG > 1: planes untouched, the rows' dPre_{l-1} written by the epilogue)
     }
   }
+  DL_STAMP(41);
   // ---- layer-0 table gradient T0'[c][f] = sum_i [hist | onehot | 1](i, c) dPre_0[i][f] over the workgroup's rows
   {
-    float* HI = TIL + wave * 16 * HP;
-    float* D0 = TIL + DL_NW * 16 * HP + wave * 16 * G2_XP;
+    float* L0 = (float*)PLN;                         // (planes and image are dead: the rows' inputs and dPre_0 as tiles)
+    float* HI = L0 + wave * 16 * HP;
+    float* D0 = L0 + DL_NW * 16 * HP + wave * 16 * G2_XP;
     if (active) {
       for (int i = lane; i < 16 * HP; i += 64) HI[i] = 0.f;
 #pragma unroll
@@ -2266,8 +2318,8 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
       const int m2 = wave >> 1, wn = wave & 1;
       f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
       for (int wb = 0; wb < nact; ++wb) {
-        const float* Hb = TIL + wb * 16 * HP;
-        const float* Db = TIL + DL_NW * 16 * HP + wb * 16 * G2_XP;
+        const float* Hb = L0 + wb * 16 * HP;
+        const float* Db = L0 + DL_NW * 16 * HP + wb * 16 * G2_XP;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Hb[(4 * s4 + kq) * HP + m2 * 16 + li],
@@ -2280,6 +2332,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
       }
     }
   }
+  DL_STAMP(126);
 }
 
 // Training head of the dense per-layer path, ONE workgroup per subgraph (k_graph_step2's head as a launch of its own): the
@@ -2572,6 +2625,7 @@ void igmc_launch_dl_fwd(const ModelDev& m, const BatchDev& b, const float* P, in
   a.ex = m.g2_ex; a.ex_stride = m.g2_ex_stride;
   a.gs_bar = m.gs_bar; a.gs_err = m.gs_err;
   a.self_seq = self_seq;
+  a.timing = getenv("IGMC_DL_TIMING") ? atoi(getenv("IGMC_DL_TIMING")) : 0;
   const int grid = B * 2 * a.nq;
   const int ng = g2_groups(m.R);
   const size_t sm = (size_t)dlf_words(a.kp, ng) * 4;
@@ -2613,7 +2667,7 @@ int igmc_dl_wide(const ModelDev& m, const BatchDev& b, int B) {
   const int nq = (cmax + 16 * DL_NW - 1) / (16 * DL_NW), stride = (B + 7) & ~7, kp = 32 * ((cmax + 31) >> 5) + 8;
   if (B * 2 * nq > 224 || 2 * nq * stride > IGMC_TS_BLOCKS) return 0;
   const int ng = g2_groups(m.R);
-  return (size_t)dlf_words(kp, ng) * 4 <= (size_t)160 * 1024 && (size_t)dlb_words(kp) * 4 <= (size_t)160 * 1024;
+  return (size_t)dlf_words(kp, ng) * 4 <= (size_t)160 * 1024 && (size_t)dlb_words(kp, ng) * 4 <= (size_t)160 * 1024;
 }
 
 int igmc_dl_bwd_eligible(const ModelDev& m, const BatchDev& b, int B) {
@@ -2637,8 +2691,9 @@ void igmc_launch_dl_bwd(const ModelDev& m, const BatchDev& b, int B, int use_fla
   a.ts_part = m.ts_part; a.ts_stride = m.ts_stride; a.slot_stride = (B + 7) & ~7;
   a.ex = m.g2_ex; a.ex_stride = m.g2_ex_stride;
   a.gs_bar = m.gs_bar; a.gs_err = m.gs_err;
+  a.timing = getenv("IGMC_DL_TIMING") ? atoi(getenv("IGMC_DL_TIMING")) : 0;
   const int grid = B * 2 * a.nq;
-  const size_t sm = (size_t)dlb_words(a.kp) * 4;
+  const size_t sm = (size_t)dlb_words(a.kp, g2_groups(m.R)) * 4;
 #ifdef IGMC_HIPEMU
   hipemu::rt().co_cs = 2 * a.nq;
   hipemu::rt().co_stride = -1;

@@ -1417,9 +1417,9 @@ __device__ __forceinline__ void reduce_ts_body(const ModelDev& m, int nparts, in
 #define IGMC_STASH_G 0
 #define IGMC_STASH_M 16
 #define IGMC_STASH_ATT 64
-#define IGMC_STASH_ATTM1 192      // Adam moments of att before the step (R <= 8; k_finalize_ts with img: every workgroup of
-#define IGMC_STASH_ATTM2 224      // the layer forms the new att, while the owner updates the moments in place)
-#define IGMC_STASH_LAYER 256
+#define IGMC_STASH_ATTM1 192      // Adam moments of att before the step (R <= 16; k_finalize_ts with img: every workgroup of
+#define IGMC_STASH_ATTM2 256      // the layer forms the new att, while the owner updates the moments in place)
+// (IGMC_STASH_LAYER floats per layer: model.h)
 #define IGMC_STASH_SCAL (4 * IGMC_STASH_LAYER)
 __device__ __forceinline__ void fin_stash_body(const ModelDev& m, const float* __restrict__ P, int l,
                                                const int64_t* ctrl) {
@@ -1457,7 +1457,7 @@ __device__ __forceinline__ void fin_stash_body(const ModelDev& m, const float* _
   }
   if (tid >= 128 && tid < 128 + na && na <= IGMC_STASH_LAYER - IGMC_STASH_ATT) {
     st[IGMC_STASH_ATT + tid - 128] = att[tid - 128];
-    if (m.adam_m1 && na <= 32) {
+    if (m.adam_m1 && na <= 64) {
       st[IGMC_STASH_ATTM1 + tid - 128] = m.adam_m1[m.off_att[l] + tid - 128];
       st[IGMC_STASH_ATTM2 + tid - 128] = m.adam_m2[m.off_att[l] + tid - 128];
     }
@@ -1933,10 +1933,11 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
       }
       __syncthreads();
     }
-    __shared__ float s_attn[32];                // the layer's att after the step (img)
+    __shared__ float s_attn[64];                // the layer's att after the step (img)
     float pn[5] = {0.f, 0.f, 0.f, 0.f, 0.f};    // this thread's basis_0..3[c][f], root[c][f] after the step (img)
     int e_img = -1;
-    const bool emit = img && at.enabled && m.g2_w && R <= G2_NR && fin <= 32;
+    const bool emit = img && at.enabled && m.g2_w && R <= G2_NR * G2_NG_MAX && fin <= 32;
+    const int ng = g2_groups(R);
     for (int e = part * IGMC_BLOCK + tid; e < nE; e += IGMC_FTS_NB * IGMC_BLOCK) {       // one round for fin <= 32
       int64_t idx[5];
       float pv[5], m1v[5], m2v[5], g[5];
@@ -1984,7 +1985,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
         const int64_t i = m.off_bias[l] + tid;
         const float bnew = fts_emit(grad, at, i, table ? t0[(size_t)(R * fin + fin) * 32 + tid] : raw[32 * IGMC_KCAT + tid],
                                     P[i], at.enabled ? at.m1[i] : 0.f, at.enabled ? at.m2[i] : 0.f);
-        if (emit && l == 0) m.g2_w[6 * G2_WIMG + (R * fin + fin) * 32 + tid] = bnew;       // layer-0 table: bias row
+        if (emit && l == 0) m.g2_w[g2_t0_off(ng) + (R * fin + fin) * 32 + tid] = bnew;       // layer-0 table: bias row
       } else if (tid >= 64 && tid < 64 + na) {     // d att[r,b] = <dW_r, basis_b> (+ ARR): fin partials, fixed order
         const int rb = tid - 64, r = rb >> 2, bb = rb & 3;
         const int64_t i = m.off_att[l] + rb;
@@ -2024,26 +2025,27 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
       if (e_img >= 0) {
         const int c = e_img >> 5, f = e_img & 31;
         if (l == 0) {       // layer-0 table [W_0[r * L + c] | root_0[c] | bias_0] (rows past R L + L stay zero: first compose)
-          float* t0w = m.g2_w + 6 * G2_WIMG;
+          float* t0w = m.g2_w + g2_t0_off(ng);
           for (int r = 0; r < R; ++r)
             t0w[(r * fin + c) * 32 + f] = g2_wsum(s_attn[r * 4], s_attn[r * 4 + 1], s_attn[r * 4 + 2], s_attn[r * 4 + 3],
                                                   pn[0], pn[1], pn[2], pn[3]);
           t0w[(R * fin + c) * 32 + f] = pn[4];
         } else {            // forward image: element (k = c, n = f); transposed image: element (k = f, n = c)
-          uint16_t* imf = (uint16_t*)(m.g2_w + (size_t)(l - 1) * 2 * G2_WIMG);
-          uint16_t* imt = (uint16_t*)(m.g2_w + (size_t)(l - 1) * 2 * G2_WIMG + G2_WIMG);
-#pragma unroll
-          for (int r = 0; r <= G2_NR; ++r) {
-            if (r >= R && r < G2_NR) continue;     // (blocks of relations the model does not have stay zero)
-            const float v = (r == G2_NR) ? pn[4]
+          // relation r -> block r % G2_NR of group r / G2_NR; root -> block G2_NR of group 0
+#pragma unroll 1
+          for (int r = 0; r <= R; ++r) {           // (blocks of relations the model does not have stay zero: first compose)
+            const float v = (r == R) ? pn[4]
                           : g2_wsum(s_attn[r * 4], s_attn[r * 4 + 1], s_attn[r * 4 + 2], s_attn[r * 4 + 3], pn[0], pn[1], pn[2], pn[3]);
+            const int grp = (r == R) ? 0 : r / G2_NR, blk = (r == R) ? G2_NR : r % G2_NR;
+            uint16_t* imf = (uint16_t*)(m.g2_w + g2_img_off(ng, l, 0, grp));
+            uint16_t* imt = (uint16_t*)(m.g2_w + g2_img_off(ng, l, 1, grp));
             uint32_t h, mi, lo;
             g2_split2(v, 0.f, h, mi, lo);
             const uint32_t t3[3] = {h, mi, lo};
 #pragma unroll
             for (int t = 0; t < G2_NT; ++t) {
-              imf[g2_img_index(t, r, c, f)] = (uint16_t)t3[t];
-              imt[g2_img_index(t, r, f, c)] = (uint16_t)t3[t];
+              imf[g2_img_index(t, blk, c, f)] = (uint16_t)t3[t];
+              imt[g2_img_index(t, blk, f, c)] = (uint16_t)t3[t];
             }
           }
         }
@@ -2333,7 +2335,7 @@ int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchD
   if (img_emitted) *img_emitted = 0;
   const int rows0 = m.R * m.L + m.L + 1;
   // the gradient / Adam kernel also leaves the weight images of the updated parameters
-  const int img = adam && m.g2_w && m.R <= G2_NR && rows0 <= 32;
+  const int img = adam && m.g2_w && m.R <= G2_NR * G2_NG_MAX && rows0 <= g2_t0_rows(m.R);
   const int l0_mfma = rows0 <= 32;
   const int gy = igmc_rows_grid(m.node_cap, 128, 512);
   const int hb = (B + 15) / 16;
