@@ -66,6 +66,7 @@ BATCH = 50
 CONFIGS = {
     'ml_1m': dict(dataset='ml_1m', mnph=100, adj_dropout=0.0, cpu='dynamic'),
     'ml_100k': dict(dataset='ml_100k', mnph=200, adj_dropout=0.2, cpu='static'),
+    'ml_10m_lite': dict(dataset='ml_10m_lite', mnph=100, adj_dropout=0.0, cpu='dynamic'),      # ten rating levels on the headline shape
     'douban': dict(dataset='douban', mnph=10000, adj_dropout=0.2, cpu='dynamic'),
     'flixster': dict(dataset='flixster', mnph=10000, adj_dropout=0.2, cpu='dynamic'),
     'yahoo_music': dict(dataset='yahoo_music', mnph=10000, adj_dropout=0.2, cpu='dynamic'),
@@ -292,7 +293,9 @@ def main():
             split = preprocessing.load_data_monti(cfg['dataset'], testing=True)
             source = 'bundled real'
         else:
-            split = preprocessing.create_trainvaltest_split(cfg['dataset'], 1234, True,
+            # (ml_10m_lite: the generator's levels 1..10 are ML-10M's half-star ratings 0.5..5.0)
+            rmap = {float(i): i / 2.0 for i in range(1, 11)} if cfg['dataset'] == 'ml_10m_lite' else None
+            split = preprocessing.create_trainvaltest_split(cfg['dataset'], 1234, True, rating_map=rmap,
                                                             verbose=int(os.environ.get('RANK', '0')) == 0)
             source = 'real' if preprocessing._find_raw(cfg['dataset'], 'ratings.dat' if cfg['dataset'] != 'ml_100k' else 'u.data') else 'synthetic'
     (_, _, A, tr_l, tr_u, tr_v, _, _, _, te_l, te_u, te_v, class_values) = split

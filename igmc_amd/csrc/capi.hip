@@ -356,7 +356,8 @@ extern "C" int igmc_batch_create(const igmc_graph* g, int max_graphs, int hop, i
   // (IGMC_DL_ALWAYS=1: also for small slots -- lets tests run those kernels on small cases)
   {
     const char* da = getenv("IGMC_DL_ALWAYS");
-    if (d.relm && (cap_u > 128 || cap_v > 128 || (da && atoi(da) == 1))) fail |= M.get(&d.relmT, (size_t)Bc * cap_v * d.relmT_ld);
+    // (more than five relations: the subgraph kernel does not take the arena whatever its slots, the dense-layer kernels do)
+    if (d.relm && (cap_u > 128 || cap_v > 128 || g->max_rel + 1 > G2_NR || (da && atoi(da) == 1))) fail |= M.get(&d.relmT, (size_t)Bc * cap_v * d.relmT_ld);
   }
   fail |= M.get(&d.s_gid, Bc * slot) | M.get(&d.s_lab, Bc * slot) | M.get(&d.s_deg, Bc * slot) |
           M.get(&d.t_list, Bc * slot) | M.get(&d.t_dist, Bc * slot);

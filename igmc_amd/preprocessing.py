@@ -24,6 +24,10 @@ _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ML_HIST = {
     'ml_100k': (943, 1682, 100000, [6110, 11370, 27145, 34174, 21201]),
     'ml_1m': (6040, 3706, 1000209, [56174, 107557, 261197, 348971, 226310]),
+    # ML-10M's ten half-star rating levels (levels 1..10 = ratings 0.5..5.0, approximate ML-10M histogram) on ml_1m's graph
+    # shape: the R = 10 counterpart of the headline workload (reference Main.py:155-163 lists ml_10m with flixster); the
+    # full 71567 x 10681 x 10M graph is a raw_data/ml_10m matter
+    'ml_10m_lite': (6040, 3706, 1000209, [94988, 384180, 118278, 790306, 370178, 2356676, 879764, 2875850, 585022, 1544812]),
 }
 
 
