@@ -1811,25 +1811,22 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
       hi[li * HP + RL + L] = 1.f;
     }
     IGMC_WAVE_SYNC();                                // (the tile is this wave's own: no workgroup barrier)
-    float o[8];
+    // [hist | onehot | 1] (16 rows x 32 / 48 table rows) @ T0 on the f32 matrix cores: the accumulators (lane = feature
+    // 16 nt + li, registers = rows 4 kq + rr) are the epilogue's layout
+    f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
+    constexpr int NJ = (NG == 1) ? 8 : 12;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = 0.f;
-    for (int c = 0; c <= RL + L; ++c) {
-      const float x = hi[li * HP + c];
-      const float4 t0 = *(const float4*)(sT0 + c * 32 + 8 * kq), t1 = *(const float4*)(sT0 + c * 32 + 8 * kq + 4);
-      o[0] += x * t0.x; o[1] += x * t0.y; o[2] += x * t0.z; o[3] += x * t0.w;
-      o[4] += x * t1.x; o[5] += x * t1.y; o[6] += x * t1.z; o[7] += x * t1.w;
+    for (int j = 0; j < NJ; ++j) {
+      const float av = hi[li * HP + 4 * j + kq];
+      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sT0[(4 * j + kq) * 32 + li], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sT0[(4 * j + kq) * 32 + 16 + li], o1, 0, 0, 0);
     }
-    // lane (row li, features 8 kq .. 8 kq + 7) -> the epilogue's layout (feature 16 nt + li, rows 4 kq + rr) through the tile
-    float* xo = XO1 + wave * 16 * G2_XP;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) xo[li * G2_XP + 8 * kq + j] = g2_tanh(o[j]);
-    IGMC_WAVE_SYNC();
     float v[2][4];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) v[nt][rr] = xo[(4 * kq + rr) * G2_XP + 16 * nt + li];
+    for (int rr = 0; rr < 4; ++rr) {
+      v[0][rr] = g2_tanh(o0[rr]);
+      v[1][rr] = g2_tanh(o1[rr]);
+    }
     fwd_out(0, v, XO0 + wave * 16 * G2_XP);
   }
   __syncthreads();                                   // the image's space (one-hot planes, inputs, table) is free
@@ -2466,21 +2463,22 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer0(Dl0Args a) {
   }
   __syncthreads();
   if (active) {
-    // h_0[row][f], f = 8 kq .. 8 kq + 7: RL + L + 1 <= 32 table rows
-    const int row = row0 + li;
-    float o[8];
+    // h_0 = tanh([hist | onehot | 1] @ T0) on the f32 matrix cores (RL + L + 1 <= 32 table rows), the order of sums of k_dl_fwd:
+    // lane = feature 16 nt + li, registers = rows 4 kq + rr
+    f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = 0.f;
-    for (int c = 0; c <= RL + L; ++c) {
-      const float x = hi[li * G2_XP + c];
-      const float4 t0 = *(const float4*)(sT0 + c * 32 + 8 * kq), t1 = *(const float4*)(sT0 + c * 32 + 8 * kq + 4);
-      o[0] += x * t0.x; o[1] += x * t0.y; o[2] += x * t0.z; o[3] += x * t0.w;
-      o[4] += x * t1.x; o[5] += x * t1.y; o[6] += x * t1.z; o[7] += x * t1.w;
+    for (int j = 0; j < 8; ++j) {
+      const float av = hi[li * G2_XP + 4 * j + kq];
+      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sT0[(4 * j + kq) * 32 + li], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sT0[(4 * j + kq) * 32 + 16 + li], o1, 0, 0, 0);
     }
-    if (row < n_own) {
-      float* dst = a.out + (size_t)(own0 + row) * 32 + 8 * kq;
-      *(float4*)dst = make_float4(g2_tanh(o[0]), g2_tanh(o[1]), g2_tanh(o[2]), g2_tanh(o[3]));
-      *(float4*)(dst + 4) = make_float4(g2_tanh(o[4]), g2_tanh(o[5]), g2_tanh(o[6]), g2_tanh(o[7]));
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = row0 + 4 * kq + rr;
+      if (row < n_own) {
+        a.out[(size_t)(own0 + row) * 32 + li] = g2_tanh(o0[rr]);
+        a.out[(size_t)(own0 + row) * 32 + 16 + li] = g2_tanh(o1[rr]);
+      }
     }
   }
 }
