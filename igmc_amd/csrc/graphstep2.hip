@@ -1965,6 +1965,11 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
   const int ts = a.ts_stride;
   const size_t slot = (size_t)g + (size_t)rem * a.slot_stride;
   float* part0 = a.ts_part + slot * ts;
+  if (a.timing && tid == 0 && bid < 1024) {        // (debug aid: start / end of every workgroup on the wall clock)
+    g_g2_wg[bid][0] = g2_wall_clock();
+    g_g2_wg[bid][1] = 0ull;
+    g_g2_wg[bid][2] = ((unsigned long long)n_own << 32) | (unsigned long long)n_opp;
+  }
   if (16 * DL_NW * q >= n_own) {                 // nothing of this side in the workgroup's rows: all-zero partial tables
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int l = 1; l < 4; ++l) {
@@ -2330,6 +2335,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
     }
   }
   DL_STAMP(126);
+  if (a.timing && tid == 0 && bid < 1024) g_g2_wg[bid][1] = g2_wall_clock();
 }
 
 // Training head of the dense per-layer path, ONE workgroup per subgraph (k_graph_step2's head as a launch of its own): the

@@ -66,6 +66,22 @@ def main():
             print('B%d g%d: wpre/reload/stage/sync %d | d bias %d | gather %d | transform + epilogue %d | sync %d | tiles + table product %d | tail %d'
                   % (l, g, d[0], d[1], d[2], d[3], d[4], d[5], nxt - c[k + 6]))
     print('layer-0 table %d | k_dl_bwd total %d' % (c[126] - c[41], c[126] - c[40]))
+    # every workgroup of the last k_dl_bwd launch on the 100 MHz wall clock
+    cmax = max(ds.cap_u, ds.cap_v) if hasattr(ds, 'cap_u') else 256
+    nwg = 50 * 2 * ((int(os.environ.get('DL_CMAX', '155')) + 127) // 128)
+    wgb = np.zeros(3 * 1024, np.uint64)
+    lib.cdll.igmc_debug_g2_wg_clocks(C.c_void_p(wgb.ctypes.data), 1024)
+    w = wgb.reshape(1024, 3)[:nwg].astype(np.int64)
+    t0 = w[:, 0].min()
+    rows = []
+    for i in range(nwg):
+        if w[i, 1] == 0:
+            continue
+        rows.append(((w[i, 1] - t0) / 100.0, (w[i, 0] - t0) / 100.0, i, int(w[i, 2] >> 32), int(w[i, 2] & 0xFFFFFFFF)))
+    rows.sort(reverse=True)
+    print('k_dl_bwd workgroups with rows: %d of %d; end of the last one %.1f us after the first start' % (len(rows), nwg, rows[0][0]))
+    for end, start, i, no, nop in rows[:8] + rows[len(rows) // 2:len(rows) // 2 + 3]:
+        print('  wg %3d (subgraph %2d, member %d): start %.1f end %.1f us; own rows %d, opposite %d' % (i, i // (nwg // 50), i % (nwg // 50), start, end, no, nop))
 
 
 main()
