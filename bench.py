@@ -235,7 +235,7 @@ def floor_us(lib, shape, class_values, cfg, dev, local, steps=40):
     return float(mean.value) if cnt.value > 0 else None
 
 
-def run_secondary(configs=('ml_100k', 'douban', 'flixster'), steps=100, warmup=10):
+def run_secondary(configs=('ml_100k', 'douban', 'flixster', 'ml_10m_lite'), steps=100, warmup=10):
     """Short runs of the other configurations (fresh processes of this file): value, us / step, dominant kernel."""
     import subprocess
     out = {}

@@ -743,7 +743,7 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
             M.get(&d.ts_raw, (size_t)4 * d.ts_stride + (size_t)4 * d.ts_stride / 32 * 4);
     if (!fail) d.datt_part = d.ts_raw + (size_t)4 * d.ts_stride;
   }
-  if (d.R <= 32) fail |= M.get(&d.fin_stash, (size_t)4 * IGMC_STASH_LAYER + 16);     // weights-only stash of k_finalize_ts (both modes)
+  if (d.R <= 128) fail |= M.get(&d.fin_stash, (size_t)4 * IGMC_STASH_LAYER + 16);     // weights-only stash of k_finalize_ts (both modes)
   d.g2_ex = nullptr;
   d.g2_fx = nullptr;
   d.g2_w = nullptr;

@@ -6,7 +6,7 @@
 #ifndef IGMC_WG_BLOCKS
 #define IGMC_WG_BLOCKS 64    // grid.x of the weight-gradient kernel (per-block partials, per layer); 128: ml_100k +1.7 %, flixster -2 %; 32: +9 us in the products
 #endif
-#define IGMC_STASH_LAYER 320  // floats per conv layer of the weights-only stash (fin_stash; layout: model.hip)
+#define IGMC_STASH_LAYER 672  // floats per conv layer of the weights-only stash (fin_stash; layout: model.hip)
 #define IGMC_TS_BLOCKS 256   // partial slots of the relation-space tables (one per workgroup of k_graph_step)
 #define IGMC_GATHER_BLOCKS 4096   // max grid of the row-walker kernels (4 rows = 4 waves per block)
 #define IGMC_L0_BLOCKS 256
@@ -38,7 +38,7 @@ struct ModelDev {
   float* ts_part;     // [4][IGMC_TS_BLOCKS][ts_stride] relation-space tables [W_r rows | root rows | bias] per layer (or NULL)
   float* ts_raw;      // [4][ts_stride] their sum over the workgroups
   int ts_stride;      // (R*32 + 33) * 32
-  float* fin_stash;   // [4][IGMC_STASH_LAYER] per conv layer: Gram of the bases [0..15], ARR matrix M [16..31], att copy [64..64+R*4);
+  float* fin_stash;   // [4][IGMC_STASH_LAYER] per conv layer: Gram of the bases [0..15], ARR matrix M [16..31], att moments [32..160), att copy [160..160+R*4);
                       // then [16] Adam scalars of the step -- written by k_tail_ts, read by k_finalize_ts (or NULL)
   float* datt_part;   // [4*ts_stride/32][4] partial <dW_r, basis_b> products of 32 table elements (k_tail_ts)
   int* gs_bar;        // k_graph_step clusters: [0] workgroups that finished the launch, [1] launch sequence number

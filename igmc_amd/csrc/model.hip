@@ -1416,9 +1416,9 @@ __device__ __forceinline__ void reduce_ts_body(const ModelDev& m, int nparts, in
 // place while other workgroups still need the old values) and, from the control block, the Adam scalars of the step.
 #define IGMC_STASH_G 0
 #define IGMC_STASH_M 16
-#define IGMC_STASH_ATT 64
-#define IGMC_STASH_ATTM1 192      // Adam moments of att before the step (R <= 16; k_finalize_ts with img: every workgroup of
-#define IGMC_STASH_ATTM2 256      // the layer forms the new att, while the owner updates the moments in place)
+#define IGMC_STASH_ATTM1 32       // Adam moments of att before the step (R <= 16; k_finalize_ts with img: every workgroup of
+#define IGMC_STASH_ATTM2 96       // the layer forms the new att, while the owner updates the moments in place)
+#define IGMC_STASH_ATT 160        // copy of att: R <= 128
 // (IGMC_STASH_LAYER floats per layer: model.h)
 #define IGMC_STASH_SCAL (4 * IGMC_STASH_LAYER)
 __device__ __forceinline__ void fin_stash_body(const ModelDev& m, const float* __restrict__ P, int l,
@@ -1455,11 +1455,13 @@ __device__ __forceinline__ void fin_stash_body(const ModelDev& m, const float* _
     }
     st[IGMC_STASH_M + tid - 64] = sacc;
   }
-  if (tid >= 128 && tid < 128 + na && na <= IGMC_STASH_LAYER - IGMC_STASH_ATT) {
-    st[IGMC_STASH_ATT + tid - 128] = att[tid - 128];
-    if (m.adam_m1 && na <= 64) {
-      st[IGMC_STASH_ATTM1 + tid - 128] = m.adam_m1[m.off_att[l] + tid - 128];
-      st[IGMC_STASH_ATTM2 + tid - 128] = m.adam_m2[m.off_att[l] + tid - 128];
+  if (tid >= 128 && na <= IGMC_STASH_LAYER - IGMC_STASH_ATT) {
+    for (int i = tid - 128; i < na; i += IGMC_BLOCK - 128) {
+      st[IGMC_STASH_ATT + i] = att[i];
+      if (m.adam_m1 && na <= 64) {
+        st[IGMC_STASH_ATTM1 + i] = m.adam_m1[m.off_att[l] + i];
+        st[IGMC_STASH_ATTM2 + i] = m.adam_m2[m.off_att[l] + i];
+      }
     }
   }
   if (l == 0 && ctrl && tid >= 192 && tid < 198) {
@@ -1877,7 +1879,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
     const float* raw = m.graw + (size_t)(l >= 1 ? l - 1 : 0) * wgs;
     // basis-space mode, layer 0: d att[r,b] = <dW_r, basis_b> needs every basis element of the layer BEFORE its owner
     // (a thread of this very workgroup: nE <= 256) updates it -> formed first, then a barrier
-    __shared__ float s_gatt0[128];
+    __shared__ float s_gatt0[512];
     if (bs && l == 0) {
       if (part == 0) {
         // a thread owns element e = tid (strided by the workgroup for fin > 8) of every product: the R table values and
@@ -1986,8 +1988,9 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
         const float bnew = fts_emit(grad, at, i, table ? t0[(size_t)(R * fin + fin) * 32 + tid] : raw[32 * IGMC_KCAT + tid],
                                     P[i], at.enabled ? at.m1[i] : 0.f, at.enabled ? at.m2[i] : 0.f);
         if (emit && l == 0) m.g2_w[g2_t0_off(ng) + (R * fin + fin) * 32 + tid] = bnew;       // layer-0 table: bias row
-      } else if (tid >= 64 && tid < 64 + na) {     // d att[r,b] = <dW_r, basis_b> (+ ARR): fin partials, fixed order
-        const int rb = tid - 64, r = rb >> 2, bb = rb & 3;
+      } else if (tid >= 64) {                      // d att[r,b] = <dW_r, basis_b> (+ ARR): fin partials, fixed order
+       for (int rb = tid - 64; rb < na; rb += IGMC_BLOCK - 64) {      // (one entry a thread up to 48 relations)
+        const int r = rb >> 2, bb = rb & 3;
         const int64_t i = m.off_att[l] + rb;
         const float pold = st[IGMC_STASH_ATT + rb];
         // (img: the moments before the step come from the stash -- the owner workgroup updates them in place meanwhile)
@@ -2018,6 +2021,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
         }
         const float anew = fts_emit(grad, at, i, g, pold, m1o, m2o, part == 0);
         if (emit) s_attn[rb] = anew;
+       }
       }
     }
     if (emit) {
@@ -2113,15 +2117,10 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_adam(float* __restrict__ p, cons
     eps = (float)d[IGMC_CTRL_EPS];
     wd = (float)d[IGMC_CTRL_WD];
   }
-  for (int64_t i = (int64_t)blockIdx.x * IGMC_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * IGMC_BLOCK) {
-    float gi = g[i];
-    const float pi = p[i];
-    if (wd != 0.f) gi += wd * pi;
-    const float a = beta1 * m1[i] + (1.f - beta1) * gi;
-    const float v = beta2 * m2[i] + (1.f - beta2) * gi * gi;
-    m1[i] = a;
-    m2[i] = v;
-    p[i] = pi - step_size * a / (sqrtf(v) * inv_sqrt_bc2 + eps);
+  {   // a contiguous slice per workgroup, eight elements a thread and round with all their loads in flight (adam_range)
+    const int64_t chunk = ((n + gridDim.x - 1) / gridDim.x + IGMC_BLOCK - 1) / IGMC_BLOCK * IGMC_BLOCK;
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+    if (lo < n) adam_range<8>(p, g, m1, m2, lo, hi, step_size, inv_sqrt_bc2, beta1, beta2, eps, wd);
   }
   if (fin.enabled && blockIdx.x == 0) loss_body(fin.b, fin.m, fin.ARR, fin.loss, fin.total, smf);
   if (ctrl && tick) {
@@ -2322,7 +2321,7 @@ int igmc_step_exchange_inside(const ModelDev& m, const BatchDev& b, int B) {
   int cs2 = 1;
   if (m.R * m.L + m.L + 1 <= 32 && igmc_g2_eligible(m, b, B, &lay2, &cs2))
     return igmc_fin_mode() && m.fin_stash && m.datt_part && m.R <= 8;
-  return igmc_fin_mode() && m.fin_stash && m.R <= 32;
+  return igmc_fin_mode() && m.fin_stash && m.R <= 128;
 }
 
 int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchDev& b, float* P, int B, int use_flags,
@@ -2478,10 +2477,10 @@ int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchD
   {
     const int wgs2 = igmc_wg_stride(), n0 = rows0 * 32, na = m.R * 4;
     const int nblk = (nsl * wgs2 + 63) / 64 + (l0_mfma ? 0 : (n0 + 63) / 64) + (3 * na + 3) / 4;
-    // gradient / Adam tail without hand-offs (k_finalize_ts in basis-space mode) where the stash fits: R <= 32 (the
+    // gradient / Adam tail without hand-offs (k_finalize_ts in basis-space mode) where the stash fits: R <= 128 (the
     // layer-0 table comes from the MFMA weight-gradient kernel or from k_l0_bwd's partials: same place, same layout);
     // IGMC_FIN_MODE=0: the hand-off version (k_finalize)
-    const int fbs = igmc_fin_mode() && m.fin_stash && m.R <= 32;
+    const int fbs = igmc_fin_mode() && m.fin_stash && m.R <= 128;
     IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk + (fbs ? 4 : 0), IGMC_BLOCK, 0, stream, m, gl, l0_mfma,
                  IGMC_WG_BLOCKS, (const float*)P, (const int64_t*)(adam ? at.ctrl : nullptr), fbs ? 4 : 0);
     if (xch && fbs) {      // the reduced basis-space sums (+ layer-0 table, d att) and the lin gradients, over the ranks
@@ -2542,9 +2541,11 @@ void igmc_launch_regroup(int64_t* ctrl, int M, int64_t first_cur, int64_t first_
   IGMC_PLAUNCH("k_regroup", k_regroup, 1, 64, 0, stream, ctrl, M, first_cur, first_next);
 }
 
+// (one workgroup per 2048 elements, at most 256: the tick of the step's last workgroup is an atomic round trip per workgroup on
+//  ONE counter -- 550 single-round workgroups spent 20 us of a 28 us launch queueing on it)
 static int adam_grid(int64_t n) {
-  int grid = (int)((n + IGMC_BLOCK - 1) / IGMC_BLOCK);
-  if (grid > 1024) grid = 1024;
+  int grid = (int)((n + 8 * IGMC_BLOCK - 1) / (8 * IGMC_BLOCK));
+  if (grid > 256) grid = 256;
   return grid < 1 ? 1 : grid;
 }
 

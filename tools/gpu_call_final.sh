@@ -22,12 +22,14 @@ timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pyt
 timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; tail -2 $O/smoke.log
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err                      # the driver's default form (200 / 20, all legs)
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver.json 2> $O/bench_driver.err
-for c in douban ml_100k flixster yahoo_music; do
+for c in douban ml_100k flixster ml_10m_lite yahoo_music; do
   st=200; [ $c = yahoo_music ] && st=64
   timeout 400 python bench.py --config $c --steps $st --warmup 20 --no-cpu-baseline --dp-steps 0 > $O/bench_$c.json 2> $O/bench_$c.err
 done
 timeout 300 python bench.py --dgcnn-rs --config douban --steps 200 --warmup 20 --no-cpu-baseline --dp-steps 0 --rmse-links 0 > $O/bench_dgcnn_douban.json 2> $O/bench_dgcnn_douban.err
 timeout 200 python tools/g2_phase_clocks.py > $O/phase_clocks.txt 2>&1
+timeout 200 python tools/dl_phase_clocks.py flixster 0 2>&1 | grep -v amdgpu.ids > $O/dl_phase_clocks_flixster.txt
+DL_CMAX=201 timeout 200 python tools/dl_phase_clocks.py ml_100k 0 2>&1 | grep -v amdgpu.ids > $O/dl_phase_clocks_ml100k.txt
 timeout 200 python tools/g2_phase_clocks.py --overlap > $O/phase_clocks_overlap.txt 2>&1
 python - "$O" <<'PY'
 import json,glob,sys
