@@ -132,13 +132,16 @@ def test_free_running_dropout(be, name, n, force_undirected):
 
 
 @pytest.mark.parametrize('name,cluster,drop', [('synth_cap', '1', True), ('synth_cap', '4', False), ('synth_nocap', '1', True),
-                                               ('flixster', '1', True)])
+                                               ('flixster', '1', True), ('yahoo_music', '1', True)])
 def test_fused_train_step_tracks_torch_adam(be, monkeypatch, name, cluster, drop):
     """``igmc_train_step`` (k_graph_step -> k_tail_ts -> k_finalize_ts incl. Adam for the capped case; per-layer kernels +
     k_finalize_ts in basis-space mode for the uncapped one and for flixster's 10 relations, whose layer-0 table comes from
-    k_l0_bwd) over 4 different batches vs ``pyg_ref.train_step`` + ``torch.optim.Adam``."""
+    k_l0_bwd; yahoo_music's 71 relations take the same tail: more than one d att entry a thread) over 4 different batches vs
+    ``pyg_ref.train_step`` + ``torch.optim.Adam``."""
     monkeypatch.setenv('IGMC_GS_CLUSTER', cluster)
-    res = PC.run_fused_train_trajectory(be, sub(name, 16), R=10 if name == 'flixster' else 5, steps=4, batch=4, use_dropout=drop)
+    R = {'flixster': 10, 'yahoo_music': 71}.get(name, 5)
+    n = 8 if name == 'yahoo_music' else 16
+    res = PC.run_fused_train_trajectory(be, sub(name, n), R=R, steps=4, batch=n // 4, use_dropout=drop)
     assert res['frac_off'] < 2e-3
 
 
