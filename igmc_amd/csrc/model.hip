@@ -1829,6 +1829,10 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize(ModelDev m, const float
 // (k_finalize needs two in-kernel hand-offs for the same work -- layer-wide before Adam, grid-wide before the tick --
 //  each an agent-scope fence pair + an atomic round trip.)
 #define IGMC_FTS_NB 4
+// The basis-space mode of this tail is correct up to 128 relations (the stash holds them) but only pays up to 32: its per-relation
+// loops (ARR matrix and value in the stash role, layer 0's d att) are serial in R -- yahoo_music's 71 relations measured
+// k_reduce_partials 15 -> 30 us and the gradient / Adam launch 57 -> 64 us against k_finalize (profiles/r04_experiments).
+#define IGMC_FBS_MAX_R 32
 // gradient g of parameter i -> flat gradient, Adam moments, parameter; returns the parameter's value after the step.
 // store = false: the value only (a workgroup that needs a neighbour's updated parameter forms it itself; the owner stores)
 __device__ __forceinline__ float fts_emit(float* __restrict__ grad, const AdamTail& at, int64_t i, float g, float pold,
@@ -2321,7 +2325,7 @@ int igmc_step_exchange_inside(const ModelDev& m, const BatchDev& b, int B) {
   int cs2 = 1;
   if (m.R * m.L + m.L + 1 <= 32 && igmc_g2_eligible(m, b, B, &lay2, &cs2))
     return igmc_fin_mode() && m.fin_stash && m.datt_part && m.R <= 8;
-  return igmc_fin_mode() && m.fin_stash && m.R <= 128;
+  return igmc_fin_mode() && m.fin_stash && m.R <= IGMC_FBS_MAX_R;
 }
 
 int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchDev& b, float* P, int B, int use_flags,
@@ -2477,10 +2481,10 @@ int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchD
   {
     const int wgs2 = igmc_wg_stride(), n0 = rows0 * 32, na = m.R * 4;
     const int nblk = (nsl * wgs2 + 63) / 64 + (l0_mfma ? 0 : (n0 + 63) / 64) + (3 * na + 3) / 4;
-    // gradient / Adam tail without hand-offs (k_finalize_ts in basis-space mode) where the stash fits: R <= 128 (the
+    // gradient / Adam tail without hand-offs (k_finalize_ts in basis-space mode) for R <= IGMC_FBS_MAX_R (the
     // layer-0 table comes from the MFMA weight-gradient kernel or from k_l0_bwd's partials: same place, same layout);
     // IGMC_FIN_MODE=0: the hand-off version (k_finalize)
-    const int fbs = igmc_fin_mode() && m.fin_stash && m.R <= 128;
+    const int fbs = igmc_fin_mode() && m.fin_stash && m.R <= IGMC_FBS_MAX_R;
     IGMC_PLAUNCH("k_reduce_partials", k_reduce_partials, nblk + (fbs ? 4 : 0), IGMC_BLOCK, 0, stream, m, gl, l0_mfma,
                  IGMC_WG_BLOCKS, (const float*)P, (const int64_t*)(adam ? at.ctrl : nullptr), fbs ? 4 : 0);
     if (xch && fbs) {      // the reduced basis-space sums (+ layer-0 table, d att) and the lin gradients, over the ranks

@@ -136,7 +136,7 @@ def test_free_running_dropout(be, name, n, force_undirected):
 def test_fused_train_step_tracks_torch_adam(be, monkeypatch, name, cluster, drop):
     """``igmc_train_step`` (k_graph_step -> k_tail_ts -> k_finalize_ts incl. Adam for the capped case; per-layer kernels +
     k_finalize_ts in basis-space mode for the uncapped one and for flixster's 10 relations, whose layer-0 table comes from
-    k_l0_bwd; yahoo_music's 71 relations take the same tail: more than one d att entry a thread) over 4 different batches vs
+    k_l0_bwd; yahoo_music's 71 relations: k_finalize's hand-off tail) over 4 different batches vs
     ``pyg_ref.train_step`` + ``torch.optim.Adam``."""
     monkeypatch.setenv('IGMC_GS_CLUSTER', cluster)
     R = {'flixster': 10, 'yahoo_music': 71}.get(name, 5)

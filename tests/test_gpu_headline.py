@@ -93,7 +93,7 @@ def test_headline_fused_train_steps_track_torch_adam(be, ml1m, monkeypatch, capf
     ('ml1m', 250, 5, 100, True),            # subgraph kernel with edge flags
     ('douban', 250, 5, None, True),         # per-layer kernels + k_finalize (uncapped)
     ('flixster', 250, 10, None, False),     # R = 10: relation groups on the dense layers
-    ('yahoo_music', 100, 71, None, True),   # R = 71: row walkers + the basis-space tail (several d att entries a thread)
+    ('yahoo_music', 100, 71, None, True),   # R = 71: row walkers + k_finalize
 ])
 def test_fused_train_steps_other_paths(be, ml1m, name, n, R, mnph, drop):
     case = ml1m if name == 'ml1m' else monti_case(name, n)
