@@ -1186,6 +1186,19 @@ struct DlArgs {
 #define DL_NW 8                   // waves (= 16-row bundles) per workgroup of the dense layer kernel
 #define DL_THREADS (64 * DL_NW)
 static_assert(DL_THREADS == DL_THREADS_PRIM, "dlx_reload (g2_prims.h) is written for this workgroup size");
+// The rows of a side are split EVENLY over its nq workgroups, in whole 16-row bundles: workgroup q takes bundles [bpw q, bpw (q + 1))
+// with bpw = ceil(bundles of the side / nq) <= DL_NW.  (First-fill -- 128 rows to workgroup 0, the rest to workgroup 1 -- left a
+// flixster launch waiting for its one 8-bundle workgroup while half of the workgroups had no rows at all.)
+struct DlRows {
+  int base, nact;                 // first row of the workgroup, bundles of it that hold rows (0: nothing of the side here)
+};
+__device__ __forceinline__ DlRows dl_rows(int n_own, int nq, int q) {
+  const int nb = (n_own + 15) >> 4, bpw = (nb + nq - 1) / nq, left = nb - bpw * q;
+  DlRows r;
+  r.base = 16 * bpw * q;
+  r.nact = left < 0 ? 0 : (left < bpw ? left : bpw);
+  return r;
+}
 #define DL_PIT 2                  // plane-staging items per thread: 128 * k-steps / DL_THREADS, k-steps <= 8
 #define DL_RIT 17                 // block-row dwords per lane: 16 rows x (32 * k-steps + 8) / 4 / 64, k-steps <= 8
 // LDS plan (4-byte words): [own rows XOA][TS: h_{l-1} rows HSA, d bias scratch][planes | block rows | weight image][sums]
@@ -1212,7 +1225,8 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
   float* wpart = TS ? a.ts_part + ((size_t)a.l * IGMC_TS_BLOCKS + g + (size_t)rem * a.slot_stride) * ts : nullptr;
   float* part0 = TS ? a.ts_part + ((size_t)g + (size_t)rem * a.slot_stride) * ts : nullptr;
   const int rows0 = R * a.L + a.L + 1;
-  if (16 * DL_NW * q >= n_own) {                 // nothing of this side in the workgroup's rows (uniform)
+  const DlRows dr = dl_rows(n_own, a.nq, q);
+  if (dr.nact == 0) {                            // nothing of this side in the workgroup's rows (uniform)
     if (BWD && !TS && tid < R * 4) a.gatt_part[(size_t)bid * R * 4 + tid] = 0.f;
     if (TS) {                                    // an all-zero partial table (the reduction reads every slot)
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1235,8 +1249,8 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
   float* TIL = (float*)PLN;                                          // TS: [DL_NW][16][G2_TP] T' tiles (aliases the above)
   float* sred = (float*)PLN + dl_words_mid(kp, TS);                  // [DL_NW][32] + att [32]
   float* s_att = sred + DL_NW * 32;
-  const int row0 = 16 * DL_NW * q + 16 * wave;
-  const bool active = row0 < n_own;
+  const int row0 = dr.base + 16 * wave;
+  const bool active = wave < dr.nact;              // (=> row0 < n_own; the waves past the workgroup's bundles idle)
   // ---- staging.  A workgroup is one residency round of the launch, so its duration is its chain of memory round trips:
   // EVERY load of the staging work is requested here, before the first use (clamped addresses instead of predicates: no
   // branches, values zeroed afterwards), and the scheduling barrier keeps the compiler from sinking them to their uses.
@@ -1327,7 +1341,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int i = lane + 64 * u, r = i >> 3, c4 = i & 7;
-      *(float4*)(XO + r * G2_XP + 4 * c4) = (row0 + r < n_own) ? xq[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+      *(float4*)(XO + r * G2_XP + 4 * c4) = (active && row0 + r < n_own) ? xq[u] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 #pragma unroll
@@ -1487,8 +1501,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
         for (int rr = 0; rr < 4; ++rr) HS[(4 * kq + rr) * G2_XP + 16 * nt + li] = xprev[nt][rr];
     }
     __syncthreads();
-    const int nbun = (n_own - 16 * DL_NW * q + 15) >> 4;
-    const int nact = nbun < DL_NW ? nbun : DL_NW;  // bundles of this workgroup that hold rows
+    const int nact = dr.nact;                      // bundles of this workgroup that hold rows
     {
       f32x4 w3[3];
 #pragma unroll
@@ -1647,7 +1660,8 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
   const uint32_t seq = g2_ld_seq(a.gs_bar);
   const uint32_t tag0 = seq * 8u + 1u;
   auto tag16 = [&](int x) { return 1u + (tag0 + (uint32_t)x) % 65535u; };
-  if (16 * DL_NW * q >= n_own) {                 // nothing of this side in the workgroup's rows: nobody waits for it
+  const DlRows dr = dl_rows(n_own, a.nq, q);
+  if (dr.nact == 0) {                            // nothing of this side in the workgroup's rows: nobody waits for it
     dlx_seq_done(a.gs_bar, a.self_seq);
     return;
   }
@@ -1667,18 +1681,24 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
   uint32_t* OHP = (uint32_t*)sW2;                                         // [8 labels][kp] bf16
   float* HIA = (float*)(OHP + (8 * kp >> 1));                             // [DL_NW][16][HP]
   float* sT0 = (NG == 1) ? HIA + DL_NW * 16 * G2_XP : (float*)sW2 + G2_WIMG;      // [32][32] / behind the image: [64][32]
-  const int row0 = 16 * DL_NW * q + 16 * wave;
-  const bool active = row0 < n_own;
+  const int row0 = dr.base + 16 * wave;
+  const bool active = wave < dr.nact;
   const size_t exs = a.ex_stride;
   unsigned long long* ex_own = a.ex + ((size_t)g * 2 + side) * (32 * DLX_K);
   const unsigned long long* ex_opp = a.ex + ((size_t)g * 2 + (1 - side)) * (32 * DLX_K);
 
-  // ---- every 4096 launches the owner of a row range clears it in all exchange buffers: a 16-bit tag then never meets a
-  //      word older than 4096 launches (tags repeat after 8191)
+  // ---- every 4096 launches the side's region is cleared in all exchange buffers -- a 16-bit tag then never meets a word
+  //      older than 4096 launches (tags repeat after 65535) -- by the rows' owners of THIS launch (nobody else writes
+  //      them), workgroup 0 also taking the rows past the side up to the slot capacity (nobody's in this launch)
   if ((seq & 4095u) == 0u) {
-    for (int x = 0; x < 5; ++x) {
-      unsigned long long* e = a.ex + x * exs + ((size_t)g * 2 + side) * (32 * DLX_K) + 16 * DL_NW * q;
-      for (int i = tid; i < 32 * 8 * DL_NW; i += DL_THREADS) g2_store16(e + (i / (8 * DL_NW)) * DLX_K + 2 * (i % (8 * DL_NW)), 0u, 0u, 0u, 0u);
+    const int rcap = 128 * a.nq < DLX_K ? 128 * a.nq : DLX_K;
+    for (int part = 0; part < (q == 0 ? 2 : 1); ++part) {
+      const int r0 = part ? ((n_own + 15) >> 4) << 4 : dr.base, r1 = part ? rcap : dr.base + 16 * dr.nact;
+      const int np = (r1 - r0) >> 1;                 // 16-byte stores (two rows) per feature
+      for (int x = 0; x < 5; ++x) {
+        unsigned long long* e = a.ex + x * exs + ((size_t)g * 2 + side) * (32 * DLX_K) + r0;
+        for (int i = tid; i < 32 * np; i += DL_THREADS) g2_store16(e + (i / np) * DLX_K + 2 * (i % np), 0u, 0u, 0u, 0u);
+      }
     }
     g2_wait_vm0();
   }
@@ -1970,7 +1990,8 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
     g_g2_wg[bid][1] = 0ull;
     g_g2_wg[bid][2] = ((unsigned long long)n_own << 32) | (unsigned long long)n_opp;
   }
-  if (16 * DL_NW * q >= n_own) {                 // nothing of this side in the workgroup's rows: all-zero partial tables
+  const DlRows dr = dl_rows(n_own, a.nq, q);
+  if (dr.nact == 0) {                            // nothing of this side in the workgroup's rows: all-zero partial tables
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int l = 1; l < 4; ++l) {
       float* wp = a.ts_part + ((size_t)l * IGMC_TS_BLOCKS + slot) * ts;
@@ -1996,8 +2017,8 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
   float2* sW2 = (float2*)(PLN + (G2_NT * 32 * kp >> 1));                  // [G2_WIMG words]
   // T' tiles: [DL_NW][16][G2_TP] over planes + image (NG = 1) / [DL_NW / 2][16][G2_TP] over the image (NG > 1)
   float* TIL = (NG == 1) ? (float*)PLN : (float*)sW2;
-  const int row0 = 16 * DL_NW * q + 16 * wave;
-  const bool active = row0 < n_own;
+  const int row0 = dr.base + 16 * wave;
+  const bool active = wave < dr.nact;
   const size_t exs = a.ex_stride;
   unsigned long long* ex_own = a.ex + ((size_t)g * 2 + side) * (32 * DLX_K);
   const unsigned long long* ex_opp = a.ex + ((size_t)g * 2 + (1 - side)) * (32 * DLX_K);
@@ -2060,14 +2081,13 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
     p2[32 * kp >> 1] = mi & 0xFFFFu;
     p2[2 * (32 * kp >> 1)] = lo & 0xFFFFu;
   } else if (tid < 64 && q == 0) {
-    XOA[tid & 31] = d3;                            // own target row = row 0 of the side's first bundle
+    XOA[tid & 31] = d3;                            // own target row = row 0 of the side's first bundle (workgroup 0's)
   }
   // (no barrier: the layer loop starts with one)
 
   const unsigned char* rmo = RMW + (size_t)(wave * 16 + li) * rmp + 8 * kq;
   const int kbit = side ? IGMC_RELM_KF : IGMC_RELM_KT;                   // keep bit of the edge own -> opposite
-  const int nbun = (n_own - 16 * DL_NW * q + 15) >> 4;
-  const int nact = nbun < DL_NW ? nbun : DL_NW;    // bundles of this workgroup that hold rows
+  const int nact = dr.nact;                        // bundles of this workgroup that hold rows
   float* XO = XOA + wave * 16 * G2_XP;
   float* T = TIL + ((NG == 1) ? wave : (wave & 3)) * 16 * G2_TP;
   float* HS = HSA + wave * 16 * G2_XP;
@@ -2114,8 +2134,8 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
       int tid_g = threadIdx.x;
       G2_OPAQUE(tid_g);
       const int tid = tid_g, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
-      const int row0 = 16 * DL_NW * q + 16 * wave;
-      const bool active = row0 < n_own;
+      const int row0 = dr.base + 16 * wave;
+      const bool active = wave < nact;
       const unsigned char* rmo = RMW + (size_t)(wave * 16 + li) * rmp + 8 * kq;
       float* XO = XOA + wave * 16 * G2_XP;
       float* T = TIL + ((NG == 1) ? wave : (wave & 3)) * 16 * G2_TP;
@@ -2385,7 +2405,8 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer0(Dl0Args a) {
   const int g = bid / (2 * a.nq), rem = bid - g * 2 * a.nq, side = rem / a.nq, q = rem - side * a.nq;
   const int cu = a.n_users[g], cv = a.n_items[g];
   const int n_own = side ? cv : cu, n_opp = side ? cu : cv;
-  if (16 * DL_NW * q >= n_own) return;
+  const DlRows dr = dl_rows(n_own, a.nq, q);
+  if (dr.nact == 0) return;
   const int R = a.R, L = a.L, RL = R * L;
   const int nb = a.node_off[g];
   const int own0 = nb + (side ? cu : 0), opp0 = nb + (side ? 0 : cu);
@@ -2395,8 +2416,8 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer0(Dl0Args a) {
   unsigned char* RMW = (unsigned char*)(OHP + (8 * kp >> 1));            // [DL_NW][16][rmp] bytes
   float* HI = (float*)(RMW + DL_NW * 16 * rmp);                          // [DL_NW][16][G2_XP] input rows [hist | onehot | 1]
   float* sT0 = HI + DL_NW * 16 * G2_XP;                                  // [32][32]
-  const int row0 = 16 * DL_NW * q + 16 * wave;
-  const bool active = row0 < n_own;
+  const int row0 = dr.base + 16 * wave;
+  const bool active = wave < dr.nact;
   for (int i = tid; i < 256; i += DL_THREADS) ((float4*)sT0)[i] = ((const float4*)a.t0)[i];
   // one thread per node pair of the opposite side (<= 160): its two labels once, the eight plane words from them
   const int own_lab = (row0 + li < n_own) ? (int)a.node_label[own0 + row0 + li] : 0;      // (used after the gather)
