@@ -1199,6 +1199,15 @@ __device__ __forceinline__ DlRows dl_rows(int n_own, int nq, int q) {
   r.nact = left < 0 ? 0 : (left < bpw ? left : bpw);
   return r;
 }
+// Workgroups per side: one per 128 rows of the slot capacity -- and a second one for slots of 33..128 rows where the whole
+// launch still fits one workgroup per CU and the partial-table slots: the bundles of a side are split evenly (dl_rows), so a
+// 101-row side becomes 4 + 3 bundles on two CUs instead of 7 on one.
+static int dl_nq(int cmax, int B) {
+  int nq = (cmax + 16 * DL_NW - 1) / (16 * DL_NW);
+  if (nq == 1 && cmax > 32 && 4 * B <= 224 && 4 * ((B + 7) & ~7) <= IGMC_TS_BLOCKS) nq = 2;
+  return nq;
+}
+
 #define DL_PIT 2                  // plane-staging items per thread: 128 * k-steps / DL_THREADS, k-steps <= 8
 #define DL_RIT 17                 // block-row dwords per lane: 16 rows x (32 * k-steps + 8) / 4 / 64, k-steps <= 8
 // LDS plan (4-byte words): [own rows XOA][TS: h_{l-1} rows HSA, d bias scratch][planes | block rows | weight image][sums]
@@ -2521,7 +2530,7 @@ void igmc_launch_dl_layer0(const ModelDev& m, const BatchDev& b, int B, int trai
   a.n_users = b.n_users; a.n_items = b.n_items; a.node_off = b.node_off; a.node_label = b.node_label;
   a.relm = b.relm; a.relmT = b.relmT;
   a.cap_u = b.cap_u; a.cap_v = b.cap_v; a.relm_ld = b.relm_ld; a.relmT_ld = b.relmT_ld;
-  a.nq = (cmax + 16 * DL_NW - 1) / (16 * DL_NW); a.R = m.R; a.L = m.L; a.kp = 32 * ((cmax + 31) >> 5) + 8;
+  a.nq = dl_nq(cmax, B); a.R = m.R; a.L = m.L; a.kp = 32 * ((cmax + 31) >> 5) + 8;
   a.t0 = m.g2_w + 6 * G2_WIMG;
   a.out = m.h[0];
   a.cnt0 = training ? m.cnt0 : nullptr;
@@ -2548,7 +2557,7 @@ static int dl_base_ok(const ModelDev& m, const BatchDev& b, int B, int wide) {
   const int rows0 = m.R * m.L + m.L + 1;
   if (wide ? (m.R <= G2_NR || m.R > G2_NR * G2_NG_MAX || rows0 > 48) : (m.R > G2_NR || rows0 > 32)) return 0;
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
-  return cmax <= 256 && B * 2 * ((cmax + 16 * DL_NW - 1) / (16 * DL_NW)) <= IGMC_GATHER_BLOCKS;
+  return cmax <= 256 && B * 2 * (dl_nq(cmax, B)) <= IGMC_GATHER_BLOCKS;
 }
 int igmc_dl_eligible(const ModelDev& m, const BatchDev& b, int B) {
   if (!dl_base_ok(m, b, B, 0)) return 0;
@@ -2563,14 +2572,14 @@ int igmc_dl_ts_eligible(const ModelDev& m, const BatchDev& b, int B) {
   if (e && atoi(e) == 0) return 0;
   if (!igmc_dl_eligible(m, b, B) || !m.ts_part || !m.cnt0) return 0;
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
-  const int nq = (cmax + 16 * DL_NW - 1) / (16 * DL_NW), stride = (B + 7) & ~7;
+  const int nq = dl_nq(cmax, B), stride = (B + 7) & ~7;
   if (2 * nq * stride > IGMC_TS_BLOCKS || m.R * m.L > 20) return 0;
   return dl_lds(32 * ((cmax + 31) >> 5) + 8, true) <= (size_t)160 * 1024;
 }
 
 int igmc_dl_grid(const BatchDev& b, int B) {
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
-  return B * 2 * ((cmax + 16 * DL_NW - 1) / (16 * DL_NW));
+  return B * 2 * (dl_nq(cmax, B));
 }
 
 void igmc_launch_g2_compose(const ModelDev& m, const float* P, void* stream) {
@@ -2587,7 +2596,7 @@ void igmc_launch_dl_layer(const ModelDev& m, const BatchDev& b, const float* P, 
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
   a.n_users = b.n_users; a.n_items = b.n_items; a.node_off = b.node_off; a.relm = b.relm; a.relmT = b.relmT;
   a.cap_u = b.cap_u; a.cap_v = b.cap_v; a.relm_ld = b.relm_ld; a.relmT_ld = b.relmT_ld;
-  a.nq = (cmax + 16 * DL_NW - 1) / (16 * DL_NW); a.R = m.R; a.D = m.D; a.l = l; a.kp = 32 * ((cmax + 31) >> 5) + 8;
+  a.nq = dl_nq(cmax, B); a.R = m.R; a.D = m.D; a.l = l; a.kp = 32 * ((cmax + 31) >> 5) + 8;
   a.in = bwd ? m.dpre[l] : m.h[l - 1];
   a.hprev = m.h[l - 1];
   a.out = bwd ? m.dpre[l - 1] : m.h[l];
@@ -2626,7 +2635,7 @@ int igmc_dl_fwd_eligible(const ModelDev& m, const BatchDev& b, int B) {
   if (e && atoi(e) == 0) return 0;
   if (!igmc_dl_eligible(m, b, B) || !m.g2_ex || m.ex_nodes < DLX_K || b.graph_cap > m.g2_graphs) return 0;
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
-  const int nq = (cmax + 16 * DL_NW - 1) / (16 * DL_NW);
+  const int nq = dl_nq(cmax, B);
   if (B * 2 * nq > 224) return 0;                  // (one workgroup per CU, all of them resident: the members wait for each other)
   return (size_t)dlf_words(32 * ((cmax + 31) >> 5) + 8) * 4 <= (size_t)160 * 1024;
 }
@@ -2639,7 +2648,7 @@ void igmc_launch_dl_fwd(const ModelDev& m, const BatchDev& b, const float* P, in
   a.n_users = b.n_users; a.n_items = b.n_items; a.node_off = b.node_off; a.node_label = b.node_label;
   a.relm = b.relm; a.relmT = b.relmT;
   a.cap_u = b.cap_u; a.cap_v = b.cap_v; a.relm_ld = b.relm_ld; a.relmT_ld = b.relmT_ld;
-  a.nq = (cmax + 16 * DL_NW - 1) / (16 * DL_NW); a.R = m.R; a.L = m.L; a.kp = 32 * ((cmax + 31) >> 5) + 8;
+  a.nq = dl_nq(cmax, B); a.R = m.R; a.L = m.L; a.kp = 32 * ((cmax + 31) >> 5) + 8;
   for (int l = 0; l < 4; ++l) {
     a.h[l] = m.h[l];
     a.off_bias[l] = (int)m.off_bias[l];
@@ -2689,7 +2698,7 @@ int igmc_dl_wide(const ModelDev& m, const BatchDev& b, int B) {
   if (et && atoi(et) == 0) return 0;
   if (!m.g2_ex || m.ex_nodes < DLX_K || b.graph_cap > m.g2_graphs || !m.ts_part || !m.cnt0) return 0;
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
-  const int nq = (cmax + 16 * DL_NW - 1) / (16 * DL_NW), stride = (B + 7) & ~7, kp = 32 * ((cmax + 31) >> 5) + 8;
+  const int nq = dl_nq(cmax, B), stride = (B + 7) & ~7, kp = 32 * ((cmax + 31) >> 5) + 8;
   if (B * 2 * nq > 224 || 2 * nq * stride > IGMC_TS_BLOCKS) return 0;
   const int ng = g2_groups(m.R);
   return (size_t)dlf_words(kp, ng) * 4 <= (size_t)160 * 1024 && (size_t)dlb_words(kp, ng) * 4 <= (size_t)160 * 1024;
@@ -2710,7 +2719,7 @@ void igmc_launch_dl_bwd(const ModelDev& m, const BatchDev& b, int B, int use_fla
   a.n_users = b.n_users; a.n_items = b.n_items; a.node_off = b.node_off; a.node_label = b.node_label;
   a.relm = b.relm; a.relmT = b.relmT;
   a.cap_u = b.cap_u; a.cap_v = b.cap_v; a.relm_ld = b.relm_ld; a.relmT_ld = b.relmT_ld;
-  a.nq = (cmax + 16 * DL_NW - 1) / (16 * DL_NW); a.R = m.R; a.L = m.L; a.D = m.D; a.kp = 32 * ((cmax + 31) >> 5) + 8;
+  a.nq = dl_nq(cmax, B); a.R = m.R; a.L = m.L; a.D = m.D; a.kp = 32 * ((cmax + 31) >> 5) + 8;
   for (int l = 0; l < 3; ++l) a.h[l] = m.h[l];
   a.dpre3 = m.dpre[3]; a.gfeat = m.gfeat; a.g2_w = m.g2_w; a.cnt0 = m.cnt0;
   a.ts_part = m.ts_part; a.ts_stride = m.ts_stride; a.slot_stride = (B + 7) & ~7;
