@@ -1967,6 +1967,16 @@ struct DlbArgs {
   int* gs_bar;
   int* gs_err;
   int timing;
+  // head != 0: the launch also runs the subgraph's readout + MLP head (head_sub.h) in its set-up -- every workgroup of a subgraph
+  // for itself, under the latency of its block-row loads -- instead of a k_head_sub launch in front of it
+  int head;
+  BatchDev hb;
+  ModelDev hm;
+  const float* P;
+  const uint8_t* inj_mask;
+  uint64_t seed, step;
+  float mult, grad_scale;
+  float* out;
 };
 
 // (ng > 1: the T' tiles of FOUR bundles at a time, over the image alone -- the planes stay in place for the next group)
@@ -2043,7 +2053,6 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
     const int rc = row0 + r < n_own ? row0 + r : n_own - 1, cc = c < ldw ? c : ldw - 1;
     rmq[u] = ((const uint32_t*)(rsrc + (size_t)rc * ldb))[cc];
   }
-  const float d3 = (tid < 64) ? a.dpre3[(size_t)((tid >> 5) ? own0 : opp0) * 32 + (tid & 31)] : 0.f;   // opposite | own target row
   // (the rows' neighbour-label histograms -- the layer-0 table's inputs -- are requested under the LAST table product: held
   //  from here they cost registers, and spills, through all three layers)
   uint16_t c0q[C0N];
@@ -2082,6 +2091,13 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
     }
   }
   __syncthreads();
+  if (a.head) {   // loss head of the subgraph in the image's space (free until the first layer stages its image); what it leaves
+                  // in HBM -- dPre_3 of the target rows, d feat -- is read back below by this very workgroup (barrier in between)
+    const uint64_t hstep = a.hm.ctrl ? (uint64_t)a.hm.ctrl[IGMC_CTRL_STEP] : a.step;
+    head_sub_body<true>(a.hb, a.hm, a.P, g, tid, (float*)sW2, a.inj_mask, a.seed, hstep, a.mult, a.grad_scale, a.out);
+    __syncthreads();
+  }
+  const float d3 = (tid < 64) ? a.dpre3[(size_t)((tid >> 5) ? own0 : opp0) * 32 + (tid & 31)] : 0.f;   // opposite | own target row
   if (tid < 32) {                                  // dPre_3 of the opposite side's target node: the three terms of node 0
     uint32_t h, mi, lo;
     g2_split2(d3, 0.f, h, mi, lo);
@@ -2712,7 +2728,7 @@ int igmc_dl_bwd_eligible(const ModelDev& m, const BatchDev& b, int B) {
   return (size_t)dlb_words(32 * ((cmax + 31) >> 5) + 8) * 4 <= (size_t)160 * 1024;
 }
 
-void igmc_launch_dl_bwd(const ModelDev& m, const BatchDev& b, int B, int use_flags, void* stream) {
+void igmc_launch_dl_bwd(const ModelDev& m, const BatchDev& b, int B, int use_flags, void* stream, const DlHead* head) {
   DlbArgs a;
   memset(&a, 0, sizeof(a));
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
@@ -2726,6 +2742,10 @@ void igmc_launch_dl_bwd(const ModelDev& m, const BatchDev& b, int B, int use_fla
   a.ex = m.g2_ex; a.ex_stride = m.g2_ex_stride;
   a.gs_bar = m.gs_bar; a.gs_err = m.gs_err;
   a.timing = getenv("IGMC_DL_TIMING") ? atoi(getenv("IGMC_DL_TIMING")) : 0;
+  if (head) {
+    a.head = 1; a.hb = b; a.hm = m; a.P = head->P; a.inj_mask = head->inj_mask; a.seed = head->seed; a.step = head->step;
+    a.mult = head->mult; a.grad_scale = head->grad_scale; a.out = head->out;
+  }
   const int grid = B * 2 * a.nq;
   const size_t sm = (size_t)dlb_words(a.kp, g2_groups(m.R)) * 4;
 #ifdef IGMC_HIPEMU

@@ -98,7 +98,15 @@ int igmc_dl_ts_eligible(const ModelDev& m, const BatchDev& b, int B);
 int igmc_dl_fwd_eligible(const ModelDev& m, const BatchDev& b, int B);
 int igmc_dl_bwd_eligible(const ModelDev& m, const BatchDev& b, int B);
 int igmc_dl_wide(const ModelDev& m, const BatchDev& b, int B);
-void igmc_launch_dl_bwd(const ModelDev& m, const BatchDev& b, int B, int use_flags, void* stream);
+// (head != NULL: the launch runs the subgraphs' loss head itself -- no k_head_sub launch in front of it)
+struct DlHead {
+  const float* P;
+  const uint8_t* inj_mask;
+  uint64_t seed, step;
+  float mult, grad_scale;
+  float* out;
+};
+void igmc_launch_dl_bwd(const ModelDev& m, const BatchDev& b, int B, int use_flags, void* stream, const DlHead* head = nullptr);
 void igmc_launch_dl_fwd(const ModelDev& m, const BatchDev& b, const float* P, int B, int training, int use_flags,
                         float* zero_out, int self_seq, void* stream);
 void igmc_launch_head_sub(const ModelDev& m, const BatchDev& b, const float* P, int B, const uint8_t* inj_mask, uint64_t seed,

@@ -2432,12 +2432,21 @@ int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchD
   // -- k_tail_ts sums the workgroups' tables and forms d lin1 / d lin2, k_finalize_ts turns them into gradients (+ Adam) --
   // replaces the Y products, G, the weight-gradient products and their reduction
   if (dlts) {
-    // the head: one workgroup per subgraph (side features included)
-    igmc_launch_head_sub(m, b, (const float*)P, B, inj_mask, seed, step, mult, grad_scale, out, stream);
-    if (wide || (dlf && igmc_dl_bwd_eligible(m, b, B)))
-      igmc_launch_dl_bwd(m, b, B, use_flags, stream);         // the three backward layers as ONE launch
-    else
+    if (wide || (dlf && igmc_dl_bwd_eligible(m, b, B))) {
+      // the three backward layers as ONE launch, the loss head of each subgraph (side features included) in its set-up
+      // (IGMC_DL_HEAD=0: the head as a launch of its own in front of it)
+      const char* eh = getenv("IGMC_DL_HEAD");
+      DlHead hd;
+      hd.P = (const float*)P; hd.inj_mask = inj_mask; hd.seed = seed; hd.step = step; hd.mult = mult; hd.grad_scale = grad_scale;
+      hd.out = out;
+      const bool inside = !(eh && atoi(eh) == 0);
+      if (!inside) igmc_launch_head_sub(m, b, (const float*)P, B, inj_mask, seed, step, mult, grad_scale, out, stream);
+      igmc_launch_dl_bwd(m, b, B, use_flags, stream, inside ? &hd : nullptr);
+    } else {
+      // the head: one workgroup per subgraph, then one launch per backward layer
+      igmc_launch_head_sub(m, b, (const float*)P, B, inj_mask, seed, step, mult, grad_scale, out, stream);
       for (int l = 3; l >= 1; --l) igmc_launch_dl_layer(m, b, (const float*)P, B, l, 1, use_flags, nullptr, stream, 1);
+    }
     const int gstride = (B + 7) & ~7, gg = igmc_dl_grid(b, B) / B * gstride;
     IGMC_PLAUNCH("k_tail_ts", k_tail_ts, 8 * ny + (4 * m.ts_stride + 63) / 64 + 4, IGMC_BLOCK, 0, stream, b, m,
                  (const float*)P, grad_scale, mult, 2.f, grad, 8 * ny, gg, gstride, B, 4,
