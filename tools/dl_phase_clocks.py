@@ -67,8 +67,12 @@ def main():
                   % (l, g, d[0], d[1], d[2], d[3], d[4], d[5], nxt - c[k + 6]))
     print('layer-0 table %d | k_dl_bwd total %d' % (c[126] - c[41], c[126] - c[40]))
     # every workgroup of the last k_dl_bwd launch on the 100 MHz wall clock
-    cmax = max(ds.cap_u, ds.cap_v) if hasattr(ds, 'cap_u') else 256
-    nwg = 50 * 2 * ((int(os.environ.get('DL_CMAX', '155')) + 127) // 128)
+    # workgroups per side as graphstep2.hip's dl_nq (DL_CMAX = the larger slot capacity of the arena: flixster 155, ml_100k 201)
+    cmax = int(os.environ.get('DL_CMAX', {'flixster': 155, 'ml_100k': 201, 'ml_10m_lite': 101}.get(cfgname, 155)))
+    nq = (cmax + 127) // 128
+    if nq == 1 and cmax > 32:
+        nq = 2
+    nwg = 50 * 2 * nq
     wgb = np.zeros(3 * 1024, np.uint64)
     lib.cdll.igmc_debug_g2_wg_clocks(C.c_void_p(wgb.ctypes.data), 1024)
     w = wgb.reshape(1024, 3)[:nwg].astype(np.int64)

@@ -29,7 +29,7 @@ done
 timeout 300 python bench.py --dgcnn-rs --config douban --steps 200 --warmup 20 --no-cpu-baseline --dp-steps 0 --rmse-links 0 > $O/bench_dgcnn_douban.json 2> $O/bench_dgcnn_douban.err
 timeout 200 python tools/g2_phase_clocks.py > $O/phase_clocks.txt 2>&1
 timeout 200 python tools/dl_phase_clocks.py flixster 0 2>&1 | grep -v amdgpu.ids > $O/dl_phase_clocks_flixster.txt
-DL_CMAX=201 timeout 200 python tools/dl_phase_clocks.py ml_100k 0 2>&1 | grep -v amdgpu.ids > $O/dl_phase_clocks_ml100k.txt
+timeout 200 python tools/dl_phase_clocks.py ml_100k 0 2>&1 | grep -v amdgpu.ids > $O/dl_phase_clocks_ml100k.txt
 timeout 200 python tools/g2_phase_clocks.py --overlap > $O/phase_clocks_overlap.txt 2>&1
 python - "$O" <<'PY'
 import json,glob,sys
