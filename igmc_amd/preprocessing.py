@@ -5,7 +5,7 @@ test_labels, test_u, test_v, class_values)`` whose ``adj_train`` stores rating-l
 
 * :func:`load_data_monti`      -- flixster / douban / yahoo_music, restating the split logic of
   reference ``preprocessing.py:203-333`` on the bundled matrices (read from the ``.npz`` produced by
-  ``tests/golden/convert_mat.py``, or from the original HDF5 ``.mat`` when h5py is importable).
+  ``tests/golden/convert_mat.py``, or from the original MATLAB -v7.3 ``.mat`` through ``igmc_amd/mat73.py``).
 * :func:`synth_ml`             -- MovieLens-shaped synthetic generator of SURVEY.md section 8(d)
   (MovieLens itself is not available offline).
 * :func:`create_trainvaltest_split` -- random split with the reference's proportions
@@ -48,28 +48,28 @@ def _load_monti_arrays(dataset):
     p = _find_raw(dataset, 'training_test_dataset.mat')
     if p is None:
         raise FileNotFoundError('raw_data/%s/training_test_dataset.{npz,mat} not found' % dataset)
-    import h5py  # optional: only for the original MATLAB v7.3 files
+    from . import mat73      # the HDF5 subset of MATLAB's -v7.3 files, read directly (the reference uses h5py)
     out = {}
-    with h5py.File(p, 'r') as db:
-        def dense(name):
-            ds = db[name]
-            if isinstance(ds, h5py.Group) and 'ir' in ds.keys():
-                return sp.csc_matrix((np.asarray(ds['data']), np.asarray(ds['ir']), np.asarray(ds['jc']))
-                                     ).astype(np.float32).toarray()
-            return np.asarray(ds).astype(np.float32).T   # MATLAB column-major (ref preprocessing.py:49-51)
-        M = dense('M')
-        out['shape'] = np.array(M.shape, np.int64)
-        r, c = np.nonzero(M)
-        out['M_row'], out['M_col'], out['M_val'] = r.astype(np.int32), c.astype(np.int32), M[r, c]
-        for k in ('Otraining', 'Otest'):
-            r, c = np.nonzero(dense(k))
-            out[k + '_row'], out[k + '_col'] = r.astype(np.int32), c.astype(np.int32)
-        for k in ('W_users', 'W_movies', 'W_tracks'):
-            if k in db.keys():
-                W = dense(k)
-                r, c = np.nonzero(W)
-                out[k + '_shape'] = np.array(W.shape, np.int64)
-                out[k + '_row'], out[k + '_col'], out[k + '_val'] = r.astype(np.int32), c.astype(np.int32), W[r, c]
+    db = mat73.File(p)
+    def dense(name):
+        ds = db[name]
+        if isinstance(ds, mat73.Group) and 'ir' in ds.keys():
+            return sp.csc_matrix((np.asarray(ds['data']), np.asarray(ds['ir']), np.asarray(ds['jc']))
+                                 ).astype(np.float32).toarray()
+        return np.asarray(ds).astype(np.float32).T   # MATLAB column-major (ref preprocessing.py:49-51)
+    M = dense('M')
+    out['shape'] = np.array(M.shape, np.int64)
+    r, c = np.nonzero(M)
+    out['M_row'], out['M_col'], out['M_val'] = r.astype(np.int32), c.astype(np.int32), M[r, c]
+    for k in ('Otraining', 'Otest'):
+        r, c = np.nonzero(dense(k))
+        out[k + '_row'], out[k + '_col'] = r.astype(np.int32), c.astype(np.int32)
+    for k in ('W_users', 'W_movies', 'W_tracks'):
+        if k in db.keys():
+            W = dense(k)
+            r, c = np.nonzero(W)
+            out[k + '_shape'] = np.array(W.shape, np.int64)
+            out[k + '_row'], out[k + '_col'], out[k + '_val'] = r.astype(np.int32), c.astype(np.int32), W[r, c]
     return out
 
 
