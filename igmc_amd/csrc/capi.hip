@@ -357,7 +357,9 @@ extern "C" int igmc_batch_create(const igmc_graph* g, int max_graphs, int hop, i
   {
     const char* da = getenv("IGMC_DL_ALWAYS");
     // (more than five relations: the subgraph kernel does not take the arena whatever its slots, the dense-layer kernels do)
-    if (d.relm && (cap_u > 128 || cap_v > 128 || g->max_rel + 1 > G2_NR || (da && atoi(da) == 1))) fail |= M.get(&d.relmT, (size_t)Bc * cap_v * d.relmT_ld);
+    // ... and so for a layer-0 table of more than 32 rows (two hops: the graph's relations x 6 labels)
+    const int nlab = 2 * hop + 2;
+    if (d.relm && (cap_u > 128 || cap_v > 128 || g->max_rel + 1 > G2_NR || (g->max_rel + 1) * nlab + nlab + 1 > 32 || (da && atoi(da) == 1))) fail |= M.get(&d.relmT, (size_t)Bc * cap_v * d.relmT_ld);
   }
   fail |= M.get(&d.s_gid, Bc * slot) | M.get(&d.s_lab, Bc * slot) | M.get(&d.s_deg, Bc * slot) |
           M.get(&d.t_list, Bc * slot) | M.get(&d.t_dist, Bc * slot);
@@ -754,10 +756,10 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   d.g2_ex_stride = (size_t)Bc * 2 * 32 * d.ex_nodes;
   const int wide = d.R <= G2_NR * G2_NG_MAX;      // relation groups of the dense-layer kernels (g2_image.h)
   if (wide && Bc <= 2048) {
-    fail |= M.get(&d.g2_ex, 5 * d.g2_ex_stride) | M.get(&d.g2_fx, Bc * 256) | M.get(&d.g2_w, g2_w_words(d.R));
+    fail |= M.get(&d.g2_ex, 5 * d.g2_ex_stride) | M.get(&d.g2_fx, Bc * 256) | M.get(&d.g2_w, g2_w_words(d.R, d.L));
     d.g2_graphs = (int)Bc;
   } else if (wide) {
-    fail |= M.get(&d.g2_w, g2_w_words(d.R));      // weight images alone: the dense per-layer kernels (any head)
+    fail |= M.get(&d.g2_w, g2_w_words(d.R, d.L));      // weight images alone: the dense per-layer kernels (any head)
   }
   fail |= M.get(&d.gs_bar, 2 * Bc + 1);
   fail |= M.get(&d.gs_ts, 4);

@@ -11,16 +11,22 @@
 // accumulators hold the input features of a row.
 #define G2_WIMG (G2_NT * (G2_NR + 1) * 2 * 64 * 4)   // 4-byte words of one staged image (36 KB)
 // Models with more than G2_NR relations take them in GROUPS of G2_NR (R <= G2_NR * G2_NG_MAX): one staged image per group --
-// block G2_NR of group 0 = root, of the other groups = zero -- and a layer-0 table of 64 rows.
+// block G2_NR of group 0 = root, of the other groups = zero -- and a layer-0 table of 64 rows.  A model whose layer-0 table
+// [R L relation-label rows | L root rows | bias] has more than 32 rows (two hops: L = 6) takes the same two-group layout
+// (its second group holds no relation and is skipped at run time): the layout is chosen by g2_groups(R, L).
 // g2_w: [3 layers][forward image, transposed image][group] then the layer-0 table [32 | 64][32] f32
 #define G2_NG_MAX 2
-__host__ __device__ static inline int g2_groups(int R) { return (R + G2_NR - 1) / G2_NR; }
-__host__ __device__ static inline int g2_t0_rows(int R) { return R <= G2_NR ? 32 : 64; }
+__host__ __device__ static inline int g2_rel_groups(int R) { return (R + G2_NR - 1) / G2_NR; }      // groups that hold relations
+__host__ __device__ static inline int g2_groups(int R, int L) {
+  const int ng = g2_rel_groups(R);
+  return (ng == 1 && R * L + L + 1 > 32) ? 2 : ng;
+}
+__host__ __device__ static inline int g2_t0_rows(int R, int L) { return g2_groups(R, L) == 1 ? 32 : 64; }
 __host__ __device__ static inline size_t g2_img_off(int ng, int l, int trans, int grp) {
   return (size_t)(((l - 1) * 2 + trans) * ng + grp) * G2_WIMG;
 }
 __host__ __device__ static inline size_t g2_t0_off(int ng) { return (size_t)6 * ng * G2_WIMG; }
-__host__ __device__ static inline size_t g2_w_words(int R) { return g2_t0_off(g2_groups(R)) + (size_t)g2_t0_rows(R) * 32; }
+__host__ __device__ static inline size_t g2_w_words(int R, int L) { return g2_t0_off(g2_groups(R, L)) + (size_t)g2_t0_rows(R, L) * 32; }
 
 #ifndef IGMC_HIPEMU
 typedef __bf16 g2_bf16x2 __attribute__((ext_vector_type(2)));

@@ -912,7 +912,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_compose(ModelDev m, const flo
   const int tid = threadIdx.x, R = m.R, L = m.L, RL = R * L, LF = L * 32;
   // blockIdx.x: 2 * (3 layers x relation groups x 6 matrices) image blocks (bit 0 = transposed), then the layer-0 table blocks
   // (32 rows each)
-  const int ng = g2_groups(R);
+  const int ng = g2_groups(R, L);
   const int tableb = 2 * 3 * ng * (G2_NR + 1);
   const int mi = (int)(blockIdx.x >> 1);                   // matrix of the images: (layer, group, block)
   const int l = ((int)blockIdx.x >= tableb) ? 0 : 1 + mi / (ng * (G2_NR + 1)), trans = blockIdx.x & 1;
@@ -1104,7 +1104,7 @@ int igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* P
   const int grid = (cs > 1) ? cs * B : igmc_gs_grid(B);
   const size_t sm = (size_t)lay.words * 4;
   if (!m.img_current) {
-    IGMC_PLAUNCH("k_g2_compose", k_g2_compose, 2 * 3 * g2_groups(m.R) * (G2_NR + 1) + g2_t0_rows(m.R) / 32, G2_THREADS, 0, stream, m, P, m.g2_w);
+    IGMC_PLAUNCH("k_g2_compose", k_g2_compose, 2 * 3 * g2_groups(m.R, m.L) * (G2_NR + 1) + g2_t0_rows(m.R, m.L) / 32, G2_THREADS, 0, stream, m, P, m.g2_w);
     ++g_igmc_compose_count;
   }
 #ifdef IGMC_HIPEMU
@@ -1676,6 +1676,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
   }
   DL_STAMP(0);
   const int R = a.R, L = a.L, RL = R * L;
+  const int ngr = (NG == 1) ? 1 : g2_rel_groups(R);      // groups that hold relations (a two-hop model's second group: none)
   const int nb = a.node_off[g];
   const int own0 = nb + (side ? cu : 0), opp0 = nb + (side ? 0 : cu);
   const int kp = a.kp, rmp = kp;
@@ -1804,7 +1805,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
     float* hi = HIA + wave * 16 * HP;
     const int row = row0 + li;
 #pragma unroll 1
-    for (int grp = 0; grp < NG; ++grp) {
+    for (int grp = 0; grp < ngr; ++grp) {
       const uint32_t rb = (uint32_t)(G2_NR * grp);
       f32x4 hacc[G2_NR];
 #pragma unroll
@@ -1876,14 +1877,14 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
     o[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     o[1] = o[0];
 #pragma unroll 1
-    for (int grp = 0; grp < NG; ++grp) {
+    for (int grp = 0; grp < ngr; ++grp) {
       const uint32_t rb = (uint32_t)(G2_NR * grp);
       if (grp > 0) {                                 // the next group's image takes the place of the last one
         __syncthreads();
         stage();
         __syncthreads();
       }
-      if (grp + 1 < NG) wpre(l, grp + 1);
+      if (grp + 1 < ngr) wpre(l, grp + 1);
       else if (l < 3) wpre(l + 1, 0);
       DL_STAMP(5 + (l - 1) * 9 + 3 * grp);
       if (active) {
@@ -2001,6 +2002,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
   const int cu = a.n_users[g], cv = a.n_items[g];
   const int n_own = side ? cv : cu, n_opp = side ? cu : cv;
   const int R = a.R, L = a.L, RL = R * L, rows0 = RL + L + 1;
+  const int ngr = (NG == 1) ? 1 : g2_rel_groups(R);      // groups that hold relations
   const int ts = a.ts_stride;
   const size_t slot = (size_t)g + (size_t)rem * a.slot_stride;
   float* part0 = a.ts_part + slot * ts;
@@ -2151,7 +2153,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
         }
     }
 #pragma unroll 1
-    for (int grp = 0; grp < NG; ++grp) {
+    for (int grp = 0; grp < ngr; ++grp) {
       const uint32_t rb = (uint32_t)(G2_NR * grp);
       const int sk = 42 + ((3 - l) * NG + grp) * 7;      // (phase clocks)
       // per-lane indices re-derived from an opaque copy of the thread index: what is computed from them stays inside the
@@ -2227,7 +2229,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
           o[0] += og[0];
           o[1] += og[1];
         }
-        if (grp == NG - 1) {
+        if (grp == ngr - 1) {
           unsigned long long* exb = ex_own + (6 - l) * exs + (size_t)li * DLX_K + row0 + 4 * kq;
           const uint32_t tgb = tag16(6 - l);
 #pragma unroll
@@ -2239,7 +2241,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
               dv[nt][rr] = ok ? (o[nt][rr] + addv[nt][rr]) * (1.f - x * x) : 0.f;
             }
             if (l > 1) g2_publish4(exb + (size_t)nt * 16 * DLX_K, 0, dv[nt], tgb);
-            if (NG > 1 && l > 1) {                   // dPre_{l-1} of the rows becomes the next layer's own rows: nobody reads
+            if (NG > 1 && grp > 0 && l > 1) {        // dPre_{l-1} of the rows becomes the next layer's own rows: nobody reads
 #pragma unroll                                       // this tile any more (the d root block belongs to group 0's product)
               for (int rr = 0; rr < 4; ++rr) XO[(4 * kq + rr) * G2_XP + 16 * nt + li] = dv[nt][rr];
             }
@@ -2249,7 +2251,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
       DL_STAMP(sk + 4);
       __syncthreads();                               // every wave is done with planes / image: the T' tiles take their space
       DL_STAMP(sk + 5);
-      if (l == 1 && grp == NG - 1) {
+      if (l == 1 && grp == ngr - 1) {
         int lane_ = lane;                            // (opaque: the address arithmetic stays here, not above the layer loop)
         G2_OPAQUE(lane_);
 #pragma unroll
@@ -2332,7 +2334,14 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
           for (int i = tid; i < (G2_NT * 32 * kp >> 3); i += DL_THREADS) ((float4*)PLN)[i] = z4;
           __syncthreads();                           // (the zero fill is complete before the reload writes into it)
         }
-      }                                              // (NG > 1: planes untouched, the rows' dPre_{l-1} written by the epilogue)
+      } else if (ngr == 1 && l > 1) {                // (one group that holds relations: its product has just read dPre_l)
+        if (active) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) XO[(4 * kq + rr) * G2_XP + 16 * nt + li] = dv[nt][rr];
+        }
+      }                                              // (else: planes untouched, the rows' dPre_{l-1} written by the epilogue)
     }
   }
   DL_STAMP(41);
@@ -2571,7 +2580,8 @@ static int dl_base_ok(const ModelDev& m, const BatchDev& b, int B, int wide) {
   if (e && atoi(e) == 0) return 0;
   if (!b.relm || !b.relmT || !m.g2_w || m.L > 8) return 0;
   const int rows0 = m.R * m.L + m.L + 1;
-  if (wide ? (m.R <= G2_NR || m.R > G2_NR * G2_NG_MAX || rows0 > 48) : (m.R > G2_NR || rows0 > 32)) return 0;
+  // wide: the two-group layout -- six to ten relations, or a layer-0 table of 33..48 rows (two hops)
+  if (wide ? (g2_groups(m.R, m.L) == 1 || m.R > G2_NR * G2_NG_MAX || rows0 > 48) : (m.R > G2_NR || rows0 > 32)) return 0;
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
   return cmax <= 256 && B * 2 * (dl_nq(cmax, B)) <= IGMC_GATHER_BLOCKS;
 }
@@ -2601,7 +2611,7 @@ int igmc_dl_grid(const BatchDev& b, int B) {
 void igmc_launch_g2_compose(const ModelDev& m, const float* P, void* stream) {
   if (m.img_current) return;      // (igmc_model_weights_unchanged: the images of these parameters are in place)
   ++g_igmc_compose_count;
-  IGMC_PLAUNCH("k_g2_compose", k_g2_compose, 2 * 3 * g2_groups(m.R) * (G2_NR + 1) + g2_t0_rows(m.R) / 32, G2_THREADS, 0, stream, m, P, m.g2_w);
+  IGMC_PLAUNCH("k_g2_compose", k_g2_compose, 2 * 3 * g2_groups(m.R, m.L) * (G2_NR + 1) + g2_t0_rows(m.R, m.L) / 32, G2_THREADS, 0, stream, m, P, m.g2_w);
 }
 
 // one conv layer pass: forward (bwd = 0: h_{l-1} -> h_l) or backward (dPre_l -> dPre_{l-1}, G, d att partials)
@@ -2677,7 +2687,7 @@ void igmc_launch_dl_fwd(const ModelDev& m, const BatchDev& b, const float* P, in
   a.self_seq = self_seq;
   a.timing = getenv("IGMC_DL_TIMING") ? atoi(getenv("IGMC_DL_TIMING")) : 0;
   const int grid = B * 2 * a.nq;
-  const int ng = g2_groups(m.R);
+  const int ng = g2_groups(m.R, m.L);
   const size_t sm = (size_t)dlf_words(a.kp, ng) * 4;
 #ifdef IGMC_HIPEMU
   hipemu::rt().co_cs = 2 * a.nq;                   // the members of a subgraph run together
@@ -2716,7 +2726,7 @@ int igmc_dl_wide(const ModelDev& m, const BatchDev& b, int B) {
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
   const int nq = dl_nq(cmax, B), stride = (B + 7) & ~7, kp = 32 * ((cmax + 31) >> 5) + 8;
   if (B * 2 * nq > 224 || 2 * nq * stride > IGMC_TS_BLOCKS) return 0;
-  const int ng = g2_groups(m.R);
+  const int ng = g2_groups(m.R, m.L);
   return (size_t)dlf_words(kp, ng) * 4 <= (size_t)160 * 1024 && (size_t)dlb_words(kp, ng) * 4 <= (size_t)160 * 1024;
 }
 
@@ -2747,12 +2757,12 @@ void igmc_launch_dl_bwd(const ModelDev& m, const BatchDev& b, int B, int use_fla
     a.mult = head->mult; a.grad_scale = head->grad_scale; a.out = head->out;
   }
   const int grid = B * 2 * a.nq;
-  const size_t sm = (size_t)dlb_words(a.kp, g2_groups(m.R)) * 4;
+  const size_t sm = (size_t)dlb_words(a.kp, g2_groups(m.R, m.L)) * 4;
 #ifdef IGMC_HIPEMU
   hipemu::rt().co_cs = 2 * a.nq;
   hipemu::rt().co_stride = -1;
 #endif
-  if (g2_groups(m.R) == 1) {
+  if (g2_groups(m.R, m.L) == 1) {
     if (use_flags) IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<true, 1>), grid, DL_THREADS, sm, stream, a);
     else IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<false, 1>), grid, DL_THREADS, sm, stream, a);
   } else {

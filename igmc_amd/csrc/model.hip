@@ -1943,7 +1943,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
     float pn[5] = {0.f, 0.f, 0.f, 0.f, 0.f};    // this thread's basis_0..3[c][f], root[c][f] after the step (img)
     int e_img = -1;
     const bool emit = img && at.enabled && m.g2_w && R <= G2_NR * G2_NG_MAX && fin <= 32;
-    const int ng = g2_groups(R);
+    const int ng = g2_groups(R, m.L);
     for (int e = part * IGMC_BLOCK + tid; e < nE; e += IGMC_FTS_NB * IGMC_BLOCK) {       // one round for fin <= 32
       int64_t idx[5];
       float pv[5], m1v[5], m2v[5], g[5];
@@ -2338,7 +2338,7 @@ int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchD
   if (img_emitted) *img_emitted = 0;
   const int rows0 = m.R * m.L + m.L + 1;
   // the gradient / Adam kernel also leaves the weight images of the updated parameters
-  const int img = adam && m.g2_w && m.R <= G2_NR * G2_NG_MAX && rows0 <= g2_t0_rows(m.R);
+  const int img = adam && m.g2_w && m.R <= G2_NR * G2_NG_MAX && rows0 <= (g2_t0_rows(m.R, m.L) == 32 ? 32 : 48);
   const int l0_mfma = rows0 <= 32;
   const int gy = igmc_rows_grid(m.node_cap, 128, 512);
   const int hb = (B + 15) / 16;

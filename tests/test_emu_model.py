@@ -347,3 +347,14 @@ def test_free_running_dropout_on_a_lean_arena_with_ten_relations(be, monkeypatch
     assert res['worst_grad_err'] < 1e-4
     eager = PC.run_free_running_dropout(be, sub('flixster', 16), R=10, force_undirected=False, lean=False)
     assert eager['keep_rate'] == res['keep_rate']
+
+
+@pytest.mark.parametrize('name,R,n', [('hand_h2', 5, 5), ('flixster_h2', 10, 4)])
+def test_two_hops_take_the_dense_layers(be, name, R, n):
+    """Two hops (six node labels, reference util_functions.py:248-262): the layer-0 table [R L | L | 1] has 37 (R = 5) rows --
+    more than the 32 of the one-group layout -- so the model takes the two-group layout of the dense-layer kernels (64-row
+    table; with five relations the second group holds none and is skipped); flixster's ten relations x six labels = 67 rows
+    stay on the per-layer kernels."""
+    res = PC.run_model_parity(be, sub(name, n), R=R, use_dropout=True)
+    assert res['worst_grad_err'] < 1e-4
+    assert bool(res['batch'].dense_layers(res['ws'])) == (R == 5)

@@ -86,6 +86,8 @@ def test_sampler_free_run(be, name):
 def test_model_forward_backward_parity(be, name, n, R, drop, mult):
     res = PC.run_model_parity(be, sub(name, n), R=R, use_dropout=drop, multiply_by=mult)
     assert res['worst_grad_err'] < PC.GRAD_TOL
+    if name == 'hand_h2':      # two hops, five relations: 37 layer-0 table rows -> the two-group layout of the dense-layer kernels
+        assert res['batch'].dense_layers(res['ws'])
 
 
 @pytest.mark.parametrize('name,n,R,drop', [('synth_cap', 16, 5, True), ('synth_nocap:100', 16, 5, False)])
