@@ -75,39 +75,39 @@ __device__ __forceinline__ float sp_cat(const ModelDev& m, int i, int j) {
 // descending by key, ties by ascending node index (torch.sort(stable=True, descending=True) order)
 __device__ __forceinline__ bool sp_before(float ka, int ia, float kb, int ib) { return ka > kb || (ka == kb && ia < ib); }
 
-// the k first nodes of graph g in sort-pool order -> sel[0..k) (batch-wide node index, -1 = padding); LDS: keys / idx [P]
+// the k first nodes of graph g in sort-pool order -> sel[0..k) (batch-wide node index, -1 = padding); LDS: keys / idx [P].
+// RANK sort: the position of node i is the number of nodes that come before it (the order is total: ties go to the lower
+// index), counted by four threads per node over a quarter of the nodes each -- every lane of a wave reads the same key at
+// the same time (an LDS broadcast) -- and summed with integer LDS atomics.  n^2 / 1024 = 64 compare steps a thread at
+// n = 256, one barrier; the bitonic network it replaces was 36 barrier-separated stages with 128 busy threads.
 __device__ void sp_select(const BatchDev& b, const ModelDev& m, const SpDev& sp, int g, float* keys, int* idx, int* sel_out) {
   const int tid = threadIdx.x;
   const int n0 = b.node_off[g], n = b.node_off[g + 1] - n0;
-  int P = 1;
-  while (P < n) P <<= 1;
-  for (int i = tid; i < P; i += SP_WG) {
-    keys[i] = (i < n) ? m.h[3][(size_t)(n0 + i) * 32] : -3.0e38f;
-    idx[i] = (i < n) ? i : 0x7fffffff;
+  for (int i = tid; i < n; i += SP_WG) {
+    keys[i] = m.h[3][(size_t)(n0 + i) * 32];
+    idx[i] = 0;
   }
+  for (int p = tid; p < sp.k; p += SP_WG) sel_out[p] = -1;
   __syncthreads();
-  for (int size = 2; size <= P; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = tid; t < (P >> 1); t += SP_WG) {
-        const int lo = ((t / stride) * (stride << 1)) + (t % stride), hi = lo + stride;
-        const bool up = ((lo & size) == 0);                  // this sub-sequence is sorted "before-first"
-        const float ka = keys[lo], kb = keys[hi];
-        const int ia = idx[lo], ib = idx[hi];
-        const bool swap = up ? sp_before(kb, ib, ka, ia) : sp_before(ka, ia, kb, ib);
-        if (swap) {
-          keys[lo] = kb; keys[hi] = ka;
-          idx[lo] = ib; idx[hi] = ia;
-        }
-      }
-      __syncthreads();
+  const int nr = (n + 63) & ~63, q4 = (n + 3) >> 2;
+  for (int e = tid; e < 4 * nr; e += SP_WG) {
+    const int part = e / nr, i = e - part * nr;
+    if (i < n) {
+      const float ki = keys[i];
+      const int j0 = part * q4, j1 = (j0 + q4 < n) ? j0 + q4 : n;
+      int cnt = 0;
+      for (int j = j0; j < j1; ++j) cnt += sp_before(keys[j], j, ki, i) ? 1 : 0;
+      if (cnt) atomicAdd(&idx[i], cnt);
     }
   }
-  for (int p = tid; p < sp.k; p += SP_WG) sel_out[p] = (p < n) ? n0 + idx[p] : -1;
+  __syncthreads();
+  for (int i = tid; i < n; i += SP_WG)
+    if (idx[i] < sp.k) sel_out[idx[i]] = n0 + i;
   __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------- forward
-// dynamic LDS: keys[P] | idx[P] | sel[k] | w1[16*97+16] | w2[32*80+32] | y1[16*k] | z[16*Q1] | y2[32*Q2] | a1[128] | red[8]
+// dynamic LDS: keys[P] | idx[P] | sel[k] | w1[16*97+16] | w2[32*80+32] | y1[16*k] | z[16*Q1] | y2[32*Q2] | a1[128] | red[8] | xs[k*98]
 template <bool TRAIN>
 __global__ __launch_bounds__(SP_WG) void k_sp_fwd(BatchDev b, ModelDev m, SpDev sp, const float* __restrict__ Pd,
                                                         const uint8_t* __restrict__ inj_mask, uint64_t seed,
@@ -130,24 +130,42 @@ __global__ __launch_bounds__(SP_WG) void k_sp_fwd(BatchDev b, ModelDev m, SpDev 
   for (int i = tid; i < SP_C2 * SP_C1 * SP_KW + SP_C2; i += SP_WG) w2[i] = Pd[sp.t_c2w + i];
   sp_select(b, m, sp, g, keys, idx, sel);
   for (int p = tid; p < k; p += SP_WG) sp.sel[(size_t)g * k + p] = sel[p];
-  // conv1 (one pooled row per thread: its 97 channels are read once) + ReLU
-  for (int p = tid; p < k; p += SP_WG) {
-    const int i = sel[p];
-    float acc[SP_C1];
+  // conv1 + ReLU.  The pooled rows are staged in LDS once (coalesced), then one (row, output channel) per thread: lanes =
+  // 16 channels x 4 rows (the row's value is a broadcast, the 16 weights sit in 16 banks).  One pooled row per thread with
+  // its 97 channels read from HBM inside the loop left 60 of 1024 threads walking 97 serial round trips.
+  float* xs = red + 8;                               // [k][SP_C + 1]
+  for (int i = tid; i < k * 128; i += SP_WG) {
+    const int p = i >> 7, c = i & 127;
+    if (c < SP_C) xs[p * (SP_C + 1) + c] = (sel[p] >= 0) ? sp_cat(m, sel[p], c) : 0.f;
+  }
+  __syncthreads();
+  {   // y1[oc][p] = relu(bias[oc] + sum_j x[p][j] w1[oc][j]): k x 16, K = 97 on the f32 matrix cores, a 16-row tile per wave
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    for (int mt = wave; 16 * mt < k; mt += SP_WG / 64) {
+      const int p = 16 * mt + li;                    // A: rows = pooled positions, B: columns = output channels
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int j0 = 0; j0 < SP_C; j0 += 16) {
+        float av[4], bv[4];
 #pragma unroll
-    for (int oc = 0; oc < SP_C1; ++oc) acc[oc] = w1[SP_C1 * SP_C + oc];
-    if (i >= 0) {
-      for (int j = 0; j < SP_C; ++j) {
-        const float x = sp_cat(m, i, j);
+        for (int u = 0; u < 4; ++u) {
+          const int j = j0 + 4 * u + kq;
+          av[u] = (p < k && j < SP_C) ? xs[p * (SP_C + 1) + j] : 0.f;
+          bv[u] = (j < SP_C) ? w1[li * SP_C + j] : 0.f;
+        }
 #pragma unroll
-        for (int oc = 0; oc < SP_C1; ++oc) acc[oc] += w1[oc * SP_C + j] * x;
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
       }
-    }
+      const float bias = w1[SP_C1 * SP_C + li];
 #pragma unroll
-    for (int oc = 0; oc < SP_C1; ++oc) {
-      const float v = acc[oc] > 0.f ? acc[oc] : 0.f;
-      y1[oc * k + p] = v;
-      if (TRAIN) sp.y1[((size_t)g * SP_C1 + oc) * k + p] = v;
+      for (int r = 0; r < 4; ++r) {                   // D[row 4 kq + r][column li] = position 16 mt + 4 kq + r, channel li
+        const int pp = 16 * mt + 4 * kq + r;
+        if (pp < k) {
+          const float a = acc[r] + bias;
+          const float v = a > 0.f ? a : 0.f;
+          y1[li * k + pp] = v;
+          if (TRAIN) sp.y1[((size_t)g * SP_C1 + li) * k + pp] = v;
+        }
+      }
     }
   }
   __syncthreads();
@@ -157,15 +175,35 @@ __global__ __launch_bounds__(SP_WG) void k_sp_fwd(BatchDev b, ModelDev m, SpDev 
     z[i] = a >= c ? a : c;
   }
   __syncthreads();
-  for (int i = tid; i < SP_C2 * Q2; i += SP_WG) {            // conv2 + ReLU; flatten index = oc2 * Q2 + q
-    const int oc = i / Q2, q = i - oc * Q2;
-    float acc = w2[SP_C2 * SP_C1 * SP_KW + oc];
-    for (int ic = 0; ic < SP_C1; ++ic)
+  {   // conv2 + ReLU: y2[oc][q] = relu(bias[oc] + sum_(ic, t) w2[oc][ic][t] z[ic][q + t]): 32 x Q2, K = 80; flatten = oc * Q2 + q
+    const int lane2 = tid & 63, wave2 = tid >> 6, li = lane2 & 15, kq = lane2 >> 4;
+    const int ntq = (Q2 + 15) >> 4;
+    for (int tile = wave2; tile < 2 * ntq; tile += SP_WG / 64) {
+      const int mt = tile / ntq, nt = tile - mt * ntq;
+      const int q = 16 * nt + li;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int k0 = 0; k0 < SP_C1 * SP_KW; k0 += 16) {
+        float av[4], bv[4];
 #pragma unroll
-      for (int t = 0; t < SP_KW; ++t) acc += w2[(oc * SP_C1 + ic) * SP_KW + t] * z[ic * Q1 + q + t];
-    const float v = acc > 0.f ? acc : 0.f;
-    y2[i] = v;
-    sp.flat[(size_t)g * dense + i] = v;             // lin1 / lin2 run batched over the subgraphs (k_sp_lin_fwd)
+        for (int u = 0; u < 4; ++u) {
+          const int kk = k0 + 4 * u + kq, ic = kk / SP_KW, t = kk - ic * SP_KW;
+          av[u] = w2[((16 * mt + li) * SP_C1 + ic) * SP_KW + t];
+          bv[u] = (q < Q2) ? z[ic * Q1 + q + t] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+      }
+      if (q < Q2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int oc = 16 * mt + 4 * kq + r;
+          const float a = acc[r] + w2[SP_C2 * SP_C1 * SP_KW + oc];
+          const float v = a > 0.f ? a : 0.f;
+          y2[oc * Q2 + q] = v;
+          sp.flat[(size_t)g * dense + oc * Q2 + q] = v;             // lin1 / lin2 run batched over the subgraphs (k_sp_lin_fwd)
+        }
+      }
+    }
   }
   (void)a1s; (void)red; (void)lane; (void)wave; (void)inj_mask; (void)seed; (void)step; (void)out;
 }
@@ -309,10 +347,28 @@ __global__ __launch_bounds__(SP_THREADS) void k_sp_dflat(BatchDev b, ModelDev m,
 }
 
 // ---------------------------------------------------------------------------------------------- backward
+// debug aid (IGMC_SP_TIMING=1; igmc_debug_sp_clocks): shader-clock stamps of workgroup 0 of the last k_sp_bwd launch
+__device__ unsigned long long g_sp_clk[16];
+#ifdef IGMC_HIPEMU
+#define SP_STAMP(k) do { } while (0)
+#else
+#define SP_STAMP(k) do { if (timing && blockIdx.x == 0 && threadIdx.x == 0) g_sp_clk[k] = __builtin_readcyclecounter(); } while (0)
+#endif
+extern "C" int igmc_debug_sp_clocks(unsigned long long* out, int n) {
+#ifndef IGMC_HIPEMU
+  if (n > 16) n = 16;
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sp_clk), (size_t)n * sizeof(unsigned long long)) != hipSuccess) return 1;
+#else
+  for (int i = 0; i < n; ++i) out[i] = 0;
+#endif
+  return 0;
+}
 // dynamic LDS: sel[k] | rank[nmax] | w1[16*97] | w2[32*80] | y1[16*k] | z[16*Q1] | dy2[32*Q2] | dzp[16*Q1] | dy1[16*k] | dz[128] | xs[k*98]
 __global__ __launch_bounds__(SP_WG) void k_sp_bwd(BatchDev b, ModelDev m, SpDev sp, const float* __restrict__ Pd,
-                                                        float grad_scale) {
+                                                        float grad_scale, int timing) {
   IGMC_DYN_SMEM(smem);
+  SP_STAMP(0);
   const int g = blockIdx.x, tid = threadIdx.x;
   const int k = sp.k, Q1 = sp.Q1, Q2 = sp.Q2, dense = sp.dense;
   const int n0 = b.node_off[g], n = b.node_off[g + 1] - n0;
@@ -334,6 +390,7 @@ __global__ __launch_bounds__(SP_WG) void k_sp_bwd(BatchDev b, ModelDev m, SpDev 
   // (dz, d out and d flat: k_sp_dflat, batched over the subgraphs)
   for (int i = tid; i < dense; i += SP_WG) dy2[i] = sp.dflat[(size_t)g * dense + i];
   __syncthreads();
+  SP_STAMP(1);
   for (int p = tid; p < k; p += SP_WG)
     if (sel[p] >= 0) rank[sel[p] - n0] = p;
   for (int i = tid; i < SP_C1 * Q1; i += SP_WG) {
@@ -342,30 +399,62 @@ __global__ __launch_bounds__(SP_WG) void k_sp_bwd(BatchDev b, ModelDev m, SpDev 
     z[i] = a >= c ? a : c;
   }
   __syncthreads();
-  // conv2: weight / bias gradient of this graph, gradient w.r.t. the pooled sequence
+  SP_STAMP(2);
+  // conv2: weight / bias gradient of this graph and the gradient w.r.t. the pooled sequence -- three small matrix products
+  // (operands read straight from the LDS arrays, no im2col copy) on v_mfma_f32_16x16x4_f32, one 16 x 16 output tile per wave:
+  //   d w2[oc][(ic, t)] = sum_q dy2[oc][q] z[ic][q + t]              32 x 80, K = Q2:        waves 0..9
+  //   dzp[ic][qp]       = sum_(oc, t) w2[oc][ic][t] dy2[oc][qp - t]   16 x Q1, K = 32 * 5:    waves 10..
+  // (the scalar loops they replace read two LDS words per product: 13 + 9 k cycles of this kernel)
   float* pc2 = sp.part_c2 + (size_t)g * (SP_C2 * SP_C1 * SP_KW + SP_C2);
-  for (int i = tid; i < SP_C2 * SP_C1 * SP_KW; i += SP_WG) {
-    const int oc = i / (SP_C1 * SP_KW), rem = i - oc * (SP_C1 * SP_KW), ic = rem / SP_KW, t = rem - ic * SP_KW;
-    float s = 0.f;
-    for (int q = 0; q < Q2; ++q) s += dy2[oc * Q2 + q] * z[ic * Q1 + q + t];
-    pc2[i] = s;
+  {
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    if (wave < 10) {
+      const int mt = wave / 5, nt = wave - 5 * mt;
+      const int oc = 16 * mt + li, nn = 16 * nt + li, ic = nn / SP_KW, t = nn - ic * SP_KW;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int q0 = 0; q0 < Q2; q0 += 16) {           // (the operands of four k-steps are requested together)
+        float av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int q = q0 + 4 * u + kq;
+          av[u] = (q < Q2) ? dy2[oc * Q2 + q] : 0.f;
+          bv[u] = (q < Q2) ? z[ic * Q1 + q + t] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pc2[(16 * mt + 4 * kq + r) * (SP_C1 * SP_KW) + nn] = acc[r];
+    } else {
+      const int ntiles = (Q1 + 15) >> 4;
+      for (int nt = wave - 10; nt < ntiles; nt += SP_WG / 64 - 10) {
+        const int qp = 16 * nt + li;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < SP_C2 * SP_KW; k0 += 16) {
+          float av[4], bv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int kk = k0 + 4 * u + kq, oc = kk / SP_KW, t = kk - oc * SP_KW, q = qp - t;
+            av[u] = w2[(oc * SP_C1 + li) * SP_KW + t];
+            bv[u] = (q >= 0 && q < Q2 && qp < Q1) ? dy2[oc * Q2 + q] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+        }
+        if (qp < Q1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dzp[(4 * kq + r) * Q1 + qp] = acc[r];
+        }
+      }
+    }
   }
   for (int oc = tid; oc < SP_C2; oc += SP_WG) {
     float s = 0.f;
     for (int q = 0; q < Q2; ++q) s += dy2[oc * Q2 + q];
     pc2[SP_C2 * SP_C1 * SP_KW + oc] = s;
   }
-  for (int i = tid; i < SP_C1 * Q1; i += SP_WG) {
-    const int ic = i / Q1, qp = i - ic * Q1;
-    float s = 0.f;
-    for (int oc = 0; oc < SP_C2; ++oc)
-#pragma unroll
-      for (int t = 0; t < SP_KW; ++t) {
-        const int q = qp - t;
-        if (q >= 0 && q < Q2) s += w2[(oc * SP_C1 + ic) * SP_KW + t] * dy2[oc * Q2 + q];
-      }
-    dzp[i] = s;
-  }
+  SP_STAMP(3);
+  SP_STAMP(4);
   __syncthreads();
   // max-pool (the first maximum takes the gradient, like torch) and conv1's ReLU
   for (int i = tid; i < SP_C1 * k; i += SP_WG) {
@@ -379,6 +468,7 @@ __global__ __launch_bounds__(SP_WG) void k_sp_bwd(BatchDev b, ModelDev m, SpDev 
     dy1[i] = d;
   }
   __syncthreads();
+  SP_STAMP(5);
   // conv1: weight / bias gradient of this graph.  The pooled rows come from LDS (staged once, coalesced): read from global memory inside the p loop they were 360 serial round trips per thread, 100 us of this kernel.
   float* xs = dzs + 128;                             // [k][SP_C + 1]
   for (int i = tid; i < k * 128; i += SP_WG) {
@@ -386,40 +476,83 @@ __global__ __launch_bounds__(SP_WG) void k_sp_bwd(BatchDev b, ModelDev m, SpDev 
     if (c < SP_C) xs[p * (SP_C + 1) + c] = (sel[p] >= 0) ? sp_cat(m, sel[p], c) : 0.f;
   }
   __syncthreads();
+  SP_STAMP(6);
   float* pc1 = sp.part_c1 + (size_t)g * (SP_C1 * SP_C + SP_C1);
-  for (int i = tid; i < SP_C1 * SP_C; i += SP_WG) {
-    const int oc = i / SP_C, j = i - oc * SP_C;
-    float s = 0.f;
-    for (int p = 0; p < k; ++p) {
-      const float d = dy1[oc * k + p];
-      if (d != 0.f && sel[p] >= 0) s += d * xs[p * (SP_C + 1) + j];
+  {   // d w1[oc][j] = sum_p dy1[oc][p] x[p][j]: 16 x 97, K = k, on the f32 matrix cores, waves 0..6 one 16-column tile each
+      // (rows of padding positions are zero in xs; the scalar loop -- 2 k LDS words per output -- was 43 k cycles of 97 k)
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    if (wave < (SP_C + 15) / 16) {
+      const int j = 16 * wave + li;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int p0 = 0; p0 < k; p0 += 16) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int p = p0 + 4 * u + kq;
+          av[u] = (p < k) ? dy1[li * k + p] : 0.f;
+          bv[u] = (p < k && j < SP_C) ? xs[p * (SP_C + 1) + j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+      }
+      if (j < SP_C) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pc1[(4 * kq + r) * SP_C + j] = acc[r];
+      }
     }
-    pc1[i] = s;
   }
   for (int oc = tid; oc < SP_C1; oc += SP_WG) {
     float s = 0.f;
     for (int p = 0; p < k; ++p) s += dy1[oc * k + p];
     pc1[SP_C1 * SP_C + oc] = s;
   }
-  // gradient w.r.t. the node states: every node of the graph is written exactly once (zeros when it was not pooled)
+  SP_STAMP(7);
+  // gradient w.r.t. the node states.  First per POOLED position on the f32 matrix cores, G[p][c] = sum_oc dy1[oc][p] w1[oc][c]
+  // (k x 97, K = 16: 49 tiles over the 16 waves) into the rows' LDS array (the pooled rows are no longer needed), ...
+  __syncthreads();                                   // (conv1's weight gradient has read xs)
+  {
+    const int lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    const int mtiles = (k + 15) >> 4, ntiles = (SP_C + 15) >> 4;
+    for (int tile = wave; tile < mtiles * ntiles; tile += SP_WG / 64) {
+      const int mt = tile / ntiles, nt = tile - mt * ntiles;
+      const int p = 16 * mt + li, c = 16 * nt + li;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      float av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int oc = 4 * u + kq;
+        av[u] = (p < k) ? dy1[oc * k + p] : 0.f;
+        bv[u] = (c < SP_C) ? w1[oc * SP_C + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+      if (c < SP_C) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pp = 16 * mt + 4 * kq + r;
+          if (pp < k) xs[pp * (SP_C + 1) + c] = acc[r];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ... then every node of the graph is written exactly once (zeros when it was not pooled)
   for (int i = tid; i < n * 128; i += SP_WG) {
     const int node = i >> 7, c = i & 127;             // c < 96: channel of h_0..h_2; c >= 96: column c - 96 of dPre_3
     const int p = rank[node];
     const size_t row = (size_t)(n0 + node) * 32;
-    float v = 0.f;
     if (c < 96) {
-      if (p >= 0)
-        for (int oc = 0; oc < SP_C1; ++oc) v += dy1[oc * k + p] * w1[oc * SP_C + c];
-      sp.dcat[c >> 5][row + (c & 31)] = v;
+      sp.dcat[c >> 5][row + (c & 31)] = (p >= 0) ? xs[p * (SP_C + 1) + c] : 0.f;
     } else {
+      float v = 0.f;
       if (p >= 0 && c == 96) {
-        for (int oc = 0; oc < SP_C1; ++oc) v += dy1[oc * k + p] * w1[oc * SP_C + 96];
         const float hv = m.h[3][row];
-        v *= 1.f - hv * hv;
+        v = xs[p * (SP_C + 1) + 96] * (1.f - hv * hv);
       }
       m.dpre[3][row + (c - 96)] = v;
     }
   }
+  SP_STAMP(8);
   (void)dzs; (void)grad_scale;
 }
 
@@ -499,7 +632,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sp_wgrad(BatchDev b, SpDev sp, i
 // ---------------------------------------------------------------------------------------------- host side
 static size_t sp_fwd_lds(const SpDev& sp) {
   return (size_t)(2 * sp.P + sp.k + SP_C1 * SP_C + SP_C1 + SP_C2 * SP_C1 * SP_KW + SP_C2 + SP_C1 * sp.k + SP_C1 * sp.Q1 +
-                  SP_C2 * sp.Q2 + 128 + 8) * 4;
+                  SP_C2 * sp.Q2 + 128 + 8 + sp.k * (SP_C + 1)) * 4;
 }
 static size_t sp_bwd_lds(const SpDev& sp) {
   return (size_t)(sp.k + sp.nmax + SP_C1 * SP_C + SP_C2 * SP_C1 * SP_KW + SP_C1 * sp.k + SP_C1 * sp.Q1 + SP_C2 * sp.Q2 +
@@ -540,7 +673,7 @@ void igmc_launch_sp_backward(const ModelDev& m, const SpDev& sp, const BatchDev&
                              void* stream) {
   IGMC_PLAUNCH("k_sp_dflat", k_sp_dflat, dim3((B + 15) / 16, (sp.dense / 16 + 3) / 4), SP_THREADS, 0, stream, b, m, sp, Pd,
                grad_scale);
-  IGMC_PLAUNCH("k_sp_bwd", k_sp_bwd, B, SP_WG, sp_bwd_lds(sp), stream, b, m, sp, Pd, grad_scale);
+  IGMC_PLAUNCH("k_sp_bwd", k_sp_bwd, B, SP_WG, sp_bwd_lds(sp), stream, b, m, sp, Pd, grad_scale, getenv("IGMC_SP_TIMING") ? 1 : 0);
 }
 
 void igmc_launch_sp_wgrad(const ModelDev& m, const SpDev& sp, const BatchDev& b, int B, const float* ge, float* Gd,
