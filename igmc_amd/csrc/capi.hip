@@ -1616,11 +1616,11 @@ extern "C" int igmc_sortpool_loss_grad(igmc_sortpool* sp, const float* d_params,
   const int B = b->last_B;
   ensure_csr(b, stream);
   igmc_launch_sp_pack(m->d, sp->d, d_params, sp->pe, stream);
-  igmc_launch_conv_forward(m->d, b->d, sp->pe, B, 1, use_edge_flags, stream);
+  ModelDev md = m->d;        // (with the dense readout gradient: the conv kernels then know which backward form follows)
+  for (int l = 0; l < 3; ++l) md.dcat[l] = sp->d.dcat[l];
+  igmc_launch_conv_forward(md, b->d, sp->pe, B, 1, use_edge_flags, stream);
   igmc_launch_sp_forward(m->d, sp->d, b->d, d_params, B, 1, d_lin_mask, seed, step, d_out, stream);
   igmc_launch_sp_backward(m->d, sp->d, b->d, d_params, B, grad_scale > 0.f ? grad_scale : 1.f / (float)B, stream);
-  ModelDev md = m->d;
-  for (int l = 0; l < 3; ++l) md.dcat[l] = sp->d.dcat[l];
   igmc_launch_conv_backward(md, b->d, sp->pe, B, use_edge_flags, ARR * arr_scale, sp->ge, stream);
   igmc_launch_sp_wgrad(m->d, sp->d, b->d, B, sp->ge, d_grad, stream);
   if (d_loss) igmc_launch_loss(m->d, b->d, ARR, d_loss, stream);

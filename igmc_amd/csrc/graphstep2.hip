@@ -1957,8 +1957,12 @@ struct DlbArgs {
   const uint8_t* relmT;
   int cap_u, cap_v, relm_ld, relmT_ld, nq, R, L, D, kp;
   const float* h[3];             // h_0 .. h_2
-  const float* dpre3;            // [N, 32]: the head's dPre_3 (target rows)
+  const float* dpre3;            // [N, 32]: the head's dPre_3 (target rows; dense3: every row)
   const float* gfeat;            // [B, D] readout gradient on the target rows
+  // dense3 != 0 (sort-pool readout, reference models.py:123-167): dPre_3 is dense -- planes and own rows of layer 3 are staged from
+  // dpre3's rows -- and the readout gradient of layers 0..2 arrives per row in dcat[l] [N, 32] instead of gfeat on the target rows
+  int dense3;
+  const float* dcat[3];
   const float* g2_w;
   const uint16_t* cnt0;
   float* ts_part;
@@ -2099,8 +2103,41 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
     head_sub_body<true>(a.hb, a.hm, a.P, g, tid, (float*)sW2, a.inj_mask, a.seed, hstep, a.mult, a.grad_scale, a.out);
     __syncthreads();
   }
-  const float d3 = (tid < 64) ? a.dpre3[(size_t)((tid >> 5) ? own0 : opp0) * 32 + (tid & 31)] : 0.f;   // opposite | own target row
-  if (tid < 32) {                                  // dPre_3 of the opposite side's target node: the three terms of node 0
+  if (a.dense3) {
+    // dPre_3 of every row: the opposite side's rows as bf16 planes (a thread: two nodes x four features, as k_dl_layer stages
+    // its input), the bundles' own rows into their tiles
+    const int tstride = 32 * kp >> 1;
+#pragma unroll
+    for (int u = 0; u < DL_PIT; ++u) {
+      const int i = tid + u * DL_THREADS, jp = i >> 3, fq = i & 7;
+      if (i >= 16 * nks * 8) continue;
+      const bool k0 = 2 * jp < n_opp, k1 = 2 * jp + 1 < n_opp;
+      const int j0 = k0 ? 2 * jp : n_opp - 1, j1 = k1 ? 2 * jp + 1 : n_opp - 1;
+      const float4 x0 = *(const float4*)(a.dpre3 + (size_t)(opp0 + j0) * 32 + 4 * fq);
+      const float4 x1 = *(const float4*)(a.dpre3 + (size_t)(opp0 + j1) * 32 + 4 * fq);
+      const float v0[4] = {x0.x, x0.y, x0.z, x0.w}, v1[4] = {x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        uint32_t h, mi, lo;
+        g2_split2(k0 ? v0[c] : 0.f, k1 ? v1[c] : 0.f, h, mi, lo);
+        uint32_t* pp = PLN + ((4 * fq + c) * kp >> 1) + jp;
+        pp[0] = h;
+        pp[tstride] = mi;
+        pp[2 * tstride] = lo;
+      }
+    }
+    if (active) {
+      float* XOw = XOA + wave * 16 * G2_XP;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = lane + 64 * u, r = i >> 3, c4 = i & 7;
+        if (row0 + r < n_own) *(float4*)(XOw + r * G2_XP + 4 * c4) = *(const float4*)(a.dpre3 + (size_t)(own0 + row0 + r) * 32 + 4 * c4);
+      }
+    }
+  }
+  const float d3 = (!a.dense3 && tid < 64) ? a.dpre3[(size_t)((tid >> 5) ? own0 : opp0) * 32 + (tid & 31)] : 0.f;   // opposite | own target row
+  if (a.dense3) {
+  } else if (tid < 32) {                           // dPre_3 of the opposite side's target node: the three terms of node 0
     uint32_t h, mi, lo;
     g2_split2(d3, 0.f, h, mi, lo);
     uint32_t* p2 = PLN + (tid * kp >> 1);
@@ -2149,7 +2186,8 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
           const int rw2 = row0 + 4 * kq_ + rr, rwc = rw2 < n_own ? rw2 : n_own - 1;
           const float hv = a.h[l - 1][(size_t)(own0 + rwc) * 32 + 16 * nt + li_];
           xprev[nt][rr] = (rw2 < n_own) ? hv : 0.f;      // (rows past the side: zero K entries of the table product)
-          addv[nt][rr] = (rw2 == 0) ? a.gfeat[(size_t)g * a.D + side * 128 + (l - 1) * 32 + 16 * nt + li_] : 0.f;
+          if (a.dense3) addv[nt][rr] = (rw2 < n_own) ? a.dcat[l - 1][(size_t)(own0 + rwc) * 32 + 16 * nt + li_] : 0.f;
+          else addv[nt][rr] = (rw2 == 0) ? a.gfeat[(size_t)g * a.D + side * 128 + (l - 1) * 32 + 16 * nt + li_] : 0.f;
         }
     }
 #pragma unroll 1
@@ -2198,7 +2236,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
       if (active) {
         const int tstride = 32 * kp >> 1, toff = 16 * kp >> 1;
         const uint32_t* base = PLN + (li * kp >> 1) + 4 * kq;
-        const int nke = (l == 3) ? 1 : nks;           // dPre_3 lives on node 0: one k-step
+        const int nke = (l == 3 && !a.dense3) ? 1 : nks;      // dPre_3 of the centre-node readout lives on node 0: one k-step
 #pragma unroll 1
         for (int s = 0; s < nke; ++s) {
           const uint2 w = *(const uint2*)(rmo + 32 * s);
@@ -2738,7 +2776,7 @@ int igmc_dl_bwd_eligible(const ModelDev& m, const BatchDev& b, int B) {
   return (size_t)dlb_words(32 * ((cmax + 31) >> 5) + 8) * 4 <= (size_t)160 * 1024;
 }
 
-void igmc_launch_dl_bwd(const ModelDev& m, const BatchDev& b, int B, int use_flags, void* stream, const DlHead* head) {
+void igmc_launch_dl_bwd(const ModelDev& m, const BatchDev& b, int B, int use_flags, void* stream, const DlHead* head, int dense3) {
   DlbArgs a;
   memset(&a, 0, sizeof(a));
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
@@ -2752,6 +2790,10 @@ void igmc_launch_dl_bwd(const ModelDev& m, const BatchDev& b, int B, int use_fla
   a.ex = m.g2_ex; a.ex_stride = m.g2_ex_stride;
   a.gs_bar = m.gs_bar; a.gs_err = m.gs_err;
   a.timing = getenv("IGMC_DL_TIMING") ? atoi(getenv("IGMC_DL_TIMING")) : 0;
+  if (dense3) {
+    a.dense3 = 1;
+    for (int l = 0; l < 3; ++l) a.dcat[l] = m.dcat[l];
+  }
   if (head) {
     a.head = 1; a.hb = b; a.hm = m; a.P = head->P; a.inj_mask = head->inj_mask; a.seed = head->seed; a.step = head->step;
     a.mult = head->mult; a.grad_scale = head->grad_scale; a.out = head->out;

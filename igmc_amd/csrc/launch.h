@@ -106,7 +106,9 @@ struct DlHead {
   float mult, grad_scale;
   float* out;
 };
-void igmc_launch_dl_bwd(const ModelDev& m, const BatchDev& b, int B, int use_flags, void* stream, const DlHead* head = nullptr);
+// (dense3: the sort-pool family's backward -- dPre_3 of every row from m.dpre[3], the readout gradient of layers 0..2 from m.dcat)
+void igmc_launch_dl_bwd(const ModelDev& m, const BatchDev& b, int B, int use_flags, void* stream, const DlHead* head = nullptr,
+                        int dense3 = 0);
 void igmc_launch_dl_fwd(const ModelDev& m, const BatchDev& b, const float* P, int B, int training, int use_flags,
                         float* zero_out, int self_seq, void* stream);
 void igmc_launch_head_sub(const ModelDev& m, const BatchDev& b, const float* P, int B, const uint8_t* inj_mask, uint64_t seed,

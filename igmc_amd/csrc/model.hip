@@ -2200,6 +2200,19 @@ void igmc_launch_forward(const ModelDev& m, const ModelAux& ax, const BatchDev& 
   (void)ax;
 }
 
+static inline int igmc_fin_mode() {
+  const char* fe = getenv("IGMC_FIN_MODE");        // 0: the hand-off version of the gradient / Adam tail (k_finalize); read
+  return fe ? atoi(fe) : 1;                        // on every call: tests switch it per case
+}
+
+// 1 = the conv backward of a dense readout gradient (sort-pool family) takes the one-launch form with relation-space tables
+// (igmc_launch_conv_backward); the forward then need not leave the Y products behind
+static int igmc_conv_bwd_tables(const ModelDev& m, const BatchDev& b, int B) {
+  const int fts = igmc_fin_mode() && m.fin_stash && m.datt_part && m.R <= 8;
+  return fts && m.R * m.L + m.L + 1 <= 32 && m.dcat[0] && igmc_dl_eligible(m, b, B) && igmc_dl_fwd_eligible(m, b, B) &&
+         igmc_dl_bwd_eligible(m, b, B);
+}
+
 // The four conv layers alone (h_0..h_3 left in HBM): the per-layer kernels, whatever the readout that follows
 // (centre-node readout of IGMC: igmc_launch_forward; sort-pool readout of DGCNN_RS: sortpool.hip)
 void igmc_launch_conv_forward(const ModelDev& m, const BatchDev& b, const float* P, int B, int training, int use_flags,
@@ -2240,7 +2253,7 @@ void igmc_launch_conv_forward(const ModelDev& m, const BatchDev& b, const float*
     }
   }
   // training: the products Y_l = h_{l-1} @ [basis_0 | .. | basis_3] the backward's att gradient reads
-  if (training) IGMC_PLAUNCH("k_dense_y_all", k_dense_y_all, dim3(g64, 3), IGMC_BLOCK, ysz, stream, b, m, P);
+  if (training && !igmc_conv_bwd_tables(m, b, B)) IGMC_PLAUNCH("k_dense_y_all", k_dense_y_all, dim3(g64, 3), IGMC_BLOCK, ysz, stream, b, m, P);
 }
 
 void igmc_launch_backward(const ModelDev& m, const ModelAux& ax, const BatchDev& b, const float* P, int B, int use_flags,
@@ -2283,6 +2296,22 @@ void igmc_launch_conv_backward(const ModelDev& m, const BatchDev& b, const float
   const int gt = igmc_xcd_grid(m, B, 16, 2048);
   const size_t bsm4 = (size_t)(16 * IGMC_TP + 1024 + m.R * 4 + 16 * m.R * 4) * sizeof(float);
   const int dl = igmc_dl_eligible(m, b, B);     // (the images of this step were composed by the forward)
+  // Dense readout gradient (sort-pool family) on the one-launch backward of the dense layers: dPre_3 of every row from
+  // m.dpre[3], the readout gradient of layers 0..2 added per row from m.dcat, relation-space tables -> k_tail_ts (no lin1 / lin2
+  // role) -> k_finalize_ts: three launches instead of the three layer passes, the Y products' consumers (k_wgrad), the
+  // partials' reduction and k_finalize.  (IGMC_DL_TS=0 / IGMC_DL_FUSED=0|1: the per-layer form below.)
+  {
+    if (igmc_conv_bwd_tables(m, b, B)) {
+      igmc_launch_dl_bwd(m, b, B, use_flags, stream, nullptr, 1);
+      const int gstride = (B + 7) & ~7, gg = igmc_dl_grid(b, B) / B * gstride;
+      IGMC_PLAUNCH("k_tail_ts", k_tail_ts, (4 * m.ts_stride + 63) / 64 + 4, IGMC_BLOCK, 0, stream, b, m, P, 0.f, 1.f, 2.f, grad,
+                   0, gg, gstride, B, 4, (const int64_t*)nullptr, 1);
+      AdamTail none;
+      memset(&none, 0, sizeof(none));
+      IGMC_PLAUNCH("k_finalize", k_finalize_ts, 4 * IGMC_FTS_NB, IGMC_BLOCK, 0, stream, m, P, grad, arr_coef, none, 0, 0, 0);
+      return;
+    }
+  }
   for (int l = 3; l >= 1; --l) {
     // transposed gather of dPre_l (+ d att partials), then [G | dPre_l] @ [basis^T ; root^T] + backward epilogue
     if (dl) {
@@ -2313,10 +2342,6 @@ void igmc_launch_conv_backward(const ModelDev& m, const BatchDev& b, const float
 
 // Fused-step sequence (loss + gradients [+ Adam]) with the multi-role launches:
 //   l0_fwd, 3 x layer_fwd, {head fwd+bwd | Y}, 3 x layer_bwd, {weight grads | lin grads}, reduce, finalize[+Adam]
-static inline int igmc_fin_mode() {
-  const char* fe = getenv("IGMC_FIN_MODE");        // 0: the hand-off version of the gradient / Adam tail (k_finalize); read
-  return fe ? atoi(fe) : 1;                        // on every call: tests switch it per case
-}
 
 int igmc_step_exchange_inside(const ModelDev& m, const BatchDev& b, int B) {
   const int ny = (m.D / 16 + 3) / 4;

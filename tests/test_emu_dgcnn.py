@@ -14,7 +14,10 @@ def be():
 
 
 def sub(name, n):
+    name, _, cap = name.partition(':')       # 'case:cap' = the case's graph and links with another per-hop cap
     case = dict(CASES[name])
+    if cap:
+        case['mnph'] = int(cap)
     case['recs'], case['links'], case['link_labels'] = case['recs'][:n], case['links'][:n], case['link_labels'][:n]
     return case
 
@@ -76,3 +79,25 @@ def test_sortpool_kernels_against_the_reference_models_py_fixture(be):
     from helpers import load_model_golden
     res = PC.run_reference_fixture_dgcnn(be, load_model_golden('dgcnn_rs'), 8)
     assert res['k'] == 40
+
+
+@pytest.mark.parametrize('form', ['tables', 'per_layer'])
+@pytest.mark.parametrize('name,n,k,drop', [('synth_cap', 6, 40, True), ('synth_nocap:100', 4, 30, False)])
+def test_dgcnn_rs_on_the_dense_layer_kernels(be, monkeypatch, name, n, k, drop, form):
+    """The conv layers of the sort-pool family on the dense-layer kernels (arenas with the transposed block): forward as ONE
+    launch, backward either as ONE launch with relation-space tables -- dPre_3 of every row and the per-row readout gradient
+    ``dcat`` instead of the centre-node head's target rows -- or one launch per layer pass (G / Y form, IGMC_DL_TS=0)."""
+    monkeypatch.setenv('IGMC_DL_ALWAYS', '1')
+    monkeypatch.setenv('IGMC_GRAPH_STEP', '0')
+    if form == 'per_layer':
+        monkeypatch.setenv('IGMC_DL_TS', '0')
+    from igmc_amd import engine
+    engine.profile_enable(be.lib, True)
+    try:
+        res = PC.run_dgcnn_parity(be, sub(name, n), R=5, k=k, use_dropout=drop)
+        ran = [nm for nm, _, _ in engine.profile_fetch(be.lib)]
+    finally:
+        engine.profile_enable(be.lib, False)
+    assert res['worst_grad_err'] < 1e-3
+    assert 'k_dl_fwd' in ran
+    assert ('k_dl_bwd' in ran) == (form == 'tables') and ('k_dl_layer_bwd' in ran) == (form == 'per_layer'), ran
