@@ -52,11 +52,11 @@ __global__ __launch_bounds__(SP_THREADS) void k_sp_pack(ModelDev m, SpDev sp, co
 }
 
 // true-layout gradient of the conv parameters <- engine-layout gradient
-__global__ __launch_bounds__(SP_THREADS) void k_sp_unpack(ModelDev m, SpDev sp, const float* __restrict__ ge,
-                                                           float* __restrict__ Gd) {
+__device__ __forceinline__ void sp_unpack_body(const ModelDev& m, const SpDev& sp, const float* __restrict__ ge,
+                                               float* __restrict__ Gd, int blk, int nblk) {
   const int64_t n = sp.t_conv_end;
   const int64_t o3 = m.off_basis[3];
-  for (int64_t i = (int64_t)blockIdx.x * SP_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * SP_THREADS) {
+  for (int64_t i = (int64_t)blk * SP_THREADS + threadIdx.x; i < n; i += (int64_t)nblk * SP_THREADS) {
     float v;
     if (i < o3) v = ge[i];
     else if (i < sp.t_root3) v = ge[m.off_basis[3] + (i - sp.t_basis3) * 32];
@@ -65,6 +65,10 @@ __global__ __launch_bounds__(SP_THREADS) void k_sp_unpack(ModelDev m, SpDev sp, 
     else v = ge[m.off_att[3] + (i - sp.t_att3)];
     Gd[i] = v;
   }
+}
+__global__ __launch_bounds__(SP_THREADS) void k_sp_unpack(ModelDev m, SpDev sp, const float* __restrict__ ge,
+                                                           float* __restrict__ Gd) {
+  sp_unpack_body(m, sp, ge, Gd, blockIdx.x, gridDim.x);
 }
 
 // one channel of the concatenated state of node i
@@ -559,9 +563,16 @@ __global__ __launch_bounds__(SP_WG) void k_sp_bwd(BatchDev b, ModelDev m, SpDev 
 // ---------------------------------------------------------------------------------------------- weight gradients over the batch
 // blocks [0, nb1): lin1.weight tiles (one element per thread: sum over the graphs of dz[g][j] * flat[g][i]);
 // then the conv1 / conv2 partial sums (one output per thread) and one block for lin1.bias + lin2
-__global__ __launch_bounds__(SP_THREADS) void k_sp_wgrad(BatchDev b, SpDev sp, int B, int nb1, float* __restrict__ Gd) {
+// ... and (nun > 0) nun more blocks that bring the conv parameters' gradient from the engine layout into the true one (what
+// k_sp_unpack does as a launch of its own): disjoint elements of Gd, nothing in this launch reads them
+__global__ __launch_bounds__(SP_THREADS) void k_sp_wgrad(BatchDev b, SpDev sp, int B, int nb1, float* __restrict__ Gd, ModelDev m,
+                                                          const float* __restrict__ ge, int nun) {
   const int tid = threadIdx.x;
   const int dense = sp.dense;
+  if ((int)blockIdx.x >= (int)gridDim.x - nun) {
+    sp_unpack_body(m, sp, ge, Gd, (int)blockIdx.x - ((int)gridDim.x - nun), nun);
+    return;
+  }
   if ((int)blockIdx.x < nb1) {
     // d lin1.weight[j][i] = sum_g dz[g][j] flat[g][i]: 8 x (dense / 16) output tiles, one per wave, K = the subgraphs
     const int lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
@@ -680,6 +691,6 @@ void igmc_launch_sp_wgrad(const ModelDev& m, const SpDev& sp, const BatchDev& b,
                           void* stream) {
   const int nb1 = (8 * (sp.dense / 16) + 3) / 4;        // d lin1.weight: one 16 x 16 output tile per wave
   const int nbc = (SP_C1 * SP_C + SP_C1 + SP_THREADS - 1) / SP_THREADS + (SP_C2 * SP_C1 * SP_KW + SP_C2 + SP_THREADS - 1) / SP_THREADS;
-  IGMC_PLAUNCH("k_sp_wgrad", k_sp_wgrad, nb1 + nbc + 1, SP_THREADS, 0, stream, b, sp, B, nb1, Gd);
-  IGMC_PLAUNCH("k_sp_unpack", k_sp_unpack, 64, SP_THREADS, 0, stream, m, sp, ge, Gd);
+  const int nun = 32;
+  IGMC_PLAUNCH("k_sp_wgrad", k_sp_wgrad, nb1 + nbc + 1 + nun, SP_THREADS, 0, stream, b, sp, B, nb1, Gd, m, ge, nun);
 }

@@ -30,6 +30,7 @@ timeout 300 python bench.py --dgcnn-rs --config douban --steps 200 --warmup 20 -
 timeout 200 python tools/g2_phase_clocks.py > $O/phase_clocks.txt 2>&1
 timeout 200 python tools/dl_phase_clocks.py flixster 0 2>&1 | grep -v amdgpu.ids > $O/dl_phase_clocks_flixster.txt
 timeout 200 python tools/dl_phase_clocks.py ml_100k 0 2>&1 | grep -v amdgpu.ids > $O/dl_phase_clocks_ml100k.txt
+timeout 200 python tools/sp_phase_clocks.py 2>&1 | grep -v amdgpu.ids | tail -11 > $O/sp_bwd_phase_clocks.txt
 timeout 200 python tools/g2_phase_clocks.py --overlap > $O/phase_clocks_overlap.txt 2>&1
 python - "$O" <<'PY'
 import json,glob,sys
