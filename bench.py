@@ -74,7 +74,7 @@ CONFIGS = {
 PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')      # (ml_1m; other configs: r04_pmc_traffic_<config>.json)
 # timer label of the HIP-event profile -> kernel symbol in the code object (what rocprofv3 lists)
 SYMBOLS = {'k_dl_layer_fwd': 'k_dl_layer<FLAGS, false, false>', 'k_rgcn_layer_fwd': 'k_rgcn_layer4<FLAGS, false>',
-           'k_dl_bwd': 'k_dl_bwd<FLAGS, NG>', 'k_dl_fwd': 'k_dl_fwd<FLAGS, true, NG>'}
+           'k_dl_bwd': 'k_dl_bwd<FLAGS, NG, false>', 'k_dl_fwd': 'k_dl_fwd<FLAGS, true, NG>'}
 
 
 def kernel_source_sha():
@@ -560,7 +560,7 @@ def main():
             if dom == 'k_graph_step':
                 symbol = 'k_graph_step2<%s, true>' % flags
             elif dom == 'k_dl_bwd':       # (NG: relation groups of five, graphstep2.hip)
-                symbol = 'k_dl_bwd<%s, %d>' % (flags, (len(class_values) + 4) // 5)
+                symbol = 'k_dl_bwd<%s, %d, %s>' % (flags, (len(class_values) + 4) // 5, 'true' if args.dgcnn_rs else 'false')
             elif dom == 'k_dl_fwd':
                 symbol = 'k_dl_fwd<%s, true, %d>' % (flags, (len(class_values) + 4) // 5)
             roofline = dict(bound='hbm', kernel=symbol, timer_label=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',

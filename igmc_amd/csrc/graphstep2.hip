@@ -1994,7 +1994,9 @@ __host__ __device__ static inline int dlb_words(int kp, int ng = 1) {
 // NG > 1 (relation groups, g2_image.h): a layer runs group after group -- gather, transform (accumulating dX), T' tiles, the
 // group's blocks of the table.  The next group's gather needs the planes again, so here the tiles take the place of the
 // IMAGE only: four bundles' tiles at a time (two rounds of the table product for a workgroup with more than four bundles).
-template <bool FLAGS, int NG>
+// DENSE3: the sort-pool family's dense readout gradient (DlbArgs::dense3; a compile-time switch: as a run-time one it cost the
+// centre-node variants 2 us).
+template <bool FLAGS, int NG, bool DENSE3>
 __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
   constexpr int HP = (NG == 1) ? G2_XP : DLF_HP2;           // pitch of a row's layer-0 input
   constexpr int C0N = (NG == 1) ? 5 : 11;                   // histogram entries a lane holds: 16 R L / 64
@@ -2097,13 +2099,13 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
     }
   }
   __syncthreads();
-  if (a.head) {   // loss head of the subgraph in the image's space (free until the first layer stages its image); what it leaves
+  if (!DENSE3 && a.head) {   // loss head of the subgraph in the image's space (free until the first layer stages its image); what it leaves
                   // in HBM -- dPre_3 of the target rows, d feat -- is read back below by this very workgroup (barrier in between)
     const uint64_t hstep = a.hm.ctrl ? (uint64_t)a.hm.ctrl[IGMC_CTRL_STEP] : a.step;
     head_sub_body<true>(a.hb, a.hm, a.P, g, tid, (float*)sW2, a.inj_mask, a.seed, hstep, a.mult, a.grad_scale, a.out);
     __syncthreads();
   }
-  if (a.dense3) {
+  if (DENSE3) {
     // dPre_3 of every row: the opposite side's rows as bf16 planes (a thread: two nodes x four features, as k_dl_layer stages
     // its input), the bundles' own rows into their tiles
     const int tstride = 32 * kp >> 1;
@@ -2135,8 +2137,8 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
       }
     }
   }
-  const float d3 = (!a.dense3 && tid < 64) ? a.dpre3[(size_t)((tid >> 5) ? own0 : opp0) * 32 + (tid & 31)] : 0.f;   // opposite | own target row
-  if (a.dense3) {
+  const float d3 = (!DENSE3 && tid < 64) ? a.dpre3[(size_t)((tid >> 5) ? own0 : opp0) * 32 + (tid & 31)] : 0.f;   // opposite | own target row
+  if (DENSE3) {
   } else if (tid < 32) {                           // dPre_3 of the opposite side's target node: the three terms of node 0
     uint32_t h, mi, lo;
     g2_split2(d3, 0.f, h, mi, lo);
@@ -2186,7 +2188,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
           const int rw2 = row0 + 4 * kq_ + rr, rwc = rw2 < n_own ? rw2 : n_own - 1;
           const float hv = a.h[l - 1][(size_t)(own0 + rwc) * 32 + 16 * nt + li_];
           xprev[nt][rr] = (rw2 < n_own) ? hv : 0.f;      // (rows past the side: zero K entries of the table product)
-          if (a.dense3) addv[nt][rr] = (rw2 < n_own) ? a.dcat[l - 1][(size_t)(own0 + rwc) * 32 + 16 * nt + li_] : 0.f;
+          if (DENSE3) addv[nt][rr] = (rw2 < n_own) ? a.dcat[l - 1][(size_t)(own0 + rwc) * 32 + 16 * nt + li_] : 0.f;
           else addv[nt][rr] = (rw2 == 0) ? a.gfeat[(size_t)g * a.D + side * 128 + (l - 1) * 32 + 16 * nt + li_] : 0.f;
         }
     }
@@ -2236,7 +2238,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
       if (active) {
         const int tstride = 32 * kp >> 1, toff = 16 * kp >> 1;
         const uint32_t* base = PLN + (li * kp >> 1) + 4 * kq;
-        const int nke = (l == 3 && !a.dense3) ? 1 : nks;      // dPre_3 of the centre-node readout lives on node 0: one k-step
+        const int nke = (l == 3 && !DENSE3) ? 1 : nks;      // dPre_3 of the centre-node readout lives on node 0: one k-step
 #pragma unroll 1
         for (int s = 0; s < nke; ++s) {
           const uint2 w = *(const uint2*)(rmo + 32 * s);
@@ -2805,11 +2807,16 @@ void igmc_launch_dl_bwd(const ModelDev& m, const BatchDev& b, int B, int use_fla
   hipemu::rt().co_stride = -1;
 #endif
   if (g2_groups(m.R, m.L) == 1) {
-    if (use_flags) IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<true, 1>), grid, DL_THREADS, sm, stream, a);
-    else IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<false, 1>), grid, DL_THREADS, sm, stream, a);
-  } else {
-    if (use_flags) IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<true, 2>), grid, DL_THREADS, sm, stream, a);
-    else IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<false, 2>), grid, DL_THREADS, sm, stream, a);
+    if (dense3) {
+      if (use_flags) IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<true, 1, true>), grid, DL_THREADS, sm, stream, a);
+      else IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<false, 1, true>), grid, DL_THREADS, sm, stream, a);
+    } else {
+      if (use_flags) IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<true, 1, false>), grid, DL_THREADS, sm, stream, a);
+      else IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<false, 1, false>), grid, DL_THREADS, sm, stream, a);
+    }
+  } else {        // (relation groups: centre-node readout only -- igmc_conv_bwd_tables asks for the one-group layout)
+    if (use_flags) IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<true, 2, false>), grid, DL_THREADS, sm, stream, a);
+    else IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<false, 2, false>), grid, DL_THREADS, sm, stream, a);
   }
 }
 
@@ -2823,7 +2830,8 @@ int igmc_dl_prepare() {
   if (hipFuncSetAttribute((const void*)k_dl_layer<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_dl_layer<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
 #define DL_MAXLDS(k) if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1
-  DL_MAXLDS((k_dl_bwd<true, 1>)); DL_MAXLDS((k_dl_bwd<false, 1>)); DL_MAXLDS((k_dl_bwd<true, 2>)); DL_MAXLDS((k_dl_bwd<false, 2>));
+  DL_MAXLDS((k_dl_bwd<true, 1, false>)); DL_MAXLDS((k_dl_bwd<false, 1, false>)); DL_MAXLDS((k_dl_bwd<true, 2, false>)); DL_MAXLDS((k_dl_bwd<false, 2, false>));
+  DL_MAXLDS((k_dl_bwd<true, 1, true>)); DL_MAXLDS((k_dl_bwd<false, 1, true>));
   DL_MAXLDS((k_dl_fwd<true, true, 1>)); DL_MAXLDS((k_dl_fwd<false, true, 1>)); DL_MAXLDS((k_dl_fwd<true, false, 1>)); DL_MAXLDS((k_dl_fwd<false, false, 1>));
   DL_MAXLDS((k_dl_fwd<true, true, 2>)); DL_MAXLDS((k_dl_fwd<false, true, 2>)); DL_MAXLDS((k_dl_fwd<true, false, 2>)); DL_MAXLDS((k_dl_fwd<false, false, 2>));
 #undef DL_MAXLDS

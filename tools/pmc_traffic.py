@@ -35,7 +35,7 @@ def main():
     name = NAME
     KERNEL = 'k_graph_step2<false, true>' if config == 'ml_1m' else 'k_graph_step2<true, true>'
     if config == 'ml_100k':                  # cap 200: the one-launch backward of the dense layers (edge dropout: <true>)
-        name, KERNEL = 'k_dl_bwd', 'k_dl_bwd<true, 1>'
+        name, KERNEL = 'k_dl_bwd', 'k_dl_bwd<true, 1, false>'
     c = {}
     for f in ('pmc1.txt', 'pmc2.txt'):
         c.update(counters('%s/%s' % (src, f), KERNEL))
