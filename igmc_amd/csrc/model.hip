@@ -1425,15 +1425,53 @@ __device__ __forceinline__ void fin_stash_body(const ModelDev& m, const float* _
                                                const int64_t* ctrl) {
   __shared__ float sg10[4][10];
   __shared__ float sG[16];
+  __shared__ float s_att[128];                       // att[r][b] of the layer (R <= 32: else read from HBM where needed)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nE = ((l == 0) ? m.L : 32) * 32, R = m.R, na = R * 4;
   const float* basis = P + m.off_basis[l];
-  const float* att = P + m.off_att[l];
+  const float* attg = P + m.off_att[l];
   float* st = m.fin_stash + l * IGMC_STASH_LAYER;
+  // Every load of the role is requested HERE, before the first use: att, the thread's (<= 4) elements of the four bases, att's
+  // Adam moments, the step's scalars.  Left inside the loops below they were a dozen dependent round trips -- the longest
+  // chain of the whole k_tail_ts launch.
+  const bool small = na <= 128;
+  const float attv = (small && tid < na) ? attg[tid] : 0.f;
+  float bq[4][4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int e = tid + it * IGMC_BLOCK, ec = e < nE ? e : nE - 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bq[it][q] = (e < nE) ? basis[q * nE + ec] : 0.f;
+  }
+  float m1v = 0.f, m2v = 0.f;
+  const bool mom = m.adam_m1 && na <= 64 && tid >= 128 && tid < 128 + na;
+  if (mom) {
+    m1v = m.adam_m1[m.off_att[l] + tid - 128];
+    m2v = m.adam_m2[m.off_att[l] + tid - 128];
+  }
+  double scal = 0.0;
+  const bool sc = l == 0 && ctrl && tid >= 192 && tid < 198;
+  if (sc) {
+    const double* d = (const double*)ctrl;
+    const int k = tid - 192;
+    const int src = (k == 0) ? IGMC_CTRL_STEP_SIZE : (k == 1) ? IGMC_CTRL_INV_SQRT_BC2 : (k == 2) ? IGMC_CTRL_BETA1
+                  : (k == 3) ? IGMC_CTRL_BETA2 : (k == 4) ? IGMC_CTRL_EPS : IGMC_CTRL_WD;
+    scal = d[src];
+  }
+  if (small && tid < na) s_att[tid] = attv;
   float gp[10];
 #pragma unroll
   for (int q = 0; q < 10; ++q) gp[q] = 0.f;
-  for (int e = tid; e < nE; e += IGMC_BLOCK) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {                     // (element order per thread as before: e = tid, tid + 256, ..)
+    if (tid + it * IGMC_BLOCK < nE) {
+      const float b0 = bq[it][0], b1 = bq[it][1], b2 = bq[it][2], b3 = bq[it][3];
+      gp[0] += b0 * b0; gp[1] += b0 * b1; gp[2] += b0 * b2; gp[3] += b0 * b3;
+      gp[4] += b1 * b1; gp[5] += b1 * b2; gp[6] += b1 * b3;
+      gp[7] += b2 * b2; gp[8] += b2 * b3; gp[9] += b3 * b3;
+    }
+  }
+  for (int e = tid + 4 * IGMC_BLOCK; e < nE; e += IGMC_BLOCK) {      // (nE <= 1024: never)
     const float b0 = basis[e], b1 = basis[nE + e], b2 = basis[2 * nE + e], b3 = basis[3 * nE + e];
     gp[0] += b0 * b0; gp[1] += b0 * b1; gp[2] += b0 * b2; gp[3] += b0 * b3;
     gp[4] += b1 * b1; gp[5] += b1 * b2; gp[6] += b1 * b3;
@@ -1445,6 +1483,8 @@ __device__ __forceinline__ void fin_stash_body(const ModelDev& m, const float* _
 #pragma unroll
     for (int q = 0; q < 10; ++q) sg10[wave][q] = gp[q];
   }
+  __syncthreads();                                   // s_att, sg10
+  const float* att = small ? (const float*)s_att : attg;
   if (tid >= 64 && tid < 80) {           // M[b][b'] = sum_r att[r,b] c[r,b'],  c[r] = 2 (d[r-1] - d[r]),  d[r] = att[r+1]-att[r]
     const int bb = (tid - 64) >> 2, bp = tid & 3;
     float sacc = 0.f;
@@ -1459,19 +1499,12 @@ __device__ __forceinline__ void fin_stash_body(const ModelDev& m, const float* _
     for (int i = tid - 128; i < na; i += IGMC_BLOCK - 128) {
       st[IGMC_STASH_ATT + i] = att[i];
       if (m.adam_m1 && na <= 64) {
-        st[IGMC_STASH_ATTM1 + i] = m.adam_m1[m.off_att[l] + i];
-        st[IGMC_STASH_ATTM2 + i] = m.adam_m2[m.off_att[l] + i];
+        st[IGMC_STASH_ATTM1 + i] = mom && i == tid - 128 ? m1v : m.adam_m1[m.off_att[l] + i];
+        st[IGMC_STASH_ATTM2 + i] = mom && i == tid - 128 ? m2v : m.adam_m2[m.off_att[l] + i];
       }
     }
   }
-  if (l == 0 && ctrl && tid >= 192 && tid < 198) {
-    const double* d = (const double*)ctrl;
-    const int k = tid - 192;
-    const int src = (k == 0) ? IGMC_CTRL_STEP_SIZE : (k == 1) ? IGMC_CTRL_INV_SQRT_BC2 : (k == 2) ? IGMC_CTRL_BETA1
-                  : (k == 3) ? IGMC_CTRL_BETA2 : (k == 4) ? IGMC_CTRL_EPS : IGMC_CTRL_WD;
-    m.fin_stash[IGMC_STASH_SCAL + k] = (float)d[src];
-  }
-  __syncthreads();
+  if (sc) m.fin_stash[IGMC_STASH_SCAL + tid - 192] = (float)scal;
   if (tid == 0) {
     const int ij[10][2] = {{0, 0}, {0, 1}, {0, 2}, {0, 3}, {1, 1}, {1, 2}, {1, 3}, {2, 2}, {2, 3}, {3, 3}};
     for (int q = 0; q < 10; ++q) {
