@@ -1156,8 +1156,10 @@ __global__ __launch_bounds__(512) void k_head_bwd_a_mfma(BatchDev b, ModelDev m,
 // d lin2.bias = 1^T dp with three more MFMAs per step (B operand = 1 / dp_g), so there is no serial tail.
 __device__ __forceinline__ void head_bwd_w_body(const BatchDev& b, const ModelDev& m, const float* __restrict__ P,
                                                 const float* __restrict__ gout, int from_err, float grad_scale,
-                                                float mult, float drop_scale, float* __restrict__ grad, int bx, int by) {
-  const int B = b.totals[3], D = m.D, tid = threadIdx.x;
+                                                float mult, float drop_scale, float* __restrict__ grad, int bx, int by,
+                                                int B_known = -1) {
+  // (the batch size: a caller that has it in its arguments saves the dependent round trip to the arena's totals)
+  const int B = B_known >= 0 ? B_known : b.totals[3], D = m.D, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int j0 = bx * 16;
@@ -1357,6 +1359,19 @@ __device__ __forceinline__ void reduce_ts_body(const ModelDev& m, int nparts, in
   const int o0 = blk * 64 + 4 * o4;                     // first of the thread's four outputs (ts is a multiple of 32: the four share a layer)
   const int l = o0 / ts, i0 = o0 % ts;
   const bool ok4 = l < 4 && (l > 0 || i0 < rows0 * 32);
+  // wave 0's second role (Pold): the four basis values of ITS output blk * 64 + lane, requested together with the partials
+  float pbv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (Pold && wave == 0) {
+    const int o = blk * 64 + lane, lo_ = o / ts, i = o % ts;
+    if (lo_ < 4) {
+      const int nE = ((lo_ == 0) ? m.L : 32) * 32;
+      if (i < m.R * nE) {
+        const float* basis = Pold + m.off_basis[lo_] + i % nE;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) pbv[bb] = basis[bb * nE];
+      }
+    }
+  }
   float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (ok4) {
     // slot of member c of subgraph g = g + c * stride (one-workgroup launches: stride = IGMC_TS_BLOCKS, cs = 1); the valid
@@ -1393,15 +1408,9 @@ __device__ __forceinline__ void reduce_ts_body(const ModelDev& m, int nparts, in
     if (!ok) tot = 0.f;
     if (ok) m.ts_raw[o] = tot;
     if (Pold) {
-      float pb[4] = {0.f, 0.f, 0.f, 0.f};
-      if (lo_ < 4) {
-        const int nE = ((lo_ == 0) ? m.L : 32) * 32;
-        if (i < m.R * nE) {
-          const float* basis = Pold + m.off_basis[lo_] + i % nE;
+      float pb[4];
 #pragma unroll
-          for (int bb = 0; bb < 4; ++bb) pb[bb] = tot * basis[bb * nE];
-        }
-      }
+      for (int bb = 0; bb < 4; ++bb) pb[bb] = tot * pbv[bb];      // (pbv is zero outside the dW_r blocks)
 #pragma unroll
       for (int bb = 0; bb < 4; ++bb)
 #pragma unroll
@@ -1535,7 +1544,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_tail_ts(BatchDev b, ModelDev m, 
   const int nred = (int)gridDim.x - nlin - nstash;
   if (bump_seq && blockIdx.x == 0 && threadIdx.x == 0) m.gs_bar[1] += 1;      // (every workgroup of k_graph_step2 is done)
   if ((int)blockIdx.x < nlin)
-    head_bwd_w_body(b, m, P, nullptr, 1, grad_scale, mult, drop_scale, grad, blockIdx.x & 7, blockIdx.x >> 3);
+    head_bwd_w_body(b, m, P, nullptr, 1, grad_scale, mult, drop_scale, grad, blockIdx.x & 7, blockIdx.x >> 3, B);
   else if ((int)blockIdx.x < nlin + nred)
     reduce_ts_body(m, nparts, stride, B, blockIdx.x - nlin, nstash ? P : nullptr);
   else
