@@ -1918,7 +1918,15 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
   if ((int)blockIdx.x < 4 * IGMC_FTS_NB) {
     const int l = blockIdx.x / IGMC_FTS_NB, part = blockIdx.x % IGMC_FTS_NB;
     const int fin = (l == 0) ? m.L : 32, nE = fin * 32, R = m.R, na = R * 4;
-    const float* st = stash + l * IGMC_STASH_LAYER;
+    const float* stg = stash + l * IGMC_STASH_LAYER;
+    __shared__ float s_st[IGMC_STASH_LAYER];      // the layer's stash: requested first, read from LDS after the barrier below
+    float stq[(IGMC_STASH_LAYER + IGMC_BLOCK - 1) / IGMC_BLOCK];
+#pragma unroll
+    for (int u = 0; u < (IGMC_STASH_LAYER + IGMC_BLOCK - 1) / IGMC_BLOCK; ++u) {
+      const int i = tid + u * IGMC_BLOCK;
+      stq[u] = stg[i < IGMC_STASH_LAYER ? i : IGMC_STASH_LAYER - 1];
+    }
+    const float* st = s_st;
     const int wgs = 32 * IGMC_KCAT + 32;
     const bool table = !bs || l == 0;
     const float* t0 = bs ? m.graw + 3 * wgs + 3 * na : m.ts_raw + (size_t)l * m.ts_stride;
@@ -1986,37 +1994,83 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
     int e_img = -1;
     const bool emit = img && at.enabled && m.g2_w && R <= G2_NR * G2_NG_MAX && fin <= 32;
     const int ng = g2_groups(R, m.L);
-    for (int e = part * IGMC_BLOCK + tid; e < nE; e += IGMC_FTS_NB * IGMC_BLOCK) {       // one round for fin <= 32
-      int64_t idx[5];
-      float pv[5], m1v[5], m2v[5], g[5];
+    // ---- every load of the workgroup is requested here, before the first store: the thread's column of the main pass
+    // (nE <= 1024: ONE element a thread), the bias role's four values, the att role's first entry (its fin partial sums or
+    // the basis-space gradient, the parameter and its moments).  The stores of the main pass used to come first: the two
+    // roles then paid a second round trip, and the weight images wait for the att role.
+    const int e = part * IGMC_BLOCK + tid;
+    const bool has = e < nE;
+    int64_t idx[5];
+    float pv[5], m1v[5], m2v[5], g[5], tv[8];
 #pragma unroll
-      for (int q = 0; q < 5; ++q) {
-        idx[q] = (q < 4) ? m.off_basis[l] + (int64_t)q * nE + e : m.off_root[l] + e;
-        pv[q] = P[idx[q]];
-        m1v[q] = at.enabled ? at.m1[idx[q]] : 0.f;
-        m2v[q] = at.enabled ? at.m2[idx[q]] : 0.f;
-        g[q] = 0.f;
-      }
+    for (int q = 0; q < 5; ++q) {
+      idx[q] = (q < 4) ? m.off_basis[l] + (int64_t)q * nE + (has ? e : 0) : m.off_root[l] + (has ? e : 0);
+      pv[q] = has ? P[idx[q]] : 0.f;
+      m1v[q] = (has && at.enabled) ? at.m1[idx[q]] : 0.f;
+      m2v[q] = (has && at.enabled) ? at.m2[idx[q]] : 0.f;
+      g[q] = 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) tv[r] = 0.f;
+    if (has) {
       if (table) {
-        float tv[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) tv[r] = (r < R) ? t0[(size_t)r * nE + e] : 0.f;
         g[4] = t0[(size_t)R * nE + e];
+      } else {
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) g[bb] = raw[(e >> 5) * IGMC_KCAT + bb * 32 + (e & 31)];
+        g[4] = raw[(e >> 5) * IGMC_KCAT + 128 + (e & 31)];
+      }
+    }
+    const bool roles = part == 0 || emit;
+    const bool bias_role = roles && tid < 32 && part == 0;
+    const bool att_role = roles && !bias_role && tid >= 64 && tid - 64 < na;
+    float bq[4] = {0.f, 0.f, 0.f, 0.f};          // bias role: gradient source, parameter, moments
+    if (bias_role) {
+      const int64_t i = m.off_bias[l] + tid;
+      bq[0] = table ? t0[(size_t)(R * fin + fin) * 32 + tid] : raw[32 * IGMC_KCAT + tid];
+      bq[1] = P[i];
+      bq[2] = at.enabled ? at.m1[i] : 0.f;
+      bq[3] = at.enabled ? at.m2[i] : 0.f;
+    }
+    float dpre[32], am1 = 0.f, am2 = 0.f, ag = 0.f;      // att role, entry tid - 64
+#pragma unroll
+    for (int k = 0; k < 32; ++k) dpre[k] = 0.f;
+    if (att_role) {
+      const int rb = tid - 64, r = rb >> 2, bb = rb & 3;
+      const int64_t i = m.off_att[l] + rb;
+      if (at.enabled && !emit) {
+        am1 = at.m1[i];
+        am2 = at.m2[i];
+      }
+      if (bs) {
+        if (l > 0) ag = m.graw[3 * wgs + (size_t)(l - 1) * na + rb];
+      } else {
+        const float* dp = m.datt_part + ((size_t)l * m.ts_stride + (size_t)r * nE) / 32 * 4 + bb;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) dpre[k] = (k < fin) ? dp[(size_t)k * 4] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < (IGMC_STASH_LAYER + IGMC_BLOCK - 1) / IGMC_BLOCK; ++u) {
+      const int i = tid + u * IGMC_BLOCK;
+      if (i < IGMC_STASH_LAYER) s_st[i] = stq[u];
+    }
+    __syncthreads();
+    if (has) {       // one round for fin <= 32
+      if (table) {
 #pragma unroll
         for (int r = 0; r < 8; ++r)
           if (r < R) {
 #pragma unroll
             for (int bb = 0; bb < 4; ++bb) g[bb] += st[IGMC_STASH_ATT + r * 4 + bb] * tv[r];
           }
-        for (int r = 8; r < R; ++r) {          // (more than 8 relations: basis-space mode only)
+        for (int r = 8; r < R; ++r) {
           const float tvr = t0[(size_t)r * nE + e];
 #pragma unroll
           for (int bb = 0; bb < 4; ++bb) g[bb] += st[IGMC_STASH_ATT + r * 4 + bb] * tvr;
         }
-      } else {
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) g[bb] = raw[(e >> 5) * IGMC_KCAT + bb * 32 + (e & 31)];
-        g[4] = raw[(e >> 5) * IGMC_KCAT + 128 + (e & 31)];
       }
       if (arr_coef != 0.f) {
 #pragma unroll
@@ -2028,23 +2082,26 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
       for (int q = 0; q < 5; ++q) pn[q] = fts_emit(grad, at, idx[q], g[q], pv[q], m1v[q], m2v[q]);
       e_img = e;
     }
-    if (part == 0 || emit) {
-      if (tid < 32 && part == 0) {                 // d bias
+    if (roles) {
+      if (bias_role) {                             // d bias
         const int64_t i = m.off_bias[l] + tid;
-        const float bnew = fts_emit(grad, at, i, table ? t0[(size_t)(R * fin + fin) * 32 + tid] : raw[32 * IGMC_KCAT + tid],
-                                    P[i], at.enabled ? at.m1[i] : 0.f, at.enabled ? at.m2[i] : 0.f);
+        const float bnew = fts_emit(grad, at, i, bq[0], bq[1], bq[2], bq[3]);
         if (emit && l == 0) m.g2_w[g2_t0_off(ng) + (R * fin + fin) * 32 + tid] = bnew;       // layer-0 table: bias row
       } else if (tid >= 64) {                      // d att[r,b] = <dW_r, basis_b> (+ ARR): fin partials, fixed order
        for (int rb = tid - 64; rb < na; rb += IGMC_BLOCK - 64) {      // (one entry a thread up to 48 relations)
         const int r = rb >> 2, bb = rb & 3;
+        const bool first = rb == tid - 64;         // (its operands were requested above)
         const int64_t i = m.off_att[l] + rb;
         const float pold = st[IGMC_STASH_ATT + rb];
         // (img: the moments before the step come from the stash -- the owner workgroup updates them in place meanwhile)
-        const float m1o = !at.enabled ? 0.f : emit ? st[IGMC_STASH_ATTM1 + rb] : at.m1[i];
-        const float m2o = !at.enabled ? 0.f : emit ? st[IGMC_STASH_ATTM2 + rb] : at.m2[i];
+        const float m1o = !at.enabled ? 0.f : emit ? st[IGMC_STASH_ATTM1 + rb] : first ? am1 : at.m1[i];
+        const float m2o = !at.enabled ? 0.f : emit ? st[IGMC_STASH_ATTM2 + rb] : first ? am2 : at.m2[i];
         float g = 0.f;
         if (bs) {
-          g = (l == 0) ? s_gatt0[rb] : m.graw[3 * wgs + (size_t)(l - 1) * na + rb];
+          g = (l == 0) ? s_gatt0[rb] : first ? ag : m.graw[3 * wgs + (size_t)(l - 1) * na + rb];
+        } else if (first && fin <= 32) {
+#pragma unroll
+          for (int k = 0; k < 32; ++k) g += dpre[k];
         } else {
           const float* dp = m.datt_part + ((size_t)l * m.ts_stride + (size_t)r * nE) / 32 * 4 + bb;
           for (int k0 = 0; k0 < fin; k0 += 32) {
