@@ -37,6 +37,28 @@ def test_dgcnn_rs_forward_backward_parity(be, name, n, R, k, drop):
     assert res['worst_grad_err'] < 2e-3
 
 
+@pytest.mark.parametrize('form', ['tables', 'per_layer'])
+@pytest.mark.parametrize('name,n,k,drop', [('synth_nocap:100', 16, 60, True), ('douban', 24, 30, True)])
+def test_dgcnn_rs_on_the_dense_layer_kernels(be, monkeypatch, name, n, k, drop, form):
+    """The conv layers of the sort-pool family on the dense-layer kernels (what the step graph's arenas take): forward as ONE
+    launch; backward as ONE launch with relation-space tables -- dPre_3 of every row, the per-row readout gradient -- or one
+    launch per layer pass (IGMC_DL_TS=0).  Loss and every gradient vs the oracle."""
+    from igmc_amd import engine
+    monkeypatch.setenv('IGMC_DL_ALWAYS', '1')
+    monkeypatch.setenv('IGMC_GRAPH_STEP', '0')
+    if form == 'per_layer':
+        monkeypatch.setenv('IGMC_DL_TS', '0')
+    engine.profile_enable(be.lib, True)
+    try:
+        res = PC.run_dgcnn_parity(be, sub(name, n), R=5, k=k, use_dropout=drop)
+        ran = [nm for nm, _, _ in engine.profile_fetch(be.lib)]
+    finally:
+        engine.profile_enable(be.lib, False)
+    assert res['worst_grad_err'] < 2e-3
+    assert 'k_dl_fwd' in ran
+    assert ('k_dl_bwd' in ran) == (form == 'tables') and ('k_dl_layer_bwd' in ran) == (form == 'per_layer'), ran
+
+
 def test_dgcnn_rs_bitwise_reproducible(be):
     r1 = PC.run_dgcnn_parity(be, sub('synth_nocap', 16), R=5, k=20)
     r2 = PC.run_dgcnn_parity(be, sub('synth_nocap', 16), R=5, k=20)
