@@ -1157,7 +1157,7 @@ struct DlArgs {
   const int32_t* node_off;
   const uint8_t* relm;
   const uint8_t* relmT;
-  int cap_u, cap_v, relm_ld, relmT_ld, nq, R, D, l, kp;
+  int cap_u, cap_v, relm_ld, relmT_ld, nqu, nqv, R, D, l, kp;
   const float* in;         // forward: h_{l-1}; backward: dPre_l                       [N, 32]
   const float* hprev;      // backward: h_{l-1}
   float* out;              // forward: h_l; backward: dPre_{l-1}
@@ -1199,15 +1199,33 @@ __device__ __forceinline__ DlRows dl_rows(int n_own, int nq, int q) {
   r.nact = left < 0 ? 0 : (left < bpw ? left : bpw);
   return r;
 }
-// Workgroups per side: one per 128 rows of the slot capacity -- and a second one for slots of 33..128 rows where the whole
-// launch still fits one workgroup per CU and the partial-table slots: the bundles of a side are split evenly (dl_rows), so a
-// 101-row side becomes 4 + 3 bundles on two CUs instead of 7 on one.
-static int dl_nq(int cmax, int B) {
-  int nq = (cmax + 16 * DL_NW - 1) / (16 * DL_NW);
-  if (nq == 1 && cmax > 32 && 4 * B <= 224 && 4 * ((B + 7) & ~7) <= IGMC_TS_BLOCKS) nq = 2;
-  return nq;
+// Workgroups of a subgraph: at least one per 128 rows of a side's slot capacity, then -- while the whole launch still fits one
+// workgroup per CU (224) and the partial-table slots -- one more for the side whose workgroups would hold the most bundles, as
+// long as that is more than two: the bundles of a side are split evenly over its workgroups (dl_rows), so a 101 + 101-row
+// slot runs as (4 + 3) + (4 + 3) bundles on four CUs, flixster's 50 + 155 rows as 4 + (4 + 3 + 3).
+struct DlSplit {
+  int nqu, nqv;                   // workgroups of the user side / of the item side
+};
+static DlSplit dl_split(int cap_u, int cap_v, int B) {
+  DlSplit sp;
+  sp.nqu = (cap_u + 16 * DL_NW - 1) / (16 * DL_NW);
+  sp.nqv = (cap_v + 16 * DL_NW - 1) / (16 * DL_NW);
+  const int stride = (B + 7) & ~7;
+  int pmax = B > 0 ? 224 / B : 0;
+  if (IGMC_TS_BLOCKS / stride < pmax) pmax = IGMC_TS_BLOCKS / stride;
+  const int nbu = (cap_u + 15) >> 4, nbv = (cap_v + 15) >> 4;
+  while (sp.nqu + sp.nqv < pmax) {
+    const int pu = (nbu + sp.nqu - 1) / sp.nqu, pv = (nbv + sp.nqv - 1) / sp.nqv;
+    if ((pu > pv ? pu : pv) <= 2) break;
+    if (pu >= pv) ++sp.nqu;
+    else ++sp.nqv;
+  }
+  return sp;
 }
-
+// (workgroup index -> subgraph, side, workgroup of the side)
+#define DL_DECODE(a, bid, g, rem, side, q, nqs)                                      \
+  const int g = (bid) / ((a).nqu + (a).nqv), rem = (bid) - g * ((a).nqu + (a).nqv);  \
+  const int side = rem >= (a).nqu ? 1 : 0, q = side ? rem - (a).nqu : rem, nqs = side ? (a).nqv : (a).nqu
 #define DL_PIT 2                  // plane-staging items per thread: 128 * k-steps / DL_THREADS, k-steps <= 8
 #define DL_RIT 17                 // block-row dwords per lane: 16 rows x (32 * k-steps + 8) / 4 / 64, k-steps <= 8
 // LDS plan (4-byte words): [own rows XOA][TS: h_{l-1} rows HSA, d bias scratch][planes | block rows | weight image][sums]
@@ -1225,7 +1243,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int bid = blockIdx.x;
-  const int g = bid / (2 * a.nq), rem = bid - g * 2 * a.nq, side = rem / a.nq, q = rem - side * a.nq;
+  DL_DECODE(a, bid, g, rem, side, q, nqs);
   const int cu = a.n_users[g], cv = a.n_items[g];
   const int n_own = side ? cv : cu, n_opp = side ? cu : cv;
   const int R = a.R;
@@ -1234,7 +1252,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
   float* wpart = TS ? a.ts_part + ((size_t)a.l * IGMC_TS_BLOCKS + g + (size_t)rem * a.slot_stride) * ts : nullptr;
   float* part0 = TS ? a.ts_part + ((size_t)g + (size_t)rem * a.slot_stride) * ts : nullptr;
   const int rows0 = R * a.L + a.L + 1;
-  const DlRows dr = dl_rows(n_own, a.nq, q);
+  const DlRows dr = dl_rows(n_own, nqs, q);
   if (dr.nact == 0) {                            // nothing of this side in the workgroup's rows (uniform)
     if (BWD && !TS && tid < R * 4) a.gatt_part[(size_t)bid * R * 4 + tid] = 0.f;
     if (TS) {                                    // an all-zero partial table (the reduction reads every slot)
@@ -1633,7 +1651,7 @@ struct DlfArgs {
   const uint8_t* node_label;
   const uint8_t* relm;
   const uint8_t* relmT;
-  int cap_u, cap_v, relm_ld, relmT_ld, nq, R, L, kp;
+  int cap_u, cap_v, relm_ld, relmT_ld, nqu, nqv, R, L, kp;
   float* h[4];
   float* zero_out;               // training: dPre_3 rows cleared (or NULL)
   uint16_t* cnt0;                // training: [N, R * L] (or NULL)
@@ -1663,13 +1681,13 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int bid = blockIdx.x;
-  const int g = bid / (2 * a.nq), rem = bid - g * 2 * a.nq, side = rem / a.nq, q = rem - side * a.nq;
+  DL_DECODE(a, bid, g, rem, side, q, nqs);
   const int cu = a.n_users[g], cv = a.n_items[g];
   const int n_own = side ? cv : cu, n_opp = side ? cu : cv;
   const uint32_t seq = g2_ld_seq(a.gs_bar);
   const uint32_t tag0 = seq * 8u + 1u;
   auto tag16 = [&](int x) { return 1u + (tag0 + (uint32_t)x) % 65535u; };
-  const DlRows dr = dl_rows(n_own, a.nq, q);
+  const DlRows dr = dl_rows(n_own, nqs, q);
   if (dr.nact == 0) {                            // nothing of this side in the workgroup's rows: nobody waits for it
     dlx_seq_done(a.gs_bar, a.self_seq);
     return;
@@ -1701,7 +1719,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
   //      older than 4096 launches (tags repeat after 65535) -- by the rows' owners of THIS launch (nobody else writes
   //      them), workgroup 0 also taking the rows past the side up to the slot capacity (nobody's in this launch)
   if ((seq & 4095u) == 0u) {
-    const int rcap = 128 * a.nq < DLX_K ? 128 * a.nq : DLX_K;
+    const int rcap = 128 * nqs < DLX_K ? 128 * nqs : DLX_K;
     for (int part = 0; part < (q == 0 ? 2 : 1); ++part) {
       const int r0 = part ? ((n_own + 15) >> 4) << 4 : dr.base, r1 = part ? rcap : dr.base + 16 * dr.nact;
       const int np = (r1 - r0) >> 1;                 // 16-byte stores (two rows) per feature
@@ -1955,7 +1973,7 @@ struct DlbArgs {
   const uint8_t* node_label;
   const uint8_t* relm;
   const uint8_t* relmT;
-  int cap_u, cap_v, relm_ld, relmT_ld, nq, R, L, D, kp;
+  int cap_u, cap_v, relm_ld, relmT_ld, nqu, nqv, R, L, D, kp;
   const float* h[3];             // h_0 .. h_2
   const float* dpre3;            // [N, 32]: the head's dPre_3 (target rows; dense3: every row)
   const float* gfeat;            // [B, D] readout gradient on the target rows
@@ -2004,7 +2022,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int bid = blockIdx.x;
-  const int g = bid / (2 * a.nq), rem = bid - g * 2 * a.nq, side = rem / a.nq, q = rem - side * a.nq;
+  DL_DECODE(a, bid, g, rem, side, q, nqs);
   const int cu = a.n_users[g], cv = a.n_items[g];
   const int n_own = side ? cv : cu, n_opp = side ? cu : cv;
   const int R = a.R, L = a.L, RL = R * L, rows0 = RL + L + 1;
@@ -2017,7 +2035,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
     g_g2_wg[bid][1] = 0ull;
     g_g2_wg[bid][2] = ((unsigned long long)n_own << 32) | (unsigned long long)n_opp;
   }
-  const DlRows dr = dl_rows(n_own, a.nq, q);
+  const DlRows dr = dl_rows(n_own, nqs, q);
   if (dr.nact == 0) {                            // nothing of this side in the workgroup's rows: all-zero partial tables
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int l = 1; l < 4; ++l) {
@@ -2464,7 +2482,7 @@ struct Dl0Args {
   const uint8_t* node_label;
   const uint8_t* relm;
   const uint8_t* relmT;
-  int cap_u, cap_v, relm_ld, relmT_ld, nq, R, L, kp;
+  int cap_u, cap_v, relm_ld, relmT_ld, nqu, nqv, R, L, kp;
   const float* t0;         // composed layer-0 table [32][32]
   float* out;              // h_0 [N, 32]
   uint16_t* cnt0;          // [N, R * L] or NULL
@@ -2476,10 +2494,10 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer0(Dl0Args a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int bid = blockIdx.x;
-  const int g = bid / (2 * a.nq), rem = bid - g * 2 * a.nq, side = rem / a.nq, q = rem - side * a.nq;
+  DL_DECODE(a, bid, g, rem, side, q, nqs);
   const int cu = a.n_users[g], cv = a.n_items[g];
   const int n_own = side ? cv : cu, n_opp = side ? cu : cv;
-  const DlRows dr = dl_rows(n_own, a.nq, q);
+  const DlRows dr = dl_rows(n_own, nqs, q);
   if (dr.nact == 0) return;
   const int R = a.R, L = a.L, RL = R * L;
   const int nb = a.node_off[g];
@@ -2595,11 +2613,11 @@ void igmc_launch_dl_layer0(const ModelDev& m, const BatchDev& b, int B, int trai
   a.n_users = b.n_users; a.n_items = b.n_items; a.node_off = b.node_off; a.node_label = b.node_label;
   a.relm = b.relm; a.relmT = b.relmT;
   a.cap_u = b.cap_u; a.cap_v = b.cap_v; a.relm_ld = b.relm_ld; a.relmT_ld = b.relmT_ld;
-  a.nq = dl_nq(cmax, B); a.R = m.R; a.L = m.L; a.kp = 32 * ((cmax + 31) >> 5) + 8;
+  { const DlSplit sq = dl_split(b.cap_u, b.cap_v, B); a.nqu = sq.nqu; a.nqv = sq.nqv; } a.R = m.R; a.L = m.L; a.kp = 32 * ((cmax + 31) >> 5) + 8;
   a.t0 = m.g2_w + 6 * G2_WIMG;
   a.out = m.h[0];
   a.cnt0 = training ? m.cnt0 : nullptr;
-  const int grid = B * 2 * a.nq;
+  const int grid = B * (a.nqu + a.nqv);
   const size_t sm = dl0_lds(a.kp);
   if (training) {
     if (use_flags) IGMC_PLAUNCH("k_dl_layer0", (k_dl_layer0<true, true>), grid, DL_THREADS, sm, stream, a);
@@ -2623,7 +2641,8 @@ static int dl_base_ok(const ModelDev& m, const BatchDev& b, int B, int wide) {
   // wide: the two-group layout -- six to ten relations, or a layer-0 table of 33..48 rows (two hops)
   if (wide ? (g2_groups(m.R, m.L) == 1 || m.R > G2_NR * G2_NG_MAX || rows0 > 48) : (m.R > G2_NR || rows0 > 32)) return 0;
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
-  return cmax <= 256 && B * 2 * (dl_nq(cmax, B)) <= IGMC_GATHER_BLOCKS;
+  const DlSplit sq = dl_split(b.cap_u, b.cap_v, B);
+  return cmax <= 256 && B * (sq.nqu + sq.nqv) <= IGMC_GATHER_BLOCKS;
 }
 int igmc_dl_eligible(const ModelDev& m, const BatchDev& b, int B) {
   if (!dl_base_ok(m, b, B, 0)) return 0;
@@ -2638,14 +2657,16 @@ int igmc_dl_ts_eligible(const ModelDev& m, const BatchDev& b, int B) {
   if (e && atoi(e) == 0) return 0;
   if (!igmc_dl_eligible(m, b, B) || !m.ts_part || !m.cnt0) return 0;
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
-  const int nq = dl_nq(cmax, B), stride = (B + 7) & ~7;
-  if (2 * nq * stride > IGMC_TS_BLOCKS || m.R * m.L > 20) return 0;
+  const DlSplit sq = dl_split(b.cap_u, b.cap_v, B);
+  const int stride = (B + 7) & ~7;
+  if ((sq.nqu + sq.nqv) * stride > IGMC_TS_BLOCKS || m.R * m.L > 20) return 0;
   return dl_lds(32 * ((cmax + 31) >> 5) + 8, true) <= (size_t)160 * 1024;
 }
 
 int igmc_dl_grid(const BatchDev& b, int B) {
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
-  return B * 2 * (dl_nq(cmax, B));
+  const DlSplit sq = dl_split(b.cap_u, b.cap_v, B);
+  return B * (sq.nqu + sq.nqv);
 }
 
 void igmc_launch_g2_compose(const ModelDev& m, const float* P, void* stream) {
@@ -2662,7 +2683,7 @@ void igmc_launch_dl_layer(const ModelDev& m, const BatchDev& b, const float* P, 
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
   a.n_users = b.n_users; a.n_items = b.n_items; a.node_off = b.node_off; a.relm = b.relm; a.relmT = b.relmT;
   a.cap_u = b.cap_u; a.cap_v = b.cap_v; a.relm_ld = b.relm_ld; a.relmT_ld = b.relmT_ld;
-  a.nq = dl_nq(cmax, B); a.R = m.R; a.D = m.D; a.l = l; a.kp = 32 * ((cmax + 31) >> 5) + 8;
+  { const DlSplit sq = dl_split(b.cap_u, b.cap_v, B); a.nqu = sq.nqu; a.nqv = sq.nqv; } a.R = m.R; a.D = m.D; a.l = l; a.kp = 32 * ((cmax + 31) >> 5) + 8;
   a.in = bwd ? m.dpre[l] : m.h[l - 1];
   a.hprev = m.h[l - 1];
   a.out = bwd ? m.dpre[l - 1] : m.h[l];
@@ -2674,7 +2695,7 @@ void igmc_launch_dl_layer(const ModelDev& m, const BatchDev& b, const float* P, 
   a.img = m.g2_w + (size_t)((l - 1) * 2 + (bwd ? 1 : 0)) * G2_WIMG;
   a.bias = P + m.off_bias[l]; a.att = P + m.off_att[l];
   a.L = m.L;
-  const int grid = B * 2 * a.nq;
+  const int grid = B * (a.nqu + a.nqv);
   if (bwd && tables) {       // relation-space tables instead of G / d att partials (igmc_dl_ts_eligible)
     a.ts_part = m.ts_part; a.ts_stride = m.ts_stride; a.slot_stride = (B + 7) & ~7;
     a.cnt0 = m.cnt0; a.node_label = b.node_label;
@@ -2701,8 +2722,8 @@ int igmc_dl_fwd_eligible(const ModelDev& m, const BatchDev& b, int B) {
   if (e && atoi(e) == 0) return 0;
   if (!igmc_dl_eligible(m, b, B) || !m.g2_ex || m.ex_nodes < DLX_K || b.graph_cap > m.g2_graphs) return 0;
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
-  const int nq = dl_nq(cmax, B);
-  if (B * 2 * nq > 224) return 0;                  // (one workgroup per CU, all of them resident: the members wait for each other)
+  const DlSplit sq = dl_split(b.cap_u, b.cap_v, B);
+  if (B * (sq.nqu + sq.nqv) > 224) return 0;                  // (one workgroup per CU, all of them resident: the members wait for each other)
   return (size_t)dlf_words(32 * ((cmax + 31) >> 5) + 8) * 4 <= (size_t)160 * 1024;
 }
 
@@ -2714,7 +2735,7 @@ void igmc_launch_dl_fwd(const ModelDev& m, const BatchDev& b, const float* P, in
   a.n_users = b.n_users; a.n_items = b.n_items; a.node_off = b.node_off; a.node_label = b.node_label;
   a.relm = b.relm; a.relmT = b.relmT;
   a.cap_u = b.cap_u; a.cap_v = b.cap_v; a.relm_ld = b.relm_ld; a.relmT_ld = b.relmT_ld;
-  a.nq = dl_nq(cmax, B); a.R = m.R; a.L = m.L; a.kp = 32 * ((cmax + 31) >> 5) + 8;
+  { const DlSplit sq = dl_split(b.cap_u, b.cap_v, B); a.nqu = sq.nqu; a.nqv = sq.nqv; } a.R = m.R; a.L = m.L; a.kp = 32 * ((cmax + 31) >> 5) + 8;
   for (int l = 0; l < 4; ++l) {
     a.h[l] = m.h[l];
     a.off_bias[l] = (int)m.off_bias[l];
@@ -2726,11 +2747,11 @@ void igmc_launch_dl_fwd(const ModelDev& m, const BatchDev& b, const float* P, in
   a.gs_bar = m.gs_bar; a.gs_err = m.gs_err;
   a.self_seq = self_seq;
   a.timing = getenv("IGMC_DL_TIMING") ? atoi(getenv("IGMC_DL_TIMING")) : 0;
-  const int grid = B * 2 * a.nq;
+  const int grid = B * (a.nqu + a.nqv);
   const int ng = g2_groups(m.R, m.L);
   const size_t sm = (size_t)dlf_words(a.kp, ng) * 4;
 #ifdef IGMC_HIPEMU
-  hipemu::rt().co_cs = 2 * a.nq;                   // the members of a subgraph run together
+  hipemu::rt().co_cs = a.nqu + a.nqv;                   // the members of a subgraph run together
   hipemu::rt().co_stride = -1;                     // (= consecutive workgroups)
 #endif
   if (ng == 1) {
@@ -2764,8 +2785,9 @@ int igmc_dl_wide(const ModelDev& m, const BatchDev& b, int B) {
   if (et && atoi(et) == 0) return 0;
   if (!m.g2_ex || m.ex_nodes < DLX_K || b.graph_cap > m.g2_graphs || !m.ts_part || !m.cnt0) return 0;
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
-  const int nq = dl_nq(cmax, B), stride = (B + 7) & ~7, kp = 32 * ((cmax + 31) >> 5) + 8;
-  if (B * 2 * nq > 224 || 2 * nq * stride > IGMC_TS_BLOCKS) return 0;
+  const DlSplit sq = dl_split(b.cap_u, b.cap_v, B);
+  const int stride = (B + 7) & ~7, kp = 32 * ((cmax + 31) >> 5) + 8;
+  if (B * (sq.nqu + sq.nqv) > 224 || (sq.nqu + sq.nqv) * stride > IGMC_TS_BLOCKS) return 0;
   const int ng = g2_groups(m.R, m.L);
   return (size_t)dlf_words(kp, ng) * 4 <= (size_t)160 * 1024 && (size_t)dlb_words(kp, ng) * 4 <= (size_t)160 * 1024;
 }
@@ -2785,7 +2807,7 @@ void igmc_launch_dl_bwd(const ModelDev& m, const BatchDev& b, int B, int use_fla
   a.n_users = b.n_users; a.n_items = b.n_items; a.node_off = b.node_off; a.node_label = b.node_label;
   a.relm = b.relm; a.relmT = b.relmT;
   a.cap_u = b.cap_u; a.cap_v = b.cap_v; a.relm_ld = b.relm_ld; a.relmT_ld = b.relmT_ld;
-  a.nq = dl_nq(cmax, B); a.R = m.R; a.L = m.L; a.D = m.D; a.kp = 32 * ((cmax + 31) >> 5) + 8;
+  { const DlSplit sq = dl_split(b.cap_u, b.cap_v, B); a.nqu = sq.nqu; a.nqv = sq.nqv; } a.R = m.R; a.L = m.L; a.D = m.D; a.kp = 32 * ((cmax + 31) >> 5) + 8;
   for (int l = 0; l < 3; ++l) a.h[l] = m.h[l];
   a.dpre3 = m.dpre[3]; a.gfeat = m.gfeat; a.g2_w = m.g2_w; a.cnt0 = m.cnt0;
   a.ts_part = m.ts_part; a.ts_stride = m.ts_stride; a.slot_stride = (B + 7) & ~7;
@@ -2800,10 +2822,10 @@ void igmc_launch_dl_bwd(const ModelDev& m, const BatchDev& b, int B, int use_fla
     a.head = 1; a.hb = b; a.hm = m; a.P = head->P; a.inj_mask = head->inj_mask; a.seed = head->seed; a.step = head->step;
     a.mult = head->mult; a.grad_scale = head->grad_scale; a.out = head->out;
   }
-  const int grid = B * 2 * a.nq;
+  const int grid = B * (a.nqu + a.nqv);
   const size_t sm = (size_t)dlb_words(a.kp, g2_groups(m.R, m.L)) * 4;
 #ifdef IGMC_HIPEMU
-  hipemu::rt().co_cs = 2 * a.nq;
+  hipemu::rt().co_cs = a.nqu + a.nqv;
   hipemu::rt().co_stride = -1;
 #endif
   if (g2_groups(m.R, m.L) == 1) {

@@ -67,12 +67,20 @@ def main():
                   % (l, g, d[0], d[1], d[2], d[3], d[4], d[5], nxt - c[k + 6]))
     print('layer-0 table %d | k_dl_bwd total %d' % (c[126] - c[41], c[126] - c[40]))
     # every workgroup of the last k_dl_bwd launch on the 100 MHz wall clock
-    # workgroups per side as graphstep2.hip's dl_nq (DL_CMAX = the larger slot capacity of the arena: flixster 155, ml_100k 201)
-    cmax = int(os.environ.get('DL_CMAX', {'flixster': 155, 'ml_100k': 201, 'ml_10m_lite': 101}.get(cfgname, 155)))
-    nq = (cmax + 127) // 128
-    if nq == 1 and cmax > 32:
-        nq = 2
-    nwg = 50 * 2 * nq
+    # workgroups of a subgraph as graphstep2.hip's dl_split (DL_CAPS = the arena's slot capacities, users x items)
+    cu, cv = [int(x) for x in os.environ.get('DL_CAPS', {'flixster': '50x155', 'ml_100k': '201x201', 'ml_10m_lite': '101x101'}.get(cfgname, '155x155')).split('x')]
+    nqu, nqv = (cu + 127) // 128, (cv + 127) // 128
+    nbu, nbv = (cu + 15) // 16, (cv + 15) // 16
+    while nqu + nqv < 4:
+        pu, pv = -(-nbu // nqu), -(-nbv // nqv)
+        if max(pu, pv) <= 2:
+            break
+        if pu >= pv:
+            nqu += 1
+        else:
+            nqv += 1
+    per = nqu + nqv
+    nwg = 50 * per
     wgb = np.zeros(3 * 1024, np.uint64)
     lib.cdll.igmc_debug_g2_wg_clocks(C.c_void_p(wgb.ctypes.data), 1024)
     w = wgb.reshape(1024, 3)[:nwg].astype(np.int64)
@@ -85,7 +93,7 @@ def main():
     rows.sort(reverse=True)
     print('k_dl_bwd workgroups with rows: %d of %d; end of the last one %.1f us after the first start' % (len(rows), nwg, rows[0][0]))
     for end, start, i, no, nop in rows[:8] + rows[len(rows) // 2:len(rows) // 2 + 3]:
-        print('  wg %3d (subgraph %2d, member %d): start %.1f end %.1f us; own rows %d, opposite %d' % (i, i // (nwg // 50), i % (nwg // 50), start, end, no, nop))
+        print('  wg %3d (subgraph %2d, member %d): start %.1f end %.1f us; own rows %d, opposite %d' % (i, i // per, i % per, start, end, no, nop))
 
 
 main()
