@@ -1,5 +1,5 @@
 #!/bin/bash
-# bench lines (flixster, ml_10m_lite, ml_100k, ml_1m, DGCNN douban) + the gpu suite
+# bench lines of the dense-layer configurations (flixster, ml_10m_lite, ml_100k), the headline and DGCNN_RS on douban + the gpu suite
 cd "$(dirname "$0")/.." || exit 1
 O=gpurun_out/${1:-wide4}; mkdir -p $O
 export TMPDIR=/tmp
