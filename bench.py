@@ -26,7 +26,8 @@ The ONE JSON line printed by rank 0 also carries
   cpu_baseline  : the oracle's restatement of the reference CPU path, structured like the reference
                   (train_eval.py:40-45: extraction in worker processes, PyG-1.4.2 per-edge-weight formulation in torch on
                   the host cores), on a bounded sample of the same workload; ``--config ml_100k`` times BASELINE.json
-                  configs[0] (static pre-extracted subgraphs, 1 worker).
+                  configs[0] (static pre-extracted subgraphs, 1 worker).  ``extraction_twin``: the extraction half alone
+                  through oracle/extract_cpu.c (OpenMP, the engine's sampling keys) on the granted cores.
   rmse          : test RMSE of the checkpoint the timed steps produced, on a fixed slice of the test links, plus the same
                   figure from the oracle on a smaller slice (the metric names "test RMSE"; parity bar 1e-4).
 """
@@ -179,6 +180,24 @@ def cpu_baseline_worker(path):
                extraction_workers=n_workers,
                sample='%d train steps of batch %d in %.1f s; %s; PyG-1.4.2-formulation fwd/bwd + Adam '
                       '(oracle/pyg_ref.py, torch threads=%d)' % (steps, BATCH, el, how, threads))
+    # the extraction half alone on this host: the OpenMP twin the parity suite holds the HIP extraction to
+    # (oracle/extract_cpu.c: the engine's own stateless sampling, so the same subgraphs), on the granted cores
+    try:
+        from oracle import extract_cpu
+        th = extract_cpu.set_threads(max(1, min(ncpu, 64)))
+        G = extract_cpu.prepare(A)
+        m = int(min(len(perm), 20000))
+        cap = int(z['mnph']) + 1
+        pu, pv = z['tr_u'][perm[:m]], z['tr_v'][perm[:m]]
+        kw = dict(hop=1, sample_ratio=1.0, max_nodes_per_hop=int(z['mnph']), seed=1, epoch=1, cap_u=cap, cap_v=cap, raw=True)
+        extract_cpu.extract_batch(G, pu, pv, 0, min(m, 256), **kw)
+        t2 = time.perf_counter()
+        for f in range(0, m, 2000):         # (chunks bound the output arrays: cap^2 edge slots per link)
+            extract_cpu.extract_batch(G, pu, pv, f, min(2000, m - f), **kw)
+        rec['extraction_twin'] = dict(value=m / (time.perf_counter() - t2), unit='subgraphs/s', cores=th, kind='twin',
+                                      sample='%d links, extraction only (no model), oracle/extract_cpu.c, %d OpenMP threads' % (m, th))
+    except Exception as e:          # (an extra figure: never fails the baseline)
+        rec['extraction_twin'] = dict(error=repr(e)[:200])
     print('CPU_BASELINE_JSON ' + json.dumps(rec))
 
 
