@@ -26,8 +26,9 @@ The ONE JSON line printed by rank 0 also carries
   cpu_baseline  : the oracle's restatement of the reference CPU path, structured like the reference
                   (train_eval.py:40-45: extraction in worker processes, PyG-1.4.2 per-edge-weight formulation in torch on
                   the host cores), on a bounded sample of the same workload; ``--config ml_100k`` times BASELINE.json
-                  configs[0] (static pre-extracted subgraphs, 1 worker).  ``extraction_twin``: the extraction half alone
-                  through oracle/extract_cpu.c (OpenMP, the engine's sampling keys) on the granted cores.
+                  configs[0] (static pre-extracted subgraphs, 1 worker).  ``twin`` / ``extraction_twin``: baseline #2 -- the
+                  same step (and its extraction half alone) through the OpenMP host twins oracle/extract_cpu.c +
+                  oracle/model_cpu.c on the granted cores: a CPU-shaped implementation, not the reference's formulation.
   rmse          : test RMSE of the checkpoint the timed steps produced, on a fixed slice of the test links, plus the same
                   figure from the oracle on a smaller slice (the metric names "test RMSE"; parity bar 1e-4).
 """
@@ -180,24 +181,51 @@ def cpu_baseline_worker(path):
                extraction_workers=n_workers,
                sample='%d train steps of batch %d in %.1f s; %s; PyG-1.4.2-formulation fwd/bwd + Adam '
                       '(oracle/pyg_ref.py, torch threads=%d)' % (steps, BATCH, el, how, threads))
-    # the extraction half alone on this host: the OpenMP twin the parity suite holds the HIP extraction to
-    # (oracle/extract_cpu.c: the engine's own stateless sampling, so the same subgraphs), on the granted cores
+    # baseline #2: the OpenMP host twins the parity suite holds the HIP path to -- oracle/extract_cpu.c (the
+    # engine's own stateless sampling, so the same subgraphs) and oracle/model_cpu.c (subgraph per thread, aggregate-then-
+    # transform; forward + loss + backward + Adam) -- as a training loop on the granted cores: what a CPU-shaped
+    # implementation of the same step reaches, beside the reference's formulation above
     try:
-        from oracle import extract_cpu
+        from oracle import extract_cpu, model_cpu
         th = extract_cpu.set_threads(max(1, min(ncpu, 64)))
+        model_cpu.set_threads(th)
         G = extract_cpu.prepare(A)
+        mnph = int(z['mnph'])
+        cap = mnph + 1
+        kw = dict(hop=1, sample_ratio=1.0, max_nodes_per_hop=mnph, seed=1, epoch=1, cap_u=cap, cap_v=cap, raw=True)
         m = int(min(len(perm), 20000))
-        cap = int(z['mnph']) + 1
         pu, pv = z['tr_u'][perm[:m]], z['tr_v'][perm[:m]]
-        kw = dict(hop=1, sample_ratio=1.0, max_nodes_per_hop=int(z['mnph']), seed=1, epoch=1, cap_u=cap, cap_v=cap, raw=True)
         extract_cpu.extract_batch(G, pu, pv, 0, min(m, 256), **kw)
         t2 = time.perf_counter()
         for f in range(0, m, 2000):         # (chunks bound the output arrays: cap^2 edge slots per link)
             extract_cpu.extract_batch(G, pu, pv, f, min(2000, m - f), **kw)
         rec['extraction_twin'] = dict(value=m / (time.perf_counter() - t2), unit='subgraphs/s', cores=th, kind='twin',
                                       sample='%d links, extraction only (no model), oracle/extract_cpu.c, %d OpenMP threads' % (m, th))
-    except Exception as e:          # (an extra figure: never fails the baseline)
-        rec['extraction_twin'] = dict(error=repr(e)[:200])
+        tw = pyg_ref.IGMCRef(4, (32, 32, 32, 32), len(cv), 4, adj_dropout=0.0, fast=False)
+        cfg_t = model_cpu.config_of(tw)
+        flat = model_cpu.flat_from_model(tw, cfg_t)
+        m1, m2 = np.zeros_like(flat), np.zeros_like(flat)
+        yv = np.asarray(cv, np.float64)[np.asarray(z['tr_l'])[perm[:m]]].astype(np.float32)
+        rng = np.random.default_rng(1)
+        keep_p = 1.0 - adj_dropout
+        steps_t, t3, last = 0, time.perf_counter(), None
+        while steps_t < m // BATCH and (steps_t < 3 or time.perf_counter() - t3 < 5.0):
+            f = steps_t * BATCH
+            cb = model_cpu.collate_raw(extract_cpu.extract_batch(G, pu, pv, f, BATCH, **kw), cap, cap)
+            if adj_dropout > 0:             # dropout_adj: Bernoulli(1 - p) per directed edge (reference models.py:193-198)
+                kp = rng.random(len(cb['src'])) < keep_p
+                ge = np.repeat(np.arange(BATCH), np.diff(cb['edge_off']))[kp]
+                cb.update(src=cb['src'][kp], dst=cb['dst'][kp], rel=cb['rel'][kp])
+                cb['edge_off'] = np.concatenate([[0], np.cumsum(np.bincount(ge, minlength=BATCH))]).astype(np.int64)
+            _, gr, last = model_cpu.loss_grad(cfg_t, flat, cb, y=yv[f:f + BATCH], lin_mask=rng.random((BATCH, 128)) < 0.5, ARR=0.001)
+            steps_t += 1
+            model_cpu.adam_step(flat, gr, m1, m2, steps_t)
+        el_t = time.perf_counter() - t3
+        rec['twin'] = dict(value=steps_t * BATCH / el_t, unit='subgraphs/s', cores=th, kind='twin', final_loss=last[0],
+                           sample='%d train steps of batch %d in %.1f s: extraction + forward + loss + backward + Adam through '
+                                  'oracle/extract_cpu.c + oracle/model_cpu.c, %d OpenMP threads' % (steps_t, BATCH, el_t, th))
+    except Exception as e:          # (extra figures: never fail the baseline)
+        rec['twin'] = dict(error=repr(e)[:200])
     print('CPU_BASELINE_JSON ' + json.dumps(rec))
 
 

@@ -272,7 +272,8 @@ def run_model_parity(be, case, R, ARR=0.001, use_dropout=True, multiply_by=1.0, 
     assert got_loss[0] == pytest_approx(float(rl), LOSS_RTOL)
     assert worst < GRAD_TOL, '%s: max rel-to-peak grad error %.3e' % (worst_key, worst)
     res.update(train_out=got_out, loss=got_loss, worst_grad_err=worst, ws=ws, batch=b, graph=g, P=P, flat=flat,
-               ref=ref, d=d, side=side_buf)
+               ref=ref, d=d, side=side_buf, grads=gg, pyg=pyg, lin_mask=lin_mask, edge_keep=keep if use_dropout else None,
+               oracle=(float(rl), ro.numpy(), {k: v.numpy() for k, v in rg.items()}))
     return res
 
 
