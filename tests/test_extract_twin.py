@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import parity_checks as PC
-from helpers import graph_canonical, load_extract_golden
+from helpers import golden_canonical, graph_canonical, load_extract_golden
 from oracle import extract_cpu
 
 CASES = load_extract_golden()
@@ -58,3 +58,40 @@ def test_twin_matches_the_gpu_extraction_at_the_headline_shape():
                                      sample_ratio=case['sample_ratio'], max_nodes_per_hop=case['mnph'], seed=11, epoch=4)
     compare(d, case, twin)
     assert max(len(t[0]) for t in twin) == 101 and max(len(t[1]) for t in twin) == 101      # (the cap binds on both sides)
+
+
+@pytest.mark.parametrize('h', [1, 2])
+def test_twin_matches_the_oracle_extractor_on_random_graphs(h):
+    """No engine in the loop: without caps nothing is sampled, so the twin must return the node sets, labels and induced edges
+    of ``oracle/extract_ref.py`` (pinned to the reference) -- empty rows / columns, isolated and rated target pairs."""
+    from helpers import random_case
+    for seed in range(40):
+        case = random_case(5000 * h + seed, h)
+        n = len(case['links'])
+        twin = extract_cpu.extract_batch(case['A'], case['links'][:, 0], case['links'][:, 1], 0, n, hop=h)
+        for (tu, tv, tul, tvl, te), rec, (i, j) in zip(twin, case['recs'], case['links']):
+            gun, gvn, gulab, gvlab, gt = golden_canonical(rec)
+            assert tu[0] == i and tv[0] == j and sorted(tu) == sorted(gun.tolist()) and sorted(tv) == sorted(gvn.tolist())
+            assert tul == gulab and tvl == gvlab
+            assert te == [tuple(int(x) for x in e) for e in gt]
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_twin_matches_the_reference_goldens_where_nothing_is_sampled(name):
+    """Golden records of the UNMODIFIED reference (tests/golden/make_golden.py): wherever neither the per-hop cap nor the
+    ratio cut a candidate set, the twin's subgraph IS the reference's."""
+    case = CASES[name]
+    n = min(8, len(case['recs']))
+    args = (case['A'], case['links'][:, 0], case['links'][:, 1], 0, n)
+    free = extract_cpu.extract_batch(*args, hop=case['h'])
+    capped = extract_cpu.extract_batch(*args, hop=case['h'], sample_ratio=case['sample_ratio'], max_nodes_per_hop=case['mnph'])
+    compared = 0
+    for g in range(n):
+        if not (np.array_equal(free[g][0], capped[g][0]) and np.array_equal(free[g][1], capped[g][1])):
+            continue                                   # (sampled: CPython's random.sample is not reproducible, SURVEY H1)
+        gun, gvn, gulab, gvlab, gt = golden_canonical(case['recs'][g])
+        tu, tv, tul, tvl, te = capped[g]
+        assert sorted(tu) == sorted(gun.tolist()) and sorted(tv) == sorted(gvn.tolist()) and tul == gulab and tvl == gvlab
+        assert te == [tuple(int(x) for x in e) for e in gt]
+        compared += 1
+    assert compared > 0 or name in ('synth_cap', 'douban_cap20', 'synth_h2_ratio')
