@@ -12,11 +12,13 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CSRC = os.path.join(ROOT, 'igmc_amd', 'csrc')
+# (debug hooks of the same-box A/B tooling: an experimental copy of the sources built into libraries of its own --
+#  IGMC_CSRC_DIR / IGMC_HIP_LIB_OUT / IGMC_EMU_LIB_OUT; the product never sets them)
+CSRC = os.environ.get('IGMC_CSRC_DIR') or os.path.join(ROOT, 'igmc_amd', 'csrc')
 SOURCES = ['extract.hip', 'model.hip', 'graphstep2.hip', 'sortpool.hip', 'capi.hip']
-HEADERS = ['common.h', 'model.h', 'launch.h', 'sortpool.h', 'g2_image.h', 'g2_prims.h', 'head_sub.h', '../../include/igmc_hip.h', '../../include/igmc_rng.h']
-HIP_LIB = os.path.join(ROOT, 'igmc_amd', 'lib', 'libigmc_hip.so')
-EMU_LIB = os.path.join(ROOT, 'tests', 'emu', 'libigmc_emu.so')
+HEADERS = sorted(h for h in os.listdir(CSRC) if h.endswith('.h')) + ['../../include/igmc_hip.h', '../../include/igmc_rng.h']
+HIP_LIB = os.environ.get('IGMC_HIP_LIB_OUT') or os.path.join(ROOT, 'igmc_amd', 'lib', 'libigmc_hip.so')
+EMU_LIB = os.environ.get('IGMC_EMU_LIB_OUT') or os.path.join(ROOT, 'tests', 'emu', 'libigmc_emu.so')
 
 
 def _newer(target, deps):
