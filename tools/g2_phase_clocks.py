@@ -1,5 +1,7 @@
 """Debug aid: phase clocks of k_graph_step2 (IGMC_GS_TIMING=1) on the bench workload: workgroup 0 (user side, member 0) and
-member 2 (item side) of subgraph 0.   python tools/g2_phase_clocks.py [--overlap]"""
+member 2 (item side) of subgraph 0.   python tools/g2_phase_clocks.py [--overlap] [--group]
+(--group: the clocks of the LAST step of a pair of groups launched eagerly -- what an experimental library with a deferred tail,
+IGMC_LIB_PATH + IGMC_DEFER_TAIL=1, runs as a fused launch; its wait shows as stamps 55..57, its tail roles as slots 900..)"""
 import ctypes as C
 import os
 import sys
@@ -43,6 +45,8 @@ def main():
     sg.begin_epoch(perm, 1)
     for _ in range(20):
         sg.step()
+    if '--group' in sys.argv:
+        sg.steps(2 * sg.M)
     torch.cuda.synchronize()
     buf = np.zeros(128, np.uint64)
     lib.cdll.igmc_debug_g2_clocks(C.c_void_p(buf.ctypes.data), 128)
@@ -58,6 +62,19 @@ def main():
     for l in (1, 2, 3):
         print('L%d fwd: wave 0 compute alone %d | %d' % (l, c[36 + l - 1] - c[7 + 3 * (l - 1)], c[100 + l - 1] - c[71 + 3 * (l - 1)]))
     fine(c)
+    if c[55] and c[56] >= c[55]:          # (a library with the deferred tail: the wait for the previous step's tail)
+        print('deferred tail: set-up done -> flag seen %d | fence + layer-0 table + step word %d  (cycles, member 0)' % (
+            c[56] - c[55], c[57] - c[56]))
+        big = np.zeros(1024 * 3, np.uint64)
+        lib.cdll.igmc_debug_g2_wg_clocks(C.c_void_p(big.ctypes.data), 1024)
+        bw = big.reshape(1024, 3).astype(np.int64)
+        t0 = bw[:200, 0].min()
+        roles = [i for i in range(900, 1024) if bw[i, 0] > 0]
+        if roles:
+            st, bd, ar = [(bw[roles, k] - t0) / 100.0 for k in (0, 2, 1)]
+            print('tail roles (%d): start min/max %.1f / %.1f us | body done min/median/max %.1f / %.1f / %.1f | arrived max %.1f '
+                  '(vs the first subgraph workgroup)' % (len(roles), st.min(), st.max(), bd.min(), np.median(bd), bd.max(), ar.max()))
+            print('  per role body time (us): ' + ' '.join('%.1f' % x for x in (bd - st)))
     wg = np.zeros(200 * 3, np.uint64)
     if hasattr(lib.cdll, 'igmc_debug_g2_wg_clocks'):
         lib.cdll.igmc_debug_g2_wg_clocks(C.c_void_p(wg.ctypes.data), 200)
