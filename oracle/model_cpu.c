@@ -143,8 +143,9 @@ static void bucket(int n, int R, int e, const int32_t* key, const int32_t* other
 }
 
 /* One subgraph: forward; with acc != NULL also the backward pass into the thread's accumulators
- * (acc[0 .. n_params): root / bias / lin slots of the flat layout, acc[n_params ..): dW_l[r]).  Returns 0, or -1 when the
- * graph lacks a target node (label 0 = the user, label 1 = the item: reference models.py:205-206). */
+ * (acc[0 .. n_params): root / bias / lin slots of the flat layout, acc[n_params ..): dW_l[r]).  Returns 0; -1 when the
+ * graph lacks a target node (label 0 = the user, label 1 = the item: reference models.py:205-206), -2 / -3 for a label /
+ * an edge outside the subgraph's ranges. */
 static int graph_pass(const Cfg* C, const float* P, const float* W, const float* WT, const float* RT, int n, const int32_t* lab, int e, const int32_t* src,
                       const int32_t* dst, const uint8_t* rel, int32_t base, float y, const uint8_t* mask, int training,
                       float mult, float gscale, float* out, float* acc, Scratch* S) {
@@ -155,6 +156,10 @@ static int graph_pass(const Cfg* C, const float* P, const float* W, const float*
     if (lab[v] == 1 && tv < 0) tv = v;
   }
   if (tu < 0 || tv < 0) return -1;
+  for (int v = 0; v < n; ++v)
+    if (lab[v] < 0 || lab[v] >= C->dims[0]) return -2;                      /* a label beyond the one-hot width */
+  for (int k = 0; k < e; ++k)                                               /* an edge that leaves its subgraph / a relation beyond R */
+    if (src[k] < base || src[k] >= base + n || dst[k] < base || dst[k] >= base + n || rel[k] >= R) return -3;
   bucket(n, R, e, dst, src, rel, base, S->iptr, S->inb, S->fill);          /* messages flow source -> target */
   memset(S->x0, 0, sizeof(float) * (size_t)n * md);
   for (int v = 0; v < n; ++v) S->x0[(size_t)v * md + lab[v]] = 1.f;
@@ -314,7 +319,7 @@ static int graph_pass(const Cfg* C, const float* P, const float* W, const float*
  *   training : 1 = lin_mask [B][hid] (uint8 keep flags of the 0.5 dropout) is applied; 0 = eval
  *   grad     : NULL = forward only; else the flat gradient of  mean_g (out_g - y_g)^2 + ARR * sum_l sum_r ||W_l[r+1] - W_l[r]||^2
  *   loss     : NULL or [2]: that loss, and the sum of squared errors
- * Returns 0; -1 bad configuration; -2 a subgraph without its two target nodes. */
+ * Returns 0; -1 bad configuration; -2 a malformed subgraph (no target pair, a label / edge / relation out of range). */
 int igmc_cpu_model_loss_grad(int nl, const int* dims, int R, int NB, int hid, const float* params, int B,
                              const int64_t* node_off, const int32_t* label, const int64_t* edge_off, const int32_t* src,
                              const int32_t* dst, const uint8_t* rel, const float* y, const uint8_t* lin_mask, int training,

@@ -177,3 +177,21 @@ def test_gpu_headline_batch_matches_the_twin(drop):
     res = PC.run_model_parity(be, case, R=5, use_dropout=drop, check_eval=False)
     assert res['d']['B'] == 50 and res['d']['E'] > 150000
     compare_engine(res, 5)
+
+
+def test_twin_rejects_malformed_batches():
+    case = CASES['hand']
+    cb = twin_batch(case, 0, 2)
+    ref = PC.make_ref_model(4, 5, seed=1)
+    cfg = model_cpu.config_of(ref)
+    flat = model_cpu.flat_from_model(ref, cfg)
+    for key, val in (('label', 9), ('rel', 7), ('src', int(cb['node_off'][-1]))):
+        bad = dict(cb)
+        bad[key] = cb[key].copy()
+        bad[key][0] = val
+        with pytest.raises(RuntimeError):
+            model_cpu.loss_grad(cfg, flat, bad, want_grad=False)
+    no_target = dict(cb)
+    no_target['label'] = np.maximum(cb['label'], 2).astype(np.int32)
+    with pytest.raises(RuntimeError):
+        model_cpu.loss_grad(cfg, flat, no_target, want_grad=False)
