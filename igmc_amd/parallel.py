@@ -135,14 +135,39 @@ class PeerComm(object):
         r, w = rank(), world_size()
         h = C.c_void_p()
         handle = (C.c_uint8 * 64)()
-        lib.call('igmc_comm_peer_alloc', r, w, int(device), int(max_floats), C.byref(h), C.cast(handle, C.c_void_p))
-        self.handle = h
-        handles = [bytes(handle)]
+        # The allocation is the fallible step (hipMalloc, the IPC handle, world > IGMC_MAX_PEERS): EVERY rank takes part in
+        # the one gather of (status, handle) whatever happened locally, and every rank raises after it when any rank failed
+        # -- a rank that left early would be in grad_comm's next collective while the others wait in this one.
+        status = 'ok'
+        try:
+            lib.call('igmc_comm_peer_alloc', r, w, int(device), int(max_floats), C.byref(h), C.cast(handle, C.c_void_p))
+            self.handle = h
+        except RuntimeError as e:
+            status = str(e) or 'igmc_comm_peer_alloc failed'
+        got = [(status, bytes(handle))]
         if is_dist() and w > 1:
-            handles = [None] * w
-            dist.all_gather_object(handles, bytes(handle))
-        blob = (C.c_uint8 * (64 * w)).from_buffer_copy(b''.join(handles))
-        lib.call('igmc_comm_peer_connect', self.handle, C.cast(blob, C.c_void_p))
+            got = [None] * w
+            dist.all_gather_object(got, (status, bytes(handle)))
+        bad = ['rank %d: %s' % (k, s) for k, (s, _) in enumerate(got) if s != 'ok']
+        if bad:
+            self.close()
+            raise RuntimeError('peer communicator: ' + '; '.join(bad))
+        blob = (C.c_uint8 * (64 * w)).from_buffer_copy(b''.join(hh for _, hh in got))
+        # (mapping the peers' buffers can fail too -- peer access refused: the outcome is agreed on the same way)
+        status = 'ok'
+        try:
+            lib.call('igmc_comm_peer_connect', self.handle, C.cast(blob, C.c_void_p))
+        except RuntimeError as e:
+            status = str(e) or 'igmc_comm_peer_connect failed'
+        if is_dist() and w > 1:
+            got = [None] * w
+            dist.all_gather_object(got, status)
+            bad = ['rank %d: %s' % (k, s) for k, s in enumerate(got) if s != 'ok']
+        else:
+            bad = [] if status == 'ok' else [status]
+        if bad:
+            self.close()
+            raise RuntimeError('peer communicator: ' + '; '.join(bad))
         self.fine_grained = lib.cdll.igmc_comm_kind(self.handle) == 4
         # self-test (also the first use of the mapped pointers): sum of r + 1 over the ranks, two launches = both slots
         dev = torch.device('cuda', int(device))

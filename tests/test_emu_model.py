@@ -349,6 +349,40 @@ def test_free_running_dropout_on_a_lean_arena_with_ten_relations(be, monkeypatch
     assert eager['keep_rate'] == res['keep_rate']
 
 
+def ten_levels(case):
+    """An ML-like case with every rating level split into two half-star levels (by a hash of the pair): ten relations
+    on the case's own graph shape -- ml_10m's levels on an ml_1m-like graph (bench.py's ``ml_10m_lite``)."""
+    c = dict(case)
+    A = case['A'].tocoo()
+    half = ((A.row.astype(np.int64) * 2654435761 + A.col.astype(np.int64) * 40503) >> 7) & 1
+    import scipy.sparse as sp
+    c['A'] = sp.csr_matrix((2.0 * A.data - 1.0 + half, (A.row, A.col)), shape=A.shape)
+    c['class_values'] = np.arange(1, 11, dtype=np.float64) / 2.0
+    lab = np.asarray(case['link_labels'], np.int64)
+    c['link_labels'] = 2 * lab + (np.arange(len(lab)) & 1)
+    c['recs'] = [None] * len(case['links'])
+    return c
+
+
+@pytest.mark.parametrize('drop,lean', [(False, True), (True, False)])
+def test_ten_relations_at_cap_100(be, drop, lean):
+    """R = 10 x cap 100 (up to 101 rows a side: two workgroups per side AND two relation groups in one launch) -- the
+    ml_10m_lite shape of bench.py, GPU twin: test_gpu_headline.py::test_ml10m_lite_batch_matches_oracle."""
+    case = ten_levels(sub('synth_nocap:100', 4))
+    res = PC.run_model_parity(be, case, R=10, use_dropout=drop, lean=lean)
+    assert res['worst_grad_err'] < 1e-4
+    assert res['batch'].dense_layers(res['ws'])
+    assert int(res['d']['erel'].max()) >= 8
+
+
+def test_ten_relations_at_cap_100_in_the_fused_train_step(be):
+    case = ten_levels(sub('synth_nocap:100', 8))
+    runs = [PC.run_fused_train_trajectory(be, case, R=10, steps=4, batch=2, use_dropout=True) for _ in range(2)]
+    assert runs[0]['frac_off'] < PC.TRAJ_FRAC_OFF
+    for k in ('params', 'm1', 'm2'):
+        assert np.array_equal(runs[0][k], runs[1][k]), k
+
+
 @pytest.mark.parametrize('name,R,n', [('hand_h2', 5, 5), ('flixster_h2', 10, 4)])
 def test_two_hops_take_the_dense_layers(be, name, R, n):
     """Two hops (six node labels, reference util_functions.py:248-262): the layer-0 table [R L | L | 1] has 37 (R = 5) rows --

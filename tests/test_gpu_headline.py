@@ -152,6 +152,54 @@ def test_flixster_fused_train_steps_are_bit_reproducible(be):
         assert np.array_equal(runs[0][k], runs[1][k]), k
 
 
+def ml10m_case(n, seed=4):
+    """The R = 10 counterpart of the headline shape (bench.py's ``ml_10m_lite``: ML-10M's ten half-star levels on the
+    ml_1m-shaped graph, cap 100; reference Main.py:155-163 lists ml_10m beside flixster)."""
+    from igmc_amd import preprocessing
+    rmap = {float(i): i / 2.0 for i in range(1, 11)}
+    split = preprocessing.create_trainvaltest_split('ml_10m_lite', 1234, True, rating_map=rmap, verbose=False)
+    (_, _, A, tr_l, tr_u, tr_v, _, _, _, _, _, _, cv) = split
+    pick = np.random.default_rng(seed).permutation(len(tr_u))[:n]
+    links = np.stack([tr_u[pick], tr_v[pick]], 1).astype(np.int64)
+    return dict(A=A, links=links, link_labels=np.asarray(tr_l)[pick].astype(np.int64),
+                class_values=np.asarray(cv, dtype=np.float64), h=1, sample_ratio=1.0, mnph=100, recs=[None] * n)
+
+
+@pytest.fixture(scope='module')
+def ml10m():
+    return ml10m_case(250)
+
+
+@pytest.mark.parametrize('drop,lean', [(False, True), (True, False), (True, True)])
+def test_ml10m_lite_batch_matches_oracle(be, ml10m, drop, lean):
+    """Ten relations x cap 100 x batch 50 (E ~ 270 k): two workgroups per side AND two relation groups on k_dl_fwd /
+    k_dl_bwd -- the product of what flixster (relation groups at 49 x 155 slots) and the cap-100 cases (R = 5) cover
+    separately, and a shape bench.py times (``secondary.ml_10m_lite``).  Forward, loss, every gradient vs the oracle."""
+    case = first(ml10m, 50)
+    assert len(case['class_values']) == 10
+    res = PC.run_model_parity(be, case, R=10, use_dropout=drop, lean=lean)
+    assert res['worst_grad_err'] < PC.GRAD_TOL
+    assert res['batch'].dense_layers(res['ws'])
+    d = res['d']
+    assert d['B'] == 50 and 50 * 150 < d['N'] <= 50 * 202 and d['E'] > 150000
+    assert int(d['erel'].max()) >= 8                   # relation codes of the second group are present
+    PC.check_sampled(d, case)
+
+
+def test_ml10m_lite_free_running_dropout_on_the_dense_blocks(be, ml10m):
+    res = PC.run_free_running_dropout(be, first(ml10m, 50, 50), R=10, p=0.2, force_undirected=False, lean=True)
+    assert res['worst_grad_err'] < PC.GRAD_TOL
+
+
+def test_ml10m_lite_fused_train_steps_track_torch_adam_and_are_bit_reproducible(be, ml10m):
+    """Five fused steps (k_dl_fwd -> k_dl_bwd -> k_tail_ts -> k_finalize_ts with the group images of the next step) on five
+    batches of 50 vs pyg_ref.train_step + torch Adam, twice from the same state: the same bits."""
+    runs = [PC.run_fused_train_trajectory(be, ml10m, R=10, steps=5, batch=50, use_dropout=True) for _ in range(2)]
+    assert runs[0]['frac_off'] < PC.TRAJ_FRAC_OFF
+    for k in ('params', 'm1', 'm2'):
+        assert np.array_equal(runs[0][k], runs[1][k]), k
+
+
 @pytest.mark.parametrize('lean', [False, True])
 def test_ml100k_cap200_batch_matches_oracle(be, lean):
     """BASELINE.json configs[1]: ml_100k shape, cap 200, adj-dropout 0.2, batch 50 -- slots of 201 nodes a side: the dense
