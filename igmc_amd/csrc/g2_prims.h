@@ -68,11 +68,48 @@ __device__ __forceinline__ void g2_expand4(uint32_t w, uint32_t r1, int keepbit,
 #endif
 }
 
+// ... the same in two steps: 0xFF in the bytes that match (kept resident), and the bf16 pairs of eight bytes from two masks
+template <bool FLAGS>
+__device__ __forceinline__ uint32_t g2_bytemask(uint32_t w, uint32_t r1, int keepbit) {
+  uint32_t mk = w & (0x01010101u * IGMC_RELM_CODE);
+  if (FLAGS) mk &= ((w >> keepbit) & 0x01010101u) * IGMC_RELM_CODE;
+  const uint32_t t = mk ^ (0x01010101u * r1);
+  const uint32_t eq = ~(t + 0x7F7F7F7Fu) & 0x80808080u;
+  return (eq >> 7) * 0xFFu;
+}
+__device__ __forceinline__ u32x4 g2_mask_frag(uint32_t m0, uint32_t m1) {
+  u32x4 f;
+#ifdef IGMC_HIPEMU
+  f[0] = ((m0 & 0xFFu) ? 0x3F80u : 0u) | ((m0 & 0xFF00u) ? 0x3F800000u : 0u);
+  f[1] = ((m0 & 0xFF0000u) ? 0x3F80u : 0u) | ((m0 & 0xFF000000u) ? 0x3F800000u : 0u);
+  f[2] = ((m1 & 0xFFu) ? 0x3F80u : 0u) | ((m1 & 0xFF00u) ? 0x3F800000u : 0u);
+  f[3] = ((m1 & 0xFF0000u) ? 0x3F80u : 0u) | ((m1 & 0xFF000000u) ? 0x3F800000u : 0u);
+#else
+  f[0] = __builtin_amdgcn_perm(m0, m0, 0x01010000u) & 0x3F803F80u;
+  f[1] = __builtin_amdgcn_perm(m0, m0, 0x03030202u) & 0x3F803F80u;
+  f[2] = __builtin_amdgcn_perm(m1, m1, 0x01010000u) & 0x3F803F80u;
+  f[3] = __builtin_amdgcn_perm(m1, m1, 0x03030202u) & 0x3F803F80u;
+#endif
+  return f;
+}
+
 __device__ __forceinline__ float g2_tanh(float x) {
 #ifdef IGMC_HIPEMU
   return tanhf(x);
 #else
   return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x));
+#endif
+}
+
+// 16 bytes per lane, global -> LDS, without passing through registers (global_load_lds_dwordx4): the destination is the
+// WAVE-UNIFORM base + 16 * lane, the source address is per lane.  Asynchronous: a pending one counts on the vector
+// counter; the barrier (or wait) in front of the first read of the destination retires it.
+__device__ __forceinline__ void g2_glds16(const float4* src_wave, float4* lds_wave, int lane) {
+#ifndef IGMC_HIPEMU
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_wave + lane),
+                                   (__attribute__((address_space(3))) void*)lds_wave, 16, 0, 0);
+#else
+  lds_wave[lane] = src_wave[lane];
 #endif
 }
 
@@ -108,12 +145,13 @@ __device__ __forceinline__ void g2_pub_f32(unsigned long long* p, float v, uint3
 }
 
 // The planes [term][feature][node] of one side from its exchange region ex[feature][KMAX nodes]: nodes < npad (a
-// multiple of 16, <= 128) of all 32 features = 16 * npad word pairs, <= 8 per thread.  Two halves, so that the round
+// multiple of 16, <= 128) of all 32 features = 16 * npad word pairs, <= G2_PPT per thread of the 512.  Two halves, so that the round
 // trip can run under other work: g2_poll_issue requests every pair of the thread (16-byte sc1 buffer loads the compiler
 // tracks -- no inline asm, nothing to mis-schedule), g2_poll_finish consumes them; pairs whose tags are not this
 // exchange's are requested again until they are.
+#define G2_PPT 4                  // word pairs per thread: 32 features x 64 pairs / G2_THREADS
 struct G2Poll {
-  u32x4 v[8];
+  u32x4 v[G2_PPT];
 };
 #ifndef IGMC_HIPEMU
 __device__ __forceinline__ u32x4 g2_ld16_sc1(const unsigned long long* base, int byte_off) {
@@ -123,11 +161,11 @@ __device__ __forceinline__ u32x4 g2_ld16_sc1(const unsigned long long* base, int
 #endif
 __device__ __forceinline__ void g2_poll_issue(G2Poll& pq, const unsigned long long* ex, int npad) {
 #ifndef IGMC_HIPEMU
-  // pair p = thread + 256 u  ->  feature p >> 6, node pair p & 63 (pairs past npad are never consumed)
+  // pair p = thread + 512 u  ->  feature p >> 6, node pair p & 63 (pairs past npad are never consumed)
   const int t0 = (int)threadIdx.x;
   (void)npad;
 #pragma unroll
-  for (int u = 0; u < 8; ++u) pq.v[u] = g2_ld16_sc1(ex, (t0 + u * G2_THREADS) * 16);
+  for (int u = 0; u < G2_PPT; ++u) pq.v[u] = g2_ld16_sc1(ex, (t0 + u * G2_THREADS) * 16);
 #else
   (void)pq; (void)ex; (void)npad;
 #endif
@@ -139,14 +177,14 @@ __device__ __forceinline__ void g2_poll_finish(G2Poll& pq, uint32_t* pl, int kp,
 #ifndef IGMC_HIPEMU
   (void)total;
   const int q0 = t0 & 63;                                                 // this thread's node pair (of 64 per feature)
-  uint32_t pend = (q0 < hp) ? 0xFFu : 0u;
-  const int d0 = ((t0 >> 6) * kp >> 1) + q0;                              // feature (t0 >> 6) + 4 u
+  uint32_t pend = (q0 < hp) ? ((1u << G2_PPT) - 1u) : 0u;
+  const int d0 = ((t0 >> 6) * kp >> 1) + q0;                              // feature (t0 >> 6) + 8 u
   for (int it = 0;; ++it) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < G2_PPT; ++u) {
       const u32x4 V = pq.v[u];
       if ((pend & (1u << u)) && (V.y >> 16) == tag16 && (V.w >> 16) == tag16) {
-        const int d = d0 + u * (4 * kp >> 1);                              // dword index inside a term's plane
+        const int d = d0 + u * ((G2_THREADS / 64) * kp >> 1);              // dword index inside a term's plane
         pl[d] = (V.x & 0xFFFFu) | (V.z << 16);
         pl[tstride + d] = (V.x >> 16) | (V.z & 0xFFFF0000u);
         pl[2 * tstride + d] = (V.y & 0xFFFFu) | (V.w << 16);
@@ -160,7 +198,7 @@ __device__ __forceinline__ void g2_poll_finish(G2Poll& pq, uint32_t* pl, int kp,
     }
     __builtin_amdgcn_s_sleep(2);
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < G2_PPT; ++u)
       if (pend & (1u << u)) pq.v[u] = g2_ld16_sc1(ex, (t0 + u * G2_THREADS) * 16);
   }
 #else

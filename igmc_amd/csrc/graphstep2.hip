@@ -38,8 +38,10 @@
 #include <stdio.h>
 #include <string.h>
 
-#define G2_THREADS 256
-#define G2_NW 4
+#define G2_THREADS 512            // k_graph_step2: eight waves = two per SIMD
+#define G2_NB 4                   // 16-row bundles of a workgroup; a bundle is worked by a PAIR of waves (2 b, 2 b + 1), one
+                                  // per 16-column feature tile: gather, half of the transform's K, epilogue of that tile
+#define G2C_THREADS 256           // k_g2_compose
 #define G2_KS 4                   // k-steps of 32 opposite-side nodes (K <= 128)
 #define G2_TP (G2_NR * 32 + 4)    // pitch of a wave's 16-row T' tile (backward)
 #define G2_XP 36                  // pitch of a wave's 16-row x / dPre / h tile
@@ -53,27 +55,21 @@ __device__ unsigned long long g_g2_clk[128];
 __device__ unsigned long long g_g2_wg[1024][3];
 #include "g2_prims.h"      // the gfx950 primitives of this file (and their stand-ins for the CPU emulation build)
 
-// ---- the relation-space aggregate of one bundle on the matrix cores: acc[r][t] (lane = row, regs = features
-//      16 t + 4 (lane >> 4) + 0..3) = sum over the opposite side's nodes of A_r[row][node] * x[node][feature].
-//      All G2_NR relations always run (fragments of absent relations are zero); the six plane fragments of k-step s + 1
-//      are requested before the 30 MFMAs of k-step s are issued.
-__device__ __forceinline__ void g2_gather(const uint32_t* pl, int kp, int nks, const uint32_t (&A)[G2_NR][G2_KS][4],
-                                          int li, int kq, f32x4 (&acc)[G2_NR][2]) {
+// ---- the relation-space aggregate of one bundle on the matrix cores, ONE 16-column feature tile of it (the wave's half
+//      hf of the pair): acc[r] (lane = row, regs = features 16 hf + 4 (lane >> 4) + 0..3) = sum over the opposite side's
+//      nodes of A_r[row][node] * x[node][feature].  All G2_NR relations always run (fragments of absent relations are
+//      zero); the three plane fragments of k-step s + 1 are requested before the 15 MFMAs of k-step s are issued.
+//      frag(r, s) yields the A_r fragment of k-step s (resident registers, or expanded from the block bytes).
+template <typename Frag>
+__device__ __forceinline__ void g2_gather_h(const uint32_t* pl, int kp, int nks, Frag frag, int li, int kq, int hf, f32x4 (&acc)[G2_NR]) {
 #pragma unroll
-  for (int r = 0; r < G2_NR; ++r) {
-    acc[r][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
+  for (int r = 0; r < G2_NR; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int tstride = 32 * kp >> 1;            // dwords per term
-  const uint32_t* base = pl + (li * kp >> 1) + 4 * kq;
-  const int toff = 16 * kp >> 1;               // second feature tile
-  u32x4 pf[2][2 * G2_NT];
+  const uint32_t* base = pl + ((16 * hf + li) * kp >> 1) + 4 * kq;
+  u32x4 pf[2][G2_NT];
   auto request = [&](int s, int buf) {
 #pragma unroll
-    for (int sp = 0; sp < G2_NT; ++sp) {
-      pf[buf][2 * sp] = *(const u32x4*)(base + sp * tstride + 16 * s);
-      pf[buf][2 * sp + 1] = *(const u32x4*)(base + sp * tstride + toff + 16 * s);
-    }
+    for (int sp = 0; sp < G2_NT; ++sp) pf[buf][sp] = *(const u32x4*)(base + sp * tstride + 16 * s);
   };
   request(0, 0);
 #pragma unroll
@@ -82,15 +78,78 @@ __device__ __forceinline__ void g2_gather(const uint32_t* pl, int kp, int nks, c
       if (s + 1 < G2_KS) request(s + 1, (s + 1) & 1);      // unconditional (a k-step past the side reads bytes that are
       G2_SCHED_BARRIER();                                  // never used): a guarded request is sunk below the MFMAs
 #pragma unroll
-      for (int q = 0; q < 2 * G2_NT; ++q) {
+      for (int r = 0; r < G2_NR; ++r) {
+        const u32x4 fr = frag(r, s);         // formed ONCE per (relation, k-step): 8 VALU ops for the three terms' MFMAs
 #pragma unroll
-        for (int r = 0; r < G2_NR; ++r) {
-          const u32x4 af = {A[r][s][0], A[r][s][1], A[r][s][2], A[r][s][3]};
-          acc[r][q & 1] = g2_mfma_bf16(pf[s & 1][q], af, acc[r][q & 1]);
-        }
+        for (int q = 0; q < G2_NT; ++q) acc[r] = g2_mfma_bf16(pf[s & 1][q], fr, acc[r]);
       }
       G2_SCHED_BARRIER();
     }
+  }
+}
+
+// This wave's HALF of the dense transform  out = [T_0..T_4 | x] @ [W_0; ..; W_4; root]: the K slots that belong to its
+// feature tile -- input features 16 hf + 0..15 of every relation block and of the bundle's own rows x -- against BOTH
+// output tiles; the pair's two partial outputs are summed through LDS by the caller.  Same arithmetic as g2_transform
+// (both operands as three bf16 terms, six products), one 16x16x32 step = TWO blocks' halves: (T_0, T_1), (T_2, T_3),
+// (T_4, x).  The gather's accumulators are the A operand (lane (row li, kq): features 16 hf + 4 kq + 0..3 of a block = four
+// k-slots); the B operand takes the matching 8-byte half (dwords 2 hf, 2 hf + 1) of the lane's 16-byte fragment of each of
+// the step's two blocks in the staged image (g2_image.h: elements 0..3 = rows 4 kq + e, 4..7 = rows 16 + 4 kq + e - 4).
+__device__ __forceinline__ void g2_transform_h(const f32x4 (&acc)[G2_NR], const float* xrows, const uint32_t* sW, int li, int kq, int hf,
+                                               f32x4 (&o)[2]) {
+  f32x4 o0a = (f32x4){0.f, 0.f, 0.f, 0.f}, o0b = o0a, o1a = o0a, o1b = o0a;
+  const float4 xv = *(const float4*)(xrows + li * G2_XP + 16 * hf + 4 * kq);
+  const uint2* wf = (const uint2*)sW + 2 * (kq * 16 + li) + hf;     // the lane's half fragment inside a [64]-lane group
+  uint2 bf[2][2 * G2_NT][2];                                        // [buffer][2 term + nt][block of the step]
+  auto request = [&](int st, int buf) {
+#pragma unroll
+    for (int t = 0; t < G2_NT; ++t)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2) bf[buf][2 * t + nt][b2] = wf[((t * (G2_NR + 1) + 2 * st + b2) * 2 + nt) * 128];
+  };
+  request(0, 0);
+#pragma unroll
+  for (int st = 0; st < (G2_NR + 1) / 2; ++st) {
+    if (st + 1 < (G2_NR + 1) / 2) request(st + 1, (st + 1) & 1);
+    float v[8];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      v[rr] = acc[2 * st][rr];
+      v[4 + rr] = (2 * st + 1 < G2_NR) ? acc[(2 * st + 1 < G2_NR) ? 2 * st + 1 : 0][rr] : (rr == 0 ? xv.x : rr == 1 ? xv.y : rr == 2 ? xv.z : xv.w);
+    }
+    u32x4 ah, am, al;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t h, mi, lo;
+      g2_split2(v[2 * q], v[2 * q + 1], h, mi, lo);
+      ah[q] = h;
+      am[q] = mi;
+      al[q] = lo;
+    }
+    G2_SCHED_BARRIER();
+    u32x4 b[2 * G2_NT];
+#pragma unroll
+    for (int q = 0; q < 2 * G2_NT; ++q) b[q] = (u32x4){bf[st & 1][q][0].x, bf[st & 1][q][0].y, bf[st & 1][q][1].x, bf[st & 1][q][1].y};
+    o0a = g2_mfma_bf16(ah, b[0], o0a);
+    o1a = g2_mfma_bf16(ah, b[1], o1a);
+    o0b = g2_mfma_bf16(ah, b[2], o0b);
+    o1b = g2_mfma_bf16(ah, b[3], o1b);
+    o0a = g2_mfma_bf16(am, b[0], o0a);
+    o1a = g2_mfma_bf16(am, b[1], o1a);
+    o0b = g2_mfma_bf16(ah, b[4], o0b);
+    o1b = g2_mfma_bf16(ah, b[5], o1b);
+    o0a = g2_mfma_bf16(al, b[0], o0a);
+    o1a = g2_mfma_bf16(al, b[1], o1a);
+    o0b = g2_mfma_bf16(am, b[2], o0b);
+    o1b = g2_mfma_bf16(am, b[3], o1b);
+    G2_SCHED_BARRIER();
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    o[0][rr] = o0a[rr] + o0b[rr];
+    o[1][rr] = o1a[rr] + o1b[rr];
   }
 }
 
@@ -224,10 +283,11 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
   unsigned char* RM = (unsigned char*)(S + lay.tile);   // [2][rmr][rmc + 8] bytes: relm (rows = users) and its transpose
                                                         // (rows = items); set-up only: aliases the backward's T' tiles
   unsigned char* slab = (unsigned char*)(S + lay.lab);  // [2][128] node labels of both sides
-  float* XOA = S + lay.xo;                              // [2][4 waves][16][G2_XP]: the bundle's own rows of x / dPre
+  float* XOA = S + lay.xo;                              // [2][4 bundles][16][G2_XP]: the bundle's own rows of x / dPre
   float* HSS = S + lay.hs;                              // [4][16][G2_XP] h_{l-1} rows of the bundle (backward)
   float* TILES = S + lay.tile;                          // [4][16][G2_TP] T' rows of the bundle (backward)
   float* HIST = S + lay.hist;                           // [4][16][G2_XP] layer-0 input [code histogram | onehot | 1]
+  float* PXA = S + lay.px;                              // [4 bundles][2 waves][64 lanes] x 4: the pair's partial outputs
   float2* sW2 = (float2*)(S + lay.wreg);                // [G2_WIMG words] B operand of the layer as bf16 term fragments
   float* sT0 = S + lay.t0;                              // [32][32] layer-0 table
   float* sfeat = S + lay.head;            // [256] centre-node readout
@@ -235,8 +295,8 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
   float* sa1 = sgf + 256;                 // [128]
   float* skeep = sa1 + 128;               // [128]
   float* sdz = skeep + 128;               // [128]
-  float* sred = sdz + 128;                // [256]
-  float* misc = sred + 256;               // [16]
+  float* sred = sdz + 128;                // [512]
+  float* misc = sred + 512;               // [16]
   const int R = a.R, L = a.L, RL = R * L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
@@ -273,19 +333,19 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
   auto load_label = [&](int g2) {
     // (capacity of the lane's side by arithmetic on the two VALUES: a per-lane select between the two kernel-argument
     //  fields compiles to a vector load from the argument segment + a vmcnt(0) wait in front of every other load)
-    const int hi = tid >> 7, t7 = tid & 127;
+    const int hi = (tid >> 7) & 1, t7 = tid & 127;              // (threads 256.. repeat the first 256: their value is unused)
     const int capx = a.cap_u + hi * (a.cap_v - a.cap_u);
     return (int)a.s_lab[(size_t)g2 * a.slot + hi * a.cap_u + ((t7 < capx) ? t7 : 0)];
   };
-  uint32_t rmv[16];          // dword (tid & 31) of rows (tid >> 5) + 8 q  (ld <= 128 bytes, <= 128 rows)
+  uint32_t rmv[8];           // dword (tid & 31) of rows (tid >> 5) + 16 q  (ld <= 128 bytes, <= 128 rows)
   auto load_relm = [&](int g2) {
     const uint32_t* rm = (const uint32_t*)(a.relm + (size_t)g2 * a.cap_u * ld) + (tid >> 5) * ldw + (tid & 31);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) rmv[q] = ((tid & 31) < ldw && (tid >> 5) + 8 * q < a.cap_u) ? rm[8 * q * ldw] : 0u;
+    for (int q = 0; q < 8; ++q) rmv[q] = ((tid & 31) < ldw && (tid >> 5) + 16 * q < a.cap_u) ? rm[16 * q * ldw] : 0u;
   };
   int labv_raw = 0;
-  // layer-0 table: requested here, written to LDS at the end of the set-up (no wait for it in the prologue)
-  const float4 t0v = ((const float4*)(a.g2_w + 6 * G2_WIMG))[tid];
+  // layer-0 table (4 KB): requested here, global -> LDS directly, landed by the set-up's barriers
+  if (tid < 256) g2_glds16((const float4*)(a.g2_w + 6 * G2_WIMG) + (tid & ~63), (float4*)sT0 + (tid & ~63), tid & 63);
   // partial-table slot of this workgroup: member c of subgraph g -> g + c * stride (what k_tail_ts sums)
   const int tslot = (cs > 1) ? g_first + cm * a.stride : (int)blockIdx.x;
   f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};        // layer-0 table gradient tile (code half, feature half) of this wave
@@ -301,7 +361,9 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
     G2_OPAQUE(tid_g);
     const int tid = tid_g, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
-    const int gw = cm * G2_NW + wave;
+    const int bw = wave >> 1, hf = wave & 1;              // bundle of the workgroup, feature tile of the pair (waves 2 b and
+                                                          // 2 b + 1 sit on different SIMDs; each SIMD holds two bundles' waves)
+    const int gw = cm * G2_NB + bw;
     const int side = gw / half, bi = gw - side * half;    // this wave's side (0 users, 1 items) and bundle of that side
     labv_raw = load_label(g);
     load_relm(g);
@@ -316,11 +378,13 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
     const int sx = (nsides == 2) ? side : 0, so = (nsides == 2) ? 1 - side : 0;    // LDS images of own / opposite side
     uint32_t* pl = PLN + so * (G2_NT * 32 * kp >> 1);
     uint32_t* ohp = OHP + so * (8 * kp >> 1);
-    float* XO0 = XOA + wave * 16 * G2_XP;                     // ping
-    float* XO1 = XOA + (G2_NW + wave) * 16 * G2_XP;           // pong
-    float* HS = HSS + wave * 16 * G2_XP;
-    float* T = TILES + wave * 16 * G2_TP;
-    float* HI = HIST + wave * 16 * G2_XP;
+    float* XO0 = XOA + bw * 16 * G2_XP;                       // ping
+    float* XO1 = XOA + (G2_NB + bw) * 16 * G2_XP;             // pong
+    float* HS = HSS + bw * 16 * G2_XP;
+    float* T = TILES + bw * 16 * G2_TP;
+    float* HI = HIST + bw * 16 * G2_XP;
+    f32x4* PXo = (f32x4*)PXA + (bw * 2 + hf) * 64 + lane;           // this wave's partial of the PARTNER's tile
+    const f32x4* PXi = (const f32x4*)PXA + (bw * 2 + (1 - hf)) * 64 + lane;    // the partner's partial of this wave's tile
     // exchange regions of this subgraph: [exchange x][g][side][32 features][128 nodes]
     unsigned long long* ex_own = a.g2_ex + ((size_t)g * 2 + side) * 4096;
     const unsigned long long* ex_opp = a.g2_ex + ((size_t)g * 2 + (1 - side)) * 4096;
@@ -345,11 +409,11 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int i = tid; i < nsides * (G2_NT * 32 * kp >> 3); i += G2_THREADS) ((float4*)PLN)[i] = z4;
       for (int i = tid; i < (2 * rmr * rmp >> 4); i += G2_THREADS) ((float4*)RM)[i] = z4;
-      for (int i = tid; i < 2 * G2_NW * 16 * G2_XP / 4; i += G2_THREADS) ((float4*)XOA)[i] = z4;
-      for (int i = tid; i < G2_NW * 16 * G2_XP / 4; i += G2_THREADS) ((float4*)HIST)[i] = z4;
+      for (int i = tid; i < 2 * G2_NB * 16 * G2_XP / 4; i += G2_THREADS) ((float4*)XOA)[i] = z4;
+      for (int i = tid; i < G2_NB * 16 * G2_XP / 4; i += G2_THREADS) ((float4*)HIST)[i] = z4;
     }
     G2_STAMP(49);
-    slab[tid] = (unsigned char)(((tid & 127) < ((tid >> 7) ? cv : cu)) ? labv_raw : 255);
+    if (tid < 256) slab[tid] = (unsigned char)(((tid & 127) < ((tid >> 7) ? cv : cu)) ? labv_raw : 255);
     G2_STAMP(50);
     __syncthreads();
     G2_STAMP(2);
@@ -357,8 +421,8 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
       int tid_ = tid;
       G2_OPAQUE(tid_);
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {        // row-major image (rows = users): one dword per lane, conflict-free
-        const int u = (tid_ >> 5) + 8 * q, c4 = (tid_ & 31) * 4;
+      for (int q = 0; q < 8; ++q) {         // row-major image (rows = users): one dword per lane, conflict-free
+        const int u = (tid_ >> 5) + 16 * q, c4 = (tid_ & 31) * 4;
         if ((tid_ & 31) < ldw && u < cu && c4 < rmc) *(uint32_t*)(RM + (size_t)u * rmp + c4) = rmv[q];
       }
     }
@@ -391,11 +455,18 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
     G2_STAMP(3);
     // ---- A fragments of this wave's bundle: A[r][s] = the 16 x 32 block (rows of the bundle) x (opposite nodes 32 s ..)
     //      of relation r as the MFMA B operand of the transposed gather; forward and (with edge dropout) backward masks
-    uint32_t AF[G2_NR][G2_KS][4];
-    uint32_t AB[FLAGS ? G2_NR : 1][FLAGS ? G2_KS : 1][4];
+    //      (both waves of a pair hold the bundle's fragments).  Two waves per SIMD leave a wave 256 registers: the fragments
+    //      stay resident as BYTE masks -- AM[r][s][h] = 0xFF in the bytes of the four nodes 4 (2 kq + h) .. + 3 of k-step s
+    //      whose block byte is relation r (40 registers instead of 80) -- and become bf16 1.0 / 0.0 pairs by a byte
+    //      permute + and per dword right in front of their MFMAs (VALU work that runs under the partner wave's matrix
+    //      work).  With edge dropout the BACKWARD masks (the other keep bit) are derived from the eight block bytes per
+    //      k-step inside the backward gather.
+    uint32_t AM[G2_NR][G2_KS][2];
+    uint32_t RB[FLAGS ? G2_KS : 1][2];
+    const int kb = side ? IGMC_RELM_KF : IGMC_RELM_KT;      // keep bit of the edge  own -> opposite
     {
       const unsigned char* rmo = RM + (size_t)side * rmr * rmp + (size_t)(row0 + li) * rmp;
-      const int kf = side ? IGMC_RELM_KT : IGMC_RELM_KF, kb = side ? IGMC_RELM_KF : IGMC_RELM_KT;     // keep bit of the edge  opposite -> own  /  own -> opposite
+      const int kf = side ? IGMC_RELM_KT : IGMC_RELM_KF;    // keep bit of the edge  opposite -> own
 #pragma unroll
       for (int s = 0; s < G2_KS; ++s) {
         uint32_t w0 = 0u, w1 = 0u;
@@ -404,61 +475,69 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
           w0 = w.x;
           w1 = w.y;
         }
+        if constexpr (FLAGS) {
+          RB[s][0] = w0;
+          RB[s][1] = w1;
+        }
 #pragma unroll
         for (int r = 0; r < G2_NR; ++r) {
-          g2_expand4<FLAGS>(w0, (uint32_t)(r + 1), kf, AF[r][s][0], AF[r][s][1]);
-          g2_expand4<FLAGS>(w1, (uint32_t)(r + 1), kf, AF[r][s][2], AF[r][s][3]);
-          if constexpr (FLAGS) {
-            g2_expand4<true>(w0, (uint32_t)(r + 1), kb, AB[r][s][0], AB[r][s][1]);
-            g2_expand4<true>(w1, (uint32_t)(r + 1), kb, AB[r][s][2], AB[r][s][3]);
-          }
+          AM[r][s][0] = g2_bytemask<FLAGS>(w0, (uint32_t)(r + 1), kf);
+          AM[r][s][1] = g2_bytemask<FLAGS>(w1, (uint32_t)(r + 1), kf);
         }
       }
     }
-    if (first_graph) ((float4*)sT0)[tid] = t0v;
+    // (opaque copies: the compiler would otherwise form all 20 fragments once and keep them -- the 80 registers again)
+    auto frag_f = [&](int r, int s) {
+      uint32_t m0 = AM[r][s][0], m1 = AM[r][s][1];
+      G2_OPAQUE(m0);
+      G2_OPAQUE(m1);
+      return g2_mask_frag(m0, m1);
+    };
+    auto frag_b = [&](int r, int s) {
+      uint32_t m0 = FLAGS ? RB[FLAGS ? s : 0][0] : AM[r][s][0], m1 = FLAGS ? RB[FLAGS ? s : 0][1] : AM[r][s][1];
+      G2_OPAQUE(m0);
+      G2_OPAQUE(m1);
+      if constexpr (FLAGS) return g2_mask_frag(g2_bytemask<true>(m0, (uint32_t)(r + 1), kb), g2_bytemask<true>(m1, (uint32_t)(r + 1), kb));
+      else return g2_mask_frag(m0, m1);
+    };
     __syncthreads();                    // RM is dead from here on (its bytes are the backward's tiles)
     G2_STAMP(4);
 
     // B operand of the next conv layer ([W_0; ..; W_4; root] or the transposes, composed once per step by
     // k_g2_compose): requested a phase ahead, written to LDS by stage()
-    float4 wq[9];
-    auto wpre = [&](int l, int trans) {
+    // It travels global -> LDS directly (global_load_lds, 1 KB per wave instruction; no staging registers, no ds_write
+    // pass), requested as soon as the previous image is dead -- right behind the barrier that ends a layer's matrix work --
+    // and landed by the barrier in front of the next layer's (the waves drain their vector counter there anyway).
+    static_assert(G2_WIMG % 256 == 0, "an image is a whole number of 1 KB pieces");
+    auto wload = [&](int l, int trans) {
       const float4* src = (const float4*)(a.g2_w + (size_t)((l - 1) * 2 + trans) * G2_WIMG);
 #pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        const int i = tid + q * G2_THREADS;
-        wq[q] = (i < G2_WIMG / 4) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j < (G2_WIMG / 256 + G2_THREADS / 64 - 1) / (G2_THREADS / 64); ++j) {
+        const int c = wave + j * (G2_THREADS / 64);
+        if (c < G2_WIMG / 256) g2_glds16(src + c * 64, (float4*)sW2 + c * 64, lane);
       }
     };
-    auto stage = [&]() {
-#pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        const int i = tid + q * G2_THREADS;
-        if (i < G2_WIMG / 4) ((float4*)sW2)[i] = wq[q];
-      }
-    };
-    wpre(1, 0);
+    wload(1, 0);
     // epilogue of a forward layer: tanh, own rows -> LDS tile + h_l (this wave re-reads them in the backward),
     // bf16 terms -> exchange x (l < 3), centre rows -> readout
-    auto fwd_out = [&](int l, const f32x4 (&o)[2], float bias0, float bias1, float* XO) {
-      float* hrow = a.h[l] + (size_t)(nbs + row0 + 4 * kq) * 32 + li;                 // rows 4 kq + rr, feature li (+ 16)
+    //      -- of this wave's feature tile (output features 16 hf + li)
+    auto fwd_out = [&](int l, const f32x4& o, float bias, float* XO) {
+      const int nt = hf;
+      float* hrow = a.h[l] + (size_t)(nbs + row0 + 4 * kq) * 32 + li;                 // rows 4 kq + rr, feature 16 nt + li
       unsigned long long* exl = a.g2_ex + l * exs + ((size_t)g * 2 + side) * 4096 + (size_t)li * 128 + row0 + 4 * kq;
       float* xo = XO + 4 * kq * G2_XP + li;
       const uint32_t tg = tag16(l);
+      float v[4];
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        float v[4];
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const float tv = g2_tanh(o[nt][rr] + (nt ? bias1 : bias0));
-          const bool ok = row0 + 4 * kq + rr < n_own;
-          v[rr] = ok ? tv : 0.f;
-          xo[rr * G2_XP + 16 * nt] = v[rr];
-          if (TRAIN && ok) hrow[rr * 32 + 16 * nt] = v[rr];
-        }
-        if (l < 3) g2_publish4(exl + nt * 16 * 128, 0, v, tg);
-        if (bi == 0 && kq == 0) g2_pub_f32(fx + side * 128 + l * 32 + 16 * nt + li, v[0], tag0 + G2_FXTAG);
+      for (int rr = 0; rr < 4; ++rr) {
+        const float tv = g2_tanh(o[rr] + bias);
+        const bool ok = row0 + 4 * kq + rr < n_own;
+        v[rr] = ok ? tv : 0.f;
+        xo[rr * G2_XP + 16 * nt] = v[rr];
+        if (TRAIN && ok) hrow[rr * 32 + 16 * nt] = v[rr];
       }
+      if (l < 3) g2_publish4(exl + nt * 16 * 128, 0, v, tg);
+      if (bi == 0 && kq == 0) g2_pub_f32(fx + side * 128 + l * 32 + 16 * nt + li, v[0], tag0 + G2_FXTAG);
     };
 
     // ================================================================ layer 0: h0 = tanh([hist | onehot(label) | 1] @ T0)
@@ -478,10 +557,10 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
       for (int s = 0; s < G2_KS; ++s) {
 #pragma unroll
         for (int r = 0; r < G2_NR; ++r) {
-          const u32x4 af = {AF[r][s][0], AF[r][s][1], AF[r][s][2], AF[r][s][3]};
-          hacc[r] = g2_mfma_bf16(pfh[s], af, hacc[r]);
+          hacc[r] = g2_mfma_bf16(pfh[s], frag_f(r, s), hacc[r]);
         }
       }
+      // (both waves of the pair form the whole histogram and write the same values: no hand-off between them in layer 0)
       G2_STAMP(51);
       // lane (row li, kq): counts of labels 4 kq + rr -> the row's input vector [hist | onehot(own label) | 1]
 #pragma unroll
@@ -494,17 +573,14 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
         HI[li * G2_XP + RL + L] = 1.f;
       }
       IGMC_WAVE_SYNC();
-      f32x4 o[2];
-      o[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      o[1] = o[0];
+      f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float av = HI[li * G2_XP + 4 * j + kq];
-        o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sT0[(4 * j + kq) * 32 + li], o[0], 0, 0, 0);
-        o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sT0[(4 * j + kq) * 32 + 16 + li], o[1], 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(av, sT0[(4 * j + kq) * 32 + 16 * hf + li], o, 0, 0, 0);
       }
       G2_STAMP(52);
-      fwd_out(0, o, 0.f, 0.f, XO0);
+      fwd_out(0, o, 0.f, XO0);
     }
     G2_STAMP(5);
 
@@ -513,60 +589,77 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
     for (int l = 1; l < 4; ++l) {
       float* XOc = (l & 1) ? XO0 : XO1;             // x of the bundle's own rows (h_{l-1})
       float* XOn = (l & 1) ? XO1 : XO0;             // h_l
-      stage();
       G2_STAMP(6 + 3 * (l - 1));
-      const float bias0 = P[a.off_bias[l] + li], bias1 = P[a.off_bias[l] + 16 + li];
-      // the opposite side's h_{l-1} as bf16 planes
-      for (int s2 = 0; s2 < nsides; ++s2) {
-        const int sd = (nsides == 2) ? s2 : 1 - side;
-        const int n_sd = sd ? cv : cu;
-        g2_reload(PLN + s2 * (G2_NT * 32 * kp >> 1), kp, a.g2_ex + (l - 1) * exs + ((size_t)g * 2 + sd) * 4096,
-                  ((n_sd + 15) >> 4) << 4, tag16(l - 1), a.gs_err);
+      const float bias0 = P[a.off_bias[l] + 16 * hf + li];
+      // the opposite side's h_{l-1} as bf16 planes; the layer's weight image is requested behind the exchange words'
+      // first requests (the previous image died at the previous layer's barrier) and lands while they are polled
+      if (nsides == 1) {
+        G2Poll pq;
+        const unsigned long long* exr = a.g2_ex + (l - 1) * exs + ((size_t)g * 2 + (1 - side)) * 4096;
+        const int npad = ((n_opp + 15) >> 4) << 4;
+        g2_poll_issue(pq, exr, npad);
+        if (l > 1) wload(l, 0);
+        g2_poll_finish(pq, PLN, kp, exr, npad, tag16(l - 1), a.gs_err);
+      } else {
+        if (l > 1) wload(l, 0);
+        for (int s2 = 0; s2 < nsides; ++s2) {
+          const int n_sd = s2 ? cv : cu;
+          g2_reload(PLN + s2 * (G2_NT * 32 * kp >> 1), kp, a.g2_ex + (l - 1) * exs + ((size_t)g * 2 + s2) * 4096,
+                    ((n_sd + 15) >> 4) << 4, tag16(l - 1), a.gs_err);
+        }
       }
       __syncthreads();
       G2_STAMP(7 + 3 * (l - 1));
-      float bias0_ = bias0, bias1_ = bias1;       // landed: no wait for them is left inside the epilogue (a wait there
+      float bias0_ = bias0;                       // landed: no wait for it is left inside the epilogue (a wait there
       G2_OPAQUE(bias0_);                          // would also drain the epilogue's own stores, one round trip each)
-      G2_OPAQUE(bias1_);
-      if (l < 3) wpre(l + 1, 0);
+      f32x4 o[2];
       if (active) {
         int lane_ = lane;
         G2_OPAQUE(lane_);
         const int li_ = lane_ & 15, kq_ = lane_ >> 4;
-        f32x4 acc[G2_NR][2];
-        g2_gather(pl, kp, nks, AF, li_, kq_, acc);
+        f32x4 acc[G2_NR];
+        g2_gather_h(pl, kp, nks, frag_f, li_, kq_, hf, acc);
         if (l == 2) G2_STAMP(40);
-        f32x4 o[2];
-        g2_transform(acc, XOc, (const uint32_t*)sW2, li_, kq_, o);
+        g2_transform_h(acc, XOc, (const uint32_t*)sW2, li_, kq_, hf, o);
         if (l == 2) G2_STAMP(41);
-        fwd_out(l, o, bias0_, bias1_, XOn);
+        *PXo = hf ? o[0] : o[1];                    // the partner's tile: this wave's half of its K
+      }
+      __syncthreads();                              // the pair's partials are exchanged (planes / sW2 are dead as well)
+      if (l == 2) G2_STAMP(42);
+      if (active) {
+        const f32x4 po = *PXi;
+        f32x4 of;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) of[rr] = hf ? po[rr] + o[1][rr] : o[0][rr] + po[rr];      // (K half 0 + K half 1)
+        fwd_out(l, of, bias0_, XOn);
       }
       G2_STAMP(36 + (l - 1));
-      __syncthreads();                              // planes / sW2 may be overwritten
+      // (no barrier here: planes / sW2 were dead at the barrier above; the pair's two halves of h_l in XOn and the reuse of
+      //  PX are ordered by the next phase's barrier -- behind the next layer's reload, or the readout poll)
       G2_STAMP(8 + 3 * (l - 1));
     }
 
     // ================================================================ head: lin1 / ReLU / dropout / lin2 / residual
-    sfeat[tid] = g2_poll_f32(fx + tid, tag0 + G2_FXTAG, a.gs_err);
+    if (tid < 256) sfeat[tid] = g2_poll_f32(fx + tid, tag0 + G2_FXTAG, a.gs_err);
     __syncthreads();
     G2_STAMP(15);
     {
-      // lin1 (256 -> 128): wave w takes hidden units 32 w .. 32 w + 31.  One weight row (1 KB, 8 cache lines) per load
-      // instruction, lane = 4 consecutive fan-in columns; the 32 per-lane partial dot products are then reduced over the
-      // 64 lanes by a transposing butterfly (each step halves the values a lane holds): lanes 2 j, 2 j + 1 end up with
-      // unit 32 w + j.  (A lane per row-half -- 64 cache lines per load instruction -- kept the head at ~10 k cycles.)
-      const int ju = tid >> 1, part = tid & 1;         // hidden unit of this lane pair after the reduction
+      // lin1 (256 -> 128): wave w takes hidden units 16 w .. 16 w + 15.  One weight row (1 KB, 8 cache lines) per load
+      // instruction, lane = 4 consecutive fan-in columns; the 16 per-lane partial dot products are then reduced over the
+      // 64 lanes by a transposing butterfly (each step halves the values a lane holds) over lane bits 4..1 and two plain
+      // steps over bits 0 and 5: lanes with (lane >> 1 & 15) = j end up with unit 16 w + j.  (A lane per row-half -- 64
+      // cache lines per load instruction -- kept the head at ~10 k cycles.)
+      const int ju = 16 * wave + ((lane >> 1) & 15), part = (lane & 1) | (lane >> 5);     // hidden unit of this lane; part 0 stores
       const float4 f4 = *(const float4*)(sfeat + 4 * lane);
-      const float* wrow = P + a.off_l1w + (int64_t)(32 * wave) * 256 + 4 * lane;
-      float v[32];
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {       // two batches of 16 rows: all 16 requests leave before the first use
+      const float* wrow = P + a.off_l1w + (int64_t)(16 * wave) * 256 + 4 * lane;
+      float v[16];
+      {                                      // 16 rows: all 16 requests leave before the first use
         float4 w4[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) w4[q] = *(const float4*)(wrow + (16 * hh + q) * 256);
+        for (int q = 0; q < 16; ++q) w4[q] = *(const float4*)(wrow + q * 256);
         G2_SCHED_BARRIER();
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[16 * hh + q] = (w4[q].x * f4.x + w4[q].y * f4.y) + (w4[q].z * f4.z + w4[q].w * f4.w);
+        for (int q = 0; q < 16; ++q) v[q] = (w4[q].x * f4.x + w4[q].y * f4.y) + (w4[q].z * f4.z + w4[q].w * f4.w);
         G2_SCHED_BARRIER();
       }
       // (one literal stage per halving: a loop over the stages is not unrolled and turns v[] into select chains)
@@ -578,9 +671,10 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
           v[i] = keep + __shfl_xor(send, 2 * (H));                                   \
         }                                                                            \
       }
-      G2_BFLY(16) G2_BFLY(8) G2_BFLY(4) G2_BFLY(2) G2_BFLY(1)
+      G2_BFLY(8) G2_BFLY(4) G2_BFLY(2) G2_BFLY(1)
 #undef G2_BFLY
-      const float s = v[0] + __shfl_xor(v[0], 1);
+      float s = v[0] + __shfl_xor(v[0], 1);
+      s += __shfl_xor(s, 32);
       G2_STAMP(54);
       if (part == 0) {
         float av = s + P[a.off_l1b + ju];
@@ -627,13 +721,13 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
         sdz[tid] = dzv;
         if (cm == 0) a.dz[g * 128 + tid] = dzv;
       }
-      if (cm == 0) a.feat[(size_t)g * a.D + tid] = sfeat[tid];
+      if (cm == 0 && tid < 256) a.feat[(size_t)g * a.D + tid] = sfeat[tid];
       __syncthreads();
-      {   // d feat = dz @ lin1.weight: wave w takes hidden units 32 w .. 32 w + 31, lane -> 4 fan-in columns; rows with
+      {   // d feat = dz @ lin1.weight: wave w takes hidden units 16 w .. 16 w + 15, lane -> 4 fan-in columns; rows with
           // dz == 0 (ReLU / dropout: ~3/4 of them) are skipped wave-uniformly
         const float* w1 = P + a.off_l1w + 4 * lane;
         float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        unsigned long long nz = __ballot(lane < 32 && sdz[32 * wave + (lane & 31)] != 0.f);
+        unsigned long long nz = __ballot(lane < 16 && sdz[16 * wave + (lane & 15)] != 0.f);
         while (nz) {
           int q[8];
           float4 wv[8];
@@ -641,19 +735,21 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
           for (int u = 0; u < 8; ++u) {
             q[u] = nz ? (int)__builtin_ctzll(nz) : -1;
             if (nz) nz &= nz - 1;
-            wv[u] = (q[u] >= 0) ? *(const float4*)(w1 + (int64_t)(32 * wave + q[u]) * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
+            wv[u] = (q[u] >= 0) ? *(const float4*)(w1 + (int64_t)(16 * wave + q[u]) * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
           }
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            const float dzv = (q[u] >= 0) ? sdz[32 * wave + q[u]] : 0.f;
+            const float dzv = (q[u] >= 0) ? sdz[16 * wave + q[u]] : 0.f;
             s4.x += dzv * wv[u].x; s4.y += dzv * wv[u].y; s4.z += dzv * wv[u].z; s4.w += dzv * wv[u].w;
           }
         }
         *(float4*)(TILES + wave * 256 + 4 * lane) = s4;
       }
+      wload(3, 1);            // the first backward layer's image: lands under the dPre_3 set-up and the first backward gather
       __syncthreads();
-      {
-        const float v = (TILES[tid] + TILES[256 + tid]) + (TILES[512 + tid] + TILES[768 + tid]);
+      if (tid < 256) {
+        const float v = ((TILES[tid] + TILES[256 + tid]) + (TILES[512 + tid] + TILES[768 + tid])) +
+                        ((TILES[1024 + tid] + TILES[1280 + tid]) + (TILES[1536 + tid] + TILES[1792 + tid]));
         sgf[tid] = v;
         if (cm == 0) a.gfeat[(size_t)g * a.D + tid] = v;
       }
@@ -682,7 +778,6 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
         const float hv = sfeat[side * 128 + 96 + lane];
         XO0[lane] = sgf[side * 128 + 96 + lane] * (1.f - hv * hv);
       }
-      wpre(3, 1);
       __syncthreads();
       G2_STAMP(18);
 
@@ -691,13 +786,12 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
       for (int l = 3; l >= 1; --l) {
         float* XOc = (l & 1) ? XO0 : XO1;            // dPre_l of the bundle's own rows
         float* XOn = (l & 1) ? XO1 : XO0;            // dPre_{l-1}
-        stage();
         float* wpart = a.ts_part + ((size_t)l * IGMC_TS_BLOCKS + tslot) * ts;
         {   // d bias_l = column sums of dPre_l over this workgroup's rows (fixed order)
           const int n = tid & 31, part = tid >> 5;
           float sb = 0.f;
-          for (int row = part; row < G2_NW * 16; row += G2_THREADS / 32)
-            sb += XOA[(((l & 1) ? 0 : G2_NW) + (row >> 4)) * 16 * G2_XP + (row & 15) * G2_XP + n];
+          for (int row = part; row < G2_NB * 16; row += G2_THREADS / 32)
+            sb += XOA[(((l & 1) ? 0 : G2_NB) + (row >> 4)) * 16 * G2_XP + (row & 15) * G2_XP + n];
           sred[part * 32 + n] = sb;
         }
         __syncthreads();
@@ -708,123 +802,124 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
           else wpart[(R * 32 + 32) * 32 + tid] += s;
         }
         G2_STAMP(19 + 5 * (3 - l));
-        float hreg[2][4];
+        float hreg[4];                               // h_{l-1}: rows 4 kq + rr, feature 16 hf + li
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) hreg[nt][rr] = 0.f;
+        for (int rr = 0; rr < 4; ++rr) hreg[rr] = 0.f;
+        f32x4 o[2];
+        unsigned long long* exb = a.g2_ex + (6 - l) * exs + ((size_t)g * 2 + side) * 4096 + (size_t)li * 128 + row0 + 4 * kq;
+        const uint32_t tgb = tag16(6 - l);
         if (active) {
           // h_{l-1} of the bundle's rows (written by this very wave in the forward): tanh' and the table product
           {
-            const float* hrow = a.h[l - 1] + (size_t)(nbs + row0 + 4 * kq) * 32 + li;
+            const float* hrow = a.h[l - 1] + (size_t)(nbs + row0 + 4 * kq) * 32 + 16 * hf + li;
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-              for (int rr = 0; rr < 4; ++rr)
-                if (row0 + 4 * kq + rr < n_own) hreg[nt][rr] = hrow[rr * 32 + 16 * nt];
+            for (int rr = 0; rr < 4; ++rr)
+              if (row0 + 4 * kq + rr < n_own) hreg[rr] = hrow[rr * 32];
           }
           int lane_ = lane;
           G2_OPAQUE(lane_);
           const int li_ = lane_ & 15, kq_ = lane_ >> 4;
-          f32x4 acc[G2_NR][2];
+          f32x4 acc[G2_NR];
           if (l == 2) G2_STAMP(43);
-          if constexpr (FLAGS) g2_gather(pl, kp, (l == 3) ? 1 : nks, AB, li_, kq_, acc);
-          else g2_gather(pl, kp, (l == 3) ? 1 : nks, AF, li_, kq_, acc);
+          g2_gather_h(pl, kp, (l == 3) ? 1 : nks, frag_b, li_, kq_, hf, acc);
           if (l == 2) G2_STAMP(44);
-          // T' rows of the bundle -> LDS (B operand of the weight-gradient table): lane = row, 4 consecutive features
+          // T' rows of the bundle -> LDS (B operand of the weight-gradient table): lane = row, 4 consecutive features of
+          // this wave's tile
 #pragma unroll
           for (int r = 0; r < G2_NR; ++r)
+            *(float4*)(T + li * G2_TP + r * 32 + 16 * hf + 4 * kq) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-              *(float4*)(T + li * G2_TP + r * 32 + 16 * t + 4 * kq) = make_float4(acc[r][t][0], acc[r][t][1], acc[r][t][2], acc[r][t][3]);
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) HS[(4 * kq + rr) * G2_XP + 16 * nt + li] = hreg[nt][rr];
-          // dX = [T' | dPre_l] @ [W_r^T ; root^T], + readout gradient on the centre row, * tanh'(h_{l-1})
-          f32x4 o[2];
-          unsigned long long* exb = a.g2_ex + (6 - l) * exs + ((size_t)g * 2 + side) * 4096 + (size_t)li * 128 + row0 + 4 * kq;
-          const uint32_t tgb = tag16(6 - l);
+          for (int rr = 0; rr < 4; ++rr) HS[(4 * kq + rr) * G2_XP + 16 * hf + li] = hreg[rr];
+          // dX = [T' | dPre_l] @ [W_r^T ; root^T]: this wave's half of K, both output tiles
           if (l == 2) G2_STAMP(45);
-          g2_transform(acc, XOc, (const uint32_t*)sW2, li_, kq_, o);
+          g2_transform_h(acc, XOc, (const uint32_t*)sW2, li_, kq_, hf, o);
           if (l == 2) G2_STAMP(46);
+          *PXo = hf ? o[0] : o[1];
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            const int f = 16 * nt + li;
-            float v[4];
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-              const int row = 4 * kq + rr;
-              float d = o[nt][rr];
-              if (bi == 0 && row == 0) d += sgf[side * 128 + (l - 1) * 32 + f];
-              const float x = hreg[nt][rr];
-              v[rr] = (row0 + row < n_own) ? d * (1.f - x * x) : 0.f;
-              XOn[row * G2_XP + f] = v[rr];
-            }
-            if (l > 1) g2_publish4(exb + nt * 16 * 128, 0, v, tgb);
-          }
-        } else {
-          // idle wave: its tile / h rows are K entries of the workgroup's table product
+          for (int rr = 0; rr < 4; ++rr) G2_OPAQUE(hreg[rr]);      // landed here: behind the image request below a wait for
+                                                                   // them would wait for the whole image as well
+        } else if (hf == 0) {
+          // idle bundle: its tile / h rows are K entries of the workgroup's table product
           for (int i = lane; i < 16 * G2_TP; i += 64) T[i] = 0.f;
           for (int i = lane; i < 16 * G2_XP; i += 64) HS[i] = 0.f;
         }
+        __syncthreads();                             // the pair's partials are exchanged; tiles / h chunks complete
+        if (l == 2) G2_STAMP(47);
+        if (active) {
+          // + readout gradient on the centre row, * tanh'(h_{l-1}): output features 16 hf + li of rows 4 kq + rr
+          const f32x4 po = *PXi;
+          const int f = 16 * hf + li;
+          float v[4];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int row = 4 * kq + rr;
+            float d = hf ? po[rr] + o[1][rr] : o[0][rr] + po[rr];
+            if (bi == 0 && row == 0) d += sgf[side * 128 + (l - 1) * 32 + f];
+            const float x = hreg[rr];
+            v[rr] = (row0 + row < n_own) ? d * (1.f - x * x) : 0.f;
+            XOn[row * G2_XP + f] = v[rr];
+          }
+          if (l > 1) g2_publish4(exb + hf * 16 * 128, 0, v, tgb);
+        }
         G2_STAMP(20 + 5 * (3 - l));
-        __syncthreads();                             // the four tiles / h chunks / dPre tiles of the workgroup are complete
+        // (no barrier: the table product reads T' / h_{l-1} / dPre_l, complete at the barrier above; the dPre_{l-1} halves
+        //  just written are ordered by the barrier at the end of the layer)
         G2_STAMP(21 + 5 * (3 - l));
+        if (l > 1) wload(l - 1, 1);                  // next image: lands under the table product (LDS + matrix work only)
         G2Poll pq;
         const int npad_opp = ((n_opp + 15) >> 4) << 4;
         {
-          // weight-gradient table h_{l-1}^T [T' | dPre_l], split by OUTPUT tile: wave w computes 6 of the 2 x 12 tiles
+          // weight-gradient table h_{l-1}^T [T' | dPre_l], split by OUTPUT tile: wave w computes 3 of the 2 x 12 tiles
           // (row half m2 = in-features, column tile nt: 0..9 = T' of relation nt >> 1, 10..11 = dPre -> d root) over
           // K = the 64 rows of the workgroup's four bundles -- no cross-wave reduction
-          f32x4 w6[6];
+          f32x4 w3[3];
 #pragma unroll
-          for (int i6 = 0; i6 < 6; ++i6) w6[i6] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          const int m2w = wave >> 1, wo = wave & 1;
+          for (int i3 = 0; i3 < 3; ++i3) w3[i3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          const int m2w = wave >> 2, wo = wave & 3;       // tiles 3 wo .. 3 wo + 2 of the row half
 #pragma unroll 1
-          for (int wb = 0; wb < G2_NW; ++wb) {
+          for (int wb = 0; wb < G2_NB; ++wb) {
             // the exchange of dPre_{l-1} runs UNDER the table product: its words are requested half way through (the
             // other members published them before their own barrier) and consumed after it
             if (wb == 2 && l > 1 && nsides == 1) g2_poll_issue(pq, a.g2_ex + (6 - l) * exs + ((size_t)g * 2 + (1 - side)) * 4096, npad_opp);
             const float* Tb = TILES + wb * 16 * G2_TP;
             const float* Hb = HSS + wb * 16 * G2_XP;
-            const float* Db = XOA + (((l & 1) ? 0 : G2_NW) + wb) * 16 * G2_XP;
-            float av[4], bw[4][6];
+            const float* Db = XOA + (((l & 1) ? 0 : G2_NB) + wb) * 16 * G2_XP;
+            float av[4], bw3[4][3];
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
               av[s4] = Hb[(4 * s4 + kq) * G2_XP + m2w * 16 + li];
               const float* tb = Tb + (4 * s4 + kq) * G2_TP + li;
+              const float* db = Db + (4 * s4 + kq) * G2_XP + li;
 #pragma unroll
-              for (int i6 = 0; i6 < 4; ++i6) bw[s4][i6] = tb[(wo * 6 + i6) * 16];
-              const float* pr = wo ? Db + (4 * s4 + kq) * G2_XP + li : tb + 64;     // column tiles 10, 11 (odd waves) / 4, 5
-              bw[s4][4] = pr[0];
-              bw[s4][5] = pr[16];
+              for (int i3 = 0; i3 < 3; ++i3) {
+                const int nt = 3 * wo + i3;              // (wave-uniform: column tiles 10, 11 come from the dPre tile)
+                bw3[s4][i3] = (nt < 2 * G2_NR) ? tb[nt * 16] : db[(nt - 2 * G2_NR) * 16];
+              }
             }
             G2_SCHED_BARRIER();
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-              for (int i6 = 0; i6 < 6; ++i6)
-                w6[i6] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bw[s4][i6], w6[i6], 0, 0, 0);
+              for (int i3 = 0; i3 < 3; ++i3)
+                w3[i3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bw3[s4][i3], w3[i3], 0, 0, 0);
           }
 #pragma unroll
-          for (int i6 = 0; i6 < 6; ++i6) {
-            const int tt = wave * 6 + i6, m2 = tt / 12, nt = tt % 12;
+          for (int i3 = 0; i3 < 3; ++i3) {
+            const int m2 = m2w, nt = 3 * wo + i3;
             const int r = nt >> 1;                      // 32-column block: relation, or G2_NR = root
             if (r >= R && r < G2_NR) continue;
             float* pp = wpart + (kq * 4) * 32 + li + (r < R ? r : R) * 1024 + m2 * 512 + (nt & 1) * 16;
             if (first_graph) {
 #pragma unroll
-              for (int rr = 0; rr < 4; ++rr) pp[rr * 32] = w6[i6][rr];
+              for (int rr = 0; rr < 4; ++rr) pp[rr * 32] = w3[i3][rr];
             } else {
 #pragma unroll
-              for (int rr = 0; rr < 4; ++rr) pp[rr * 32] += w6[i6][rr];
+              for (int rr = 0; rr < 4; ++rr) pp[rr * 32] += w3[i3][rr];
             }
           }
         }
         G2_STAMP(22 + 5 * (3 - l));
         if (l > 1) {
-          wpre(l - 1, 1);
           if (nsides == 1) {
             g2_poll_finish(pq, PLN, kp, a.g2_ex + (6 - l) * exs + ((size_t)g * 2 + (1 - side)) * 4096, npad_opp, tag16(6 - l), a.gs_err);
           } else {
@@ -841,11 +936,11 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
 
       // ============================================================== layer-0 table gradient (dPre_0 is in XO1)
       // T0'[c][f] = sum_i [hist | onehot | 1](i, c) dPre_0[i][f] over this workgroup's rows; wave = (code half, feature half)
-      {
+      if (wave < 4) {
         const int m2 = wave >> 1, wn = wave & 1;
-        for (int wb = 0; wb < G2_NW; ++wb) {
+        for (int wb = 0; wb < G2_NB; ++wb) {
           const float* Hb = HIST + wb * 16 * G2_XP;
-          const float* Db = XOA + (G2_NW + wb) * 16 * G2_XP;
+          const float* Db = XOA + (G2_NB + wb) * 16 * G2_XP;
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4)
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Hb[(4 * s4 + kq) * G2_XP + m2 * 16 + li],
@@ -858,7 +953,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
     }
   }
 
-  if (TRAIN) {
+  if (TRAIN && wave < 4) {
     float* part0 = a.ts_part + (size_t)tslot * ts;             // slice 0 of [4][IGMC_TS_BLOCKS][ts]
     const int m2 = wave >> 1, wn = wave & 1;
 #pragma unroll
@@ -907,7 +1002,7 @@ extern "C" int igmc_debug_g2_clocks(unsigned long long* out, int n) {
 // (element (k, n) at [k][n & 15].{x: n < 16, y: n >= 16}, rows padded to G2_WP float2) and of the backward (their
 // transposes), and the layer-0 table [W0[r*L + c] | root0[c] | bias0].  37 small workgroups: the launch is as long as one
 // round trip to the weights plus three 8-byte stores per thread.
-__global__ __launch_bounds__(G2_THREADS) void k_g2_compose(ModelDev m, const float* P, float* w) {
+__global__ __launch_bounds__(G2C_THREADS) void k_g2_compose(ModelDev m, const float* P, float* w) {
   __shared__ float s_att[4 * G2_NR * G2_NG_MAX];
   const int tid = threadIdx.x, R = m.R, L = m.L, RL = R * L, LF = L * 32;
   // blockIdx.x: 2 * (3 layers x relation groups x 6 matrices) image blocks (bit 0 = transposed), then the layer-0 table blocks
@@ -923,7 +1018,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_compose(ModelDev m, const flo
     float bv[4][4], rv[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int i = tid + q * G2_THREADS, c = c0 + (i >> 5), f = i & 31;
+      const int i = tid + q * G2C_THREADS, c = c0 + (i >> 5), f = i & 31;
       const int cf = (c < RL) ? (c % L) * 32 + f : 0;
 #pragma unroll
       for (int bb = 0; bb < 4; ++bb) bv[q][bb] = (c < RL) ? P[m.off_basis[0] + bb * LF + cf] : 0.f;
@@ -933,7 +1028,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_g2_compose(ModelDev m, const flo
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int i = tid + q * G2_THREADS, c = c0 + (i >> 5);
+      const int i = tid + q * G2C_THREADS, c = c0 + (i >> 5);
       float sacc = rv[q];
       if (c < RL) {
         const int r = c / L;
@@ -1042,18 +1137,20 @@ int igmc_g2_layout(const ModelDev& m, const BatchDev& b, int cs, G2Layout* lay) 
   lay->planes = o; o += lay->nsides * (G2_NT * 32 * lay->kp >> 1);
   lay->ohp = o; o += lay->nsides * (8 * lay->kp >> 1);
   lay->lab = o; o += 64;
-  lay->xo = o; o += 2 * G2_NW * 16 * G2_XP;
-  lay->hs = o; o += G2_NW * 16 * G2_XP;
-  int tw = G2_NW * 16 * G2_TP;
+  lay->xo = o; o += 2 * G2_NB * 16 * G2_XP;
+  lay->hs = o; o += G2_NB * 16 * G2_XP;
+  int tw = G2_NB * 16 * G2_TP;
+  if (tw < (G2_THREADS / 64) * 256) tw = (G2_THREADS / 64) * 256;      // (d feat partials of the eight waves)
   const int rw = 2 * lay->rmr * (lay->rmc + 8) / 4;
   if (rw > tw) tw = rw;
   if (tw < 1024) tw = 1024;
   lay->tile = o; o += tw;
-  lay->hist = o; o += G2_NW * 16 * G2_XP;
+  lay->hist = o; o += G2_NB * 16 * G2_XP;
+  lay->px = o; o += G2_NB * 2 * 64 * 4;
   lay->wreg = o; o += G2_WIMG;
   lay->t0 = o; o += 1024;
   lay->att = o; o += 64;
-  lay->head = o; o += 256 + 256 + 3 * 128 + 256 + 16;
+  lay->head = o; o += 256 + 256 + 3 * 128 + 512 + 16;
   lay->words = o;
   return (size_t)o * 4 <= 160 * 1024;
 }
@@ -1104,7 +1201,7 @@ int igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* P
   const int grid = (cs > 1) ? cs * B : igmc_gs_grid(B);
   const size_t sm = (size_t)lay.words * 4;
   if (!m.img_current) {
-    IGMC_PLAUNCH("k_g2_compose", k_g2_compose, 2 * 3 * g2_groups(m.R, m.L) * (G2_NR + 1) + g2_t0_rows(m.R, m.L) / 32, G2_THREADS, 0, stream, m, P, m.g2_w);
+    IGMC_PLAUNCH("k_g2_compose", k_g2_compose, 2 * 3 * g2_groups(m.R, m.L) * (G2_NR + 1) + g2_t0_rows(m.R, m.L) / 32, G2C_THREADS, 0, stream, m, P, m.g2_w);
     ++g_igmc_compose_count;
   }
 #ifdef IGMC_HIPEMU
@@ -2672,7 +2769,7 @@ int igmc_dl_grid(const BatchDev& b, int B) {
 void igmc_launch_g2_compose(const ModelDev& m, const float* P, void* stream) {
   if (m.img_current) return;      // (igmc_model_weights_unchanged: the images of these parameters are in place)
   ++g_igmc_compose_count;
-  IGMC_PLAUNCH("k_g2_compose", k_g2_compose, 2 * 3 * g2_groups(m.R, m.L) * (G2_NR + 1) + g2_t0_rows(m.R, m.L) / 32, G2_THREADS, 0, stream, m, P, m.g2_w);
+  IGMC_PLAUNCH("k_g2_compose", k_g2_compose, 2 * 3 * g2_groups(m.R, m.L) * (G2_NR + 1) + g2_t0_rows(m.R, m.L) / 32, G2C_THREADS, 0, stream, m, P, m.g2_w);
 }
 
 // one conv layer pass: forward (bwd = 0: h_{l-1} -> h_l) or backward (dPre_l -> dPre_{l-1}, G, d att partials)

@@ -96,9 +96,9 @@ def fine(c):
     print('set-up (member 0): loop start -> loads issued %d | zero fills %d | label store %d | barrier %d' % (
         c[48] - c[1], c[49] - c[48], c[50] - c[49], c[2] - c[50]))
     print('layer 0: hist MFMAs %d | tile + transform %d | epilogue %d' % (c[51] - c[4], c[52] - c[51], c[5] - c[52]))
-    print('L2 fwd wave 0: gather %d | transform %d | epilogue %d' % (c[40] - c[10], c[41] - c[40], c[37] - c[41]))
-    print('B2 wave 0: h loads issued %d | gather %d | tile + HS writes %d | transform %d | epilogue %d' % (
-        c[43] - c[24], c[44] - c[43], c[45] - c[44], c[46] - c[45], c[25] - c[46]))
+    print('L2 fwd wave 0: gather %d | transform %d | pair barrier %d | epilogue %d' % (c[40] - c[10], c[41] - c[40], c[42] - c[41], c[37] - c[42]))
+    print('B2 wave 0: h loads issued %d | gather %d | tile + HS writes %d | transform %d | pair barrier %d | epilogue %d' % (
+        c[43] - c[24], c[44] - c[43], c[45] - c[44], c[46] - c[45], c[47] - c[46], c[25] - c[47]))
     print('head: readout -> lin1 dot done %d | rest of head forward %d' % (c[54] - c[15], c[16] - c[54]))
 
 
