@@ -748,6 +748,8 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   if (d.R <= 128) fail |= M.get(&d.fin_stash, (size_t)4 * IGMC_STASH_LAYER + 16);     // weights-only stash of k_finalize_ts (both modes)
   d.g2_ex = nullptr;
   d.g2_fx = nullptr;
+  d.g2_px = nullptr;
+  d.g2_px_stride = 0;
   d.g2_w = nullptr;
   d.g2_graphs = 0;
   // exchange regions [32 features][256 nodes a side] of the one-launch dense layers (k_dl_fwd / k_dl_bwd); the subgraph
@@ -758,6 +760,11 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   if (wide && Bc <= 2048) {
     fail |= M.get(&d.g2_ex, 5 * d.g2_ex_stride) | M.get(&d.g2_fx, Bc * 256) | M.get(&d.g2_w, g2_w_words(d.R, d.L));
     d.g2_graphs = (int)Bc;
+    // the subgraph kernel's plane exchange (R <= 5): 320 KB per subgraph slot
+    if (d.R <= G2_NR && Bc <= 1024) {
+      d.g2_px_stride = (size_t)Bc * 2 * 32768;
+      fail |= M.get(&d.g2_px, 5 * d.g2_px_stride);
+    }
   } else if (wide) {
     fail |= M.get(&d.g2_w, g2_w_words(d.R, d.L));      // weight images alone: the dense per-layer kernels (any head)
   }
@@ -802,6 +809,7 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   if (m->d.g2_ex) {
     HIPCHECK(hipMemset(m->d.g2_ex, 0, 5 * m->d.g2_ex_stride * sizeof(unsigned long long)));
     HIPCHECK(hipMemset(m->d.g2_fx, 0, (size_t)max_graphs * 256 * sizeof(unsigned long long)));
+    if (m->d.g2_px) HIPCHECK(hipMemset(m->d.g2_px, 0, 5 * m->d.g2_px_stride));      // flags 0 (never a launch's tag), planes finite
   }
   if (igmc_model_prepare(d)) {
     M.release();

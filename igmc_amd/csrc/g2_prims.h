@@ -12,7 +12,7 @@
   do {                                                                                                     \
     if (a.timing && threadIdx.x == 0) {                                                                    \
       if (blockIdx.x == 0) g_g2_clk[k] = __builtin_readcyclecounter();                                     \
-      else if (a.cs > 2 && (int)blockIdx.x == 2 && (k) < 40) g_g2_clk[64 + (k)] = __builtin_readcyclecounter(); \
+      else if (a.cs > 2 && (int)blockIdx.x == 8 * (a.cs / 2) && (k) < 40) g_g2_clk[64 + (k)] = __builtin_readcyclecounter(); \
     }                                                                                                      \
   } while (0)
 #endif
@@ -104,10 +104,11 @@ __device__ __forceinline__ float g2_tanh(float x) {
 // 16 bytes per lane, global -> LDS, without passing through registers (global_load_lds_dwordx4): the destination is the
 // WAVE-UNIFORM base + 16 * lane, the source address is per lane.  Asynchronous: a pending one counts on the vector
 // counter; the barrier (or wait) in front of the first read of the destination retires it.
+template <int AUX = 0>          // 16 = sc1: past the CU's L1 (data another CU of the XCD has just written)
 __device__ __forceinline__ void g2_glds16(const float4* src_wave, float4* lds_wave, int lane) {
 #ifndef IGMC_HIPEMU
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_wave + lane),
-                                   (__attribute__((address_space(3))) void*)lds_wave, 16, 0, 0);
+                                   (__attribute__((address_space(3))) void*)lds_wave, 16, 0, AUX);
 #else
   lds_wave[lane] = src_wave[lane];
 #endif
@@ -142,6 +143,63 @@ __device__ __forceinline__ void g2_pub_f32(unsigned long long* p, float v, uint3
   memcpy(&bits, &v, 4);
   *p = ((unsigned long long)tag << 32) | (unsigned long long)bits;
 #endif
+}
+
+// ---- plane exchange of the subgraph kernel (k_graph_step2) ------------------------------------------------------------
+// The members of a cluster sit on ONE XCD (graphstep2.hip: workgroup -> (subgraph, member)), so the rows they exchange can
+// stay in that XCD's L2: the producer writes bf16 term planes [term][feature][node] -- the very image the gather reads from
+// LDS -- with ORDINARY stores (acknowledged by the L2 in ~120 ns; an sc1 store is written through to memory: ~430 ns, and a
+// bulk poll of lines under write-through took microseconds, profiles/r05_experiments/xcd_*.txt), waits for their
+// acknowledgement and raises ONE flag word per wave; a consumer wave polls the flags of the opposite side's bundles (sc1
+// loads: past the CU's L1, served by the shared L2) and then copies the planes global -> LDS directly (global_load_lds).
+// Region of one (exchange, subgraph, side): G2_PX_BYTES; planes at 0 (192 * kp bytes <= 26112), 64 flag words at G2_PX_FLAGS.
+#define G2_PX_BYTES 32768
+#define G2_PX_FLAGS 28672
+// the four rows node0 .. node0 + 3 (node0 % 4 == 0) of feature f: one 8-byte store per term
+__device__ __forceinline__ void g2_publish_planes(unsigned char* px, int kp, int f, int node0, const float (&v)[4]) {
+  uint32_t h0, m0, l0, h1, m1, l1;
+  g2_split2(v[0], v[1], h0, m0, l0);
+  g2_split2(v[2], v[3], h1, m1, l1);
+  unsigned char* p = px + ((size_t)f * kp + node0) * 2;
+  const size_t ts = (size_t)32 * kp * 2;
+  *(uint2*)p = make_uint2(h0, h1);
+  *(uint2*)(p + ts) = make_uint2(m0, m1);
+  *(uint2*)(p + 2 * ts) = make_uint2(l0, l1);
+}
+// every store of the wave so far is in the L2; then its flag
+__device__ __forceinline__ void g2_flag_raise(unsigned char* px, int slot, uint32_t tag, int lane) {
+#ifndef IGMC_HIPEMU
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_store((unsigned long long*)(px + G2_PX_FLAGS) + slot, (unsigned long long)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#else
+  if (lane == 0) ((unsigned long long*)(px + G2_PX_FLAGS))[slot] = (unsigned long long)tag;
+#endif
+}
+// the wave waits until the first n flags of the region carry this exchange's tag (lane i polls flag i)
+__device__ __forceinline__ void g2_flags_wait(const unsigned char* px, int n, uint32_t tag, int lane, int* err) {
+  const unsigned long long* fl = (const unsigned long long*)(px + G2_PX_FLAGS);
+  for (long it = 0;; ++it) {
+#ifndef IGMC_HIPEMU
+    const unsigned long long w = (lane < n) ? __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned long long)tag;
+#else
+    const unsigned long long w = (lane < n) ? fl[lane] : (unsigned long long)tag;
+#endif
+    if (__ballot(w != (unsigned long long)tag) == 0ull) break;
+    if (it > (1L << 20)) {
+      *err = 1;
+      break;
+    }
+#ifndef IGMC_HIPEMU
+    __builtin_amdgcn_s_sleep(1);
+#else
+    hipemu::yield();
+#endif
+  }
+}
+// planes of one side, global -> LDS, 1 KB pieces dealt to the waves of the workgroup (the LDS image is padded to whole pieces)
+__device__ __forceinline__ void g2_planes_load(uint32_t* pl, const unsigned char* px, int kp, int wave, int lane, int nwaves) {
+  const int pieces = (192 * kp + 1023) >> 10;
+  for (int c = wave; c < pieces; c += nwaves) g2_glds16<16>((const float4*)px + c * 64, (float4*)pl + c * 64, lane);
 }
 
 // The planes [term][feature][node] of one side from its exchange region ex[feature][KMAX nodes]: nodes < npad (a

@@ -245,9 +245,9 @@ struct G2Args {
   int R, L, D, ts_stride;
   float* h[4];
   float* ts_part;
-  unsigned long long* g2_ex;
+  unsigned char* g2_px;        // plane exchange regions [5 exchanges][graphs][2 sides][G2_PX_BYTES] (g2_prims.h)
   unsigned long long* g2_fx;
-  size_t g2_ex_stride;
+  size_t g2_px_stride;         // bytes per exchange
   const float* g2_w;
   int* gs_bar;
   int* gs_err;
@@ -308,14 +308,17 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
   // next -- a partly resident chip (another kernel holding CUs) slows the launch down but cannot leave every resident
   // member waiting for a non-resident one.  (Members need not share an XCD: sc1 words are served from the coherent
   // level wherever they were written.)  The bounded polls stay as the backstop.
-  const int cm = (cs > 1) ? (int)(blockIdx.x % cs) : 0;
+  // Workgroups are dealt to the eight XCDs round robin by index: the members c = 0 .. cs - 1 of cluster (j, x) are the
+  // workgroups 8 cs j + 8 c + x -- one XCD, one L2, which is where they exchange their rows (g2_prims.h); an XCD takes the
+  // members of its clusters one after the other, so the residency argument above holds per XCD.
+  const int cm = (cs > 1) ? (int)((blockIdx.x >> 3) % cs) : 0;
   const int half = 2 * cs;                              // waves of the cluster per side
   const int rmr = lay.rmr, rmc = lay.rmc, rmp = lay.rmc + 8;      // image rows, columns, row pitch (bytes)
   const uint32_t seq = g2_ld_seq(a.gs_bar);
   const uint32_t tag0 = seq * 8u + 1u;
   const uint64_t step = a.ctrl ? (uint64_t)a.ctrl[IGMC_CTRL_STEP] : a.step;
   if (a.ts && tid == 0) g2_clock_open(a.ts);
-  auto tag16 = [&](int x) { return 1u + (tag0 + (uint32_t)x) % 65535u; };
+  auto xtag = [&](int x) { return tag0 + (uint32_t)x; };      // flag value of exchange x of this launch (never 0)
   G2_STAMP(0);
   if (a.timing && tid == 0 && blockIdx.x < 1024) {
     g_g2_wg[blockIdx.x][0] = g2_wall_clock();
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
 
   // ---- the first subgraph's extents are requested before anything else (two dependent round trips overlap with
   //      the staging of the layer-0 table, which k_g2_compose formed from the current weights)
-  const int g_first = (cs > 1) ? (int)(blockIdx.x / cs) : (int)blockIdx.x;
+  const int g_first = (cs > 1) ? (int)(blockIdx.x / (8 * cs)) * 8 + (int)(blockIdx.x & 7) : (int)blockIdx.x;
   const int g_pre = (g_first < a.graph_cap) ? g_first : a.graph_cap - 1;      // (a padding workgroup: any valid slot)
   const int pre_cu = a.n_users[g_pre], pre_cv = a.n_items[g_pre];
   // ... and so are the set-up's global loads, which depend on the subgraph slot only (labels from the per-graph scratch
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
     const int row0 = 16 * bi;
     const int nks = (n_opp + 31) >> 5;
     const int sx = (nsides == 2) ? side : 0, so = (nsides == 2) ? 1 - side : 0;    // LDS images of own / opposite side
-    uint32_t* pl = PLN + so * (G2_NT * 32 * kp >> 1);
+    uint32_t* pl = PLN + so * lay.pside;
     uint32_t* ohp = OHP + so * (8 * kp >> 1);
     float* XO0 = XOA + bw * 16 * G2_XP;                       // ping
     float* XO1 = XOA + (G2_NB + bw) * 16 * G2_XP;             // pong
@@ -385,29 +388,19 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
     float* HI = HIST + bw * 16 * G2_XP;
     f32x4* PXo = (f32x4*)PXA + (bw * 2 + hf) * 64 + lane;           // this wave's partial of the PARTNER's tile
     const f32x4* PXi = (const f32x4*)PXA + (bw * 2 + (1 - hf)) * 64 + lane;    // the partner's partial of this wave's tile
-    // exchange regions of this subgraph: [exchange x][g][side][32 features][128 nodes]
-    unsigned long long* ex_own = a.g2_ex + ((size_t)g * 2 + side) * 4096;
-    const unsigned long long* ex_opp = a.g2_ex + ((size_t)g * 2 + (1 - side)) * 4096;
-    const size_t exs = a.g2_ex_stride;
+    // plane exchange regions of this subgraph: [exchange x][g][side]
+    const size_t exs = a.g2_px_stride;
+    auto px_of = [&](int x, int sd) { return a.g2_px + (size_t)x * exs + ((size_t)g * 2 + sd) * G2_PX_BYTES; };
     unsigned long long* fx = a.g2_fx + (size_t)g * 256;
+    const int nbun_opp = (n_opp + 15) >> 4;
 
-    // ---- every 4096 launches the owner of a node range clears it in all exchange buffers: a 16-bit tag then never
-    //      meets a word older than 4096 launches (tags repeat after 8191)
-    if ((seq & 4095u) == 0u) {
-      for (int bb2 = bi; bb2 < 8; bb2 += half)
-        for (int x = 0; x < 5; ++x) {
-          unsigned long long* e = a.g2_ex + x * exs + ((size_t)g * 2 + side) * 4096 + 16 * bb2;
-          for (int i = lane; i < 32 * 8; i += 64) g2_store16(e + (i >> 3) * 128 + 2 * (i & 7), 0u, 0u, 0u, 0u);
-        }
-      g2_wait_vm0();
-    }
     // ---- set-up: labels, relm in the orientation of this workgroup's side(s), one-hot label planes, zeroed planes.
     //      The global loads (one label per thread, <= 16 relm dwords per thread) are requested first, the LDS zero fills
     //      (16-byte stores) run under their latency.
     G2_STAMP(48);
     {
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int i = tid; i < nsides * (G2_NT * 32 * kp >> 3); i += G2_THREADS) ((float4*)PLN)[i] = z4;
+      for (int i = tid; i < nsides * (lay.pside >> 2); i += G2_THREADS) ((float4*)PLN)[i] = z4;
       for (int i = tid; i < (2 * rmr * rmp >> 4); i += G2_THREADS) ((float4*)RM)[i] = z4;
       for (int i = tid; i < 2 * G2_NB * 16 * G2_XP / 4; i += G2_THREADS) ((float4*)XOA)[i] = z4;
       for (int i = tid; i < G2_NB * 16 * G2_XP / 4; i += G2_THREADS) ((float4*)HIST)[i] = z4;
@@ -524,9 +517,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
     auto fwd_out = [&](int l, const f32x4& o, float bias, float* XO) {
       const int nt = hf;
       float* hrow = a.h[l] + (size_t)(nbs + row0 + 4 * kq) * 32 + li;                 // rows 4 kq + rr, feature 16 nt + li
-      unsigned long long* exl = a.g2_ex + l * exs + ((size_t)g * 2 + side) * 4096 + (size_t)li * 128 + row0 + 4 * kq;
       float* xo = XO + 4 * kq * G2_XP + li;
-      const uint32_t tg = tag16(l);
       float v[4];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
@@ -536,8 +527,22 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
         xo[rr * G2_XP + 16 * nt] = v[rr];
         if (TRAIN && ok) hrow[rr * 32 + 16 * nt] = v[rr];
       }
-      if (l < 3) g2_publish4(exl + nt * 16 * 128, 0, v, tg);
+      if (l < 3) g2_publish_planes(px_of(l, side), kp, 16 * nt + li, row0 + 4 * kq, v);
       if (bi == 0 && kq == 0) g2_pub_f32(fx + side * 128 + l * 32 + 16 * nt + li, v[0], tag0 + G2_FXTAG);
+    };
+    // this wave's rows of exchange x are in the L2: its flag (every wave of an active bundle, after its epilogue)
+    auto raise = [&](int x) { g2_flag_raise(px_of(x, side), 2 * bi + hf, xtag(x), lane); };
+    // the opposite side's planes of exchange x: wait for the flags of its bundles' waves, then global -> LDS
+    auto fetch = [&](int x) {
+      if (nsides == 1) {
+        g2_flags_wait(px_of(x, 1 - side), 2 * nbun_opp, xtag(x), lane, a.gs_err);
+        g2_planes_load(PLN, px_of(x, 1 - side), kp, wave, lane, G2_THREADS / 64);
+      } else {
+        for (int s2 = 0; s2 < 2; ++s2) {
+          g2_flags_wait(px_of(x, s2), 2 * (((s2 ? cv : cu) + 15) >> 4), xtag(x), lane, a.gs_err);
+          g2_planes_load(PLN + s2 * lay.pside, px_of(x, s2), kp, wave, lane, G2_THREADS / 64);
+        }
+      }
     };
 
     // ================================================================ layer 0: h0 = tanh([hist | onehot(label) | 1] @ T0)
@@ -581,6 +586,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
       }
       G2_STAMP(52);
       fwd_out(0, o, 0.f, XO0);
+      raise(0);
     }
     G2_STAMP(5);
 
@@ -591,23 +597,10 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
       float* XOn = (l & 1) ? XO1 : XO0;             // h_l
       G2_STAMP(6 + 3 * (l - 1));
       const float bias0 = P[a.off_bias[l] + 16 * hf + li];
-      // the opposite side's h_{l-1} as bf16 planes; the layer's weight image is requested behind the exchange words'
-      // first requests (the previous image died at the previous layer's barrier) and lands while they are polled
-      if (nsides == 1) {
-        G2Poll pq;
-        const unsigned long long* exr = a.g2_ex + (l - 1) * exs + ((size_t)g * 2 + (1 - side)) * 4096;
-        const int npad = ((n_opp + 15) >> 4) << 4;
-        g2_poll_issue(pq, exr, npad);
-        if (l > 1) wload(l, 0);
-        g2_poll_finish(pq, PLN, kp, exr, npad, tag16(l - 1), a.gs_err);
-      } else {
-        if (l > 1) wload(l, 0);
-        for (int s2 = 0; s2 < nsides; ++s2) {
-          const int n_sd = s2 ? cv : cu;
-          g2_reload(PLN + s2 * (G2_NT * 32 * kp >> 1), kp, a.g2_ex + (l - 1) * exs + ((size_t)g * 2 + s2) * 4096,
-                    ((n_sd + 15) >> 4) << 4, tag16(l - 1), a.gs_err);
-        }
-      }
+      // the opposite side's h_{l-1} as bf16 planes, and the layer's weight image (the previous one died at the previous
+      // layer's barrier): both global -> LDS, landed by the barrier below
+      fetch(l - 1);
+      if (l > 1) wload(l, 0);
       __syncthreads();
       G2_STAMP(7 + 3 * (l - 1));
       float bias0_ = bias0;                       // landed: no wait for it is left inside the epilogue (a wait there
@@ -632,6 +625,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) of[rr] = hf ? po[rr] + o[1][rr] : o[0][rr] + po[rr];      // (K half 0 + K half 1)
         fwd_out(l, of, bias0_, XOn);
+        if (l < 3) raise(l);
       }
       G2_STAMP(36 + (l - 1));
       // (no barrier here: planes / sW2 were dead at the barrier above; the pair's two halves of h_l in XOn and the reuse of
@@ -759,7 +753,10 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
       //      planes are rebuilt locally (node 0 of every feature; everything else zero): no exchange
       //      (only the first k-step -- nodes 0..31 of every term / feature row -- is read by layer 3's gather; the rest of
       //      the planes still holds h_2: finite values that the next exchange overwrites)
-      for (int i = tid; i < nsides * G2_NT * 32 * 16; i += G2_THREADS) PLN[(i >> 4) * (kp >> 1) + (i & 15)] = 0u;
+      for (int i = tid; i < nsides * G2_NT * 32 * 16; i += G2_THREADS) {
+        const int s2 = i / (G2_NT * 32 * 16), r2 = i - s2 * (G2_NT * 32 * 16);
+        PLN[s2 * lay.pside + (r2 >> 4) * (kp >> 1) + (r2 & 15)] = 0u;
+      }
       for (int i = lane; i < 16 * G2_XP; i += 64) XO0[i] = 0.f;
       __syncthreads();
       if (tid < 32 * nsides) {
@@ -769,7 +766,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
         const float d = sgf[sd * 128 + 96 + f] * (1.f - hv * hv);
         uint32_t h, mi, lo;
         g2_split2(d, 0.f, h, mi, lo);
-        uint32_t* p2 = PLN + s2 * (G2_NT * 32 * kp >> 1) + (f * kp >> 1);
+        uint32_t* p2 = PLN + s2 * lay.pside + (f * kp >> 1);
         p2[0] = h & 0xFFFFu;
         p2[32 * kp >> 1] = mi & 0xFFFFu;
         p2[2 * (32 * kp >> 1)] = lo & 0xFFFFu;
@@ -806,8 +803,6 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) hreg[rr] = 0.f;
         f32x4 o[2];
-        unsigned long long* exb = a.g2_ex + (6 - l) * exs + ((size_t)g * 2 + side) * 4096 + (size_t)li * 128 + row0 + 4 * kq;
-        const uint32_t tgb = tag16(6 - l);
         if (active) {
           // h_{l-1} of the bundle's rows (written by this very wave in the forward): tanh' and the table product
           {
@@ -859,15 +854,16 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
             v[rr] = (row0 + row < n_own) ? d * (1.f - x * x) : 0.f;
             XOn[row * G2_XP + f] = v[rr];
           }
-          if (l > 1) g2_publish4(exb + hf * 16 * 128, 0, v, tgb);
+          if (l > 1) {
+            g2_publish_planes(px_of(6 - l, side), kp, f, row0 + 4 * kq, v);
+            raise(6 - l);
+          }
         }
         G2_STAMP(20 + 5 * (3 - l));
         // (no barrier: the table product reads T' / h_{l-1} / dPre_l, complete at the barrier above; the dPre_{l-1} halves
         //  just written are ordered by the barrier at the end of the layer)
         G2_STAMP(21 + 5 * (3 - l));
         if (l > 1) wload(l - 1, 1);                  // next image: lands under the table product (LDS + matrix work only)
-        G2Poll pq;
-        const int npad_opp = ((n_opp + 15) >> 4) << 4;
         {
           // weight-gradient table h_{l-1}^T [T' | dPre_l], split by OUTPUT tile: wave w computes 3 of the 2 x 12 tiles
           // (row half m2 = in-features, column tile nt: 0..9 = T' of relation nt >> 1, 10..11 = dPre -> d root) over
@@ -878,9 +874,6 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
           const int m2w = wave >> 2, wo = wave & 3;       // tiles 3 wo .. 3 wo + 2 of the row half
 #pragma unroll 1
           for (int wb = 0; wb < G2_NB; ++wb) {
-            // the exchange of dPre_{l-1} runs UNDER the table product: its words are requested half way through (the
-            // other members published them before their own barrier) and consumed after it
-            if (wb == 2 && l > 1 && nsides == 1) g2_poll_issue(pq, a.g2_ex + (6 - l) * exs + ((size_t)g * 2 + (1 - side)) * 4096, npad_opp);
             const float* Tb = TILES + wb * 16 * G2_TP;
             const float* Hb = HSS + wb * 16 * G2_XP;
             const float* Db = XOA + (((l & 1) ? 0 : G2_NB) + wb) * 16 * G2_XP;
@@ -919,17 +912,9 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
           }
         }
         G2_STAMP(22 + 5 * (3 - l));
-        if (l > 1) {
-          if (nsides == 1) {
-            g2_poll_finish(pq, PLN, kp, a.g2_ex + (6 - l) * exs + ((size_t)g * 2 + (1 - side)) * 4096, npad_opp, tag16(6 - l), a.gs_err);
-          } else {
-            for (int s2 = 0; s2 < nsides; ++s2) {
-              const int n_sd = s2 ? cv : cu;
-              g2_reload(PLN + s2 * (G2_NT * 32 * kp >> 1), kp, a.g2_ex + (6 - l) * exs + ((size_t)g * 2 + s2) * 4096,
-                        ((n_sd + 15) >> 4) << 4, tag16(6 - l), a.gs_err);
-            }
-          }
-        }
+        // the opposite side's dPre_{l-1}: its waves raised their flags before their own table products (the exchange ran
+        // under this one); global -> LDS, landed by the barrier below
+        if (l > 1) fetch(6 - l);
         __syncthreads();
         G2_STAMP(23 + 5 * (3 - l));
       }
@@ -1123,7 +1108,7 @@ int igmc_gs_grid(int B) {
 // LDS plan + eligibility for a batch arena / cluster size
 int igmc_g2_layout(const ModelDev& m, const BatchDev& b, int cs, G2Layout* lay) {
   const int RL = m.R * m.L;
-  if (m.S != 0 || m.D != 256 || m.R > G2_NR || m.L > 8 || RL + m.L + 1 > 32 || !m.ts_part || !m.g2_ex || !m.g2_w || !b.relm) return 0;
+  if (m.S != 0 || m.D != 256 || m.R > G2_NR || m.L > 8 || RL + m.L + 1 > 32 || !m.ts_part || !m.g2_px || !m.g2_fx || !m.g2_w || !b.relm) return 0;
   const int half = 2 * cs;
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
   if (cmax > 16 * half || cmax > 128) return 0;
@@ -1134,7 +1119,8 @@ int igmc_g2_layout(const ModelDev& m, const BatchDev& b, int cs, G2Layout* lay) 
   lay->rmr = ((cmax + 15) >> 4) << 4;
   lay->rmc = kmax;
   int o = 0;
-  lay->planes = o; o += lay->nsides * (G2_NT * 32 * lay->kp >> 1);
+  lay->pside = ((G2_NT * 32 * lay->kp * 2 + 1023) & ~1023) >> 2;      // words of one side's planes, padded to 1 KB pieces
+  lay->planes = o; o += lay->nsides * lay->pside;
   lay->ohp = o; o += lay->nsides * (8 * lay->kp >> 1);
   lay->lab = o; o += 64;
   lay->xo = o; o += 2 * G2_NB * 16 * G2_XP;
@@ -1155,10 +1141,40 @@ int igmc_g2_layout(const ModelDev& m, const BatchDev& b, int cs, G2Layout* lay) 
   return (size_t)o * 4 <= 160 * 1024;
 }
 
+// The plane exchange of k_graph_step2 goes through the L2 of ONE XCD: workgroups b and b + 8 of a launch must sit on the
+// same XCD (round-robin dispatch over the eight XCDs of an MI355X in SPX mode; trivially true on a one-XCD partition).
+// Checked once per process on the device itself -- the hardware XCC id of every workgroup of a 64-workgroup launch -- and
+// the subgraph kernel is not used where it does not hold (the dense-layer kernels, whose exchange is device-coherent, run).
+__global__ void k_g2_xcc_probe(int* out) {
+  if (threadIdx.x == 0) out[blockIdx.x] = (int)(g2_xcc_id() & 15ull);
+}
+static int igmc_g2_xcd_ok() {
+#ifdef IGMC_HIPEMU
+  return 1;
+#else
+  static int ok = -1;
+  if (ok >= 0) return ok;
+  ok = 0;
+  int* d = nullptr;
+  int h[64];
+  if (hipMalloc((void**)&d, sizeof(h)) != hipSuccess) return ok;
+  hipLaunchKernelGGL(k_g2_xcc_probe, dim3(64), dim3(64), 0, 0, d);
+  if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+    ok = 1;
+    for (int b = 0; b + 8 < 64; ++b)
+      if (h[b] != h[b + 8]) ok = 0;
+  }
+  (void)hipFree(d);
+  if (!ok) fprintf(stderr, "[igmc] workgroups b and b + 8 of a launch do not share an XCD on this device: the subgraph kernel is not used\n");
+  return ok;
+#endif
+}
+
 // 1 = the matrix-core subgraph kernel takes this batch configuration (IGMC_GRAPH_STEP=0 forces the per-layer kernels)
 int igmc_g2_eligible(const ModelDev& m, const BatchDev& b, int B, G2Layout* lay, int* cs_out) {
   const char* en = getenv("IGMC_GRAPH_STEP");      // read on every call: tests switch it per case
   if (en && atoi(en) == 0) return 0;
+  if (!igmc_g2_xcd_ok()) return 0;
   const int cs = igmc_gs_cluster(B);
   if (!igmc_g2_layout(m, b, cs, lay)) return 0;
   *cs_out = cs;
@@ -1180,7 +1196,7 @@ int igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* P
     a.h[l] = m.h[l];
     a.off_bias[l] = (int)m.off_bias[l];
   }
-  a.ts_part = m.ts_part; a.g2_ex = m.g2_ex; a.g2_fx = m.g2_fx; a.g2_ex_stride = m.g2_ex_stride; a.g2_w = m.g2_w;
+  a.ts_part = m.ts_part; a.g2_px = m.g2_px; a.g2_fx = m.g2_fx; a.g2_px_stride = m.g2_px_stride; a.g2_w = m.g2_w;
   a.gs_bar = m.gs_bar; a.gs_err = m.gs_err; a.a1 = m.a1; a.dz = m.dz; a.feat = m.feat; a.gfeat = m.gfeat; a.err = m.err;
   a.lmask = m.lmask; a.ctrl = m.ctrl;
   a.off_l1w = (int)m.off_l1w; a.off_l1b = (int)m.off_l1b; a.off_l2w = (int)m.off_l2w; a.off_l2b = (int)m.off_l2b;
@@ -1198,7 +1214,7 @@ int igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* P
   a.self_seq = (!training || a.ts) ? 1 : 0;
   a.cs = cs;
   a.stride = (cs > 1) ? ((B + 7) & ~7) : 1;
-  const int grid = (cs > 1) ? cs * B : igmc_gs_grid(B);
+  const int grid = (cs > 1) ? cs * 8 * ((B + 7) / 8) : igmc_gs_grid(B);      // (clusters in XCD-aligned blocks of 8 cs workgroups)
   const size_t sm = (size_t)lay.words * 4;
   if (!m.img_current) {
     IGMC_PLAUNCH("k_g2_compose", k_g2_compose, 2 * 3 * g2_groups(m.R, m.L) * (G2_NR + 1) + g2_t0_rows(m.R, m.L) / 32, G2C_THREADS, 0, stream, m, P, m.g2_w);
@@ -1207,7 +1223,8 @@ int igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* P
 #ifdef IGMC_HIPEMU
   if (cs > 1) {        // (after the launch above: a launch consumes the co-residency request)
     hipemu::rt().co_cs = cs;
-    hipemu::rt().co_stride = -1;       // members of a cluster = consecutive workgroups
+    hipemu::rt().co_stride = 8;        // members of cluster (j, x) = workgroups 8 cs j + x + 8 c
+    hipemu::rt().co_block = 8 * cs;
   }
 #endif
   if (getenv("IGMC_GS_TRACE")) fprintf(stderr, "[igmc] k_graph_step B=%d train=%d flags=%d v2 kp=%d lds=%zu cluster=%d grid=%d\n", B, training, use_flags, lay.kp, sm, cs, grid);
@@ -1225,6 +1242,7 @@ int igmc_dl_prepare();
 int igmc_gs_prepare() { return igmc_g2_prepare(); }
 int igmc_g2_prepare() {
   if (igmc_dl_prepare()) return 1;
+  (void)igmc_g2_xcd_ok();      // (probed here, at model creation: never inside a stream capture)
 #ifndef IGMC_HIPEMU
   const int mx = 160 * 1024;
   if (hipFuncSetAttribute((const void*)k_graph_step2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;

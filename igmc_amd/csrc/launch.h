@@ -80,7 +80,7 @@ void igmc_launch_finish(const ModelDev& m, const BatchDev& b, float* p, const fl
 
 // graphstep2.hip: one cluster of workgroups per enclosing subgraph, relational aggregation on the matrix cores
 struct G2Layout {      // LDS plan of graphstep2.hip, offsets in 4-byte words
-  int kp, nsides, rmr, rmc;
+  int kp, nsides, rmr, rmc, pside;
   int planes, ohp, lab, xo, hs, tile, hist, px, wreg, t0, att, head, words;
 };
 void igmc_launch_side_gather(const float* src, int S, const int32_t* link_idx, int first, int B, const int64_t* ctrl,

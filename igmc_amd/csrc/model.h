@@ -49,6 +49,8 @@ struct ModelDev {
   unsigned long long* g2_ex;   // graphstep2: [5 exchanges][g2_graphs][2 sides][32 features][128 nodes] {hi, mid, lo, tag} words
   size_t g2_ex_stride;         // words per exchange
   unsigned long long* g2_fx;   // [g2_graphs][256] {f32, tag} words of the centre-node readout
+  unsigned char* g2_px;        // k_graph_step2's plane exchange: [5 exchanges][g2_graphs][2 sides][32 KB] (g2_prims.h); null: not allocated
+  size_t g2_px_stride;         // bytes per exchange
   int g2_graphs;               // subgraph slots of the two buffers above (0: not allocated)
   float* g2_w;                 // [6 images of (5*32+32) x 20 float2 | 1024] composed weights of the step (k_g2_compose)
   int ex_nodes;                // nodes a side the exchange regions of g2_ex hold: 128 (k_graph_step2) or 256 (k_dl_fwd)

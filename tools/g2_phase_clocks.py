@@ -40,11 +40,15 @@ def main():
     model.reset_parameters()
     opt = FlatAdam(model, lr=1e-3)
     ov = '--overlap' in sys.argv
-    sg = StepGraph(model, opt, ds, 50, 0.001, use_graph=False, overlap=ov)
-    perm = torch.randperm(len(ds))[:5000]
+    gr = '--graph' in sys.argv          # the clocks of the LAST step of a hipGraph replay (what bench.py times)
+    sg = StepGraph(model, opt, ds, 50, 0.001, use_graph=gr, overlap=ov or gr)
+    perm = torch.randperm(len(ds))[:20000 if gr else 5000]
     sg.begin_epoch(perm, 1)
     for _ in range(20):
         sg.step()
+    if gr:
+        sg.prepare(steps_hint=200)
+        sg.steps(200)
     if '--group' in sys.argv:
         sg.steps(2 * sg.M)
     torch.cuda.synchronize()
@@ -75,21 +79,28 @@ def main():
             print('tail roles (%d): start min/max %.1f / %.1f us | body done min/median/max %.1f / %.1f / %.1f | arrived max %.1f '
                   '(vs the first subgraph workgroup)' % (len(roles), st.min(), st.max(), bd.min(), np.median(bd), bd.max(), ar.max()))
             print('  per role body time (us): ' + ' '.join('%.1f' % x for x in (bd - st)))
-    wg = np.zeros(200 * 3, np.uint64)
+    NWG = 224                     # 50 subgraphs in XCD-aligned blocks of 32 workgroups: wg = 32 j + 8 member + x, subgraph 8 j + x
+    wg = np.zeros(NWG * 3, np.uint64)
     if hasattr(lib.cdll, 'igmc_debug_g2_wg_clocks'):
-        lib.cdll.igmc_debug_g2_wg_clocks(C.c_void_p(wg.ctypes.data), 200)
-        w = wg.reshape(200, 3).astype(np.int64)
+        lib.cdll.igmc_debug_g2_wg_clocks(C.c_void_p(wg.ctypes.data), NWG)
+        w = wg.reshape(NWG, 3).astype(np.int64)
+        sub = np.array([(i // 32) * 8 + (i % 8) for i in range(NWG)])
+        mem = np.array([(i // 8) % 4 for i in range(NWG)])
+        keep = sub < 50
+        ids = np.arange(NWG)[keep]
+        w, sub, mem = w[keep], sub[keep], mem[keep]
         t0 = w[:, 0].min()
         st, en = (w[:, 0] - t0) / 100.0, (w[:, 1] - t0) / 100.0          # us (100 MHz wall clock)
-        print('per-workgroup (200): start min/median/max %.1f / %.1f / %.1f us; end min/median/max %.1f / %.1f / %.1f us; '
+        print('per-workgroup (200 of 224): start min/median/max %.1f / %.1f / %.1f us; end min/median/max %.1f / %.1f / %.1f us; '
               'duration min/median/max %.1f / %.1f / %.1f us' % (st.min(), np.median(st), st.max(), en.min(), np.median(en),
                                                                  en.max(), (en - st).min(), np.median(en - st), (en - st).max()))
         late = np.argsort(-en)[:8]
         print('last to end: ' + ', '.join('wg %d (subgraph %d, member %d, xcc %d): start %.1f end %.1f' % (
-            i, i // 4, i % 4, w[i, 2] & 15, st[i], en[i]) for i in late))
-        dur = (en - st).reshape(50, 4)
-        print('per-subgraph duration of the slowest member: min %.1f median %.1f max %.1f us' % (
-            dur.max(1).min(), np.median(dur.max(1)), dur.max(1).max()))
+            ids[i], sub[i], mem[i], w[i, 2] & 15, st[i], en[i]) for i in late))
+        dmax = np.array([(en - st)[sub == g].max() for g in range(50)])
+        print('per-subgraph duration of the slowest member: min %.1f median %.1f max %.1f us' % (dmax.min(), np.median(dmax), dmax.max()))
+        xc = [len(set((w[sub == g, 2] & 15).tolist())) for g in range(50)]
+        print('XCDs per cluster: max %d (1 = every cluster on one XCD)' % max(xc))
 
 
 def fine(c):

@@ -150,7 +150,10 @@ struct Runtime {
   // cluster launch (k_graph_step): the NEXT launch runs the workgroups b, b + co_stride, ..., (co_cs of them) of a 1-D
   // grid TOGETHER, round-robin over all their work-items, so that they can exchange data through global memory with
   // polling loops that call hipemu::yield(); consumed (reset to 1) by that launch
-  int co_cs = 1, co_stride = 0;
+  // co_block > 0: the members of a cluster are b, b + co_stride, .. INSIDE blocks of co_block = co_cs * co_stride consecutive
+  // workgroups (cluster (j, x) = workgroups j * co_block + x + c * co_stride, x < co_stride): the layout that puts the members
+  // of a cluster on ONE XCD of a round-robin dispatch
+  int co_cs = 1, co_stride = 0, co_block = 0;
   std::function<void()> body;
   long n_switch = 0;
 };
@@ -268,9 +271,10 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> bo
   r.body = body;
   r.bdim = block;
   r.gdim = grid;
-  const int cs = r.co_cs, stride = r.co_stride;
+  const int cs = r.co_cs, stride = r.co_stride, cblock = r.co_block;
   r.co_cs = 1;
   r.co_stride = 0;
+  r.co_block = 0;
   int nthreads = block.x * block.y * block.z;
   if (cs > 1) {
     // clusters: members g, g + stride, .. of a 1-D grid are resident together (NOTE: function-scope `__shared__`
@@ -278,6 +282,19 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> bo
     // (stride < 0: the members of cluster g are the consecutive workgroups g * cs .. g * cs + cs - 1)
     if (grid.y != 1 || grid.z != 1 || stride == 0) { fprintf(stderr, "hipemu: cluster launches need a 1-D grid\n"); abort(); }
     if ((int)r.blocks.size() < cs) r.blocks.resize(cs);
+    if (cblock > 0) {
+      for (unsigned base = 0; base < grid.x; base += (unsigned)cblock)
+        for (int x = 0; x < stride; ++x) {
+          r.nres = 0;
+          for (int c = 0; c < cs; ++c) {
+            const unsigned b = base + (unsigned)(x + c * stride);
+            if (b < grid.x) prepare_block(r.blocks[r.nres++], uint3_emu{b, 0, 0}, shmem);
+          }
+          if (r.nres) run_resident(nthreads);
+        }
+      r.nres = 1;
+      return;
+    }
     const int ngroups = (stride < 0) ? ((int)grid.x + cs - 1) / cs : stride;
     for (int g = 0; g < ngroups; ++g) {
       r.nres = 0;
