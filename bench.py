@@ -569,9 +569,10 @@ def main():
                     tot += 5 * (deg_u[users[0]] + deg_v[items[0]] + int(deg_u[users].sum())) + (hi - lo) + 9 * e_sg // 2
                 ext_bytes.append(tot)
             Ns.append(d['N'])
-            # SURVEY.md 8(d) counts E AFTER edge dropout: the arena holds every induced edge, the kept ones carry bit 0
-            # of their flag byte (k_relm_dropout / k_edge_flags; all set when the configuration has no dropout)
-            Es.append(int((np.asarray(d['eflag']) & 1).sum()) if cfg['adj_dropout'] > 0 else d['E'])
+            # SURVEY.md 8(d) counts E AFTER edge dropout.  The arena holds every induced edge and the kept ones as flag
+            # bits of the dense blocks (drawn per step by k_relm_dropout; the CSR copy inspected here is emitted on demand
+            # and carries no draws on a lean arena): the kept count is taken at its expectation, E (1 - p)
+            Es.append(d['E'] * (1.0 - cfg['adj_dropout']))
             nu_ = np.asarray(d['n_users'][:d['B']], np.int64)
             nv_ = np.diff(np.asarray(d['node_off'][:d['B'] + 1], np.int64)) - nu_
             bundles.append(int(((nu_ + 15) // 16).sum() + ((nv_ + 15) // 16).sum()))

@@ -370,6 +370,17 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
     const int side = gw / half, bi = gw - side * half;    // this wave's side (0 users, 1 items) and bundle of that side
     labv_raw = load_label(g);
     load_relm(g);
+    // ---- the LDS zero fills (16-byte stores) run under the latency of the set-up's global loads: placed in front of
+    //      everything that needs the subgraph's extents (a wait for THOSE in front of the fills is a round trip of idling)
+    G2_STAMP(48);
+    {
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = tid; i < nsides * (lay.pside >> 2); i += G2_THREADS) ((float4*)PLN)[i] = z4;
+      for (int i = tid; i < (2 * rmr * rmp >> 4); i += G2_THREADS) ((float4*)RM)[i] = z4;
+      for (int i = tid; i < 2 * G2_NB * 16 * G2_XP / 4; i += G2_THREADS) ((float4*)XOA)[i] = z4;
+      for (int i = tid; i < G2_NB * 16 * G2_XP / 4; i += G2_THREADS) ((float4*)HIST)[i] = z4;
+    }
+    G2_STAMP(49);
     const int cu = first_graph ? pre_cu : a.n_users[g], cv = first_graph ? pre_cv : a.n_items[g];
     const int n_own = side ? cv : cu, n_opp = side ? cu : cv;
     const int nbs = g * a.slot + (side ? a.cap_u : 0);       // first row of this wave's side in the h_l scratch (slot-based:
@@ -394,18 +405,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
     unsigned long long* fx = a.g2_fx + (size_t)g * 256;
     const int nbun_opp = (n_opp + 15) >> 4;
 
-    // ---- set-up: labels, relm in the orientation of this workgroup's side(s), one-hot label planes, zeroed planes.
-    //      The global loads (one label per thread, <= 16 relm dwords per thread) are requested first, the LDS zero fills
-    //      (16-byte stores) run under their latency.
-    G2_STAMP(48);
-    {
-      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int i = tid; i < nsides * (lay.pside >> 2); i += G2_THREADS) ((float4*)PLN)[i] = z4;
-      for (int i = tid; i < (2 * rmr * rmp >> 4); i += G2_THREADS) ((float4*)RM)[i] = z4;
-      for (int i = tid; i < 2 * G2_NB * 16 * G2_XP / 4; i += G2_THREADS) ((float4*)XOA)[i] = z4;
-      for (int i = tid; i < G2_NB * 16 * G2_XP / 4; i += G2_THREADS) ((float4*)HIST)[i] = z4;
-    }
-    G2_STAMP(49);
+    // ---- set-up: labels, the block image (rows = users), one-hot label planes
     if (tid < 256) slab[tid] = (unsigned char)(((tid & 127) < ((tid >> 7) ? cv : cu)) ? labv_raw : 255);
     G2_STAMP(50);
     __syncthreads();
@@ -419,21 +419,9 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
         if ((tid_ & 31) < ldw && u < cu && c4 < rmc) *(uint32_t*)(RM + (size_t)u * rmp + c4) = rmv[q];
       }
     }
-    if (nsides == 2 || side == 1) {
-      // the transposed image (rows = items) from the row-major one: lane = item v, dword = users 4 u4 .. 4 u4 + 3
-      // (byte reads of consecutive items are one LDS dword; the pitch rmc + 8 spreads the dword writes over 16 banks)
-      __syncthreads();
-      unsigned char* rt = RM + (size_t)rmr * rmp;
-      const int nu4 = (cu + 3) >> 2;
-      for (int i = tid; i < 128 * nu4; i += G2_THREADS) {
-        const int v = i & 127, u4 = i >> 7;
-        if (v < cv) {
-          const unsigned char* p = RM + (size_t)(4 * u4) * rmp + v;
-          const uint32_t w = (uint32_t)p[0] | ((uint32_t)p[rmp] << 8) | ((uint32_t)p[2 * rmp] << 16) | ((uint32_t)p[3 * rmp] << 24);
-          *(uint32_t*)(rt + (size_t)v * rmp + 4 * u4) = w;
-        }
-      }
-    }
+    // (no transposed image: an item-side lane gathers the eight block bytes of a k-step -- its item's column, eight
+    //  consecutive users -- straight from the row-major image when it forms its masks; the transposition pass and its
+    //  barrier kept the item side ~2 k cycles behind the user side, which then waited for the items' h_0)
     {
       // one-hot planes of the labels of the opposite side(s): plane[label][node] = 1.0 (bf16)
       for (int i = tid; i < nsides * 8 * (kp >> 1); i += G2_THREADS) {
@@ -458,15 +446,23 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
     uint32_t RB[FLAGS ? G2_KS : 1][2];
     const int kb = side ? IGMC_RELM_KF : IGMC_RELM_KT;      // keep bit of the edge  own -> opposite
     {
-      const unsigned char* rmo = RM + (size_t)side * rmr * rmp + (size_t)(row0 + li) * rmp;
+      const unsigned char* rmo = RM + (size_t)(row0 + li) * rmp;       // user side: the lane's row of the image
+      const unsigned char* rmc_ = RM + (row0 + li);                    // item side: the lane's column of it
       const int kf = side ? IGMC_RELM_KT : IGMC_RELM_KF;    // keep bit of the edge  opposite -> own
 #pragma unroll
       for (int s = 0; s < G2_KS; ++s) {
         uint32_t w0 = 0u, w1 = 0u;
         if (active && s < nks && 32 * s + 8 * kq < rmc) {
-          const uint2 w = *(const uint2*)(rmo + 32 * s + 8 * kq);
-          w0 = w.x;
-          w1 = w.y;
+          if (side == 0) {
+            const uint2 w = *(const uint2*)(rmo + 32 * s + 8 * kq);
+            w0 = w.x;
+            w1 = w.y;
+          } else {
+            // (rows past the users of the subgraph are zero: the image was cleared and only rows < cu were written)
+            const unsigned char* pc = rmc_ + (size_t)(32 * s + 8 * kq) * rmp;
+            w0 = (uint32_t)pc[0] | ((uint32_t)pc[rmp] << 8) | ((uint32_t)pc[2 * rmp] << 16) | ((uint32_t)pc[3 * rmp] << 24);
+            w1 = (uint32_t)pc[4 * rmp] | ((uint32_t)pc[5 * rmp] << 8) | ((uint32_t)pc[6 * rmp] << 16) | ((uint32_t)pc[7 * rmp] << 24);
+          }
         }
         if constexpr (FLAGS) {
           RB[s][0] = w0;
