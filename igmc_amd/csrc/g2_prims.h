@@ -134,10 +134,12 @@ __device__ __forceinline__ void g2_store16(unsigned long long* p, uint32_t x, ui
   p[1] = ((unsigned long long)w << 32) | z;
 #endif
 }
+// (an ORDINARY 8-byte store: its readers -- g2_poll_f32, sc1 loads -- sit on the writer's XCD and find it in the shared L2
+//  ~250 ns after issue; written through to memory with sc1 it took ~570 ns, profiles/r05_experiments/xcd_oneway.txt)
 __device__ __forceinline__ void g2_pub_f32(unsigned long long* p, float v, uint32_t tag) {
 #ifndef IGMC_HIPEMU
   __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
+                     __HIP_MEMORY_SCOPE_WAVEFRONT);
 #else
   uint32_t bits;
   memcpy(&bits, &v, 4);

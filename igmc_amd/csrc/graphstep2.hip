@@ -518,12 +518,19 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const float tv = g2_tanh(o[rr] + bias);
-        const bool ok = row0 + 4 * kq + rr < n_own;
-        v[rr] = ok ? tv : 0.f;
-        xo[rr * G2_XP + 16 * nt] = v[rr];
-        if (TRAIN && ok) hrow[rr * 32 + 16 * nt] = v[rr];
+        v[rr] = (row0 + 4 * kq + rr < n_own) ? tv : 0.f;
       }
-      if (l < 3) g2_publish_planes(px_of(l, side), kp, 16 * nt + li, row0 + 4 * kq, v);
+      // the planes and their flag FIRST (what the other side waits for: the flag's wait covers three 8-byte stores only);
+      // the wave's own copies -- LDS tile, h_l rows for the backward, the readout word -- go out behind it
+      if (l < 3) {
+        g2_publish_planes(px_of(l, side), kp, 16 * nt + li, row0 + 4 * kq, v);
+        g2_flag_raise(px_of(l, side), 2 * bi + hf, xtag(l), lane);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        xo[rr * G2_XP + 16 * nt] = v[rr];
+        if (TRAIN && row0 + 4 * kq + rr < n_own) hrow[rr * 32 + 16 * nt] = v[rr];
+      }
       if (bi == 0 && kq == 0) g2_pub_f32(fx + side * 128 + l * 32 + 16 * nt + li, v[0], tag0 + G2_FXTAG);
     };
     // this wave's rows of exchange x are in the L2: its flag (every wave of an active bundle, after its epilogue)
@@ -582,7 +589,6 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
       }
       G2_STAMP(52);
       fwd_out(0, o, 0.f, XO0);
-      raise(0);
     }
     G2_STAMP(5);
 
@@ -621,7 +627,6 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) of[rr] = hf ? po[rr] + o[1][rr] : o[0][rr] + po[rr];      // (K half 0 + K half 1)
         fwd_out(l, of, bias0_, XOn);
-        if (l < 3) raise(l);
       }
       G2_STAMP(36 + (l - 1));
       // (no barrier here: planes / sW2 were dead at the barrier above; the pair's two halves of h_l in XOn and the reuse of
@@ -848,12 +853,13 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
             if (bi == 0 && row == 0) d += sgf[side * 128 + (l - 1) * 32 + f];
             const float x = hreg[rr];
             v[rr] = (row0 + row < n_own) ? d * (1.f - x * x) : 0.f;
-            XOn[row * G2_XP + f] = v[rr];
           }
           if (l > 1) {
             g2_publish_planes(px_of(6 - l, side), kp, f, row0 + 4 * kq, v);
             raise(6 - l);
           }
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) XOn[(4 * kq + rr) * G2_XP + f] = v[rr];
         }
         G2_STAMP(20 + 5 * (3 - l));
         // (no barrier: the table product reads T' / h_{l-1} / dPre_l, complete at the barrier above; the dPre_{l-1} halves
