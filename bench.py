@@ -504,13 +504,16 @@ def main():
         sg.detach()
         single_us, single_host = timed_us(sg, D)
         os.environ['IGMC_FORCE_DP_PATH'], os.environ['IGMC_DP_ALLREDUCE_ALWAYS'] = '1', '1'
+        # (a one-rank peer communicator needs no exchange and launches none; here it is made to launch its kernel all the
+        #  same -- the launch is what a G > 1 step adds on top of the link's latency)
+        os.environ['IGMC_PEER_ALWAYS'] = '1'
         try:
             sg_dp = StepGraph(model, opt, ds, BATCH, 0.001)
             dp_us, dp_host = timed_us(sg_dp, D)
             in_graph = sg_dp.graph is not None
             sg_dp.check()
         finally:
-            del os.environ['IGMC_FORCE_DP_PATH'], os.environ['IGMC_DP_ALLREDUCE_ALWAYS']
+            del os.environ['IGMC_FORCE_DP_PATH'], os.environ['IGMC_DP_ALLREDUCE_ALWAYS'], os.environ['IGMC_PEER_ALWAYS']
         dp_structure = dict(steps=D, single_gpu_us=single_us, dp_us=dp_us, dp_structure_us=dp_us - single_us,
                             allreduce_in_graph=bool(in_graph),
                             host_enqueue_us_per_step=dict(single_gpu=single_host, dp=dp_host),

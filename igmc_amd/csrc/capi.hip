@@ -1203,6 +1203,7 @@ struct PeerArgs {
   unsigned long long* pub[IGMC_MAX_PEERS];
   int world, rank;
   int64_t cap;
+  unsigned long long timeout_ticks;      // bound of a poll on the device's constant-rate clock (100 MHz)
   int* state;
   float* a;
   int64_t na;
@@ -1228,9 +1229,18 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_peer_allreduce(PeerArgs p) {
     mine[i] = w;
 #endif
   }
+  // A rank may be late by far more than a kernel's length -- first-step capture, a checkpoint write on rank 0, a
+  // time-sliced device: the polls are bounded by WALL-CLOCK time (p.timeout_ticks, a minute by default), not by an
+  // iteration count.  A word that never arrives leaves the spans UNTOUCHED (no partial or foreign sum is ever written) and
+  // raises the sticky p.state[2]; the gradient / Adam kernel behind this launch then leaves the parameters alone
+  // (AdamTail::skip) and the host raises at its next check (igmc_comm_check).
+#ifndef IGMC_HIPEMU
+  const unsigned long long t_start = wall_clock64();
+#endif
   for (int64_t i = t0; i < n; i += T) {
     float s = 0.f;
-    for (int r = 0; r < p.world; ++r) {
+    bool ok = true;
+    for (int r = 0; r < p.world && ok; ++r) {
       const unsigned long long* src = p.pub[r] + base + i;
       unsigned long long w = 0;
       for (long it = 0;; ++it) {
@@ -1240,7 +1250,13 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_peer_allreduce(PeerArgs p) {
         w = *src;
 #endif
         if ((w >> 32) == (unsigned long long)seq) break;
-        if (it > (1L << 22)) {
+#ifndef IGMC_HIPEMU
+        if ((it & 63) == 63 && wall_clock64() - t_start > p.timeout_ticks) ok = false;
+        if (__hip_atomic_load(p.state + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ok = false;      // (another thread gave up)
+#else
+        if (it > (1L << 22)) ok = false;
+#endif
+        if (!ok) {
           p.state[2] = 1;
           break;
         }
@@ -1250,8 +1266,10 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_peer_allreduce(PeerArgs p) {
       }
       s += __uint_as_float((uint32_t)w);
     }
-    if (i < p.na) p.a[i] = s;
-    else p.b[i - p.na] = s;
+    if (ok) {
+      if (i < p.na) p.a[i] = s;
+      else p.b[i - p.na] = s;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1345,7 +1363,13 @@ extern "C" int igmc_comm_check(igmc_comm* c, void* stream) {
   if (c->peer && c->d_state) {
     int st[4];
     HIPCHECK(hipMemcpy(st, c->d_state, sizeof(st), hipMemcpyDeviceToHost));
-    if (st[2]) IGMC_FAIL("peer all-reduce: a poll for another rank's words timed out (results of that launch are invalid)");
+    if (st[2]) {
+      // reported once: the flag is cleared so that a caller that recovers (or tears the job down in order) is not told again
+      const int zero = 0;
+      (void)hipMemcpy(c->d_state + 2, &zero, sizeof(int), hipMemcpyHostToDevice);
+      IGMC_FAIL("peer all-reduce: another rank's words did not arrive within the time limit (IGMC_PEER_TIMEOUT_S); the spans of that "
+                "launch were left unsummed and the optimiser step behind it was skipped");
+    }
   }
 #endif
   return 0;
@@ -1361,14 +1385,18 @@ extern "C" int igmc_comm_kind(const igmc_comm* c) {
 
 static int peer_sum2(igmc_comm* c, float* a, int64_t na, float* b, int64_t nb, void* stream) {
   if (!c->connected) { g_err = "peer communicator is not connected (igmc_comm_peer_connect)"; return 1; }
+  if (c->world == 1 && !getenv("IGMC_PEER_ALWAYS")) return 0;      // one rank: the spans ARE the sums (IGMC_PEER_ALWAYS: test hook)
   if (!a) na = 0;
   if (!b) nb = 0;
+  double tmo = 60.0;
+  if (const char* e = getenv("IGMC_PEER_TIMEOUT_S")) tmo = atof(e) > 0 ? atof(e) : tmo;
   // spans beyond a slot go in pieces (each piece is a launch of its own: the sequence number advances per launch)
   while (na + nb > 0) {
     PeerArgs p;
     memset(&p, 0, sizeof(p));
     for (int r = 0; r < c->world; ++r) p.pub[r] = c->pub[r];
     p.world = c->world; p.rank = c->rank; p.cap = c->cap; p.state = c->d_state;
+    p.timeout_ticks = (unsigned long long)(tmo * 1e8);
     const int64_t ta = na < c->cap ? na : c->cap;
     const int64_t tb = (nb < c->cap - ta) ? nb : c->cap - ta;
     p.a = a; p.na = ta; p.b = b; p.nb = tb;
@@ -1480,7 +1508,7 @@ extern "C" int igmc_train_step_dp(igmc_model* m, igmc_comm* comm, float* d_param
   ImgScope img(m, d_params);
   int emitted = 0;
   if (igmc_step_exchange_inside(m->d, b->d, B)) {
-    StepExchange x = {comm_sum2, comm};
+    StepExchange x = {comm_sum2, comm, (comm && comm->peer) ? comm->d_state + 2 : nullptr};
     // (the ARR term depends on the weights only: every rank adds it in full AFTER the exchange)
     const int rc = igmc_launch_train_step(m->d, m->ax, b->d, d_params, B, use_edge_flags, d_lin_mask, seed, step, multiply_by,
                                           ARR, d_out, d_grad, d_exp_avg, d_exp_avg_sq, step_size, inv, beta1, beta2, eps,

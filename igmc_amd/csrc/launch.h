@@ -53,6 +53,8 @@ struct AdamTail;
 struct StepExchange {
   int (*sum)(void* user, float* a, int64_t na, float* b, int64_t nb, void* stream);
   void* user;
+  const int* failed;      // device word the exchange raises when its sums are NOT in place (a peer never delivered): the
+                          // gradient / Adam kernel behind it then leaves parameters, moments and step counters alone; or null
 };
 // 1 = a step on this arena keeps its gradient sources in exchangeable form (igmc_launch_loss_grad honours `xch`)
 int igmc_step_exchange_inside(const ModelDev& m, const BatchDev& b, int B);

@@ -1676,6 +1676,8 @@ struct AdamTail {
   float* loss;
   double* total;
   int use_flags;      // the step ran under edge dropout (the tick then also checks the arena's dropout stamp)
+  const int* skip;    // data-parallel step: set by the gradient exchange when its sums did not arrive (StepExchange::failed);
+                      // the whole launch then returns at once -- no parameter, moment or counter is touched
 };
 
 // IGMC_FIN_NB workgroups per conv layer: turn the reduced partials into the flat gradient, add the
@@ -1691,6 +1693,7 @@ struct AdamTail {
 #define IGMC_FIN_NB 8
 __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize(ModelDev m, const float* P, float* __restrict__ grad,
                                                            float arr_coef, AdamTail at, int ts_mode) {
+  if (at.skip && *at.skip) return;      // (uniform over the launch: written by the kernel in front of it)
   __shared__ float smf[8];
   __shared__ float sG[16], sM[16];
   __shared__ int s_lastl;
@@ -1904,6 +1907,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
   // bs != 0: the per-layer path's sources -- conv layers 1..3 in BASIS space (graw: d basis_b, d root, d bias straight
   // from the weight-gradient kernel, d att from the layer kernels' partials), layer 0 as its relation-space table in graw;
   // the stash comes from k_reduce_partials.  bs == 0: the relation-space tables of the subgraph kernels (ts_raw).
+  if (at.skip && *at.skip) return;      // (uniform over the launch: written by the kernel in front of it)
   __shared__ float smf[8];
   const int tid = threadIdx.x;
   const float* stash = m.fin_stash;
@@ -2473,6 +2477,7 @@ int igmc_launch_loss_grad(const ModelDev& m_in, const ModelAux& ax, const BatchD
   memset(&at, 0, sizeof(at));
   if (adam) at = *adam;
   at.use_flags = use_flags;
+  at.skip = xch ? xch->failed : nullptr;
   if (!fast_head) {      // generic sequence
     igmc_launch_forward(m, ax, b, P, B, 1, use_flags, inj_mask, seed, step, mult, out, stream);
     igmc_launch_backward(m, ax, b, P, B, use_flags, nullptr, 1, grad_scale, mult, 2.f, ARR * arr_scale, grad, stream);

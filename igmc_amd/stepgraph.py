@@ -555,6 +555,10 @@ class StepGraph(GroupPipeline):
                              % str(e).splitlines()[0])
             self.use_graph, self.graph = False, None
             torch.cuda.synchronize()
+        # every rank is through its capture (or has given it up) before any rank replays: the first replay of a fast rank
+        # would otherwise poll the exchange words of a rank that is still capturing (the polls are bounded by wall-clock time)
+        if self.comm is not None:
+            parallel.barrier()
         return self.graph
 
     def prepare(self, steps_hint=None, group=None, prime=True):
