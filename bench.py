@@ -73,7 +73,7 @@ CONFIGS = {
     'flixster': dict(dataset='flixster', mnph=10000, adj_dropout=0.2, cpu='dynamic'),
     'yahoo_music': dict(dataset='yahoo_music', mnph=10000, adj_dropout=0.2, cpu='dynamic'),
 }
-PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')      # (ml_1m; other configs: r04_pmc_traffic_<config>.json)
+PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json')      # (ml_1m; other configs: r05_pmc_traffic_<config>.json)
 # timer label of the HIP-event profile -> kernel symbol in the code object (what rocprofv3 lists)
 SYMBOLS = {'k_dl_layer_fwd': 'k_dl_layer<FLAGS, false, false>', 'k_rgcn_layer_fwd': 'k_rgcn_layer4<FLAGS, false>',
            'k_dl_bwd': 'k_dl_bwd<FLAGS, NG, false>', 'k_dl_fwd': 'k_dl_fwd<FLAGS, true, NG>'}

@@ -1,6 +1,6 @@
 """HBM-side traffic of the roofline kernel from the PMC summaries of tools/profile_round.sh.
 
-    python tools/pmc_traffic.py gpurun_out/prof profiles/r04_pmc_traffic.json [config]
+    python tools/pmc_traffic.py gpurun_out/prof profiles/r05_pmc_traffic.json [config]
 
 The record is stamped with the hash of the kernel sources (bench.kernel_source_sha) and the commit (IGMC_COMMIT):
 bench.py reports ``roofline.traffic`` from it only while the sources it runs are the ones that were profiled.
