@@ -1835,7 +1835,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
   // ---- every 4096 launches the side's region is cleared in all exchange buffers -- a 16-bit tag then never meets a word
   //      older than 4096 launches (tags repeat after 65535) -- by the rows' owners of THIS launch (nobody else writes
   //      them), workgroup 0 also taking the rows past the side up to the slot capacity (nobody's in this launch)
-  if ((seq & 4095u) == 0u) {
+  if ((seq & 4094u) == 0u) {      // (either parity of the sequence number: a path that advances it twice per step only ever shows one)
     const int rcap = 128 * nqs < DLX_K ? 128 * nqs : DLX_K;
     for (int part = 0; part < (q == 0 ? 2 : 1); ++part) {
       const int r0 = part ? ((n_own + 15) >> 4) << 4 : dr.base, r1 = part ? rcap : dr.base + 16 * dr.nact;
@@ -2900,6 +2900,10 @@ int igmc_dl_wide(const ModelDev& m, const BatchDev& b, int B) {
   if (e && atoi(e) != 2) return 0;
   const char* et = getenv("IGMC_DL_TS");
   if (et && atoi(et) == 0) return 0;
+  // (the same predicate as the launch sequence's `fts_pre`, model.hip: with the tables' tail switched off -- IGMC_FIN_MODE=0 --
+  //  or its stash missing the step does NOT go wide, and the arena must then carry the CSR the row walkers read)
+  const char* ef = getenv("IGMC_FIN_MODE");
+  if ((ef && atoi(ef) == 0) || !m.fin_stash || !m.datt_part) return 0;
   if (!m.g2_ex || m.ex_nodes < DLX_K || b.graph_cap > m.g2_graphs || !m.ts_part || !m.cnt0) return 0;
   const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v;
   const DlSplit sq = dl_split(b.cap_u, b.cap_v, B);
