@@ -282,18 +282,23 @@ def floor_us(lib, shape, class_values, cfg, dev, local, steps=40):
     return float(mean.value) if cnt.value > 0 else None
 
 
-def run_secondary(configs=('ml_100k', 'douban', 'flixster', 'ml_10m_lite'), steps=100, warmup=10):
-    """Short runs of the other configurations (fresh processes of this file): value, us / step, dominant kernel."""
+def run_secondary(configs=('ml_100k', 'douban', 'flixster', 'ml_10m_lite', 'yahoo_music', 'dgcnn_rs:douban'), steps=100, warmup=10):
+    """Short runs of the other configurations (fresh processes of this file): value, us / step, dominant kernel.
+    ``dgcnn_rs:<config>`` = the sort-pool readout family (--dgcnn-rs) on that configuration's data."""
     import subprocess
     out = {}
     for c in configs:
-        cmd = [sys.executable, os.path.abspath(__file__), '--config', c, '--steps', str(steps), '--warmup', str(warmup),
+        fam, _, cfgname = c.rpartition(':')
+        st = 64 if cfgname == 'yahoo_music' else steps          # (yahoo_music: 5 335 training links = 106 batches)
+        cmd = [sys.executable, os.path.abspath(__file__), '--config', cfgname, '--steps', str(st), '--warmup', str(warmup),
                '--no-cpu-baseline', '--dp-steps', '0', '--rmse-links', '0', '--profile-steps', '16', '--no-secondary']
+        if fam == 'dgcnn_rs':
+            cmd.append('--dgcnn-rs')
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
             d = json.loads(r.stdout.decode().strip().splitlines()[-1])
             rf = d.get('roofline') or {}
-            out[c] = dict(value=d['value'], us_per_step=d['ms_per_step'] * 1e3, steps=steps, warmup=warmup,
+            out[c] = dict(value=d['value'], us_per_step=d['ms_per_step'] * 1e3, steps=st, warmup=warmup,
                           workload=d['config']['workload'], dominant_kernel=rf.get('kernel'), kernel_us=rf.get('avg_us'),
                           frac=rf.get('frac'), floor_us=rf.get('floor_us'), kernels_us=d.get('kernels_us'))
         except Exception as e:
