@@ -155,8 +155,11 @@ __device__ __forceinline__ void g2_pub_f32(unsigned long long* p, float v, uint3
 // acknowledgement and raises ONE flag word per wave; a consumer wave polls the flags of the opposite side's bundles (sc1
 // loads: past the CU's L1, served by the shared L2) and then copies the planes global -> LDS directly (global_load_lds).
 // Region of one (exchange, subgraph, side): G2_PX_BYTES; planes at 0 (192 * kp bytes <= 26112), 64 flag words at G2_PX_FLAGS.
+// The dense-layer kernels (<= 256 nodes a side: planes of up to 50688 bytes) use the same protocol in regions of DLX_PX_BYTES.
 #define G2_PX_BYTES 32768
 #define G2_PX_FLAGS 28672
+#define DLX_PX_BYTES 65536
+#define DLX_PX_FLAGS 61440
 // the four rows node0 .. node0 + 3 (node0 % 4 == 0) of feature f: one 8-byte store per term
 __device__ __forceinline__ void g2_publish_planes(unsigned char* px, int kp, int f, int node0, const float (&v)[4]) {
   uint32_t h0, m0, l0, h1, m1, l1;
@@ -169,17 +172,17 @@ __device__ __forceinline__ void g2_publish_planes(unsigned char* px, int kp, int
   *(uint2*)(p + 2 * ts) = make_uint2(l0, l1);
 }
 // every store of the wave so far is in the L2; then its flag
-__device__ __forceinline__ void g2_flag_raise(unsigned char* px, int slot, uint32_t tag, int lane) {
+__device__ __forceinline__ void g2_flag_raise(unsigned char* px, int slot, uint32_t tag, int lane, int flags_off = G2_PX_FLAGS) {
 #ifndef IGMC_HIPEMU
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0) __hip_atomic_store((unsigned long long*)(px + G2_PX_FLAGS) + slot, (unsigned long long)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  if (lane == 0) __hip_atomic_store((unsigned long long*)(px + flags_off) + slot, (unsigned long long)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 #else
-  if (lane == 0) ((unsigned long long*)(px + G2_PX_FLAGS))[slot] = (unsigned long long)tag;
+  if (lane == 0) ((unsigned long long*)(px + flags_off))[slot] = (unsigned long long)tag;
 #endif
 }
 // the wave waits until the first n flags of the region carry this exchange's tag (lane i polls flag i)
-__device__ __forceinline__ void g2_flags_wait(const unsigned char* px, int n, uint32_t tag, int lane, int* err) {
-  const unsigned long long* fl = (const unsigned long long*)(px + G2_PX_FLAGS);
+__device__ __forceinline__ void g2_flags_wait(const unsigned char* px, int n, uint32_t tag, int lane, int* err, int flags_off = G2_PX_FLAGS) {
+  const unsigned long long* fl = (const unsigned long long*)(px + flags_off);
   for (long it = 0;; ++it) {
 #ifndef IGMC_HIPEMU
     const unsigned long long w = (lane < n) ? __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned long long)tag;
@@ -197,6 +200,12 @@ __device__ __forceinline__ void g2_flags_wait(const unsigned char* px, int n, ui
     hipemu::yield();
 #endif
   }
+}
+// ... the same without writing past the image: the last piece is copied by the lanes that hold bytes of it only
+__device__ __forceinline__ void g2_planes_load_exact(uint32_t* pl, const unsigned char* px, int bytes, int wave, int lane, int nwaves) {
+  const int pieces = (bytes + 1023) >> 10;
+  for (int c = wave; c < pieces; c += nwaves)
+    if (c * 1024 + lane * 16 < bytes) g2_glds16<16>((const float4*)px + c * 64, (float4*)pl + c * 64, lane);
 }
 // planes of one side, global -> LDS, 1 KB pieces dealt to the waves of the workgroup (the LDS image is padded to whole pieces)
 __device__ __forceinline__ void g2_planes_load(uint32_t* pl, const unsigned char* px, int kp, int wave, int lane, int nwaves) {

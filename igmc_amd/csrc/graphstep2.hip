@@ -1343,6 +1343,12 @@ static DlSplit dl_split(int cap_u, int cap_v, int B) {
 #define DL_DECODE(a, bid, g, rem, side, q, nqs)                                      \
   const int g = (bid) / ((a).nqu + (a).nqv), rem = (bid) - g * ((a).nqu + (a).nqv);  \
   const int side = rem >= (a).nqu ? 1 : 0, q = side ? rem - (a).nqu : rem, nqs = side ? (a).nqv : (a).nqu
+// ... of the ONE-LAUNCH kernels (k_dl_fwd / k_dl_bwd), whose members exchange rows through the L2 of one XCD: workgroups are
+// dealt to the eight XCDs round robin by index, so the members rem = 0 .. nmem - 1 of subgraph 8 j + x are the workgroups
+// 8 nmem j + 8 rem + x (the launch is padded to whole blocks of 8 nmem workgroups; g >= B: nothing to do)
+#define DLX_DECODE(a, bid, g, rem, side, q, nqs)                                                              \
+  const int g = ((bid) / (8 * ((a).nqu + (a).nqv))) * 8 + ((bid) & 7), rem = ((bid) >> 3) % ((a).nqu + (a).nqv); \
+  const int side = rem >= (a).nqu ? 1 : 0, q = side ? rem - (a).nqu : rem, nqs = side ? (a).nqv : (a).nqu
 #define DL_PIT 2                  // plane-staging items per thread: 128 * k-steps / DL_THREADS, k-steps <= 8
 #define DL_RIT 17                 // block-row dwords per lane: 16 rows x (32 * k-steps + 8) / 4 / 64, k-steps <= 8
 // LDS plan (4-byte words): [own rows XOA][TS: h_{l-1} rows HSA, d bias scratch][planes | block rows | weight image][sums]
@@ -1781,6 +1787,7 @@ struct DlfArgs {
   int* gs_err;
   int self_seq;                  // 1: the last workgroup advances the launch sequence number (no kernel follows that would)
   int timing;                    // debug aid: workgroup + 1 whose phase clocks are recorded (DL_STAMP)
+  int B;                         // subgraphs of the batch (the launch is padded to XCD-aligned blocks of workgroups)
 };
 
 // NG = relation groups (g2_image.h): NG > 1 takes the relations five at a time -- gather of group g, then the transform with
@@ -1798,12 +1805,16 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int bid = blockIdx.x;
-  DL_DECODE(a, bid, g, rem, side, q, nqs);
+  DLX_DECODE(a, bid, g, rem, side, q, nqs);
+  if (g >= a.B) {                                // padding of the launch
+    dlx_seq_done(a.gs_bar, a.self_seq);
+    return;
+  }
   const int cu = a.n_users[g], cv = a.n_items[g];
   const int n_own = side ? cv : cu, n_opp = side ? cu : cv;
   const uint32_t seq = g2_ld_seq(a.gs_bar);
   const uint32_t tag0 = seq * 8u + 1u;
-  auto tag16 = [&](int x) { return 1u + (tag0 + (uint32_t)x) % 65535u; };
+  auto xtag = [&](int x) { return tag0 + (uint32_t)x; };      // flag value of exchange x of this launch (never 0)
   const DlRows dr = dl_rows(n_own, nqs, q);
   if (dr.nact == 0) {                            // nothing of this side in the workgroup's rows: nobody waits for it
     dlx_seq_done(a.gs_bar, a.self_seq);
@@ -1828,25 +1839,10 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
   float* sT0 = (NG == 1) ? HIA + DL_NW * 16 * G2_XP : (float*)sW2 + G2_WIMG;      // [32][32] / behind the image: [64][32]
   const int row0 = dr.base + 16 * wave;
   const bool active = wave < dr.nact;
+  // plane exchange regions (g2_prims.h: bf16 term planes [term][feature][kp] + a flag per bundle, through the XCD's L2)
   const size_t exs = a.ex_stride;
-  unsigned long long* ex_own = a.ex + ((size_t)g * 2 + side) * (32 * DLX_K);
-  const unsigned long long* ex_opp = a.ex + ((size_t)g * 2 + (1 - side)) * (32 * DLX_K);
-
-  // ---- every 4096 launches the side's region is cleared in all exchange buffers -- a 16-bit tag then never meets a word
-  //      older than 4096 launches (tags repeat after 65535) -- by the rows' owners of THIS launch (nobody else writes
-  //      them), workgroup 0 also taking the rows past the side up to the slot capacity (nobody's in this launch)
-  if ((seq & 4094u) == 0u) {      // (either parity of the sequence number: a path that advances it twice per step only ever shows one)
-    const int rcap = 128 * nqs < DLX_K ? 128 * nqs : DLX_K;
-    for (int part = 0; part < (q == 0 ? 2 : 1); ++part) {
-      const int r0 = part ? ((n_own + 15) >> 4) << 4 : dr.base, r1 = part ? rcap : dr.base + 16 * dr.nact;
-      const int np = (r1 - r0) >> 1;                 // 16-byte stores (two rows) per feature
-      for (int x = 0; x < 5; ++x) {
-        unsigned long long* e = a.ex + x * exs + ((size_t)g * 2 + side) * (32 * DLX_K) + r0;
-        for (int i = tid; i < 32 * np; i += DL_THREADS) g2_store16(e + (i / np) * DLX_K + 2 * (i % np), 0u, 0u, 0u, 0u);
-      }
-    }
-    g2_wait_vm0();
-  }
+  auto px_of = [&](int x, int sd) { return (unsigned char*)(a.ex + (size_t)x * exs + ((size_t)g * 2 + sd) * (32 * DLX_K)); };
+  static_assert(32 * DLX_K * 8 == DLX_PX_BYTES, "an exchange region of the dense-layer kernels is 64 KB");
 
   // ---- staging: every global load of the set-up is requested before the first use
   const int ldb = side ? a.relmT_ld : a.relm_ld, ldw = ldb >> 2;
@@ -1915,23 +1911,32 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
   // epilogue of a layer: the bundle's rows -> LDS tile (next layer's own rows), h_l, exchange x = l (bf16 terms)
   auto fwd_out = [&](int l, const float (&v)[2][4], float* XO) {
     float* hrow = a.h[l] + (size_t)(own0 + row0 + 4 * kq) * 32 + li;
-    unsigned long long* exl = ex_own + l * exs + (size_t)li * DLX_K + row0 + 4 * kq;
-    const uint32_t tg = tag16(l);
+    float w[2][4];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      float w[4];
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) w[nt][rr] = (row0 + 4 * kq + rr < n_own) ? v[nt][rr] : 0.f;
+    // the planes and the bundle's flag first (what the other side waits for), the wave's own copies behind them
+    if (l < 3) {
+      g2_publish_planes(px_of(l, side), kp, li, row0 + 4 * kq, w[0]);
+      g2_publish_planes(px_of(l, side), kp, 16 + li, row0 + 4 * kq, w[1]);
+      g2_flag_raise(px_of(l, side), row0 >> 4, xtag(l), lane, DLX_PX_FLAGS);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const bool ok = row0 + 4 * kq + rr < n_own;
-        w[rr] = ok ? v[nt][rr] : 0.f;
-        XO[(4 * kq + rr) * G2_XP + 16 * nt + li] = w[rr];
-        if (ok) {
-          hrow[rr * 32 + 16 * nt] = w[rr];
+        XO[(4 * kq + rr) * G2_XP + 16 * nt + li] = w[nt][rr];
+        if (row0 + 4 * kq + rr < n_own) {
+          hrow[rr * 32 + 16 * nt] = w[nt][rr];
           if (l == 3 && a.zero_out) a.zero_out[(size_t)(own0 + row0 + 4 * kq + rr) * 32 + 16 * nt + li] = 0.f;
         }
       }
-      if (l < 3) g2_publish4(exl + (size_t)nt * 16 * DLX_K, 0, w, tg);
-    }
+  };
+  // the opposite side's planes of exchange x: wait for the flags of its bundles, then global -> LDS (landed by the barrier)
+  auto fetch = [&](int x) {
+    g2_flags_wait(px_of(x, 1 - side), (n_opp + 15) >> 4, xtag(x), lane, a.gs_err, DLX_PX_FLAGS);
+    g2_planes_load_exact(PLN, px_of(x, 1 - side), 192 * kp, wave, lane, DL_NW);
   };
 
   // ================================================================ layer 0: h_0 = tanh([hist | onehot(label) | 1] @ T0)
@@ -2005,7 +2010,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
     stage();
     const float bias0 = a.P[a.off_bias[l] + li], bias1 = a.P[a.off_bias[l] + 16 + li];
     DL_STAMP(3 + (l - 1) * 9);
-    dlx_reload(PLN, kp, ex_opp + (l - 1) * exs, npad_opp, tag16(l - 1), a.gs_err);
+    fetch(l - 1);
     __syncthreads();
     DL_STAMP(4 + (l - 1) * 9);
     f32x4 o[2];
@@ -2107,6 +2112,7 @@ struct DlbArgs {
   int* gs_bar;
   int* gs_err;
   int timing;
+  int B;                         // subgraphs of the batch (the launch is padded to XCD-aligned blocks of workgroups)
   // head != 0: the launch also runs the subgraph's readout + MLP head (head_sub.h) in its set-up -- every workgroup of a subgraph
   // for itself, under the latency of its block-row loads -- instead of a k_head_sub launch in front of it
   int head;
@@ -2139,7 +2145,8 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int bid = blockIdx.x;
-  DL_DECODE(a, bid, g, rem, side, q, nqs);
+  DLX_DECODE(a, bid, g, rem, side, q, nqs);
+  if (g >= a.B) return;                          // padding of the launch
   const int cu = a.n_users[g], cv = a.n_items[g];
   const int n_own = side ? cv : cu, n_opp = side ? cu : cv;
   const int R = a.R, L = a.L, RL = R * L, rows0 = RL + L + 1;
@@ -2165,7 +2172,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
   DL_STAMP(40);
   const uint32_t seq = g2_ld_seq(a.gs_bar);
   const uint32_t tag0 = seq * 8u + 1u;
-  auto tag16 = [&](int x) { return 1u + (tag0 + (uint32_t)x) % 65535u; };
+  auto xtag = [&](int x) { return tag0 + (uint32_t)x; };      // flag value of exchange x of this launch (never 0)
   const int nb = a.node_off[g];
   const int own0 = nb + (side ? cu : 0), opp0 = nb + (side ? 0 : cu);
   const int kp = a.kp, rmp = kp;
@@ -2182,8 +2189,8 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
   const int row0 = dr.base + 16 * wave;
   const bool active = wave < dr.nact;
   const size_t exs = a.ex_stride;
-  unsigned long long* ex_own = a.ex + ((size_t)g * 2 + side) * (32 * DLX_K);
-  const unsigned long long* ex_opp = a.ex + ((size_t)g * 2 + (1 - side)) * (32 * DLX_K);
+  // plane exchange regions (g2_prims.h: bf16 term planes + a flag per bundle, through the XCD's L2)
+  auto px_of = [&](int x, int sd) { return (unsigned char*)(a.ex + (size_t)x * a.ex_stride + ((size_t)g * 2 + sd) * (32 * DLX_K)); };
 
   // ---- staging: block rows, the target rows of dPre_3, the layer-0 inputs of the rows (layer-0 table gradient), image 3
   const int ldb = side ? a.relmT_ld : a.relm_ld, ldw = ldb >> 2;
@@ -2344,7 +2351,10 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
       float* HS = HSA + wave * 16 * G2_XP;
       DL_STAMP(sk);
       wpre(l, grp);
-      if (l < 3 && grp == 0) dlx_reload(PLN, kp, ex_opp + (5 - l) * exs, npad_opp, tag16(5 - l), a.gs_err);
+      if (l < 3 && grp == 0) {       // the opposite side's dPre_l: flags of its bundles, then global -> LDS (landed by the barrier)
+        g2_flags_wait(px_of(5 - l, 1 - side), (n_opp + 15) >> 4, xtag(5 - l), lane, a.gs_err, DLX_PX_FLAGS);
+        g2_planes_load_exact(PLN, px_of(5 - l, 1 - side), 192 * kp, wave, lane, DL_NW);
+      }
       stage();
       __syncthreads();                               // planes, image, dPre_l of the rows are in place
       DL_STAMP(sk + 1);
@@ -2405,8 +2415,6 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
           o[1] += og[1];
         }
         if (grp == ngr - 1) {
-          unsigned long long* exb = ex_own + (6 - l) * exs + (size_t)li * DLX_K + row0 + 4 * kq;
-          const uint32_t tgb = tag16(6 - l);
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
@@ -2415,12 +2423,13 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
               const float x = xprev[nt][rr];
               dv[nt][rr] = ok ? (o[nt][rr] + addv[nt][rr]) * (1.f - x * x) : 0.f;
             }
-            if (l > 1) g2_publish4(exb + (size_t)nt * 16 * DLX_K, 0, dv[nt], tgb);
+            if (l > 1) g2_publish_planes(px_of(6 - l, side), kp, 16 * nt + li, row0 + 4 * kq, dv[nt]);
             if (NG > 1 && grp > 0 && l > 1) {        // dPre_{l-1} of the rows becomes the next layer's own rows: nobody reads
 #pragma unroll                                       // this tile any more (the d root block belongs to group 0's product)
               for (int rr = 0; rr < 4; ++rr) XO[(4 * kq + rr) * G2_XP + 16 * nt + li] = dv[nt][rr];
             }
           }
+          if (l > 1) g2_flag_raise(px_of(6 - l, side), row0 >> 4, xtag(6 - l), lane, DLX_PX_FLAGS);      // the bundle's dPre_{l-1} is in the L2
         }
       }
       DL_STAMP(sk + 4);
@@ -2835,6 +2844,7 @@ void igmc_launch_dl_layer(const ModelDev& m, const BatchDev& b, const float* P, 
 // 1 = the forward of this arena's dense layers runs as ONE launch (k_dl_fwd): exchange regions for 256 nodes a side, every
 // workgroup of the launch resident at once (IGMC_DL_FUSED=0: the per-layer launches)
 int igmc_dl_fwd_eligible(const ModelDev& m, const BatchDev& b, int B) {
+  if (!igmc_g2_xcd_ok()) return 0;      // (the members' exchange goes through the L2 of one XCD)
   const char* e = getenv("IGMC_DL_FUSED");
   if (e && atoi(e) == 0) return 0;
   if (!igmc_dl_eligible(m, b, B) || !m.g2_ex || m.ex_nodes < DLX_K || b.graph_cap > m.g2_graphs) return 0;
@@ -2864,12 +2874,14 @@ void igmc_launch_dl_fwd(const ModelDev& m, const BatchDev& b, const float* P, in
   a.gs_bar = m.gs_bar; a.gs_err = m.gs_err;
   a.self_seq = self_seq;
   a.timing = getenv("IGMC_DL_TIMING") ? atoi(getenv("IGMC_DL_TIMING")) : 0;
-  const int grid = B * (a.nqu + a.nqv);
+  a.B = B;
+  const int grid = 8 * ((B + 7) / 8) * (a.nqu + a.nqv);      // (XCD-aligned blocks of 8 * members workgroups: DLX_DECODE)
   const int ng = g2_groups(m.R, m.L);
   const size_t sm = (size_t)dlf_words(a.kp, ng) * 4;
 #ifdef IGMC_HIPEMU
-  hipemu::rt().co_cs = a.nqu + a.nqv;                   // the members of a subgraph run together
-  hipemu::rt().co_stride = -1;                     // (= consecutive workgroups)
+  hipemu::rt().co_cs = a.nqu + a.nqv;                   // the members of a subgraph run together:
+  hipemu::rt().co_stride = 8;                           // workgroups 8 nmem j + x + 8 rem
+  hipemu::rt().co_block = 8 * (a.nqu + a.nqv);
 #endif
   if (ng == 1) {
     if (training) {
@@ -2895,6 +2907,7 @@ void igmc_launch_dl_fwd(const ModelDev& m, const BatchDev& b, const float* P, in
 // relations in groups: k_dl_fwd / k_head_sub / k_dl_bwd<*, NG> with the relation-space tables behind them -- all of it or
 // nothing (the per-layer kernels k_dl_layer0 / k_dl_layer stop at G2_NR relations)
 int igmc_dl_wide(const ModelDev& m, const BatchDev& b, int B) {
+  if (!igmc_g2_xcd_ok()) return 0;      // (the members' exchange goes through the L2 of one XCD)
   if (!dl_base_ok(m, b, B, 1)) return 0;
   const char* e = getenv("IGMC_DL_FUSED");
   if (e && atoi(e) != 2) return 0;
@@ -2914,6 +2927,7 @@ int igmc_dl_wide(const ModelDev& m, const BatchDev& b, int B) {
 }
 
 int igmc_dl_bwd_eligible(const ModelDev& m, const BatchDev& b, int B) {
+  if (!igmc_g2_xcd_ok()) return 0;      // (the members' exchange goes through the L2 of one XCD)
   if (!igmc_dl_fwd_eligible(m, b, B) || !igmc_dl_ts_eligible(m, b, B)) return 0;
   const char* e = getenv("IGMC_DL_FUSED");
   if (e && atoi(e) == 1) return 0;                 // (1: the forward only)
@@ -2943,11 +2957,13 @@ void igmc_launch_dl_bwd(const ModelDev& m, const BatchDev& b, int B, int use_fla
     a.head = 1; a.hb = b; a.hm = m; a.P = head->P; a.inj_mask = head->inj_mask; a.seed = head->seed; a.step = head->step;
     a.mult = head->mult; a.grad_scale = head->grad_scale; a.out = head->out;
   }
-  const int grid = B * (a.nqu + a.nqv);
+  a.B = B;
+  const int grid = 8 * ((B + 7) / 8) * (a.nqu + a.nqv);      // (XCD-aligned blocks of 8 * members workgroups: DLX_DECODE)
   const size_t sm = (size_t)dlb_words(a.kp, g2_groups(m.R, m.L)) * 4;
 #ifdef IGMC_HIPEMU
   hipemu::rt().co_cs = a.nqu + a.nqv;
-  hipemu::rt().co_stride = -1;
+  hipemu::rt().co_stride = 8;
+  hipemu::rt().co_block = 8 * (a.nqu + a.nqv);
 #endif
   if (g2_groups(m.R, m.L) == 1) {
     if (dense3) {
