@@ -114,26 +114,7 @@ __device__ __forceinline__ void g2_glds16(const float4* src_wave, float4* lds_wa
 #endif
 }
 
-// ---- exchange words ------------------------------------------------------------------------------------------------
-// plane word of one value: {hi | mid << 16, lo | tag << 16}; two nodes of one feature per 16-byte access
-// The store is a COMPILER-TRACKED sc1 buffer store (descriptor base = the wave's first lane's address, per-lane byte offset
-// behind it: every call site hands the lowest address to the first active lane).  As inline asm the compiler's vmcnt
-// bookkeeping did not see it: every wait for a load issued BEFORE an epilogue's publishes -- the next layer's weight image
-// in stage() -- then also waited for the oldest stores behind that load (profiles/r04_g2_tracked_stores_ab.txt).
-__device__ __forceinline__ void g2_store16(unsigned long long* p, uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
-#ifndef IGMC_HIPEMU
-  const u32x4 v = {x, y, z, w};
-  const unsigned long long pa = (unsigned long long)p;
-  const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pa);
-  const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pa >> 32));
-  const unsigned long long base = ((unsigned long long)bhi << 32) | blo;
-  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
-  __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)(pa - base), 0, 16);      // aux 16 = sc1: written through to the coherent level
-#else
-  p[0] = ((unsigned long long)y << 32) | x;
-  p[1] = ((unsigned long long)w << 32) | z;
-#endif
-}
+// ---- the readout words of the subgraph kernel: 8-byte {f32, tag}, polled ------------------------------------------------
 // (an ORDINARY 8-byte store: its readers -- g2_poll_f32, sc1 loads -- sit on the writer's XCD and find it in the shared L2
 //  ~250 ns after issue; written through to memory with sc1 it took ~570 ns, profiles/r05_experiments/xcd_oneway.txt)
 __device__ __forceinline__ void g2_pub_f32(unsigned long long* p, float v, uint32_t tag) {
@@ -211,95 +192,6 @@ __device__ __forceinline__ void g2_planes_load_exact(uint32_t* pl, const unsigne
 __device__ __forceinline__ void g2_planes_load(uint32_t* pl, const unsigned char* px, int kp, int wave, int lane, int nwaves) {
   const int pieces = (192 * kp + 1023) >> 10;
   for (int c = wave; c < pieces; c += nwaves) g2_glds16<16>((const float4*)px + c * 64, (float4*)pl + c * 64, lane);
-}
-
-// The planes [term][feature][node] of one side from its exchange region ex[feature][KMAX nodes]: nodes < npad (a
-// multiple of 16, <= 128) of all 32 features = 16 * npad word pairs, <= G2_PPT per thread of the 512.  Two halves, so that the round
-// trip can run under other work: g2_poll_issue requests every pair of the thread (16-byte sc1 buffer loads the compiler
-// tracks -- no inline asm, nothing to mis-schedule), g2_poll_finish consumes them; pairs whose tags are not this
-// exchange's are requested again until they are.
-#define G2_PPT 4                  // word pairs per thread: 32 features x 64 pairs / G2_THREADS
-struct G2Poll {
-  u32x4 v[G2_PPT];
-};
-#ifndef IGMC_HIPEMU
-__device__ __forceinline__ u32x4 g2_ld16_sc1(const unsigned long long* base, int byte_off) {
-  __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
-  return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);       // aux 16 = sc1: served by L2, bypasses this CU's L1
-}
-#endif
-__device__ __forceinline__ void g2_poll_issue(G2Poll& pq, const unsigned long long* ex, int npad) {
-#ifndef IGMC_HIPEMU
-  // pair p = thread + 512 u  ->  feature p >> 6, node pair p & 63 (pairs past npad are never consumed)
-  const int t0 = (int)threadIdx.x;
-  (void)npad;
-#pragma unroll
-  for (int u = 0; u < G2_PPT; ++u) pq.v[u] = g2_ld16_sc1(ex, (t0 + u * G2_THREADS) * 16);
-#else
-  (void)pq; (void)ex; (void)npad;
-#endif
-}
-__device__ __forceinline__ void g2_poll_finish(G2Poll& pq, uint32_t* pl, int kp, const unsigned long long* ex, int npad,
-                                               uint32_t tag16, int* err) {
-  const int hp = npad >> 1, total = 32 * hp, t0 = (int)threadIdx.x;      // pairs per feature, pairs in all
-  const int tstride = 32 * kp >> 1;                                       // dwords per term
-#ifndef IGMC_HIPEMU
-  (void)total;
-  const int q0 = t0 & 63;                                                 // this thread's node pair (of 64 per feature)
-  uint32_t pend = (q0 < hp) ? ((1u << G2_PPT) - 1u) : 0u;
-  const int d0 = ((t0 >> 6) * kp >> 1) + q0;                              // feature (t0 >> 6) + 8 u
-  for (int it = 0;; ++it) {
-#pragma unroll
-    for (int u = 0; u < G2_PPT; ++u) {
-      const u32x4 V = pq.v[u];
-      if ((pend & (1u << u)) && (V.y >> 16) == tag16 && (V.w >> 16) == tag16) {
-        const int d = d0 + u * ((G2_THREADS / 64) * kp >> 1);              // dword index inside a term's plane
-        pl[d] = (V.x & 0xFFFFu) | (V.z << 16);
-        pl[tstride + d] = (V.x >> 16) | (V.z & 0xFFFF0000u);
-        pl[2 * tstride + d] = (V.y & 0xFFFFu) | (V.w << 16);
-        pend &= ~(1u << u);
-      }
-    }
-    if (!pend) break;
-    if (it > (1 << 20)) {
-      *err = 1;
-      break;
-    }
-    __builtin_amdgcn_s_sleep(2);
-#pragma unroll
-    for (int u = 0; u < G2_PPT; ++u)
-      if (pend & (1u << u)) pq.v[u] = g2_ld16_sc1(ex, (t0 + u * G2_THREADS) * 16);
-  }
-#else
-  (void)pq;
-  for (int p = t0; p < total; p += G2_THREADS) {
-    const int f = p / hp, q = p - f * hp;
-    const unsigned long long* e = ex + f * 128 + 2 * q;
-    long spins = 0;
-    for (;;) {
-      const unsigned long long a = e[0], b2 = e[1];
-      if ((uint32_t)(a >> 48) == tag16 && (uint32_t)(b2 >> 48) == tag16) {
-        const uint32_t ax = (uint32_t)a, ay = (uint32_t)(a >> 32), bx = (uint32_t)b2, by = (uint32_t)(b2 >> 32);
-        const int d = (f * kp >> 1) + q;
-        pl[d] = (ax & 0xFFFFu) | (bx << 16);
-        pl[tstride + d] = (ax >> 16) | (bx & 0xFFFF0000u);
-        pl[2 * tstride + d] = (ay & 0xFFFFu) | (by << 16);
-        break;
-      }
-      if (++spins > (1L << 22)) {
-        *err = 1;
-        break;
-      }
-      hipemu::yield();
-    }
-  }
-#endif
-}
-__device__ __forceinline__ void g2_reload(uint32_t* pl, int kp, const unsigned long long* ex, int npad, uint32_t tag16,
-                                          int* err) {
-  G2Poll pq;
-  g2_poll_issue(pq, ex, npad);
-  g2_poll_finish(pq, pl, kp, ex, npad, tag16, err);
 }
 
 // one 8-byte {f32, tag} word, polled
@@ -399,69 +291,7 @@ __device__ __forceinline__ void g2_clock_close(unsigned long long* ts, unsigned 
 #endif
 
 // ---- exchange of the dense-layer kernels (k_dl_fwd / k_dl_bwd): regions of DLX_K nodes a side, 512-thread workgroups -----
-#define DLX_K 256
-#define DL_THREADS_PRIM 512
-// planes [term][feature][node] of one side from its exchange region ex[feature][DLX_K]: nodes < npad (a multiple of 16) of
-// all 32 features, 8 word pairs per thread of a 512-thread workgroup, polled until their tags are this exchange's
-__device__ __forceinline__ void dlx_reload(uint32_t* pl, int kp, const unsigned long long* ex, int npad, uint32_t tag16,
-                                           int* err) {
-  const int hp = npad >> 1, t0 = (int)threadIdx.x;
-  const int tstride = 32 * kp >> 1;
-#ifndef IGMC_HIPEMU
-  // pair p = thread + 512 u -> feature p >> 7, node pair p & 127
-  const int q0 = t0 & 127;
-  uint32_t pend = (q0 < hp) ? 0xFFu : 0u;
-  const int d0 = ((t0 >> 7) * kp >> 1) + q0;                               // feature (t0 >> 7) + 4 u
-  u32x4 v[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) v[u] = g2_ld16_sc1(ex, (t0 + u * DL_THREADS_PRIM) * 16);
-  for (int it = 0;; ++it) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const u32x4 V = v[u];
-      if ((pend & (1u << u)) && (V.y >> 16) == tag16 && (V.w >> 16) == tag16) {
-        const int d = d0 + u * (4 * kp >> 1);
-        pl[d] = (V.x & 0xFFFFu) | (V.z << 16);
-        pl[tstride + d] = (V.x >> 16) | (V.z & 0xFFFF0000u);
-        pl[2 * tstride + d] = (V.y & 0xFFFFu) | (V.w << 16);
-        pend &= ~(1u << u);
-      }
-    }
-    if (!pend) break;
-    if (it > (1 << 20)) {
-      *err = 1;
-      break;
-    }
-    __builtin_amdgcn_s_sleep(2);
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (pend & (1u << u)) v[u] = g2_ld16_sc1(ex, (t0 + u * DL_THREADS_PRIM) * 16);
-  }
-#else
-  for (int p = t0; p < 32 * hp; p += DL_THREADS_PRIM) {
-    const int f = p / hp, q = p - f * hp;
-    const unsigned long long* e = ex + f * DLX_K + 2 * q;
-    long spins = 0;
-    for (;;) {
-      const unsigned long long a = e[0], b2 = e[1];
-      if ((uint32_t)(a >> 48) == tag16 && (uint32_t)(b2 >> 48) == tag16) {
-        const uint32_t ax = (uint32_t)a, ay = (uint32_t)(a >> 32), bx = (uint32_t)b2, by = (uint32_t)(b2 >> 32);
-        const int d = (f * kp >> 1) + q;
-        pl[d] = (ax & 0xFFFFu) | (bx << 16);
-        pl[tstride + d] = (ax >> 16) | (bx & 0xFFFF0000u);
-        pl[2 * tstride + d] = (ay & 0xFFFFu) | (by << 16);
-        break;
-      }
-      if (++spins > (1L << 22)) {
-        *err = 1;
-        break;
-      }
-      hipemu::yield();
-    }
-  }
-#endif
-}
-
+#define DLX_K 256                 // nodes a side of the dense-layer kernels (an exchange region = 32 * DLX_K 8-byte words = DLX_PX_BYTES)
 // launch sequence number of the exchange tags: advanced once per launch chain, after every workgroup has read it
 __device__ __forceinline__ void dlx_seq_done(int* gs_bar, int self_seq) {
   if (threadIdx.x != 0 || !self_seq) return;

@@ -220,16 +220,6 @@ __device__ __forceinline__ void g2_transform(const f32x4 (&acc)[G2_NR][2], const
   }
 }
 
-// the four rows 4 kq .. 4 kq + 3 of output feature f as exchange words: two 16-byte stores
-__device__ __forceinline__ void g2_publish4(unsigned long long* exf, int node0, const float (&v)[4], uint32_t tag16) {
-  uint32_t h0, m0, l0, h1, m1, l1;
-  g2_split2(v[0], v[1], h0, m0, l0);
-  g2_split2(v[2], v[3], h1, m1, l1);
-  const uint32_t tg = tag16 << 16;
-  g2_store16(exf + node0, (h0 & 0xFFFFu) | (m0 << 16), (l0 & 0xFFFFu) | tg, (h0 >> 16) | (m0 & 0xFFFF0000u), (l0 >> 16) | tg);
-  g2_store16(exf + node0 + 2, (h1 & 0xFFFFu) | (m1 << 16), (l1 & 0xFFFFu) | tg, (h1 >> 16) | (m1 & 0xFFFF0000u), (l1 >> 16) | tg);
-}
-
 // Everything the kernel reads, in ONE compact argument block (the full BatchDev / ModelDev / GsArgs views are ~1.3 KB of
 // kernel arguments: loading and address-forming from them cost ~1200 scalar instructions before the first useful load).
 struct G2Args {
@@ -1302,7 +1292,6 @@ struct DlArgs {
 // (DL_FMAC: g2_prims.h)
 #define DL_NW 8                   // waves (= 16-row bundles) per workgroup of the dense layer kernel
 #define DL_THREADS (64 * DL_NW)
-static_assert(DL_THREADS == DL_THREADS_PRIM, "dlx_reload (g2_prims.h) is written for this workgroup size");
 // The rows of a side are split EVENLY over its nq workgroups, in whole 16-row bundles: workgroup q takes bundles [bpw q, bpw (q + 1))
 // with bpw = ceil(bundles of the side / nq) <= DL_NW.  (First-fill -- 128 rows to workgroup 0, the rest to workgroup 1 -- left a
 // flixster launch waiting for its one 8-bundle workgroup while half of the workgroups had no rows at all.)
