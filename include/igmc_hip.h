@@ -295,8 +295,12 @@ int igmc_adam_step_ctrl(float* d_params, const float* d_grad, float* d_exp_avg, 
  *                         trip, bit-identical replicas, capturable.  _alloc creates the rank's buffer (slots of `max_floats`)
  *                         and returns its 64-byte IPC handle; the caller hands the handles of all ranks (world x 64 bytes,
  *                         rank order, any transport) to _connect.  Used like any other communicator afterwards.
- *   igmc_comm_check     : synchronises `stream`; fails if a bounded poll of the peer exchange ran out (a rank that never
- *                         published); igmc_comm_kind: 0 one rank, 1 RCCL, 2 host callback, 3 peer-mapped buffers (4: in fine-grained memory).
+ *                         A one-rank peer communicator launches nothing (the spans are the sums).  The polls are bounded by
+ *                         WALL-CLOCK time (IGMC_PEER_TIMEOUT_S, default 60 s): a word that never arrives leaves the spans
+ *                         unsummed, raises a device word, and the gradient / Adam kernel of igmc_train_step_dp behind the
+ *                         exchange then touches no parameter, moment or step counter.
+ *   igmc_comm_check     : synchronises `stream`; fails -- once -- if a rank's words did not arrive in time in a peer exchange
+ *                         since the last check; igmc_comm_kind: 0 one rank, 1 RCCL, 2 host callback, 3 peer-mapped buffers (4: in fine-grained memory).
  */
 typedef struct igmc_comm igmc_comm;
 typedef int (*igmc_allreduce_fn)(void* user, float* d_buf, int64_t n, void* stream);

@@ -1,6 +1,7 @@
-"""More than 65535 training launches in one process per path: the 16-bit tags of the exchange words wrap (the 4096-launch
-clears of the exchange regions are what keeps a reader from ever meeting a stale word with its launch's tag), bounded polls
-and the arena stamps are checked by StepGraph.check() after every epoch.
+"""Long runs in one process per path (70 k+ training launches): the exchange flags carry the launch sequence number (32 bits
+since round 5: no tag wrap, no periodic clear of the exchange regions -- rounds 3 / 4 had 16-bit tags in the data words);
+bounded polls and the arena stamps are checked by StepGraph.check() after every epoch, with evaluation batches between the
+epochs (they advance the sequence number by one: both parities).
    python tools/exp_tag_wrap.py [ml_1m|ml_100k|flixster ...]"""
 import os
 import sys
