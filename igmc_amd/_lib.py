@@ -77,6 +77,7 @@ SIGNATURES = {
                                  f32, f32, vp]),
     'igmc_ctrl_tick': (i32, [vp, vp]),
     'igmc_ctrl_regroup': (i32, [vp, i32, i64, i64, vp]),
+    'igmc_ctrl_gate': (i32, [vp, i32, i32, f64, i32, f64, vp]),
     'igmc_batch_set_ctrl': (i32, [vp, vp]),
     'igmc_model_set_ctrl': (i32, [vp, vp]),
     'igmc_adam_step_ctrl': (i32, [vp, vp, vp, vp, i64, vp, vp]),

@@ -981,6 +981,14 @@ extern "C" int igmc_ctrl_regroup(int64_t* d_ctrl, int M, int64_t first_cur, int6
   HIPCHECK(hipGetLastError());
   return 0;
 }
+extern "C" int igmc_ctrl_gate(const int64_t* d_ctrl, int q, int gk_min, double delay_us, int delay_always, double timeout_us,
+                              void* stream) {
+  if (!d_ctrl || gk_min < 0 || !(timeout_us >= 0.0) || !(delay_us >= 0.0) || delay_us > 1000.0) IGMC_FAIL("bad arguments");
+  // (wall_clock64: 100 MHz)
+  igmc_launch_gate(d_ctrl, q & 1, gk_min, (long long)(delay_us * 100.0), delay_always != 0, (long long)(timeout_us * 100.0), stream);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
 extern "C" int igmc_batch_set_ctrl(igmc_batch* b, const int64_t* d_ctrl) {
   if (!b) IGMC_FAIL("null batch");
   b->ctrl = d_ctrl;

@@ -2210,6 +2210,32 @@ __global__ void k_regroup(int64_t* ctrl, int M, int64_t first_cur, int64_t first
   ctrl[IGMC_CTRL_FIRST_ODD] = first_next;
 }
 
+// pacing gate of the extraction chain (igmc_ctrl_gate): one wave that returns once `gk_min` steps of the group of parity q
+// are done -- or that group is over, or `timeout_ticks` of the 100 MHz wall clock have passed -- and then, if it had to wait
+// for that step (or `delay_always`), `delay_ticks` later: the step that has just begun gets its workgroups onto the chip first.
+// The kernels queued behind the gate on its stream start then.  A HINT, never a dependency: whatever follows the gate is
+// correct at any time (the extraction of the NEXT group touches nothing the running group reads), so a gate that gives up
+// only costs the pacing.
+__global__ void k_step_gate(const int64_t* ctrl, int q, int gk_min, long long delay_ticks, int delay_always,
+                            long long timeout_ticks) {
+#ifndef IGMC_HIPEMU
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const long long t0 = wall_clock64();
+  bool waited = false;
+  for (;;) {
+    if ((igmc_ctrl_ld(ctrl + IGMC_CTRL_GQ) & 1) != (int64_t)(q & 1)) return;
+    if (igmc_ctrl_ld(ctrl + IGMC_CTRL_GK) >= (int64_t)gk_min) break;
+    if (wall_clock64() - t0 > timeout_ticks) return;
+    waited = true;
+    __builtin_amdgcn_s_sleep(16);
+  }
+  if (waited || delay_always) {
+    const long long t1 = wall_clock64();
+    while (wall_clock64() - t1 < delay_ticks) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
+}
+
 __global__ __launch_bounds__(IGMC_BLOCK) void k_adam(float* __restrict__ p, const float* __restrict__ g,
                                                        float* __restrict__ m1, float* __restrict__ m2, int64_t n,
                                                        float step_size, float inv_sqrt_bc2, float beta1, float beta2,
@@ -2681,6 +2707,10 @@ void igmc_launch_sse(const BatchDev& b, const float* out, double* acc, void* str
 void igmc_launch_tick(int64_t* ctrl, void* stream) { IGMC_PLAUNCH("k_tick", k_tick, 1, 64, 0, stream, ctrl); }
 void igmc_launch_regroup(int64_t* ctrl, int M, int64_t first_cur, int64_t first_next, void* stream) {
   IGMC_PLAUNCH("k_regroup", k_regroup, 1, 64, 0, stream, ctrl, M, first_cur, first_next);
+}
+void igmc_launch_gate(const int64_t* ctrl, int q, int gk_min, long long delay_ticks, int delay_always, long long timeout_ticks,
+                      void* stream) {
+  IGMC_PLAUNCH("k_step_gate", k_step_gate, 1, 64, 0, stream, ctrl, q, gk_min, delay_ticks, delay_always, timeout_ticks);
 }
 
 // (one workgroup per 2048 elements, at most 256: the tick of the step's last workgroup is an atomic round trip per workgroup on

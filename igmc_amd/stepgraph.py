@@ -126,26 +126,36 @@ class GroupPipeline(object):
         cur = [self._arena(q, i) for i in range(self.M)]
         for i in range(self.M):
             self._arena(1 - q, i)
-        # PACED extraction (default): launch j of the next group's extraction may start when step j * per of this group
-        # starts (= when the step before it has finished) -- never in the middle of a step.  The subgraph kernel needs a CU
-        # to itself (one wave per SIMD with the whole register file): dispatched together with an extraction launch it takes
-        # its 200 CUs first and the extraction workgroups fill the other 56; an extraction launch that is already spread over
-        # the chip when the subgraph kernel arrives makes its workgroups wait for whole CUs to drain (+13 us on such steps).
-        # Default where the subgraph kernel takes the steps (same-box: its launches 63.2 -> 60.8 us, step 87.8 -> 87.3 us);
-        # elsewhere the extraction chain runs free beside the group's steps (the longer chain of the cap-200 arenas, confined
-        # to the CUs the dense-layer launches leave, would reach the group's join late: 125.8 -> 129.9 us).  IGMC_EXTRACT_PACED=0|1.
+        # PACED extraction (default where the subgraph kernel takes the steps): launch j of the next group's extraction is held
+        # back until step j * per of this group has begun -- and 10 us longer.  The subgraph kernel's workgroups need whole CUs
+        # (two waves per SIMD with 256 registers each): once its 200-224 workgroups are on the chip an extraction launch runs in
+        # the CUs it leaves and costs the step ~3 us; dispatched TOGETHER with it (or just before it) the extraction's
+        # workgroups take CUs the subgraph kernel then waits for: +14 us on that step, and as a launch of two batches lasts about
+        # as long as a step the two stay in lock-step for several steps (tools/exp_group_timeline.py: in-graph wall-clock
+        # marks; profiles/r05_experiments/group_timeline_*.txt).
+        # HOW a launch is held back (IGMC_EXTRACT_PACED): 2 (default) = a one-wave GATE kernel in front of it on the extraction
+        # chain that polls the control block's step counter and then waits IGMC_GATE_DELAY_US (igmc_ctrl_gate) -- no edge
+        # leaves the step chain; 1 = an edge from the end of step j * per - 1 (the launch then starts with the step: 75.5 vs
+        # 74.3 us/step in the 20-step form); 0 = not at all (76.1).  Elsewhere (dense-layer kernels, sort-pool family) the
+        # extraction chain runs free beside the group's steps: the longer chain of the cap-200 arenas, confined to the CUs the
+        # dense-layer launches leave, would reach the group's join late (125.8 -> 129.9 us, round 4).
         plan = self._extract_plan(1 - q, self.M)
-        paced = os.environ.get('IGMC_EXTRACT_PACED', '1' if self._paced_default() else '0') != '0' and len(plan) > 1
+        mode = os.environ.get('IGMC_EXTRACT_PACED', '2' if self._paced_default() else '0')
+        paced = mode != '0' and len(plan) > 1
         per = max(1, self.M // max(1, len(plan)))
         self._fork()
         nxt = 0
         for i in range(self.M):
-            mark = self._mark() if (paced and nxt < len(plan) and i == nxt * per and i > 0) else None
+            mark = None
+            if paced and nxt < len(plan) and i == nxt * per and (i > 0 or mode == '2'):
+                mark = self._mark() if mode == '1' else ('gate', q, i)
             if q == 1 or i > 0:
                 # inside a pair of groups nothing but the previous step touches the parameters: that step left the weight
                 # images of its updated parameters behind, this one starts with the subgraph kernel
                 self._hint_unchanged()
-            # (the model kernels are enqueued BEFORE the extraction launch that becomes ready with them)
+            # (the model kernels are enqueued BEFORE the extraction launch that becomes ready with them: capturing the group's
+            #  first extraction launch in front of its first step makes the launch start before the subgraph kernel is on the
+            #  chip -- 78.0 vs 74.3 us/step in the 20-step form, profiles/r05_experiments)
             self._enqueue_step(cur[i], self.B)
             if paced and nxt < len(plan) and i == nxt * per:
                 self._side_after(mark, plan[nxt])
@@ -400,9 +410,20 @@ class StepGraph(GroupPipeline):
         ev.record(torch.cuda.current_stream())
         return ev
 
+    GATE_TIMEOUT_US = 2000.0      # a gate that has not seen its step after this long lets the extraction go (a hint only)
+    GATE_DELAY_US = 10.0          # ... and it opens this long after its step began (IGMC_GATE_DELAY_US): the step's subgraph kernel
+                                  # is on the chip by then, the extraction launch takes the CUs it leaves
+
     def _side_after(self, mark, fn):
         if self.side is not None and mark is not None:
-            self.side.wait_event(mark)
+            if isinstance(mark, tuple):         # ('gate', q, steps of the group that must be done)
+                # (the first launch of a group has no step to wait for: it is released at the group's start, together with
+                #  the group's first step -- the delay applies to it unconditionally)
+                delay = float(os.environ.get('IGMC_GATE_DELAY_US', self.GATE_DELAY_US))
+                self.lib.call('igmc_ctrl_gate', C.c_void_p(self.ctrl.data_ptr()), int(mark[1]), int(mark[2]), delay,
+                              1 if int(mark[2]) == 0 else 0, self.GATE_TIMEOUT_US, C.c_void_p(self.side.cuda_stream))
+            else:
+                self.side.wait_event(mark)
         self._side(fn)
 
     def begin_epoch(self, perm, epoch):

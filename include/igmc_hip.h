@@ -231,6 +231,14 @@ int igmc_ctrl_tick(int64_t* d_ctrl, void* stream);
 /* Starts a new group at the current position (no reference counterpart): M steps per group, gk = 0, gq = 0,
  * cursor_0 = first_cur (the batch of the next step), cursor_1 = first_next (first batch of the group after it). */
 int igmc_ctrl_regroup(int64_t* d_ctrl, int M, int64_t first_cur, int64_t first_next, void* stream);
+/* Pacing gate for work on ANOTHER stream (no reference counterpart): a one-wave kernel on `stream` that ends once gk_min
+ * steps of the running group of parity q are done (ctrl.gk >= gk_min), or that group is over (ctrl.gq != q), or timeout_us
+ * microseconds have passed -- whichever comes first; when it had to wait for the step counter (or delay_always != 0) it ends
+ * delay_us (<= 1000) later, so that the step which has just begun has its workgroups on the chip before whatever is queued
+ * behind the gate on `stream` (the extraction of the next group's batches) starts beside it: an extraction launch dispatched
+ * TOGETHER with the subgraph kernel costs that step ~14 us, one dispatched 10 us behind it ~3 (profiles/r05_experiments).
+ * No graph edge leaves the step chain.  A hint, not a dependency: the work behind the gate must be correct whenever it runs. */
+int igmc_ctrl_gate(const int64_t* d_ctrl, int q, int gk_min, double delay_us, int delay_always, double timeout_us, void* stream);
 int igmc_batch_set_ctrl(igmc_batch* b, const int64_t* d_ctrl);
 int igmc_model_set_ctrl(igmc_model* m, const int64_t* d_ctrl);
 /* Adam + loss/epoch-total epilogue in ONE launch (the step's last kernel): updates d_params like

@@ -240,6 +240,65 @@ def test_main_script_end_to_end(tmp_path):
     assert (res / 'cmd_input.txt').exists()
 
 
+def test_step_gate_waits_for_the_step_counter():
+    """igmc_ctrl_gate: a one-wave kernel on the extraction chain's stream that ends when the running group has done its
+    gk_min steps (the tick of a step on ANOTHER stream releases it), when that group is over, or after its timeout -- a
+    pacing hint without a graph edge out of the step chain."""
+    import ctypes as C
+    import time
+    import torch
+    from igmc_amd import _lib
+    lib = _lib.load()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    ctrl = torch.zeros(_lib.CTRL['WORDS'], dtype=torch.int64, device='cuda')
+    main = torch.cuda.current_stream()
+    lib.call('igmc_ctrl_regroup', vp(ctrl), 4, 0, 200, C.c_void_p(main.cuda_stream))
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+
+    def gate(q, gk, timeout_us, delay_us=0.0, always=0):
+        lib.call('igmc_ctrl_gate', vp(ctrl), q, gk, float(delay_us), always, float(timeout_us), C.c_void_p(side.cuda_stream))
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        side.synchronize()
+        return time.perf_counter() - t0
+    # nothing to wait for: no step needed / the other parity's group is not the running one
+    assert timed(lambda: gate(0, 0, 50000)) < 0.02
+    assert timed(lambda: gate(1, 3, 50000)) < 0.02
+    # a step that never comes: the gate gives up after its timeout (and not before)
+    dt = timed(lambda: gate(0, 1, 20000))
+    assert 0.018 < dt < 0.2, dt
+
+    # released by the tick of a step on the other stream
+    def released():
+        gate(0, 1, 500000)
+        time.sleep(0.01)
+        assert not side.query()              # still polling
+        lib.call('igmc_ctrl_tick', vp(ctrl), C.c_void_p(main.cuda_stream))
+    dt = timed(released)
+    assert 0.009 < dt < 0.2, dt
+    assert int(ctrl[_lib.CTRL['GK']].item()) == 1
+    # ... and once the group of parity 0 is over (4 ticks: gq flips), its gates pass whatever they asked for
+    for _ in range(3):
+        lib.call('igmc_ctrl_tick', vp(ctrl), C.c_void_p(main.cuda_stream))
+    torch.cuda.synchronize()
+    assert int(ctrl[_lib.CTRL['GQ']].item()) == 1
+    assert timed(lambda: gate(0, 3, 500000)) < 0.02
+    # the delay behind the step: only for a gate that had to wait, or on request
+    lib.call('igmc_ctrl_regroup', vp(ctrl), 4, 0, 200, C.c_void_p(main.cuda_stream))
+    torch.cuda.synchronize()
+    t_no, t_always = min(timed(lambda: gate(0, 0, 50000, delay_us=1000.0)) for _ in range(5)), \
+        min(timed(lambda: gate(0, 0, 50000, delay_us=1000.0, always=1)) for _ in range(5))
+    assert t_no < 0.0009 and 0.001 <= t_always < 0.02, (t_no, t_always)
+    with pytest.raises(Exception):
+        lib.call('igmc_ctrl_gate', None, 0, 0, 0.0, 0, 1.0, None)
+    with pytest.raises(Exception):
+        lib.call('igmc_ctrl_gate', vp(ctrl), 0, 0, 5000.0, 0, 1.0, None)
+
+
 def test_step_graph_paths_agree(flix, monkeypatch):
     """The captured single-GPU step (igmc_train_step inside a hipGraph, the next group's extraction on a second stream;
     groups of 4 steps per graph launch here, one step per launch with IGMC_GROUP_STEPS=1), the eager step, and the

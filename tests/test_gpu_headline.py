@@ -373,6 +373,13 @@ def test_step_graph_is_bit_reproducible_and_structure_independent(ml1m, monkeypa
     sg_e, eager = _trajectory(ds, drop, perm, use_graph=False, overlap=False, group=8)
     assert not any(g is not None for g in sg_e.graphs)
     _assert_same(ref, eager, 'eager one-stream launches vs groups of 8')
+    # ... however the next group's extraction launches are held back beside the steps: gate kernels polling the step counter
+    # (the default here), edges out of the step chain, or not at all
+    for mode in ('1', '0'):
+        monkeypatch.setenv('IGMC_EXTRACT_PACED', mode)
+        _, pm = _trajectory(ds, drop, perm, group=8)
+        _assert_same(ref, pm, 'extraction pacing mode %s vs the gates' % mode)
+    monkeypatch.delenv('IGMC_EXTRACT_PACED')
     # ... == the data-parallel step (igmc_train_step_dp) on a one-rank RCCL communicator: the subgraph kernel's tables and
     # the lin gradients go through a grouped all-reduce captured between k_tail_ts and k_finalize_ts -- a sum over one rank
     monkeypatch.setenv('IGMC_FORCE_DP_PATH', '1')
