@@ -22,6 +22,10 @@ timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pyt
 timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; tail -2 $O/smoke.log
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err                      # the driver's default form (200 / 20, all legs)
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver.json 2> $O/bench_driver.err
+# (the 20-step form varies by a few us/step from run to run: four more short ones, timed region only)
+for i in 2 3 4 5; do
+  timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --dp-steps 0 --rmse-links 0 --no-secondary --no-floor --profile-steps 0 > $O/bench_driver_$i.json 2> $O/bench_driver_$i.err
+done
 for c in douban ml_100k flixster ml_10m_lite yahoo_music; do
   st=200; [ $c = yahoo_music ] && st=64
   timeout 400 python bench.py --config $c --steps $st --warmup 20 --no-cpu-baseline --dp-steps 0 > $O/bench_$c.json 2> $O/bench_$c.err
