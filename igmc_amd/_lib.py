@@ -94,7 +94,7 @@ SIGNATURES = {
 BUF = dict(NODE_OFF=0, N_USERS=1, NODE_LABEL=2, NODE_GID=3, NODE_GRAPH=4, ROW_PTR=5, ECR=6, ECODE=7,
            EFLAG=8, Y=9, TOTALS=10)
 CTRL = dict(STEP=0, FIRST=1, EPOCH=2, ADAM_T=3, BATCH=4, DONE=5, FIRST_ODD=6, K=7, LR=8, BETA1=9, BETA2=10, EPS=11, WD=12, STEP_SIZE=13,
-            INV_SQRT_BC2=14, GROUP=15, GK=16, GQ=17, SYNC_ERR=18, WORDS=24)
+            INV_SQRT_BC2=14, GROUP=15, GK=16, GQ=17, SYNC_ERR=18, GATE_TIMEOUTS=19, WORDS=24)
 ALLREDUCE_FN = C.CFUNCTYPE(i32, vp, vp, i64, vp)      # igmc_allreduce_fn (igmc_comm_create_host)
 P = dict(BASIS=0, ROOT=1, BIAS=2, ATT=3, LIN1_W=4, LIN1_B=5, LIN2_W=6, LIN2_B=7)
 

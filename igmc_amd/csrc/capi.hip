@@ -981,7 +981,7 @@ extern "C" int igmc_ctrl_regroup(int64_t* d_ctrl, int M, int64_t first_cur, int6
   HIPCHECK(hipGetLastError());
   return 0;
 }
-extern "C" int igmc_ctrl_gate(const int64_t* d_ctrl, int q, int gk_min, double delay_us, int delay_always, double timeout_us,
+extern "C" int igmc_ctrl_gate(int64_t* d_ctrl, int q, int gk_min, double delay_us, int delay_always, double timeout_us,
                               void* stream) {
   if (!d_ctrl || gk_min < 0 || !(timeout_us >= 0.0) || !(delay_us >= 0.0) || delay_us > 1000.0) IGMC_FAIL("bad arguments");
   // (wall_clock64: 100 MHz)

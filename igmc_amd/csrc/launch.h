@@ -24,7 +24,7 @@ void igmc_launch_relm_dropout(const BatchDev& b, int B, float p, int force_undir
                               const int64_t* ctrl, void* stream);
 void igmc_launch_tick(int64_t* ctrl, void* stream);
 void igmc_launch_regroup(int64_t* ctrl, int M, int64_t first_cur, int64_t first_next, void* stream);
-void igmc_launch_gate(const int64_t* ctrl, int q, int gk_min, long long delay_ticks, int delay_always, long long timeout_ticks,
+void igmc_launch_gate(int64_t* ctrl, int q, int gk_min, long long delay_ticks, int delay_always, long long timeout_ticks,
                       void* stream);
 void igmc_launch_fill_u8(uint8_t* p, int64_t n, uint8_t v, void* stream);
 int igmc_extract_prepare(size_t smem);

@@ -2216,7 +2216,7 @@ __global__ void k_regroup(int64_t* ctrl, int M, int64_t first_cur, int64_t first
 // The kernels queued behind the gate on its stream start then.  A HINT, never a dependency: whatever follows the gate is
 // correct at any time (the extraction of the NEXT group touches nothing the running group reads), so a gate that gives up
 // only costs the pacing.
-__global__ void k_step_gate(const int64_t* ctrl, int q, int gk_min, long long delay_ticks, int delay_always,
+__global__ void k_step_gate(int64_t* ctrl, int q, int gk_min, long long delay_ticks, int delay_always,
                             long long timeout_ticks) {
 #ifndef IGMC_HIPEMU
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -2225,7 +2225,10 @@ __global__ void k_step_gate(const int64_t* ctrl, int q, int gk_min, long long de
   for (;;) {
     if ((igmc_ctrl_ld(ctrl + IGMC_CTRL_GQ) & 1) != (int64_t)(q & 1)) return;
     if (igmc_ctrl_ld(ctrl + IGMC_CTRL_GK) >= (int64_t)gk_min) break;
-    if (wall_clock64() - t0 > timeout_ticks) return;
+    if (wall_clock64() - t0 > timeout_ticks) {      // (counted: a caller whose gates keep giving up paces by edges instead)
+      atomicAdd((unsigned long long*)(ctrl + IGMC_CTRL_GATE_TIMEOUTS), 1ull);
+      return;
+    }
     waited = true;
     __builtin_amdgcn_s_sleep(16);
   }
@@ -2708,7 +2711,7 @@ void igmc_launch_tick(int64_t* ctrl, void* stream) { IGMC_PLAUNCH("k_tick", k_ti
 void igmc_launch_regroup(int64_t* ctrl, int M, int64_t first_cur, int64_t first_next, void* stream) {
   IGMC_PLAUNCH("k_regroup", k_regroup, 1, 64, 0, stream, ctrl, M, first_cur, first_next);
 }
-void igmc_launch_gate(const int64_t* ctrl, int q, int gk_min, long long delay_ticks, int delay_always, long long timeout_ticks,
+void igmc_launch_gate(int64_t* ctrl, int q, int gk_min, long long delay_ticks, int delay_always, long long timeout_ticks,
                       void* stream) {
   IGMC_PLAUNCH("k_step_gate", k_step_gate, 1, 64, 0, stream, ctrl, q, gk_min, delay_ticks, delay_always, timeout_ticks);
 }

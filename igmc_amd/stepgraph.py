@@ -140,7 +140,7 @@ class GroupPipeline(object):
         # extraction chain runs free beside the group's steps: the longer chain of the cap-200 arenas, confined to the CUs the
         # dense-layer launches leave, would reach the group's join late (125.8 -> 129.9 us, round 4).
         plan = self._extract_plan(1 - q, self.M)
-        mode = os.environ.get('IGMC_EXTRACT_PACED', '2' if self._paced_default() else '0')
+        mode = os.environ.get('IGMC_EXTRACT_PACED', (getattr(self, 'pacing_fallback', None) or '2') if self._paced_default() else '0')
         paced = mode != '0' and len(plan) > 1
         per = max(1, self.M // max(1, len(plan)))
         self._fork()
@@ -648,7 +648,19 @@ class StepGraph(GroupPipeline):
         self.lib.call('igmc_model_check', self.ws.handle, C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if self.comm is not None and hasattr(self.comm, 'check'):       # (peer exchange: a bounded poll that ran out)
             self.comm.check(torch.cuda.current_stream().cuda_stream)
-        err = int(self.ctrl[_lib.CTRL['SYNC_ERR']].item())
+        words = self.ctrl.cpu()
+        err = int(words[_lib.CTRL['SYNC_ERR']])
+        # pacing gates that gave up (igmc_ctrl_gate): harmless one by one, but gates that KEEP timing out mean the two chains
+        # are not served concurrently here (dispatches serialised by a profiler, both streams on one hardware queue) and every
+        # gate costs its timeout: pace by graph edges from now on (the graph is captured again on its next use)
+        gave_up = int(words[_lib.CTRL['GATE_TIMEOUTS']])
+        if gave_up >= 4 and getattr(self, 'pacing_fallback', None) is None:
+            sys.stderr.write('igmc_amd: %d pacing gates of the extraction chain timed out (streams not served concurrently?); '
+                             'pacing by graph edges from here on\n' % gave_up)
+            self.pacing_fallback = '1'
+            self.graph = None
+        if gave_up:
+            self.ctrl[_lib.CTRL['GATE_TIMEOUTS']] = 0
         if err:
             what = []
             if err & 2:

@@ -226,7 +226,7 @@ enum { IGMC_CTRL_STEP = 0, IGMC_CTRL_FIRST = 1, IGMC_CTRL_EPOCH = 2, IGMC_CTRL_A
        IGMC_CTRL_DONE = 5, IGMC_CTRL_FIRST_ODD = 6, IGMC_CTRL_K = 7,
        IGMC_CTRL_LR = 8, IGMC_CTRL_BETA1 = 9, IGMC_CTRL_BETA2 = 10, IGMC_CTRL_EPS = 11, IGMC_CTRL_WD = 12,
        IGMC_CTRL_STEP_SIZE = 13, IGMC_CTRL_INV_SQRT_BC2 = 14, IGMC_CTRL_GROUP = 15, IGMC_CTRL_GK = 16,
-       IGMC_CTRL_GQ = 17, IGMC_CTRL_SYNC_ERR = 18, IGMC_CTRL_WORDS = 24 };
+       IGMC_CTRL_GQ = 17, IGMC_CTRL_SYNC_ERR = 18, IGMC_CTRL_GATE_TIMEOUTS = 19, IGMC_CTRL_WORDS = 24 };
 int igmc_ctrl_tick(int64_t* d_ctrl, void* stream);
 /* Starts a new group at the current position (no reference counterpart): M steps per group, gk = 0, gq = 0,
  * cursor_0 = first_cur (the batch of the next step), cursor_1 = first_next (first batch of the group after it). */
@@ -237,8 +237,11 @@ int igmc_ctrl_regroup(int64_t* d_ctrl, int M, int64_t first_cur, int64_t first_n
  * delay_us (<= 1000) later, so that the step which has just begun has its workgroups on the chip before whatever is queued
  * behind the gate on `stream` (the extraction of the next group's batches) starts beside it: an extraction launch dispatched
  * TOGETHER with the subgraph kernel costs that step ~14 us, one dispatched 10 us behind it ~3 (profiles/r05_experiments).
- * No graph edge leaves the step chain.  A hint, not a dependency: the work behind the gate must be correct whenever it runs. */
-int igmc_ctrl_gate(const int64_t* d_ctrl, int q, int gk_min, double delay_us, int delay_always, double timeout_us, void* stream);
+ * No graph edge leaves the step chain.  A hint, not a dependency: the work behind the gate must be correct whenever it runs.
+ * A gate that gives up counts itself in ctrl[IGMC_CTRL_GATE_TIMEOUTS]: where the two streams are not served concurrently (a
+ * profiler or AMD_SERIALIZE_KERNEL serialising dispatches, both streams on one hardware queue) every gate would cost its
+ * timeout -- the caller reads the counter and goes back to pacing by graph edges (StepGraph.check). */
+int igmc_ctrl_gate(int64_t* d_ctrl, int q, int gk_min, double delay_us, int delay_always, double timeout_us, void* stream);
 int igmc_batch_set_ctrl(igmc_batch* b, const int64_t* d_ctrl);
 int igmc_model_set_ctrl(igmc_model* m, const int64_t* d_ctrl);
 /* Adam + loss/epoch-total epilogue in ONE launch (the step's last kernel): updates d_params like

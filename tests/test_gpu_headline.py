@@ -380,6 +380,14 @@ def test_step_graph_is_bit_reproducible_and_structure_independent(ml1m, monkeypa
         _, pm = _trajectory(ds, drop, perm, group=8)
         _assert_same(ref, pm, 'extraction pacing mode %s vs the gates' % mode)
     monkeypatch.delenv('IGMC_EXTRACT_PACED')
+    # gates that KEEP giving up (here: a timeout of zero -- what a profiler that serialises the dispatches does to them at 2 ms
+    # apiece) are counted in the control block; the epoch's check() reads the count and the object paces by edges from then on
+    from igmc_amd.stepgraph import StepGraph
+    monkeypatch.setattr(StepGraph, 'GATE_TIMEOUT_US', 0.0)
+    sg_t, pt = _trajectory(ds, drop, perm, group=8)
+    assert sg_t.pacing_fallback == '1'
+    _assert_same(ref, pt, 'gates timing out, then edges, vs the gates')
+    monkeypatch.setattr(StepGraph, 'GATE_TIMEOUT_US', 2000.0)
     # ... == the data-parallel step (igmc_train_step_dp) on a one-rank RCCL communicator: the subgraph kernel's tables and
     # the lin gradients go through a grouped all-reduce captured between k_tail_ts and k_finalize_ts -- a sum over one rank
     monkeypatch.setenv('IGMC_FORCE_DP_PATH', '1')
