@@ -1786,12 +1786,23 @@ struct DlfArgs {
 __host__ __device__ static inline int dlf_words(int kp, int ng = 1) {
   return 2 * DL_NW * 16 * G2_XP + (G2_NT * 32 * kp >> 1) + DL_NW * 4 * kp + G2_WIMG + (ng > 1 ? 64 * 32 : 0);
 }
+// GS (group split, two relation groups, at most DL_NW / 2 bundles a workgroup): waves 0..3 take the bundles' first relation group,
+// waves 4..7 the second one, both groups' images resident -- half as many bundle slots (row tiles, block rows), one tile per bundle
+// for the second group's partial output, two images
+#define DL_GB (DL_NW / 2)
+__host__ __device__ static inline int dlf_words_gs(int kp) {
+  return 3 * DL_GB * 16 * G2_XP + (G2_NT * 32 * kp >> 1) + DL_GB * 4 * kp + 2 * G2_WIMG + 64 * 32;
+}
 
-template <bool FLAGS, bool STORE, int NG>
+template <bool FLAGS, bool STORE, int NG, bool GS = false>
 __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
+  static_assert(!GS || NG == 2, "the group split is for two relation groups");
   constexpr int HP = (NG == 1) ? G2_XP : DLF_HP2;
+  constexpr int NB = GS ? DL_GB : DL_NW;           // bundle slots of the workgroup
   IGMC_DYN_SMEM(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bw = GS ? (wave & (DL_GB - 1)) : wave;      // bundle of the wave, and (GS) the relation group it takes
+  const int gw = GS ? wave / DL_GB : 0;
   const int li = lane & 15, kq = lane >> 4;
   const int bid = blockIdx.x;
   DLX_DECODE(a, bid, g, rem, side, q, nqs);
@@ -1817,17 +1828,20 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
   const int kp = a.kp, rmp = kp;
   const int nks = (n_opp + 31) >> 5;
   const int npad_opp = ((n_opp + 15) >> 4) << 4;
-  float* XO0 = (float*)smem;                                              // [DL_NW][16][G2_XP] ping
-  float* XO1 = XO0 + DL_NW * 16 * G2_XP;                                  // pong
-  uint32_t* PLN = (uint32_t*)(XO1 + DL_NW * 16 * G2_XP);                  // [3][32][kp] bf16
-  unsigned char* RMW = (unsigned char*)(PLN + (G2_NT * 32 * kp >> 1));    // [DL_NW][16][rmp] bytes
-  float2* sW2 = (float2*)(RMW + DL_NW * 16 * rmp);                        // [G2_WIMG words]
+  float* XO0 = (float*)smem;                                              // [NB][16][G2_XP] ping
+  float* XO1 = XO0 + NB * 16 * G2_XP;                                     // pong
+  float* PXP = XO1 + NB * 16 * G2_XP;                                     // GS: [NB][16][G2_XP] the second group's partial outputs
+  uint32_t* PLN = (uint32_t*)(XO1 + (GS ? 2 : 1) * NB * 16 * G2_XP);      // [3][32][kp] bf16
+  unsigned char* RMW = (unsigned char*)(PLN + (G2_NT * 32 * kp >> 1));    // [NB][16][rmp] bytes
+  float2* sW2 = (float2*)(RMW + NB * 16 * rmp);                           // [G2_WIMG words]
   // layer 0 only, inside the image's space: one-hot label planes, the rows' inputs, the layer-0 table
   uint32_t* OHP = (uint32_t*)sW2;                                         // [8 labels][kp] bf16
-  float* HIA = (float*)(OHP + (8 * kp >> 1));                             // [DL_NW][16][HP]
+  float* HIA = (float*)(OHP + (8 * kp >> 1));                             // [NB][16][HP]
   float* sT0 = (NG == 1) ? HIA + DL_NW * 16 * G2_XP : (float*)sW2 + G2_WIMG;      // [32][32] / behind the image: [64][32]
-  const int row0 = dr.base + 16 * wave;
-  const bool active = wave < dr.nact;
+  float2* sW2b = (float2*)(sT0 + 64 * 32);                                // GS: the second group's image
+  const int row0 = dr.base + 16 * bw;
+  const bool active = bw < dr.nact;
+  const bool lead = !GS || gw == 0;                // the wave that owns the bundle's rows (set-up, layer 0, epilogues)
   // plane exchange regions (g2_prims.h: bf16 term planes [term][feature][kp] + a flag per bundle, through the XCD's L2)
   const size_t exs = a.ex_stride;
   auto px_of = [&](int x, int sd) { return (unsigned char*)(a.ex + (size_t)x * exs + ((size_t)g * 2 + sd) * (32 * DLX_K)); };
@@ -1842,7 +1856,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
   for (int u = 0; u < DL_RIT; ++u) {
     const int i = lane + 64 * u, r = i / rw, c = i - r * rw;
     const int rc = row0 + r < n_own ? row0 + r : n_own - 1, cc = c < ldw ? c : ldw - 1;
-    rmq[u] = ((const uint32_t*)(rsrc + (size_t)rc * ldb))[cc];
+    rmq[u] = lead ? ((const uint32_t*)(rsrc + (size_t)rc * ldb))[cc] : 0u;
   }
   const int own_lab = (int)a.node_label[own0 + (row0 + li < n_own ? row0 + li : n_own - 1)];
   int l0 = 255, l1 = 255;                         // labels of the opposite side's node pair tid (< 16 nks <= 128)
@@ -1870,19 +1884,30 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
       if (i < G2_WIMG / 4) ((f32x4*)sW2)[i] = wq[u];
     }
   };
+  // GS: the image of layer l for THIS wave's relation group, global -> LDS directly (no registers in between), 1 KB pieces
+  // dealt to the four waves of the group; requested when its space is free, landed by the barrier in front of its first use
+  auto wload = [&](int l) {
+    const float4* src = (const float4*)(a.g2_w + g2_img_off(NG, l, 0, gw));
+    float4* dst = (float4*)(gw ? sW2b : sW2);
+#pragma unroll
+    for (int j = 0; j < (G2_WIMG / 256 + DL_GB - 1) / DL_GB; ++j) {
+      const int c = bw + j * DL_GB;
+      if (c < G2_WIMG / 256) g2_glds16(src + c * 64, dst + c * 64, lane);
+    }
+  };
   G2_SCHED_BARRIER();
   {   // zero fills under the loads' latency: planes (k-steps past the published rows must read zeros), both row tiles, inputs
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < (G2_NT * 32 * kp >> 3); i += DL_THREADS) ((float4*)PLN)[i] = z4;
-    for (int i = tid; i < 2 * DL_NW * 16 * G2_XP / 4; i += DL_THREADS) ((float4*)XO0)[i] = z4;
-    for (int i = tid; i < DL_NW * 16 * HP / 4; i += DL_THREADS) ((float4*)HIA)[i] = z4;
+    for (int i = tid; i < 2 * NB * 16 * G2_XP / 4; i += DL_THREADS) ((float4*)XO0)[i] = z4;
+    for (int i = tid; i < NB * 16 * HP / 4; i += DL_THREADS) ((float4*)HIA)[i] = z4;
   }
   if (tid < 16 * nks) {
 #pragma unroll
     for (int lb = 0; lb < 8; ++lb) OHP[(lb * kp >> 1) + tid] = ((l0 == lb) ? 0x3F80u : 0u) | ((l1 == lb) ? 0x3F800000u : 0u);
   }
-  {
-    uint32_t* dst = (uint32_t*)(RMW + (size_t)wave * 16 * rmp);
+  if (lead) {
+    uint32_t* dst = (uint32_t*)(RMW + (size_t)bw * 16 * rmp);
 #pragma unroll
     for (int u = 0; u < DL_RIT; ++u) {
       const int i = lane + 64 * u, r = i / rw, c = i - r * rw;
@@ -1891,11 +1916,12 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
   }
   ((float2*)sT0)[tid] = t0v;
   if (NG > 1) ((float2*)sT0)[DL_THREADS + tid] = t0w;
-  wpre(1, 0);
+  if (!GS) wpre(1, 0);
+  else if (gw == 1) wload(1);                      // (the second group's image has a space of its own: free from the start)
   __syncthreads();
   DL_STAMP(1);
 
-  const unsigned char* rmo = RMW + (size_t)(wave * 16 + li) * rmp + 8 * kq;
+  const unsigned char* rmo = RMW + (size_t)(bw * 16 + li) * rmp + 8 * kq;
   const int kbit = side ? IGMC_RELM_KT : IGMC_RELM_KF;                   // keep bit of the edge opposite -> own
   // epilogue of a layer: the bundle's rows -> LDS tile (next layer's own rows), h_l, exchange x = l (bf16 terms)
   auto fwd_out = [&](int l, const float (&v)[2][4], float* XO) {
@@ -1929,9 +1955,9 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
   };
 
   // ================================================================ layer 0: h_0 = tanh([hist | onehot(label) | 1] @ T0)
-  if (active) {
+  if (active && lead) {
     const uint32_t* ohp = OHP + ((li & 7) * kp >> 1) + 4 * kq;
-    float* hi = HIA + wave * 16 * HP;
+    float* hi = HIA + bw * 16 * HP;
     const int row = row0 + li;
 #pragma unroll 1
     for (int grp = 0; grp < ngr; ++grp) {
@@ -1986,16 +2012,86 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
       v[0][rr] = g2_tanh(o0[rr]);
       v[1][rr] = g2_tanh(o1[rr]);
     }
-    fwd_out(0, v, XO0 + wave * 16 * G2_XP);
+    fwd_out(0, v, XO0 + bw * 16 * G2_XP);
   }
   __syncthreads();                                   // the image's space (one-hot planes, inputs, table) is free
   DL_STAMP(2);
+  if (GS && gw == 0) wload(1);
 
   // ================================================================ conv layers 1..3
 #pragma unroll 1
   for (int l = 1; l < 4; ++l) {
-    float* XOc = ((l & 1) ? XO0 : XO1) + wave * 16 * G2_XP;      // h_{l-1} of the bundle's rows
-    float* XOn = ((l & 1) ? XO1 : XO0) + wave * 16 * G2_XP;      // h_l
+    float* XOc = ((l & 1) ? XO0 : XO1) + bw * 16 * G2_XP;        // h_{l-1} of the bundle's rows
+    float* XOn = ((l & 1) ? XO1 : XO0) + bw * 16 * G2_XP;        // h_l
+    if constexpr (GS) {
+      // both groups at once: waves 0..3 gather and transform the bundles' first relation group, waves 4..7 the second one (its
+      // image has no root block: the own rows it multiplies are the first group's tile, times zeros); the second group's
+      // output goes to the bundle's partial tile, the first group's wave adds it (0 + first + second, the order of the
+      // group-after-group form) and runs the epilogue
+      const float bias0 = a.P[a.off_bias[l] + li], bias1 = a.P[a.off_bias[l] + 16 + li];
+      DL_STAMP(3 + (l - 1) * 9);
+      fetch(l - 1);
+      __syncthreads();                               // planes and both images have landed
+      DL_STAMP(4 + (l - 1) * 9);
+      f32x4 og[2];
+      og[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      og[1] = og[0];
+      if (active) {
+        const uint32_t rb = (uint32_t)(G2_NR * gw);
+        f32x4 acc[G2_NR][2];
+#pragma unroll
+        for (int r = 0; r < G2_NR; ++r) {
+          acc[r][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          acc[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        const int tstride = 32 * kp >> 1, toff = 16 * kp >> 1;
+        const uint32_t* base = PLN + (li * kp >> 1) + 4 * kq;
+#pragma unroll 1
+        for (int s = 0; s < nks; ++s) {
+          const uint2 w = *(const uint2*)(rmo + 32 * s);
+          u32x4 pf[2 * G2_NT];
+#pragma unroll
+          for (int sp = 0; sp < G2_NT; ++sp) {
+            pf[2 * sp] = *(const u32x4*)(base + sp * tstride + 16 * s);
+            pf[2 * sp + 1] = *(const u32x4*)(base + sp * tstride + toff + 16 * s);
+          }
+#pragma unroll
+          for (int r = 0; r < G2_NR; ++r) {
+            u32x4 af;
+            uint32_t a0, a1, a2, a3;
+            g2_expand4<FLAGS>(w.x, rb + (uint32_t)(r + 1), kbit, a0, a1);
+            g2_expand4<FLAGS>(w.y, rb + (uint32_t)(r + 1), kbit, a2, a3);
+            af[0] = a0; af[1] = a1; af[2] = a2; af[3] = a3;
+#pragma unroll
+            for (int qq = 0; qq < 2 * G2_NT; ++qq) acc[r][qq & 1] = g2_mfma_bf16(pf[qq], af, acc[r][qq & 1]);
+          }
+        }
+        DL_STAMP(6 + (l - 1) * 9);
+        g2_transform(acc, XOc, (const uint32_t*)(gw ? sW2b : sW2), li, kq, og);
+        DL_STAMP(7 + (l - 1) * 9);
+        if (gw == 1) {
+          f32x4* px = (f32x4*)(PXP + bw * 16 * G2_XP) + 2 * lane;
+          px[0] = og[0];
+          px[1] = og[1];
+        }
+      }
+      __syncthreads();                               // partial outputs in place; both images are free
+      if (l < 3) wload(l + 1);
+      if (active && gw == 0) {
+        const f32x4* px = (const f32x4*)(PXP + bw * 16 * G2_XP) + 2 * lane;
+        const f32x4 p0 = px[0], p1 = px[1];
+        float v[2][4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          v[0][rr] = g2_tanh(((0.f + og[0][rr]) + p0[rr]) + bias0);
+          v[1][rr] = g2_tanh(((0.f + og[1][rr]) + p1[rr]) + bias1);
+        }
+        fwd_out(l, v, XOn);
+      }
+      DL_STAMP(11 + (l - 1) * 9);
+      __syncthreads();                               // planes may be overwritten
+      continue;
+    }
     stage();
     const float bias0 = a.P[a.off_bias[l] + li], bias1 = a.P[a.off_bias[l] + 16 + li];
     DL_STAMP(3 + (l - 1) * 9);
@@ -2126,10 +2222,18 @@ __host__ __device__ static inline int dlb_words(int kp, int ng = 1) {
 // IMAGE only: four bundles' tiles at a time (two rounds of the table product for a workgroup with more than four bundles).
 // DENSE3: the sort-pool family's dense readout gradient (DlbArgs::dense3; a compile-time switch: as a run-time one it cost the
 // centre-node variants 2 us).
-template <bool FLAGS, int NG, bool DENSE3>
+// (GS: row / h / partial tiles of DL_GB bundles, their block rows, the planes, both groups' transposed images -- whose space
+//  the T' tiles of one group at a time take over)
+__host__ __device__ static inline int dlb_words_gs(int kp) {
+  return 3 * DL_GB * 16 * G2_XP + DL_GB * 4 * kp + (G2_NT * 32 * kp >> 1) + 2 * G2_WIMG;
+}
+
+template <bool FLAGS, int NG, bool DENSE3, bool GS = false>
 __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
+  static_assert(!GS || (NG == 2 && !DENSE3), "the group split is for two relation groups with the centre-node readout");
   constexpr int HP = (NG == 1) ? G2_XP : DLF_HP2;           // pitch of a row's layer-0 input
   constexpr int C0N = (NG == 1) ? 5 : 11;                   // histogram entries a lane holds: 16 R L / 64
+  constexpr int NB = GS ? DL_GB : DL_NW;                    // bundle slots of the workgroup
   IGMC_DYN_SMEM(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
@@ -2167,16 +2271,21 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
   const int kp = a.kp, rmp = kp;
   const int nks = (n_opp + 31) >> 5;
   const int npad_opp = ((n_opp + 15) >> 4) << 4;
-  float* XOA = (float*)smem;                                              // [DL_NW][16][G2_XP] dPre_l of the rows
-  float* HSA = XOA + DL_NW * 16 * G2_XP;                                  // [DL_NW][16][G2_XP] h_{l-1} of the rows
+  float* XOA = (float*)smem;                                              // [NB][16][G2_XP] dPre_l of the rows
+  float* HSA = XOA + NB * 16 * G2_XP;                                     // [NB][16][G2_XP] h_{l-1} of the rows
   float* sbias = HSA;                                                     // (d bias scratch: dead before the h rows land)
-  unsigned char* RMW = (unsigned char*)(HSA + DL_NW * 16 * G2_XP);        // [DL_NW][16][rmp] bytes
-  uint32_t* PLN = (uint32_t*)(RMW + DL_NW * 16 * rmp);                    // [3][32][kp] bf16
+  float* PXP = HSA + NB * 16 * G2_XP;                                     // GS: [NB][16][G2_XP] the second group's partial dX
+  unsigned char* RMW = (unsigned char*)(HSA + (GS ? 2 : 1) * NB * 16 * G2_XP);      // [NB][16][rmp] bytes
+  uint32_t* PLN = (uint32_t*)(RMW + NB * 16 * rmp);                       // [3][32][kp] bf16
   float2* sW2 = (float2*)(PLN + (G2_NT * 32 * kp >> 1));                  // [G2_WIMG words]
-  // T' tiles: [DL_NW][16][G2_TP] over planes + image (NG = 1) / [DL_NW / 2][16][G2_TP] over the image (NG > 1)
+  float2* sW2b = sW2 + G2_WIMG / 2;                                       // GS: the second group's image
+  // T' tiles: [DL_NW][16][G2_TP] over planes + image (NG = 1) / [DL_NW / 2][16][G2_TP] over the image (NG > 1; GS: both images)
   float* TIL = (NG == 1) ? (float*)PLN : (float*)sW2;
-  const int row0 = dr.base + 16 * wave;
-  const bool active = wave < dr.nact;
+  const int bw0 = GS ? (wave & (DL_GB - 1)) : wave;       // bundle of the wave, and (GS) the relation group it takes
+  const int gw0 = GS ? wave / DL_GB : 0;
+  const bool lead0 = !GS || gw0 == 0;
+  const int row0 = dr.base + 16 * bw0;
+  const bool active = bw0 < dr.nact;
   const size_t exs = a.ex_stride;
   // plane exchange regions (g2_prims.h: bf16 term planes + a flag per bundle, through the XCD's L2)
   auto px_of = [&](int x, int sd) { return (unsigned char*)(a.ex + (size_t)x * a.ex_stride + ((size_t)g * 2 + sd) * (32 * DLX_K)); };
@@ -2190,7 +2299,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
   for (int u = 0; u < DL_RIT; ++u) {
     const int i = lane + 64 * u, r = i / rw, c = i - r * rw;
     const int rc = row0 + r < n_own ? row0 + r : n_own - 1, cc = c < ldw ? c : ldw - 1;
-    rmq[u] = ((const uint32_t*)(rsrc + (size_t)rc * ldb))[cc];
+    rmq[u] = lead0 ? ((const uint32_t*)(rsrc + (size_t)rc * ldb))[cc] : 0u;
   }
   // (the rows' neighbour-label histograms -- the layer-0 table's inputs -- are requested under the LAST table product: held
   //  from here they cost registers, and spills, through all three layers)
@@ -2215,14 +2324,25 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
       if (i < G2_WIMG / 4) ((f32x4*)sW2)[i] = wq[u];
     }
   };
+  // GS: the transposed image of layer l for THIS wave's relation group, global -> LDS directly, 1 KB pieces dealt to the four
+  // waves of the group; requested when the images' space is free, landed by the barrier in front of its first use
+  auto wload = [&](int l) {
+    const float4* src = (const float4*)(a.g2_w + g2_img_off(NG, l, 1, gw0));
+    float4* dst = (float4*)(gw0 ? sW2b : sW2);
+#pragma unroll
+    for (int j = 0; j < (G2_WIMG / 256 + DL_GB - 1) / DL_GB; ++j) {
+      const int c = bw0 + j * DL_GB;
+      if (c < G2_WIMG / 256) g2_glds16(src + c * 64, dst + c * 64, lane);
+    }
+  };
   G2_SCHED_BARRIER();
   {   // planes (dPre_3: node 0 of the opposite side only; k-steps past the published rows read zeros later) and row tiles
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i < (G2_NT * 32 * kp >> 3); i += DL_THREADS) ((float4*)PLN)[i] = z4;
-    for (int i = tid; i < 2 * DL_NW * 16 * G2_XP / 4; i += DL_THREADS) ((float4*)XOA)[i] = z4;
+    for (int i = tid; i < 2 * NB * 16 * G2_XP / 4; i += DL_THREADS) ((float4*)XOA)[i] = z4;
   }
-  {
-    uint32_t* dst = (uint32_t*)(RMW + (size_t)wave * 16 * rmp);
+  if (lead0) {
+    uint32_t* dst = (uint32_t*)(RMW + (size_t)bw0 * 16 * rmp);
 #pragma unroll
     for (int u = 0; u < DL_RIT; ++u) {
       const int i = lane + 64 * u, r = i / rw, c = i - r * rw;
@@ -2282,12 +2402,12 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
   }
   // (no barrier: the layer loop starts with one)
 
-  const unsigned char* rmo = RMW + (size_t)(wave * 16 + li) * rmp + 8 * kq;
+  const unsigned char* rmo = RMW + (size_t)(bw0 * 16 + li) * rmp + 8 * kq;
   const int kbit = side ? IGMC_RELM_KF : IGMC_RELM_KT;                   // keep bit of the edge own -> opposite
   const int nact = dr.nact;                        // bundles of this workgroup that hold rows
-  float* XO = XOA + wave * 16 * G2_XP;
+  float* XO = XOA + bw0 * 16 * G2_XP;
   float* T = TIL + ((NG == 1) ? wave : (wave & 3)) * 16 * G2_TP;
-  float* HS = HSA + wave * 16 * G2_XP;
+  float* HS = HSA + bw0 * 16 * G2_XP;
   float dv[2][4];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
@@ -2308,7 +2428,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
         xprev[nt][rr] = 0.f;
         addv[nt][rr] = 0.f;
       }
-    if (active) {   // h_{l-1} of the rows and the readout gradient: requested ahead of the exchange poll / the image
+    if (active && lead0) {   // h_{l-1} of the rows and the readout gradient: requested ahead of the exchange poll / the image
       int lane_ = lane;
       G2_OPAQUE(lane_);
       const int li_ = lane_ & 15, kq_ = lane_ >> 4;
@@ -2322,6 +2442,180 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
           if (DENSE3) addv[nt][rr] = (rw2 < n_own) ? a.dcat[l - 1][(size_t)(own0 + rwc) * 32 + 16 * nt + li_] : 0.f;
           else addv[nt][rr] = (rw2 == 0) ? a.gfeat[(size_t)g * a.D + side * 128 + (l - 1) * 32 + 16 * nt + li_] : 0.f;
         }
+    }
+    if constexpr (GS) {
+      // ---- both relation groups at once: waves 0..3 gather and transform the bundles' first group, waves 4..7 the second one
+      //      (its image has no root block: the dPre_l rows it multiplies meet zeros); the second group's partial dX goes to the
+      //      bundle's partial tile, the first group's wave adds it (0 + first + second: the order of the group-after-group
+      //      form) and runs the epilogue.  The table products follow group after group on all eight waves -- the second
+      //      group's first: its waves lay down their T' tiles while the leaders are in their epilogue.
+      int tid_g = threadIdx.x;
+      G2_OPAQUE(tid_g);
+      const int tid = tid_g, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+      const int bw = wave & (DL_GB - 1), gw = wave / DL_GB;
+      const int row0 = dr.base + 16 * bw;
+      const bool active = bw < nact;
+      const unsigned char* rmo = RMW + (size_t)(bw * 16 + li) * rmp + 8 * kq;
+      float* XO = XOA + bw * 16 * G2_XP;
+      float* T = TIL + bw * 16 * G2_TP;
+      float* HS = HSA + bw * 16 * G2_XP;
+      const int sk = 42 + (3 - l) * NG * 7;          // (phase clocks)
+      DL_STAMP(sk);
+      wload(l);
+      if (l < 3) {       // the opposite side's dPre_l: flags of its bundles, then global -> LDS (landed by the barrier)
+        g2_flags_wait(px_of(5 - l, 1 - side), (n_opp + 15) >> 4, xtag(5 - l), lane, a.gs_err, DLX_PX_FLAGS);
+        g2_planes_load_exact(PLN, px_of(5 - l, 1 - side), 192 * kp, wave, lane, DL_NW);
+      }
+      __syncthreads();                               // planes, both images, dPre_l of the rows are in place
+      DL_STAMP(sk + 1);
+      {   // d bias_l = column sums of dPre_l over the workgroup's rows (fixed order)
+        {
+          const int n = tid & 31, part = tid >> 5;
+          float sb = 0.f;
+          for (int row = part; row < NB * 16; row += DL_THREADS / 32) sb += XOA[(row >> 4) * 16 * G2_XP + (row & 15) * G2_XP + n];
+          sbias[part * 32 + n] = sb;
+        }
+        __syncthreads();
+        if (tid < 32) {
+          float s2 = 0.f;
+#pragma unroll
+          for (int p2 = 0; p2 < DL_THREADS / 32; ++p2) s2 += sbias[p2 * 32 + tid];
+          wpart[(R * 32 + 32) * 32 + tid] = s2;
+        }
+      }
+      DL_STAMP(sk + 2);
+      f32x4 acc[G2_NR][2];
+#pragma unroll
+      for (int r = 0; r < G2_NR; ++r) {
+        acc[r][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      f32x4 og[2];
+      og[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      og[1] = og[0];
+      if (active) {
+        const uint32_t rb = (uint32_t)(G2_NR * gw);
+        const int tstride = 32 * kp >> 1, toff = 16 * kp >> 1;
+        const uint32_t* base = PLN + (li * kp >> 1) + 4 * kq;
+        const int nke = (l == 3) ? 1 : nks;          // dPre_3 of the centre-node readout lives on node 0: one k-step
+#pragma unroll 1
+        for (int s2 = 0; s2 < nke; ++s2) {
+          const uint2 w = *(const uint2*)(rmo + 32 * s2);
+          u32x4 pf[2 * G2_NT];
+#pragma unroll
+          for (int sp = 0; sp < G2_NT; ++sp) {
+            pf[2 * sp] = *(const u32x4*)(base + sp * tstride + 16 * s2);
+            pf[2 * sp + 1] = *(const u32x4*)(base + sp * tstride + toff + 16 * s2);
+          }
+#pragma unroll
+          for (int r = 0; r < G2_NR; ++r) {
+            u32x4 af;
+            uint32_t a0, a1, a2, a3;
+            g2_expand4<FLAGS>(w.x, rb + (uint32_t)(r + 1), kbit, a0, a1);
+            g2_expand4<FLAGS>(w.y, rb + (uint32_t)(r + 1), kbit, a2, a3);
+            af[0] = a0; af[1] = a1; af[2] = a2; af[3] = a3;
+#pragma unroll
+            for (int qq = 0; qq < 2 * G2_NT; ++qq) acc[r][qq & 1] = g2_mfma_bf16(pf[qq], af, acc[r][qq & 1]);
+          }
+        }
+        DL_STAMP(sk + 3);
+        g2_transform(acc, XO, (const uint32_t*)(gw ? sW2b : sW2), li, kq, og);
+        if (gw == 1) {
+          f32x4* px = (f32x4*)(PXP + bw * 16 * G2_XP) + 2 * lane;
+          px[0] = og[0];
+          px[1] = og[1];
+        }
+      }
+      DL_STAMP(sk + 4);
+      __syncthreads();                               // partial dX in place; every wave is done with planes / images
+      DL_STAMP(sk + 5);
+      if (active && gw == 0) {
+        const f32x4* px = (const f32x4*)(PXP + bw * 16 * G2_XP) + 2 * lane;
+        const f32x4 p0 = px[0], p1 = px[1];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const bool ok = row0 + 4 * kq + rr < n_own;
+            const float x = xprev[nt][rr];
+            const float ov = (0.f + og[nt][rr]) + (nt ? p1[rr] : p0[rr]);
+            dv[nt][rr] = ok ? (ov + addv[nt][rr]) * (1.f - x * x) : 0.f;
+          }
+          if (l > 1) g2_publish_planes(px_of(6 - l, side), kp, 16 * nt + li, row0 + 4 * kq, dv[nt]);
+        }
+        if (l > 1) g2_flag_raise(px_of(6 - l, side), row0 >> 4, xtag(6 - l), lane, DLX_PX_FLAGS);      // the bundle's dPre_{l-1} is in the L2
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) HS[(4 * kq + rr) * G2_XP + 16 * nt + li] = xprev[nt][rr];
+        if (l == 1) {
+          int lane_ = lane;                          // (opaque: the address arithmetic stays here, not above the layer loop)
+          G2_OPAQUE(lane_);
+#pragma unroll
+          for (int u = 0; u < C0N; ++u) {
+            const int i = lane_ + 64 * u, r = i / RL, c = i - r * RL;
+            const int rc = (r < 16 && row0 + r < n_own) ? row0 + r : n_own - 1;
+            c0q[u] = a.cnt0[(size_t)(own0 + rc) * RL + (r < 16 ? c : 0)];
+          }
+        }
+      }
+#pragma unroll 1
+      for (int gi = 0; gi < 2; ++gi) {
+        const int grp = 1 - gi;                      // table h_{l-1}^T [T'_0 .. T'_4 | dPre_l] of group grp (d root: group 0)
+        const uint32_t rb = (uint32_t)(G2_NR * grp);
+        if (active && gw == grp) {
+#pragma unroll
+          for (int r = 0; r < G2_NR; ++r)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+              *(float4*)(T + li * G2_TP + r * 32 + 16 * t + 4 * kq) = make_float4(acc[r][t][0], acc[r][t][1], acc[r][t][2], acc[r][t][3]);
+        }
+        __syncthreads();                             // the group's tiles (and, first time round, the h rows) are in place
+        f32x4 w3[3];
+#pragma unroll
+        for (int i3 = 0; i3 < 3; ++i3) w3[i3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int m2w = wave >> 2, nt0 = 3 * (wave & 3);
+#pragma unroll 1
+        for (int wb = 0; wb < nact; ++wb) {
+          const float* Tb = TIL + wb * 16 * G2_TP;
+          const float* Hb = HSA + wb * 16 * G2_XP;
+          const float* Db = XOA + wb * 16 * G2_XP;
+          float av[4], bwv[4][3];
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) {
+            av[s4] = Hb[(4 * s4 + kq) * G2_XP + m2w * 16 + li];
+#pragma unroll
+            for (int i3 = 0; i3 < 3; ++i3) {
+              const int nt = nt0 + i3;
+              bwv[s4][i3] = (nt < 2 * G2_NR) ? Tb[(4 * s4 + kq) * G2_TP + nt * 16 + li]
+                                             : Db[(4 * s4 + kq) * G2_XP + (nt - 2 * G2_NR) * 16 + li];
+            }
+          }
+          G2_SCHED_BARRIER();
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int i3 = 0; i3 < 3; ++i3) w3[i3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bwv[s4][i3], w3[i3], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i3 = 0; i3 < 3; ++i3) {
+          const int nt = nt0 + i3, r = nt >> 1;         // 32-column block: relation rb + r, or G2_NR = dPre_l (d root: group 0)
+          const int rg = (int)rb + r;
+          if (r < G2_NR ? rg >= R : grp > 0) continue;
+          float* pp = wpart + (kq * 4) * 32 + li + (r < G2_NR ? rg : R) * 1024 + m2w * 512 + (nt & 1) * 16;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) pp[rr * 32] = w3[i3][rr];
+        }
+        __syncthreads();                             // the group's tiles are consumed
+      }
+      DL_STAMP(sk + 6);
+      if (l > 1 && active && gw == 0) {              // dPre_{l-1} of the rows becomes the next layer's own rows (the d root
+#pragma unroll                                       // block of group 0's product has read dPre_l)
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) XO[(4 * kq + rr) * G2_XP + 16 * nt + li] = dv[nt][rr];
+      }
+      continue;
     }
 #pragma unroll 1
     for (int grp = 0; grp < ngr; ++grp) {
@@ -2521,8 +2815,9 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
   // ---- layer-0 table gradient T0'[c][f] = sum_i [hist | onehot | 1](i, c) dPre_0[i][f] over the workgroup's rows
   {
     float* L0 = (float*)PLN;                         // (planes and image are dead: the rows' inputs and dPre_0 as tiles)
-    float* HI = L0 + wave * 16 * HP;
-    float* D0 = L0 + DL_NW * 16 * HP + wave * 16 * G2_XP;
+    float* HI = L0 + bw0 * 16 * HP;
+    float* D0 = L0 + NB * 16 * HP + bw0 * 16 * G2_XP;
+    const bool active = bw0 < nact && lead0;
     if (active) {
       for (int i = lane; i < 16 * HP; i += 64) HI[i] = 0.f;
 #pragma unroll
@@ -2548,7 +2843,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
       f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f};
       for (int wb = 0; wb < nact; ++wb) {
         const float* Hb = L0 + wb * 16 * HP;
-        const float* Db = L0 + DL_NW * 16 * HP + wb * 16 * G2_XP;
+        const float* Db = L0 + NB * 16 * HP + wb * 16 * G2_XP;
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Hb[(4 * s4 + kq) * HP + m2 * 16 + li],
@@ -2843,6 +3138,20 @@ int igmc_dl_fwd_eligible(const ModelDev& m, const BatchDev& b, int B) {
   return (size_t)dlf_words(32 * ((cmax + 31) >> 5) + 8) * 4 <= (size_t)160 * 1024;
 }
 
+// 1 = the group-split forms of k_dl_fwd / k_dl_bwd take this arena: two relation groups, no workgroup with more than DL_NW / 2
+// bundles (dl_split / dl_rows over the slot capacities), both images beside the planes in LDS.  IGMC_DL_GSPLIT=0: the
+// group-after-group form (test hook).
+static int dl_gsplit(const ModelDev& m, const BatchDev& b, int B) {
+  if (g2_groups(m.R, m.L) != 2 || g2_rel_groups(m.R) != 2) return 0;
+  const char* e = getenv("IGMC_DL_GSPLIT");
+  if (e && atoi(e) == 0) return 0;
+  const DlSplit sq = dl_split(b.cap_u, b.cap_v, B);
+  const int nbu = (b.cap_u + 15) >> 4, nbv = (b.cap_v + 15) >> 4;
+  if ((nbu + sq.nqu - 1) / sq.nqu > DL_GB || (nbv + sq.nqv - 1) / sq.nqv > DL_GB) return 0;
+  const int cmax = b.cap_u > b.cap_v ? b.cap_u : b.cap_v, kp = 32 * ((cmax + 31) >> 5) + 8;
+  return (size_t)dlf_words_gs(kp) * 4 <= 160 * 1024 && (size_t)dlb_words_gs(kp) * 4 <= 160 * 1024;
+}
+
 void igmc_launch_dl_fwd(const ModelDev& m, const BatchDev& b, const float* P, int B, int training, int use_flags,
                         float* zero_out, int self_seq, void* stream) {
   DlfArgs a;
@@ -2866,7 +3175,8 @@ void igmc_launch_dl_fwd(const ModelDev& m, const BatchDev& b, const float* P, in
   a.B = B;
   const int grid = 8 * ((B + 7) / 8) * (a.nqu + a.nqv);      // (XCD-aligned blocks of 8 * members workgroups: DLX_DECODE)
   const int ng = g2_groups(m.R, m.L);
-  const size_t sm = (size_t)dlf_words(a.kp, ng) * 4;
+  const int gs = dl_gsplit(m, b, B);
+  const size_t sm = (size_t)(gs ? dlf_words_gs(a.kp) : dlf_words(a.kp, ng)) * 4;
 #ifdef IGMC_HIPEMU
   hipemu::rt().co_cs = a.nqu + a.nqv;                   // the members of a subgraph run together:
   hipemu::rt().co_stride = 8;                           // workgroups 8 nmem j + x + 8 rem
@@ -2879,6 +3189,14 @@ void igmc_launch_dl_fwd(const ModelDev& m, const BatchDev& b, const float* P, in
     } else {
       if (use_flags) IGMC_PLAUNCH("k_dl_fwd", (k_dl_fwd<true, false, 1>), grid, DL_THREADS, sm, stream, a);
       else IGMC_PLAUNCH("k_dl_fwd", (k_dl_fwd<false, false, 1>), grid, DL_THREADS, sm, stream, a);
+    }
+  } else if (gs) {
+    if (training) {
+      if (use_flags) IGMC_PLAUNCH("k_dl_fwd", (k_dl_fwd<true, true, 2, true>), grid, DL_THREADS, sm, stream, a);
+      else IGMC_PLAUNCH("k_dl_fwd", (k_dl_fwd<false, true, 2, true>), grid, DL_THREADS, sm, stream, a);
+    } else {
+      if (use_flags) IGMC_PLAUNCH("k_dl_fwd", (k_dl_fwd<true, false, 2, true>), grid, DL_THREADS, sm, stream, a);
+      else IGMC_PLAUNCH("k_dl_fwd", (k_dl_fwd<false, false, 2, true>), grid, DL_THREADS, sm, stream, a);
     }
   } else {
     if (training) {
@@ -2948,7 +3266,8 @@ void igmc_launch_dl_bwd(const ModelDev& m, const BatchDev& b, int B, int use_fla
   }
   a.B = B;
   const int grid = 8 * ((B + 7) / 8) * (a.nqu + a.nqv);      // (XCD-aligned blocks of 8 * members workgroups: DLX_DECODE)
-  const size_t sm = (size_t)dlb_words(a.kp, g2_groups(m.R, m.L)) * 4;
+  const int gs = !dense3 && dl_gsplit(m, b, B);
+  const size_t sm = (size_t)(gs ? dlb_words_gs(a.kp) : dlb_words(a.kp, g2_groups(m.R, m.L))) * 4;
 #ifdef IGMC_HIPEMU
   hipemu::rt().co_cs = a.nqu + a.nqv;
   hipemu::rt().co_stride = 8;
@@ -2962,6 +3281,9 @@ void igmc_launch_dl_bwd(const ModelDev& m, const BatchDev& b, int B, int use_fla
       if (use_flags) IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<true, 1, false>), grid, DL_THREADS, sm, stream, a);
       else IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<false, 1, false>), grid, DL_THREADS, sm, stream, a);
     }
+  } else if (gs) {
+    if (use_flags) IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<true, 2, false, true>), grid, DL_THREADS, sm, stream, a);
+    else IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<false, 2, false, true>), grid, DL_THREADS, sm, stream, a);
   } else {        // (relation groups: centre-node readout only -- igmc_conv_bwd_tables asks for the one-group layout)
     if (use_flags) IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<true, 2, false>), grid, DL_THREADS, sm, stream, a);
     else IGMC_PLAUNCH("k_dl_bwd", (k_dl_bwd<false, 2, false>), grid, DL_THREADS, sm, stream, a);
@@ -2980,8 +3302,10 @@ int igmc_dl_prepare() {
 #define DL_MAXLDS(k) if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1
   DL_MAXLDS((k_dl_bwd<true, 1, false>)); DL_MAXLDS((k_dl_bwd<false, 1, false>)); DL_MAXLDS((k_dl_bwd<true, 2, false>)); DL_MAXLDS((k_dl_bwd<false, 2, false>));
   DL_MAXLDS((k_dl_bwd<true, 1, true>)); DL_MAXLDS((k_dl_bwd<false, 1, true>));
+  DL_MAXLDS((k_dl_bwd<true, 2, false, true>)); DL_MAXLDS((k_dl_bwd<false, 2, false, true>));
   DL_MAXLDS((k_dl_fwd<true, true, 1>)); DL_MAXLDS((k_dl_fwd<false, true, 1>)); DL_MAXLDS((k_dl_fwd<true, false, 1>)); DL_MAXLDS((k_dl_fwd<false, false, 1>));
   DL_MAXLDS((k_dl_fwd<true, true, 2>)); DL_MAXLDS((k_dl_fwd<false, true, 2>)); DL_MAXLDS((k_dl_fwd<true, false, 2>)); DL_MAXLDS((k_dl_fwd<false, false, 2>));
+  DL_MAXLDS((k_dl_fwd<true, true, 2, true>)); DL_MAXLDS((k_dl_fwd<false, true, 2, true>)); DL_MAXLDS((k_dl_fwd<true, false, 2, true>)); DL_MAXLDS((k_dl_fwd<false, false, 2, true>));
 #undef DL_MAXLDS
   if (hipFuncSetAttribute((const void*)k_dl_layer0<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
   if (hipFuncSetAttribute((const void*)k_dl_layer0<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;

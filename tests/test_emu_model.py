@@ -375,6 +375,25 @@ def test_ten_relations_at_cap_100(be, drop, lean):
     assert int(res['d']['erel'].max()) >= 8
 
 
+@pytest.mark.parametrize('drop', [False, True])
+def test_group_split_equals_group_after_group(be, monkeypatch, drop):
+    """Ten relations with at most four bundles a workgroup (cap 100; flixster): waves 0..3 take the bundles' first relation
+    group and waves 4..7 the second one at the same time (k_dl_fwd / k_dl_bwd<..., GS>), instead of every wave taking the two
+    groups one after the other (IGMC_DL_GSPLIT=0).  Same sums in the same order: outputs, loss, every gradient bit for bit."""
+    res = {}
+    for tag in ('split', 'serial'):
+        if tag == 'serial':
+            monkeypatch.setenv('IGMC_DL_GSPLIT', '0')
+        r = PC.run_model_parity(be, ten_levels(sub('synth_nocap:100', 4)), R=10, use_dropout=drop)
+        assert r['worst_grad_err'] < 1e-4 and r['batch'].dense_layers(r['ws'])
+        res[tag] = r
+    for k in ('train_out', 'loss'):
+        assert np.array_equal(np.asarray(res['split'][k]), np.asarray(res['serial'][k])), k
+    assert set(res['split']['grads']) == set(res['serial']['grads']) and res['split']['grads']
+    for k, g in res['split']['grads'].items():
+        assert np.array_equal(g, res['serial']['grads'][k]), k
+
+
 def test_ten_relations_at_cap_100_in_the_fused_train_step(be):
     case = ten_levels(sub('synth_nocap:100', 8))
     runs = [PC.run_fused_train_trajectory(be, case, R=10, steps=4, batch=2, use_dropout=True) for _ in range(2)]

@@ -26,7 +26,8 @@ def main():
     if cfg['dataset'] in ('douban', 'flixster', 'yahoo_music'):
         split = preprocessing.load_data_monti(cfg['dataset'], testing=True)
     else:
-        split = preprocessing.create_trainvaltest_split(cfg['dataset'], 1234, True, verbose=False)
+        rmap = {float(i): i / 2.0 for i in range(1, 11)} if cfg['dataset'] == 'ml_10m_lite' else None
+        split = preprocessing.create_trainvaltest_split(cfg['dataset'], 1234, True, rating_map=rmap, verbose=False)
     (_, _, A, tr_l, tr_u, tr_v, _, _, _, _, _, _, class_values) = split
     ds = MyDynamicDataset('data/bench', A, (tr_u, tr_v), tr_l, 1, 1.0, cfg['mnph'], None, None, class_values, device=0, seed=1)
     model = IGMC(ds, latent_dim=[32, 32, 32, 32], num_relations=len(class_values), num_bases=4, regression=True,
@@ -46,6 +47,22 @@ def main():
     print('%s, workgroup %d (subgraph %d), relation groups %d; shader cycles' % (cfgname, wg, wg // 4, ng))
     f = c[:40]
     print('k_dl_fwd: set-up %d | layer 0 %d' % (f[1] - f[0], f[2] - f[1]))
+    gs = ng == 2 and os.environ.get('IGMC_DL_GSPLIT', '1') != '0' and cfgname in ('flixster', 'ml_10m_lite')
+    if gs:      # group split: both relation groups at once on the two halves of the workgroup (graphstep2.hip, GS)
+        for l in (1, 2, 3):
+            b = 3 + (l - 1) * 9
+            print('L%d: reload + sync %d | gather %d | transform %d | partial hand-off + epilogue %d'
+                  % (l, f[b + 1] - f[b], f[b + 3] - f[b + 1], f[b + 4] - f[b + 3], f[b + 8] - f[b + 4]))
+        print('k_dl_fwd total %d' % (f[30] - f[0]))
+        print('k_dl_bwd: set-up %d' % (c[42] - c[40]))
+        for l in (3, 2, 1):
+            k = 42 + (3 - l) * 14
+            nxt = c[k + 14] if l > 1 else c[41]
+            print('B%d: images / reload / sync %d | d bias %d | gather %d | transform %d | sync %d | epilogue + two table products %d | tail %d'
+                  % (l, c[k + 1] - c[k], c[k + 2] - c[k + 1], c[k + 3] - c[k + 2], c[k + 4] - c[k + 3], c[k + 5] - c[k + 4],
+                     c[k + 6] - c[k + 5], nxt - c[k + 6]))
+        print('layer-0 table %d | k_dl_bwd total %d' % (c[126] - c[41], c[126] - c[40]))
+        return
     for l in (1, 2, 3):
         b = 3 + (l - 1) * 9
         line = 'L%d: stage + reload + sync %d' % (l, f[b + 1] - f[b])
