@@ -1917,7 +1917,6 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
   ((float2*)sT0)[tid] = t0v;
   if (NG > 1) ((float2*)sT0)[DL_THREADS + tid] = t0w;
   if (!GS) wpre(1, 0);
-  else if (gw == 1) wload(1);                      // (the second group's image has a space of its own: free from the start)
   __syncthreads();
   DL_STAMP(1);
 
@@ -1955,12 +1954,14 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
   };
 
   // ================================================================ layer 0: h_0 = tanh([hist | onehot(label) | 1] @ T0)
-  if (active && lead) {
+  // (GS: the two waves of a bundle count one relation group each into the bundle's input tile)
+  if (active) {
     const uint32_t* ohp = OHP + ((li & 7) * kp >> 1) + 4 * kq;
     float* hi = HIA + bw * 16 * HP;
     const int row = row0 + li;
+    const int g_lo = GS ? gw : 0, g_hi = GS ? gw + 1 : ngr;
 #pragma unroll 1
-    for (int grp = 0; grp < ngr; ++grp) {
+    for (int grp = g_lo; grp < g_hi; ++grp) {
       const uint32_t rb = (uint32_t)(G2_NR * grp);
       f32x4 hacc[G2_NR];
 #pragma unroll
@@ -1991,11 +1992,15 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
           }
         }
     }
-    if (kq == 0 && row < n_own) {
+    if (lead && kq == 0 && row < n_own) {
       hi[li * HP + RL + own_lab] = 1.f;
       hi[li * HP + RL + L] = 1.f;
     }
-    IGMC_WAVE_SYNC();                                // (the tile is this wave's own: no workgroup barrier)
+  }
+  if (GS) __syncthreads();                           // (both halves of the bundles' input tiles)
+  if (active && lead) {
+    float* hi = HIA + bw * 16 * HP;
+    if (!GS) IGMC_WAVE_SYNC();                       // (the tile is this wave's own: no workgroup barrier)
     // [hist | onehot | 1] (16 rows x 32 / 48 table rows) @ T0 on the f32 matrix cores: the accumulators (lane = feature
     // 16 nt + li, registers = rows 4 kq + rr) are the epilogue's layout
     f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
@@ -2016,7 +2021,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
   }
   __syncthreads();                                   // the image's space (one-hot planes, inputs, table) is free
   DL_STAMP(2);
-  if (GS && gw == 0) wload(1);
+  if (GS) wload(1);                                  // (requested here, not earlier: a pending one would be waited for at every barrier above)
 
   // ================================================================ conv layers 1..3
 #pragma unroll 1
