@@ -2295,6 +2295,9 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
   // plane exchange regions (g2_prims.h: bf16 term planes + a flag per bundle, through the XCD's L2)
   auto px_of = [&](int x, int sd) { return (unsigned char*)(a.ex + (size_t)x * a.ex_stride + ((size_t)g * 2 + sd) * (32 * DLX_K)); };
 
+  // the loss head's loads (features of the target rows, the wave's lin1 rows) go out first: over by the time the head starts
+  HeadPre hpre;
+  if (!DENSE3 && a.head) head_sub_prefetch(hpre, a.hb, a.hm, a.P, g, tid, nb, nb + cu);
   // ---- staging: block rows, the target rows of dPre_3, the layer-0 inputs of the rows (layer-0 table gradient), image 3
   const int ldb = side ? a.relmT_ld : a.relm_ld, ldw = ldb >> 2;
   const uint8_t* rsrc = side ? a.relmT + (size_t)g * a.cap_v * a.relmT_ld : a.relm + (size_t)g * a.cap_u * a.relm_ld;
@@ -2358,7 +2361,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
   if (!DENSE3 && a.head) {   // loss head of the subgraph in the image's space (free until the first layer stages its image); what it leaves
                   // in HBM -- dPre_3 of the target rows, d feat -- is read back below by this very workgroup (barrier in between)
     const uint64_t hstep = a.hm.ctrl ? (uint64_t)a.hm.ctrl[IGMC_CTRL_STEP] : a.step;
-    head_sub_body<true>(a.hb, a.hm, a.P, g, tid, (float*)sW2, a.inj_mask, a.seed, hstep, a.mult, a.grad_scale, a.out);
+    head_sub_compute<true>(hpre, a.hb, a.hm, a.P, g, tid, nb, nb + cu, (float*)sW2, a.inj_mask, a.seed, hstep, a.mult, a.grad_scale, a.out);
     __syncthreads();
   }
   if (DENSE3) {
@@ -2870,19 +2873,22 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
 // target rows.  (k_head_train's head role takes 16 subgraphs per workgroup on the f32 matrix cores: four workgroups at
 // batch 50, 19 us of dependent round trips; 50 workgroups of one subgraph each are done in a third of that.)  Side features
 // (--use-features, reference models.py:208-209) ride along: D = 256 + S, the body is head_sub.h.
-__global__ __launch_bounds__(256) void k_head_sub(BatchDev b, ModelDev m, const float* __restrict__ P,
+__global__ __launch_bounds__(512) void k_head_sub(BatchDev b, ModelDev m, const float* __restrict__ P,
                                                     const uint8_t* __restrict__ inj_mask, uint64_t seed, uint64_t step_arg,
                                                     float mult, float grad_scale, float* __restrict__ out) {
   IGMC_DYN_SMEM(smem);
   const int g = blockIdx.x;
   if (g >= b.totals[3]) return;
   const uint64_t step = m.ctrl ? (uint64_t)m.ctrl[IGMC_CTRL_STEP] : step_arg;
-  head_sub_body<true>(b, m, P, g, (int)threadIdx.x, (float*)smem, inj_mask, seed, step, mult, grad_scale, out);
+  const int nu = b.node_off[g], nv = nu + b.n_users[g];
+  HeadPre hp;
+  head_sub_prefetch(hp, b, m, P, g, (int)threadIdx.x, nu, nv);
+  head_sub_compute<true>(hp, b, m, P, g, (int)threadIdx.x, nu, nv, (float*)smem, inj_mask, seed, step, mult, grad_scale, out);
 }
 
 void igmc_launch_head_sub(const ModelDev& m, const BatchDev& b, const float* P, int B, const uint8_t* inj_mask, uint64_t seed,
                           uint64_t step, float mult, float grad_scale, float* out, void* stream) {
-  IGMC_PLAUNCH("k_head_sub", k_head_sub, B, 256, (size_t)igmc_head_sub_lds_floats(m.D) * sizeof(float), stream, b, m, P, inj_mask,
+  IGMC_PLAUNCH("k_head_sub", k_head_sub, B, 512, (size_t)igmc_head_sub_lds_floats(m.D) * sizeof(float), stream, b, m, P, inj_mask,
                seed, step, mult, grad_scale, out);
 }
 

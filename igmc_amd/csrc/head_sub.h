@@ -1,8 +1,9 @@
-// head_sub.h -- readout + MLP head of ONE subgraph by 256 threads (reference models.py:203-215; internal).
+// head_sub.h -- readout + MLP head of ONE subgraph by 512 threads (reference models.py:203-215; internal).
 //
 // The conv features of the two target rows (+ the link's side-feature row, models.py:208-209) -> lin1 / ReLU / dropout(0.5) /
 // lin2 / residual -> (training) dz, d feat and dPre_3 on the target rows.  The body of k_head_sub (graphstep2.hip: a launch of
-// its own behind the dense-layer forward); threads past the first 256 of a larger workgroup only take part in the barriers.
+// its own behind the dense-layer forward) and of the head inside k_dl_bwd's set-up -- the same code, so the two launch forms
+// agree bit for bit.
 #pragma once
 #include "model.h"
 
@@ -12,35 +13,57 @@
 #define IGMC_HS_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
 
-// LDS of the head: sfeat[D] | sa1[128] | skeep[128] | sdz[128] | sred[128] | part4[4 * 256] | misc[4]
-static inline int igmc_head_sub_lds_floats(int D) { return ((D + 3) & ~3) + 4 * 128 + 4 * 256 + 4; }
+// LDS of the head: sfeat[D] | sa1[128] | skeep[128] | sdz[128] | sred[128] | part8[8 * 256] | misc[4]
+static inline int igmc_head_sub_lds_floats(int D) { return ((D + 3) & ~3) + 4 * 128 + 8 * 256 + 4; }
 
+// What the head loads that depends on nothing but the subgraph and the parameters: requested by the caller AHEAD of its own
+// set-up (k_dl_bwd: in front of its block-row staging), so that the head's first two round trips -- the target rows' features,
+// the wave's sixteen lin1 rows -- are over when the head starts.  512 threads = eight waves: wave w takes hidden units
+// 16 w .. 16 w + 15, lane = 4 fan-in columns.
+struct HeadPre {
+  float fv, yv, l2b, l1b, l2w, l2w_t;
+  float4 w4[16];
+};
+
+// nu / nv: first node of the subgraph's users / items in the collated batch (b.node_off[g], + b.n_users[g])
+__device__ __forceinline__ void head_sub_prefetch(HeadPre& hp, const BatchDev& b, const ModelDev& m, const float* __restrict__ P,
+                                                  int g, int tid, int nu, int nv) {
+  const int D = m.D;
+  const int lane = tid & 63, wave = (tid >> 6) & 7;
+  const int t8 = tid & 255;
+  const size_t trow = (size_t)((t8 >> 7) ? nv : nu) * 32 + (t8 & 31);          // feature t8: side, layer, column
+  const int ju = 16 * wave + ((lane >> 1) & 15);
+  hp.fv = m.h[(t8 >> 5) & 3][trow];
+  hp.yv = b.y[g];
+  hp.l2b = P[m.off_l2b];
+  hp.l1b = P[m.off_l1b + ju];
+  hp.l2w = P[m.off_l2w + ju];
+  hp.l2w_t = P[m.off_l2w + (tid & 127)];
+  const float* wrow = P + m.off_l1w + (int64_t)(16 * wave) * D + 4 * lane;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) hp.w4[q] = *(const float4*)(wrow + (int64_t)q * D);
+}
+
+// The head of subgraph g by 512 threads (eight waves), on what head_sub_prefetch requested.
 template <bool TRAIN>
-__device__ __forceinline__ void head_sub_body(const BatchDev& b, const ModelDev& m, const float* __restrict__ P, int g,
-                                              int tid, float* lds, const uint8_t* __restrict__ inj_mask, uint64_t seed,
-                                              uint64_t step, float mult, float grad_scale, float* __restrict__ out,
-                                              float* dpre3_alt = nullptr, size_t alt_bias = 0) {
+__device__ __forceinline__ void head_sub_compute(const HeadPre& hp, const BatchDev& b, const ModelDev& m, const float* __restrict__ P,
+                                                 int g, int tid, int nu, int nv, float* lds, const uint8_t* __restrict__ inj_mask,
+                                                 uint64_t seed, uint64_t step, float mult, float grad_scale, float* __restrict__ out,
+                                                 float* dpre3_alt = nullptr, size_t alt_bias = 0) {
   const int D = m.D, S = m.S;
   float* sfeat = lds;
   float* sa1 = sfeat + ((D + 3) & ~3);
   float* skeep = sa1 + 128;
   float* sdz = skeep + 128;
   float* sred = sdz + 128;
-  float* part4 = sred + 128;
-  float* misc = part4 + 4 * 256;
+  float* part8 = sred + 128;
+  float* misc = part8 + 8 * 256;
   const bool on = tid < 256;
-  const int lane = tid & 63, wave = (tid >> 6) & 3;
-  const int nu = b.node_off[g], nv = nu + b.n_users[g];
+  const int lane = tid & 63, wave = (tid >> 6) & 7;
   const int t8 = tid & 255;
-  const size_t trow = (size_t)((t8 >> 7) ? nv : nu) * 32 + (t8 & 31);          // feature tid: side, layer, column
-  float fv = 0.f, yv = 0.f, l2b = 0.f, l1b = 0.f, l2w = 0.f, l2w_t = 0.f;
+  const size_t trow = (size_t)((t8 >> 7) ? nv : nu) * 32 + (t8 & 31);
+  const float fv = hp.fv;
   if (on) {
-    fv = m.h[(tid >> 5) & 3][trow];
-    yv = b.y[g];
-    l2b = P[m.off_l2b];
-    l1b = P[m.off_l1b + (tid >> 1)];
-    l2w = P[m.off_l2w + (tid >> 1)];
-    l2w_t = P[m.off_l2w + (tid & 127)];
     sfeat[tid] = fv;
     if (TRAIN) m.feat[(size_t)g * D + tid] = fv;
     for (int k = tid; k < S; k += 256) {
@@ -50,24 +73,15 @@ __device__ __forceinline__ void head_sub_body(const BatchDev& b, const ModelDev&
     }
   }
   __syncthreads();
-  if (on) {
-    // lin1 (256 [+ S] -> 128): wave w takes hidden units 32 w .. 32 w + 31; one weight row (1 KB of its conv part) per load
-    // instruction, lane = 4 fan-in columns; the 32 per-lane partial dot products are reduced over the 64 lanes by a
-    // transposing butterfly; the side-feature columns are a short dot product of the unit's owner lane
-    const int ju = tid >> 1, part = tid & 1;
+  {
+    // lin1 (256 [+ S] -> 128): the 16 per-lane partial dot products of the wave's units are reduced over the 64 lanes by a
+    // transposing butterfly (lane bits 4..1 -> the unit, bits 0 and 5 summed last); the side-feature columns are a short dot
+    // product of the unit's owner lane
+    const int ju = 16 * wave + ((lane >> 1) & 15);
     const float4 f4 = *(const float4*)(sfeat + 4 * lane);
-    const float* wrow = P + m.off_l1w + (int64_t)(32 * wave) * D + 4 * lane;
-    float v[32];
+    float v[16];
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      float4 w4[16];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) w4[q] = *(const float4*)(wrow + (int64_t)(16 * hh + q) * D);
-      IGMC_HS_SCHED_BARRIER();
-#pragma unroll
-      for (int q = 0; q < 16; ++q) v[16 * hh + q] = (w4[q].x * f4.x + w4[q].y * f4.y) + (w4[q].z * f4.z + w4[q].w * f4.w);
-      IGMC_HS_SCHED_BARRIER();
-    }
+    for (int q = 0; q < 16; ++q) v[q] = (hp.w4[q].x * f4.x + hp.w4[q].y * f4.y) + (hp.w4[q].z * f4.z + hp.w4[q].w * f4.w);
 #define IGMC_HS_BFLY(H)                                                              \
     {                                                                                \
       const bool up = (lane & (2 * (H))) != 0;                                       \
@@ -76,17 +90,18 @@ __device__ __forceinline__ void head_sub_body(const BatchDev& b, const ModelDev&
         v[i] = keep + __shfl_xor(send, 2 * (H));                                     \
       }                                                                              \
     }
-    IGMC_HS_BFLY(16) IGMC_HS_BFLY(8) IGMC_HS_BFLY(4) IGMC_HS_BFLY(2) IGMC_HS_BFLY(1)
+    IGMC_HS_BFLY(8) IGMC_HS_BFLY(4) IGMC_HS_BFLY(2) IGMC_HS_BFLY(1)
 #undef IGMC_HS_BFLY
     float s = v[0] + __shfl_xor(v[0], 1);
-    if (part == 0) {
+    s += __shfl_xor(s, 32);
+    if ((lane & 33) == 0) {
       if (S > 0) {
         const float* ws = P + m.off_l1w + (int64_t)ju * D + 256;
         float ss = 0.f;
         for (int k = 0; k < S; ++k) ss += ws[k] * sfeat[256 + k];
         s += ss;
       }
-      float av = s + l1b;
+      float av = s + hp.l1b;
       av = av > 0.f ? av : 0.f;
       int keep = 1;
       if (TRAIN) {
@@ -97,34 +112,34 @@ __device__ __forceinline__ void head_sub_body(const BatchDev& b, const ModelDev&
         sa1[ju] = av;
         skeep[ju] = keep ? 1.f : 0.f;
       }
-      sred[ju] = (TRAIN ? (keep ? av * 2.f : 0.f) : av) * l2w;       // F.dropout(p = 0.5): kept * 2
+      sred[ju] = (TRAIN ? (keep ? av * 2.f : 0.f) : av) * hp.l2w;       // F.dropout(p = 0.5): kept * 2
     }
   }
   __syncthreads();
-  if (on && wave == 0) {
+  if (tid < 64) {
     float s = sred[lane] + sred[lane + 64];
     s = igmc_wave_sum_f(s);
     if (lane == 0) {
-      const float o = (s + l2b) * mult;
+      const float o = (s + hp.l2b) * mult;
       out[g] = o;
-      m.err[g] = o - yv;
-      misc[0] = o - yv;
+      m.err[g] = o - hp.yv;
+      misc[0] = o - hp.yv;
     }
   }
   if (!TRAIN) return;
   __syncthreads();
   if (tid < 128) {
     const float dp = 2.f * misc[0] * grad_scale * mult;
-    const float dzv = (sa1[tid] > 0.f && skeep[tid] != 0.f) ? dp * l2w_t * 2.f : 0.f;
+    const float dzv = (sa1[tid] > 0.f && skeep[tid] != 0.f) ? dp * hp.l2w_t * 2.f : 0.f;
     sdz[tid] = dzv;
     m.dz[g * 128 + tid] = dzv;
   }
   __syncthreads();
-  if (on) {   // d feat = dz @ lin1.weight (conv columns): wave w takes hidden units 32 w .. 32 w + 31, lane -> 4 fan-in columns;
-              // rows with dz == 0 (ReLU / dropout: ~3/4 of them) are skipped wave-uniformly
+  {   // d feat = dz @ lin1.weight (conv columns): wave w takes hidden units 16 w .. 16 w + 15, lane -> 4 fan-in columns;
+      // rows with dz == 0 (ReLU / dropout: ~3/4 of them) are skipped wave-uniformly
     const float* w1 = P + m.off_l1w + 4 * lane;
     float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned long long nz = __ballot(lane < 32 && sdz[32 * wave + (lane & 31)] != 0.f);
+    unsigned long long nz = __ballot(lane < 16 && sdz[16 * wave + (lane & 15)] != 0.f);
     while (nz) {
       int q[8];
       float4 wv[8];
@@ -132,19 +147,20 @@ __device__ __forceinline__ void head_sub_body(const BatchDev& b, const ModelDev&
       for (int u = 0; u < 8; ++u) {
         q[u] = nz ? (int)__builtin_ctzll(nz) : -1;
         if (nz) nz &= nz - 1;
-        wv[u] = (q[u] >= 0) ? *(const float4*)(w1 + (int64_t)(32 * wave + q[u]) * D) : make_float4(0.f, 0.f, 0.f, 0.f);
+        wv[u] = (q[u] >= 0) ? *(const float4*)(w1 + (int64_t)(16 * wave + q[u]) * D) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const float dzv = (q[u] >= 0) ? sdz[32 * wave + q[u]] : 0.f;
+        const float dzv = (q[u] >= 0) ? sdz[16 * wave + q[u]] : 0.f;
         s4.x += dzv * wv[u].x; s4.y += dzv * wv[u].y; s4.z += dzv * wv[u].z; s4.w += dzv * wv[u].w;
       }
     }
-    *(float4*)(part4 + wave * 256 + 4 * lane) = s4;
+    *(float4*)(part8 + wave * 256 + 4 * lane) = s4;
   }
   __syncthreads();
   if (on) {
-    const float v = (part4[tid] + part4[256 + tid]) + (part4[512 + tid] + part4[768 + tid]);
+    const float v = ((part8[tid] + part8[256 + tid]) + (part8[512 + tid] + part8[768 + tid])) +
+                    ((part8[1024 + tid] + part8[1280 + tid]) + (part8[1536 + tid] + part8[1792 + tid]));
     m.gfeat[(size_t)g * D + tid] = v;
     if (((tid >> 5) & 3) == 3) {      // dPre_3: non-zero on the two target rows only
       m.dpre[3][trow] = v * (1.f - fv * fv);
