@@ -2230,7 +2230,8 @@ __host__ __device__ static inline int dlb_words(int kp, int ng = 1) {
 // (GS: row / h / partial tiles of DL_GB bundles, their block rows, the planes, both groups' transposed images -- whose space
 //  the T' tiles of one group at a time take over)
 __host__ __device__ static inline int dlb_words_gs(int kp) {
-  return 3 * DL_GB * 16 * G2_XP + DL_GB * 4 * kp + (G2_NT * 32 * kp >> 1) + 2 * G2_WIMG;
+  const int mid = (G2_NT * 32 * kp >> 1) + 2 * G2_WIMG, til = 2 * DL_GB * 16 * G2_TP;      // (the T' tiles of both groups alias them)
+  return 3 * DL_GB * 16 * G2_XP + DL_GB * 4 * kp + (mid > til ? mid : til);
 }
 
 template <bool FLAGS, int NG, bool DENSE3, bool GS = false>
@@ -2465,7 +2466,6 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
       const bool active = bw < nact;
       const unsigned char* rmo = RMW + (size_t)(bw * 16 + li) * rmp + 8 * kq;
       float* XO = XOA + bw * 16 * G2_XP;
-      float* T = TIL + bw * 16 * G2_TP;
       float* HS = HSA + bw * 16 * G2_XP;
       const int sk = 42 + (3 - l) * NG * 7;          // (phase clocks)
       DL_STAMP(sk);
@@ -2537,6 +2537,14 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
       DL_STAMP(sk + 4);
       __syncthreads();                               // partial dX in place; every wave is done with planes / images
       DL_STAMP(sk + 5);
+      float* T8 = (float*)PLN + (gw * NB + bw) * 16 * G2_TP;      // the T' tile of (group, bundle): over planes + images
+      if (active && gw == 1) {                       // (laid down while the leaders are in their epilogue)
+#pragma unroll
+        for (int r = 0; r < G2_NR; ++r)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            *(float4*)(T8 + li * G2_TP + r * 32 + 16 * t + 4 * kq) = make_float4(acc[r][t][0], acc[r][t][1], acc[r][t][2], acc[r][t][3]);
+      }
       if (active && gw == 0) {
         const f32x4* px = (const f32x4*)(PXP + bw * 16 * G2_XP) + 2 * lane;
         const f32x4 p0 = px[0], p1 = px[1];
@@ -2567,55 +2575,64 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
           }
         }
       }
-#pragma unroll 1
-      for (int gi = 0; gi < 2; ++gi) {
-        const int grp = 1 - gi;                      // table h_{l-1}^T [T'_0 .. T'_4 | dPre_l] of group grp (d root: group 0)
-        const uint32_t rb = (uint32_t)(G2_NR * grp);
-        if (active && gw == grp) {
+      // ---- the tables h_{l-1}^T [T'_0 .. T'_4 | dPre_l] of BOTH groups in one pass: the T' tiles of the two groups x four
+      //      bundles take the place of planes + images (all dead: the next layer's fetch rewrites the whole plane image);
+      //      wave = (row half, three column tiles) of either group's table -- six independent accumulators
+      if (active && gw == 0) {
 #pragma unroll
-          for (int r = 0; r < G2_NR; ++r)
+        for (int r = 0; r < G2_NR; ++r)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-              *(float4*)(T + li * G2_TP + r * 32 + 16 * t + 4 * kq) = make_float4(acc[r][t][0], acc[r][t][1], acc[r][t][2], acc[r][t][3]);
-        }
-        __syncthreads();                             // the group's tiles (and, first time round, the h rows) are in place
-        f32x4 w3[3];
+          for (int t = 0; t < 2; ++t)
+            *(float4*)(T8 + li * G2_TP + r * 32 + 16 * t + 4 * kq) = make_float4(acc[r][t][0], acc[r][t][1], acc[r][t][2], acc[r][t][3]);
+      }
+      __syncthreads();                               // tiles and h rows are in place
+      {
+        f32x4 w3[2][3];
 #pragma unroll
-        for (int i3 = 0; i3 < 3; ++i3) w3[i3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+          for (int i3 = 0; i3 < 3; ++i3) w3[gq][i3] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int m2w = wave >> 2, nt0 = 3 * (wave & 3);
 #pragma unroll 1
         for (int wb = 0; wb < nact; ++wb) {
-          const float* Tb = TIL + wb * 16 * G2_TP;
+          const float* Tb0 = (const float*)PLN + wb * 16 * G2_TP;
+          const float* Tb1 = (const float*)PLN + (NB + wb) * 16 * G2_TP;
           const float* Hb = HSA + wb * 16 * G2_XP;
           const float* Db = XOA + wb * 16 * G2_XP;
-          float av[4], bwv[4][3];
+          float av[4], bwv[2][4][3];
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4) {
             av[s4] = Hb[(4 * s4 + kq) * G2_XP + m2w * 16 + li];
 #pragma unroll
             for (int i3 = 0; i3 < 3; ++i3) {
               const int nt = nt0 + i3;
-              bwv[s4][i3] = (nt < 2 * G2_NR) ? Tb[(4 * s4 + kq) * G2_TP + nt * 16 + li]
-                                             : Db[(4 * s4 + kq) * G2_XP + (nt - 2 * G2_NR) * 16 + li];
+              bwv[0][s4][i3] = (nt < 2 * G2_NR) ? Tb0[(4 * s4 + kq) * G2_TP + nt * 16 + li]
+                                                : Db[(4 * s4 + kq) * G2_XP + (nt - 2 * G2_NR) * 16 + li];
+              bwv[1][s4][i3] = (nt < 2 * G2_NR) ? Tb1[(4 * s4 + kq) * G2_TP + nt * 16 + li] : 0.f;
             }
           }
           G2_SCHED_BARRIER();
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-            for (int i3 = 0; i3 < 3; ++i3) w3[i3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bwv[s4][i3], w3[i3], 0, 0, 0);
+            for (int i3 = 0; i3 < 3; ++i3) {
+              w3[0][i3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bwv[0][s4][i3], w3[0][i3], 0, 0, 0);
+              if (nt0 + i3 < 2 * G2_NR) w3[1][i3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s4], bwv[1][s4][i3], w3[1][i3], 0, 0, 0);
+            }
         }
 #pragma unroll
-        for (int i3 = 0; i3 < 3; ++i3) {
-          const int nt = nt0 + i3, r = nt >> 1;         // 32-column block: relation rb + r, or G2_NR = dPre_l (d root: group 0)
-          const int rg = (int)rb + r;
-          if (r < G2_NR ? rg >= R : grp > 0) continue;
-          float* pp = wpart + (kq * 4) * 32 + li + (r < G2_NR ? rg : R) * 1024 + m2w * 512 + (nt & 1) * 16;
+        for (int gq = 0; gq < 2; ++gq)
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) pp[rr * 32] = w3[i3][rr];
-        }
-        __syncthreads();                             // the group's tiles are consumed
+          for (int i3 = 0; i3 < 3; ++i3) {
+            const int nt = nt0 + i3, r = nt >> 1;       // 32-column block: relation 5 gq + r, or G2_NR = dPre_l (d root: group 0)
+            const int rg = G2_NR * gq + r;
+            if (r < G2_NR ? rg >= R : gq > 0) continue;
+            float* pp = wpart + (kq * 4) * 32 + li + (r < G2_NR ? rg : R) * 1024 + m2w * 512 + (nt & 1) * 16;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) pp[rr * 32] = w3[gq][i3][rr];
+          }
       }
+      __syncthreads();                               // tiles, h rows and dPre_l are consumed
       DL_STAMP(sk + 6);
       if (l > 1 && active && gw == 0) {              // dPre_{l-1} of the rows becomes the next layer's own rows (the d root
 #pragma unroll                                       // block of group 0's product has read dPre_l)
