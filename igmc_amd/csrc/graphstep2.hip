@@ -1412,10 +1412,12 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
   const int ldb = side ? a.relmT_ld : a.relm_ld, ldw = ldb >> 2;
   const uint8_t* rsrc = side ? a.relmT + (size_t)g * a.cap_v * a.relmT_ld : a.relm + (size_t)g * a.cap_u * a.relm_ld;
   const int rw = rmp >> 2;
+  // (r = i / rw for i < 17 * 64 without a division per element: the quotient by a 20-bit reciprocal is exact there)
+  const uint32_t rw_magic = ((1u << 20) + (uint32_t)rw - 1u) / (uint32_t)rw;
   uint32_t rmq[DL_RIT];                            // this wave's 16 rows of the dense block, dwords lane + 64 u
 #pragma unroll
   for (int u = 0; u < DL_RIT; ++u) {
-    const int i = lane + 64 * u, r = i / rw, c = i - r * rw;
+    const int i = lane + 64 * u, r = (int)(((uint32_t)i * rw_magic) >> 20), c = i - r * rw;
     const int rc = row0 + r < n_own ? row0 + r : n_own - 1, cc = c < ldw ? c : ldw - 1;
     rmq[u] = ((const uint32_t*)(rsrc + (size_t)rc * ldb))[cc];
   }
@@ -1471,7 +1473,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
     uint32_t* dst = (uint32_t*)(RMW + (size_t)wave * 16 * rmp);
 #pragma unroll
     for (int u = 0; u < DL_RIT; ++u) {
-      const int i = lane + 64 * u, r = i / rw, c = i - r * rw;
+      const int i = lane + 64 * u, r = (int)(((uint32_t)i * rw_magic) >> 20), c = i - r * rw;
       if (i < 16 * rw) dst[i] = (row0 + r < n_own && c < ldw && 4 * c < 32 * nks) ? rmq[u] : 0u;
     }
   }
@@ -1761,6 +1763,8 @@ struct DlfArgs {
   const int32_t* n_items;
   const int32_t* node_off;
   const uint8_t* node_label;
+  const uint8_t* s_lab;          // the arena's slot-based labels [graph][slot] (node_label is its collated copy)
+  int slot;
   const uint8_t* relm;
   const uint8_t* relmT;
   int cap_u, cap_v, relm_ld, relmT_ld, nqu, nqv, R, L, kp;
@@ -1851,18 +1855,24 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
   const int ldb = side ? a.relmT_ld : a.relm_ld, ldw = ldb >> 2;
   const uint8_t* rsrc = side ? a.relmT + (size_t)g * a.cap_v * a.relmT_ld : a.relm + (size_t)g * a.cap_u * a.relm_ld;
   const int rw = rmp >> 2;
+  // (r = i / rw for i < 17 * 64 without a division per element: the quotient by a 20-bit reciprocal is exact there)
+  const uint32_t rw_magic = ((1u << 20) + (uint32_t)rw - 1u) / (uint32_t)rw;
   uint32_t rmq[DL_RIT];
 #pragma unroll
   for (int u = 0; u < DL_RIT; ++u) {
-    const int i = lane + 64 * u, r = i / rw, c = i - r * rw;
+    const int i = lane + 64 * u, r = (int)(((uint32_t)i * rw_magic) >> 20), c = i - r * rw;
     const int rc = row0 + r < n_own ? row0 + r : n_own - 1, cc = c < ldw ? c : ldw - 1;
     rmq[u] = lead ? ((const uint32_t*)(rsrc + (size_t)rc * ldb))[cc] : 0u;
   }
-  const int own_lab = (int)a.node_label[own0 + (row0 + li < n_own ? row0 + li : n_own - 1)];
+  // (labels from the arena's slot-based array, of which the collated node_label is a copy: no wait for the subgraph's node
+  //  offset in front of these loads)
+  const uint8_t* slab_own = a.s_lab + (size_t)g * a.slot + (side ? a.cap_u : 0);
+  const uint8_t* slab_opp = a.s_lab + (size_t)g * a.slot + (side ? 0 : a.cap_u);
+  const int own_lab = (int)slab_own[row0 + li < n_own ? row0 + li : n_own - 1];
   int l0 = 255, l1 = 255;                         // labels of the opposite side's node pair tid (< 16 nks <= 128)
   if (tid < 16 * nks) {
-    l0 = (2 * tid < n_opp) ? (int)a.node_label[opp0 + 2 * tid] : 255;
-    l1 = (2 * tid + 1 < n_opp) ? (int)a.node_label[opp0 + 2 * tid + 1] : 255;
+    l0 = (2 * tid < n_opp) ? (int)slab_opp[2 * tid] : 255;
+    l1 = (2 * tid + 1 < n_opp) ? (int)slab_opp[2 * tid + 1] : 255;
   }
   // layer-0 table: 1024 (NG = 1: eight bytes a thread) / 2048 floats
   const float2 t0v = ((const float2*)(a.g2_w + g2_t0_off(NG)))[tid];
@@ -1906,14 +1916,16 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
 #pragma unroll
     for (int lb = 0; lb < 8; ++lb) OHP[(lb * kp >> 1) + tid] = ((l0 == lb) ? 0x3F80u : 0u) | ((l1 == lb) ? 0x3F800000u : 0u);
   }
+  DL_STAMP(31);
   if (lead) {
     uint32_t* dst = (uint32_t*)(RMW + (size_t)bw * 16 * rmp);
 #pragma unroll
     for (int u = 0; u < DL_RIT; ++u) {
-      const int i = lane + 64 * u, r = i / rw, c = i - r * rw;
+      const int i = lane + 64 * u, r = (int)(((uint32_t)i * rw_magic) >> 20), c = i - r * rw;
       if (i < 16 * rw) dst[i] = (row0 + r < n_own && c < ldw && 4 * c < 32 * nks) ? rmq[u] : 0u;
     }
   }
+  DL_STAMP(32);
   ((float2*)sT0)[tid] = t0v;
   if (NG > 1) ((float2*)sT0)[DL_THREADS + tid] = t0w;
   if (!GS) wpre(1, 0);
@@ -2183,6 +2195,8 @@ struct DlbArgs {
   const int32_t* n_items;
   const int32_t* node_off;
   const uint8_t* node_label;
+  const uint8_t* s_lab;          // the arena's slot-based labels [graph][slot]
+  int slot;
   const uint8_t* relm;
   const uint8_t* relmT;
   int cap_u, cap_v, relm_ld, relmT_ld, nqu, nqv, R, L, D, kp;
@@ -2303,10 +2317,12 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
   const int ldb = side ? a.relmT_ld : a.relm_ld, ldw = ldb >> 2;
   const uint8_t* rsrc = side ? a.relmT + (size_t)g * a.cap_v * a.relmT_ld : a.relm + (size_t)g * a.cap_u * a.relm_ld;
   const int rw = rmp >> 2;
+  // (r = i / rw for i < 17 * 64 without a division per element: the quotient by a 20-bit reciprocal is exact there)
+  const uint32_t rw_magic = ((1u << 20) + (uint32_t)rw - 1u) / (uint32_t)rw;
   uint32_t rmq[DL_RIT];
 #pragma unroll
   for (int u = 0; u < DL_RIT; ++u) {
-    const int i = lane + 64 * u, r = i / rw, c = i - r * rw;
+    const int i = lane + 64 * u, r = (int)(((uint32_t)i * rw_magic) >> 20), c = i - r * rw;
     const int rc = row0 + r < n_own ? row0 + r : n_own - 1, cc = c < ldw ? c : ldw - 1;
     rmq[u] = lead0 ? ((const uint32_t*)(rsrc + (size_t)rc * ldb))[cc] : 0u;
   }
@@ -2315,7 +2331,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
   uint16_t c0q[C0N];
 #pragma unroll
   for (int u = 0; u < C0N; ++u) c0q[u] = 0;
-  const int own_lab = (int)a.node_label[own0 + (row0 + li < n_own ? row0 + li : n_own - 1)];
+  const int own_lab = (int)a.s_lab[(size_t)g * a.slot + (side ? a.cap_u : 0) + (row0 + li < n_own ? row0 + li : n_own - 1)];
   constexpr int NWQ = (G2_WIMG / 4 + DL_THREADS - 1) / DL_THREADS;
   f32x4 wq[NWQ];                                  // a layer's transposed weight image: requested at the top of the layer,
   auto wpre = [&](int l, int grp) {               // stored behind the exchange poll (held across a layer it costs 38 spills)
@@ -2354,7 +2370,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
     uint32_t* dst = (uint32_t*)(RMW + (size_t)bw0 * 16 * rmp);
 #pragma unroll
     for (int u = 0; u < DL_RIT; ++u) {
-      const int i = lane + 64 * u, r = i / rw, c = i - r * rw;
+      const int i = lane + 64 * u, r = (int)(((uint32_t)i * rw_magic) >> 20), c = i - r * rw;
       if (i < 16 * rw) dst[i] = (row0 + r < n_own && c < ldw && 4 * c < 32 * nks) ? rmq[u] : 0u;
     }
   }
@@ -2962,17 +2978,19 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_layer0(Dl0Args a) {
     const uint8_t* src = side ? a.relmT + (size_t)g * a.cap_v * a.relmT_ld : a.relm + (size_t)g * a.cap_u * a.relm_ld;
     uint32_t* dst = (uint32_t*)(RMW + (size_t)wave * 16 * rmp);
     const int rw = rmp >> 2;
+  // (r = i / rw for i < 17 * 64 without a division per element: the quotient by a 20-bit reciprocal is exact there)
+  const uint32_t rw_magic = ((1u << 20) + (uint32_t)rw - 1u) / (uint32_t)rw;
     uint32_t rmq[DL_RIT];                          // all requested before the first use (see k_dl_layer)
 #pragma unroll
     for (int u = 0; u < DL_RIT; ++u) {
-      const int i = lane + 64 * u, r = i / rw, c = i - r * rw;
+      const int i = lane + 64 * u, r = (int)(((uint32_t)i * rw_magic) >> 20), c = i - r * rw;
       const int rc = row0 + r < n_own ? row0 + r : n_own - 1, cc = c < ldw ? c : ldw - 1;
       rmq[u] = ((const uint32_t*)(src + (size_t)rc * ldb))[cc];
     }
     G2_SCHED_BARRIER();
 #pragma unroll
     for (int u = 0; u < DL_RIT; ++u) {
-      const int i = lane + 64 * u, r = i / rw, c = i - r * rw;
+      const int i = lane + 64 * u, r = (int)(((uint32_t)i * rw_magic) >> 20), c = i - r * rw;
       if (i < 16 * rw) dst[i] = (row0 + r < n_own && c < ldw && 4 * c < 32 * nks) ? rmq[u] : 0u;
     }
   }
@@ -3189,6 +3207,7 @@ void igmc_launch_dl_fwd(const ModelDev& m, const BatchDev& b, const float* P, in
   a.relm = b.relm; a.relmT = b.relmT;
   a.cap_u = b.cap_u; a.cap_v = b.cap_v; a.relm_ld = b.relm_ld; a.relmT_ld = b.relmT_ld;
   { const DlSplit sq = dl_split(b.cap_u, b.cap_v, B); a.nqu = sq.nqu; a.nqv = sq.nqv; } a.R = m.R; a.L = m.L; a.kp = 32 * ((cmax + 31) >> 5) + 8;
+  a.s_lab = b.s_lab; a.slot = b.slot;
   for (int l = 0; l < 4; ++l) {
     a.h[l] = m.h[l];
     a.off_bias[l] = (int)m.off_bias[l];
@@ -3278,6 +3297,7 @@ void igmc_launch_dl_bwd(const ModelDev& m, const BatchDev& b, int B, int use_fla
   a.relm = b.relm; a.relmT = b.relmT;
   a.cap_u = b.cap_u; a.cap_v = b.cap_v; a.relm_ld = b.relm_ld; a.relmT_ld = b.relmT_ld;
   { const DlSplit sq = dl_split(b.cap_u, b.cap_v, B); a.nqu = sq.nqu; a.nqv = sq.nqv; } a.R = m.R; a.L = m.L; a.D = m.D; a.kp = 32 * ((cmax + 31) >> 5) + 8;
+  a.s_lab = b.s_lab; a.slot = b.slot;
   for (int l = 0; l < 3; ++l) a.h[l] = m.h[l];
   a.dpre3 = m.dpre[3]; a.gfeat = m.gfeat; a.g2_w = m.g2_w; a.cnt0 = m.cnt0;
   a.ts_part = m.ts_part; a.ts_stride = m.ts_stride; a.slot_stride = (B + 7) & ~7;

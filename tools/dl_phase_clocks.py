@@ -47,6 +47,9 @@ def main():
     print('%s, workgroup %d (subgraph %d), relation groups %d; shader cycles' % (cfgname, wg, wg // 4, ng))
     f = c[:40]
     print('k_dl_fwd: set-up %d | layer 0 %d' % (f[1] - f[0], f[2] - f[1]))
+    if f[31]:
+        print('  (set-up: -> zero fills done %d | block rows stored %d | barrier %d;  layer 0: histogram %d | pair barrier %d | table product + tanh %d | epilogue %d | end barrier %d)'
+              % (f[31] - f[0], f[32] - f[31], f[1] - f[32], f[33] - f[1], f[34] - f[33], f[35] - f[34], f[36] - f[35], f[2] - f[36]))
     gs = ng == 2 and os.environ.get('IGMC_DL_GSPLIT', '1') != '0' and cfgname in ('flixster', 'ml_10m_lite')
     if gs:      # group split: both relation groups at once on the two halves of the workgroup (graphstep2.hip, GS)
         for l in (1, 2, 3):
