@@ -82,6 +82,7 @@ class GroupPipeline(object):
         self.M = self.M_default
         self.use_graph = bool(use_graph)
         self.graph = None
+        self.pacing_fallback = None     # '1' once the extraction chain's pacing gates kept timing out (StepGraph.check)
         self.n_links = 0
         self.k = 0                      # steps done in the current epoch
         self.gq, self.gk = 0, 0         # parity of the current group, steps done in it (mirrors of the control block)
@@ -140,7 +141,7 @@ class GroupPipeline(object):
         # extraction chain runs free beside the group's steps: the longer chain of the cap-200 arenas, confined to the CUs the
         # dense-layer launches leave, would reach the group's join late (125.8 -> 129.9 us, round 4).
         plan = self._extract_plan(1 - q, self.M)
-        mode = os.environ.get('IGMC_EXTRACT_PACED', (getattr(self, 'pacing_fallback', None) or '2') if self._paced_default() else '0')
+        mode = os.environ.get('IGMC_EXTRACT_PACED', (self.pacing_fallback or '2') if self._paced_default() else '0')
         paced = mode != '0' and len(plan) > 1
         per = max(1, self.M // max(1, len(plan)))
         self._fork()
@@ -654,7 +655,7 @@ class StepGraph(GroupPipeline):
         # are not served concurrently here (dispatches serialised by a profiler, both streams on one hardware queue) and every
         # gate costs its timeout: pace by graph edges from now on (the graph is captured again on its next use)
         gave_up = int(words[_lib.CTRL['GATE_TIMEOUTS']])
-        if gave_up >= 4 and getattr(self, 'pacing_fallback', None) is None:
+        if gave_up >= 4 and self.pacing_fallback is None:
             sys.stderr.write('igmc_amd: %d pacing gates of the extraction chain timed out (streams not served concurrently?); '
                              'pacing by graph edges from here on\n' % gave_up)
             self.pacing_fallback = '1'
