@@ -2830,17 +2830,15 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
       __syncthreads();                               // tiles, h rows and dPre_l are consumed
       if (NG == 1) {
         if (l > 1) {
-          // dPre_{l-1} of the rows becomes the next layer's own rows; the planes' first k-steps were tiles: zero what the
-          // next reload does not cover
+          // dPre_{l-1} of the rows becomes the next layer's own rows.  (The planes' space held the tiles: the next layer's
+          // fetch copies the WHOLE plane image of its exchange region -- 192 kp bytes, g2_planes_load_exact -- over it; a zero
+          // fill + barrier here, from the days of row-by-row reloads, cost 2.5 k cycles a layer.)
           if (active) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
               for (int rr = 0; rr < 4; ++rr) XO[(4 * kq + rr) * G2_XP + 16 * nt + li] = dv[nt][rr];
           }
-          const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-          for (int i = tid; i < (G2_NT * 32 * kp >> 3); i += DL_THREADS) ((float4*)PLN)[i] = z4;
-          __syncthreads();                           // (the zero fill is complete before the reload writes into it)
         }
       } else if (ngr == 1 && l > 1) {                // (one group that holds relations: its product has just read dPre_l)
         if (active) {
