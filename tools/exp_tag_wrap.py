@@ -45,8 +45,9 @@ def run(cfgname, want_steps=70000):
         steps += (n + 49) // 50
     torch.cuda.synchronize()
     ok = all(np.isfinite(losses)) and losses[-1] < losses[0]
-    print('%s: %d steps in %d epochs, %.1f s; mean loss of epoch 1 / last: %.4f / %.4f; %s'
-          % (cfgname, steps, ep, time.time() - t0, losses[0], losses[-1], 'OK' if ok else 'SUSPECT'))
+    print('%s: %d steps in %d epochs, %.1f s; mean loss of epoch 1 / last: %.4f / %.4f; pacing gates %s; %s'
+          % (cfgname, steps, ep, time.time() - t0, losses[0], losses[-1],
+             'fell back to edges' if sg.pacing_fallback else 'never gave up often enough to fall back', 'OK' if ok else 'SUSPECT'))
     return ok
 
 
