@@ -306,6 +306,42 @@ def run_secondary(configs=('ml_100k', 'douban', 'flixster', 'ml_10m_lite', 'yaho
     return out
 
 
+def spawn_ranks(n, out):
+    """``python bench.py --gpus N`` started WITHOUT a launcher: start the N ranks (one process per device, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* as torch.distributed.run would set them, rendezvous on 127.0.0.1) and wait for them.  Rank 0's
+    stdout -- the ONE JSON line -- goes to ``out``, everything else to stderr.  Fewer visible devices than N is an error
+    (rc 2), unless the one-GPU dry run is asked for explicitly (IGMC_LOCAL_DEVICE, tools/gpu_dp_dry.sh).  Returns the
+    first non-zero exit code of a rank (the others are terminated by PID)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n and 'IGMC_LOCAL_DEVICE' not in os.environ:
+        sys.stderr.write('bench.py: --gpus %d but %d device(s) visible; refusing to run fewer ranks than asked for\n' % (n, have))
+        return 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=out if r == 0 else sys.stderr, stderr=sys.stderr))
+    rc, live = 0, list(procs)
+    while live:
+        for p in list(live):
+            c = p.poll()
+            if c is None:
+                continue
+            live.remove(p)
+            if c != 0 and rc == 0:
+                rc = c
+                for q in live:              # a rank failed: the others would wait in a collective for it
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     # stdout carries the ONE JSON line and nothing else: libraries that print to the C-level stdout (RCCL's version banner
     # at communicator creation, flushed at exit) are pointed at stderr for the whole run
@@ -332,9 +368,26 @@ def main():
                     help='skip the short runs of the other configurations the default run appends (secondary)')
     ap.add_argument('--no-floor', action='store_true', help='skip the latency-floor leg of the roofline (edgeless batch)')
     ap.add_argument('--cpu-baseline-worker', default=None, help=argparse.SUPPRESS)
+    ap.add_argument('--dp-transport', default=None, choices=['auto', 'p2p', 'rccl', 'host'],
+                    help='gradient exchange of the data-parallel step (N > 1): p2p = one-shot all-reduce over peer-mapped buffers, '
+                         'rccl = the library\'s own RCCL communicator, host = torch.distributed\'s process group; auto (default) = '
+                         'the first of p2p -> rccl -> host every rank can set up (igmc_amd/parallel.py: grad_comm)')
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args.cpu_baseline_worker)
+    if args.dp_transport:
+        os.environ['IGMC_DP_TRANSPORT'] = args.dp_transport
+    if args.gpus < 1:
+        sys.stderr.write('bench.py: --gpus must be >= 1\n')
+        sys.exit(2)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher of N ranks of this very file
+        # (one per device; rank 0 prints the ONE JSON line) -- never a silent one-GPU run under an N-GPU label
+        sys.exit(spawn_ranks(args.gpus, real_stdout))
+    if int(os.environ.get('WORLD_SIZE', '1')) != args.gpus:
+        # (a launcher that started another number of ranks than --gpus asks for: refuse -- the line's n_gpus must be what ran)
+        sys.stderr.write('bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks\n' % (args.gpus, os.environ.get('WORLD_SIZE', '1')))
+        sys.exit(2)
     cfg = CONFIGS[args.config]
     want_cpu = not args.no_cpu_baseline and int(os.environ.get('WORLD_SIZE', '1')) <= 1
 
@@ -353,11 +406,13 @@ def main():
     (_, _, A, tr_l, tr_u, tr_v, _, _, _, te_l, te_u, te_v, class_values) = split
     # (IGMC_DIST_BACKEND=gloo + IGMC_LOCAL_DEVICE=0 + IGMC_DP_HOST_COMM=1: a dry run of the multi-rank path with every rank
     #  on ONE GPU -- RCCL refuses that -- to exercise this file's N > 1 logic; its throughput means nothing)
-    rank, world = parallel.init_from_env(os.environ.get('IGMC_DIST_BACKEND', 'nccl'))
-    if world != args.gpus:
-        if rank == 0:
-            sys.stderr.write('warning: --gpus %d but WORLD_SIZE %d (using WORLD_SIZE)\n' % (args.gpus, world))
     local = int(os.environ.get('IGMC_LOCAL_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+    if not torch.cuda.is_available() or local >= torch.cuda.device_count():
+        sys.stderr.write('bench.py: rank %s wants device %d, %d visible\n' % (os.environ.get('RANK', '0'), local,
+                                                                                 torch.cuda.device_count() if torch.cuda.is_available() else 0))
+        sys.exit(2)
+    rank, world = parallel.init_from_env(os.environ.get('IGMC_DIST_BACKEND', 'nccl'))
+    assert world == args.gpus
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if os.environ.get('IGMC_LIB_PATH'):                # debug hook: time an experimental build of the library
@@ -461,28 +516,53 @@ def main():
         if world > 1:
             torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
             torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
-        scratch = torch.zeros_like(model.flat_grad())
-        for _ in range(5):
-            sg.comm.all_reduce_(scratch, st)
-        torch.cuda.synchronize()
-        parallel.barrier()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(50):
-            sg.comm.all_reduce_(scratch, st)
-        e1.record()
-        torch.cuda.synchronize()
-        # (rccl_* only when RCCL IS the transport: a host-callback communicator over gloo reports under comm_*)
-        is_rccl = isinstance(sg.comm, parallel.GradComm)
-        transport = getattr(sg.comm, 'transport', 'rccl' if is_rccl else 'host-callback')
-        if hasattr(sg.comm, 'check'):
-            sg.comm.check(st)
-        dp_check = dict(transport=transport, rccl_rank=rk if is_rccl else None, rccl_world=ws_ if is_rccl else None,
+        def time_allreduce(comm, n):
+            scratch = torch.zeros(n, dtype=torch.float32, device=dev)
+            for _ in range(5):
+                comm.all_reduce_(scratch, st)
+            torch.cuda.synchronize()
+            parallel.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                comm.all_reduce_(scratch, st)
+            e1.record()
+            torch.cuda.synchronize()
+            if hasattr(comm, 'check'):
+                comm.check(st)
+            return e0.elapsed_time(e1) / 50 * 1e3
+
+        # what a step exchanges (igmc_train_step_dp: the reduced tables + basis partials + lin gradients) vs the flat gradient
+        n_flat = int(model.flat_grad().numel())
+        transport = getattr(sg.comm, 'transport', 'host-callback')
+        comms = {transport.split(':')[0].replace('host-callback', 'host'): sg.comm}
+        # the OTHER transports, set up for measurement only (every rank takes part: make_comm is a collective), so that one
+        # run reports the exchange over p2p AND over RCCL -- and RCCL's own view of the world (ncclCommCount) whatever the
+        # training steps went over
+        others = {}
+        if world > 1:
+            for kind in ('p2p', 'rccl'):
+                if kind not in comms:
+                    c, why = parallel.make_comm(lib, local, kind)
+                    others[kind] = why if c is None else 'ok'
+                    if c is not None:
+                        comms[kind] = c
+        allreduce_us = {k: time_allreduce(c, n_flat) for k, c in comms.items()}
+        rccl = comms.get('rccl')
+        rccl_rank, rccl_world = rccl.info() if rccl is not None else (None, None)
+        dp_check = dict(transport=transport, rccl_rank=rccl_rank, rccl_world=rccl_world,
+                        rccl_unavailable=None if rccl is not None else others.get('rccl'),
+                        p2p_unavailable=None if 'p2p' in comms else others.get('p2p'),
                         comm_rank=rk, comm_world=ws_, launcher_rank=rank, launcher_world=world,
-                        ranks_agree=bool(rk == rank and ws_ == world),
+                        ranks_agree=bool(rk == rank and ws_ == world and (rccl is None or (rccl_rank, rccl_world) == (rank, world))),
                         replicas_identical=bool(torch.equal(lo, hi)), param_checksum=float(chk[0].item()),
-                        allreduce_us=e0.elapsed_time(e1) / 50 * 1e3, allreduce_floats=int(scratch.numel()),
-                        allreduce_in_graph=bool(sg.graph is not None))
+                        allreduce_us=allreduce_us.get(transport.split(':')[0].replace('host-callback', 'host')),
+                        allreduce_us_by_transport=allreduce_us, allreduce_floats=n_flat,
+                        allreduce_in_graph=bool(sg.graph is not None),
+                        devices=[torch.cuda.get_device_name(local), 'device %d of %d visible' % (local, torch.cuda.device_count())])
+        for k, c in comms.items():
+            if c is not sg.comm:
+                c.close()
 
     # ---- launch structure of a data-parallel step, measured on ONE GPU: the same steps with the multi-GPU step forced --
     # igmc_train_step_dp: the single-GPU step's kernels + ONE grouped all-reduce (a ONE-RANK RCCL communicator here) of the

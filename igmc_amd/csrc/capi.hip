@@ -1239,9 +1239,18 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_peer_allreduce(PeerArgs p) {
   }
   // A rank may be late by far more than a kernel's length -- first-step capture, a checkpoint write on rank 0, a
   // time-sliced device: the polls are bounded by WALL-CLOCK time (p.timeout_ticks, a minute by default), not by an
-  // iteration count.  A word that never arrives leaves the spans UNTOUCHED (no partial or foreign sum is ever written) and
-  // raises the sticky p.state[2]; the gradient / Adam kernel behind this launch then leaves the parameters alone
-  // (AdamTail::skip) and the host raises at its next check (igmc_comm_check).
+  // iteration count.  A word that never arrives raises the sticky p.state[2]: the element is left as it was, every thread
+  // that sees the flag stops summing, but elements summed BEFORE a thread gave up stay summed -- after a time-out the spans
+  // are a mixture of sums and local values and MUST NOT be used (no foreign or torn value is ever written: a word counts
+  // only with this launch's tag in it).  The gradient / Adam kernel of igmc_train_step_dp behind this launch reads the
+  // flag and leaves parameters, moments and counters alone (AdamTail::skip); the host raises at its next check
+  // (igmc_comm_check).  Callers of the bare igmc_allreduce_grads must call igmc_comm_check before they use the spans.
+  //
+  // CROSS-DEVICE visibility (the words of rank r live in r's HBM, fine-grained, mapped over xGMI): value and flag are ONE
+  // 8-byte word written by ONE system-scope atomic store (global_store_dwordx2 sc0 sc1: written through, never parked in the
+  // writer's L2) and read by ONE system-scope atomic load (sc0 sc1: never served from the reader's L2) -- single-copy
+  // atomic, so a reader sees either the old word (old tag: polls again) or the whole new one.  Nothing else is published
+  // through these buffers, so no release / acquire ordering BETWEEN words is needed: every word validates itself.
 #ifndef IGMC_HIPEMU
   const unsigned long long t_start = wall_clock64();
 #endif

@@ -169,16 +169,36 @@ class PeerComm(object):
             self.close()
             raise RuntimeError('peer communicator: ' + '; '.join(bad))
         self.fine_grained = lib.cdll.igmc_comm_kind(self.handle) == 4
-        # self-test (also the first use of the mapped pointers): sum of r + 1 over the ranks, two launches = both slots
+        # SELF-TEST (also the first use of the mapped pointers) -- what ``auto`` keys on, and the cross-DEVICE proof of the
+        # exchange where the ranks sit on different GPUs: eight launches (both slots four times over, slot reuse included)
+        # of element-distinct values, rank r contributing (r + 1) (1 + i % 7) + k at element i of launch k -- a stale word
+        # of an earlier launch, a word of the wrong slot or a torn read gives a wrong sum somewhere.  Bounded by a short
+        # wall-clock limit of its own (IGMC_PEER_SELFTEST_TIMEOUT_S, 20 s): a node whose peer memory is not visible fails
+        # HERE, within seconds and on every rank, and grad_comm moves on to RCCL.  Outcome raised after the last launch, so
+        # that every rank issues the same launches whatever it sees.
         dev = torch.device('cuda', int(device))
         st = torch.cuda.current_stream(dev).cuda_stream
-        for k in range(2):
-            t = torch.full((1000 + 37 * k,), float(r + 1), dtype=torch.float32, device=dev)
-            self.all_reduce_(t, st)
+        keep = os.environ.get('IGMC_PEER_TIMEOUT_S')
+        os.environ['IGMC_PEER_TIMEOUT_S'] = os.environ.get('IGMC_PEER_SELFTEST_TIMEOUT_S', '20')
+        bad = None
+        try:
+            for k in range(8):
+                n = 1000 + 4093 * k
+                ramp = 1.0 + (torch.arange(n, device=dev) % 7).float()
+                t = float(r + 1) * ramp + float(k)
+                self.all_reduce_(t, st)
+                want = (w * (w + 1) / 2.0) * ramp + float(w * k)
+                if bad is None and not bool((t == want).all().item()):
+                    i = int((t != want).nonzero()[0].item())
+                    bad = 'launch %d, element %d: %g, expected %g' % (k, i, float(t[i]), float(want[i]))
             self.check(st)
-            want = w * (w + 1) / 2.0
-            if not bool((t == want).all().item()):
-                raise RuntimeError('peer all-reduce self-test: wrong sums (%r, expected %g)' % (t[:4].tolist(), want))
+        finally:
+            if keep is None:
+                os.environ.pop('IGMC_PEER_TIMEOUT_S', None)
+            else:
+                os.environ['IGMC_PEER_TIMEOUT_S'] = keep
+        if bad:
+            raise RuntimeError('peer all-reduce self-test: wrong sums (%s)' % bad)
 
     def check(self, stream):
         self.lib.call('igmc_comm_check', self.handle, self.C.c_void_p(stream))
@@ -311,28 +331,48 @@ def grad_comm(lib, device):
     if want == 'auto' and os.environ.get('IGMC_DP_NO_P2P', '0') == '1':
         order = ('rccl', 'host')
     for kind in order:
-        comm, why = None, ''
-        if kind == 'host':
-            if not is_dist():
-                why = 'no torch.distributed process group'
-            else:
-                comm = process_group_comm(lib, device)
-        else:
-            try:
-                comm = PeerComm(lib, device) if kind == 'p2p' else GradComm(lib, device)
-            except RuntimeError as e:          # (RCCL missing / refusing this set of ranks; IPC or the self-test failing)
-                why = str(e)
-        if _agree(comm is not None, device):
+        comm, why = make_comm(lib, device, kind)
+        if comm is not None:
             if tried:
                 print('[igmc] gradient exchange over %s (%s)' % (kind, '; '.join(tried)), file=sys.stderr)
             _grad_comms[key] = comm
             return comm
-        if comm is not None:
-            comm.close()
         tried.append('%s could not be set up on every rank: %s' % (kind, why or 'another rank failed'))
-        if want != 'auto':
-            break
     raise RuntimeError('no gradient exchange: ' + '; '.join(tried))
+
+
+def make_comm(lib, device, kind):
+    """A communicator of ONE kind (``p2p`` / ``rccl`` / ``host``) on every rank, or ``(None, why)`` on every rank: the ranks
+    agree on the outcome (a collective), so nobody is left holding a communicator the others could not set up.  Every rank
+    must call this at the same point.  ``grad_comm`` walks its transports through it; ``bench.py`` uses it to time the
+    transports it is NOT training over (``dp_check.allreduce_us``) and to read RCCL's own view of the world size."""
+    comm, why = None, ''
+    if kind == 'host':
+        if not is_dist():
+            why = 'no torch.distributed process group'
+        else:
+            comm = process_group_comm(lib, device)
+    else:
+        try:
+            comm = PeerComm(lib, device) if kind == 'p2p' else GradComm(lib, device)
+        except RuntimeError as e:          # (RCCL missing / refusing this set of ranks; IPC or the self-test failing)
+            why = str(e)
+    if _agree(comm is not None, device):
+        return comm, ''
+    if comm is not None:
+        comm.close()
+    return None, why or 'another rank failed'
+
+
+def all_reduce_max_int(value, device=None):
+    """MAX over the ranks of a small host-side integer (decisions every rank must take together)."""
+    if not (is_dist() and world_size() > 1):
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64)
+    if dist.get_backend() == 'nccl':
+        t = t.to(torch.device('cuda', int(device) if device is not None else torch.cuda.current_device()))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
 
 
 def barrier():

@@ -610,6 +610,10 @@ class StepGraph(GroupPipeline):
         if fresh and self.graph is not None and prime and self.avail >= self.M and \
                 self.n_links // self.B - self.k >= 2 * self.M:
             self._prime()
+            if self.graph is None and self.use_graph:       # (the primed graph's gates timed out: captured again, edge-paced)
+                self._capture()
+                if self.graph is not None:
+                    self._prime()
         return self.use_graph
 
     def _prime(self):
@@ -628,6 +632,19 @@ class StepGraph(GroupPipeline):
         for _ in range(launches):
             self.graph.replay()
             torch.cuda.synchronize()
+        # The priming launches double as the PROBE of the extraction chain's pacing gates: where the graph's two
+        # chains are not served concurrently (a profiler serialising dispatches, one hardware queue) every gate spins for its
+        # whole time-out -- found here, before the first real group, instead of at the first check() an epoch later.
+        if launches > 0 and self.pacing_fallback is None and self._paced_default() and \
+                os.environ.get('IGMC_EXTRACT_PACED') is None:
+            gave_up = int(self.ctrl[_lib.CTRL['GATE_TIMEOUTS']].item())
+            if self.comm is not None and self.world > 1:
+                gave_up = parallel.all_reduce_max_int(gave_up, self.dev.index)
+            if gave_up >= 4:
+                sys.stderr.write('igmc_amd: %d pacing gates timed out while the step graph was primed (streams not served '
+                                 'concurrently?); pacing by graph edges\n' % gave_up)
+                self.pacing_fallback = '1'
+                self.graph = None
         for t, k in zip((m.flat_parameters(), self.opt.exp_avg, self.opt.exp_avg_sq, self.ctrl, self.total, self.loss), keep):
             t.copy_(k)
         self._regroup()
@@ -655,9 +672,16 @@ class StepGraph(GroupPipeline):
         # are not served concurrently here (dispatches serialised by a profiler, both streams on one hardware queue) and every
         # gate costs its timeout: pace by graph edges from now on (the graph is captured again on its next use)
         gave_up = int(words[_lib.CTRL['GATE_TIMEOUTS']])
-        if gave_up >= 4 and self.pacing_fallback is None:
+        if self.comm is not None and self.world > 1 and self.pacing_fallback is None and self._paced_default():
+            # Under data parallelism the fallback is a decision of ALL ranks (the MAX of their counts): a rank that dropped
+            # its graph alone would wait in _capture()'s barrier while the others replay theirs, whose in-graph exchange then
+            # polls this rank's words until it times out.  Every rank reaches check() at the same points of a run.
+            gave_up_all = parallel.all_reduce_max_int(gave_up, self.dev.index)
+        else:
+            gave_up_all = gave_up
+        if gave_up_all >= 4 and self.pacing_fallback is None:
             sys.stderr.write('igmc_amd: %d pacing gates of the extraction chain timed out (streams not served concurrently?); '
-                             'pacing by graph edges from here on\n' % gave_up)
+                             'pacing by graph edges from here on\n' % gave_up_all)
             self.pacing_fallback = '1'
             self.graph = None
         if gave_up:

@@ -307,9 +307,11 @@ int igmc_adam_step_ctrl(float* d_params, const float* d_grad, float* d_exp_avg, 
  *                         and returns its 64-byte IPC handle; the caller hands the handles of all ranks (world x 64 bytes,
  *                         rank order, any transport) to _connect.  Used like any other communicator afterwards.
  *                         A one-rank peer communicator launches nothing (the spans are the sums).  The polls are bounded by
- *                         WALL-CLOCK time (IGMC_PEER_TIMEOUT_S, default 60 s): a word that never arrives leaves the spans
- *                         unsummed, raises a device word, and the gradient / Adam kernel of igmc_train_step_dp behind the
- *                         exchange then touches no parameter, moment or step counter.
+ *                         WALL-CLOCK time (IGMC_PEER_TIMEOUT_S, default 60 s): a word that never arrives raises a sticky
+ *                         device word -- the spans of that launch are then PARTLY summed (elements finished before the
+ *                         time-out hold sums, the others their local values; never a foreign or torn value) and must not be
+ *                         used -- and the gradient / Adam kernel of igmc_train_step_dp behind the exchange touches no
+ *                         parameter, moment or step counter.  After a bare igmc_allreduce_grads call igmc_comm_check.
  *   igmc_comm_check     : synchronises `stream`; fails -- once -- if a rank's words did not arrive in time in a peer exchange
  *                         since the last check; igmc_comm_kind: 0 one rank, 1 RCCL, 2 host callback, 3 peer-mapped buffers (4: in fine-grained memory).
  */

@@ -600,28 +600,7 @@ def test_static_dataset_cache(flix, tmp_path):
     assert torch.equal(finals[0][0], finals[1][0]) and finals[0][1] == finals[1][1]
 
 
-@pytest.mark.parametrize('transport', ['p2p', 'host_comm', 'fallback'])
-def test_two_ranks_on_one_gpu(tmp_path, transport):
-    """The data-parallel step (igmc_train_step_dp: the subgraph kernel's tables + lin gradients summed over the ranks between
-    k_tail_ts and k_finalize_ts) with TWO ranks on real kernels.  RCCL refuses two ranks on one device, so the exchange
-    goes through torch.distributed's gloo group (IGMC_DP_HOST_COMM=1: a host-callback communicator staged through the
-    host, steps launched eagerly) -- everything else is the product path (StepGraph's group pipeline, the ragged last
-    batch).
-    (a) Both ranks walk the SAME links: the mean over two identical half-batches is the single-GPU gradient, and because
-        1 / (2 B) is exactly half of 1 / B every intermediate is an exact half -- the trajectory must equal the single-GPU
-        step's bit for bit.
-    (b) Links sharded perm[k::2] (three full batches and a ragged one per rank): replicas bit-identical, losses finite,
-        two spans exchanged per step.
-    `p2p`: the exchange is the library's one-shot all-reduce over peer-mapped buffers (igmc_comm_peer_*: HIP IPC handles work
-    between two processes on ONE device), steps captured into the group graphs -- the product's multi-GPU transport on real
-    kernels; the same two checks, plus the transport's name.
-    `fallback`: p2p ruled out, the library tries its own RCCL communicator, RCCL refuses ("Duplicate GPU"), the ranks agree
-    on that over the process group and all of them fall back to it (parallel.grad_comm)."""
-    import os
-    import subprocess
-    import sys
-    script = tmp_path / 'dp2.py'
-    script.write_text(r'''
+_DP2_SCRIPT = r'''
 import os, sys
 sys.path.insert(0, %r)
 import numpy as np, torch, torch.distributed as dist
@@ -631,8 +610,8 @@ from igmc_amd.stepgraph import StepGraph
 from igmc_amd.train_eval import FlatAdam
 from igmc_amd.util_functions import MyDynamicDataset
 rank, world = int(os.environ['RANK']), 2
-torch.cuda.set_device(0)
-dist.init_process_group(backend='gloo', init_method='tcp://127.0.0.1:%%s' %% os.environ.get('DP2_PORT', '29643'), rank=rank, world_size=world)
+torch.cuda.set_device(int(os.environ.get('DP2_DEVICE', '0')))
+dist.init_process_group(backend=os.environ.get('DP2_BACKEND', 'gloo'), init_method='tcp://127.0.0.1:%%s' %% os.environ.get('DP2_PORT', '29643'), rank=rank, world_size=world)
 (_, _, adj, trl, tru, trv, _, _, _, _, _, _, cv) = preprocessing.load_data_monti('douban', testing=True)
 n = 2 * (50 * 3 + 7)
 tr = MyDynamicDataset('data/t/dp2_%%d' %% rank, adj, (tru[:n], trv[:n]), trl[:n], 1, 1.0, 10000, None, None, cv)
@@ -671,11 +650,16 @@ assert len(mine) == 157
 total, cnt = sg.run_epoch(mine, 1)
 P = state(model, opt)[0]
 both = [torch.zeros_like(P) for _ in range(world)]
-dist.all_gather(both, P)
+if dist.get_backend() == 'nccl':
+    both = [b.cuda() for b in both]
+    dist.all_gather(both, P.cuda())
+    both = [b.cpu() for b in both]
+else:
+    dist.all_gather(both, P)
 assert torch.equal(both[0], both[1]), 'replicas differ'
 assert np.isfinite(float(total.item())) and float(total.item()) > 0 and opt.t == 4
 assert not torch.equal(P, dp[0])
-if sg.comm.transport == 'p2p':
+if sg.comm.transport in ('p2p', 'rccl'):
     # ---- (c) the same sharded epoch with the steps CAPTURED (pairs of one-step groups replayed from the hipGraph, the peer
     #      exchange inside them: its launch sequence number lives on the device) == the eager launches, bit for bit
     model, opt = fresh()
@@ -697,20 +681,55 @@ if sg.comm.transport == 'p2p':
     for _ in range(50):
         sg.comm.all_reduce_(t, st)
     e1.record()
-    sg.comm.check(st)
-    print('rank', rank, 'p2p all-reduce of 61000 floats: %%.1f us' %% (e0.elapsed_time(e1) / 50 * 1e3), 'fine-grained buffers:', sg.comm.fine_grained)
+    if hasattr(sg.comm, 'check'):
+        sg.comm.check(st)
+    print('rank', rank, sg.comm.transport, 'all-reduce of 61000 floats: %%.1f us' %% (e0.elapsed_time(e1) / 50 * 1e3), 'fine-grained buffers:', getattr(sg.comm, 'fine_grained', None),
+          'device', torch.cuda.current_device())
 print('rank', rank, 'dp2 ok')
 dist.destroy_process_group()
-''' % ROOT)
+'''
+
+
+@pytest.mark.parametrize('transport', ['p2p', 'host_comm', 'fallback'])
+def test_two_ranks_on_one_gpu(tmp_path, transport):
+    """The data-parallel step (igmc_train_step_dp: the subgraph kernel's tables + lin gradients summed over the ranks between
+    k_tail_ts and k_finalize_ts) with TWO ranks on real kernels.  RCCL refuses two ranks on one device, so the exchange
+    goes through torch.distributed's gloo group (IGMC_DP_HOST_COMM=1: a host-callback communicator staged through the
+    host, steps launched eagerly) -- everything else is the product path (StepGraph's group pipeline, the ragged last
+    batch).
+    (a) Both ranks walk the SAME links: the mean over two identical half-batches is the single-GPU gradient, and because
+        1 / (2 B) is exactly half of 1 / B every intermediate is an exact half -- the trajectory must equal the single-GPU
+        step's bit for bit.
+    (b) Links sharded perm[k::2] (three full batches and a ragged one per rank): replicas bit-identical, losses finite,
+        two spans exchanged per step.
+    `p2p`: the exchange is the library's one-shot all-reduce over peer-mapped buffers (igmc_comm_peer_*: HIP IPC handles work
+    between two processes on ONE device), steps captured into the group graphs -- the product's multi-GPU transport on real
+    kernels; the same two checks, plus the transport's name.
+    `fallback`: p2p ruled out, the library tries its own RCCL communicator, RCCL refuses ("Duplicate GPU"), the ranks agree
+    on that over the process group and all of them fall back to it (parallel.grad_comm)."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / 'dp2.py'
+    script.write_text(_DP2_SCRIPT % ROOT)
+    _run_dp2(script, transport, two_devices=False)
+
+
+def _run_dp2(script, transport, two_devices):
+    import os
+    import subprocess
+    import sys
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', HSA_ENABLE_IPC_MODE_LEGACY='0',
-                   DP2_PORT={'host_comm': '29643', 'fallback': '29644', 'p2p': '29645'}[transport],
-                   DP2_EXPECT={'host_comm': 'host-callback:gloo', 'fallback': 'host-callback:gloo', 'p2p': 'p2p'}[transport])
+                   DP2_PORT={'host_comm': '29643', 'fallback': '29644', 'p2p': '29645', 'rccl': '29646'}[transport],
+                   DP2_EXPECT={'host_comm': 'host-callback:gloo', 'fallback': 'host-callback:gloo', 'p2p': 'p2p', 'rccl': 'rccl'}[transport])
         env.pop('IGMC_DP_HOST_COMM', None)
-        env['IGMC_DP_TRANSPORT'] = {'host_comm': 'host', 'p2p': 'p2p'}.get(transport, 'auto')
+        env['IGMC_DP_TRANSPORT'] = {'host_comm': 'host', 'p2p': 'p2p', 'rccl': 'rccl'}.get(transport, 'auto')
         if transport == 'fallback':
             env['IGMC_DP_NO_P2P'] = '1'          # (auto would take p2p: rule it out to walk rccl -> host)
+        if two_devices:
+            env.update(DP2_DEVICE=str(r), DP2_BACKEND='nccl', DP2_PORT=str(int(env['DP2_PORT']) + 10))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
@@ -718,6 +737,22 @@ dist.destroy_process_group()
         assert 'rank %d dp2 ok' % r in o
         print(o[-300:])
         assert ('rccl could not be set up on every rank' in o) == (transport == 'fallback'), o[-2000:]
+
+
+@pytest.mark.parametrize('transport', ['p2p', 'rccl'])
+def test_two_ranks_on_two_gpus(tmp_path, transport):
+    """``test_two_ranks_on_one_gpu``'s checks with the two ranks on two DIFFERENT devices (skipped on a one-GPU box), over the
+    peer-mapped exchange AND over the library's RCCL communicator, rendezvous over torch.distributed's ``nccl`` backend --
+    the product's multi-GPU configuration: (a) two identical half-batches == the single-GPU step bit for bit, (b) sharded
+    links with a ragged last batch: replicas bit-identical, (c) the steps captured into the group graphs (the exchange
+    inside them) == the eager launches.  The steps run the subgraph kernel (uncapped douban).  This is where the exchange
+    words cross xGMI: fine-grained IPC memory of another device, no shared L2 -- what one device cannot show."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    script = tmp_path / 'dp2.py'
+    script.write_text(_DP2_SCRIPT % ROOT)
+    _run_dp2(script, transport, two_devices=True)
 
 
 def test_captured_all_reduce_next_to_a_torch_distributed_process_group(tmp_path):

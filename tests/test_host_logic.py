@@ -44,6 +44,23 @@ def test_product_package_never_imports_the_oracle():
     assert not bad, bad
 
 
+def test_bench_never_runs_fewer_ranks_than_asked_for():
+    """``python bench.py --gpus N`` without a launcher spawns its N ranks itself; with fewer than N visible devices it refuses
+    (rc != 0, nothing on stdout) instead of measuring one GPU under an N-GPU label; a launcher that started another number
+    of ranks than ``--gpus`` is refused the same way."""
+    import subprocess
+    bench = os.path.join(ROOT, 'bench.py')
+    env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'IGMC_LOCAL_DEVICE'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, bench, '--gpus', '2', '--steps', '4', '--warmup', '1'], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 2 and r.stdout.strip() == b'' and b'refusing' in r.stderr, (r.returncode, r.stderr[-500:])
+    r = subprocess.run([sys.executable, bench, '--gpus', '4', '--steps', '4', '--warmup', '1'], env=dict(env, WORLD_SIZE='2', RANK='0'),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 2 and r.stdout.strip() == b'' and b'WORLD_SIZE=2' in r.stderr, (r.returncode, r.stderr[-500:])
+
+
 def test_shard_positions():
     import torch
     from igmc_amd import parallel

@@ -8,8 +8,8 @@ for n in 2 4 8; do
   # (more than two processes on one chip: the subgraph kernel's clusters of four co-resident workgroups per subgraph no longer
   #  fit next to each other -- its bounded polls raise; those runs take the per-layer kernels, the exchange is the same)
   [ $n -gt 2 ] && export IGMC_GRAPH_STEP=0
-  IGMC_DIST_BACKEND=gloo IGMC_LOCAL_DEVICE=0 IGMC_DP_TRANSPORT=p2p timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n \
-    --master-addr 127.0.0.1 --master-port $((29700 + n)) bench.py --gpus $n --steps 20 --warmup 5 --profile-steps 0 --rmse-links 0 \
+  # (round 6: no launcher -- bench.py spawns its N ranks itself; IGMC_LOCAL_DEVICE=0 is the explicit request for a one-GPU dry run)
+  IGMC_DIST_BACKEND=gloo IGMC_LOCAL_DEVICE=0 timeout 600 python bench.py --gpus $n --dp-transport p2p --steps 20 --warmup 5 --profile-steps 0 --rmse-links 0 \
     > $O/bench_${n}ranks.json 2> $O/bench_${n}ranks.err
   python - "$O/bench_${n}ranks.json" <<'PY'
 import json,sys
