@@ -128,6 +128,7 @@ def check_sampled(d, case):
     from oracle import extract_ref as X
     A, Acsc = case['A'], case['A'].tocsc()
     check_batch_structure(d, 2 * case['h'] + 2)
+    ranks = []          # normalised id-ranks of the chosen candidates wherever a cap / ratio cut a hop-1 candidate set
     for g, rec in enumerate(case['recs']):
         users, items, ulab, vlab, edges = graph_canonical(d, g)
         i, j = case['links'][g]
@@ -138,6 +139,13 @@ def check_sampled(d, case):
             cand_u = set(Acsc.indices[Acsc.indptr[j]:Acsc.indptr[j + 1]].tolist()) - {i}
             cand_v = set(A.indices[A.indptr[i]:A.indptr[i + 1]].tolist()) - {j}
             assert set(users[1:].tolist()) <= cand_u and set(items[1:].tolist()) <= cand_v
+            for chosen, cand in ((users[1:], cand_u), (items[1:], cand_v)):
+                if 0 < len(chosen) < len(cand):
+                    order = {c: r for r, c in enumerate(sorted(cand))}
+                    n, k = len(cand), len(chosen)
+                    m = np.mean([(order[int(c)] + 0.5) / n for c in chosen])
+                    # (mean rank of a simple random k-sample of n equally spaced ranks: 1/2, variance (n^2 - 1) / (12 n^2) (n - k) / (k (n - 1)))
+                    ranks.append((m, (n * n - 1.0) / (12.0 * n * n) * (n - k) / (k * (n - 1.0))))
             if rec is None:
                 # no reference record (full-size cases): the sizes the reference would produce follow from the candidate
                 # sets alone (util_functions.py:222-229: int(ratio * len), then the per-hop cap)
@@ -156,6 +164,13 @@ def check_sampled(d, case):
                                              node_lists=(users, items, udist, vdist))
         ce = X.canonical_edges(users, items, out[0], out[1], out[2])
         assert np.array_equal(ce, edges)
+    # The reference draws a UNIFORM subset (random.sample, util_functions.py:222-229): the chosen candidates' id-ranks average
+    # 1/2.  A sampler with an id bias -- the k lowest or highest ids, a prefix of the CSR row -- fails here (the distribution
+    # proper -- inclusion counts, pairs, sides, epochs -- is tests/test_sampler_stats.py).
+    if len(ranks) >= 8:
+        mean = float(np.mean([m for m, _ in ranks]))
+        sd = float(np.sqrt(np.sum([v for _, v in ranks]))) / len(ranks)
+        assert abs(mean - 0.5) < 6.0 * sd, 'sampled candidates are not uniform over the candidate ids: mean id-rank %.3f (sd %.3f, %d sets)' % (mean, sd, len(ranks))
 
 
 # ====================================================================== model parity

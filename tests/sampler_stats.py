@@ -185,14 +185,16 @@ def report(draws, seeds=SEEDS, epochs=EPOCHS, reps=10):
         lines.append('link %d: users x items of the same draw, joint counts of %d ids: Pearson %.1f (independent uniform: %.1f +- %.1f, '
                      'z = %+.2f)' % (L, m, js, mu, sdj, zs))
         worst['z_sides'] = max(worst['z_sides'], abs(zs))
-        # consecutive epochs of the same (seed, position): rows are seed-major, epoch, position
-        per = Xu.shape[0] // (len(seeds) * ne)
-        Xs = Xu.reshape(len(seeds), ne, per, n)
-        a, b = Xs[:, :-1].reshape(-1, n), Xs[:, 1:].reshape(-1, n)
+        # consecutive epochs of the same (seed, position): rows are seed-major, epoch, position.  (Epoch e + 1 is the second
+        # member of one pair and the first of the next: the null replicates are paired up the same way.)
+        def epoch_pairs(X):
+            per = X.shape[0] // (len(seeds) * ne)
+            Xs = X.reshape(len(seeds), ne, per, n)
+            return Xs[:, :-1].reshape(-1, n), Xs[:, 1:].reshape(-1, n)
+        a, b = epoch_pairs(Xu)
         es, m = joint_stat(a, b)
         rng = np.random.default_rng(3000 + L)
-        ze, mu, sde = calibrated_z(lambda A_, B_: joint_stat(A_, B_)[0], es,
-                                   lambda r: (uniform_inclusion(a.shape[0], n, rng), uniform_inclusion(a.shape[0], n, rng)), reps)
+        ze, mu, sde = calibrated_z(lambda A_, B_: joint_stat(A_, B_)[0], es, lambda r: epoch_pairs(uniform_inclusion(D, n, rng)), reps)
         lines.append('link %d: users of epochs e and e + 1 of the same link, joint counts: Pearson %.1f (independent uniform: %.1f +- '
                      '%.1f, z = %+.2f)' % (L, es, mu, sde, ze))
         worst['z_epochs'] = max(worst['z_epochs'], abs(ze))
