@@ -628,6 +628,9 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
     if (tid < 256) sfeat[tid] = g2_poll_f32(fx + tid, tag0 + G2_FXTAG, a.gs_err);
     __syncthreads();
     G2_STAMP(15);
+    // (the wave's sixteen lin1 rows stay in registers: d feat = dz @ lin1.weight below needs exactly these rows and columns
+    //  again -- a second round trip to the weights, behind a data-dependent row selection, was 2 k cycles of the chain)
+    float4 w4[16];
     {
       // lin1 (256 -> 128): wave w takes hidden units 16 w .. 16 w + 15.  One weight row (1 KB, 8 cache lines) per load
       // instruction, lane = 4 consecutive fan-in columns; the 16 per-lane partial dot products are then reduced over the
@@ -639,7 +642,6 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
       const float* wrow = P + a.off_l1w + (int64_t)(16 * wave) * 256 + 4 * lane;
       float v[16];
       {                                      // 16 rows: all 16 requests leave before the first use
-        float4 w4[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) w4[q] = *(const float4*)(wrow + q * 256);
         G2_SCHED_BARRIER();
@@ -708,24 +710,18 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
       }
       if (cm == 0 && tid < 256) a.feat[(size_t)g * a.D + tid] = sfeat[tid];
       __syncthreads();
-      {   // d feat = dz @ lin1.weight: wave w takes hidden units 16 w .. 16 w + 15, lane -> 4 fan-in columns; rows with
-          // dz == 0 (ReLU / dropout: ~3/4 of them) are skipped wave-uniformly
-        const float* w1 = P + a.off_l1w + 4 * lane;
+      {   // d feat = dz @ lin1.weight: wave w takes hidden units 16 w .. 16 w + 15, lane -> 4 fan-in columns, from the rows
+          // the forward left in registers (rows with dz == 0 -- ReLU / dropout: ~3/4 of them -- add exact zeros)
         float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        unsigned long long nz = __ballot(lane < 16 && sdz[16 * wave + (lane & 15)] != 0.f);
-        while (nz) {
-          int q[8];
-          float4 wv[8];
+        const float4* dz4 = (const float4*)(sdz + 16 * wave);
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            q[u] = nz ? (int)__builtin_ctzll(nz) : -1;
-            if (nz) nz &= nz - 1;
-            wv[u] = (q[u] >= 0) ? *(const float4*)(w1 + (int64_t)(16 * wave + q[u]) * 256) : make_float4(0.f, 0.f, 0.f, 0.f);
-          }
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const float4 d4 = dz4[q4];
+          const float dq[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const float dzv = (q[u] >= 0) ? sdz[16 * wave + q[u]] : 0.f;
-            s4.x += dzv * wv[u].x; s4.y += dzv * wv[u].y; s4.z += dzv * wv[u].z; s4.w += dzv * wv[u].w;
+          for (int u = 0; u < 4; ++u) {
+            const float4 wv = w4[4 * q4 + u];
+            s4.x += dq[u] * wv.x; s4.y += dq[u] * wv.y; s4.z += dq[u] * wv.z; s4.w += dq[u] * wv.w;
           }
         }
         *(float4*)(TILES + wave * 256 + 4 * lane) = s4;

@@ -2,7 +2,7 @@
 ``random.sample`` + torch's RNG streams are not reproducible on a device, so the engine draws from counter-based hashes).
 
 One small CAPPED configuration -- 600 x 400 ratings matrix, ~60 ratings a user / ~90 an item, max-nodes-per-hop 20 (the cap
-binds on practically every link, as at the headline configuration), edge dropout 0.2, batch 50, 4 epochs over 2 000 training
+binds on practically every link, as at the headline configuration), edge dropout 0.2, batch 50, 8 epochs over 2 000 training
 links, 500 static test links -- trained from ``SEEDS`` different seeds by
 
   the engine   MyDynamicDataset / MyDataset + IGMC + train_multiple_epochs: samples = k smallest ``igmc_sample_key``, edge and
@@ -21,8 +21,8 @@ import numpy as np
 import scipy.sparse as sp
 
 N_USERS, N_ITEMS, NNZ = 600, 400, 36000
-CAP, EPOCHS, BATCH, N_TRAIN, N_TEST = 20, 4, 50, 2000, 500
-SEEDS = (11, 12, 13, 14, 15)
+CAP, EPOCHS, BATCH, N_TRAIN, N_TEST = 20, 8, 50, 2000, 500
+SEEDS = tuple(range(11, 21))
 ADJ_DROPOUT, LR, ARR = 0.2, 1e-3, 0.001
 
 
@@ -103,5 +103,6 @@ def oracle_runs(seeds=SEEDS):
     """The oracle's runs in fresh worker processes (spawned: the caller may hold a GPU context), one per seed."""
     import multiprocessing as mp
     from concurrent.futures import ProcessPoolExecutor
-    with ProcessPoolExecutor(max_workers=min(len(seeds), 5), mp_context=mp.get_context('spawn')) as ex:
+    from igmc_amd.hostcpu import cpu_budget          # the CPUs this container is GRANTED, not the ones it sees
+    with ProcessPoolExecutor(max_workers=min(len(seeds), max(1, cpu_budget() // 2)), mp_context=mp.get_context('spawn')) as ex:
         return list(ex.map(_oracle_worker, seeds))

@@ -1,5 +1,5 @@
 """Free-running training: the engine's RNG path (hash sampler, hash dropout) against the reference's (``random.sample`` +
-torch RNG; restated by the oracle) -- agreement of the final test RMSE IN DISTRIBUTION on a small capped configuration, five
+torch RNG; restated by the oracle) -- agreement of the final test RMSE IN DISTRIBUTION on a small capped configuration, ten
 seeds a side (``free_run_parity.py``).  Both sides are deterministic given their seeds, so the
 outcome is a property of the code, not of the day."""
 import pytest

@@ -40,4 +40,4 @@ if __name__ == '__main__':
     t2 = time.time()
     _, _, lines = F.compare(engine, oracle)
     print('\n'.join(lines))
-    print('# wall: oracle %.1f s (5 processes), engine %.1f s' % (t1 - t0, t2 - t1))
+    print('# wall: oracle %.1f s (worker processes), engine %.1f s' % (t1 - t0, t2 - t1))
