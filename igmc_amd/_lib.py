@@ -63,6 +63,7 @@ SIGNATURES = {
     'igmc_sortpool_loss_grad': (i32, [vp, vp, vp, i32, vp, u64, u64, f32, f32, f32, vp, vp, vp, vp]),
     'igmc_sortpool_step_finish': (i32, [vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp]),
     'igmc_sse_accumulate': (i32, [vp, vp, vp, vp]),
+    'igmc_sse_accumulate_tick': (i32, [vp, vp, vp, vp, vp]),
     'igmc_comm_unique_id': (i32, [vp]),
     'igmc_comm_create': (i32, [vp, i32, i32, i32, C.POINTER(vp)]),
     'igmc_comm_destroy': (None, [vp]),

@@ -963,7 +963,13 @@ extern "C" int igmc_adam_step(float* d_params, const float* d_grad, float* d_exp
 
 extern "C" int igmc_sse_accumulate(const float* d_out, const igmc_batch* b, double* d_acc, void* stream) {
   if (!d_out || !b || !d_acc) IGMC_FAIL("null argument");
-  igmc_launch_sse(b->d, d_out, d_acc, stream);
+  igmc_launch_sse(b->d, d_out, d_acc, nullptr, stream);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+extern "C" int igmc_sse_accumulate_tick(const float* d_out, const igmc_batch* b, double* d_acc, int64_t* d_ctrl, void* stream) {
+  if (!d_out || !b || !d_acc || !d_ctrl) IGMC_FAIL("null argument");
+  igmc_launch_sse(b->d, d_out, d_acc, d_ctrl, stream);
   HIPCHECK(hipGetLastError());
   return 0;
 }

@@ -73,7 +73,7 @@ int igmc_launch_train_step(const ModelDev& m, const ModelAux& ax, const BatchDev
                            float beta2, float eps, float wd, int64_t* ctrl, int* done, float* loss, double* total,
                            void* stream, float grad_scale = 0.f, const StepExchange* xch = nullptr, int* img_emitted = nullptr);
 void igmc_launch_loss(const ModelDev& m, const BatchDev& b, float ARR, float* loss, void* stream);
-void igmc_launch_sse(const BatchDev& b, const float* out, double* acc, void* stream);
+void igmc_launch_sse(const BatchDev& b, const float* out, double* acc, int64_t* ctrl, void* stream);
 int igmc_model_prepare(const ModelDev& m);
 void igmc_launch_adam(float* p, const float* g, float* m1, float* m2, int64_t n, float step_size,
                       float inv_sqrt_bc2, float beta1, float beta2, float eps, float wd, int64_t* ctrl, int tick,

@@ -2179,7 +2179,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_loss(BatchDev b, ModelDev m, flo
   loss_body(b, m, ARR, loss, nullptr, smf);
 }
 
-__global__ __launch_bounds__(IGMC_BLOCK) void k_sse_acc(BatchDev b, const float* __restrict__ out, double* acc) {
+__global__ __launch_bounds__(IGMC_BLOCK) void k_sse_acc(BatchDev b, const float* __restrict__ out, double* acc, int64_t* ctrl) {
   __shared__ float smf[8];
   const int B = b.totals[3];
   float s = 0.f;
@@ -2191,6 +2191,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_sse_acc(BatchDev b, const float*
   if (threadIdx.x == 0) {
     acc[0] += (double)s;
     acc[1] += (double)B;
+    if (ctrl) ctrl_advance(ctrl);      // the evaluation step's tick in the same launch (igmc_sse_accumulate_tick)
   }
 }
 
@@ -2703,8 +2704,8 @@ void igmc_launch_loss(const ModelDev& m, const BatchDev& b, float ARR, float* lo
   IGMC_PLAUNCH("k_loss", k_loss, 1, IGMC_BLOCK, 0, stream, b, m, ARR, loss);
 }
 
-void igmc_launch_sse(const BatchDev& b, const float* out, double* acc, void* stream) {
-  IGMC_PLAUNCH("k_sse_acc", k_sse_acc, 1, IGMC_BLOCK, 0, stream, b, out, acc);
+void igmc_launch_sse(const BatchDev& b, const float* out, double* acc, int64_t* ctrl, void* stream) {
+  IGMC_PLAUNCH("k_sse_acc", k_sse_acc, 1, IGMC_BLOCK, 0, stream, b, out, acc, ctrl);
 }
 
 void igmc_launch_tick(int64_t* ctrl, void* stream) { IGMC_PLAUNCH("k_tick", k_tick, 1, 64, 0, stream, ctrl); }

@@ -272,8 +272,12 @@ class ModelWorkspace(object):
         self.lib.call('igmc_adam_step', _p(params), _p(grad), _p(exp_avg), _p(exp_avg_sq), self.n_params, int(step),
                       float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), _p(stream))
 
-    def sse_accumulate(self, out, batch, acc, stream=None):
-        self.lib.call('igmc_sse_accumulate', _p(out), batch.handle, _p(acc), _p(stream))
+    def sse_accumulate(self, out, batch, acc, stream=None, ctrl=None):
+        """``ctrl``: the control block of a grouped evaluation pipeline -- its tick in the same launch."""
+        if ctrl is not None:
+            self.lib.call('igmc_sse_accumulate_tick', _p(out), batch.handle, _p(acc), _p(ctrl), _p(stream))
+        else:
+            self.lib.call('igmc_sse_accumulate', _p(out), batch.handle, _p(acc), _p(stream))
 
     def close(self):
         if getattr(self, 'handle', None):

@@ -69,6 +69,20 @@ def _group_size(steps_hint, default):
     return default
 
 
+def _group_size_for(n_steps, cap=MAX_GROUP):
+    """Group size M <= ``cap`` for a run of ``n_steps`` steps that is NOT a multiple of a convenient length (an evaluation pass
+    over a test set): the M that leaves the fewest steps outside whole graph launches of 2 M steps -- those run eagerly,
+    extraction and model step one after the other, at about twice the cost --, the larger M on a tie."""
+    n = int(n_steps)
+    cap = max(1, min(int(cap), MAX_GROUP, max(1, n // 2)))
+    best, rest = cap, n % (2 * cap)
+    for m in range(cap, min(cap, 7), -1):
+        r = n % (2 * m)
+        if r < rest:
+            best, rest = m, r
+    return best
+
+
 class GroupPipeline(object):
     """Host logic of the grouped step pipeline -- which extraction / step / re-grouping is launched when --, independent of
     what launches them.  A backend supplies ``_arena(q, i)``, ``_extract(arena, sel, B)``, ``_enqueue_step(arena, B)``,
@@ -713,8 +727,8 @@ class EvalGraph(StepGraph):
         m, st = self.model, torch.cuda.current_stream().cuda_stream
         self.ws.forward(m.flat_parameters().data_ptr(), arena, self.out.data_ptr(), training=False,
                         multiply_by=float(m.multiply_by), stream=st)
-        self.ws.sse_accumulate(self.out.data_ptr(), arena, self.acc.data_ptr(), stream=st)
-        self.lib.call('igmc_ctrl_tick', C.c_void_p(self.ctrl.data_ptr()), C.c_void_p(st))
+        # (squared errors + the step's tick in ONE launch: an evaluation step is two launches)
+        self.ws.sse_accumulate(self.out.data_ptr(), arena, self.acc.data_ptr(), stream=st, ctrl=self.ctrl.data_ptr())
 
     def _count(self, n):
         pass

@@ -22,7 +22,7 @@ import torch.nn.functional as F
 
 from . import _lib, engine, parallel
 from .models import IGMC
-from .stepgraph import EvalGraph, StepGraph
+from .stepgraph import EvalGraph, StepGraph, _group_size_for
 from .util_functions import DeviceBatch
 
 device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
@@ -264,7 +264,9 @@ def eval_loss(model, loader, device, regression=False, show_progress=False):
         if eg is None or eg.model is not model:
             if eg is not None:
                 eg.detach()
-            eg = EvalGraph(model, loader.dataset, loader.batch_size, group=min(32, max(1, nb // 2)))
+            # (group size: the one that leaves the fewest steps outside whole graph launches -- 100 batches as two launches
+            #  of 50 steps instead of one of 64 and 36 eager steps, which took as long as the 64)
+            eg = EvalGraph(model, loader.dataset, loader.batch_size, group=_group_size_for(nb))
             loader._evalgraph = eg
         acc = eg.run(loader.epoch_positions(), loader.epoch).clone()
         _check_workspaces(model)

@@ -335,6 +335,9 @@ int igmc_train_step_dp(igmc_model* m, igmc_comm* comm, float* d_params, const ig
 
 /* Eval reduction helper (reference train_eval.py:195): d_acc[0] += sum_g (out-y)^2, d_acc[1] += B. */
 int igmc_sse_accumulate(const float* d_out, const igmc_batch* b, double* d_acc, void* stream);
+/* ... and, in the same launch, the tick that ends an evaluation step of the grouped pipeline (igmc_ctrl_tick): an evaluation step
+ * is then the forward launch + this one. */
+int igmc_sse_accumulate_tick(const float* d_out, const igmc_batch* b, double* d_acc, int64_t* d_ctrl, void* stream);
 
 /* Per-kernel timing of the last call (HIP events on the launch stream); names/ms arrays are
  * filled up to `cap` (ms = total over `calls` launches of that kernel since the last fetch);
