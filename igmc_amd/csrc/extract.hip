@@ -525,6 +525,9 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_fill(GraphDev G, BatchDev b) {
 // equal slices of it and every thread takes entries at stride 256 inside the slice, locating its row by a binary
 // search over the <= 256 row starts.  (One wave per ROW, as before, made the kernel as long as the longest row: an
 // active user's 2 400 ratings = 10 dependent 256-entry rounds = 35-50 us for ~8 MB of traffic.)
+#ifndef RELM_Q
+#define RELM_Q 4          // entries a thread has in flight per round
+#endif
 __device__ __forceinline__ void relm_body(const GraphDev& G, const BatchDev& b) {
   IGMC_DYN_SMEM(smem);
   __shared__ int sm[16];
@@ -565,29 +568,40 @@ __device__ __forceinline__ void relm_body(const GraphDev& G, const BatchDev& b) 
   const int S = gridDim.y;
   const int lo = (int)((long long)total * blockIdx.y / S), hi = (int)((long long)total * (blockIdx.y + 1) / S);
   int c = 0;
-  for (int e0 = lo; e0 < hi; e0 += 4 * IGMC_BLOCK) {
-    int j[4], rl[4], row[4];
+  // A thread's entries e = lo + tid, + 256, + 512, .. only grow: ONE binary search for its first entry, then the row index
+  // walks forward (rows average a few hundred entries, the stride is 256: less than one step per entry -- the per-entry
+  // binary search was eight dependent LDS reads in front of every global load); RELM_Q entries per round are in flight.
+  int arow = 0;
+  {
+    const int e = lo + tid;
+    if (e < hi) {
+      int a = 0, z = cu;                       // largest row with rstart[row] <= e
+      while (z - a > 1) {
+        const int mid = (a + z) >> 1;
+        if (rstart[mid] <= e) a = mid;
+        else z = mid;
+      }
+      arow = a;
+    }
+  }
+  for (int e0 = lo; e0 < hi; e0 += RELM_Q * IGMC_BLOCK) {
+    int j[RELM_Q], rl[RELM_Q], row[RELM_Q];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < RELM_Q; ++q) {
       const int e = e0 + q * IGMC_BLOCK + tid;
       j[q] = -1;
       rl[q] = 0;
       row[q] = 0;
       if (e < hi) {
-        int a = 0, z = cu;                     // largest row with rstart[row] <= e
-        while (z - a > 1) {
-          const int mid = (a + z) >> 1;
-          if (rstart[mid] <= e) a = mid;
-          else z = mid;
-        }
-        row[q] = a;
-        const int p = rbase[a] + (e - rstart[a]);
+        while (rstart[arow + 1] <= e) ++arow;  // (rstart[cu] = total > e: ends; empty rows are stepped over)
+        row[q] = arow;
+        const int p = rbase[arow] + (e - rstart[arow]);
         j[q] = G.u_idx[p];
         rl[q] = (int)G.u_rel[p];
       }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < RELM_Q; ++q) {
       if (j[q] < 0) continue;
       const bool mt = (j[q] == v0) ? (row[q] != 0) : bm_test(sel_v, j[q]);
       if (mt) {

@@ -23,6 +23,9 @@ if __name__ == '__main__':
     ap.add_argument('--dynamic', action='store_true')
     ap.add_argument('--reps', type=int, default=3)
     a = ap.parse_args()
+    if os.environ.get('IGMC_LIB_PATH'):                # debug hook: an experimental build of the library
+        from igmc_amd import _lib
+        _lib.LIB_PATH = os.environ['IGMC_LIB_PATH']
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):
         split = preprocessing.create_trainvaltest_split(a.config, 1234, True, verbose=False)
