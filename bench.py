@@ -696,7 +696,7 @@ def main():
             symbol = SYMBOLS.get(dom, dom)
             flags = 'true' if cfg['adj_dropout'] > 0 else 'false'
             if dom == 'k_graph_step':
-                symbol = 'k_graph_step2<%s, true>' % flags
+                symbol = 'k_graph_step2<%s, true, true>' % flags
             elif dom == 'k_dl_bwd':       # (NG: relation groups of five, graphstep2.hip)
                 symbol = 'k_dl_bwd<%s, %d, %s>' % (flags, (len(class_values) + 4) // 5, 'true' if args.dgcnn_rs else 'false')
             elif dom == 'k_dl_fwd':

@@ -261,7 +261,11 @@ struct G2Args {
   G2Layout lay2;
 };
 
-template <bool FLAGS, bool TRAIN>
+// ONCE: a workgroup takes exactly one subgraph (clusters, cs > 1: every product launch) -- the body is then STRAIGHT-LINE code.
+// Written as a loop over subgraphs, the compiler hoisted every subgraph-invariant scalar -- some 120 LDS section bases,
+// strides and argument fields -- into the loop's preheader and parked them in VGPR lanes: 430 scalar instructions (~3.4 k
+// cycles, profiles/r06_g2_phase_clocks.txt "loop start -> loads issued") before the first vector load of the launch left.
+template <bool FLAGS, bool TRAIN, bool ONCE>
 __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
   const float* P = a.P;
   IGMC_DYN_SMEM(smem);
@@ -345,8 +349,8 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
   bool first_graph = true;
   G2_STAMP(1);
 
-#pragma unroll 1
-  for (int g = g_first; g < B; g += (cs > 1) ? B : (int)gridDim.x) {
+  int g = g_first;
+  if (g < B) do {
     // per-lane indices are re-derived from an opaque copy of the thread index INSIDE the subgraph loop: everything
     // computed from them then stays inside it (hoisted out of the loop, hundreds of loop-invariant addresses occupy --
     // and spill -- registers for the whole kernel)
@@ -924,7 +928,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
       __syncthreads();
       G2_STAMP(34);
     }
-  }
+  } while (!ONCE && (g += (int)gridDim.x) < B);
 
   if (TRAIN && wave < 4) {
     float* part0 = a.ts_part + (size_t)tslot * ts;             // slice 0 of [4][IGMC_TS_BLOCKS][ts]
@@ -1216,12 +1220,20 @@ int igmc_launch_graph_step2(const ModelDev& m, const BatchDev& b, const float* P
   }
 #endif
   if (getenv("IGMC_GS_TRACE")) fprintf(stderr, "[igmc] k_graph_step B=%d train=%d flags=%d v2 kp=%d lds=%zu cluster=%d grid=%d\n", B, training, use_flags, lay.kp, sm, cs, grid);
-  if (training) {
-    if (use_flags) IGMC_PLAUNCH("k_graph_step", (k_graph_step2<true, true>), grid, G2_THREADS, sm, stream, a);
-    else IGMC_PLAUNCH("k_graph_step", (k_graph_step2<false, true>), grid, G2_THREADS, sm, stream, a);
+  if (cs > 1) {        // one subgraph per workgroup: the straight-line variants
+    if (training) {
+      if (use_flags) IGMC_PLAUNCH("k_graph_step", (k_graph_step2<true, true, true>), grid, G2_THREADS, sm, stream, a);
+      else IGMC_PLAUNCH("k_graph_step", (k_graph_step2<false, true, true>), grid, G2_THREADS, sm, stream, a);
+    } else {
+      if (use_flags) IGMC_PLAUNCH("k_graph_fwd", (k_graph_step2<true, false, true>), grid, G2_THREADS, sm, stream, a);
+      else IGMC_PLAUNCH("k_graph_fwd", (k_graph_step2<false, false, true>), grid, G2_THREADS, sm, stream, a);
+    }
+  } else if (training) {
+    if (use_flags) IGMC_PLAUNCH("k_graph_step", (k_graph_step2<true, true, false>), grid, G2_THREADS, sm, stream, a);
+    else IGMC_PLAUNCH("k_graph_step", (k_graph_step2<false, true, false>), grid, G2_THREADS, sm, stream, a);
   } else {
-    if (use_flags) IGMC_PLAUNCH("k_graph_fwd", (k_graph_step2<true, false>), grid, G2_THREADS, sm, stream, a);
-    else IGMC_PLAUNCH("k_graph_fwd", (k_graph_step2<false, false>), grid, G2_THREADS, sm, stream, a);
+    if (use_flags) IGMC_PLAUNCH("k_graph_fwd", (k_graph_step2<true, false, false>), grid, G2_THREADS, sm, stream, a);
+    else IGMC_PLAUNCH("k_graph_fwd", (k_graph_step2<false, false, false>), grid, G2_THREADS, sm, stream, a);
   }
   return a.self_seq ? 0 : 1;
 }
@@ -1233,10 +1245,12 @@ int igmc_g2_prepare() {
   (void)igmc_g2_xcd_ok();      // (probed here, at model creation: never inside a stream capture)
 #ifndef IGMC_HIPEMU
   const int mx = 160 * 1024;
-  if (hipFuncSetAttribute((const void*)k_graph_step2<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
-  if (hipFuncSetAttribute((const void*)k_graph_step2<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
-  if (hipFuncSetAttribute((const void*)k_graph_step2<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
-  if (hipFuncSetAttribute((const void*)k_graph_step2<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
+  const void* fns[8] = {(const void*)k_graph_step2<true, true, true>,   (const void*)k_graph_step2<false, true, true>,
+                        (const void*)k_graph_step2<true, false, true>,  (const void*)k_graph_step2<false, false, true>,
+                        (const void*)k_graph_step2<true, true, false>,  (const void*)k_graph_step2<false, true, false>,
+                        (const void*)k_graph_step2<true, false, false>, (const void*)k_graph_step2<false, false, false>};
+  for (const void* fn : fns)
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess) return 1;
 #endif
   return 0;
 }

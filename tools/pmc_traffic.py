@@ -33,7 +33,7 @@ def main():
     config = sys.argv[3] if len(sys.argv) > 3 else 'ml_1m'
     # bench.py's roofline kernel: training instantiation, with edge flags when the config has adj-dropout
     name = NAME
-    KERNEL = 'k_graph_step2<false, true>' if config == 'ml_1m' else 'k_graph_step2<true, true>'
+    KERNEL = 'k_graph_step2<false, true, true>' if config == 'ml_1m' else 'k_graph_step2<true, true, true>'
     if config == 'ml_100k':                  # cap 200: the one-launch backward of the dense layers (edge dropout: <true>)
         name, KERNEL = 'k_dl_bwd', 'k_dl_bwd<true, 1, false>'
     c = {}
