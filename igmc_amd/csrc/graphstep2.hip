@@ -629,8 +629,16 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
     }
 
     // ================================================================ head: lin1 / ReLU / dropout / lin2 / residual
+    // the head's small operands -- this lane's lin1 bias and lin2 weight, lin2's bias, the target rating, the lin2 weight of
+    // the dz pass -- are requested HERE, in front of the readout poll: left at their uses they were three dependent round trips
+    // (bias / weight behind the lin1 butterfly, lin2 bias / y behind the next barrier, the dz pass's weight behind the one
+    // after) inside a phase that is nothing but latency
+    const int ju_h = 16 * wave + ((lane >> 1) & 15);
+    float hd_l1b = P[a.off_l1b + ju_h], hd_l2w = P[a.off_l2w + ju_h], hd_l2b = P[a.off_l2b], hd_y = a.y[g];
+    float hd_l2wt = TRAIN ? P[a.off_l2w + (tid & 127)] : 0.f;
     if (tid < 256) sfeat[tid] = g2_poll_f32(fx + tid, tag0 + G2_FXTAG, a.gs_err);
     __syncthreads();
+    G2_OPAQUE(hd_l1b); G2_OPAQUE(hd_l2w); G2_OPAQUE(hd_l2b); G2_OPAQUE(hd_y); G2_OPAQUE(hd_l2wt);      // (landed with the poll)
     G2_STAMP(15);
     // (the wave's sixteen lin1 rows stay in registers: d feat = dz @ lin1.weight below needs exactly these rows and columns
     //  again -- a second round trip to the weights, behind a data-dependent row selection, was 2 k cycles of the chain)
@@ -668,7 +676,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
       s += __shfl_xor(s, 32);
       G2_STAMP(54);
       if (part == 0) {
-        float av = s + P[a.off_l1b + ju];
+        float av = s + hd_l1b;
         av = av > 0.f ? av : 0.f;
         int keep = 1;
         if (TRAIN) {
@@ -681,7 +689,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
           sa1[ju] = av;
           skeep[ju] = keep ? 1.f : 0.f;
         }
-        sred[ju] = (TRAIN ? (keep ? av * 2.f : 0.f) : av) * P[a.off_l2w + ju];      // F.dropout(p = 0.5): kept * 2
+        sred[ju] = (TRAIN ? (keep ? av * 2.f : 0.f) : av) * hd_l2w;      // F.dropout(p = 0.5): kept * 2
       }
     }
     __syncthreads();
@@ -689,8 +697,8 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
       float s = sred[lane] + sred[lane + 64];
       s = igmc_wave_sum_f(s);
       if (lane == 0) {
-        const float o = (s + P[a.off_l2b]) * a.mult;
-        const float e = o - a.y[g];
+        const float o = (s + hd_l2b) * a.mult;
+        const float e = o - hd_y;
         if (cm == 0) {
           a.out[g] = o;
           a.err[g] = e;
@@ -708,7 +716,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
       G2_STAMP(16);
       if (tid < 128) {
         const float dp = 2.f * misc[0] * a.grad_scale * a.mult;
-        const float dzv = (sa1[tid] > 0.f && skeep[tid] != 0.f) ? dp * P[a.off_l2w + tid] * 2.f : 0.f;
+        const float dzv = (sa1[tid] > 0.f && skeep[tid] != 0.f) ? dp * hd_l2wt * 2.f : 0.f;
         sdz[tid] = dzv;
         if (cm == 0) a.dz[g * 128 + tid] = dzv;
       }
