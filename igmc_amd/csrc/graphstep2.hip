@@ -369,8 +369,12 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
     G2_STAMP(48);
     {
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int i = tid; i < nsides * (lay.pside >> 2); i += G2_THREADS) ((float4*)PLN)[i] = z4;
-      for (int i = tid; i < (2 * rmr * rmp >> 4); i += G2_THREADS) ((float4*)RM)[i] = z4;
+      // (the plane image is NOT cleared: its first reader is layer 1's gather, behind a fetch that copies the whole image
+      //  from the exchange region -- planes_load -- and dPre_3's set-up clears what it needs itself; of the block image
+      //  only the row-major one is read since the transposed one went: its rows up to the last k-step an item-side lane can
+      //  touch, 32 G2_KS, which may lie past the rmr rows of the image proper)
+      const int zrows = (2 * rmr < 32 * G2_KS) ? 2 * rmr : 32 * G2_KS;
+      for (int i = tid; i < ((zrows * rmp + 15) >> 4); i += G2_THREADS) ((float4*)RM)[i] = z4;
       for (int i = tid; i < 2 * G2_NB * 16 * G2_XP / 4; i += G2_THREADS) ((float4*)XOA)[i] = z4;
       for (int i = tid; i < G2_NB * 16 * G2_XP / 4; i += G2_THREADS) ((float4*)HIST)[i] = z4;
     }
@@ -587,7 +591,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
     G2_STAMP(5);
 
     // ================================================================ conv layers 1..3, forward
-#pragma unroll 1
+#pragma unroll
     for (int l = 1; l < 4; ++l) {
       float* XOc = (l & 1) ? XO0 : XO1;             // x of the bundle's own rows (h_{l-1})
       float* XOn = (l & 1) ? XO1 : XO0;             // h_l
@@ -778,7 +782,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
       G2_STAMP(18);
 
       // ============================================================== conv layers 3..1, backward
-#pragma unroll 1
+#pragma unroll
       for (int l = 3; l >= 1; --l) {
         float* XOc = (l & 1) ? XO0 : XO1;            // dPre_l of the bundle's own rows
         float* XOn = (l & 1) ? XO1 : XO0;            // dPre_{l-1}
