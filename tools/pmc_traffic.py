@@ -35,10 +35,16 @@ def main():
     name = NAME
     KERNEL = 'k_graph_step2<false, true, true>' if config == 'ml_1m' else 'k_graph_step2<true, true, true>'
     if config == 'ml_100k':                  # cap 200: the one-launch backward of the dense layers (edge dropout: <true>)
-        name, KERNEL = 'k_dl_bwd', 'k_dl_bwd<true, 1, false>'
+        name, KERNEL = 'k_dl_bwd', 'k_dl_bwd<true, 1, false, false>'      # <FLAGS, NG, DENSE3, GS>
     c = {}
     for f in ('pmc1.txt', 'pmc2.txt'):
         c.update(counters('%s/%s' % (src, f), KERNEL))
+    if 'FETCH_SIZE' not in c or 'WRITE_SIZE' not in c:
+        # (round 5 shipped a copy of the headline record under the ml_100k name: the symbol had gained a template parameter,
+        #  nothing matched, the stale file of the previous configuration stayed in place)
+        if os.path.exists(dst):
+            os.remove(dst)
+        raise SystemExit('pmc_traffic: no counters of %s in %s/pmc1.txt / pmc2.txt' % (KERNEL, src))
     from bench import kernel_source_sha
     fetch, write = c['FETCH_SIZE'] * 1024.0, c['WRITE_SIZE'] * 1024.0
     rec = dict(kernel=name, symbol=KERNEL, config=config, src_sha=kernel_source_sha(),
