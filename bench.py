@@ -73,10 +73,10 @@ CONFIGS = {
     'flixster': dict(dataset='flixster', mnph=10000, adj_dropout=0.2, cpu='dynamic'),
     'yahoo_music': dict(dataset='yahoo_music', mnph=10000, adj_dropout=0.2, cpu='dynamic'),
 }
-PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json')      # (ml_1m; other configs: r05_pmc_traffic_<config>.json)
+PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r06_pmc_traffic.json')      # (ml_1m; other configs: r06_pmc_traffic_<config>.json)
 # timer label of the HIP-event profile -> kernel symbol in the code object (what rocprofv3 lists)
 SYMBOLS = {'k_dl_layer_fwd': 'k_dl_layer<FLAGS, false, false>', 'k_rgcn_layer_fwd': 'k_rgcn_layer4<FLAGS, false>',
-           'k_dl_bwd': 'k_dl_bwd<FLAGS, NG, false>', 'k_dl_fwd': 'k_dl_fwd<FLAGS, true, NG>'}
+           'k_dl_bwd': 'k_dl_bwd<FLAGS, NG, false, GS>', 'k_dl_fwd': 'k_dl_fwd<FLAGS, true, NG, GS>'}
 
 
 def kernel_source_sha():
@@ -697,10 +697,14 @@ def main():
             flags = 'true' if cfg['adj_dropout'] > 0 else 'false'
             if dom == 'k_graph_step':
                 symbol = 'k_graph_step2<%s, true, true>' % flags
-            elif dom == 'k_dl_bwd':       # (NG: relation groups of five, graphstep2.hip)
-                symbol = 'k_dl_bwd<%s, %d, %s>' % (flags, (len(class_values) + 4) // 5, 'true' if args.dgcnn_rs else 'false')
-            elif dom == 'k_dl_fwd':
-                symbol = 'k_dl_fwd<%s, true, %d>' % (flags, (len(class_values) + 4) // 5)
+            elif dom in ('k_dl_bwd', 'k_dl_fwd'):
+                # k_dl_bwd<FLAGS, NG, DENSE3, GS> / k_dl_fwd<FLAGS, STORE, NG, GS> (dl_kernels.h): NG relation groups of five;
+                # GS = both groups at once on the two halves of a workgroup, taken where NG = 2 and no workgroup holds more
+                # than four bundles (dl_gsplit: the bundled R = 10 configurations; not the sort-pool family's dense readout)
+                ng = (len(class_values) + 4) // 5
+                gs = 'true' if (ng == 2 and not args.dgcnn_rs) else 'false'
+                symbol = ('k_dl_bwd<%s, %d, %s, %s>' % (flags, ng, 'true' if args.dgcnn_rs else 'false', gs)) if dom == 'k_dl_bwd' \
+                    else 'k_dl_fwd<%s, true, %d, %s>' % (flags, ng, gs)
             roofline = dict(bound='hbm', kernel=symbol, timer_label=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s',
                             frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src, avg_us=avg_us,
                             avg_us_source='device launch clock under hipGraph replay + overlapped extraction'

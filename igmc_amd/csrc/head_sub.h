@@ -135,24 +135,19 @@ __device__ __forceinline__ void head_sub_compute(const HeadPre& hp, const BatchD
     m.dz[g * 128 + tid] = dzv;
   }
   __syncthreads();
-  {   // d feat = dz @ lin1.weight (conv columns): wave w takes hidden units 16 w .. 16 w + 15, lane -> 4 fan-in columns;
-      // rows with dz == 0 (ReLU / dropout: ~3/4 of them) are skipped wave-uniformly
-    const float* w1 = P + m.off_l1w + 4 * lane;
+  {   // d feat = dz @ lin1.weight (conv columns): wave w takes hidden units 16 w .. 16 w + 15, lane -> 4 fan-in columns -- from
+      // the rows the prefetch left in registers (round 6: a second, data-dependent round trip to the weights before; rows with
+      // dz == 0 -- ReLU / dropout: ~3/4 of them -- add exact zeros, the non-zero rows in the same order as before)
     float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned long long nz = __ballot(lane < 16 && sdz[16 * wave + (lane & 15)] != 0.f);
-    while (nz) {
-      int q[8];
-      float4 wv[8];
+    const float4* dz4 = (const float4*)(sdz + 16 * wave);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        q[u] = nz ? (int)__builtin_ctzll(nz) : -1;
-        if (nz) nz &= nz - 1;
-        wv[u] = (q[u] >= 0) ? *(const float4*)(w1 + (int64_t)(16 * wave + q[u]) * D) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const float4 d4 = dz4[q4];
+      const float dq[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float dzv = (q[u] >= 0) ? sdz[16 * wave + q[u]] : 0.f;
-        s4.x += dzv * wv[u].x; s4.y += dzv * wv[u].y; s4.z += dzv * wv[u].z; s4.w += dzv * wv[u].w;
+      for (int u = 0; u < 4; ++u) {
+        const float4 wv = hp.w4[4 * q4 + u];
+        s4.x += dq[u] * wv.x; s4.y += dq[u] * wv.y; s4.z += dq[u] * wv.z; s4.w += dq[u] * wv.w;
       }
     }
     *(float4*)(part8 + wave * 256 + 4 * lane) = s4;

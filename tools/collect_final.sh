@@ -1,8 +1,8 @@
 #!/bin/bash
 # copies the outputs of a final GPU session (tools/gpu_call_final.sh <tag>) from gpurun_out/<tag>/ into profiles/ under the
-# round's names:   bash tools/collect_final.sh r05_final3 r05
+# round's names:   bash tools/collect_final.sh r06_final3 r06
 cd "$(dirname "$0")/.." || exit 1
-S=gpurun_out/$1; R=${2:-r05}
+S=gpurun_out/$1; R=${2:-r06}
 for f in $S/bench_*.json; do n=$(basename $f .json); cp $f profiles/${R}_final_${n}.json; done
 cp $S/kernel_stats.txt profiles/${R}_rocprofv3_kernel_stats.txt
 cp $S/kernel_stats_ml100k.txt profiles/${R}_rocprofv3_kernel_stats_ml100k.txt

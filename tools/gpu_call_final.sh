@@ -6,13 +6,13 @@ O=gpurun_out/${1:-final}; mkdir -p $O
 export TMPDIR=/tmp
 IGMC_COMMIT=${IGMC_COMMIT:-unknown} bash tools/profile_round.sh ml_1m > $O/profile_round.log 2>&1
 cp gpurun_out/prof/*.txt gpurun_out/prof/*.json $O/ 2>/dev/null
-cp gpurun_out/prof/pmc_traffic.json profiles/r05_pmc_traffic.json 2>/dev/null        # (same file is committed afterwards)
+cp gpurun_out/prof/pmc_traffic.json profiles/r06_pmc_traffic.json 2>/dev/null        # (same file is committed afterwards)
 # config 2 (ml_100k, cap 200): the same recipe into its own directory, traffic record of its roofline kernel
 mkdir -p gpurun_out/prof_ml1m && cp gpurun_out/prof/* gpurun_out/prof_ml1m/ 2>/dev/null
 IGMC_COMMIT=${IGMC_COMMIT:-unknown} bash tools/profile_round.sh ml_100k > $O/profile_round_ml100k.log 2>&1
 for f in pmc1 pmc2 pmc3; do cp gpurun_out/prof/$f.txt $O/${f}_ml100k.txt 2>/dev/null; done
 cp gpurun_out/prof/pmc_traffic.json $O/pmc_traffic_ml_100k.json 2>/dev/null
-cp gpurun_out/prof/pmc_traffic.json profiles/r05_pmc_traffic_ml_100k.json 2>/dev/null
+cp gpurun_out/prof/pmc_traffic.json profiles/r06_pmc_traffic_ml_100k.json 2>/dev/null
 cp gpurun_out/prof_ml1m/* gpurun_out/prof/ 2>/dev/null
 # kernel trace of config 2 (ml_100k, cap 200)
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $OLDPWD/$O/kt100k -- python $OLDPWD/bench.py --config ml_100k --steps 100 --warmup 10 --no-cpu-baseline --profile-steps 0 --rmse-links 0 --dp-steps 0 --no-secondary > $OLDPWD/$O/kt100k.log 2>&1 )
