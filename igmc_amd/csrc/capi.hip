@@ -757,13 +757,20 @@ extern "C" int igmc_model_create(int device, int num_relations, int num_bases, i
   d.ex_nodes = 256;
   d.g2_ex_stride = (size_t)Bc * 2 * 32 * d.ex_nodes;
   const int wide = d.R <= G2_NR * G2_NG_MAX;      // relation groups of the dense-layer kernels (g2_image.h)
-  if (wide && Bc <= 2048) {
+  // (both exchanges go through the L2 of one XCD: where the probe says workgroups b and b + 8 do not share one, neither kernel
+  //  family is eligible and ~1 MB per subgraph slot of exchange regions would be allocated for nothing -- ADVICE r5)
+  const int xcd_ok = igmc_g2_xcd_ok();
+  if (wide && Bc <= 2048 && xcd_ok) {
     fail |= M.get(&d.g2_ex, 5 * d.g2_ex_stride) | M.get(&d.g2_fx, Bc * 256) | M.get(&d.g2_w, g2_w_words(d.R, d.L));
     d.g2_graphs = (int)Bc;
     // the subgraph kernel's plane exchange (R <= 5): 320 KB per subgraph slot
     if (d.R <= G2_NR && Bc <= 1024) {
       d.g2_px_stride = (size_t)Bc * 2 * 32768;
       fail |= M.get(&d.g2_px, 5 * d.g2_px_stride);
+    } else if (d.R <= G2_NR) {
+      static bool told = false;
+      if (!told) fprintf(stderr, "[igmc] batches of more than 1024 subgraphs: no plane-exchange regions -- the dense-layer / per-layer kernels take the steps, not the subgraph kernel\n");
+      told = true;
     }
   } else if (wide) {
     fail |= M.get(&d.g2_w, g2_w_words(d.R, d.L));      // weight images alone: the dense per-layer kernels (any head)
@@ -1005,6 +1012,22 @@ extern "C" int igmc_model_set_ctrl(igmc_model* m, const int64_t* d_ctrl) {
   m->d.ctrl = d_ctrl;
   return 0;
 }
+// INVARIANT of the plane / row exchange regions (g2_px, g2_ex, g2_fx): every value in them is FINITE.  A consumer copies the
+// whole plane image of the opposite side, rows past that side's extent included -- whatever an earlier launch left in the
+// subgraph slot --, and relies on 0 * stale == 0 (the A-block bytes there are zero).  Steps that ran on non-finite parameters
+// can leave NaN / Inf rows behind which would poison every later gather of the slot, even after the parameters are restored:
+// the regions are cleared (flags included: 0 is never a launch's tag) whenever parameters are loaded (models.load_state_dict)
+// and when an exchange timed out (igmc_model_check below).
+extern "C" int igmc_model_reset_exchange(igmc_model* m, void* stream) {
+  if (!m) IGMC_FAIL("null model");
+  hipStream_t st = (hipStream_t)stream;
+  if (m->d.g2_ex) {
+    HIPCHECK(hipMemsetAsync(m->d.g2_ex, 0, 5 * m->d.g2_ex_stride * sizeof(unsigned long long), st));
+    HIPCHECK(hipMemsetAsync(m->d.g2_fx, 0, (size_t)m->d.g2_graphs * 256 * sizeof(unsigned long long), st));
+    if (m->d.g2_px) HIPCHECK(hipMemsetAsync(m->d.g2_px, 0, 5 * m->d.g2_px_stride, st));
+  }
+  return 0;
+}
 extern "C" int igmc_model_check(igmc_model* m, void* stream) {
   if (!m) IGMC_FAIL("null model");
   int v = 0;
@@ -1013,6 +1036,8 @@ extern "C" int igmc_model_check(igmc_model* m, void* stream) {
     HIPCHECK(hipMemcpy(&v, m->d.gs_err, sizeof(int), hipMemcpyDeviceToHost));
     if (v) {
       HIPCHECK(hipMemset(m->d.gs_bar, 0, (2 * (size_t)m->d.graph_cap + 1) * sizeof(int)));
+      (void)igmc_model_reset_exchange(m, stream);        // (sequence number and flags restart together; partial rows gone)
+      HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
       IGMC_FAIL("a workgroup-cluster exchange of k_graph_step2 timed out (GPU shared with another job?): results of the "
                 "affected steps are invalid; set IGMC_GS_CLUSTER=1 or IGMC_GRAPH_STEP=0");
     }

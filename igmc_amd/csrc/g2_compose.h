@@ -163,16 +163,25 @@ int igmc_g2_layout(const ModelDev& m, const BatchDev& b, int cs, G2Layout* lay) 
 
 // The plane exchange of k_graph_step2 goes through the L2 of ONE XCD: workgroups b and b + 8 of a launch must sit on the
 // same XCD (round-robin dispatch over the eight XCDs of an MI355X in SPX mode; trivially true on a one-XCD partition).
-// Checked once per process on the device itself -- the hardware XCC id of every workgroup of a 64-workgroup launch -- and
-// the subgraph kernel is not used where it does not hold (the dense-layer kernels, whose exchange is device-coherent, run).
+// Checked once per DEVICE on the device itself -- the hardware XCC id of every workgroup of a 64-workgroup launch -- and
+// neither the subgraph kernel nor the one-launch dense-layer kernels (k_dl_fwd / k_dl_bwd: the same exchange since round 5)
+// are used where it does not hold: the per-layer kernels run.
 __global__ void k_g2_xcc_probe(int* out) {
   if (threadIdx.x == 0) out[blockIdx.x] = (int)(g2_xcc_id() & 15ull);
 }
-static int igmc_g2_xcd_ok() {
+int igmc_g2_xcd_ok() {
 #ifdef IGMC_HIPEMU
   return 1;
 #else
-  static int ok = -1;
+  static int oks[64];
+  static bool init = false;
+  if (!init) {
+    for (int i = 0; i < 64; ++i) oks[i] = -1;
+    init = true;
+  }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  int& ok = oks[dev];
   if (ok >= 0) return ok;
   ok = 0;
   int* d = nullptr;
@@ -185,7 +194,7 @@ static int igmc_g2_xcd_ok() {
       if (h[b] != h[b + 8]) ok = 0;
   }
   (void)hipFree(d);
-  if (!ok) fprintf(stderr, "[igmc] workgroups b and b + 8 of a launch do not share an XCD on this device: the subgraph kernel is not used\n");
+  if (!ok) fprintf(stderr, "[igmc] device %d: workgroups b and b + 8 of a launch do not share an XCD: the subgraph kernel and the one-launch dense layers are not used\n", dev);
   return ok;
 #endif
 }

@@ -83,6 +83,7 @@ void igmc_launch_finish(const ModelDev& m, const BatchDev& b, float* p, const fl
                         int64_t* ctrl, float ARR, float* loss, double* total, int use_flags, void* stream);
 
 // graphstep2.hip: one cluster of workgroups per enclosing subgraph, relational aggregation on the matrix cores
+int igmc_g2_xcd_ok();      // g2_compose.h: 1 = workgroups b and b + 8 of a launch share an XCD on the current device
 struct G2Layout {      // LDS plan of graphstep2.hip, offsets in 4-byte words
   int kp, nsides, rmr, rmc, pside;
   int planes, ohp, lab, xo, hs, tile, hist, px, wreg, t0, att, head, words;

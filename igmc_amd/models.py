@@ -161,6 +161,17 @@ class IGMC(nn.Module):
         self._ws = {}
         return out
 
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        """``nn.Module.load_state_dict`` + the engine's invariant that its exchange regions hold finite values only: steps
+        that ran on diverged (non-finite) parameters may have left NaN rows in a subgraph slot, which every later gather of that
+        slot would multiply by its zero block entries -- cleared whenever parameters are restored (``igmc_model_reset_exchange``)."""
+        out = super().load_state_dict(state_dict, *args, **kwargs)
+        if self._flat.device.type == 'cuda':
+            st = torch.cuda.current_stream(self._flat.device).cuda_stream
+            for ws in self._ws.values():
+                ws.lib.call('igmc_model_reset_exchange', ws.handle, engine._p(st))
+        return out
+
     def flat_parameters(self):
         return self._flat
 

@@ -356,6 +356,10 @@ int igmc_model_check(igmc_model* m, void* stream);
 /* 1 when forward / loss_grad / train_step on (this arena, batch size B) run the matrix-core subgraph kernel, which
  * reads the dense blocks only (see igmc_batch_set_lean); 0 otherwise.  No reference counterpart. */
 int igmc_model_dense_path(const igmc_model* m, const igmc_batch* b, int B);
+/* Clears the row / plane exchange regions of the subgraph and dense-layer kernels (enqueued on `stream`).  They must only ever
+ * hold finite values (a consumer copies whole plane images, stale rows of earlier launches included, and multiplies them by
+ * zero block entries): call it after steps that ran on non-finite parameters, e.g. when parameters are restored. */
+int igmc_model_reset_exchange(igmc_model* m, void* stream);
 
 /* 1 when the arena's slots (129..256 nodes a side, dense block + transposed copy) send the conv layers of the per-layer
  * sequence to the matrix-core layer kernels (k_dl_layer) instead of the CSR row walkers. */
