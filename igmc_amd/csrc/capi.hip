@@ -350,7 +350,7 @@ extern "C" int igmc_batch_create(const igmc_graph* g, int max_graphs, int hop, i
   d.relm_ld = (int)((cap_v + 3) & ~(size_t)3);
   // dense path: rows of the block fit one 256-entry super-chunk and block + row starts fit the default LDS window
   // (a byte of the block holds relation + 1 in bits 0-3 and the two keep bits of edge dropout in bits 4-5: <= 15 relations)
-  if (g->max_rel + 1 <= (int)IGMC_RELM_CODE && cap_u <= 256 && cap_v <= 256 && cap_u * (size_t)d.relm_ld + slot * 4 <= 60 * 1024) fail |= M.get(&d.relm, (size_t)Bc * cap_u * d.relm_ld);   // dense induced block per link
+  if (g->max_rel + 1 <= (int)IGMC_RELM_CODE && cap_u <= 256 && cap_v <= 256 && cap_u * (size_t)d.relm_ld + slot * 4 <= 60 * 1024) fail |= M.get(&d.relm, (size_t)Bc * cap_u * d.relm_ld + (size_t)128 * d.relm_ld + 128);   // dense induced block per link (+ a tail pad: the subgraph kernel's lanes read up to 128 rows from a slot's start unguarded)
   // slots too large for the subgraph kernel (> 128 nodes a side) but with a dense block: the transposed copy feeds the
   // item-side workgroups of the dense per-layer kernels (denselayer.hip)
   // (IGMC_DL_ALWAYS=1: also for small slots -- lets tests run those kernels on small cases)

@@ -56,8 +56,6 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
   const int kp = lay.kp, nsides = lay.nsides;
   uint32_t* PLN = (uint32_t*)(S + lay.planes);          // [nsides][3 terms][32 features][kp] bf16: gather source
   uint32_t* OHP = (uint32_t*)(S + lay.ohp);             // [nsides][8 labels][kp] bf16 one-hot label planes (layer 0)
-  unsigned char* RM = (unsigned char*)(S + lay.tile);   // [2][rmr][rmc + 8] bytes: relm (rows = users) and its transpose
-                                                        // (rows = items); set-up only: aliases the backward's T' tiles
   unsigned char* slab = (unsigned char*)(S + lay.lab);  // [2][128] node labels of both sides
   float* XOA = S + lay.xo;                              // [2][4 bundles][16][G2_XP]: the bundle's own rows of x / dPre
   float* HSS = S + lay.hs;                              // [4][16][G2_XP] h_{l-1} rows of the bundle (backward)
@@ -89,7 +87,6 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
   // members of its clusters one after the other, so the residency argument above holds per XCD.
   const int cm = (cs > 1) ? (int)((blockIdx.x >> 3) % cs) : 0;
   const int half = 2 * cs;                              // waves of the cluster per side
-  const int rmr = lay.rmr, rmc = lay.rmc, rmp = lay.rmc + 8;      // image rows, columns, row pitch (bytes)
   const uint32_t seq = g2_ld_seq(a.gs_bar);
   const uint32_t tag0 = seq * 8u + 1u;
   const uint64_t step = a.ctrl ? (uint64_t)a.ctrl[IGMC_CTRL_STEP] : a.step;
@@ -107,20 +104,14 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
   const int g_pre = (g_first < a.graph_cap) ? g_first : a.graph_cap - 1;      // (a padding workgroup: any valid slot)
   const int pre_cu = a.n_users[g_pre], pre_cv = a.n_items[g_pre];
   // ... and so are the set-up's global loads, which depend on the subgraph slot only (labels from the per-graph scratch
-  // slots, relm rows up to the slot capacity): ONE round trip, under the kernel's scalar prologue
-  const int ld = a.relm_ld, ldw = ld >> 2;
+  // slots, the block bytes of the lane's fragments): ONE round trip, under the kernel's scalar prologue
+  const int ld = a.relm_ld;
   auto load_label = [&](int g2) {
     // (capacity of the lane's side by arithmetic on the two VALUES: a per-lane select between the two kernel-argument
     //  fields compiles to a vector load from the argument segment + a vmcnt(0) wait in front of every other load)
     const int hi = (tid >> 7) & 1, t7 = tid & 127;              // (threads 256.. repeat the first 256: their value is unused)
     const int capx = a.cap_u + hi * (a.cap_v - a.cap_u);
     return (int)a.s_lab[(size_t)g2 * a.slot + hi * a.cap_u + ((t7 < capx) ? t7 : 0)];
-  };
-  uint32_t rmv[8];           // dword (tid & 31) of rows (tid >> 5) + 16 q  (ld <= 128 bytes, <= 128 rows)
-  auto load_relm = [&](int g2) {
-    const uint32_t* rm = (const uint32_t*)(a.relm + (size_t)g2 * a.cap_u * ld) + (tid >> 5) * ldw + (tid & 31);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) rmv[q] = ((tid & 31) < ldw && (tid >> 5) + 16 * q < a.cap_u) ? rm[16 * q * ldw] : 0u;
   };
   int labv_raw = 0;
   // layer-0 table (4 KB): requested here, global -> LDS directly, landed by the set-up's barriers
@@ -145,18 +136,39 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
     const int gw = cm * G2_NB + bw;
     const int side = gw / half, bi = gw - side * half;    // this wave's side (0 users, 1 items) and bundle of that side
     labv_raw = load_label(g);
-    load_relm(g);
+    // The block bytes of THIS LANE's fragments -- the 8 opposite-side nodes 32 s + 8 kq .. + 7 of its row (users: 8 consecutive
+    // bytes of the row; items: the column, one byte of 8 consecutive rows) -- straight from the arena's row-major block into
+    // registers (round 6).  They went global -> registers -> an LDS image -> registers before: a 35 KB zero fill, the image's
+    // stores, a gather of it and two of the set-up's three barriers, all in front of layer 0.  Rows of the slot past the
+    // subgraph's users hold an earlier subgraph's bytes (the extraction clears cu rows): masked below, once the extents are in.
+    // No bounds checks: the arena's block allocation carries a tail pad of 128 rows (capi.hip), so a lane of an inactive row
+    // or k-step reads bytes that exist and are then masked -- by `active` / the row's validity, and by the count of valid
+    // opposite-side nodes among the lane's eight (the per-load selects of a guarded form cost the item side 5 k cycles).
+    uint32_t bw0[G2_KS], bw1[G2_KS];
+    {
+      const unsigned char* rmg = a.relm + (size_t)g * a.cap_u * ld;      // (uniform: scalar base, 32-bit lane offsets)
+      const uint32_t rrow = (uint32_t)(16 * bi + li);
+#pragma unroll
+      for (int s = 0; s < G2_KS; ++s) {
+        const uint32_t c0 = (uint32_t)(32 * s + 8 * kq);
+        if (side == 0) {
+          const uint32_t* p4 = (const uint32_t*)(rmg + (rrow * (uint32_t)ld + c0));      // (ld % 4 == 0)
+          bw0[s] = p4[0];
+          bw1[s] = p4[1];
+        } else {
+          const unsigned char* pc = rmg + (c0 * (uint32_t)ld + rrow);
+          bw0[s] = (uint32_t)pc[0] | ((uint32_t)pc[ld] << 8) | ((uint32_t)pc[2 * ld] << 16) | ((uint32_t)pc[3 * ld] << 24);
+          bw1[s] = (uint32_t)pc[4 * ld] | ((uint32_t)pc[5 * ld] << 8) | ((uint32_t)pc[6 * ld] << 16) | ((uint32_t)pc[7 * ld] << 24);
+        }
+      }
+    }
     // ---- the LDS zero fills (16-byte stores) run under the latency of the set-up's global loads: placed in front of
     //      everything that needs the subgraph's extents (a wait for THOSE in front of the fills is a round trip of idling)
     G2_STAMP(48);
     {
       const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
       // (the plane image is NOT cleared: its first reader is layer 1's gather, behind a fetch that copies the whole image
-      //  from the exchange region -- planes_load -- and dPre_3's set-up clears what it needs itself; of the block image
-      //  only the row-major one is read since the transposed one went: its rows up to the last k-step an item-side lane can
-      //  touch, 32 G2_KS, which may lie past the rmr rows of the image proper)
-      const int zrows = (2 * rmr < 32 * G2_KS) ? 2 * rmr : 32 * G2_KS;
-      for (int i = tid; i < ((zrows * rmp + 15) >> 4); i += G2_THREADS) ((float4*)RM)[i] = z4;
+      //  from the exchange region -- planes_load -- and dPre_3's set-up clears what it needs itself; there is no block image)
       for (int i = tid; i < 2 * G2_NB * 16 * G2_XP / 4; i += G2_THREADS) ((float4*)XOA)[i] = z4;
       for (int i = tid; i < G2_NB * 16 * G2_XP / 4; i += G2_THREADS) ((float4*)HIST)[i] = z4;
     }
@@ -191,18 +203,6 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
     __syncthreads();
     G2_STAMP(2);
     {
-      int tid_ = tid;
-      G2_OPAQUE(tid_);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {         // row-major image (rows = users): one dword per lane, conflict-free
-        const int u = (tid_ >> 5) + 16 * q, c4 = (tid_ & 31) * 4;
-        if ((tid_ & 31) < ldw && u < cu && c4 < rmc) *(uint32_t*)(RM + (size_t)u * rmp + c4) = rmv[q];
-      }
-    }
-    // (no transposed image: an item-side lane gathers the eight block bytes of a k-step -- its item's column, eight
-    //  consecutive users -- straight from the row-major image when it forms its masks; the transposition pass and its
-    //  barrier kept the item side ~2 k cycles behind the user side, which then waited for the items' h_0)
-    {
       // one-hot planes of the labels of the opposite side(s): plane[label][node] = 1.0 (bf16)
       for (int i = tid; i < nsides * 8 * (kp >> 1); i += G2_THREADS) {
         const int s2 = i / (8 * (kp >> 1)), rem = i - s2 * (8 * (kp >> 1));
@@ -226,22 +226,20 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
     uint32_t RB[FLAGS ? G2_KS : 1][2];
     const int kb = side ? IGMC_RELM_KF : IGMC_RELM_KT;      // keep bit of the edge  own -> opposite
     {
-      const unsigned char* rmo = RM + (size_t)(row0 + li) * rmp;       // user side: the lane's row of the image
-      const unsigned char* rmc_ = RM + (row0 + li);                    // item side: the lane's column of it
       const int kf = side ? IGMC_RELM_KT : IGMC_RELM_KF;    // keep bit of the edge  opposite -> own
 #pragma unroll
       for (int s = 0; s < G2_KS; ++s) {
         uint32_t w0 = 0u, w1 = 0u;
-        if (active && s < nks && 32 * s + 8 * kq < rmc) {
-          if (side == 0) {
-            const uint2 w = *(const uint2*)(rmo + 32 * s + 8 * kq);
-            w0 = w.x;
-            w1 = w.y;
-          } else {
-            // (rows past the users of the subgraph are zero: the image was cleared and only rows < cu were written)
-            const unsigned char* pc = rmc_ + (size_t)(32 * s + 8 * kq) * rmp;
-            w0 = (uint32_t)pc[0] | ((uint32_t)pc[rmp] << 8) | ((uint32_t)pc[2 * rmp] << 16) | ((uint32_t)pc[3 * rmp] << 24);
-            w1 = (uint32_t)pc[4 * rmp] | ((uint32_t)pc[5 * rmp] << 8) | ((uint32_t)pc[6 * rmp] << 16) | ((uint32_t)pc[7 * rmp] << 24);
+        if (active && s < nks && row0 + li < n_own) {
+          w0 = bw0[s];
+          w1 = bw1[s];
+          {   // the lane's 8 bytes are 8 opposite-side nodes: past that side's extent they are stale rows (items' lanes) or
+              // the next row's bytes (users' lanes, where the row pitch ends inside the k-step)
+            const int keep = n_opp - (32 * s + 8 * kq);
+            if (keep < 8) {
+              w1 = (keep <= 4) ? 0u : (w1 & (0xFFFFFFFFu >> (8 * (8 - keep))));
+              if (keep < 4) w0 = (keep <= 0) ? 0u : (w0 & (0xFFFFFFFFu >> (8 * (4 - keep))));
+            }
           }
         }
         if constexpr (FLAGS) {
@@ -269,8 +267,7 @@ __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
       if constexpr (FLAGS) return g2_mask_frag(g2_bytemask<true>(m0, (uint32_t)(r + 1), kb), g2_bytemask<true>(m1, (uint32_t)(r + 1), kb));
       else return g2_mask_frag(m0, m1);
     };
-    __syncthreads();                    // RM is dead from here on (its bytes are the backward's tiles)
-    G2_STAMP(4);
+    G2_STAMP(4);                        // (no barrier: the masks came from registers; the one-hot planes were landed above)
 
     // B operand of the next conv layer ([W_0; ..; W_4; root] or the transposes, composed once per step by
     // k_g2_compose): requested a phase ahead, written to LDS by stage()
