@@ -17,3 +17,9 @@ cp $S/smoke.log profiles/${R}_smoke.log
 cp $S/dl_phase_clocks_flixster.txt profiles/${R}_dl_phase_clocks_flixster.txt
 cp $S/dl_phase_clocks_ml100k.txt profiles/${R}_dl_phase_clocks_ml100k.txt
 cp $S/sp_bwd_phase_clocks.txt profiles/${R}_sp_bwd_phase_clocks.txt
+cp $S/sampler_stats.txt profiles/${R}_sampler_stats.txt
+cp $S/eval_bench.txt profiles/${R}_eval_bench.txt
+for f in $S/recipe_*.log $S/transfer_*.log; do cp $f profiles/${R}_$(basename $f); done
+cp $S/recipes_summary.txt profiles/${R}_recipes_summary.txt
+cp $S/dp_dry_runs.txt profiles/${R}_dp_dry_runs.txt
+cp $S/parity_observed.txt profiles/${R}_parity_observed.txt

@@ -18,7 +18,8 @@ cp gpurun_out/prof_ml1m/* gpurun_out/prof/ 2>/dev/null
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $OLDPWD/$O/kt100k -- python $OLDPWD/bench.py --config ml_100k --steps 100 --warmup 10 --no-cpu-baseline --profile-steps 0 --rmse-links 0 --dp-steps 0 --no-secondary > $OLDPWD/$O/kt100k.log 2>&1 )
 { echo "# commit ${IGMC_COMMIT:-unknown}; rocprofv3 --kernel-trace --stats -- python bench.py --config ml_100k --steps 100 --warmup 10 --no-cpu-baseline --profile-steps 0 --rmse-links 0 --dp-steps 0 --no-secondary"; python tools/rocprof_summary.py $O/kt100k; } > $O/kernel_stats_ml100k.txt 2>&1
 rm -rf $O/kt100k
-timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log; head -4 $O/pytest.log
+rm -f gpurun_out/parity_observed.jsonl
+timeout 1200 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; cp gpurun_out/parity_observed.jsonl $O/parity_observed.jsonl 2>/dev/null; python tools/parity_observed_summary.py $O/parity_observed.jsonl "the -m gpu suite of this session, commit ${IGMC_COMMIT:-unknown}" > $O/parity_observed.txt 2>&1; echo "pytest rc=$?" | tee -a $O/pytest.log; head -4 $O/pytest.log
 timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; tail -2 $O/smoke.log
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err                      # the driver's default form (200 / 20, all legs)
 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver.json 2> $O/bench_driver.err
@@ -36,6 +37,14 @@ timeout 200 python tools/dl_phase_clocks.py flixster 0 2>&1 | grep -v amdgpu.ids
 timeout 200 python tools/dl_phase_clocks.py ml_100k 0 2>&1 | grep -v amdgpu.ids > $O/dl_phase_clocks_ml100k.txt
 timeout 200 python tools/sp_phase_clocks.py 2>&1 | grep -v amdgpu.ids | tail -11 > $O/sp_bwd_phase_clocks.txt
 timeout 200 python tools/g2_phase_clocks.py --overlap > $O/phase_clocks_overlap.txt 2>&1
+# round 6: the sampler's distribution + free-running statistical parity, evaluation throughput, the recipes (three Monti sets,
+# BASELINE config 5), the data-parallel dry runs with self-spawned ranks on this one GPU
+timeout 600 python tools/sampler_report.py > $O/sampler_stats.txt 2> $O/sampler_stats.err
+{ python tools/eval_bench.py --links 20000; python tools/eval_bench.py --links 20000 --dynamic; python tools/eval_bench.py --links 5000; } 2>&1 | grep -v amdgpu.ids > $O/eval_bench.txt
+IGMC_COMMIT=${IGMC_COMMIT:-unknown} bash tools/gpu_recipes.sh $(basename $O) > $O/recipes_summary.txt 2>&1
+IGMC_COMMIT=${IGMC_COMMIT:-unknown} bash tools/gpu_recipes_config5.sh $(basename $O) >> $O/recipes_summary.txt 2>&1
+bash tools/gpu_dp_dry.sh $(basename $O)/dp > $O/dp_dry_runs.txt 2>&1
+cat $O/recipes_summary.txt; tail -3 $O/eval_bench.txt; tail -4 $O/sampler_stats.txt; cat $O/dp_dry_runs.txt | cut -c1-400
 python - "$O" <<'PY'
 import json,glob,sys
 for f in sorted(glob.glob(sys.argv[1]+'/bench_*.json')):
