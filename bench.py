@@ -306,6 +306,32 @@ def run_secondary(configs=('ml_100k', 'douban', 'flixster', 'ml_10m_lite', 'yaho
     return out
 
 
+def run_recipe(dataset='douban', epochs=40):
+    """A CONVERGED test RMSE in the driver's line: the reference's recipe on one bundled real dataset -- ``Main.py --data-name
+    douban --epochs 40 --testing --ensemble`` (reference README.md:43; the paper reports 0.721) -- in a fresh process and a
+    scratch directory, ~10 s.  The ``rmse`` leg above is a parity check of a ~100-step checkpoint, not model quality."""
+    import re
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        cmd = [sys.executable, os.path.join(ROOT, 'Main.py'), '--data-name', dataset, '--epochs', str(epochs), '--testing', '--ensemble']
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, cwd=td, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        except subprocess.TimeoutExpired:
+            return dict(error='timeout', command=' '.join(cmd[1:]))
+        out = r.stdout.decode(errors='replace')
+        wall = time.perf_counter() - t0
+    ens = re.search(r'Ensemble test rmse is: ([0-9.]+)', out)
+    fin = re.search(r'Final Test RMSE: ([0-9.]+), Duration: ([0-9.]+)', out)
+    if r.returncode != 0 or not ens or not fin:
+        return dict(error='rc %d' % r.returncode, tail=out[-300:], command=' '.join(cmd[1:]))
+    return dict(dataset=dataset + ' (bundled real data)', command='python ' + ' '.join(os.path.basename(c) if c.endswith('.py') else c for c in cmd[1:]),
+                epochs=epochs, ensemble_test_rmse=float(ens.group(1)), last_epoch_test_rmse=float(fin.group(1)),
+                train_seconds=float(fin.group(2)), wall_seconds=wall, paper_rmse=0.721,
+                note='reference recipe (README.md:43) end to end on this GPU: 40 epochs + the ensemble of checkpoints 10..40')
+
+
 def spawn_ranks(n, out):
     """``python bench.py --gpus N`` started WITHOUT a launcher: start the N ranks (one process per device, RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* as torch.distributed.run would set them, rendezvous on 127.0.0.1) and wait for them.  Rank 0's
@@ -751,8 +777,10 @@ def main():
     # ---- the other configurations, short runs of this very file (N = 1, default configuration only): BASELINE.json
     #      configs[1] (ml_100k cap 200) and the bundled real datasets, so that one driver-run line carries them
     secondary = None
+    recipe = None
     if world == 1 and args.config == 'ml_1m' and not args.no_secondary and not args.dgcnn_rs:
         secondary = run_secondary()
+        recipe = run_recipe()
 
     # ---- RMSE of the checkpoint the steps above produced (fixed slice of the test links)
     rmse = None
@@ -811,7 +839,7 @@ def main():
                        'graphs_captured_before_timing': bool(captured), 'steps_per_graph_launch': 2 * group_steps},
             'roofline': roofline, 'cpu_baseline': cpu, 'rmse': rmse, 'extraction': extraction,
             'dp_structure_us': dp_structure['dp_structure_us'] if dp_structure else None, 'dp_structure': dp_structure,
-            'dp_check': dp_check, 'secondary': secondary,
+            'dp_check': dp_check, 'secondary': secondary, 'recipe': recipe,
             'timing_check': {'wall_ms': dt * 1e3, 'gpu_event_ms': gpu_ms, 'host_enqueue_ms': t_enq * 1e3},
             'final_loss': final_loss, 'kernels_us': {k: round(v['us'], 2) for k, v in kernels.items()},
             'kernel_src_sha': kernel_source_sha(),
