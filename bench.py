@@ -573,12 +573,22 @@ def main():
                     others[kind] = why if c is None else 'ok'
                     if c is not None:
                         comms[kind] = c
-        allreduce_us = {k: time_allreduce(c, n_flat) for k, c in comms.items()}
+        allreduce_us = {}
+        for k, c in comms.items():          # (a diagnostic leg: a transport that fails here is reported, the line is not lost)
+            try:
+                allreduce_us[k] = time_allreduce(c, n_flat)
+            except Exception as e:          # noqa: BLE001
+                allreduce_us[k] = None
+                others[k] = 'timing failed: %s' % (str(e).splitlines()[0] if str(e) else repr(e))
         rccl = comms.get('rccl')
-        rccl_rank, rccl_world = rccl.info() if rccl is not None else (None, None)
+        try:
+            rccl_rank, rccl_world = rccl.info() if rccl is not None else (None, None)
+        except Exception as e:              # noqa: BLE001
+            rccl_rank, rccl_world = None, None
+            others['rccl'] = 'info failed: %s' % e
         dp_check = dict(transport=transport, rccl_rank=rccl_rank, rccl_world=rccl_world,
-                        rccl_unavailable=None if rccl is not None else others.get('rccl'),
-                        p2p_unavailable=None if 'p2p' in comms else others.get('p2p'),
+                        rccl_unavailable=None if (rccl is not None and others.get('rccl') in (None, 'ok')) else others.get('rccl'),
+                        p2p_unavailable=None if ('p2p' in comms and others.get('p2p') in (None, 'ok')) else others.get('p2p'),
                         comm_rank=rk, comm_world=ws_, launcher_rank=rank, launcher_world=world,
                         ranks_agree=bool(rk == rank and ws_ == world and (rccl is None or (rccl_rank, rccl_world) == (rank, world))),
                         replicas_identical=bool(torch.equal(lo, hi)), param_checksum=float(chk[0].item()),
