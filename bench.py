@@ -383,7 +383,8 @@ def main():
     ap.add_argument('--config', default='ml_1m', choices=sorted(CONFIGS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-steps', type=int, default=40)
-    ap.add_argument('--rmse-links', type=int, default=5000)
+    ap.add_argument('--rmse-links', type=int, default=20000,
+                    help='test links of the RMSE / evaluation-throughput leg (0 = skip); 400 batches: the pass is whole graph launches')
     ap.add_argument('--dp-steps', type=int, default=96,
                     help='steps per launch structure of the dp_structure leg (N=1 only; 0 = skip)')
     ap.add_argument('--dgcnn-rs', action='store_true', help='the sort-pool readout family (reference models.py:123-167) instead of IGMC')
