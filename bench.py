@@ -529,6 +529,7 @@ def main():
     sg.check()                                          # no device-side wait timed out, no stamp mismatch
     final_loss = float(sg.loss[0].item())
     group_steps = sg.M
+    launch_steps = sg.M if getattr(sg, 'single_launch', False) else 2 * sg.M      # (a run of at most 32 steps is ONE single-group launch)
 
     # ---- data parallelism, self-validation (world > 1): the ranks RCCL sees on the library's communicator, equality of the
     # replicas after the timed steps (every rank applied the same all-reduced gradients: parameter checksums must agree bit
@@ -595,7 +596,7 @@ def main():
                         replicas_identical=bool(torch.equal(lo, hi)), param_checksum=float(chk[0].item()),
                         allreduce_us=allreduce_us.get(transport.split(':')[0].replace('host-callback', 'host')),
                         allreduce_us_by_transport=allreduce_us, allreduce_floats=n_flat,
-                        allreduce_in_graph=bool(sg.graph is not None),
+                        allreduce_in_graph=any(g is not None for g in sg.graphs),
                         devices=[torch.cuda.get_device_name(local), 'device %d of %d visible' % (local, torch.cuda.device_count())])
         for k, c in comms.items():
             if c is not sg.comm:
@@ -632,7 +633,7 @@ def main():
         try:
             sg_dp = StepGraph(model, opt, ds, BATCH, 0.001)
             dp_us, dp_host = timed_us(sg_dp, D)
-            in_graph = sg_dp.graph is not None
+            in_graph = any(g is not None for g in sg_dp.graphs)
             sg_dp.check()
         finally:
             del os.environ['IGMC_FORCE_DP_PATH'], os.environ['IGMC_DP_ALLREDUCE_ALWAYS'], os.environ['IGMC_PEER_ALWAYS']
@@ -656,7 +657,7 @@ def main():
         if sg.use_graph:
             import ctypes as C
             lib.igmc_profile_enable(2)
-            sg.graph = None
+            sg.drop_graphs()
             new_epoch_if_needed()
             sg.prepare()
             Pr = max(1, -(-P // (2 * sg.M))) * 2 * sg.M
@@ -668,7 +669,7 @@ def main():
             if cnt.value > 0:
                 replay_us = float(mean.value)
             lib.igmc_profile_enable(0)
-            sg.graph = None
+            sg.drop_graphs()
         # (2) every kernel with HIP events on its launch stream: the same launch structure enqueued eagerly (the extraction
         #     of the next group still runs beside the model kernels), then a few single steps whose batches are inspected
         engine.profile_enable(lib, True)
@@ -847,7 +848,7 @@ def main():
                                    'ARR 0.001, Adam' % (cfg['dataset'], ' (DGCNN_RS)' if args.dgcnn_rs else '', cfg['mnph'], BATCH,
                                                         cfg['adj_dropout']),
                        'parallelism': 'dp%d' % world, 'global_batch': BATCH * world,
-                       'graphs_captured_before_timing': bool(captured), 'steps_per_graph_launch': 2 * group_steps},
+                       'graphs_captured_before_timing': bool(captured), 'steps_per_graph_launch': launch_steps, 'group_steps': group_steps},
             'roofline': roofline, 'cpu_baseline': cpu, 'rmse': rmse, 'extraction': extraction,
             'dp_structure_us': dp_structure['dp_structure_us'] if dp_structure else None, 'dp_structure': dp_structure,
             'dp_check': dp_check, 'secondary': secondary, 'recipe': recipe,

@@ -61,8 +61,12 @@ def _ctrl_words(step, epoch, adam_t, batch, group, lr, beta1, beta2, eps, wd):
 
 def _group_size(steps_hint, default):
     """Largest M <= MAX_GROUP with 2 M | ``steps_hint`` (a run of a known length is then whole graph launches of 2 M
-    steps); ``default`` when only tiny groups divide."""
+    steps); ``default`` when only tiny groups divide.  A run of at most MAX_GROUP steps is ONE group (a single-group
+    launch, ``GroupPipeline.steps``): two groups of ten cost 70.0 us/step where one launch of 2 x 20 costs 67.6 -- a group's
+    fixed costs (its boundary, the first launches of its extraction chain) weigh on every step of it."""
     n = int(steps_hint)
+    if 4 <= n <= MAX_GROUP:
+        return n
     for m in range(MAX_GROUP, 3, -1):
         if n % (2 * m) == 0:
             return m
@@ -96,6 +100,8 @@ class GroupPipeline(object):
         self.M = self.M_default
         self.use_graph = bool(use_graph)
         self.graph = None
+        self.graph1 = [None, None]      # single-group launches: the group of parity q alone (+ the next group's extraction)
+        self.single_launch = False      # prepare(): the run it was told about is ONE single-group launch
         self.pacing_fallback = None     # '1' once the extraction chain's pacing gates kept timing out (StepGraph.check)
         self.n_links = 0
         self.k = 0                      # steps done in the current epoch
@@ -136,8 +142,10 @@ class GroupPipeline(object):
         self.gq, self.gk = 0, 0
         self._fill_group()
 
-    def _enqueue_group(self, q):
-        """M steps on the arenas of parity ``q`` || extraction of the next group's M batches into the other set."""
+    def _enqueue_group(self, q, standalone=False):
+        """M steps on the arenas of parity ``q`` || extraction of the next group's M batches into the other set.
+        ``standalone``: the group is a launch of its own (not the second half of a pair): nothing is known about what ran in
+        front of its first step."""
         cur = [self._arena(q, i) for i in range(self.M)]
         for i in range(self.M):
             self._arena(1 - q, i)
@@ -164,8 +172,8 @@ class GroupPipeline(object):
             mark = None
             if paced and nxt < len(plan) and i == nxt * per and (i > 0 or mode == '2'):
                 mark = self._mark() if mode == '1' else ('gate', q, i)
-            if q == 1 or i > 0:
-                # inside a pair of groups nothing but the previous step touches the parameters: that step left the weight
+            if (q == 1 and not standalone) or i > 0:
+                # inside a launch nothing but the previous step touches the parameters: that step left the weight
                 # images of its updated parameters behind, this one starts with the subgraph kernel
                 self._hint_unchanged()
             # (the model kernels are enqueued BEFORE the extraction launch that becomes ready with them: capturing the group's
@@ -240,9 +248,27 @@ class GroupPipeline(object):
                 self._advance(2 * M)
                 self.gq, self.gk, self.avail = 0, 0, M
                 n -= 2 * M
+            elif n >= M and M >= 2 and (self.steps_done >= 1 or not self.use_graph) and self.gk == 0 and self.avail >= M and \
+                    self.n_links // self.B - self.k >= M:
+                # what is left is at least ONE group, extracted and waiting in its arenas: a single-group launch (the group of
+                # the current parity + the extraction of the group behind it) instead of M eager steps
+                q = self.gq
+                g = self._capture_single(q) if self.use_graph else None
+                if g is not None:
+                    g.replay()
+                else:
+                    self._enqueue_group(q, standalone=True)
+                self._last = self._arena(q, M - 1)
+                self._advance(M)
+                self.gq, self.gk, self.avail = q ^ 1, 0, M
+                n -= M
             else:
                 self._single()
                 n -= 1
+
+    def _capture_single(self, q):
+        """A replayable graph of ``_enqueue_group(q, standalone=True)`` or None (backends without graphs)."""
+        return None
 
 
 class StepGraph(GroupPipeline):
@@ -566,11 +592,26 @@ class StepGraph(GroupPipeline):
 
     @property
     def graphs(self):                   # (compatibility of older call sites: the captured graphs)
-        return [self.graph]
+        return [self.graph] + list(self.graph1)
+
+    def drop_graphs(self):
+        """Forget every captured graph (they are captured again on their next use)."""
+        self.graph, self.graph1 = None, [None, None]
 
     def _capture(self):
         if self.graph is not None or not self.use_graph:
             return self.graph
+        self.graph = self._capture_fn(self._enqueue_pair)
+        return self.graph
+
+    def _capture_single(self, q):
+        if self.graph1[q] is not None or not self.use_graph:
+            return self.graph1[q]
+        self.graph1[q] = self._capture_fn(lambda: self._enqueue_group(q, standalone=True))
+        return self.graph1[q]
+
+    def _capture_fn(self, enqueue):
+        """The launches of ``enqueue()`` as a hipGraph, or None (capture refused under data parallelism: eager from then on)."""
         for qq in (0, 1):                   # (arenas and arena sets are created on first use: never inside a capture)
             self._arena(qq, self.M - 1)
             self._batch_sets(qq)
@@ -582,20 +623,19 @@ class StepGraph(GroupPipeline):
             # capture must only police THIS thread; a refused capture is not fatal -- the same launches then run eagerly
             # (capturing executes nothing, so no step is lost)
             with torch.cuda.graph(g, **(dict(capture_error_mode='thread_local') if dist else {})):
-                self._enqueue_pair()
-            self.graph = g
+                enqueue()
         except RuntimeError as e:
             if self.comm is None and not dist:
                 raise
             sys.stderr.write('igmc_amd: hipGraph capture refused under data parallelism (%s); launching eagerly\n'
                              % str(e).splitlines()[0])
-            self.use_graph, self.graph = False, None
+            self.use_graph, self.graph, self.graph1, g = False, None, [None, None], None
             torch.cuda.synchronize()
         # every rank is through its capture (or has given it up) before any rank replays: the first replay of a fast rank
         # would otherwise poll the exchange words of a rank that is still capturing (the polls are bounded by wall-clock time)
         if self.comm is not None:
             parallel.barrier()
-        return self.graph
+        return g
 
     def prepare(self, steps_hint=None, group=None, prime=True):
         """Capture every hipGraph this object will replay NOW and align the groups with the current position.
@@ -614,23 +654,31 @@ class StepGraph(GroupPipeline):
         elif steps_hint:
             M = _group_size(steps_hint, self.M_default)
         if M != self.M:
-            self.M, self.graph = M, None
+            self.M = M
+            self.drop_graphs()
             self.avail = 0
         if self.gq != 0 or self.gk != 0 or self.avail < self.M:
             self._regroup()
-        fresh = self.graph is None
-        self._capture()
+        # a run shorter than a pair of groups is ONE single-group launch (steps()): that graph is the one to have ready
+        single = steps_hint is not None and self.M <= int(steps_hint) < 2 * self.M
+        self.single_launch = bool(single)
+        # (single-group launches alternate between the two parities' graphs: both are captured, and primed in that order)
+        have = (lambda: self.graph1[0] if self.graph1[1] is not None else None) if single else (lambda: self.graph)
+        cap = (lambda: (self._capture_single(0), self._capture_single(1))) if single else self._capture
+        order = (lambda: [self.graph1[0], self.graph1[1], self.graph1[0]]) if single else (lambda: [self.graph] * 3)
+        fresh = have() is None
+        cap()
         # (a launch reads link positions up to 3 M batches ahead of its first step: only where steps() would launch it too)
-        if fresh and self.graph is not None and prime and self.avail >= self.M and \
+        if fresh and have() is not None and prime and self.avail >= self.M and \
                 self.n_links // self.B - self.k >= 2 * self.M:
-            self._prime()
-            if self.graph is None and self.use_graph:       # (the primed graph's gates timed out: captured again, edge-paced)
-                self._capture()
-                if self.graph is not None:
-                    self._prime()
+            self._prime(order())
+            if have() is None and self.use_graph:           # (the primed graph's gates timed out: captured again, edge-paced)
+                cap()
+                if have() is not None:
+                    self._prime(order())
         return self.use_graph
 
-    def _prime(self):
+    def _prime(self, graphs=None):
         """First launch of the freshly instantiated graph with its effects undone.  The first launch of a hipGraph costs
         ~140 us more than the following ones (profiles/r02_callB_graph_first_replay.txt) -- a one-time cost like the code
         object load of a kernel's first launch.  The launch runs 2 M real steps; parameters, Adam moments, control block and
@@ -643,8 +691,9 @@ class StepGraph(GroupPipeline):
         # positions below (k + (2 L + 1) M) B, which must stay inside the padded permutation buffer.
         room = (self.n_links // self.B - self.k + self.pad // self.B) // self.M
         launches = min(max(1, int(os.environ.get('IGMC_PRIME_LAUNCHES', '3'))), (room - 1) // 2)
-        for _ in range(launches):
-            self.graph.replay()
+        graphs = graphs if graphs is not None else [self.graph] * 3
+        for g in graphs[:launches]:         # (single-group launches: parity 0, parity 1, parity 0 -- the order steps() replays them in)
+            g.replay()
             torch.cuda.synchronize()
         # The priming launches double as the PROBE of the extraction chain's pacing gates: where the graph's two
         # chains are not served concurrently (a profiler serialising dispatches, one hardware queue) every gate spins for its
@@ -658,7 +707,7 @@ class StepGraph(GroupPipeline):
                 sys.stderr.write('igmc_amd: %d pacing gates timed out while the step graph was primed (streams not served '
                                  'concurrently?); pacing by graph edges\n' % gave_up)
                 self.pacing_fallback = '1'
-                self.graph = None
+                self.drop_graphs()
         for t, k in zip((m.flat_parameters(), self.opt.exp_avg, self.opt.exp_avg_sq, self.ctrl, self.total, self.loss), keep):
             t.copy_(k)
         self._regroup()
@@ -697,7 +746,7 @@ class StepGraph(GroupPipeline):
             sys.stderr.write('igmc_amd: %d pacing gates of the extraction chain timed out (streams not served concurrently?); '
                              'pacing by graph edges from here on\n' % gave_up_all)
             self.pacing_fallback = '1'
-            self.graph = None
+            self.drop_graphs()
         if gave_up:
             self.ctrl[_lib.CTRL['GATE_TIMEOUTS']] = 0
         if err:

@@ -347,7 +347,8 @@ def test_step_graph_is_bit_reproducible_and_structure_independent(ml1m, monkeypa
     * groups of 8 per launch == groups of 4 == every step launched eagerly on one stream: the same kernels on the same
       batches, whatever launches them.
     Two epochs of 24 steps each (1200 links): the first epoch of a process holds an eager first step + a re-grouping, both
-    epochs hold whole groups replayed from the graph and an eagerly launched remainder."""
+    epochs hold whole groups replayed from the graph; what is left behind the pairs is an eagerly launched remainder (first
+    epoch) or one more group as a single-group launch (second epoch, round 6)."""
     import torch
     from igmc_amd.util_functions import MyDynamicDataset
     if data == 'ml_1m':
@@ -365,6 +366,9 @@ def test_step_graph_is_bit_reproducible_and_structure_independent(ml1m, monkeypa
     perm = torch.randperm(len(ds), generator=torch.Generator().manual_seed(5))
     sg, ref = _trajectory(ds, drop, perm, group=8)
     assert sg.ws.dense_path(sg.arenas[0], 50) and any(g is not None for g in sg.graphs) and ref[4] == 48
+    # (the second epoch's 24 steps = a pair of groups of 8 + ONE single-group launch of the third group; the first epoch's
+    #  23 steps behind its eager first one = a pair + 7 eager steps)
+    assert sg.graph is not None and sg.graph1[0] is not None and sg.graph1[1] is None
     for rep in range(2):
         _, again = _trajectory(ds, drop, perm, group=8)
         _assert_same(ref, again, 'groups of 8, repeat %d' % rep)
