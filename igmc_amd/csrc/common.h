@@ -115,6 +115,24 @@ __device__ __forceinline__ uint64_t igmc_ctrl_drop_key(const int64_t* ctrl, int 
 // ------------------------------------------------------------------ small device helpers
 __device__ __forceinline__ int igmc_lane() { return threadIdx.x & 63; }
 
+// The tail kernels take the views of the batch and of the model BY VALUE: ~1.3 KB of kernel arguments, 20 cache lines that no
+// one has touched before the launch.  The compiler loads a field right in front of its first use and waits for it -- one scalar
+// round trip to memory per line, ONE AFTER THE OTHER down the prologue (k_finalize_ts: 2.5 k cycles before its first vector
+// load left).  This requests one dword of every line of the first BYTES bytes back to back and waits once; the compiler's own
+// loads then hit the scalar cache.  (k_graph_step2's 416 bytes gained nothing from it: profiles/r06_experiments.)
+template <int BYTES>
+__device__ __forceinline__ void igmc_kernarg_warm() {
+#ifndef IGMC_HIPEMU
+  typedef const __attribute__((address_space(4))) uint32_t* kp_t;
+  kp_t p = (kp_t)__builtin_amdgcn_kernarg_segment_ptr();
+  uint32_t v[(BYTES + 63) / 64];
+#pragma unroll
+  for (int i = 0; i < (BYTES + 63) / 64; ++i) v[i] = p[16 * i];
+#pragma unroll
+  for (int i = 0; i < (BYTES + 63) / 64; ++i) asm volatile("" ::"s"(v[i]));
+#endif
+}
+
 // exclusive scan over the 256 threads of a block; *total = sum.  sm: >= 8 ints of LDS.
 __device__ __forceinline__ int igmc_block_scan_excl(int v, int* total, int* sm) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

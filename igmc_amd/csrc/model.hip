@@ -1541,6 +1541,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_tail_ts(BatchDev b, ModelDev m, 
                                                           float grad_scale, float mult, float drop_scale,
                                                           float* __restrict__ grad, int nlin, int nparts, int stride,
                                                           int B, int nstash, const int64_t* ctrl, int bump_seq) {
+  igmc_kernarg_warm<sizeof(BatchDev) + sizeof(ModelDev) + 64>();
   const int nred = (int)gridDim.x - nlin - nstash;
   if (bump_seq && blockIdx.x == 0 && threadIdx.x == 0) m.gs_bar[1] += 1;      // (every workgroup of k_graph_step2 is done)
   if ((int)blockIdx.x < nlin)
@@ -1904,6 +1905,7 @@ __device__ __forceinline__ float fts_emit(float* __restrict__ grad, const AdamTa
 // subgraph kernel: one launch and one round trip to the weights less per step.
 __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const float* P, float* __restrict__ grad,
                                                               float arr_coef, AdamTail at, int nlin, int bs, int img) {
+  igmc_kernarg_warm<sizeof(ModelDev) + sizeof(AdamTail) + 48>();
   // bs != 0: the per-layer path's sources -- conv layers 1..3 in BASIS space (graw: d basis_b, d root, d bias straight
   // from the weight-gradient kernel, d att from the layer kernels' partials), layer 0 as its relation-space table in graw;
   // the stash comes from k_reduce_partials.  bs == 0: the relation-space tables of the subgraph kernels (ts_raw).
@@ -2062,30 +2064,8 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
       if (i < IGMC_STASH_LAYER) s_st[i] = stq[u];
     }
     __syncthreads();
-    if (has) {       // one round for fin <= 32
-      if (table) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-          if (r < R) {
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb) g[bb] += st[IGMC_STASH_ATT + r * 4 + bb] * tv[r];
-          }
-        for (int r = 8; r < R; ++r) {
-          const float tvr = t0[(size_t)r * nE + e];
-#pragma unroll
-          for (int bb = 0; bb < 4; ++bb) g[bb] += st[IGMC_STASH_ATT + r * 4 + bb] * tvr;
-        }
-      }
-      if (arr_coef != 0.f) {
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb)
-          g[bb] += arr_coef * (st[IGMC_STASH_M + bb * 4 + 0] * pv[0] + st[IGMC_STASH_M + bb * 4 + 1] * pv[1] +
-                               st[IGMC_STASH_M + bb * 4 + 2] * pv[2] + st[IGMC_STASH_M + bb * 4 + 3] * pv[3]);
-      }
-#pragma unroll
-      for (int q = 0; q < 5; ++q) pn[q] = fts_emit(grad, at, idx[q], g[q], pv[q], m1v[q], m2v[q]);
-      e_img = e;
-    }
+    // (the bias / att roles FIRST: the weight images wait for the layer's new att, formed by wave 1 -- behind its share of the
+    //  main pass it kept every other wave of the workgroup waiting at the barrier below for 2.6 k cycles)
     if (roles) {
       if (bias_role) {                             // d bias
         const int64_t i = m.off_bias[l] + tid;
@@ -2130,6 +2110,30 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
         if (emit) s_attn[rb] = anew;
        }
       }
+    }
+    if (has) {       // one round for fin <= 32
+      if (table) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+          if (r < R) {
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) g[bb] += st[IGMC_STASH_ATT + r * 4 + bb] * tv[r];
+          }
+        for (int r = 8; r < R; ++r) {
+          const float tvr = t0[(size_t)r * nE + e];
+#pragma unroll
+          for (int bb = 0; bb < 4; ++bb) g[bb] += st[IGMC_STASH_ATT + r * 4 + bb] * tvr;
+        }
+      }
+      if (arr_coef != 0.f) {
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb)
+          g[bb] += arr_coef * (st[IGMC_STASH_M + bb * 4 + 0] * pv[0] + st[IGMC_STASH_M + bb * 4 + 1] * pv[1] +
+                               st[IGMC_STASH_M + bb * 4 + 2] * pv[2] + st[IGMC_STASH_M + bb * 4 + 3] * pv[3]);
+      }
+#pragma unroll
+      for (int q = 0; q < 5; ++q) pn[q] = fts_emit(grad, at, idx[q], g[q], pv[q], m1v[q], m2v[q]);
+      e_img = e;
     }
     if (emit) {
       __syncthreads();
