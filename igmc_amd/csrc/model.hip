@@ -2147,7 +2147,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
           t0w[(R * fin + c) * 32 + f] = pn[4];
         } else {            // forward image: element (k = c, n = f); transposed image: element (k = f, n = c)
           // relation r -> block r % G2_NR of group r / G2_NR; root -> block G2_NR of group 0
-#pragma unroll 1
+#pragma unroll 3
           for (int r = 0; r <= R; ++r) {           // (blocks of relations the model does not have stay zero: first compose)
             const float v = (r == R) ? pn[4]
                           : g2_wsum(s_attn[r * 4], s_attn[r * 4 + 1], s_attn[r * 4 + 2], s_attn[r * 4 + 3], pn[0], pn[1], pn[2], pn[3]);
