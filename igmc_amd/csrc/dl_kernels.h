@@ -107,6 +107,7 @@ __host__ __device__ static inline int dl_words_mid(int kp, bool ts) {
 }
 template <bool FLAGS, bool BWD, bool TS>
 __global__ __launch_bounds__(DL_THREADS) void k_dl_layer(DlArgs a) {
+  igmc_kernarg_warm<sizeof(DlArgs) + 32>();
   static_assert(!TS || BWD, "tables are a product of the backward pass");
   IGMC_DYN_SMEM(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -557,6 +558,7 @@ __host__ __device__ static inline int dlf_words_gs(int kp) {
 
 template <bool FLAGS, bool STORE, int NG, bool GS = false>
 __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
+  igmc_kernarg_warm<sizeof(DlfArgs) + 32>();
   static_assert(!GS || NG == 2, "the group split is for two relation groups");
   constexpr int HP = (NG == 1) ? G2_XP : DLF_HP2;
   constexpr int NB = GS ? DL_GB : DL_NW;           // bundle slots of the workgroup
@@ -1007,6 +1009,7 @@ __host__ __device__ static inline int dlb_words_gs(int kp) {
 
 template <bool FLAGS, int NG, bool DENSE3, bool GS = false>
 __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
+  igmc_kernarg_warm<sizeof(DlbArgs) + 32>();
   static_assert(!GS || (NG == 2 && !DENSE3), "the group split is for two relation groups with the centre-node readout");
   constexpr int HP = (NG == 1) ? G2_XP : DLF_HP2;           // pitch of a row's layer-0 input
   constexpr int C0N = (NG == 1) ? 5 : 11;                   // histogram entries a lane holds: 16 R L / 64
@@ -1664,6 +1667,7 @@ __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
 __global__ __launch_bounds__(512) void k_head_sub(BatchDev b, ModelDev m, const float* __restrict__ P,
                                                     const uint8_t* __restrict__ inj_mask, uint64_t seed, uint64_t step_arg,
                                                     float mult, float grad_scale, float* __restrict__ out) {
+  igmc_kernarg_warm<sizeof(BatchDev) + sizeof(ModelDev) + 32>();
   IGMC_DYN_SMEM(smem);
   const int g = blockIdx.x;
   if (g >= b.totals[3]) return;
@@ -1699,6 +1703,7 @@ struct Dl0Args {
 
 template <bool FLAGS, bool STORE>
 __global__ __launch_bounds__(DL_THREADS) void k_dl_layer0(Dl0Args a) {
+  igmc_kernarg_warm<sizeof(Dl0Args) + 32>();
   IGMC_DYN_SMEM(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;

@@ -319,11 +319,12 @@ __device__ __forceinline__ void extract_nodes_body(const ExtractArgs& a) {
   }
 }
 
-__global__ __launch_bounds__(IGMC_BLOCK) void k_extract_nodes(ExtractArgs a) { extract_nodes_body(a); }
+__global__ __launch_bounds__(IGMC_BLOCK) void k_extract_nodes(ExtractArgs a) { igmc_kernarg_warm<sizeof(ExtractArgs) + 32>(); extract_nodes_body(a); }
 // ... for a whole GROUP of batches in one launch (igmc_extract_group): blockIdx.z = batch i of the group, its arena =
 // set[i], its selector = a.first + 2 i (selector q | (i << 1), igmc_hip.h).  Extraction is a dependent chain per workgroup,
 // so its throughput is the number of workgroups in flight: M batches in one launch take about as long as two or three.
 __global__ __launch_bounds__(IGMC_BLOCK) void k_extract_nodes_set(ExtractArgs a, const BatchDev* __restrict__ set) {
+  igmc_kernarg_warm<sizeof(ExtractArgs) + 32>();
   a.b = set[blockIdx.z];
   a.first += 2 * (int)blockIdx.z;
   extract_nodes_body(a);
@@ -346,6 +347,7 @@ __device__ void rebuild_sel(const int32_t* sg, int cap_u, int cu, int cv, uint32
 // Arow[u_nodes][:, v_nodes] with the target entry removed (reference :236-238).  Row r of graph g
 // (users first, then items) is owned by exactly one wave: r = (blockIdx.y*4 + wave) mod (4*S).
 __global__ __launch_bounds__(IGMC_BLOCK) void k_count(GraphDev G, BatchDev b) {
+  igmc_kernarg_warm<sizeof(GraphDev) + sizeof(BatchDev) + 32>();
   IGMC_DYN_SMEM(smem);
   const int g = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -394,6 +396,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_count(GraphDev G, BatchDev b) {
 // ---------------------------------------------------------------- kernel 4: CSR fill
 // Entry layout: ecr = source node (24 bits) | relation << 24 ;  ecode = relation*L + label(source).
 __global__ __launch_bounds__(IGMC_BLOCK) void k_fill(GraphDev G, BatchDev b) {
+  igmc_kernarg_warm<sizeof(GraphDev) + sizeof(BatchDev) + 32>();
   IGMC_DYN_SMEM(smem);
   __shared__ int sm[16];
   const int g = blockIdx.x, B = gridDim.x;
@@ -615,12 +618,13 @@ __device__ __forceinline__ void relm_body(const GraphDev& G, const BatchDev& b) 
   c = igmc_wave_sum_i(c);
   if (lane == 0 && c) atomicAdd(&b.edge_cnt[g], 2 * c);   // directed edges; integer => order-independent
 }
-__global__ __launch_bounds__(IGMC_BLOCK) void k_relm(GraphDev G, BatchDev b) { relm_body(G, b); }
-__global__ __launch_bounds__(IGMC_BLOCK) void k_relm_set(GraphDev G, const BatchDev* __restrict__ set) { relm_body(G, set[blockIdx.z]); }
+__global__ __launch_bounds__(IGMC_BLOCK) void k_relm(GraphDev G, BatchDev b) { igmc_kernarg_warm<sizeof(GraphDev) + sizeof(BatchDev) + 32>(); relm_body(G, b); }
+__global__ __launch_bounds__(IGMC_BLOCK) void k_relm_set(GraphDev G, const BatchDev* __restrict__ set) { igmc_kernarg_warm<sizeof(GraphDev) + 32>(); relm_body(G, set[blockIdx.z]); }
 
 
 // kernel 3d: batch offsets, degrees, row pointers and the relation-sorted CSR, all from relm
 __global__ __launch_bounds__(IGMC_BLOCK) void k_emit(BatchDev b) {
+  igmc_kernarg_warm<sizeof(BatchDev) + 32>();
   IGMC_DYN_SMEM(smem);
   __shared__ int sm[16];
   const int g = blockIdx.x, B = gridDim.x;
@@ -782,7 +786,7 @@ __device__ __forceinline__ void emit_nodes_body(const BatchDev& b) {
     b.node_graph[nb + n] = g;
   }
 }
-__global__ __launch_bounds__(IGMC_BLOCK) void k_emit_nodes(BatchDev b) { emit_nodes_body(b); }
+__global__ __launch_bounds__(IGMC_BLOCK) void k_emit_nodes(BatchDev b) { igmc_kernarg_warm<sizeof(BatchDev) + 32>(); emit_nodes_body(b); }
 __global__ __launch_bounds__(IGMC_BLOCK) void k_emit_nodes_set(const BatchDev* __restrict__ set) { emit_nodes_body(set[blockIdx.z]); }
 
 
@@ -795,6 +799,7 @@ void igmc_launch_emit_nodes(const BatchDev& b, int B, void* stream) {
 // (shared by the two directions when force_undirected).  16 lanes per CSR row.
 __global__ __launch_bounds__(IGMC_BLOCK) void k_edge_flags(BatchDev b, float p, int force_undirected,
                                                             uint64_t seed, uint64_t step_arg, const int64_t* ctrl) {
+  igmc_kernarg_warm<sizeof(BatchDev) + 32>();
   // control block: key by (epoch, batch index) of the selected batch -- race-free under prefetching
   const uint64_t step = ctrl ? igmc_ctrl_drop_key(ctrl, igmc_ctrl_first(ctrl, (int)step_arg)) : step_arg;
   if (blockIdx.x == 0 && threadIdx.x == 0) b.stamp[1] = ctrl ? (int64_t)step : -1;
@@ -825,6 +830,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_edge_flags(BatchDev b, float p, 
 
 // keep bits of the dense block from the per-entry flags (after flags were injected / cleared through the C ABI)
 __global__ __launch_bounds__(IGMC_BLOCK) void k_relm_flags(BatchDev b) {
+  igmc_kernarg_warm<sizeof(BatchDev) + 32>();
   const int N = b.totals[0];
   const int grp = (blockIdx.x * IGMC_BLOCK + threadIdx.x) >> 4, t = threadIdx.x & 15;
   const int ngrp = (gridDim.x * IGMC_BLOCK) >> 4;
@@ -873,6 +879,7 @@ __device__ __forceinline__ void relm_dropout_body(const BatchDev& b, float p, in
 }
 __global__ __launch_bounds__(IGMC_BLOCK) void k_relm_dropout(BatchDev b, float p, int force_undirected, uint64_t seed,
                                                               uint64_t step_arg, const int64_t* ctrl) {
+  igmc_kernarg_warm<sizeof(BatchDev) + 32>();
   relm_dropout_body(b, p, force_undirected, seed, step_arg, ctrl);
 }
 __global__ __launch_bounds__(IGMC_BLOCK) void k_relm_dropout_set(const BatchDev* __restrict__ set, float p, int force_undirected,
@@ -899,6 +906,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_load_nodes(BatchDev b, const int
                                                             const uint8_t* udist, const int64_t* voff, const int32_t* vnodes,
                                                             const uint8_t* vdist, const float* link_y, const int32_t* link_idx,
                                                             int first_arg, const int64_t* ctrl) {
+  igmc_kernarg_warm<sizeof(BatchDev) + 32>();
   const int g = blockIdx.x, tid = threadIdx.x;
   const int first = ctrl ? igmc_ctrl_first(ctrl, first_arg) : first_arg;
   const int pos = link_idx ? link_idx[first + g] : first + g;

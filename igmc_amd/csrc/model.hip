@@ -61,6 +61,7 @@ __device__ __forceinline__ XcdSeg igmc_xcd_segment(const BatchDev& b) {
 template <bool FLAGS, bool STORE>
 __global__ __launch_bounds__(IGMC_BLOCK) void k_l0_fwd(BatchDev b, ModelDev m, const float* __restrict__ P,
                                                          float* __restrict__ out) {
+  igmc_kernarg_warm<sizeof(BatchDev) + sizeof(ModelDev) + 32>();
   IGMC_DYN_SMEM(smem);
   const int RL = m.R * m.L, LF = m.L * 32;
   float* sW0 = (float*)smem;                 // [R*L][32]
@@ -320,6 +321,7 @@ __device__ __forceinline__ void dense_body(const BatchDev& b, const float* __res
 
 // Y_l = h_{l-1} @ [basis_0|..|basis_3] for l = 1..3 in ONE launch (blockIdx.y = l-1)
 __global__ __launch_bounds__(IGMC_BLOCK) void k_dense_y_all(BatchDev b, ModelDev m, const float* __restrict__ P) {
+  igmc_kernarg_warm<sizeof(BatchDev) + sizeof(ModelDev) + 32>();
   IGMC_DYN_SMEM(smem);
   const int li = blockIdx.y;
   dense_body<0, 32, 128, EPI_NONE, W_YCAT>(b, nullptr, m.h[li], P + m.off_basis[li + 1], nullptr, nullptr, m.Y[li],
@@ -338,6 +340,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_dense_y_all(BatchDev b, ModelDev
 template <bool FLAGS, bool BWD>
 __global__ __launch_bounds__(IGMC_BLOCK) void k_rgcn_layer4(BatchDev b, ModelDev m, const float* __restrict__ P, int l,
                                                              float* __restrict__ zero_out) {
+  igmc_kernarg_warm<sizeof(BatchDev) + sizeof(ModelDev) + 32>();
   IGMC_DYN_SMEM(smem);
   const int R = m.R;
   float* tile = (float*)smem;               // [16][IGMC_TP]
@@ -595,6 +598,7 @@ __device__ __forceinline__ void wgrad_body(const BatchDev& b, const ModelDev& m,
 }
 
 __global__ __launch_bounds__(IGMC_BLOCK) void k_wgrad(BatchDev b, ModelDev m, int ly_base) {
+  igmc_kernarg_warm<sizeof(BatchDev) + sizeof(ModelDev) + 32>();
   wgrad_body(b, m, ly_base + blockIdx.y);
 }
 
@@ -605,6 +609,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_wgrad(BatchDev b, ModelDev m, in
 template <int KMAX>
 __global__ __launch_bounds__(IGMC_BLOCK) void k_l0_bwd(BatchDev b, ModelDev m, const float* __restrict__ dpre,
                                                          float* __restrict__ part) {
+  igmc_kernarg_warm<sizeof(BatchDev) + sizeof(ModelDev) + 32>();
   const int N = b.totals[0];
   const int RL = m.R * m.L, rows = RL + m.L + 1;
   const int f = threadIdx.x & 31, cg = threadIdx.x >> 5;
@@ -659,6 +664,7 @@ template <bool FEAT_LDS>
 __global__ __launch_bounds__(512) void k_head_fwd(BatchDev b, ModelDev m, const float* __restrict__ P, int training,
                                                     const uint8_t* __restrict__ inj_mask, uint64_t seed,
                                                     uint64_t step_arg, float mult, float* __restrict__ out) {
+  igmc_kernarg_warm<sizeof(BatchDev) + sizeof(ModelDev) + 32>();
   IGMC_DYN_SMEM(smem);
   const uint64_t step = m.ctrl ? (uint64_t)m.ctrl[IGMC_CTRL_STEP] : step_arg;
   __shared__ float sa[IGMC_HG][128];
@@ -727,6 +733,7 @@ __global__ __launch_bounds__(1024) void k_head_bwd_a(BatchDev b, ModelDev m, con
                                                        const float* __restrict__ gout, int from_err,
                                                        float grad_scale, float mult, float drop_scale,
                                                        float* __restrict__ dpre_top) {
+  igmc_kernarg_warm<sizeof(BatchDev) + sizeof(ModelDev) + 32>();
   __shared__ float sdz[IGMC_HG][128];
   __shared__ float sred[3][IGMC_HG][256];
   const int B = b.totals[3];
@@ -790,6 +797,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_head_bwd_w(BatchDev b, ModelDev 
                                                              const float* __restrict__ gout, int from_err,
                                                              float grad_scale, float mult, float drop_scale,
                                                              float* __restrict__ grad) {
+  igmc_kernarg_warm<sizeof(BatchDev) + sizeof(ModelDev) + 32>();
   __shared__ float sfe[IGMC_HW_G][256];
   __shared__ float sdz[IGMC_HW_G][8];
   const int B = b.totals[3];
@@ -854,6 +862,7 @@ __global__ __launch_bounds__(512) void k_head_fwd_mfma(BatchDev b, ModelDev m, c
                                                          int training, const uint8_t* __restrict__ inj_mask,
                                                          uint64_t seed, uint64_t step_arg, float mult,
                                                          float* __restrict__ out) {
+  igmc_kernarg_warm<sizeof(BatchDev) + sizeof(ModelDev) + 32>();
   __shared__ float spart[8][16];
   const uint64_t step = m.ctrl ? (uint64_t)m.ctrl[IGMC_CTRL_STEP] : step_arg;
   const int B = b.totals[3], D = m.D;
@@ -919,6 +928,7 @@ __global__ __launch_bounds__(512) void k_head_train(BatchDev b, ModelDev m, cons
                                                       const uint8_t* __restrict__ inj_mask, uint64_t seed,
                                                       uint64_t step_arg, float mult, float grad_scale,
                                                       float* __restrict__ out) {
+  igmc_kernarg_warm<sizeof(BatchDev) + sizeof(ModelDev) + 32>();
   IGMC_DYN_SMEM(smem);
   if (blockIdx.y > 0) {
     const int ly = blockIdx.y - 1;
@@ -1100,6 +1110,7 @@ __global__ __launch_bounds__(512) void k_head_bwd_a_mfma(BatchDev b, ModelDev m,
                                                            const float* __restrict__ gout, int from_err,
                                                            float grad_scale, float mult, float drop_scale,
                                                            float* __restrict__ dpre_top) {
+  igmc_kernarg_warm<sizeof(BatchDev) + sizeof(ModelDev) + 32>();
   const int B = b.totals[3], D = m.D;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, kq = lane >> 4;
@@ -1229,6 +1240,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_head_bwd_w_mfma(BatchDev b, Mode
                                                                   const float* __restrict__ gout, int from_err,
                                                                   float grad_scale, float mult, float drop_scale,
                                                                   float* __restrict__ grad) {
+  igmc_kernarg_warm<sizeof(BatchDev) + sizeof(ModelDev) + 32>();
   head_bwd_w_body(b, m, P, gout, from_err, grad_scale, mult, drop_scale, grad, blockIdx.x, blockIdx.y);
 }
 
@@ -1238,6 +1250,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_wgrad_head(BatchDev b, ModelDev 
                                                              const float* __restrict__ gout, int from_err,
                                                              float grad_scale, float mult, float drop_scale,
                                                              float* __restrict__ grad, int nsl) {
+  igmc_kernarg_warm<sizeof(BatchDev) + sizeof(ModelDev) + 32>();
   if ((int)blockIdx.y < nsl) {
     wgrad_body(b, m, blockIdx.y);
   } else {
@@ -1258,6 +1271,7 @@ __device__ __forceinline__ void fin_stash_body(const ModelDev& m, const float* _
 __global__ __launch_bounds__(IGMC_BLOCK) void k_reduce_partials(ModelDev m, int n_gatt_parts, int l0_mfma,
                                                                   int n_wg_parts, const float* __restrict__ P,
                                                                   const int64_t* ctrl, int nstash) {
+  igmc_kernarg_warm<sizeof(ModelDev) + 32>();
   __shared__ float sred[4][64];
   if (nstash && (int)blockIdx.x >= (int)gridDim.x - nstash) {
     fin_stash_body(m, P, (int)blockIdx.x - ((int)gridDim.x - nstash), ctrl);
@@ -1694,6 +1708,7 @@ struct AdamTail {
 #define IGMC_FIN_NB 8
 __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize(ModelDev m, const float* P, float* __restrict__ grad,
                                                            float arr_coef, AdamTail at, int ts_mode) {
+  igmc_kernarg_warm<sizeof(ModelDev) + sizeof(AdamTail) + 32>();
   if (at.skip && *at.skip) return;      // (uniform over the launch: written by the kernel in front of it)
   __shared__ float smf[8];
   __shared__ float sG[16], sM[16];
@@ -2179,11 +2194,13 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const fl
 }
 
 __global__ __launch_bounds__(IGMC_BLOCK) void k_loss(BatchDev b, ModelDev m, float ARR, float* __restrict__ loss) {
+  igmc_kernarg_warm<sizeof(BatchDev) + sizeof(ModelDev) + 32>();
   __shared__ float smf[8];
   loss_body(b, m, ARR, loss, nullptr, smf);
 }
 
 __global__ __launch_bounds__(IGMC_BLOCK) void k_sse_acc(BatchDev b, const float* __restrict__ out, double* acc, int64_t* ctrl) {
+  igmc_kernarg_warm<sizeof(BatchDev) + 32>();
   __shared__ float smf[8];
   const int B = b.totals[3];
   float s = 0.f;

@@ -33,6 +33,7 @@
 // engine layout (model.h: every layer 32 wide) <- true layout (layer 3 has ONE output column)
 __global__ __launch_bounds__(SP_THREADS) void k_sp_pack(ModelDev m, SpDev sp, const float* __restrict__ Pd,
                                                          float* __restrict__ pe) {
+  igmc_kernarg_warm<sizeof(ModelDev) + sizeof(SpDev) + 32>();
   const int64_t n = m.off_l1w;                       // conv parameters of the engine layout
   const int64_t o3 = m.off_basis[3];                 // layers 0..2 sit at identical offsets in both layouts
   for (int64_t i = (int64_t)blockIdx.x * SP_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * SP_THREADS) {
@@ -68,6 +69,7 @@ __device__ __forceinline__ void sp_unpack_body(const ModelDev& m, const SpDev& s
 }
 __global__ __launch_bounds__(SP_THREADS) void k_sp_unpack(ModelDev m, SpDev sp, const float* __restrict__ ge,
                                                            float* __restrict__ Gd) {
+  igmc_kernarg_warm<sizeof(ModelDev) + sizeof(SpDev) + 32>();
   sp_unpack_body(m, sp, ge, Gd, blockIdx.x, gridDim.x);
 }
 
@@ -116,6 +118,7 @@ template <bool TRAIN>
 __global__ __launch_bounds__(SP_WG) void k_sp_fwd(BatchDev b, ModelDev m, SpDev sp, const float* __restrict__ Pd,
                                                         const uint8_t* __restrict__ inj_mask, uint64_t seed,
                                                         uint64_t step_arg, float* __restrict__ out) {
+  igmc_kernarg_warm<sizeof(BatchDev) + sizeof(ModelDev) + sizeof(SpDev) + 32>();
   IGMC_DYN_SMEM(smem);
   const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int k = sp.k, Q1 = sp.Q1, Q2 = sp.Q2, dense = sp.dense, P = sp.P;
@@ -222,6 +225,7 @@ template <bool TRAIN>
 __global__ __launch_bounds__(SP_THREADS) void k_sp_lin_fwd(BatchDev b, ModelDev m, SpDev sp, const float* __restrict__ Pd,
                                                              const uint8_t* __restrict__ inj_mask, uint64_t seed,
                                                              uint64_t step_arg, float* __restrict__ out) {
+  igmc_kernarg_warm<sizeof(BatchDev) + sizeof(ModelDev) + sizeof(SpDev) + 32>();
   __shared__ float sacc[4][64][4];
   __shared__ int s_last;
   const int B = b.totals[3], dense = sp.dense;
@@ -303,6 +307,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_sp_lin_fwd(BatchDev b, ModelDev 
 // forward's a1 / mask / residual (the first column tile also stores it, and d out, for the weight-gradient kernel)
 __global__ __launch_bounds__(SP_THREADS) void k_sp_dflat(BatchDev b, ModelDev m, SpDev sp, const float* __restrict__ Pd,
                                                           float grad_scale) {
+  igmc_kernarg_warm<sizeof(BatchDev) + sizeof(ModelDev) + sizeof(SpDev) + 32>();
   const int B = b.totals[3], dense = sp.dense;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, kq = lane >> 4;
@@ -371,6 +376,7 @@ extern "C" int igmc_debug_sp_clocks(unsigned long long* out, int n) {
 // dynamic LDS: sel[k] | rank[nmax] | w1[16*97] | w2[32*80] | y1[16*k] | z[16*Q1] | dy2[32*Q2] | dzp[16*Q1] | dy1[16*k] | dz[128] | xs[k*98]
 __global__ __launch_bounds__(SP_WG) void k_sp_bwd(BatchDev b, ModelDev m, SpDev sp, const float* __restrict__ Pd,
                                                         float grad_scale, int timing) {
+  igmc_kernarg_warm<sizeof(BatchDev) + sizeof(ModelDev) + sizeof(SpDev) + 32>();
   IGMC_DYN_SMEM(smem);
   SP_STAMP(0);
   const int g = blockIdx.x, tid = threadIdx.x;
@@ -567,6 +573,7 @@ __global__ __launch_bounds__(SP_WG) void k_sp_bwd(BatchDev b, ModelDev m, SpDev 
 // k_sp_unpack does as a launch of its own): disjoint elements of Gd, nothing in this launch reads them
 __global__ __launch_bounds__(SP_THREADS) void k_sp_wgrad(BatchDev b, SpDev sp, int B, int nb1, float* __restrict__ Gd, ModelDev m,
                                                           const float* __restrict__ ge, int nun) {
+  igmc_kernarg_warm<sizeof(BatchDev) + sizeof(SpDev) + sizeof(ModelDev) + 32>();
   const int tid = threadIdx.x;
   const int dense = sp.dense;
   if ((int)blockIdx.x >= (int)gridDim.x - nun) {
