@@ -457,3 +457,20 @@ def test_data_parallel_group_pipeline_gloo(tmp_path, mode):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o[-3000:]
         assert 'rank %d pipeline ok' % r in o
+
+
+def test_group_sizes_of_short_and_odd_runs():
+    """Launch structure chosen for a run of a known length: whole pairs of groups where 2 M divides it, ONE single-group launch
+    for a run of at most 32 steps, and for an evaluation pass the M that leaves the fewest steps outside whole launches."""
+    from igmc_amd.stepgraph import MAX_GROUP, _group_size, _group_size_for
+    assert MAX_GROUP == 32
+    assert _group_size(200, 32) == 25 and _group_size(64, 32) == 32 and _group_size(40, 32) == 20
+    assert _group_size(20, 32) == 20 and _group_size(30, 32) == 30 and _group_size(4, 32) == 4      # single-group launches
+    assert _group_size(3, 32) == 32 and _group_size(67, 32) == 32                                  # nothing divides: the default
+    for n in (16, 17, 24, 53, 100, 273, 2000, 2001):
+        cap = min(32, n // 2)
+        m = _group_size_for(n)
+        assert 8 <= m <= cap
+        assert n % (2 * m) == min(n % (2 * k) for k in range(8, cap + 1)), n      # the fewest steps outside whole launches
+    assert _group_size_for(8) == 4 and _group_size_for(9) == 4                      # (below sixteen steps: half the run)
+    assert _group_size_for(100) == 25 and _group_size_for(24) == 12
