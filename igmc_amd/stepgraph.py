@@ -87,6 +87,30 @@ def _group_size_for(n_steps, cap=MAX_GROUP):
     return best
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    """The extraction chain's stream of a device: ONE stream of the process's own per device (hipStreamCreateWithFlags,
+    non-blocking), never one of torch's pooled streams.  torch hands out 32 pooled streams round robin and ``torch.cuda.graph``
+    captures on one of them; a process that has captured a few dozen two-branch step graphs -- a test session, a sweep -- gets a
+    pooled stream back in the other role, and the HIP runtime then crashes in ``hip::Graph::UpdateStreams`` at the next replay
+    (``profiles/r06_experiments/README.md``: found with the test files in another order; the round-5 tree has it too)."""
+    if os.environ.get('IGMC_POOLED_SIDE_STREAM', '0') == '1':          # (A/B hook: torch's pooled stream, as before round 6)
+        return torch.cuda.Stream(device=dev)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so'))
+        h = C.c_void_p()
+        with torch.cuda.device(key):
+            rc = hip.hipStreamCreateWithFlags(C.byref(h), 1)          # hipStreamNonBlocking
+        if rc != 0 or not h.value:
+            return torch.cuda.Stream(device=dev)                       # (no runtime handle: the pooled stream, as before)
+        st = _SIDE_STREAMS[key] = torch.cuda.ExternalStream(h.value, device=dev)
+    return st
+
+
 class GroupPipeline(object):
     """Host logic of the grouped step pipeline -- which extraction / step / re-grouping is launched when --, independent of
     what launches them.  A backend supplies ``_arena(q, i)``, ``_extract(arena, sel, B)``, ``_enqueue_step(arena, B)``,
@@ -307,7 +331,7 @@ class StepGraph(GroupPipeline):
         self.total = torch.zeros(1, dtype=torch.float64, device=self.dev)
         # the multi-GPU step (gradient kernels -> all-reduce -> Adam launch) can be forced on one GPU to test it
         self.dp_path = self.TRAINING and (self.world > 1 or os.environ.get('IGMC_FORCE_DP_PATH', '0') == '1')
-        self.side = torch.cuda.Stream(device=self.dev) if overlap else None
+        self.side = _side_stream(self.dev) if overlap else None
         # gradient exchange: the library's own RCCL communicator (igmc_allreduce_grads), enqueued on the step's stream
         self.comm = parallel.grad_comm(self.lib, self.dev.index if self.dev.index is not None else 0) if self.dp_path else None
         if self.comm is not None and not getattr(self.comm, 'capturable', True):

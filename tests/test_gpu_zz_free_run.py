@@ -11,9 +11,7 @@ pytestmark = pytest.mark.gpu
 
 def test_free_running_test_rmse_agrees_with_the_reference_rng_path_in_distribution(monkeypatch):
     # (eager launches: the trajectories are bit-identical to the hipGraph replays -- test_step_graph_is_bit_reproducible_and_
-    #  structure_independent -- and twenty more captured graphs in one test session are twenty more chances to meet the HIP
-    #  runtime's crash in hip::Graph::UpdateStreams, profiles/r06_experiments/README.md; this file also sorts LAST among the
-    #  GPU test files so that it cannot change what the older files see)
+    #  structure_independent -- and twenty graph captures less keep this file's run short)
     monkeypatch.setenv('IGMC_NO_GRAPH', '1')
     monkeypatch.setenv('IGMC_NO_EVAL_GRAPH', '1')
     D = F.make_data()
