@@ -21,6 +21,7 @@ from igmc_amd.util_functions import MyDynamicDataset  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--group', type=int, default=10)
+ap.add_argument('--single', type=int, default=0, help='a run of that many steps (<= 32) as ONE single-group launch (round 6)')
 ap.add_argument('--delay-us', type=float, default=0.0, help='a spin kernel of that length in front of every extraction launch (behind its gate)')
 args = ap.parse_args()
 M = args.group
@@ -72,21 +73,30 @@ sg._enqueue_step, sg._side = enqueue_step, side
 sg.begin_epoch(perm, 1)
 sg.step()
 rec[0] = True
-sg.prepare(group=M)
-rec[0] = False
-n_marks = len(labels)
-for _ in range(4):
-    sg.steps(2 * M)
+if args.single:
+    M = args.single
+    sg.prepare(steps_hint=M)
+    rec[0] = False
+    n_marks = len(labels) // 2          # (both parities' graphs were captured: the marks of the first one)
+    N = M
+    sg.steps(2 * M)                     # parity 0, parity 1: back at the first graph
+else:
+    sg.prepare(group=M)
+    rec[0] = False
+    n_marks = len(labels)
+    N = 2 * M
+    for _ in range(4):
+        sg.steps(N)
 torch.cuda.synchronize()
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 ev0.record()
-sg.steps(2 * M)
+sg.steps(N)
 ev1.record()
 torch.cuda.synchronize()
 t = buf[:n_marks].cpu().numpy().astype('int64')
 print('# IGMC_EXTRACT_PACED=%s delay %.0f us' % (os.environ.get('IGMC_EXTRACT_PACED', 'default'), args.delay_us))
 print('# M = %d, %d marks; the replay between two synchronizes: %.2f us/step by HIP events (with the marks in it)'
-      % (M, n_marks, ev0.elapsed_time(ev1) * 1e3 / (2 * M)))
+      % (M, n_marks, ev0.elapsed_time(ev1) * 1e3 / N))
 order = sorted(range(n_marks), key=lambda i: t[i])
 t0 = t[order[0]]
 for i in order:
