@@ -596,6 +596,7 @@ def main():
                         replicas_identical=bool(torch.equal(lo, hi)), param_checksum=float(chk[0].item()),
                         allreduce_us=allreduce_us.get(transport.split(':')[0].replace('host-callback', 'host')),
                         allreduce_us_by_transport=allreduce_us, allreduce_floats=n_flat,
+                        auto_choice_us=getattr(sg.comm, 'auto_us', None),      # (auto: the step exchange timed over p2p and rccl at start-up)
                         allreduce_in_graph=any(g is not None for g in sg.graphs),
                         devices=[torch.cuda.get_device_name(local), 'device %d of %d visible' % (local, torch.cuda.device_count())])
         for k, c in comms.items():

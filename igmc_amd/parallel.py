@@ -335,10 +335,65 @@ def grad_comm(lib, device):
         if comm is not None:
             if tried:
                 print('[igmc] gradient exchange over %s (%s)' % (kind, '; '.join(tried)), file=sys.stderr)
+            if want == 'auto' and kind == 'p2p' and world_size() > 1 and os.environ.get('IGMC_DP_AUTO_MEASURE', '1') == '1':
+                comm = _faster_of_p2p_and_rccl(lib, device, comm)
             _grad_comms[key] = comm
             return comm
         tried.append('%s could not be set up on every rank: %s' % (kind, why or 'another rank failed'))
     raise RuntimeError('no gradient exchange: ' + '; '.join(tried))
+
+
+def _exchange_us(comm, device, n=61000, reps=20):
+    """Microseconds per all-reduce of ``n`` floats (a step's exchange) on this rank's stream, MAX over the ranks."""
+    dev = torch.device('cuda', int(device))
+    st = torch.cuda.current_stream(dev).cuda_stream
+    t = torch.zeros(n, dtype=torch.float32, device=dev)
+    for _ in range(3):
+        comm.all_reduce_(t, st)
+    torch.cuda.synchronize(dev)
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        comm.all_reduce_(t, st)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    if hasattr(comm, 'check'):
+        comm.check(st)
+    us = torch.tensor([e0.elapsed_time(e1) / reps * 1e3], dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+    dist.all_reduce(us, op=dist.ReduceOp.MAX)
+    return float(us.item())
+
+
+def _faster_of_p2p_and_rccl(lib, device, p2p):
+    """``auto`` with more than one rank and a peer exchange that passed its self-test: the library's RCCL communicator is set up
+    beside it, a step's exchange (61 k floats) is timed over both -- MAX over the ranks, so every rank sees the same two numbers --
+    and the steps go over the faster one.  Whatever fails on the way (RCCL refusing this set of ranks, a timing that raises)
+    leaves the peer exchange in place.  ``IGMC_DP_AUTO_MEASURE=0``: p2p without the comparison."""
+    import sys
+    rccl, why = make_comm(lib, device, 'rccl')
+    if rccl is None:
+        return p2p
+    ok, us = True, {}
+    try:
+        us['p2p'] = _exchange_us(p2p, device)
+        us['rccl'] = _exchange_us(rccl, device)
+    except Exception as e:          # noqa: BLE001  (a diagnostic comparison: never the reason a run fails)
+        ok = False
+        print('[igmc] gradient exchange: timing p2p against rccl failed (%s); p2p' % e, file=sys.stderr)
+    if not _agree(ok, device):
+        rccl.close()
+        return p2p
+    pick = 'rccl' if us['rccl'] < us['p2p'] else 'p2p'
+    if rank() == 0:
+        print('[igmc] gradient exchange: p2p %.1f us, rccl %.1f us per step exchange -> %s' % (us['p2p'], us['rccl'], pick), file=sys.stderr)
+    if pick == 'rccl':
+        p2p.close()
+        rccl.auto_us = us          # (what the choice was made on: bench.py's dp_check carries it)
+        return rccl
+    rccl.close()
+    p2p.auto_us = us
+    return p2p
 
 
 def make_comm(lib, device, kind):
