@@ -110,7 +110,15 @@ __device__ uint32_t radix_select(const uint32_t* bm, int W, int k, uint64_t salt
   return prefix;
 }
 
-// keep only the k candidates with the smallest keys (uniform k-subset, reference :222-229)
+#ifndef IGMC_SAMPLE_PARK
+#define IGMC_SAMPLE_PARK IGMC_BLOCK      // (tests build with 2 to drive the four-pass path)
+#endif
+// keep only the k candidates with the smallest keys (uniform k-subset, reference :222-229).  Two walks over the candidate
+// bits: (1) histogram of the keys' top byte -> the byte b that holds the k-th smallest key and how many (r) of its keys are
+// wanted; (2) keep every key below b outright and park the keys OF b (cnt / 256 of them on average) in a short list, whose
+// r smallest are then found by counting -- each parked key against the others -- and set again.  A list that would not
+// fit (more than 256 keys in one byte of a hash: not seen) goes through radix_select's four passes instead; the kept set
+// is the same either way: the k smallest keys, which never tie (igmc_rng.h).
 __device__ void sample_fringe(uint32_t* bm, int W, int cnt, int k, uint64_t salt, int* hist, int* sm) {
   if (k >= cnt) return;
   if (k <= 0) {
@@ -118,34 +126,94 @@ __device__ void sample_fringe(uint32_t* bm, int W, int cnt, int k, uint64_t salt
     __syncthreads();
     return;
   }
-  const uint32_t T = radix_select(bm, W, k, salt, hist, sm);
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  for (int w = threadIdx.x; w < W; w += IGMC_BLOCK) {
+    uint32_t bits = bm[w];
+    while (bits) {
+      const int bp = __ffs((int)bits) - 1;
+      bits &= bits - 1u;
+      atomicAdd(&hist[igmc_sample_key(salt, (uint32_t)(w * 32 + bp)) >> 24], 1);
+    }
+  }
+  __syncthreads();
+  const int c = hist[threadIdx.x];
+  int tot;
+  const int ex = igmc_block_scan_excl(c, &tot, sm);
+  if (c > 0 && ex < k && k <= ex + c) {
+    sm[8] = (int)threadIdx.x;
+    sm[9] = k - ex;
+    sm[10] = c;
+  }
+  if (threadIdx.x == 0) sm[11] = 0;
+  __syncthreads();
+  const uint32_t b = (uint32_t)sm[8];
+  const int r = sm[9], cb = sm[10];
+  if (cb > IGMC_SAMPLE_PARK) {
+    __syncthreads();
+    const uint32_t T = radix_select(bm, W, k, salt, hist, sm);
+    for (int w = threadIdx.x; w < W; w += IGMC_BLOCK) {
+      uint32_t bits = bm[w], keep = 0u;
+      while (bits) {
+        const int bp = __ffs((int)bits) - 1;
+        bits &= bits - 1u;
+        if (igmc_sample_key(salt, (uint32_t)(w * 32 + bp)) <= T) keep |= 1u << bp;
+      }
+      bm[w] = keep;
+    }
+    __syncthreads();
+    return;
+  }
+  uint32_t* ckey = (uint32_t*)hist;          // (every count was read before the scan's barriers)
+  int* cid = hist + IGMC_BLOCK;
   for (int w = threadIdx.x; w < W; w += IGMC_BLOCK) {
     uint32_t bits = bm[w], keep = 0u;
     while (bits) {
       const int bp = __ffs((int)bits) - 1;
       bits &= bits - 1u;
-      if (igmc_sample_key(salt, (uint32_t)(w * 32 + bp)) <= T) keep |= 1u << bp;
+      const uint32_t key = igmc_sample_key(salt, (uint32_t)(w * 32 + bp));
+      if ((key >> 24) < b) keep |= 1u << bp;
+      else if ((key >> 24) == b) {
+        const int s = atomicAdd(&sm[11], 1);
+        ckey[s] = key;
+        cid[s] = w * 32 + bp;
+      }
     }
     bm[w] = keep;
   }
   __syncthreads();
+  if ((int)threadIdx.x < cb) {
+    const uint32_t mine = ckey[threadIdx.x];
+    int below = 0;
+    for (int j = 0; j < cb; ++j) below += ckey[j] < mine;
+    const int id = cid[threadIdx.x];
+    if (below < r) atomicOr(&bm[id >> 5], 1u << (id & 31));
+  }
+  __syncthreads();
 }
 
-// append the set bits of bm (ascending id) to list[cnt..], tag them with `dist`, OR into sel
+// append the set bits of bm (ascending id) to list[cnt..], tag them with `dist`, OR into sel.  SLOTS (one-hop split
+// launch): the fringe is the whole selection of this side and arrives in ascending id, so position in the list IS the
+// local index -- the node slot (s_gid, s_lab) is written here and the rank pass after the hops has nothing left to do.
+template <bool SLOTS>
 __device__ int append_fringe(const uint32_t* bm, uint32_t* sel, int W, int32_t* list, uint8_t* dists,
-                             int cnt, int dist, int* sm) {
+                             int cnt, int dist, int* sm, int32_t* sg = nullptr, uint8_t* sl = nullptr, int side = 0) {
   int running = cnt;
   for (int base = 0; base < W; base += IGMC_BLOCK) {
     const int w = base + threadIdx.x;
     uint32_t bits = (w < W) ? bm[w] : 0u;
     int tot;
     int o = running + igmc_block_scan_excl(__popc(bits), &tot, sm);
-    if (w < W) sel[w] |= bits;
+    if (!SLOTS && w < W) sel[w] |= bits;
     while (bits) {
       const int bp = __ffs((int)bits) - 1;
       bits &= bits - 1u;
       list[o] = w * 32 + bp;
       dists[o] = (uint8_t)dist;
+      if (SLOTS) {
+        sg[o] = w * 32 + bp;
+        sl[o] = (uint8_t)(2 * dist + side);        // reference :245
+      }
       ++o;
     }
     running += tot;
@@ -156,7 +224,7 @@ __device__ int append_fringe(const uint32_t* bm, uint32_t* sel, int W, int32_t* 
 // ---------------------------------------------------------------- kernel 1
 __device__ __forceinline__ void extract_nodes_body(const ExtractArgs& a) {
   IGMC_DYN_SMEM(smem);
-  __shared__ int hist[256];
+  __shared__ int hist[2 * IGMC_BLOCK];      // sample_fringe: 256 counts, then keys | ids of the deciding byte
   __shared__ int sm[16];
   const int g = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -205,11 +273,13 @@ __device__ __forceinline__ void extract_nodes_body(const ExtractArgs& a) {
         tl[0] = u0;
         td[0] = 0;
         a.b.y[g] = a.link_y[pos];
+        if (a.split) { sg[0] = u0; sl[0] = 0; }
       }
       if (do_v) {
         vis_v[v0 >> 5] |= 1u << (v0 & 31);
         tl[cap_u] = v0;
         td[cap_u] = 0;
+        if (a.split) { sg[cap_u] = v0; sl[cap_u] = 1; }
       }
     }
     cu = 1;
@@ -264,8 +334,14 @@ __device__ __forceinline__ void extract_nodes_body(const ExtractArgs& a) {
       if (do_u) sample_fringe(new_u, Wu, cnt_u, ku, igmc_sample_salt(a.seed, epoch, link_uid, dist, 0), hist, sm);
       if (do_v) sample_fringe(new_v, Wv, cnt_v, kv, igmc_sample_salt(a.seed, epoch, link_uid, dist, 1), hist, sm);
       if (ku == 0 && kv == 0) break;   // reference :230-231 (a split launch has one hop: nothing follows either way)
-      const int ncu = do_u ? append_fringe(new_u, sel_u, Wu, tl, td, cu, dist, sm) : cu;
-      const int ncv = do_v ? append_fringe(new_v, sel_v, Wv, tl + cap_u, td + cap_u, cv, dist, sm) : cv;
+      int ncu = cu, ncv = cv;
+      if (a.split) {
+        if (do_u) ncu = append_fringe<true>(new_u, sel_u, Wu, tl, td, cu, dist, sm, sg, sl, 0);
+        if (do_v) ncv = append_fringe<true>(new_v, sel_v, Wv, tl + cap_u, td + cap_u, cv, dist, sm, sg + cap_u, sl + cap_u, 1);
+      } else {
+        ncu = append_fringe<false>(new_u, sel_u, Wu, tl, td, cu, dist, sm);
+        ncv = append_fringe<false>(new_v, sel_v, Wv, tl + cap_u, td + cap_u, cv, dist, sm);
+      }
       fu_lo = cu; fu_hi = ncu; cu = ncu;
       fv_lo = cv; fv_hi = ncv; cv = ncv;
       __syncthreads();
@@ -281,24 +357,27 @@ __device__ __forceinline__ void extract_nodes_body(const ExtractArgs& a) {
   }
   __syncthreads();
 
-  // local index = 1 + rank among the selected ids (ascending); targets are local 0
-  if (do_u) bm_prefix(sel_u, pre_u, Wu, sm);
-  if (do_v) bm_prefix(sel_v, pre_v, Wv, sm);
-  __syncthreads();
-  if (do_u)
-    for (int i = tid; i < cu; i += IGMC_BLOCK) {
-      const int id = tl[i];
-      const int li = (i == 0) ? 0 : 1 + bm_rank(sel_u, pre_u, id);
-      sg[li] = id;
-      sl[li] = (uint8_t)(2 * td[i]);             // reference :245
-    }
-  if (do_v)
-    for (int i = tid; i < cv; i += IGMC_BLOCK) {
-      const int id = tl[cap_u + i];
-      const int li = (i == 0) ? 0 : 1 + bm_rank(sel_v, pre_v, id);
-      sg[cap_u + li] = id;
-      sl[cap_u + li] = (uint8_t)(2 * td[cap_u + i] + 1);
-    }
+  // local index = 1 + rank among the selected ids (ascending); targets are local 0.  (A free-running split launch wrote
+  // its slots while appending: one hop, one fringe, already in id order.)
+  if (!a.split || a.replay) {
+    if (do_u) bm_prefix(sel_u, pre_u, Wu, sm);
+    if (do_v) bm_prefix(sel_v, pre_v, Wv, sm);
+    __syncthreads();
+    if (do_u)
+      for (int i = tid; i < cu; i += IGMC_BLOCK) {
+        const int id = tl[i];
+        const int li = (i == 0) ? 0 : 1 + bm_rank(sel_u, pre_u, id);
+        sg[li] = id;
+        sl[li] = (uint8_t)(2 * td[i]);             // reference :245
+      }
+    if (do_v)
+      for (int i = tid; i < cv; i += IGMC_BLOCK) {
+        const int id = tl[cap_u + i];
+        const int li = (i == 0) ? 0 : 1 + bm_rank(sel_v, pre_v, id);
+        sg[cap_u + li] = id;
+        sl[cap_u + li] = (uint8_t)(2 * td[cap_u + i] + 1);
+      }
+  }
   if (tid == 0) {
     if (do_u) {
       a.b.n_users[g] = cu;
