@@ -47,6 +47,7 @@ SIGNATURES = {
     'igmc_batch_set_lean': (i32, [vp, i32]),
     'igmc_batch_want_transposed': (i32, [vp]),
     'igmc_model_dense_path': (i32, [vp, vp, i32]),
+    'igmc_model_step_form': (i32, [vp, vp, i32]),
     'igmc_model_reset_exchange': (i32, [vp, vp]),
     'igmc_model_create': (i32, [i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(vp)]),
     'igmc_model_destroy': (None, [vp]),

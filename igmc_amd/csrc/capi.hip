@@ -895,6 +895,14 @@ extern "C" int igmc_model_dense_path(const igmc_model* m, const igmc_batch* b, i
   return (rows0 <= 32 && m->d.D % 16 == 0 && igmc_g2_eligible(m->d, b->d, B, &lay, &cs)) ? 1 : 0;
 }
 
+extern "C" int igmc_model_step_form(const igmc_model* m, const igmc_batch* b, int B) {
+  if (!m || !b) return 0;
+  if (igmc_model_dense_path(m, b, B)) return 1;
+  if (igmc_dl_wide_gsplit(m->d, b->d, B)) return 3;
+  if (igmc_dl_wide(m->d, b->d, B) || (igmc_dl_eligible(m->d, b->d, B) && igmc_dl_fwd_eligible(m->d, b->d, B))) return 2;
+  return 0;
+}
+
 static int check_fit(igmc_model* m, const igmc_batch* b, std::string* why) {
   if (!m || !b) { *why = "null model or batch"; return 1; }
   if (b->last_B <= 0) { *why = "batch is empty (run igmc_extract_batch first)"; return 1; }

@@ -558,6 +558,7 @@ __host__ __device__ static inline int dlf_words_gs(int kp) {
 
 template <bool FLAGS, bool STORE, int NG, bool GS = false>
 __global__ __launch_bounds__(DL_THREADS) void k_dl_fwd(DlfArgs a) {
+  __builtin_amdgcn_s_setprio(3);      // (step chain: ahead of the extraction chain's waves wherever the two share a SIMD)
   igmc_kernarg_warm<sizeof(DlfArgs) + 32>();
   static_assert(!GS || NG == 2, "the group split is for two relation groups");
   constexpr int HP = (NG == 1) ? G2_XP : DLF_HP2;
@@ -1009,6 +1010,7 @@ __host__ __device__ static inline int dlb_words_gs(int kp) {
 
 template <bool FLAGS, int NG, bool DENSE3, bool GS = false>
 __global__ __launch_bounds__(DL_THREADS) void k_dl_bwd(DlbArgs a) {
+  __builtin_amdgcn_s_setprio(3);      // (step chain: ahead of the extraction chain's waves wherever the two share a SIMD)
   igmc_kernarg_warm<sizeof(DlbArgs) + 32>();
   static_assert(!GS || (NG == 2 && !DENSE3), "the group split is for two relation groups with the centre-node readout");
   constexpr int HP = (NG == 1) ? G2_XP : DLF_HP2;           // pitch of a row's layer-0 input
@@ -2020,6 +2022,9 @@ void igmc_launch_dl_fwd(const ModelDev& m, const BatchDev& b, const float* P, in
 // 1 = more than G2_NR relations (<= G2_NR * G2_NG_MAX, layer-0 table <= 48 rows) on the one-launch dense kernels, which take the
 // relations in groups: k_dl_fwd / k_head_sub / k_dl_bwd<*, NG> with the relation-space tables behind them -- all of it or
 // nothing (the per-layer kernels k_dl_layer0 / k_dl_layer stop at G2_NR relations)
+// 1 = ... and in the group-split form (dl_gsplit): both relation groups at once on the halves of a workgroup
+int igmc_dl_wide_gsplit(const ModelDev& m, const BatchDev& b, int B) { return igmc_dl_wide(m, b, B) && dl_gsplit(m, b, B); }
+
 int igmc_dl_wide(const ModelDev& m, const BatchDev& b, int B) {
   if (!igmc_g2_xcd_ok()) return 0;      // (the members' exchange goes through the L2 of one XCD)
   if (!dl_base_ok(m, b, B, 1)) return 0;

@@ -49,6 +49,7 @@ struct G2Args {
 // cycles, profiles/r06_g2_phase_clocks.txt "loop start -> loads issued") before the first vector load of the launch left.
 template <bool FLAGS, bool TRAIN, bool ONCE>
 __global__ __launch_bounds__(G2_THREADS) void k_graph_step2(G2Args a) {
+  __builtin_amdgcn_s_setprio(3);      // (step chain: ahead of the extraction chain's waves wherever the two share a SIMD)
   const float* P = a.P;
   IGMC_DYN_SMEM(smem);
   float* S = (float*)smem;

@@ -103,6 +103,7 @@ int igmc_dl_ts_eligible(const ModelDev& m, const BatchDev& b, int B);
 int igmc_dl_fwd_eligible(const ModelDev& m, const BatchDev& b, int B);
 int igmc_dl_bwd_eligible(const ModelDev& m, const BatchDev& b, int B);
 int igmc_dl_wide(const ModelDev& m, const BatchDev& b, int B);
+int igmc_dl_wide_gsplit(const ModelDev& m, const BatchDev& b, int B);
 // (head != NULL: the launch runs the subgraphs' loss head itself -- no k_head_sub launch in front of it)
 struct DlHead {
   const float* P;

@@ -1555,6 +1555,7 @@ __global__ __launch_bounds__(IGMC_BLOCK) void k_tail_ts(BatchDev b, ModelDev m, 
                                                           float grad_scale, float mult, float drop_scale,
                                                           float* __restrict__ grad, int nlin, int nparts, int stride,
                                                           int B, int nstash, const int64_t* ctrl, int bump_seq) {
+  __builtin_amdgcn_s_setprio(3);      // (step chain: ahead of the extraction chain's waves wherever the two share a SIMD)
   igmc_kernarg_warm<sizeof(BatchDev) + sizeof(ModelDev) + 64>();
   const int nred = (int)gridDim.x - nlin - nstash;
   if (bump_seq && blockIdx.x == 0 && threadIdx.x == 0) m.gs_bar[1] += 1;      // (every workgroup of k_graph_step2 is done)
@@ -1920,6 +1921,7 @@ __device__ __forceinline__ float fts_emit(float* __restrict__ grad, const AdamTa
 // subgraph kernel: one launch and one round trip to the weights less per step.
 __global__ __launch_bounds__(IGMC_BLOCK) void k_finalize_ts(ModelDev m, const float* P, float* __restrict__ grad,
                                                               float arr_coef, AdamTail at, int nlin, int bs, int img) {
+  __builtin_amdgcn_s_setprio(3);      // (step chain: ahead of the extraction chain's waves wherever the two share a SIMD)
   igmc_kernarg_warm<sizeof(ModelDev) + sizeof(AdamTail) + 48>();
   // bs != 0: the per-layer path's sources -- conv layers 1..3 in BASIS space (graw: d basis_b, d root, d bias straight
   // from the weight-gradient kernel, d att from the layer kernels' partials), layer 0 as its relation-space table in graw;

@@ -267,6 +267,11 @@ class ModelWorkspace(object):
         """True when forward / loss_grad / train_step on (batch arena, B) take the matrix-core subgraph kernel."""
         return bool(self.lib.igmc_model_dense_path(self.handle, batch.handle, int(B)))
 
+    def step_form(self, batch, B):
+        """Kernels of a training step on (batch arena, B): 1 subgraph kernel, 2 dense-layer kernels, 3 those in their
+        group-split form, 0 per-layer kernels (igmc_model_step_form)."""
+        return int(self.lib.igmc_model_step_form(self.handle, batch.handle, int(B)))
+
     def adam_step(self, params, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8,
                   weight_decay=0.0, stream=None):
         self.lib.call('igmc_adam_step', _p(params), _p(grad), _p(exp_avg), _p(exp_avg_sq), self.n_params, int(step),

@@ -465,8 +465,18 @@ class StepGraph(GroupPipeline):
             i0 += n
         return plan
 
+    def _step_form(self):
+        if getattr(self, '_form', None) is None:
+            self._form = 0 if self.sp is not None else self.ws.step_form(self._arena(0, 0), self.B)
+        return self._form
+
     def _paced_default(self):
-        return self.sp is None and bool(self.ws.dense_path(self._arena(0, 0), self.B))
+        # subgraph kernel, and the group-split dense-layer kernels (cap <= 128 arenas, two relation groups: an extraction
+        # launch is shorter than a step there too, and running free it lands on the boundaries of the step's launches --
+        # flixster 89.5 -> 88.2, ml_10m_lite 100.0 -> 98.0 us/step, round 6); the cap-200 arenas' longer chain runs free
+        # (ml_100k: 102.8 free, 103.9 .. 106.6 gated)
+        f = self._step_form()
+        return f == 1 or (f == 3 and self.TRAINING)
 
     def _mark(self):
         if self.side is None:
@@ -478,13 +488,16 @@ class StepGraph(GroupPipeline):
     GATE_TIMEOUT_US = 2000.0      # a gate that has not seen its step after this long lets the extraction go (a hint only)
     GATE_DELAY_US = 10.0          # ... and it opens this long after its step began (IGMC_GATE_DELAY_US): the step's subgraph kernel
                                   # is on the chip by then, the extraction launch takes the CUs it leaves
+    GATE_DELAY_DL_US = 40.0       # ... dense-layer kernels: once the step's SECOND launch (k_dl_bwd, ~31 us in) is on the chip -- a
+                                  # gate that opens around that boundary costs most (delay 10: 98.1 .. 103.6 us/step on ml_10m_lite)
 
     def _side_after(self, mark, fn):
         if self.side is not None and mark is not None:
             if isinstance(mark, tuple):         # ('gate', q, steps of the group that must be done)
                 # (the first launch of a group has no step to wait for: it is released at the group's start, together with
                 #  the group's first step -- the delay applies to it unconditionally)
-                delay = float(os.environ.get('IGMC_GATE_DELAY_US', self.GATE_DELAY_US))
+                delay = float(os.environ.get('IGMC_GATE_DELAY_US',
+                                             self.GATE_DELAY_DL_US if self._step_form() == 3 else self.GATE_DELAY_US))
                 self.lib.call('igmc_ctrl_gate', C.c_void_p(self.ctrl.data_ptr()), int(mark[1]), int(mark[2]), delay,
                               1 if int(mark[2]) == 0 else 0, self.GATE_TIMEOUT_US, C.c_void_p(self.side.cuda_stream))
             else:

@@ -356,6 +356,11 @@ int igmc_model_check(igmc_model* m, void* stream);
 /* 1 when forward / loss_grad / train_step on (this arena, batch size B) run the matrix-core subgraph kernel, which
  * reads the dense blocks only (see igmc_batch_set_lean); 0 otherwise.  No reference counterpart. */
 int igmc_model_dense_path(const igmc_model* m, const igmc_batch* b, int B);
+/* Which kernels a training step on (this arena, batch size B) is made of -- what a caller that overlaps the extraction of
+ * the next batches with the steps needs to know to pace it (igmc_ctrl_gate): 1 = the subgraph kernel (igmc_model_dense_path),
+ * 2 = the one-launch dense-layer kernels, 3 = those in their group-split form (two relation groups at once), 0 = the
+ * per-layer kernels.  No reference counterpart. */
+int igmc_model_step_form(const igmc_model* m, const igmc_batch* b, int B);
 /* Clears the row / plane exchange regions of the subgraph and dense-layer kernels (enqueued on `stream`).  They must only ever
  * hold finite values (a consumer copies whole plane images, stale rows of earlier launches included, and multiplies them by
  * zero block entries): call it after steps that ran on non-finite parameters, e.g. when parameters are restored. */

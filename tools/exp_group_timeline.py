@@ -23,15 +23,19 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--group', type=int, default=10)
 ap.add_argument('--single', type=int, default=0, help='a run of that many steps (<= 32) as ONE single-group launch (round 6)')
 ap.add_argument('--delay-us', type=float, default=0.0, help='a spin kernel of that length in front of every extraction launch (behind its gate)')
+ap.add_argument('--config', default='ml_1m', help="dataset (preprocessing.create_trainvaltest_split): ml_1m, ml_10m_lite, ...")
 args = ap.parse_args()
+if os.environ.get('IGMC_LIB_PATH'):                # debug hook: an experimental build of the library
+    from igmc_amd import _lib
+    _lib.LIB_PATH = os.environ['IGMC_LIB_PATH']
 M = args.group
 mk = C.CDLL(os.path.join(ROOT, 'tools', 'ubench', 'libclock_mark.so'))
 mk.clock_mark.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-split = preprocessing.create_trainvaltest_split('ml_1m', 1234, True, verbose=False)
+split = preprocessing.create_trainvaltest_split(args.config, 1234, True, verbose=False)
 (_, _, A, tr_l, tr_u, tr_v, _, _, _, _, _, _, cv) = split
 torch.cuda.set_device(0)
 ds = MyDynamicDataset('data/x', A, (tr_u, tr_v), tr_l, 1, 1.0, 100, None, None, cv, device=0, seed=1)
-model = IGMC(ds, latent_dim=[32, 32, 32, 32], num_relations=5, num_bases=4, regression=True, adj_dropout=0.0, seed=1).to('cuda')
+model = IGMC(ds, latent_dim=[32, 32, 32, 32], num_relations=len(cv), num_bases=4, regression=True, adj_dropout=0.0, seed=1).to('cuda')
 model.reset_parameters()
 opt = FlatAdam(model, lr=1e-3)
 perm = torch.randperm(len(ds), generator=torch.Generator().manual_seed(1))

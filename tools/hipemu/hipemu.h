@@ -466,6 +466,7 @@ static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v
 static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+static inline void __builtin_amdgcn_s_setprio(int) {}      // (wave issue priority: no meaning under the emulation)
 static inline int __builtin_amdgcn_readfirstlane(int v) {
   hipemu::WaveState& w = hipemu::my_wave();
   const int buf = w.gen & 1;

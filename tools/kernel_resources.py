@@ -13,7 +13,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CSRC = os.path.join(ROOT, 'igmc_amd', 'csrc')
+CSRC = os.environ.get('IGMC_CSRC_DIR') or os.path.join(ROOT, 'igmc_amd', 'csrc')      # (a variant's sources: tools/build_variant.sh)
 LLVM = '/opt/rocm/lib/llvm/bin'
 
 
