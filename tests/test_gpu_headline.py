@@ -72,6 +72,7 @@ def test_headline_batch_matches_oracle(be, ml1m, drop, monkeypatch, capfd):
     assert res['worst_grad_err'] < PC.GRAD_TOL
     d = res['d']
     assert d['B'] == 50 and 50 * 150 < d['N'] <= 50 * 202 and d['E'] > 150000       # the headline shape, not a toy
+    assert res['ws'].step_form(res['batch'], 50) == 1         # (igmc_model_step_form: what the pipeline paces its extraction by)
     PC.check_sampled(d, case)
     err = capfd.readouterr().err
     assert 'k_graph_step B=50 train=1' in err and 'cluster=4' in err, err[-400:]
@@ -180,6 +181,7 @@ def test_ml10m_lite_batch_matches_oracle(be, ml10m, drop, lean):
     res = PC.run_model_parity(be, case, R=10, use_dropout=drop, lean=lean)
     assert res['worst_grad_err'] < PC.GRAD_TOL
     assert res['batch'].dense_layers(res['ws'])
+    assert res['ws'].step_form(res['batch'], 50) == 3         # dense-layer kernels, both relation groups at once
     d = res['d']
     assert d['B'] == 50 and 50 * 150 < d['N'] <= 50 * 202 and d['E'] > 150000
     assert int(d['erel'].max()) >= 8                   # relation codes of the second group are present
@@ -208,6 +210,7 @@ def test_ml100k_cap200_batch_matches_oracle(be, lean):
     res = PC.run_model_parity(be, case, R=5, use_dropout=True, lean=lean)
     assert res['worst_grad_err'] < PC.GRAD_TOL
     assert res['batch'].dense_layers(res['ws'])
+    assert res['ws'].step_form(res['batch'], 50) == 2         # dense-layer kernels, one relation group
     PC.check_sampled(res['d'], case)
     assert res['d']['N'] > 50 * 200
 
