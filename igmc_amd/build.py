@@ -63,9 +63,7 @@ def build_hip(force=False, verbose=False):
     return HIP_LIB
 
 
-def build_emu(force=False, defines=(), out=None):
-    """defines / out: a second emulation build with other compile-time switches (tests of rarely taken kernel paths)."""
-    EMU_LIB = out or globals()['EMU_LIB']
+def build_emu(force=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     emu_h = os.path.join(ROOT, 'tools', 'hipemu', 'hipemu.h')
     deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [emu_h]
@@ -80,7 +78,7 @@ def build_emu(force=False, defines=(), out=None):
         raise RuntimeError('clang++ not found (needed for ext_vector_type in the emulation build)')
     os.makedirs(os.path.dirname(EMU_LIB), exist_ok=True)
     cmd = [cxx, '-x', 'c++', '-std=c++17', '-O2', '-g', '-fPIC', '-shared', '-DIGMC_HIPEMU', '-Wno-unused-value',
-           '-include', emu_h, '-o', EMU_LIB] + ['-D' + d for d in defines] + srcs
+           '-include', emu_h, '-o', EMU_LIB] + srcs
     _run(cmd)
     return EMU_LIB
 

@@ -110,15 +110,19 @@ __device__ uint32_t radix_select(const uint32_t* bm, int W, int k, uint64_t salt
   return prefix;
 }
 
-#ifndef IGMC_SAMPLE_PARK
-#define IGMC_SAMPLE_PARK IGMC_BLOCK      // (tests build with 2 to drive the four-pass path)
+#ifdef IGMC_HIPEMU
+// (CPU emulation only: the tests lower the bound through the environment to drive the four-pass path)
+static inline int igmc_sample_park() { const char* e = getenv("IGMC_SAMPLE_PARK"); return e ? atoi(e) : IGMC_BLOCK; }
+#define IGMC_SAMPLE_PARK igmc_sample_park()
+#else
+#define IGMC_SAMPLE_PARK IGMC_BLOCK
 #endif
 // keep only the k candidates with the smallest keys (uniform k-subset, reference :222-229).  Two walks over the candidate
 // bits: (1) histogram of the keys' top byte -> the byte b that holds the k-th smallest key and how many (r) of its keys are
 // wanted; (2) keep every key below b outright and park the keys OF b (cnt / 256 of them on average) in a short list, whose
 // r smallest are then found by counting -- each parked key against the others -- and set again.  A list that would not
-// fit (more than 256 keys in one byte of a hash: not seen) goes through radix_select's four passes instead; the kept set
-// is the same either way: the k smallest keys, which never tie (igmc_rng.h).
+// fit (more than 256 keys in one byte of a hash: not seen; tests force it) goes through radix_select's four passes instead;
+// the kept set is the same either way: the k smallest keys, which never tie (igmc_rng.h).
 __device__ void sample_fringe(uint32_t* bm, int W, int cnt, int k, uint64_t salt, int* hist, int* sm) {
   if (k >= cnt) return;
   if (k <= 0) {

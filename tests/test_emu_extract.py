@@ -48,21 +48,16 @@ def test_sampler_free_run(be, name):
     assert not np.array_equal(d['node_gid'], d3['node_gid'])
 
 
-def test_sampler_four_pass_path_keeps_the_same_subset(be):
+def test_sampler_four_pass_path_keeps_the_same_subset(be, monkeypatch):
     """sample_fringe parks the keys of the deciding byte in a 256-entry list and falls back to radix_select's four passes
-    when they would not fit -- which a hash never produces.  A build with a 2-entry list takes the fallback on (nearly)
-    every draw and must extract the very same batches."""
-    import ctypes
-    import os
-    from igmc_amd import _lib, build
-    out = os.path.join(os.path.dirname(build.EMU_LIB), 'libigmc_emu_park2.so')
-    path = build.build_emu(defines=('IGMC_SAMPLE_PARK=2',), out=out)
-    be2 = PC.EmuBackend()
-    be2.lib = _lib.bind(ctypes.CDLL(path), path)
+    when they would not fit -- which a hash never produces.  With a bound of 0 (emulation builds read it from the environment)
+    the fallback is taken on every draw and must extract the very same batches."""
     for name in ('synth_cap', 'synth_h2_ratio'):
         case = dict(CASES[name])
+        monkeypatch.delenv('IGMC_SAMPLE_PARK', raising=False)
         _, _, d = PC.extract_case(be, case, replay=False, seed=7, epoch=3)
-        _, _, d2 = PC.extract_case(be2, case, replay=False, seed=7, epoch=3)
+        monkeypatch.setenv('IGMC_SAMPLE_PARK', '0')
+        _, _, d2 = PC.extract_case(be, case, replay=False, seed=7, epoch=3)
         PC.check_sampled(d2, case)
         for k in ('node_gid', 'col', 'row_ptr', 'etype'):
             if k in d:
