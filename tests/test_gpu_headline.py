@@ -452,3 +452,47 @@ def test_small_batches_match_the_reference_fixtures(be, case):
     from helpers import load_model_golden
     res = PC.run_reference_fixture(be, load_model_golden(case), 8)
     assert res['params_frac_off'] < PC.TRAJ_FRAC_OFF
+
+
+def test_extraction_bitmaps_of_a_200k_node_graph(be, monkeypatch):
+    """A rating graph of 170 000 users x 40 000 items: the LDS bitmaps of an extraction workgroup take 105 KB (the limit is
+    ~300 k ids, igmc_batch_create) -- far from the 20 KB of the MovieLens shapes the other tests run on.  The single-batch
+    launch against the host twin on hub links where the cap binds; then one epoch of the grouped step graph
+    (k_extract_nodes_set: what the training pipeline uses) == the same epoch with one batch per extraction launch, bit for bit."""
+    import scipy.sparse as ssp
+    import torch
+    from igmc_amd.util_functions import MyDynamicDataset
+    from oracle import extract_cpu
+    import test_extract_twin as T
+    rng = np.random.default_rng(23)
+    nu, nv = 170000, 40000
+    u = rng.integers(0, nu, 500000)
+    v = rng.integers(0, nv, 500000)
+    hub_users = rng.choice(nu, 3000, replace=False)          # item 7: rated by 3 000 users
+    hub_items = rng.choice(nv, 2500, replace=False)          # user 11: rates 2 500 items
+    u = np.concatenate([u, hub_users, np.full(2500, 11)])
+    v = np.concatenate([v, np.full(3000, 7), hub_items])
+    r = rng.integers(1, 6, len(u)).astype(np.float32)
+    A = ssp.csr_matrix(ssp.coo_matrix((r, (u, v)), shape=(nu, nv)))
+    A.data = np.clip(np.rint(A.data), 1, 5).astype(np.float32)           # (duplicate pairs were summed)
+    cv = np.arange(1, 6, dtype=np.float64)
+    coo = A.tocoo()
+    hubs = np.flatnonzero((coo.col == 7) | (coo.row == 11))
+    pick = np.concatenate([rng.choice(hubs, 150, replace=False), rng.permutation(coo.nnz)[:250]])
+    lu, lv, ly = coo.row[pick].astype(np.int64), coo.col[pick].astype(np.int64), (coo.data[pick] - 1).astype(np.int64)
+    # single-batch launch (k_extract_nodes) against the OpenMP twin: node sets, order, labels, induced edges
+    case = dict(A=A, links=np.stack([lu[:24], lv[:24]], 1), link_labels=ly[:24], class_values=cv, h=1, sample_ratio=1.0,
+                mnph=100, recs=[None] * 24)
+    _, _, d = PC.extract_case(be, case, replay=False, seed=11, epoch=4)
+    twin = extract_cpu.extract_batch(A, case['links'][:, 0], case['links'][:, 1], 0, 24, hop=1, sample_ratio=1.0,
+                                     max_nodes_per_hop=100, seed=11, epoch=4)
+    T.compare(d, case, twin)
+    assert max(len(t[0]) for t in twin) == 101 and max(len(t[1]) for t in twin) == 101          # the cap binds
+    # the training pipeline: group launches (k_extract_nodes_set) == one batch per launch
+    ds = MyDynamicDataset('data/t/big', A, (lu, lv), ly, 1, 1.0, 100, None, None, cv, device=0, seed=1)
+    perm = torch.randperm(len(ds), generator=torch.Generator().manual_seed(5))
+    sg, ref = _trajectory(ds, 0.0, perm, epochs=1, group=4)
+    assert sg.ws.dense_path(sg.arenas[0], 50) and ref[4] == 8
+    monkeypatch.setenv('IGMC_GROUP_EXTRACT_CHUNK', '1')
+    _, single = _trajectory(ds, 0.0, perm, epochs=1, group=4)
+    _assert_same(ref, single, 'one batch per extraction launch vs group launches on a 210 000-node graph')
