@@ -475,8 +475,18 @@ class StepGraph(GroupPipeline):
         # launch is shorter than a step there too, and running free it lands on the boundaries of the step's launches --
         # flixster 89.5 -> 88.2, ml_10m_lite 100.0 -> 98.0 us/step, round 6); the cap-200 arenas' longer chain runs free
         # (ml_100k: 102.8 free, 103.9 .. 106.6 gated)
-        f = self._step_form()
-        return f == 1 or (f == 3 and self.TRAINING)
+        return self.pacing_policy(self._step_form(), self.TRAINING)[0]
+
+    @classmethod
+    def pacing_policy(cls, form, training):
+        """(extraction launches held back by gates?, microseconds into the step at which a gate opens) for the kernels a step
+        is made of (``igmc_model_step_form``: 1 subgraph kernel, 2 dense-layer kernels, 3 their group-split form, 0 per-layer
+        kernels); evaluation passes gate the subgraph kernel only."""
+        if form == 1:
+            return True, cls.GATE_DELAY_US
+        if form == 3 and training:
+            return True, cls.GATE_DELAY_DL_US
+        return False, cls.GATE_DELAY_US
 
     def _mark(self):
         if self.side is None:
@@ -496,8 +506,7 @@ class StepGraph(GroupPipeline):
             if isinstance(mark, tuple):         # ('gate', q, steps of the group that must be done)
                 # (the first launch of a group has no step to wait for: it is released at the group's start, together with
                 #  the group's first step -- the delay applies to it unconditionally)
-                delay = float(os.environ.get('IGMC_GATE_DELAY_US',
-                                             self.GATE_DELAY_DL_US if self._step_form() == 3 else self.GATE_DELAY_US))
+                delay = float(os.environ.get('IGMC_GATE_DELAY_US', self.pacing_policy(self._step_form(), self.TRAINING)[1]))
                 self.lib.call('igmc_ctrl_gate', C.c_void_p(self.ctrl.data_ptr()), int(mark[1]), int(mark[2]), delay,
                               1 if int(mark[2]) == 0 else 0, self.GATE_TIMEOUT_US, C.c_void_p(self.side.cuda_stream))
             else:
