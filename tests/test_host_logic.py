@@ -485,3 +485,26 @@ def test_pacing_policy_by_the_kernels_of_a_step():
     assert StepGraph.pacing_policy(3, True) == (True, 40.0) and StepGraph.pacing_policy(3, False)[0] is False
     assert StepGraph.pacing_policy(2, True)[0] is False and StepGraph.pacing_policy(0, True)[0] is False
 
+
+def test_batches_per_extraction_launch_follow_the_density_of_the_graph(monkeypatch):
+    """``StepGraph._chunk``: two batches per extraction launch, one where a link's two neighbourhoods hold fewer than 128
+    candidates on average (the Monti sets); the environment overrides; evaluation passes keep two."""
+    import types
+    from igmc_amd.stepgraph import EvalGraph, StepGraph
+    monkeypatch.delenv('IGMC_GROUP_EXTRACT_CHUNK', raising=False)
+
+    def chunk(cls, n_users, n_items, nnz, M=25):
+        sg = object.__new__(cls)
+        sg.M = M
+        sg.ds = types.SimpleNamespace(graph=types.SimpleNamespace(n_users=n_users, n_items=n_items, nnz=nnz))
+        return sg._chunk()
+
+    assert chunk(StepGraph, 3000, 3000, 26173) == 1            # flixster: 17 candidates a link
+    assert chunk(StepGraph, 3000, 3000, 123202) == 1           # douban: 82
+    assert chunk(StepGraph, 943, 1682, 100000) == 2            # ml_100k: 165
+    assert chunk(StepGraph, 6040, 3706, 1000209) == 2          # ml_1m: 435
+    assert chunk(EvalGraph, 3000, 3000, 26173) == 2
+    assert chunk(StepGraph, 6040, 3706, 1000209, M=1) == 1     # (never more than a group)
+    monkeypatch.setenv('IGMC_GROUP_EXTRACT_CHUNK', '4')
+    assert chunk(StepGraph, 3000, 3000, 26173) == 4
+
