@@ -7,7 +7,7 @@ graph-launch boundary costs 35-100 us).  Structure:
 * the per-step scalars (offset into the link permutation, epoch, step counter for the dropout hashes, Adam bias
   corrections) live in a small HBM control block advanced by the step's own last kernel (``include/igmc_hip.h``,
   device-side step control), so the launch sequence of a step never changes and is captured ONCE;
-* steps run in groups of M (``IGMC_GROUP_STEPS``, default 32): the M batches of a group sit in M arenas (one arena set per
+* steps run in groups of M (``IGMC_GROUP_STEPS``, default 50): the M batches of a group sit in M arenas (one arena set per
   group parity, 288 GB of HBM make that free), and a group is
 
       main :  step(arena q,0) -> step(arena q,1) -> ... -> step(arena q,M-1) ---------+-> join
@@ -39,7 +39,8 @@ import torch
 
 from . import _lib, parallel
 
-MAX_GROUP = 32
+MAX_GROUP = 50               # steps of a group (arenas of an arena set); 32 until round 6: a group's fixed costs -- fork / join, its first
+                             # step, the first launches of its extraction chain -- are ~60 us, 64.4 -> 63.2 us/step from 25 to 50
 SPARSE_CANDIDATES = 128.0    # mean (user degree + item degree) below which extraction launches go batch by batch (_chunk)
 GROUP_EXTRACT_CHUNK = 2      # batches per extraction launch (igmc_extract_group; measured: profiles/r03_extract_chunk_sweep.txt); 0 / 1 = arena by arena
 
@@ -74,7 +75,10 @@ def _group_size(steps_hint, default):
     return default
 
 
-def _group_size_for(n_steps, cap=MAX_GROUP):
+EVAL_MAX_GROUP = 32          # evaluation passes: groups of 50 were slower (1.29 M against 1.33 M subgraphs/s over 20 000 links, round 6)
+
+
+def _group_size_for(n_steps, cap=EVAL_MAX_GROUP):
     """Group size M <= ``cap`` for a run of ``n_steps`` steps that is NOT a multiple of a convenient length (an evaluation pass
     over a test set): the M that leaves the fewest steps outside whole graph launches of 2 M steps -- those run eagerly,
     extraction and model step one after the other, at about twice the cost --, the larger M on a tie."""
@@ -308,7 +312,7 @@ class StepGraph(GroupPipeline):
         self.world = parallel.world_size()
         flat = model.flat_parameters()
         self.dev = flat.device
-        env = os.environ.get('IGMC_GROUP_STEPS', os.environ.get('IGMC_GRAPH_STEPS', '32'))
+        env = os.environ.get('IGMC_GROUP_STEPS', os.environ.get('IGMC_GRAPH_STEPS', str(MAX_GROUP)))
         if use_graph is None:
             use_graph = os.environ.get('IGMC_NO_GRAPH', '0') != '1'
         if overlap is None:

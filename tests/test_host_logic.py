@@ -461,12 +461,13 @@ def test_data_parallel_group_pipeline_gloo(tmp_path, mode):
 
 def test_group_sizes_of_short_and_odd_runs():
     """Launch structure chosen for a run of a known length: whole pairs of groups where 2 M divides it, ONE single-group launch
-    for a run of at most 32 steps, and for an evaluation pass the M that leaves the fewest steps outside whole launches."""
+    for a run of at most 50 steps, and for an evaluation pass the M that leaves the fewest steps outside whole launches."""
     from igmc_amd.stepgraph import MAX_GROUP, _group_size, _group_size_for
-    assert MAX_GROUP == 32
-    assert _group_size(200, 32) == 25 and _group_size(64, 32) == 32 and _group_size(40, 32) == 20
-    assert _group_size(20, 32) == 20 and _group_size(30, 32) == 30 and _group_size(4, 32) == 4      # single-group launches
-    assert _group_size(3, 32) == 32 and _group_size(67, 32) == 32                                  # nothing divides: the default
+    assert MAX_GROUP == 50
+    assert _group_size(200, 50) == 50 and _group_size(400, 50) == 50 and _group_size(64, 50) == 32 and _group_size(128, 50) == 32
+    assert _group_size(20, 50) == 20 and _group_size(30, 50) == 30 and _group_size(4, 50) == 4      # single-group launches
+    assert _group_size(40, 50) == 40 and _group_size(50, 50) == 50
+    assert _group_size(3, 50) == 50 and _group_size(67, 50) == 50                                  # nothing divides: the default
     for n in (16, 17, 24, 53, 100, 273, 2000, 2001):
         cap = min(32, n // 2)
         m = _group_size_for(n)
