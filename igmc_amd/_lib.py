@@ -45,6 +45,7 @@ SIGNATURES = {
     'igmc_batch_set_side_features': (i32, [vp, vp, i32]),
     'igmc_batch_bind_side_source': (i32, [vp, vp, i32]),
     'igmc_batch_set_lean': (i32, [vp, i32]),
+    'igmc_batch_assume_size': (i32, [vp, i32]),
     'igmc_batch_want_transposed': (i32, [vp]),
     'igmc_model_dense_path': (i32, [vp, vp, i32]),
     'igmc_model_step_form': (i32, [vp, vp, i32]),

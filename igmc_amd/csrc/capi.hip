@@ -541,6 +541,13 @@ static void ensure_csr(const igmc_batch* b, void* stream) {
   if (b->lean && b->d.relm && b->last_B > 0) igmc_launch_emit(b->d, b->last_B, stream);
 }
 
+extern "C" int igmc_batch_assume_size(igmc_batch* b, int B) {
+  if (!b) IGMC_FAIL("null batch");
+  if (B <= 0 || B > b->d.graph_cap) IGMC_FAIL("batch size out of range");
+  b->last_B = B;
+  return 0;
+}
+
 extern "C" int igmc_batch_set_lean(igmc_batch* b, int lean) {
   if (!b) IGMC_FAIL("null batch");
   b->lean = lean ? 1 : 0;

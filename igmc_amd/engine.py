@@ -139,6 +139,11 @@ class Batch(object):
         collated CSR is emitted on demand (``igmc_batch_set_lean``)."""
         self.lib.call('igmc_batch_set_lean', self.handle, int(bool(lean)))
 
+    def assume_size(self, B):
+        """The arena holds ``B`` subgraphs extracted by a replayed launch (``igmc_batch_assume_size``)."""
+        self.lib.call('igmc_batch_assume_size', self.handle, int(B))
+        self.B = int(B)
+
     def info(self, stream=None):
         info = _lib.BatchInfo()
         self.lib.call('igmc_batch_get_info', self.handle, C.byref(info), _p(stream))

@@ -248,12 +248,19 @@ class GroupPipeline(object):
         if self.gk >= self.avail or not full:
             self._extract(arena, self.gq | (self.gk << 1), B)      # (a prefetch assumed a full batch)
             self.avail = self.gk + 1 if full else self.avail
+        else:
+            # prefetched -- possibly by a REPLAYED launch, which leaves no trace on the host: the arena's last extraction CALL
+            # may be an older one of another size (the ragged last batch of the epoch before)
+            self._assume_full(arena)
         self._enqueue_step(arena, B)
         self._last = arena
         self._advance(1)
         self.gk += 1
         if self.gk >= self.M:
             self.gq, self.gk, self.avail = self.gq ^ 1, 0, 0
+
+    def _assume_full(self, arena):
+        """Backends whose arenas remember the size of their last extraction call are told it is a full batch."""
 
     def step(self, B=None):
         """One optimisation step on the next ``B`` links of the epoch permutation (eager launches)."""
@@ -572,6 +579,9 @@ class StepGraph(GroupPipeline):
     def _hint_unchanged(self):
         if self.sp is None:
             self.lib.call('igmc_model_weights_unchanged', self.ws.handle, 1)
+
+    def _assume_full(self, arena):
+        arena.assume_size(self.B)
 
     # ------------------------------------------------------------------ one step
     def _model(self, arena, B):

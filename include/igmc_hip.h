@@ -147,6 +147,11 @@ int igmc_batch_bind_side_source(igmc_batch* b, const float* d_side_all, int n_si
  * calls that need it (get_info / download / edge flags / model calls that run the per-layer kernels).  The training
  * loop sets it when igmc_model_dense_path() says the model will take the dense path for this arena and batch size. */
 int igmc_batch_set_lean(igmc_batch* b, int lean);
+/* The arena holds a batch of B subgraphs that a REPLAYED launch extracted (a captured igmc_extract_batch / igmc_extract_group
+ * leaves no host-side trace when its hipGraph is replayed): the model calls take the batch size of an arena from its last
+ * extraction call on the host, which may be an older one with another size (the ragged last batch of an epoch).  Callers
+ * that consume a prefetched arena outside the graph that filled it say so here.  No reference counterpart. */
+int igmc_batch_assume_size(igmc_batch* b, int B);
 /* Keep the transposed copy of the dense induced blocks too (arenas get one by themselves when a side exceeds 128 nodes):
  * the item-side operand of the dense-layer kernels, for models the subgraph kernel does not take although the blocks exist
  * (sort-pool readout, side features) -- their conv layers then run on the matrix cores instead of walking CSR rows.

@@ -496,3 +496,22 @@ def test_extraction_bitmaps_of_a_200k_node_graph(be, monkeypatch):
     monkeypatch.setenv('IGMC_GROUP_EXTRACT_CHUNK', '1')
     _, single = _trajectory(ds, 0.0, perm, epochs=1, group=4)
     _assert_same(ref, single, 'one batch per extraction launch vs group launches on a 210 000-node graph')
+
+
+def test_prefetched_arena_after_a_ragged_batch_keeps_its_size():
+    """An epoch of 29 full batches + 6 links in groups of 8: a pair of groups, ONE single-group launch (which leaves the odd
+    arena set current), eager steps on that set, the ragged batch in one of its arenas.  In the next epoch the same arena is
+    filled inside a REPLAYED launch and consumed by an eager step -- which took its batch size from the arena's last extraction
+    CALL on the host, the ragged one (found in round 6: epochs of douban / flixster with groups of 50 drifted from the eager
+    order from the second epoch on).  Three epochs, replayed launches == eager launches, bit for bit."""
+    import torch
+    from igmc_amd import preprocessing
+    from igmc_amd.util_functions import MyDynamicDataset
+    (_, _, A, tr_l, tr_u, tr_v, _, _, _, _, _, _, cv) = preprocessing.load_data_monti('douban', testing=True)
+    n = 29 * 50 + 6
+    ds = MyDynamicDataset('data/t/ragged_d', A, (tr_u[:n], tr_v[:n]), tr_l[:n], 1, 1.0, 10000, None, None, cv, device=0, seed=1)
+    perm = torch.randperm(len(ds), generator=torch.Generator().manual_seed(5))
+    sg, ref = _trajectory(ds, 0.2, perm, epochs=3, group=8)
+    assert sg.graph is not None and sg.graph1[0] is not None and ref[4] == 3 * 30
+    _, eager = _trajectory(ds, 0.2, perm, epochs=3, use_graph=False, overlap=False, group=8)
+    _assert_same(ref, eager, 'replayed launches vs eager launches over three epochs with a ragged last batch')
